@@ -1,0 +1,173 @@
+/*
+ * zkwg.h -- C-ABI of the MI355X-native batched witness generator ("zkwg") for the
+ * zk-email `EmailVerifier` circom circuit.
+ *
+ * This is the drop-in boundary: a plain C interface (pointers
+ * and sizes only, no torch / HIP types) that a host binding (N-API addon, ctypes,
+ * cgo ...) calls in place of the circom-generated WASM witness calculator.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference
+ * repository root):
+ *
+ *   zkwg_circuit_create      <- `wasm_tester(circuit.circom, {...})`
+ *                                packages/circuits/tests/email-verifier.test.ts:21-31
+ *                                (compiling `component main = EmailVerifier(...)`,
+ *                                tests/test-circuits/email-verifier-test.circom:5,
+ *                                rsa-test.circom:5, sha-test.circom:5) and the
+ *                                `${circuitName}.wasm` argument of
+ *                                packages/helpers/src/chunked-zkey.ts:80-84
+ *   zkwg_calculate_batch     <- `circuit.calculateWitness(input)`
+ *                                packages/circuits/tests/email-verifier.test.ts:43
+ *                                and the first half of `snarkjs.groth16.fullProve`
+ *                                (packages/helpers/src/chunked-zkey.ts:80), batched
+ *   zkwg_calculate_batch_device  same, inputs/outputs already resident in HBM
+ *   zkwg_pack_input          <- the `CircuitInput` object built by
+ *                                packages/helpers/src/input-generators.ts:190-252
+ *   zkwg_wtns_size / zkwg_write_wtns <- `snarkjs wtns calculate` / generate_witness.js
+ *                                docs/zk-email-docs/UsageGuide/README.md:132-140
+ *   zkwg_write_sym           <- the compiler's `.sym` file used by
+ *                                circom_tester `assertOut` (email-verifier.test.ts:204)
+ *   per-email status codes   <- circom_runtime exception codes; 4 = "Assert Failed"
+ *                                (email-verifier.test.ts:73-79)
+ *
+ * All witness values are integers mod the BN254 scalar prime r
+ * (packages/helpers/src/constants.ts:1), stored as 32-byte little-endian,
+ * non-Montgomery field elements exactly as in a `.wtns` data section.
+ *
+ * Threading: a circuit handle is immutable after creation and may be shared; each
+ * zkwg_calculate_* call is serialised on the HIP stream it is given (or the
+ * handle's own stream).  No global state.
+ */
+#ifndef ZKWG_H
+#define ZKWG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKWG_ABI_VERSION 1
+
+/* `component main = ...` choices (the reference's own test mains). */
+enum zkwg_main_kind {
+  ZKWG_MAIN_EMAIL_VERIFIER = 0, /* EmailVerifier(maxHeader,maxBody,n,k,ignoreBodyHashCheck,0,0,0), public [pubkey] */
+  ZKWG_MAIN_SHA256_BYTES = 1,   /* Sha256Bytes(maxHeader), public [paddedIn, paddedInLength] (sha-test.circom) */
+  ZKWG_MAIN_RSA_VERIFIER = 2    /* RSAVerifier65537(n,k), public [modulus] (rsa-test.circom) */
+};
+
+/* Witness layouts.  KEPT_V1 is the compact layout documented in DESIGN.md. */
+enum zkwg_layout { ZKWG_LAYOUT_KEPT_V1 = 0 };
+
+typedef struct zkwg_config {
+  uint32_t main_kind;                /* enum zkwg_main_kind */
+  uint32_t max_header;               /* maxHeadersLength (multiple of 64) */
+  uint32_t max_body;                 /* maxBodyLength   (multiple of 64; 0 if unused) */
+  uint32_t n;                        /* bits per RSA limb   (121) */
+  uint32_t k;                        /* number of RSA limbs (17)  */
+  uint32_t ignore_body_hash_check;   /* template flag, email-verifier.circom:42 */
+  uint32_t enable_header_masking;    /* must be 0 (not built yet) */
+  uint32_t enable_body_masking;      /* must be 0 */
+  uint32_t remove_soft_line_breaks;  /* must be 0 */
+  uint32_t layout;                   /* enum zkwg_layout */
+} zkwg_config;
+
+/* Fields of one packed input record (one record per email). */
+enum zkwg_input_field {
+  ZKWG_IN_HEADER = 0,         /* u8[max_header]  emailHeader / paddedIn            */
+  ZKWG_IN_BODY = 1,           /* u8[max_body]    emailBody                         */
+  ZKWG_IN_PRECOMPUTED_SHA = 2,/* u8[32]          precomputedSHA                    */
+  ZKWG_IN_PUBKEY = 3,         /* 17 x 16-byte LE limbs: pubkey / modulus           */
+  ZKWG_IN_SIGNATURE = 4,      /* 17 x 16-byte LE limbs                             */
+  ZKWG_IN_MESSAGE = 5,        /* 17 x 16-byte LE limbs (RSA main only)             */
+  ZKWG_IN_HEADER_LEN = 6,     /* u32 emailHeaderLength / paddedInLength            */
+  ZKWG_IN_BODY_LEN = 7,       /* u32 emailBodyLength                               */
+  ZKWG_IN_BODY_HASH_INDEX = 8,/* u32 bodyHashIndex                                 */
+  ZKWG_IN_NFIELDS = 9
+};
+
+/* Per-email status: circom_runtime exception codes. */
+enum zkwg_status {
+  ZKWG_OK = 0,
+  ZKWG_ERR_ASSERT_FAILED = 4 /* a `===` / assert failed: "Assert Failed" */
+};
+
+/* API return codes (negative = misuse / runtime failure). */
+enum zkwg_rc {
+  ZKWG_RC_OK = 0,
+  ZKWG_RC_BAD_CONFIG = -1,
+  ZKWG_RC_BAD_ARG = -2,
+  ZKWG_RC_NO_DEVICE = -3,
+  ZKWG_RC_HIP_ERROR = -4,
+  ZKWG_RC_OOM = -5
+};
+
+typedef struct zkwg_circuit zkwg_circuit_t;
+
+int zkwg_abi_version(void);
+const char* zkwg_strerror(int rc_or_status);
+
+/* Create / destroy.  `device` is a HIP device ordinal; device < 0 builds a
+ * layout-only handle (no GPU needed: sizes, .sym, .wtns and packing still work,
+ * zkwg_calculate_* return ZKWG_RC_NO_DEVICE). */
+int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out);
+void zkwg_circuit_destroy(zkwg_circuit_t* c);
+
+/* Geometry. */
+uint64_t zkwg_witness_len(const zkwg_circuit_t* c);   /* W: field elements per witness */
+uint64_t zkwg_witness_bytes(const zkwg_circuit_t* c); /* 32 * W */
+uint32_t zkwg_num_public(const zkwg_circuit_t* c);    /* outputs + public inputs: w[1..nPublic] */
+uint64_t zkwg_input_stride(const zkwg_circuit_t* c);  /* bytes per packed input record */
+uint64_t zkwg_input_offset(const zkwg_circuit_t* c, int field); /* byte offset inside a record */
+uint64_t zkwg_scratch_bytes(const zkwg_circuit_t* c, uint64_t n_emails); /* device scratch for a batch */
+
+/* Pack one email's inputs into a record (host helper; every pointer may be NULL
+ * when the main kind does not use that field).  Limbs are 17 x 16-byte LE. */
+int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* record,
+                    const uint8_t* header, uint32_t header_len,
+                    const uint8_t* body, uint32_t body_len,
+                    const uint8_t* precomputed_sha, const uint8_t* pubkey_limbs,
+                    const uint8_t* signature_limbs, const uint8_t* message_limbs,
+                    uint32_t body_hash_index);
+
+/* Host-buffer batch: H2D of `packed_inputs` (n_emails records), kernels, D2H of
+ * n_emails witnesses (32*W bytes each, `out_stride` bytes apart; out_wtns may be
+ * NULL to fetch only `status`).  Processes the batch in tiles that fit `max_tile`
+ * emails (0 = choose from free HBM). */
+int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed_inputs, uint64_t n_emails,
+                         uint8_t* out_wtns, uint64_t out_stride, int32_t* status,
+                         uint64_t max_tile);
+
+/* Device-resident batch: every pointer is a device pointer on the handle's
+ * device; `hip_stream` is a hipStream_t passed as void* (NULL = default stream).
+ * d_scratch must hold zkwg_scratch_bytes(c, n_emails).  Asynchronous. */
+int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails,
+                                void* d_out_wtns, uint64_t out_stride, void* d_status,
+                                void* d_scratch, void* hip_stream);
+
+/* Time the dominant kernel(s) of the last zkwg_calculate_batch_device call with
+ * HIP events recorded on the launch stream.  Returns ms in *ms for kernel index
+ * `which` (see zkwg_kernel_name); negative rc if timing was not enabled. */
+int zkwg_set_timing(zkwg_circuit_t* c, int enable);
+int zkwg_last_kernel_ms(zkwg_circuit_t* c, int which, float* ms);
+int zkwg_num_kernels(const zkwg_circuit_t* c);
+const char* zkwg_kernel_name(const zkwg_circuit_t* c, int which);
+/* Witness slots (field elements) written per email by kernel `which`. */
+uint64_t zkwg_kernel_slots(const zkwg_circuit_t* c, int which);
+
+/* `.wtns` container: 4-byte magic "wtns", u32 version 2,
+ * u32 nSections 2; section 1: u32 n8=32, 32-byte LE prime, u32 nWitness;
+ * section 2: nWitness x 32-byte LE values. */
+uint64_t zkwg_wtns_size(const zkwg_circuit_t* c);
+int zkwg_write_wtns(const zkwg_circuit_t* c, const uint8_t* witness, uint8_t* out, uint64_t out_cap);
+
+/* Symbol table of the layout, one line per witness slot: "slot,slot,0,name\n"
+ * (the `.sym` line format `labelIdx,varIdx,componentIdx,name`).  Returns bytes
+ * needed; writes at most cap bytes. */
+uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKWG_H */

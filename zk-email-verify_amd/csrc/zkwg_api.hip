@@ -1,0 +1,342 @@
+// C-ABI of libzkwg.so (see include/zkwg.h): schedule construction, launch sequence,
+// host<->device staging, .wtns / .sym writers.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/zkwg.h"
+#include "zkwg_kernels.h"
+#include "zkwg_layout.h"
+
+#define ZK_MAX_KERNELS 8
+
+struct zkwg_circuit {
+  zkwg_config cfg;
+  ZkSched s;
+  int device;
+  uint4* d_invtab;
+  hipStream_t own_stream;
+  int timing;
+  int n_kernels;
+  const char* kname[ZK_MAX_KERNELS];
+  u64 kslots[ZK_MAX_KERNELS];
+  hipEvent_t ev[ZK_MAX_KERNELS + 1];
+  bool ev_valid;
+};
+
+static bool build_sched(const zkwg_config& cfg, ZkSched& s) {
+  memset(&s, 0, sizeof(s));
+  if (cfg.layout != ZKWG_LAYOUT_KEPT_V1) return false;
+  if (cfg.enable_header_masking || cfg.enable_body_masking || cfg.remove_soft_line_breaks) return false;
+  if (cfg.max_header % 64 != 0 || cfg.max_body % 64 != 0) return false;
+  s.main_kind = cfg.main_kind;
+  s.n = cfg.n; s.k = cfg.k; s.ignore_body = cfg.ignore_body_hash_check;
+  // input record
+  u32 off = 0;
+  s.in_off[ZKWG_IN_HEADER] = off; off += cfg.max_header;
+  s.in_off[ZKWG_IN_BODY] = off; off += cfg.max_body;
+  s.in_off[ZKWG_IN_PRECOMPUTED_SHA] = off; off += 32;
+  off = (off + 15u) & ~15u;
+  s.in_off[ZKWG_IN_PUBKEY] = off; off += 17 * 16;
+  s.in_off[ZKWG_IN_SIGNATURE] = off; off += 17 * 16;
+  s.in_off[ZKWG_IN_MESSAGE] = off; off += 17 * 16;
+  s.in_off[ZKWG_IN_HEADER_LEN] = off; off += 4;
+  s.in_off[ZKWG_IN_BODY_LEN] = off; off += 4;
+  s.in_off[ZKWG_IN_BODY_HASH_INDEX] = off; off += 4;
+  s.in_stride = (off + 15u) & ~15u;
+
+  auto init_frame = [&](ZkShaFrame& f, u32 max_bytes, u32 partial, u32 in_data, u32 in_len) {
+    f.max_bytes = max_bytes;
+    f.nblocks = max_bytes / 64;
+    f.lenbits = zk_log2ceil((u64)max_bytes * 8);
+    f.partial = partial;
+    f.in_data = in_data; f.in_len = in_len; f.in_pre = s.in_off[ZKWG_IN_PRECOMPUTED_SHA];
+    f.hstate_base = s.hstates_per_email;
+    s.hstates_per_email += f.nblocks + 1;
+    s.total_blocks += f.nblocks;
+  };
+
+  ZkWalker w;
+  u64 max_small = 256;  // largest |d| whose inverse the kernels look up
+  switch (cfg.main_kind) {
+    case ZKWG_MAIN_SHA256_BYTES:
+      if (cfg.max_header == 0) return false;
+      s.nframes = 1;
+      init_frame(s.fr[0], cfg.max_header, 0, s.in_off[ZKWG_IN_HEADER], s.in_off[ZKWG_IN_HEADER_LEN]);
+      zk_walk_main_sha(w, s);
+      max_small = std::max<u64>(max_small, s.fr[0].nblocks + 2);
+      break;
+    default:
+      return false;
+  }
+  s.W = w.cur;
+  s.inv_table_len = 2 * max_small + 1;
+  return true;
+}
+
+// inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
+static void build_inv_table(u64 len, std::vector<Fr>& tab) {
+  const long long half = (long long)(len / 2);
+  tab.assign(len, fr_zero());
+  std::vector<Fr> inv(half + 1, fr_zero());  // Montgomery form
+  if (half >= 1) inv[1] = fr_R();
+  // inv[i] = -(r / i) * inv[r mod i]  (mod r); r / i and r % i by long division on 4 limbs
+  for (long long i = 2; i <= half; ++i) {
+    const u64 p[4] = {ZK_P0, ZK_P1, ZK_P2, ZK_P3};
+    u64 q[4];
+    unsigned __int128 rem = 0;
+    for (int j = 3; j >= 0; --j) {
+      unsigned __int128 cur = (rem << 64) | p[j];
+      q[j] = (u64)(cur / (u64)i);
+      rem = cur % (u64)i;
+    }
+    Fr qf{{q[0], q[1], q[2], q[3]}};
+    Fr t = fr_mont_mul(fr_to_mont(qf), inv[(u64)rem]);
+    inv[i] = fr_neg(t);
+  }
+  for (long long d = 1; d <= half; ++d) {
+    Fr v = fr_from_mont(inv[d]);
+    tab[(u64)(half + d)] = v;
+    tab[(u64)(half - d)] = fr_neg(v);
+  }
+}
+
+extern "C" {
+
+int zkwg_abi_version(void) { return ZKWG_ABI_VERSION; }
+
+const char* zkwg_strerror(int rc) {
+  switch (rc) {
+    case ZKWG_RC_OK: return "ok";
+    case ZKWG_ERR_ASSERT_FAILED: return "Error: Assert Failed.";
+    case 1: return "Signal not found";
+    case 2: return "Too many signals set";
+    case 3: return "Signal already set";
+    case 5: return "Not enough memory";
+    case 6: return "Input signal array access exceeds the size";
+    case ZKWG_RC_BAD_CONFIG: return "zkwg: unsupported circuit configuration";
+    case ZKWG_RC_BAD_ARG: return "zkwg: bad argument";
+    case ZKWG_RC_NO_DEVICE: return "zkwg: no HIP device (layout-only handle or HIP unavailable)";
+    case ZKWG_RC_HIP_ERROR: return "zkwg: HIP runtime error";
+    case ZKWG_RC_OOM: return "zkwg: out of device memory";
+    default: return "zkwg: unknown code";
+  }
+}
+
+int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out) {
+  if (!cfg || !out) return ZKWG_RC_BAD_ARG;
+  zkwg_circuit* c = new zkwg_circuit();
+  memset(c, 0, sizeof(*c));
+  c->cfg = *cfg;
+  c->device = -1;
+  if (!build_sched(*cfg, c->s)) { delete c; return ZKWG_RC_BAD_CONFIG; }
+  // kernel table
+  c->n_kernels = 3;
+  c->kname[0] = "zk_sha_chain"; c->kslots[0] = 0;
+  c->kname[1] = "zk_sha_expand"; c->kslots[1] = (u64)c->s.total_blocks * ZK_COMP_SLOTS;
+  c->kname[2] = "zk_misc"; c->kslots[2] = c->s.W - c->kslots[1];
+  if (device >= 0) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return ZKWG_RC_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { delete c; return ZKWG_RC_HIP_ERROR; }
+    c->device = device;
+    std::vector<Fr> tab;
+    build_inv_table(c->s.inv_table_len, tab);
+    if (hipMalloc((void**)&c->d_invtab, tab.size() * sizeof(Fr)) != hipSuccess) { delete c; return ZKWG_RC_OOM; }
+    if (hipMemcpy(c->d_invtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) {
+      hipFree(c->d_invtab); delete c; return ZKWG_RC_HIP_ERROR;
+    }
+    hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventCreate(&c->ev[i]);
+  }
+  *out = c;
+  return ZKWG_RC_OK;
+}
+
+void zkwg_circuit_destroy(zkwg_circuit_t* c) {
+  if (!c) return;
+  if (c->device >= 0) {
+    hipSetDevice(c->device);
+    hipFree(c->d_invtab);
+    hipStreamDestroy(c->own_stream);
+    for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventDestroy(c->ev[i]);
+  }
+  delete c;
+}
+
+uint64_t zkwg_witness_len(const zkwg_circuit_t* c) { return c->s.W; }
+uint64_t zkwg_witness_bytes(const zkwg_circuit_t* c) { return c->s.W * 32; }
+uint32_t zkwg_num_public(const zkwg_circuit_t* c) { return c->s.n_public; }
+uint64_t zkwg_input_stride(const zkwg_circuit_t* c) { return c->s.in_stride; }
+uint64_t zkwg_input_offset(const zkwg_circuit_t* c, int field) {
+  if (field < 0 || field >= ZKWG_IN_NFIELDS) return (uint64_t)-1;
+  return c->s.in_off[field];
+}
+uint64_t zkwg_scratch_bytes(const zkwg_circuit_t* c, uint64_t n_emails) {
+  return n_emails * (u64)c->s.hstates_per_email * 32 + 256;
+}
+
+int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header, uint32_t header_len,
+                    const uint8_t* body, uint32_t body_len, const uint8_t* pre, const uint8_t* pubkey,
+                    const uint8_t* sig, const uint8_t* msg, uint32_t bh_index) {
+  if (!c || !rec) return ZKWG_RC_BAD_ARG;
+  const ZkSched& s = c->s;
+  memset(rec, 0, s.in_stride);
+  if (header) memcpy(rec + s.in_off[ZKWG_IN_HEADER], header, c->cfg.max_header);
+  if (body) memcpy(rec + s.in_off[ZKWG_IN_BODY], body, c->cfg.max_body);
+  if (pre) memcpy(rec + s.in_off[ZKWG_IN_PRECOMPUTED_SHA], pre, 32);
+  if (pubkey) memcpy(rec + s.in_off[ZKWG_IN_PUBKEY], pubkey, 17 * 16);
+  if (sig) memcpy(rec + s.in_off[ZKWG_IN_SIGNATURE], sig, 17 * 16);
+  if (msg) memcpy(rec + s.in_off[ZKWG_IN_MESSAGE], msg, 17 * 16);
+  memcpy(rec + s.in_off[ZKWG_IN_HEADER_LEN], &header_len, 4);
+  memcpy(rec + s.in_off[ZKWG_IN_BODY_LEN], &body_len, 4);
+  memcpy(rec + s.in_off[ZKWG_IN_BODY_HASH_INDEX], &bh_index, 4);
+  return ZKWG_RC_OK;
+}
+
+int zkwg_set_timing(zkwg_circuit_t* c, int enable) {
+  if (!c) return ZKWG_RC_BAD_ARG;
+  c->timing = enable;
+  c->ev_valid = false;
+  return ZKWG_RC_OK;
+}
+int zkwg_num_kernels(const zkwg_circuit_t* c) { return c->n_kernels; }
+const char* zkwg_kernel_name(const zkwg_circuit_t* c, int which) {
+  return (which >= 0 && which < c->n_kernels) ? c->kname[which] : "";
+}
+uint64_t zkwg_kernel_slots(const zkwg_circuit_t* c, int which) {
+  return (which >= 0 && which < c->n_kernels) ? c->kslots[which] : 0;
+}
+int zkwg_last_kernel_ms(zkwg_circuit_t* c, int which, float* ms) {
+  if (!c || !ms || which < 0 || which >= c->n_kernels) return ZKWG_RC_BAD_ARG;
+  if (!c->timing || !c->ev_valid) return ZKWG_RC_BAD_ARG;
+  if (hipEventSynchronize(c->ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  if (hipEventElapsedTime(ms, c->ev[which], c->ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  return ZKWG_RC_OK;
+}
+
+int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_out,
+                                uint64_t out_stride, void* d_status, void* d_scratch, void* hip_stream) {
+  if (!c || !d_in || !d_out || !d_status || !d_scratch) return ZKWG_RC_BAD_ARG;
+  if (c->device < 0) return ZKWG_RC_NO_DEVICE;
+  if (n == 0) return ZKWG_RC_OK;
+  if (out_stride != c->s.W * 32 || n > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const ZkSched& s = c->s;
+  const u8* in = (const u8*)d_in;
+  u32* hst = (u32*)d_scratch;
+  uint4* wit = (uint4*)d_out;
+  int* status = (int*)d_status;
+  const u32 ne = (u32)n;
+  const bool tm = c->timing != 0;
+  if (hipMemsetAsync(status, 0, n * sizeof(int), st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  int ki = 0;
+  if (tm) hipEventRecord(c->ev[ki], st);
+  {
+    u32 threads = ne * s.nframes;
+    hipLaunchKernelGGL(zk_sha_chain, dim3((threads + 63) / 64), dim3(64), 0, st, s, in, hst, ne);
+  }
+  if (tm) hipEventRecord(c->ev[++ki], st);
+  {
+    u64 units = (u64)ne * s.total_blocks;
+    u64 grid = (units + ZK_EXPAND_WAVES - 1) / ZK_EXPAND_WAVES;
+    hipLaunchKernelGGL(zk_sha_expand, dim3((u32)grid), dim3(64 * ZK_EXPAND_WAVES), 0, st, s, in, hst, wit, ne);
+  }
+  if (tm) hipEventRecord(c->ev[++ki], st);
+  switch (s.main_kind) {
+    case ZKWG_MAIN_SHA256_BYTES:
+      hipLaunchKernelGGL(zk_misc_sha_main, dim3(ne), dim3(256), 0, st, s, in, hst, c->d_invtab, wit, status, ne);
+      break;
+  }
+  if (tm) { hipEventRecord(c->ev[++ki], st); c->ev_valid = true; }
+  if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  return ZKWG_RC_OK;
+}
+
+int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
+                         uint64_t out_stride, int32_t* status, uint64_t max_tile) {
+  if (!c || !packed || !status) return ZKWG_RC_BAD_ARG;
+  if (c->device < 0) return ZKWG_RC_NO_DEVICE;
+  if (n == 0) return ZKWG_RC_OK;
+  const u64 wbytes = c->s.W * 32;
+  if (out_wtns && out_stride < wbytes) return ZKWG_RC_BAD_ARG;
+  if (hipSetDevice(c->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  const u64 per_email = wbytes + c->s.in_stride + (u64)c->s.hstates_per_email * 32 + 16;
+  u64 tile = max_tile ? max_tile : std::max<u64>(1, (u64)(free_b * 0.8) / per_email);
+  tile = std::min<u64>(tile, n);
+  u8 *d_in = nullptr, *d_out = nullptr, *d_scr = nullptr;
+  int* d_status = nullptr;
+  int rc = ZKWG_RC_OK;
+  if (hipMalloc((void**)&d_in, tile * c->s.in_stride) != hipSuccess ||
+      hipMalloc((void**)&d_out, tile * wbytes) != hipSuccess ||
+      hipMalloc((void**)&d_scr, zkwg_scratch_bytes(c, tile)) != hipSuccess ||
+      hipMalloc((void**)&d_status, tile * sizeof(int)) != hipSuccess) {
+    rc = ZKWG_RC_OOM;
+  }
+  hipStream_t st = c->own_stream;
+  for (u64 base = 0; rc == ZKWG_RC_OK && base < n; base += tile) {
+    u64 cnt = std::min<u64>(tile, n - base);
+    if (hipMemcpyAsync(d_in, packed + base * c->s.in_stride, cnt * c->s.in_stride, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
+    rc = zkwg_calculate_batch_device(c, d_in, cnt, d_out, wbytes, d_status, d_scr, st);
+    if (rc != ZKWG_RC_OK) break;
+    if (out_wtns) {
+      if (out_stride == wbytes) {
+        if (hipMemcpyAsync(out_wtns + base * out_stride, d_out, cnt * wbytes, hipMemcpyDeviceToHost, st) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
+      } else {
+        if (hipMemcpy2DAsync(out_wtns + base * out_stride, out_stride, d_out, wbytes, wbytes, cnt, hipMemcpyDeviceToHost, st) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
+      }
+    }
+    if (hipMemcpyAsync(status + base, d_status, cnt * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
+    if (hipStreamSynchronize(st) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
+  }
+  hipFree(d_in); hipFree(d_out); hipFree(d_scr); hipFree(d_status);
+  return rc;
+}
+
+uint64_t zkwg_wtns_size(const zkwg_circuit_t* c) { return 12 + 12 + 40 + 12 + c->s.W * 32; }
+
+int zkwg_write_wtns(const zkwg_circuit_t* c, const uint8_t* witness, uint8_t* out, uint64_t cap) {
+  if (!c || !witness || !out) return ZKWG_RC_BAD_ARG;
+  if (cap < zkwg_wtns_size(c)) return ZKWG_RC_BAD_ARG;
+  u8* p = out;
+  auto w32 = [&](u32 v) { memcpy(p, &v, 4); p += 4; };
+  auto w64 = [&](u64 v) { memcpy(p, &v, 8); p += 8; };
+  memcpy(p, "wtns", 4); p += 4;
+  w32(2); w32(2);
+  w32(1); w64(40);
+  w32(32);
+  const u64 prime[4] = {ZK_P0, ZK_P1, ZK_P2, ZK_P3};
+  memcpy(p, prime, 32); p += 32;
+  w32((u32)c->s.W);
+  w32(2); w64(c->s.W * 32);
+  memcpy(p, witness, c->s.W * 32);
+  return ZKWG_RC_OK;
+}
+
+uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap) {
+  ZkSched tmp = c->s;
+  ZkWalker w;
+  w.names = true;
+  u64 pos = 0;
+  w.sink = [&](u64 slot, const std::string& name) {
+    char buf[64];
+    int n = snprintf(buf, sizeof(buf), "%llu,%llu,0,", (unsigned long long)slot, (unsigned long long)slot);
+    u64 need = (u64)n + name.size() + 1;
+    if (out && pos + need <= cap) {
+      memcpy(out + pos, buf, n);
+      memcpy(out + pos + n, name.data(), name.size());
+      out[pos + n + name.size()] = '\n';
+    }
+    pos += need;
+  };
+  switch (tmp.main_kind) {
+    case ZKWG_MAIN_SHA256_BYTES: zk_walk_main_sha(w, tmp); break;
+  }
+  return pos;
+}
+
+}  // extern "C"

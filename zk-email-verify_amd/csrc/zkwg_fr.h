@@ -1,0 +1,180 @@
+// BN254 scalar-field (Fr) arithmetic, 4 x 64-bit limbs, Montgomery form.
+// Shared by the host-side schedule builder (inverse tables, Poseidon constants)
+// and the gfx950 kernels.  r = CIRCOM_FIELD_MODULUS
+// (reference: packages/helpers/src/constants.ts:1).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZK_HD __host__ __device__ __forceinline__
+#else
+#define ZK_HD inline
+#endif
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef uint8_t u8;
+
+struct Fr {
+  u64 l[4];
+};
+
+#define ZK_P0 0x43e1f593f0000001ULL
+#define ZK_P1 0x2833e84879b97091ULL
+#define ZK_P2 0xb85045b68181585dULL
+#define ZK_P3 0x30644e72e131a029ULL
+#define ZK_N0 0xc2e1f593efffffffULL  // -r^{-1} mod 2^64
+
+ZK_HD void zk_mul64(u64 a, u64 b, u64& lo, u64& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  lo = a * b;
+  hi = __umul64hi(a, b);
+#else
+  unsigned __int128 p = (unsigned __int128)a * b;
+  lo = (u64)p;
+  hi = (u64)(p >> 64);
+#endif
+}
+
+// (carry, out) = a + b + carry
+ZK_HD u64 zk_adc(u64 a, u64 b, u64& carry) {
+  u64 s = a + b;
+  u64 c1 = s < a;
+  u64 s2 = s + carry;
+  u64 c2 = s2 < s;
+  carry = c1 + c2;
+  return s2;
+}
+// (borrow, out) = a - b - borrow
+ZK_HD u64 zk_sbb(u64 a, u64 b, u64& borrow) {
+  u64 d = a - b;
+  u64 b1 = a < b;
+  u64 d2 = d - borrow;
+  u64 b2 = d < borrow;
+  borrow = b1 + b2;
+  return d2;
+}
+
+ZK_HD Fr fr_p() { return Fr{{ZK_P0, ZK_P1, ZK_P2, ZK_P3}}; }
+ZK_HD Fr fr_zero() { return Fr{{0, 0, 0, 0}}; }
+ZK_HD Fr fr_from_u64(u64 x) { return Fr{{x, 0, 0, 0}}; }  // standard form
+// Montgomery constants
+ZK_HD Fr fr_R() { return Fr{{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}}; }
+ZK_HD Fr fr_R2() { return Fr{{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}}; }
+
+ZK_HD bool fr_is_zero(const Fr& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+ZK_HD bool fr_eq(const Fr& a, const Fr& b) {
+  return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3];
+}
+// a >= b as 256-bit integers
+ZK_HD bool fr_geq(const Fr& a, const Fr& b) {
+  for (int i = 3; i >= 0; --i) {
+    if (a.l[i] > b.l[i]) return true;
+    if (a.l[i] < b.l[i]) return false;
+  }
+  return true;
+}
+ZK_HD Fr fr_sub_raw(const Fr& a, const Fr& b, u64& borrow) {
+  Fr r;
+  borrow = 0;
+  for (int i = 0; i < 4; ++i) r.l[i] = zk_sbb(a.l[i], b.l[i], borrow);
+  return r;
+}
+ZK_HD Fr fr_add_raw(const Fr& a, const Fr& b, u64& carry) {
+  Fr r;
+  carry = 0;
+  for (int i = 0; i < 4; ++i) r.l[i] = zk_adc(a.l[i], b.l[i], carry);
+  return r;
+}
+// modular add/sub/neg (inputs in [0, r))
+ZK_HD Fr fr_add(const Fr& a, const Fr& b) {
+  u64 c;
+  Fr s = fr_add_raw(a, b, c);  // < 2r < 2^255, no carry out
+  if (fr_geq(s, fr_p())) {
+    u64 bw;
+    s = fr_sub_raw(s, fr_p(), bw);
+  }
+  return s;
+}
+ZK_HD Fr fr_sub(const Fr& a, const Fr& b) {
+  u64 bw;
+  Fr d = fr_sub_raw(a, b, bw);
+  if (bw) {
+    u64 c;
+    d = fr_add_raw(d, fr_p(), c);
+  }
+  return d;
+}
+ZK_HD Fr fr_neg(const Fr& a) {
+  if (fr_is_zero(a)) return a;
+  u64 bw;
+  return fr_sub_raw(fr_p(), a, bw);
+}
+
+// Montgomery product a*b*R^{-1} mod r  (CIOS, 4 x 64-bit limbs)
+ZK_HD Fr fr_mont_mul(const Fr& a, const Fr& b) {
+  const u64 p[4] = {ZK_P0, ZK_P1, ZK_P2, ZK_P3};
+  u64 t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u64 carry = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u64 lo, hi;
+      zk_mul64(a.l[j], b.l[i], lo, hi);
+      u64 c = 0;
+      u64 s = zk_adc(t[j], lo, c);
+      hi += c;
+      c = 0;
+      s = zk_adc(s, carry, c);
+      hi += c;
+      t[j] = s;
+      carry = hi;
+    }
+    u64 c = 0;
+    t[4] = zk_adc(t[4], carry, c);
+    t[5] = c;
+    u64 m = t[0] * ZK_N0;
+    u64 lo, hi;
+    zk_mul64(m, p[0], lo, hi);
+    c = 0;
+    (void)zk_adc(t[0], lo, c);
+    carry = hi + c;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      zk_mul64(m, p[j], lo, hi);
+      c = 0;
+      u64 s = zk_adc(t[j], lo, c);
+      hi += c;
+      c = 0;
+      s = zk_adc(s, carry, c);
+      hi += c;
+      t[j - 1] = s;
+      carry = hi;
+    }
+    c = 0;
+    t[3] = zk_adc(t[4], carry, c);
+    t[4] = t[5] + c;
+  }
+  Fr r{{t[0], t[1], t[2], t[3]}};
+  if (t[4] || fr_geq(r, fr_p())) {
+    u64 bw;
+    r = fr_sub_raw(r, fr_p(), bw);
+  }
+  return r;
+}
+ZK_HD Fr fr_to_mont(const Fr& a) { return fr_mont_mul(a, fr_R2()); }
+ZK_HD Fr fr_from_mont(const Fr& a) { return fr_mont_mul(a, fr_from_u64(1)); }
+
+// a^(r-2) in Montgomery form (a in Montgomery form); 0 -> 0
+ZK_HD Fr fr_mont_inv(const Fr& a) {
+  // exponent r - 2
+  const u64 e[4] = {ZK_P0 - 2, ZK_P1, ZK_P2, ZK_P3};
+  Fr acc = fr_R();  // 1 in Montgomery form
+  for (int i = 253; i >= 0; --i) {
+    acc = fr_mont_mul(acc, acc);
+    if ((e[i >> 6] >> (i & 63)) & 1) acc = fr_mont_mul(acc, a);
+  }
+  return acc;
+}

@@ -1,0 +1,217 @@
+"""zkwg -- Python host side of the MI355X-native batched witness generator.
+
+Mirrors the interface the reference uses for this path:
+
+* circom_runtime's `WitnessCalculator` (`calculateWitness`, `calculateBinWitness`,
+  `calculateWTNSBin`) as called through `circom_tester.wasm` in
+  packages/circuits/tests/email-verifier.test.ts:21-44 and through
+  `snarkjs.groth16.fullProve` in packages/helpers/src/chunked-zkey.ts:80-84;
+* the `CircuitInput` object of packages/helpers/src/input-generators.ts:6-18.
+
+Everything below the `WitnessCalculator` goes through the C-ABI of libzkwg.so; there
+is no CPU fallback (a missing library or GPU raises).
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import Config, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER
+
+FIELD_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+class ZkwgError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise ZkwgError(_lib.load().zkwg_strerror(rc).decode() + f" (rc={rc})")
+
+
+def _limbs_bytes(vals, n_limbs=17):
+    """list of ints (each < 2^128) -> n_limbs x 16-byte little-endian."""
+    vals = list(vals)
+    if len(vals) > n_limbs:
+        raise ZkwgError("Too many values for input signal")
+    if len(vals) < n_limbs:
+        raise ZkwgError("Not enough values for input signal")
+    out = bytearray()
+    for v in vals:
+        v = int(v) % FIELD_MODULUS
+        if v >> 128:
+            raise ZkwgError("limb does not fit the packed 128-bit input path")
+        out += v.to_bytes(16, "little")
+    return bytes(out)
+
+
+class Circuit:
+    """A compiled circuit handle (`component main = ...` with its template parameters)."""
+
+    def __init__(self, main_kind=MAIN_EMAIL_VERIFIER, max_header=1024, max_body=1536, n=121, k=17,
+                 ignore_body_hash_check=0, device=0):
+        self.lib = _lib.load()
+        self.cfg = Config(main_kind, max_header, max_body, n, k, ignore_body_hash_check, 0, 0, 0, 0)
+        h = C.c_void_p()
+        _check(self.lib.zkwg_circuit_create(C.byref(self.cfg), device, C.byref(h)))
+        self.h = h
+        self.device = device
+        self.W = self.lib.zkwg_witness_len(h)
+        self.witness_bytes = self.lib.zkwg_witness_bytes(h)
+        self.n_public = self.lib.zkwg_num_public(h)
+        self.in_stride = self.lib.zkwg_input_stride(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zkwg_circuit_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- input marshalling (CircuitInput -> packed record) -------------------------------
+    def _signal_sizes(self):
+        c = self.cfg
+        if c.main_kind == MAIN_SHA256_BYTES:
+            return {"paddedIn": c.max_header, "paddedInLength": 1}
+        if c.main_kind == MAIN_RSA_VERIFIER:
+            return {"message": c.k, "signature": c.k, "modulus": c.k}
+        sizes = {"emailHeader": c.max_header, "emailHeaderLength": 1, "pubkey": c.k, "signature": c.k}
+        if not c.ignore_body_hash_check:
+            sizes.update({"bodyHashIndex": 1, "precomputedSHA": 32, "emailBody": c.max_body,
+                          "emailBodyLength": 1})
+        return sizes
+
+    def pack(self, inp):
+        """CircuitInput dict (numbers / decimal strings / lists of them) -> packed record bytes.
+        Error messages follow circom_runtime."""
+        sizes = self._signal_sizes()
+        flat = {}
+        for key, val in inp.items():
+            if key not in sizes:
+                raise ZkwgError(f"Signal not found: {key}")
+            vals = [int(x) for x in val] if isinstance(val, (list, tuple)) else [int(val)]
+            if len(vals) > sizes[key]:
+                raise ZkwgError(f"Too many values for input signal {key}")
+            if len(vals) < sizes[key]:
+                raise ZkwgError(f"Not enough values for input signal {key}")
+            flat[key] = [v % FIELD_MODULUS for v in vals]
+        if len(flat) != len(sizes):
+            raise ZkwgError(f"Not all inputs have been set. Only {len(flat)} out of {len(sizes)}")
+
+        def as_bytes(vals, what):
+            for v in vals:
+                if v > 255:
+                    raise ZkwgError(f"{what}: value {v} does not fit the packed byte input path")
+            return bytes(vals)
+
+        def as_u32(v, what):
+            if v >> 32:
+                raise ZkwgError(f"{what}: value does not fit the packed u32 input path")
+            return v
+
+        c = self.cfg
+        rec = (C.c_uint8 * self.in_stride)()
+        header = body = pre = pub = sig = msg = None
+        hlen = blen = bhi = 0
+        if c.main_kind == MAIN_SHA256_BYTES:
+            header = as_bytes(flat["paddedIn"], "paddedIn")
+            hlen = as_u32(flat["paddedInLength"][0], "paddedInLength")
+        elif c.main_kind == MAIN_RSA_VERIFIER:
+            msg = _limbs_bytes(flat["message"]); sig = _limbs_bytes(flat["signature"])
+            pub = _limbs_bytes(flat["modulus"])
+        else:
+            header = as_bytes(flat["emailHeader"], "emailHeader")
+            hlen = as_u32(flat["emailHeaderLength"][0], "emailHeaderLength")
+            pub = _limbs_bytes(flat["pubkey"]); sig = _limbs_bytes(flat["signature"])
+            if not c.ignore_body_hash_check:
+                body = as_bytes(flat["emailBody"], "emailBody")
+                blen = as_u32(flat["emailBodyLength"][0], "emailBodyLength")
+                pre = as_bytes(flat["precomputedSHA"], "precomputedSHA")
+                bhi = as_u32(flat["bodyHashIndex"][0], "bodyHashIndex")
+        _check(self.lib.zkwg_pack_input(self.h, rec, header, hlen, body, blen, pre, pub, sig, msg, bhi))
+        return bytes(rec)
+
+    # -- batch calculation -------------------------------------------------------------------
+    def calculate_batch_host(self, records, want_witness=True, max_tile=0):
+        """records: bytes of n packed records.  Returns (witness bytes or None, status list)."""
+        n = len(records) // self.in_stride
+        assert n * self.in_stride == len(records)
+        status = (C.c_int32 * n)()
+        out = (C.c_uint8 * (n * self.witness_bytes))() if want_witness else None
+        _check(self.lib.zkwg_calculate_batch(self.h, records, n, out, self.witness_bytes, status, max_tile))
+        return (bytes(out) if want_witness else None), list(status)
+
+    def calculate_batch_device(self, d_in, n, d_out, d_status, d_scratch, stream=None):
+        """Device-resident launch; arguments are torch CUDA tensors (plumbing only)."""
+        sp = stream.cuda_stream if stream is not None else 0
+        _check(self.lib.zkwg_calculate_batch_device(self.h, d_in.data_ptr(), n, d_out.data_ptr(),
+                                                    self.witness_bytes, d_status.data_ptr(),
+                                                    d_scratch.data_ptr(), sp))
+
+    def scratch_bytes(self, n):
+        return self.lib.zkwg_scratch_bytes(self.h, n)
+
+    def set_timing(self, on):
+        _check(self.lib.zkwg_set_timing(self.h, 1 if on else 0))
+
+    def kernel_times_ms(self):
+        out = {}
+        for i in range(self.lib.zkwg_num_kernels(self.h)):
+            ms = C.c_float()
+            _check(self.lib.zkwg_last_kernel_ms(self.h, i, C.byref(ms)))
+            out[self.lib.zkwg_kernel_name(self.h, i).decode()] = (ms.value, self.lib.zkwg_kernel_slots(self.h, i))
+        return out
+
+    def wtns(self, witness_bytes):
+        size = self.lib.zkwg_wtns_size(self.h)
+        out = (C.c_uint8 * size)()
+        _check(self.lib.zkwg_write_wtns(self.h, witness_bytes, out, size))
+        return bytes(out)
+
+    def symbols(self):
+        """[(slot, name)] of the layout (the .sym table)."""
+        need = self.lib.zkwg_write_sym(self.h, None, 0)
+        buf = C.create_string_buffer(need)
+        self.lib.zkwg_write_sym(self.h, buf, need)
+        out = []
+        for line in buf.raw[:need].decode().splitlines():
+            a, _, _, name = line.split(",", 3)
+            out.append((int(a), name))
+        return out
+
+
+class WitnessCalculator:
+    """circom_runtime `WitnessCalculator`-shaped front end over a `Circuit`."""
+
+    def __init__(self, circuit):
+        self.circuit = circuit
+
+    def _run_one(self, inp):
+        rec = self.circuit.pack(inp)
+        wit, status = self.circuit.calculate_batch_host(rec)
+        if status[0] != 0:
+            raise ZkwgError(self.circuit.lib.zkwg_strerror(status[0]).decode())
+        return wit
+
+    def calculateBinWitness(self, inp, sanityCheck=False):
+        return self._run_one(inp)
+
+    def calculateWitness(self, inp, sanityCheck=False):
+        b = self._run_one(inp)
+        return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+    def calculateWTNSBin(self, inp, sanityCheck=False):
+        return self.circuit.wtns(self._run_one(inp))
+
+    def calculateBatch(self, inputs):
+        recs = b"".join(self.circuit.pack(i) for i in inputs)
+        wit, status = self.circuit.calculate_batch_host(recs)
+        wb = self.circuit.witness_bytes
+        return [wit[i * wb:(i + 1) * wb] for i in range(len(inputs))], status
+
+
+def witness_ints(b):
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]

@@ -1,0 +1,82 @@
+"""ctypes binding of libzkwg.so (the C-ABI declared in include/zkwg.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be
+loaded this module raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libzkwg.so"))
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("main_kind", C.c_uint32),
+        ("max_header", C.c_uint32),
+        ("max_body", C.c_uint32),
+        ("n", C.c_uint32),
+        ("k", C.c_uint32),
+        ("ignore_body_hash_check", C.c_uint32),
+        ("enable_header_masking", C.c_uint32),
+        ("enable_body_masking", C.c_uint32),
+        ("remove_soft_line_breaks", C.c_uint32),
+        ("layout", C.c_uint32),
+    ]
+
+
+MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER = 0, 1, 2
+(IN_HEADER, IN_BODY, IN_PRECOMPUTED_SHA, IN_PUBKEY, IN_SIGNATURE, IN_MESSAGE,
+ IN_HEADER_LEN, IN_BODY_LEN, IN_BODY_HASH_INDEX) = range(9)
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"zkwg: HIP library not built: {LIB_PATH} missing "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C zk-email-verify_amd/csrc`)")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    sig = {
+        "zkwg_abi_version": (i32, []),
+        "zkwg_strerror": (C.c_char_p, [i32]),
+        "zkwg_circuit_create": (i32, [C.POINTER(Config), i32, C.POINTER(vp)]),
+        "zkwg_circuit_destroy": (None, [vp]),
+        "zkwg_witness_len": (u64, [vp]),
+        "zkwg_witness_bytes": (u64, [vp]),
+        "zkwg_num_public": (u32, [vp]),
+        "zkwg_input_stride": (u64, [vp]),
+        "zkwg_input_offset": (u64, [vp, i32]),
+        "zkwg_scratch_bytes": (u64, [vp, u64]),
+        "zkwg_pack_input": (i32, [vp, vp, vp, u32, vp, u32, vp, vp, vp, vp, u32]),
+        "zkwg_calculate_batch": (i32, [vp, vp, u64, vp, u64, vp, u64]),
+        "zkwg_calculate_batch_device": (i32, [vp, vp, u64, vp, u64, vp, vp, vp]),
+        "zkwg_set_timing": (i32, [vp, i32]),
+        "zkwg_last_kernel_ms": (i32, [vp, i32, C.POINTER(C.c_float)]),
+        "zkwg_num_kernels": (i32, [vp]),
+        "zkwg_kernel_name": (C.c_char_p, [vp, i32]),
+        "zkwg_kernel_slots": (u64, [vp, i32]),
+        "zkwg_wtns_size": (u64, [vp]),
+        "zkwg_write_wtns": (i32, [vp, vp, vp, u64]),
+        "zkwg_write_sym": (u64, [vp, vp, u64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTS = [
+    "zkwg_abi_version", "zkwg_strerror", "zkwg_circuit_create", "zkwg_circuit_destroy",
+    "zkwg_witness_len", "zkwg_witness_bytes", "zkwg_num_public", "zkwg_input_stride",
+    "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_pack_input", "zkwg_calculate_batch",
+    "zkwg_calculate_batch_device", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_num_kernels",
+    "zkwg_kernel_name", "zkwg_kernel_slots", "zkwg_wtns_size", "zkwg_write_wtns", "zkwg_write_sym",
+]
