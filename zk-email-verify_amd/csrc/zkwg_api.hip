@@ -2,6 +2,7 @@
 // host<->device staging, .wtns / .sym writers.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -16,7 +17,11 @@ struct zkwg_circuit {
   zkwg_config cfg;
   ZkSched s;
   int device;
-  uint4* d_invtab;
+  Fr* d_invtab;
+  ZkSeg* d_segs;
+  u32* d_first_seg;
+  std::vector<ZkSeg> segs;
+  std::vector<u32> first_seg;
   hipStream_t own_stream;
   int timing;
   int n_kernels;
@@ -26,7 +31,8 @@ struct zkwg_circuit {
   bool ev_valid;
 };
 
-static bool build_sched(const zkwg_config& cfg, ZkSched& s) {
+static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& segs,
+                        std::vector<u32>& first_seg) {
   memset(&s, 0, sizeof(s));
   if (cfg.layout != ZKWG_LAYOUT_KEPT_V1) return false;
   if (cfg.enable_header_masking || cfg.enable_body_masking || cfg.remove_soft_line_breaks) return false;
@@ -54,12 +60,13 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s) {
     f.partial = partial;
     f.in_data = in_data; f.in_len = in_len; f.in_pre = s.in_off[ZKWG_IN_PRECOMPUTED_SHA];
     f.hstate_base = s.hstates_per_email;
+    f.block_base = s.total_blocks;
     s.hstates_per_email += f.nblocks + 1;
     s.total_blocks += f.nblocks;
   };
 
   ZkWalker w;
-  u64 max_small = 256;  // largest |d| whose inverse the kernels look up
+  u64 max_small = 256;  // largest |d| whose inverse zk_expand looks up
   switch (cfg.main_kind) {
     case ZKWG_MAIN_SHA256_BYTES:
       if (cfg.max_header == 0) return false;
@@ -71,15 +78,29 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s) {
     default:
       return false;
   }
+  if (w.seg_cur != w.cur) return false;  // the segment table must tile the witness exactly
   s.W = w.cur;
-  s.inv_table_len = 2 * max_small + 1;
+  s.inv_half = (u32)max_small;
+  s.img_bits = w.nbits + 1;
+  s.img_small = (w.nsmall + 3u) & ~3u;
+  s.img_fr = w.nfr + 1;
+  segs = std::move(w.segs);
+  s.nsegs = (u32)segs.size();
+  s.nportions = (u32)((s.W + ZK_PORTION - 1) / ZK_PORTION);
+  first_seg.assign(s.nportions, 0);
+  u32 si = 0;
+  for (u32 p = 0; p < s.nportions; ++p) {
+    u64 slot0 = (u64)p * ZK_PORTION;
+    while (si + 1 < s.nsegs && segs[si].slot + segs[si].nslots <= slot0) ++si;
+    first_seg[p] = si;
+  }
   return true;
 }
 
 // inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
-static void build_inv_table(u64 len, std::vector<Fr>& tab) {
-  const long long half = (long long)(len / 2);
-  tab.assign(len, fr_zero());
+static void build_inv_table(u32 inv_half, std::vector<Fr>& tab) {
+  const long long half = (long long)inv_half;
+  tab.assign(2 * (u64)inv_half + 1, fr_zero());
   std::vector<Fr> inv(half + 1, fr_zero());  // Montgomery form
   if (half >= 1) inv[1] = fr_R();
   // inv[i] = -(r / i) * inv[r mod i]  (mod r); r / i and r % i by long division on 4 limbs
@@ -128,25 +149,31 @@ const char* zkwg_strerror(int rc) {
 int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out) {
   if (!cfg || !out) return ZKWG_RC_BAD_ARG;
   zkwg_circuit* c = new zkwg_circuit();
-  memset(c, 0, sizeof(*c));
   c->cfg = *cfg;
   c->device = -1;
-  if (!build_sched(*cfg, c->s)) { delete c; return ZKWG_RC_BAD_CONFIG; }
-  // kernel table
+  if (!build_sched(*cfg, c->s, c->segs, c->first_seg)) { delete c; return ZKWG_RC_BAD_CONFIG; }
+  // kernel table (launch order)
   c->n_kernels = 3;
   c->kname[0] = "zk_sha_chain"; c->kslots[0] = 0;
-  c->kname[1] = "zk_sha_expand"; c->kslots[1] = (u64)c->s.total_blocks * ZK_COMP_SLOTS;
-  c->kname[2] = "zk_misc"; c->kslots[2] = c->s.W - c->kslots[1];
+  c->kname[1] = "zk_sha_trace"; c->kslots[1] = 0;
+  c->kname[2] = "zk_expand"; c->kslots[2] = c->s.W;
   if (device >= 0) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return ZKWG_RC_NO_DEVICE; }
     if (hipSetDevice(device) != hipSuccess) { delete c; return ZKWG_RC_HIP_ERROR; }
     c->device = device;
     std::vector<Fr> tab;
-    build_inv_table(c->s.inv_table_len, tab);
-    if (hipMalloc((void**)&c->d_invtab, tab.size() * sizeof(Fr)) != hipSuccess) { delete c; return ZKWG_RC_OOM; }
-    if (hipMemcpy(c->d_invtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) {
-      hipFree(c->d_invtab); delete c; return ZKWG_RC_HIP_ERROR;
+    build_inv_table(c->s.inv_half, tab);
+    bool ok = hipMalloc((void**)&c->d_invtab, tab.size() * sizeof(Fr)) == hipSuccess &&
+              hipMalloc((void**)&c->d_segs, c->segs.size() * sizeof(ZkSeg)) == hipSuccess &&
+              hipMalloc((void**)&c->d_first_seg, c->first_seg.size() * sizeof(u32)) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_invtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(ZkSeg), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(c->d_first_seg, c->first_seg.data(), c->first_seg.size() * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+      hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg);
+      delete c;
+      return ZKWG_RC_OOM;
     }
     hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventCreate(&c->ev[i]);
@@ -159,7 +186,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
-    hipFree(c->d_invtab);
+    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg);
     hipStreamDestroy(c->own_stream);
     for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventDestroy(c->ev[i]);
   }
@@ -174,8 +201,11 @@ uint64_t zkwg_input_offset(const zkwg_circuit_t* c, int field) {
   if (field < 0 || field >= ZKWG_IN_NFIELDS) return (uint64_t)-1;
   return c->s.in_off[field];
 }
-uint64_t zkwg_scratch_bytes(const zkwg_circuit_t* c, uint64_t n_emails) {
-  return n_emails * (u64)c->s.hstates_per_email * 32 + 256;
+static u64 align256(u64 x) { return (x + 255) & ~255ull; }
+uint64_t zkwg_scratch_bytes(const zkwg_circuit_t* c, uint64_t n) {
+  const ZkSched& s = c->s;
+  return align256(n * (u64)s.hstates_per_email * 32) + align256(n * (u64)s.img_bits * 8) +
+         align256(n * (u64)s.img_small * 4) + align256(n * (u64)s.img_fr * 32) + 256;
 }
 
 int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header, uint32_t header_len,
@@ -222,34 +252,39 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n,
   if (!c || !d_in || !d_out || !d_status || !d_scratch) return ZKWG_RC_BAD_ARG;
   if (c->device < 0) return ZKWG_RC_NO_DEVICE;
   if (n == 0) return ZKWG_RC_OK;
-  if (out_stride != c->s.W * 32 || n > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
-  hipStream_t st = (hipStream_t)hip_stream;
   const ZkSched& s = c->s;
-  const u8* in = (const u8*)d_in;
-  u32* hst = (u32*)d_scratch;
-  uint4* wit = (uint4*)d_out;
-  int* status = (int*)d_status;
+  if (out_stride != s.W * 32 || n * (u64)s.nportions > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
+  if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_in & 15)) return ZKWG_RC_BAD_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
   const u32 ne = (u32)n;
+  ZkBufs B;
+  u8* scr = (u8*)d_scratch;
+  B.in = (const u8*)d_in;
+  B.hst = (u32*)scr; scr += align256(n * (u64)s.hstates_per_email * 32);
+  B.bits = (u64*)scr; scr += align256(n * (u64)s.img_bits * 8);
+  B.small = (u32*)scr; scr += align256(n * (u64)s.img_small * 4);
+  B.frv = (Fr*)scr;
+  B.invtab = c->d_invtab;
+  B.segs = c->d_segs;
+  B.first_seg = c->d_first_seg;
+  B.wit = (uint4*)d_out;
+  B.status = (int*)d_status;
+  B.n_emails = ne;
   const bool tm = c->timing != 0;
-  if (hipMemsetAsync(status, 0, n * sizeof(int), st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  if (hipMemsetAsync(B.status, 0, n * sizeof(int), st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   int ki = 0;
   if (tm) hipEventRecord(c->ev[ki], st);
   {
     u32 threads = ne * s.nframes;
-    hipLaunchKernelGGL(zk_sha_chain, dim3((threads + 63) / 64), dim3(64), 0, st, s, in, hst, ne);
+    hipLaunchKernelGGL(zk_sha_chain, dim3((threads + 63) / 64), dim3(64), 0, st, s, B);
   }
   if (tm) hipEventRecord(c->ev[++ki], st);
   {
     u64 units = (u64)ne * s.total_blocks;
-    u64 grid = (units + ZK_EXPAND_WAVES - 1) / ZK_EXPAND_WAVES;
-    hipLaunchKernelGGL(zk_sha_expand, dim3((u32)grid), dim3(64 * ZK_EXPAND_WAVES), 0, st, s, in, hst, wit, ne);
+    hipLaunchKernelGGL(zk_sha_trace, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
   }
   if (tm) hipEventRecord(c->ev[++ki], st);
-  switch (s.main_kind) {
-    case ZKWG_MAIN_SHA256_BYTES:
-      hipLaunchKernelGGL(zk_misc_sha_main, dim3(ne), dim3(256), 0, st, s, in, hst, c->d_invtab, wit, status, ne);
-      break;
-  }
+  hipLaunchKernelGGL(zk_expand, dim3(ne * s.nportions), dim3(256), 0, st, s, B);
   if (tm) { hipEventRecord(c->ev[++ki], st); c->ev_valid = true; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;
@@ -265,7 +300,7 @@ int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, u
   if (hipSetDevice(c->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  const u64 per_email = wbytes + c->s.in_stride + (u64)c->s.hstates_per_email * 32 + 16;
+  const u64 per_email = wbytes + c->s.in_stride + zkwg_scratch_bytes(c, 64) / 64 + 16;
   u64 tile = max_tile ? max_tile : std::max<u64>(1, (u64)(free_b * 0.8) / per_email);
   tile = std::min<u64>(tile, n);
   u8 *d_in = nullptr, *d_out = nullptr, *d_scr = nullptr;

@@ -1,0 +1,191 @@
+// zk_expand -- the streaming expansion kernel (the HBM-write-bound kernel of the path).
+//
+// Every witness element is a 32-byte little-endian field element, but >95 % of the
+// EmailVerifier witness is single bits and nearly all the rest fits 128 bits.  The
+// compute kernels therefore leave a compact per-email IMAGE (packed bit groups, small
+// integers, a few thousand genuine field elements), and this one kernel expands image
+// + input record into the final `.wtns` data section, guided by the circuit's static
+// segment table (zkwg_sched.h).  One workgroup writes one contiguous 32 KiB portion
+// (ZK_PORTION slots) of one witness; consecutive workgroups write consecutive portions,
+// so at any instant the chip writes one dense moving window of HBM (fill-like DRAM
+// page locality), 1 KiB of contiguous bytes per wavefront store instruction, each
+// witness byte written exactly once.
+//
+// Reference semantic being produced: the witness vector of
+// `circuit.calculateWitness(input)` (packages/circuits/tests/email-verifier.test.ts:43),
+// i.e. section 2 of the `.wtns` file.
+#include "zkwg_dev.h"
+#include "zkwg_kernels.h"
+
+#define ZK_EXPAND_THREADS 256
+
+// chunk c (16-byte units, absolute within the email's witness) of a segment, per type.
+// r = slot index inside the segment, half = 0 (low 16 bytes) / 1 (high 16 bytes).
+
+__global__ __launch_bounds__(ZK_EXPAND_THREADS) void zk_expand(ZkSched s, ZkBufs B) {
+  const u32 p = blockIdx.x % s.nportions;
+  const u32 e = blockIdx.x / s.nportions;
+  if (e >= B.n_emails) return;
+  const u64 slot0 = (u64)p * ZK_PORTION;
+  const u64 slot1 = min(s.W, slot0 + ZK_PORTION);
+  uint4* __restrict__ wit = B.wit + (u64)e * s.W * 2;
+  const u8* __restrict__ rec = B.in + (u64)e * s.in_stride;
+  const u64* __restrict__ bits = B.bits + (u64)e * s.img_bits;
+  const u32* __restrict__ small = B.small + (u64)e * s.img_small;
+  const Fr* __restrict__ frv = B.frv + (u64)e * s.img_fr;
+  const uint4* __restrict__ invtab = (const uint4*)B.invtab;
+  const u32 tid = threadIdx.x;
+
+  for (u32 si = B.first_seg[p]; si < s.nsegs; ++si) {
+    const ZkSeg sg = B.segs[si];
+    if (sg.slot >= slot1) break;
+    const u64 lo = max(sg.slot, slot0);
+    const u64 hi = min(sg.slot + sg.nslots, slot1);
+    const u32 r0 = (u32)(lo - sg.slot);         // first in-segment slot handled here
+    const u32 nch = (u32)(hi - lo) * 2;          // chunks to write
+    uint4* __restrict__ dst = wit + lo * 2;
+
+    switch (sg.type) {
+      case ZSEG_SMALL:
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) v.x = small[sg.src + r0 + (c >> 1)];
+          dst[c] = v;
+        }
+        break;
+      case ZSEG_FR: {
+        const uint4* src = (const uint4*)(frv + sg.src + r0);
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) dst[c] = src[c];
+        break;
+      }
+      case ZSEG_BITS:
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) {
+            u32 r = r0 + (c >> 1);
+            u32 g = r / sg.a, bit = r - g * sg.a;
+            v.x = (u32)(bits[sg.src + g * sg.b + (bit >> 6)] >> (bit & 63)) & 1u;
+          }
+          dst[c] = v;
+        }
+        break;
+      case ZSEG_SHA_SP:
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) {
+            u32 r = r0 + (c >> 1);
+            u32 i = r / ZK_SP_SLOTS, q = r - i * ZK_SP_SLOTS;
+            u32 sub = min(q >> 5, 4u);
+            v.x = (u32)(bits[sg.src + i * 5 + sub] >> (q - sub * 32)) & 1u;
+          }
+          dst[c] = v;
+        }
+        break;
+      case ZSEG_SHA_T1:
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) {
+            u32 r = r0 + (c >> 1);
+            u32 i = r / ZK_T1_SLOTS, q = r - i * ZK_T1_SLOTS;
+            u32 sub = min(q >> 5, 3u);
+            v.x = (u32)(bits[sg.src + i * 4 + sub] >> (q - sub * 32)) & 1u;
+          }
+          dst[c] = v;
+        }
+        break;
+      case ZSEG_SHA_T2:
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) {
+            u32 r = r0 + (c >> 1);
+            u32 i = r / ZK_T2_SLOTS, q = r - i * ZK_T2_SLOTS;
+            u32 sub = min(q >> 5, 4u);
+            v.x = (u32)(bits[sg.src + i * 5 + sub] >> (q - sub * 32)) & 1u;
+          }
+          dst[c] = v;
+        }
+        break;
+      case ZSEG_ISZ: {
+        const int half_tab = (int)s.inv_half;
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          u32 r = r0 + (c >> 1);
+          int d = (int)small[sg.src + (r >> 1)];
+          uint4 v = zk_zero4();
+          if (!(r & 1u)) {
+            if (!(c & 1u)) v.x = (d == 0);
+          } else {
+            d = max(-half_tab, min(half_tab, d));
+            v = invtab[(u32)(d + half_tab) * 2 + (c & 1u)];
+          }
+          dst[c] = v;
+        }
+        break;
+      }
+      case ZSEG_SEL: {
+        // 256 x ItemAtIndex(NB): per output bit k: nums[NB], then NB x (isz.out, isz.inv)
+        const u32 NB = sg.a, per = 3 * NB;
+        const int idx = (int)small[sg.src];
+        const int half_tab = (int)s.inv_half;
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          u32 r = r0 + (c >> 1), hf = c & 1u;
+          u32 k = r / per, q = r - k * per;
+          uint4 v = zk_zero4();
+          if (q < NB) {
+            if (!hf && (int)q == idx) v.x = (small[sg.b + (k >> 5)] >> (31 - (k & 31))) & 1u;
+          } else {
+            u32 t = q - NB, j = t >> 1;
+            if (!(t & 1u)) {
+              if (!hf) v.x = ((int)j == idx);
+            } else {
+              int d = idx - (int)j;  // isz.in = index - j
+              d = max(-half_tab, min(half_tab, d));
+              v = invtab[(u32)(d + half_tab) * 2 + hf];
+            }
+          }
+          dst[c] = v;
+        }
+        break;
+      }
+      case ZSEG_IN8:
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) v.x = rec[sg.src + r0 + (c >> 1)];
+          dst[c] = v;
+        }
+        break;
+      case ZSEG_IN8BITS:
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) {
+            u32 r = r0 + (c >> 1);
+            v.x = (u32)(rec[sg.src + (r >> 3)] >> (r & 7)) & 1u;
+          }
+          dst[c] = v;
+        }
+        break;
+      case ZSEG_LIMB:
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) v = *(const uint4*)(rec + sg.src + 16 * (r0 + (c >> 1)));
+          dst[c] = v;
+        }
+        break;
+      case ZSEG_LTBITS: {
+        const long long base = (long long)(int)small[sg.src] + (1ll << sg.a);
+        const u32 per = sg.a + 1;
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) {
+            u32 r = r0 + (c >> 1);
+            u32 i = r / per, bit = r - i * per;
+            v.x = (u32)((u64)(base - (long long)i) >> bit) & 1u;
+          }
+          dst[c] = v;
+        }
+        break;
+      }
+      default:
+        break;
+    }
+  }
+}

@@ -1,7 +1,9 @@
-// Witness schedule: the compact "kept-v1" layout as segment offsets.
-// Built once per circuit on the host (zkwg_sched.cpp) and passed by value to the
-// kernels.  All `s_*` members are witness slot indices (field-element units)
-// relative to the start of one email's witness.
+// Witness schedule of one circuit: the compact "kept-v1" layout lowered into
+//   (1) a static SEGMENT TABLE that tiles the witness [0, W) -- consumed by the single
+//       streaming expansion kernel zk_expand (the HBM-write-bound kernel), and
+//   (2) the offsets at which the compute kernels deposit their results inside the
+//       per-email compact IMAGE (packed bit groups / small ints / field elements).
+// Built once per circuit on the host (zkwg_layout.h) and passed to kernels by value.
 #pragma once
 #include <stdint.h>
 #include "zkwg_fr.h"
@@ -15,10 +17,7 @@
 #define ZK_SP_SLOTS 162u
 #define ZK_T1_SLOTS 131u
 #define ZK_T2_SLOTS 161u
-#define ZK_SEC_SP_END (48u * ZK_SP_SLOTS)                   // 7776
-#define ZK_SEC_T1_END (ZK_SEC_SP_END + 64u * ZK_T1_SLOTS)   // 16160
-#define ZK_SEC_T2_END (ZK_SEC_T1_END + 64u * ZK_T2_SLOTS)   // 26464
-// trace groups (one u64 per 32..35-bit group)
+// trace groups (one u64 word per 32..35-bit group)
 #define ZK_G_SP 0u
 #define ZK_G_T1 240u
 #define ZK_G_T2 496u
@@ -26,6 +25,35 @@
 #define ZK_G_SUME 880u
 #define ZK_G_FSUM 944u
 #define ZK_TRACE_GROUPS 952u
+
+// ---------------------------------------------------------------- segment table
+// Every witness slot belongs to exactly one segment.  `src` indexes the email's image
+// (or its input record); bit vectors are LSB-first inside little-endian u64 words.
+enum ZkSegType : u32 {
+  ZSEG_SMALL = 0,   // slot r = small[src + r]                                  (u32 values)
+  ZSEG_FR = 1,      // slot r = fr[src + r]                                     (32-byte values)
+  ZSEG_BITS = 2,    // groups of a bits, b words/group: bit (r%a) of bits[src + (r/a)*b ...]
+  ZSEG_SHA_SP = 3,  // 162-slot periods over 5 words (32,32,32,32,34 bits)
+  ZSEG_SHA_T1 = 4,  // 131-slot periods over 4 words (32,32,32,35)
+  ZSEG_SHA_T2 = 5,  // 161-slot periods over 5 words (32,32,32,32,33)
+  ZSEG_ISZ = 6,     // IsZero pairs: d = (i32)small[src + r/2]; even: d==0, odd: d^-1 (table)
+  ZSEG_SEL = 7,     // ItemAtIndex(a) x 256: idx=(i32)small[src]; digest words small[b..b+8)
+  ZSEG_IN8 = 8,     // slot r = input byte  in[src + r]
+  ZSEG_IN8BITS = 9, // Num2Bits(8) of input bytes: bit (r&7) of in[src + r/8]
+  ZSEG_LIMB = 10,   // slot r = 16-byte LE limb in[src + 16 r]
+  ZSEG_LTBITS = 11, // LessThan(a) arrays: v = (i32)small[src] + 2^a - i, i = r/(a+1), bit r%(a+1)
+  ZSEG_NTYPES = 12
+};
+
+struct ZkSeg {
+  u64 slot;    // first witness slot
+  u32 nslots;  // length
+  u32 type;    // ZkSegType
+  u32 src;     // source offset (see type)
+  u32 a, b, c; // type parameters
+};
+
+#define ZK_PORTION 1024u  // witness slots expanded by one workgroup of zk_expand (32 KiB)
 
 struct ZkShaFrame {      // one Sha256Bytes / Sha256BytesPartial instance
   u32 max_bytes;         // maxByteLength
@@ -36,12 +64,14 @@ struct ZkShaFrame {      // one Sha256Bytes / Sha256BytesPartial instance
   u32 in_len;            // byte offset of the u32 length
   u32 in_pre;            // byte offset of precomputedSHA[32] (partial only)
   u32 hstate_base;       // first chaining-state index (units of 8 x u32) in scratch
-  u64 s_inBlockIndex;    // 1 slot
-  u64 s_lenbits;         // lenbits+1 slots (LessEqThan -> LessThan -> Num2Bits)
-  u64 s_comp;            // nblocks x ZK_COMP_SLOTS
-  u64 s_sel;             // 256 x (nblocks nums + nblocks x (isz.out, isz.inv))
-  u64 s_bytes;           // max_bytes x 8
-  u64 s_states;          // 32 x 8 (partial only)
+  u32 block_base;        // index of this frame's first block among the email's blocks
+  // image offsets
+  u32 b_trace;           // bits: nblocks x ZK_TRACE_GROUPS words
+  u32 b_lenbits;         // bits: 1 word, the LessEqThan Num2Bits input
+  u32 b_digest;          // bits: 4 words, selected hash as one LSB-first 256-bit group (bit k = out[k])
+  u32 m_ibi;             // small: inBlockIndex
+  u32 m_idx;             // small: (i32) inBlockIndex - 1
+  u32 m_digest;          // small: 8 words, state after block idx (the selected hash)
 };
 
 struct ZkSched {
@@ -54,11 +84,30 @@ struct ZkSched {
   u32 in_stride;         // bytes per input record
   u32 in_off[9];         // enum zkwg_input_field -> byte offset
   u32 n_public;
+  u32 nsegs;
+  u32 nportions;         // ceil(W / ZK_PORTION)
+  u32 img_bits;          // u64 words per email
+  u32 img_small;         // u32 words per email
+  u32 img_fr;            // Fr elements per email
+  u32 inv_half;          // inverse table covers d in [-inv_half, inv_half]
   u64 W;                 // witness length in field elements
-  u64 inv_table_len;     // entries in the small-inverse table
   ZkShaFrame fr[2];
-  // main-component I/O slots
-  u64 s_out;             // first output slot (always 1)
-  u64 s_pub_in;          // first public input slot
-  u64 s_prv_in;          // first private input slot
+  // image offsets of main-level values
+  u32 m_one;             // small: constant 1
+  u32 m_hdr_len;         // small: emailHeaderLength / paddedInLength
+};
+
+// Device pointers of one launch (kernel argument, by value).
+struct ZkBufs {
+  const u8* in;          // packed input records
+  u32* hst;              // SHA chaining states
+  u64* bits;             // image: bit groups      [n_emails][img_bits]
+  u32* small;            // image: small integers  [n_emails][img_small]
+  Fr* frv;               // image: field elements  [n_emails][img_fr]
+  const Fr* invtab;      // d^-1 for d in [-inv_half, inv_half]
+  const ZkSeg* segs;     // segment table
+  const u32* first_seg;  // first segment overlapping each portion
+  uint4* wit;            // output witnesses
+  int* status;           // per-email status
+  u32 n_emails;
 };
