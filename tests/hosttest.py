@@ -1,0 +1,103 @@
+"""Test-only helpers: host build of the product's schedule builder + wave-collective RSA
+core (tests/native/hosttest.cpp), and a Python restatement of zk_expand's segment semantics
+so that CPU tests can turn a compact image into a witness without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+from conftest import ROOT
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+_SO = os.path.join(ROOT, "tests", "native", "libzkwg_hosttest.so")
+_SRC = os.path.join(ROOT, "tests", "native", "hosttest.cpp")
+_CSRC = os.path.join(ROOT, "zk-email-verify_amd", "csrc")
+
+
+class Seg(C.Structure):
+    _fields_ = [("slot", C.c_uint64), ("nslots", C.c_uint32), ("type", C.c_uint32),
+                ("src", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("c", C.c_uint32)]
+
+
+def load():
+    deps = [_SRC] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
+    if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", _CSRC, _SRC, "-o", _SO])
+    lib = C.CDLL(_SO)
+    lib.ht_create.restype = C.c_void_p
+    lib.ht_create.argtypes = [C.c_void_p]
+    lib.ht_destroy.argtypes = [C.c_void_p]
+    lib.ht_W.restype = C.c_uint64
+    lib.ht_W.argtypes = [C.c_void_p]
+    lib.ht_segs.restype = C.POINTER(Seg)
+    lib.ht_segs.argtypes = [C.c_void_p]
+    for f in ("ht_nsegs", "ht_img_bits", "ht_img_small", "ht_img_fr", "ht_in_stride", "ht_inv_half", "ht_m_one"):
+        getattr(lib, f).restype = C.c_uint32
+        getattr(lib, f).argtypes = [C.c_void_p]
+    lib.ht_in_off.restype = C.c_uint32
+    lib.ht_in_off.argtypes = [C.c_void_p, C.c_int]
+    lib.ht_run_rsa.restype = C.c_int
+    lib.ht_run_rsa.argtypes = [C.c_void_p] * 6
+    return lib
+
+
+def expand(lib, h, rec, bits, small, frv):
+    """Python restatement of zk_expand (zkwg_kernels_expand.hip): image -> witness ints."""
+    W = lib.ht_W(h)
+    segs = lib.ht_segs(h)
+    half = lib.ht_inv_half(h)
+    out = [None] * W
+
+    def i32(x):
+        return x - (1 << 32) if x >> 31 else x
+
+    def inv(d):
+        return 0 if d == 0 else pow(d % P, P - 2, P)
+
+    def fr(i):
+        return int.from_bytes(bytes(frv[32 * i:32 * i + 32]), "little")
+
+    for si in range(lib.ht_nsegs(h)):
+        s = segs[si]
+        for r in range(s.nslots):
+            t = s.type
+            if t == 0:
+                v = small[s.src + r]
+            elif t == 1:
+                v = fr(s.src + r)
+            elif t == 2:
+                g, bit = divmod(r, s.a)
+                v = (bits[s.src + g * s.b + (bit >> 6)] >> (bit & 63)) & 1
+            elif t in (3, 4, 5):
+                per, nw, last = {3: (162, 5, 4), 4: (131, 4, 3), 5: (161, 5, 4)}[t]
+                i, q = divmod(r, per)
+                sub = min(q >> 5, last)
+                v = (bits[s.src + i * nw + sub] >> (q - 32 * sub)) & 1
+            elif t == 6:
+                d = i32(small[s.src + (r >> 1)])
+                v = (1 if d == 0 else 0) if r % 2 == 0 else inv(max(-half, min(half, d)))
+            elif t == 7:
+                NB = s.a
+                idx = i32(small[s.src])
+                k, q = divmod(r, 3 * NB)
+                if q < NB:
+                    v = ((small[s.b + (k >> 5)] >> (31 - (k & 31))) & 1) if q == idx else 0
+                else:
+                    tt = q - NB
+                    j = tt >> 1
+                    v = (1 if j == idx else 0) if tt % 2 == 0 else inv(max(-half, min(half, idx - j)))
+            elif t == 8:
+                v = rec[s.src + r]
+            elif t == 9:
+                v = (rec[s.src + (r >> 3)] >> (r & 7)) & 1
+            elif t == 10:
+                v = int.from_bytes(bytes(rec[s.src + 16 * r:s.src + 16 * r + 16]), "little")
+            elif t == 11:
+                base = i32(small[s.src]) + (1 << s.a)
+                i, bit = divmod(r, s.a + 1)
+                v = ((base - i) >> bit) & 1
+            else:
+                raise ValueError(t)
+            assert out[s.slot + r] is None
+            out[s.slot + r] = v
+    assert all(x is not None for x in out)
+    return out

@@ -1,0 +1,45 @@
+// Test-only host build of the wave-collective RSA core (zkwg_rsa_core.h) and of the
+// schedule builder.  NOT part of the product: it lets the CPU test-suite check the
+// lane-parallel RSA code and the segment table against the oracle without a GPU.
+#include <stdlib.h>
+#include <vector>
+#include "zkwg_build.h"
+#include "zkwg_rsa_core.h"
+
+struct HT {
+  ZkSched s;
+  std::vector<ZkSeg> segs;
+  std::vector<u32> first;
+};
+
+extern "C" {
+void* ht_create(const zkwg_config* cfg) {
+  HT* h = new HT();
+  if (!build_sched(*cfg, h->s, h->segs, h->first)) { delete h; return nullptr; }
+  return h;
+}
+void ht_destroy(void* p) { delete (HT*)p; }
+uint64_t ht_W(void* p) { return ((HT*)p)->s.W; }
+uint32_t ht_nsegs(void* p) { return ((HT*)p)->s.nsegs; }
+const void* ht_segs(void* p) { return ((HT*)p)->segs.data(); }
+uint32_t ht_img_bits(void* p) { return ((HT*)p)->s.img_bits; }
+uint32_t ht_img_small(void* p) { return ((HT*)p)->s.img_small; }
+uint32_t ht_img_fr(void* p) { return ((HT*)p)->s.img_fr; }
+uint32_t ht_in_stride(void* p) { return ((HT*)p)->s.in_stride; }
+uint32_t ht_in_off(void* p, int f) { return ((HT*)p)->s.in_off[f]; }
+uint32_t ht_inv_half(void* p) { return ((HT*)p)->s.inv_half; }
+uint32_t ht_m_one(void* p) { return ((HT*)p)->s.m_one; }
+// run the RSA block of one email on the host; digest = 8 state words or NULL
+int ht_run_rsa(void* p, const uint8_t* rec, const uint32_t* digest, uint64_t* bits, uint32_t* small, void* frv) {
+  HT* h = (HT*)p;
+  ZkRsaLds* S = new ZkRsaLds();
+  u32 lt_eq[40];
+  zk_rsa_email(*S, h->s.rsa, rec, digest, bits, small, (Fr*)frv, lt_eq);
+  int ok = (int)S->ok;
+  delete S;
+  return ok;
+}
+// Fr helpers for unit tests
+void ht_fr_mul(const void* a, const void* b, void* out) { *(Fr*)out = fr_mul_std(*(const Fr*)a, *(const Fr*)b); }
+void ht_fr_inv(const void* a, void* out) { *(Fr*)out = fr_inv_std(*(const Fr*)a); }
+}

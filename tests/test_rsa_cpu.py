@@ -1,0 +1,76 @@
+"""CPU tests of the RSA path: the product's wave-collective RSA core (host build) + segment
+table against the literal Python oracle, on the reference's own RSA KATs
+(packages/circuits/tests/rsa.test.ts:64-144)."""
+import ctypes as C
+import random
+
+import pytest
+
+import hosttest
+from zkwg._lib import Config, MAIN_RSA_VERIFIER
+
+
+def limbs(x, n=121, k=17):
+    return [(x >> (n * i)) & ((1 << n) - 1) for i in range(k)]
+
+
+KAT_SIG = 102386562682221859025549328916727857389789009840935140645361501981959969535413501251999442013082353139290537518086128904993091119534674934202202277050635907008004079788691412782712147797487593510040249832242022835902734939817209358184800954336078838331094308355388211284440290335887813714894626653613586546719
+KAT_PUB = 106773687078109007595028366084970322147907086635176067918161636756354740353674098686965493426431314019237945536387044259034050617425729739578628872957481830432099721612688699974185290306098360072264136606623400336518126533605711223527682187548332314997606381158951535480830524587400401856271050333371205030999
+KAT_MSG = [1156466847851242602709362303526378170, 191372789510123109308037416804949834, 7204] + [0] * 14
+
+
+def run_host_rsa(message, sig, mod):
+    lib = hosttest.load()
+    cfg = Config(MAIN_RSA_VERIFIER, 0, 0, 121, 17, 0, 0, 0, 0, 0)
+    h = lib.ht_create(C.byref(cfg))
+    assert h
+    rec = (C.c_uint8 * lib.ht_in_stride(h))()
+
+    def put(field, vals):
+        off = lib.ht_in_off(h, field)
+        for i, v in enumerate(vals):
+            rec[off + 16 * i:off + 16 * i + 16] = list(int(v).to_bytes(16, "little"))
+
+    put(3, mod); put(4, sig); put(5, message)
+    bits = (C.c_uint64 * lib.ht_img_bits(h))()
+    small = (C.c_uint32 * lib.ht_img_small(h))()
+    frv = (C.c_uint8 * (32 * lib.ht_img_fr(h)))()
+    small[lib.ht_m_one(h)] = 1
+    ok = lib.ht_run_rsa(h, rec, None, bits, small, frv)
+    wit = hosttest.expand(lib, h, rec, bits, small, frv)
+    lib.ht_destroy(h)
+    return ok, wit
+
+
+def oracle_rsa(message, sig, mod):
+    from oracle.pyref import zkemail as zk, comp
+    main = zk.RSAVerifier65537(121, 17, message, sig, mod, is_main=True)
+    return comp.witness_kept(main)
+
+
+def test_rsa_1024_kat_host_core_matches_oracle():
+    ok, wit = run_host_rsa(KAT_MSG, limbs(KAT_SIG), limbs(KAT_PUB))
+    assert ok == 1
+    assert wit == oracle_rsa(KAT_MSG, limbs(KAT_SIG), limbs(KAT_PUB))
+
+
+def test_rsa_wrong_message_fails():
+    from oracle.pyref import comp
+    m2 = list(KAT_MSG)
+    m2[0] += 1
+    ok, _ = run_host_rsa(m2, limbs(KAT_SIG), limbs(KAT_PUB))
+    assert ok == 0
+    with pytest.raises(comp.AssertFailed):
+        oracle_rsa(m2, limbs(KAT_SIG), limbs(KAT_PUB))
+
+
+def test_rsa_2048_synthetic_key():
+    from zkwg.synth import test_key, pkcs1_sign_digest
+    import hashlib
+    key = test_key()
+    digest = hashlib.sha256(b"zkwg synthetic header").digest()
+    sig = pkcs1_sign_digest(key, digest)
+    msg = limbs(int.from_bytes(digest, "big"))
+    ok, wit = run_host_rsa(msg, limbs(sig), limbs(key["n"]))
+    assert ok == 1
+    assert wit == oracle_rsa(msg, limbs(sig), limbs(key["n"]))

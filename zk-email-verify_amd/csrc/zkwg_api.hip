@@ -10,6 +10,7 @@
 #include "../../include/zkwg.h"
 #include "zkwg_kernels.h"
 #include "zkwg_layout.h"
+#include "zkwg_build.h"
 
 #define ZK_MAX_KERNELS 8
 
@@ -30,72 +31,6 @@ struct zkwg_circuit {
   hipEvent_t ev[ZK_MAX_KERNELS + 1];
   bool ev_valid;
 };
-
-static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& segs,
-                        std::vector<u32>& first_seg) {
-  memset(&s, 0, sizeof(s));
-  if (cfg.layout != ZKWG_LAYOUT_KEPT_V1) return false;
-  if (cfg.enable_header_masking || cfg.enable_body_masking || cfg.remove_soft_line_breaks) return false;
-  if (cfg.max_header % 64 != 0 || cfg.max_body % 64 != 0) return false;
-  s.main_kind = cfg.main_kind;
-  s.n = cfg.n; s.k = cfg.k; s.ignore_body = cfg.ignore_body_hash_check;
-  // input record
-  u32 off = 0;
-  s.in_off[ZKWG_IN_HEADER] = off; off += cfg.max_header;
-  s.in_off[ZKWG_IN_BODY] = off; off += cfg.max_body;
-  s.in_off[ZKWG_IN_PRECOMPUTED_SHA] = off; off += 32;
-  off = (off + 15u) & ~15u;
-  s.in_off[ZKWG_IN_PUBKEY] = off; off += 17 * 16;
-  s.in_off[ZKWG_IN_SIGNATURE] = off; off += 17 * 16;
-  s.in_off[ZKWG_IN_MESSAGE] = off; off += 17 * 16;
-  s.in_off[ZKWG_IN_HEADER_LEN] = off; off += 4;
-  s.in_off[ZKWG_IN_BODY_LEN] = off; off += 4;
-  s.in_off[ZKWG_IN_BODY_HASH_INDEX] = off; off += 4;
-  s.in_stride = (off + 15u) & ~15u;
-
-  auto init_frame = [&](ZkShaFrame& f, u32 max_bytes, u32 partial, u32 in_data, u32 in_len) {
-    f.max_bytes = max_bytes;
-    f.nblocks = max_bytes / 64;
-    f.lenbits = zk_log2ceil((u64)max_bytes * 8);
-    f.partial = partial;
-    f.in_data = in_data; f.in_len = in_len; f.in_pre = s.in_off[ZKWG_IN_PRECOMPUTED_SHA];
-    f.hstate_base = s.hstates_per_email;
-    f.block_base = s.total_blocks;
-    s.hstates_per_email += f.nblocks + 1;
-    s.total_blocks += f.nblocks;
-  };
-
-  ZkWalker w;
-  u64 max_small = 256;  // largest |d| whose inverse zk_expand looks up
-  switch (cfg.main_kind) {
-    case ZKWG_MAIN_SHA256_BYTES:
-      if (cfg.max_header == 0) return false;
-      s.nframes = 1;
-      init_frame(s.fr[0], cfg.max_header, 0, s.in_off[ZKWG_IN_HEADER], s.in_off[ZKWG_IN_HEADER_LEN]);
-      zk_walk_main_sha(w, s);
-      max_small = std::max<u64>(max_small, s.fr[0].nblocks + 2);
-      break;
-    default:
-      return false;
-  }
-  if (w.seg_cur != w.cur) return false;  // the segment table must tile the witness exactly
-  s.W = w.cur;
-  s.inv_half = (u32)max_small;
-  s.img_bits = w.nbits + 1;
-  s.img_small = (w.nsmall + 3u) & ~3u;
-  s.img_fr = w.nfr + 1;
-  segs = std::move(w.segs);
-  s.nsegs = (u32)segs.size();
-  s.nportions = (u32)((s.W + ZK_PORTION - 1) / ZK_PORTION);
-  first_seg.assign(s.nportions, 0);
-  u32 si = 0;
-  for (u32 p = 0; p < s.nportions; ++p) {
-    u64 slot0 = (u64)p * ZK_PORTION;
-    while (si + 1 < s.nsegs && segs[si].slot + segs[si].nslots <= slot0) ++si;
-    first_seg[p] = si;
-  }
-  return true;
-}
 
 // inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
 static void build_inv_table(u32 inv_half, std::vector<Fr>& tab) {
@@ -153,10 +88,11 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
   c->device = -1;
   if (!build_sched(*cfg, c->s, c->segs, c->first_seg)) { delete c; return ZKWG_RC_BAD_CONFIG; }
   // kernel table (launch order)
-  c->n_kernels = 3;
+  c->n_kernels = 4;
   c->kname[0] = "zk_sha_chain"; c->kslots[0] = 0;
   c->kname[1] = "zk_sha_trace"; c->kslots[1] = 0;
-  c->kname[2] = "zk_expand"; c->kslots[2] = c->s.W;
+  c->kname[2] = "zk_rsa"; c->kslots[2] = 0;
+  c->kname[3] = "zk_expand"; c->kslots[3] = c->s.W;
   if (device >= 0) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return ZKWG_RC_NO_DEVICE; }
@@ -274,15 +210,17 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n,
   if (hipMemsetAsync(B.status, 0, n * sizeof(int), st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   int ki = 0;
   if (tm) hipEventRecord(c->ev[ki], st);
-  {
+  if (s.nframes) {
     u32 threads = ne * s.nframes;
     hipLaunchKernelGGL(zk_sha_chain, dim3((threads + 63) / 64), dim3(64), 0, st, s, B);
   }
   if (tm) hipEventRecord(c->ev[++ki], st);
-  {
+  if (s.nframes) {
     u64 units = (u64)ne * s.total_blocks;
     hipLaunchKernelGGL(zk_sha_trace, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
   }
+  if (tm) hipEventRecord(c->ev[++ki], st);
+  if (s.rsa.present) hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), 0, st, s, B);
   if (tm) hipEventRecord(c->ev[++ki], st);
   hipLaunchKernelGGL(zk_expand, dim3(ne * s.nportions), dim3(256), 0, st, s, B);
   if (tm) { hipEventRecord(c->ev[++ki], st); c->ev_valid = true; }
@@ -370,6 +308,7 @@ uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap) {
   };
   switch (tmp.main_kind) {
     case ZKWG_MAIN_SHA256_BYTES: zk_walk_main_sha(w, tmp); break;
+    case ZKWG_MAIN_RSA_VERIFIER: zk_walk_main_rsa(w, tmp); break;
   }
   return pos;
 }

@@ -6,3 +6,4 @@
 __global__ void zk_sha_chain(ZkSched s, ZkBufs B);   // zkwg_kernels_sha.hip
 __global__ void zk_sha_trace(ZkSched s, ZkBufs B);   // zkwg_kernels_sha.hip
 __global__ void zk_expand(ZkSched s, ZkBufs B);      // zkwg_kernels_expand.hip
+__global__ void zk_rsa(ZkSched s, ZkBufs B);         // zkwg_kernels_rsa.hip

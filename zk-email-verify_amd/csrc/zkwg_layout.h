@@ -151,3 +151,91 @@ static inline void zk_walk_main_sha(ZkWalker& w, ZkSched& s) {
   zk_walk_sha_frame(w, "main", s.fr[0]);
   s.n_public = 256 + s.fr[0].max_bytes + 1;
 }
+
+// ------------------------------------------------------------------ RSA (lib/rsa.circom, lib/fp.circom, lib/bigint.circom)
+static inline void zk_alloc_blt(ZkWalker& w, ZkBltLayout& L) {
+  L.b_lt = w.alloc_bits(34);
+  L.f_eq = w.alloc_fr(34);
+  L.m_gates = w.alloc_small(48);
+}
+// BigLessThan(121,17): lt[17] (Num2Bits(122)), eq[17] (isz.out, isz.inv), ors/ands/eq_ands[16]
+static inline void zk_walk_blt(ZkWalker& w, const std::string& p, const ZkBltLayout& L) {
+  w.seg(ZSEG_BITS, 17 * 122, L.b_lt, 122, 2);
+  for (u32 i = 0; i < 17; ++i) w.arr(zk_idx(p + ".lt", i) + ".n2b.out", 122);
+  w.seg(ZSEG_FR, 34, L.f_eq);
+  for (u32 i = 0; i < 17; ++i) {
+    w.one(zk_idx(p + ".eq", i) + ".isz.out");
+    w.one(zk_idx(p + ".eq", i) + ".isz.inv");
+  }
+  w.seg(ZSEG_SMALL, 48, L.m_gates);
+  for (u32 i = 0; i < 16; ++i) w.one(zk_idx(p + ".ors", i) + ".out");
+  for (u32 i = 0; i < 16; ++i) w.one(zk_idx(p + ".ands", i) + ".out");
+  for (u32 i = 0; i < 16; ++i) w.one(zk_idx(p + ".eq_ands", i) + ".out");
+}
+static inline void zk_alloc_fpmul(ZkWalker& w, ZkFpMulLayout& F) {
+  F.f_main = w.alloc_fr(100);
+  F.b_qr = w.alloc_bits(68);
+  zk_alloc_blt(w, F.blt);
+  F.f_carry = w.alloc_fr(33);
+  F.b_carry = w.alloc_bits(96);
+}
+// FpMul(121,17) (lib/fp.circom:16-81)
+static inline void zk_walk_fpmul(ZkWalker& w, const std::string& p, const ZkFpMulLayout& F) {
+  w.seg(ZSEG_FR, 100, F.f_main);
+  w.arr(p + ".v_ab", 33); w.arr(p + ".q", 17); w.arr(p + ".r", 17); w.arr(p + ".v_pq_r", 33);
+  w.seg(ZSEG_BITS, 34 * 121, F.b_qr, 121, 2);
+  for (u32 i = 0; i < 17; ++i) w.arr(zk_idx(p + ".q_range_check", i) + ".out", 121);
+  for (u32 i = 0; i < 17; ++i) w.arr(zk_idx(p + ".r_range_check", i) + ".out", 121);
+  zk_walk_blt(w, p + ".r_p_lt_check", F.blt);
+  w.seg(ZSEG_FR, 33, F.f_carry);
+  w.arr(p + ".tCheck.carry", 33);
+  w.seg(ZSEG_BITS, 32 * 131, F.b_carry, 131, 3);
+  for (u32 i = 0; i < 32; ++i) w.arr(zk_idx(p + ".tCheck.carryRangeChecks", i) + ".out", 131);
+}
+static inline void zk_alloc_rsa(ZkWalker& w, ZkRsaLayout& R) {
+  R.present = 1;
+  R.b_modbits = w.alloc_bits(34);
+  R.b_msgbits = w.alloc_bits(34);
+  R.m_modzero = w.alloc_small(205);
+  R.b_sigbits = w.alloc_bits(34);
+  if (R.msg_from_digest) R.f_msg = w.alloc_fr(17);
+  zk_alloc_blt(w, R.blt);
+  for (u32 m = 0; m < 17; ++m) zk_alloc_fpmul(w, R.mul[m]);
+}
+// RSAVerifier65537(121,17) sub-tree (lib/rsa.circom:13-46)
+static inline void zk_walk_rsa(ZkWalker& w, const std::string& p, const ZkRsaLayout& R) {
+  w.seg(ZSEG_BITS, 17 * 121, R.b_modbits, 121, 2);
+  for (u32 i = 0; i < 17; ++i) w.arr(zk_idx(p + ".padder.modulusN2B", i) + ".out", 121);
+  w.seg(ZSEG_BITS, 17 * 121, R.b_msgbits, 121, 2);
+  for (u32 i = 0; i < 17; ++i) w.arr(zk_idx(p + ".padder.messageN2B", i) + ".out", 121);
+  w.seg(ZSEG_ISZ, 2 * 205, R.m_modzero);
+  for (u32 i = 0; i < 205; ++i) {
+    w.one(zk_idx(p + ".padder.modulusZero", i) + ".out");
+    w.one(zk_idx(p + ".padder.modulusZero", i) + ".inv");
+  }
+  w.seg(ZSEG_BITS, 17 * 121, R.b_sigbits, 121, 2);
+  for (u32 i = 0; i < 17; ++i) w.arr(zk_idx(p + ".signatureRangeCheck", i) + ".out", 121);
+  zk_walk_blt(w, p + ".bigLessThan", R.blt);
+  for (u32 m = 0; m < 16; ++m) zk_walk_fpmul(w, zk_idx(p + ".bigPow.doublers", m), R.mul[m]);
+  zk_walk_fpmul(w, p + ".bigPow.adder", R.mul[16]);
+}
+
+// main = RSAVerifier65537(121,17), public [modulus]
+// (packages/circuits/tests/test-circuits/rsa-test.circom:5)
+static inline void zk_walk_main_rsa(ZkWalker& w, ZkSched& s) {
+  s.m_one = w.alloc_small(1);
+  s.m_hdr_len = w.alloc_small(1);
+  s.rsa.msg_from_digest = 0;
+  s.rsa.in_mod = s.in_off[3]; s.rsa.in_sig = s.in_off[4]; s.rsa.in_msg = s.in_off[5];
+  zk_alloc_rsa(w, s.rsa);
+  w.seg(ZSEG_SMALL, 1, s.m_one);
+  w.one("one");
+  w.seg(ZSEG_LIMB, 17, s.rsa.in_mod);
+  w.arr("main.modulus", 17);
+  w.seg(ZSEG_LIMB, 17, s.rsa.in_msg);
+  w.arr("main.message", 17);
+  w.seg(ZSEG_LIMB, 17, s.rsa.in_sig);
+  w.arr("main.signature", 17);
+  zk_walk_rsa(w, "main", s.rsa);
+  s.n_public = 17;
+}

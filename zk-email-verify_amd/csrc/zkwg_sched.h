@@ -74,6 +74,34 @@ struct ZkShaFrame {      // one Sha256Bytes / Sha256BytesPartial instance
   u32 m_digest;          // small: 8 words, state after block idx (the selected hash)
 };
 
+// image offsets of one BigLessThan instance (lib/bigint.circom:16-60)
+struct ZkBltLayout {
+  u32 b_lt;     // bits: 17 x 2 words (Num2Bits(122) inputs)
+  u32 f_eq;     // fr: 34 = 17 x (isz.out, isz.inv)
+  u32 m_gates;  // small: ors[16], ands[16], eq_ands[16]
+};
+// image offsets of one FpMul instance (lib/fp.circom:16-81)
+struct ZkFpMulLayout {
+  u32 f_main;   // fr: v_ab[33], q[17], r[17], v_pq_r[33]
+  u32 b_qr;     // bits: 34 x 2 words (q then r limbs)
+  ZkBltLayout blt;
+  u32 f_carry;  // fr: carry[33]
+  u32 b_carry;  // bits: 32 x 3 words (carry + 2^130)
+};
+// RSAVerifier65537(121,17) (lib/rsa.circom:13-46)
+struct ZkRsaLayout {
+  u32 present;                 // 0 = circuit has no RSA block
+  u32 in_mod, in_sig, in_msg;  // byte offsets in the input record
+  u32 msg_from_digest;         // 1: message = header digest (EmailVerifier), 0: from the record
+  u32 m_digest;                // small: header digest words (msg_from_digest)
+  u32 b_modbits, b_msgbits;    // bits: 17 x 2 words each
+  u32 m_modzero;               // small: 205 popcounts (IsZero inputs)
+  u32 b_sigbits;               // bits: 17 x 2 words
+  u32 f_msg;                   // fr: message limbs (rsaMessage outputs; EmailVerifier only)
+  ZkBltLayout blt;             // signature < modulus
+  ZkFpMulLayout mul[17];       // doublers[0..15], adder
+};
+
 struct ZkSched {
   u32 main_kind;
   u32 n, k;
@@ -95,8 +123,10 @@ struct ZkSched {
   // image offsets of main-level values
   u32 m_one;             // small: constant 1
   u32 m_hdr_len;         // small: emailHeaderLength / paddedInLength
+  ZkRsaLayout rsa;
 };
 
+#if defined(__HIPCC__)
 // Device pointers of one launch (kernel argument, by value).
 struct ZkBufs {
   const u8* in;          // packed input records
@@ -111,3 +141,4 @@ struct ZkBufs {
   int* status;           // per-email status
   u32 n_emails;
 };
+#endif
