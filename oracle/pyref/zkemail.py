@@ -573,3 +573,145 @@ def Sha256BytesPartial(maxByteLength, paddedIn, paddedInLength, preHash):
     out.setall(sha.o, "L")
     c.o = out.v
     return c
+
+
+# ------------------------------------------------------------ utils/hash.circom
+
+
+def PoseidonLarge(bitsPerChunk, chunkSize, in_):
+    """utils/hash.circom:15-39."""
+    from . import poseidon as pos
+    assert chunkSize > 16 and chunkSize <= 32 and bitsPerChunk * 2 < 251
+    halfChunkSize = chunkSize >> 1
+    if chunkSize % 2 == 1:
+        halfChunkSize += 1
+    c = Comp(f"PoseidonLarge({bitsPerChunk},{chunkSize})")
+    out = c.out("out")
+    c.inp("in", chunkSize).setall(in_, "L")
+    poseidonInput = c.mid("poseidonInput", halfChunkSize)
+    for i in range(halfChunkSize):
+        if i == halfChunkSize - 1 and chunkSize % 2 == 1:
+            poseidonInput.set(in_[2 * i], "L", i)
+        else:
+            poseidonInput.set(in_[2 * i] + (1 << bitsPerChunk) * in_[2 * i + 1], "L", i)
+    h = c.sub("anon_Poseidon", pos.Poseidon(halfChunkSize, poseidonInput.v))
+    c.o = out.set(h.o, "L")
+    return c
+
+
+# ------------------------------------------------------------ email-verifier.circom
+
+
+def EmailVerifier(maxHeadersLength, maxBodyLength, n, k, ignoreBodyHashCheck, inputs, body_hash_regex=None):
+    """email-verifier.circom:42-174 with enableHeaderMasking = enableBodyMasking =
+    removeSoftLineBreaks = 0; main component, `public [ pubkey ]`
+    (tests/test-circuits/email-verifier-test.circom:5).
+
+    `inputs`: dict of integer lists/ints keyed by signal name.  `body_hash_regex(msg)` ->
+    Comp with .o = (out, reveal0[]) stands for the [EXT] BodyHashRegex template."""
+    assert maxHeadersLength % 64 == 0 and maxBodyLength % 64 == 0
+    assert n * k > 2048 and n < (255 // 2)
+    c = Comp(f"EmailVerifier({maxHeadersLength},{maxBodyLength},{n},{k},{ignoreBodyHashCheck},0,0,0)", is_main=True)
+    c.public = {"pubkey"}
+    emailHeader = [int(x) % P for x in inputs["emailHeader"]]
+    emailHeaderLength = int(inputs["emailHeaderLength"]) % P
+    pubkey = [int(x) % P for x in inputs["pubkey"]]
+    signature = [int(x) % P for x in inputs["signature"]]
+    # declaration order (email-verifier.circom:49-54, 70-71, 109-112)
+    c.inp("emailHeader", maxHeadersLength).setall(emailHeader, "K")
+    c.inp("emailHeaderLength").set(emailHeaderLength, "K")
+    c.inp("pubkey", k).setall(pubkey, "K")
+    c.inp("signature", k).setall(signature, "K")
+    pubkeyHash = c.out("pubkeyHash")
+    sha_sig = c.mid("sha", 256)
+    shaHi = c.out("shaHi")
+    shaLo = c.out("shaLo")
+
+    n2bHeaderLength = c.sub("n2bHeaderLength", cl.Num2Bits(log2Ceil(maxHeadersLength), emailHeaderLength))
+    c.sub("anon_AssertZeroPadding_header", AssertZeroPadding(maxHeadersLength, emailHeader, emailHeaderLength))
+    shab = c.sub("anon_Sha256Bytes", Sha256Bytes(maxHeadersLength, emailHeader, emailHeaderLength))
+    sha = shab.o
+    sha_sig.setall(sha, "L")
+    bitPacker = c.sub("bitPacker", PackBits(256, 128, sha))
+    shaHi.set(bitPacker.o[0], "L")
+    shaLo.set(bitPacker.o[1], "L")
+
+    rsaMessageSize = (256 + n) // n
+    rm_in = [[0] * n for _ in range(rsaMessageSize)]
+    for i in range(256):
+        rm_in[i // n][i % n] = sha[255 - i]
+    rsaMessage = [c.sub(f"rsaMessage[{i}]", cl.Bits2Num(n, rm_in[i])) for i in range(rsaMessageSize)]
+    message = [rsaMessage[i].o for i in range(rsaMessageSize)] + [0] * (k - rsaMessageSize)
+    c.sub("rsaVerifier", RSAVerifier65537(n, k, message, signature, pubkey))
+
+    if ignoreBodyHashCheck != 1:
+        bodyHashIndex = int(inputs["bodyHashIndex"]) % P
+        precomputedSHA = [int(x) % P for x in inputs["precomputedSHA"]]
+        emailBody = [int(x) % P for x in inputs["emailBody"]]
+        emailBodyLength = int(inputs["emailBodyLength"]) % P
+        c.inp("bodyHashIndex").set(bodyHashIndex, "K")
+        c.inp("precomputedSHA", 32).setall(precomputedSHA, "K")
+        c.inp("emailBody", maxBodyLength).setall(emailBody, "K")
+        c.inp("emailBodyLength").set(emailBodyLength, "K")
+        c.sub("n2bBodyLength", cl.Num2Bits(log2Ceil(maxBodyLength), emailBodyLength))
+        c.sub("anon_AssertZeroPadding_body", AssertZeroPadding(maxBodyLength, emailBody, emailBodyLength))
+        rx = c.sub("anon_BodyHashRegex", body_hash_regex(emailHeader))
+        bhRegexMatch = c.mid("bhRegexMatch").set(rx.o[0], "L")
+        bhReveal = c.mid("bhReveal", maxHeadersLength)
+        bhReveal.setall(rx.o[1], "L")
+        c.eq(bhRegexMatch, 1, "bhRegexMatch === 1 (email-verifier.circom:127)")
+        shaB64Length = 44
+        sel = c.sub("anon_SelectRegexReveal", SelectRegexReveal(maxHeadersLength, shaB64Length, bhReveal.v, bodyHashIndex))
+        c.mid("bhBase64", shaB64Length).setall(sel.o, "L")
+        b64 = c.sub("anon_Base64Decode", Base64Decode(32, sel.o))
+        c.mid("headerBodyHash", 32).setall(b64.o, "L")
+        shap = c.sub("anon_Sha256BytesPartial", Sha256BytesPartial(maxBodyLength, emailBody, emailBodyLength, precomputedSHA))
+        c.mid("computedBodyHash", 256).setall(shap.o, "L")
+        for i in range(32):
+            bits = [0] * 8
+            for j in range(8):
+                bits[7 - j] = shap.o[i * 8 + j]
+            b2n = c.sub(f"computedBodyHashInts[{i}]", cl.Bits2Num(8, bits))
+            c.eq(b2n.o, b64.o[i], "computedBodyHashInts[i].out === headerBodyHash[i] (email-verifier.circom:145)")
+
+    ph = c.sub("anon_PoseidonLarge", PoseidonLarge(n, k, pubkey))
+    pubkeyHash.set(ph.o, "L")
+    c.o = (pubkeyHash.v[0], shaHi.v[0], shaLo.v[0])
+    return c
+
+
+# ------------------------------------------------------------ BodyHashRegex [EXT]
+import re as _re
+
+# @zk-email/zk-regex-circom 2.3.2, circuits/common/body_hash_regex.circom (source absent,
+# yarn.lock:2794-2802).  Regex compiled by zk-regex (email-verifier.circom:126 call site):
+#   (\r\n|^)dkim-signature:([a-z]+=[^;]+; )+bh=[a-zA-Z0-9+/=]+;      public part: the bh value
+# zk-regex feeds the DFA the byte 255 in front of the message to stand for `^`.
+_BH_RE = _re.compile(rb"(?:\r\n|\xff)dkim-signature:(?:[a-z]+=[^;]+; )+bh=([a-zA-Z0-9+/=]+);")
+
+
+def BodyHashRegex(msg_bytes, msg):
+    """Interface-level restatement: `out` = number of matches != 0, `reveal0[i]` = msg[i] inside
+    the public (bh value) part of a match, else 0.  The DFA-internal signals of the generated
+    circuit are NOT restated (parity unpinned); only reveal0 (quadratic:
+    `reveal0[i] <== in[i+1] * is_reveal0[i]`) is part of the kept layout."""
+    c = Comp(f"BodyHashRegex({msg_bytes})")
+    out = c.out("out")
+    reveal0 = c.out("reveal0", msg_bytes)
+    c.inp("msg", msg_bytes).setall(msg, "L")
+    data = b"\xff" + bytes(int(x) & 0xFF for x in msg)
+    rev = [0] * msg_bytes
+    n = 0
+    pos = 0
+    while True:
+        m = _BH_RE.search(data, pos)
+        if not m:
+            break
+        n += 1
+        for i in range(m.start(1), m.end(1)):
+            rev[i - 1] = data[i]
+        pos = m.end()
+    out.set(1 if n else 0, "L")
+    reveal0.setall(rev, "Q")
+    c.o = (out.v[0], reveal0.v)
+    return c

@@ -37,6 +37,9 @@ def load():
     lib.ht_in_off.argtypes = [C.c_void_p, C.c_int]
     lib.ht_run_rsa.restype = C.c_int
     lib.ht_run_rsa.argtypes = [C.c_void_p] * 6
+    lib.ht_poseidon.argtypes = [C.c_void_p] * 3
+    lib.ht_regex_scan.restype = C.c_uint32
+    lib.ht_regex_scan.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     return lib
 
 
@@ -95,6 +98,43 @@ def expand(lib, h, rec, bits, small, frv):
                 base = i32(small[s.src]) + (1 << s.a)
                 i, bit = divmod(r, s.a + 1)
                 v = ((base - i) >> bit) & 1
+            elif t == 12:
+                bl, N = s.a, s.c
+                per = 6 + bl + 1
+                start = i32(small[s.src])
+                if r < per - 2:
+                    i, q = 0, (r if r < 4 else r + 2)
+                else:
+                    i, q = divmod(r - (per - 2), per)
+                    i += 1
+                if q < 6:
+                    d = (start - i) if q < 2 else (i32(small[s.b + i]) if q < 4 else i32(small[s.b + i - 1]))
+                    v = (1 if d == 0 else 0) if q % 2 == 0 else inv(max(-half, min(half, d)))
+                else:
+                    v = ((start + 43 + (1 << bl) - i) >> (q - 6)) & 1
+            elif t == 13:
+                N = s.a
+                j, i = divmod(r, N)
+                sh = small[s.src] & ((2 << j) - 1)
+                v = small[s.b + (i + sh) % N]
+            elif t in (14, 15):
+                per = 68 if t == 15 else 6
+                g, q = divmod(r, per)
+                ch = small[s.src + g]
+                rAZ, raz, r09 = int(65 <= ch <= 90), int(97 <= ch <= 122), int(48 <= ch <= 57)
+                sAZ = rAZ * (ch - 65); saz = sAZ + raz * (ch - 71); s09 = saz + r09 * (ch + 4)
+                spl = s09 + (ch == 43) * (ch + 19); ssl = spl + (ch == 47) * (ch + 16)
+                if t == 14:
+                    v = (ssl >> q) & 1
+                elif q < 8:
+                    v = [rAZ, sAZ, raz, saz, r09, s09, spl, ssl][q]
+                elif q < 62:
+                    k, bit = divmod(q - 8, 9)
+                    v = ([ch + 256 - 91, 64 + 256 - ch, ch + 256 - 123, 96 + 256 - ch, ch + 256 - 58, 47 + 256 - ch][k] >> bit) & 1
+                else:
+                    k = (q - 62) >> 1
+                    d = ch - [43, 47, 61][k]
+                    v = (1 if d == 0 else 0) if (q - 62) % 2 == 0 else inv(max(-half, min(half, d)))
             else:
                 raise ValueError(t)
             assert out[s.slot + r] is None

@@ -5,6 +5,8 @@
 #include <vector>
 #include "zkwg_build.h"
 #include "zkwg_rsa_core.h"
+#include "zkwg_poseidon_core.h"
+#include "zkwg_regex_core.h"
 
 struct HT {
   ZkSched s;
@@ -38,6 +40,20 @@ int ht_run_rsa(void* p, const uint8_t* rec, const uint32_t* digest, uint64_t* bi
   int ok = (int)S->ok;
   delete S;
   return ok;
+}
+// PoseidonLarge(121,17) of 17 x 16-byte limbs: out420 = S-box signals, hash = pubkeyHash
+void ht_poseidon(const uint8_t* limbs, void* out420, void* hash) {
+  std::vector<Fr> C, M;
+  build_poseidon_constants(10, 8, 60, C, M);
+  ZkPosLds* S = new ZkPosLds();
+  u64 l[17][2];
+  memcpy(l, limbs, sizeof(l));
+  zk_poseidon_large(*S, l, C.data(), M.data(), (Fr*)out420, (Fr*)hash);
+  delete S;
+}
+uint32_t ht_regex_scan(const uint8_t* msg, uint32_t n, uint32_t* rev) {
+  for (uint32_t i = 0; i < n; ++i) rev[i] = 0;
+  return zk_bh_regex_scan(msg, n, rev);
 }
 // Fr helpers for unit tests
 void ht_fr_mul(const void* a, const void* b, void* out) { *(Fr*)out = fr_mul_std(*(const Fr*)a, *(const Fr*)b); }

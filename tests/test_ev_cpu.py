@@ -1,0 +1,87 @@
+"""CPU tests for the EmailVerifier main: layout/symbol table vs the oracle, host builds of the
+Poseidon core and the BodyHashRegex scanner vs the oracle / Python `re`."""
+import ctypes as C
+import random
+
+import hosttest
+
+
+def _oracle_ev(N, M, ignore, inp):
+    from oracle.pyref import zkemail as zk
+    return zk.EmailVerifier(N, M, 121, 17, ignore, inp, body_hash_regex=lambda m: zk.BodyHashRegex(N, m))
+
+
+def _inputs(N, M, ignore, index=0, body_len=100):
+    from zkwg import synth, inputs
+    d = synth.synthetic_dkim_result(7, index, body_len=body_len)
+    return inputs.generate_email_verifier_inputs_from_dkim_result(d, N, M, ignore_body_hash_check=bool(ignore))
+
+
+def test_ev_layout_matches_oracle_with_and_without_body():
+    import zkwg
+    from oracle.pyref import comp
+    for ignore in (1, 0):
+        N, M = 576, 192
+        main = _oracle_ev(N, M, ignore, _inputs(N, M, ignore))
+        sym = comp.symbols_kept(main)
+        c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, ignore_body_hash_check=ignore, device=-1)
+        assert c.W == len(sym)
+        got = c.symbols()
+        assert got == sym
+        assert c.n_public == 20
+
+
+def test_poseidon_host_core_matches_oracle():
+    from oracle.pyref import zkemail as zk, comp
+    from zkwg.synth import test_key
+    lib = hosttest.load()
+    n = test_key()["n"]
+    limbs = [(n >> (121 * i)) & ((1 << 121) - 1) for i in range(17)]
+    buf = b"".join(x.to_bytes(16, "little") for x in limbs)
+    out = (C.c_uint8 * (32 * 420))()
+    h = (C.c_uint8 * 32)()
+    lib.ht_poseidon(buf, out, h)
+    pl = zk.PoseidonLarge(121, 17, limbs)
+    kept = [v for _, v, k in pl.walk("x") if comp.is_kept(k)]
+    got = [int.from_bytes(bytes(out[32 * i:32 * i + 32]), "little") for i in range(420)]
+    assert got == kept
+    assert int.from_bytes(bytes(h), "little") == pl.o
+
+
+def test_poseidon_known_vectors():
+    # poseidon([1,2]) is the globally known circomlib vector; [1,2,3,4] is circomlibjs' own test
+    from oracle.pyref import poseidon
+    assert poseidon.poseidon_hash([1, 2]) == 7853200120776062878684798364095072458815029376092732009249414926327459813530
+    assert poseidon.poseidon_hash([1, 2, 3, 4]) == 18821383157269793795438455681495246036402687001665670618754263018637548127333
+
+
+def test_regex_scanner_vs_python_re():
+    from oracle.pyref import zkemail as zk
+    lib = hosttest.load()
+    rng = random.Random(5)
+    from zkwg import synth
+    N = 576
+    cases = []
+    for i in range(40):
+        hdr = bytearray(synth.synthetic_dkim_result(3, i, body_len=80)["headers"])
+        mode = i % 8
+        if mode == 1:
+            hdr[rng.randrange(len(hdr))] = rng.randrange(256)
+        elif mode == 2:
+            k = hdr.find(b"bh=")
+            hdr[k + 10] = ord(";")
+        elif mode == 3:
+            hdr = hdr.replace(b"dkim-signature:", b"dkim-signaturE:")
+        elif mode == 4:
+            hdr = hdr.replace(b"; bh=", b";bh=")
+        elif mode == 5:
+            hdr = b"dkim-signature:a=b; bh=QUJD; x" + hdr[:300]
+        elif mode == 6:
+            hdr = bytearray(rng.randrange(256) for _ in range(400))
+        cases.append(bytes(hdr[:N]).ljust(N, b"\0"))
+    for msg in cases:
+        rev = (C.c_uint32 * N)()
+        n = lib.ht_regex_scan(msg, N, rev)
+        o = zk.BodyHashRegex(N, list(msg))
+        assert (1 if n else 0) == o.o[0]
+        assert list(rev) == o.o[1]

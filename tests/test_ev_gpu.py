@@ -1,0 +1,84 @@
+"""GPU parity: main = EmailVerifier(maxHeader, maxBody, 121, 17, ignoreBodyHashCheck, 0, 0, 0)
+(reference: packages/circuits/tests/email-verifier.test.ts, email-verifier-no-body.test.ts) --
+HIP witness vs the literal Python oracle, bit-exact; tamper cases must give "Assert Failed"."""
+import copy
+import hashlib
+
+import pytest
+
+from test_ev_cpu import _inputs, _oracle_ev
+
+pytestmark = pytest.mark.gpu
+
+
+def _circuit(N, M, ignore):
+    import zkwg
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, ignore_body_hash_check=ignore, device=0)
+    return c, zkwg.WitnessCalculator(c)
+
+
+@pytest.mark.parametrize("ignore", [1, 0])
+def test_ev_small_batch_bit_exact(ignore):
+    import zkwg
+    from oracle.pyref import comp
+    N, M = 576, 192
+    c, wc = _circuit(N, M, ignore)
+    ins = [_inputs(N, M, ignore, index=i, body_len=40 + 13 * i) for i in range(5)]
+    wits, status = wc.calculateBatch(ins)
+    assert status == [0] * 5
+    for inp, wb in zip(ins, wits):
+        main = _oracle_ev(N, M, ignore, inp)
+        w = zkwg.witness_ints(wb)
+        assert w == comp.witness_kept(main)
+        # outputs first: pubkeyHash, shaHi, shaLo (email-verifier.test.ts:188-207 checks w[1])
+        assert (w[1], w[2], w[3]) == main.o
+
+
+def test_ev_tamper_cases_assert_failed():
+    # email-verifier.test.ts:61-186: invalid signature / tampered header / tampered body /
+    # non-zero padding / wrong bodyHashIndex each make calculateWitness throw "Assert Failed"
+    import zkwg
+    from oracle.pyref import comp
+    N, M = 576, 192
+    c, wc = _circuit(N, M, 0)
+    good = _inputs(N, M, 0, index=3, body_len=77)
+
+    def mutated(fn):
+        x = copy.deepcopy(good)
+        fn(x)
+        return x
+
+    def set_(key, idx, val):
+        def f(x):
+            x[key][idx] = str(val)
+        return f
+
+    hlen, blen = int(good["emailHeaderLength"]), int(good["emailBodyLength"])
+    bad = [
+        mutated(set_("signature", 0, int(good["signature"][0]) ^ 1)),          # :61-79
+        mutated(set_("emailHeader", 0, int(good["emailHeader"][0]) ^ 1)),      # :81-102 header tampered
+        mutated(set_("emailBody", 0, int(good["emailBody"][0]) ^ 1)),          # :125-146 body tampered
+        mutated(set_("emailHeader", hlen + 1, 1)),                             # :104-123 padding not zero
+        mutated(set_("emailBody", blen + 1, 1)),                               # :148-166 body padding not zero
+        mutated(lambda x: x.__setitem__("bodyHashIndex", str(int(x["bodyHashIndex"]) + 1))),  # :168-186
+    ]
+    wits, status = wc.calculateBatch([good] + bad)
+    assert status[0] == 0
+    assert status[1:] == [4] * len(bad)
+    for b in bad:
+        with pytest.raises(comp.AssertFailed):
+            _oracle_ev(N, M, 0, b)
+        with pytest.raises(zkwg.ZkwgError, match="Assert Failed"):
+            wc.calculateWitness(b)
+
+
+def test_ev_default_size_one_email_bit_exact():
+    # BASELINE.json configs[0]: EmailVerifier(1024, 1536, 121, 17, 0,0,0,0), one email
+    import zkwg
+    from oracle.pyref import comp
+    N, M = 1024, 1536
+    c, wc = _circuit(N, M, 0)
+    inp = _inputs(N, M, 0, index=11, body_len=1024)
+    w = wc.calculateWitness(inp)
+    main = _oracle_ev(N, M, 0, inp)
+    assert w == comp.witness_kept(main)

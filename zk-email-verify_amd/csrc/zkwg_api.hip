@@ -19,6 +19,7 @@ struct zkwg_circuit {
   ZkSched s;
   int device;
   Fr* d_invtab;
+  Fr* d_pos;      // Poseidon(9): C[680] then M[100]
   ZkSeg* d_segs;
   u32* d_first_seg;
   std::vector<ZkSeg> segs;
@@ -88,11 +89,12 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
   c->device = -1;
   if (!build_sched(*cfg, c->s, c->segs, c->first_seg)) { delete c; return ZKWG_RC_BAD_CONFIG; }
   // kernel table (launch order)
-  c->n_kernels = 4;
+  c->n_kernels = 5;
   c->kname[0] = "zk_sha_chain"; c->kslots[0] = 0;
   c->kname[1] = "zk_sha_trace"; c->kslots[1] = 0;
-  c->kname[2] = "zk_rsa"; c->kslots[2] = 0;
-  c->kname[3] = "zk_expand"; c->kslots[3] = c->s.W;
+  c->kname[2] = "zk_misc_ev"; c->kslots[2] = 0;
+  c->kname[3] = "zk_rsa"; c->kslots[3] = 0;
+  c->kname[4] = "zk_expand"; c->kslots[4] = c->s.W;
   if (device >= 0) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return ZKWG_RC_NO_DEVICE; }
@@ -106,7 +108,15 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
     ok = ok && hipMemcpy(c->d_invtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(ZkSeg), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(c->d_first_seg, c->first_seg.data(), c->first_seg.size() * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && c->s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER) {
+      std::vector<Fr> C, M;
+      build_poseidon_constants(10, 8, 60, C, M);
+      C.insert(C.end(), M.begin(), M.end());
+      ok = hipMalloc((void**)&c->d_pos, C.size() * sizeof(Fr)) == hipSuccess &&
+           hipMemcpy(c->d_pos, C.data(), C.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) {
+      hipFree(c->d_pos);
       hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg);
       delete c;
       return ZKWG_RC_OOM;
@@ -122,7 +132,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
-    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg);
+    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos);
     hipStreamDestroy(c->own_stream);
     for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventDestroy(c->ev[i]);
   }
@@ -201,6 +211,8 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n,
   B.small = (u32*)scr; scr += align256(n * (u64)s.img_small * 4);
   B.frv = (Fr*)scr;
   B.invtab = c->d_invtab;
+  B.pos_c = c->d_pos;
+  B.pos_m = c->d_pos ? c->d_pos + 680 : nullptr;
   B.segs = c->d_segs;
   B.first_seg = c->d_first_seg;
   B.wit = (uint4*)d_out;
@@ -219,6 +231,8 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n,
     u64 units = (u64)ne * s.total_blocks;
     hipLaunchKernelGGL(zk_sha_trace, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
   }
+  if (tm) hipEventRecord(c->ev[++ki], st);
+  if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 0, st, s, B);
   if (tm) hipEventRecord(c->ev[++ki], st);
   if (s.rsa.present) hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), 0, st, s, B);
   if (tm) hipEventRecord(c->ev[++ki], st);
@@ -309,6 +323,7 @@ uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap) {
   switch (tmp.main_kind) {
     case ZKWG_MAIN_SHA256_BYTES: zk_walk_main_sha(w, tmp); break;
     case ZKWG_MAIN_RSA_VERIFIER: zk_walk_main_rsa(w, tmp); break;
+    case ZKWG_MAIN_EMAIL_VERIFIER: zk_walk_main_ev(w, tmp); break;
   }
   return pos;
 }

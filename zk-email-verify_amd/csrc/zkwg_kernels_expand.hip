@@ -184,6 +184,96 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void zk_expand(ZkSched s, ZkBufs
         }
         break;
       }
+      case ZSEG_REGSEL: {
+        // SelectRegexReveal (utils/regex.circom:31-37): per index i: IsEqual(i,start) (out,inv),
+        // IsZero(in[i]) (out,inv), [i>0: IsZero(in[i-1]) (out,inv)], GreaterThan(bl)(i, start+43) bits
+        const u32 bl = sg.a, per = 6 + bl + 1, N = sg.c;
+        const int start = (int)small[sg.src];
+        const int half_tab = (int)s.inv_half;
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          u32 r = r0 + (c >> 1), hf = c & 1u;
+          u32 i, q;
+          if (r < per - 2) {  // index 0 has no "previous" IsZero
+            i = 0; q = r < 4 ? r : r + 2;
+          } else {
+            u32 rr = r - (per - 2);
+            i = 1 + rr / per; q = rr - (i - 1) * per;
+          }
+          uint4 v = zk_zero4();
+          if (q < 6) {
+            int d;
+            if (q < 2) d = start - (int)i;                       // isz.in = in[1] - in[0] = startIndex - i
+            else if (q < 4) d = (int)small[sg.b + (i < N ? i : N - 1)];
+            else d = (int)small[sg.b + (i ? i - 1 : 0)];
+            if (!(q & 1u)) {
+              if (!hf) v.x = (d == 0);
+            } else {
+              d = max(-half_tab, min(half_tab, d));
+              v = invtab[(u32)(d + half_tab) * 2 + hf];
+            }
+          } else if (!hf) {
+            long long val = (long long)start + 43 + (1ll << bl) - (long long)i;
+            v.x = (u32)((u64)val >> (q - 6)) & 1u;
+          }
+          dst[c] = v;
+        }
+        break;
+      }
+      case ZSEG_VSHIFT: {
+        const u32 N = sg.a;
+        const u32 shift = small[sg.src];
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) {
+            u32 r = r0 + (c >> 1);
+            u32 j = r / N, i = r - j * N;
+            u32 sh = shift & ((2u << j) - 1u);
+            v.x = small[sg.b + (i + sh) % N];
+          }
+          dst[c] = v;
+        }
+        break;
+      }
+      case ZSEG_B64BITS:
+      case ZSEG_B64: {
+        const int half_tab = (int)s.inv_half;
+        const u32 per = sg.type == ZSEG_B64 ? 68u : 6u;
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          u32 r = r0 + (c >> 1), hf = c & 1u;
+          u32 g = r / per, q = r - g * per;
+          const int ch = (int)small[sg.src + g];
+          // lib/base64.circom:71-128
+          const u32 rAZ = (ch >= 65 && ch <= 90), raz = (ch >= 97 && ch <= 122), r09 = (ch >= 48 && ch <= 57);
+          const u32 sAZ = rAZ * (u32)(ch - 65);
+          const u32 saz = sAZ + raz * (u32)(ch - 71);
+          const u32 s09 = saz + r09 * (u32)(ch + 4);
+          const u32 spl = s09 + (ch == 43) * (u32)(ch + 19);
+          const u32 ssl = spl + (ch == 47) * (u32)(ch + 16);
+          uint4 v = zk_zero4();
+          if (sg.type == ZSEG_B64BITS) {
+            if (!hf) v.x = (ssl >> q) & 1u;
+          } else if (q < 8) {
+            const u32 mids[8] = {rAZ, sAZ, raz, saz, r09, s09, spl, ssl};
+            if (!hf) v.x = mids[q];
+          } else if (q < 62) {
+            u32 k = (q - 8) / 9, bit = (q - 8) - k * 9;
+            // le_Z: in+256-91, ge_A: 64+256-in, le_z: in+256-123, ge_a: 96+256-in, le_9: in+256-58, ge_0: 47+256-in
+            const int vals[6] = {ch + 256 - 91, 64 + 256 - ch, ch + 256 - 123, 96 + 256 - ch, ch + 256 - 58, 47 + 256 - ch};
+            if (!hf) v.x = ((u32)vals[k] >> bit) & 1u;
+          } else {
+            u32 k = (q - 62) >> 1;
+            int d = ch - (k == 0 ? 43 : (k == 1 ? 47 : 61));
+            if (!((q - 62) & 1u)) {
+              if (!hf) v.x = (d == 0);
+            } else {
+              d = max(-half_tab, min(half_tab, d));
+              v = invtab[(u32)(d + half_tab) * 2 + hf];
+            }
+          }
+          dst[c] = v;
+        }
+        break;
+      }
       default:
         break;
     }

@@ -1,0 +1,71 @@
+// zk_misc_ev -- the small-integer blocks of EmailVerifier's body-hash path, one wavefront per
+// email: BodyHashRegex scan, SelectRegexReveal / VarShiftLeft inputs, Base64Decode and the
+// final body-hash comparison (packages/circuits/email-verifier.circom:124-146).  Produces
+// image values + assertion status; zk_expand derives every per-index signal on the fly.
+#include "zkwg_dev.h"
+#include "zkwg_kernels.h"
+#include "zkwg_regex_core.h"
+
+__global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
+  const u32 e = blockIdx.x;
+  if (e >= B.n_emails) return;
+  const u32 lane = threadIdx.x;
+  const u8* rec = B.in + (u64)e * s.in_stride;
+  u64* bits = B.bits + (u64)e * s.img_bits;
+  u32* small = B.small + (u64)e * s.img_small;
+  const u32 N = s.fr[0].max_bytes;
+  u32* rev = small + s.m_rev;
+  __shared__ u32 ok_sh;
+  if (lane == 0) ok_sh = 1;
+  for (u32 i = lane; i < N; i += 64) rev[i] = 0;
+  __syncthreads();
+  const u32 start = *(const u32*)(rec + s.in_off[8]);  // bodyHashIndex
+  if (lane == 0) {
+    u32 matches = zk_bh_regex_scan(rec + s.fr[0].in_data, N, rev);
+    if (matches == 0) ok_sh = 0;                        // bhRegexMatch === 1
+    small[s.m_bh_idx] = start;
+    bits[s.b_shift] = start;
+    u32 blh = 0;
+    for (u32 n = N - 1; n > 0; n >>= 1) ++blh;
+    if (start >= (1u << blh)) ok_sh = 0;                // VarShiftLeft.n2b = Num2Bits(log2Ceil(N))
+    if ((u64)start + 43 >= (1ull << s.sel_bits)) ok_sh = 0;  // GreaterThan(bl) Num2Bits at i = 0
+  }
+  __syncthreads();
+  // SelectRegexReveal assertions (utils/regex.circom:39-47)
+  for (u32 i = lane; i < N; i += 64) {
+    bool bad = false;
+    if (i == start) bad = rev[i] == 0 || (i > 0 && rev[i - 1] != 0);
+    if ((u64)i > (u64)start + 43 && rev[i] != 0) bad = true;
+    if (bad) ok_sh = 0;
+  }
+  // bhBase64[g] = VarShiftLeft(N, 44)(bhReveal, bodyHashIndex)[g] = rev[(g + shift) mod N]
+  __shared__ u32 vals[44];
+  if (lane < 44) {
+    u32 ch = rev[(lane + start % N) % N];
+    small[s.m_chars + lane] = ch;
+    // Base64Lookup (lib/base64.circom:71-128)
+    u32 v = 0;
+    bool valid = true;
+    if (ch >= 65 && ch <= 90) v = ch - 65;
+    else if (ch >= 97 && ch <= 122) v = ch - 71;
+    else if (ch >= 48 && ch <= 57) v = ch + 4;
+    else if (ch == 43) v = 62;
+    else if (ch == 47) v = 63;
+    else if (ch == 61) v = 0;
+    else valid = false;
+    vals[lane] = v;
+    if (!valid) ok_sh = 0;                              // base64.circom:127
+  }
+  __syncthreads();
+  // computedBodyHashInts[i].out === headerBodyHash[i]  (email-verifier.circom:139-146)
+  if (lane < 32) {
+    u32 g = lane / 3, k = lane % 3;
+    u32 v0 = vals[4 * g], v1 = vals[4 * g + 1], v2 = vals[4 * g + 2], v3 = vals[4 * g + 3];
+    u32 byte = k == 0 ? ((v0 << 2) | (v1 >> 4)) : (k == 1 ? (((v1 & 15) << 4) | (v2 >> 2)) : (((v2 & 3) << 6) | v3));
+    u32 w = small[s.fr[1].m_digest + (lane >> 2)];
+    u32 expect = (w >> (24 - 8 * (lane & 3))) & 0xff;
+    if ((byte & 0xff) != expect) ok_sh = 0;
+  }
+  __syncthreads();
+  if (lane == 0 && !ok_sh) B.status[e] = 4;
+}

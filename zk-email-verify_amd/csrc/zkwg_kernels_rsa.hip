@@ -2,6 +2,7 @@
 #include "zkwg_dev.h"
 #include "zkwg_kernels.h"
 #include "zkwg_rsa_core.h"
+#include "zkwg_poseidon_core.h"
 
 __global__ __launch_bounds__(64) void zk_rsa(ZkSched s, ZkBufs B) {
   __shared__ ZkRsaLds S;
@@ -16,4 +17,9 @@ __global__ __launch_bounds__(64) void zk_rsa(ZkSched s, ZkBufs B) {
   if (s.main_kind == 2 && threadIdx.x == 0) small[s.m_one] = 1;  // no SHA chain kernel in this main
   zk_rsa_email(S, s.rsa, rec, digest, bits, small, frv, lt_eq);
   if (threadIdx.x == 0 && !S.ok) B.status[e] = 4;
+  if (s.main_kind == 0) {
+    // pubkeyHash <== PoseidonLarge(n, k)(pubkey)   (email-verifier.circom:173)
+    __shared__ ZkPosLds PS;
+    zk_poseidon_large(PS, S.p121, B.pos_c, B.pos_m, frv + s.f_pos, frv + s.f_out);
+  }
 }

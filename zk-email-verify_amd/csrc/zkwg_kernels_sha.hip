@@ -40,11 +40,19 @@ __global__ __launch_bounds__(64) void zk_sha_chain(ZkSched s, ZkBufs B) {
   small[f.m_ibi] = ibi;
   small[f.m_idx] = (u32)(int)idx;  // ibi < 2^26, so idx fits an i32
   bits[f.b_lenbits] = (u64)n2b_in;
-  if (!ok) B.status[e] = 4;
-  if (fi == 0) {
-    small[s.m_one] = 1;
-    small[s.m_hdr_len] = len;
+  if (fi == 0) small[s.m_one] = 1;
+  if (f.m_len != ~0u) small[f.m_len] = len;
+  if (f.azp) {
+    // Num2Bits(log2Ceil(max))(length) (email-verifier.circom:58-59,116-117) and
+    // AssertZeroPadding(max)(data, length) (utils/array.circom:149-164)
+    small[f.m_len_m1] = (u32)((int)len - 1);
+    bits[f.b_len] = len;
+    u32 bl = 0;
+    for (u32 n = f.max_bytes - 1; n > 0; n >>= 1) ++bl;
+    ok = ok && len < (1u << bl);
+    for (u32 i = len; i < f.max_bytes; ++i) ok = ok && rec[f.in_data + i] == 0;
   }
+  if (!ok) B.status[e] = 4;
 
   u32 st[8];
   if (f.partial) {
@@ -67,6 +75,12 @@ __global__ __launch_bounds__(64) void zk_sha_chain(ZkSched s, ZkBufs B) {
       for (int j = 0; j < 4; ++j)
         bits[f.b_digest + j] = (u64)__builtin_bitreverse32(st[2 * j]) |
                                ((u64)__builtin_bitreverse32(st[2 * j + 1]) << 32);
+      if (fi == 0 && s.main_kind == 0) {
+        // shaHi / shaLo = PackBits(256,128)(sha) (email-verifier.circom:68-71): big-endian halves
+        Fr* frv = B.frv + (u64)e * s.img_fr;
+        frv[s.f_out + 1] = Fr{{((u64)st[2] << 32) | st[3], ((u64)st[0] << 32) | st[1], 0, 0}};
+        frv[s.f_out + 2] = Fr{{((u64)st[6] << 32) | st[7], ((u64)st[4] << 32) | st[5], 0, 0}};
+      }
     }
   }
 }

@@ -139,6 +139,7 @@ static inline void zk_walk_sha_frame(ZkWalker& w, const std::string& p, const Zk
 static inline void zk_walk_main_sha(ZkWalker& w, ZkSched& s) {
   s.m_one = w.alloc_small(1);
   s.m_hdr_len = w.alloc_small(1);
+  s.fr[0].m_len = s.m_hdr_len;
   zk_alloc_sha_frame(w, s.fr[0]);
   w.seg(ZSEG_SMALL, 1, s.m_one);
   w.one("one");
@@ -238,4 +239,118 @@ static inline void zk_walk_main_rsa(ZkWalker& w, ZkSched& s) {
   w.arr("main.signature", 17);
   zk_walk_rsa(w, "main", s.rsa);
   s.n_public = 17;
+}
+
+// ------------------------------------------------------------------ EmailVerifier main
+// (packages/circuits/email-verifier.circom:42-174, flags (ignoreBodyHashCheck, 0, 0, 0),
+//  `component main { public [ pubkey ] }`, tests/test-circuits/email-verifier-test.circom:5)
+static inline void zk_frame_len_alloc(ZkWalker& w, ZkShaFrame& f) {
+  f.m_len = w.alloc_small(1);
+  f.m_len_m1 = w.alloc_small(1);
+  f.b_len = w.alloc_bits(1);
+  f.azp = 1;
+}
+static inline void zk_walk_azp(ZkWalker& w, const std::string& p, const ZkShaFrame& f) {
+  const u32 bl = zk_log2ceil(f.max_bytes);
+  w.seg(ZSEG_LTBITS, (u64)f.max_bytes * (bl + 1), f.m_len_m1, bl);
+  if (!w.names) w.skip((u64)f.max_bytes * (bl + 1));
+  else for (u32 i = 0; i < f.max_bytes; ++i) w.arr(zk_idx(p + ".lessThans", i) + ".n2b.out", bl + 1);
+}
+static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
+  const u32 N = s.fr[0].max_bytes;
+  const u32 M = s.body ? s.fr[1].max_bytes : 0;
+  // image allocations
+  s.m_one = w.alloc_small(1);
+  s.f_out = w.alloc_fr(3);
+  zk_frame_len_alloc(w, s.fr[0]);
+  s.m_hdr_len = s.fr[0].m_len;
+  zk_alloc_sha_frame(w, s.fr[0]);
+  s.rsa.msg_from_digest = 1;
+  s.rsa.in_mod = s.in_off[3]; s.rsa.in_sig = s.in_off[4]; s.rsa.in_msg = 0;
+  s.rsa.m_digest = s.fr[0].m_digest;
+  zk_alloc_rsa(w, s.rsa);
+  if (s.body) {
+    zk_frame_len_alloc(w, s.fr[1]);
+    zk_alloc_sha_frame(w, s.fr[1]);
+    s.m_bh_idx = w.alloc_small(1);
+    s.m_rev = w.alloc_small(N);
+    s.m_chars = w.alloc_small(44);
+    s.b_shift = w.alloc_bits(1);
+    s.sel_bits = zk_log2ceil((u64)N + 44 - 1);
+  }
+  s.f_pos = w.alloc_fr(420);
+
+  // main I/O: [1], outputs, public inputs, private inputs
+  w.seg(ZSEG_SMALL, 1, s.m_one); w.one("one");
+  w.seg(ZSEG_FR, 3, s.f_out);
+  w.one("main.pubkeyHash"); w.one("main.shaHi"); w.one("main.shaLo");
+  w.seg(ZSEG_LIMB, 17, s.rsa.in_mod); w.arr("main.pubkey", 17);
+  w.seg(ZSEG_IN8, N, s.fr[0].in_data); w.arr("main.emailHeader", N);
+  w.seg(ZSEG_SMALL, 1, s.fr[0].m_len); w.one("main.emailHeaderLength");
+  w.seg(ZSEG_LIMB, 17, s.rsa.in_sig); w.arr("main.signature", 17);
+  if (s.body) {
+    w.seg(ZSEG_SMALL, 1, s.m_bh_idx); w.one("main.bodyHashIndex");
+    w.seg(ZSEG_IN8, 32, s.fr[1].in_pre); w.arr("main.precomputedSHA", 32);
+    w.seg(ZSEG_IN8, M, s.fr[1].in_data); w.arr("main.emailBody", M);
+    w.seg(ZSEG_SMALL, 1, s.fr[1].m_len); w.one("main.emailBodyLength");
+  }
+  // sub-components in creation order
+  const u32 blh = zk_log2ceil(N);
+  w.seg(ZSEG_BITS, blh, s.fr[0].b_len, blh, 1);
+  w.arr("main.n2bHeaderLength.out", blh);
+  zk_walk_azp(w, "main.anon_AssertZeroPadding_header", s.fr[0]);
+  zk_walk_sha_frame(w, "main.anon_Sha256Bytes", s.fr[0]);
+  zk_walk_rsa(w, "main.rsaVerifier", s.rsa);
+  if (s.body) {
+    const u32 blb = zk_log2ceil(M);
+    w.seg(ZSEG_BITS, blb, s.fr[1].b_len, blb, 1);
+    w.arr("main.n2bBodyLength.out", blb);
+    zk_walk_azp(w, "main.anon_AssertZeroPadding_body", s.fr[1]);
+    // BodyHashRegex [EXT]: interface level only (reveal0), see DESIGN.md
+    w.seg(ZSEG_SMALL, N, s.m_rev);
+    w.arr("main.anon_BodyHashRegex.reveal0", N);
+    // SelectRegexReveal(N, 44) (utils/regex.circom:17-52)
+    const std::string sr = "main.anon_SelectRegexReveal";
+    const u32 bl = s.sel_bits, per = 6 + bl + 1;
+    w.seg(ZSEG_REGSEL, (u64)(per - 2) + (u64)(N - 1) * per, s.m_bh_idx, bl, s.m_rev, N);
+    if (!w.names) w.skip((u64)(per - 2) + (u64)(N - 1) * per);
+    else for (u32 i = 0; i < N; ++i) {
+      w.one(zk_idx(sr + ".anon_IsEqual", i) + ".isz.out"); w.one(zk_idx(sr + ".anon_IsEqual", i) + ".isz.inv");
+      w.one(zk_idx(sr + ".anon_IsZero", i) + ".out"); w.one(zk_idx(sr + ".anon_IsZero", i) + ".inv");
+      if (i) { w.one(zk_idx(sr + ".anon_IsPrevZero", i) + ".out"); w.one(zk_idx(sr + ".anon_IsPrevZero", i) + ".inv"); }
+      w.arr(zk_idx(sr + ".anon_GreaterThan", i) + ".lt.n2b.out", bl + 1);
+    }
+    w.seg(ZSEG_VSHIFT, (u64)blh * N, s.m_bh_idx, N, s.m_rev);
+    w.arr(sr + ".anon_VarShiftLeft.tmp", blh * N);
+    w.seg(ZSEG_BITS, blh, s.b_shift, blh, 1);
+    w.arr(sr + ".anon_VarShiftLeft.n2b.out", blh);
+    // Base64Decode(32) (lib/base64.circom:14-64)
+    const std::string b64 = "main.anon_Base64Decode";
+    w.seg(ZSEG_B64BITS, 44 * 6, s.m_chars);
+    for (u32 g = 0; g < 11; ++g) for (u32 j = 0; j < 4; ++j)
+      w.arr(b64 + ".bitsIn[" + std::to_string(g) + "][" + std::to_string(j) + "].out", 6);
+    w.seg(ZSEG_B64, 44 * 68, s.m_chars);
+    for (u32 g = 0; g < 11; ++g) for (u32 j = 0; j < 4; ++j) {
+      std::string t = b64 + ".translate[" + std::to_string(g) + "][" + std::to_string(j) + "]";
+      const char* mids[8] = {"range_AZ", "sum_AZ", "range_az", "sum_az", "range_09", "sum_09", "sum_plus", "sum_slash"};
+      for (auto m : mids) w.one(t + "." + m);
+      const char* cmps[6] = {"le_Z", "ge_A.lt", "le_z", "ge_a.lt", "le_9", "ge_0.lt"};
+      for (auto m : cmps) w.arr(t + "." + m + ".n2b.out", 9);
+      const char* eqs[3] = {"equal_plus", "equal_slash", "equal_eqsign"};
+      for (auto m : eqs) { w.one(t + "." + m + ".out"); w.one(t + "." + m + ".inv"); }
+    }
+    zk_walk_sha_frame(w, "main.anon_Sha256BytesPartial", s.fr[1]);
+  }
+  // PoseidonLarge(121,17) -> Poseidon(9): 8x10 + 60 S-boxes x (out, in2, in4)
+  w.seg(ZSEG_FR, 420, s.f_pos);
+  const std::string pp = "main.anon_PoseidonLarge.anon_Poseidon.pEx";
+  for (u32 r = 0; r < 8; ++r) for (u32 j = 0; j < 10; ++j) {
+    std::string t = pp + ".sigmaF[" + std::to_string(r) + "][" + std::to_string(j) + "]";
+    w.one(t + ".out"); w.one(t + ".in2"); w.one(t + ".in4");
+  }
+  for (u32 r = 0; r < 60; ++r) {
+    std::string t = zk_idx(pp + ".sigmaP", r);
+    w.one(t + ".out"); w.one(t + ".in2"); w.one(t + ".in4");
+  }
+  s.n_public = 3 + 17;
 }

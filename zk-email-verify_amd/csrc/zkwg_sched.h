@@ -42,7 +42,11 @@ enum ZkSegType : u32 {
   ZSEG_IN8BITS = 9, // Num2Bits(8) of input bytes: bit (r&7) of in[src + r/8]
   ZSEG_LIMB = 10,   // slot r = 16-byte LE limb in[src + 16 r]
   ZSEG_LTBITS = 11, // LessThan(a) arrays: v = (i32)small[src] + 2^a - i, i = r/(a+1), bit r%(a+1)
-  ZSEG_NTYPES = 12
+  ZSEG_REGSEL = 12, // SelectRegexReveal(c, 44) per-index comparators: start=(i32)small[src], a=bitLength, reveal bytes small[b..b+c)
+  ZSEG_VSHIFT = 13, // VarShiftLeft(a, .).tmp[j][i] = small[b + (i + (shift & (2^(j+1)-1))) % a], shift=small[src]
+  ZSEG_B64BITS = 14,// Base64Decode bitsIn: 6 bits of the decoded value of char small[src + r/6]
+  ZSEG_B64 = 15,    // Base64Lookup(char small[src + r/68]): 8 mids, 6 x 9 comparator bits, 3 IsZero pairs
+  ZSEG_NTYPES = 16
 };
 
 struct ZkSeg {
@@ -72,6 +76,11 @@ struct ZkShaFrame {      // one Sha256Bytes / Sha256BytesPartial instance
   u32 m_ibi;             // small: inBlockIndex
   u32 m_idx;             // small: (i32) inBlockIndex - 1
   u32 m_digest;          // small: 8 words, state after block idx (the selected hash)
+  // EmailVerifier-level values owned by the frame's chain thread (0xffffffff = absent)
+  u32 m_len;             // small: the length input
+  u32 m_len_m1;          // small: (i32) length - 1   (AssertZeroPadding LessThan inputs)
+  u32 b_len;             // bits: 1 word, the length (Num2Bits(log2Ceil(max)))
+  u32 azp;               // 1: check length range + zero padding (email-verifier.circom:58-63,116-121)
 };
 
 // image offsets of one BigLessThan instance (lib/bigint.circom:16-60)
@@ -124,6 +133,15 @@ struct ZkSched {
   u32 m_one;             // small: constant 1
   u32 m_hdr_len;         // small: emailHeaderLength / paddedInLength
   ZkRsaLayout rsa;
+  // EmailVerifier main (email-verifier.circom:42-174)
+  u32 f_out;             // fr: pubkeyHash, shaHi, shaLo
+  u32 f_pos;             // fr: 420 Poseidon S-box signals
+  u32 body;              // 1: body-hash path present (ignoreBodyHashCheck != 1)
+  u32 m_bh_idx;          // small: bodyHashIndex (also SelectRegexReveal.startIndex / VarShiftLeft.shift)
+  u32 m_rev;             // small: bhReveal[max_header]
+  u32 m_chars;           // small: bhBase64[44]
+  u32 b_shift;           // bits: 1 word, bodyHashIndex (VarShiftLeft.n2b)
+  u32 sel_bits;          // log2Ceil(max_header + 43)
 };
 
 #if defined(__HIPCC__)
@@ -135,6 +153,8 @@ struct ZkBufs {
   u32* small;            // image: small integers  [n_emails][img_small]
   Fr* frv;               // image: field elements  [n_emails][img_fr]
   const Fr* invtab;      // d^-1 for d in [-inv_half, inv_half]
+  const Fr* pos_c;       // Poseidon(9) round constants (Montgomery form), 680
+  const Fr* pos_m;       // Poseidon(9) MDS matrix (Montgomery form), 10 x 10 row-major
   const ZkSeg* segs;     // segment table
   const u32* first_seg;  // first segment overlapping each portion
   uint4* wit;            // output witnesses
