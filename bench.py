@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- EmailVerifier witnesses/s on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic emails that is already
+resident in HBM: `EmailVerifier(1024,1536,121,17,0,0,0,0)`, 1 KB bodies, batch 4096 per GPU
+(BASELINE.json configs[2]), processed in tiles whose witnesses stay in HBM (a 2-tile ring that
+is overwritten; the host-delivered, PCIe-bound rate is discussed in DESIGN.md).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel zk_expand (HBM-write
+bound): achieved = (32 W + I) bytes x emails per launch / average launch duration measured
+with HIP events on the launch stream inside the timed region.  `cpu_baseline` is the C
+oracle ("port", oracle/c) timed on this box's host cores on a bounded sample (rank 0, N=1).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "zk-email-verify_amd", "py"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="emails per GPU per step")
+    ap.add_argument("--tile", type=int, default=512, help="emails per launch (HBM-resident tile)")
+    ap.add_argument("--distinct", type=int, default=512, help="distinct synthetic emails generated per rank")
+    ap.add_argument("--max-header", type=int, default=1024)
+    ap.add_argument("--max-body", type=int, default=1536)
+    ap.add_argument("--body-len", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=512, help="emails timed for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import zkwg
+    from zkwg import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank)
+    tile = min(args.tile, args.batch)
+    assert args.batch % tile == 0
+    ntiles = args.batch // tile
+    distinct = min(args.distinct, args.batch)
+    assert tile % distinct == 0 or distinct % tile == 0
+
+    # synthetic inputs: `distinct` different signed emails per rank (seeded by rank), replicated to
+    # fill the batch; resident in HBM before timing starts.
+    recs, fields = synth.packed_batch(c, seed=0x5A4B + rank, n=distinct, body_len=args.body_len)
+    h_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).view(distinct, c.in_stride)
+    reps = (args.batch + distinct - 1) // distinct
+    d_in = h_in.repeat(reps, 1)[:args.batch].contiguous().to(dev)
+    d_out = [torch.empty(tile * c.witness_bytes, dtype=torch.uint8, device=dev) for _ in range(min(2, ntiles))]
+    d_status = torch.zeros(args.batch, dtype=torch.int32, device=dev)
+    d_scr = torch.empty(c.scratch_bytes(tile), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        for t in range(ntiles):
+            c.calculate_batch_device(d_in[t * tile:(t + 1) * tile], tile, d_out[t % len(d_out)],
+                                     d_status[t * tile:(t + 1) * tile], d_scr, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    assert int(d_status.abs().sum().item()) == 0, "synthetic emails must all verify"
+    c.set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    summ = c.timing_summary()
+
+    if rank == 0:
+        total_emails = args.batch * world * args.steps
+        value = total_emails / dt
+        ex_ms, ex_launches, _ = summ["zk_expand"]
+        bytes_per_email = 32 * c.W + c.in_stride
+        achieved = bytes_per_email * tile / (ex_ms / ex_launches * 1e-3) / 1e9
+        kernels_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in summ.items()}
+        res = {
+            "metric": "EmailVerifier witnesses/sec", "value": round(value, 1), "unit": "witnesses/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 (BN254 Fr, 4x64-bit limbs) / u32 bit-vectors", "data": "synthetic",
+            "config": {"workload": f"EmailVerifier({args.max_header},{args.max_body},121,17,0,0,0,0) batch={args.batch}/GPU, "
+                                   f"{args.body_len} B bodies, witnesses device-resident",
+                       "batch_per_gpu": args.batch, "tile": tile, "witness_len": c.W,
+                       "witness_bytes": c.witness_bytes, "layout": "kept-v1", "parallelism": f"shard x{world} (no collective)"},
+            "roofline": {"bound": "hbm", "kernel": "zk_expand", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch": bytes_per_email * tile, "avg_launch_ms": round(ex_ms / ex_launches, 4),
+                         "launches_timed": ex_launches},
+            "kernel_ms_per_launch": kernels_ms,
+            "fr_field_ops_per_s": round(value * c.W, 1),
+        }
+        if args.cpu_sample > 0 and world == 1:
+            from oracle import coracle
+            n = min(args.cpu_sample, distinct)
+            sub = {k: (v[:n] if isinstance(v, list) else v[:n * (len(v) // distinct)]) for k, v in fields.items()}
+            cores = os.cpu_count() or 1
+            # every witness fully written to (per-thread) host memory, like the GPU path writes HBM
+            buf = (ctypes.c_uint8 * (cores * 32 * c.W))()
+            W, st, sec = coracle.run_fields(args.max_header, args.max_body, 0, sub, n, threads=cores, out=buf,
+                                            per_thread_out=True)
+            assert W == c.W and st == [0] * n
+            res["cpu_baseline"] = {"value": round(n / sec, 2), "unit": "witnesses/s", "cores": cores, "kind": "port",
+                                   "sample": f"{n} of the same synthetic emails, C oracle (oracle/c), OpenMP over emails, witness written to host memory"}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,9 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_packed_inputs, 
  * `which` (see zkwg_kernel_name); negative rc if timing was not enabled. */
 int zkwg_set_timing(zkwg_circuit_t* c, int enable);
 int zkwg_last_kernel_ms(zkwg_circuit_t* c, int which, float* ms);
+/* Sum of kernel `which`'s durations over the launches recorded since zkwg_set_timing(c, 1)
+ * (at most the last 64 launches), and how many launches that sum covers. */
+int zkwg_timing_summary(zkwg_circuit_t* c, int which, float* total_ms, uint32_t* launches);
 int zkwg_num_kernels(const zkwg_circuit_t* c);
 const char* zkwg_kernel_name(const zkwg_circuit_t* c, int which);
 /* Witness slots (field elements) written per email by kernel `which`. */

@@ -1,0 +1,634 @@
+/*
+ * zkwg_oracle.c -- scalar C restatement of the EmailVerifier witness calculation.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): the fast tier of the oracle and the
+ * `cpu_baseline` ("port") of bench.py.  It walks the reference's template tree exactly like
+ * the literal Python oracle (oracle/pyref) and emits the *kept* signals in circom O0 order
+ * (DESIGN.md "layout kept-v1") as 32-byte little-endian field elements.  It is pinned against
+ * oracle/pyref (which carries the reference's known answers) by tests/test_oracle_c.py.
+ *
+ * Reference sources restated (paths under /root/reference/packages/circuits):
+ *   email-verifier.circom:42-174, lib/sha.circom:17-292, lib/rsa.circom:13-181,
+ *   lib/fp.circom:16-81, lib/bigint.circom:16-94, lib/bigint-func.circom (long_div as exact
+ *   integer floor division), lib/base64.circom:14-128, utils/array.circom:16-164,
+ *   utils/regex.circom:17-52, utils/hash.circom:15-39; [EXT] circomlib bitify / comparators /
+ *   sha256 / poseidon restated as in oracle/pyref/circomlib.py and poseidon.py.
+ *
+ * Arithmetic style is deliberately different from the product's kernels: every value is
+ * computed as a field element (carries by field division by 2^121, bits by Num2Bits of the
+ * field element), single email at a time, no packed images.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <omp.h>
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------ field Fr (BN254 scalar) */
+typedef struct { u64 l[4]; } fe;
+static const fe FE_P = {{0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+static const fe FE_R2 = {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}};
+#define FE_N0 0xc2e1f593efffffffULL
+
+static int fe_geq(const fe* a, const fe* b) {
+  for (int i = 3; i >= 0; --i) { if (a->l[i] > b->l[i]) return 1; if (a->l[i] < b->l[i]) return 0; }
+  return 1;
+}
+static int fe_is_zero(const fe* a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static fe fe_u64(u64 x) { fe r = {{x, 0, 0, 0}}; return r; }
+static fe fe_add(fe a, fe b) {
+  fe r; u128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (u64)c; c >>= 64; }
+  if (c || fe_geq(&r, &FE_P)) { u128 bw = 0; for (int i = 0; i < 4; ++i) { u128 d = (u128)r.l[i] - FE_P.l[i] - bw; r.l[i] = (u64)d; bw = (d >> 64) & 1; } }
+  return r;
+}
+static fe fe_sub(fe a, fe b) {
+  fe r; u128 bw = 0;
+  for (int i = 0; i < 4; ++i) { u128 d = (u128)a.l[i] - b.l[i] - bw; r.l[i] = (u64)d; bw = (d >> 64) & 1; }
+  if (bw) { u128 c = 0; for (int i = 0; i < 4; ++i) { c += (u128)r.l[i] + FE_P.l[i]; r.l[i] = (u64)c; c >>= 64; } }
+  return r;
+}
+static fe fe_neg(fe a) { return fe_sub(fe_u64(0), a); }
+static fe fe_montmul(fe a, fe b) {
+  u64 t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (u64)c; c >>= 64; }
+    c += t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
+    u64 m = t[0] * FE_N0;
+    c = (u128)m * FE_P.l[0] + t[0]; c >>= 64;
+    for (int j = 1; j < 4; ++j) { c += (u128)m * FE_P.l[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
+    c += t[4]; t[3] = (u64)c; t[4] = t[5] + (u64)(c >> 64);
+  }
+  fe r = {{t[0], t[1], t[2], t[3]}};
+  if (t[4] || fe_geq(&r, &FE_P)) { u128 bw = 0; for (int i = 0; i < 4; ++i) { u128 d = (u128)r.l[i] - FE_P.l[i] - bw; r.l[i] = (u64)d; bw = (d >> 64) & 1; } }
+  return r;
+}
+static fe fe_mul(fe a, fe b) { return fe_montmul(fe_montmul(a, b), FE_R2); }
+/* a^{-1}: binary extended Euclid on standard-form values; 0 -> 0 */
+static void fe_shr1(fe* x, u64 top) {
+  x->l[0] = (x->l[0] >> 1) | (x->l[1] << 63); x->l[1] = (x->l[1] >> 1) | (x->l[2] << 63);
+  x->l[2] = (x->l[2] >> 1) | (x->l[3] << 63); x->l[3] = (x->l[3] >> 1) | (top << 63);
+}
+static void fe_half(fe* x) {
+  u64 top = 0;
+  if (x->l[0] & 1) { u128 c = 0; for (int i = 0; i < 4; ++i) { c += (u128)x->l[i] + FE_P.l[i]; x->l[i] = (u64)c; c >>= 64; } top = (u64)c; }
+  fe_shr1(x, top);
+}
+static fe fe_inv(fe a) {
+  if (fe_is_zero(&a)) return a;
+  fe u = a, v = FE_P, x1 = fe_u64(1), x2 = fe_u64(0), one = fe_u64(1);
+  while (memcmp(&u, &one, sizeof(fe)) && memcmp(&v, &one, sizeof(fe))) {
+    while (!(u.l[0] & 1)) { fe_shr1(&u, 0); fe_half(&x1); }
+    while (!(v.l[0] & 1)) { fe_shr1(&v, 0); fe_half(&x2); }
+    if (fe_geq(&u, &v)) { u128 bw = 0; for (int i = 0; i < 4; ++i) { u128 d = (u128)u.l[i] - v.l[i] - bw; u.l[i] = (u64)d; bw = (d >> 64) & 1; } x1 = fe_sub(x1, x2); }
+    else { u128 bw = 0; for (int i = 0; i < 4; ++i) { u128 d = (u128)v.l[i] - u.l[i] - bw; v.l[i] = (u64)d; bw = (d >> 64) & 1; } x2 = fe_sub(x2, x1); }
+  }
+  return memcmp(&u, &one, sizeof(fe)) ? x2 : x1;
+}
+static fe fe_from_i64(long long v) { return v >= 0 ? fe_u64((u64)v) : fe_neg(fe_u64((u64)(-v))); }
+static fe fe_from_limb(const u64* l2) { fe r = {{l2[0], l2[1], 0, 0}}; return r; }
+static fe fe_pow2(unsigned k) { fe r = {{0, 0, 0, 0}}; r.l[k >> 6] = 1ULL << (k & 63); return r; }
+
+/* ------------------------------------------------------------------ witness output */
+typedef struct { u8* out; u64 n; u64 cap; int failed; } W;
+static void emit_fe(W* w, fe v) { if (w->n < w->cap) memcpy(w->out + 32 * w->n, v.l, 32); w->n++; }
+static void emit_u(W* w, u64 v) { emit_fe(w, fe_u64(v)); }
+static void fail(W* w) { w->failed = 1; }
+/* Num2Bits(n)(x): emits n bits, asserts sum === in */
+static void num2bits(W* w, fe x, unsigned n) {
+  for (unsigned i = 0; i < n; ++i) emit_u(w, (x.l[i >> 6] >> (i & 63)) & 1);
+  for (unsigned i = n; i < 256; ++i) if ((x.l[i >> 6] >> (i & 63)) & 1) { fail(w); break; }
+}
+/* IsZero(x): emits out, inv; returns out */
+static unsigned iszero(W* w, fe x) { unsigned o = fe_is_zero(&x); emit_u(w, o); emit_fe(w, fe_inv(x)); return o; }
+/* LessThan(n)(a, b): emits Num2Bits(n+1)(a + 2^n - b); returns out */
+static unsigned lessthan(W* w, unsigned n, fe a, fe b) {
+  fe v = fe_sub(fe_add(a, fe_pow2(n)), b);
+  num2bits(w, v, n + 1);
+  return 1 - (unsigned)((v.l[n >> 6] >> (n & 63)) & 1);
+}
+static unsigned log2ceil(u64 a) { u64 n = a - 1; unsigned r = 0; while (n) { ++r; n >>= 1; } return r; }
+
+/* ------------------------------------------------------------------ SHA-256 (circomlib sha256/) */
+static const u32 K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static const u32 IV256[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+static u32 rotr(u32 x, int r) { return (x >> r) | (x << (32 - r)); }
+static void bits32(W* w, u32 v) { for (int k = 0; k < 32; ++k) emit_u(w, (v >> k) & 1); }
+static void bitsn(W* w, u64 v, int n) { for (int k = 0; k < n; ++k) emit_u(w, (v >> k) & 1); }
+/* Xor3(a,b,c): out then mid */
+static u32 xor3(W* w, u32 a, u32 b, u32 c) { u32 o = a ^ b ^ c; bits32(w, o); bits32(w, b & c); return o; }
+/* one Sha256compression: st (8 words) updated; emits the kept signals */
+static void sha_compression(W* w, u32* st, const u8* blk) {
+  u32 wv[64];
+  for (int t = 0; t < 16; ++t) wv[t] = ((u32)blk[4 * t] << 24) | ((u32)blk[4 * t + 1] << 16) | ((u32)blk[4 * t + 2] << 8) | blk[4 * t + 3];
+  for (int t = 16; t < 64; ++t) { /* sigmaPlus[t-16]: sigma1(in2), sigma0(in15), BinSum(32,4) */
+    u32 x2 = wv[t - 2], x15 = wv[t - 15];
+    u32 s1 = xor3(w, rotr(x2, 17), rotr(x2, 19), x2 >> 10);
+    u32 s0 = xor3(w, rotr(x15, 7), rotr(x15, 18), x15 >> 3);
+    u64 sum = (u64)s1 + wv[t - 7] + s0 + wv[t - 16];
+    bitsn(w, sum, 34);
+    wv[t] = (u32)sum;
+  }
+  /* t1[64], t2[64], suma[64], sume[64] are separate component arrays: record then emit in order */
+  u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+  static __thread u32 r_e[64], r_f[64], r_g[64], r_a[64], r_b[64], r_c[64];
+  static __thread u64 r_t1[64], r_t2[64], r_suma[64], r_sume[64];
+  for (int t = 0; t < 64; ++t) {
+    r_e[t] = e; r_f[t] = f; r_g[t] = g; r_a[t] = a; r_b[t] = b; r_c[t] = c;
+    u32 bs1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g);
+    u64 t1 = (u64)h + bs1 + ch + K256[t] + wv[t];
+    u32 bs0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), maj = (a & b) ^ (a & c) ^ (b & c);
+    u64 t2 = (u64)bs0 + maj;
+    u64 sume = (u64)d + (u32)t1, suma = (u64)(u32)t1 + (u32)t2;
+    r_t1[t] = t1; r_t2[t] = t2; r_suma[t] = suma; r_sume[t] = sume;
+    h = g; g = f; f = e; e = (u32)sume; d = c; c = b; b = a; a = (u32)suma;
+  }
+  for (int t = 0; t < 64; ++t) { /* T1: ch.out, bigsigma1.xor3 (out, mid), sum.out[35] */
+    u32 e_ = r_e[t];
+    bits32(w, (e_ & r_f[t]) ^ (~e_ & r_g[t]));
+    xor3(w, rotr(e_, 6), rotr(e_, 11), rotr(e_, 25));
+    bitsn(w, r_t1[t], 35);
+  }
+  for (int t = 0; t < 64; ++t) { /* T2: bigsigma0.xor3, maj (out, mid), sum.out[33] */
+    u32 a_ = r_a[t];
+    xor3(w, rotr(a_, 2), rotr(a_, 13), rotr(a_, 22));
+    u32 mid = r_b[t] & r_c[t];
+    bits32(w, (a_ & (r_b[t] ^ r_c[t])) | mid);
+    bits32(w, mid);
+    bitsn(w, r_t2[t], 33);
+  }
+  for (int t = 0; t < 64; ++t) bitsn(w, r_suma[t], 33);
+  for (int t = 0; t < 64; ++t) bitsn(w, r_sume[t], 33);
+  u32 fin[8] = {a, b, c, d, e, f, g, h};
+  for (int j = 0; j < 8; ++j) { u64 s = (u64)st[j] + fin[j]; bitsn(w, s, 33); st[j] = (u32)s; }
+}
+
+/* inverse table of small integers, d in [-INVT, INVT] */
+#define INVT 70000
+static fe* g_invtab = NULL;
+static void init_invtab(void) {
+  if (g_invtab) return;
+  fe* t = (fe*)calloc(2 * INVT + 1, sizeof(fe));
+  /* batch inversion (Montgomery's trick) of 1..INVT */
+  fe* pre = (fe*)malloc((INVT + 1) * sizeof(fe));
+  fe acc = fe_u64(1);
+  for (long long i = 1; i <= INVT; ++i) { pre[i] = acc; acc = fe_mul(acc, fe_u64((u64)i)); }
+  fe inv = fe_inv(acc);
+  for (long long i = INVT; i >= 1; --i) { fe v = fe_mul(inv, pre[i]); inv = fe_mul(inv, fe_u64((u64)i)); t[INVT + i] = v; t[INVT - i] = fe_neg(v); }
+  free(pre);
+  g_invtab = t;
+}
+static fe small_inv(long long d) {
+  if (d >= -INVT && d <= INVT) return g_invtab[INVT + d];
+  return fe_inv(fe_from_i64(d));
+}
+/* IsZero of a small signed integer (table inverse) */
+static unsigned iszero_small(W* w, long long d) { emit_u(w, d == 0); emit_fe(w, small_inv(d)); return d == 0; }
+
+/* Sha256General / Sha256Partial core + Sha256Bytes[Partial] wrapper.  Returns digest words. */
+static void sha_frame(W* w, const u8* data, u32 max_bytes, u32 len, const u8* pre /* NULL = IV */, u32* digest) {
+  const u32 NB = max_bytes / 64;
+  const unsigned nb = log2ceil((u64)max_bytes * 8);
+  const u64 lenbits = (u64)len * 8;
+  const u64 ibi = lenbits >> 9;                       /* inBlockIndex <-- paddedInLength >> 9 */
+  emit_u(w, ibi);
+  if (lenbits != ibi * 512) fail(w);
+  /* LessEqThan(nb)(paddedInLength, maxBits) */
+  if (lessthan(w, nb, fe_u64(lenbits), fe_u64((u64)max_bytes * 8 + 1)) != 1) fail(w);
+  u32 st[8];
+  if (pre) for (int j = 0; j < 8; ++j) st[j] = ((u32)pre[4 * j] << 24) | ((u32)pre[4 * j + 1] << 16) | ((u32)pre[4 * j + 2] << 8) | pre[4 * j + 3];
+  else memcpy(st, IV256, sizeof(st));
+  u32* outs = (u32*)malloc((size_t)NB * 8 * sizeof(u32));
+  for (u32 b = 0; b < NB; ++b) { sha_compression(w, st, data + 64 * b); memcpy(outs + 8 * b, st, 32); }
+  /* arraySelectors[256] = ItemAtIndex(NB)(compression outs bit k, inBlockIndex - 1) */
+  const long long idx = (long long)ibi - 1;
+  if (idx < 0 || idx >= (long long)NB) fail(w);       /* calcTotalIndex.sum === 1 */
+  for (u32 k = 0; k < 256; ++k) {
+    for (u32 j = 0; j < NB; ++j) { /* calcTotalValue.nums[j] = eqs[j].out * in[j] */
+      u32 bit = (outs[8 * j + (k >> 5)] >> (31 - (k & 31))) & 1;
+      emit_u(w, ((long long)j == idx) ? bit : 0);
+    }
+    for (u32 j = 0; j < NB; ++j) iszero_small(w, idx - (long long)j);  /* eqs[j].isz: in = index - j */
+  }
+  const u32 sel = (u32)(idx < 0 ? 0 : (idx >= (long long)NB ? NB - 1 : idx));
+  memcpy(digest, outs + 8 * sel, 32);
+  free(outs);
+  for (u32 i = 0; i < max_bytes; ++i) bitsn(w, data[i], 8);       /* bytes[i] = Num2Bits(8) */
+  if (pre) for (u32 i = 0; i < 32; ++i) bitsn(w, pre[i], 8);       /* states[i] */
+}
+
+/* ------------------------------------------------------------------ big integers (64-bit limbs) */
+#define BN 36
+typedef struct { u64 d[2 * BN]; } bn; /* up to 72 limbs */
+static void bn_zero(bn* a) { memset(a, 0, sizeof(*a)); }
+static int bn_top(const bn* a, int n) { while (n > 0 && a->d[n - 1] == 0) --n; return n; }
+static void bn_mul(bn* out, const bn* a, const bn* b, int n) { /* out = a*b over n limbs each -> 2n */
+  bn_zero(out);
+  for (int i = 0; i < n; ++i) { u128 c = 0; for (int j = 0; j < n; ++j) { c += (u128)a->d[i] * b->d[j] + out->d[i + j]; out->d[i + j] = (u64)c; c >>= 64; } out->d[i + n] = (u64)c; }
+}
+/* q = floor(x / m), r = x mod m; x has nx limbs, m has nm significant limbs (nm >= 1) */
+static void bn_divmod(bn* q, bn* r, const bn* x, int nx, const bn* m, int nm) {
+  bn_zero(q); bn_zero(r);
+  nm = bn_top(m, nm); nx = bn_top(x, nx);
+  if (nm == 0) return;
+  if (nx < nm) { *r = *x; return; }
+  int sh = __builtin_clzll(m->d[nm - 1]);
+  u64 dn[BN + 2], un[2 * BN + 2];
+  for (int i = nm - 1; i > 0; --i) dn[i] = sh ? (m->d[i] << sh) | (m->d[i - 1] >> (64 - sh)) : m->d[i];
+  dn[0] = m->d[0] << sh;
+  un[nx] = sh ? x->d[nx - 1] >> (64 - sh) : 0;
+  for (int i = nx - 1; i > 0; --i) un[i] = sh ? (x->d[i] << sh) | (x->d[i - 1] >> (64 - sh)) : x->d[i];
+  un[0] = x->d[0] << sh;
+  for (int j = nx - nm; j >= 0; --j) {
+    u128 num = ((u128)un[j + nm] << 64) | un[j + nm - 1];
+    u128 qhat = num / dn[nm - 1], rhat = num % dn[nm - 1];
+    while ((qhat >> 64) || (nm > 1 && qhat * dn[nm - 2] > ((rhat << 64) | un[j + nm - 2]))) { --qhat; rhat += dn[nm - 1]; if (rhat >> 64) break; }
+    u128 borrow = 0, carry = 0;
+    for (int i = 0; i < nm; ++i) { u128 p = qhat * dn[i] + carry; carry = p >> 64; u128 s = (u128)un[i + j] - (u64)p - borrow; un[i + j] = (u64)s; borrow = (s >> 64) & 1; }
+    u128 s = (u128)un[j + nm] - carry - borrow; un[j + nm] = (u64)s;
+    if ((s >> 64) & 1) { --qhat; u128 c = 0; for (int i = 0; i < nm; ++i) { c += (u128)un[i + j] + dn[i]; un[i + j] = (u64)c; c >>= 64; } un[j + nm] += (u64)c; }
+    q->d[j] = (u64)qhat;
+  }
+  for (int i = 0; i < nm; ++i) r->d[i] = sh ? (un[i] >> sh) | (un[i + 1] << (64 - sh)) : un[i];
+}
+static void bn_from_limbs121(bn* out, u64 (*l)[2]) { /* sum l[i] * 2^(121 i), limbs < 2^121 */
+  bn_zero(out);
+  for (int i = 0; i < 17; ++i) for (int half = 0; half < 2; ++half) {
+    unsigned pos = 121 * i + 64 * half; u64 v = l[i][half];
+    out->d[pos >> 6] |= v << (pos & 63);
+    if (pos & 63) out->d[(pos >> 6) + 1] |= v >> (64 - (pos & 63));
+  }
+}
+static void bn_to_limbs121(u64 (*l)[2], const bn* a) {
+  for (int i = 0; i < 17; ++i) {
+    unsigned pos = 121 * i; u64 lo, hi;
+    unsigned w = pos >> 6, o = pos & 63;
+    lo = (a->d[w] >> o) | (o ? a->d[w + 1] << (64 - o) : 0);
+    hi = (a->d[w + 1] >> o) | (o ? a->d[w + 2] << (64 - o) : 0);
+    l[i][0] = lo; l[i][1] = hi & ((1ULL << 57) - 1);
+  }
+}
+
+/* ------------------------------------------------------------------ lib/bigint.circom, lib/fp.circom, lib/rsa.circom */
+/* BigLessThan(121,17)(a, b) */
+static unsigned big_less_than(W* w, u64 (*a)[2], u64 (*b)[2]) {
+  unsigned lt[17], eq[17];
+  for (int i = 0; i < 17; ++i) lt[i] = lessthan(w, 121, fe_from_limb(a[i]), fe_from_limb(b[i]));
+  for (int i = 0; i < 17; ++i) eq[i] = iszero(w, fe_sub(fe_from_limb(b[i]), fe_from_limb(a[i])));  /* IsEqual: in[1]-in[0] */
+  unsigned ors[16], ands[16], eqa[16];
+  for (int i = 15; i >= 0; --i) {
+    if (i == 15) { ands[i] = eq[16] & lt[15]; eqa[i] = eq[16] & eq[15]; ors[i] = lt[16] | ands[i]; }
+    else { ands[i] = eqa[i + 1] & lt[i]; eqa[i] = eqa[i + 1] & eq[i]; ors[i] = ors[i + 1] | ands[i]; }
+  }
+  for (int i = 0; i < 16; ++i) emit_u(w, ors[i]);
+  for (int i = 0; i < 16; ++i) emit_u(w, ands[i]);
+  for (int i = 0; i < 16; ++i) emit_u(w, eqa[i]);
+  return ors[0];
+}
+static fe poly_eval(u64 (*l)[2], unsigned x) { /* sum l[i] x^i mod r (bigint-func.circom:56-62) */
+  fe v = fe_u64(0), xp = fe_u64(1), fx = fe_u64(x);
+  for (int i = 0; i < 17; ++i) { v = fe_add(v, fe_mul(fe_from_limb(l[i]), xp)); xp = fe_mul(xp, fx); }
+  return v;
+}
+/* FpMul(121,17): emits everything, writes r limbs to out */
+static void fpmul(W* w, u64 (*a)[2], u64 (*b)[2], u64 (*p)[2], u64 (*out)[2]) {
+  fe v_ab[33], v_pq_r[33];
+  for (unsigned x = 0; x < 33; ++x) v_ab[x] = fe_mul(poly_eval(a, x), poly_eval(b, x));
+  /* long_div(n, k, k, ab_proper, p): exact integer quotient and remainder of a*b by p */
+  bn A, B, Pm, X, Q, R;
+  bn_from_limbs121(&A, a); bn_from_limbs121(&B, b); bn_from_limbs121(&Pm, p);
+  bn_mul(&X, &A, &B, 33);
+  u64 q[17][2], r[17][2];
+  if (bn_top(&Pm, 33) == 0) { memset(q, 0, sizeof(q)); memset(r, 0, sizeof(r)); fail(w); }
+  else { bn_divmod(&Q, &R, &X, 66, &Pm, 33); bn_to_limbs121(q, &Q); bn_to_limbs121(r, &R); if (bn_top(&Q, 66) > 33 || (Q.d[32] >> 9)) fail(w); }
+  for (unsigned x = 0; x < 33; ++x) emit_fe(w, v_ab[x]);
+  for (int i = 0; i < 17; ++i) emit_fe(w, fe_from_limb(q[i]));
+  for (int i = 0; i < 17; ++i) emit_fe(w, fe_from_limb(r[i]));
+  for (unsigned x = 0; x < 33; ++x) { v_pq_r[x] = fe_add(fe_mul(poly_eval(p, x), poly_eval(q, x)), poly_eval(r, x)); emit_fe(w, v_pq_r[x]); }
+  for (int i = 0; i < 17; ++i) num2bits(w, fe_from_limb(q[i]), 121);
+  for (int i = 0; i < 17; ++i) num2bits(w, fe_from_limb(r[i]), 121);
+  if (big_less_than(w, r, p) != 1) fail(w);
+  /* t = interp(v_ab - v_pq_r) = coefficients of A*B - P*Q - R (mod r); CheckCarryToZero(121,249,33) */
+  fe t[33];
+  for (int i = 0; i < 33; ++i) {
+    fe acc = fe_u64(0);
+    for (int j = 0; j < 17; ++j) { int k = i - j; if (k < 0 || k > 16) continue;
+      acc = fe_add(acc, fe_mul(fe_from_limb(a[j]), fe_from_limb(b[k])));
+      acc = fe_sub(acc, fe_mul(fe_from_limb(p[j]), fe_from_limb(q[k]))); }
+    if (i < 17) acc = fe_sub(acc, fe_from_limb(r[i]));
+    t[i] = acc;
+  }
+  static __thread int inv_init = 0; static __thread fe inv2_121;
+  if (!inv_init) { inv2_121 = fe_inv(fe_pow2(121)); inv_init = 1; }
+  fe carry[33];
+  fe prev = fe_u64(0);
+  for (int i = 0; i < 32; ++i) { carry[i] = fe_mul(fe_add(t[i], prev), inv2_121); prev = carry[i]; } /* carry <-- (in + carry) / 2^n */
+  carry[32] = fe_u64(0);
+  for (int i = 0; i < 33; ++i) emit_fe(w, carry[i]);
+  for (int i = 0; i < 32; ++i) num2bits(w, fe_add(carry[i], fe_pow2(130)), 131);
+  fe last = fe_add(t[32], carry[31]);
+  if (!fe_is_zero(&last)) fail(w);
+  memcpy(out, r, sizeof(r));
+}
+/* RSAVerifier65537(121,17) */
+static void rsa_verifier(W* w, u64 (*msg)[2], u64 (*sig)[2], u64 (*mod)[2]) {
+  /* RSAPad */
+  for (int i = 0; i < 17; ++i) num2bits(w, fe_from_limb(mod[i]), 121);
+  for (int i = 0; i < 17; ++i) num2bits(w, fe_from_limb(msg[i]), 121);
+  u8 modbits[2057 + 16], msgbits[2057 + 16], padded[2057 + 16];
+  memset(modbits, 0, sizeof(modbits)); memset(msgbits, 0, sizeof(msgbits)); memset(padded, 0, sizeof(padded));
+  for (int i = 0; i < 17; ++i) for (int j = 0; j < 121; ++j) { modbits[121 * i + j] = (mod[i][j >> 6] >> (j & 63)) & 1; msgbits[121 * i + j] = (msg[i][j >> 6] >> (j & 63)) & 1; }
+  for (int i = 256; i < 2057; ++i) if (msgbits[i]) fail(w);
+  for (int i = 0; i < 256; ++i) padded[i] = msgbits[i];
+  static const u8 DI[19] = {0x20, 0x04, 0x00, 0x05, 0x01, 0x02, 0x04, 0x03, 0x65, 0x01, 0x48, 0x86, 0x60, 0x09, 0x06, 0x0d, 0x30, 0x31, 0x30};
+  for (int i = 256; i < 408; ++i) padded[i] = (DI[(i - 256) >> 3] >> ((i - 256) & 7)) & 1;
+  long long prefix = 0;
+  long long zin[206]; int zhave[206]; memset(zhave, 0, sizeof(zhave));
+  for (int i = 2056; i >= 416; --i) {
+    if (i + 8 < 2057) {
+      prefix += modbits[i + 8];
+      if (i % 8 == 0) { int idx = (i - 416) / 8; zin[idx] = prefix; zhave[idx] = 1; padded[i] = prefix != 0; }
+      else padded[i] = padded[i + 1];
+    } else padded[i] = 0;
+  }
+  for (int idx = 0; idx < 206; ++idx) if (zhave[idx]) iszero_small(w, zin[idx]);
+  for (int i = 416; i < 416 + 65; ++i) if (!padded[i]) fail(w);
+  for (int i = 0; i < 17; ++i) num2bits(w, fe_from_limb(sig[i]), 121);     /* signatureRangeCheck */
+  if (big_less_than(w, sig, mod) != 1) fail(w);
+  /* FpPow65537Mod: doublers[16], adder */
+  u64 cur[17][2], nxt[17][2];
+  memcpy(cur, sig, sizeof(cur));
+  for (int m = 0; m < 16; ++m) { fpmul(w, cur, cur, mod, nxt); memcpy(cur, nxt, sizeof(cur)); }
+  fpmul(w, sig, cur, mod, nxt);
+  for (int i = 0; i < 17; ++i) { /* bigPow.out[i] === padder.out[i] */
+    u64 lo = 0, hi = 0;
+    for (int j = 0; j < 121; ++j) { if (padded[121 * i + j]) { if (j < 64) lo |= 1ULL << j; else hi |= 1ULL << (j - 64); } }
+    if (lo != nxt[i][0] || hi != nxt[i][1]) fail(w);
+  }
+}
+
+/* ------------------------------------------------------------------ Poseidon(9) */
+static fe* g_posC = NULL; static fe* g_posM = NULL; /* standard form */
+static void init_poseidon(void) {
+  if (g_posC) return;
+  const unsigned t = 10, rf = 8, rp = 60;
+  u8 st[80]; int k = 0, head = 0;
+#define PUT(v, wd) for (int i_ = (wd) - 1; i_ >= 0; --i_) st[k++] = ((v) >> i_) & 1
+  PUT(1, 2); PUT(0, 4); PUT(254, 12); PUT(t, 12); PUT(rf, 10); PUT(rp, 10);
+  while (k < 80) st[k++] = 1;
+#define STEP(nb) do { nb = st[(head + 62) % 80] ^ st[(head + 51) % 80] ^ st[(head + 38) % 80] ^ st[(head + 23) % 80] ^ st[(head + 13) % 80] ^ st[head]; st[head] = nb; head = (head + 1) % 80; } while (0)
+  u8 nb;
+  for (int i = 0; i < 160; ++i) STEP(nb);
+  fe* C = (fe*)malloc((rf + rp) * t * sizeof(fe));
+  fe xy[20];
+  unsigned have = 0, havexy = 0;
+  while (havexy < 2 * t) {
+    fe v = fe_u64(0);
+    for (int i = 0; i < 254; ++i) {
+      STEP(nb); while (nb == 0) { STEP(nb); STEP(nb); } STEP(nb);
+      v.l[3] = (v.l[3] << 1) | (v.l[2] >> 63); v.l[2] = (v.l[2] << 1) | (v.l[1] >> 63);
+      v.l[1] = (v.l[1] << 1) | (v.l[0] >> 63); v.l[0] = (v.l[0] << 1) | nb;
+    }
+    if (have < (rf + rp) * t) { if (!fe_geq(&v, &FE_P)) C[have++] = v; }
+    else { while (fe_geq(&v, &FE_P)) v = fe_sub(v, FE_P); xy[havexy++] = v; }
+  }
+  fe* M = (fe*)malloc(t * t * sizeof(fe));
+  for (unsigned i = 0; i < t; ++i) for (unsigned j = 0; j < t; ++j) M[i * t + j] = fe_inv(fe_add(xy[i], xy[t + j]));
+  g_posM = M; g_posC = C;
+}
+static fe sigma(W* w, fe x) { fe x2 = fe_mul(x, x), x4 = fe_mul(x2, x2), x5 = fe_mul(x4, x); emit_fe(w, x5); emit_fe(w, x2); emit_fe(w, x4); return x5; }
+static fe poseidon_large(W* w, u64 (*pk)[2]) {
+  fe stt[10]; stt[0] = fe_u64(0);
+  for (int i = 0; i < 9; ++i) stt[i + 1] = (i < 8) ? fe_add(fe_from_limb(pk[2 * i]), fe_mul(fe_pow2(121), fe_from_limb(pk[2 * i + 1]))) : fe_from_limb(pk[16]);
+  /* sigmaF[8][10] precede sigmaP[60] in component order: buffer the partial-round signals */
+  fe pbuf[180]; int np = 0;
+  W tmp = {(u8*)pbuf, 0, 180, 0};
+  for (int r = 0; r < 68; ++r) {
+    for (int j = 0; j < 10; ++j) stt[j] = fe_add(stt[j], g_posC[r * 10 + j]);
+    if (r < 4 || r >= 64) { for (int j = 0; j < 10; ++j) stt[j] = sigma(w, stt[j]); }
+    else { stt[0] = sigma(&tmp, stt[0]); np += 3; }
+    fe nw[10];
+    for (int i = 0; i < 10; ++i) { fe acc = fe_u64(0); for (int j = 0; j < 10; ++j) acc = fe_add(acc, fe_mul(g_posM[i * 10 + j], stt[j])); nw[i] = acc; }
+    memcpy(stt, nw, sizeof(nw));
+    if (r == 67) for (int q = 0; q < np; ++q) emit_fe(w, pbuf[q]);
+  }
+  return stt[0];
+}
+
+/* ------------------------------------------------------------------ BodyHashRegex (interface level) */
+static int is_b64(u8 c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '+' || c == '/' || c == '='; }
+/* backtracking matcher for ([a-z]+=[^;]+; )+bh=[a-zA-Z0-9+/=]+;  starting at d[pos]; tags = tags parsed so far */
+static int match_tags(const u8* d, int n, int pos, int tags, int* vs, int* ve) {
+  if (tags >= 1 && pos + 3 <= n && d[pos] == 'b' && d[pos + 1] == 'h' && d[pos + 2] == '=') {
+    int q = pos + 3;
+    while (q < n && is_b64(d[q])) ++q;
+    /* greedy [..]+ then ';' : the run is followed by a non-b64 byte, so only the full run can work */
+    if (q > pos + 3 && q < n && d[q] == ';') { *vs = pos + 3; *ve = q; return q + 1; }
+  }
+  int q = pos;
+  while (q < n && d[q] >= 'a' && d[q] <= 'z') ++q;
+  if (q == pos) return -1;
+  /* [a-z]+ is followed by '=' which is not in [a-z]: the name is the full run */
+  if (q >= n || d[q] != '=') return -1;
+  int v = q + 1, e = v;
+  while (e < n && d[e] != ';') ++e;
+  if (e == v || e + 1 >= n || d[e] != ';' || d[e + 1] != ' ') return -1;
+  return match_tags(d, n, e + 2, tags + 1, vs, ve);
+}
+static unsigned body_hash_regex(const u8* msg, u32 N, u32* rev) {
+  u8* d = (u8*)malloc(N + 1);
+  d[0] = 255; memcpy(d + 1, msg, N);
+  const int n = (int)N + 1;
+  memset(rev, 0, N * sizeof(u32));
+  unsigned matches = 0;
+  int pos = 0;
+  while (pos < n) {
+    int s = -1;
+    if (d[pos] == 255) s = pos + 1; else if (pos + 1 < n && d[pos] == '\r' && d[pos + 1] == '\n') s = pos + 2;
+    int end = -1, vs = 0, ve = 0;
+    if (s >= 0 && s + 15 <= n && memcmp(d + s, "dkim-signature:", 15) == 0) end = match_tags(d, n, s + 15, 0, &vs, &ve);
+    if (end >= 0) { ++matches; for (int q = vs; q < ve; ++q) rev[q - 1] = d[q]; pos = end; }
+    else ++pos;
+  }
+  free(d);
+  return matches;
+}
+
+/* ------------------------------------------------------------------ main circuits */
+typedef struct {
+  u32 main_kind, max_header, max_body, ignore_body;
+} ocfg;
+
+static void load_limbs(u64 (*dst)[2], const u8* src) { for (int i = 0; i < 17; ++i) { memcpy(&dst[i][0], src + 16 * i, 8); memcpy(&dst[i][1], src + 16 * i + 8, 8); } }
+static void emit_limbs(W* w, u64 (*l)[2]) { for (int i = 0; i < 17; ++i) emit_fe(w, fe_from_limb(l[i])); }
+static void check_limbs(W* w, u64 (*l)[2]) { for (int i = 0; i < 17; ++i) if (l[i][1] >> 57) fail(w); }
+
+/* AssertZeroPadding(N)(in, startIndex) */
+static void assert_zero_padding(W* w, const u8* in, u32 N, u32 start) {
+  const unsigned bl = log2ceil(N);
+  for (u32 i = 0; i < N; ++i) { unsigned lt = lessthan(w, bl, fe_from_i64((long long)start - 1), fe_u64(i)); if (lt && in[i]) fail(w); }
+}
+
+/* one email; returns witness length; status via w->failed */
+static void email_verifier(W* w, const ocfg* c, const u8* header, u32 hlen, const u8* body, u32 blen,
+                           const u8* pre, const u8* pubkey, const u8* sig, u32 bh_index) {
+  const u32 N = c->max_header, M = c->max_body;
+  u64 pk[17][2], sg[17][2], msg[17][2];
+  load_limbs(pk, pubkey); load_limbs(sg, sig);
+  check_limbs(w, pk); check_limbs(w, sg);
+  emit_u(w, 1);
+  const u64 out_slot = w->n;      /* pubkeyHash, shaHi, shaLo patched at the end */
+  emit_u(w, 0); emit_u(w, 0); emit_u(w, 0);
+  emit_limbs(w, pk);
+  for (u32 i = 0; i < N; ++i) emit_u(w, header[i]);
+  emit_u(w, hlen);
+  emit_limbs(w, sg);
+  if (!c->ignore_body) { emit_u(w, bh_index); for (int i = 0; i < 32; ++i) emit_u(w, pre[i]); for (u32 i = 0; i < M; ++i) emit_u(w, body[i]); emit_u(w, blen); }
+  num2bits(w, fe_u64(hlen), log2ceil(N));
+  assert_zero_padding(w, header, N, hlen);
+  u32 dig[8];
+  sha_frame(w, header, N, hlen, NULL, dig);
+  /* rsaMessage: sha bits as a 256-bit big-endian integer in 121-bit limbs */
+  { bn D; bn_zero(&D); for (int j = 0; j < 4; ++j) D.d[j] = ((u64)dig[6 - 2 * j] << 32) | dig[7 - 2 * j]; bn_to_limbs121(msg, &D); }
+  rsa_verifier(w, msg, sg, pk);
+  if (!c->ignore_body) {
+    num2bits(w, fe_u64(blen), log2ceil(M));
+    assert_zero_padding(w, body, M, blen);
+    u32* rev = (u32*)malloc(N * sizeof(u32));
+    if (body_hash_regex(header, N, rev) == 0) fail(w);
+    for (u32 i = 0; i < N; ++i) emit_u(w, rev[i]);
+    /* SelectRegexReveal(N, 44) */
+    const unsigned bl = log2ceil((u64)N + 43);
+    for (u32 i = 0; i < N; ++i) {
+      unsigned is_start = iszero_small(w, (long long)bh_index - (long long)i);
+      unsigned is_zero = iszero_small(w, rev[i]);
+      unsigned prev_zero = 1;
+      if (i > 0) prev_zero = iszero_small(w, rev[i - 1]);
+      unsigned above = lessthan(w, bl, fe_u64((u64)bh_index + 43), fe_u64(i));   /* GreaterThan(i, start+43) */
+      if (is_start && is_zero) fail(w);
+      if (is_start && !prev_zero) fail(w);
+      if (above && !is_zero) fail(w);
+    }
+    const unsigned blh = log2ceil(N);
+    u32* cur = (u32*)malloc(N * sizeof(u32)); u32* nx = (u32*)malloc(N * sizeof(u32));
+    memcpy(cur, rev, N * sizeof(u32));
+    for (unsigned j = 0; j < blh; ++j) { /* VarShiftLeft.tmp[j][i] */
+      unsigned bit = (bh_index >> j) & 1;
+      for (u32 i = 0; i < N; ++i) { u32 off = (u32)(((u64)i + (1ULL << j)) % N); nx[i] = bit ? cur[off] : cur[i]; emit_u(w, nx[i]); }
+      u32* t_ = cur; cur = nx; nx = t_;
+    }
+    num2bits(w, fe_u64(bh_index), blh);
+    /* Base64Decode(32) */
+    u32 vals[44]; u32 chars[44];
+    for (int g = 0; g < 44; ++g) chars[g] = cur[g];
+    for (int g = 0; g < 44; ++g) { /* value first (needed by bitsIn) */
+      u32 ch = chars[g], v = 0;
+      if (ch >= 65 && ch <= 90) v = ch - 65; else if (ch >= 97 && ch <= 122) v = ch - 71; else if (ch >= 48 && ch <= 57) v = ch + 4;
+      else if (ch == 43) v = 62; else if (ch == 47) v = 63; else if (ch == 61) v = 0; else fail(w);
+      vals[g] = v;
+    }
+    for (int g = 0; g < 44; ++g) bitsn(w, vals[g], 6);                /* bitsIn[g/4][g%4] */
+    for (int g = 0; g < 44; ++g) { /* translate[g/4][g%4] = Base64Lookup */
+      long long ch = chars[g];
+      u64 rAZ = (ch >= 65 && ch <= 90), raz = (ch >= 97 && ch <= 122), r09 = (ch >= 48 && ch <= 57);
+      u64 sAZ = rAZ * (u64)(ch - 65), saz = sAZ + raz * (u64)(ch - 71), s09 = saz + r09 * (u64)(ch + 4);
+      u64 spl = s09 + (ch == 43) * (u64)(ch + 19), ssl = spl + (ch == 47) * (u64)(ch + 16);
+      emit_u(w, rAZ); emit_u(w, sAZ); emit_u(w, raz); emit_u(w, saz); emit_u(w, r09); emit_u(w, s09); emit_u(w, spl); emit_u(w, ssl);
+      lessthan(w, 8, fe_u64((u64)ch), fe_u64(91)); lessthan(w, 8, fe_u64(64), fe_u64((u64)ch));
+      lessthan(w, 8, fe_u64((u64)ch), fe_u64(123)); lessthan(w, 8, fe_u64(96), fe_u64((u64)ch));
+      lessthan(w, 8, fe_u64((u64)ch), fe_u64(58)); lessthan(w, 8, fe_u64(47), fe_u64((u64)ch));
+      iszero_small(w, ch - 43); iszero_small(w, ch - 47); iszero_small(w, ch - 61);
+    }
+    u32 bdig[8];
+    sha_frame(w, body, M, blen, pre, bdig);
+    for (int i = 0; i < 32; ++i) { /* computedBodyHashInts[i].out === headerBodyHash[i] */
+      int g = i / 3, k = i % 3;
+      u32 v0 = vals[4 * g], v1 = vals[4 * g + 1], v2 = vals[4 * g + 2], v3 = vals[4 * g + 3];
+      u32 byte = k == 0 ? ((v0 << 2) | (v1 >> 4)) : (k == 1 ? (((v1 & 15) << 4) | (v2 >> 2)) : (((v2 & 3) << 6) | v3));
+      if ((byte & 0xff) != ((bdig[i >> 2] >> (24 - 8 * (i & 3))) & 0xff)) fail(w);
+    }
+    free(rev); free(cur); free(nx);
+  }
+  fe ph = poseidon_large(w, pk);
+  if (out_slot + 3 <= w->cap) {
+    fe hi = {{((u64)dig[2] << 32) | dig[3], ((u64)dig[0] << 32) | dig[1], 0, 0}};
+    fe lo = {{((u64)dig[6] << 32) | dig[7], ((u64)dig[4] << 32) | dig[5], 0, 0}};
+    memcpy(w->out + 32 * out_slot, ph.l, 32); memcpy(w->out + 32 * (out_slot + 1), hi.l, 32); memcpy(w->out + 32 * (out_slot + 2), lo.l, 32);
+  }
+}
+
+static void sha_main(W* w, const ocfg* c, const u8* header, u32 hlen) {
+  const u32 N = c->max_header;
+  emit_u(w, 1);
+  const u64 out_slot = w->n;
+  for (int i = 0; i < 256; ++i) emit_u(w, 0);
+  for (u32 i = 0; i < N; ++i) emit_u(w, header[i]);
+  emit_u(w, hlen);
+  u32 dig[8];
+  sha_frame(w, header, N, hlen, NULL, dig);
+  for (int k = 0; k < 256; ++k) if (out_slot + k < w->cap) { fe b = fe_u64((dig[k >> 5] >> (31 - (k & 31))) & 1); memcpy(w->out + 32 * (out_slot + k), b.l, 32); }
+}
+static void rsa_main(W* w, const u8* msg_l, const u8* sig_l, const u8* mod_l) {
+  u64 msg[17][2], sg[17][2], pk[17][2];
+  load_limbs(msg, msg_l); load_limbs(sg, sig_l); load_limbs(pk, mod_l);
+  check_limbs(w, msg); check_limbs(w, sg); check_limbs(w, pk);
+  emit_u(w, 1);
+  emit_limbs(w, pk); emit_limbs(w, msg); emit_limbs(w, sg);
+  rsa_verifier(w, msg, sg, pk);
+}
+
+/* ------------------------------------------------------------------ C entry points (ctypes) */
+/* Computes n witnesses.  Input fields are arrays with the given per-email strides (bytes); any
+ * unused pointer may be NULL.  out: n * out_stride bytes (may be NULL: dry run that only counts);
+ * status[i] = 0 / 4.  Returns the witness length in field elements. */
+static u64 oracle_run(int per_thread_out, u32 main_kind, u32 max_header, u32 max_body, u32 ignore_body, u64 n,
+                          const u8* header, const u32* hlen, const u8* body, const u32* blen, const u8* pre,
+                          const u8* pubkey, const u8* sig, const u8* msg, const u32* bh_index,
+                          u8* out, u64 out_stride, int* status, int threads) {
+  init_invtab(); init_poseidon();
+  ocfg c = {main_kind, max_header, max_body, ignore_body};
+  u64 wlen = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+  for (long long i = 0; i < (long long)n; ++i) {
+    u64 slot = per_thread_out ? (u64)omp_get_thread_num() : (u64)i;
+    W w = {out ? out + slot * out_stride : NULL, 0, out ? out_stride / 32 : 0, 0};
+    if (main_kind == 0)
+      email_verifier(&w, &c, header + (u64)i * max_header, hlen[i], body ? body + (u64)i * max_body : NULL, blen ? blen[i] : 0,
+                     pre ? pre + 32 * i : NULL, pubkey + 272 * i, sig + 272 * i, bh_index ? bh_index[i] : 0);
+    else if (main_kind == 1) sha_main(&w, &c, header + (u64)i * max_header, hlen[i]);
+    else rsa_main(&w, msg + 272 * i, sig + 272 * i, pubkey + 272 * i);
+    if (status) status[i] = w.failed ? 4 : 0;
+    if (i == 0) wlen = w.n;
+  }
+  return wlen;
+}
+
+u64 zkwg_oracle_calculate(u32 main_kind, u32 max_header, u32 max_body, u32 ignore_body, u64 n,
+                          const u8* header, const u32* hlen, const u8* body, const u32* blen, const u8* pre,
+                          const u8* pubkey, const u8* sig, const u8* msg, const u32* bh_index,
+                          u8* out, u64 out_stride, int* status, int threads) {
+  return oracle_run(0, main_kind, max_header, max_body, ignore_body, n, header, hlen, body, blen, pre, pubkey, sig, msg,
+                    bh_index, out, out_stride, status, threads);
+}
+/* Timing variant for bench.py's cpu_baseline: `out` holds one witness buffer PER THREAD
+ * (threads * out_stride bytes); every email's witness is fully written, then overwritten. */
+u64 zkwg_oracle_time(u32 main_kind, u32 max_header, u32 max_body, u32 ignore_body, u64 n,
+                     const u8* header, const u32* hlen, const u8* body, const u32* blen, const u8* pre,
+                     const u8* pubkey, const u8* sig, const u8* msg, const u32* bh_index,
+                     u8* out, u64 out_stride, int* status, int threads) {
+  return oracle_run(1, main_kind, max_header, max_body, ignore_body, n, header, hlen, body, blen, pre, pubkey, sig, msg,
+                    bh_index, out, out_stride, status, threads);
+}

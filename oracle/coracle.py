@@ -1,0 +1,89 @@
+"""ctypes front end of the fast C oracle (oracle/c/zkwg_oracle.c).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c")
+_SO = os.path.join(_DIR, "libzkwg_oracle.so")
+_lib = None
+
+
+def load(build_if_missing=True):
+    global _lib
+    if _lib is None:
+        src = os.path.join(_DIR, "zkwg_oracle.c")
+        stale = not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO))
+        if stale and build_if_missing:
+            subprocess.check_call(["make", "-C", _DIR, "-s"])
+        lib = C.CDLL(_SO)
+        lib.zkwg_oracle_calculate.restype = C.c_uint64
+        lib.zkwg_oracle_calculate.argtypes = [C.c_uint32] * 4 + [C.c_uint64] + [C.c_void_p] * 9 + [
+            C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        lib.zkwg_oracle_time.restype = C.c_uint64
+        lib.zkwg_oracle_time.argtypes = lib.zkwg_oracle_calculate.argtypes
+        _lib = lib
+    return _lib
+
+
+def _limbs(vals):
+    return b"".join((int(v) % (1 << 128)).to_bytes(16, "little") for v in vals)
+
+
+def calculate(main_kind, max_header, max_body, ignore_body, inputs, threads=1, want_witness=True):
+    """inputs: list of CircuitInput-like dicts (ints / decimal strings).  Returns (list of witness
+    bytes, status list, W)."""
+    lib = load()
+    n = len(inputs)
+    hdr = hl = body = bl = pre = pub = sig = msg = bhi = None
+    u32a = lambda xs: (C.c_uint32 * n)(*[int(x) & 0xFFFFFFFF for x in xs])
+    if main_kind == 1:
+        hdr = b"".join(bytes(int(b) for b in i["paddedIn"]) for i in inputs)
+        hl = u32a(i["paddedInLength"] for i in inputs)
+    elif main_kind == 2:
+        pub = b"".join(_limbs(i["modulus"]) for i in inputs)
+        sig = b"".join(_limbs(i["signature"]) for i in inputs)
+        msg = b"".join(_limbs(i["message"]) for i in inputs)
+    else:
+        hdr = b"".join(bytes(int(b) for b in i["emailHeader"]) for i in inputs)
+        hl = u32a(i["emailHeaderLength"] for i in inputs)
+        pub = b"".join(_limbs(i["pubkey"]) for i in inputs)
+        sig = b"".join(_limbs(i["signature"]) for i in inputs)
+        if not ignore_body:
+            body = b"".join(bytes(int(b) for b in i["emailBody"]) for i in inputs)
+            bl = u32a(i["emailBodyLength"] for i in inputs)
+            pre = b"".join(bytes(int(b) for b in i["precomputedSHA"]) for i in inputs)
+            bhi = u32a(i["bodyHashIndex"] for i in inputs)
+    args = (main_kind, max_header, max_body, ignore_body, n, hdr, hl, body, bl, pre, pub, sig, msg, bhi)
+    W = lib.zkwg_oracle_calculate(*args, None, 0, None, 1)
+    status = (C.c_int * n)()
+    out = None
+    if want_witness:
+        out = (C.c_uint8 * (n * W * 32))()
+    lib.zkwg_oracle_calculate(*args, out, W * 32, status, threads)
+    wits = [C.string_at(C.addressof(out) + i * W * 32, W * 32) for i in range(n)] if want_witness else None
+    return wits, list(status), W
+
+
+def run_fields(max_header, max_body, ignore_body, fields, n, threads=1, out=None, per_thread_out=False):
+    """Time/run the C oracle on pre-marshalled field arrays (as produced by zkwg.synth.packed_batch).
+    `out`: optional ctypes buffer of n * 32 * W bytes (or threads * 32 * W with per_thread_out=True:
+    the cpu_baseline timing mode, every witness fully written into its thread's buffer).
+    Returns (W, status list, seconds)."""
+    import time
+    lib = load()
+    u32a = lambda xs: (C.c_uint32 * n)(*xs)
+    hdr, pub, sig = bytes(fields["header"]), bytes(fields["pubkey"]), bytes(fields["sig"])
+    hl = u32a(fields["hlen"])
+    body = bl = pre = bhi = None
+    if not ignore_body:
+        body, pre = bytes(fields["body"]), bytes(fields["pre"])
+        bl, bhi = u32a(fields["blen"]), u32a(fields["bhi"])
+    args = (0, max_header, max_body, ignore_body, n, hdr, hl, body, bl, pre, pub, sig, None, bhi)
+    W = lib.zkwg_oracle_calculate(0, max_header, max_body, ignore_body, 1, hdr, hl, body, bl, pre, pub, sig, None, bhi,
+                                  None, 0, None, 1)
+    status = (C.c_int * n)()
+    t0 = time.perf_counter()
+    fn = lib.zkwg_oracle_time if per_thread_out else lib.zkwg_oracle_calculate
+    fn(*args, out, (W * 32) if out is not None else 0, status, threads)
+    dt = time.perf_counter() - t0
+    return W, list(status), dt

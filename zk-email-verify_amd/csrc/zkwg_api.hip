@@ -13,6 +13,7 @@
 #include "zkwg_build.h"
 
 #define ZK_MAX_KERNELS 8
+#define ZK_EV_RING 64
 
 struct zkwg_circuit {
   zkwg_config cfg;
@@ -29,7 +30,8 @@ struct zkwg_circuit {
   int n_kernels;
   const char* kname[ZK_MAX_KERNELS];
   u64 kslots[ZK_MAX_KERNELS];
-  hipEvent_t ev[ZK_MAX_KERNELS + 1];
+  hipEvent_t ev[ZK_EV_RING][ZK_MAX_KERNELS + 1];
+  u64 launches;   // launches recorded since timing was enabled
   bool ev_valid;
 };
 
@@ -122,7 +124,8 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
       return ZKWG_RC_OOM;
     }
     hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventCreate(&c->ev[i]);
+    for (int r = 0; r < ZK_EV_RING; ++r)
+      for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventCreate(&c->ev[r][i]);
   }
   *out = c;
   return ZKWG_RC_OK;
@@ -134,7 +137,8 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     hipSetDevice(c->device);
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos);
     hipStreamDestroy(c->own_stream);
-    for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventDestroy(c->ev[i]);
+    for (int r = 0; r < ZK_EV_RING; ++r)
+      for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventDestroy(c->ev[r][i]);
   }
   delete c;
 }
@@ -176,6 +180,7 @@ int zkwg_set_timing(zkwg_circuit_t* c, int enable) {
   if (!c) return ZKWG_RC_BAD_ARG;
   c->timing = enable;
   c->ev_valid = false;
+  c->launches = 0;
   return ZKWG_RC_OK;
 }
 int zkwg_num_kernels(const zkwg_circuit_t* c) { return c->n_kernels; }
@@ -188,8 +193,25 @@ uint64_t zkwg_kernel_slots(const zkwg_circuit_t* c, int which) {
 int zkwg_last_kernel_ms(zkwg_circuit_t* c, int which, float* ms) {
   if (!c || !ms || which < 0 || which >= c->n_kernels) return ZKWG_RC_BAD_ARG;
   if (!c->timing || !c->ev_valid) return ZKWG_RC_BAD_ARG;
-  if (hipEventSynchronize(c->ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
-  if (hipEventElapsedTime(ms, c->ev[which], c->ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  hipEvent_t* ev = c->ev[(c->launches - 1) % ZK_EV_RING];
+  if (hipEventSynchronize(ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  if (hipEventElapsedTime(ms, ev[which], ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  return ZKWG_RC_OK;
+}
+int zkwg_timing_summary(zkwg_circuit_t* c, int which, float* total_ms, uint32_t* launches) {
+  if (!c || !total_ms || !launches || which < 0 || which >= c->n_kernels) return ZKWG_RC_BAD_ARG;
+  if (!c->timing || !c->ev_valid) return ZKWG_RC_BAD_ARG;
+  const u64 cnt = c->launches < ZK_EV_RING ? c->launches : ZK_EV_RING;
+  float tot = 0.f;
+  for (u64 k = 0; k < cnt; ++k) {
+    hipEvent_t* ev = c->ev[(c->launches - 1 - k) % ZK_EV_RING];
+    float ms = 0.f;
+    if (hipEventSynchronize(ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+    if (hipEventElapsedTime(&ms, ev[which], ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (uint32_t)cnt;
   return ZKWG_RC_OK;
 }
 
@@ -221,23 +243,24 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n,
   const bool tm = c->timing != 0;
   if (hipMemsetAsync(B.status, 0, n * sizeof(int), st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   int ki = 0;
-  if (tm) hipEventRecord(c->ev[ki], st);
+  hipEvent_t* evs = c->ev[c->launches % ZK_EV_RING];
+  if (tm) hipEventRecord(evs[ki], st);
   if (s.nframes) {
     u32 threads = ne * s.nframes;
     hipLaunchKernelGGL(zk_sha_chain, dim3((threads + 63) / 64), dim3(64), 0, st, s, B);
   }
-  if (tm) hipEventRecord(c->ev[++ki], st);
+  if (tm) hipEventRecord(evs[++ki], st);
   if (s.nframes) {
     u64 units = (u64)ne * s.total_blocks;
     hipLaunchKernelGGL(zk_sha_trace, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
   }
-  if (tm) hipEventRecord(c->ev[++ki], st);
+  if (tm) hipEventRecord(evs[++ki], st);
   if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 0, st, s, B);
-  if (tm) hipEventRecord(c->ev[++ki], st);
+  if (tm) hipEventRecord(evs[++ki], st);
   if (s.rsa.present) hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), 0, st, s, B);
-  if (tm) hipEventRecord(c->ev[++ki], st);
+  if (tm) hipEventRecord(evs[++ki], st);
   hipLaunchKernelGGL(zk_expand, dim3(ne * s.nportions), dim3(256), 0, st, s, B);
-  if (tm) { hipEventRecord(c->ev[++ki], st); c->ev_valid = true; }
+  if (tm) { hipEventRecord(evs[++ki], st); c->ev_valid = true; c->launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;
 }

@@ -165,6 +165,15 @@ class Circuit:
             out[self.lib.zkwg_kernel_name(self.h, i).decode()] = (ms.value, self.lib.zkwg_kernel_slots(self.h, i))
         return out
 
+    def timing_summary(self):
+        """{kernel: (total_ms, launches, slots_per_email)} over the launches since set_timing(True)."""
+        out = {}
+        for i in range(self.lib.zkwg_num_kernels(self.h)):
+            ms, cnt = C.c_float(), C.c_uint32()
+            _check(self.lib.zkwg_timing_summary(self.h, i, C.byref(ms), C.byref(cnt)))
+            out[self.lib.zkwg_kernel_name(self.h, i).decode()] = (ms.value, cnt.value, self.lib.zkwg_kernel_slots(self.h, i))
+        return out
+
     def wtns(self, witness_bytes):
         size = self.lib.zkwg_wtns_size(self.h)
         out = (C.c_uint8 * size)()

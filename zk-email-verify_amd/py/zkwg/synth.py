@@ -73,3 +73,45 @@ def synthetic_dkim_result(seed, index, body_len=1024):
     ).encode()
     sig = pkcs1_sign_digest(key, hashlib.sha256(headers).digest())
     return {"headers": headers, "body": body, "bodyHash": bh, "publicKey": key["n"], "signature": sig}
+
+
+def packed_batch(circuit, seed, n, body_len=1024, first_index=0):
+    """n packed input records (bytes, circuit.in_stride each) for an EmailVerifier circuit, built
+    exactly as generate_email_verifier_inputs_from_dkim_result would (input-generators.ts:190-252)
+    but written straight into the packed record layout (no decimal-string round trip).
+    Also returns the per-email field arrays for the oracle."""
+    from . import inputs as gen
+    from ._lib import (IN_HEADER, IN_BODY, IN_PRECOMPUTED_SHA, IN_PUBKEY, IN_SIGNATURE, IN_HEADER_LEN,
+                       IN_BODY_LEN, IN_BODY_HASH_INDEX)
+    cfg = circuit.cfg
+    stride = circuit.in_stride
+    off = [circuit.lib.zkwg_input_offset(circuit.h, f) for f in range(9)]
+    buf = bytearray(n * stride)
+    fields = {"header": bytearray(), "hlen": [], "body": bytearray(), "blen": [], "pre": bytearray(),
+              "pubkey": bytearray(), "sig": bytearray(), "bhi": []}
+
+    def limbs16(x):
+        return b"".join(((x >> (121 * i)) & ((1 << 121) - 1)).to_bytes(16, "little") for i in range(17))
+
+    for i in range(n):
+        d = synthetic_dkim_result(seed, first_index + i, body_len)
+        hp, hl = gen.sha256_pad(d["headers"], cfg.max_header)
+        base = i * stride
+        buf[base + off[IN_HEADER]:base + off[IN_HEADER] + cfg.max_header] = hp
+        buf[base + off[IN_HEADER_LEN]:base + off[IN_HEADER_LEN] + 4] = hl.to_bytes(4, "little")
+        pk, sg = limbs16(d["publicKey"]), limbs16(d["signature"])
+        buf[base + off[IN_PUBKEY]:base + off[IN_PUBKEY] + 272] = pk
+        buf[base + off[IN_SIGNATURE]:base + off[IN_SIGNATURE] + 272] = sg
+        fields["header"] += hp; fields["hlen"].append(hl); fields["pubkey"] += pk; fields["sig"] += sg
+        if not cfg.ignore_body_hash_check:
+            body = d["body"]
+            sha_len = ((len(body) + 63 + 65) // 64) * 64
+            bp, bpl = gen.sha256_pad(body, max(cfg.max_body, sha_len))
+            pre, rem, rem_len = gen.generate_partial_sha(bp, bpl, None, cfg.max_body)
+            bhi = d["headers"].find(d["bodyHash"].encode())
+            buf[base + off[IN_BODY]:base + off[IN_BODY] + cfg.max_body] = rem
+            buf[base + off[IN_PRECOMPUTED_SHA]:base + off[IN_PRECOMPUTED_SHA] + 32] = pre
+            buf[base + off[IN_BODY_LEN]:base + off[IN_BODY_LEN] + 4] = rem_len.to_bytes(4, "little")
+            buf[base + off[IN_BODY_HASH_INDEX]:base + off[IN_BODY_HASH_INDEX] + 4] = bhi.to_bytes(4, "little")
+            fields["body"] += rem; fields["blen"].append(rem_len); fields["pre"] += pre; fields["bhi"].append(bhi)
+    return bytes(buf), fields
