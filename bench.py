@@ -75,14 +75,37 @@ def main():
     reps = (args.batch + distinct - 1) // distinct
     d_in = h_in.repeat(reps, 1)[:args.batch].contiguous().to(dev)
     d_out = [torch.empty(tile * c.witness_bytes, dtype=torch.uint8, device=dev) for _ in range(min(2, ntiles))]
-    d_status = torch.zeros(args.batch, dtype=torch.int32, device=dev)
-    d_scr = torch.empty(c.scratch_bytes(tile), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream()
+    d_status = [torch.zeros(args.batch, dtype=torch.int32, device=dev) for _ in range(2)]
+    # Two-phase pipeline: the compute kernels of a whole batch ("prepare": ~0.4 MB of compact image
+    # per email) run on one stream while the previous batch's witnesses are streamed out tile by tile
+    # ("expand", the HBM-bound kernel) on another; images are double-buffered.
+    d_scr = [torch.empty(c.scratch_bytes(args.batch), dtype=torch.uint8, device=dev) for _ in range(2)]
+    s_prep, s_exp = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ev_prep = [torch.cuda.Event() for _ in range(2)]
+    ev_exp = [torch.cuda.Event() for _ in range(2)]
+    state = {"k": 0, "table": None}
+    # per-email result rows (w[0..3] = 1, pubkeyHash, shaHi, shaLo) saved before the ring slot is reused
+    from zkwg import shard
+    d_rows = torch.empty((args.batch, 128), dtype=torch.uint8, device=dev)
 
     def step():
-        for t in range(ntiles):
-            c.calculate_batch_device(d_in[t * tile:(t + 1) * tile], tile, d_out[t % len(d_out)],
-                                     d_status[t * tile:(t + 1) * tile], d_scr, stream)
+        k = state["k"]
+        b = k % 2
+        if k >= 2:
+            s_prep.wait_event(ev_exp[b])          # image buffer b is free again
+        c.prepare_device(d_in, args.batch, d_status[b], d_scr[b], s_prep)
+        ev_prep[b].record(s_prep)
+        s_exp.wait_event(ev_prep[b])
+        with torch.cuda.stream(s_exp):
+            for t in range(ntiles):
+                o = d_out[t % len(d_out)]
+                c.expand_device(d_in, args.batch, d_scr[b], t * tile, tile, o, s_exp)
+                d_rows[t * tile:(t + 1) * tile].copy_(o.view(tile, c.witness_bytes)[:, :128])
+            # the only exchange step: gather the 100-byte/email result table on rank 0 (RCCL over xGMI)
+            table = shard.result_table(d_status[b], d_rows)
+            state["table"] = shard.gather_table(dist, table, args.batch * world, rank, world) if dist is not None else table
+        ev_exp[b].record(s_exp)
+        state["k"] = k + 1
 
     def barrier():
         torch.cuda.synchronize()
@@ -93,7 +116,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    assert int(d_status.abs().sum().item()) == 0, "synthetic emails must all verify"
+    assert int(d_status[0].abs().sum().item()) == 0, "synthetic emails must all verify"
+    state["k"] = 0
     c.set_timing(True)
     barrier()
     t0 = time.perf_counter()
@@ -122,7 +146,7 @@ def main():
             "config": {"workload": f"EmailVerifier({args.max_header},{args.max_body},121,17,0,0,0,0) batch={args.batch}/GPU, "
                                    f"{args.body_len} B bodies, witnesses device-resident",
                        "batch_per_gpu": args.batch, "tile": tile, "witness_len": c.W,
-                       "witness_bytes": c.witness_bytes, "layout": "kept-v1", "parallelism": f"shard x{world} (no collective)"},
+                       "witness_bytes": c.witness_bytes, "layout": "kept-v1", "parallelism": f"shard x{world}, result-table gather only"},
             "roofline": {"bound": "hbm", "kernel": "zk_expand", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "bytes_per_launch": bytes_per_email * tile, "avg_launch_ms": round(ex_ms / ex_launches, 4),

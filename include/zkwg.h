@@ -146,6 +146,19 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_packed_inputs, 
                                 void* d_out_wtns, uint64_t out_stride, void* d_status,
                                 void* d_scratch, void* hip_stream);
 
+/* The two phases of zkwg_calculate_batch_device, separately launchable (e.g. on different
+ * streams, with different granularity):
+ *   zkwg_prepare_device  runs every compute kernel for n_emails and leaves their compact
+ *                        images in d_scratch (zkwg_scratch_bytes(c, n_emails)) + d_status;
+ *   zkwg_expand_device   streams the witnesses of emails [first, first+count) of that prepared
+ *                        batch into d_out_wtns (count * 32 W bytes) -- the HBM-write-bound kernel.
+ * The images are ~1 % of the witness size, so a whole batch can be prepared at once while its
+ * witnesses are expanded tile by tile into a smaller output ring. */
+int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails, void* d_status,
+                        void* d_scratch, void* hip_stream);
+int zkwg_expand_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails, const void* d_scratch,
+                       uint64_t first, uint64_t count, void* d_out_wtns, uint64_t out_stride, void* hip_stream);
+
 /* Time the dominant kernel(s) of the last zkwg_calculate_batch_device call with
  * HIP events recorded on the launch stream.  Returns ms in *ms for kernel index
  * `which` (see zkwg_kernel_name); negative rc if timing was not enabled. */

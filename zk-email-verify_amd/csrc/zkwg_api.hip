@@ -30,9 +30,12 @@ struct zkwg_circuit {
   int n_kernels;
   const char* kname[ZK_MAX_KERNELS];
   u64 kslots[ZK_MAX_KERNELS];
-  hipEvent_t ev[ZK_EV_RING][ZK_MAX_KERNELS + 1];
-  u64 launches;   // launches recorded since timing was enabled
-  bool ev_valid;
+  hipEvent_t ev[ZK_EV_RING][2];                    // zk_expand launches: start, stop
+  hipEvent_t pev[ZK_EV_RING][ZK_MAX_KERNELS + 1];  // prepare launches: boundaries between kernels
+  u64 launches;   // expand launches recorded since timing was enabled
+  u64 prep_launches;
+  bool ev_valid, prep_valid;
+  int expand_threads;
 };
 
 // inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
@@ -89,7 +92,13 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
   zkwg_circuit* c = new zkwg_circuit();
   c->cfg = *cfg;
   c->device = -1;
-  if (!build_sched(*cfg, c->s, c->segs, c->first_seg)) { delete c; return ZKWG_RC_BAD_CONFIG; }
+  // tuning knobs (DESIGN.md "zk_expand geometry"): slots per workgroup and threads per workgroup
+  u32 portion = ZK_PORTION_DEFAULT;
+  c->expand_threads = 256;
+  if (const char* v = getenv("ZKWG_PORTION")) portion = (u32)atoi(v);
+  if (const char* v = getenv("ZKWG_EXPAND_THREADS")) c->expand_threads = atoi(v);
+  if (portion < 64 || portion > (1u << 20)) portion = ZK_PORTION_DEFAULT;
+  if (!build_sched(*cfg, c->s, c->segs, c->first_seg, portion)) { delete c; return ZKWG_RC_BAD_CONFIG; }
   // kernel table (launch order)
   c->n_kernels = 5;
   c->kname[0] = "zk_sha_chain"; c->kslots[0] = 0;
@@ -124,8 +133,10 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
       return ZKWG_RC_OOM;
     }
     hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    for (int r = 0; r < ZK_EV_RING; ++r)
-      for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventCreate(&c->ev[r][i]);
+    for (int r = 0; r < ZK_EV_RING; ++r) {
+      for (int i = 0; i < 2; ++i) hipEventCreate(&c->ev[r][i]);
+      for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventCreate(&c->pev[r][i]);
+    }
   }
   *out = c;
   return ZKWG_RC_OK;
@@ -137,8 +148,10 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     hipSetDevice(c->device);
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos);
     hipStreamDestroy(c->own_stream);
-    for (int r = 0; r < ZK_EV_RING; ++r)
-      for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventDestroy(c->ev[r][i]);
+    for (int r = 0; r < ZK_EV_RING; ++r) {
+      for (int i = 0; i < 2; ++i) hipEventDestroy(c->ev[r][i]);
+      for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventDestroy(c->pev[r][i]);
+    }
   }
   delete c;
 }
@@ -180,7 +193,9 @@ int zkwg_set_timing(zkwg_circuit_t* c, int enable) {
   if (!c) return ZKWG_RC_BAD_ARG;
   c->timing = enable;
   c->ev_valid = false;
+  c->prep_valid = false;
   c->launches = 0;
+  c->prep_launches = 0;
   return ZKWG_RC_OK;
 }
 int zkwg_num_kernels(const zkwg_circuit_t* c) { return c->n_kernels; }
@@ -190,42 +205,45 @@ const char* zkwg_kernel_name(const zkwg_circuit_t* c, int which) {
 uint64_t zkwg_kernel_slots(const zkwg_circuit_t* c, int which) {
   return (which >= 0 && which < c->n_kernels) ? c->kslots[which] : 0;
 }
+// events of kernel `which` in the k-th most recent recorded launch (k = 0: last); false if none
+static bool timing_events(zkwg_circuit* c, int which, u64 k, hipEvent_t& a, hipEvent_t& b) {
+  if (which == c->n_kernels - 1) {
+    if (!c->ev_valid || k >= c->launches || k >= ZK_EV_RING) return false;
+    hipEvent_t* ev = c->ev[(c->launches - 1 - k) % ZK_EV_RING];
+    a = ev[0]; b = ev[1];
+  } else {
+    if (!c->prep_valid || k >= c->prep_launches || k >= ZK_EV_RING) return false;
+    hipEvent_t* ev = c->pev[(c->prep_launches - 1 - k) % ZK_EV_RING];
+    a = ev[which]; b = ev[which + 1];
+  }
+  return true;
+}
 int zkwg_last_kernel_ms(zkwg_circuit_t* c, int which, float* ms) {
-  if (!c || !ms || which < 0 || which >= c->n_kernels) return ZKWG_RC_BAD_ARG;
-  if (!c->timing || !c->ev_valid) return ZKWG_RC_BAD_ARG;
-  hipEvent_t* ev = c->ev[(c->launches - 1) % ZK_EV_RING];
-  if (hipEventSynchronize(ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
-  if (hipEventElapsedTime(ms, ev[which], ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  if (!c || !ms || which < 0 || which >= c->n_kernels || !c->timing) return ZKWG_RC_BAD_ARG;
+  hipEvent_t a, b;
+  if (!timing_events(c, which, 0, a, b)) return ZKWG_RC_BAD_ARG;
+  if (hipEventSynchronize(b) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  if (hipEventElapsedTime(ms, a, b) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;
 }
 int zkwg_timing_summary(zkwg_circuit_t* c, int which, float* total_ms, uint32_t* launches) {
-  if (!c || !total_ms || !launches || which < 0 || which >= c->n_kernels) return ZKWG_RC_BAD_ARG;
-  if (!c->timing || !c->ev_valid) return ZKWG_RC_BAD_ARG;
-  const u64 cnt = c->launches < ZK_EV_RING ? c->launches : ZK_EV_RING;
+  if (!c || !total_ms || !launches || which < 0 || which >= c->n_kernels || !c->timing) return ZKWG_RC_BAD_ARG;
   float tot = 0.f;
-  for (u64 k = 0; k < cnt; ++k) {
-    hipEvent_t* ev = c->ev[(c->launches - 1 - k) % ZK_EV_RING];
+  u64 k = 0;
+  hipEvent_t a, b;
+  for (; timing_events(c, which, k, a, b); ++k) {
     float ms = 0.f;
-    if (hipEventSynchronize(ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
-    if (hipEventElapsedTime(&ms, ev[which], ev[which + 1]) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+    if (hipEventSynchronize(b) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return ZKWG_RC_HIP_ERROR;
     tot += ms;
   }
   *total_ms = tot;
-  *launches = (uint32_t)cnt;
+  *launches = (uint32_t)k;
   return ZKWG_RC_OK;
 }
 
-int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_out,
-                                uint64_t out_stride, void* d_status, void* d_scratch, void* hip_stream) {
-  if (!c || !d_in || !d_out || !d_status || !d_scratch) return ZKWG_RC_BAD_ARG;
-  if (c->device < 0) return ZKWG_RC_NO_DEVICE;
-  if (n == 0) return ZKWG_RC_OK;
+static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n, void* d_scratch) {
   const ZkSched& s = c->s;
-  if (out_stride != s.W * 32 || n * (u64)s.nportions > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
-  if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_in & 15)) return ZKWG_RC_BAD_ARG;
-  hipStream_t st = (hipStream_t)hip_stream;
-  const u32 ne = (u32)n;
-  ZkBufs B;
   u8* scr = (u8*)d_scratch;
   B.in = (const u8*)d_in;
   B.hst = (u32*)scr; scr += align256(n * (u64)s.hstates_per_email * 32);
@@ -237,13 +255,29 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n,
   B.pos_m = c->d_pos ? c->d_pos + 680 : nullptr;
   B.segs = c->d_segs;
   B.first_seg = c->d_first_seg;
-  B.wit = (uint4*)d_out;
+  B.wit = nullptr;
+  B.status = nullptr;
+  B.n_emails = (u32)n;
+  B.e_first = 0;
+}
+
+int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_status, void* d_scratch,
+                        void* hip_stream) {
+  if (!c || !d_in || !d_status || !d_scratch) return ZKWG_RC_BAD_ARG;
+  if (c->device < 0) return ZKWG_RC_NO_DEVICE;
+  if (n == 0) return ZKWG_RC_OK;
+  const ZkSched& s = c->s;
+  if (n > 0x3fffffffull) return ZKWG_RC_BAD_ARG;
+  if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_in & 15)) return ZKWG_RC_BAD_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const u32 ne = (u32)n;
+  ZkBufs B;
+  fill_bufs(c, B, d_in, n, d_scratch);
   B.status = (int*)d_status;
-  B.n_emails = ne;
   const bool tm = c->timing != 0;
   if (hipMemsetAsync(B.status, 0, n * sizeof(int), st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   int ki = 0;
-  hipEvent_t* evs = c->ev[c->launches % ZK_EV_RING];
+  hipEvent_t* evs = c->pev[c->prep_launches % ZK_EV_RING];
   if (tm) hipEventRecord(evs[ki], st);
   if (s.nframes) {
     u32 threads = ne * s.nframes;
@@ -258,11 +292,44 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n,
   if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 0, st, s, B);
   if (tm) hipEventRecord(evs[++ki], st);
   if (s.rsa.present) hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), 0, st, s, B);
-  if (tm) hipEventRecord(evs[++ki], st);
-  hipLaunchKernelGGL(zk_expand, dim3(ne * s.nportions), dim3(256), 0, st, s, B);
-  if (tm) { hipEventRecord(evs[++ki], st); c->ev_valid = true; c->launches++; }
+  if (tm) { hipEventRecord(evs[++ki], st); c->prep_valid = true; c->prep_launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;
+}
+
+int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const void* d_scratch, uint64_t first,
+                       uint64_t count, void* d_out, uint64_t out_stride, void* hip_stream) {
+  if (!c || !d_in || !d_out || !d_scratch) return ZKWG_RC_BAD_ARG;
+  if (c->device < 0) return ZKWG_RC_NO_DEVICE;
+  if (count == 0) return ZKWG_RC_OK;
+  const ZkSched& s = c->s;
+  if (first + count > n || out_stride != s.W * 32 || count * (u64)s.nportions > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
+  if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_out & 15)) return ZKWG_RC_BAD_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  ZkBufs B;
+  fill_bufs(c, B, d_in, n, (void*)d_scratch);
+  B.wit = (uint4*)d_out;
+  B.e_first = (u32)first;
+  B.n_emails = (u32)(first + count);
+  const bool tm = c->timing != 0;
+  hipEvent_t* evs = c->ev[c->launches % ZK_EV_RING];
+  if (tm) hipEventRecord(evs[0], st);
+  const dim3 grid((u32)(count * s.nportions));
+  if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
+  else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
+  else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);
+  if (tm) { hipEventRecord(evs[1], st); c->ev_valid = true; c->launches++; }
+  if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  return ZKWG_RC_OK;
+}
+
+int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_out,
+                                uint64_t out_stride, void* d_status, void* d_scratch, void* hip_stream) {
+  if (!c || !d_in || !d_out || !d_status || !d_scratch) return ZKWG_RC_BAD_ARG;
+  if (n == 0) return ZKWG_RC_OK;
+  int rc = zkwg_prepare_device(c, d_in, n, d_status, d_scratch, hip_stream);
+  if (rc != ZKWG_RC_OK) return rc;
+  return zkwg_expand_device(c, d_in, n, d_scratch, 0, n, d_out, out_stride, hip_stream);
 }
 
 int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,

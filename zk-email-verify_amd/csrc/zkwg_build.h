@@ -7,7 +7,7 @@
 #include "zkwg_layout.h"
 
 static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& segs,
-                        std::vector<u32>& first_seg) {
+                        std::vector<u32>& first_seg, u32 portion = ZK_PORTION_DEFAULT) {
   memset(&s, 0, sizeof(s));
   if (cfg.layout != ZKWG_LAYOUT_KEPT_V1) return false;
   if (cfg.enable_header_masking || cfg.enable_body_masking || cfg.remove_soft_line_breaks) return false;
@@ -81,11 +81,12 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
   s.img_fr = w.nfr + 1;
   segs = std::move(w.segs);
   s.nsegs = (u32)segs.size();
-  s.nportions = (u32)((s.W + ZK_PORTION - 1) / ZK_PORTION);
+  s.portion = portion;
+  s.nportions = (u32)((s.W + portion - 1) / portion);
   first_seg.assign(s.nportions, 0);
   u32 si = 0;
   for (u32 p = 0; p < s.nportions; ++p) {
-    u64 slot0 = (u64)p * ZK_PORTION;
+    u64 slot0 = (u64)p * portion;
     while (si + 1 < s.nsegs && segs[si].slot + segs[si].nslots <= slot0) ++si;
     first_seg[p] = si;
   }

@@ -17,18 +17,19 @@
 #include "zkwg_dev.h"
 #include "zkwg_kernels.h"
 
-#define ZK_EXPAND_THREADS 256
 
 // chunk c (16-byte units, absolute within the email's witness) of a segment, per type.
 // r = slot index inside the segment, half = 0 (low 16 bytes) / 1 (high 16 bytes).
 
-__global__ __launch_bounds__(ZK_EXPAND_THREADS) void zk_expand(ZkSched s, ZkBufs B) {
+template <int ZK_EXPAND_THREADS>
+__device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B) {
   const u32 p = blockIdx.x % s.nportions;
-  const u32 e = blockIdx.x / s.nportions;
+  const u32 el = blockIdx.x / s.nportions;   // email index inside this launch
+  const u32 e = el + B.e_first;              // email index inside the prepared batch
   if (e >= B.n_emails) return;
-  const u64 slot0 = (u64)p * ZK_PORTION;
-  const u64 slot1 = min(s.W, slot0 + ZK_PORTION);
-  uint4* __restrict__ wit = B.wit + (u64)e * s.W * 2;
+  const u64 slot0 = (u64)p * s.portion;
+  const u64 slot1 = min(s.W, slot0 + s.portion);
+  uint4* __restrict__ wit = B.wit + (u64)el * s.W * 2;
   const u8* __restrict__ rec = B.in + (u64)e * s.in_stride;
   const u64* __restrict__ bits = B.bits + (u64)e * s.img_bits;
   const u32* __restrict__ small = B.small + (u64)e * s.img_small;
@@ -279,3 +280,7 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void zk_expand(ZkSched s, ZkBufs
     }
   }
 }
+
+__global__ __launch_bounds__(256) void zk_expand_256(ZkSched s, ZkBufs B) { zk_expand_body<256>(s, B); }
+__global__ __launch_bounds__(512) void zk_expand_512(ZkSched s, ZkBufs B) { zk_expand_body<512>(s, B); }
+__global__ __launch_bounds__(1024) void zk_expand_1024(ZkSched s, ZkBufs B) { zk_expand_body<1024>(s, B); }

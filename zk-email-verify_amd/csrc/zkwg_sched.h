@@ -57,7 +57,7 @@ struct ZkSeg {
   u32 a, b, c; // type parameters
 };
 
-#define ZK_PORTION 1024u  // witness slots expanded by one workgroup of zk_expand (32 KiB)
+#define ZK_PORTION_DEFAULT 1024u  // witness slots expanded by one workgroup of zk_expand
 
 struct ZkShaFrame {      // one Sha256Bytes / Sha256BytesPartial instance
   u32 max_bytes;         // maxByteLength
@@ -122,7 +122,8 @@ struct ZkSched {
   u32 in_off[9];         // enum zkwg_input_field -> byte offset
   u32 n_public;
   u32 nsegs;
-  u32 nportions;         // ceil(W / ZK_PORTION)
+  u32 portion;           // witness slots expanded by one workgroup of zk_expand
+  u32 nportions;         // ceil(W / portion)
   u32 img_bits;          // u64 words per email
   u32 img_small;         // u32 words per email
   u32 img_fr;            // Fr elements per email
@@ -159,6 +160,7 @@ struct ZkBufs {
   const u32* first_seg;  // first segment overlapping each portion
   uint4* wit;            // output witnesses
   int* status;           // per-email status
-  u32 n_emails;
+  u32 n_emails;          // emails covered by the image arrays / this launch
+  u32 e_first;           // zk_expand: first email to expand (wit points at its witness)
 };
 #endif

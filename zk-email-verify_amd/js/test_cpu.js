@@ -1,0 +1,21 @@
+'use strict';
+// CPU smoke of the N-API addon + shim (no GPU): layout-only handle, packing, error texts.
+const assert = require('assert');
+const z = require('./zkwg.js');
+const c = new z.Circuit({ mainKind: z.MAIN_SHA256_BYTES, maxHeader: 128, maxBody: 0 }, -1);
+assert.strictEqual(c.witnessLen > 0, true);
+assert.strictEqual(c.numPublic, 256 + 128 + 1);
+const padded = new Array(128).fill(0); padded[0] = 0x80;
+const rec = c.pack({ paddedIn: padded.map(String), paddedInLength: '64' });
+assert.strictEqual(rec.length, c.inputStride);
+assert.strictEqual(rec[c.offsets[0]], 0x80);
+assert.strictEqual(rec.readUInt32LE(c.offsets[6]), 64);
+assert.throws(() => c.pack({ nope: 1 }), /Signal not found/);
+assert.throws(() => c.pack({ paddedIn: padded.concat([1]), paddedInLength: 64 }), /Too many values for input signal paddedIn/);
+assert.throws(() => c.pack({ paddedIn: padded.slice(1), paddedInLength: 64 }), /Not enough values for input signal paddedIn/);
+assert.throws(() => c.pack({ paddedIn: padded }), /Not all inputs have been set. Only 1 out of 2/);
+const ev = new z.Circuit({ maxHeader: 576, maxBody: 192 }, -1);
+assert.strictEqual(ev.numPublic, 20);
+new z.WitnessCalculator(c).calculateWitness({ paddedIn: padded, paddedInLength: 64 }).then(
+  () => { console.error('expected a no-device error'); process.exit(1); },
+  (e) => { assert.ok(/no HIP device/.test(e.message)); console.log('js cpu ok W(sha128)=' + c.witnessLen + ' W(ev576/192)=' + ev.witnessLen); });

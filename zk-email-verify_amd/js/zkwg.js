@@ -1,0 +1,132 @@
+'use strict';
+/*
+ * zkwg.js -- Node host side of the MI355X-native batched witness generator.
+ *
+ * Keeps the API surface the reference calls for this path:
+ *   - circom_runtime's WitnessCalculator: calculateWitness / calculateBinWitness /
+ *     calculateWTNSBin (packages/circuits/tests/email-verifier.test.ts:43 via circom_tester,
+ *     and inside snarkjs.groth16.fullProve, packages/helpers/src/chunked-zkey.ts:80-84);
+ *   - snarkjs `wtns.calculate(input, wasm, wtnsFileName | {type: "mem"})`;
+ *   - the `CircuitInput` object of packages/helpers/src/input-generators.ts:6-18 is accepted as is.
+ * Everything goes through the N-API addon -> C-ABI (include/zkwg.h) -> HIP kernels.
+ * Plain JS for node >= 12.22 (no optional chaining / nullish coalescing).
+ */
+const fs = require('fs');
+const path = require('path');
+const addon = require(path.join(__dirname, 'zkwg_addon.node'));
+
+const FIELD_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
+const MAIN_EMAIL_VERIFIER = 0, MAIN_SHA256_BYTES = 1, MAIN_RSA_VERIFIER = 2;
+const IN = { HEADER: 0, BODY: 1, PRECOMPUTED_SHA: 2, PUBKEY: 3, SIGNATURE: 4, MESSAGE: 5, HEADER_LEN: 6, BODY_LEN: 7, BODY_HASH_INDEX: 8 };
+
+function norm(v) {
+  let x = BigInt(v) % FIELD_MODULUS;
+  if (x < 0n) x += FIELD_MODULUS;
+  return x;
+}
+
+class Circuit {
+  /** opts: {mainKind, maxHeader, maxBody, n, k, ignoreBodyHashCheck}; device < 0 = layout-only handle */
+  constructor(opts, device) {
+    this.opts = Object.assign({ mainKind: MAIN_EMAIL_VERIFIER, maxHeader: 1024, maxBody: 1536, n: 121, k: 17, ignoreBodyHashCheck: 0 }, opts || {});
+    this.handle = addon.createCircuit(this.opts, device === undefined ? 0 : device);
+    Object.assign(this, addon.info(this.handle));
+  }
+
+  signalSizes() {
+    const o = this.opts;
+    if (o.mainKind === MAIN_SHA256_BYTES) return { paddedIn: o.maxHeader, paddedInLength: 1 };
+    if (o.mainKind === MAIN_RSA_VERIFIER) return { message: o.k, signature: o.k, modulus: o.k };
+    const s = { emailHeader: o.maxHeader, emailHeaderLength: 1, pubkey: o.k, signature: o.k };
+    if (!o.ignoreBodyHashCheck) Object.assign(s, { bodyHashIndex: 1, precomputedSHA: 32, emailBody: o.maxBody, emailBodyLength: 1 });
+    return s;
+  }
+
+  /** CircuitInput -> packed record (Buffer).  Error texts follow circom_runtime. */
+  pack(input) {
+    const sizes = this.signalSizes();
+    const flat = {};
+    let nset = 0;
+    for (const key of Object.keys(input)) {
+      if (!(key in sizes)) throw new Error('Signal not found: ' + key);
+      const vals = (Array.isArray(input[key]) ? input[key] : [input[key]]).map(norm);
+      if (vals.length > sizes[key]) throw new Error('Too many values for input signal ' + key);
+      if (vals.length < sizes[key]) throw new Error('Not enough values for input signal ' + key);
+      flat[key] = vals;
+      nset++;
+    }
+    const want = Object.keys(sizes).length;
+    if (nset !== want) throw new Error('Not all inputs have been set. Only ' + nset + ' out of ' + want);
+    const rec = Buffer.alloc(this.inputStride);
+    const off = this.offsets;
+    const bytes = (field, vals, what) => {
+      vals.forEach((v, i) => {
+        if (v > 255n) throw new Error(what + ': value ' + v + ' does not fit the packed byte input path');
+        rec[off[field] + i] = Number(v);
+      });
+    };
+    const u32 = (field, v, what) => {
+      if (v >> 32n) throw new Error(what + ': value does not fit the packed u32 input path');
+      rec.writeUInt32LE(Number(v), off[field]);
+    };
+    const limbs = (field, vals, what) => {
+      vals.forEach((v, i) => {
+        if (v >> 128n) throw new Error(what + ': limb does not fit the packed 128-bit input path');
+        rec.writeBigUInt64LE(v & 0xffffffffffffffffn, off[field] + 16 * i);
+        rec.writeBigUInt64LE(v >> 64n, off[field] + 16 * i + 8);
+      });
+    };
+    const o = this.opts;
+    if (o.mainKind === MAIN_SHA256_BYTES) {
+      bytes(IN.HEADER, flat.paddedIn, 'paddedIn'); u32(IN.HEADER_LEN, flat.paddedInLength[0], 'paddedInLength');
+    } else if (o.mainKind === MAIN_RSA_VERIFIER) {
+      limbs(IN.MESSAGE, flat.message, 'message'); limbs(IN.SIGNATURE, flat.signature, 'signature'); limbs(IN.PUBKEY, flat.modulus, 'modulus');
+    } else {
+      bytes(IN.HEADER, flat.emailHeader, 'emailHeader'); u32(IN.HEADER_LEN, flat.emailHeaderLength[0], 'emailHeaderLength');
+      limbs(IN.PUBKEY, flat.pubkey, 'pubkey'); limbs(IN.SIGNATURE, flat.signature, 'signature');
+      if (!o.ignoreBodyHashCheck) {
+        bytes(IN.BODY, flat.emailBody, 'emailBody'); u32(IN.BODY_LEN, flat.emailBodyLength[0], 'emailBodyLength');
+        bytes(IN.PRECOMPUTED_SHA, flat.precomputedSHA, 'precomputedSHA'); u32(IN.BODY_HASH_INDEX, flat.bodyHashIndex[0], 'bodyHashIndex');
+      }
+    }
+    return rec;
+  }
+}
+
+class WitnessCalculator {
+  constructor(circuit) { this.circuit = circuit; }
+
+  async _one(input, asWtns) {
+    const rec = this.circuit.pack(input);
+    const r = await addon.calculateBatch(this.circuit.handle, rec, true, !!asWtns);
+    if (r.status[0] !== 0) throw new Error(addon.strerror(r.status[0]));
+    return r.witness;
+  }
+  /** -> Promise<bigint[]>  (circom_runtime calculateWitness) */
+  async calculateWitness(input, sanityCheck) { return addon.witnessToBigInts(await this._one(input, false)); }
+  /** -> Promise<Uint8Array> of 32*W bytes (circom_runtime calculateBinWitness) */
+  async calculateBinWitness(input, sanityCheck) { return this._one(input, false); }
+  /** -> Promise<Uint8Array> .wtns file bytes (circom_runtime calculateWTNSBin) */
+  async calculateWTNSBin(input, sanityCheck) { return this._one(input, true); }
+  /** inputs[] -> Promise<{wtns: Buffer[], status: Int32Array}>; never throws for a failed email */
+  async calculateBatch(inputs, wantWitness) {
+    const recs = Buffer.concat(inputs.map((i) => this.circuit.pack(i)));
+    const r = await addon.calculateBatch(this.circuit.handle, recs, wantWitness !== false, false);
+    const wb = this.circuit.witnessBytes;
+    const wtns = r.witness ? inputs.map((_, i) => r.witness.slice(i * wb, (i + 1) * wb)) : [];
+    return { wtns, status: r.status };
+  }
+}
+
+/** snarkjs-shaped `wtns.calculate(input, circuitOrWasm, wtnsFileName | {type:"mem"})`.  The second
+ * argument is a zkwg Circuit (where the reference passes the path of the circom WASM). */
+const wtns = {
+  async calculate(input, circuit, wtnsFile) {
+    const wc = new WitnessCalculator(circuit);
+    const bin = await wc.calculateWTNSBin(input);
+    if (wtnsFile && typeof wtnsFile === 'object' && wtnsFile.type === 'mem') { wtnsFile.data = bin; return; }
+    fs.writeFileSync(wtnsFile, bin);
+  },
+};
+
+module.exports = { Circuit, WitnessCalculator, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };

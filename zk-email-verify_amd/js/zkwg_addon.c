@@ -1,0 +1,203 @@
+/*
+ * zkwg_addon.c -- thin N-API addon over the C-ABI of libzkwg.so (include/zkwg.h).
+ *
+ * This is the binding a maintainer of the reference adds so that the Node/TypeScript host
+ * keeps its `calculateWitness` / `snarkjs.wtns.calculate` call sites
+ * (packages/circuits/tests/email-verifier.test.ts:43, packages/helpers/src/chunked-zkey.ts:80)
+ * while the witness is computed on the GPU.  N-API >= 6 (BigInt words), node >= 12.22.
+ * All heavy work runs on a libuv worker thread (napi_create_async_work).
+ */
+#include <node_api.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/zkwg.h"
+
+#define NAPI_OK(call) do { if ((call) != napi_ok) { napi_throw_error(env, NULL, "zkwg addon: N-API call failed: " #call); return NULL; } } while (0)
+
+static void circuit_finalize(napi_env env, void* data, void* hint) { zkwg_circuit_destroy((zkwg_circuit_t*)data); }
+
+static int get_u32(napi_env env, napi_value obj, const char* key, uint32_t* out, uint32_t dflt) {
+  napi_value v; bool has = false;
+  *out = dflt;
+  if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return 0;
+  if (napi_get_named_property(env, obj, key, &v) != napi_ok) return -1;
+  return napi_get_value_uint32(env, v, out) == napi_ok ? 0 : -1;
+}
+
+/* createCircuit({mainKind,maxHeader,maxBody,n,k,ignoreBodyHashCheck}, device) -> External */
+static napi_value CreateCircuit(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkwg_config cfg; memset(&cfg, 0, sizeof(cfg));
+  get_u32(env, argv[0], "mainKind", &cfg.main_kind, 0);
+  get_u32(env, argv[0], "maxHeader", &cfg.max_header, 1024);
+  get_u32(env, argv[0], "maxBody", &cfg.max_body, 1536);
+  get_u32(env, argv[0], "n", &cfg.n, 121);
+  get_u32(env, argv[0], "k", &cfg.k, 17);
+  get_u32(env, argv[0], "ignoreBodyHashCheck", &cfg.ignore_body_hash_check, 0);
+  int32_t device = 0;
+  if (argc > 1) napi_get_value_int32(env, argv[1], &device);
+  zkwg_circuit_t* c = NULL;
+  int rc = zkwg_circuit_create(&cfg, device, &c);
+  if (rc != ZKWG_RC_OK) { napi_throw_error(env, NULL, zkwg_strerror(rc)); return NULL; }
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, c, circuit_finalize, NULL, &ext));
+  return ext;
+}
+
+static zkwg_circuit_t* unwrap(napi_env env, napi_value v) {
+  void* p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok) { napi_throw_type_error(env, NULL, "zkwg: circuit handle expected"); return NULL; }
+  return (zkwg_circuit_t*)p;
+}
+
+/* info(circuit) -> {witnessLen, witnessBytes, numPublic, inputStride, wtnsSize, offsets: [9]} */
+static napi_value Info(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkwg_circuit_t* c = unwrap(env, argv[0]);
+  if (!c) return NULL;
+  napi_value obj, v, arr;
+  NAPI_OK(napi_create_object(env, &obj));
+  NAPI_OK(napi_create_double(env, (double)zkwg_witness_len(c), &v)); NAPI_OK(napi_set_named_property(env, obj, "witnessLen", v));
+  NAPI_OK(napi_create_double(env, (double)zkwg_witness_bytes(c), &v)); NAPI_OK(napi_set_named_property(env, obj, "witnessBytes", v));
+  NAPI_OK(napi_create_uint32(env, zkwg_num_public(c), &v)); NAPI_OK(napi_set_named_property(env, obj, "numPublic", v));
+  NAPI_OK(napi_create_double(env, (double)zkwg_input_stride(c), &v)); NAPI_OK(napi_set_named_property(env, obj, "inputStride", v));
+  NAPI_OK(napi_create_double(env, (double)zkwg_wtns_size(c), &v)); NAPI_OK(napi_set_named_property(env, obj, "wtnsSize", v));
+  NAPI_OK(napi_create_array_with_length(env, ZKWG_IN_NFIELDS, &arr));
+  for (int f = 0; f < ZKWG_IN_NFIELDS; ++f) {
+    NAPI_OK(napi_create_double(env, (double)zkwg_input_offset(c, f), &v));
+    NAPI_OK(napi_set_element(env, arr, f, v));
+  }
+  NAPI_OK(napi_set_named_property(env, obj, "offsets", arr));
+  return obj;
+}
+
+/* ---- async batch calculation -------------------------------------------------------------- */
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref in_ref;
+  zkwg_circuit_t* c;
+  const uint8_t* in;
+  uint64_t n;
+  uint8_t* out;      /* malloc'ed: n * witness_bytes (NULL if want_witness == 0) */
+  int32_t* status;   /* malloc'ed */
+  int want_witness;
+  int as_wtns;       /* 1: wrap each witness into a .wtns container */
+  int rc;
+} calc_job;
+
+static void calc_execute(napi_env env, void* data) {
+  calc_job* j = (calc_job*)data;
+  const uint64_t wb = zkwg_witness_bytes(j->c);
+  j->status = (int32_t*)calloc(j->n, sizeof(int32_t));
+  if (j->want_witness) j->out = (uint8_t*)malloc(j->n * wb);
+  if (!j->status || (j->want_witness && !j->out)) { j->rc = ZKWG_RC_OOM; return; }
+  j->rc = zkwg_calculate_batch(j->c, j->in, j->n, j->out, wb, j->status, 0);
+}
+
+static void free_cb(napi_env env, void* data, void* hint) { free(data); }
+
+static void calc_complete(napi_env env, napi_status st, void* data) {
+  calc_job* j = (calc_job*)data;
+  napi_value result = NULL, err = NULL, msg;
+  if (j->rc != ZKWG_RC_OK) {
+    napi_create_string_utf8(env, zkwg_strerror(j->rc), NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &err);
+  } else {
+    napi_value obj, statusArr, ab, wit;
+    napi_create_object(env, &obj);
+    void* sdata;
+    napi_create_arraybuffer(env, j->n * sizeof(int32_t), &sdata, &ab);
+    memcpy(sdata, j->status, j->n * sizeof(int32_t));
+    napi_create_typedarray(env, napi_int32_array, j->n, ab, 0, &statusArr);
+    napi_set_named_property(env, obj, "status", statusArr);
+    if (j->want_witness) {
+      const uint64_t wb = zkwg_witness_bytes(j->c);
+      if (j->as_wtns && j->n == 1) {
+        const uint64_t ws = zkwg_wtns_size(j->c);
+        uint8_t* w = (uint8_t*)malloc(ws);
+        zkwg_write_wtns(j->c, j->out, w, ws);
+        napi_create_external_buffer(env, ws, w, free_cb, NULL, &wit);
+        free(j->out);
+      } else {
+        napi_create_external_buffer(env, j->n * wb, j->out, free_cb, NULL, &wit);
+      }
+      j->out = NULL;
+      napi_set_named_property(env, obj, "witness", wit);
+    }
+    result = obj;
+  }
+  if (err) napi_reject_deferred(env, j->deferred, err); else napi_resolve_deferred(env, j->deferred, result);
+  napi_delete_reference(env, j->in_ref);
+  napi_delete_async_work(env, j->work);
+  free(j->status); free(j->out); free(j);
+}
+
+/* calculateBatch(circuit, recordsBuffer, wantWitness, asWtns) -> Promise<{status: Int32Array, witness?: Buffer}> */
+static napi_value CalculateBatch(napi_env env, napi_callback_info info) {
+  size_t argc = 4; napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkwg_circuit_t* c = unwrap(env, argv[0]);
+  if (!c) return NULL;
+  void* data; size_t len;
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &len));
+  const uint64_t stride = zkwg_input_stride(c);
+  if (len == 0 || len % stride) { napi_throw_range_error(env, NULL, "zkwg: records buffer is not a whole number of input records"); return NULL; }
+  calc_job* j = (calc_job*)calloc(1, sizeof(calc_job));
+  j->c = c; j->in = (const uint8_t*)data; j->n = len / stride;
+  bool b = true;
+  if (argc > 2) napi_get_value_bool(env, argv[2], &b);
+  j->want_witness = b ? 1 : 0;
+  b = false;
+  if (argc > 3) napi_get_value_bool(env, argv[3], &b);
+  j->as_wtns = b ? 1 : 0;
+  napi_value promise, name;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_reference(env, argv[1], 1, &j->in_ref));   /* keep the input buffer alive */
+  NAPI_OK(napi_create_string_utf8(env, "zkwg.calculateBatch", NAPI_AUTO_LENGTH, &name));
+  NAPI_OK(napi_create_async_work(env, NULL, name, calc_execute, calc_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
+/* witnessToBigInts(buffer) -> bigint[]   (32-byte LE words -> napi_create_bigint_words) */
+static napi_value WitnessToBigInts(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  void* data; size_t len;
+  NAPI_OK(napi_get_buffer_info(env, argv[0], &data, &len));
+  size_t n = len / 32;
+  napi_value arr;
+  NAPI_OK(napi_create_array_with_length(env, n, &arr));
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t words[4];
+    memcpy(words, (const uint8_t*)data + 32 * i, 32);
+    napi_value v;
+    NAPI_OK(napi_create_bigint_words(env, 0, 4, words, &v));
+    NAPI_OK(napi_set_element(env, arr, i, v));
+  }
+  return arr;
+}
+
+static napi_value StrError(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1]; int32_t code = 0; napi_value s;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  napi_get_value_int32(env, argv[0], &code);
+  NAPI_OK(napi_create_string_utf8(env, zkwg_strerror(code), NAPI_AUTO_LENGTH, &s));
+  return s;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+  napi_property_descriptor d[] = {
+      {"createCircuit", NULL, CreateCircuit, NULL, NULL, NULL, napi_default, NULL},
+      {"info", NULL, Info, NULL, NULL, NULL, napi_default, NULL},
+      {"calculateBatch", NULL, CalculateBatch, NULL, NULL, NULL, napi_default, NULL},
+      {"witnessToBigInts", NULL, WitnessToBigInts, NULL, NULL, NULL, napi_default, NULL},
+      {"strerror", NULL, StrError, NULL, NULL, NULL, napi_default, NULL},
+  };
+  napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d);
+  return exports;
+}
+NAPI_MODULE(zkwg_addon, Init)

@@ -151,6 +151,17 @@ class Circuit:
                                                     self.witness_bytes, d_status.data_ptr(),
                                                     d_scratch.data_ptr(), sp))
 
+    def prepare_device(self, d_in, n, d_status, d_scratch, stream=None):
+        """Phase 1: all compute kernels for n emails -> compact images in d_scratch."""
+        sp = stream.cuda_stream if stream is not None else 0
+        _check(self.lib.zkwg_prepare_device(self.h, d_in.data_ptr(), n, d_status.data_ptr(), d_scratch.data_ptr(), sp))
+
+    def expand_device(self, d_in, n, d_scratch, first, count, d_out, stream=None):
+        """Phase 2: stream the witnesses of emails [first, first+count) into d_out."""
+        sp = stream.cuda_stream if stream is not None else 0
+        _check(self.lib.zkwg_expand_device(self.h, d_in.data_ptr(), n, d_scratch.data_ptr(), first, count,
+                                           d_out.data_ptr(), self.witness_bytes, sp))
+
     def scratch_bytes(self, n):
         return self.lib.zkwg_scratch_bytes(self.h, n)
 

@@ -1,0 +1,42 @@
+"""Multi-GPU sharding of a batch: one process per GPU, emails are independent
+units, rank r owns a contiguous range, no data-path collective.  The only exchange is the
+gather of the small per-email result table {status, pubkeyHash, shaHi, shaLo} (100 bytes per
+email) to rank 0 -- over RCCL/xGMI on GPUs (backend "nccl"), gloo in the CPU tests.  The bulk
+`.wtns` bytes stay on the GPU that produced them (or leave through that GPU's own PCIe link).
+"""
+import torch
+
+TABLE_BYTES = 4 + 3 * 32  # i32 status + three 32-byte public outputs
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous range [lo, hi) of emails owned by `rank` (first n_total % world ranks get one more)."""
+    base, extra = divmod(n_total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def result_table(status, witness_rows):
+    """status: int32[n]; witness_rows: uint8[n, >=128] (first 128 bytes of each witness: w[0..3]).
+    Returns uint8[n, TABLE_BYTES]."""
+    n = status.shape[0]
+    t = torch.empty((n, TABLE_BYTES), dtype=torch.uint8, device=status.device)
+    t[:, :4] = status.view(torch.uint8).view(n, 4)
+    t[:, 4:] = witness_rows[:, 32:128]
+    return t
+
+
+def gather_table(dist, local_table, n_total, rank, world):
+    """Gather every rank's table on rank 0 (returns uint8[n_total, TABLE_BYTES] there, None elsewhere).
+    Shards may differ by one row, so rows are padded to the largest shard for the collective."""
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    mx = max(sizes)
+    pad = torch.zeros((mx, TABLE_BYTES), dtype=torch.uint8, device=local_table.device)
+    pad[:local_table.shape[0]] = local_table
+    if world == 1:
+        return local_table
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
