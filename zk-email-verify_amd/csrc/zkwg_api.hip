@@ -36,6 +36,7 @@ struct zkwg_circuit {
   u64 prep_launches;
   bool ev_valid, prep_valid;
   int expand_threads;
+  int emails_per_wg;
 };
 
 // inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
@@ -97,6 +98,8 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
   c->expand_threads = 256;
   if (const char* v = getenv("ZKWG_PORTION")) portion = (u32)atoi(v);
   if (const char* v = getenv("ZKWG_EXPAND_THREADS")) c->expand_threads = atoi(v);
+  c->emails_per_wg = 1;
+  if (const char* v = getenv("ZKWG_EMAILS_PER_WG")) c->emails_per_wg = std::max(1, atoi(v));
   if (portion < 64 || portion > (1u << 20)) portion = ZK_PORTION_DEFAULT;
   if (!build_sched(*cfg, c->s, c->segs, c->first_seg, portion)) { delete c; return ZKWG_RC_BAD_CONFIG; }
   // kernel table (launch order)
@@ -259,6 +262,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.status = nullptr;
   B.n_emails = (u32)n;
   B.e_first = 0;
+  B.emails_per_wg = 1;
 }
 
 int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_status, void* d_scratch,
@@ -314,7 +318,8 @@ int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   const bool tm = c->timing != 0;
   hipEvent_t* evs = c->ev[c->launches % ZK_EV_RING];
   if (tm) hipEventRecord(evs[0], st);
-  const dim3 grid((u32)(count * s.nportions));
+  B.emails_per_wg = (u32)c->emails_per_wg;
+  const dim3 grid((u32)(((count + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions));
   if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
   else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
   else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);

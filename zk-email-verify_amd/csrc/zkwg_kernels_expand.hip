@@ -23,17 +23,16 @@
 
 template <int ZK_EXPAND_THREADS>
 __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B) {
+  // workgroup (p, g): portion p of the emails [g*E, g*E+E) of this launch.  The segment lookup is
+  // email-independent, so its latency is paid once per workgroup and amortised over E emails.
   const u32 p = blockIdx.x % s.nportions;
-  const u32 el = blockIdx.x / s.nportions;   // email index inside this launch
-  const u32 e = el + B.e_first;              // email index inside the prepared batch
-  if (e >= B.n_emails) return;
+  const u32 g = blockIdx.x / s.nportions;
+  const u32 E = B.emails_per_wg;
+  const u32 el0 = g * E;                                   // first email (launch-local index)
+  const u32 el1 = min(el0 + E, B.n_emails - B.e_first);    // one past the last
+  if (el0 >= el1) return;
   const u64 slot0 = (u64)p * s.portion;
   const u64 slot1 = min(s.W, slot0 + s.portion);
-  uint4* __restrict__ wit = B.wit + (u64)el * s.W * 2;
-  const u8* __restrict__ rec = B.in + (u64)e * s.in_stride;
-  const u64* __restrict__ bits = B.bits + (u64)e * s.img_bits;
-  const u32* __restrict__ small = B.small + (u64)e * s.img_small;
-  const Fr* __restrict__ frv = B.frv + (u64)e * s.img_fr;
   const uint4* __restrict__ invtab = (const uint4*)B.invtab;
   const u32 tid = threadIdx.x;
 
@@ -44,7 +43,13 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
     const u64 hi = min(sg.slot + sg.nslots, slot1);
     const u32 r0 = (u32)(lo - sg.slot);         // first in-segment slot handled here
     const u32 nch = (u32)(hi - lo) * 2;          // chunks to write
-    uint4* __restrict__ dst = wit + lo * 2;
+   for (u32 el = el0; el < el1; ++el) {
+    const u32 e = el + B.e_first;                // email index inside the prepared batch
+    uint4* __restrict__ dst = B.wit + ((u64)el * s.W + lo) * 2;
+    const u8* __restrict__ rec = B.in + (u64)e * s.in_stride;
+    const u64* __restrict__ bits = B.bits + (u64)e * s.img_bits;
+    const u32* __restrict__ small = B.small + (u64)e * s.img_small;
+    const Fr* __restrict__ frv = B.frv + (u64)e * s.img_fr;
 
     switch (sg.type) {
       case ZSEG_SMALL:
@@ -278,6 +283,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
       default:
         break;
     }
+   }
   }
 }
 

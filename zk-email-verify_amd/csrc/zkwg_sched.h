@@ -162,5 +162,6 @@ struct ZkBufs {
   int* status;           // per-email status
   u32 n_emails;          // emails covered by the image arrays / this launch
   u32 e_first;           // zk_expand: first email to expand (wit points at its witness)
+  u32 emails_per_wg;     // zk_expand: emails handled by one workgroup (same portion of each)
 };
 #endif

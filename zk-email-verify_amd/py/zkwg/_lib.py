@@ -40,6 +40,12 @@ def load():
         raise ImportError(
             f"zkwg: HIP library not built: {LIB_PATH} missing "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C zk-email-verify_amd/csrc`)")
+    # PyTorch (when present) bundles its own HIP runtime; load it first so that libzkwg.so binds to
+    # the same libamdhip64 instance -- two HIP runtimes in one process cannot both open the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     sig = {
