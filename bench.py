@@ -80,7 +80,8 @@ def main():
     # per email) run on one stream while the previous batch's witnesses are streamed out tile by tile
     # ("expand", the HBM-bound kernel) on another; images are double-buffered.
     d_scr = [torch.empty(c.scratch_bytes(args.batch), dtype=torch.uint8, device=dev) for _ in range(2)]
-    s_prep, s_exp = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    prio = int(os.environ.get('ZKWG_BENCH_EXP_PRIO', '-1'))
+    s_prep, s_exp = torch.cuda.Stream(device=dev, priority=0), torch.cuda.Stream(device=dev, priority=prio)
     ev_prep = [torch.cuda.Event() for _ in range(2)]
     ev_exp = [torch.cuda.Event() for _ in range(2)]
     state = {"k": 0, "table": None}

@@ -27,6 +27,18 @@ __global__ __launch_bounds__(THREADS) void fill_persist(uint4* dst, unsigned chu
   }
 }
 
+// wave-contiguous: each wave writes KB_PER_WAVE consecutive KiB (dense 1 KiB per store instruction)
+template <int THREADS, int KB_PER_WAVE>
+__global__ __launch_bounds__(THREADS) void fill_wavecontig(uint4* dst, unsigned long long total) {
+  const unsigned waves = THREADS / 64, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long base = ((unsigned long long)blockIdx.x * waves + wave) * (KB_PER_WAVE * 64ull);
+  uint4 v = make_uint4(blockIdx.x & 1, 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < KB_PER_WAVE; ++k) {
+    unsigned long long c = base + k * 64 + lane;
+    if (c < total) dst[c] = v;
+  }
+}
 template <class F> float timeit(F f, int iters = 5) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   f(); CK(hipDeviceSynchronize());
@@ -56,6 +68,10 @@ int main() {
     ms = timeit([&] { hipLaunchKernelGGL((fill_k<1024, 1>), dim3(grid), dim3(1024), 0, 0, d, cpw, total); });
     printf("fill 1024thr   %4u KB/WG: %7.3f ms %6.0f GB/s\n", kb, ms, bytes / ms / 1e6);
   }
+#define WC(T, K) do { unsigned long long per = (T / 64) * (K * 64ull); unsigned grid = (unsigned)((total + per - 1) / per); \
+    ms = timeit([&] { hipLaunchKernelGGL((fill_wavecontig<T, K>), dim3(grid), dim3(T), 0, 0, d, total); }); \
+    printf("wavecontig %4d thr %2d KB/wave: %7.3f ms %6.0f GB/s\n", T, K, ms, bytes / ms / 1e6); } while (0)
+  WC(256, 1); WC(256, 2); WC(256, 4); WC(256, 8); WC(512, 2); WC(512, 4); WC(1024, 1); WC(1024, 2); WC(1024, 4); WC(64, 4); WC(64, 8); WC(128, 4);
   for (unsigned g : {256u * 4, 256u * 8, 256u * 16}) {
     unsigned cpw = 32 * 1024 / 16;
     ms = timeit([&] { hipLaunchKernelGGL((fill_persist<256>), dim3(g), dim3(256), 0, 0, d, cpw, total / cpw); });

@@ -319,8 +319,10 @@ int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   hipEvent_t* evs = c->ev[c->launches % ZK_EV_RING];
   if (tm) hipEventRecord(evs[0], st);
   B.emails_per_wg = (u32)c->emails_per_wg;
-  const dim3 grid((u32)(((count + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions));
-  if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
+  const u64 units = ((count + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions;
+  const dim3 grid((u32)units);
+  if (c->expand_threads == 64) hipLaunchKernelGGL(zk_expand_wave, dim3((u32)((units + 3) / 4)), dim3(256), 0, st, s, B);
+  else if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
   else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
   else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);
   if (tm) { hipEventRecord(evs[1], st); c->ev_valid = true; c->launches++; }

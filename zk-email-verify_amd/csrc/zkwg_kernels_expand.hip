@@ -21,12 +21,18 @@
 // chunk c (16-byte units, absolute within the email's witness) of a segment, per type.
 // r = slot index inside the segment, half = 0 (low 16 bytes) / 1 (high 16 bytes).
 
-template <int ZK_EXPAND_THREADS>
+// WAVE_MODE = false: one workgroup per (portion, email group), threads interleaved over the portion.
+// WAVE_MODE = true : one WAVEFRONT per (portion, email group): every wave writes its own contiguous
+//                    portion (1 KiB per store instruction, back to back), 4 such waves per workgroup.
+template <int ZK_BLOCK_THREADS, bool WAVE_MODE>
 __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B) {
+  constexpr u32 ZK_EXPAND_THREADS = WAVE_MODE ? 64u : (u32)ZK_BLOCK_THREADS;
+  constexpr u32 UNITS_PER_BLOCK = WAVE_MODE ? (u32)ZK_BLOCK_THREADS / 64u : 1u;
+  const u32 unit = blockIdx.x * UNITS_PER_BLOCK + (WAVE_MODE ? (threadIdx.x >> 6) : 0u);
   // workgroup (p, g): portion p of the emails [g*E, g*E+E) of this launch.  The segment lookup is
   // email-independent, so its latency is paid once per workgroup and amortised over E emails.
-  const u32 p = blockIdx.x % s.nportions;
-  const u32 g = blockIdx.x / s.nportions;
+  const u32 p = unit % s.nportions;
+  const u32 g = unit / s.nportions;
   const u32 E = B.emails_per_wg;
   const u32 el0 = g * E;                                   // first email (launch-local index)
   const u32 el1 = min(el0 + E, B.n_emails - B.e_first);    // one past the last
@@ -34,7 +40,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
   const u64 slot0 = (u64)p * s.portion;
   const u64 slot1 = min(s.W, slot0 + s.portion);
   const uint4* __restrict__ invtab = (const uint4*)B.invtab;
-  const u32 tid = threadIdx.x;
+  const u32 tid = WAVE_MODE ? (threadIdx.x & 63u) : threadIdx.x;
 
   for (u32 si = B.first_seg[p]; si < s.nsegs; ++si) {
     const ZkSeg sg = B.segs[si];
@@ -287,6 +293,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
   }
 }
 
-__global__ __launch_bounds__(256) void zk_expand_256(ZkSched s, ZkBufs B) { zk_expand_body<256>(s, B); }
-__global__ __launch_bounds__(512) void zk_expand_512(ZkSched s, ZkBufs B) { zk_expand_body<512>(s, B); }
-__global__ __launch_bounds__(1024) void zk_expand_1024(ZkSched s, ZkBufs B) { zk_expand_body<1024>(s, B); }
+__global__ __launch_bounds__(256) void zk_expand_256(ZkSched s, ZkBufs B) { zk_expand_body<256, false>(s, B); }
+__global__ __launch_bounds__(512) void zk_expand_512(ZkSched s, ZkBufs B) { zk_expand_body<512, false>(s, B); }
+__global__ __launch_bounds__(1024) void zk_expand_1024(ZkSched s, ZkBufs B) { zk_expand_body<1024, false>(s, B); }
+__global__ __launch_bounds__(256) void zk_expand_wave(ZkSched s, ZkBufs B) { zk_expand_body<256, true>(s, B); }

@@ -57,7 +57,7 @@ struct ZkSeg {
   u32 a, b, c; // type parameters
 };
 
-#define ZK_PORTION_DEFAULT 1024u  // witness slots expanded by one workgroup of zk_expand
+#define ZK_PORTION_DEFAULT 2048u  // witness slots expanded by one workgroup of zk_expand
 
 struct ZkShaFrame {      // one Sha256Bytes / Sha256BytesPartial instance
   u32 max_bytes;         // maxByteLength
