@@ -293,7 +293,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     hipLaunchKernelGGL(zk_sha_trace, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
   }
   if (tm) hipEventRecord(evs[++ki], st);
-  if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 0, st, s, B);
+  if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 5 * s.fr[0].max_bytes, st, s, B);
   if (tm) hipEventRecord(evs[++ki], st);
   if (s.rsa.present) hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), 0, st, s, B);
   if (tm) { hipEventRecord(evs[++ki], st); c->prep_valid = true; c->prep_launches++; }

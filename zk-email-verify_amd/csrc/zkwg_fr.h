@@ -112,50 +112,76 @@ ZK_HD Fr fr_neg(const Fr& a) {
   return fr_sub_raw(fr_p(), a, bw);
 }
 
-// Montgomery product a*b*R^{-1} mod r  (CIOS, 4 x 64-bit limbs)
+// Montgomery product a*b*R^{-1} mod r (CIOS).  Host: 4 x 64-bit limbs via __int128.  gfx950 has no
+// 64x64 multiplier: the device path runs the same algorithm on 8 x 32-bit limbs so that every
+// inner step is one v_mad_u64_u32 (32x32+64) plus one 64-bit add.
 ZK_HD Fr fr_mont_mul(const Fr& a, const Fr& b) {
-  const u64 p[4] = {ZK_P0, ZK_P1, ZK_P2, ZK_P3};
-  u64 t[6] = {0, 0, 0, 0, 0, 0};
+#if defined(__HIP_DEVICE_COMPILE__)
+  const u32 P32[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  const u32 N0_32 = 0xefffffffu;  // -r^{-1} mod 2^32
+  u32 A[8], Bv[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    u64 carry = 0;
+    A[2 * i] = (u32)a.l[i]; A[2 * i + 1] = (u32)(a.l[i] >> 32);
+    Bv[2 * i] = (u32)b.l[i]; Bv[2 * i + 1] = (u32)(b.l[i] >> 32);
+  }
+  u32 t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      u64 lo, hi;
-      zk_mul64(a.l[j], b.l[i], lo, hi);
-      u64 c = 0;
-      u64 s = zk_adc(t[j], lo, c);
-      hi += c;
-      c = 0;
-      s = zk_adc(s, carry, c);
-      hi += c;
-      t[j] = s;
-      carry = hi;
-    }
+  for (int i = 0; i < 8; ++i) {
     u64 c = 0;
-    t[4] = zk_adc(t[4], carry, c);
-    t[5] = c;
-    u64 m = t[0] * ZK_N0;
-    u64 lo, hi;
-    zk_mul64(m, p[0], lo, hi);
-    c = 0;
-    (void)zk_adc(t[0], lo, c);
-    carry = hi + c;
 #pragma unroll
-    for (int j = 1; j < 4; ++j) {
-      zk_mul64(m, p[j], lo, hi);
-      c = 0;
-      u64 s = zk_adc(t[j], lo, c);
-      hi += c;
-      c = 0;
-      s = zk_adc(s, carry, c);
-      hi += c;
-      t[j - 1] = s;
-      carry = hi;
+    for (int j = 0; j < 8; ++j) {
+      c = (u64)A[j] * Bv[i] + t[j] + c;   // <= (2^32-1)^2 + 2(2^32-1) < 2^64
+      t[j] = (u32)c;
+      c >>= 32;
     }
-    c = 0;
-    t[3] = zk_adc(t[4], carry, c);
-    t[4] = t[5] + c;
+    c += t[8];
+    t[8] = (u32)c;
+    t[9] = (u32)(c >> 32);
+    const u32 m = t[0] * N0_32;
+    c = (u64)m * P32[0] + t[0];
+    c >>= 32;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      c = (u64)m * P32[j] + t[j] + c;
+      t[j - 1] = (u32)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[7] = (u32)c;
+    t[8] = t[9] + (u32)(c >> 32);
+  }
+  Fr r{{(u64)t[0] | ((u64)t[1] << 32), (u64)t[2] | ((u64)t[3] << 32), (u64)t[4] | ((u64)t[5] << 32),
+        (u64)t[6] | ((u64)t[7] << 32)}};
+  if (t[8] || fr_geq(r, fr_p())) {
+    u64 bw;
+    r = fr_sub_raw(r, fr_p(), bw);
+  }
+  return r;
+#else
+  const u64 p[4] = {ZK_P0, ZK_P1, ZK_P2, ZK_P3};
+  u64 t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    unsigned __int128 c = 0;
+    for (int j = 0; j < 4; ++j) {
+      c += (unsigned __int128)a.l[j] * b.l[i] + t[j];
+      t[j] = (u64)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (u64)c;
+    t[5] = (u64)(c >> 64);
+    const u64 m = t[0] * ZK_N0;
+    c = (unsigned __int128)m * p[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; ++j) {
+      c += (unsigned __int128)m * p[j] + t[j];
+      t[j - 1] = (u64)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (u64)c;
+    t[4] = t[5] + (u64)(c >> 64);
   }
   Fr r{{t[0], t[1], t[2], t[3]}};
   if (t[4] || fr_geq(r, fr_p())) {
@@ -163,6 +189,7 @@ ZK_HD Fr fr_mont_mul(const Fr& a, const Fr& b) {
     r = fr_sub_raw(r, fr_p(), bw);
   }
   return r;
+#endif
 }
 ZK_HD Fr fr_to_mont(const Fr& a) { return fr_mont_mul(a, fr_R2()); }
 ZK_HD Fr fr_from_mont(const Fr& a) { return fr_mont_mul(a, fr_from_u64(1)); }

@@ -14,14 +14,17 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   u64* bits = B.bits + (u64)e * s.img_bits;
   u32* small = B.small + (u64)e * s.img_small;
   const u32 N = s.fr[0].max_bytes;
-  u32* rev = small + s.m_rev;
+  // header bytes and the reveal array are staged in LDS: the scan is a serial byte loop
+  extern __shared__ u32 dyn_lds[];
+  u32* rev = dyn_lds;                 // N words
+  u8* hdr = (u8*)(dyn_lds + N);       // N bytes
   __shared__ u32 ok_sh;
   if (lane == 0) ok_sh = 1;
-  for (u32 i = lane; i < N; i += 64) rev[i] = 0;
+  for (u32 i = lane; i < N; i += 64) { rev[i] = 0; hdr[i] = rec[s.fr[0].in_data + i]; }
   __syncthreads();
   const u32 start = *(const u32*)(rec + s.in_off[8]);  // bodyHashIndex
   if (lane == 0) {
-    u32 matches = zk_bh_regex_scan(rec + s.fr[0].in_data, N, rev);
+    u32 matches = zk_bh_regex_scan(hdr, N, rev);
     if (matches == 0) ok_sh = 0;                        // bhRegexMatch === 1
     small[s.m_bh_idx] = start;
     bits[s.b_shift] = start;
@@ -31,6 +34,7 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
     if ((u64)start + 43 >= (1ull << s.sel_bits)) ok_sh = 0;  // GreaterThan(bl) Num2Bits at i = 0
   }
   __syncthreads();
+  for (u32 i = lane; i < N; i += 64) small[s.m_rev + i] = rev[i];
   // SelectRegexReveal assertions (utils/regex.circom:39-47)
   for (u32 i = lane; i < N; i += 64) {
     bool bad = false;

@@ -101,21 +101,21 @@ ZK_HD u256s u256_sub(const u256s& a, const u256s& b) {
 }
 ZK_HD bool u256_is_neg(const u256s& a) { return (a.l[3] >> 63) != 0; }
 ZK_HD bool u256_is_zero(const u256s& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
-// a * x + y, x small
+// a * x + y, x small (x < 2^32); y = 128-bit (two u64)
 ZK_HD u256s u256_mul_small_add(const u256s& a, u32 x, const u64* y2) {
-  u256s r; u64 carry = 0;
-  for (int i = 0; i < 4; ++i) {
-    u64 lo, hi;
-    zk_mul64(a.l[i], (u64)x, lo, hi);
-    u64 c = 0;
-    r.l[i] = zk_adc(lo, carry, c);
-    carry = hi + c;
-  }
+  // 8 x (32x32+64) multiply-adds: one v_mad_u64_u32 each on gfx950
+  u32 al[8];
+  for (int i = 0; i < 4; ++i) { al[2 * i] = (u32)a.l[i]; al[2 * i + 1] = (u32)(a.l[i] >> 32); }
+  const u32 yl[4] = {(u32)y2[0], (u32)(y2[0] >> 32), (u32)y2[1], (u32)(y2[1] >> 32)};
+  u32 rl[8];
   u64 c = 0;
-  r.l[0] = zk_adc(r.l[0], y2[0], c);
-  r.l[1] = zk_adc(r.l[1], y2[1], c);
-  r.l[2] = zk_adc(r.l[2], 0, c);
-  r.l[3] = zk_adc(r.l[3], 0, c);
+  for (int i = 0; i < 8; ++i) {
+    c = (u64)al[i] * x + (i < 4 ? yl[i] : 0u) + c;
+    rl[i] = (u32)c;
+    c >>= 32;
+  }
+  u256s r;
+  for (int i = 0; i < 4; ++i) r.l[i] = (u64)rl[2 * i] | ((u64)rl[2 * i + 1] << 32);
   return r;
 }
 // (a1:a0) * (b1:b0) -> 256-bit
