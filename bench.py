@@ -139,6 +139,16 @@ def main():
         bytes_per_email = 32 * c.W + c.in_stride
         achieved = bytes_per_email * tile / (ex_ms / ex_launches * 1e-3) / 1e9
         kernels_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in summ.items()}
+        # HBM traffic of zk_expand from PMC counters: collected separately with rocprofv3 (--pmc passes
+        # cannot run inside this process) and committed under profiles/; reported only for the exact
+        # workload it was measured on.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pm["tile"] == tile and pm["witness_len"] == c.W:
+                traffic = round(pm["traffic_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "EmailVerifier witnesses/sec", "value": round(value, 1), "unit": "witnesses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -149,7 +159,7 @@ def main():
                        "batch_per_gpu": args.batch, "tile": tile, "witness_len": c.W,
                        "witness_bytes": c.witness_bytes, "layout": "kept-v1", "parallelism": f"shard x{world}, result-table gather only"},
             "roofline": {"bound": "hbm", "kernel": "zk_expand", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": bytes_per_email * tile, "avg_launch_ms": round(ex_ms / ex_launches, 4),
                          "launches_timed": ex_launches},
             "kernel_ms_per_launch": kernels_ms,
