@@ -428,43 +428,88 @@ static fe poseidon_large(W* w, u64 (*pk)[2]) {
   return stt[0];
 }
 
-/* ------------------------------------------------------------------ BodyHashRegex (interface level) */
-static int is_b64(u8 c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '+' || c == '/' || c == '='; }
-/* backtracking matcher for ([a-z]+=[^;]+; )+bh=[a-zA-Z0-9+/=]+;  starting at d[pos]; tags = tags parsed so far */
-static int match_tags(const u8* d, int n, int pos, int tags, int* vs, int* ve) {
-  if (tags >= 1 && pos + 3 <= n && d[pos] == 'b' && d[pos + 1] == 'h' && d[pos + 2] == '=') {
-    int q = pos + 3;
-    while (q < n && is_b64(d[q])) ++q;
-    /* greedy [..]+ then ';' : the run is followed by a non-b64 byte, so only the full run can work */
-    if (q > pos + 3 && q < n && d[q] == ';') { *vs = pos + 3; *ve = q; return q + 1; }
+/* ------------------------------------------------------------------ BodyHashRegex: zkwg DFA circuit v1 */
+/* Restates oracle/pyref/zkemail.py BodyHashRegexV1 (the [EXT] zk-regex generated circuit is absent):
+ * tables from tools/gen_bh_dfa.py.  Emits the kept signals in component order and returns the match
+ * count; rev[] receives reveal0. */
+#include "bh_dfa_tables.h"
+static void multi_or_pair(W* w, unsigned cnt) { emit_u(w, cnt == 0); emit_fe(w, small_inv((long long)cnt)); }
+static unsigned body_hash_regex(W* w, const u8* msg, u32 N, u32* rev) {
+  const u32 nb = N + 1;
+  u8* in = (u8*)malloc(nb);
+  in[0] = 255; memcpy(in + 1, msg, N);
+  u8* st = (u8*)calloc(nb + 2, 1);        /* st[j]: active non-zero state before in[j] */
+  u8* fze = (u8*)calloc(nb + 1, 1);
+  unsigned acc_count = 0;
+  for (u32 i = 0; i < nb; ++i) {
+    unsigned s_ = st[i], nx = s_ ? ZK_DFA_DELTA[s_][in[i]] : 255;
+    fze[i] = nx == 255;
+    if (nx == 255) { nx = ZK_DFA_DELTA[0][in[i]]; if (nx == 255) nx = 0; }
+    st[i + 1] = (u8)nx;
+    acc_count += nx == ZK_DFA_ACCEPT;
   }
-  int q = pos;
-  while (q < n && d[q] >= 'a' && d[q] <= 'z') ++q;
-  if (q == pos) return -1;
-  /* [a-z]+ is followed by '=' which is not in [a-z]: the name is the full run */
-  if (q >= n || d[q] != '=') return -1;
-  int v = q + 1, e = v;
-  while (e < n && d[e] != ';') ++e;
-  if (e == v || e + 1 >= n || d[e] != ';' || d[e + 1] != ' ') return -1;
-  return match_tags(d, n, e + 2, tags + 1, vs, ve);
-}
-static unsigned body_hash_regex(const u8* msg, u32 N, u32* rev) {
-  u8* d = (u8*)malloc(N + 1);
-  d[0] = 255; memcpy(d + 1, msg, N);
-  const int n = (int)N + 1;
-  memset(rev, 0, N * sizeof(u32));
-  unsigned matches = 0;
-  int pos = 0;
-  while (pos < n) {
-    int s = -1;
-    if (d[pos] == 255) s = pos + 1; else if (pos + 1 < n && d[pos] == '\r' && d[pos + 1] == '\n') s = pos + 2;
-    int end = -1, vs = 0, ve = 0;
-    if (s >= 0 && s + 15 <= n && memcmp(d + s, "dkim-signature:", 15) == 0) end = match_tags(d, n, s + 15, 0, &vs, &ve);
-    if (end >= 0) { ++matches; for (int q = vs; q < ve; ++q) rev[q - 1] = d[q]; pos = end; }
-    else ++pos;
+  /* live chain (backwards) */
+  u8* live = (u8*)calloc(nb + 2, 1);
+  u8* c1 = (u8*)calloc(nb + 1, 1); u8* tt = (u8*)calloc(nb + 1, 1);
+  for (u32 j = nb; j >= 1; --j) {
+    unsigned c = (j < nb) ? (live[j + 1] & (1u - fze[j])) : 0;
+    unsigned acc = st[j] == ZK_DFA_ACCEPT;
+    c1[j - 1] = (u8)c; tt[j - 1] = (u8)((1u - acc) & c);
+    live[j] = (u8)(acc | tt[j - 1]);
   }
-  free(d);
-  return matches;
+  /* own signals: reveal0, live_c1, live_t, prev_states0, is_reveal0 */
+  u8* isrev = (u8*)calloc(N, 1);
+  for (u32 i = 0; i < N; ++i) {
+    unsigned sub = 0;
+    for (int k = 0; k < ZK_DFA_NPUBLIC; ++k) sub |= (st[i + 1] == ZK_DFA_PUBLIC[k][0] && st[i + 2] == ZK_DFA_PUBLIC[k][1]);
+    isrev[i] = (u8)(sub & live[i + 2]);
+    rev[i] = isrev[i] ? msg[i] : 0;
+  }
+  for (u32 i = 0; i < N; ++i) emit_u(w, rev[i]);
+  for (u32 j = 0; j < nb; ++j) emit_u(w, c1[j]);
+  for (u32 j = 0; j < nb; ++j) emit_u(w, tt[j]);
+  for (int k = 0; k < ZK_DFA_NPUBLIC; ++k)
+    for (u32 i = 0; i < N; ++i) emit_u(w, st[i + 1] == ZK_DFA_PUBLIC[k][0] && st[i + 2] == ZK_DFA_PUBLIC[k][1]);
+  for (u32 i = 0; i < N; ++i) emit_u(w, isrev[i]);
+  /* eq[n][i] */
+  for (int k = 0; k < ZK_DFA_NPRIM; ++k) if (ZK_DFA_PRIM[k][0] == 0)
+    for (u32 i = 0; i < nb; ++i) iszero_small(w, (long long)ZK_DFA_PRIM[k][1] - (long long)in[i]);
+  /* lt[2n][i], lt[2n+1][i] */
+  for (int k = 0; k < ZK_DFA_NPRIM; ++k) if (ZK_DFA_PRIM[k][0] == 1) {
+    for (u32 i = 0; i < nb; ++i) lessthan(w, 8, fe_u64(ZK_DFA_PRIM[k][1] - 1), fe_u64(in[i]));
+    for (u32 i = 0; i < nb; ++i) lessthan(w, 8, fe_u64(in[i]), fe_u64(ZK_DFA_PRIM[k][2] + 1));
+  }
+  for (int k = 0; k < ZK_DFA_NPRIM; ++k) if (ZK_DFA_PRIM[k][0] == 1)
+    for (u32 i = 0; i < nb; ++i) emit_u(w, in[i] >= ZK_DFA_PRIM[k][1] && in[i] <= ZK_DFA_PRIM[k][2]);
+  /* cls_or[n][i] */
+  for (int k = 0; k < ZK_DFA_NCLASS; ++k) if (ZK_DFA_CLASS[k][1] > 1)
+    for (u32 i = 0; i < nb; ++i) multi_or_pair(w, (unsigned)__builtin_popcount(ZK_DFA_PRIMMASK[in[i]] & ZK_DFA_CLASS_MEMBERS[k]));
+  /* and[t][i] */
+  for (int t = 0; t < ZK_DFA_NTRANS; ++t)
+    for (u32 i = 0; i < nb; ++i) {
+      unsigned from = ZK_DFA_TRANS[t][0], on = from ? (st[i] == from) : fze[i];
+      emit_u(w, on & ((ZK_DFA_CLSMASK[in[i]] >> ZK_DFA_TRANS[t][2]) & 1u));
+    }
+  /* tmp_or[n][i] */
+  for (int d = 1; d < ZK_DFA_STATES; ++d) {
+    int nz = 0;
+    for (int t = 0; t < ZK_DFA_NTRANS; ++t) nz += (ZK_DFA_TRANS[t][1] == d && ZK_DFA_TRANS[t][0] != 0);
+    if (nz > 1) for (u32 i = 0; i < nb; ++i) multi_or_pair(w, st[i] && ZK_DFA_DELTA[st[i]][in[i]] == d);
+  }
+  for (u32 i = 0; i < nb; ++i) { emit_u(w, fze[i]); emit_u(w, 1u - fze[i]); }   /* fze[i] = MultiNOR: is_zero.out, inv(sum) */
+  for (int d = 1; d < ZK_DFA_STATES; ++d) {
+    int nz = 0, z = 0;
+    for (int t = 0; t < ZK_DFA_NTRANS; ++t) if (ZK_DFA_TRANS[t][1] == d) { if (ZK_DFA_TRANS[t][0]) ++nz; else ++z; }
+    if (nz && z) for (u32 i = 0; i < nb; ++i) multi_or_pair(w, st[i + 1] == d);
+  }
+  multi_or_pair(w, acc_count);                                                   /* is_accepted */
+  for (u32 i = 0; i < N; ++i) {
+    unsigned cnt = 0;
+    for (int k = 0; k < ZK_DFA_NPUBLIC; ++k) cnt += (st[i + 1] == ZK_DFA_PUBLIC[k][0] && st[i + 2] == ZK_DFA_PUBLIC[k][1]);
+    multi_or_pair(w, cnt);
+  }
+  free(in); free(st); free(fze); free(live); free(c1); free(tt); free(isrev);
+  return acc_count;
 }
 
 /* ------------------------------------------------------------------ main circuits */
@@ -508,8 +553,7 @@ static void email_verifier(W* w, const ocfg* c, const u8* header, u32 hlen, cons
     num2bits(w, fe_u64(blen), log2ceil(M));
     assert_zero_padding(w, body, M, blen);
     u32* rev = (u32*)malloc(N * sizeof(u32));
-    if (body_hash_regex(header, N, rev) == 0) fail(w);
-    for (u32 i = 0; i < N; ++i) emit_u(w, rev[i]);
+    if (body_hash_regex(w, header, N, rev) == 0) fail(w);
     /* SelectRegexReveal(N, 44) */
     const unsigned bl = log2ceil((u64)N + 43);
     for (u32 i = 0; i < N; ++i) {

@@ -715,3 +715,212 @@ def BodyHashRegex(msg_bytes, msg):
     reveal0.setall(rev, "Q")
     c.o = (out.v[0], reveal0.v)
     return c
+
+
+# ------------------------------------------------------------ BodyHashRegex, DFA circuit (zkwg v1)
+import json as _json
+import os as _os
+
+_DFA = None
+
+
+def bh_dfa():
+    global _DFA
+    if _DFA is None:
+        p = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "zk-email-verify_amd", "data", "bh_dfa.json")
+        _DFA = _json.load(open(p))
+    return _DFA
+
+
+def MultiOR(n, ins):
+    """[EXT] zk-regex regex_helpers.circom MultiOR(n): sums (linear); is_zero = IsZero(sum); out <== 1 - is_zero.out."""
+    c = Comp(f"MultiOR({n})")
+    out = c.out("out")
+    c.inp("in", n).setall(ins, "L")
+    sums = c.mid("sums", n)
+    acc = 0
+    for i in range(n):
+        acc = (acc + ins[i]) % P
+        sums.set(acc, "L", i)
+    isz = c.sub("is_zero", cl.IsZero(acc))
+    c.o = out.set(1 - isz.o, "L")
+    return c
+
+
+def MultiNOR(n, ins):
+    """[EXT] regex_helpers.circom MultiNOR(n): out <== IsZero(sum).out."""
+    c = Comp(f"MultiNOR({n})")
+    out = c.out("out")
+    c.inp("in", n).setall(ins, "L")
+    isz = c.sub("is_zero", cl.IsZero(sum(ins) % P))
+    c.o = out.set(isz.o, "L")
+    return c
+
+
+def BodyHashRegexV1(msg_bytes, msg):
+    """zkwg's own DFA circuit for the body-hash regex, in the style of zk-regex's generated circom
+    (the real generated file is [EXT] and absent -- parity unpinned).  Tables:
+    zk-email-verify_amd/data/bh_dfa.json (tools/gen_bh_dfa.py).
+
+    in[0] = 255 (stands for `^`), in[i+1] = msg[i].  State 0 is permanently active; a transition out of
+    state 0 fires only when no other state continues (from_zero_enabled).  Component arrays are declared
+    [k][num_bytes] (kind-major), like zk-regex's eq/lt/and arrays.
+    """
+    T = bh_dfa()
+    S, ACC = T["n_states"], T["accept"]
+    prims, classes, trans, public = T["prims"], T["classes"], T["transitions"], T["public"]
+    nb = msg_bytes + 1
+    c = Comp(f"BodyHashRegex({msg_bytes})")
+    out = c.out("out")
+    reveal0 = c.out("reveal0", msg_bytes)
+    c.inp("msg", msg_bytes).setall(msg, "L")
+    in_sig = c.mid("in", nb)
+    in_ = [255] + [int(x) % P for x in msg]
+    in_sig.setall(in_, "L")
+    st_sig = c.mid("states", (nb + 1) * S)
+    tmp_sig = c.mid("states_tmp", (nb + 1) * S)
+    fze_sig = c.mid("from_zero_enabled", nb + 1)
+    live_c1 = c.mid("live_c1", nb)
+    live_t = c.mid("live_t", nb)
+    live = c.mid("live", nb + 2)
+    prev_sig = c.mid("prev_states0", len(public) * msg_bytes)
+    substr_sig = c.mid("is_substr0", msg_bytes)
+    isrev_sig = c.mid("is_reveal0", msg_bytes)
+
+    eq_idx = [k for k, p in enumerate(prims) if p[0] == "eq"]
+    rg_idx = [k for k, p in enumerate(prims) if p[0] == "range"]
+    multi_cls = [k for k, cdef in enumerate(classes) if len(cdef["members"]) > 1]
+    incoming = {d: [] for d in range(S)}
+    for t_i, (f, to, cid) in enumerate(trans):
+        incoming[to].append(t_i)
+    tmp_multi = [d for d in range(1, S) if len([t for t in incoming[d] if trans[t][0] != 0]) > 1]
+    st_multi = [d for d in range(1, S) if [t for t in incoming[d] if trans[t][0] == 0] and [t for t in incoming[d] if trans[t][0] != 0]]
+
+    eq = {k: [None] * nb for k in eq_idx}
+    lt = {k: [None] * nb for k in rg_idx}        # (lo-side, hi-side)
+    and_rng = {k: [None] * nb for k in rg_idx}
+    cls_or = {k: [None] * nb for k in multi_cls}
+    and_t = [[None] * nb for _ in trans]
+    tmp_or = {d: [None] * nb for d in tmp_multi}
+    fze_c = [None] * nb
+    st_or = {d: [None] * nb for d in st_multi}
+
+    states = [[0] * S for _ in range(nb + 1)]
+    tmps = [[0] * S for _ in range(nb + 1)]
+    fze = [0] * (nb + 1)
+    for j in range(nb + 1):
+        states[j][0] = 1
+    for i in range(nb):
+        b = in_[i]
+        pv = {}
+        for k in eq_idx:
+            eq[k][i] = cl.IsEqual(b, prims[k][1])
+            pv[k] = eq[k][i].o
+        for k in rg_idx:
+            lo, hi = prims[k][1], prims[k][2]
+            a = cl.LessThan(8, lo - 1, b)
+            bb = cl.LessThan(8, b, hi + 1)
+            lt[k][i] = (a, bb)
+            and_rng[k][i] = cl.AND(a.o, bb.o)
+            pv[k] = and_rng[k][i].o
+        cv = []
+        for k, cdef in enumerate(classes):
+            if len(cdef["members"]) > 1:
+                cls_or[k][i] = MultiOR(len(cdef["members"]), [pv[m] for m in cdef["members"]])
+                v = cls_or[k][i].o
+            else:
+                v = pv[cdef["members"][0]]
+            cv.append((1 - v) % P if cdef["neg"] else v)
+        # transitions from non-zero states
+        for t_i, (f, to, cid) in enumerate(trans):
+            if f != 0:
+                and_t[t_i][i] = cl.AND(states[i][f], cv[cid])
+        for d in range(1, S):
+            inc = [t for t in incoming[d] if trans[t][0] != 0]
+            if len(inc) == 0:
+                tmps[i + 1][d] = 0
+            elif len(inc) == 1:
+                tmps[i + 1][d] = and_t[inc[0]][i].o
+            else:
+                tmp_or[d][i] = MultiOR(len(inc), [and_t[t][i].o for t in inc])
+                tmps[i + 1][d] = tmp_or[d][i].o
+        fze_c[i] = MultiNOR(S - 1, tmps[i + 1][1:])
+        fze[i] = fze_c[i].o
+        for t_i, (f, to, cid) in enumerate(trans):
+            if f == 0:
+                and_t[t_i][i] = cl.AND(fze[i], cv[cid])
+        for d in range(1, S):
+            z = [t for t in incoming[d] if trans[t][0] == 0]
+            if not z:
+                states[i + 1][d] = tmps[i + 1][d]
+            elif d in st_multi:
+                st_or[d][i] = MultiOR(2, [tmps[i + 1][d], and_t[z[0]][i].o])
+                states[i + 1][d] = st_or[d][i].o
+            else:
+                states[i + 1][d] = and_t[z[0]][i].o
+    fze[nb] = 0
+    is_accepted = MultiOR(nb + 1, [states[j][ACC] for j in range(nb + 1)])
+    out.set(is_accepted.o, "L")
+    # live[j]: the thread that is in states[j] reaches the accept state without restarting
+    lv = [0] * (nb + 2)
+    for j in range(nb, 0, -1):
+        c1 = (lv[j + 1] * (1 - fze[j])) % P if j < nb else 0
+        live_c1.set(c1, "Q", j - 1)
+        tt = ((1 - states[j][ACC]) * c1) % P
+        live_t.set(tt, "Q", j - 1)
+        lv[j] = (states[j][ACC] + tt) % P
+    live.setall(lv, "L")
+    rev = [0] * msg_bytes
+    substr_or = [None] * msg_bytes
+    for i in range(msg_bytes):
+        pvals = []
+        for k, (s_, d_) in enumerate(public):
+            v = states[i + 1][s_] * states[i + 2][d_]
+            prev_sig.set(v, "Q", k * msg_bytes + i)
+            pvals.append(v)
+        substr_or[i] = MultiOR(len(public), pvals)
+        substr_sig.set(substr_or[i].o, "L", i)
+        ir = (substr_or[i].o * lv[i + 2]) % P
+        isrev_sig.set(ir, "Q", i)
+        rev[i] = (in_[i + 1] * ir) % P
+    reveal0.setall(rev, "Q")
+    flat = []
+    for j in range(nb + 1):
+        flat += states[j]
+    st_sig.setall(flat, "L")
+    flat = []
+    for j in range(nb + 1):
+        flat += tmps[j]
+    tmp_sig.setall(flat, "L")
+    fze_sig.setall(fze, "L")
+    # sub-components in declaration order, kind-major like zk-regex's `component eq[..][num_bytes]`
+    for n_, k in enumerate(eq_idx):
+        for i in range(nb):
+            c.sub(f"eq[{n_}][{i}]", eq[k][i])
+    for n_, k in enumerate(rg_idx):
+        for i in range(nb):
+            c.sub(f"lt[{2 * n_}][{i}]", lt[k][i][0])
+        for i in range(nb):
+            c.sub(f"lt[{2 * n_ + 1}][{i}]", lt[k][i][1])
+    for n_, k in enumerate(rg_idx):
+        for i in range(nb):
+            c.sub(f"and_rng[{n_}][{i}]", and_rng[k][i])
+    for n_, k in enumerate(multi_cls):
+        for i in range(nb):
+            c.sub(f"cls_or[{n_}][{i}]", cls_or[k][i])
+    for t_i in range(len(trans)):
+        for i in range(nb):
+            c.sub(f"and[{t_i}][{i}]", and_t[t_i][i])
+    for n_, d in enumerate(tmp_multi):
+        for i in range(nb):
+            c.sub(f"tmp_or[{n_}][{i}]", tmp_or[d][i])
+    for i in range(nb):
+        c.sub(f"fze[{i}]", fze_c[i])
+    for n_, d in enumerate(st_multi):
+        for i in range(nb):
+            c.sub(f"st_or[{n_}][{i}]", st_or[d][i])
+    c.sub("is_accepted", is_accepted)
+    for i in range(msg_bytes):
+        c.sub(f"substr_or[{i}]", substr_or[i])
+    c.o = (out.v[0], reveal0.v)
+    return c

@@ -8,7 +8,7 @@ import hosttest
 
 def _oracle_ev(N, M, ignore, inp):
     from oracle.pyref import zkemail as zk
-    return zk.EmailVerifier(N, M, 121, 17, ignore, inp, body_hash_regex=lambda m: zk.BodyHashRegex(N, m))
+    return zk.EmailVerifier(N, M, 121, 17, ignore, inp, body_hash_regex=lambda m: zk.BodyHashRegexV1(N, m))
 
 
 def _inputs(N, M, ignore, index=0, body_len=100):
@@ -53,6 +53,23 @@ def test_poseidon_known_vectors():
     from oracle.pyref import poseidon
     assert poseidon.poseidon_hash([1, 2]) == 7853200120776062878684798364095072458815029376092732009249414926327459813530
     assert poseidon.poseidon_hash([1, 2, 3, 4]) == 18821383157269793795438455681495246036402687001665670618754263018637548127333
+
+
+def test_dfa_circuit_agrees_with_python_re_on_fuzzed_headers():
+    """The DFA circuit (zkwg v1) and the interface-level restatement (Python `re`) reveal the same bytes."""
+    from oracle.pyref import zkemail as zk
+    from zkwg import synth
+    rng = random.Random(9)
+    N = 320
+    for i in range(12):
+        hdr = bytearray(synth.synthetic_dkim_result(4, i, body_len=60)["headers"][-300:])
+        if i % 3 == 1:
+            hdr[rng.randrange(len(hdr))] = rng.randrange(256)
+        if i % 3 == 2:
+            hdr = b"\r\ndkim-signature:a=b; bh=QUJD; x\r\n" + hdr[:250]
+        msg = list(bytes(hdr[:N]).ljust(N, b"\0"))
+        a, b = zk.BodyHashRegexV1(N, msg), zk.BodyHashRegex(N, msg)
+        assert a.o == b.o
 
 
 def test_regex_scanner_vs_python_re():

@@ -66,6 +66,9 @@ static void build_inv_table(u32 inv_half, std::vector<Fr>& tab) {
   }
 }
 
+extern "C" int zk_expand_init_tables(void);
+extern "C" int zk_misc_init_tables(void);
+
 extern "C" {
 
 int zkwg_abi_version(void) { return ZKWG_ABI_VERSION; }
@@ -114,6 +117,7 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return ZKWG_RC_NO_DEVICE; }
     if (hipSetDevice(device) != hipSuccess) { delete c; return ZKWG_RC_HIP_ERROR; }
     c->device = device;
+    if (zk_expand_init_tables() != 0 || zk_misc_init_tables() != 0) { delete c; return ZKWG_RC_HIP_ERROR; }
     std::vector<Fr> tab;
     build_inv_table(c->s.inv_half, tab);
     bool ok = hipMalloc((void**)&c->d_invtab, tab.size() * sizeof(Fr)) == hipSuccess &&
@@ -293,7 +297,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     hipLaunchKernelGGL(zk_sha_trace, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
   }
   if (tm) hipEventRecord(evs[++ki], st);
-  if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 5 * s.fr[0].max_bytes, st, s, B);
+  if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 7 * s.fr[0].max_bytes + 64, st, s, B);
   if (tm) hipEventRecord(evs[++ki], st);
   if (s.rsa.present) hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), 0, st, s, B);
   if (tm) { hipEventRecord(evs[++ki], st); c->prep_valid = true; c->prep_launches++; }

@@ -5,6 +5,12 @@
 #include "zkwg_dev.h"
 #include "zkwg_kernels.h"
 #include "zkwg_regex_core.h"
+#include "zkwg_bh_dfa.h"
+
+static __constant__ unsigned char ZKM_DELTA[ZK_DFA_STATES][256];
+extern "C" int zk_misc_init_tables(void) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(ZKM_DELTA), ZK_DFA_DELTA, sizeof(ZK_DFA_DELTA)) == hipSuccess ? 0 : -1;
+}
 
 __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   const u32 e = blockIdx.x;
@@ -18,14 +24,58 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   extern __shared__ u32 dyn_lds[];
   u32* rev = dyn_lds;                 // N words
   u8* hdr = (u8*)(dyn_lds + N);       // N bytes
+  u8* stl = hdr + N;                  // N + 3 state bytes (st[0..N+2))
+  u8* live = stl + N + 4;             // N + 3
   __shared__ u32 ok_sh;
   if (lane == 0) ok_sh = 1;
   for (u32 i = lane; i < N; i += 64) { rev[i] = 0; hdr[i] = rec[s.fr[0].in_data + i]; }
   __syncthreads();
   const u32 start = *(const u32*)(rec + s.in_off[8]);  // bodyHashIndex
   if (lane == 0) {
-    u32 matches = zk_bh_regex_scan(hdr, N, rev);
-    if (matches == 0) ok_sh = 0;                        // bhRegexMatch === 1
+    // BodyHashRegex DFA (zkwg v1 circuit): state 0 is always active, a transition out of state 0
+    // fires only when no other state continues; st[j] = the active non-zero state before in[j] (0: none)
+    const u32 nb = N + 1;
+    u32 st = 0, acc_count = 0;
+    stl[0] = 0;
+    for (u32 i = 0; i < nb; ++i) {
+      const u32 b = i == 0 ? 255u : hdr[i - 1];
+      u32 nx = st ? ZKM_DELTA[st][b] : 255u;
+      if (nx == 255u) { nx = ZKM_DELTA[0][b]; if (nx == 255u) nx = 0; }
+      st = nx;
+      stl[i + 1] = (u8)st;
+      acc_count += (st == ZK_DFA_ACCEPT);
+    }
+    stl[nb + 1] = 0;
+    if (acc_count == 0) ok_sh = 0;                      // bhRegexMatch === 1
+    small[s.m_dfa_acc] = acc_count;
+    // live[j] (j = nb .. 1): the thread in st[j] reaches the accept state without restarting
+    u32* own = small + s.m_dfa_own;                     // live_c1[nb], live_t[nb], prev[NP][N], is_reveal0[N]
+    live[nb + 1] = 0;
+    for (u32 j = nb; j >= 1; --j) {
+      const u32 b = hdr[j - 1 < N ? j - 1 : 0];
+      u32 c1 = 0;
+      if (j < nb) {                                     // fze[j] = no non-zero-origin transition at position j
+        const u32 sj = stl[j];
+        const u32 fze = sj ? (ZKM_DELTA[sj][b] == 255u) : 1u;
+        c1 = live[j + 1] & (1u - fze);
+      }
+      const u32 acc = stl[j] == ZK_DFA_ACCEPT;
+      const u32 tt = (1u - acc) & c1;
+      own[j - 1] = c1;
+      own[nb + j - 1] = tt;
+      live[j] = (u8)(acc | tt);
+    }
+    for (u32 i = 0; i < N; ++i) {
+      u32 sub = 0;
+      for (u32 k = 0; k < ZK_DFA_NPUBLIC; ++k) {
+        const u32 pv = (stl[i + 1] == ZK_DFA_PUBLIC[k][0] && stl[i + 2] == ZK_DFA_PUBLIC[k][1]);
+        own[2 * nb + k * N + i] = pv;
+        sub |= pv;
+      }
+      const u32 ir = sub & live[i + 2];
+      own[2 * nb + ZK_DFA_NPUBLIC * N + i] = ir;
+      rev[i] = ir ? hdr[i] : 0;
+    }
     small[s.m_bh_idx] = start;
     bits[s.b_shift] = start;
     u32 blh = 0;
@@ -35,6 +85,10 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   }
   __syncthreads();
   for (u32 i = lane; i < N; i += 64) small[s.m_rev + i] = rev[i];
+  {  // packed state bytes for zk_expand
+    u8* dst_st = (u8*)(small + s.m_dfa_st);
+    for (u32 i = lane; i < N + 3; i += 64) dst_st[i] = stl[i];
+  }
   // SelectRegexReveal assertions (utils/regex.circom:39-47)
   for (u32 i = lane; i < N; i += 64) {
     bool bad = false;

@@ -17,6 +17,7 @@
 #include <vector>
 #include <functional>
 #include "zkwg_sched.h"
+#include "zkwg_bh_dfa.h"
 
 struct ZkWalker {
   u64 cur = 0;        // next free slot (advanced by one/arr/skip)
@@ -241,6 +242,95 @@ static inline void zk_walk_main_rsa(ZkWalker& w, ZkSched& s) {
   s.n_public = 17;
 }
 
+// ------------------------------------------------------------------ BodyHashRegex DFA circuit (zkwg v1)
+// [EXT] zk-regex's generated body_hash_regex.circom is absent; this is zkwg's own circuit of the same
+// style over the DFA tables of tools/gen_bh_dfa.py (restated literally in oracle/pyref/zkemail.py
+// BodyHashRegexV1).  Component arrays are [k][num_bytes], kind-major.
+static inline void zk_alloc_bh_regex(ZkWalker& w, ZkSched& s, u32 N) {
+  const u32 nb = N + 1;
+  s.m_rev = w.alloc_small(N);
+  s.m_dfa_own = w.alloc_small(2 * nb + ZK_DFA_NPUBLIC * N + N);
+  s.m_dfa_st = w.alloc_small((nb + 1 + 3) / 4 + 1);
+  s.m_dfa_acc = w.alloc_small(1);
+}
+static inline void zk_walk_bh_regex(ZkWalker& w, const std::string& p, const ZkSched& s, u32 N) {
+  const u32 nb = N + 1;
+  auto arr2 = [&](const std::string& base, u32 k, u32 n, const char* a, const char* b) {
+    if (!w.names) { w.skip(2 * (u64)n); return; }
+    for (u32 i = 0; i < n; ++i) {
+      std::string q = base + "[" + std::to_string(k) + "][" + std::to_string(i) + "]";
+      w.one(q + a); w.one(q + b);
+    }
+  };
+  // own signals: outputs (reveal0), then the quadratic intermediates
+  w.seg(ZSEG_SMALL, N, s.m_rev);
+  w.arr(p + ".reveal0", N);
+  w.seg(ZSEG_SMALL, 2 * nb + ZK_DFA_NPUBLIC * N + N, s.m_dfa_own);
+  w.arr(p + ".live_c1", nb); w.arr(p + ".live_t", nb);
+  w.arr(p + ".prev_states0", ZK_DFA_NPUBLIC * N); w.arr(p + ".is_reveal0", N);
+  // eq[n][i]
+  u32 n_eq = 0, n_rg = 0;
+  for (u32 k = 0; k < ZK_DFA_NPRIM; ++k) if (ZK_DFA_PRIM[k][0] == 0) {
+    w.seg(ZSEG_DFA, 2 * (u64)nb, s.m_dfa_st, ZDFA_EQ, ZK_DFA_PRIM[k][1]);
+    arr2(p + ".eq", n_eq++, nb, ".isz.out", ".isz.inv");
+  }
+  // lt[2n][i] = LessThan(8)(lo-1, in), lt[2n+1][i] = LessThan(8)(in, hi+1)
+  for (u32 k = 0; k < ZK_DFA_NPRIM; ++k) if (ZK_DFA_PRIM[k][0] == 1) {
+    const u32 lo = ZK_DFA_PRIM[k][1], hi = ZK_DFA_PRIM[k][2];
+    for (u32 side = 0; side < 2; ++side) {
+      // n2b.in = in[0] + 256 - in[1]:  side 0: (lo-1) + 256 - in ; side 1: in + 256 - (hi+1)
+      w.seg(ZSEG_DFA, 9 * (u64)nb, s.m_dfa_st, ZDFA_LT, side == 0 ? lo + 255 : 255 - hi, side);
+      if (!w.names) w.skip(9 * (u64)nb);
+      else for (u32 i = 0; i < nb; ++i)
+        w.arr(p + ".lt[" + std::to_string(2 * n_rg + side) + "][" + std::to_string(i) + "].n2b.out", 9);
+    }
+    ++n_rg;
+  }
+  n_rg = 0;
+  for (u32 k = 0; k < ZK_DFA_NPRIM; ++k) if (ZK_DFA_PRIM[k][0] == 1) {
+    w.seg(ZSEG_DFA, nb, s.m_dfa_st, ZDFA_RNG, ZK_DFA_PRIM[k][1], ZK_DFA_PRIM[k][2]);
+    if (!w.names) w.skip(nb);
+    else for (u32 i = 0; i < nb; ++i) w.one(p + ".and_rng[" + std::to_string(n_rg) + "][" + std::to_string(i) + "].out");
+    ++n_rg;
+  }
+  u32 n_cls = 0;
+  for (u32 k = 0; k < ZK_DFA_NCLASS; ++k) if (ZK_DFA_CLASS[k][1] > 1) {
+    w.seg(ZSEG_DFA, 2 * (u64)nb, s.m_dfa_st, ZDFA_CLS, k, ZK_DFA_CLASS_MEMBERS[k]);
+    arr2(p + ".cls_or", n_cls++, nb, ".is_zero.out", ".is_zero.inv");
+  }
+  for (u32 t = 0; t < ZK_DFA_NTRANS; ++t) {
+    w.seg(ZSEG_DFA, nb, s.m_dfa_st, ZDFA_AND, ZK_DFA_TRANS[t][0], ZK_DFA_TRANS[t][2]);
+    if (!w.names) w.skip(nb);
+    else for (u32 i = 0; i < nb; ++i) w.one(p + ".and[" + std::to_string(t) + "][" + std::to_string(i) + "].out");
+  }
+  // states with several incoming non-zero-origin transitions (tmp_or), and with both kinds (st_or)
+  u32 n_tmp = 0, n_st = 0;
+  for (u32 d = 1; d < ZK_DFA_STATES; ++d) {
+    u32 nz = 0;
+    for (u32 t = 0; t < ZK_DFA_NTRANS; ++t) if (ZK_DFA_TRANS[t][1] == d && ZK_DFA_TRANS[t][0] != 0) ++nz;
+    if (nz > 1) {
+      w.seg(ZSEG_DFA, 2 * (u64)nb, s.m_dfa_st, ZDFA_TMP, d);
+      arr2(p + ".tmp_or", n_tmp++, nb, ".is_zero.out", ".is_zero.inv");
+    }
+  }
+  w.seg(ZSEG_DFA, 2 * (u64)nb, s.m_dfa_st, ZDFA_FZE);
+  if (!w.names) w.skip(2 * (u64)nb);
+  else for (u32 i = 0; i < nb; ++i) { w.one(zk_idx(p + ".fze", i) + ".is_zero.out"); w.one(zk_idx(p + ".fze", i) + ".is_zero.inv"); }
+  for (u32 d = 1; d < ZK_DFA_STATES; ++d) {
+    u32 nz = 0, z = 0;
+    for (u32 t = 0; t < ZK_DFA_NTRANS; ++t) if (ZK_DFA_TRANS[t][1] == d) { if (ZK_DFA_TRANS[t][0] != 0) ++nz; else ++z; }
+    if (nz && z) {
+      w.seg(ZSEG_DFA, 2 * (u64)nb, s.m_dfa_st, ZDFA_ST, d);
+      arr2(p + ".st_or", n_st++, nb, ".is_zero.out", ".is_zero.inv");
+    }
+  }
+  w.seg(ZSEG_ISZ, 2, s.m_dfa_acc);
+  w.one(p + ".is_accepted.is_zero.out"); w.one(p + ".is_accepted.is_zero.inv");
+  w.seg(ZSEG_DFA, 2 * (u64)N, s.m_dfa_st, ZDFA_SUB);
+  if (!w.names) w.skip(2 * (u64)N);
+  else for (u32 i = 0; i < N; ++i) { w.one(zk_idx(p + ".substr_or", i) + ".is_zero.out"); w.one(zk_idx(p + ".substr_or", i) + ".is_zero.inv"); }
+}
+
 // ------------------------------------------------------------------ EmailVerifier main
 // (packages/circuits/email-verifier.circom:42-174, flags (ignoreBodyHashCheck, 0, 0, 0),
 //  `component main { public [ pubkey ] }`, tests/test-circuits/email-verifier-test.circom:5)
@@ -273,7 +363,7 @@ static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
     zk_frame_len_alloc(w, s.fr[1]);
     zk_alloc_sha_frame(w, s.fr[1]);
     s.m_bh_idx = w.alloc_small(1);
-    s.m_rev = w.alloc_small(N);
+    zk_alloc_bh_regex(w, s, N);
     s.m_chars = w.alloc_small(44);
     s.b_shift = w.alloc_bits(1);
     s.sel_bits = zk_log2ceil((u64)N + 44 - 1);
@@ -306,9 +396,7 @@ static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
     w.seg(ZSEG_BITS, blb, s.fr[1].b_len, blb, 1);
     w.arr("main.n2bBodyLength.out", blb);
     zk_walk_azp(w, "main.anon_AssertZeroPadding_body", s.fr[1]);
-    // BodyHashRegex [EXT]: interface level only (reveal0), see DESIGN.md
-    w.seg(ZSEG_SMALL, N, s.m_rev);
-    w.arr("main.anon_BodyHashRegex.reveal0", N);
+    zk_walk_bh_regex(w, "main.anon_BodyHashRegex", s, N);
     // SelectRegexReveal(N, 44) (utils/regex.circom:17-52)
     const std::string sr = "main.anon_SelectRegexReveal";
     const u32 bl = s.sel_bits, per = 6 + bl + 1;

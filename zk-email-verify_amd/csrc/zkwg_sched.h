@@ -46,7 +46,21 @@ enum ZkSegType : u32 {
   ZSEG_VSHIFT = 13, // VarShiftLeft(a, .).tmp[j][i] = small[b + (i + (shift & (2^(j+1)-1))) % a], shift=small[src]
   ZSEG_B64BITS = 14,// Base64Decode bitsIn: 6 bits of the decoded value of char small[src + r/6]
   ZSEG_B64 = 15,    // Base64Lookup(char small[src + r/68]): 8 mids, 6 x 9 comparator bits, 3 IsZero pairs
-  ZSEG_NTYPES = 16
+  ZSEG_DFA = 16,    // BodyHashRegex DFA circuit arrays: a = ZkDfaKind, b/c = parameters, src = small idx of the packed state bytes
+  ZSEG_NTYPES = 17
+};
+
+// ZSEG_DFA kinds (component arrays of the regex circuit, one entry per header position)
+enum ZkDfaKind : u32 {
+  ZDFA_EQ = 0,   // IsEqual(in[i], b): (isz.out, isz.inv), isz.in = b - in[i]
+  ZDFA_LT = 1,   // LessThan(8) Num2Bits(9) of  b + (c ? +in[i] : -in[i])
+  ZDFA_RNG = 2,  // AND: b <= in[i] <= c
+  ZDFA_CLS = 3,  // MultiOR over the primitive tests in mask c: (is_zero.out, is_zero.inv)
+  ZDFA_AND = 4,  // transition gate: from-state b (0: from_zero_enabled[i]), class c
+  ZDFA_TMP = 5,  // MultiOR states_tmp[i+1][b]: (is_zero.out, is_zero.inv)
+  ZDFA_FZE = 6,  // MultiNOR -> from_zero_enabled[i]: (is_zero.out, is_zero.inv)
+  ZDFA_ST = 7,   // MultiOR(2) states[i+1][b]: (is_zero.out, is_zero.inv)
+  ZDFA_SUB = 8   // MultiOR over the public transitions at message index i: (is_zero.out, is_zero.inv)
 };
 
 struct ZkSeg {
@@ -143,6 +157,10 @@ struct ZkSched {
   u32 m_chars;           // small: bhBase64[44]
   u32 b_shift;           // bits: 1 word, bodyHashIndex (VarShiftLeft.n2b)
   u32 sel_bits;          // log2Ceil(max_header + 43)
+  // BodyHashRegex DFA circuit (zkwg v1)
+  u32 m_dfa_st;          // small: packed state bytes st[0..max_header+1] (4 per word)
+  u32 m_dfa_own;         // small: live_c1[nb], live_t[nb], prev_states0[NP][N], is_reveal0[N]
+  u32 m_dfa_acc;         // small: number of positions in the accept state
 };
 
 #if defined(__HIPCC__)
