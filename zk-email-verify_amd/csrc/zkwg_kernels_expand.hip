@@ -18,16 +18,6 @@
 #include "zkwg_kernels.h"
 #include "zkwg_bh_dfa.h"
 
-// DFA tables of the body-hash regex in constant memory (tools/gen_bh_dfa.py)
-static __constant__ unsigned char ZKD_DELTA[ZK_DFA_STATES][256];
-static __constant__ unsigned int ZKD_PRIMMASK[256];
-static __constant__ unsigned int ZKD_CLSMASK[256];
-static __constant__ unsigned char ZKD_PUBLIC[ZK_DFA_NPUBLIC][2];
-
-
-// chunk c (16-byte units, absolute within the email's witness) of a segment, per type.
-// r = slot index inside the segment, half = 0 (low 16 bytes) / 1 (high 16 bytes).
-
 // WAVE_MODE = false: one workgroup per (portion, email group), threads interleaved over the portion.
 // WAVE_MODE = true : one WAVEFRONT per (portion, email group): every wave writes its own contiguous
 //                    portion (1 KiB per store instruction, back to back), 4 such waves per workgroup.
@@ -295,25 +285,28 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
       }
       case ZSEG_DFA: {
         // BodyHashRegex DFA circuit arrays (zkwg_layout.h zk_walk_bh_regex): one entry per position i of
-        // in[] = [255, header...]; everything derives from (in[i], st[i], st[i+1]).
+        // in[] = [255, header...].  zk_misc_ev left one word per position: in | st<<8 | nx<<16 | st_next<<24
+        // (nx = the transition out of a non-zero state, 255 = none) plus the class / primitive truth masks.
         const u32 kind = sg.a;
         const u32 per = (kind == ZDFA_LT) ? 9u : ((kind == ZDFA_RNG || kind == ZDFA_AND) ? 1u : 2u);
-        const u8* __restrict__ stb = (const u8*)(small + sg.src);
-        const u8* __restrict__ hdr = rec + s.fr[0].in_data;
+        const u32* __restrict__ pos = small + sg.src;
+        const u32* __restrict__ cmask = small + s.m_dfa_cm;
+        const u32* __restrict__ pmask = small + s.m_dfa_pm;
         const int half_tab = (int)s.inv_half;
         for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
           const u32 r = r0 + (c >> 1), hf = c & 1u;
           const u32 i = r / per, q = r - i * per;
           uint4 v = zk_zero4();
           if (kind == ZDFA_SUB) {            // message index i: transition st[i+1] -> st[i+2]
+            const u32 w1 = pos[i + 1];
+            const u32 s1 = (w1 >> 8) & 255u, s2 = w1 >> 24;
             u32 cnt = 0;
 #pragma unroll
-            for (u32 k = 0; k < ZK_DFA_NPUBLIC; ++k) cnt += (stb[i + 1] == ZKD_PUBLIC[k][0] && stb[i + 2] == ZKD_PUBLIC[k][1]);
+            for (u32 k = 0; k < ZK_DFA_NPUBLIC; ++k) cnt += (s1 == ZK_DFA_PUBLIC[k][0] && s2 == ZK_DFA_PUBLIC[k][1]);
             if (!hf) v.x = q == 0 ? (cnt == 0) : cnt;
           } else {
-            const u32 b = i == 0 ? 255u : hdr[i - 1];
-            const u32 st = stb[i];
-            const u32 nx = st ? ZKD_DELTA[st][b] : 255u;      // non-zero-origin transition (255: none)
+            const u32 w0 = pos[i];
+            const u32 b = w0 & 255u, st = (w0 >> 8) & 255u, nx = (w0 >> 16) & 255u, sn = w0 >> 24;
             const u32 fze = nx == 255u;
             switch (kind) {
               case ZDFA_EQ: {
@@ -329,18 +322,18 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
               }
               case ZDFA_RNG: if (!hf) v.x = (b >= sg.b && b <= sg.c); break;
               case ZDFA_CLS: {
-                const u32 cnt = __builtin_popcount(ZKD_PRIMMASK[b] & sg.c);
+                const u32 cnt = __builtin_popcount(pmask[i] & sg.c);
                 if (!hf) v.x = q == 0 ? (cnt == 0) : cnt;     // members are disjoint: cnt in {0,1}
                 break;
               }
               case ZDFA_AND: {
                 const u32 from_on = sg.b ? (st == sg.b) : fze;
-                if (!hf) v.x = from_on & ((ZKD_CLSMASK[b] >> sg.c) & 1u);
+                if (!hf) v.x = from_on & ((cmask[i] >> sg.c) & 1u);
                 break;
               }
               case ZDFA_TMP: { const u32 cnt = (nx == sg.b); if (!hf) v.x = q == 0 ? (cnt == 0) : cnt; break; }
               case ZDFA_FZE: if (!hf) v.x = q == 0 ? fze : (1u - fze); break;
-              case ZDFA_ST: { const u32 cnt = (stb[i + 1] == sg.b); if (!hf) v.x = q == 0 ? (cnt == 0) : cnt; break; }
+              case ZDFA_ST: { const u32 cnt = (sn == sg.b); if (!hf) v.x = q == 0 ? (cnt == 0) : cnt; break; }
               default: break;
             }
           }
@@ -360,11 +353,4 @@ __global__ __launch_bounds__(512) void zk_expand_512(ZkSched s, ZkBufs B) { zk_e
 __global__ __launch_bounds__(1024) void zk_expand_1024(ZkSched s, ZkBufs B) { zk_expand_body<1024, false>(s, B); }
 __global__ __launch_bounds__(256) void zk_expand_wave(ZkSched s, ZkBufs B) { zk_expand_body<256, true>(s, B); }
 
-// copy the generated DFA tables into constant memory (called once per device by zkwg_circuit_create)
-extern "C" int zk_expand_init_tables(void) {
-  if (hipMemcpyToSymbol(HIP_SYMBOL(ZKD_DELTA), ZK_DFA_DELTA, sizeof(ZK_DFA_DELTA)) != hipSuccess) return -1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(ZKD_PRIMMASK), ZK_DFA_PRIMMASK, sizeof(ZK_DFA_PRIMMASK)) != hipSuccess) return -1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(ZKD_CLSMASK), ZK_DFA_CLSMASK, sizeof(ZK_DFA_CLSMASK)) != hipSuccess) return -1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(ZKD_PUBLIC), ZK_DFA_PUBLIC, sizeof(ZK_DFA_PUBLIC)) != hipSuccess) return -1;
-  return 0;
-}
+extern "C" int zk_expand_init_tables(void) { return 0; }

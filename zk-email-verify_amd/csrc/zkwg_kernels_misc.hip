@@ -7,9 +7,14 @@
 #include "zkwg_regex_core.h"
 #include "zkwg_bh_dfa.h"
 
-static __constant__ unsigned char ZKM_DELTA[ZK_DFA_STATES][256];
+static __device__ unsigned char ZKM_DELTA[ZK_DFA_STATES][256];
+static __device__ unsigned int ZKM_CLSMASK[256];
+static __device__ unsigned int ZKM_PRIMMASK[256];
 extern "C" int zk_misc_init_tables(void) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(ZKM_DELTA), ZK_DFA_DELTA, sizeof(ZK_DFA_DELTA)) == hipSuccess ? 0 : -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ZKM_DELTA), ZK_DFA_DELTA, sizeof(ZK_DFA_DELTA)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ZKM_CLSMASK), ZK_DFA_CLSMASK, sizeof(ZK_DFA_CLSMASK)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ZKM_PRIMMASK), ZK_DFA_PRIMMASK, sizeof(ZK_DFA_PRIMMASK)) != hipSuccess) return -1;
+  return 0;
 }
 
 __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
@@ -46,6 +51,7 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
       acc_count += (st == ZK_DFA_ACCEPT);
     }
     stl[nb + 1] = 0;
+    stl[nb + 2] = 0;
     if (acc_count == 0) ok_sh = 0;                      // bhRegexMatch === 1
     small[s.m_dfa_acc] = acc_count;
     // live[j] (j = nb .. 1): the thread in st[j] reaches the accept state without restarting
@@ -85,9 +91,14 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   }
   __syncthreads();
   for (u32 i = lane; i < N; i += 64) small[s.m_rev + i] = rev[i];
-  {  // packed state bytes for zk_expand
-    u8* dst_st = (u8*)(small + s.m_dfa_st);
-    for (u32 i = lane; i < N + 3; i += 64) dst_st[i] = stl[i];
+  // per-position words for zk_expand's ZSEG_DFA: in | st<<8 | nx<<16 | st_next<<24, class mask, prim mask
+  for (u32 i = lane; i < N + 2; i += 64) {
+    const u32 b = i == 0 ? 255u : (i <= N ? hdr[i - 1] : 0u);
+    const u32 st = stl[i];
+    const u32 nx = (st && i <= N) ? ZKM_DELTA[st][b] : 255u;
+    small[s.m_dfa_st + i] = b | (st << 8) | (nx << 16) | ((u32)stl[i + 1 <= N + 2 ? i + 1 : N + 2] << 24);
+    small[s.m_dfa_cm + i] = ZKM_CLSMASK[b];
+    small[s.m_dfa_pm + i] = ZKM_PRIMMASK[b];
   }
   // SelectRegexReveal assertions (utils/regex.circom:39-47)
   for (u32 i = lane; i < N; i += 64) {

@@ -250,7 +250,9 @@ static inline void zk_alloc_bh_regex(ZkWalker& w, ZkSched& s, u32 N) {
   const u32 nb = N + 1;
   s.m_rev = w.alloc_small(N);
   s.m_dfa_own = w.alloc_small(2 * nb + ZK_DFA_NPUBLIC * N + N);
-  s.m_dfa_st = w.alloc_small((nb + 1 + 3) / 4 + 1);
+  s.m_dfa_st = w.alloc_small(nb + 1);
+  s.m_dfa_cm = w.alloc_small(nb + 1);
+  s.m_dfa_pm = w.alloc_small(nb + 1);
   s.m_dfa_acc = w.alloc_small(1);
 }
 static inline void zk_walk_bh_regex(ZkWalker& w, const std::string& p, const ZkSched& s, u32 N) {

@@ -46,7 +46,7 @@ enum ZkSegType : u32 {
   ZSEG_VSHIFT = 13, // VarShiftLeft(a, .).tmp[j][i] = small[b + (i + (shift & (2^(j+1)-1))) % a], shift=small[src]
   ZSEG_B64BITS = 14,// Base64Decode bitsIn: 6 bits of the decoded value of char small[src + r/6]
   ZSEG_B64 = 15,    // Base64Lookup(char small[src + r/68]): 8 mids, 6 x 9 comparator bits, 3 IsZero pairs
-  ZSEG_DFA = 16,    // BodyHashRegex DFA circuit arrays: a = ZkDfaKind, b/c = parameters, src = small idx of the packed state bytes
+  ZSEG_DFA = 16,    // BodyHashRegex DFA circuit arrays: a = ZkDfaKind, b/c = parameters, src = small idx of the per-position words (then class masks, primitive masks)
   ZSEG_NTYPES = 17
 };
 
@@ -158,7 +158,9 @@ struct ZkSched {
   u32 b_shift;           // bits: 1 word, bodyHashIndex (VarShiftLeft.n2b)
   u32 sel_bits;          // log2Ceil(max_header + 43)
   // BodyHashRegex DFA circuit (zkwg v1)
-  u32 m_dfa_st;          // small: packed state bytes st[0..max_header+1] (4 per word)
+  u32 m_dfa_st;          // small: per position i of in[] (N+2 words): in[i] | st[i]<<8 | nx<<16 | st[i+1]<<24 (nx = delta(st[i],in[i]) from a non-zero state, else 255)
+  u32 m_dfa_cm;          // small: per position, class truth mask of in[i]
+  u32 m_dfa_pm;          // small: per position, primitive-test truth mask of in[i]
   u32 m_dfa_own;         // small: live_c1[nb], live_t[nb], prev_states0[NP][N], is_reveal0[N]
   u32 m_dfa_acc;         // small: number of positions in the accept state
 };
