@@ -287,58 +287,55 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
         // BodyHashRegex DFA circuit arrays (zkwg_layout.h zk_walk_bh_regex): one entry per position i of
         // in[] = [255, header...].  zk_misc_ev left one word per position: in | st<<8 | nx<<16 | st_next<<24
         // (nx = the transition out of a non-zero state, 255 = none) plus the class / primitive truth masks.
-        const u32 kind = sg.a;
-        const u32 per = (kind == ZDFA_LT) ? 9u : ((kind == ZDFA_RNG || kind == ZDFA_AND) ? 1u : 2u);
         const u32* __restrict__ pos = small + sg.src;
         const u32* __restrict__ cmask = small + s.m_dfa_cm;
         const u32* __restrict__ pmask = small + s.m_dfa_pm;
         const int half_tab = (int)s.inv_half;
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
-          const u32 r = r0 + (c >> 1), hf = c & 1u;
-          const u32 i = r / per, q = r - i * per;
-          uint4 v = zk_zero4();
-          if (kind == ZDFA_SUB) {            // message index i: transition st[i+1] -> st[i+2]
-            const u32 w1 = pos[i + 1];
-            const u32 s1 = (w1 >> 8) & 255u, s2 = w1 >> 24;
-            u32 cnt = 0;
-#pragma unroll
-            for (u32 k = 0; k < ZK_DFA_NPUBLIC; ++k) cnt += (s1 == ZK_DFA_PUBLIC[k][0] && s2 == ZK_DFA_PUBLIC[k][1]);
-            if (!hf) v.x = q == 0 ? (cnt == 0) : cnt;
-          } else {
-            const u32 w0 = pos[i];
-            const u32 b = w0 & 255u, st = (w0 >> 8) & 255u, nx = (w0 >> 16) & 255u, sn = w0 >> 24;
-            const u32 fze = nx == 255u;
-            switch (kind) {
-              case ZDFA_EQ: {
-                int d = (int)sg.b - (int)b;                   // isz.in = in[1] - in[0] = ch - in[i]
-                if (q == 0) { if (!hf) v.x = (d == 0); }
-                else { d = max(-half_tab, min(half_tab, d)); v = invtab[(u32)(d + half_tab) * 2 + hf]; }
-                break;
-              }
-              case ZDFA_LT: {
-                const u32 val = sg.c ? sg.b + b : sg.b - b;
-                if (!hf) v.x = (val >> q) & 1u;
-                break;
-              }
-              case ZDFA_RNG: if (!hf) v.x = (b >= sg.b && b <= sg.c); break;
-              case ZDFA_CLS: {
-                const u32 cnt = __builtin_popcount(pmask[i] & sg.c);
-                if (!hf) v.x = q == 0 ? (cnt == 0) : cnt;     // members are disjoint: cnt in {0,1}
-                break;
-              }
-              case ZDFA_AND: {
-                const u32 from_on = sg.b ? (st == sg.b) : fze;
-                if (!hf) v.x = from_on & ((cmask[i] >> sg.c) & 1u);
-                break;
-              }
-              case ZDFA_TMP: { const u32 cnt = (nx == sg.b); if (!hf) v.x = q == 0 ? (cnt == 0) : cnt; break; }
-              case ZDFA_FZE: if (!hf) v.x = q == 0 ? fze : (1u - fze); break;
-              case ZDFA_ST: { const u32 cnt = (sn == sg.b); if (!hf) v.x = q == 0 ? (cnt == 0) : cnt; break; }
-              default: break;
-            }
-          }
-          dst[c] = v;
+        const u32 pb = sg.b, pc = sg.c;
+        // PER = kept slots per position (compile time); f(i, q, word) -> small value (high half is zero)
+#define ZK_DFA_LOOP(PER, IDX_OFF, EXPR)                                                   \
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {                              \
+          uint4 v = zk_zero4();                                                           \
+          if (!(c & 1u)) {                                                                \
+            const u32 r = r0 + (c >> 1);                                                  \
+            const u32 i = r / (PER), q = r - i * (PER);                                   \
+            const u32 w0 = pos[i + (IDX_OFF)];                                            \
+            const u32 b = w0 & 255u, st = (w0 >> 8) & 255u, nx = (w0 >> 16) & 255u, sn = w0 >> 24; \
+            (void)b; (void)st; (void)nx; (void)sn; (void)q;                               \
+            v.x = (EXPR);                                                                 \
+          }                                                                               \
+          dst[c] = v;                                                                     \
         }
+        switch (sg.a) {
+          case ZDFA_EQ:
+            for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+              const u32 r = r0 + (c >> 1), hf = c & 1u;
+              const u32 i = r >> 1;
+              int d = (int)pb - (int)(pos[i] & 255u);          // isz.in = in[1] - in[0] = ch - in[i]
+              uint4 v = zk_zero4();
+              if (!(r & 1u)) { if (!hf) v.x = (d == 0); }
+              else { d = max(-half_tab, min(half_tab, d)); v = invtab[(u32)(d + half_tab) * 2 + hf]; }
+              dst[c] = v;
+            }
+            break;
+          case ZDFA_LT: ZK_DFA_LOOP(9u, 0u, ((pc ? pb + b : pb - b) >> q) & 1u) break;
+          case ZDFA_RNG: ZK_DFA_LOOP(1u, 0u, (b >= pb && b <= pc)) break;
+          case ZDFA_CLS: ZK_DFA_LOOP(2u, 0u, (q == 0) ^ (__builtin_popcount(pmask[i] & pc) != 0)) break;
+          case ZDFA_AND: ZK_DFA_LOOP(1u, 0u, (pb ? (st == pb) : (nx == 255u)) & ((cmask[i] >> pc) & 1u)) break;
+          case ZDFA_TMP: ZK_DFA_LOOP(2u, 0u, (q == 0) ^ (nx == pb)) break;
+          case ZDFA_FZE: ZK_DFA_LOOP(2u, 0u, (q == 0) ^ (nx != 255u)) break;
+          case ZDFA_ST: ZK_DFA_LOOP(2u, 0u, (q == 0) ^ (sn == pb)) break;
+          case ZDFA_SUB: {
+            // message index i: transition st[i+1] -> st[i+2] = (st, sn) of word i+1
+            u32 pubs[ZK_DFA_NPUBLIC];
+#pragma unroll
+            for (u32 k = 0; k < ZK_DFA_NPUBLIC; ++k) pubs[k] = ZK_DFA_PUBLIC[k][0] | ((u32)ZK_DFA_PUBLIC[k][1] << 8);
+            ZK_DFA_LOOP(2u, 1u, (q == 0) ^ ((st | (sn << 8)) == pubs[0] || (ZK_DFA_NPUBLIC > 1 && (st | (sn << 8)) == pubs[ZK_DFA_NPUBLIC > 1 ? 1 : 0])))
+            break;
+          }
+          default: break;
+        }
+#undef ZK_DFA_LOOP
         break;
       }
       default:
@@ -348,7 +345,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
   }
 }
 
-__global__ __launch_bounds__(256) void zk_expand_256(ZkSched s, ZkBufs B) { zk_expand_body<256, false>(s, B); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand_256(ZkSched s, ZkBufs B) { zk_expand_body<256, false>(s, B); }
 __global__ __launch_bounds__(512) void zk_expand_512(ZkSched s, ZkBufs B) { zk_expand_body<512, false>(s, B); }
 __global__ __launch_bounds__(1024) void zk_expand_1024(ZkSched s, ZkBufs B) { zk_expand_body<1024, false>(s, B); }
 __global__ __launch_bounds__(256) void zk_expand_wave(ZkSched s, ZkBufs B) { zk_expand_body<256, true>(s, B); }
