@@ -82,3 +82,19 @@ def test_ev_default_size_one_email_bit_exact():
     w = wc.calculateWitness(inp)
     main = _oracle_ev(N, M, 0, inp)
     assert w == comp.witness_kept(main)
+
+
+def test_ev_with_sha_precompute_selector_bit_exact():
+    # email-verifier-with-*-sha-precompute-selector tests: the body prefix is hashed on the host,
+    # the circuit starts from the midstate (Sha256BytesPartial with a non-IV preHash)
+    import zkwg
+    from zkwg import synth, inputs
+    from oracle.pyref import comp
+    N, M = 576, 256
+    c, wc = _circuit(N, M, 0)
+    d = synth.synthetic_dkim_result(8, 1, body_len=700)
+    sel = d["body"][520:532].decode()
+    inp = inputs.generate_email_verifier_inputs_from_dkim_result(d, N, M, sha_precompute_selector=sel)
+    assert inp["precomputedSHA"] != [str(b) for b in bytes.fromhex("6a09e667bb67ae853c6ef372a54ff53a510e527f9b05688c1f83d9ab5be0cd19")]
+    w = wc.calculateWitness(inp)
+    assert w == comp.witness_kept(_oracle_ev(N, M, 0, inp))
