@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--max-header", type=int, default=1024)
     ap.add_argument("--max-body", type=int, default=1536)
     ap.add_argument("--body-len", type=int, default=1024)
+    ap.add_argument("--rsa-throttle", type=int, default=3, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="emails timed for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -94,6 +95,9 @@ def main():
         b = k % 2
         if k >= 2:
             s_prep.wait_event(ev_exp[b])          # image buffer b is free again
+        # the first prepare has nothing to overlap with: run it at full occupancy; later ones share the
+        # chip with the previous batch's zk_expand and are throttled so that expand keeps its wave slots
+        c.set_prepare_throttle(0 if k == 0 else args.rsa_throttle)
         c.prepare_device(d_in, args.batch, d_status[b], d_scr[b], s_prep)
         ev_prep[b].record(s_prep)
         s_exp.wait_event(ev_prep[b])

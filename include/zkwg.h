@@ -159,6 +159,11 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t
 int zkwg_expand_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails, const void* d_scratch,
                        uint64_t first, uint64_t count, void* d_out_wtns, uint64_t out_stride, void* hip_stream);
 
+/* Throttle for pipelined use: when zkwg_prepare_device runs concurrently with zkwg_expand_device of
+ * the previous batch, cap the resident zk_rsa wavefronts per CU (each holds 164 VGPRs) so that the
+ * HBM-bound expand kernel keeps its occupancy.  0 = no cap (default; lowest prepare latency). */
+int zkwg_set_prepare_throttle(zkwg_circuit_t* c, int rsa_wavefronts_per_cu);
+
 /* Time the dominant kernel(s) of the last zkwg_calculate_batch_device call with
  * HIP events recorded on the launch stream.  Returns ms in *ms for kernel index
  * `which` (see zkwg_kernel_name); negative rc if timing was not enabled. */

@@ -37,6 +37,7 @@ struct zkwg_circuit {
   bool ev_valid, prep_valid;
   int expand_threads;
   int emails_per_wg;
+  int rsa_wgs_per_cu;
 };
 
 // inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
@@ -102,6 +103,8 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
   if (const char* v = getenv("ZKWG_PORTION")) portion = (u32)atoi(v);
   if (const char* v = getenv("ZKWG_EXPAND_THREADS")) c->expand_threads = atoi(v);
   c->emails_per_wg = 1;
+  c->rsa_wgs_per_cu = 0;
+  if (const char* v = getenv("ZKWG_RSA_WGS_PER_CU")) c->rsa_wgs_per_cu = atoi(v);
   if (const char* v = getenv("ZKWG_EMAILS_PER_WG")) c->emails_per_wg = std::max(1, atoi(v));
   if (portion < 64 || portion > (1u << 20)) portion = ZK_PORTION_DEFAULT;
   if (!build_sched(*cfg, c->s, c->segs, c->first_seg, portion)) { delete c; return ZKWG_RC_BAD_CONFIG; }
@@ -196,6 +199,11 @@ int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header
   return ZKWG_RC_OK;
 }
 
+int zkwg_set_prepare_throttle(zkwg_circuit_t* c, int rsa_wavefronts_per_cu) {
+  if (!c || rsa_wavefronts_per_cu < 0) return ZKWG_RC_BAD_ARG;
+  c->rsa_wgs_per_cu = rsa_wavefronts_per_cu;
+  return ZKWG_RC_OK;
+}
 int zkwg_set_timing(zkwg_circuit_t* c, int enable) {
   if (!c) return ZKWG_RC_BAD_ARG;
   c->timing = enable;
@@ -299,7 +307,16 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
   if (tm) hipEventRecord(evs[++ki], st);
   if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 7 * s.fr[0].max_bytes + 64, st, s, B);
   if (tm) hipEventRecord(evs[++ki], st);
-  if (s.rsa.present) hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), 0, st, s, B);
+  if (s.rsa.present) {
+    // optional throttle: pad the workgroup's LDS claim so that only `rsa_wgs_per_cu` RSA wavefronts
+    // (164 VGPRs each) are resident per CU, leaving registers/slots to a concurrently running zk_expand
+    u32 dyn = 0;
+    if (c->rsa_wgs_per_cu > 0) {
+      const u32 per = (160u * 1024u) / (u32)c->rsa_wgs_per_cu;
+      dyn = per > 14u * 1024u ? std::min(per - 14u * 1024u, 50u * 1024u) : 0u;
+    }
+    hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), dyn, st, s, B);
+  }
   if (tm) { hipEventRecord(evs[++ki], st); c->prep_valid = true; c->prep_launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;

@@ -165,6 +165,9 @@ class Circuit:
     def scratch_bytes(self, n):
         return self.lib.zkwg_scratch_bytes(self.h, n)
 
+    def set_prepare_throttle(self, rsa_wavefronts_per_cu):
+        _check(self.lib.zkwg_set_prepare_throttle(self.h, rsa_wavefronts_per_cu))
+
     def set_timing(self, on):
         _check(self.lib.zkwg_set_timing(self.h, 1 if on else 0))
 
