@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--max-header", type=int, default=1024)
     ap.add_argument("--max-body", type=int, default=1536)
     ap.add_argument("--body-len", type=int, default=1024)
+    ap.add_argument("--prep-batch", type=int, default=1024, help="emails per prepare launch (pipeline granularity)")
     ap.add_argument("--rsa-throttle", type=int, default=3, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="emails timed for cpu_baseline (0 = skip)")
     args = ap.parse_args()
@@ -76,41 +77,47 @@ def main():
     reps = (args.batch + distinct - 1) // distinct
     d_in = h_in.repeat(reps, 1)[:args.batch].contiguous().to(dev)
     d_out = [torch.empty(tile * c.witness_bytes, dtype=torch.uint8, device=dev) for _ in range(min(2, ntiles))]
-    d_status = [torch.zeros(args.batch, dtype=torch.int32, device=dev) for _ in range(2)]
-    # Two-phase pipeline: the compute kernels of a whole batch ("prepare": ~0.4 MB of compact image
-    # per email) run on one stream while the previous batch's witnesses are streamed out tile by tile
-    # ("expand", the HBM-bound kernel) on another; images are double-buffered.
-    d_scr = [torch.empty(c.scratch_bytes(args.batch), dtype=torch.uint8, device=dev) for _ in range(2)]
+    # Two-phase pipeline: the compute kernels of a sub-batch of `prep` emails ("prepare": ~0.45 MB of
+    # compact image per email) run on one stream while the previous sub-batch's witnesses are streamed
+    # out tile by tile ("expand", the HBM-bound kernel) on another; images are double-buffered.
+    prep = min(args.prep_batch, args.batch)
+    assert args.batch % prep == 0 and prep % tile == 0
+    nsub, tiles_per_sub = args.batch // prep, prep // tile
+    d_status = torch.zeros(args.batch, dtype=torch.int32, device=dev)
+    d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(2)]
     prio = int(os.environ.get('ZKWG_BENCH_EXP_PRIO', '-1'))
     s_prep, s_exp = torch.cuda.Stream(device=dev, priority=0), torch.cuda.Stream(device=dev, priority=prio)
     ev_prep = [torch.cuda.Event() for _ in range(2)]
     ev_exp = [torch.cuda.Event() for _ in range(2)]
-    state = {"k": 0, "table": None}
+    state = {"j": 0, "table": None}
     # per-email result rows (w[0..3] = 1, pubkeyHash, shaHi, shaLo) saved before the ring slot is reused
     from zkwg import shard
     d_rows = torch.empty((args.batch, 128), dtype=torch.uint8, device=dev)
 
     def step():
-        k = state["k"]
-        b = k % 2
-        if k >= 2:
-            s_prep.wait_event(ev_exp[b])          # image buffer b is free again
-        # the first prepare has nothing to overlap with: run it at full occupancy; later ones share the
-        # chip with the previous batch's zk_expand and are throttled so that expand keeps its wave slots
-        c.set_prepare_throttle(0 if k == 0 else args.rsa_throttle)
-        c.prepare_device(d_in, args.batch, d_status[b], d_scr[b], s_prep)
-        ev_prep[b].record(s_prep)
-        s_exp.wait_event(ev_prep[b])
+        for sb in range(nsub):
+            j = state["j"]
+            b = j % 2
+            lo = sb * prep
+            if j >= 2:
+                s_prep.wait_event(ev_exp[b])      # image buffer b is free again
+            # the very first prepare has nothing to overlap with: run it at full occupancy; later ones share
+            # the chip with the previous sub-batch's zk_expand and are throttled so expand keeps its wave slots
+            c.set_prepare_throttle(0 if j == 0 else args.rsa_throttle)
+            c.prepare_device(d_in[lo:lo + prep], prep, d_status[lo:lo + prep], d_scr[b], s_prep)
+            ev_prep[b].record(s_prep)
+            s_exp.wait_event(ev_prep[b])
+            with torch.cuda.stream(s_exp):
+                for t in range(tiles_per_sub):
+                    o = d_out[(sb * tiles_per_sub + t) % len(d_out)]
+                    c.expand_device(d_in[lo:lo + prep], prep, d_scr[b], t * tile, tile, o, s_exp)
+                    d_rows[lo + t * tile:lo + (t + 1) * tile].copy_(o.view(tile, c.witness_bytes)[:, :128])
+            ev_exp[b].record(s_exp)
+            state["j"] = j + 1
         with torch.cuda.stream(s_exp):
-            for t in range(ntiles):
-                o = d_out[t % len(d_out)]
-                c.expand_device(d_in, args.batch, d_scr[b], t * tile, tile, o, s_exp)
-                d_rows[t * tile:(t + 1) * tile].copy_(o.view(tile, c.witness_bytes)[:, :128])
             # the only exchange step: gather the 100-byte/email result table on rank 0 (RCCL over xGMI)
-            table = shard.result_table(d_status[b], d_rows)
+            table = shard.result_table(d_status, d_rows)
             state["table"] = shard.gather_table(dist, table, args.batch * world, rank, world) if dist is not None else table
-        ev_exp[b].record(s_exp)
-        state["k"] = k + 1
 
     def barrier():
         torch.cuda.synchronize()
@@ -121,8 +128,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    assert int(d_status[0].abs().sum().item()) == 0, "synthetic emails must all verify"
-    state["k"] = 0
+    assert int(d_status.abs().sum().item()) == 0, "synthetic emails must all verify"
+    state["j"] = 0
     c.set_timing(True)
     barrier()
     t0 = time.perf_counter()

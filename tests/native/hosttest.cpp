@@ -51,9 +51,10 @@ void ht_poseidon(const uint8_t* limbs, void* out420, void* hash) {
   zk_poseidon_large(*S, l, C.data(), M.data(), (Fr*)out420, (Fr*)hash);
   delete S;
 }
-uint32_t ht_regex_scan(const uint8_t* msg, uint32_t n, uint32_t* rev) {
-  for (uint32_t i = 0; i < n; ++i) rev[i] = 0;
-  return zk_bh_regex_scan(msg, n, rev);
+// the product's DFA scan (zkwg_regex_core.h) on the host: rev[n], own[2(n+1) + NP n + n]; returns accept count
+uint32_t ht_regex_scan(const uint8_t* msg, uint32_t n, uint32_t* rev, uint32_t* own) {
+  std::vector<u8> st(n + 4), live(n + 4);
+  return zk_bh_dfa_scan(msg, n, ZK_DFA_DELTA, st.data(), live.data(), own, rev);
 }
 // Fr helpers for unit tests
 void ht_fr_mul(const void* a, const void* b, void* out) { *(Fr*)out = fr_mul_std(*(const Fr*)a, *(const Fr*)b); }

@@ -96,9 +96,13 @@ def test_regex_scanner_vs_python_re():
         elif mode == 6:
             hdr = bytearray(rng.randrange(256) for _ in range(400))
         cases.append(bytes(hdr[:N]).ljust(N, b"\0"))
-    for msg in cases:
+    for ci, msg in enumerate(cases):
         rev = (C.c_uint32 * N)()
-        n = lib.ht_regex_scan(msg, N, rev)
-        o = zk.BodyHashRegex(N, list(msg))
+        own = (C.c_uint32 * (2 * (N + 1) + 3 * N))()
+        n = lib.ht_regex_scan(msg, N, rev, own)
+        o = zk.BodyHashRegex(N, list(msg))           # interface semantics (Python `re`)
         assert (1 if n else 0) == o.o[0]
         assert list(rev) == o.o[1]
+        if ci % 6 == 0:
+            v1 = zk.BodyHashRegexV1(N, list(msg))    # the DFA circuit restated literally
+            assert list(rev) == v1.o[1] and (1 if n else 0) == v1.o[0]

@@ -37,51 +37,10 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   __syncthreads();
   const u32 start = *(const u32*)(rec + s.in_off[8]);  // bodyHashIndex
   if (lane == 0) {
-    // BodyHashRegex DFA (zkwg v1 circuit): state 0 is always active, a transition out of state 0
-    // fires only when no other state continues; st[j] = the active non-zero state before in[j] (0: none)
-    const u32 nb = N + 1;
-    u32 st = 0, acc_count = 0;
-    stl[0] = 0;
-    for (u32 i = 0; i < nb; ++i) {
-      const u32 b = i == 0 ? 255u : hdr[i - 1];
-      u32 nx = st ? ZKM_DELTA[st][b] : 255u;
-      if (nx == 255u) { nx = ZKM_DELTA[0][b]; if (nx == 255u) nx = 0; }
-      st = nx;
-      stl[i + 1] = (u8)st;
-      acc_count += (st == ZK_DFA_ACCEPT);
-    }
-    stl[nb + 1] = 0;
-    stl[nb + 2] = 0;
+    // BodyHashRegex DFA scan (zkwg_regex_core.h): states, live chain, helper signals, reveal0
+    const u32 acc_count = zk_bh_dfa_scan(hdr, N, ZKM_DELTA, stl, live, small + s.m_dfa_own, rev);
     if (acc_count == 0) ok_sh = 0;                      // bhRegexMatch === 1
     small[s.m_dfa_acc] = acc_count;
-    // live[j] (j = nb .. 1): the thread in st[j] reaches the accept state without restarting
-    u32* own = small + s.m_dfa_own;                     // live_c1[nb], live_t[nb], prev[NP][N], is_reveal0[N]
-    live[nb + 1] = 0;
-    for (u32 j = nb; j >= 1; --j) {
-      const u32 b = hdr[j - 1 < N ? j - 1 : 0];
-      u32 c1 = 0;
-      if (j < nb) {                                     // fze[j] = no non-zero-origin transition at position j
-        const u32 sj = stl[j];
-        const u32 fze = sj ? (ZKM_DELTA[sj][b] == 255u) : 1u;
-        c1 = live[j + 1] & (1u - fze);
-      }
-      const u32 acc = stl[j] == ZK_DFA_ACCEPT;
-      const u32 tt = (1u - acc) & c1;
-      own[j - 1] = c1;
-      own[nb + j - 1] = tt;
-      live[j] = (u8)(acc | tt);
-    }
-    for (u32 i = 0; i < N; ++i) {
-      u32 sub = 0;
-      for (u32 k = 0; k < ZK_DFA_NPUBLIC; ++k) {
-        const u32 pv = (stl[i + 1] == ZK_DFA_PUBLIC[k][0] && stl[i + 2] == ZK_DFA_PUBLIC[k][1]);
-        own[2 * nb + k * N + i] = pv;
-        sub |= pv;
-      }
-      const u32 ir = sub & live[i + 2];
-      own[2 * nb + ZK_DFA_NPUBLIC * N + i] = ir;
-      rev[i] = ir ? hdr[i] : 0;
-    }
     small[s.m_bh_idx] = start;
     bits[s.b_shift] = start;
     u32 blh = 0;
