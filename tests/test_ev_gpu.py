@@ -90,7 +90,7 @@ def test_ev_with_sha_precompute_selector_bit_exact():
     import zkwg
     from zkwg import synth, inputs
     from oracle.pyref import comp
-    N, M = 576, 256
+    N, M = 576, 320   # remaining body pads to 256 bytes; the length must stay below maxBodyLength
     c, wc = _circuit(N, M, 0)
     d = synth.synthetic_dkim_result(8, 1, body_len=700)
     sel = d["body"][520:532].decode()
