@@ -39,6 +39,24 @@ __global__ __launch_bounds__(THREADS) void fill_wavecontig(uint4* dst, unsigned 
     if (c < total) dst[c] = v;
   }
 }
+// like fill_wavecontig, but every even lane first loads one u64 from a small L2-resident table (index
+// derived from the chunk id) and writes a bit of it: the zk_expand access pattern without the tables
+template <int THREADS, int KB_PER_WAVE>
+__global__ __launch_bounds__(THREADS) void fill_wavecontig_ld(uint4* dst, const unsigned long long* tab, unsigned long long total) {
+  const unsigned waves = THREADS / 64, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long base = ((unsigned long long)blockIdx.x * waves + wave) * (KB_PER_WAVE * 64ull);
+  unsigned long long w[KB_PER_WAVE];
+#pragma unroll
+  for (int k = 0; k < KB_PER_WAVE; ++k) {
+    unsigned long long c = base + k * 64 + lane;
+    w[k] = (lane & 1) ? 0ull : tab[(c >> 6) % 952 + ((c >> 16) & 1023) * 952];
+  }
+#pragma unroll
+  for (int k = 0; k < KB_PER_WAVE; ++k) {
+    unsigned long long c = base + k * 64 + lane;
+    if (c < total) dst[c] = make_uint4((unsigned)(w[k] >> (lane >> 1)) & 1u, 0, 0, 0);
+  }
+}
 template <class F> float timeit(F f, int iters = 5) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   f(); CK(hipDeviceSynchronize());
@@ -72,6 +90,11 @@ int main() {
     ms = timeit([&] { hipLaunchKernelGGL((fill_wavecontig<T, K>), dim3(grid), dim3(T), 0, 0, d, total); }); \
     printf("wavecontig %4d thr %2d KB/wave: %7.3f ms %6.0f GB/s\n", T, K, ms, bytes / ms / 1e6); } while (0)
   WC(256, 1); WC(256, 2); WC(256, 4); WC(256, 8); WC(512, 2); WC(512, 4); WC(1024, 1); WC(1024, 2); WC(1024, 4); WC(64, 4); WC(64, 8); WC(128, 4);
+  unsigned long long* tab; CK(hipMalloc((void**)&tab, 1024 * 952 * 8)); CK(hipMemset(tab, 0x55, 1024 * 952 * 8));
+#define WL(T, K) do { unsigned long long per = (T / 64) * (K * 64ull); unsigned grid = (unsigned)((total + per - 1) / per); \
+    ms = timeit([&] { hipLaunchKernelGGL((fill_wavecontig_ld<T, K>), dim3(grid), dim3(T), 0, 0, d, tab, total); }); \
+    printf("wavecontig+load %4d thr %2d KB/wave: %7.3f ms %6.0f GB/s\n", T, K, ms, bytes / ms / 1e6); } while (0)
+  WL(256, 1); WL(256, 2); WL(256, 4); WL(256, 8); WL(256, 16); WL(64, 4); WL(64, 8); WL(512, 4); WL(1024, 4);
   for (unsigned g : {256u * 4, 256u * 8, 256u * 16}) {
     unsigned cpw = 32 * 1024 / 16;
     ms = timeit([&] { hipLaunchKernelGGL((fill_persist<256>), dim3(g), dim3(256), 0, 0, d, cpw, total / cpw); });
