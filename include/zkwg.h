@@ -133,11 +133,17 @@ int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* record,
 
 /* Host-buffer batch: H2D of `packed_inputs` (n_emails records), kernels, D2H of
  * n_emails witnesses (32*W bytes each, `out_stride` bytes apart; out_wtns may be
- * NULL to fetch only `status`).  Processes the batch in tiles that fit `max_tile`
- * emails (0 = choose from free HBM). */
+ * NULL to fetch only `status`).  Processes the batch in tiles of `max_tile` emails
+ * (0 = 256, reduced if HBM is short); witness buffers are double-buffered so the
+ * D2H copy of tile t overlaps the kernels of tile t+1.  One call at a time per handle. */
 int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed_inputs, uint64_t n_emails,
                          uint8_t* out_wtns, uint64_t out_stride, int32_t* status,
                          uint64_t max_tile);
+
+/* Page-locked host memory for `out_wtns` (optional): with it the D2H copy of one tile overlaps the
+ * kernels of the next tile. */
+void* zkwg_alloc_pinned(uint64_t bytes);
+void zkwg_free_pinned(void* p);
 
 /* Device-resident batch: every pointer is a device pointer on the handle's
  * device; `hip_stream` is a hipStream_t passed as void* (NULL = default stream).

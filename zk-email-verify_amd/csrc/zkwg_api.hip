@@ -6,6 +6,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <mutex>
 #include <algorithm>
 #include "../../include/zkwg.h"
 #include "zkwg_kernels.h"
@@ -25,7 +26,13 @@ struct zkwg_circuit {
   u32* d_first_seg;
   std::vector<ZkSeg> segs;
   std::vector<u32> first_seg;
-  hipStream_t own_stream;
+  hipStream_t own_stream, copy_stream;
+  // host-buffer path: cached device staging buffers (double-buffered witnesses)
+  std::mutex hb_mutex;
+  u8 *hb_in, *hb_out[2], *hb_scr;
+  int* hb_status[2];
+  u64 hb_tile;
+  hipEvent_t hb_done[2], hb_copied[2];
   int timing;
   int n_kernels;
   const char* kname[ZK_MAX_KERNELS];
@@ -143,6 +150,8 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
       return ZKWG_RC_OOM;
     }
     hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2; ++i) { hipEventCreateWithFlags(&c->hb_done[i], hipEventDisableTiming); hipEventCreateWithFlags(&c->hb_copied[i], hipEventDisableTiming); }
     for (int r = 0; r < ZK_EV_RING; ++r) {
       for (int i = 0; i < 2; ++i) hipEventCreate(&c->ev[r][i]);
       for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventCreate(&c->pev[r][i]);
@@ -157,6 +166,9 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (c->device >= 0) {
     hipSetDevice(c->device);
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos);
+    hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
+    for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); }
+    hipStreamDestroy(c->copy_stream);
     hipStreamDestroy(c->own_stream);
     for (int r = 0; r < ZK_EV_RING; ++r) {
       for (int i = 0; i < 2; ++i) hipEventDestroy(c->ev[r][i]);
@@ -360,6 +372,26 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n,
   return zkwg_expand_device(c, d_in, n, d_scratch, 0, n, d_out, out_stride, hip_stream);
 }
 
+// Device staging buffers of the host-buffer path, cached in the handle (grow-only).
+static int ensure_host_path_buffers(zkwg_circuit* c, u64 tile) {
+  if (c->hb_tile >= tile) return ZKWG_RC_OK;
+  hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr);
+  hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
+  c->hb_in = c->hb_out[0] = c->hb_out[1] = c->hb_scr = nullptr;
+  c->hb_status[0] = c->hb_status[1] = nullptr;
+  c->hb_tile = 0;
+  const u64 wbytes = c->s.W * 32;
+  if (hipMalloc((void**)&c->hb_in, tile * c->s.in_stride) != hipSuccess ||
+      hipMalloc((void**)&c->hb_out[0], tile * wbytes) != hipSuccess ||
+      hipMalloc((void**)&c->hb_out[1], tile * wbytes) != hipSuccess ||
+      hipMalloc((void**)&c->hb_scr, zkwg_scratch_bytes(c, tile)) != hipSuccess ||
+      hipMalloc((void**)&c->hb_status[0], tile * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&c->hb_status[1], tile * sizeof(int)) != hipSuccess)
+    return ZKWG_RC_OOM;
+  c->hb_tile = tile;
+  return ZKWG_RC_OK;
+}
+
 int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
                          uint64_t out_stride, int32_t* status, uint64_t max_tile) {
   if (!c || !packed || !status) return ZKWG_RC_BAD_ARG;
@@ -367,40 +399,49 @@ int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, u
   if (n == 0) return ZKWG_RC_OK;
   const u64 wbytes = c->s.W * 32;
   if (out_wtns && out_stride < wbytes) return ZKWG_RC_BAD_ARG;
+  std::lock_guard<std::mutex> lock(c->hb_mutex);   // one host-path call at a time per handle
   if (hipSetDevice(c->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  // tile: two witness buffers must fit; default 256 emails (the D2H of one tile overlaps the kernels of the next)
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  const u64 per_email = wbytes + c->s.in_stride + zkwg_scratch_bytes(c, 64) / 64 + 16;
-  u64 tile = max_tile ? max_tile : std::max<u64>(1, (u64)(free_b * 0.8) / per_email);
+  const u64 have = (u64)free_b + c->hb_tile * (2 * wbytes);
+  const u64 per_email = 2 * wbytes + c->s.in_stride + zkwg_scratch_bytes(c, 64) / 64 + 64;
+  u64 tile = max_tile ? max_tile : 256;
+  tile = std::min<u64>(tile, std::max<u64>(1, (u64)(have * 0.8) / per_email));
   tile = std::min<u64>(tile, n);
-  u8 *d_in = nullptr, *d_out = nullptr, *d_scr = nullptr;
-  int* d_status = nullptr;
-  int rc = ZKWG_RC_OK;
-  if (hipMalloc((void**)&d_in, tile * c->s.in_stride) != hipSuccess ||
-      hipMalloc((void**)&d_out, tile * wbytes) != hipSuccess ||
-      hipMalloc((void**)&d_scr, zkwg_scratch_bytes(c, tile)) != hipSuccess ||
-      hipMalloc((void**)&d_status, tile * sizeof(int)) != hipSuccess) {
-    rc = ZKWG_RC_OOM;
-  }
-  hipStream_t st = c->own_stream;
-  for (u64 base = 0; rc == ZKWG_RC_OK && base < n; base += tile) {
-    u64 cnt = std::min<u64>(tile, n - base);
-    if (hipMemcpyAsync(d_in, packed + base * c->s.in_stride, cnt * c->s.in_stride, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
-    rc = zkwg_calculate_batch_device(c, d_in, cnt, d_out, wbytes, d_status, d_scr, st);
+  int rc = ensure_host_path_buffers(c, tile);
+  if (rc != ZKWG_RC_OK) return rc;
+  hipStream_t st = c->own_stream, cs = c->copy_stream;
+  u64 t = 0;
+  for (u64 base = 0; rc == ZKWG_RC_OK && base < n; base += tile, ++t) {
+    const u64 cnt = std::min<u64>(tile, n - base);
+    const int b = (int)(t & 1);
+    if (t >= 2 && hipStreamWaitEvent(st, c->hb_copied[b], 0) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
+    if (hipMemcpyAsync(c->hb_in, packed + base * c->s.in_stride, cnt * c->s.in_stride, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
+    rc = zkwg_calculate_batch_device(c, c->hb_in, cnt, c->hb_out[b], wbytes, c->hb_status[b], c->hb_scr, st);
     if (rc != ZKWG_RC_OK) break;
+    if (hipEventRecord(c->hb_done[b], st) != hipSuccess || hipStreamWaitEvent(cs, c->hb_done[b], 0) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
     if (out_wtns) {
-      if (out_stride == wbytes) {
-        if (hipMemcpyAsync(out_wtns + base * out_stride, d_out, cnt * wbytes, hipMemcpyDeviceToHost, st) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
-      } else {
-        if (hipMemcpy2DAsync(out_wtns + base * out_stride, out_stride, d_out, wbytes, wbytes, cnt, hipMemcpyDeviceToHost, st) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
-      }
+      hipError_t e = (out_stride == wbytes)
+          ? hipMemcpyAsync(out_wtns + base * out_stride, c->hb_out[b], cnt * wbytes, hipMemcpyDeviceToHost, cs)
+          : hipMemcpy2DAsync(out_wtns + base * out_stride, out_stride, c->hb_out[b], wbytes, wbytes, cnt, hipMemcpyDeviceToHost, cs);
+      if (e != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
     }
-    if (hipMemcpyAsync(status + base, d_status, cnt * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
-    if (hipStreamSynchronize(st) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
+    if (hipMemcpyAsync(status + base, c->hb_status[b], cnt * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
+    if (hipEventRecord(c->hb_copied[b], cs) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
   }
-  hipFree(d_in); hipFree(d_out); hipFree(d_scr); hipFree(d_status);
+  if (hipStreamSynchronize(st) != hipSuccess) rc = rc == ZKWG_RC_OK ? ZKWG_RC_HIP_ERROR : rc;
+  if (hipStreamSynchronize(cs) != hipSuccess) rc = rc == ZKWG_RC_OK ? ZKWG_RC_HIP_ERROR : rc;
   return rc;
 }
+
+// Page-locked host memory for witness output buffers: lets the D2H copy of one tile overlap the
+// kernels of the next (pageable destinations work too, the copy is then staged by the runtime).
+void* zkwg_alloc_pinned(uint64_t bytes) {
+  void* p = nullptr;
+  return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+void zkwg_free_pinned(void* p) { if (p) hipHostFree(p); }
 
 uint64_t zkwg_wtns_size(const zkwg_circuit_t* c) { return 12 + 12 + 40 + 12 + c->s.W * 32; }
 

@@ -61,6 +61,8 @@ def load():
         "zkwg_scratch_bytes": (u64, [vp, u64]),
         "zkwg_pack_input": (i32, [vp, vp, vp, u32, vp, u32, vp, vp, vp, vp, u32]),
         "zkwg_calculate_batch": (i32, [vp, vp, u64, vp, u64, vp, u64]),
+        "zkwg_alloc_pinned": (vp, [u64]),
+        "zkwg_free_pinned": (None, [vp]),
         "zkwg_calculate_batch_device": (i32, [vp, vp, u64, vp, u64, vp, vp, vp]),
         "zkwg_prepare_device": (i32, [vp, vp, u64, vp, vp, vp]),
         "zkwg_expand_device": (i32, [vp, vp, u64, vp, u64, u64, vp, u64, vp]),
@@ -87,6 +89,6 @@ EXPORTS = [
     "zkwg_abi_version", "zkwg_strerror", "zkwg_circuit_create", "zkwg_circuit_destroy",
     "zkwg_witness_len", "zkwg_witness_bytes", "zkwg_num_public", "zkwg_input_stride",
     "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_pack_input", "zkwg_calculate_batch",
-    "zkwg_calculate_batch_device", "zkwg_prepare_device", "zkwg_expand_device", "zkwg_set_prepare_throttle", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_timing_summary", "zkwg_num_kernels",
+    "zkwg_alloc_pinned", "zkwg_free_pinned", "zkwg_calculate_batch_device", "zkwg_prepare_device", "zkwg_expand_device", "zkwg_set_prepare_throttle", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_timing_summary", "zkwg_num_kernels",
     "zkwg_kernel_name", "zkwg_kernel_slots", "zkwg_wtns_size", "zkwg_write_wtns", "zkwg_write_sym",
 ]
