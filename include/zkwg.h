@@ -140,6 +140,27 @@ int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed_inputs, uint64
                          uint8_t* out_wtns, uint64_t out_stride, int32_t* status,
                          uint64_t max_tile);
 
+/* Batched input generation on the device (the step right before the path): restates
+ * generateEmailVerifierInputsFromDKIMResult (packages/helpers/src/input-generators.ts:190-252) with
+ * sha256Pad / generatePartialSHA (sha-utils.ts:30-111) and toCircomBigIntBytes (binary-format.ts:71-83).
+ * All pointers are device pointers; `selector` is the optional shaPrecomputeSelector (shared by the
+ * batch).  d_records receives n packed input records (zkwg_input_stride each); d_gen_status[i]:
+ *   0 ok | 1 header does not fit maxHeadersLength | 2 remaining body longer than maxBodyLength
+ *   | 3 selector not found in the body | 4 body longer than body_stride.   EmailVerifier main only. */
+typedef struct zkwg_dkim_batch {
+  const uint8_t* headers;        /* [n][header_stride] canonical signed header bytes */
+  const uint32_t* header_len;    /* [n] */
+  const uint8_t* bodies;         /* [n][body_stride] canonical body bytes (NULL if ignoreBodyHashCheck) */
+  const uint32_t* body_len;      /* [n] */
+  const uint8_t* body_hash_b64;  /* [n][44] bodyHash, base64 text */
+  const uint8_t* pubkey_be;      /* [n][256] RSA modulus, big-endian */
+  const uint8_t* signature_be;   /* [n][256] signature, big-endian */
+  const uint8_t* selector;       /* shaPrecomputeSelector bytes or NULL */
+  uint32_t header_stride, body_stride, selector_len;
+} zkwg_dkim_batch;
+int zkwg_generate_inputs_device(zkwg_circuit_t* c, const zkwg_dkim_batch* batch, uint64_t n_emails,
+                                void* d_records, void* d_gen_status, void* hip_stream);
+
 /* Page-locked host memory for `out_wtns` (optional): with it the D2H copy of one tile overlaps the
  * kernels of the next tile. */
 void* zkwg_alloc_pinned(uint64_t bytes);

@@ -435,6 +435,25 @@ int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, u
   return rc;
 }
 
+int zkwg_generate_inputs_device(zkwg_circuit_t* c, const zkwg_dkim_batch* b, uint64_t n, void* d_records,
+                                void* d_gen_status, void* hip_stream) {
+  if (!c || !b || !d_records || !d_gen_status) return ZKWG_RC_BAD_ARG;
+  if (c->device < 0) return ZKWG_RC_NO_DEVICE;
+  if (c->s.main_kind != ZKWG_MAIN_EMAIL_VERIFIER) return ZKWG_RC_BAD_CONFIG;
+  if (n == 0) return ZKWG_RC_OK;
+  if (!b->headers || !b->header_len || !b->pubkey_be || !b->signature_be) return ZKWG_RC_BAD_ARG;
+  if (c->s.body && (!b->bodies || !b->body_len || !b->body_hash_b64)) return ZKWG_RC_BAD_ARG;
+  if (b->selector_len && !b->selector) return ZKWG_RC_BAD_ARG;
+  ZkDkimBatch D;
+  D.headers = b->headers; D.header_len = b->header_len; D.bodies = b->bodies; D.body_len = b->body_len;
+  D.body_hash_b64 = b->body_hash_b64; D.pubkey_be = b->pubkey_be; D.signature_be = b->signature_be;
+  D.selector = b->selector; D.header_stride = b->header_stride; D.body_stride = b->body_stride;
+  D.selector_len = b->selector_len;
+  hipLaunchKernelGGL(zk_gen_inputs, dim3((u32)n), dim3(64), 0, (hipStream_t)hip_stream, c->s, D, (u8*)d_records,
+                     (int*)d_gen_status, (u32)n);
+  return hipGetLastError() == hipSuccess ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
+}
+
 // Page-locked host memory for witness output buffers: lets the D2H copy of one tile overlap the
 // kernels of the next (pageable destinations work too, the copy is then staged by the runtime).
 void* zkwg_alloc_pinned(uint64_t bytes) {

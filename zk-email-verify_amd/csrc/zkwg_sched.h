@@ -165,6 +165,20 @@ struct ZkSched {
   u32 m_dfa_acc;         // small: number of positions in the accept state
 };
 
+// Raw DKIM results of a batch (device pointers) -- input of zk_gen_inputs; mirrors the fields of
+// `DKIMVerificationResult` that generateEmailVerifierInputsFromDKIMResult reads.
+struct ZkDkimBatch {
+  const u8* headers;       // [n][header_stride] canonical signed header bytes
+  const u32* header_len;   // [n]
+  const u8* bodies;        // [n][body_stride] canonical body bytes
+  const u32* body_len;     // [n]
+  const u8* body_hash_b64; // [n][44] bodyHash (base64 text)
+  const u8* pubkey_be;     // [n][256] RSA modulus, big-endian
+  const u8* signature_be;  // [n][256] signature, big-endian
+  const u8* selector;      // shaPrecomputeSelector bytes (shared by the batch) or NULL
+  u32 header_stride, body_stride, selector_len;
+};
+
 #if defined(__HIPCC__)
 // Device pointers of one launch (kernel argument, by value).
 struct ZkBufs {

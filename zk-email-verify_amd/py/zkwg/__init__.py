@@ -238,3 +238,39 @@ class WitnessCalculator:
 
 def witness_ints(b):
     return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+def generate_inputs_device(circuit, dkim_results, selector=None, stream=None):
+    """Batched input generation on the GPU (zkwg_generate_inputs_device).  dkim_results: list of dicts with
+    headers, body, bodyHash, publicKey, signature (as `verifyDKIMSignature` returns them).  Returns
+    (records: torch.uint8[n, in_stride] on the device, gen_status: list[int])."""
+    import torch
+    from ._lib import DkimBatch
+    n = len(dkim_results)
+    dev = torch.device("cuda", circuit.device)
+    hs = max(len(d["headers"]) for d in dkim_results)
+    bs = max(len(d.get("body") or b"") for d in dkim_results) or 1
+
+    def pack(rows, width):
+        buf = bytearray(n * width)
+        for i, r in enumerate(rows):
+            buf[i * width:i * width + len(r)] = r
+        return torch.frombuffer(buf, dtype=torch.uint8).to(dev)
+
+    t_hdr = pack([d["headers"] for d in dkim_results], hs)
+    t_hl = torch.tensor([len(d["headers"]) for d in dkim_results], dtype=torch.int32, device=dev)
+    t_body = pack([d.get("body") or b"" for d in dkim_results], bs)
+    t_bl = torch.tensor([len(d.get("body") or b"") for d in dkim_results], dtype=torch.int32, device=dev)
+    t_bh = pack([(d.get("bodyHash") or "").encode().ljust(44, b"\0")[:44] for d in dkim_results], 44)
+    t_pk = pack([int(d["publicKey"]).to_bytes(256, "big") for d in dkim_results], 256)
+    t_sg = pack([int(d["signature"]).to_bytes(256, "big") for d in dkim_results], 256)
+    sel = selector.encode() if isinstance(selector, str) else (selector or b"")
+    t_sel = torch.frombuffer(bytearray(sel or b"\0"), dtype=torch.uint8).to(dev)
+    b = DkimBatch(t_hdr.data_ptr(), t_hl.data_ptr(), t_body.data_ptr(), t_bl.data_ptr(), t_bh.data_ptr(),
+                  t_pk.data_ptr(), t_sg.data_ptr(), t_sel.data_ptr() if sel else None, hs, bs, len(sel))
+    recs = torch.empty((n, circuit.in_stride), dtype=torch.uint8, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    sp = stream.cuda_stream if stream is not None else 0
+    _check(circuit.lib.zkwg_generate_inputs_device(circuit.h, C.byref(b), n, recs.data_ptr(), st.data_ptr(), sp))
+    torch.cuda.synchronize()
+    return recs, st.cpu().tolist()

@@ -71,12 +71,27 @@ def sha256_pad(message: bytes, max_sha_bytes: int):
     return res, message_len
 
 
+def find_index_in_uint8array(array: bytes, selector: bytes) -> int:
+    """sha-utils.ts:9-24, literally (on a mismatch j restarts at 0 and i still advances, so this is NOT a
+    general substring search: "aab" is not found in "aaab")."""
+    i = j = 0
+    while i < len(array):
+        if array[i] == selector[j]:
+            j += 1
+            if j == len(selector):
+                return i - j + 1
+        else:
+            j = 0
+        i += 1
+    return -1
+
+
 def generate_partial_sha(body: bytes, body_length: int, selector_string, max_remaining_body_length: int):
     """sha-utils.ts:30-80."""
     selector_index = 0
     if selector_string:
         sel = selector_string.encode() if isinstance(selector_string, str) else selector_string
-        selector_index = body.find(sel)
+        selector_index = find_index_in_uint8array(body, sel)
         if selector_index == -1:
             raise ValueError(f'SHA precompute selector "{selector_string}" not found in the body')
     sha_cutoff_index = (selector_index // 64) * 64
