@@ -58,11 +58,25 @@ __device__ __forceinline__ void zk_sha256_iv(u32* h) {
   h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
 }
 
+// 16 big-endian message words of a 64-byte block; 16-byte loads when the block is 16-byte aligned
+__device__ __forceinline__ void zk_load_block_be(u32* w, const u8* blk) {
+  if ((((uintptr_t)blk) & 15u) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint4 q = *(const uint4*)(blk + 16 * i);
+      w[4 * i + 0] = __builtin_bswap32(q.x); w[4 * i + 1] = __builtin_bswap32(q.y);
+      w[4 * i + 2] = __builtin_bswap32(q.z); w[4 * i + 3] = __builtin_bswap32(q.w);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = zk_ldbe32(blk + 4 * i);
+  }
+}
+
 // Plain compression (no trace): st <- compress(st, block bytes)
 __device__ inline void zk_sha256_compress(u32* st, const u8* blk) {
   u32 w[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) w[i] = zk_ldbe32(blk + 4 * i);
+  zk_load_block_be(w, blk);
   u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
 #pragma unroll
   for (int t = 0; t < 64; ++t) {

@@ -49,8 +49,7 @@ __global__ __launch_bounds__(64) void zk_sha_chain(ZkSched s, ZkBufs B) {
     bits[f.b_len] = len;
     u32 bl = 0;
     for (u32 n = f.max_bytes - 1; n > 0; n >>= 1) ++bl;
-    ok = ok && len < (1u << bl);
-    for (u32 i = len; i < f.max_bytes; ++i) ok = ok && rec[f.in_data + i] == 0;
+    ok = ok && len < (1u << bl);   // (the zero-padding scan itself is spread over zk_sha_trace's lanes)
   }
   if (!ok) B.status[e] = 4;
 
@@ -101,8 +100,28 @@ __global__ __launch_bounds__(64) void zk_sha_trace(ZkSched s, ZkBufs B) {
   u64* tr = B.bits + (u64)e * s.img_bits + f.b_trace + (u64)blk * ZK_TRACE_GROUPS;
 
   u32 w[64];
+  zk_load_block_be(w, blkp);
+  if (f.azp) {
+    // AssertZeroPadding(max)(data, length) (utils/array.circom:149-164): bytes at index >= length are zero;
+    // every lane checks the 64 bytes of its own block
+    const u32 len = *(const u32*)(B.in + (u64)e * s.in_stride + f.in_len);
+    const u32 base = 64u * blk;
+    bool bad = false;
+    if (len <= base) {
 #pragma unroll
-  for (int t = 0; t < 16; ++t) w[t] = zk_ldbe32(blkp + 4 * t);
+      for (int t = 0; t < 16; ++t) bad = bad || (w[t] != 0);
+    } else if (len < base + 64u) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const u32 first = base + 4u * t;                 // message word t holds bytes first..first+3, big-endian
+        u32 mask = 0;
+        if (len <= first) mask = 0xffffffffu;
+        else if (len < first + 4u) mask = 0xffffffffu >> (8u * (len - first));
+        bad = bad || ((w[t] & mask) != 0);
+      }
+    }
+    if (bad) B.status[e] = 4;
+  }
 #pragma unroll
   for (int t = 16; t < 64; ++t) {  // sigmaPlus[t-16]
     u32 x2 = w[t - 2], x15 = w[t - 15];
