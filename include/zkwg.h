@@ -67,9 +67,9 @@ typedef struct zkwg_config {
   uint32_t n;                        /* bits per RSA limb   (121) */
   uint32_t k;                        /* number of RSA limbs (17)  */
   uint32_t ignore_body_hash_check;   /* template flag, email-verifier.circom:42 */
-  uint32_t enable_header_masking;    /* must be 0 (not built yet) */
-  uint32_t enable_body_masking;      /* must be 0 */
-  uint32_t remove_soft_line_breaks;  /* must be 0 */
+  uint32_t enable_header_masking;    /* template flag: headerMask input, maskedHeader output */
+  uint32_t enable_body_masking;      /* template flag: bodyMask input, maskedBody output */
+  uint32_t remove_soft_line_breaks;  /* must be 0 (not built yet) */
   uint32_t layout;                   /* enum zkwg_layout */
 } zkwg_config;
 
@@ -84,7 +84,9 @@ enum zkwg_input_field {
   ZKWG_IN_HEADER_LEN = 6,     /* u32 emailHeaderLength / paddedInLength            */
   ZKWG_IN_BODY_LEN = 7,       /* u32 emailBodyLength                               */
   ZKWG_IN_BODY_HASH_INDEX = 8,/* u32 bodyHashIndex                                 */
-  ZKWG_IN_NFIELDS = 9
+  ZKWG_IN_HEADER_MASK = 9,    /* u8[max_header]  headerMask (enable_header_masking)  */
+  ZKWG_IN_BODY_MASK = 10,     /* u8[max_body]    bodyMask   (enable_body_masking)    */
+  ZKWG_IN_NFIELDS = 11
 };
 
 /* Per-email status: circom_runtime exception codes. */
@@ -130,6 +132,8 @@ int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* record,
                     const uint8_t* precomputed_sha, const uint8_t* pubkey_limbs,
                     const uint8_t* signature_limbs, const uint8_t* message_limbs,
                     uint32_t body_hash_index);
+/* headerMask / bodyMask of one record (flag variants; either pointer may be NULL). */
+int zkwg_pack_masks(const zkwg_circuit_t* c, uint8_t* record, const uint8_t* header_mask, const uint8_t* body_mask);
 
 /* Host-buffer batch: H2D of `packed_inputs` (n_emails records), kernels, D2H of
  * n_emails witnesses (32*W bytes each, `out_stride` bytes apart; out_wtns may be

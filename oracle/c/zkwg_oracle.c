@@ -515,6 +515,7 @@ static unsigned body_hash_regex(W* w, const u8* msg, u32 N, u32* rev) {
 /* ------------------------------------------------------------------ main circuits */
 typedef struct {
   u32 main_kind, max_header, max_body, ignore_body;
+  u32 mask_header, mask_body;   /* enableHeaderMasking / enableBodyMasking */
 } ocfg;
 
 static void load_limbs(u64 (*dst)[2], const u8* src) { for (int i = 0; i < 17; ++i) { memcpy(&dst[i][0], src + 16 * i, 8); memcpy(&dst[i][1], src + 16 * i + 8, 8); } }
@@ -528,8 +529,13 @@ static void assert_zero_padding(W* w, const u8* in, u32 N, u32 start) {
 }
 
 /* one email; returns witness length; status via w->failed */
+/* ByteMask(n) (utils/bytes.circom:173-185): out[i] <== in[i] * mask[i]; AssertBit on every mask[i] */
+static void byte_mask(W* w, const u8* in, const u8* mask, u32 n) {
+  for (u32 i = 0; i < n; ++i) { if (mask[i] > 1) fail(w); emit_u(w, (u64)in[i] * mask[i]); }
+}
 static void email_verifier(W* w, const ocfg* c, const u8* header, u32 hlen, const u8* body, u32 blen,
-                           const u8* pre, const u8* pubkey, const u8* sig, u32 bh_index) {
+                           const u8* pre, const u8* pubkey, const u8* sig, u32 bh_index,
+                           const u8* hmask, const u8* bmask) {
   const u32 N = c->max_header, M = c->max_body;
   u64 pk[17][2], sg[17][2], msg[17][2];
   load_limbs(pk, pubkey); load_limbs(sg, sig);
@@ -537,11 +543,15 @@ static void email_verifier(W* w, const ocfg* c, const u8* header, u32 hlen, cons
   emit_u(w, 1);
   const u64 out_slot = w->n;      /* pubkeyHash, shaHi, shaLo patched at the end */
   emit_u(w, 0); emit_u(w, 0); emit_u(w, 0);
+  if (c->mask_header) for (u32 i = 0; i < N; ++i) emit_u(w, (u64)header[i] * hmask[i]);      /* maskedHeader (output) */
+  if (c->mask_body) for (u32 i = 0; i < M; ++i) emit_u(w, (u64)body[i] * bmask[i]);          /* maskedBody (output) */
   emit_limbs(w, pk);
   for (u32 i = 0; i < N; ++i) emit_u(w, header[i]);
   emit_u(w, hlen);
   emit_limbs(w, sg);
-  if (!c->ignore_body) { emit_u(w, bh_index); for (int i = 0; i < 32; ++i) emit_u(w, pre[i]); for (u32 i = 0; i < M; ++i) emit_u(w, body[i]); emit_u(w, blen); }
+  if (c->mask_header) for (u32 i = 0; i < N; ++i) emit_u(w, hmask[i]);
+  if (!c->ignore_body) { emit_u(w, bh_index); for (int i = 0; i < 32; ++i) emit_u(w, pre[i]); for (u32 i = 0; i < M; ++i) emit_u(w, body[i]); emit_u(w, blen);
+    if (c->mask_body) for (u32 i = 0; i < M; ++i) emit_u(w, bmask[i]); }
   num2bits(w, fe_u64(hlen), log2ceil(N));
   assert_zero_padding(w, header, N, hlen);
   u32 dig[8];
@@ -549,6 +559,7 @@ static void email_verifier(W* w, const ocfg* c, const u8* header, u32 hlen, cons
   /* rsaMessage: sha bits as a 256-bit big-endian integer in 121-bit limbs */
   { bn D; bn_zero(&D); for (int j = 0; j < 4; ++j) D.d[j] = ((u64)dig[6 - 2 * j] << 32) | dig[7 - 2 * j]; bn_to_limbs121(msg, &D); }
   rsa_verifier(w, msg, sg, pk);
+  if (c->mask_header) byte_mask(w, header, hmask, N);
   if (!c->ignore_body) {
     num2bits(w, fe_u64(blen), log2ceil(M));
     assert_zero_padding(w, body, M, blen);
@@ -605,6 +616,7 @@ static void email_verifier(W* w, const ocfg* c, const u8* header, u32 hlen, cons
       if ((byte & 0xff) != ((bdig[i >> 2] >> (24 - 8 * (i & 3))) & 0xff)) fail(w);
     }
     free(rev); free(cur); free(nx);
+    if (c->mask_body) byte_mask(w, body, bmask, M);
   }
   fe ph = poseidon_large(w, pk);
   if (out_slot + 3 <= w->cap) {
@@ -638,12 +650,18 @@ static void rsa_main(W* w, const u8* msg_l, const u8* sig_l, const u8* mod_l) {
 /* Computes n witnesses.  Input fields are arrays with the given per-email strides (bytes); any
  * unused pointer may be NULL.  out: n * out_stride bytes (may be NULL: dry run that only counts);
  * status[i] = 0 / 4.  Returns the witness length in field elements. */
+/* flag variants: per-email headerMask / bodyMask arrays for the next calculate call (NULL = flag off) */
+static const u8* g_hmask = NULL;
+static const u8* g_bmask = NULL;
+void zkwg_oracle_set_masks(const u8* header_mask, const u8* body_mask) { g_hmask = header_mask; g_bmask = body_mask; }
+
 static u64 oracle_run(int per_thread_out, u32 main_kind, u32 max_header, u32 max_body, u32 ignore_body, u64 n,
                           const u8* header, const u32* hlen, const u8* body, const u32* blen, const u8* pre,
                           const u8* pubkey, const u8* sig, const u8* msg, const u32* bh_index,
                           u8* out, u64 out_stride, int* status, int threads) {
   init_invtab(); init_poseidon();
-  ocfg c = {main_kind, max_header, max_body, ignore_body};
+  const u8* hmask = g_hmask; const u8* bmask = g_bmask;
+  ocfg c = {main_kind, max_header, max_body, ignore_body, hmask != NULL, bmask != NULL};
   u64 wlen = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
   for (long long i = 0; i < (long long)n; ++i) {
@@ -651,7 +669,8 @@ static u64 oracle_run(int per_thread_out, u32 main_kind, u32 max_header, u32 max
     W w = {out ? out + slot * out_stride : NULL, 0, out ? out_stride / 32 : 0, 0};
     if (main_kind == 0)
       email_verifier(&w, &c, header + (u64)i * max_header, hlen[i], body ? body + (u64)i * max_body : NULL, blen ? blen[i] : 0,
-                     pre ? pre + 32 * i : NULL, pubkey + 272 * i, sig + 272 * i, bh_index ? bh_index[i] : 0);
+                     pre ? pre + 32 * i : NULL, pubkey + 272 * i, sig + 272 * i, bh_index ? bh_index[i] : 0,
+                     hmask ? hmask + (u64)i * max_header : NULL, bmask ? bmask + (u64)i * max_body : NULL);
     else if (main_kind == 1) sha_main(&w, &c, header + (u64)i * max_header, hlen[i]);
     else rsa_main(&w, msg + 272 * i, sig + 272 * i, pubkey + 272 * i);
     if (status) status[i] = w.failed ? 4 : 0;

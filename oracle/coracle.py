@@ -19,6 +19,8 @@ def load(build_if_missing=True):
         lib.zkwg_oracle_calculate.restype = C.c_uint64
         lib.zkwg_oracle_calculate.argtypes = [C.c_uint32] * 4 + [C.c_uint64] + [C.c_void_p] * 9 + [
             C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        lib.zkwg_oracle_set_masks.restype = None
+        lib.zkwg_oracle_set_masks.argtypes = [C.c_void_p, C.c_void_p]
         lib.zkwg_oracle_time.restype = C.c_uint64
         lib.zkwg_oracle_time.argtypes = lib.zkwg_oracle_calculate.argtypes
         _lib = lib
@@ -53,6 +55,12 @@ def calculate(main_kind, max_header, max_body, ignore_body, inputs, threads=1, w
             bl = u32a(i["emailBodyLength"] for i in inputs)
             pre = b"".join(bytes(int(b) for b in i["precomputedSHA"]) for i in inputs)
             bhi = u32a(i["bodyHashIndex"] for i in inputs)
+    hm = bm = None
+    if main_kind == 0 and "headerMask" in inputs[0]:
+        hm = b"".join(bytes(int(b) for b in i["headerMask"]) for i in inputs)
+    if main_kind == 0 and "bodyMask" in inputs[0]:
+        bm = b"".join(bytes(int(b) for b in i["bodyMask"]) for i in inputs)
+    lib.zkwg_oracle_set_masks(hm, bm)
     args = (main_kind, max_header, max_body, ignore_body, n, hdr, hl, body, bl, pre, pub, sig, msg, bhi)
     W = lib.zkwg_oracle_calculate(*args, None, 0, None, 1)
     status = (C.c_int * n)()
@@ -61,6 +69,7 @@ def calculate(main_kind, max_header, max_body, ignore_body, inputs, threads=1, w
         out = (C.c_uint8 * (n * W * 32))()
     lib.zkwg_oracle_calculate(*args, out, W * 32, status, threads)
     wits = [C.string_at(C.addressof(out) + i * W * 32, W * 32) for i in range(n)] if want_witness else None
+    lib.zkwg_oracle_set_masks(None, None)
     return wits, list(status), W
 
 

@@ -602,7 +602,8 @@ def PoseidonLarge(bitsPerChunk, chunkSize, in_):
 # ------------------------------------------------------------ email-verifier.circom
 
 
-def EmailVerifier(maxHeadersLength, maxBodyLength, n, k, ignoreBodyHashCheck, inputs, body_hash_regex=None):
+def EmailVerifier(maxHeadersLength, maxBodyLength, n, k, ignoreBodyHashCheck, inputs, body_hash_regex=None,
+                  enableHeaderMasking=0, enableBodyMasking=0):
     """email-verifier.circom:42-174 with enableHeaderMasking = enableBodyMasking =
     removeSoftLineBreaks = 0; main component, `public [ pubkey ]`
     (tests/test-circuits/email-verifier-test.circom:5).
@@ -611,7 +612,7 @@ def EmailVerifier(maxHeadersLength, maxBodyLength, n, k, ignoreBodyHashCheck, in
     Comp with .o = (out, reveal0[]) stands for the [EXT] BodyHashRegex template."""
     assert maxHeadersLength % 64 == 0 and maxBodyLength % 64 == 0
     assert n * k > 2048 and n < (255 // 2)
-    c = Comp(f"EmailVerifier({maxHeadersLength},{maxBodyLength},{n},{k},{ignoreBodyHashCheck},0,0,0)", is_main=True)
+    c = Comp(f"EmailVerifier({maxHeadersLength},{maxBodyLength},{n},{k},{ignoreBodyHashCheck},{enableHeaderMasking},{enableBodyMasking},0)", is_main=True)
     c.public = {"pubkey"}
     emailHeader = [int(x) % P for x in inputs["emailHeader"]]
     emailHeaderLength = int(inputs["emailHeaderLength"]) % P
@@ -644,6 +645,13 @@ def EmailVerifier(maxHeadersLength, maxBodyLength, n, k, ignoreBodyHashCheck, in
     message = [rsaMessage[i].o for i in range(rsaMessageSize)] + [0] * (k - rsaMessageSize)
     c.sub("rsaVerifier", RSAVerifier65537(n, k, message, signature, pubkey))
 
+    if enableHeaderMasking == 1:   # email-verifier.circom:97-105
+        headerMask = [int(x) % P for x in inputs["headerMask"]]
+        c.inp("headerMask", maxHeadersLength).setall(headerMask, "K")
+        maskedHeader = c.out("maskedHeader", maxHeadersLength)
+        bm = c.sub("byteMask_header", ByteMask(maxHeadersLength, emailHeader, headerMask))
+        maskedHeader.setall(bm.o, "L")
+
     if ignoreBodyHashCheck != 1:
         bodyHashIndex = int(inputs["bodyHashIndex"]) % P
         precomputedSHA = [int(x) % P for x in inputs["precomputedSHA"]]
@@ -673,6 +681,12 @@ def EmailVerifier(maxHeadersLength, maxBodyLength, n, k, ignoreBodyHashCheck, in
                 bits[7 - j] = shap.o[i * 8 + j]
             b2n = c.sub(f"computedBodyHashInts[{i}]", cl.Bits2Num(8, bits))
             c.eq(b2n.o, b64.o[i], "computedBodyHashInts[i].out === headerBodyHash[i] (email-verifier.circom:145)")
+        if enableBodyMasking == 1:   # email-verifier.circom:158-166
+            bodyMask = [int(x) % P for x in inputs["bodyMask"]]
+            c.inp("bodyMask", maxBodyLength).setall(bodyMask, "K")
+            maskedBody = c.out("maskedBody", maxBodyLength)
+            bmb = c.sub("byteMask_body", ByteMask(maxBodyLength, emailBody, bodyMask))
+            maskedBody.setall(bmb.o, "L")
 
     ph = c.sub("anon_PoseidonLarge", PoseidonLarge(n, k, pubkey))
     pubkeyHash.set(ph.o, "L")

@@ -74,7 +74,6 @@ static void build_inv_table(u32 inv_half, std::vector<Fr>& tab) {
   }
 }
 
-extern "C" int zk_expand_init_tables(void);
 extern "C" int zk_misc_init_tables(void);
 
 extern "C" {
@@ -127,7 +126,7 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return ZKWG_RC_NO_DEVICE; }
     if (hipSetDevice(device) != hipSuccess) { delete c; return ZKWG_RC_HIP_ERROR; }
     c->device = device;
-    if (zk_expand_init_tables() != 0 || zk_misc_init_tables() != 0) { delete c; return ZKWG_RC_HIP_ERROR; }
+    if (zk_misc_init_tables() != 0) { delete c; return ZKWG_RC_HIP_ERROR; }
     std::vector<Fr> tab;
     build_inv_table(c->s.inv_half, tab);
     bool ok = hipMalloc((void**)&c->d_invtab, tab.size() * sizeof(Fr)) == hipSuccess &&
@@ -211,6 +210,12 @@ int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header
   return ZKWG_RC_OK;
 }
 
+int zkwg_pack_masks(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header_mask, const uint8_t* body_mask) {
+  if (!c || !rec) return ZKWG_RC_BAD_ARG;
+  if (header_mask && c->s.mask_header) memcpy(rec + c->s.in_off[ZKWG_IN_HEADER_MASK], header_mask, c->cfg.max_header);
+  if (body_mask && c->s.mask_body) memcpy(rec + c->s.in_off[ZKWG_IN_BODY_MASK], body_mask, c->cfg.max_body);
+  return ZKWG_RC_OK;
+}
 int zkwg_set_prepare_throttle(zkwg_circuit_t* c, int rsa_wavefronts_per_cu) {
   if (!c || rsa_wavefronts_per_cu < 0) return ZKWG_RC_BAD_ARG;
   c->rsa_wgs_per_cu = rsa_wavefronts_per_cu;

@@ -10,7 +10,9 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
                         std::vector<u32>& first_seg, u32 portion = ZK_PORTION_DEFAULT) {
   memset(&s, 0, sizeof(s));
   if (cfg.layout != ZKWG_LAYOUT_KEPT_V1) return false;
-  if (cfg.enable_header_masking || cfg.enable_body_masking || cfg.remove_soft_line_breaks) return false;
+  if (cfg.remove_soft_line_breaks) return false;
+  if ((cfg.enable_header_masking || cfg.enable_body_masking) && cfg.main_kind != ZKWG_MAIN_EMAIL_VERIFIER) return false;
+  if (cfg.enable_body_masking && cfg.ignore_body_hash_check) return false;
   if (cfg.max_header % 64 != 0 || cfg.max_body % 64 != 0) return false;
   s.main_kind = cfg.main_kind;
   s.n = cfg.n; s.k = cfg.k; s.ignore_body = cfg.ignore_body_hash_check;
@@ -26,7 +28,12 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
   s.in_off[ZKWG_IN_HEADER_LEN] = off; off += 4;
   s.in_off[ZKWG_IN_BODY_LEN] = off; off += 4;
   s.in_off[ZKWG_IN_BODY_HASH_INDEX] = off; off += 4;
+  off = (off + 15u) & ~15u;
+  s.in_off[ZKWG_IN_HEADER_MASK] = off; off += cfg.enable_header_masking ? cfg.max_header : 0;
+  s.in_off[ZKWG_IN_BODY_MASK] = off; off += cfg.enable_body_masking ? cfg.max_body : 0;
   s.in_stride = (off + 15u) & ~15u;
+  s.mask_header = cfg.enable_header_masking ? 1u : 0u;
+  s.mask_body = cfg.enable_body_masking ? 1u : 0u;
 
   auto init_frame = [&](ZkShaFrame& f, u32 max_bytes, u32 partial, u32 in_data, u32 in_len) {
     f.max_bytes = max_bytes;

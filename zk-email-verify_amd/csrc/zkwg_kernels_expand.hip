@@ -162,6 +162,13 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
           dst[c] = v;
         }
         break;
+      case ZSEG_IN8MASK:
+        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          uint4 v = zk_zero4();
+          if (!(c & 1u)) { const u32 r = r0 + (c >> 1); v.x = (u32)rec[sg.src + r] * (u32)rec[sg.a + r]; }
+          dst[c] = v;
+        }
+        break;
       case ZSEG_IN8BITS:
         for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
           uint4 v = zk_zero4();
@@ -350,4 +357,3 @@ __global__ __launch_bounds__(512) void zk_expand_512(ZkSched s, ZkBufs B) { zk_e
 __global__ __launch_bounds__(1024) void zk_expand_1024(ZkSched s, ZkBufs B) { zk_expand_body<1024, false>(s, B); }
 __global__ __launch_bounds__(256) void zk_expand_wave(ZkSched s, ZkBufs B) { zk_expand_body<256, true>(s, B); }
 
-extern "C" int zk_expand_init_tables(void) { return 0; }

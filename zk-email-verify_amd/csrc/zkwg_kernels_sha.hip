@@ -122,6 +122,13 @@ __global__ __launch_bounds__(64) void zk_sha_trace(ZkSched s, ZkBufs B) {
     }
     if (bad) B.status[e] = 4;
   }
+  if ((fi == 0 && s.mask_header) || (fi == 1 && s.mask_body)) {
+    // ByteMask.bit_check[i] = AssertBit(): mask[i] * (mask[i] - 1) === 0  (utils/bytes.circom:155-158)
+    const u8* mk = B.in + (u64)e * s.in_stride + s.in_off[fi == 0 ? 9 : 10] + 64u * blk;
+    bool bad = false;
+    for (int t = 0; t < 64; ++t) bad = bad || (mk[t] > 1);
+    if (bad) B.status[e] = 4;
+  }
 #pragma unroll
   for (int t = 16; t < 64; ++t) {  // sigmaPlus[t-16]
     u32 x2 = w[t - 2], x15 = w[t - 15];

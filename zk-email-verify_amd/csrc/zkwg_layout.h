@@ -200,7 +200,6 @@ static inline void zk_alloc_rsa(ZkWalker& w, ZkRsaLayout& R) {
   R.b_msgbits = w.alloc_bits(34);
   R.m_modzero = w.alloc_small(205);
   R.b_sigbits = w.alloc_bits(34);
-  if (R.msg_from_digest) R.f_msg = w.alloc_fr(17);
   zk_alloc_blt(w, R.blt);
   for (u32 m = 0; m < 17; ++m) zk_alloc_fpmul(w, R.mul[m]);
 }
@@ -376,15 +375,19 @@ static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
   w.seg(ZSEG_SMALL, 1, s.m_one); w.one("one");
   w.seg(ZSEG_FR, 3, s.f_out);
   w.one("main.pubkeyHash"); w.one("main.shaHi"); w.one("main.shaLo");
+  if (s.mask_header) { w.seg(ZSEG_IN8MASK, N, s.fr[0].in_data, s.in_off[9]); w.arr("main.maskedHeader", N); }
+  if (s.mask_body) { w.seg(ZSEG_IN8MASK, M, s.fr[1].in_data, s.in_off[10]); w.arr("main.maskedBody", M); }
   w.seg(ZSEG_LIMB, 17, s.rsa.in_mod); w.arr("main.pubkey", 17);
   w.seg(ZSEG_IN8, N, s.fr[0].in_data); w.arr("main.emailHeader", N);
   w.seg(ZSEG_SMALL, 1, s.fr[0].m_len); w.one("main.emailHeaderLength");
   w.seg(ZSEG_LIMB, 17, s.rsa.in_sig); w.arr("main.signature", 17);
+  if (s.mask_header) { w.seg(ZSEG_IN8, N, s.in_off[9]); w.arr("main.headerMask", N); }
   if (s.body) {
     w.seg(ZSEG_SMALL, 1, s.m_bh_idx); w.one("main.bodyHashIndex");
     w.seg(ZSEG_IN8, 32, s.fr[1].in_pre); w.arr("main.precomputedSHA", 32);
     w.seg(ZSEG_IN8, M, s.fr[1].in_data); w.arr("main.emailBody", M);
     w.seg(ZSEG_SMALL, 1, s.fr[1].m_len); w.one("main.emailBodyLength");
+    if (s.mask_body) { w.seg(ZSEG_IN8, M, s.in_off[10]); w.arr("main.bodyMask", M); }
   }
   // sub-components in creation order
   const u32 blh = zk_log2ceil(N);
@@ -393,6 +396,10 @@ static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
   zk_walk_azp(w, "main.anon_AssertZeroPadding_header", s.fr[0]);
   zk_walk_sha_frame(w, "main.anon_Sha256Bytes", s.fr[0]);
   zk_walk_rsa(w, "main.rsaVerifier", s.rsa);
+  if (s.mask_header) {  // ByteMask(maxHeadersLength) (utils/bytes.circom:173-185): out[i] <== in[i] * mask[i]
+    w.seg(ZSEG_IN8MASK, N, s.fr[0].in_data, s.in_off[9]);
+    w.arr("main.byteMask_header.out", N);
+  }
   if (s.body) {
     const u32 blb = zk_log2ceil(M);
     w.seg(ZSEG_BITS, blb, s.fr[1].b_len, blb, 1);
@@ -430,6 +437,10 @@ static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
       for (auto m : eqs) { w.one(t + "." + m + ".out"); w.one(t + "." + m + ".inv"); }
     }
     zk_walk_sha_frame(w, "main.anon_Sha256BytesPartial", s.fr[1]);
+    if (s.mask_body) {
+      w.seg(ZSEG_IN8MASK, M, s.fr[1].in_data, s.in_off[10]);
+      w.arr("main.byteMask_body.out", M);
+    }
   }
   // PoseidonLarge(121,17) -> Poseidon(9): 8x10 + 60 S-boxes x (out, in2, in4)
   w.seg(ZSEG_FR, 420, s.f_pos);
@@ -442,5 +453,5 @@ static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
     std::string t = zk_idx(pp + ".sigmaP", r);
     w.one(t + ".out"); w.one(t + ".in2"); w.one(t + ".in4");
   }
-  s.n_public = 3 + 17;
+  s.n_public = 3 + (s.mask_header ? N : 0) + (s.mask_body ? M : 0) + 17;
 }

@@ -521,7 +521,6 @@ ZK_DEV inline void zk_rsa_email(ZkRsaLds& S, const ZkRsaLayout& R, const u8* rec
     bits[R.b_modbits + 2 * i] = S.p121[i][0]; bits[R.b_modbits + 2 * i + 1] = S.p121[i][1];
     bits[R.b_msgbits + 2 * i] = m0;           bits[R.b_msgbits + 2 * i + 1] = m1;
     bits[R.b_sigbits + 2 * i] = S.s121[i][0]; bits[R.b_sigbits + 2 * i + 1] = S.s121[i][1];
-    if (digest) frv[R.f_msg + i] = Fr{{m0, m1, 0, 0}};
   }
   ZK_SYNC();
   ZK_PAR_FOR(w, ZK_BIG) {

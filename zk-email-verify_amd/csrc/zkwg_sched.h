@@ -47,7 +47,8 @@ enum ZkSegType : u32 {
   ZSEG_B64BITS = 14,// Base64Decode bitsIn: 6 bits of the decoded value of char small[src + r/6]
   ZSEG_B64 = 15,    // Base64Lookup(char small[src + r/68]): 8 mids, 6 x 9 comparator bits, 3 IsZero pairs
   ZSEG_DFA = 16,    // BodyHashRegex DFA circuit arrays: a = ZkDfaKind, b/c = parameters, src = small idx of the per-position words (then class masks, primitive masks)
-  ZSEG_NTYPES = 17
+  ZSEG_IN8MASK = 17,// ByteMask: in[src + r] * in[a + r]   (data byte times mask byte)
+  ZSEG_NTYPES = 18
 };
 
 // ZSEG_DFA kinds (component arrays of the regex circuit, one entry per header position)
@@ -120,7 +121,6 @@ struct ZkRsaLayout {
   u32 b_modbits, b_msgbits;    // bits: 17 x 2 words each
   u32 m_modzero;               // small: 205 popcounts (IsZero inputs)
   u32 b_sigbits;               // bits: 17 x 2 words
-  u32 f_msg;                   // fr: message limbs (rsaMessage outputs; EmailVerifier only)
   ZkBltLayout blt;             // signature < modulus
   ZkFpMulLayout mul[17];       // doublers[0..15], adder
 };
@@ -133,7 +133,7 @@ struct ZkSched {
   u32 total_blocks;      // sum of nblocks
   u32 hstates_per_email; // sum of (nblocks+1)
   u32 in_stride;         // bytes per input record
-  u32 in_off[9];         // enum zkwg_input_field -> byte offset
+  u32 in_off[11];        // enum zkwg_input_field -> byte offset
   u32 n_public;
   u32 nsegs;
   u32 portion;           // witness slots expanded by one workgroup of zk_expand
@@ -152,6 +152,7 @@ struct ZkSched {
   u32 f_out;             // fr: pubkeyHash, shaHi, shaLo
   u32 f_pos;             // fr: 420 Poseidon S-box signals
   u32 body;              // 1: body-hash path present (ignoreBodyHashCheck != 1)
+  u32 mask_header, mask_body;  // template flags enableHeaderMasking / enableBodyMasking
   u32 m_bh_idx;          // small: bodyHashIndex (also SelectRegexReveal.startIndex / VarShiftLeft.shift)
   u32 m_rev;             // small: bhReveal[max_header]
   u32 m_chars;           // small: bhBase64[44]

@@ -48,9 +48,10 @@ class Circuit:
     """A compiled circuit handle (`component main = ...` with its template parameters)."""
 
     def __init__(self, main_kind=MAIN_EMAIL_VERIFIER, max_header=1024, max_body=1536, n=121, k=17,
-                 ignore_body_hash_check=0, device=0):
+                 ignore_body_hash_check=0, device=0, enable_header_masking=0, enable_body_masking=0):
         self.lib = _lib.load()
-        self.cfg = Config(main_kind, max_header, max_body, n, k, ignore_body_hash_check, 0, 0, 0, 0)
+        self.cfg = Config(main_kind, max_header, max_body, n, k, ignore_body_hash_check, enable_header_masking,
+                          enable_body_masking, 0, 0)
         h = C.c_void_p()
         _check(self.lib.zkwg_circuit_create(C.byref(self.cfg), device, C.byref(h)))
         self.h = h
@@ -79,9 +80,13 @@ class Circuit:
         if c.main_kind == MAIN_RSA_VERIFIER:
             return {"message": c.k, "signature": c.k, "modulus": c.k}
         sizes = {"emailHeader": c.max_header, "emailHeaderLength": 1, "pubkey": c.k, "signature": c.k}
+        if c.enable_header_masking:
+            sizes["headerMask"] = c.max_header
         if not c.ignore_body_hash_check:
             sizes.update({"bodyHashIndex": 1, "precomputedSHA": 32, "emailBody": c.max_body,
                           "emailBodyLength": 1})
+            if c.enable_body_masking:
+                sizes["bodyMask"] = c.max_body
         return sizes
 
     def pack(self, inp):
@@ -132,6 +137,10 @@ class Circuit:
                 pre = as_bytes(flat["precomputedSHA"], "precomputedSHA")
                 bhi = as_u32(flat["bodyHashIndex"][0], "bodyHashIndex")
         _check(self.lib.zkwg_pack_input(self.h, rec, header, hlen, body, blen, pre, pub, sig, msg, bhi))
+        if c.main_kind == MAIN_EMAIL_VERIFIER and (c.enable_header_masking or c.enable_body_masking):
+            hm = as_bytes(flat["headerMask"], "headerMask") if c.enable_header_masking else None
+            bm = as_bytes(flat["bodyMask"], "bodyMask") if c.enable_body_masking else None
+            _check(self.lib.zkwg_pack_masks(self.h, rec, hm, bm))
         return bytes(rec)
 
     # -- batch calculation -------------------------------------------------------------------
