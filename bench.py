@@ -55,13 +55,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    # test hooks (single-GPU smoke of the N>1 code path): ZKWG_BENCH_FORCE_DEVICE puts every rank on one
+    # GPU, ZKWG_BENCH_BACKEND=gloo replaces RCCL (two ranks cannot share a GPU under RCCL)
+    if os.environ.get("ZKWG_BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["ZKWG_BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("ZKWG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank)
     tile = min(args.tile, args.batch)
@@ -117,6 +125,8 @@ def main():
         with torch.cuda.stream(s_exp):
             # the only exchange step: gather the 100-byte/email result table on rank 0 (RCCL over xGMI)
             table = shard.result_table(d_status, d_rows)
+            if dist is not None and backend != "nccl":
+                table = table.cpu()                     # gloo test hook: gather on the host
             state["table"] = shard.gather_table(dist, table, args.batch * world, rank, world) if dist is not None else table
 
     def barrier():
@@ -138,7 +148,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     summ = c.timing_summary()
