@@ -322,7 +322,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     hipLaunchKernelGGL(zk_sha_trace, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
   }
   if (tm) hipEventRecord(evs[++ki], st);
-  if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 7 * s.fr[0].max_bytes + 64, st, s, B);
+  if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 7 * s.fr[0].max_bytes + 64 + ZK_DFA_STATES * 256 + 16, st, s, B);
   if (tm) hipEventRecord(evs[++ki], st);
   if (s.rsa.present) {
     // optional throttle: pad the workgroup's LDS claim so that only `rsa_wgs_per_cu` RSA wavefronts

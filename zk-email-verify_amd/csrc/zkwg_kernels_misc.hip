@@ -31,6 +31,9 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   u8* hdr = (u8*)(dyn_lds + N);       // N bytes
   u8* stl = hdr + N;                  // N + 3 state bytes (st[0..N+2))
   u8* live = stl + N + 4;             // N + 3
+  // the DFA transition table (7 KiB) is staged in LDS too: the scan is a chain of dependent lookups
+  unsigned char (*delta_l)[256] = (unsigned char (*)[256])(live + N + 4);
+  for (u32 i = lane; i < ZK_DFA_STATES * 64u; i += 64) ((u32*)delta_l)[i] = ((const u32*)ZKM_DELTA)[i];
   __shared__ u32 ok_sh;
   if (lane == 0) ok_sh = 1;
   for (u32 i = lane; i < N; i += 64) { rev[i] = 0; hdr[i] = rec[s.fr[0].in_data + i]; }
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   const u32 start = *(const u32*)(rec + s.in_off[8]);  // bodyHashIndex
   if (lane == 0) {
     // BodyHashRegex DFA scan (zkwg_regex_core.h): states, live chain, helper signals, reveal0
-    const u32 acc_count = zk_bh_dfa_scan(hdr, N, ZKM_DELTA, stl, live, small + s.m_dfa_own, rev);
+    const u32 acc_count = zk_bh_dfa_scan(hdr, N, delta_l, stl, live, small + s.m_dfa_own, rev);
     if (acc_count == 0) ok_sh = 0;                      // bhRegexMatch === 1
     small[s.m_dfa_acc] = acc_count;
     small[s.m_bh_idx] = start;
