@@ -380,11 +380,12 @@ static void rsa_verifier(W* w, u64 (*msg)[2], u64 (*sig)[2], u64 (*mod)[2]) {
   }
 }
 
-/* ------------------------------------------------------------------ Poseidon(9) */
-static fe* g_posC = NULL; static fe* g_posM = NULL; /* standard form */
-static void init_poseidon(void) {
-  if (g_posC) return;
-  const unsigned t = 10, rf = 8, rp = 60;
+/* ------------------------------------------------------------------ Poseidon(t - 1) */
+static fe* g_pC[18]; static fe* g_pM[18]; /* standard form, indexed by t */
+static const unsigned POS_RP[16] = {56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68}; /* t = 2..17 */
+static void init_poseidon_t(const unsigned t) {
+  if (g_pC[t]) return;
+  const unsigned rf = 8, rp = POS_RP[t - 2];
   u8 st[80]; int k = 0, head = 0;
 #define PUT(v, wd) for (int i_ = (wd) - 1; i_ >= 0; --i_) st[k++] = ((v) >> i_) & 1
   PUT(1, 2); PUT(0, 4); PUT(254, 12); PUT(t, 12); PUT(rf, 10); PUT(rp, 10);
@@ -393,7 +394,7 @@ static void init_poseidon(void) {
   u8 nb;
   for (int i = 0; i < 160; ++i) STEP(nb);
   fe* C = (fe*)malloc((rf + rp) * t * sizeof(fe));
-  fe xy[20];
+  fe xy[34];
   unsigned have = 0, havexy = 0;
   while (havexy < 2 * t) {
     fe v = fe_u64(0);
@@ -407,8 +408,13 @@ static void init_poseidon(void) {
   }
   fe* M = (fe*)malloc(t * t * sizeof(fe));
   for (unsigned i = 0; i < t; ++i) for (unsigned j = 0; j < t; ++j) M[i * t + j] = fe_inv(fe_add(xy[i], xy[t + j]));
-  g_posM = M; g_posC = C;
+  g_pM[t] = M; g_pC[t] = C;
+#undef PUT
+#undef STEP
 }
+#define g_posC g_pC[10]
+#define g_posM g_pM[10]
+static void init_poseidon(void) { init_poseidon_t(10); init_poseidon_t(3); init_poseidon_t(17); }
 static fe sigma(W* w, fe x) { fe x2 = fe_mul(x, x), x4 = fe_mul(x2, x2), x5 = fe_mul(x4, x); emit_fe(w, x5); emit_fe(w, x2); emit_fe(w, x4); return x5; }
 static fe poseidon_large(W* w, u64 (*pk)[2]) {
   fe stt[10]; stt[0] = fe_u64(0);
@@ -426,6 +432,78 @@ static fe poseidon_large(W* w, u64 (*pk)[2]) {
     if (r == 67) for (int q = 0; q < np; ++q) emit_fe(w, pbuf[q]);
   }
   return stt[0];
+}
+
+/* Poseidon(t - 1)(inputs) as oracle/pyref/poseidon.py: textbook rounds, kept signals = Sigma (out, in2, in4),
+ * sigmaF[8][t] before sigmaP[rp] in component order */
+static fe poseidon_t(W* w, unsigned t, const fe* inputs) {
+  const unsigned rp = POS_RP[t - 2];
+  fe stt[17], nw[17];
+  stt[0] = fe_u64(0);
+  for (unsigned i = 1; i < t; ++i) stt[i] = inputs[i - 1];
+  fe* pbuf = (fe*)malloc(3 * rp * sizeof(fe));
+  W tmp = {(u8*)pbuf, 0, 3 * rp, 0};
+  const fe* C = g_pC[t]; const fe* M = g_pM[t];
+  for (unsigned r = 0; r < 8 + rp; ++r) {
+    for (unsigned j = 0; j < t; ++j) stt[j] = fe_add(stt[j], C[r * t + j]);
+    if (r < 4 || r >= 4 + rp) { for (unsigned j = 0; j < t; ++j) stt[j] = sigma(w, stt[j]); }
+    else stt[0] = sigma(&tmp, stt[0]);
+    for (unsigned i = 0; i < t; ++i) { fe acc = fe_u64(0); for (unsigned j = 0; j < t; ++j) acc = fe_add(acc, fe_mul(M[i * t + j], stt[j])); nw[i] = acc; }
+    memcpy(stt, nw, t * sizeof(fe));
+  }
+  for (unsigned q = 0; q < 3 * rp; ++q) emit_fe(w, pbuf[q]);
+  free(pbuf);
+  return stt[0];
+}
+/* PoseidonModular(n) (utils/hash.circom:50-84), n % 16 == 0 here */
+static fe poseidon_modular(W* w, const fe* in, unsigned n) {
+  fe out = fe_u64(0);
+  for (unsigned i = 0; i < n / 16; ++i) {
+    fe h = poseidon_t(w, 17, in + 16 * i);
+    if (i == 0) out = h; else { fe pr[2] = {out, h}; out = poseidon_t(w, 3, pr); }
+  }
+  return out;
+}
+/* RemoveSoftLineBreaks(M) (helpers/remove-soft-line-breaks.circom:14-126) as a sub-component:
+ * kept signals in the order of oracle/pyref/zkemail.py RemoveSoftLineBreaks; returns isValid */
+static unsigned remove_soft_line_breaks(W* w, const u8* enc, const u8* dec, u32 M) {
+  /* r comes from a sub-component that is walked later: evaluate the hasher into a side buffer first */
+  const u32 nch = 2 * M / 16;
+  const u64 hcap = (u64)nch * 612 + (u64)(nch - 1) * 243;
+  fe* hbuf = (fe*)malloc(hcap * sizeof(fe));
+  W hw = {(u8*)hbuf, 0, hcap, 0};
+  fe* hin = (fe*)malloc(2 * M * sizeof(fe));
+  for (u32 i = 0; i < M; ++i) { hin[i] = fe_u64(enc[i]); hin[M + i] = fe_u64(dec[i]); }
+  const fe r = poseidon_modular(&hw, hin, 2 * M);
+  free(hin);
+  u8* sb = (u8*)calloc(M + 2, 1); u8* sz = (u8*)calloc(M, 1);
+  for (u32 i = 0; i + 2 < M; ++i) sb[i] = enc[i] == 61 && enc[i + 1] == 13 && enc[i + 2] == 10;
+  for (u32 i = 0; i < M; ++i) sz[i] = sb[i] + (i >= 1 ? sb[i - 1] : 0) + (i >= 2 ? sb[i - 2] : 0);
+  for (u32 i = 0; i < M; ++i) emit_u(w, (u64)(1 - sz[i]) * enc[i]);                          /* processed */
+  for (u32 i = 0; i + 2 < M; ++i) emit_u(w, enc[i] == 61 && enc[i + 1] == 13);                /* tempSoftBreak */
+  for (u32 i = 0; i + 2 < M; ++i) emit_u(w, sb[i]);                                          /* isSoftBreak[0..M-3] */
+  fe* rEnc = (fe*)malloc(M * sizeof(fe)); fe* c0 = (fe*)malloc(M * sizeof(fe));
+  for (u32 i = 0; i < M; ++i) {
+    fe a = i ? fe_mul(rEnc[i - 1], r) : r, b = i ? rEnc[i - 1] : fe_u64(1);
+    c0[i] = a; rEnc[i] = sz[i] ? b : a;      /* sz is 0/1 here: "=\r\n" cannot overlap itself */
+  }
+  fe acc = fe_u64(0);
+  for (u32 i = 0; i < M; ++i) { acc = fe_add(acc, fe_mul(rEnc[i], fe_u64((u64)(1 - sz[i]) * enc[i]))); emit_fe(w, acc); }   /* sumEnc */
+  const fe sumEnc = acc;
+  fe* rDec = (fe*)malloc(M * sizeof(fe));
+  rDec[0] = r;
+  for (u32 i = 1; i < M; ++i) { rDec[i] = fe_mul(rDec[i - 1], r); emit_fe(w, rDec[i]); }        /* rDec[1..] */
+  acc = fe_u64(0);
+  for (u32 i = 0; i < M; ++i) { acc = fe_add(acc, fe_mul(rDec[i], fe_u64(dec[i]))); emit_fe(w, acc); }                   /* sumDec */
+  const fe sumDec = acc;
+  for (u32 i = 0; i < M; ++i) { if (i) emit_fe(w, c0[i]); emit_fe(w, rEnc[i]); }               /* muxEnc[i].c[0], .mux.out[0] */
+  for (u64 q = 0; q < hcap; ++q) emit_fe(w, hbuf[q]);                                          /* rHasher */
+  for (u32 i = 0; i < M; ++i) iszero_small(w, 61 - (long long)enc[i]);
+  for (u32 i = 0; i + 1 < M; ++i) iszero_small(w, 13 - (long long)enc[i + 1]);
+  for (u32 i = 0; i + 2 < M; ++i) iszero_small(w, 10 - (long long)enc[i + 2]);
+  const unsigned valid = iszero(w, fe_sub(sumDec, sumEnc));
+  free(hbuf); free(sb); free(sz); free(rEnc); free(c0); free(rDec);
+  return valid;
 }
 
 /* ------------------------------------------------------------------ BodyHashRegex: zkwg DFA circuit v1 */
@@ -516,6 +594,7 @@ static unsigned body_hash_regex(W* w, const u8* msg, u32 N, u32* rev) {
 typedef struct {
   u32 main_kind, max_header, max_body, ignore_body;
   u32 mask_header, mask_body;   /* enableHeaderMasking / enableBodyMasking */
+  u32 rslb;                     /* removeSoftLineBreaks */
 } ocfg;
 
 static void load_limbs(u64 (*dst)[2], const u8* src) { for (int i = 0; i < 17; ++i) { memcpy(&dst[i][0], src + 16 * i, 8); memcpy(&dst[i][1], src + 16 * i + 8, 8); } }
@@ -535,7 +614,7 @@ static void byte_mask(W* w, const u8* in, const u8* mask, u32 n) {
 }
 static void email_verifier(W* w, const ocfg* c, const u8* header, u32 hlen, const u8* body, u32 blen,
                            const u8* pre, const u8* pubkey, const u8* sig, u32 bh_index,
-                           const u8* hmask, const u8* bmask) {
+                           const u8* hmask, const u8* bmask, const u8* decoded) {
   const u32 N = c->max_header, M = c->max_body;
   u64 pk[17][2], sg[17][2], msg[17][2];
   load_limbs(pk, pubkey); load_limbs(sg, sig);
@@ -551,6 +630,7 @@ static void email_verifier(W* w, const ocfg* c, const u8* header, u32 hlen, cons
   emit_limbs(w, sg);
   if (c->mask_header) for (u32 i = 0; i < N; ++i) emit_u(w, hmask[i]);
   if (!c->ignore_body) { emit_u(w, bh_index); for (int i = 0; i < 32; ++i) emit_u(w, pre[i]); for (u32 i = 0; i < M; ++i) emit_u(w, body[i]); emit_u(w, blen);
+    if (c->rslb) for (u32 i = 0; i < M; ++i) emit_u(w, decoded[i]);                        /* decodedEmailBodyIn */
     if (c->mask_body) for (u32 i = 0; i < M; ++i) emit_u(w, bmask[i]); }
   num2bits(w, fe_u64(hlen), log2ceil(N));
   assert_zero_padding(w, header, N, hlen);
@@ -616,6 +696,7 @@ static void email_verifier(W* w, const ocfg* c, const u8* header, u32 hlen, cons
       if ((byte & 0xff) != ((bdig[i >> 2] >> (24 - 8 * (i & 3))) & 0xff)) fail(w);
     }
     free(rev); free(cur); free(nx);
+    if (c->rslb && !remove_soft_line_breaks(w, body, decoded, M)) fail(w);   /* qpEncodingChecker.isValid === 1 */
     if (c->mask_body) byte_mask(w, body, bmask, M);
   }
   fe ph = poseidon_large(w, pk);
@@ -653,6 +734,9 @@ static void rsa_main(W* w, const u8* msg_l, const u8* sig_l, const u8* mod_l) {
 /* flag variants: per-email headerMask / bodyMask arrays for the next calculate call (NULL = flag off) */
 static const u8* g_hmask = NULL;
 static const u8* g_bmask = NULL;
+static const u8* g_decoded = NULL;
+/* removeSoftLineBreaks = 1: per-email decodedEmailBodyIn arrays for the next calculate call (NULL = flag off) */
+void zkwg_oracle_set_decoded(const u8* decoded) { g_decoded = decoded; }
 void zkwg_oracle_set_masks(const u8* header_mask, const u8* body_mask) { g_hmask = header_mask; g_bmask = body_mask; }
 
 static u64 oracle_run(int per_thread_out, u32 main_kind, u32 max_header, u32 max_body, u32 ignore_body, u64 n,
@@ -661,7 +745,8 @@ static u64 oracle_run(int per_thread_out, u32 main_kind, u32 max_header, u32 max
                           u8* out, u64 out_stride, int* status, int threads) {
   init_invtab(); init_poseidon();
   const u8* hmask = g_hmask; const u8* bmask = g_bmask;
-  ocfg c = {main_kind, max_header, max_body, ignore_body, hmask != NULL, bmask != NULL};
+  const u8* decoded = g_decoded;
+  ocfg c = {main_kind, max_header, max_body, ignore_body, hmask != NULL, bmask != NULL, decoded != NULL};
   u64 wlen = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
   for (long long i = 0; i < (long long)n; ++i) {
@@ -670,7 +755,8 @@ static u64 oracle_run(int per_thread_out, u32 main_kind, u32 max_header, u32 max
     if (main_kind == 0)
       email_verifier(&w, &c, header + (u64)i * max_header, hlen[i], body ? body + (u64)i * max_body : NULL, blen ? blen[i] : 0,
                      pre ? pre + 32 * i : NULL, pubkey + 272 * i, sig + 272 * i, bh_index ? bh_index[i] : 0,
-                     hmask ? hmask + (u64)i * max_header : NULL, bmask ? bmask + (u64)i * max_body : NULL);
+                     hmask ? hmask + (u64)i * max_header : NULL, bmask ? bmask + (u64)i * max_body : NULL,
+                     decoded ? decoded + (u64)i * max_body : NULL);
     else if (main_kind == 1) sha_main(&w, &c, header + (u64)i * max_header, hlen[i]);
     else rsa_main(&w, msg + 272 * i, sig + 272 * i, pubkey + 272 * i);
     if (status) status[i] = w.failed ? 4 : 0;

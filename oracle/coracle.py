@@ -21,6 +21,8 @@ def load(build_if_missing=True):
             C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         lib.zkwg_oracle_set_masks.restype = None
         lib.zkwg_oracle_set_masks.argtypes = [C.c_void_p, C.c_void_p]
+        lib.zkwg_oracle_set_decoded.restype = None
+        lib.zkwg_oracle_set_decoded.argtypes = [C.c_void_p]
         lib.zkwg_oracle_time.restype = C.c_uint64
         lib.zkwg_oracle_time.argtypes = lib.zkwg_oracle_calculate.argtypes
         _lib = lib
@@ -60,7 +62,11 @@ def calculate(main_kind, max_header, max_body, ignore_body, inputs, threads=1, w
         hm = b"".join(bytes(int(b) for b in i["headerMask"]) for i in inputs)
     if main_kind == 0 and "bodyMask" in inputs[0]:
         bm = b"".join(bytes(int(b) for b in i["bodyMask"]) for i in inputs)
+    dec = None
+    if main_kind == 0 and "decodedEmailBodyIn" in inputs[0]:
+        dec = b"".join(bytes(int(b) for b in i["decodedEmailBodyIn"]) for i in inputs)
     lib.zkwg_oracle_set_masks(hm, bm)
+    lib.zkwg_oracle_set_decoded(dec)
     args = (main_kind, max_header, max_body, ignore_body, n, hdr, hl, body, bl, pre, pub, sig, msg, bhi)
     W = lib.zkwg_oracle_calculate(*args, None, 0, None, 1)
     status = (C.c_int * n)()
@@ -70,6 +76,7 @@ def calculate(main_kind, max_header, max_body, ignore_body, inputs, threads=1, w
     lib.zkwg_oracle_calculate(*args, out, W * 32, status, threads)
     wits = [C.string_at(C.addressof(out) + i * W * 32, W * 32) for i in range(n)] if want_witness else None
     lib.zkwg_oracle_set_masks(None, None)
+    lib.zkwg_oracle_set_decoded(None)
     return wits, list(status), W
 
 
@@ -87,6 +94,8 @@ def run_fields(max_header, max_body, ignore_body, fields, n, threads=1, out=None
     if not ignore_body:
         body, pre = bytes(fields["body"]), bytes(fields["pre"])
         bl, bhi = u32a(fields["blen"]), u32a(fields["bhi"])
+    dec = bytes(fields["decoded"]) if fields.get("decoded") else None
+    lib.zkwg_oracle_set_decoded(dec)
     args = (0, max_header, max_body, ignore_body, n, hdr, hl, body, bl, pre, pub, sig, None, bhi)
     W = lib.zkwg_oracle_calculate(0, max_header, max_body, ignore_body, 1, hdr, hl, body, bl, pre, pub, sig, None, bhi,
                                   None, 0, None, 1)
@@ -95,4 +104,5 @@ def run_fields(max_header, max_body, ignore_body, fields, n, threads=1, out=None
     fn = lib.zkwg_oracle_time if per_thread_out else lib.zkwg_oracle_calculate
     fn(*args, out, (W * 32) if out is not None else 0, status, threads)
     dt = time.perf_counter() - t0
+    lib.zkwg_oracle_set_decoded(None)
     return W, list(status), dt

@@ -599,20 +599,154 @@ def PoseidonLarge(bitsPerChunk, chunkSize, in_):
     return c
 
 
+def Slice(n, start, end, in_):
+    """utils/array.circom:175-186: out[i - start] <== in[i]."""
+    assert n >= end and start >= 0 and end >= start
+    c = Comp(f"Slice({n},{start},{end})")
+    out = c.out("out", end - start)
+    c.inp("in", n).setall(in_, "L")
+    out.setall(in_[start:end], "L")
+    c.o = out.v
+    return c
+
+
+def PoseidonModular(numElements, in_):
+    """utils/hash.circom:50-84: Poseidon(16) per chunk, chained through Poseidon(2)."""
+    from . import poseidon as pos
+    c = Comp(f"PoseidonModular({numElements})")
+    out = c.out("out")
+    c.inp("in", numElements).setall(in_, "L")
+    chunks = numElements // 16
+    last_chunk_size = numElements % 16
+    if last_chunk_size != 0:
+        chunks += 1
+    _out = 0
+    for i in range(chunks):
+        start = i * 16
+        end = start + 16
+        if end > numElements:
+            end = numElements
+            sl = c.sub(f"anon_Slice[{i}]", Slice(numElements, start, end, in_))
+            ch = c.sub(f"anon_Poseidon_chunk[{i}]", pos.Poseidon(last_chunk_size, sl.o))
+        else:
+            sl = c.sub(f"anon_Slice[{i}]", Slice(numElements, start, end, in_))
+            ch = c.sub(f"anon_Poseidon_chunk[{i}]", pos.Poseidon(16, sl.o))
+        if i == 0:
+            _out = ch.o
+        else:
+            _out = c.sub(f"anon_Poseidon_merge[{i}]", pos.Poseidon(2, [_out, ch.o])).o
+    c.o = out.set(_out, "L")
+    return c
+
+
+def Mux1(c0, c1, s, how0="L"):
+    """circomlib mux1.circom [EXT]: Mux1 wraps MultiMux1(1); out <== (c[1] - c[0])*s + c[0].
+    `how0`: how the parent assigned c[0] (RemoveSoftLineBreaks feeds a product into it)."""
+    c = Comp("Mux1")
+    out = c.out("out")
+    ci = c.inp("c", 2)
+    ci.set(c0, how0, 0)
+    ci.set(c1, "L", 1)
+    c.inp("s").set(s, "L")
+    m = Comp("MultiMux1(1)")
+    mout = m.out("out", 1)
+    m.inp("c", 2).setall([c0, c1], "L")      # c[0][0], c[0][1]
+    m.inp("s").set(s, "L")
+    mout.set((c1 - c0) * s + c0, "Q", 0)
+    c.sub("mux", m)
+    c.o = out.set(mout.v[0], "L")
+    return c
+
+
+def RemoveSoftLineBreaks(maxLength, encoded, decoded, is_main=False):
+    """helpers/remove-soft-line-breaks.circom:14-126."""
+    c = Comp(f"RemoveSoftLineBreaks({maxLength})", is_main=is_main)
+    M = maxLength
+    isValid = c.out("isValid")
+    c.inp("encoded", M).setall(encoded, "L")
+    c.inp("decoded", M).setall(decoded, "L")
+    encoded = [x % P for x in encoded]
+    decoded = [x % P for x in decoded]
+    r_s = c.mid("r")
+    processed = c.mid("processed", M)
+    isEquals = c.mid("isEquals", M)
+    isCr = c.mid("isCr", M)
+    isLf = c.mid("isLf", M)
+    tempSoftBreak = c.mid("tempSoftBreak", M - 2)
+    isSoftBreak = c.mid("isSoftBreak", M)
+    shouldZero = c.mid("shouldZero", M)
+    rEnc = c.mid("rEnc", M)
+    sumEnc = c.mid("sumEnc", M)
+    rDec = c.mid("rDec", M)
+    sumDec = c.mid("sumDec", M)
+    # `component muxEnc[maxLength]` is declared before rHasher (:33-36)
+    mux_slots = [None] * M
+    for i in range(M):
+        c.subs.append([f"muxEnc[{i}]", None])
+        mux_slots[i] = c.subs[-1]
+    rHasher = c.sub("rHasher", PoseidonModular(2 * M, encoded + decoded))
+    r = r_s.set(rHasher.o, "L")
+    for i in range(M):
+        isEquals.set(c.sub(f"anon_IsEqual_eq[{i}]", cl.IsEqual(encoded[i], 61)).o, "L", i)
+    for i in range(M - 1):
+        isCr.set(c.sub(f"anon_IsEqual_cr[{i}]", cl.IsEqual(encoded[i + 1], 13)).o, "L", i)
+    isCr.set(0, "L", M - 1)
+    for i in range(M - 2):
+        isLf.set(c.sub(f"anon_IsEqual_lf[{i}]", cl.IsEqual(encoded[i + 2], 10)).o, "L", i)
+    isLf.set(0, "L", M - 2)
+    isLf.set(0, "L", M - 1)
+    for i in range(M - 2):
+        tempSoftBreak.set(isEquals.v[i] * isCr.v[i], "Q", i)
+        isSoftBreak.set(tempSoftBreak.v[i] * isLf.v[i], "Q", i)
+    isSoftBreak.set(0, "L", M - 2)
+    isSoftBreak.set(0, "L", M - 1)
+    for i in range(M):
+        if i == 0:
+            v = isSoftBreak.v[i]
+        elif i == 1:
+            v = isSoftBreak.v[i] + isSoftBreak.v[i - 1]
+        elif i == M - 1:
+            v = isSoftBreak.v[i - 1] + isSoftBreak.v[i - 2]
+        else:
+            v = isSoftBreak.v[i] + isSoftBreak.v[i - 1] + isSoftBreak.v[i - 2]
+        shouldZero.set(v, "L", i)
+    for i in range(M):
+        processed.set((1 - shouldZero.v[i]) * encoded[i], "Q", i)
+    m0 = Mux1(r, 1, shouldZero.v[0], "L")
+    mux_slots[0][1] = m0
+    rEnc.set(m0.o, "L", 0)
+    for i in range(1, M):
+        mi = Mux1(rEnc.v[i - 1] * r % P, rEnc.v[i - 1], shouldZero.v[i], "Q")
+        mux_slots[i][1] = mi
+        rEnc.set(mi.o, "L", i)
+    c.subs = [tuple(x) if isinstance(x, list) else x for x in c.subs]
+    rDec.set(r, "L", 0)
+    for i in range(1, M):
+        rDec.set(rDec.v[i - 1] * r, "Q", i)
+    sumEnc.set(rEnc.v[0] * processed.v[0], "Q", 0)
+    for i in range(1, M):
+        sumEnc.set(sumEnc.v[i - 1] + rEnc.v[i] * processed.v[i], "Q", i)
+    sumDec.set(rDec.v[0] * decoded[0], "Q", 0)
+    for i in range(1, M):
+        sumDec.set(sumDec.v[i - 1] + rDec.v[i] * decoded[i], "Q", i)
+    fin = c.sub("anon_IsEqual_final", cl.IsEqual(sumEnc.v[M - 1], sumDec.v[M - 1]))
+    c.o = isValid.set(fin.o, "L")
+    return c
+
+
 # ------------------------------------------------------------ email-verifier.circom
 
 
 def EmailVerifier(maxHeadersLength, maxBodyLength, n, k, ignoreBodyHashCheck, inputs, body_hash_regex=None,
-                  enableHeaderMasking=0, enableBodyMasking=0):
-    """email-verifier.circom:42-174 with enableHeaderMasking = enableBodyMasking =
-    removeSoftLineBreaks = 0; main component, `public [ pubkey ]`
+                  enableHeaderMasking=0, enableBodyMasking=0, removeSoftLineBreaks=0):
+    """email-verifier.circom:42-174; main component, `public [ pubkey ]`
     (tests/test-circuits/email-verifier-test.circom:5).
 
     `inputs`: dict of integer lists/ints keyed by signal name.  `body_hash_regex(msg)` ->
     Comp with .o = (out, reveal0[]) stands for the [EXT] BodyHashRegex template."""
     assert maxHeadersLength % 64 == 0 and maxBodyLength % 64 == 0
     assert n * k > 2048 and n < (255 // 2)
-    c = Comp(f"EmailVerifier({maxHeadersLength},{maxBodyLength},{n},{k},{ignoreBodyHashCheck},{enableHeaderMasking},{enableBodyMasking},0)", is_main=True)
+    c = Comp(f"EmailVerifier({maxHeadersLength},{maxBodyLength},{n},{k},{ignoreBodyHashCheck},{enableHeaderMasking},{enableBodyMasking},{removeSoftLineBreaks})", is_main=True)
     c.public = {"pubkey"}
     emailHeader = [int(x) % P for x in inputs["emailHeader"]]
     emailHeaderLength = int(inputs["emailHeaderLength"]) % P
@@ -681,6 +815,11 @@ def EmailVerifier(maxHeadersLength, maxBodyLength, n, k, ignoreBodyHashCheck, in
                 bits[7 - j] = shap.o[i * 8 + j]
             b2n = c.sub(f"computedBodyHashInts[{i}]", cl.Bits2Num(8, bits))
             c.eq(b2n.o, b64.o[i], "computedBodyHashInts[i].out === headerBodyHash[i] (email-verifier.circom:145)")
+        if removeSoftLineBreaks == 1:   # email-verifier.circom:148-156
+            decodedEmailBodyIn = [int(x) % P for x in inputs["decodedEmailBodyIn"]]
+            c.inp("decodedEmailBodyIn", maxBodyLength).setall(decodedEmailBodyIn, "K")
+            qp = c.sub("qpEncodingChecker", RemoveSoftLineBreaks(maxBodyLength, emailBody, decodedEmailBodyIn))
+            c.eq(qp.o, 1, "qpEncodingChecker.isValid === 1 (email-verifier.circom:155)")
         if enableBodyMasking == 1:   # email-verifier.circom:158-166
             bodyMask = [int(x) % P for x in inputs["bodyMask"]]
             c.inp("bodyMask", maxBodyLength).setall(bodyMask, "K")

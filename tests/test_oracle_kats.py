@@ -134,3 +134,28 @@ def test_bigint_func_long_div_matches_integer_division():
         q = sum(v << (121 * i) for i, v in enumerate(out[0][:18]))
         r = sum(v << (121 * i) for i, v in enumerate(out[1][:17]))
         assert (q, r) == divmod(a * b, p)
+
+
+def test_remove_soft_line_breaks_test_ts():
+    # packages/circuits/tests/remove-soft-line-breaks.test.ts: all 7 cases of RemoveSoftLineBreaks(32)
+    # (fixture extracted by tests/golden/make_rslb_kats.py)
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "rslb_kats.json")))
+    assert len(kat["cases"]) == 7
+    for case in kat["cases"]:
+        c = zk.RemoveSoftLineBreaks(kat["maxLength"], case["encoded"], case["decoded"], is_main=True)
+        assert c.o == case["isValid"], case["name"]
+
+
+def test_poseidon16_known_vector_and_modular_chain():
+    # circomlibjs' own test vector for 16 inputs pins the regenerated t = 17 constants used by
+    # PoseidonModular (utils/hash.circom:50-84); the chain mirrors helpers/src/hash.ts:19-52.
+    from oracle.pyref import poseidon
+    assert poseidon.poseidon_hash(list(range(1, 17))) == \
+        9989051620750914585850546081941653841776809718687451684622678807385399211877
+    rng = random.Random(37)
+    xs = [rng.randrange(1 << 53) for _ in range(37)]   # poseidon-modular.test.ts:26-28 shape
+    out = None
+    for i in range(0, 37, 16):
+        h = poseidon.poseidon_hash(xs[i:i + 16])
+        out = h if out is None else poseidon.poseidon_hash([out, h])
+    assert zk.PoseidonModular(37, xs).o == out

@@ -113,8 +113,44 @@ def to_circom_bigint_bytes(num: int):
     return [str((num >> (i * CIRCOM_BIGINT_N)) & msk) for i in range(CIRCOM_BIGINT_K)]
 
 
+def remove_soft_line_breaks(body: bytes):
+    """input-generators.ts:127-158: drops every "=\r\n", zero-pads back to len(body); also returns
+    the clean -> original position map."""
+    result = bytearray()
+    position_map = {}
+    i = 0
+    n = len(body)
+    while i < n:
+        if i + 2 < n and body[i] == 61 and body[i + 1] == 13 and body[i + 2] == 10:
+            i += 3
+        else:
+            position_map[len(result)] = i
+            result.append(body[i])
+            i += 1
+    result.extend(b"\0" * (n - len(result)))
+    return bytes(result), position_map
+
+
+def get_adjusted_selector(original_body: bytes, selector: str, clean_content: bytes, position_map) -> str:
+    """input-generators.ts:44-105 (findSelectorInCleanContent + getAdjustedSelector)."""
+    body_string = original_body.decode("utf-8", errors="replace")
+    if selector in body_string:
+        return selector
+    clean_string = clean_content.decode("utf-8", errors="replace")
+    selector_index = clean_string.find(selector)
+    if selector_index == -1:
+        raise ValueError(f'SHA precompute selector "{selector}" not found in cleaned body')
+    if selector_index not in position_map:
+        raise ValueError("Failed to map selector position to original body")
+    original_index = position_map[selector_index]
+    return body_string[original_index:original_index + len(selector) + 3]
+
+
 def generate_email_verifier_inputs_from_dkim_result(dkim, max_headers_length=None, max_body_length=None,
-                                                    ignore_body_hash_check=False, sha_precompute_selector=None):
+                                                    ignore_body_hash_check=False, sha_precompute_selector=None,
+                                                    enable_header_masking=False, header_mask=None,
+                                                    enable_body_masking=False, body_mask=None,
+                                                    remove_soft_line_breaks_flag=False):
     """input-generators.ts:190-252.  `dkim` = dict(headers: bytes, body: bytes, bodyHash: str,
     publicKey: int, signature: int) -- the DKIMVerificationResult fields the function uses."""
     headers = dkim["headers"]
@@ -125,6 +161,8 @@ def generate_email_verifier_inputs_from_dkim_result(dkim, max_headers_length=Non
         "pubkey": to_circom_bigint_bytes(dkim["publicKey"]),
         "signature": to_circom_bigint_bytes(dkim["signature"]),
     }
+    if enable_header_masking:
+        inputs["headerMask"] = list(header_mask)
     if not ignore_body_hash_check:
         body, body_hash = dkim.get("body"), dkim.get("bodyHash")
         if not body and body != b"" or not body_hash:
@@ -133,10 +171,20 @@ def generate_email_verifier_inputs_from_dkim_result(dkim, max_headers_length=Non
         max_body = max_body_length or MAX_BODY_PADDED_BYTES
         body_sha_length = ((len(body) + 63 + 65) // 64) * 64
         body_padded, body_padded_len = sha256_pad(body, max(max_body, body_sha_length))
+        adjusted_selector = sha_precompute_selector
+        if sha_precompute_selector:
+            clean, pmap = remove_soft_line_breaks(body_padded)
+            sel = sha_precompute_selector if isinstance(sha_precompute_selector, str) else sha_precompute_selector.decode()
+            adjusted_selector = get_adjusted_selector(body, sel, clean, pmap)
         pre, remaining, remaining_len = generate_partial_sha(body_padded, body_padded_len,
-                                                             sha_precompute_selector, max_body)
+                                                             adjusted_selector, max_body)
         inputs["emailBodyLength"] = str(remaining_len)
         inputs["precomputedSHA"] = [str(b) for b in pre]
         inputs["bodyHashIndex"] = str(body_hash_index)
         inputs["emailBody"] = [str(b) for b in remaining]
+        if remove_soft_line_breaks_flag:
+            clean, _ = remove_soft_line_breaks(remaining)
+            inputs["decodedEmailBodyIn"] = [str(b) for b in clean]
+        if enable_body_masking:
+            inputs["bodyMask"] = list(body_mask)
     return inputs

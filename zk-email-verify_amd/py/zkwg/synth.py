@@ -38,25 +38,33 @@ def pkcs1_sign_digest(key, digest: bytes) -> int:
     return m2 + h * key["q"]
 
 
-def synthetic_body(rng, length):
-    """printable ASCII, <= 76-char lines, CRLF line ends, exactly one trailing CRLF, no trailing spaces."""
+def synthetic_body(rng, length, soft_breaks=False):
+    """printable ASCII, <= 76-char lines, CRLF line ends, exactly one trailing CRLF, no trailing spaces.
+    soft_breaks: quoted-printable style, about half of the lines end in a soft line break "=\\r\\n"
+    (and no other '=' appears, as in QP text without escapes)."""
     out = bytearray()
     while len(out) < length - 2:
         n = min(76, length - 2 - len(out) - 2)
         if n <= 0:
             break
-        line = bytes(rng.randrange(0x21, 0x7F) for _ in range(n))
+        if soft_breaks:
+            line = bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz ABCDEFGHIJ0123456789.,;:!?-") for _ in range(n))
+            line = line.rstrip(b" ") + b"x" * (n - len(line.rstrip(b" ")))
+            if n == 76 and rng.random() < 0.5:
+                line = line[:75] + b"="
+        else:
+            line = bytes(rng.randrange(0x21, 0x7F) for _ in range(n))
         out += line + b"\r\n"
     while len(out) < length - 2:
         out[-2:-2] = b"x"
     return bytes(out[:length - 2]) + b"\r\n" if len(out) >= length else bytes(out)
 
 
-def synthetic_dkim_result(seed, index, body_len=1024):
+def synthetic_dkim_result(seed, index, body_len=1024, soft_breaks=False):
     """dict(headers, body, bodyHash, publicKey, signature) as `verifyDKIMSignature` would return."""
     rng = random.Random((seed << 20) ^ index)
     key = test_key()
-    body = synthetic_body(rng, body_len)
+    body = synthetic_body(rng, body_len, soft_breaks)
     bh = base64.b64encode(hashlib.sha256(body).digest()).decode()
     mid = "%016x" % rng.getrandbits(64)
     subj = "".join(chr(rng.randrange(0x61, 0x7B)) for _ in range(rng.randrange(8, 24)))
