@@ -69,7 +69,7 @@ typedef struct zkwg_config {
   uint32_t ignore_body_hash_check;   /* template flag, email-verifier.circom:42 */
   uint32_t enable_header_masking;    /* template flag: headerMask input, maskedHeader output */
   uint32_t enable_body_masking;      /* template flag: bodyMask input, maskedBody output */
-  uint32_t remove_soft_line_breaks;  /* must be 0 (not built yet) */
+  uint32_t remove_soft_line_breaks;  /* template flag: decodedEmailBodyIn input, RemoveSoftLineBreaks check */
   uint32_t layout;                   /* enum zkwg_layout */
 } zkwg_config;
 
@@ -86,7 +86,8 @@ enum zkwg_input_field {
   ZKWG_IN_BODY_HASH_INDEX = 8,/* u32 bodyHashIndex                                 */
   ZKWG_IN_HEADER_MASK = 9,    /* u8[max_header]  headerMask (enable_header_masking)  */
   ZKWG_IN_BODY_MASK = 10,     /* u8[max_body]    bodyMask   (enable_body_masking)    */
-  ZKWG_IN_NFIELDS = 11
+  ZKWG_IN_DECODED_BODY = 11,  /* u8[max_body]    decodedEmailBodyIn (remove_soft_line_breaks) */
+  ZKWG_IN_NFIELDS = 12
 };
 
 /* Per-email status: circom_runtime exception codes. */
@@ -134,6 +135,9 @@ int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* record,
                     uint32_t body_hash_index);
 /* headerMask / bodyMask of one record (flag variants; either pointer may be NULL). */
 int zkwg_pack_masks(const zkwg_circuit_t* c, uint8_t* record, const uint8_t* header_mask, const uint8_t* body_mask);
+/* decodedEmailBodyIn of one record (remove_soft_line_breaks = 1): max_body bytes, the output of
+ * `removeSoftLineBreaks(bodyRemaining)` (packages/helpers/src/input-generators.ts:127-158, 241-244). */
+int zkwg_pack_decoded_body(const zkwg_circuit_t* c, uint8_t* record, const uint8_t* decoded_body);
 
 /* Host-buffer batch: H2D of `packed_inputs` (n_emails records), kernels, D2H of
  * n_emails witnesses (32*W bytes each, `out_stride` bytes apart; out_wtns may be

@@ -6,6 +6,7 @@
 #include "zkwg_build.h"
 #include "zkwg_rsa_core.h"
 #include "zkwg_poseidon_core.h"
+#include "zkwg_poseidon_sparse.h"
 #include "zkwg_regex_core.h"
 
 struct HT {
@@ -50,6 +51,22 @@ void ht_poseidon(const uint8_t* limbs, void* out420, void* hash) {
   memcpy(l, limbs, sizeof(l));
   zk_poseidon_large(*S, l, C.data(), M.data(), (Fr*)out420, (Fr*)hash);
   delete S;
+}
+// Poseidon(t-1) through the product's sparse-partial-round evaluator (zkwg_poseidon_sparse.h):
+// inputs = t-1 standard-form Fr, emit = 3*(8t+rp) Fr, returns 0 on success
+int ht_poseidon_sparse(uint32_t t, const void* inputs, void* emit, void* hash) {
+  const u32 rp = ZK_POS_RP_TAB[t - 2];
+  std::vector<Fr> C, M, tab;
+  build_poseidon_constants(t, 8, rp, C, M);
+  if (!zk_build_poseidon_sparse(t, rp, C, M, tab)) return 1;
+  std::vector<Fr> st(t, fr_zero());
+  memcpy(&st[1], inputs, (t - 1) * sizeof(Fr));
+  Fr h;
+  if (t == 3) h = zk_poseidon_sparse<3>(st.data(), 1, tab.data(), rp, (Fr*)emit);
+  else if (t == 17) h = zk_poseidon_sparse<17>(st.data(), 1, tab.data(), rp, (Fr*)emit);
+  else return 2;
+  *(Fr*)hash = h;
+  return 0;
 }
 // the product's DFA scan (zkwg_regex_core.h) on the host: rev[n], own[2(n+1) + NP n + n]; returns accept count
 uint32_t ht_regex_scan(const uint8_t* msg, uint32_t n, uint32_t* rev, uint32_t* own) {

@@ -106,3 +106,28 @@ def test_regex_scanner_vs_python_re():
         if ci % 6 == 0:
             v1 = zk.BodyHashRegexV1(N, list(msg))    # the DFA circuit restated literally
             assert list(rev) == v1.o[1] and (1 if n else 0) == v1.o[0]
+
+
+def test_poseidon_sparse_host_core_matches_oracle():
+    # the product's sparse-partial-round Poseidon (t = 3 and t = 17, PoseidonModular's two arities)
+    # against the textbook rounds of the oracle: hash and every kept Sigma signal
+    import ctypes as C
+    import random
+    from oracle.pyref import poseidon
+    from oracle.pyref.comp import witness_kept
+    lib = hosttest.load()
+    rng = random.Random(5)
+    for t in (3, 17):
+        for trial in range(2):
+            xs = [rng.randrange(256) for _ in range(t - 1)] if trial == 0 else [rng.randrange(poseidon.P) for _ in range(t - 1)]
+            comp = poseidon.Poseidon(t - 1, xs)
+            kept = witness_kept(comp)[1:]
+            n = 3 * (8 * t + poseidon.N_ROUNDS_P[t - 2])
+            assert len(kept) == n
+            inp = b"".join(x.to_bytes(32, "little") for x in xs)
+            emit = C.create_string_buffer(32 * n)
+            h = C.create_string_buffer(32)
+            assert lib.ht_poseidon_sparse(t, inp, emit, h) == 0
+            assert int.from_bytes(h.raw, "little") == comp.o
+            got = [int.from_bytes(emit.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+            assert got == kept

@@ -1,0 +1,80 @@
+"""Flag variant removeSoftLineBreaks (email-verifier.circom:148-156, helpers/remove-soft-line-breaks.circom;
+reference tests remove-soft-line-breaks.test.ts -- its 7 known answers are in test_oracle_kats.py -- and
+email-verifier-with-soft-line-breaks.test.ts)."""
+import pytest
+
+N, M = 576, 384
+
+
+def _inputs(index=0, body_len=300):
+    from zkwg import synth, inputs as gen
+    d = synth.synthetic_dkim_result(11, index, body_len, soft_breaks=True)
+    inp = gen.generate_email_verifier_inputs_from_dkim_result(d, N, M, remove_soft_line_breaks_flag=True)
+    return inp
+
+
+def _oracle(inp):
+    from oracle.pyref import zkemail as zk
+    return zk.EmailVerifier(N, M, 121, 17, 0, inp, body_hash_regex=lambda m: zk.BodyHashRegexV1(N, m),
+                            removeSoftLineBreaks=1)
+
+
+def test_soft_line_break_layout_and_c_oracle_match_literal_oracle():
+    import zkwg
+    from oracle import coracle
+    from oracle.pyref import comp
+    inp = _inputs()
+    assert bytes(int(b) for b in inp["emailBody"]).count(b"=\r\n") >= 1
+    main = _oracle(inp)
+    sym = comp.symbols_kept(main)
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=-1, remove_soft_line_breaks=1)
+    assert c.W == len(sym) and c.symbols() == sym and c.n_public == 3 + 17
+    wits, status, W = coracle.calculate(0, N, M, 0, [inp])
+    assert status == [0] and W == c.W
+    assert wits[0] == b"".join(v.to_bytes(32, "little") for v in comp.witness_kept(main))
+    # a wrong decoded body: the RLC comparison fails -> Assert Failed in both tiers
+    bad = dict(inp)
+    bad["decodedEmailBodyIn"] = list(inp["decodedEmailBodyIn"])
+    bad["decodedEmailBodyIn"][7] = str(int(bad["decodedEmailBodyIn"][7]) ^ 1)
+    with pytest.raises(comp.AssertFailed):
+        _oracle(bad)
+    assert coracle.calculate(0, N, M, 0, [bad], want_witness=False)[1] == [4]
+
+
+def test_helper_remove_soft_line_breaks():
+    # input-generators.ts:107-126 doc example + position map
+    from zkwg import inputs as gen
+    clean, pmap = gen.remove_soft_line_breaks(bytes([72, 101, 108, 108, 111, 61, 13, 10, 87, 111, 114, 108, 100]))
+    assert list(clean) == [72, 101, 108, 108, 111, 87, 111, 114, 108, 100, 0, 0, 0]
+    assert pmap == {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 8, 6: 9, 7: 10, 8: 11, 9: 12}
+    assert gen.get_adjusted_selector(b"Hel=\r\nlo", "Hello", *gen.remove_soft_line_breaks(b"Hel=\r\nlo")) == "Hel=\r\nlo"
+
+
+@pytest.mark.gpu
+def test_soft_line_breaks_on_gpu_bit_exact():
+    import zkwg
+    from oracle import coracle
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, remove_soft_line_breaks=1)
+    wc = zkwg.WitnessCalculator(c)
+    inps = [_inputs(i, 150 + 40 * i) for i in range(5)]
+    assert sum(bytes(int(b) for b in i["emailBody"]).count(b"=\r\n") for i in inps) >= 3
+    bad = dict(inps[4])
+    bad["decodedEmailBodyIn"] = list(bad["decodedEmailBodyIn"])
+    bad["decodedEmailBodyIn"][3] = "65" if bad["decodedEmailBodyIn"][3] != "65" else "66"
+    inps.append(bad)
+    recs = b"".join(c.pack(i) for i in inps)
+    wit, status = c.calculate_batch_host(recs)
+    owit, ostatus, W = coracle.calculate(0, N, M, 0, inps, threads=4)
+    assert W == c.W
+    assert status == ostatus == [0, 0, 0, 0, 0, 4]
+    wb = c.witness_bytes
+    for i in range(5):
+        got, exp = wit[i * wb:(i + 1) * wb], owit[i]
+        if got != exp:
+            first = next(k for k in range(c.W) if got[32 * k:32 * k + 32] != exp[32 * k:32 * k + 32])
+            raise AssertionError(f"email {i}: first differing slot {first} ({dict(c.symbols()).get(first)})")
+    # the reference-shaped entry point on one email
+    w = wc.calculateWitness(inps[0])
+    assert b"".join(v.to_bytes(32, "little") for v in w) == owit[0]
+    with pytest.raises(zkwg.ZkwgError, match="Assert Failed"):
+        wc.calculateWitness(bad)

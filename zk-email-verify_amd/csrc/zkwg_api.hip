@@ -12,6 +12,7 @@
 #include "zkwg_kernels.h"
 #include "zkwg_layout.h"
 #include "zkwg_build.h"
+#include "zkwg_poseidon_sparse.h"
 
 #define ZK_MAX_KERNELS 8
 #define ZK_EV_RING 64
@@ -22,6 +23,8 @@ struct zkwg_circuit {
   int device;
   Fr* d_invtab;
   Fr* d_pos;      // Poseidon(9): C[680] then M[100]
+  u32 pos2_off;
+  Fr* d_pos_rs;   // removeSoftLineBreaks: Poseidon(16) then Poseidon(2) sparse-round tables
   ZkSeg* d_segs;
   u32* d_first_seg;
   std::vector<ZkSeg> segs;
@@ -120,7 +123,12 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
   c->kname[1] = "zk_sha_trace"; c->kslots[1] = 0;
   c->kname[2] = "zk_misc_ev"; c->kslots[2] = 0;
   c->kname[3] = "zk_rsa"; c->kslots[3] = 0;
-  c->kname[4] = "zk_expand"; c->kslots[4] = c->s.W;
+  if (c->s.rslb) {
+    c->n_kernels = 7;
+    c->kname[4] = "zk_rslb_chunks"; c->kslots[4] = 0;
+    c->kname[5] = "zk_rslb_chain"; c->kslots[5] = 0;
+  }
+  c->kname[c->n_kernels - 1] = "zk_expand"; c->kslots[c->n_kernels - 1] = c->s.W;
   if (device >= 0) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return ZKWG_RC_NO_DEVICE; }
@@ -142,8 +150,19 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
       ok = hipMalloc((void**)&c->d_pos, C.size() * sizeof(Fr)) == hipSuccess &&
            hipMemcpy(c->d_pos, C.data(), C.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
     }
+    if (ok && c->s.rslb) {
+      std::vector<Fr> C, M, t16, t2;
+      build_poseidon_constants(17, 8, 68, C, M);
+      ok = zk_build_poseidon_sparse(17, 68, C, M, t16);
+      build_poseidon_constants(3, 8, 57, C, M);
+      ok = ok && zk_build_poseidon_sparse(3, 57, C, M, t2);
+      c->pos2_off = (u32)t16.size();
+      t16.insert(t16.end(), t2.begin(), t2.end());
+      ok = ok && hipMalloc((void**)&c->d_pos_rs, t16.size() * sizeof(Fr)) == hipSuccess &&
+           hipMemcpy(c->d_pos_rs, t16.data(), t16.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) {
-      hipFree(c->d_pos);
+      hipFree(c->d_pos); hipFree(c->d_pos_rs);
       hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg);
       delete c;
       return ZKWG_RC_OOM;
@@ -164,7 +183,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
-    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos);
+    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos); hipFree(c->d_pos_rs);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); }
     hipStreamDestroy(c->copy_stream);
@@ -214,6 +233,11 @@ int zkwg_pack_masks(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header
   if (!c || !rec) return ZKWG_RC_BAD_ARG;
   if (header_mask && c->s.mask_header) memcpy(rec + c->s.in_off[ZKWG_IN_HEADER_MASK], header_mask, c->cfg.max_header);
   if (body_mask && c->s.mask_body) memcpy(rec + c->s.in_off[ZKWG_IN_BODY_MASK], body_mask, c->cfg.max_body);
+  return ZKWG_RC_OK;
+}
+int zkwg_pack_decoded_body(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* decoded_body) {
+  if (!c || !rec || !decoded_body || !c->s.rslb) return ZKWG_RC_BAD_ARG;
+  memcpy(rec + c->s.in_off[ZKWG_IN_DECODED_BODY], decoded_body, c->cfg.max_body);
   return ZKWG_RC_OK;
 }
 int zkwg_set_prepare_throttle(zkwg_circuit_t* c, int rsa_wavefronts_per_cu) {
@@ -285,6 +309,8 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.invtab = c->d_invtab;
   B.pos_c = c->d_pos;
   B.pos_m = c->d_pos ? c->d_pos + 680 : nullptr;
+  B.pos16 = c->d_pos_rs;
+  B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
   B.first_seg = c->d_first_seg;
   B.wit = nullptr;
@@ -333,6 +359,14 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       dyn = per > 14u * 1024u ? std::min(per - 14u * 1024u, 50u * 1024u) : 0u;
     }
     hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), dyn, st, s, B);
+  }
+  if (s.rslb) {
+    // removeSoftLineBreaks: chunk hashes (one lane per 16-byte chunk), then the serial merge chain + scans
+    if (tm) hipEventRecord(evs[++ki], st);
+    const u64 units = (u64)ne * s.rs_nch;
+    hipLaunchKernelGGL(zk_rslb_chunks, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
+    if (tm) hipEventRecord(evs[++ki], st);
+    hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
   }
   if (tm) { hipEventRecord(evs[++ki], st); c->prep_valid = true; c->prep_launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;

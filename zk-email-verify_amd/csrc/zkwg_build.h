@@ -10,7 +10,7 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
                         std::vector<u32>& first_seg, u32 portion = ZK_PORTION_DEFAULT) {
   memset(&s, 0, sizeof(s));
   if (cfg.layout != ZKWG_LAYOUT_KEPT_V1) return false;
-  if (cfg.remove_soft_line_breaks) return false;
+  if (cfg.remove_soft_line_breaks && (cfg.main_kind != ZKWG_MAIN_EMAIL_VERIFIER || cfg.ignore_body_hash_check)) return false;
   if ((cfg.enable_header_masking || cfg.enable_body_masking) && cfg.main_kind != ZKWG_MAIN_EMAIL_VERIFIER) return false;
   if (cfg.enable_body_masking && cfg.ignore_body_hash_check) return false;
   if (cfg.max_header % 64 != 0 || cfg.max_body % 64 != 0) return false;
@@ -31,7 +31,10 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
   off = (off + 15u) & ~15u;
   s.in_off[ZKWG_IN_HEADER_MASK] = off; off += cfg.enable_header_masking ? cfg.max_header : 0;
   s.in_off[ZKWG_IN_BODY_MASK] = off; off += cfg.enable_body_masking ? cfg.max_body : 0;
+  off = (off + 15u) & ~15u;
+  s.in_off[ZKWG_IN_DECODED_BODY] = off; off += cfg.remove_soft_line_breaks ? cfg.max_body : 0;
   s.in_stride = (off + 15u) & ~15u;
+  s.rslb = cfg.remove_soft_line_breaks ? 1u : 0u;
   s.mask_header = cfg.enable_header_masking ? 1u : 0u;
   s.mask_body = cfg.enable_body_masking ? 1u : 0u;
 

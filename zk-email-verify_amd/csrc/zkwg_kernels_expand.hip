@@ -345,6 +345,42 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
 #undef ZK_DFA_LOOP
         break;
       }
+      case ZSEG_RSLB: {
+        // RemoveSoftLineBreaks arrays derived from the emailBody bytes alone
+        // (helpers/remove-soft-line-breaks.circom:47-91): "=\r\n" at j  <=>  isSoftBreak[j]
+        const u8* __restrict__ enc = rec + sg.src;
+        const int half_tab = (int)s.inv_half;
+        if (sg.a == ZRS_EQ) {
+          for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+            const u32 r = r0 + (c >> 1), hf = c & 1u;
+            int d = (int)sg.c - (int)enc[(r >> 1) + sg.b];   // isz.in = in[1] - in[0]
+            uint4 v = zk_zero4();
+            if (!(r & 1u)) { if (!hf) v.x = (d == 0); }
+            else { d = max(-half_tab, min(half_tab, d)); v = invtab[(u32)(d + half_tab) * 2 + hf]; }
+            dst[c] = v;
+          }
+        } else {
+          const u32 M = sg.b;
+          for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+            uint4 v = zk_zero4();
+            if (!(c & 1u)) {
+              const u32 r = r0 + (c >> 1);
+              if (sg.a == ZRS_TSB) v.x = (enc[r] == 61u) & (enc[r + 1] == 13u);
+              else if (sg.a == ZRS_SB) v.x = (enc[r] == 61u) & (enc[r + 1] == 13u) & (enc[r + 2] == 10u);
+              else {  // processed[r]: zero inside a soft break starting at r, r-1 or r-2 (starts only below M-2)
+                bool z = false;
+#pragma unroll
+                for (u32 k = 0; k < 3; ++k) {
+                  if (r >= k && r - k + 2 < M) { const u32 j = r - k; z = z || (enc[j] == 61u && enc[j + 1] == 13u && enc[j + 2] == 10u); }
+                }
+                v.x = z ? 0u : (u32)enc[r];
+              }
+            }
+            dst[c] = v;
+          }
+        }
+        break;
+      }
       default:
         break;
     }

@@ -1,0 +1,85 @@
+// RemoveSoftLineBreaks(maxBody) witness values (template flag removeSoftLineBreaks,
+// packages/circuits/email-verifier.circom:148-156, helpers/remove-soft-line-breaks.circom:14-126):
+//   r = PoseidonModular(2*maxBody)(encoded || decoded)   (utils/hash.circom:50-84)
+//   random-linear-combination sums sumEnc / sumDec over powers of r, final IsEqual.
+// This is the one genuinely Fr-heavy block of the path (about 1.2 M field products per email at
+// maxBody = 1536), and it is embarrassingly parallel in its first stage:
+//   zk_rslb_chunks : one LANE per (email, 16-byte chunk): Poseidon(16), 612 S-box signals + the digest
+//   zk_rslb_chain  : one lane per email: the Poseidon(2) merge chain (inherently serial), the r-power
+//                    scans and the final comparison
+// The S-box signals go straight into the image's Fr area; zk_expand copies them into the witness.
+#include "zkwg_dev.h"
+#include "zkwg_kernels.h"
+#include "zkwg_poseidon_sparse.h"
+
+__global__ __launch_bounds__(64) void zk_rslb_chunks(ZkSched s, ZkBufs B) {
+  __shared__ Fr st[17 * 64];
+  const u32 lane = threadIdx.x;
+  const u64 unit = (u64)blockIdx.x * 64 + lane;
+  const u32 e = (u32)(unit / s.rs_nch), c = (u32)(unit % s.rs_nch);
+  if (e >= B.n_emails) return;
+  const u8* rec = B.in + (u64)e * s.in_stride;
+  const u32 half = s.rs_nch / 2;   // chunks [0, half): encoded (= emailBody), [half, 2 half): decoded
+  const uint4 raw = *(const uint4*)(rec + (c < half ? s.fr[1].in_data + 16u * c : s.in_off[11] + 16u * (c - half)));
+  const u32 w[4] = {raw.x, raw.y, raw.z, raw.w};
+  Fr* stl = st + lane;
+  stl[0] = fr_zero();
+#pragma unroll
+  for (u32 i = 0; i < 16; ++i) stl[(1 + i) * 64] = fr_from_u64((w[i >> 2] >> (8 * (i & 3))) & 255u);
+  Fr* frv = B.frv + (u64)e * s.img_fr;
+  const Fr h = zk_poseidon_sparse<17>(stl, 64, B.pos16, 68, frv + s.f_rs_hash + zk_rs_chunk_off(c));
+  frv[s.f_rs_chunk + c] = h;
+}
+
+__global__ __launch_bounds__(64) void zk_rslb_chain(ZkSched s, ZkBufs B) {
+  __shared__ Fr st[3 * 64];
+  const u32 lane = threadIdx.x;
+  const u32 e = blockIdx.x * 64 + lane;
+  if (e >= B.n_emails) return;
+  const u8* rec = B.in + (u64)e * s.in_stride;
+  Fr* frv = B.frv + (u64)e * s.img_fr;
+  Fr* stl = st + lane;
+  // _out = Poseidon(2)([_out, chunk_hash]) (utils/hash.circom:76-80)
+  Fr out = frv[s.f_rs_chunk];
+  for (u32 c = 1; c < s.rs_nch; ++c) {
+    stl[0] = fr_zero(); stl[64] = out; stl[128] = frv[s.f_rs_chunk + c];
+    out = zk_poseidon_sparse<3>(stl, 64, B.pos2, 57, frv + s.f_rs_hash + zk_rs_chunk_off(c) + ZK_P16_KEPT);
+  }
+  const Fr r = out;
+  const Fr rm = fr_to_mont(r);
+  const u32 M = s.fr[1].max_bytes;
+  const u8* enc = rec + s.fr[1].in_data;
+  const u8* dec = rec + s.in_off[11];
+  Fr* mux = frv + s.f_rs_mux;
+  Fr* sum_enc = frv + s.f_rs_sum_enc;
+  Fr* rdec = frv + s.f_rs_rdec;
+  Fr* sum_dec = frv + s.f_rs_sum_dec;
+  Fr rEnc = fr_zero(), sumEnc = fr_zero(), rDec = r, sumDec = fr_zero();
+  // window of soft-break starts: sb0 = isSoftBreak[i], sb1 = [i-1], sb2 = [i-2]
+  u32 sb1 = 0, sb2 = 0;
+  u32 b0 = enc[0], b1 = enc[1], b2 = enc[2];
+  for (u32 i = 0; i < M; ++i) {
+    const u32 sb0 = (i + 2 < M) && b0 == 61u && b1 == 13u && b2 == 10u;
+    const bool z = (sb0 | sb1 | sb2) != 0;                         // shouldZero[i] (:72-83)
+    const Fr c0 = i ? fr_mont_mul(rEnc, rm) : r;                    // muxEnc[i].c[0] (:93-101)
+    const Fr prev = i ? rEnc : fr_from_u64(1);
+    rEnc = z ? prev : c0;
+    if (i) mux[2 * i - 1] = c0;
+    mux[2 * i] = rEnc;
+    const u32 proc = z ? 0u : b0;                                   // processed[i] (:86-88)
+    if (proc) sumEnc = fr_add(sumEnc, fr_mont_mul(rEnc, fr_to_mont(fr_from_u64(proc))));
+    sum_enc[i] = sumEnc;
+    if (i) { rDec = fr_mont_mul(rDec, rm); rdec[i - 1] = rDec; }
+    const u32 d = dec[i];
+    if (d) sumDec = fr_add(sumDec, fr_mont_mul(rDec, fr_to_mont(fr_from_u64(d))));
+    sum_dec[i] = sumDec;
+    sb2 = sb1; sb1 = sb0;
+    b0 = b1; b1 = b2; b2 = (i + 3 < M) ? enc[i + 3] : 0u;
+  }
+  // isValid <== IsEqual()([sumEnc[M-1], sumDec[M-1]]); qpEncodingChecker.isValid === 1
+  const Fr diff = fr_sub(sumDec, sumEnc);
+  const bool valid = fr_is_zero(diff);
+  frv[s.f_rs_final] = fr_from_u64(valid ? 1 : 0);
+  frv[s.f_rs_final + 1] = valid ? fr_zero() : fr_from_mont(fr_mont_inv(fr_to_mont(diff)));
+  if (!valid) B.status[e] = 4;
+}

@@ -332,6 +332,66 @@ static inline void zk_walk_bh_regex(ZkWalker& w, const std::string& p, const ZkS
   else for (u32 i = 0; i < N; ++i) { w.one(zk_idx(p + ".substr_or", i) + ".is_zero.out"); w.one(zk_idx(p + ".substr_or", i) + ".is_zero.inv"); }
 }
 
+// ------------------------------------------------------------------ RemoveSoftLineBreaks
+// helpers/remove-soft-line-breaks.circom:14-126 as `main.qpEncodingChecker` (email-verifier.circom:148-156);
+// PoseidonModular / Poseidon from utils/hash.circom:50-84 and circomlib poseidon.circom [EXT].
+static inline void zk_alloc_rslb(ZkWalker& w, ZkSched& s, u32 M) {
+  s.rs_nch = 2 * M / 16;
+  s.f_rs_chunk = w.alloc_fr(s.rs_nch);
+  s.f_rs_sum_enc = w.alloc_fr(M);
+  s.f_rs_rdec = w.alloc_fr(M - 1);
+  s.f_rs_sum_dec = w.alloc_fr(M);
+  s.f_rs_mux = w.alloc_fr(2 * M - 1);
+  s.f_rs_hash = w.alloc_fr(s.rs_nch * ZK_P16_KEPT + (s.rs_nch - 1) * ZK_P2_KEPT);
+  s.f_rs_final = w.alloc_fr(2);
+}
+static inline void zk_walk_poseidon_names(ZkWalker& w, const std::string& p, u32 t, u32 rp) {
+  if (!w.names) { w.skip(3 * (8 * t + rp)); return; }
+  for (u32 r = 0; r < 8; ++r) for (u32 j = 0; j < t; ++j) {
+    std::string q = p + ".pEx.sigmaF[" + std::to_string(r) + "][" + std::to_string(j) + "]";
+    w.one(q + ".out"); w.one(q + ".in2"); w.one(q + ".in4");
+  }
+  for (u32 r = 0; r < rp; ++r) {
+    std::string q = zk_idx(p + ".pEx.sigmaP", r);
+    w.one(q + ".out"); w.one(q + ".in2"); w.one(q + ".in4");
+  }
+}
+static inline void zk_walk_rslb(ZkWalker& w, const std::string& p, const ZkSched& s, u32 M) {
+  const u32 enc = s.fr[1].in_data;
+  // intermediates with a quadratic definition, in declaration order (:20-31)
+  w.seg(ZSEG_RSLB, M, enc, ZRS_PROC, M); w.arr(p + ".processed", M);
+  w.seg(ZSEG_RSLB, M - 2, enc, ZRS_TSB); w.arr(p + ".tempSoftBreak", M - 2);
+  w.seg(ZSEG_RSLB, M - 2, enc, ZRS_SB); w.arr(p + ".isSoftBreak", M - 2);
+  w.seg(ZSEG_FR, M, s.f_rs_sum_enc); w.arr(p + ".sumEnc", M);
+  w.seg(ZSEG_FR, M - 1, s.f_rs_rdec);
+  if (!w.names) w.skip(M - 1); else for (u32 i = 1; i < M; ++i) w.one(zk_idx(p + ".rDec", i));
+  w.seg(ZSEG_FR, M, s.f_rs_sum_dec); w.arr(p + ".sumDec", M);
+  // muxEnc[i] = Mux1 -> MultiMux1(1): c[0] is fed a product for i >= 1 (:99-101); mux.out[0] is quadratic
+  w.seg(ZSEG_FR, 2 * M - 1, s.f_rs_mux);
+  if (!w.names) w.skip(2 * M - 1);
+  else for (u32 i = 0; i < M; ++i) {
+    if (i) w.one(zk_idx(p + ".muxEnc", i) + ".c[0]");
+    w.one(zk_idx(p + ".muxEnc", i) + ".mux.out[0]");
+  }
+  // rHasher = PoseidonModular(2M): Poseidon(16) per chunk, Poseidon(2) merges
+  const u32 nh = s.rs_nch * ZK_P16_KEPT + (s.rs_nch - 1) * ZK_P2_KEPT;
+  w.seg(ZSEG_FR, nh, s.f_rs_hash);
+  for (u32 c = 0; c < s.rs_nch; ++c) {
+    zk_walk_poseidon_names(w, zk_idx(p + ".rHasher.anon_Poseidon_chunk", c), 17, 68);
+    if (c) zk_walk_poseidon_names(w, zk_idx(p + ".rHasher.anon_Poseidon_merge", c), 3, 57);
+  }
+  // IsEqual()([encoded[i], 61]) / ([encoded[i+1], 13]) / ([encoded[i+2], 10]) (:47-62)
+  const char* nm[3] = {".anon_IsEqual_eq", ".anon_IsEqual_cr", ".anon_IsEqual_lf"};
+  const u32 ch[3] = {61, 13, 10};
+  for (u32 k = 0; k < 3; ++k) {
+    w.seg(ZSEG_RSLB, 2 * (M - k), enc, ZRS_EQ, k, ch[k]);
+    if (!w.names) w.skip(2 * (M - k));
+    else for (u32 i = 0; i < M - k; ++i) { w.one(zk_idx(p + nm[k], i) + ".isz.out"); w.one(zk_idx(p + nm[k], i) + ".isz.inv"); }
+  }
+  w.seg(ZSEG_FR, 2, s.f_rs_final);
+  w.one(p + ".anon_IsEqual_final.isz.out"); w.one(p + ".anon_IsEqual_final.isz.inv");
+}
+
 // ------------------------------------------------------------------ EmailVerifier main
 // (packages/circuits/email-verifier.circom:42-174, flags (ignoreBodyHashCheck, 0, 0, 0),
 //  `component main { public [ pubkey ] }`, tests/test-circuits/email-verifier-test.circom:5)
@@ -368,6 +428,7 @@ static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
     s.m_chars = w.alloc_small(44);
     s.b_shift = w.alloc_bits(1);
     s.sel_bits = zk_log2ceil((u64)N + 44 - 1);
+    if (s.rslb) zk_alloc_rslb(w, s, M);
   }
   s.f_pos = w.alloc_fr(420);
 
@@ -387,6 +448,7 @@ static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
     w.seg(ZSEG_IN8, 32, s.fr[1].in_pre); w.arr("main.precomputedSHA", 32);
     w.seg(ZSEG_IN8, M, s.fr[1].in_data); w.arr("main.emailBody", M);
     w.seg(ZSEG_SMALL, 1, s.fr[1].m_len); w.one("main.emailBodyLength");
+    if (s.rslb) { w.seg(ZSEG_IN8, M, s.in_off[11]); w.arr("main.decodedEmailBodyIn", M); }
     if (s.mask_body) { w.seg(ZSEG_IN8, M, s.in_off[10]); w.arr("main.bodyMask", M); }
   }
   // sub-components in creation order
@@ -437,6 +499,7 @@ static inline void zk_walk_main_ev(ZkWalker& w, ZkSched& s) {
       for (auto m : eqs) { w.one(t + "." + m + ".out"); w.one(t + "." + m + ".inv"); }
     }
     zk_walk_sha_frame(w, "main.anon_Sha256BytesPartial", s.fr[1]);
+    if (s.rslb) zk_walk_rslb(w, "main.qpEncodingChecker", s, M);
     if (s.mask_body) {
       w.seg(ZSEG_IN8MASK, M, s.fr[1].in_data, s.in_off[10]);
       w.arr("main.byteMask_body.out", M);

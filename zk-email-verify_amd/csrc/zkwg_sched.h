@@ -48,7 +48,16 @@ enum ZkSegType : u32 {
   ZSEG_B64 = 15,    // Base64Lookup(char small[src + r/68]): 8 mids, 6 x 9 comparator bits, 3 IsZero pairs
   ZSEG_DFA = 16,    // BodyHashRegex DFA circuit arrays: a = ZkDfaKind, b/c = parameters, src = small idx of the per-position words (then class masks, primitive masks)
   ZSEG_IN8MASK = 17,// ByteMask: in[src + r] * in[a + r]   (data byte times mask byte)
-  ZSEG_NTYPES = 18
+  ZSEG_RSLB = 18,   // RemoveSoftLineBreaks byte-derived arrays over in[src ..]: a = ZkRslbKind, b/c = parameters
+  ZSEG_NTYPES = 19
+};
+
+// ZSEG_RSLB kinds (helpers/remove-soft-line-breaks.circom:14-126); enc = the emailBody bytes at src
+enum ZkRslbKind : u32 {
+  ZRS_PROC = 0,  // processed[r] = (1 - shouldZero[r]) * enc[r]           (b = maxLength)
+  ZRS_TSB = 1,   // tempSoftBreak[r] = (enc[r] == '=') * (enc[r+1] == CR)
+  ZRS_SB = 2,    // isSoftBreak[r]   = tempSoftBreak[r] * (enc[r+2] == LF)
+  ZRS_EQ = 3     // IsEqual([enc[i + b], c]) pairs (isz.out, isz.inv), i = r / 2, isz.in = c - enc[i + b]
 };
 
 // ZSEG_DFA kinds (component arrays of the regex circuit, one entry per header position)
@@ -133,7 +142,7 @@ struct ZkSched {
   u32 total_blocks;      // sum of nblocks
   u32 hstates_per_email; // sum of (nblocks+1)
   u32 in_stride;         // bytes per input record
-  u32 in_off[11];        // enum zkwg_input_field -> byte offset
+  u32 in_off[12];        // enum zkwg_input_field -> byte offset
   u32 n_public;
   u32 nsegs;
   u32 portion;           // witness slots expanded by one workgroup of zk_expand
@@ -164,7 +173,21 @@ struct ZkSched {
   u32 m_dfa_pm;          // small: per position, primitive-test truth mask of in[i]
   u32 m_dfa_own;         // small: live_c1[nb], live_t[nb], prev_states0[NP][N], is_reveal0[N]
   u32 m_dfa_acc;         // small: number of positions in the accept state
+  // RemoveSoftLineBreaks(max_body) (template flag removeSoftLineBreaks, email-verifier.circom:148-156)
+  u32 rslb;              // 1: present
+  u32 rs_nch;            // 2 * max_body / 16 Poseidon(16) chunks of PoseidonModular(2 * max_body)
+  u32 f_rs_chunk;        // fr: rs_nch chunk digests (not part of the witness)
+  u32 f_rs_sum_enc;      // fr: sumEnc[max_body]
+  u32 f_rs_rdec;         // fr: rDec[1 .. max_body)
+  u32 f_rs_sum_dec;      // fr: sumDec[max_body]
+  u32 f_rs_mux;          // fr: muxEnc: mux[0].out, then (c[0], mux.out) for i = 1 .. max_body-1
+  u32 f_rs_hash;         // fr: rHasher S-box signals: chunk 0 (612), then per chunk (612 chunk, 243 merge)
+  u32 f_rs_final;        // fr: final IsEqual (isz.out, isz.inv)
 };
+#define ZK_P16_KEPT 612u   // Poseidon(16): 3 * (8 * 17 + 68)
+#define ZK_P2_KEPT 243u    // Poseidon(2):  3 * (8 * 3 + 57)
+// offset (inside f_rs_hash) of chunk c's Poseidon(16) signals; its merge Poseidon(2) (c >= 1) follows at +612
+ZK_HD u32 zk_rs_chunk_off(u32 c) { return c == 0 ? 0u : ZK_P16_KEPT + (c - 1u) * (ZK_P16_KEPT + ZK_P2_KEPT); }
 
 // Raw DKIM results of a batch (device pointers) -- input of zk_gen_inputs; mirrors the fields of
 // `DKIMVerificationResult` that generateEmailVerifierInputsFromDKIMResult reads.
@@ -191,6 +214,8 @@ struct ZkBufs {
   const Fr* invtab;      // d^-1 for d in [-inv_half, inv_half]
   const Fr* pos_c;       // Poseidon(9) round constants (Montgomery form), 680
   const Fr* pos_m;       // Poseidon(9) MDS matrix (Montgomery form), 10 x 10 row-major
+  const Fr* pos16;       // Poseidon(16) sparse-round table (zkwg_poseidon_sparse.h), removeSoftLineBreaks only
+  const Fr* pos2;        // Poseidon(2)  sparse-round table
   const ZkSeg* segs;     // segment table
   const u32* first_seg;  // first segment overlapping each portion
   uint4* wit;            // output witnesses

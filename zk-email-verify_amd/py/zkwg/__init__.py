@@ -48,10 +48,11 @@ class Circuit:
     """A compiled circuit handle (`component main = ...` with its template parameters)."""
 
     def __init__(self, main_kind=MAIN_EMAIL_VERIFIER, max_header=1024, max_body=1536, n=121, k=17,
-                 ignore_body_hash_check=0, device=0, enable_header_masking=0, enable_body_masking=0):
+                 ignore_body_hash_check=0, device=0, enable_header_masking=0, enable_body_masking=0,
+                 remove_soft_line_breaks=0):
         self.lib = _lib.load()
         self.cfg = Config(main_kind, max_header, max_body, n, k, ignore_body_hash_check, enable_header_masking,
-                          enable_body_masking, 0, 0)
+                          enable_body_masking, remove_soft_line_breaks, 0)
         h = C.c_void_p()
         _check(self.lib.zkwg_circuit_create(C.byref(self.cfg), device, C.byref(h)))
         self.h = h
@@ -85,6 +86,8 @@ class Circuit:
         if not c.ignore_body_hash_check:
             sizes.update({"bodyHashIndex": 1, "precomputedSHA": 32, "emailBody": c.max_body,
                           "emailBodyLength": 1})
+            if c.remove_soft_line_breaks:
+                sizes["decodedEmailBodyIn"] = c.max_body
             if c.enable_body_masking:
                 sizes["bodyMask"] = c.max_body
         return sizes
@@ -141,6 +144,8 @@ class Circuit:
             hm = as_bytes(flat["headerMask"], "headerMask") if c.enable_header_masking else None
             bm = as_bytes(flat["bodyMask"], "bodyMask") if c.enable_body_masking else None
             _check(self.lib.zkwg_pack_masks(self.h, rec, hm, bm))
+        if c.main_kind == MAIN_EMAIL_VERIFIER and c.remove_soft_line_breaks:
+            _check(self.lib.zkwg_pack_decoded_body(self.h, rec, as_bytes(flat["decodedEmailBodyIn"], "decodedEmailBodyIn")))
         return bytes(rec)
 
     # -- batch calculation -------------------------------------------------------------------

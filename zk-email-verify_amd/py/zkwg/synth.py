@@ -90,19 +90,20 @@ def packed_batch(circuit, seed, n, body_len=1024, first_index=0):
     Also returns the per-email field arrays for the oracle."""
     from . import inputs as gen
     from ._lib import (IN_HEADER, IN_BODY, IN_PRECOMPUTED_SHA, IN_PUBKEY, IN_SIGNATURE, IN_HEADER_LEN,
-                       IN_BODY_LEN, IN_BODY_HASH_INDEX)
+                       IN_BODY_LEN, IN_BODY_HASH_INDEX, IN_DECODED_BODY)
     cfg = circuit.cfg
     stride = circuit.in_stride
-    off = [circuit.lib.zkwg_input_offset(circuit.h, f) for f in range(9)]
+    off = [circuit.lib.zkwg_input_offset(circuit.h, f) for f in range(12)]
+    rslb = bool(cfg.remove_soft_line_breaks)
     buf = bytearray(n * stride)
     fields = {"header": bytearray(), "hlen": [], "body": bytearray(), "blen": [], "pre": bytearray(),
-              "pubkey": bytearray(), "sig": bytearray(), "bhi": []}
+              "pubkey": bytearray(), "sig": bytearray(), "bhi": [], "decoded": bytearray()}
 
     def limbs16(x):
         return b"".join(((x >> (121 * i)) & ((1 << 121) - 1)).to_bytes(16, "little") for i in range(17))
 
     for i in range(n):
-        d = synthetic_dkim_result(seed, first_index + i, body_len)
+        d = synthetic_dkim_result(seed, first_index + i, body_len, soft_breaks=rslb)
         hp, hl = gen.sha256_pad(d["headers"], cfg.max_header)
         base = i * stride
         buf[base + off[IN_HEADER]:base + off[IN_HEADER] + cfg.max_header] = hp
@@ -122,4 +123,8 @@ def packed_batch(circuit, seed, n, body_len=1024, first_index=0):
             buf[base + off[IN_BODY_LEN]:base + off[IN_BODY_LEN] + 4] = rem_len.to_bytes(4, "little")
             buf[base + off[IN_BODY_HASH_INDEX]:base + off[IN_BODY_HASH_INDEX] + 4] = bhi.to_bytes(4, "little")
             fields["body"] += rem; fields["blen"].append(rem_len); fields["pre"] += pre; fields["bhi"].append(bhi)
+            if rslb:
+                clean, _ = gen.remove_soft_line_breaks(rem)
+                buf[base + off[IN_DECODED_BODY]:base + off[IN_DECODED_BODY] + cfg.max_body] = clean
+                fields["decoded"] += clean
     return bytes(buf), fields
