@@ -59,3 +59,21 @@ def test_device_input_generation_with_selector_and_errors():
     d = dict(ds[0], body=b"x" * 640 + b"aaab" + b"y" * 100)
     _, st = zkwg.generate_inputs_device(c, [d], selector="aab")
     assert st == [3]
+
+
+def test_device_input_generation_remove_soft_line_breaks():
+    # removeSoftLineBreaks = 1: decodedEmailBodyIn = removeSoftLineBreaks(bodyRemaining) built on the device
+    import zkwg
+    from zkwg import synth, inputs
+    N, M = 576, 640
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, remove_soft_line_breaks=1)
+    ds = [synth.synthetic_dkim_result(14, i, body_len=200 + 60 * i, soft_breaks=True) for i in range(6)]
+    assert sum(d["body"].count(b"=\r\n") for d in ds) >= 6
+    recs, st = zkwg.generate_inputs_device(c, ds)
+    assert st == [0] * 6
+    host = recs.cpu().numpy()
+    for i, d in enumerate(ds):
+        inp = inputs.generate_email_verifier_inputs_from_dkim_result(d, N, M, remove_soft_line_breaks_flag=True)
+        assert host[i].tobytes() == c.pack(inp)
+    wit, status = c.calculate_batch_host(host.tobytes(), want_witness=False)
+    assert status == [0] * 6

@@ -119,6 +119,25 @@ __global__ __launch_bounds__(64) void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8
       const u32 cut = cut_sh;
       for (u32 i = lane; i + cut < bpad && i < M; i += 64) rec[s.in_off[1] + i] = (u8)padded(cut + i);
     }
+    if (s.rslb) {
+      // decodedEmailBodyIn = removeSoftLineBreaks(bodyRemaining) (input-generators.ts:127-158, 241-244):
+      // drop every "=\r\n", keep the order, zero fill.  The pattern cannot overlap itself, so the
+      // sequential scan equals a stream compaction: 64 bytes per step, positions from a ballot prefix.
+      __syncthreads();
+      if (!err) {
+        const u8* eb = rec + s.in_off[1];
+        u8* dec = rec + s.in_off[11];
+        auto sb = [&](int k) -> bool { return k >= 0 && (u32)k + 2 < M && eb[k] == 61 && eb[k + 1] == 13 && eb[k + 2] == 10; };
+        u32 base = 0;
+        for (u32 i0 = 0; i0 < M; i0 += 64) {
+          const int j = (int)(i0 + lane);
+          const bool keep = (u32)j < M && !(sb(j) || sb(j - 1) || sb(j - 2));
+          const u64 m = __ballot(keep);
+          if (keep) dec[base + __popcll(m & ((1ull << lane) - 1ull))] = eb[j];
+          base += __popcll(m);
+        }
+      }
+    }
   }
   __syncthreads();
   if (lane == 0) gen_status[e] = err;

@@ -16,6 +16,11 @@ assert.throws(() => c.pack({ paddedIn: padded.slice(1), paddedInLength: 64 }), /
 assert.throws(() => c.pack({ paddedIn: padded }), /Not all inputs have been set. Only 1 out of 2/);
 const ev = new z.Circuit({ maxHeader: 576, maxBody: 192 }, -1);
 assert.strictEqual(ev.numPublic, 20);
+// flag variant removeSoftLineBreaks: one more input signal, same public signals
+const qp = new z.Circuit({ maxHeader: 576, maxBody: 384, removeSoftLineBreaks: 1 }, -1);
+assert.strictEqual(qp.numPublic, 20);
+assert.strictEqual(qp.witnessLen, 881180);
+assert.strictEqual('decodedEmailBodyIn' in qp.signalSizes(), true);
 new z.WitnessCalculator(c).calculateWitness({ paddedIn: padded, paddedInLength: 64 }).then(
   () => { console.error('expected a no-device error'); process.exit(1); },
   (e) => { assert.ok(/no HIP device/.test(e.message)); console.log('js cpu ok W(sha128)=' + c.witnessLen + ' W(ev576/192)=' + ev.witnessLen); });

@@ -17,7 +17,7 @@ const addon = require(path.join(__dirname, 'zkwg_addon.node'));
 
 const FIELD_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
 const MAIN_EMAIL_VERIFIER = 0, MAIN_SHA256_BYTES = 1, MAIN_RSA_VERIFIER = 2;
-const IN = { HEADER: 0, BODY: 1, PRECOMPUTED_SHA: 2, PUBKEY: 3, SIGNATURE: 4, MESSAGE: 5, HEADER_LEN: 6, BODY_LEN: 7, BODY_HASH_INDEX: 8, HEADER_MASK: 9, BODY_MASK: 10 };
+const IN = { HEADER: 0, BODY: 1, PRECOMPUTED_SHA: 2, PUBKEY: 3, SIGNATURE: 4, MESSAGE: 5, HEADER_LEN: 6, BODY_LEN: 7, BODY_HASH_INDEX: 8, HEADER_MASK: 9, BODY_MASK: 10, DECODED_BODY: 11 };
 
 function norm(v) {
   let x = BigInt(v) % FIELD_MODULUS;
@@ -26,9 +26,9 @@ function norm(v) {
 }
 
 class Circuit {
-  /** opts: {mainKind, maxHeader, maxBody, n, k, ignoreBodyHashCheck}; device < 0 = layout-only handle */
+  /** opts: {mainKind, maxHeader, maxBody, n, k, ignoreBodyHashCheck, enableHeaderMasking, enableBodyMasking, removeSoftLineBreaks}; device < 0 = layout-only handle */
   constructor(opts, device) {
-    this.opts = Object.assign({ mainKind: MAIN_EMAIL_VERIFIER, maxHeader: 1024, maxBody: 1536, n: 121, k: 17, ignoreBodyHashCheck: 0, enableHeaderMasking: 0, enableBodyMasking: 0 }, opts || {});
+    this.opts = Object.assign({ mainKind: MAIN_EMAIL_VERIFIER, maxHeader: 1024, maxBody: 1536, n: 121, k: 17, ignoreBodyHashCheck: 0, enableHeaderMasking: 0, enableBodyMasking: 0, removeSoftLineBreaks: 0 }, opts || {});
     this.handle = addon.createCircuit(this.opts, device === undefined ? 0 : device);
     Object.assign(this, addon.info(this.handle));
   }
@@ -41,6 +41,7 @@ class Circuit {
     if (o.enableHeaderMasking) s.headerMask = o.maxHeader;
     if (!o.ignoreBodyHashCheck) {
       Object.assign(s, { bodyHashIndex: 1, precomputedSHA: 32, emailBody: o.maxBody, emailBodyLength: 1 });
+      if (o.removeSoftLineBreaks) s.decodedEmailBodyIn = o.maxBody;
       if (o.enableBodyMasking) s.bodyMask = o.maxBody;
     }
     return s;
@@ -90,6 +91,7 @@ class Circuit {
       limbs(IN.PUBKEY, flat.pubkey, 'pubkey'); limbs(IN.SIGNATURE, flat.signature, 'signature');
       if (o.enableHeaderMasking) bytes(IN.HEADER_MASK, flat.headerMask, 'headerMask');
       if (!o.ignoreBodyHashCheck && o.enableBodyMasking) bytes(IN.BODY_MASK, flat.bodyMask, 'bodyMask');
+      if (!o.ignoreBodyHashCheck && o.removeSoftLineBreaks) bytes(IN.DECODED_BODY, flat.decodedEmailBodyIn, 'decodedEmailBodyIn');
       if (!o.ignoreBodyHashCheck) {
         bytes(IN.BODY, flat.emailBody, 'emailBody'); u32(IN.BODY_LEN, flat.emailBodyLength[0], 'emailBodyLength');
         bytes(IN.PRECOMPUTED_SHA, flat.precomputedSHA, 'precomputedSHA'); u32(IN.BODY_HASH_INDEX, flat.bodyHashIndex[0], 'bodyHashIndex');

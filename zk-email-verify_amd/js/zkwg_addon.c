@@ -37,6 +37,7 @@ static napi_value CreateCircuit(napi_env env, napi_callback_info info) {
   get_u32(env, argv[0], "ignoreBodyHashCheck", &cfg.ignore_body_hash_check, 0);
   get_u32(env, argv[0], "enableHeaderMasking", &cfg.enable_header_masking, 0);
   get_u32(env, argv[0], "enableBodyMasking", &cfg.enable_body_masking, 0);
+  get_u32(env, argv[0], "removeSoftLineBreaks", &cfg.remove_soft_line_breaks, 0);
   int32_t device = 0;
   if (argc > 1) napi_get_value_int32(env, argv[1], &device);
   zkwg_circuit_t* c = NULL;
