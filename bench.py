@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--body-len", type=int, default=1024)
     ap.add_argument("--prep-batch", type=int, default=1024, help="emails per prepare launch (pipeline granularity)")
     ap.add_argument("--rsa-throttle", type=int, default=3, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap)")
+    ap.add_argument("--remove-soft-line-breaks", type=int, default=0,
+                    help="template flag removeSoftLineBreaks (flag-variant measurement; the headline config keeps 0)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="emails timed for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -71,7 +73,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank)
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank,
+                     remove_soft_line_breaks=args.remove_soft_line_breaks)
     tile = min(args.tile, args.batch)
     assert args.batch % tile == 0
     ntiles = args.batch // tile
@@ -175,7 +178,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 (BN254 Fr, 4x64-bit limbs) / u32 bit-vectors", "data": "synthetic",
-            "config": {"workload": f"EmailVerifier({args.max_header},{args.max_body},121,17,0,0,0,0) batch={args.batch}/GPU, "
+            "config": {"workload": f"EmailVerifier({args.max_header},{args.max_body},121,17,0,0,0,{args.remove_soft_line_breaks}) batch={args.batch}/GPU, "
                                    f"{args.body_len} B bodies, witnesses device-resident",
                        "batch_per_gpu": args.batch, "tile": tile, "witness_len": c.W,
                        "witness_bytes": c.witness_bytes, "layout": "kept-v1", "parallelism": f"shard x{world}, result-table gather only"},

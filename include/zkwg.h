@@ -57,8 +57,9 @@ enum zkwg_main_kind {
   ZKWG_MAIN_RSA_VERIFIER = 2    /* RSAVerifier65537(n,k), public [modulus] (rsa-test.circom) */
 };
 
-/* Witness layouts.  KEPT_V1 is the compact layout documented in DESIGN.md. */
-enum zkwg_layout { ZKWG_LAYOUT_KEPT_V1 = 0 };
+/* Witness layouts.  KEPT_V1 is the compact layout documented in DESIGN.md; SYM is KEPT_V1 re-ordered
+ * (and thinned) to the witness indices of a circom `.sym` file, see zkwg_circuit_create_sym. */
+enum zkwg_layout { ZKWG_LAYOUT_KEPT_V1 = 0, ZKWG_LAYOUT_SYM = 1 };
 
 typedef struct zkwg_config {
   uint32_t main_kind;                /* enum zkwg_main_kind */
@@ -115,6 +116,17 @@ const char* zkwg_strerror(int rc_or_status);
  * layout-only handle (no GPU needed: sizes, .sym, .wtns and packing still work,
  * zkwg_calculate_* return ZKWG_RC_NO_DEVICE). */
 int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out);
+/* Same, with the witness ordered as a compiled circuit's `.sym` file says (the file circom writes next
+ * to the `.r1cs`/`.wasm`; circom_tester `loadSymbols`, packages/circuits/tests/email-verifier.test.ts:204,
+ * and the order `groth16.prove(zkey, wtns)` needs, packages/helpers/src/chunked-zkey.ts:80).  `sym_text` =
+ * the file's bytes: lines "labelIdx,witnessIdx,componentIdx,name", witnessIdx -1 = eliminated.  Every
+ * signal the file keeps must be one this schedule produces (same qualified name); signals it eliminates
+ * are dropped from the output.  `alias_text` (may be NULL): rename rules "ours=theirs", one per line,
+ * applied to this library's names first (compiler-generated names of anonymous components).
+ * On ZKWG_RC_BAD_CONFIG, zkwg_last_error() says which signal did not match.  cfg->layout is ignored. */
+int zkwg_circuit_create_sym(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
+                            const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out);
+const char* zkwg_last_error(void);   /* detail of the calling thread's last ZKWG_RC_BAD_CONFIG */
 void zkwg_circuit_destroy(zkwg_circuit_t* c);
 
 /* Geometry. */
@@ -218,7 +230,7 @@ uint64_t zkwg_kernel_slots(const zkwg_circuit_t* c, int which);
 uint64_t zkwg_wtns_size(const zkwg_circuit_t* c);
 int zkwg_write_wtns(const zkwg_circuit_t* c, const uint8_t* witness, uint8_t* out, uint64_t out_cap);
 
-/* Symbol table of the layout, one line per witness slot: "slot,slot,0,name\n"
+/* Symbol table of the layout in force, one line per witness slot: "slot,slot,0,name\n"
  * (the `.sym` line format `labelIdx,varIdx,componentIdx,name`).  Returns bytes
  * needed; writes at most cap bytes. */
 uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap);

@@ -15,7 +15,8 @@ _CSRC = os.path.join(ROOT, "zk-email-verify_amd", "csrc")
 
 class Seg(C.Structure):
     _fields_ = [("slot", C.c_uint64), ("nslots", C.c_uint32), ("type", C.c_uint32),
-                ("src", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("c", C.c_uint32)]
+                ("src", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("c", C.c_uint32),
+                ("r0", C.c_uint32), ("pad", C.c_uint32)]
 
 
 def load():
@@ -25,6 +26,8 @@ def load():
     lib = C.CDLL(_SO)
     lib.ht_create.restype = C.c_void_p
     lib.ht_create.argtypes = [C.c_void_p]
+    lib.ht_create_sym.restype = C.c_void_p
+    lib.ht_create_sym.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
     lib.ht_destroy.argtypes = [C.c_void_p]
     lib.ht_W.restype = C.c_uint64
     lib.ht_W.argtypes = [C.c_void_p]
@@ -45,6 +48,46 @@ def load():
     return lib
 
 
+def synthetic_sym(symbols, n_public, seed, drop_frac=0.01, max_block=400):
+    """A `.sym` file a compiler could have written for the same circuit, made from the kept-v1 table
+    `symbols` = [(slot, name)]: main I/O stays in front, the other signals are cut into blocks that are
+    shuffled, a few signals are marked eliminated (witness index -1), label indices are unrelated.
+    Returns (text, dst) with dst[kept-v1 slot] = witness index or None."""
+    import random
+    rng = random.Random(seed)
+    W = len(symbols)
+    rest = list(range(n_public + 1, W))
+    blocks = []
+    i = 0
+    while i < len(rest):
+        n = rng.randrange(1, max_block)
+        blocks.append(rest[i:i + n])
+        i += n
+    rng.shuffle(blocks)
+    dst = [None] * W
+    w = 0
+    for s in range(n_public + 1):
+        dst[s] = w
+        w += 1
+    for b in blocks:
+        for s in b:
+            if rng.random() < drop_frac:
+                continue
+            dst[s] = w
+            w += 1
+    lines = [f"{7 * s + 3},{-1 if dst[s] is None else dst[s]},{s % 97},{symbols[s][1]}" for s in range(1, W)]
+    rng.shuffle(lines)
+    return "\n".join(lines) + "\n", dst
+
+
+def apply_sym(witness, dst):
+    out = [None] * (max(d for d in dst if d is not None) + 1)
+    for s, d in enumerate(dst):
+        if d is not None:
+            out[d] = witness[s]
+    return out
+
+
 def expand(lib, h, rec, bits, small, frv):
     """Python restatement of zk_expand (zkwg_kernels_expand.hip): image -> witness ints."""
     W = lib.ht_W(h)
@@ -63,7 +106,8 @@ def expand(lib, h, rec, bits, small, frv):
 
     for si in range(lib.ht_nsegs(h)):
         s = segs[si]
-        for r in range(s.nslots):
+        for rr in range(s.nslots):
+            r = s.r0 + rr
             t = s.type
             if t == 0:
                 v = small[s.src + r]
@@ -139,7 +183,7 @@ def expand(lib, h, rec, bits, small, frv):
                     v = (1 if d == 0 else 0) if (q - 62) % 2 == 0 else inv(max(-half, min(half, d)))
             else:
                 raise ValueError(t)
-            assert out[s.slot + r] is None
-            out[s.slot + r] = v
+            assert out[s.slot + rr] is None
+            out[s.slot + rr] = v
     assert all(x is not None for x in out)
     return out

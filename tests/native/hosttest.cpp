@@ -21,6 +21,14 @@ void* ht_create(const zkwg_config* cfg) {
   if (!build_sched(*cfg, h->s, h->segs, h->first)) { delete h; return nullptr; }
   return h;
 }
+// `.sym`-ordered variant of the same schedule (zkwg_build.h zk_sym_layout + zk_remap_segments)
+void* ht_create_sym(const zkwg_config* cfg, const char* sym, uint64_t len) {
+  HT* h = new HT();
+  ZkSymLayout L;
+  if (!build_sched(*cfg, h->s, h->segs, h->first) || !zk_sym_layout(h->s, sym, len, nullptr, 0, L) ||
+      !zk_remap_segments(h->s, h->segs, h->first, L)) { delete h; return nullptr; }
+  return h;
+}
 void ht_destroy(void* p) { delete (HT*)p; }
 uint64_t ht_W(void* p) { return ((HT*)p)->s.W; }
 uint32_t ht_nsegs(void* p) { return ((HT*)p)->s.nsegs; }

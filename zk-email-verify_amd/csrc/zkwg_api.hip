@@ -22,6 +22,7 @@ struct zkwg_circuit {
   ZkSched s;
   int device;
   Fr* d_invtab;
+  std::vector<std::string> sym_names;  // layout SYM: witness index -> name
   Fr* d_pos;      // Poseidon(9): C[680] then M[100]
   u32 pos2_off;
   Fr* d_pos_rs;   // removeSoftLineBreaks: Poseidon(16) then Poseidon(2) sparse-round tables
@@ -101,8 +102,15 @@ const char* zkwg_strerror(int rc) {
   }
 }
 
-int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out) {
-  if (!cfg || !out) return ZKWG_RC_BAD_ARG;
+static thread_local std::string g_last_error;
+const char* zkwg_last_error(void) { return g_last_error.c_str(); }
+
+static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_text, uint64_t sym_len,
+                       const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out) {
+  if (!cfg_in || !out) return ZKWG_RC_BAD_ARG;
+  zkwg_config cfg_copy = *cfg_in;
+  cfg_copy.layout = ZKWG_LAYOUT_KEPT_V1;
+  const zkwg_config* cfg = &cfg_copy;
   zkwg_circuit* c = new zkwg_circuit();
   c->cfg = *cfg;
   c->device = -1;
@@ -116,7 +124,17 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
   if (const char* v = getenv("ZKWG_RSA_WGS_PER_CU")) c->rsa_wgs_per_cu = atoi(v);
   if (const char* v = getenv("ZKWG_EMAILS_PER_WG")) c->emails_per_wg = std::max(1, atoi(v));
   if (portion < 64 || portion > (1u << 20)) portion = ZK_PORTION_DEFAULT;
-  if (!build_sched(*cfg, c->s, c->segs, c->first_seg, portion)) { delete c; return ZKWG_RC_BAD_CONFIG; }
+  if (!build_sched(*cfg, c->s, c->segs, c->first_seg, portion)) { g_last_error = "unsupported circuit configuration"; delete c; return ZKWG_RC_BAD_CONFIG; }
+  if (sym_text) {
+    ZkSymLayout L;
+    if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L) || !zk_remap_segments(c->s, c->segs, c->first_seg, L)) {
+      g_last_error = L.err.empty() ? std::string(".sym layout does not tile the witness") : L.err;
+      delete c;
+      return ZKWG_RC_BAD_CONFIG;
+    }
+    c->sym_names.swap(L.names);
+    c->cfg.layout = ZKWG_LAYOUT_SYM;
+  }
   // kernel table (launch order)
   c->n_kernels = 5;
   c->kname[0] = "zk_sha_chain"; c->kslots[0] = 0;
@@ -177,6 +195,16 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
   }
   *out = c;
   return ZKWG_RC_OK;
+}
+
+int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out) {
+  if (cfg && cfg->layout != ZKWG_LAYOUT_KEPT_V1) { g_last_error = "layout SYM needs zkwg_circuit_create_sym"; return ZKWG_RC_BAD_CONFIG; }
+  return create_impl(cfg, device, nullptr, 0, nullptr, 0, out);
+}
+int zkwg_circuit_create_sym(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
+                            const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out) {
+  if (!sym_text) return ZKWG_RC_BAD_ARG;
+  return create_impl(cfg, device, sym_text, sym_len, alias_text, alias_len, out);
 }
 
 void zkwg_circuit_destroy(zkwg_circuit_t* c) {
@@ -526,7 +554,7 @@ uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap) {
   ZkWalker w;
   w.names = true;
   u64 pos = 0;
-  w.sink = [&](u64 slot, const std::string& name) {
+  auto put = [&](u64 slot, const std::string& name) {
     char buf[64];
     int n = snprintf(buf, sizeof(buf), "%llu,%llu,0,", (unsigned long long)slot, (unsigned long long)slot);
     u64 need = (u64)n + name.size() + 1;
@@ -537,6 +565,11 @@ uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap) {
     }
     pos += need;
   };
+  if (!c->sym_names.empty()) {
+    for (u64 i = 0; i < c->sym_names.size(); ++i) put(i, c->sym_names[i]);
+    return pos;
+  }
+  w.sink = put;
   switch (tmp.main_kind) {
     case ZKWG_MAIN_SHA256_BYTES: zk_walk_main_sha(w, tmp); break;
     case ZKWG_MAIN_RSA_VERIFIER: zk_walk_main_rsa(w, tmp); break;

@@ -1,8 +1,11 @@
 // Host-side schedule construction: zkwg_config -> ZkSched + segment table.
 #pragma once
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
+#include <string>
+#include <unordered_map>
 #include "../../include/zkwg.h"
 #include "zkwg_layout.h"
 
@@ -103,6 +106,137 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
   return true;
 }
 
+
+// ------------------------------------------------------------------ `.sym`-driven layout
+// A circom `.sym` file lists every signal of the compiled circuit, one per line:
+//     labelIdx,witnessIdx,componentIdx,qualified.name        (witnessIdx = -1: eliminated by the optimiser)
+// (circom_tester `loadSymbols`, packages/circuits/tests/email-verifier.test.ts:204-206 via assertOut).
+// zk_sym_layout() turns such a file into the witness order zk_expand produces: every kept-v1 slot whose
+// name the file maps to a witness index is emitted at that index, kept-v1 slots the compiler eliminated
+// are dropped, and the file must not keep a signal the schedule cannot produce.  `alias` holds optional
+// rename rules "ours=theirs" (one per line, applied as substring replacements to OUR names first) for the
+// compiler-generated names of anonymous components.
+struct ZkSymLayout {
+  std::vector<u32> dst;            // kept-v1 slot -> witness index (0xffffffff = dropped)
+  std::vector<std::string> names;  // witness index -> name (as in the file)
+  u64 W = 0;
+  std::string err;
+};
+static inline void zk_collect_names(ZkSched tmp, std::vector<std::string>& names) {
+  ZkWalker w;
+  w.names = true;
+  names.assign(tmp.W, std::string());
+  w.sink = [&](u64 slot, const std::string& name) { if (slot < names.size()) names[slot] = name; };
+  switch (tmp.main_kind) {
+    case ZKWG_MAIN_SHA256_BYTES: zk_walk_main_sha(w, tmp); break;
+    case ZKWG_MAIN_RSA_VERIFIER: zk_walk_main_rsa(w, tmp); break;
+    default: zk_walk_main_ev(w, tmp); break;
+  }
+}
+static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const char* alias, u64 alias_len, ZkSymLayout& L) {
+  std::vector<std::string> ours;
+  zk_collect_names(s, ours);
+  // rename rules
+  std::vector<std::pair<std::string, std::string>> rules;
+  for (u64 i = 0; alias && i < alias_len;) {
+    u64 j = i;
+    while (j < alias_len && alias[j] != '\n') ++j;
+    std::string line(alias + i, alias + j);
+    while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+    size_t eq = line.find('=');
+    if (eq != std::string::npos && eq > 0) rules.emplace_back(line.substr(0, eq), line.substr(eq + 1));
+    i = j + 1;
+  }
+  if (!rules.empty())
+    for (auto& nm : ours)
+      for (auto& r : rules)
+        for (size_t pos = nm.find(r.first); pos != std::string::npos; pos = nm.find(r.first, pos + r.second.size()))
+          nm.replace(pos, r.first.size(), r.second);
+  std::unordered_map<std::string, u32> slot_of;
+  slot_of.reserve(ours.size() * 2);
+  for (u32 i = 1; i < ours.size(); ++i) slot_of.emplace(ours[i], i);
+  L.dst.assign(ours.size(), 0xffffffffu);
+  L.dst[0] = 0;
+  L.names.clear();
+  L.names.push_back("one");
+  u64 unmatched = 0, dup = 0, maxw = 0, nlines = 0;
+  std::string first_unmatched;
+  for (u64 i = 0; i < len;) {
+    u64 j = i;
+    while (j < len && text[j] != '\n') ++j;
+    // labelIdx,witnessIdx,componentIdx,name
+    const char* p = text + i;
+    const char* e = text + j;
+    while (e > p && (e[-1] == '\r' || e[-1] == ' ')) --e;
+    i = j + 1;
+    if (p == e) continue;
+    ++nlines;
+    const char* c1 = (const char*)memchr(p, ',', e - p);
+    const char* c2 = c1 ? (const char*)memchr(c1 + 1, ',', e - c1 - 1) : nullptr;
+    const char* c3 = c2 ? (const char*)memchr(c2 + 1, ',', e - c2 - 1) : nullptr;
+    if (!c3) { L.err = "malformed .sym line " + std::to_string(nlines); return false; }
+    const long long widx = strtoll(c1 + 1, nullptr, 10);
+    if (widx < 0) continue;   // eliminated signal
+    std::string name(c3 + 1, e);
+    if (widx == 0) continue;  // the constant-one wire (never listed by circom; tolerated)
+    auto it = slot_of.find(name);
+    if (it == slot_of.end()) { if (!unmatched++) first_unmatched = name; continue; }
+    if ((u64)widx >= (1ull << 32) - 1) { L.err = "witness index out of range"; return false; }
+    if (L.dst[it->second] != 0xffffffffu && L.dst[it->second] != (u32)widx) { ++dup; continue; }
+    L.dst[it->second] = (u32)widx;
+    if ((u64)widx > maxw) maxw = (u64)widx;
+    if (L.names.size() <= (u64)widx) L.names.resize((u64)widx + 1);
+    L.names[(u64)widx] = name;
+  }
+  if (unmatched) {
+    L.err = std::to_string(unmatched) + " signal(s) kept by the .sym file are not produced by this schedule (first: " + first_unmatched + ")";
+    return false;
+  }
+  if (dup) { L.err = std::to_string(dup) + " name(s) listed with two different witness indices"; return false; }
+  L.W = maxw + 1;
+  // the kept indices must tile [0, W) exactly once
+  std::vector<u8> seen(L.W, 0);
+  for (u32 d : L.dst) {
+    if (d == 0xffffffffu) continue;
+    if (seen[d]) { L.err = "witness index " + std::to_string(d) + " assigned to two signals"; return false; }
+    seen[d] = 1;
+  }
+  for (u64 i = 0; i < L.W; ++i)
+    if (!seen[i]) { L.err = "witness index " + std::to_string(i) + " is not covered by the .sym file"; return false; }
+  return true;
+}
+// Re-target the segment table: split every kept-v1 segment into maximal runs whose destinations are
+// consecutive, carry the run's offset inside the logical array in ZkSeg::r0, sort by destination.
+static bool zk_remap_segments(ZkSched& s, std::vector<ZkSeg>& segs, std::vector<u32>& first_seg, const ZkSymLayout& L) {
+  std::vector<ZkSeg> out;
+  for (const ZkSeg& g : segs) {
+    u32 i = 0;
+    while (i < g.nslots) {
+      const u32 d = L.dst[g.slot + i];
+      if (d == 0xffffffffu) { ++i; continue; }
+      u32 j = i + 1;
+      while (j < g.nslots && L.dst[g.slot + j] == d + (j - i)) ++j;
+      out.push_back(ZkSeg{d, j - i, g.type, g.src, g.a, g.b, g.c, g.r0 + i, 0});
+      i = j;
+    }
+  }
+  std::sort(out.begin(), out.end(), [](const ZkSeg& a, const ZkSeg& b) { return a.slot < b.slot; });
+  u64 cur = 0;
+  for (const ZkSeg& g : out) { if (g.slot != cur) return false; cur += g.nslots; }
+  if (cur != L.W || out.size() >= 0xffffffffull) return false;
+  segs.swap(out);
+  s.W = L.W;
+  s.nsegs = (u32)segs.size();
+  s.nportions = (u32)((s.W + s.portion - 1) / s.portion);
+  first_seg.assign(s.nportions, 0);
+  u32 si = 0;
+  for (u32 p = 0; p < s.nportions; ++p) {
+    const u64 slot0 = (u64)p * s.portion;
+    while (si + 1 < s.nsegs && segs[si].slot + segs[si].nslots <= slot0) ++si;
+    first_seg[p] = si;
+  }
+  return true;
+}
 
 // ------------------------------------------------------------------ Poseidon(9) constants
 // Regenerated from the published procedure of the Poseidon reference implementation

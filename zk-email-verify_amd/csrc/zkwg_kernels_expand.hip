@@ -44,7 +44,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
     if (sg.slot >= slot1) break;
     const u64 lo = max(sg.slot, slot0);
     const u64 hi = min(sg.slot + sg.nslots, slot1);
-    const u32 r0 = (u32)(lo - sg.slot);         // first in-segment slot handled here
+    const u32 r0 = (u32)(lo - sg.slot) + sg.r0;  // first element of the logical array handled here
     const u32 nch = (u32)(hi - lo) * 2;          // chunks to write
    for (u32 el = el0; el < el1; ++el) {
     const u32 e = el + B.e_first;                // email index inside the prepared batch

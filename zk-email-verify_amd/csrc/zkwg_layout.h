@@ -35,7 +35,7 @@ struct ZkWalker {
     // a segment holds at most 2^32-1 slots; split longer runs
     while (nslots > 0) {
       u32 n = (u32)std::min<u64>(nslots, 0x40000000ull);
-      segs.push_back(ZkSeg{seg_cur, n, type, src, a, b, c});
+      segs.push_back(ZkSeg{seg_cur, n, type, src, a, b, c, 0, 0});
       seg_cur += n;
       nslots -= n;
       if (nslots) {  // only uniform types may be split

@@ -79,6 +79,9 @@ struct ZkSeg {
   u32 type;    // ZkSegType
   u32 src;     // source offset (see type)
   u32 a, b, c; // type parameters
+  u32 r0;      // index of the segment's first element inside the logical array (0 unless a `.sym`
+               // remap split the array: zkwg_build.h zk_remap_segments)
+  u32 pad;
 };
 
 #define ZK_PORTION_DEFAULT 2048u  // witness slots expanded by one workgroup of zk_expand

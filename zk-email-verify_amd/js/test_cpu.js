@@ -16,6 +16,21 @@ assert.throws(() => c.pack({ paddedIn: padded.slice(1), paddedInLength: 64 }), /
 assert.throws(() => c.pack({ paddedIn: padded }), /Not all inputs have been set. Only 1 out of 2/);
 const ev = new z.Circuit({ maxHeader: 576, maxBody: 192 }, -1);
 assert.strictEqual(ev.numPublic, 20);
+// `.sym`-ordered witness: swap the two halves of the non-public part of a small circuit's table
+{
+  const W = c.witnessLen, np = c.numPublic;
+  const names = z.symbols(c);
+  assert.strictEqual(names.length, W);
+  {
+    const half = np + 1 + Math.floor((W - np - 1) / 2);
+    const dst = (s) => (s <= np ? s : (s < half ? s + (W - half) : s - (half - np - 1)));
+    const text = names.slice(1).map((n, i) => (i + 1) + ',' + dst(i + 1) + ',0,' + n).join('\n') + '\n';
+    const cs = new z.Circuit({ mainKind: z.MAIN_SHA256_BYTES, maxHeader: 128, maxBody: 0, sym: text }, -1);
+    assert.strictEqual(cs.witnessLen, W);
+    assert.strictEqual(z.symbols(cs)[dst(np + 1)], names[np + 1]);
+    assert.throws(() => new z.Circuit({ mainKind: z.MAIN_SHA256_BYTES, maxHeader: 128, maxBody: 0, sym: text + '5,' + W + ',0,main.nope\n' }, -1), /not produced by this schedule/);
+  }
+}
 // flag variant removeSoftLineBreaks: one more input signal, same public signals
 const qp = new z.Circuit({ maxHeader: 576, maxBody: 384, removeSoftLineBreaks: 1 }, -1);
 assert.strictEqual(qp.numPublic, 20);

@@ -26,7 +26,8 @@ function norm(v) {
 }
 
 class Circuit {
-  /** opts: {mainKind, maxHeader, maxBody, n, k, ignoreBodyHashCheck, enableHeaderMasking, enableBodyMasking, removeSoftLineBreaks}; device < 0 = layout-only handle */
+  /** opts: {mainKind, maxHeader, maxBody, n, k, ignoreBodyHashCheck, enableHeaderMasking, enableBodyMasking, removeSoftLineBreaks, sym, symAlias}
+   *  sym: text of the compiled circuit's `.sym` file -> the witness follows its indices (zkwg_circuit_create_sym); device < 0 = layout-only handle */
   constructor(opts, device) {
     this.opts = Object.assign({ mainKind: MAIN_EMAIL_VERIFIER, maxHeader: 1024, maxBody: 1536, n: 121, k: 17, ignoreBodyHashCheck: 0, enableHeaderMasking: 0, enableBodyMasking: 0, removeSoftLineBreaks: 0 }, opts || {});
     this.handle = addon.createCircuit(this.opts, device === undefined ? 0 : device);
@@ -137,4 +138,15 @@ const wtns = {
   },
 };
 
-module.exports = { Circuit, WitnessCalculator, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };
+/** names[slot] of the circuit's layout (circom_tester `loadSymbols` counterpart, email-verifier.test.ts:204) */
+function symbols(circuit) {
+  const names = [];
+  for (const line of addon.symText(circuit.handle).split('\n')) {
+    if (!line) continue;
+    const p = line.split(',');
+    names[Number(p[1])] = p.slice(3).join(',');
+  }
+  return names;
+}
+
+module.exports = { symbols, Circuit, WitnessCalculator, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };

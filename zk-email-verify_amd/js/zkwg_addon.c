@@ -10,6 +10,7 @@
 #include <node_api.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 #include "../../include/zkwg.h"
 
 #define NAPI_OK(call) do { if ((call) != napi_ok) { napi_throw_error(env, NULL, "zkwg addon: N-API call failed: " #call); return NULL; } } while (0)
@@ -22,6 +23,20 @@ static int get_u32(napi_env env, napi_value obj, const char* key, uint32_t* out,
   if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return 0;
   if (napi_get_named_property(env, obj, key, &v) != napi_ok) return -1;
   return napi_get_value_uint32(env, v, out) == napi_ok ? 0 : -1;
+}
+
+/* string property -> malloc'ed UTF-8 copy (NULL when absent / not a string) */
+static void get_str(napi_env env, napi_value obj, const char* key, char** out, size_t* len) {
+  napi_value v; bool has = false; napi_valuetype t;
+  *out = NULL; *len = 0;
+  if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return;
+  if (napi_get_named_property(env, obj, key, &v) != napi_ok || napi_typeof(env, v, &t) != napi_ok || t != napi_string) return;
+  size_t n = 0;
+  if (napi_get_value_string_utf8(env, v, NULL, 0, &n) != napi_ok) return;
+  char* buf = (char*)malloc(n + 1);
+  if (!buf) return;
+  if (napi_get_value_string_utf8(env, v, buf, n + 1, &n) != napi_ok) { free(buf); return; }
+  *out = buf; *len = n;
 }
 
 /* createCircuit({mainKind,maxHeader,maxBody,n,k,ignoreBodyHashCheck}, device) -> External */
@@ -41,8 +56,19 @@ static napi_value CreateCircuit(napi_env env, napi_callback_info info) {
   int32_t device = 0;
   if (argc > 1) napi_get_value_int32(env, argv[1], &device);
   zkwg_circuit_t* c = NULL;
-  int rc = zkwg_circuit_create(&cfg, device, &c);
-  if (rc != ZKWG_RC_OK) { napi_throw_error(env, NULL, zkwg_strerror(rc)); return NULL; }
+  /* optional `sym` (text of the compiled circuit's .sym file) and `symAlias` (rename rules) */
+  char* sym = NULL; size_t sym_len = 0; char* alias = NULL; size_t alias_len = 0;
+  get_str(env, argv[0], "sym", &sym, &sym_len);
+  get_str(env, argv[0], "symAlias", &alias, &alias_len);
+  int rc = sym ? zkwg_circuit_create_sym(&cfg, device, sym, sym_len, alias, alias_len, &c)
+               : zkwg_circuit_create(&cfg, device, &c);
+  free(sym); free(alias);
+  if (rc != ZKWG_RC_OK) {
+    char msg[512];
+    snprintf(msg, sizeof(msg), "%s%s%s", zkwg_strerror(rc), rc == ZKWG_RC_BAD_CONFIG ? ": " : "", rc == ZKWG_RC_BAD_CONFIG ? zkwg_last_error() : "");
+    napi_throw_error(env, NULL, msg);
+    return NULL;
+  }
   napi_value ext;
   NAPI_OK(napi_create_external(env, c, circuit_finalize, NULL, &ext));
   return ext;
@@ -192,6 +218,23 @@ static napi_value StrError(napi_env env, napi_callback_info info) {
   return s;
 }
 
+/* symText(circuit) -> the layout's symbol table in `.sym` line format (zkwg_write_sym) */
+static napi_value SymText(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkwg_circuit_t* c = unwrap(env, argv[0]);
+  if (!c) return NULL;
+  uint64_t need = zkwg_write_sym(c, NULL, 0);
+  char* buf = (char*)malloc(need + 1);
+  if (!buf) { napi_throw_error(env, NULL, "zkwg: out of memory"); return NULL; }
+  zkwg_write_sym(c, buf, need);
+  napi_value out;
+  napi_status st = napi_create_string_utf8(env, buf, need, &out);
+  free(buf);
+  NAPI_OK(st);
+  return out;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor d[] = {
       {"createCircuit", NULL, CreateCircuit, NULL, NULL, NULL, napi_default, NULL},
@@ -199,6 +242,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"calculateBatch", NULL, CalculateBatch, NULL, NULL, NULL, napi_default, NULL},
       {"witnessToBigInts", NULL, WitnessToBigInts, NULL, NULL, NULL, napi_default, NULL},
       {"strerror", NULL, StrError, NULL, NULL, NULL, napi_default, NULL},
+      {"symText", NULL, SymText, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d);
   return exports;

@@ -49,12 +49,22 @@ class Circuit:
 
     def __init__(self, main_kind=MAIN_EMAIL_VERIFIER, max_header=1024, max_body=1536, n=121, k=17,
                  ignore_body_hash_check=0, device=0, enable_header_masking=0, enable_body_masking=0,
-                 remove_soft_line_breaks=0):
+                 remove_soft_line_breaks=0, sym=None, sym_alias=None):
+        """sym: text of the compiled circuit's `.sym` file -> the witness follows ITS indices
+        (zkwg_circuit_create_sym); sym_alias: optional "ours=theirs" rename rules, one per line."""
         self.lib = _lib.load()
         self.cfg = Config(main_kind, max_header, max_body, n, k, ignore_body_hash_check, enable_header_masking,
                           enable_body_masking, remove_soft_line_breaks, 0)
         h = C.c_void_p()
-        _check(self.lib.zkwg_circuit_create(C.byref(self.cfg), device, C.byref(h)))
+        if sym is None:
+            rc = self.lib.zkwg_circuit_create(C.byref(self.cfg), device, C.byref(h))
+        else:
+            sb = sym.encode() if isinstance(sym, str) else bytes(sym)
+            ab = None if sym_alias is None else (sym_alias.encode() if isinstance(sym_alias, str) else bytes(sym_alias))
+            rc = self.lib.zkwg_circuit_create_sym(C.byref(self.cfg), device, sb, len(sb), ab, len(ab) if ab else 0, C.byref(h))
+        if rc == -1:
+            raise ZkwgError(f"{self.lib.zkwg_strerror(rc).decode()}: {self.lib.zkwg_last_error().decode()}")
+        _check(rc)
         self.h = h
         self.device = device
         self.W = self.lib.zkwg_witness_len(h)
