@@ -235,6 +235,24 @@ int zkwg_write_wtns(const zkwg_circuit_t* c, const uint8_t* witness, uint8_t* ou
  * needed; writes at most cap bytes. */
 uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap);
 
+/* ---- `.r1cs` reader + constraint check on the device ----------------------------
+ * Replaces circom_tester's `await circuit.checkConstraints(witness)`, which every circuit test of the
+ * reference calls right after calculateWitness (packages/circuits/tests/email-verifier.test.ts:44,
+ * sha.test.ts, rsa.test.ts, ...): for each constraint of the compiled circuit, (A.w)*(B.w) == C.w mod r.
+ * `bytes` = the iden3 `.r1cs` file circom wrote (field must be BN254 Fr).  device < 0: parse only. */
+typedef struct zkwg_r1cs zkwg_r1cs_t;
+int zkwg_r1cs_load(const uint8_t* bytes, uint64_t len, int device, zkwg_r1cs_t** out);
+void zkwg_r1cs_destroy(zkwg_r1cs_t* r);
+/* out = {nWires, nPubOut, nPubIn, nPrvIn, mConstraints, nLabels} */
+int zkwg_r1cs_info(const zkwg_r1cs_t* r, uint64_t out[6]);
+/* n witnesses resident in HBM (32-byte LE values, `stride` bytes apart, stride >= 32*nWires):
+ * d_first_bad[i] (u64) = index of the first violated constraint of witness i, UINT64_MAX if all hold.
+ * A value >= r anywhere in a checked linear combination also counts as a violation. */
+int zkwg_check_constraints_device(zkwg_r1cs_t* r, const void* d_witness, uint64_t n, uint64_t stride,
+                                  void* d_first_bad, void* hip_stream);
+/* Same for witnesses in host memory (staged through the device in tiles). */
+int zkwg_check_constraints(zkwg_r1cs_t* r, const uint8_t* witness, uint64_t n, uint64_t stride, uint64_t* first_bad);
+
 #ifdef __cplusplus
 }
 #endif

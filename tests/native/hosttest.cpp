@@ -7,6 +7,7 @@
 #include "zkwg_rsa_core.h"
 #include "zkwg_poseidon_core.h"
 #include "zkwg_poseidon_sparse.h"
+#include "zkwg_r1cs.h"
 #include "zkwg_regex_core.h"
 
 struct HT {
@@ -75,6 +76,15 @@ int ht_poseidon_sparse(uint32_t t, const void* inputs, void* emit, void* hash) {
   else return 2;
   *(Fr*)hash = h;
   return 0;
+}
+// `.r1cs` reader + check core (zkwg_r1cs.h) on the host: index of the first violated constraint, -1 if none,
+// -2 on a parse error
+long long ht_r1cs_first_bad(const uint8_t* data, uint64_t len, const void* witness) {
+  ZkR1csHost R;
+  if (!zk_r1cs_parse(data, len, R)) return -2;
+  for (u64 i = 0; i < R.n_constraints; ++i)
+    if (!zk_r1cs_check_one(R.row_ptr.data(), R.wire.data(), R.coef.data(), R.kind.data(), i, (const Fr*)witness)) return (long long)i;
+  return -1;
 }
 // the product's DFA scan (zkwg_regex_core.h) on the host: rev[n], own[2(n+1) + NP n + n]; returns accept count
 uint32_t ht_regex_scan(const uint8_t* msg, uint32_t n, uint32_t* rev, uint32_t* own) {

@@ -1,0 +1,77 @@
+"""Test-only helpers for the `.r1cs` path: a writer of the iden3 binary format, a pure-Python constraint
+evaluator (the checker of the checker) and small constraint systems with their witnesses."""
+import random
+import struct
+
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def write_r1cs(n_wires, constraints, n_pub_out=0, n_pub_in=0, n_prv_in=0, header_last=False):
+    """constraints: list of (A, B, C), each a dict wire -> coefficient (ints mod P)."""
+    def lc(d):
+        items = sorted((w, c % P) for w, c in d.items() if c % P)
+        return struct.pack("<I", len(items)) + b"".join(struct.pack("<I", w) + c.to_bytes(32, "little") for w, c in items)
+    hdr = struct.pack("<I", 32) + P.to_bytes(32, "little") + struct.pack("<IIIIQI", n_wires, n_pub_out, n_pub_in, n_prv_in,
+                                                                       n_wires, len(constraints))
+    cons = b"".join(lc(a) + lc(b) + lc(c) for a, b, c in constraints)
+    w2l = b"".join(struct.pack("<Q", i) for i in range(n_wires))
+    secs = [(1, hdr), (2, cons), (3, w2l)]
+    if header_last:
+        secs = [secs[1], secs[2], secs[0]]
+    out = b"r1cs" + struct.pack("<II", 1, len(secs))
+    for t, d in secs:
+        out += struct.pack("<IQ", t, len(d)) + d
+    return out
+
+
+def first_violation(constraints, w):
+    ev = lambda d: sum(c * w[k] for k, c in d.items()) % P
+    for i, (a, b, c) in enumerate(constraints):
+        if (ev(a) * ev(b) - ev(c)) % P:
+            return i
+    return None
+
+
+def num2bits_system(nbits, value):
+    """circomlib Num2Bits(n): wires [1, in, out[0..n)]: out_i*(out_i-1)=0 and sum 2^i out_i = in."""
+    cons = [({2 + i: 1}, {2 + i: 1, 0: -1}, {}) for i in range(nbits)]
+    cons.append(({**{2 + i: 1 << i for i in range(nbits)}, 1: -1}, {0: 1}, {}))
+    w = [1, value] + [(value >> i) & 1 for i in range(nbits)]
+    return 2 + nbits, cons, w
+
+
+def sigma_chain_system(x, rounds):
+    """poseidon.circom Sigma repeated: per round in2 = in*in, in4 = in2*in2, out = in4*in (+ round constant)."""
+    w = [1, x % P]
+    cons = []
+    cur = 1
+    for r in range(rounds):
+        v = w[cur]
+        i2, i4, o = len(w), len(w) + 1, len(w) + 2
+        w += [v * v % P, pow(v, 4, P), pow(v, 5, P)]
+        cons += [({cur: 1}, {cur: 1}, {i2: 1}), ({i2: 1}, {i2: 1}, {i4: 1}), ({i4: 1}, {cur: 1}, {o: 1})]
+        # next input = out + (r+1)  (a linear signal of its own, as Ark would be after O0)
+        nxt = len(w)
+        w.append((w[o] + r + 1) % P)
+        cons.append(({o: 1, 0: r + 1, nxt: -1}, {0: 1}, {}))
+        cur = nxt
+    return len(w), cons, w
+
+
+def random_system(seed, n_wires, m, max_terms=12):
+    """A random satisfiable system: random sparse A, B, C' and one correcting term in C per constraint."""
+    rng = random.Random(seed)
+    w = [1] + [rng.choice([0, 1, rng.randrange(256), rng.randrange(P)]) for _ in range(n_wires - 1)]
+    nz = [i for i, v in enumerate(w) if v]
+    coefs = lambda: rng.choice([1, P - 1, 2, rng.randrange(1 << 16), rng.randrange(P), 1 << rng.randrange(253)])
+    ev = lambda d: sum(c * w[k] for k, c in d.items()) % P
+    cons = []
+    for _ in range(m):
+        a = {rng.randrange(n_wires): coefs() for _ in range(rng.randrange(0, max_terms))}
+        b = {rng.randrange(n_wires): coefs() for _ in range(rng.randrange(0, max_terms))}
+        c = {rng.randrange(n_wires): coefs() for _ in range(rng.randrange(0, max_terms))}
+        k = rng.choice(nz)
+        c.pop(k, None)
+        c[k] = (ev(a) * ev(b) - ev(c)) * pow(w[k], P - 2, P) % P
+        cons.append((a, b, c))
+    return cons, w

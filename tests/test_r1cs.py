@@ -1,0 +1,180 @@
+"""`.r1cs` reader + `checkConstraints` (include/zkwg.h zkwg_r1cs_*).  No compiled circuit exists
+offline, so the constraint systems are written by tests/r1cs_util.py in the iden3 binary format: circomlib-style
+Num2Bits, a chain of Poseidon S-boxes, and large random satisfiable systems; expected results come from the
+pure-Python evaluator in the same file."""
+import ctypes as C
+
+import pytest
+
+import hosttest
+import r1cs_util as ru
+
+
+def _blob(w):
+    return b"".join(int(v).to_bytes(32, "little") for v in w)
+
+
+def test_r1cs_reader_and_check_core_on_the_host():
+    import zkwg
+    lib = hosttest.load()
+    nw, cons, w = ru.num2bits_system(8, 0xA5)
+    for header_last in (False, True):
+        data = ru.write_r1cs(nw, cons, n_pub_out=0, n_pub_in=1, n_prv_in=0, header_last=header_last)
+        r = zkwg.R1cs(data, device=-1)   # parse only
+        assert (r.n_wires, r.n_constraints, r.n_pub_in, r.n_labels) == (nw, len(cons), 1, nw)
+        with pytest.raises(zkwg.ZkwgError):
+            r.first_violations(_blob(w))   # no device: the check has no CPU fallback
+    # the same check core (zkwg_r1cs.h), host build
+    for (nw, cons, w) in (ru.num2bits_system(8, 0xA5), ru.sigma_chain_system(12345, 20)):
+        data = ru.write_r1cs(nw, cons)
+        assert lib.ht_r1cs_first_bad(data, len(data), _blob(w)) == -1
+        for k in (1, nw // 2, nw - 1):
+            w2 = list(w)
+            w2[k] = (w2[k] + 1) % ru.P
+            exp = ru.first_violation(cons, w2)
+            assert exp is not None and lib.ht_r1cs_first_bad(data, len(data), _blob(w2)) == exp
+    cons, w = ru.random_system(7, 300, 2000)
+    data = ru.write_r1cs(300, cons)
+    assert ru.first_violation(cons, w) is None and lib.ht_r1cs_first_bad(data, len(data), _blob(w)) == -1
+    w2 = list(w); w2[17] = (w2[17] + 5) % ru.P
+    assert lib.ht_r1cs_first_bad(data, len(data), _blob(w2)) == ru.first_violation(cons, w2)
+    # malformed files
+    for bad in (b"r1cx" + data[4:], data[:40], data[:12] + b"\xff" * 12 + data[24:]):
+        with pytest.raises(zkwg.ZkwgError):
+            zkwg.R1cs(bad, device=-1)
+    # a non-reduced witness value is a violation, not an accident
+    w3 = list(w); w3[17] = w[17] + ru.P if w[17] + ru.P < (1 << 256) else w[17]
+    if w3[17] != w[17]:
+        exp = next(i for i, (a, b, c) in enumerate(cons) if 17 in a or 17 in b or 17 in c)
+        assert lib.ht_r1cs_first_bad(data, len(data), _blob(w3)) == exp
+
+
+@pytest.mark.gpu
+def test_check_constraints_on_gpu():
+    import torch
+    import zkwg
+    nw, cons, w = ru.sigma_chain_system(987654321, 200)
+    r = zkwg.R1cs(ru.write_r1cs(nw, cons), device=0)
+    r.checkConstraints(w)                                   # circom_tester-shaped: silent when satisfied
+    bad = list(w); bad[5] = (bad[5] + 1) % ru.P
+    with pytest.raises(zkwg.ZkwgError, match="Constraint doesn't match"):
+        r.checkConstraints(bad)
+    with pytest.raises(zkwg.ZkwgError, match="Invalid witness length"):
+        r.checkConstraints(w[:-1])
+    # a large random system, a batch of witnesses with one corruption each, host and device entry points
+    NW, M = 5000, 60000
+    cons, w = ru.random_system(11, NW, M)
+    r = zkwg.R1cs(ru.write_r1cs(NW, cons), device=0)
+    wits, exp = [], []
+    import random
+    rng = random.Random(3)
+    for e in range(6):
+        we = list(w)
+        if e:
+            k = rng.randrange(1, NW)
+            we[k] = (we[k] + 1 + rng.randrange(100)) % ru.P
+        wits.append(_blob(we))
+        exp.append(ru.first_violation(cons, we))
+    assert exp[0] is None
+    assert r.first_violations(b"".join(wits)) == exp
+    stride = 32 * NW + 64                                    # padded stride
+    d = torch.zeros(6 * stride, dtype=torch.uint8, device="cuda:0")
+    for e in range(6):
+        d[e * stride:e * stride + 32 * NW] = torch.frombuffer(bytearray(wits[e]), dtype=torch.uint8).to("cuda:0")
+    assert r.first_violations_device(d, 6, stride) == exp
+
+
+def _poseidon9_constraints(sym, W):
+    """R1CS of the PoseidonLarge(121,17) -> Poseidon(9) block of EmailVerifier over the wires of the kept
+    layout (utils/hash.circom:15-39 + textbook Poseidon rounds): every S-box signal is constrained through
+    linear combinations of earlier wires; the last constraint ties the result to main.pubkeyHash."""
+    from oracle.pyref import poseidon
+    t, rp = 10, poseidon.N_ROUNDS_P[8]
+    Cc, M = poseidon.constants(t)
+    slot = {n: s for s, n in sym}
+    pk = [slot[f"main.pubkey[{i}]"] for i in range(17)]
+    pre = "main.anon_PoseidonLarge.anon_Poseidon.pEx."
+    state = [{}] + [({pk[2 * i]: 1, pk[2 * i + 1]: 1 << 121} if i < 8 else {pk[16]: 1}) for i in range(9)]
+    cons = []
+
+    def add(a, b):
+        out = dict(a)
+        for k, v in b.items():
+            out[k] = (out.get(k, 0) + v) % ru.P
+        return out
+
+    def sbox(lc, name):
+        o, i2, i4 = slot[name + ".out"], slot[name + ".in2"], slot[name + ".in4"]
+        cons.extend([(lc, lc, {i2: 1}), ({i2: 1}, {i2: 1}, {i4: 1}), ({i4: 1}, lc, {o: 1})])
+        return {o: 1}
+
+    fr = 0
+    for r in range(8 + rp):
+        state = [add(state[j], {0: Cc[r * t + j]}) for j in range(t)]
+        if r < 4 or r >= 4 + rp:
+            state = [sbox(state[j], f"{pre}sigmaF[{fr}][{j}]") for j in range(t)]
+            fr += 1
+        else:
+            state[0] = sbox(state[0], f"{pre}sigmaP[{r - 4}]")
+        new = []
+        for i in range(t):
+            acc = {}
+            for j in range(t):
+                acc = add(acc, {k: v * M[i][j] % ru.P for k, v in state[j].items()})
+            new.append(acc)
+        state = new
+    cons.append((add(state[0], {slot["main.pubkeyHash"]: ru.P - 1}), {0: 1}, {}))
+    return cons
+
+
+@pytest.mark.gpu
+def test_check_constraints_of_real_device_witnesses():
+    """The device witness against constraint systems derived independently of the witness kernels:
+    (1) EmailVerifier: the complete Poseidon(9) pubkey-hash block; (2) Sha256Bytes main: booleanity of every
+    slot that the segment table types as a bit (Num2Bits / xor / comparator outputs: 97 % of the witness)."""
+    import torch
+    import zkwg
+    from zkwg._lib import Config, MAIN_SHA256_BYTES
+    from test_ev_cpu import _inputs
+    from conftest import sha_pad
+    N, M = 576, 192
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    cons = _poseidon9_constraints(c.symbols(), c.W)
+    assert len(cons) == 3 * 140 + 1
+    r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=3, n_pub_in=17), device=0)
+    recs = b"".join(c.pack(_inputs(N, M, 0, index=i, body_len=80)) for i in range(3))
+    d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to("cuda:0")
+    d_out = torch.empty(3 * c.witness_bytes, dtype=torch.uint8, device="cuda:0")
+    d_status = torch.zeros(3, dtype=torch.int32, device="cuda:0")
+    d_scr = torch.empty(c.scratch_bytes(3), dtype=torch.uint8, device="cuda:0")
+    c.calculate_batch_device(d_in, 3, d_out, d_status, d_scr)
+    torch.cuda.synchronize()
+    assert d_status.cpu().tolist() == [0, 0, 0]
+    assert r.first_violations_device(d_out, 3, c.witness_bytes) == [None, None, None]
+    sl = dict((n, s) for s, n in c.symbols())["main.anon_PoseidonLarge.anon_Poseidon.pEx.sigmaP[30].in4"]
+    d_out[c.witness_bytes + 32 * sl] ^= 1                                   # flip one bit of witness 1
+    assert r.first_violations_device(d_out, 3, c.witness_bytes) == [None, 3 * (4 * 10 + 30) + 1, None]
+
+    # (2) booleanity over every bit-typed slot of a Sha256Bytes(128) witness
+    lib = hosttest.load()
+    cfg = Config(MAIN_SHA256_BYTES, 128, 0, 121, 17, 0, 0, 0, 0, 0)
+    h = lib.ht_create(C.byref(cfg))
+    segs = lib.ht_segs(h)
+    bit_slots = []
+    for i in range(lib.ht_nsegs(h)):
+        s = segs[i]
+        if s.type in (2, 3, 4, 5, 9, 11, 14):
+            bit_slots.extend(range(s.slot, s.slot + s.nslots))
+    W = lib.ht_W(h)
+    lib.ht_destroy(h)
+    assert len(bit_slots) > 0.95 * W
+    cs = zkwg.Circuit(MAIN_SHA256_BYTES, max_header=128, max_body=0, device=0)
+    assert cs.W == W
+    rb = zkwg.R1cs(ru.write_r1cs(W, [({k: 1}, {k: 1, 0: ru.P - 1}, {}) for k in bit_slots]), device=0)
+    p, n = sha_pad(b"hello world", 128)
+    w = zkwg.WitnessCalculator(cs).calculateWitness({"paddedIn": list(p), "paddedInLength": n})
+    rb.checkConstraints(w)
+    k = len(bit_slots) // 2
+    w[bit_slots[k]] = 2
+    with pytest.raises(zkwg.ZkwgError, match=f"constraint {k}\\)"):
+        rb.checkConstraints(w)

@@ -13,4 +13,6 @@ __global__ void zk_rsa(ZkSched s, ZkBufs B);         // zkwg_kernels_rsa.hip
 __global__ void zk_misc_ev(ZkSched s, ZkBufs B);     // zkwg_kernels_misc.hip
 __global__ void zk_rslb_chunks(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip
 __global__ void zk_rslb_chain(ZkSched s, ZkBufs B);
+__global__ void zk_r1cs_check(const u64* row_ptr, const u32* wire, const Fr* coef, const u8* kind, u32 m,
+                              const u8* wit, u64 stride, unsigned long long* first_bad);  // zkwg_kernels_r1cs.hip
 __global__ void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8* recs, int* gen_status, u32 n);  // zkwg_kernels_inputs.hip

@@ -31,6 +31,19 @@ assert.strictEqual(ev.numPublic, 20);
     assert.throws(() => new z.Circuit({ mainKind: z.MAIN_SHA256_BYTES, maxHeader: 128, maxBody: 0, sym: text + '5,' + W + ',0,main.nope\n' }, -1), /not produced by this schedule/);
   }
 }
+// .r1cs reader (parse-only handle): a*b = c over wires [1, a, b, c]
+{
+  const le = (v, n) => { const b = Buffer.alloc(n); let x = BigInt(v); for (let i = 0; i < n; ++i) { b[i] = Number(x & 0xffn); x >>= 8n; } return b; };
+  const lc = (terms) => Buffer.concat([le(terms.length, 4)].concat(terms.map(([w, c]) => Buffer.concat([le(w, 4), le(c, 32)]))));
+  const hdr = Buffer.concat([le(32, 4), le(z.FIELD_MODULUS, 32), le(4, 4), le(1, 4), le(0, 4), le(2, 4), le(4, 8), le(1, 4)]);
+  const cons = Buffer.concat([lc([[1, 1]]), lc([[2, 1]]), lc([[3, 1]])]);
+  const sec = (t, d) => Buffer.concat([le(t, 4), le(d.length, 8), d]);
+  const file = Buffer.concat([Buffer.from('r1cs'), le(1, 4), le(2, 4), sec(1, hdr), sec(2, cons)]);
+  const r = new z.R1cs(file, -1);
+  assert.strictEqual(r.nWires, 4); assert.strictEqual(r.nConstraints, 1); assert.strictEqual(r.nPrvIn, 2);
+  assert.throws(() => new z.R1cs(Buffer.from('nope'), -1), /malformed/);
+  assert.throws(() => r.firstViolations(Buffer.alloc(128), 1), /no HIP device/);
+}
 // flag variant removeSoftLineBreaks: one more input signal, same public signals
 const qp = new z.Circuit({ maxHeader: 576, maxBody: 384, removeSoftLineBreaks: 1 }, -1);
 assert.strictEqual(qp.numPublic, 20);

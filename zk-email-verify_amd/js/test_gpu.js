@@ -31,5 +31,21 @@ function shaPad(msg, max) {  // packages/helpers/src/sha-utils.ts:88-111
   await assert.rejects(wc.calculateWitness({ paddedIn: Array.from(p), paddedInLength: n + 1 }), /Assert Failed/);
   const b = await wc.calculateBatch([{ paddedIn: Array.from(p), paddedInLength: n }, { paddedIn: Array.from(p), paddedInLength: 0 }]);
   assert.deepStrictEqual(Array.from(b.status), [0, 4]);
+  // checkConstraints on a real device witness: booleanity of the 256 output bits of Sha256Bytes(640)
+  // written as an .r1cs file (out_i * (out_i - 1) = 0 over wires 1..256 of the W-wire witness)
+  {
+    const le = (v, k) => { const bb = Buffer.alloc(k); let x = BigInt(v); for (let i = 0; i < k; ++i) { bb[i] = Number(x & 0xffn); x >>= 8n; } return bb; };
+    const lc = (terms) => Buffer.concat([le(terms.length, 4)].concat(terms.map(([w, cf]) => Buffer.concat([le(w, 4), le(cf, 32)]))));
+    const W = c.witnessLen, M1 = z.FIELD_MODULUS - 1n;
+    const cons = [];
+    for (let i = 1; i <= 256; ++i) cons.push(lc([[i, 1]]), lc([[0, M1], [i, 1]]), lc([]));
+    const hdr = Buffer.concat([le(32, 4), le(z.FIELD_MODULUS, 32), le(W, 4), le(256, 4), le(641, 4), le(0, 4), le(W, 8), le(256, 4)]);
+    const sec = (t, d) => Buffer.concat([le(t, 4), le(d.length, 8), d]);
+    const r1 = new z.R1cs(Buffer.concat([Buffer.from('r1cs'), le(1, 4), le(2, 4), sec(2, Buffer.concat(cons)), sec(1, hdr)]), 0);
+    const w = await wc.calculateWitness({ paddedIn: Array.from(p), paddedInLength: n });
+    await r1.checkConstraints(w);
+    const bad = w.slice(); bad[7] = 2n;
+    await assert.rejects(r1.checkConstraints(bad), /Constraint doesn't match \(constraint 6\)/);
+  }
   console.log('js gpu ok');
 })().catch((e) => { console.error(e); process.exit(1); });

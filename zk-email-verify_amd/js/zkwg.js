@@ -138,6 +138,24 @@ const wtns = {
   },
 };
 
+/** The compiled circuit's `.r1cs`, for circom_tester-style `checkConstraints(witness)` on the device
+ * (packages/circuits/tests/email-verifier.test.ts:44). */
+class R1cs {
+  constructor(fileBytes, device) {
+    Object.assign(this, addon.r1csLoad(Buffer.from(fileBytes), device === undefined ? 0 : device));
+  }
+  /** witness: bigint[] (as calculateWitness returns) -> resolves, or throws "Constraint doesn't match" */
+  async checkConstraints(witness) {
+    if (witness.length !== this.nWires) throw new Error('Invalid witness length. Circuit: ' + this.nWires + ', witness: ' + witness.length);
+    const buf = Buffer.alloc(32 * witness.length);
+    witness.forEach((v, i) => { let x = BigInt(v); for (let k = 0; k < 4; ++k) { buf.writeBigUInt64LE(x & 0xffffffffffffffffn, 32 * i + 8 * k); x >>= 64n; } });
+    const bad = addon.r1csCheck(this.handle, buf, 1, buf.length)[0];
+    if (bad >= 0) throw new Error("Constraint doesn't match (constraint " + bad + ')');
+  }
+  /** n binary witnesses in one Buffer -> first violated constraint per witness (-1 = all hold) */
+  firstViolations(buf, n, stride) { return addon.r1csCheck(this.handle, buf, n, stride || 32 * this.nWires); }
+}
+
 /** names[slot] of the circuit's layout (circom_tester `loadSymbols` counterpart, email-verifier.test.ts:204) */
 function symbols(circuit) {
   const names = [];
@@ -149,4 +167,4 @@ function symbols(circuit) {
   return names;
 }
 
-module.exports = { symbols, Circuit, WitnessCalculator, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };
+module.exports = { symbols, R1cs, Circuit, WitnessCalculator, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };

@@ -218,6 +218,53 @@ static napi_value StrError(napi_env env, napi_callback_info info) {
   return s;
 }
 
+/* ---- .r1cs / checkConstraints ------------------------------------------------------------- */
+static void r1cs_finalize(napi_env env, void* data, void* hint) { (void)env; (void)hint; zkwg_r1cs_destroy((zkwg_r1cs_t*)data); }
+/* r1csLoad(fileBytes: Buffer, device) -> {handle, nWires, nPubOut, nPubIn, nPrvIn, nConstraints, nLabels} */
+static napi_value R1csLoad(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  void* data; size_t len;
+  NAPI_OK(napi_get_buffer_info(env, argv[0], &data, &len));
+  int32_t device = 0;
+  if (argc > 1) napi_get_value_int32(env, argv[1], &device);
+  zkwg_r1cs_t* r = NULL;
+  int rc = zkwg_r1cs_load((const uint8_t*)data, len, device, &r);
+  if (rc != ZKWG_RC_OK) { napi_throw_error(env, NULL, rc == ZKWG_RC_BAD_CONFIG ? "zkwg: malformed or unsupported .r1cs file" : zkwg_strerror(rc)); return NULL; }
+  uint64_t inf[6];
+  zkwg_r1cs_info(r, inf);
+  napi_value obj, ext, v;
+  NAPI_OK(napi_create_object(env, &obj));
+  NAPI_OK(napi_create_external(env, r, r1cs_finalize, NULL, &ext));
+  NAPI_OK(napi_set_named_property(env, obj, "handle", ext));
+  const char* keys[6] = {"nWires", "nPubOut", "nPubIn", "nPrvIn", "nConstraints", "nLabels"};
+  for (int i = 0; i < 6; ++i) { NAPI_OK(napi_create_double(env, (double)inf[i], &v)); NAPI_OK(napi_set_named_property(env, obj, keys[i], v)); }
+  return obj;
+}
+/* r1csCheck(handle, witnesses: Buffer, n, strideBytes) -> number[] (first violated constraint, -1 = all hold) */
+static napi_value R1csCheck(napi_env env, napi_callback_info info) {
+  size_t argc = 4; napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  void* p = NULL;
+  if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p) { napi_throw_type_error(env, NULL, "zkwg: r1cs handle expected"); return NULL; }
+  void* data; size_t len;
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &len));
+  int64_t n = 0, stride = 0;
+  napi_get_value_int64(env, argv[2], &n); napi_get_value_int64(env, argv[3], &stride);
+  if (n <= 0 || stride <= 0 || (uint64_t)n * (uint64_t)stride > len) { napi_throw_range_error(env, NULL, "zkwg: witness buffer too small"); return NULL; }
+  uint64_t* bad = (uint64_t*)malloc((size_t)n * 8);
+  int rc = zkwg_check_constraints((zkwg_r1cs_t*)p, (const uint8_t*)data, (uint64_t)n, (uint64_t)stride, bad);
+  if (rc != ZKWG_RC_OK) { free(bad); napi_throw_error(env, NULL, zkwg_strerror(rc)); return NULL; }
+  napi_value arr, v;
+  NAPI_OK(napi_create_array_with_length(env, (size_t)n, &arr));
+  for (int64_t i = 0; i < n; ++i) {
+    NAPI_OK(napi_create_double(env, bad[i] == UINT64_MAX ? -1.0 : (double)bad[i], &v));
+    NAPI_OK(napi_set_element(env, arr, (uint32_t)i, v));
+  }
+  free(bad);
+  return arr;
+}
+
 /* symText(circuit) -> the layout's symbol table in `.sym` line format (zkwg_write_sym) */
 static napi_value SymText(napi_env env, napi_callback_info info) {
   size_t argc = 1; napi_value argv[1];
@@ -243,6 +290,8 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"witnessToBigInts", NULL, WitnessToBigInts, NULL, NULL, NULL, napi_default, NULL},
       {"strerror", NULL, StrError, NULL, NULL, NULL, napi_default, NULL},
       {"symText", NULL, SymText, NULL, NULL, NULL, napi_default, NULL},
+      {"r1csLoad", NULL, R1csLoad, NULL, NULL, NULL, napi_default, NULL},
+      {"r1csCheck", NULL, R1csCheck, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d);
   return exports;

@@ -230,6 +230,58 @@ class Circuit:
         return out
 
 
+class R1cs:
+    """A compiled circuit's `.r1cs` constraint system, loaded for `checkConstraints` on the device
+    (circom_tester `circuit.checkConstraints(witness)`, packages/circuits/tests/email-verifier.test.ts:44)."""
+
+    def __init__(self, data, device=0):
+        self.lib = _lib.load()
+        data = bytes(data)
+        h = C.c_void_p()
+        _check(self.lib.zkwg_r1cs_load(data, len(data), device, C.byref(h)))
+        self.h = h
+        info = (C.c_uint64 * 6)()
+        _check(self.lib.zkwg_r1cs_info(h, info))
+        (self.n_wires, self.n_pub_out, self.n_pub_in, self.n_prv_in, self.n_constraints, self.n_labels) = [int(x) for x in info]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zkwg_r1cs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def first_violations(self, witnesses, n=None, stride=None):
+        """witnesses: bytes of n witnesses (32-byte LE values).  -> per witness: index of the first
+        violated constraint, or None."""
+        stride = stride or 32 * self.n_wires
+        n = n if n is not None else len(witnesses) // stride
+        bad = (C.c_uint64 * n)()
+        _check(self.lib.zkwg_check_constraints(self.h, bytes(witnesses), n, stride, bad))
+        return [None if b == 0xFFFFFFFFFFFFFFFF else int(b) for b in bad]
+
+    def first_violations_device(self, d_witness, n, stride, stream=None):
+        """d_witness: torch uint8 CUDA tensor holding n witnesses `stride` bytes apart."""
+        import torch
+        bad = torch.empty(n, dtype=torch.int64, device=d_witness.device)
+        st = stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _check(self.lib.zkwg_check_constraints_device(self.h, d_witness.data_ptr(), n, stride, bad.data_ptr(), st))
+        return [None if b == -1 else int(b) for b in bad.cpu().tolist()]
+
+    def checkConstraints(self, witness):
+        """circom_tester semantics on one witness given as a list of ints: raises on the first mismatch."""
+        blob = b"".join(int(v).to_bytes(32, "little") for v in witness)
+        if len(witness) != self.n_wires:
+            raise ZkwgError(f"Invalid witness length. Circuit: {self.n_wires}, witness: {len(witness)}")
+        bad = self.first_violations(blob, 1)[0]
+        if bad is not None:
+            raise ZkwgError(f"Constraint doesn't match (constraint {bad})")
+
+
 class WitnessCalculator:
     """circom_runtime `WitnessCalculator`-shaped front end over a `Circuit`."""
 

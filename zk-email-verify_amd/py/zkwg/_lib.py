@@ -88,6 +88,11 @@ def load():
         "zkwg_wtns_size": (u64, [vp]),
         "zkwg_write_wtns": (i32, [vp, vp, vp, u64]),
         "zkwg_write_sym": (u64, [vp, vp, u64]),
+        "zkwg_r1cs_load": (i32, [vp, u64, i32, C.POINTER(vp)]),
+        "zkwg_r1cs_destroy": (None, [vp]),
+        "zkwg_r1cs_info": (i32, [vp, C.POINTER(C.c_uint64)]),
+        "zkwg_check_constraints_device": (i32, [vp, vp, u64, u64, vp, vp]),
+        "zkwg_check_constraints": (i32, [vp, vp, u64, u64, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
@@ -103,4 +108,5 @@ EXPORTS = [
     "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_pack_input", "zkwg_pack_masks", "zkwg_pack_decoded_body", "zkwg_calculate_batch",
     "zkwg_generate_inputs_device", "zkwg_alloc_pinned", "zkwg_free_pinned", "zkwg_calculate_batch_device", "zkwg_prepare_device", "zkwg_expand_device", "zkwg_set_prepare_throttle", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_timing_summary", "zkwg_num_kernels",
     "zkwg_kernel_name", "zkwg_kernel_slots", "zkwg_wtns_size", "zkwg_write_wtns", "zkwg_write_sym",
+    "zkwg_r1cs_load", "zkwg_r1cs_destroy", "zkwg_r1cs_info", "zkwg_check_constraints_device", "zkwg_check_constraints",
 ]
