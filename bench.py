@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--rsa-throttle", type=int, default=3, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap)")
     ap.add_argument("--remove-soft-line-breaks", type=int, default=0,
                     help="template flag removeSoftLineBreaks (flag-variant measurement; the headline config keeps 0)")
+    ap.add_argument("--gather-wtns", type=int, default=0,
+                    help="also gather this many full witnesses per rank and step on rank 0 over RCCL (N>1 only; "
+                         "inside the timed region; default 0 = result table only, see DESIGN.md section 7)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="emails timed for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -131,6 +134,12 @@ def main():
             if dist is not None and backend != "nccl":
                 table = table.cpu()                     # gloo test hook: gather on the host
             state["table"] = shard.gather_table(dist, table, args.batch * world, rank, world) if dist is not None else table
+            if dist is not None and args.gather_wtns > 0:
+                k = min(args.gather_wtns, tile)
+                src = d_out[(nsub * tiles_per_sub - 1) % len(d_out)].view(tile, c.witness_bytes)[:k]
+                if backend != "nccl":
+                    src = src.cpu()
+                shard.gather_witnesses(dist, src, rank, world, sink=(lambda r, off, t: None))
 
     def barrier():
         torch.cuda.synchronize()
@@ -181,7 +190,7 @@ def main():
             "config": {"workload": f"EmailVerifier({args.max_header},{args.max_body},121,17,0,0,0,{args.remove_soft_line_breaks}) batch={args.batch}/GPU, "
                                    f"{args.body_len} B bodies, witnesses device-resident",
                        "batch_per_gpu": args.batch, "tile": tile, "witness_len": c.W,
-                       "witness_bytes": c.witness_bytes, "layout": "kept-v1", "parallelism": f"shard x{world}, result-table gather only"},
+                       "witness_bytes": c.witness_bytes, "layout": "kept-v1", "parallelism": f"shard x{world}, result-table gather" + (f" + {args.gather_wtns} wtns/rank/step gathered" if args.gather_wtns and world > 1 else " only")},
             "roofline": {"bound": "hbm", "kernel": "zk_expand", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": bytes_per_email * tile, "avg_launch_ms": round(ex_ms / ex_launches, 4),

@@ -30,8 +30,20 @@ def _worker(rank, world, port, n_total, q):
         rows[k, 32:128] = torch.tensor([(i * 7 + j) % 251 for j in range(96)], dtype=torch.uint8)
     table = shard.result_table(status, rows)
     full = shard.gather_table(dist, table, n_total, rank, world)
+    # bulk witness gather in chunks (3 fake witnesses of 1000 bytes per rank, 256-byte chunks)
+    wt = torch.tensor([[(rank * 31 + k * 7 + j) % 253 for j in range(1000)] for k in range(3)], dtype=torch.uint8)
+    allw = shard.gather_witnesses(dist, wt, rank, world, chunk_bytes=256)
+    got = []
+    shard.gather_witnesses(dist, wt, rank, world, chunk_bytes=512, sink=lambda r, off, t: got.append((r, off, t.clone())))
     if rank == 0:
+        assert allw.shape == (world, 3000)
+        for r in range(world):
+            assert allw[r].tolist() == [(r * 31 + k * 7 + j) % 253 for k in range(3) for j in range(1000)]
+        assert sorted((r, off) for r, off, _ in got) == [(r, off) for r in range(world) for off in range(0, 3000, 512)]
+        assert all(t.tolist() == allw[r, off:off + 512].tolist() for r, off, t in got)
         q.put(full.numpy().tobytes())
+    else:
+        assert allw is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -40,3 +40,36 @@ def gather_table(dist, local_table, n_total, rank, world):
     if rank != 0:
         return None
     return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
+
+
+def gather_witnesses(dist, local_wtns, rank, world, chunk_bytes=1 << 30, sink=None):
+    """Optional bulk exchange (BASELINE.json config C4): gather `local_wtns`
+    (uint8[k, witness_bytes], the same k on every rank) on rank 0 over RCCL/xGMI (gloo in the CPU tests), in
+    fixed chunks of at most `chunk_bytes` per rank so that the root needs only world x chunk of receive space.
+    `sink(src_rank, byte_offset, chunk_tensor)` is called on rank 0 for every received chunk (e.g. an async
+    D2H copy); without a sink rank 0 returns uint8[world, k * witness_bytes], other ranks None.
+    The production path keeps witnesses on the GPU that made them (one PCIe link per GPU beats the root's
+    single link); this exists to measure and to serve callers that want one buffer."""
+    flat = local_wtns.reshape(-1)
+    total = flat.numel()
+    if world == 1:
+        if sink is not None:
+            sink(0, 0, flat)
+            return None
+        return flat.view(1, total)
+    out = None
+    if rank == 0 and sink is None:
+        out = torch.empty((world, total), dtype=torch.uint8, device=flat.device)
+    ring = [torch.empty(min(chunk_bytes, total), dtype=torch.uint8, device=flat.device) for _ in range(world)] if rank == 0 else None
+    for off in range(0, total, chunk_bytes):
+        n = min(chunk_bytes, total - off)
+        piece = flat[off:off + n].contiguous()
+        bufs = [b[:n] for b in ring] if rank == 0 else None
+        dist.gather(piece, bufs, dst=0)
+        if rank == 0:
+            for r in range(world):
+                if sink is not None:
+                    sink(r, off, bufs[r])
+                else:
+                    out[r, off:off + n] = bufs[r]
+    return out
