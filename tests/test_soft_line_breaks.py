@@ -78,3 +78,85 @@ def test_soft_line_breaks_on_gpu_bit_exact():
     assert b"".join(v.to_bytes(32, "little") for v in w) == owit[0]
     with pytest.raises(zkwg.ZkwgError, match="Assert Failed"):
         wc.calculateWitness(bad)
+
+
+@pytest.mark.gpu
+def test_soft_line_break_edge_patterns_on_gpu():
+    """Signed emails whose bodies put "=\\r\\n" where the circuit's index arithmetic has its corners
+    (helpers/remove-soft-line-breaks.circom:47-91 and the reference's own cases in remove-soft-line-breaks.test.ts:
+    at the beginning, at the end, consecutive, incomplete sequences), every slot against the C oracle."""
+    import zkwg
+    from zkwg import synth, inputs as gen
+    from oracle import coracle
+    bodies = [
+        b"=\r\nhello\r\n",                                  # soft break at the very beginning
+        b"hello=\r\n",                                       # ... at the very end (next byte is the 0x80 pad)
+        b"ab=\r\n=\r\n=\r\ncd\r\n",                          # consecutive
+        b"a==\r\nb=\rx=\ny\r=\n=\r\r\n=\r\n\r\n",            # incomplete sequences around real ones
+        b"=" * 40 + b"\r\n" + b"x=\r" * 10 + b"\n\r\n",         # runs of '=' and "=\r"
+        (b"0123456789" * 7 + b"=\r\n") * 4 + b"end\r\n",       # QP-style long lines
+        b"no soft breaks at all\r\n",
+    ]
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, remove_soft_line_breaks=1)
+    inps = []
+    for i, b in enumerate(bodies):
+        d = synth.synthetic_dkim_result(21, i, body=b)
+        inps.append(gen.generate_email_verifier_inputs_from_dkim_result(d, N, M, remove_soft_line_breaks_flag=True))
+    # the reference helper must produce the compaction the circuit accepts
+    recs = b"".join(c.pack(i) for i in inps)
+    wit, status = c.calculate_batch_host(recs)
+    owit, ostatus, W = coracle.calculate(0, N, M, 0, inps, threads=4)
+    assert status == ostatus == [0] * len(bodies)
+    wb = c.witness_bytes
+    for i in range(len(bodies)):
+        assert wit[i * wb:(i + 1) * wb] == owit[i], f"body {i}"
+    # decoded shifted by one byte / a soft break left in place: rejected by both
+    bad = []
+    for i in (0, 2, 5):
+        b2 = dict(inps[i])
+        dec = list(b2["decodedEmailBodyIn"])
+        b2["decodedEmailBodyIn"] = ["0"] + dec[:-1]
+        bad.append(b2)
+        b3 = dict(inps[i])
+        b3["decodedEmailBodyIn"] = list(b3["emailBody"])
+        bad.append(b3)
+    _, st = c.calculate_batch_host(b"".join(c.pack(i) for i in bad), want_witness=False)
+    assert st == coracle.calculate(0, N, M, 0, bad, threads=4, want_witness=False)[1] == [4] * len(bad)
+
+
+def test_all_flags_together_layout_and_oracle_tiers():
+    # enableHeaderMasking + enableBodyMasking + removeSoftLineBreaks in one circuit: input / component order
+    import zkwg
+    from oracle import coracle
+    from oracle.pyref import zkemail as zk, comp
+    inp = dict(_inputs(3, 200))
+    inp["headerMask"] = [1 if 10 < i < 90 else 0 for i in range(N)]
+    inp["bodyMask"] = [i % 2 for i in range(M)]
+    main = zk.EmailVerifier(N, M, 121, 17, 0, inp, body_hash_regex=lambda m: zk.BodyHashRegexV1(N, m),
+                            enableHeaderMasking=1, enableBodyMasking=1, removeSoftLineBreaks=1)
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=-1, enable_header_masking=1,
+                     enable_body_masking=1, remove_soft_line_breaks=1)
+    assert c.symbols() == comp.symbols_kept(main)
+    assert len(c.pack(inp)) == c.in_stride
+    wits, status, W = coracle.calculate(0, N, M, 0, [inp])
+    assert status == [0] and W == c.W
+    assert wits[0] == b"".join(v.to_bytes(32, "little") for v in comp.witness_kept(main))
+
+
+@pytest.mark.gpu
+def test_all_flags_together_on_gpu():
+    import zkwg
+    from oracle import coracle
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, enable_header_masking=1,
+                     enable_body_masking=1, remove_soft_line_breaks=1)
+    inps = []
+    for i in range(3):
+        inp = dict(_inputs(5 + i, 180 + 30 * i))
+        inp["headerMask"] = [1 if (i + 3) * 7 < k < 200 else 0 for k in range(N)]
+        inp["bodyMask"] = [(k + i) % 2 for k in range(M)]
+        inps.append(inp)
+    wit, status = c.calculate_batch_host(b"".join(c.pack(i) for i in inps))
+    owit, ostatus, W = coracle.calculate(0, N, M, 0, inps, threads=3)
+    assert W == c.W and status == ostatus == [0, 0, 0]
+    wb = c.witness_bytes
+    assert [wit[i * wb:(i + 1) * wb] == owit[i] for i in range(3)] == [True] * 3

@@ -1,6 +1,7 @@
 // C-ABI of the `.r1cs` loader / device constraint check (include/zkwg.h, zkwg_r1cs_*).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <string>
 #include "../../include/zkwg.h"
 #include "zkwg_kernels.h"
@@ -60,12 +61,15 @@ int zkwg_check_constraints_device(zkwg_r1cs_t* r, const void* d_witness, uint64_
   if (!r || !d_witness || !d_first_bad) return ZKWG_RC_BAD_ARG;
   if (r->device < 0) return ZKWG_RC_NO_DEVICE;
   if (n == 0) return ZKWG_RC_OK;
-  if (stride < 32ull * r->h.n_wires || (stride & 15) || n > 65535) return ZKWG_RC_BAD_ARG;
+  if (stride < 32ull * r->h.n_wires || (stride & 15)) return ZKWG_RC_BAD_ARG;
   hipStream_t st = (hipStream_t)hip_stream;
   if (hipMemsetAsync(d_first_bad, 0xff, n * 8, st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   const u32 m = r->h.n_constraints;
-  if (m) hipLaunchKernelGGL(zk_r1cs_check, dim3((m + 255) / 256, (u32)n), dim3(256), 0, st, r->d_row, r->d_wire, r->d_coef,
-                            r->d_kind, m, (const u8*)d_witness, stride, (unsigned long long*)d_first_bad);
+  for (u64 lo = 0; m && lo < n; lo += 32768) {   // grid.y is limited to 65535
+    const u32 cnt = (u32)std::min<u64>(32768, n - lo);
+    hipLaunchKernelGGL(zk_r1cs_check, dim3((m + 255) / 256, cnt), dim3(256), 0, st, r->d_row, r->d_wire, r->d_coef,
+                       r->d_kind, m, (const u8*)d_witness + lo * stride, stride, (unsigned long long*)d_first_bad + lo);
+  }
   return hipGetLastError() == hipSuccess ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
 }
 

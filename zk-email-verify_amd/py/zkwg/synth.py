@@ -60,11 +60,13 @@ def synthetic_body(rng, length, soft_breaks=False):
     return bytes(out[:length - 2]) + b"\r\n" if len(out) >= length else bytes(out)
 
 
-def synthetic_dkim_result(seed, index, body_len=1024, soft_breaks=False):
-    """dict(headers, body, bodyHash, publicKey, signature) as `verifyDKIMSignature` would return."""
+def synthetic_dkim_result(seed, index, body_len=1024, soft_breaks=False, body=None):
+    """dict(headers, body, bodyHash, publicKey, signature) as `verifyDKIMSignature` would return.
+    `body`: use these canonical body bytes instead of a generated body."""
     rng = random.Random((seed << 20) ^ index)
     key = test_key()
-    body = synthetic_body(rng, body_len, soft_breaks)
+    if body is None:
+        body = synthetic_body(rng, body_len, soft_breaks)
     bh = base64.b64encode(hashlib.sha256(body).digest()).decode()
     mid = "%016x" % rng.getrandbits(64)
     subj = "".join(chr(rng.randrange(0x61, 0x7B)) for _ in range(rng.randrange(8, 24)))
