@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--rsa-throttle", type=int, default=3, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap)")
     ap.add_argument("--remove-soft-line-breaks", type=int, default=0,
                     help="template flag removeSoftLineBreaks (flag-variant measurement; the headline config keeps 0)")
+    ap.add_argument("--ring", type=int, default=2, help="image buffers in flight (prepare runs this many sub-batches ahead)")
     ap.add_argument("--gather-wtns", type=int, default=0,
                     help="also gather this many full witnesses per rank and step on rank 0 over RCCL (N>1 only; "
                          "inside the timed region; default 0 = result table only, see DESIGN.md section 7)")
@@ -98,11 +99,12 @@ def main():
     assert args.batch % prep == 0 and prep % tile == 0
     nsub, tiles_per_sub = args.batch // prep, prep // tile
     d_status = torch.zeros(args.batch, dtype=torch.int32, device=dev)
-    d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(2)]
+    R = max(2, args.ring)
+    d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(R)]
     prio = int(os.environ.get('ZKWG_BENCH_EXP_PRIO', '-1'))
     s_prep, s_exp = torch.cuda.Stream(device=dev, priority=0), torch.cuda.Stream(device=dev, priority=prio)
-    ev_prep = [torch.cuda.Event() for _ in range(2)]
-    ev_exp = [torch.cuda.Event() for _ in range(2)]
+    ev_prep = [torch.cuda.Event() for _ in range(R)]
+    ev_exp = [torch.cuda.Event() for _ in range(R)]
     state = {"j": 0, "table": None}
     # per-email result rows (w[0..3] = 1, pubkeyHash, shaHi, shaLo) saved before the ring slot is reused
     from zkwg import shard
@@ -111,9 +113,9 @@ def main():
     def step():
         for sb in range(nsub):
             j = state["j"]
-            b = j % 2
+            b = j % R
             lo = sb * prep
-            if j >= 2:
+            if j >= R:
                 s_prep.wait_event(ev_exp[b])      # image buffer b is free again
             # the very first prepare has nothing to overlap with: run it at full occupancy; later ones share
             # the chip with the previous sub-batch's zk_expand and are throttled so expand keeps its wave slots

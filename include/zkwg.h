@@ -200,7 +200,11 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_packed_inputs, 
  *   zkwg_expand_device   streams the witnesses of emails [first, first+count) of that prepared
  *                        batch into d_out_wtns (count * 32 W bytes) -- the HBM-write-bound kernel.
  * The images are ~1 % of the witness size, so a whole batch can be prepared at once while its
- * witnesses are expanded tile by tile into a smaller output ring. */
+ * witnesses are expanded tile by tile into a smaller output ring.
+ * remove_soft_line_breaks = 1: the serial Poseidon merge chain of a prepared batch runs on an internal
+ * side stream (it is latency-bound and would stall the caller's stream for ~0.2 s); d_status and the
+ * scratch images are complete once a zkwg_expand_device call on that scratch buffer has been ordered
+ * (it waits for the chain), so keep at most 16 scratch buffers in flight per handle. */
 int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails, void* d_status,
                         void* d_scratch, void* hip_stream);
 int zkwg_expand_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails, const void* d_scratch,

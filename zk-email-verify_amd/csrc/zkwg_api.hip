@@ -15,6 +15,7 @@
 #include "zkwg_poseidon_sparse.h"
 
 #define ZK_MAX_KERNELS 8
+#define ZK_RS_SLOTS 16
 #define ZK_EV_RING 64
 
 struct zkwg_circuit {
@@ -31,6 +32,13 @@ struct zkwg_circuit {
   std::vector<ZkSeg> segs;
   std::vector<u32> first_seg;
   hipStream_t own_stream, copy_stream;
+  // removeSoftLineBreaks: the serial merge chain (zk_rslb_chain, ~16 waves per 1024 emails, latency-bound)
+  // runs on a side stream so that the caller's stream can go on with the next batch; zkwg_expand_device
+  // waits for the chain of the scratch buffer it reads.
+  hipStream_t side_stream[ZK_RS_SLOTS];   // one per scratch buffer in flight: chains of different batches overlap
+  hipEvent_t rs_dep[ZK_RS_SLOTS], rs_done[ZK_RS_SLOTS];
+  const void* rs_scr[ZK_RS_SLOTS];
+  int rs_next, rs_sync;
   // host-buffer path: cached device staging buffers (double-buffered witnesses)
   std::mutex hb_mutex;
   u8 *hb_in, *hb_out[2], *hb_scr;
@@ -187,6 +195,16 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     }
     hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (c->s.rslb) {
+      for (int i = 0; i < ZK_RS_SLOTS; ++i) {
+        hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
+        hipEventCreateWithFlags(&c->rs_dep[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&c->rs_done[i], hipEventDisableTiming);
+        c->rs_scr[i] = nullptr;
+      }
+      c->rs_next = 0;
+      c->rs_sync = getenv("ZKWG_RSLB_SYNC") ? atoi(getenv("ZKWG_RSLB_SYNC")) : 0;
+    }
     for (int i = 0; i < 2; ++i) { hipEventCreateWithFlags(&c->hb_done[i], hipEventDisableTiming); hipEventCreateWithFlags(&c->hb_copied[i], hipEventDisableTiming); }
     for (int r = 0; r < ZK_EV_RING; ++r) {
       for (int i = 0; i < 2; ++i) hipEventCreate(&c->ev[r][i]);
@@ -216,6 +234,13 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); }
     hipStreamDestroy(c->copy_stream);
     hipStreamDestroy(c->own_stream);
+    if (c->s.rslb) {
+      for (int i = 0; i < ZK_RS_SLOTS; ++i) {
+        hipStreamSynchronize(c->side_stream[i]);
+        hipEventDestroy(c->rs_dep[i]); hipEventDestroy(c->rs_done[i]);
+        hipStreamDestroy(c->side_stream[i]);
+      }
+    }
     for (int r = 0; r < ZK_EV_RING; ++r) {
       for (int i = 0; i < 2; ++i) hipEventDestroy(c->ev[r][i]);
       for (int i = 0; i <= ZK_MAX_KERNELS; ++i) hipEventDestroy(c->pev[r][i]);
@@ -394,7 +419,21 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     const u64 units = (u64)ne * s.rs_nch;
     hipLaunchKernelGGL(zk_rslb_chunks, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
     if (tm) hipEventRecord(evs[++ki], st);
-    hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
+    if (c->rs_sync) {
+      hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
+    } else {
+      int slot = -1;
+      for (int i = 0; i < ZK_RS_SLOTS; ++i) if (c->rs_scr[i] == d_scratch) slot = i;
+      if (slot < 0) { slot = c->rs_next; c->rs_next = (c->rs_next + 1) % ZK_RS_SLOTS; c->rs_scr[slot] = d_scratch; }
+      hipEventRecord(c->rs_dep[slot], st);
+      hipStream_t ss = c->side_stream[slot];
+      hipStreamWaitEvent(ss, c->rs_dep[slot], 0);
+      hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B);
+      hipEventRecord(c->rs_done[slot], ss);
+      if (tm) { hipEventRecord(evs[++ki], ss); c->prep_valid = true; c->prep_launches++; }
+      if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
+      return ZKWG_RC_OK;
+    }
   }
   if (tm) { hipEventRecord(evs[++ki], st); c->prep_valid = true; c->prep_launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
@@ -415,6 +454,9 @@ int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   B.wit = (uint4*)d_out;
   B.e_first = (u32)first;
   B.n_emails = (u32)(first + count);
+  if (s.rslb && !c->rs_sync)   // the merge chain of this scratch buffer may still be running on the side stream
+    for (int i = 0; i < ZK_RS_SLOTS; ++i)
+      if (c->rs_scr[i] == d_scratch) hipStreamWaitEvent(st, c->rs_done[i], 0);
   const bool tm = c->timing != 0;
   hipEvent_t* evs = c->ev[c->launches % ZK_EV_RING];
   if (tm) hipEventRecord(evs[0], st);
