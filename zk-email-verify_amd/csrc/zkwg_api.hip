@@ -426,7 +426,9 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       for (int i = 0; i < ZK_RS_SLOTS; ++i) if (c->rs_scr[i] == d_scratch) slot = i;
       if (slot < 0) { slot = c->rs_next; c->rs_next = (c->rs_next + 1) % ZK_RS_SLOTS; c->rs_scr[slot] = d_scratch; }
       hipEventRecord(c->rs_dep[slot], st);
-      hipStream_t ss = c->side_stream[slot];
+      // two side streams are enough (a chain outlasts ~1.5 chunk kernels) and keep the process within the
+      // default number of hardware queues; more streams would share queues with the caller's streams
+      hipStream_t ss = c->side_stream[slot & 1];
       hipStreamWaitEvent(ss, c->rs_dep[slot], 0);
       hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B);
       hipEventRecord(c->rs_done[slot], ss);
