@@ -57,3 +57,28 @@ def test_body_hash_index_points_at_the_bh_value():
     i = int(inp["bodyHashIndex"])
     hdr = bytes(int(b) for b in inp["emailHeader"])
     assert hdr[i:i + 44].decode() == d["bodyHash"] and hdr[i - 3:i] == b"bh="
+
+
+def test_input_generators_test_ts_precompute_selector_on_email_good_large():
+    # packages/helpers/tests/input-generators.test.ts:39-53: selector 'thousands' on email-good-large.eml ->
+    # emailBody starts at the previous 64-byte boundary: 'h hundreds of thousands of blocks.'
+    # (fixture: canonical body extracted by tests/golden/make_email_good_large_fixture.py, pinned by its bh=)
+    import base64
+    import hashlib
+    import json
+    import os
+    from conftest import ROOT
+    from zkwg import inputs
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "email_good_large.json")))
+    body = bytes.fromhex(fx["canonical_body_hex"])
+    assert fx["body_hash_matches_bh"] and base64.b64encode(hashlib.sha256(body).digest()).decode() == fx["bh"]
+    d = {"headers": b"x: bh=" + fx["bh"].encode(), "body": body, "bodyHash": fx["bh"], "publicKey": 1, "signature": 1}
+    inp = inputs.generate_email_verifier_inputs_from_dkim_result(d, 1024, 1536, sha_precompute_selector=fx["selector"])
+    got = bytes(int(b) for b in inp["emailBody"])
+    assert got.startswith(fx["expected_body_prefix"].encode())
+    # the midstate really is the SHA-256 state of the cut-off prefix: finishing the hash from it gives bh
+    cut = body.find(got[:len(fx["expected_body_prefix"])])
+    assert cut > 0 and cut % 64 == 0
+    assert inputs.partial_sha(body[:cut]) == bytes(int(b) for b in inp["precomputedSHA"])
+    with pytest.raises(ValueError, match='SHA precompute selector "Bla Bla" not found in cleaned body'):
+        inputs.generate_email_verifier_inputs_from_dkim_result(d, 1024, 1536, sha_precompute_selector="Bla Bla")

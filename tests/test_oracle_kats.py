@@ -159,3 +159,11 @@ def test_poseidon16_known_vector_and_modular_chain():
         h = poseidon.poseidon_hash(xs[i:i + 16])
         out = h if out is None else poseidon.poseidon_hash([out, h])
     assert zk.PoseidonModular(37, xs).o == out
+
+
+def test_byte_mask_test_ts():
+    # packages/circuits/tests/byte-mask.test.ts:19-47 (ByteMask(10)); a non-bit mask value must be rejected
+    c = zk.ByteMask(10, list(range(1, 11)), [1, 0] * 5)
+    assert c.o == [1, 0, 3, 0, 5, 0, 7, 0, 9, 0]
+    with pytest.raises(comp.AssertFailed):
+        zk.ByteMask(10, list(range(1, 11)), [1, 2, 1, 0, 1, 0, 1, 0, 1, 0])
