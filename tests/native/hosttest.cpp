@@ -71,8 +71,9 @@ int ht_poseidon_sparse(uint32_t t, const void* inputs, void* emit, void* hash) {
   std::vector<Fr> st(t, fr_zero());
   memcpy(&st[1], inputs, (t - 1) * sizeof(Fr));
   Fr h;
-  if (t == 3) h = zk_poseidon_sparse<3>(st.data(), 1, tab.data(), rp, (Fr*)emit);
-  else if (t == 17) h = zk_poseidon_sparse<17>(st.data(), 1, tab.data(), rp, (Fr*)emit);
+  Fr tmp[17];
+  if (t == 3) h = zk_poseidon_sparse<3>(st.data(), 1, tab.data(), rp, (Fr*)emit, tmp, 1);
+  else if (t == 17) h = zk_poseidon_sparse<17>(st.data(), 1, tab.data(), rp, (Fr*)emit, tmp, 1);
   else return 2;
   *(Fr*)hash = h;
   return 0;

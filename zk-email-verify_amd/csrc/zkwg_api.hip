@@ -38,7 +38,7 @@ struct zkwg_circuit {
   hipStream_t side_stream[ZK_RS_SLOTS];   // one per scratch buffer in flight: chains of different batches overlap
   hipEvent_t rs_dep[ZK_RS_SLOTS], rs_done[ZK_RS_SLOTS];
   const void* rs_scr[ZK_RS_SLOTS];
-  int rs_next, rs_sync;
+  int rs_next, rs_sync, rs_nside;
   // host-buffer path: cached device staging buffers (double-buffered witnesses)
   std::mutex hb_mutex;
   u8 *hb_in, *hb_out[2], *hb_scr;
@@ -196,14 +196,21 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (c->s.rslb) {
+      // lowest priority: ROCm keeps separate hardware-queue pools per stream priority, so the side streams
+      // never share a queue with the caller's (normal / high priority) prepare and expand streams -- a shared
+      // queue would put the next batch's kernels behind a 0.2 s chain.  The chain has 1 wave per 64 emails;
+      // dispatch priority does not slow it down once resident.
+      int prio_lo = 0, prio_hi = 0;
+      hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
       for (int i = 0; i < ZK_RS_SLOTS; ++i) {
-        hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
+        hipStreamCreateWithPriority(&c->side_stream[i], hipStreamNonBlocking, prio_lo);
         hipEventCreateWithFlags(&c->rs_dep[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->rs_done[i], hipEventDisableTiming);
         c->rs_scr[i] = nullptr;
       }
       c->rs_next = 0;
       c->rs_sync = getenv("ZKWG_RSLB_SYNC") ? atoi(getenv("ZKWG_RSLB_SYNC")) : 0;
+      c->rs_nside = getenv("ZKWG_RSLB_SIDE_STREAMS") ? std::min(ZK_RS_SLOTS, std::max(1, atoi(getenv("ZKWG_RSLB_SIDE_STREAMS")))) : 2;
     }
     for (int i = 0; i < 2; ++i) { hipEventCreateWithFlags(&c->hb_done[i], hipEventDisableTiming); hipEventCreateWithFlags(&c->hb_copied[i], hipEventDisableTiming); }
     for (int r = 0; r < ZK_EV_RING; ++r) {
@@ -426,9 +433,10 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       for (int i = 0; i < ZK_RS_SLOTS; ++i) if (c->rs_scr[i] == d_scratch) slot = i;
       if (slot < 0) { slot = c->rs_next; c->rs_next = (c->rs_next + 1) % ZK_RS_SLOTS; c->rs_scr[slot] = d_scratch; }
       hipEventRecord(c->rs_dep[slot], st);
-      // two side streams are enough (a chain outlasts ~1.5 chunk kernels) and keep the process within the
-      // default number of hardware queues; more streams would share queues with the caller's streams
-      hipStream_t ss = c->side_stream[slot & 1];
+      // two side streams by default: with the caller's prepare and expand streams that is the default number
+      // of hardware queues (GPU_MAX_HW_QUEUES = 4); streams beyond that share queues and serialise.
+      // ZKWG_RSLB_SIDE_STREAMS raises it (together with GPU_MAX_HW_QUEUES).
+      hipStream_t ss = c->side_stream[slot % c->rs_nside];
       hipStreamWaitEvent(ss, c->rs_dep[slot], 0);
       hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B);
       hipEventRecord(c->rs_done[slot], ss);

@@ -191,6 +191,88 @@ ZK_HD Fr fr_mont_mul(const Fr& a, const Fr& b) {
   return r;
 #endif
 }
+// ---- lazy reduction: sum_j a_j * b_j accumulated unreduced, one Montgomery reduction at the end ----
+// Up to 17 products of values < r fit 17 x 32-bit limbs (17 r^2 < 2^513).  A dot product of n terms then
+// costs n x 64 + 64 multiplier issues instead of n x 128 (dense Poseidon rounds, zkwg_poseidon_sparse.h).
+struct FrWide {
+  u32 l[17];
+};
+ZK_HD void fr_wide_zero(FrWide& w) {
+#pragma unroll
+  for (int i = 0; i < 17; ++i) w.l[i] = 0;
+}
+// w += a * b  (a, b < 2^256; the caller keeps the running sum below 2^544)
+ZK_HD void fr_wide_mac(FrWide& w, const Fr& a, const Fr& b) {
+  u32 A[8], Bv[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    A[2 * i] = (u32)a.l[i]; A[2 * i + 1] = (u32)(a.l[i] >> 32);
+    Bv[2 * i] = (u32)b.l[i]; Bv[2 * i + 1] = (u32)(b.l[i] >> 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      c = (u64)A[k] * Bv[i] + w.l[i + k] + c;
+      w.l[i + k] = (u32)c;
+      c >>= 32;
+    }
+#pragma unroll
+    for (int k = i + 8; k < 17; ++k) {
+      c += w.l[k];
+      w.l[k] = (u32)c;
+      c >>= 32;
+    }
+  }
+}
+// w * 2^-256 mod r for w < 17 r^2 (result < 4.3 r before the final subtractions)
+ZK_HD Fr fr_wide_redc(FrWide& w) {
+  const u32 P32[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  const u32 N0_32 = 0xefffffffu;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u32 m = w.l[i] * N0_32;
+    u64 c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      c = (u64)m * P32[k] + w.l[i + k] + c;
+      w.l[i + k] = (u32)c;
+      c >>= 32;
+    }
+#pragma unroll
+    for (int k = i + 8; k < 17; ++k) {
+      c += w.l[k];
+      w.l[k] = (u32)c;
+      c >>= 32;
+    }
+  }
+  // value = l[8..16] (9 limbs), < 4.3 r: subtract 4r, 2r, r where possible
+  u32 v[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v[i] = w.l[8 + i];
+#pragma unroll
+  for (int sh = 2; sh >= 0; --sh) {
+    u32 d[9];
+    u64 bw = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      // limb i of (r << sh)
+      const u32 lo = i < 8 ? P32[i] : 0u, below = i > 0 ? P32[i - 1] : 0u;
+      const u32 pl = sh ? (u32)((lo << sh) | (below >> (32 - sh))) : lo;
+      const u64 t = (u64)v[i] - pl - bw;
+      d[i] = (u32)t;
+      bw = (t >> 32) & 1u;
+    }
+    if (!bw) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] = d[i];
+    }
+  }
+  return Fr{{(u64)v[0] | ((u64)v[1] << 32), (u64)v[2] | ((u64)v[3] << 32), (u64)v[4] | ((u64)v[5] << 32),
+             (u64)v[6] | ((u64)v[7] << 32)}};
+}
+
 ZK_HD Fr fr_to_mont(const Fr& a) { return fr_mont_mul(a, fr_R2()); }
 ZK_HD Fr fr_from_mont(const Fr& a) { return fr_mont_mul(a, fr_from_u64(1)); }
 

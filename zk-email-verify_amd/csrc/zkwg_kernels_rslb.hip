@@ -27,7 +27,8 @@ __global__ __launch_bounds__(64) void zk_rslb_chunks(ZkSched s, ZkBufs B) {
 #pragma unroll
   for (u32 i = 0; i < 16; ++i) stl[(1 + i) * 64] = fr_from_u64((w[i >> 2] >> (8 * (i & 3))) & 255u);
   Fr* frv = B.frv + (u64)e * s.img_fr;
-  const Fr h = zk_poseidon_sparse<17>(stl, 64, B.pos16, 68, frv + s.f_rs_hash + zk_rs_chunk_off(c));
+  Fr tmp[17];
+  const Fr h = zk_poseidon_sparse<17>(stl, 64, B.pos16, 68, frv + s.f_rs_hash + zk_rs_chunk_off(c), tmp, 1);
   frv[s.f_rs_chunk + c] = h;
 }
 
@@ -41,9 +42,10 @@ __global__ __launch_bounds__(64) void zk_rslb_chain(ZkSched s, ZkBufs B) {
   Fr* stl = st + lane;
   // _out = Poseidon(2)([_out, chunk_hash]) (utils/hash.circom:76-80)
   Fr out = frv[s.f_rs_chunk];
+  Fr tmp[3];
   for (u32 c = 1; c < s.rs_nch; ++c) {
     stl[0] = fr_zero(); stl[64] = out; stl[128] = frv[s.f_rs_chunk + c];
-    out = zk_poseidon_sparse<3>(stl, 64, B.pos2, 57, frv + s.f_rs_hash + zk_rs_chunk_off(c) + ZK_P16_KEPT);
+    out = zk_poseidon_sparse<3>(stl, 64, B.pos2, 57, frv + s.f_rs_hash + zk_rs_chunk_off(c) + ZK_P16_KEPT, tmp, 1);
   }
   const Fr r = out;
   const Fr rm = fr_to_mont(r);

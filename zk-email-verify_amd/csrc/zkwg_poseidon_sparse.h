@@ -36,57 +36,56 @@ ZK_HD Fr zk_sbox5(const Fr& x, Fr* emit) {
 }
 
 // One permutation.  `st`: T state elements with stride `ss` (standard form, element 0 = capacity);
-// `emit`: 3 * (8T + rp) Fr, Sigma signals in component order (sigmaF[8][T], sigmaP[rp]).
-// Returns out[0].
+// `emit`: 3 * (8T + rp) Fr, Sigma signals in component order (sigmaF[8][T], sigmaP[rp]);
+// `tmp`: T Fr of scratch with stride `ts`.  Returns out[0].
+// st[i] = sum_j y_j * mat[j*T + i] for all i, y = the current st (dense product, lazily reduced); `tmp` = T Fr of
+// per-lane scratch with stride `ts`
 template <int T>
-ZK_HD Fr zk_poseidon_sparse(Fr* st, const u32 ss, const Fr* __restrict__ tab, const u32 rp, Fr* emit) {
+ZK_HD void zk_pos_dense(Fr* st, const u32 ss, const Fr* __restrict__ mat, Fr* tmp, const u32 ts) {
+  for (u32 i = 0; i < (u32)T; ++i) {
+    FrWide w;
+    fr_wide_zero(w);
+    for (u32 j = 0; j < (u32)T; ++j) fr_wide_mac(w, st[j * ss], mat[j * T + i]);
+    tmp[i * ts] = fr_wide_redc(w);
+  }
+  for (u32 i = 0; i < (u32)T; ++i) st[i * ss] = tmp[i * ts];
+}
+
+template <int T>
+ZK_HD Fr zk_poseidon_sparse(Fr* st, const u32 ss, const Fr* __restrict__ tab, const u32 rp, Fr* emit, Fr* tmp, const u32 ts) {
   const Fr* c_first = tab;
   const Fr* mt = c_first + 4 * T;
   const Fr* c_part = mt + T * T;
   const Fr* s_part = c_part + rp * T;
   const Fr* bt = s_part + rp * (2 * T - 1);
   const Fr* c_last = bt + T * T;
-  Fr acc[T];
-  // full rounds (ark + S-box + mix fused over the source element j)
   for (u32 half = 0; half < 2; ++half) {
     if (half == 1) {
-      // partial rounds on u (u_0 lives in a register)
+      // partial rounds on u (u_0 lives in a register); the first-row dot product is reduced once
       Fr u0 = st[0];
       for (u32 k = 0; k < rp; ++k) {
         const Fr* ck = c_part + k * T;
         const Fr* sk = s_part + k * (2 * T - 1);
         const Fr y0 = zk_sbox5(fr_add(u0, ck[0]), emit + 3 * (8 * T + k));
-        Fr n0 = fr_mont_mul(y0, sk[0]);
+        FrWide w;
+        fr_wide_zero(w);
+        fr_wide_mac(w, y0, sk[0]);
         for (u32 j = 1; j < (u32)T; ++j) {
           const Fr uj = fr_add(st[j * ss], ck[j]);
-          n0 = fr_add(n0, fr_mont_mul(uj, sk[j]));
+          fr_wide_mac(w, uj, sk[j]);
           st[j * ss] = fr_add(uj, fr_mont_mul(y0, sk[T - 1 + j]));
         }
-        u0 = n0;
+        u0 = fr_wide_redc(w);
       }
       st[0] = u0;
-      // z = B u
-#pragma unroll
-      for (int i = 0; i < T; ++i) acc[i] = fr_zero();
-      for (u32 j = 0; j < (u32)T; ++j) {
-        const Fr y = st[j * ss];
-#pragma unroll
-        for (int i = 0; i < T; ++i) acc[i] = fr_add(acc[i], fr_mont_mul(y, bt[j * T + i]));
-      }
-#pragma unroll
-      for (int i = 0; i < T; ++i) st[i * ss] = acc[i];
+      zk_pos_dense<T>(st, ss, bt, tmp, ts);   // z = B u
     }
+    // full rounds: ark + S-box in place, then the dense mix
     for (u32 r = 0; r < 4; ++r) {
       const Fr* c = (half ? c_last : c_first) + r * T;
-#pragma unroll
-      for (int i = 0; i < T; ++i) acc[i] = fr_zero();
-      for (u32 j = 0; j < (u32)T; ++j) {
-        const Fr y = zk_sbox5(fr_add(st[j * ss], c[j]), emit + 3 * ((half * 4 + r) * T + j));
-#pragma unroll
-        for (int i = 0; i < T; ++i) acc[i] = fr_add(acc[i], fr_mont_mul(y, mt[j * T + i]));
-      }
-#pragma unroll
-      for (int i = 0; i < T; ++i) st[i * ss] = acc[i];
+      for (u32 j = 0; j < (u32)T; ++j)
+        st[j * ss] = zk_sbox5(fr_add(st[j * ss], c[j]), emit + 3 * ((half * 4 + r) * T + j));
+      zk_pos_dense<T>(st, ss, mt, tmp, ts);
     }
   }
   return st[0];
