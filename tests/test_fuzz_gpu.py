@@ -64,3 +64,60 @@ def test_garbage_records_do_not_crash_and_status_matches_oracle():
     lib.zkwg_oracle_calculate(0, N, M, 0, n, col(0, N), u32s(6), col(1, M), u32s(7), col(2, 32), col(3, 272), col(4, 272), None,
                               u32s(8), None, 0, ost, 4)
     assert list(ost) == status[:n]
+
+
+@pytest.mark.timeout(600)
+def test_garbage_records_with_all_flags_status_matches_oracle():
+    """Same robustness bar for the flag variants (masks + removeSoftLineBreaks): random records, valid emails
+    with a corrupted decodedEmailBodyIn / mask / body byte -- accept / reject must equal the C oracle's."""
+    import zkwg
+    from zkwg import synth
+    from oracle import coracle
+    N, M = 576, 384
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, enable_header_masking=1,
+                     enable_body_masking=1, remove_soft_line_breaks=1)
+    off = [c.lib.zkwg_input_offset(c.h, f) for f in range(12)]
+    rng = random.Random(99)
+    good, fields = synth.packed_batch(c, seed=6, n=6, body_len=250)
+    good = bytearray(good)
+    for i in range(6):     # binary masks on the valid emails
+        base = i * c.in_stride
+        good[base + off[9]:base + off[9] + N] = bytes(rng.randrange(2) for _ in range(N))
+        good[base + off[10]:base + off[10] + M] = bytes(rng.randrange(2) for _ in range(M))
+    good = bytes(good)
+    recs = [bytes(rng.randrange(256) for _ in range(c.in_stride)) for _ in range(10)]
+    for k in range(30):
+        r = bytearray(good[(k % 6) * c.in_stride:(k % 6 + 1) * c.in_stride])
+        mode = k % 6
+        if mode == 0:
+            r[off[11] + rng.randrange(200)] ^= 1 + rng.randrange(255)          # decoded body differs
+        elif mode == 1:
+            r[off[11]:off[11] + M] = r[off[1]:off[1] + M]                      # soft breaks left in place
+        elif mode == 2:
+            r[off[10] + rng.randrange(M)] = 2 + rng.randrange(254)              # non-binary body mask
+        elif mode == 3:
+            r[off[9] + rng.randrange(N)] = 2 + rng.randrange(254)               # non-binary header mask
+        elif mode == 4:
+            p = rng.randrange(200)
+            r[off[1] + p:off[1] + p + 3] = b"=\r\n"                             # body changed (hash + decoded mismatch)
+        elif mode == 5:
+            r[off[11]:off[11] + M] = bytes(M)                                   # all-zero decoded body
+        recs.append(bytes(r))
+    n = len(recs)
+    wit, status = c.calculate_batch_host(b"".join(recs) + good, want_witness=False)
+    assert status[n:] == [0] * 6 and set(status) <= {0, 4}
+
+    def col(field, width):
+        return b"".join(r[off[field]:off[field] + width] for r in recs)
+    u32s = lambda f: (C.c_uint32 * n)(*[struct.unpack("<I", r[off[f]:off[f] + 4])[0] for r in recs])
+    lib = coracle.load()
+    ost = (C.c_int * n)()
+    hm, bm, dec = col(9, N), col(10, M), col(11, M)
+    lib.zkwg_oracle_set_masks(hm, bm)
+    lib.zkwg_oracle_set_decoded(dec)
+    lib.zkwg_oracle_calculate(0, N, M, 0, n, col(0, N), u32s(6), col(1, M), u32s(7), col(2, 32), col(3, 272), col(4, 272), None,
+                              u32s(8), None, 0, ost, 8)
+    lib.zkwg_oracle_set_masks(None, None)
+    lib.zkwg_oracle_set_decoded(None)
+    assert list(ost) == status[:n]
+    assert 4 in status[10:n]
