@@ -257,6 +257,13 @@ int zkwg_check_constraints_device(zkwg_r1cs_t* r, const void* d_witness, uint64_
 /* Same for witnesses in host memory (staged through the device in tiles). */
 int zkwg_check_constraints(zkwg_r1cs_t* r, const uint8_t* witness, uint64_t n, uint64_t stride, uint64_t* first_bad);
 
+/* ---- prover hand-off -------------------------------------------------------------
+ * The step after this path is `groth16.prove(zkey, wtns)` (second half of fullProve,
+ * packages/helpers/src/chunked-zkey.ts:80).  A device-resident prover takes the witness where
+ * zkwg_expand_device left it; this converts n_values 32-byte field elements in place between the
+ * `.wtns` standard form and Montgomery form (x * 2^256 mod r), whichever its NTT / MSM kernels want. */
+int zkwg_convert_montgomery_device(void* d_values, uint64_t n_values, int to_montgomery, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

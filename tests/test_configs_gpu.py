@@ -90,3 +90,27 @@ def test_config4_long_body_65536():
     W, st, buf = _oracle(N, M, fields, n, threads=3)
     assert W == c.W and st == [0] * n
     assert wit == bytes(buf)
+
+
+def test_prover_handoff_montgomery_round_trip():
+    # zkwg_convert_montgomery_device: x -> x * 2^256 mod r in place on a device witness, and back
+    import torch
+    import zkwg
+    from conftest import sha_pad
+    P = zkwg.FIELD_MODULUS if hasattr(zkwg, "FIELD_MODULUS") else 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    c = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=0)   # the Fr-richest small witness
+    from test_rsa_cpu import KAT_MSG, KAT_SIG, KAT_PUB, limbs
+    rec = c.pack({"message": KAT_MSG, "signature": limbs(KAT_SIG), "modulus": limbs(KAT_PUB)})
+    wit, status = c.calculate_batch_host(rec)
+    assert status == [0]
+    d = torch.frombuffer(bytearray(wit), dtype=torch.uint8).to("cuda:0")
+    zkwg.convert_montgomery_device(d, c.W, True)
+    torch.cuda.synchronize()
+    m = d.cpu().numpy().tobytes()
+    R = (1 << 256) % P
+    for i in list(range(0, 64)) + list(range(c.W - 3000, c.W)):
+        x = int.from_bytes(wit[32 * i:32 * i + 32], "little")
+        assert int.from_bytes(m[32 * i:32 * i + 32], "little") == x * R % P, i
+    zkwg.convert_montgomery_device(d, c.W, False)
+    torch.cuda.synchronize()
+    assert d.cpu().numpy().tobytes() == wit

@@ -94,4 +94,14 @@ int zkwg_check_constraints(zkwg_r1cs_t* r, const uint8_t* witness, uint64_t n, u
   return rc;
 }
 
+// ---- prover hand-off: standard <-> Montgomery form of device-resident field elements
+int zkwg_convert_montgomery_device(void* d_values, uint64_t n_values, int to_montgomery, void* hip_stream) {
+  if (!d_values || ((uintptr_t)d_values & 15)) return ZKWG_RC_BAD_ARG;
+  if (n_values == 0) return ZKWG_RC_OK;
+  if (n_values > 256ull * 0x7fffffffull) return ZKWG_RC_BAD_ARG;
+  hipLaunchKernelGGL(zk_mont_convert, dim3((u32)((n_values + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                     (Fr*)d_values, (u64)n_values, to_montgomery ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
+}
+
 }  // extern "C"

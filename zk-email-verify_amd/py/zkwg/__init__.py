@@ -230,6 +230,13 @@ class Circuit:
         return out
 
 
+def convert_montgomery_device(d_values, n_values, to_montgomery=True, stream=None):
+    """In-place standard <-> Montgomery form of n_values field elements in a torch CUDA uint8 tensor
+    (prover hand-off, zkwg_convert_montgomery_device)."""
+    sp = stream.cuda_stream if stream is not None else 0
+    _check(_lib.load().zkwg_convert_montgomery_device(d_values.data_ptr(), n_values, 1 if to_montgomery else 0, sp))
+
+
 class R1cs:
     """A compiled circuit's `.r1cs` constraint system, loaded for `checkConstraints` on the device
     (circom_tester `circuit.checkConstraints(witness)`, packages/circuits/tests/email-verifier.test.ts:44)."""
