@@ -394,6 +394,9 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
   fill_bufs(c, B, d_in, n, d_scratch);
   B.status = (int*)d_status;
   const bool tm = c->timing != 0;
+  if (s.rslb && !c->rs_sync)   // a merge chain of an earlier batch may still be reading this scratch buffer
+    for (int i = 0; i < ZK_RS_SLOTS; ++i)
+      if (c->rs_scr[i] == d_scratch) hipStreamWaitEvent(st, c->rs_done[i], 0);
   if (hipMemsetAsync(B.status, 0, n * sizeof(int), st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   int ki = 0;
   hipEvent_t* evs = c->pev[c->prep_launches % ZK_EV_RING];
