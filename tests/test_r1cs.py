@@ -178,3 +178,96 @@ def test_check_constraints_of_real_device_witnesses():
     w[bit_slots[k]] = 2
     with pytest.raises(zkwg.ZkwgError, match=f"constraint {k}\\)"):
         rb.checkConstraints(w)
+
+
+def test_sha256_r1cs_derivation_holds_for_the_oracle_witness():
+    # tests/sha_r1cs.py: constraints of every Sha256compression signal of Sha256Bytes(128), from the circomlib
+    # template definitions; the C oracle's witness satisfies all of them and every such wire is constrained
+    import zkwg
+    import sha_r1cs
+    from conftest import sha_pad
+    from oracle import coracle
+    c = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=128, max_body=0, device=-1)
+    cons = sha_r1cs.sha256_bytes_constraints(c.symbols(), 128)
+    used = set()
+    for a, b, cc in cons:
+        used |= set(a) | set(b) | set(cc)
+    assert all(s in used for s, n in c.symbols() if "sha256compression" in n or n.startswith("main.bytes"))
+    for msg in (b"", b"hello world", b"x" * 100):
+        p, n = sha_pad(msg, 128)
+        w, st, W = coracle.calculate(1, 128, 0, 0, [{"paddedIn": list(p), "paddedInLength": n}])
+        wi = [int.from_bytes(w[0][32 * i:32 * i + 32], "little") for i in range(W)]
+        assert st == [0] and ru.first_violation(cons, wi) is None
+    wi[30000] ^= 1
+    assert ru.first_violation(cons, wi) is not None
+
+
+@pytest.mark.gpu
+def test_check_constraints_sha256_circuit_on_device_witnesses():
+    """`checkConstraints` with the SHA-256 constraint system (63,680 constraints for Sha256Bytes(128), derived in
+    tests/sha_r1cs.py from the circomlib templates) on witnesses straight from the device kernels."""
+    import torch
+    import zkwg
+    import sha_r1cs
+    from conftest import sha_pad
+    c = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=128, max_body=0, device=0)
+    cons = sha_r1cs.sha256_bytes_constraints(c.symbols(), 128)
+    r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=256, n_pub_in=129), device=0)
+    assert r.n_constraints == len(cons) == 63680
+    msgs = [b"", b"abc", b"hello world", bytes(range(64)), b"q" * 119]
+    recs = b""
+    for m in msgs:
+        p, n = sha_pad(m, 128)
+        recs += c.pack({"paddedIn": list(p), "paddedInLength": n})
+    d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to("cuda:0")
+    d_out = torch.empty(len(msgs) * c.witness_bytes, dtype=torch.uint8, device="cuda:0")
+    d_status = torch.zeros(len(msgs), dtype=torch.int32, device="cuda:0")
+    d_scr = torch.empty(c.scratch_bytes(len(msgs)), dtype=torch.uint8, device="cuda:0")
+    c.calculate_batch_device(d_in, len(msgs), d_out, d_status, d_scr)
+    torch.cuda.synchronize()
+    assert d_status.cpu().tolist() == [0] * len(msgs)
+    assert r.first_violations_device(d_out, len(msgs), c.witness_bytes) == [None] * len(msgs)
+    # flip one bit-signal in the middle of witness 2: exactly that witness is rejected, at the first constraint
+    # that mentions the wire
+    slot = dict((n, s) for s, n in c.symbols())["main.sha.sha256compression[1].t1[20].ch.out[7]"]
+    d_out[2 * c.witness_bytes + 32 * slot] ^= 1
+    w2 = d_out[2 * c.witness_bytes:3 * c.witness_bytes].cpu().numpy().tobytes()
+    first = ru.first_violation(cons, [int.from_bytes(w2[32 * i:32 * i + 32], "little") for i in range(c.W)])
+    assert first is not None
+    assert r.first_violations_device(d_out, len(msgs), c.witness_bytes) == [None, None, first, None, None]
+
+
+@pytest.mark.gpu
+def test_check_constraints_email_verifier_sha_and_poseidon_on_device_witnesses():
+    """EmailVerifier(576,192) device witnesses against 382,789 constraints derived from the circuit definition:
+    header Sha256Bytes, body Sha256BytesPartial (preHash wiring included) and the Poseidon pubkey hash -- every
+    SHA / Poseidon wire (51 % of the witness) is constrained."""
+    import torch
+    import zkwg
+    import sha_r1cs
+    from test_ev_cpu import _inputs
+    N, M = 576, 192
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    sym = c.symbols()
+    b = sha_r1cs.Builder({n: s for s, n in sym})
+    sha_r1cs.sha256_bytes_constraints(sym, N, "main.anon_Sha256Bytes", "main.emailHeader", builder=b)
+    sha_r1cs.sha256_bytes_constraints(sym, M, "main.anon_Sha256BytesPartial", "main.emailBody", pre="main.precomputedSHA", builder=b)
+    cons = b.cons + _poseidon9_constraints(sym, c.W)
+    assert len(cons) == 382789
+    r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=3, n_pub_in=17), device=0)
+    n = 4
+    recs = b"".join(c.pack(_inputs(N, M, 0, index=i, body_len=40 + 20 * i)) for i in range(n))
+    d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to("cuda:0")
+    d_out = torch.empty(n * c.witness_bytes, dtype=torch.uint8, device="cuda:0")
+    d_status = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    d_scr = torch.empty(c.scratch_bytes(n), dtype=torch.uint8, device="cuda:0")
+    c.calculate_batch_device(d_in, n, d_out, d_status, d_scr)
+    torch.cuda.synchronize()
+    assert d_status.cpu().tolist() == [0] * n
+    assert r.first_violations_device(d_out, n, c.witness_bytes) == [None] * n
+    slot = dict((nm, s) for s, nm in sym)["main.anon_Sha256BytesPartial.sha.sha256compression[2].suma[63].out[5]"]
+    d_out[3 * c.witness_bytes + 32 * slot] ^= 1
+    got = r.first_violations_device(d_out, n, c.witness_bytes)
+    w3 = d_out[3 * c.witness_bytes:4 * c.witness_bytes].cpu().numpy().tobytes()
+    exp = ru.first_violation(cons, [int.from_bytes(w3[32 * i:32 * i + 32], "little") for i in range(c.W)])
+    assert exp is not None and got == [None, None, None, exp]
