@@ -13,7 +13,7 @@ timeout 600 python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
     python $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.log )
 timeout 300 python bench.py --batch 256 --tile 256 --prep-batch 256 --distinct 256 --steps 10 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $OUT/${TAG}_c2_batch256.json
 timeout 600 python bench.py --max-body 65536 --body-len 60000 --batch 1024 --tile 32 --prep-batch 128 --distinct 32 --steps 2 --warmup 1 --cpu-sample 32 2>/dev/null | tail -1 > $OUT/${TAG}_c5_longbody.json
-timeout 600 python bench.py --remove-soft-line-breaks 1 --batch 4096 --prep-batch 1024 --tile 256 --ring 8 --steps 8 --warmup 1 --cpu-sample 0 2>/dev/null | tail -1 > $OUT/${TAG}_rslb.json
+timeout 600 python bench.py --remove-soft-line-breaks 1 --batch 4096 --tile 256 --prep-batch 4096 --ring 4 --steps 12 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 > $OUT/${TAG}_rslb.json
 for f in pytest_gpu.txt smoke.txt; do echo "== $f"; cat $OUT/${TAG}_$f; done
 for f in bench c2_batch256 c5_longbody rslb; do echo "== $f"; python - <<PY
 import json
