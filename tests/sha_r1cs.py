@@ -127,10 +127,22 @@ class Builder:
         return [self.binsum(f"{pre}.fsum[{j}]", [hin[j], fin[j]], 33)[:32] for j in range(8)]
 
 
-def sha256_bytes_constraints(symbols, n_bytes, comp="main", data="main.paddedIn", pre=None, builder=None):
-    """Constraints of the byte decompositions and of all n_bytes/64 compression blocks of the Sha256Bytes(n_bytes)
-    instance `comp` whose paddedIn is the signal array `data`, over the kept wires.  pre: name of the 32-byte
-    preHash array for Sha256BytesPartial (lib/sha.circom:47-80, 212-292), None for the IV."""
+def log2ceil(a):
+    n, r = a - 1, 0
+    while n > 0:
+        r += 1
+        n //= 2
+    return r
+
+
+def sha256_bytes_constraints(symbols, n_bytes, comp="main", data="main.paddedIn", pre=None, builder=None,
+                             length="main.paddedInLength", tail=True):
+    """Constraints of the Sha256Bytes(n_bytes) / Sha256BytesPartial instance `comp` whose paddedIn is the signal
+    array `data` and whose paddedInLength is the wire `length`, over the kept wires: byte decompositions, every
+    compression block, and (tail) Sha256General's block selection -- inBlockIndex, the length bound and the 256
+    ItemAtIndex selectors (lib/sha.circom:105-129, 190-198; utils/array.circom:16-64).  pre: name of the 32-byte
+    preHash array for Sha256BytesPartial (lib/sha.circom:47-80, 212-292), None for the IV.
+    Returns (constraints, out) with out = the 256 output bits (MSB first) as linear combinations."""
     slot_of = {n: s for s, n in symbols}
     b = builder or Builder(slot_of)
 
@@ -153,6 +165,51 @@ def sha256_bytes_constraints(symbols, n_bytes, comp="main", data="main.paddedIn"
         for i in range(32):
             pb += byte_bits("states", pre, i)
         hin = [[pb[32 * j + 31 - k] for k in range(32)] for j in range(8)]
-    for blk in range(n_bytes // 64):
+    nblocks = n_bytes // 64
+    block_out = []
+    for blk in range(nblocks):
         hin = b.compression(f"{comp}.sha.sha256compression[{blk}]", hin, bits[512 * blk:512 * (blk + 1)])
-    return b.cons
+        block_out.append(hin)
+    if not tail:
+        return b.cons, None
+    sha = comp + ".sha"
+    len_bits = lc_add({}, wire(slot_of[length]), 8)              # paddedInLength * 8
+    ibi = wire(slot_of[sha + ".inBlockIndex"])
+    b.cons.append((lc_add(len_bits, ibi, -512), const(1), {}))   # paddedInLength === inBlockIndex * 512
+    nb = log2ceil(n_bytes * 8)
+    # LessEqThan(nb)(len, maxBits) = LessThan(nb)(len, maxBits + 1): Num2Bits(nb+1)(len + 2^nb - maxBits - 1); === 1
+    lt = b.arr(sha + ".bitLengthVerifier.lt.n2b.out", nb + 1)
+    acc = lc_add(lc_add({}, len_bits, -1), const(n_bytes * 8 + 1 - (1 << nb)))
+    for k, o in enumerate(lt):
+        b.boolean(o)
+        acc = lc_add(acc, wire(o), 1 << k)
+    b.cons.append((acc, const(1), {}))
+    b.cons.append((wire(lt[nb]), const(1), {}))                  # out = 1 - n2b.out[nb] === 1
+    index = lc_add(ibi, const(-1))
+    out = []
+    for k in range(256):
+        q = f"{sha}.arraySelectors[{k}]"
+        tot_v, tot_i = {}, const(-1)
+        for i in range(nblocks):
+            o, inv = slot_of[f"{q}.eqs[{i}].isz.out"], slot_of[f"{q}.eqs[{i}].isz.inv"]
+            x = lc_add(index, const(-i))                         # isz.in = in[1] - in[0] = index - i
+            b.cons.append((x, wire(inv), lc_add(const(1), wire(o), -1)))
+            b.cons.append((x, wire(o), {}))
+            num = slot_of[f"{q}.calcTotalValue.nums[{i}]"]
+            blk_bit = block_out[i][k // 32][31 - k % 32]          # compression out[k], MSB-first words
+            b.cons.append((wire(o), blk_bit, wire(num)))
+            tot_v = lc_add(tot_v, wire(num))
+            tot_i = lc_add(tot_i, wire(o))
+        b.cons.append((tot_i, const(1), {}))                     # calcTotalIndex.sum === 1
+        out.append(tot_v)
+    return b.cons, out
+
+
+def sha256_main_constraints(symbols, n_bytes):
+    """`component main { public [paddedIn, paddedInLength] } = Sha256Bytes(n)` (tests/test-circuits/sha-test.circom):
+    everything above plus out[k] === the selected bit."""
+    slot_of = {n: s for s, n in symbols}
+    cons, out = sha256_bytes_constraints(symbols, n_bytes)
+    for k in range(256):
+        cons.append((lc_add(out[k], wire(slot_of[f"main.out[{k}]"]), -1), const(1), {}))
+    return cons

@@ -180,19 +180,24 @@ def test_check_constraints_of_real_device_witnesses():
         rb.checkConstraints(w)
 
 
-def test_sha256_r1cs_derivation_holds_for_the_oracle_witness():
-    # tests/sha_r1cs.py: constraints of every Sha256compression signal of Sha256Bytes(128), from the circomlib
-    # template definitions; the C oracle's witness satisfies all of them and every such wire is constrained
+def test_derived_constraint_systems_hold_for_the_oracle_witnesses():
+    # tests/sha_r1cs.py, tests/rsa_r1cs.py: COMPLETE constraint systems of the two small mains, derived from the
+    # reference / circomlib template definitions with aliases resolved onto the kept wires: every wire is
+    # constrained (except the 17 declared-but-unassigned carry[32] of CheckCarryToZero) and the oracle's
+    # witnesses satisfy all of them
     import zkwg
     import sha_r1cs
+    import rsa_r1cs
     from conftest import sha_pad
     from oracle import coracle
+    from test_rsa_cpu import KAT_MSG, KAT_SIG, KAT_PUB, limbs, oracle_rsa
     c = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=128, max_body=0, device=-1)
-    cons = sha_r1cs.sha256_bytes_constraints(c.symbols(), 128)
+    cons = sha_r1cs.sha256_main_constraints(c.symbols(), 128)
+    assert len(cons) == 65742
     used = set()
     for a, b, cc in cons:
         used |= set(a) | set(b) | set(cc)
-    assert all(s in used for s, n in c.symbols() if "sha256compression" in n or n.startswith("main.bytes"))
+    assert used == set(range(c.W))
     for msg in (b"", b"hello world", b"x" * 100):
         p, n = sha_pad(msg, 128)
         w, st, W = coracle.calculate(1, 128, 0, 0, [{"paddedIn": list(p), "paddedInLength": n}])
@@ -200,63 +205,25 @@ def test_sha256_r1cs_derivation_holds_for_the_oracle_witness():
         assert st == [0] and ru.first_violation(cons, wi) is None
     wi[30000] ^= 1
     assert ru.first_violation(cons, wi) is not None
+    cr = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=-1)
+    rcons = rsa_r1cs.rsa_main_constraints(cr.symbols())
+    assert len(rcons) == 191654
+    used = set()
+    for a, b, cc in rcons:
+        used |= set(a) | set(b) | set(cc)
+    names = dict(cr.symbols())
+    assert sorted(names[s] for s in set(range(cr.W)) - used) == sorted(
+        [f"main.bigPow.doublers[{i}].tCheck.carry[32]" for i in range(16)] + ["main.bigPow.adder.tCheck.carry[32]"])
+    w = oracle_rsa(KAT_MSG, limbs(KAT_SIG), limbs(KAT_PUB))      # packages/circuits/tests/rsa.test.ts:64-103
+    assert ru.first_violation(rcons, w) is None
+    w[100000] = (w[100000] + 1) % ru.P
+    assert ru.first_violation(rcons, w) is not None
 
 
-@pytest.mark.gpu
-def test_check_constraints_sha256_circuit_on_device_witnesses():
-    """`checkConstraints` with the SHA-256 constraint system (63,680 constraints for Sha256Bytes(128), derived in
-    tests/sha_r1cs.py from the circomlib templates) on witnesses straight from the device kernels."""
+def _device_witnesses(c, inputs):
     import torch
-    import zkwg
-    import sha_r1cs
-    from conftest import sha_pad
-    c = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=128, max_body=0, device=0)
-    cons = sha_r1cs.sha256_bytes_constraints(c.symbols(), 128)
-    r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=256, n_pub_in=129), device=0)
-    assert r.n_constraints == len(cons) == 63680
-    msgs = [b"", b"abc", b"hello world", bytes(range(64)), b"q" * 119]
-    recs = b""
-    for m in msgs:
-        p, n = sha_pad(m, 128)
-        recs += c.pack({"paddedIn": list(p), "paddedInLength": n})
-    d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to("cuda:0")
-    d_out = torch.empty(len(msgs) * c.witness_bytes, dtype=torch.uint8, device="cuda:0")
-    d_status = torch.zeros(len(msgs), dtype=torch.int32, device="cuda:0")
-    d_scr = torch.empty(c.scratch_bytes(len(msgs)), dtype=torch.uint8, device="cuda:0")
-    c.calculate_batch_device(d_in, len(msgs), d_out, d_status, d_scr)
-    torch.cuda.synchronize()
-    assert d_status.cpu().tolist() == [0] * len(msgs)
-    assert r.first_violations_device(d_out, len(msgs), c.witness_bytes) == [None] * len(msgs)
-    # flip one bit-signal in the middle of witness 2: exactly that witness is rejected, at the first constraint
-    # that mentions the wire
-    slot = dict((n, s) for s, n in c.symbols())["main.sha.sha256compression[1].t1[20].ch.out[7]"]
-    d_out[2 * c.witness_bytes + 32 * slot] ^= 1
-    w2 = d_out[2 * c.witness_bytes:3 * c.witness_bytes].cpu().numpy().tobytes()
-    first = ru.first_violation(cons, [int.from_bytes(w2[32 * i:32 * i + 32], "little") for i in range(c.W)])
-    assert first is not None
-    assert r.first_violations_device(d_out, len(msgs), c.witness_bytes) == [None, None, first, None, None]
-
-
-@pytest.mark.gpu
-def test_check_constraints_email_verifier_sha_and_poseidon_on_device_witnesses():
-    """EmailVerifier(576,192) device witnesses against 382,789 constraints derived from the circuit definition:
-    header Sha256Bytes, body Sha256BytesPartial (preHash wiring included) and the Poseidon pubkey hash -- every
-    SHA / Poseidon wire (51 % of the witness) is constrained."""
-    import torch
-    import zkwg
-    import sha_r1cs
-    from test_ev_cpu import _inputs
-    N, M = 576, 192
-    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
-    sym = c.symbols()
-    b = sha_r1cs.Builder({n: s for s, n in sym})
-    sha_r1cs.sha256_bytes_constraints(sym, N, "main.anon_Sha256Bytes", "main.emailHeader", builder=b)
-    sha_r1cs.sha256_bytes_constraints(sym, M, "main.anon_Sha256BytesPartial", "main.emailBody", pre="main.precomputedSHA", builder=b)
-    cons = b.cons + _poseidon9_constraints(sym, c.W)
-    assert len(cons) == 382789
-    r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=3, n_pub_in=17), device=0)
-    n = 4
-    recs = b"".join(c.pack(_inputs(N, M, 0, index=i, body_len=40 + 20 * i)) for i in range(n))
+    n = len(inputs)
+    recs = b"".join(c.pack(i) for i in inputs)
     d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to("cuda:0")
     d_out = torch.empty(n * c.witness_bytes, dtype=torch.uint8, device="cuda:0")
     d_status = torch.zeros(n, dtype=torch.int32, device="cuda:0")
@@ -264,10 +231,73 @@ def test_check_constraints_email_verifier_sha_and_poseidon_on_device_witnesses()
     c.calculate_batch_device(d_in, n, d_out, d_status, d_scr)
     torch.cuda.synchronize()
     assert d_status.cpu().tolist() == [0] * n
+    return d_out
+
+
+def _flip_and_expect(r, cons, c, d_out, n, e, slot):
+    """flip the lowest bit of wire `slot` of witness e: that witness alone must be rejected, at the constraint the
+    pure-Python evaluator names"""
+    d_out[e * c.witness_bytes + 32 * slot] ^= 1
+    we = d_out[e * c.witness_bytes:(e + 1) * c.witness_bytes].cpu().numpy().tobytes()
+    exp = ru.first_violation(cons, [int.from_bytes(we[32 * i:32 * i + 32], "little") for i in range(c.W)])
+    assert exp is not None
+    assert r.first_violations_device(d_out, n, c.witness_bytes) == [exp if i == e else None for i in range(n)]
+    d_out[e * c.witness_bytes + 32 * slot] ^= 1   # restore
+
+
+@pytest.mark.gpu
+def test_check_constraints_complete_sha_and_rsa_mains_on_device_witnesses():
+    """`checkConstraints` with the complete derived systems of `Sha256Bytes(128)` (65,742 constraints) and
+    `RSAVerifier65537(121,17)` (191,654) on witnesses straight from the device kernels."""
+    import zkwg
+    import sha_r1cs
+    import rsa_r1cs
+    from conftest import sha_pad
+    from zkwg import synth
+    import hashlib
+    from test_rsa_cpu import KAT_MSG, KAT_SIG, KAT_PUB, limbs
+    c = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=128, max_body=0, device=0)
+    cons = sha_r1cs.sha256_main_constraints(c.symbols(), 128)
+    r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=256, n_pub_in=129), device=0)
+    inputs = []
+    for m in (b"", b"abc", b"hello world", bytes(range(64)), b"q" * 119):
+        p, n = sha_pad(m, 128)
+        inputs.append({"paddedIn": list(p), "paddedInLength": n})
+    d_out = _device_witnesses(c, inputs)
+    assert r.first_violations_device(d_out, 5, c.witness_bytes) == [None] * 5
+    _flip_and_expect(r, cons, c, d_out, 5, 2, dict((n, s) for s, n in c.symbols())["main.sha.sha256compression[1].t1[20].ch.out[7]"])
+
+    cr = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=0)
+    rcons = rsa_r1cs.rsa_main_constraints(cr.symbols())
+    rr = zkwg.R1cs(ru.write_r1cs(cr.W, rcons, n_pub_out=0, n_pub_in=17), device=0)
+    key = synth.test_key()                                           # 2048-bit synthetic key, PKCS#1 v1.5 signature
+    dig = hashlib.sha256(b"zkwg").digest()
+    sig = synth.pkcs1_sign_digest(key, dig)
+    msg = limbs(int.from_bytes(dig, "big"))
+    inputs = [{"message": KAT_MSG, "signature": limbs(KAT_SIG), "modulus": limbs(KAT_PUB)},
+              {"message": msg, "signature": limbs(sig), "modulus": limbs(key["n"])}]
+    d_out = _device_witnesses(cr, inputs)
+    assert rr.first_violations_device(d_out, 2, cr.witness_bytes) == [None, None]
+    _flip_and_expect(rr, rcons, cr, d_out, 2, 1, dict((n, s) for s, n in cr.symbols())["main.bigPow.doublers[7].tCheck.carry[11]"])
+
+
+@pytest.mark.gpu
+def test_check_constraints_email_verifier_on_device_witnesses():
+    """EmailVerifier(576,192) device witnesses against 584,205 constraints assembled in tests/ev_r1cs.py from the
+    circuit definition (both SHA-256 instances with their selectors, shaHi/shaLo, the RSA message packing,
+    RSAVerifier65537, the Poseidon pubkey hash): 78 % of the witness wires are constrained; the rest (regex,
+    reveal shifting, Base64, zero-padding checks) is left to the oracle parity tests."""
+    import zkwg
+    import ev_r1cs
+    from test_ev_cpu import _inputs
+    N, M = 576, 192
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    cons = ev_r1cs.email_verifier_constraints(c.symbols(), N, M, _poseidon9_constraints)
+    assert len(cons) == 584205
+    r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=3, n_pub_in=17), device=0)
+    n = 4
+    d_out = _device_witnesses(c, [_inputs(N, M, 0, index=i, body_len=40 + 20 * i) for i in range(n)])
     assert r.first_violations_device(d_out, n, c.witness_bytes) == [None] * n
-    slot = dict((nm, s) for s, nm in sym)["main.anon_Sha256BytesPartial.sha.sha256compression[2].suma[63].out[5]"]
-    d_out[3 * c.witness_bytes + 32 * slot] ^= 1
-    got = r.first_violations_device(d_out, n, c.witness_bytes)
-    w3 = d_out[3 * c.witness_bytes:4 * c.witness_bytes].cpu().numpy().tobytes()
-    exp = ru.first_violation(cons, [int.from_bytes(w3[32 * i:32 * i + 32], "little") for i in range(c.W)])
-    assert exp is not None and got == [None, None, None, exp]
+    names = dict((nm, s) for s, nm in c.symbols())
+    _flip_and_expect(r, cons, c, d_out, n, 3, names["main.anon_Sha256BytesPartial.sha.sha256compression[2].suma[63].out[5]"])
+    _flip_and_expect(r, cons, c, d_out, n, 1, names["main.rsaVerifier.bigPow.adder.v_pq_r[9]"])
