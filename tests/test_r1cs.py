@@ -84,49 +84,6 @@ def test_check_constraints_on_gpu():
     assert r.first_violations_device(d, 6, stride) == exp
 
 
-def _poseidon9_constraints(sym, W):
-    """R1CS of the PoseidonLarge(121,17) -> Poseidon(9) block of EmailVerifier over the wires of the kept
-    layout (utils/hash.circom:15-39 + textbook Poseidon rounds): every S-box signal is constrained through
-    linear combinations of earlier wires; the last constraint ties the result to main.pubkeyHash."""
-    from oracle.pyref import poseidon
-    t, rp = 10, poseidon.N_ROUNDS_P[8]
-    Cc, M = poseidon.constants(t)
-    slot = {n: s for s, n in sym}
-    pk = [slot[f"main.pubkey[{i}]"] for i in range(17)]
-    pre = "main.anon_PoseidonLarge.anon_Poseidon.pEx."
-    state = [{}] + [({pk[2 * i]: 1, pk[2 * i + 1]: 1 << 121} if i < 8 else {pk[16]: 1}) for i in range(9)]
-    cons = []
-
-    def add(a, b):
-        out = dict(a)
-        for k, v in b.items():
-            out[k] = (out.get(k, 0) + v) % ru.P
-        return out
-
-    def sbox(lc, name):
-        o, i2, i4 = slot[name + ".out"], slot[name + ".in2"], slot[name + ".in4"]
-        cons.extend([(lc, lc, {i2: 1}), ({i2: 1}, {i2: 1}, {i4: 1}), ({i4: 1}, lc, {o: 1})])
-        return {o: 1}
-
-    fr = 0
-    for r in range(8 + rp):
-        state = [add(state[j], {0: Cc[r * t + j]}) for j in range(t)]
-        if r < 4 or r >= 4 + rp:
-            state = [sbox(state[j], f"{pre}sigmaF[{fr}][{j}]") for j in range(t)]
-            fr += 1
-        else:
-            state[0] = sbox(state[0], f"{pre}sigmaP[{r - 4}]")
-        new = []
-        for i in range(t):
-            acc = {}
-            for j in range(t):
-                acc = add(acc, {k: v * M[i][j] % ru.P for k, v in state[j].items()})
-            new.append(acc)
-        state = new
-    cons.append((add(state[0], {slot["main.pubkeyHash"]: ru.P - 1}), {0: 1}, {}))
-    return cons
-
-
 @pytest.mark.gpu
 def test_check_constraints_of_real_device_witnesses():
     """The device witness against constraint systems derived independently of the witness kernels:
@@ -139,7 +96,8 @@ def test_check_constraints_of_real_device_witnesses():
     from conftest import sha_pad
     N, M = 576, 192
     c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
-    cons = _poseidon9_constraints(c.symbols(), c.W)
+    from zkwg import r1cs as zr
+    cons = zr.poseidon9_constraints(c.symbols())
     assert len(cons) == 3 * 140 + 1
     r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=3, n_pub_in=17), device=0)
     recs = b"".join(c.pack(_inputs(N, M, 0, index=i, body_len=80)) for i in range(3))
@@ -181,18 +139,17 @@ def test_check_constraints_of_real_device_witnesses():
 
 
 def test_derived_constraint_systems_hold_for_the_oracle_witnesses():
-    # tests/sha_r1cs.py, tests/rsa_r1cs.py: COMPLETE constraint systems of the two small mains, derived from the
+    # zkwg.r1cs: COMPLETE constraint systems of the two small mains, derived from the
     # reference / circomlib template definitions with aliases resolved onto the kept wires: every wire is
     # constrained (except the 17 declared-but-unassigned carry[32] of CheckCarryToZero) and the oracle's
     # witnesses satisfy all of them
     import zkwg
-    import sha_r1cs
-    import rsa_r1cs
+    from zkwg import r1cs as zr
     from conftest import sha_pad
     from oracle import coracle
     from test_rsa_cpu import KAT_MSG, KAT_SIG, KAT_PUB, limbs, oracle_rsa
     c = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=128, max_body=0, device=-1)
-    cons = sha_r1cs.sha256_main_constraints(c.symbols(), 128)
+    cons = zr.sha256_main_constraints(c.symbols(), 128)
     assert len(cons) == 65742
     used = set()
     for a, b, cc in cons:
@@ -206,7 +163,7 @@ def test_derived_constraint_systems_hold_for_the_oracle_witnesses():
     wi[30000] ^= 1
     assert ru.first_violation(cons, wi) is not None
     cr = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=-1)
-    rcons = rsa_r1cs.rsa_main_constraints(cr.symbols())
+    rcons = zr.rsa_main_constraints(cr.symbols())
     assert len(rcons) == 191654
     used = set()
     for a, b, cc in rcons:
@@ -218,6 +175,39 @@ def test_derived_constraint_systems_hold_for_the_oracle_witnesses():
     assert ru.first_violation(rcons, w) is None
     w[100000] = (w[100000] + 1) % ru.P
     assert ru.first_violation(rcons, w) is not None
+    # the module's own Poseidon constants / interpolation matrix against the oracle's
+    from oracle.pyref import poseidon, bigint_func as bf
+    Cc, M = zr.poseidon_constants(10)
+    Co, Mo = poseidon.constants(10)
+    assert Cc == Co and M == Mo
+    T = zr.RsaBuilder({}, "x").interp_matrix(33)
+    for x in (0, 7, 32):
+        col = bf.poly_interp(33, [1 if y == x else 0 for y in range(33)])
+        assert [T[i][x] for i in range(33)] == [v % ru.P for v in col[:33]] and not any(v % ru.P for v in col[33:])
+
+
+def test_complete_email_verifier_constraint_system_holds_for_the_oracle_witness():
+    # zkwg.r1cs: EmailVerifier(576,192): 753,807 constraints, every wire constrained except the 17 unassigned
+    # carry[32]; the oracle witness of a valid email satisfies all of them, the .r1cs file parses back
+    import zkwg
+    from zkwg import r1cs as zr
+    from test_ev_cpu import _inputs
+    from oracle import coracle
+    N, M = 576, 192
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=-1)
+    cons = zr.email_verifier_constraints(c.symbols(), N, M)
+    assert len(cons) == 753807
+    used = set()
+    for a, b, cc in cons:
+        used |= set(a) | set(b) | set(cc)
+    names = dict(c.symbols())
+    assert sorted(names[s] for s in set(range(c.W)) - used) == sorted(
+        [f"main.rsaVerifier.bigPow.doublers[{i}].tCheck.carry[32]" for i in range(16)] + ["main.rsaVerifier.bigPow.adder.tCheck.carry[32]"])
+    w, st, W = coracle.calculate(0, N, M, 0, [_inputs(N, M, 0, index=1, body_len=100)])
+    wi = [int.from_bytes(w[0][32 * i:32 * i + 32], "little") for i in range(W)]
+    assert st == [0] and ru.first_violation(cons, wi) is None
+    r = zkwg.R1cs(zr.email_verifier_r1cs(c.symbols(), N, M), device=-1)
+    assert (r.n_wires, r.n_constraints, r.n_pub_out, r.n_pub_in, r.n_prv_in) == (c.W, 753807, 3, 17, N + 1 + 17 + 1 + 32 + M + 1)
 
 
 def _device_witnesses(c, inputs):
@@ -250,14 +240,13 @@ def test_check_constraints_complete_sha_and_rsa_mains_on_device_witnesses():
     """`checkConstraints` with the complete derived systems of `Sha256Bytes(128)` (65,742 constraints) and
     `RSAVerifier65537(121,17)` (191,654) on witnesses straight from the device kernels."""
     import zkwg
-    import sha_r1cs
-    import rsa_r1cs
+    from zkwg import r1cs as zr
     from conftest import sha_pad
     from zkwg import synth
     import hashlib
     from test_rsa_cpu import KAT_MSG, KAT_SIG, KAT_PUB, limbs
     c = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=128, max_body=0, device=0)
-    cons = sha_r1cs.sha256_main_constraints(c.symbols(), 128)
+    cons = zr.sha256_main_constraints(c.symbols(), 128)
     r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=256, n_pub_in=129), device=0)
     inputs = []
     for m in (b"", b"abc", b"hello world", bytes(range(64)), b"q" * 119):
@@ -268,7 +257,7 @@ def test_check_constraints_complete_sha_and_rsa_mains_on_device_witnesses():
     _flip_and_expect(r, cons, c, d_out, 5, 2, dict((n, s) for s, n in c.symbols())["main.sha.sha256compression[1].t1[20].ch.out[7]"])
 
     cr = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=0)
-    rcons = rsa_r1cs.rsa_main_constraints(cr.symbols())
+    rcons = zr.rsa_main_constraints(cr.symbols())
     rr = zkwg.R1cs(ru.write_r1cs(cr.W, rcons, n_pub_out=0, n_pub_in=17), device=0)
     key = synth.test_key()                                           # 2048-bit synthetic key, PKCS#1 v1.5 signature
     dig = hashlib.sha256(b"zkwg").digest()
@@ -283,17 +272,15 @@ def test_check_constraints_complete_sha_and_rsa_mains_on_device_witnesses():
 
 @pytest.mark.gpu
 def test_check_constraints_email_verifier_on_device_witnesses():
-    """EmailVerifier(576,192) device witnesses against 584,205 constraints assembled in tests/ev_r1cs.py from the
-    circuit definition (both SHA-256 instances with their selectors, shaHi/shaLo, the RSA message packing,
-    RSAVerifier65537, the Poseidon pubkey hash): 78 % of the witness wires are constrained; the rest (regex,
-    reveal shifting, Base64, zero-padding checks) is left to the oracle parity tests."""
+    """EmailVerifier(576,192) device witnesses against the COMPLETE constraint system of the kept-v1 layout
+    (zkwg.r1cs, 753,807 constraints derived from the circuit definition)."""
     import zkwg
-    import ev_r1cs
+    from zkwg import r1cs as zr
     from test_ev_cpu import _inputs
     N, M = 576, 192
     c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
-    cons = ev_r1cs.email_verifier_constraints(c.symbols(), N, M, _poseidon9_constraints)
-    assert len(cons) == 584205
+    cons = zr.email_verifier_constraints(c.symbols(), N, M)
+    assert len(cons) == 753807
     r = zkwg.R1cs(ru.write_r1cs(c.W, cons, n_pub_out=3, n_pub_in=17), device=0)
     n = 4
     d_out = _device_witnesses(c, [_inputs(N, M, 0, index=i, body_len=40 + 20 * i) for i in range(n)])
@@ -301,3 +288,5 @@ def test_check_constraints_email_verifier_on_device_witnesses():
     names = dict((nm, s) for s, nm in c.symbols())
     _flip_and_expect(r, cons, c, d_out, n, 3, names["main.anon_Sha256BytesPartial.sha.sha256compression[2].suma[63].out[5]"])
     _flip_and_expect(r, cons, c, d_out, n, 1, names["main.rsaVerifier.bigPow.adder.v_pq_r[9]"])
+    _flip_and_expect(r, cons, c, d_out, n, 0, names["main.anon_BodyHashRegex.and[7][200].out"])
+    _flip_and_expect(r, cons, c, d_out, n, 2, names["main.anon_Base64Decode.translate[3][1].sum_az"])
