@@ -290,3 +290,57 @@ def test_check_constraints_email_verifier_on_device_witnesses():
     _flip_and_expect(r, cons, c, d_out, n, 1, names["main.rsaVerifier.bigPow.adder.v_pq_r[9]"])
     _flip_and_expect(r, cons, c, d_out, n, 0, names["main.anon_BodyHashRegex.and[7][200].out"])
     _flip_and_expect(r, cons, c, d_out, n, 2, names["main.anon_Base64Decode.translate[3][1].sum_az"])
+
+
+def _flag_inputs(N, M, index_from=0):
+    """a valid all-flags input whose body contains a soft line break"""
+    from zkwg import synth, inputs as gen
+    for index in range(index_from, index_from + 50):
+        d = synth.synthetic_dkim_result(31, index, 100, soft_breaks=True)
+        if b"=\r\n" in d["body"]:
+            inp = gen.generate_email_verifier_inputs_from_dkim_result(d, N, M, remove_soft_line_breaks_flag=True)
+            inp["headerMask"] = [1 if 10 < i < 90 else 0 for i in range(N)]
+            inp["bodyMask"] = [(i + index) % 2 for i in range(M)]
+            return inp, index
+    raise AssertionError("no soft break generated")
+
+
+def test_constraint_system_with_all_template_flags_holds_for_the_oracle_witness():
+    # enableHeaderMasking + enableBodyMasking + removeSoftLineBreaks (PoseidonModular, RLC sums): complete system
+    import zkwg
+    from zkwg import r1cs as zr
+    from oracle import coracle
+    N, M = 576, 192
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=-1, enable_header_masking=1,
+                     enable_body_masking=1, remove_soft_line_breaks=1)
+    cons = zr.email_verifier_constraints(c.symbols(), N, M, 1, 1, 1)
+    used = set()
+    for a, b, cc in cons:
+        used |= set(a) | set(b) | set(cc)
+    names = dict(c.symbols())
+    assert all("tCheck.carry[32]" in names[s] for s in set(range(c.W)) - used) and len(set(range(c.W)) - used) == 17
+    inp, _ = _flag_inputs(N, M)
+    w, st, W = coracle.calculate(0, N, M, 0, [inp])
+    wi = [int.from_bytes(w[0][32 * i:32 * i + 32], "little") for i in range(W)]
+    assert st == [0] and W == c.W and ru.first_violation(cons, wi) is None
+
+
+@pytest.mark.gpu
+def test_check_constraints_all_template_flags_on_device_witnesses():
+    import zkwg
+    from zkwg import r1cs as zr
+    N, M = 576, 192
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, enable_header_masking=1,
+                     enable_body_masking=1, remove_soft_line_breaks=1)
+    cons = zr.email_verifier_constraints(c.symbols(), N, M, 1, 1, 1)
+    r = zkwg.R1cs(zr.write_r1cs(c.W, cons, n_pub_out=3 + N + M, n_pub_in=17), device=0)
+    inps, nxt = [], 0
+    for _ in range(3):
+        inp, idx = _flag_inputs(N, M, nxt)
+        inps.append(inp)
+        nxt = idx + 1
+    d_out = _device_witnesses(c, inps)
+    assert r.first_violations_device(d_out, 3, c.witness_bytes) == [None] * 3
+    names = dict((nm, s) for s, nm in c.symbols())
+    _flip_and_expect(r, cons, c, d_out, 3, 1, names["main.qpEncodingChecker.rHasher.anon_Poseidon_merge[9].pEx.sigmaP[20].in2"])
+    _flip_and_expect(r, cons, c, d_out, 3, 2, names["main.qpEncodingChecker.sumDec[50]"])

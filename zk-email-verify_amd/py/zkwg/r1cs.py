@@ -13,8 +13,8 @@ circuit, the only part that is not a restatement of a refe
     python -m zkwg.r1cs --max-header 1024 --max-body 1536 -o email-verifier.r1cs --sym email-verifier.sym
 
 writes the iden3 `.r1cs` (+ the `.sym`) of EmailVerifier(maxHeader, maxBody, 121, 17, 0, 0, 0, 0); together with
-a `.wtns` from zkwg they form a consistent triple for `snarkjs zkey new` / `groth16 prove`.  The template flag
-variants are not exported yet.  Validation: tests/test_r1cs.py (every wire constrained, oracle and device
+a `.wtns` from zkwg they form a consistent triple for `snarkjs zkey new` / `groth16 prove`.  The template flags
+enableHeaderMasking / enableBodyMasking / removeSoftLineBreaks are supported (ignoreBodyHashCheck = 1 is not).  Validation: tests/test_r1cs.py (every wire constrained, oracle and device
 witnesses satisfy every constraint, `zk_r1cs_check` agrees with a pure-Python evaluator on corrupted witnesses).
 """
 import json
@@ -610,7 +610,7 @@ def base64_decode(g, pre, chars, byte_length=32):
     return out
 
 
-def email_verifier_constraints(symbols, N, M):
+def email_verifier_constraints(symbols, N, M, enable_header_masking=0, enable_body_masking=0, remove_soft_line_breaks_flag=0):
     slot_of = {n: s for s, n in symbols}
     b = Builder(slot_of)
     _, sha = sha256_bytes_constraints(symbols, N, "main.anon_Sha256Bytes", "main.emailHeader", builder=b,
@@ -650,6 +650,21 @@ def email_verifier_constraints(symbols, N, M):
         for j in range(8):
             acc = lc_add(acc, body_sha[8 * i + j], 1 << (7 - j))
         g.lin(acc)
+    if remove_soft_line_breaks_flag:       # email-verifier.circom:148-156
+        valid = remove_soft_line_breaks(g, "main.qpEncodingChecker", body, arr("decodedEmailBodyIn", M))
+        g.lin(lc_add(valid, const(-1)))
+    # ByteMask (utils/bytes.circom:173-185): AssertBit(mask[i]); out[i] <== in[i] * mask[i]; the main outputs
+    # maskedHeader / maskedBody alias the component outputs
+    for flag, nm, data, outp, comp in ((enable_header_masking, "headerMask", header, "maskedHeader", "byteMask_header"),
+                                       (enable_body_masking, "bodyMask", body, "maskedBody", "byteMask_body")):
+        if not flag:
+            continue
+        mask = arr(nm, len(data))
+        for i in range(len(data)):
+            g.cons.append((mask[i], lc_add(mask[i], const(-1)), {}))
+            o = wire(slot_of[f"main.{comp}.out[{i}]"])
+            g.cons.append((data[i], mask[i], o))
+            g.lin(lc_add(o, wire(slot_of[f"main.{outp}[{i}]"]), -1))
     cons += poseidon9_constraints(symbols)
     return cons
 
@@ -700,17 +715,13 @@ def poseidon_constants(t):
     return C, M
 
 
-def poseidon9_constraints(symbols):
-    """The PoseidonLarge(121,17) -> Poseidon(9) block of EmailVerifier (utils/hash.circom:15-39 + textbook Poseidon
-    rounds): every S-box signal is constrained through linear combinations of earlier wires (up to 70 terms in the
-    partial rounds); the last constraint ties the result to main.pubkeyHash."""
-    t, rp = 10, N_ROUNDS_P[8]
+def poseidon_constraints(cons, slot, pre, inputs, t=None):
+    """circomlib Poseidon(len(inputs)) instance `pre` (its PoseidonEx is `pre`.pEx): S-box constraints through
+    linear combinations of earlier wires, textbook rounds; returns out as a linear combination."""
+    t = t or len(inputs) + 1
+    rp = N_ROUNDS_P[t - 2]
     Cc, M = poseidon_constants(t)
-    slot = {n: s for s, n in symbols}
-    pk = [slot[f"main.pubkey[{i}]"] for i in range(17)]
-    pre = "main.anon_PoseidonLarge.anon_Poseidon.pEx."
-    state = [{}] + [({pk[2 * i]: 1, pk[2 * i + 1]: 1 << 121} if i < 8 else {pk[16]: 1}) for i in range(9)]
-    cons = []
+    state = [{}] + list(inputs)
 
     def sbox(lc, name):
         o, i2, i4 = slot[name + ".out"], slot[name + ".in2"], slot[name + ".in4"]
@@ -721,10 +732,10 @@ def poseidon9_constraints(symbols):
     for r in range(8 + rp):
         state = [lc_add(state[j], const(Cc[r * t + j])) for j in range(t)]
         if r < 4 or r >= 4 + rp:
-            state = [sbox(state[j], f"{pre}sigmaF[{fr}][{j}]") for j in range(t)]
+            state = [sbox(state[j], f"{pre}.pEx.sigmaF[{fr}][{j}]") for j in range(t)]
             fr += 1
         else:
-            state[0] = sbox(state[0], f"{pre}sigmaP[{r - 4}]")
+            state[0] = sbox(state[0], f"{pre}.pEx.sigmaP[{r - 4}]")
         new = []
         for i in range(t):
             acc = {}
@@ -732,8 +743,90 @@ def poseidon9_constraints(symbols):
                 acc = lc_add(acc, state[j], M[i][j])
             new.append(acc)
         state = new
-    cons.append((lc_add(state[0], wire(slot["main.pubkeyHash"]), -1), const(1), {}))
+    return state[0]
+
+
+_pos_cache = {}
+_poseidon_constants_raw = poseidon_constants
+
+
+def poseidon_constants(t):   # noqa: F811  (memoised)
+    if t not in _pos_cache:
+        _pos_cache[t] = _poseidon_constants_raw(t)
+    return _pos_cache[t]
+
+
+def poseidon9_constraints(symbols):
+    """The PoseidonLarge(121,17) -> Poseidon(9) block of EmailVerifier (utils/hash.circom:15-39): the last
+    constraint ties the result to main.pubkeyHash."""
+    slot = {n: s for s, n in symbols}
+    pk = [slot[f"main.pubkey[{i}]"] for i in range(17)]
+    inputs = [({pk[2 * i]: 1, pk[2 * i + 1]: 1 << 121} if i < 8 else {pk[16]: 1}) for i in range(9)]
+    cons = []
+    out = poseidon_constraints(cons, slot, "main.anon_PoseidonLarge.anon_Poseidon", inputs)
+    cons.append((lc_add(out, wire(slot["main.pubkeyHash"]), -1), const(1), {}))
     return cons
+
+
+def remove_soft_line_breaks(g, pre, enc, dec):
+    """helpers/remove-soft-line-breaks.circom:14-126 as the component `pre`; enc / dec: lists of byte wires.
+    Returns isValid as a linear combination."""
+    M = len(enc)
+    slot = g.slot
+    # r = PoseidonModular(2M)(encoded || decoded) (utils/hash.circom:50-84)
+    data = list(enc) + list(dec)
+    r = None
+    for c in range(len(data) // 16):
+        h = poseidon_constraints(g.cons, slot, f"{pre}.rHasher.anon_Poseidon_chunk[{c}]", data[16 * c:16 * c + 16])
+        r = h if c == 0 else poseidon_constraints(g.cons, slot, f"{pre}.rHasher.anon_Poseidon_merge[{c}]", [r, h])
+    is_eq = [g.iszero(f"{pre}.anon_IsEqual_eq[{i}].isz", lc_add(const(61), enc[i], -1)) for i in range(M)]
+    is_cr = [g.iszero(f"{pre}.anon_IsEqual_cr[{i}].isz", lc_add(const(13), enc[i + 1], -1)) for i in range(M - 1)] + [{}]
+    is_lf = [g.iszero(f"{pre}.anon_IsEqual_lf[{i}].isz", lc_add(const(10), enc[i + 2], -1)) for i in range(M - 2)] + [{}, {}]
+    tsb, sb = g.arr(pre + ".tempSoftBreak", M - 2), g.arr(pre + ".isSoftBreak", M - 2)
+    is_sb = []
+    for i in range(M - 2):
+        g.cons.append((is_eq[i], is_cr[i], wire(tsb[i])))
+        g.cons.append((wire(tsb[i]), is_lf[i], wire(sb[i])))
+        is_sb.append(wire(sb[i]))
+    is_sb += [{}, {}]
+    sz = []
+    for i in range(M):
+        v = is_sb[i] if i < M - 1 else {}
+        if i == M - 1:
+            v = lc_add(is_sb[i - 1], is_sb[i - 2])
+        else:
+            if i >= 1:
+                v = lc_add(v, is_sb[i - 1])
+            if i >= 2:
+                v = lc_add(v, is_sb[i - 2])
+        sz.append(v)
+    proc = g.arr(pre + ".processed", M)
+    for i in range(M):
+        g.cons.append((one_minus(sz[i]), enc[i], wire(proc[i])))
+    # muxEnc[i] = Mux1 -> MultiMux1(1): out = (c[1] - c[0]) * s + c[0]
+    r_enc = []
+    for i in range(M):
+        if i == 0:
+            c0, c1 = r, const(1)
+        else:
+            c0w = slot[f"{pre}.muxEnc[{i}].c[0]"]
+            g.cons.append((r_enc[i - 1], r, wire(c0w)))
+            c0, c1 = wire(c0w), r_enc[i - 1]
+        o = slot[f"{pre}.muxEnc[{i}].mux.out[0]"]
+        g.cons.append((lc_add(c1, c0, -1), sz[i], lc_add(wire(o), c0, -1)))
+        r_enc.append(wire(o))
+    r_dec = [r]
+    for i in range(1, M):
+        w_ = slot[f"{pre}.rDec[{i}]"]
+        g.cons.append((r_dec[i - 1], r, wire(w_)))
+        r_dec.append(wire(w_))
+    s_enc, s_dec = g.arr(pre + ".sumEnc", M), g.arr(pre + ".sumDec", M)
+    for i in range(M):
+        prev_e = wire(s_enc[i - 1]) if i else {}
+        prev_d = wire(s_dec[i - 1]) if i else {}
+        g.cons.append((r_enc[i], wire(proc[i]), lc_add(wire(s_enc[i]), prev_e, -1)))
+        g.cons.append((r_dec[i], dec[i], lc_add(wire(s_dec[i]), prev_d, -1)))
+    return g.iszero(pre + ".anon_IsEqual_final.isz", lc_add(wire(s_dec[M - 1]), wire(s_enc[M - 1]), -1))
 
 
 def write_r1cs(n_wires, constraints, n_pub_out=0, n_pub_in=0, n_prv_in=0, header_last=False):
@@ -756,12 +849,15 @@ def write_r1cs(n_wires, constraints, n_pub_out=0, n_pub_in=0, n_prv_in=0, header
 
 
 
-def email_verifier_r1cs(symbols, N, M):
-    """bytes of the `.r1cs` file of EmailVerifier(N, M, 121, 17, 0, 0, 0, 0) over the kept-v1 wires `symbols`
-    ([(slot, name)], zkwg.Circuit.symbols()): 3 public outputs, 17 public inputs (pubkey), the rest private."""
-    cons = email_verifier_constraints(symbols, N, M)
-    n_prv = N + 1 + 17 + 1 + 32 + M + 1
-    return write_r1cs(len(symbols), cons, n_pub_out=3, n_pub_in=17, n_prv_in=n_prv)
+def email_verifier_r1cs(symbols, N, M, enable_header_masking=0, enable_body_masking=0, remove_soft_line_breaks_flag=0):
+    """bytes of the `.r1cs` file of EmailVerifier(N, M, 121, 17, 0, flags...) over the kept-v1 wires `symbols`
+    ([(slot, name)], zkwg.Circuit.symbols()): public outputs (pubkeyHash, shaHi, shaLo, masked arrays), 17 public
+    inputs (pubkey), the rest private."""
+    cons = email_verifier_constraints(symbols, N, M, enable_header_masking, enable_body_masking, remove_soft_line_breaks_flag)
+    n_out = 3 + (N if enable_header_masking else 0) + (M if enable_body_masking else 0)
+    n_prv = N + 1 + 17 + 1 + 32 + M + 1 + (N if enable_header_masking else 0) + (M if enable_body_masking else 0) + \
+        (M if remove_soft_line_breaks_flag else 0)
+    return write_r1cs(len(symbols), cons, n_pub_out=n_out, n_pub_in=17, n_prv_in=n_prv)
 
 
 def _main():
@@ -770,12 +866,18 @@ def _main():
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--max-header", type=int, default=1024)
     ap.add_argument("--max-body", type=int, default=1536)
+    ap.add_argument("--enable-header-masking", type=int, default=0)
+    ap.add_argument("--enable-body-masking", type=int, default=0)
+    ap.add_argument("--remove-soft-line-breaks", type=int, default=0)
     ap.add_argument("-o", "--output", required=True, help=".r1cs file to write")
     ap.add_argument("--sym", help="also write the layout's .sym file here")
     a = ap.parse_args()
-    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=a.max_header, max_body=a.max_body, device=-1)
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=a.max_header, max_body=a.max_body, device=-1,
+                     enable_header_masking=a.enable_header_masking, enable_body_masking=a.enable_body_masking,
+                     remove_soft_line_breaks=a.remove_soft_line_breaks)
     sym = c.symbols()
-    data = email_verifier_r1cs(sym, a.max_header, a.max_body)
+    data = email_verifier_r1cs(sym, a.max_header, a.max_body, a.enable_header_masking, a.enable_body_masking,
+                               a.remove_soft_line_breaks)
     with open(a.output, "wb") as f:
         f.write(data)
     if a.sym:
