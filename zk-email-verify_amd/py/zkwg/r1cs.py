@@ -864,6 +864,8 @@ def _main():
     import argparse
     import zkwg
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--main", choices=["email-verifier", "sha256-bytes", "rsa-verifier"], default="email-verifier",
+                    help="main component (tests/test-circuits/{email-verifier,sha,rsa}-test.circom)")
     ap.add_argument("--max-header", type=int, default=1024)
     ap.add_argument("--max-body", type=int, default=1536)
     ap.add_argument("--enable-header-masking", type=int, default=0)
@@ -872,12 +874,21 @@ def _main():
     ap.add_argument("-o", "--output", required=True, help=".r1cs file to write")
     ap.add_argument("--sym", help="also write the layout's .sym file here")
     a = ap.parse_args()
-    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=a.max_header, max_body=a.max_body, device=-1,
-                     enable_header_masking=a.enable_header_masking, enable_body_masking=a.enable_body_masking,
-                     remove_soft_line_breaks=a.remove_soft_line_breaks)
-    sym = c.symbols()
-    data = email_verifier_r1cs(sym, a.max_header, a.max_body, a.enable_header_masking, a.enable_body_masking,
-                               a.remove_soft_line_breaks)
+    if a.main == "sha256-bytes":
+        c = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=a.max_header, max_body=0, device=-1)
+        sym = c.symbols()
+        data = write_r1cs(len(sym), sha256_main_constraints(sym, a.max_header), n_pub_out=256, n_pub_in=a.max_header + 1)
+    elif a.main == "rsa-verifier":
+        c = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=-1)
+        sym = c.symbols()
+        data = write_r1cs(len(sym), rsa_main_constraints(sym), n_pub_out=0, n_pub_in=17, n_prv_in=34)
+    else:
+        c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=a.max_header, max_body=a.max_body, device=-1,
+                         enable_header_masking=a.enable_header_masking, enable_body_masking=a.enable_body_masking,
+                         remove_soft_line_breaks=a.remove_soft_line_breaks)
+        sym = c.symbols()
+        data = email_verifier_r1cs(sym, a.max_header, a.max_body, a.enable_header_masking, a.enable_body_masking,
+                                   a.remove_soft_line_breaks)
     with open(a.output, "wb") as f:
         f.write(data)
     if a.sym:
