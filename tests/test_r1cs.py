@@ -344,3 +344,17 @@ def test_check_constraints_all_template_flags_on_device_witnesses():
     names = dict((nm, s) for s, nm in c.symbols())
     _flip_and_expect(r, cons, c, d_out, 3, 1, names["main.qpEncodingChecker.rHasher.anon_Poseidon_merge[9].pEx.sigmaP[20].in2"])
     _flip_and_expect(r, cons, c, d_out, 3, 2, names["main.qpEncodingChecker.sumDec[50]"])
+
+
+@pytest.mark.gpu
+def test_witness_calculator_check_constraints_like_circom_tester():
+    # the reference's test idiom: witness = await circuit.calculateWitness(input); await circuit.checkConstraints(witness)
+    import zkwg
+    from conftest import sha_pad
+    wc = zkwg.WitnessCalculator(zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=128, max_body=0, device=0))
+    p, n = sha_pad(b"hello world", 128)
+    w = wc.calculateWitness({"paddedIn": list(p), "paddedInLength": n})
+    wc.checkConstraints(w)
+    w[40000] ^= 1
+    with pytest.raises(zkwg.ZkwgError, match="Constraint doesn't match"):
+        wc.checkConstraints(w)

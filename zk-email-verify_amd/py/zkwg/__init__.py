@@ -65,6 +65,7 @@ class Circuit:
         if rc == -1:
             raise ZkwgError(f"{self.lib.zkwg_strerror(rc).decode()}: {self.lib.zkwg_last_error().decode()}")
         _check(rc)
+        self._sym_layout = sym is not None
         self.h = h
         self.device = device
         self.W = self.lib.zkwg_witness_len(h)
@@ -317,6 +318,33 @@ class WitnessCalculator:
         wit, status = self.circuit.calculate_batch_host(recs)
         wb = self.circuit.witness_bytes
         return [wit[i * wb:(i + 1) * wb] for i in range(len(inputs))], status
+
+    def constraint_system(self):
+        """The circuit's R1CS in the layout this calculator emits (zkwg.r1cs, derived from the reference templates),
+        loaded on the circuit's device; built once per calculator."""
+        if getattr(self, "_r1cs", None) is None:
+            from . import r1cs as zr
+            c = self.circuit
+            cfg = c.cfg
+            if cfg.layout != 0 or getattr(c, "_sym_layout", False):
+                raise ZkwgError("constraint system export covers the built-in layout only; load the compiler's .r1cs with zkwg.R1cs")
+            sym = c.symbols()
+            if cfg.main_kind == MAIN_SHA256_BYTES:
+                data = zr.write_r1cs(len(sym), zr.sha256_main_constraints(sym, cfg.max_header), 256, cfg.max_header + 1)
+            elif cfg.main_kind == MAIN_RSA_VERIFIER:
+                data = zr.write_r1cs(len(sym), zr.rsa_main_constraints(sym), 0, 17, 34)
+            else:
+                if cfg.ignore_body_hash_check:
+                    raise ZkwgError("constraint system export does not cover ignoreBodyHashCheck = 1")
+                data = zr.email_verifier_r1cs(sym, cfg.max_header, cfg.max_body, cfg.enable_header_masking,
+                                              cfg.enable_body_masking, cfg.remove_soft_line_breaks)
+            self._r1cs = R1cs(data, device=c.device)
+        return self._r1cs
+
+    def checkConstraints(self, witness):
+        """circom_tester `await circuit.checkConstraints(witness)` (packages/circuits/tests/email-verifier.test.ts:44)
+        against the constraint system of this layout, on the device."""
+        self.constraint_system().checkConstraints(witness)
 
 
 def witness_ints(b):
