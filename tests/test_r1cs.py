@@ -358,3 +358,50 @@ def test_witness_calculator_check_constraints_like_circom_tester():
     w[40000] ^= 1
     with pytest.raises(zkwg.ZkwgError, match="Constraint doesn't match"):
         wc.checkConstraints(w)
+
+
+@pytest.mark.gpu
+def test_single_wire_corruptions_are_all_detected():
+    """Sanity check against under-constrained wires in the derived system: in a valid EmailVerifier(576,192) device
+    witness change ONE wire (+1) -- 384 wires sampled over the whole witness plus the first/last wires of every
+    top-level block -- and check each of the 400-odd corrupted copies on the device: every one must violate a
+    constraint.  Exempt by the circuit's own definition: the 17 declared-but-unassigned carry[32], and `IsZero.inv`
+    when the tested value is zero (circomlib: `inv <-- in != 0 ? 1/in : 0; out <== -in*inv + 1` leaves inv free there)."""
+    import random
+    import torch
+    import zkwg
+    from zkwg import r1cs as zr
+    from test_ev_cpu import _inputs
+    N, M = 576, 192
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    sym = c.symbols()
+    cons = zr.email_verifier_constraints(sym, N, M)
+    r = zkwg.R1cs(zr.write_r1cs(c.W, cons, n_pub_out=3, n_pub_in=17), device=0)
+    base = _device_witnesses(c, [_inputs(N, M, 0, index=2, body_len=90)])
+    exempt = {s for s, n in sym if n.endswith("tCheck.carry[32]")}
+    rng = random.Random(123)
+    picks = set(rng.sample(range(1, c.W), 384))
+    prev_top = None
+    for s, n in sym[1:]:                      # block boundaries: first wire of every top-level component / array
+        top = n.split(".")[1].split("[")[0] if "." in n else n
+        if top != prev_top:
+            picks.update({s, max(1, s - 1)})
+            prev_top = top
+    picks = sorted(picks - exempt)
+    k = len(picks)
+    wb = c.witness_bytes
+    d = base.view(1, wb).repeat(k, 1).contiguous()
+    idx = torch.arange(k, device="cuda:0")
+    off = torch.tensor([32 * s for s in picks], device="cuda:0")
+    low = d[idx, off].to(torch.int32)
+    d[idx, off] = ((low + 1) % 256).to(torch.uint8)          # +1 on the low byte (no carry needed for a change)
+    got = r.first_violations_device(d.view(-1), k, wb)
+    missed = [dict(sym)[picks[i]] for i in range(k) if got[i] is None]
+    assert all(n.endswith(".inv") for n in missed), [n for n in missed if not n.endswith(".inv")][:10]
+    # ... and those really are inverses of a zero: the matching `.out` wire of each is 1
+    w0 = base.cpu().numpy().tobytes()
+    slot_of = {n: s for s, n in sym}
+    for n in missed:
+        o = slot_of[n[:-4] + ".out"]
+        assert int.from_bytes(w0[32 * o:32 * o + 32], "little") == 1, n
+    assert len(missed) < k // 4
