@@ -378,6 +378,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.n_emails = (u32)n;
   B.e_first = 0;
   B.emails_per_wg = 1;
+  B.xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
 }
 
 int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_status, void* d_scratch,

@@ -226,5 +226,6 @@ struct ZkBufs {
   u32 n_emails;          // emails covered by the image arrays / this launch
   u32 e_first;           // zk_expand: first email to expand (wit points at its witness)
   u32 emails_per_wg;     // zk_expand: emails handled by one workgroup (same portion of each)
+  u32 xcd_remap;         // zk_expand: 1 = workgroup -> unit mapping that gives each of the 8 XCDs one contiguous range
 };
 #endif
