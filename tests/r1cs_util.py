@@ -1,7 +1,6 @@
 """Test-only helpers for the `.r1cs` path: a writer of the iden3 binary format, a pure-Python constraint
 evaluator (the checker of the checker) and small constraint systems with their witnesses."""
 import random
-import struct
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 

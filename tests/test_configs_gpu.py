@@ -96,7 +96,6 @@ def test_prover_handoff_montgomery_round_trip():
     # zkwg_convert_montgomery_device: x -> x * 2^256 mod r in place on a device witness, and back
     import torch
     import zkwg
-    from conftest import sha_pad
     P = zkwg.FIELD_MODULUS if hasattr(zkwg, "FIELD_MODULUS") else 21888242871839275222246405745257275088548364400416034343698204186575808495617
     c = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=0)   # the Fr-richest small witness
     from test_rsa_cpu import KAT_MSG, KAT_SIG, KAT_PUB, limbs

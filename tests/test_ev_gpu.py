@@ -2,7 +2,6 @@
 (reference: packages/circuits/tests/email-verifier.test.ts, email-verifier-no-body.test.ts) --
 HIP witness vs the literal Python oracle, bit-exact; tamper cases must give "Assert Failed"."""
 import copy
-import hashlib
 
 import pytest
 

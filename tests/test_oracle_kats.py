@@ -9,7 +9,7 @@ import random
 import pytest
 
 from conftest import ROOT, sha_pad
-from oracle.pyref import zkemail as zk, circomlib as cl, comp, bigint_func as bf
+from oracle.pyref import zkemail as zk, comp, bigint_func as bf
 
 FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "test_eml.json")))
 

@@ -2,7 +2,6 @@
 table against the literal Python oracle, on the reference's own RSA KATs
 (packages/circuits/tests/rsa.test.ts:64-144)."""
 import ctypes as C
-import random
 
 import pytest
 
