@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="emails per GPU per step")
     ap.add_argument("--tile", type=int, default=512, help="emails per launch (HBM-resident tile)")
     ap.add_argument("--distinct", type=int, default=512, help="distinct synthetic emails generated per rank")
