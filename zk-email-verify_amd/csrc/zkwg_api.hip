@@ -39,6 +39,7 @@ struct zkwg_circuit {
   hipEvent_t rs_dep[ZK_RS_SLOTS], rs_done[ZK_RS_SLOTS];
   const void* rs_scr[ZK_RS_SLOTS];
   int rs_next, rs_sync, rs_nside;
+  u32 xcd_remap;  // zk_expand workgroup -> portion mapping (ZKWG_XCD_REMAP)
   // host-buffer path: cached device staging buffers (double-buffered witnesses)
   std::mutex hb_mutex;
   u8 *hb_in, *hb_out[2], *hb_scr;
@@ -128,6 +129,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   if (const char* v = getenv("ZKWG_PORTION")) portion = (u32)atoi(v);
   if (const char* v = getenv("ZKWG_EXPAND_THREADS")) c->expand_threads = atoi(v);
   c->emails_per_wg = 1;
+  c->xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
   c->rsa_wgs_per_cu = 0;
   if (const char* v = getenv("ZKWG_RSA_WGS_PER_CU")) c->rsa_wgs_per_cu = atoi(v);
   if (const char* v = getenv("ZKWG_EMAILS_PER_WG")) c->emails_per_wg = std::max(1, atoi(v));
@@ -378,7 +380,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.n_emails = (u32)n;
   B.e_first = 0;
   B.emails_per_wg = 1;
-  B.xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
+  B.xcd_remap = c->xcd_remap;
 }
 
 int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_status, void* d_scratch,
