@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--max-body", type=int, default=1536)
     ap.add_argument("--body-len", type=int, default=1024)
     ap.add_argument("--prep-batch", type=int, default=1024, help="emails per prepare launch (pipeline granularity)")
-    ap.add_argument("--rsa-throttle", type=int, default=3, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap)")
+    ap.add_argument("--rsa-throttle", type=int, default=4, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap)")
     ap.add_argument("--remove-soft-line-breaks", type=int, default=0,
                     help="template flag removeSoftLineBreaks (flag-variant measurement; the headline config keeps 0)")
     ap.add_argument("--prep-streams", type=int, default=1, help="streams the prepare launches alternate over (2 overlaps the latency-bound prepare kernels of consecutive small sub-batches)")
