@@ -25,19 +25,18 @@ template <int ZK_BLOCK_THREADS, bool WAVE_MODE>
 __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B) {
   constexpr u32 ZK_EXPAND_THREADS = WAVE_MODE ? 64u : (u32)ZK_BLOCK_THREADS;
   constexpr u32 UNITS_PER_BLOCK = WAVE_MODE ? (u32)ZK_BLOCK_THREADS / 64u : 1u;
-  u32 unit = blockIdx.x * UNITS_PER_BLOCK + (WAVE_MODE ? (threadIdx.x >> 6) : 0u);
-  if (!WAVE_MODE && B.xcd_remap) {
-    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Give every XCD a contiguous run of units:
-    // xcd_remap = 1: one run per XCD over the whole launch; K > 1: runs of K units inside groups of 8 K units.
-    if (B.xcd_remap == 1u) {
-      const u32 per = gridDim.x >> 3;
-      if (unit < per * 8u) unit = (unit & 7u) * per + (unit >> 3);
-    } else {
-      const u32 K = B.xcd_remap, G = 8u * K;
-      const u32 g = unit / G, r = unit - g * G;
-      if ((g + 1u) * G <= gridDim.x) unit = g * G + (r & 7u) * K + (r >> 3);
-    }
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Give every XCD a contiguous run of units:
+  // xcd_remap = 1: one run per XCD over the whole launch; K > 1: runs of K workgroups inside groups of 8 K.
+  u32 blk = blockIdx.x;
+  if (B.xcd_remap == 1u) {
+    const u32 per = gridDim.x >> 3;
+    if (blk < per * 8u) blk = (blk & 7u) * per + (blk >> 3);
+  } else if (B.xcd_remap > 1u) {
+    const u32 K = B.xcd_remap, G = 8u * K;
+    const u32 g = blk / G, r = blk - g * G;
+    if ((g + 1u) * G <= gridDim.x) blk = g * G + (r & 7u) * K + (r >> 3);
   }
+  const u32 unit = blk * UNITS_PER_BLOCK + (WAVE_MODE ? (threadIdx.x >> 6) : 0u);
   // workgroup (p, g): portion p of the emails [g*E, g*E+E) of this launch.  The segment lookup is
   // email-independent, so its latency is paid once per workgroup and amortised over E emails.
   const u32 p = unit % s.nportions;
