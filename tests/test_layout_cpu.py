@@ -39,3 +39,26 @@ def test_sha_main_layout_matches_oracle():
     assert c.W == len(sym_oracle)
     assert c.symbols() == sym_oracle
     assert c.n_public == 256 + N + 1
+
+
+def test_xcd_remap_is_a_permutation_of_the_launch():
+    # zk_expand's workgroup -> unit mapping (zkwg_kernels_expand.hip) restated: every unit of
+    # a launch must be produced exactly once for any grid size and any ZKWG_XCD_REMAP setting
+    def remap(blk, grid, mode):
+        if mode == 1:
+            per = grid >> 3
+            return (blk & 7) * per + (blk >> 3) if blk < per * 8 else blk
+        if mode > 1:
+            K, G = mode, 8 * mode
+            g, r = divmod(blk, G)
+            return g * G + (r & 7) * K + (r >> 3) if (g + 1) * G <= grid else blk
+        return blk
+    for grid in (1, 7, 8, 9, 63, 64, 65, 868, 868 * 3 + 5, 4096, 12345):
+        for mode in (0, 1, 2, 16, 256, 5000):
+            assert sorted(remap(b, grid, mode) for b in range(grid)) == list(range(grid)), (grid, mode)
+    # mode 1: XCD x (= blk % 8) owns one contiguous eighth
+    grid = 868 * 512
+    per = grid >> 3
+    for x in range(8):
+        got = [remap(b, grid, 1) for b in range(x, 8 * 50, 8)]
+        assert got == list(range(x * per, x * per + 50))
