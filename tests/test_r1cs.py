@@ -215,7 +215,8 @@ def _device_witnesses(c, inputs):
     n = len(inputs)
     recs = b"".join(c.pack(i) for i in inputs)
     d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to("cuda:0")
-    d_out = torch.empty(n * c.witness_bytes, dtype=torch.uint8, device="cuda:0")
+    # poison the output first: a slot the kernels failed to write would read as 0xA5A5... (>= r) and be reported
+    d_out = torch.full((n * c.witness_bytes,), 0xA5, dtype=torch.uint8, device="cuda:0")
     d_status = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     d_scr = torch.empty(c.scratch_bytes(n), dtype=torch.uint8, device="cuda:0")
     c.calculate_batch_device(d_in, n, d_out, d_status, d_scr)
