@@ -306,6 +306,24 @@ def _flag_inputs(N, M, index_from=0):
     raise AssertionError("no soft break generated")
 
 
+def test_constraint_system_without_body_hash_check_holds_for_the_oracle_witness():
+    # ignoreBodyHashCheck = 1 (tests/test-circuits/email-verifier-no-body-test.circom)
+    import zkwg
+    from zkwg import r1cs as zr
+    from test_ev_cpu import _inputs
+    from oracle import coracle
+    N = 576
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=0, device=-1, ignore_body_hash_check=1)
+    cons = zr.email_verifier_constraints(c.symbols(), N, 0, ignore_body_hash_check=1)
+    used = set()
+    for a, b, cc in cons:
+        used |= set(a) | set(b) | set(cc)
+    assert len(set(range(c.W)) - used) == 17
+    w, st, W = coracle.calculate(0, N, 0, 1, [_inputs(N, 192, 1, index=0, body_len=60)])
+    wi = [int.from_bytes(w[0][32 * i:32 * i + 32], "little") for i in range(W)]
+    assert st == [0] and W == c.W and ru.first_violation(cons, wi) is None
+
+
 def test_constraint_system_with_all_template_flags_holds_for_the_oracle_witness():
     # enableHeaderMasking + enableBodyMasking + removeSoftLineBreaks (PoseidonModular, RLC sums): complete system
     import zkwg

@@ -334,10 +334,8 @@ class WitnessCalculator:
             elif cfg.main_kind == MAIN_RSA_VERIFIER:
                 data = zr.write_r1cs(len(sym), zr.rsa_main_constraints(sym), 0, 17, 34)
             else:
-                if cfg.ignore_body_hash_check:
-                    raise ZkwgError("constraint system export does not cover ignoreBodyHashCheck = 1")
                 data = zr.email_verifier_r1cs(sym, cfg.max_header, cfg.max_body, cfg.enable_header_masking,
-                                              cfg.enable_body_masking, cfg.remove_soft_line_breaks)
+                                              cfg.enable_body_masking, cfg.remove_soft_line_breaks, cfg.ignore_body_hash_check)
             self._r1cs = R1cs(data, device=c.device)
         return self._r1cs
 

@@ -14,7 +14,7 @@ circuit, the only part that is not a restatement of a refe
 
 writes the iden3 `.r1cs` (+ the `.sym`) of EmailVerifier(maxHeader, maxBody, 121, 17, 0, 0, 0, 0); together with
 a `.wtns` from zkwg they form a consistent triple for `snarkjs zkey new` / `groth16 prove`.  The template flags
-enableHeaderMasking / enableBodyMasking / removeSoftLineBreaks are supported (ignoreBodyHashCheck = 1 is not).  Validation: tests/test_r1cs.py (every wire constrained, oracle and device
+ignoreBodyHashCheck / enableHeaderMasking / enableBodyMasking / removeSoftLineBreaks are supported.  Validation: tests/test_r1cs.py (every wire constrained, oracle and device
 witnesses satisfy every constraint, `zk_r1cs_check` agrees with a pure-Python evaluator on corrupted witnesses).
 """
 import json
@@ -610,13 +610,16 @@ def base64_decode(g, pre, chars, byte_length=32):
     return out
 
 
-def email_verifier_constraints(symbols, N, M, enable_header_masking=0, enable_body_masking=0, remove_soft_line_breaks_flag=0):
+def email_verifier_constraints(symbols, N, M, enable_header_masking=0, enable_body_masking=0, remove_soft_line_breaks_flag=0,
+                               ignore_body_hash_check=0):
     slot_of = {n: s for s, n in symbols}
+    body_on = not ignore_body_hash_check
     b = Builder(slot_of)
     _, sha = sha256_bytes_constraints(symbols, N, "main.anon_Sha256Bytes", "main.emailHeader", builder=b,
                                                length="main.emailHeaderLength")
-    _, body_sha = sha256_bytes_constraints(symbols, M, "main.anon_Sha256BytesPartial", "main.emailBody",
-                                                    pre="main.precomputedSHA", builder=b, length="main.emailBodyLength")
+    if body_on:
+        _, body_sha = sha256_bytes_constraints(symbols, M, "main.anon_Sha256BytesPartial", "main.emailBody",
+                                               pre="main.precomputedSHA", builder=b, length="main.emailBodyLength")
     cons = b.cons
     # PackBits(256, 128) (utils/bytes.circom:194-210 via email-verifier.circom:68-71): chunk 0 -> shaHi, chunk 1 ->
     # shaLo, each chunk big-endian: out[i] = sum_j in[128 i + j] * 2^(127 - j)
@@ -634,11 +637,18 @@ def email_verifier_constraints(symbols, N, M, enable_header_masking=0, enable_bo
     g.cons = cons
     arr = lambda nm, k: [wire(slot_of[f"main.{nm}[{i}]"]) for i in range(k)]
     g.rsa_verifier(message, arr("signature", 17), arr("pubkey", 17))
-    header, body = arr("emailHeader", N), arr("emailBody", M)
-    hlen, blen = wire(slot_of["main.emailHeaderLength"]), wire(slot_of["main.emailBodyLength"])
-    bhi = wire(slot_of["main.bodyHashIndex"])
+    header = arr("emailHeader", N)
+    hlen = wire(slot_of["main.emailHeaderLength"])
     g.num2bits("main.n2bHeaderLength", hlen, log2ceil(N))
     assert_zero_padding(g, "main.anon_AssertZeroPadding_header", header, hlen)
+    if not body_on:      # email-verifier.circom:108: everything below sits inside `if (ignoreBodyHashCheck != 1)`
+        if enable_header_masking:
+            _byte_mask(g, slot_of, header, arr("headerMask", N), "maskedHeader", "byteMask_header")
+        cons += poseidon9_constraints(symbols)
+        return cons
+    body = arr("emailBody", M)
+    blen = wire(slot_of["main.emailBodyLength"])
+    bhi = wire(slot_of["main.bodyHashIndex"])
     g.num2bits("main.n2bBodyLength", blen, log2ceil(M))
     assert_zero_padding(g, "main.anon_AssertZeroPadding_body", body, blen)
     match, reveal = body_hash_regex_v1(g, "main.anon_BodyHashRegex", header)
@@ -653,20 +663,22 @@ def email_verifier_constraints(symbols, N, M, enable_header_masking=0, enable_bo
     if remove_soft_line_breaks_flag:       # email-verifier.circom:148-156
         valid = remove_soft_line_breaks(g, "main.qpEncodingChecker", body, arr("decodedEmailBodyIn", M))
         g.lin(lc_add(valid, const(-1)))
-    # ByteMask (utils/bytes.circom:173-185): AssertBit(mask[i]); out[i] <== in[i] * mask[i]; the main outputs
-    # maskedHeader / maskedBody alias the component outputs
-    for flag, nm, data, outp, comp in ((enable_header_masking, "headerMask", header, "maskedHeader", "byteMask_header"),
-                                       (enable_body_masking, "bodyMask", body, "maskedBody", "byteMask_body")):
-        if not flag:
-            continue
-        mask = arr(nm, len(data))
-        for i in range(len(data)):
-            g.cons.append((mask[i], lc_add(mask[i], const(-1)), {}))
-            o = wire(slot_of[f"main.{comp}.out[{i}]"])
-            g.cons.append((data[i], mask[i], o))
-            g.lin(lc_add(o, wire(slot_of[f"main.{outp}[{i}]"]), -1))
+    if enable_header_masking:
+        _byte_mask(g, slot_of, header, arr("headerMask", N), "maskedHeader", "byteMask_header")
+    if enable_body_masking:
+        _byte_mask(g, slot_of, body, arr("bodyMask", M), "maskedBody", "byteMask_body")
     cons += poseidon9_constraints(symbols)
     return cons
+
+
+def _byte_mask(g, slot_of, data, mask, outp, comp):
+    """ByteMask (utils/bytes.circom:173-185): AssertBit(mask[i]); out[i] <== in[i] * mask[i]; the main output array
+    aliases the component's outputs"""
+    for i in range(len(data)):
+        g.cons.append((mask[i], lc_add(mask[i], const(-1)), {}))
+        o = wire(slot_of[f"main.{comp}.out[{i}]"])
+        g.cons.append((data[i], mask[i], o))
+        g.lin(lc_add(o, wire(slot_of[f"main.{outp}[{i}]"]), -1))
 
 
 # ------------------------------------------------------------------ Poseidon(9) block, `.r1cs` writer, CLI
@@ -849,11 +861,17 @@ def write_r1cs(n_wires, constraints, n_pub_out=0, n_pub_in=0, n_prv_in=0, header
 
 
 
-def email_verifier_r1cs(symbols, N, M, enable_header_masking=0, enable_body_masking=0, remove_soft_line_breaks_flag=0):
+def email_verifier_r1cs(symbols, N, M, enable_header_masking=0, enable_body_masking=0, remove_soft_line_breaks_flag=0,
+                        ignore_body_hash_check=0):
     """bytes of the `.r1cs` file of EmailVerifier(N, M, 121, 17, 0, flags...) over the kept-v1 wires `symbols`
     ([(slot, name)], zkwg.Circuit.symbols()): public outputs (pubkeyHash, shaHi, shaLo, masked arrays), 17 public
     inputs (pubkey), the rest private."""
-    cons = email_verifier_constraints(symbols, N, M, enable_header_masking, enable_body_masking, remove_soft_line_breaks_flag)
+    cons = email_verifier_constraints(symbols, N, M, enable_header_masking, enable_body_masking, remove_soft_line_breaks_flag,
+                                      ignore_body_hash_check)
+    if ignore_body_hash_check:
+        n_out = 3 + (N if enable_header_masking else 0)
+        n_prv = N + 1 + 17 + (N if enable_header_masking else 0)
+        return write_r1cs(len(symbols), cons, n_pub_out=n_out, n_pub_in=17, n_prv_in=n_prv)
     n_out = 3 + (N if enable_header_masking else 0) + (M if enable_body_masking else 0)
     n_prv = N + 1 + 17 + 1 + 32 + M + 1 + (N if enable_header_masking else 0) + (M if enable_body_masking else 0) + \
         (M if remove_soft_line_breaks_flag else 0)
@@ -868,6 +886,7 @@ def _main():
                     help="main component (tests/test-circuits/{email-verifier,sha,rsa}-test.circom)")
     ap.add_argument("--max-header", type=int, default=1024)
     ap.add_argument("--max-body", type=int, default=1536)
+    ap.add_argument("--ignore-body-hash-check", type=int, default=0)
     ap.add_argument("--enable-header-masking", type=int, default=0)
     ap.add_argument("--enable-body-masking", type=int, default=0)
     ap.add_argument("--remove-soft-line-breaks", type=int, default=0)
@@ -884,11 +903,12 @@ def _main():
         data = write_r1cs(len(sym), rsa_main_constraints(sym), n_pub_out=0, n_pub_in=17, n_prv_in=34)
     else:
         c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=a.max_header, max_body=a.max_body, device=-1,
+                         ignore_body_hash_check=a.ignore_body_hash_check,
                          enable_header_masking=a.enable_header_masking, enable_body_masking=a.enable_body_masking,
                          remove_soft_line_breaks=a.remove_soft_line_breaks)
         sym = c.symbols()
         data = email_verifier_r1cs(sym, a.max_header, a.max_body, a.enable_header_masking, a.enable_body_masking,
-                                   a.remove_soft_line_breaks)
+                                   a.remove_soft_line_breaks, a.ignore_body_hash_check)
     with open(a.output, "wb") as f:
         f.write(data)
     if a.sym:
