@@ -104,20 +104,39 @@ def _anon_sites(node):
             yield from _anon_sites(x)
 
 
-def kept_v1_name_fn(root, sources=None):
-    """name -> kept-v1 name, for flat_walk names of `root`."""
-    al = anon_aliases(root, sources)
-    if not al:
-        return lambda n: n
-    keys = sorted(al, key=len, reverse=True)
-    rx = re.compile("|".join(re.escape(k) for k in keys))
-    # longest prefix wins; nested anonymous components need repeated substitution from the left
-    def fn(n):
-        # replace the longest matching prefix only (prefixes are full paths from `main`)
-        best = None
-        for k in keys:
-            if n.startswith(k):
-                best = k
-                break
-        return al[best] + n[len(best):] if best else n
-    return fn
+def flat_walk_kept(root, sources=None):
+    """flat_walk with kept-v1 component names: (kept_name, value, how, kind), O0 order."""
+    stack = [(root, "main")]
+    while stack:
+        inst, path = stack.pop()
+        sigs = list(inst.sigs.values())
+        outs = [s for s in sigs if s.kind == "out"]
+        ins = [s for s in sigs if s.kind == "in"]
+        mids = [s for s in sigs if s.kind == "mid"]
+        if inst.public:
+            ins = [s for s in ins if s.name in inst.public] + [s for s in ins if s.name not in inst.public]
+        for s in outs + ins + mids:
+            how = s.how
+            if not s.dims:
+                yield f"{path}.{s.name}", (s.vals[0] or 0), (how[0] if how else None), s.kind
+            else:
+                base = f"{path}.{s.name}["
+                for j, v in enumerate(s.vals):
+                    yield f"{base}{j}]", (v or 0), (how[j] if how else None), s.kind
+        sites = {}
+        for c in inst.subs:
+            m = _ANON_RE.match(c.name)
+            if m:
+                sites.setdefault(m.group(1), set()).add(int(m.group(3)))
+        if sites and sources is not None and inst.tname in sources:
+            for t, off in _anon_sites(sources[inst.tname][1]):
+                sites.setdefault(t, set()).add(off)
+        order = {t: sorted(v) for t, v in sites.items()}
+        for c in reversed(inst.subs):
+            m = _ANON_RE.match(c.name) if sites else None
+            if m:
+                t, off, idx = m.group(1), int(m.group(3)), m.group(4)
+                kname = KEPT_V1_ANON.get((inst.tname, t, order[t].index(off)), "anon_" + t) + idx
+            else:
+                kname = c.name
+            stack.append((c, path + "." + kname))
