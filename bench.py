@@ -4,21 +4,33 @@
 A "step" is one pass of the hot path over one batch of synthetic emails that is already
 resident in HBM: `EmailVerifier(1024,1536,121,17,0,0,0,0)`, 1 KB bodies, batch 4096 per GPU
 (BASELINE.json configs[2]), processed in tiles whose witnesses stay in HBM (a 2-tile ring that
-is overwritten; the host-delivered, PCIe-bound rate is discussed in DESIGN.md).
+is overwritten; the host-delivered, PCIe-bound rate is reported beside it, never as `value`).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel zk_expand (HBM-write
-bound): achieved = (32 W + I) bytes x emails per launch / average launch duration measured
-with HIP events on the launch stream inside the timed region.  `cpu_baseline` is the C
-oracle ("port", oracle/c) timed on this box's host cores on a bounded sample (rank 0, N=1).
+Rank 0 prints ONE JSON line:
+  roofline      dominant kernel zk_expand (HBM-write bound): achieved = (32 W + I) bytes x emails per
+                launch / average launch duration, HIP events on the launch stream inside the timed
+                region.  `traffic` = HBM bytes per launch from PMC counters collected IN THIS
+                INVOCATION (two separate `rocprofv3 --pmc` child passes of a 1-step run of the same
+                workload, WRITE_SIZE and FETCH_SIZE, corrected as MI355X_MICROARCH.md prescribes),
+                or null with the reason in `traffic_source`.
+  cpu_baseline  the C oracle ("port", oracle/c) built -O3 -march=native on this box, timed on its
+                host cores (all-core and single-thread), buffers pre-touched (rank 0, N=1 only).
+  other_configs BASELINE.json configs[1] (batch 256), configs[4] (maxBody 65536, batch 1024; fewer
+                steps) and the delivered-to-host (PCIe-inclusive) rate, measured in the same run.
 """
 import argparse
+import csv
 import ctypes
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +38,131 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "zk-email-verify_amd", "py"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+class Pipeline:
+    """Two-phase pipeline over one resident batch: the compute kernels of a sub-batch of `prep`
+    emails ("prepare": ~0.45 MB of compact image per email) run on one stream while the previous
+    sub-batch's witnesses are streamed out tile by tile ("expand", the HBM-bound kernel) on
+    another; images are ring-buffered, witnesses go to a 2-tile ring in HBM."""
+
+    def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=4, exp_prio=-1):
+        self.torch, self.c, self.dev, self.d_in = torch, c, dev, d_in
+        self.batch, self.tile, self.prep = batch, tile, prep
+        assert batch % prep == 0 and prep % tile == 0
+        self.nsub, self.tiles_per_sub = batch // prep, prep // tile
+        self.ntiles = batch // tile
+        self.rsa_throttle = rsa_throttle
+        self.d_out = [torch.empty(tile * c.witness_bytes, dtype=torch.uint8, device=dev) for _ in range(min(2, self.ntiles))]
+        self.d_status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.R = max(2, ring)
+        self.d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(self.R)]
+        # several prepare streams let the latency-bound prepare kernels of consecutive SMALL sub-batches overlap
+        self.s_preps = [torch.cuda.Stream(device=dev, priority=0) for _ in range(max(1, prep_streams))]
+        self.s_exp = torch.cuda.Stream(device=dev, priority=exp_prio)
+        self.ev_prep = [torch.cuda.Event() for _ in range(self.R)]
+        self.ev_exp = [torch.cuda.Event() for _ in range(self.R)]
+        self.j = 0
+        # per-email result rows (w[0..3] = 1, pubkeyHash, shaHi, shaLo) saved before the ring slot is reused
+        self.d_rows = torch.empty((batch, 128), dtype=torch.uint8, device=dev)
+
+    def step(self):
+        torch, c = self.torch, self.c
+        for sb in range(self.nsub):
+            j = self.j
+            b = j % self.R
+            s_prep = self.s_preps[j % len(self.s_preps)]
+            lo = sb * self.prep
+            if j >= self.R:
+                s_prep.wait_event(self.ev_exp[b])      # image buffer b is free again
+            # the very first prepare has nothing to overlap with: run it at full occupancy; later ones share
+            # the chip with the previous sub-batch's zk_expand and are throttled so expand keeps its wave slots
+            c.set_prepare_throttle(0 if j == 0 else self.rsa_throttle)
+            c.prepare_device(self.d_in[lo:lo + self.prep], self.prep, self.d_status[lo:lo + self.prep], self.d_scr[b], s_prep)
+            self.ev_prep[b].record(s_prep)
+            self.s_exp.wait_event(self.ev_prep[b])
+            with torch.cuda.stream(self.s_exp):
+                for t in range(self.tiles_per_sub):
+                    o = self.d_out[(sb * self.tiles_per_sub + t) % len(self.d_out)]
+                    c.expand_device(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp)
+                    self.d_rows[lo + t * self.tile:lo + (t + 1) * self.tile].copy_(o.view(self.tile, c.witness_bytes)[:, :128])
+            self.ev_exp[b].record(self.s_exp)
+            self.j = j + 1
+
+    def last_tile(self):
+        return self.d_out[(self.nsub * self.tiles_per_sub - 1) % len(self.d_out)]
+
+
+def resident_inputs(torch, c, dev, seed, distinct, batch, body_len):
+    from zkwg import synth
+    recs, fields = synth.packed_batch(c, seed=seed, n=distinct, body_len=body_len)
+    h_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).view(distinct, c.in_stride)
+    reps = (batch + distinct - 1) // distinct
+    return h_in, h_in.repeat(reps, 1)[:batch].contiguous().to(dev), fields
+
+
+def timed(torch, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def expand_roofline(c, tile):
+    summ = c.timing_summary()
+    ex_ms, ex_launches, _ = summ["zk_expand"]
+    bpe = 32 * c.W + c.in_stride
+    avg = ex_ms / max(ex_launches, 1)
+    gbs = bpe * tile / (avg * 1e-3) / 1e9
+    return summ, avg, ex_launches, gbs
+
+
+def pmc_traffic(args, tile, W):
+    """HBM bytes per zk_expand launch from PMC counters: two rocprofv3 child passes (WRITE_SIZE, then
+    FETCH_SIZE; --pmc with --kernel-trace only) of this script in --pmc-child mode (1 step of the same
+    workload).  Returns (bytes or None, source string)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found on this box"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="zkwg_pmc_", dir="/tmp")
+    try:
+        for ctr in ("WRITE_SIZE", "FETCH_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "1", "--warmup", "0",
+                   "--batch", str(args.batch), "--tile", str(tile), "--prep-batch", str(args.prep_batch),
+                   "--max-header", str(args.max_header), "--max-body", str(args.max_body),
+                   "--body-len", str(args.body_len), "--distinct", "64"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                   timeout=args.pmc_timeout)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {ctr} pass timed out after {args.pmc_timeout}s"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} pass failed (exit {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {ctr} pass wrote no counter_collection.csv"
+            got = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                   if row["Kernel_Name"].startswith("zk_expand") and row.get("Counter_Name", ctr) == ctr]
+            if not got:
+                return None, f"no zk_expand rows in the {ctr} pass"
+            vals[ctr] = (sum(got) / len(got), len(got))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # counters are in KiB; gfx950: FETCH_SIZE counts 64 B per 128 B request -> x2 (guide, HBM section)
+    write_b = vals["WRITE_SIZE"][0] * 1024.0
+    fetch_b = vals["FETCH_SIZE"][0] * 1024.0 * 2.0
+    src = (f"PMC, this invocation: rocprofv3 --kernel-trace --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate child passes, "
+           f"1 step of the same workload, {vals['WRITE_SIZE'][1]} zk_expand launches each); write {write_b / 1e9:.3f} GB + "
+           f"fetch (x2 gfx950 correction) {fetch_b / 1e9:.3f} GB per launch")
+    return write_b + fetch_b, src
 
 
 def main():
@@ -43,17 +180,21 @@ def main():
     ap.add_argument("--rsa-throttle", type=int, default=4, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap)")
     ap.add_argument("--remove-soft-line-breaks", type=int, default=0,
                     help="template flag removeSoftLineBreaks (flag-variant measurement; the headline config keeps 0)")
-    ap.add_argument("--prep-streams", type=int, default=1, help="streams the prepare launches alternate over (2 overlaps the latency-bound prepare kernels of consecutive small sub-batches)")
+    ap.add_argument("--prep-streams", type=int, default=1, help="streams the prepare launches alternate over")
     ap.add_argument("--ring", type=int, default=2, help="image buffers in flight (prepare runs this many sub-batches ahead)")
     ap.add_argument("--gather-wtns", type=int, default=0,
                     help="also gather this many full witnesses per rank and step on rank 0 over RCCL (N>1 only; "
                          "inside the timed region; default 0 = result table only, see DESIGN.md section 7)")
-    ap.add_argument("--cpu-sample", type=int, default=512, help="emails timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="emails timed for cpu_baseline (-1 = 8 per host thread, 0 = skip)")
+    ap.add_argument("--pmc-traffic", type=int, default=1, help="collect roofline.traffic with rocprofv3 --pmc child passes (N=1)")
+    ap.add_argument("--pmc-timeout", type=int, default=240)
+    ap.add_argument("--other-configs", type=int, default=1, help="also measure configs[1], configs[4] and the delivered rate (N=1)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
     import zkwg
-    from zkwg import synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,68 +223,30 @@ def main():
                      remove_soft_line_breaks=args.remove_soft_line_breaks)
     tile = min(args.tile, args.batch)
     assert args.batch % tile == 0
-    ntiles = args.batch // tile
     distinct = min(args.distinct, args.batch)
     assert tile % distinct == 0 or distinct % tile == 0
+    prep = min(args.prep_batch, args.batch)
 
     # synthetic inputs: `distinct` different signed emails per rank (seeded by rank), replicated to
     # fill the batch; resident in HBM before timing starts.
-    recs, fields = synth.packed_batch(c, seed=0x5A4B + rank, n=distinct, body_len=args.body_len)
-    h_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).view(distinct, c.in_stride)
-    reps = (args.batch + distinct - 1) // distinct
-    d_in = h_in.repeat(reps, 1)[:args.batch].contiguous().to(dev)
-    d_out = [torch.empty(tile * c.witness_bytes, dtype=torch.uint8, device=dev) for _ in range(min(2, ntiles))]
-    # Two-phase pipeline: the compute kernels of a sub-batch of `prep` emails ("prepare": ~0.45 MB of
-    # compact image per email) run on one stream while the previous sub-batch's witnesses are streamed
-    # out tile by tile ("expand", the HBM-bound kernel) on another; images are double-buffered.
-    prep = min(args.prep_batch, args.batch)
-    assert args.batch % prep == 0 and prep % tile == 0
-    nsub, tiles_per_sub = args.batch // prep, prep // tile
-    d_status = torch.zeros(args.batch, dtype=torch.int32, device=dev)
-    R = max(2, args.ring)
-    d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(R)]
-    prio = int(os.environ.get('ZKWG_BENCH_EXP_PRIO', '-1'))
-    # several prepare streams let the latency-bound prepare kernels of consecutive SMALL sub-batches overlap
-    # (batch 256: 63 k -> 81 k witnesses/s with 4); which of them share a hardware queue is up to the runtime
-    s_preps = [torch.cuda.Stream(device=dev, priority=0) for _ in range(max(1, args.prep_streams))]
-    s_exp = torch.cuda.Stream(device=dev, priority=prio)
-    ev_prep = [torch.cuda.Event() for _ in range(R)]
-    ev_exp = [torch.cuda.Event() for _ in range(R)]
-    state = {"j": 0, "table": None}
-    # per-email result rows (w[0..3] = 1, pubkeyHash, shaHi, shaLo) saved before the ring slot is reused
+    _, d_in, fields = resident_inputs(torch, c, dev, 0x5A4B + rank, distinct, args.batch, args.body_len)
+    prio = int(os.environ.get("ZKWG_BENCH_EXP_PRIO", "-1"))
+    pl = Pipeline(torch, c, dev, d_in, args.batch, tile, prep, ring=args.ring, prep_streams=args.prep_streams,
+                  rsa_throttle=args.rsa_throttle, exp_prio=prio)
     from zkwg import shard
-    d_rows = torch.empty((args.batch, 128), dtype=torch.uint8, device=dev)
+    state = {"table": None}
 
     def step():
-        for sb in range(nsub):
-            j = state["j"]
-            b = j % R
-            s_prep = s_preps[j % len(s_preps)]
-            lo = sb * prep
-            if j >= R:
-                s_prep.wait_event(ev_exp[b])      # image buffer b is free again
-            # the very first prepare has nothing to overlap with: run it at full occupancy; later ones share
-            # the chip with the previous sub-batch's zk_expand and are throttled so expand keeps its wave slots
-            c.set_prepare_throttle(0 if j == 0 else args.rsa_throttle)
-            c.prepare_device(d_in[lo:lo + prep], prep, d_status[lo:lo + prep], d_scr[b], s_prep)
-            ev_prep[b].record(s_prep)
-            s_exp.wait_event(ev_prep[b])
-            with torch.cuda.stream(s_exp):
-                for t in range(tiles_per_sub):
-                    o = d_out[(sb * tiles_per_sub + t) % len(d_out)]
-                    c.expand_device(d_in[lo:lo + prep], prep, d_scr[b], t * tile, tile, o, s_exp)
-                    d_rows[lo + t * tile:lo + (t + 1) * tile].copy_(o.view(tile, c.witness_bytes)[:, :128])
-            ev_exp[b].record(s_exp)
-            state["j"] = j + 1
-        with torch.cuda.stream(s_exp):
+        pl.step()
+        with torch.cuda.stream(pl.s_exp):
             # the only exchange step: gather the 100-byte/email result table on rank 0 (RCCL over xGMI)
-            table = shard.result_table(d_status, d_rows)
+            table = shard.result_table(pl.d_status, pl.d_rows)
             if dist is not None and backend != "nccl":
                 table = table.cpu()                     # gloo test hook: gather on the host
             state["table"] = shard.gather_table(dist, table, args.batch * world, rank, world) if dist is not None else table
             if dist is not None and args.gather_wtns > 0:
                 k = min(args.gather_wtns, tile)
-                src = d_out[(nsub * tiles_per_sub - 1) % len(d_out)].view(tile, c.witness_bytes)[:k]
+                src = pl.last_tile().view(tile, c.witness_bytes)[:k]
                 if backend != "nccl":
                     src = src.cpu()
                 shard.gather_witnesses(dist, src, rank, world, sink=(lambda r, off, t: None))
@@ -154,11 +257,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pmc_child:
+        # counter-collection child: the same launches, nothing printed (the parent parses rocprofv3's CSV)
+        for _ in range(max(1, args.steps)):
+            step()
+        torch.cuda.synchronize()
+        return
+
     for _ in range(args.warmup):
         step()
     barrier()
-    assert int(d_status.abs().sum().item()) == 0, "synthetic emails must all verify"
-    state["j"] = 0
+    assert int(pl.d_status.abs().sum().item()) == 0, "synthetic emails must all verify"
+    pl.j = 0
     c.set_timing(True)
     barrier()
     t0 = time.perf_counter()
@@ -170,25 +280,14 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    summ = c.timing_summary()
+    summ, ex_avg, ex_launches, achieved = expand_roofline(c, tile)
+    c.set_timing(False)
 
     if rank == 0:
         total_emails = args.batch * world * args.steps
         value = total_emails / dt
-        ex_ms, ex_launches, _ = summ["zk_expand"]
         bytes_per_email = 32 * c.W + c.in_stride
-        achieved = bytes_per_email * tile / (ex_ms / ex_launches * 1e-3) / 1e9
         kernels_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in summ.items()}
-        # HBM traffic of zk_expand from PMC counters: collected separately with rocprofv3 (--pmc passes
-        # cannot run inside this process) and committed under profiles/; reported only for the exact
-        # workload it was measured on.
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pm["tile"] == tile and pm["witness_len"] == c.W:
-                traffic = round(pm["traffic_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
-            pass
         res = {
             "metric": "EmailVerifier witnesses/sec", "value": round(value, 1), "unit": "witnesses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,27 +298,117 @@ def main():
                        "batch_per_gpu": args.batch, "tile": tile, "witness_len": c.W,
                        "witness_bytes": c.witness_bytes, "layout": "kept-v1", "parallelism": f"shard x{world}, result-table gather" + (f" + {args.gather_wtns} wtns/rank/step gathered" if args.gather_wtns and world > 1 else " only")},
             "roofline": {"bound": "hbm", "kernel": "zk_expand", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": bytes_per_email * tile, "avg_launch_ms": round(ex_ms / ex_launches, 4),
-                         "launches_timed": ex_launches},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "traffic_source": "not collected",
+                         "bytes_per_launch": bytes_per_email * tile, "avg_launch_ms": round(ex_avg, 4),
+                         "launches_timed": ex_launches, "launches_total": args.steps * (args.batch // tile)},
             "kernel_ms_per_launch": kernels_ms,
             "fr_field_ops_per_s": round(value * c.W, 1),
         }
-        if args.cpu_sample > 0 and world == 1:
-            from oracle import coracle
-            n = min(args.cpu_sample, distinct)
-            sub = {k: (v[:n] if isinstance(v, list) else v[:n * (len(v) // distinct)]) for k, v in fields.items()}
-            cores = os.cpu_count() or 1
-            # every witness fully written to (per-thread) host memory, like the GPU path writes HBM
-            buf = (ctypes.c_uint8 * (cores * 32 * c.W))()
-            W, st, sec = coracle.run_fields(args.max_header, args.max_body, 0, sub, n, threads=cores, out=buf,
-                                            per_thread_out=True)
-            assert W == c.W and st == [0] * n
-            res["cpu_baseline"] = {"value": round(n / sec, 2), "unit": "witnesses/s", "cores": cores, "kind": "port",
-                                   "sample": f"{n} of the same synthetic emails, C oracle (oracle/c), OpenMP over emails, witness written to host memory"}
+        single = world == 1
+        # free the main pipeline's HBM before the side measurements
+        del pl.d_out, pl.d_scr
+        torch.cuda.empty_cache()
+        if single and args.pmc_traffic:
+            t, src = pmc_traffic(args, tile, c.W)
+            res["roofline"]["traffic"] = None if t is None else round(t)
+            res["roofline"]["traffic_source"] = src
+            if t is not None:
+                res["roofline"]["traffic_over_algorithmic"] = round(t / (bytes_per_email * tile), 4)
+        elif not single:
+            res["roofline"]["traffic_source"] = "not collected (PMC passes run at N=1 only)"
+        if single and args.other_configs:
+            res["other_configs"] = other_configs(torch, zkwg, dev, local_rank, c, args)
+        if args.cpu_sample != 0 and single:
+            res["cpu_baseline"] = cpu_baseline(c, args, fields, distinct)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def other_configs(torch, zkwg, dev, local_rank, c, args):
+    """BASELINE.json configs[1] and configs[4] and the delivered-to-host rate, device-resident unless
+    said otherwise; short runs (the headline measurement above is the graded one)."""
+    out = {}
+    # configs[1]: same circuit, batch 256 (latency-bound prepare: 4 prepare streams, whole batch per launch)
+    try:
+        _, d_in, _ = resident_inputs(torch, c, dev, 0x5A4B + 101, 64, 256, args.body_len)
+        pl = Pipeline(torch, c, dev, d_in, 256, 256, 256, ring=4, prep_streams=4, rsa_throttle=args.rsa_throttle)
+        c.set_timing(True)
+        dt = timed(torch, pl.step, steps=20, warmup=3)
+        _, avg, n, gbs = expand_roofline(c, 256)
+        c.set_timing(False)
+        assert int(pl.d_status.abs().sum().item()) == 0
+        out["configs[1] batch=256"] = {"value": round(256 * 20 / dt, 1), "unit": "witnesses/s", "steps": 20,
+                                       "zk_expand_GBps": round(gbs, 1), "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4)}
+        del pl, d_in
+        torch.cuda.empty_cache()
+    except Exception as e:  # a side measurement must not lose the headline line
+        out["configs[1] batch=256"] = {"error": repr(e)[:200]}
+    # delivered to host (PCIe-inclusive): zkwg_calculate_batch with a pinned destination, double-buffered tiles
+    try:
+        n, t = 192, 64
+        h_in, _, _ = resident_inputs(torch, c, dev, 0x5A4B + 202, 64, n, args.body_len)
+        recs = bytes(h_in.repeat(3, 1)[:n].contiguous().numpy().tobytes())
+        sec = c.time_host_path(recs, n, max_tile=t, pinned=True)
+        out["delivered to pinned host memory"] = {"value": round(n / sec, 1), "unit": "witnesses/s",
+                                                  "GBps": round(n * c.witness_bytes / sec / 1e9, 2),
+                                                  "sample": f"{n} emails through zkwg_calculate_batch, tiles of {t}, PCIe-inclusive"}
+    except Exception as e:
+        out["delivered to pinned host memory"] = {"error": repr(e)[:200]}
+    # configs[4]: maxBody = 65536 (SHA-dominated), batch 1024, bodies 32K..65K-72; fewer steps
+    try:
+        c5 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=1024, max_body=65536, device=local_rank)
+        tile5 = 32
+        _, d_in, _ = resident_inputs(torch, c5, dev, 0x5A4B + 303, 16, 1024, 49152)
+        pl = Pipeline(torch, c5, dev, d_in, 1024, tile5, 128, ring=2, prep_streams=1, rsa_throttle=args.rsa_throttle)
+        c5.set_timing(True)
+        dt = timed(torch, pl.step, steps=2, warmup=1)
+        _, avg, nl, gbs = expand_roofline(c5, tile5)
+        c5.set_timing(False)
+        assert int(pl.d_status.abs().sum().item()) == 0
+        out["configs[4] maxBody=65536 batch=1024"] = {
+            "value": round(1024 * 2 / dt, 1), "unit": "witnesses/s", "steps": 2, "witness_len": c5.W,
+            "zk_expand_GBps": round(gbs, 1), "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4), "body_len": 49152}
+        del pl, d_in, c5
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["configs[4] maxBody=65536 batch=1024"] = {"error": repr(e)[:200]}
+    return out
+
+
+def cpu_baseline(c, args, fields, distinct):
+    """The C oracle (kind "port") on this box's host cores: -O3 -march=native build made here, per-thread
+    witness buffers pre-touched outside the timed region, >= 8 emails per thread, plus a single-thread
+    figure.  Every witness is fully written to host memory, like the GPU path writes HBM."""
+    from oracle import coracle
+    lib, build = coracle.load_native()
+    cores = os.cpu_count() or 1
+    n = args.cpu_sample if args.cpu_sample > 0 else 8 * cores
+    reps = (n + distinct - 1) // distinct
+
+    def take(k):
+        sub = {}
+        for key, v in fields.items():
+            if isinstance(v, list):
+                sub[key] = (v * reps)[:k]
+            else:
+                per = len(v) // distinct
+                sub[key] = (bytes(v) * reps)[:k * per]
+        return sub
+    buf = (ctypes.c_uint8 * (cores * 32 * c.W))()
+    W, st, sec = coracle.run_fields(args.max_header, args.max_body, 0, take(n), n, threads=cores, out=buf,
+                                    per_thread_out=True, lib=lib, pretouch=True)
+    assert W == c.W and st == [0] * n
+    n1 = 12
+    W, st1, sec1 = coracle.run_fields(args.max_header, args.max_body, 0, take(n1), n1, threads=1, out=buf,
+                                      per_thread_out=True, lib=lib, pretouch=True)
+    assert st1 == [0] * n1
+    return {"value": round(n / sec, 2), "unit": "witnesses/s", "cores": cores, "kind": "port",
+            "single_thread": round(n1 / sec1, 2), "build": build,
+            "sample": f"{n} emails ({n // cores} per thread) of the same synthetic workload, C oracle (oracle/c), OpenMP over "
+                      f"emails, per-thread witness buffers pre-touched, every witness fully written to host memory; "
+                      f"single_thread = {n1} emails on one core"}
 
 
 if __name__ == "__main__":

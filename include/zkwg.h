@@ -34,9 +34,14 @@
  * (packages/helpers/src/constants.ts:1), stored as 32-byte little-endian,
  * non-Montgomery field elements exactly as in a `.wtns` data section.
  *
- * Threading: a circuit handle is immutable after creation and may be shared; each
- * zkwg_calculate_* call is serialised on the HIP stream it is given (or the
- * handle's own stream).  No global state.
+ * Threading: the circuit description of a handle is immutable after creation.  The handle also
+ * owns launch bookkeeping (timing event rings, the removeSoftLineBreaks merge-chain slots, the
+ * host-path staging buffers); the device entry points take an internal lock around it and select
+ * the handle's device themselves (the caller's current HIP device is restored on return), so a
+ * handle may be shared by threads that launch on different streams.  Ordering between a
+ * zkwg_prepare_device and the zkwg_expand_device that reads its scratch buffer is the caller's
+ * (same stream, or an event).  zkwg_calculate_batch (host buffers) runs one call at a time per
+ * handle.  No global state except zkwg_last_error (thread-local).
  */
 #ifndef ZKWG_H
 #define ZKWG_H
@@ -88,7 +93,8 @@ enum zkwg_input_field {
   ZKWG_IN_HEADER_MASK = 9,    /* u8[max_header]  headerMask (enable_header_masking)  */
   ZKWG_IN_BODY_MASK = 10,     /* u8[max_body]    bodyMask   (enable_body_masking)    */
   ZKWG_IN_DECODED_BODY = 11,  /* u8[max_body]    decodedEmailBodyIn (remove_soft_line_breaks) */
-  ZKWG_IN_NFIELDS = 12
+  ZKWG_IN_RANGE_FLAGS = 12,   /* u32 bit f = an element of field f did not fit its packed slot (generic path)  */
+  ZKWG_IN_NFIELDS = 13
 };
 
 /* Per-email status: circom_runtime exception codes. */
@@ -145,6 +151,20 @@ int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* record,
                     const uint8_t* precomputed_sha, const uint8_t* pubkey_limbs,
                     const uint8_t* signature_limbs, const uint8_t* message_limbs,
                     uint32_t body_hash_index);
+/* Generic input path: `CircuitInput` values are arbitrary field elements
+ * (packages/helpers/src/input-generators.ts:6-18; circom_runtime normalises each one mod r and
+ * stores it as a full 32-byte element), while the packed record keeps bytes / u32 / 128-bit limbs.
+ * zkwg_pack_field takes `count` elements of input field `field` (ZKWG_IN_*) as 32-byte
+ * little-endian integers (any 256-bit value; reduced mod r here), starting at element `first` of
+ * that field, and writes them into the record.  An element that does not fit its slot keeps its
+ * low bits and sets bit `field` of the record's ZKWG_IN_RANGE_FLAGS word: the kernels then fail the
+ * email exactly where the circuit's own range check of that signal fails -- Num2Bits(8) of
+ * lib/sha.circom:27,60,70, Num2Bits(log2Ceil(max)) of email-verifier.circom:58,116, Num2Bits(n) of
+ * lib/rsa.circom:28,118,123, AssertBit of utils/bytes.circom:151-154, the RLC equality of
+ * helpers/remove-soft-line-breaks.circom:124 -- status 4, "Assert Failed".  Call after
+ * zkwg_pack_input (which clears the flags). */
+int zkwg_pack_field(const zkwg_circuit_t* c, uint8_t* record, int field, uint64_t first,
+                    const uint8_t* values32, uint64_t count);
 /* headerMask / bodyMask of one record (flag variants; either pointer may be NULL). */
 int zkwg_pack_masks(const zkwg_circuit_t* c, uint8_t* record, const uint8_t* header_mask, const uint8_t* body_mask);
 /* decodedEmailBodyIn of one record (remove_soft_line_breaks = 1): max_body bytes, the output of

@@ -16,7 +16,7 @@
 
 #define ZK_MAX_KERNELS 8
 #define ZK_RS_SLOTS 16
-#define ZK_EV_RING 64
+#define ZK_EV_RING 512   // launches whose HIP events are kept for zkwg_timing_summary
 
 struct zkwg_circuit {
   zkwg_config cfg;
@@ -42,6 +42,8 @@ struct zkwg_circuit {
   u32 xcd_remap;  // zk_expand workgroup -> portion mapping (ZKWG_XCD_REMAP)
   // host-buffer path: cached device staging buffers (double-buffered witnesses)
   std::mutex hb_mutex;
+  // launch bookkeeping (event rings, merge-chain slots, counters) of the device entry points
+  std::mutex dev_mutex;
   u8 *hb_in, *hb_out[2], *hb_scr;
   int* hb_status[2];
   u64 hb_tile;
@@ -61,6 +63,17 @@ struct zkwg_circuit {
 };
 
 // inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
+// Device entry points may be called from a thread whose current HIP device is not the handle's.
+struct ZkDeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit ZkDeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+  }
+  ~ZkDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 static void build_inv_table(u32 inv_half, std::vector<Fr>& tab) {
   const long long half = (long long)inv_half;
   tab.assign(2 * (u64)inv_half + 1, fr_zero());
@@ -224,14 +237,27 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   return ZKWG_RC_OK;
 }
 
+// no C++ exception may cross the C ABI (ctypes / N-API callers would abort)
+static int create_guarded(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
+                          const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out) {
+  try {
+    return create_impl(cfg, device, sym_text, sym_len, alias_text, alias_len, out);
+  } catch (const std::bad_alloc&) {
+    g_last_error = "out of host memory while building the circuit";
+    return ZKWG_RC_OOM;
+  } catch (const std::exception& e) {
+    g_last_error = std::string("circuit construction failed: ") + e.what();
+    return ZKWG_RC_BAD_CONFIG;
+  }
+}
 int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out) {
   if (cfg && cfg->layout != ZKWG_LAYOUT_KEPT_V1) { g_last_error = "layout SYM needs zkwg_circuit_create_sym"; return ZKWG_RC_BAD_CONFIG; }
-  return create_impl(cfg, device, nullptr, 0, nullptr, 0, out);
+  return create_guarded(cfg, device, nullptr, 0, nullptr, 0, out);
 }
 int zkwg_circuit_create_sym(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
                             const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out) {
   if (!sym_text) return ZKWG_RC_BAD_ARG;
-  return create_impl(cfg, device, sym_text, sym_len, alias_text, alias_len, out);
+  return create_guarded(cfg, device, sym_text, sym_len, alias_text, alias_len, out);
 }
 
 void zkwg_circuit_destroy(zkwg_circuit_t* c) {
@@ -291,6 +317,41 @@ int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header
   return ZKWG_RC_OK;
 }
 
+int zkwg_pack_field(const zkwg_circuit_t* c, uint8_t* rec, int field, uint64_t first, const uint8_t* values32,
+                    uint64_t count) {
+  if (!c || !rec || !values32 || field < 0 || field >= ZKWG_IN_RANGE_FLAGS) return ZKWG_RC_BAD_ARG;
+  const ZkSched& s = c->s;
+  u64 cap = 0;
+  u32 width = 1;   // bytes per packed element
+  switch (field) {
+    case ZKWG_IN_HEADER: cap = c->cfg.max_header; break;
+    case ZKWG_IN_BODY: cap = c->cfg.max_body; break;
+    case ZKWG_IN_PRECOMPUTED_SHA: cap = 32; break;
+    case ZKWG_IN_PUBKEY: case ZKWG_IN_SIGNATURE: case ZKWG_IN_MESSAGE: cap = 17; width = 16; break;
+    case ZKWG_IN_HEADER_LEN: case ZKWG_IN_BODY_LEN: case ZKWG_IN_BODY_HASH_INDEX: cap = 1; width = 4; break;
+    case ZKWG_IN_HEADER_MASK: cap = s.mask_header ? c->cfg.max_header : 0; break;
+    case ZKWG_IN_BODY_MASK: cap = s.mask_body ? c->cfg.max_body : 0; break;
+    case ZKWG_IN_DECODED_BODY: cap = s.rslb ? c->cfg.max_body : 0; break;
+  }
+  if (first > cap || count > cap - first) return ZKWG_RC_BAD_ARG;
+  u32 flags;
+  memcpy(&flags, rec + s.in_off[ZKWG_IN_RANGE_FLAGS], 4);
+  const Fr p = fr_p();
+  for (u64 i = 0; i < count; ++i) {
+    Fr v;
+    memcpy(v.l, values32 + 32 * i, 32);
+    while (fr_geq(v, p)) { u64 bw; v = fr_sub_raw(v, p, bw); }   // circom_runtime: normalize(BigInt(v), prime)
+    u8* dst = rec + s.in_off[field] + (first + i) * width;
+    bool fits;
+    if (width == 1) { fits = !(v.l[0] >> 8) && !v.l[1] && !v.l[2] && !v.l[3]; dst[0] = (u8)v.l[0]; }
+    else if (width == 4) { fits = !(v.l[0] >> 32) && !v.l[1] && !v.l[2] && !v.l[3]; const u32 w = (u32)v.l[0]; memcpy(dst, &w, 4); }
+    else { fits = !v.l[2] && !v.l[3]; memcpy(dst, v.l, 16); }
+    if (!fits) flags |= 1u << field;
+  }
+  memcpy(rec + s.in_off[ZKWG_IN_RANGE_FLAGS], &flags, 4);
+  return ZKWG_RC_OK;
+}
+
 int zkwg_pack_masks(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header_mask, const uint8_t* body_mask) {
   if (!c || !rec) return ZKWG_RC_BAD_ARG;
   if (header_mask && c->s.mask_header) memcpy(rec + c->s.in_off[ZKWG_IN_HEADER_MASK], header_mask, c->cfg.max_header);
@@ -309,6 +370,7 @@ int zkwg_set_prepare_throttle(zkwg_circuit_t* c, int rsa_wavefronts_per_cu) {
 }
 int zkwg_set_timing(zkwg_circuit_t* c, int enable) {
   if (!c) return ZKWG_RC_BAD_ARG;
+  std::lock_guard<std::mutex> lock(c->dev_mutex);
   c->timing = enable;
   c->ev_valid = false;
   c->prep_valid = false;
@@ -391,6 +453,9 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
   const ZkSched& s = c->s;
   if (n > 0x3fffffffull) return ZKWG_RC_BAD_ARG;
   if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_in & 15)) return ZKWG_RC_BAD_ARG;
+  std::lock_guard<std::mutex> lock(c->dev_mutex);
+  ZkDeviceGuard dg(c->device);
+  if (!dg.ok) return ZKWG_RC_HIP_ERROR;
   hipStream_t st = (hipStream_t)hip_stream;
   const u32 ne = (u32)n;
   ZkBufs B;
@@ -464,6 +529,9 @@ int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   const ZkSched& s = c->s;
   if (first + count > n || out_stride != s.W * 32 || count * (u64)s.nportions > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
   if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_out & 15)) return ZKWG_RC_BAD_ARG;
+  std::lock_guard<std::mutex> lock(c->dev_mutex);
+  ZkDeviceGuard dg(c->device);
+  if (!dg.ok) return ZKWG_RC_HIP_ERROR;
   hipStream_t st = (hipStream_t)hip_stream;
   ZkBufs B;
   fill_bufs(c, B, d_in, n, (void*)d_scratch);
@@ -574,6 +642,8 @@ int zkwg_generate_inputs_device(zkwg_circuit_t* c, const zkwg_dkim_batch* b, uin
   D.body_hash_b64 = b->body_hash_b64; D.pubkey_be = b->pubkey_be; D.signature_be = b->signature_be;
   D.selector = b->selector; D.header_stride = b->header_stride; D.body_stride = b->body_stride;
   D.selector_len = b->selector_len;
+  ZkDeviceGuard dg(c->device);
+  if (!dg.ok) return ZKWG_RC_HIP_ERROR;
   hipLaunchKernelGGL(zk_gen_inputs, dim3((u32)n), dim3(64), 0, (hipStream_t)hip_stream, c->s, D, (u8*)d_records,
                      (int*)d_gen_status, (u32)n);
   return hipGetLastError() == hipSuccess ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;

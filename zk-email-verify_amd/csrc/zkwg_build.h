@@ -31,6 +31,7 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
   s.in_off[ZKWG_IN_HEADER_LEN] = off; off += 4;
   s.in_off[ZKWG_IN_BODY_LEN] = off; off += 4;
   s.in_off[ZKWG_IN_BODY_HASH_INDEX] = off; off += 4;
+  s.in_off[ZKWG_IN_RANGE_FLAGS] = off; off += 4;   // generic input path: per-field "did not fit" bits
   off = (off + 15u) & ~15u;
   s.in_off[ZKWG_IN_HEADER_MASK] = off; off += cfg.enable_header_masking ? cfg.max_header : 0;
   s.in_off[ZKWG_IN_BODY_MASK] = off; off += cfg.enable_body_masking ? cfg.max_body : 0;
@@ -75,6 +76,10 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
       zk_walk_main_ev(w, s);
       max_small = std::max<u64>(max_small, 2100);
       max_small = std::max<u64>(max_small, (u64)cfg.max_header + 64);
+      // SelectRegexReveal's IsEqual(i, startIndex): every startIndex its range checks admit
+      // (startIndex + 43 < 2^sel_bits) must find |startIndex - i| in the table, also for a
+      // maxHeadersLength that is not a power of two
+      if (s.body) max_small = std::max<u64>(max_small, 1ull << s.sel_bits);
       max_small = std::max<u64>(max_small, std::max(s.fr[0].nblocks, s.fr[1].nblocks) + 2);
       break;
     case ZKWG_MAIN_RSA_VERIFIER:
@@ -181,7 +186,8 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
     if (widx == 0) continue;  // the constant-one wire (never listed by circom; tolerated)
     auto it = slot_of.find(name);
     if (it == slot_of.end()) { if (!unmatched++) first_unmatched = name; continue; }
-    if ((u64)widx >= (1ull << 32) - 1) { L.err = "witness index out of range"; return false; }
+    // a layout can only re-order / drop this schedule's own signals: indices beyond its length are bogus
+    if ((u64)widx >= ours.size()) { L.err = "witness index " + std::to_string(widx) + " exceeds the schedule's witness length"; return false; }
     if (L.dst[it->second] != 0xffffffffu && L.dst[it->second] != (u32)widx) { ++dup; continue; }
     L.dst[it->second] = (u32)widx;
     if ((u64)widx > maxw) maxw = (u64)widx;

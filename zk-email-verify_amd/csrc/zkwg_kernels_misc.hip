@@ -42,14 +42,14 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   if (lane == 0) {
     // BodyHashRegex DFA scan (zkwg_regex_core.h): states, live chain, helper signals, reveal0
     const u32 acc_count = zk_bh_dfa_scan(hdr, N, delta_l, stl, live, small + s.m_dfa_own, rev);
-    if (acc_count == 0) ok_sh = 0;                      // bhRegexMatch === 1
+    if (acc_count == 0) atomicAnd(&ok_sh, 0u);                      // bhRegexMatch === 1
     small[s.m_dfa_acc] = acc_count;
     small[s.m_bh_idx] = start;
     bits[s.b_shift] = start;
     u32 blh = 0;
     for (u32 n = N - 1; n > 0; n >>= 1) ++blh;
-    if (start >= (1u << blh)) ok_sh = 0;                // VarShiftLeft.n2b = Num2Bits(log2Ceil(N))
-    if ((u64)start + 43 >= (1ull << s.sel_bits)) ok_sh = 0;  // GreaterThan(bl) Num2Bits at i = 0
+    if (start >= (1u << blh)) atomicAnd(&ok_sh, 0u);                // VarShiftLeft.n2b = Num2Bits(log2Ceil(N))
+    if ((u64)start + 43 >= (1ull << s.sel_bits)) atomicAnd(&ok_sh, 0u);  // GreaterThan(bl) Num2Bits at i = 0
   }
   __syncthreads();
   for (u32 i = lane; i < N; i += 64) small[s.m_rev + i] = rev[i];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
     bool bad = false;
     if (i == start) bad = rev[i] == 0 || (i > 0 && rev[i - 1] != 0);
     if ((u64)i > (u64)start + 43 && rev[i] != 0) bad = true;
-    if (bad) ok_sh = 0;
+    if (bad) atomicAnd(&ok_sh, 0u);
   }
   // bhBase64[g] = VarShiftLeft(N, 44)(bhReveal, bodyHashIndex)[g] = rev[(g + shift) mod N]
   __shared__ u32 vals[44];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
     else if (ch == 61) v = 0;
     else valid = false;
     vals[lane] = v;
-    if (!valid) ok_sh = 0;                              // base64.circom:127
+    if (!valid) atomicAnd(&ok_sh, 0u);                              // base64.circom:127
   }
   __syncthreads();
   // computedBodyHashInts[i].out === headerBodyHash[i]  (email-verifier.circom:139-146)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
     u32 byte = k == 0 ? ((v0 << 2) | (v1 >> 4)) : (k == 1 ? (((v1 & 15) << 4) | (v2 >> 2)) : (((v2 & 3) << 6) | v3));
     u32 w = small[s.fr[1].m_digest + (lane >> 2)];
     u32 expect = (w >> (24 - 8 * (lane & 3))) & 0xff;
-    if ((byte & 0xff) != expect) ok_sh = 0;
+    if ((byte & 0xff) != expect) atomicAnd(&ok_sh, 0u);
   }
   __syncthreads();
   if (lane == 0 && !ok_sh) B.status[e] = 4;

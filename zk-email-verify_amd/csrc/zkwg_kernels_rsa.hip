@@ -16,7 +16,9 @@ __global__ __launch_bounds__(64) void zk_rsa(ZkSched s, ZkBufs B) {
   const u32* digest = s.rsa.msg_from_digest ? small + s.rsa.m_digest : nullptr;
   if (s.main_kind == 2 && threadIdx.x == 0) small[s.m_one] = 1;  // no SHA chain kernel in this main
   zk_rsa_email(S, s.rsa, rec, digest, bits, small, frv, lt_eq);
-  if (threadIdx.x == 0 && !S.ok) B.status[e] = 4;
+  // generic input path (RSA main has no SHA chain kernel to look at the range flags)
+  const bool range_bad = s.main_kind == 2 && *(const u32*)(rec + s.in_off[ZK_IN_RANGE_FLAGS]) != 0;
+  if (threadIdx.x == 0 && (!S.ok || range_bad)) B.status[e] = 4;
   if (s.main_kind == 0) {
     // pubkeyHash <== PoseidonLarge(n, k)(pubkey)   (email-verifier.circom:173)
     __shared__ ZkPosLds PS;

@@ -51,6 +51,9 @@ __global__ __launch_bounds__(64) void zk_sha_chain(ZkSched s, ZkBufs B) {
     for (u32 n = f.max_bytes - 1; n > 0; n >>= 1) ++bl;
     ok = ok && len < (1u << bl);   // (the zero-padding scan itself is spread over zk_sha_trace's lanes)
   }
+  // generic input path: an element that did not fit its packed slot fails the circuit's own range
+  // check of that signal (Num2Bits(8) / Num2Bits(121) / AssertBit / ..., include/zkwg.h zkwg_pack_field)
+  if (fi == 0 && *(const u32*)(rec + s.in_off[ZK_IN_RANGE_FLAGS]) != 0) ok = false;
   if (!ok) B.status[e] = 4;
 
   u32 st[8];

@@ -57,6 +57,9 @@ static inline bool zk_r1cs_parse(const u8* p, u64 len, ZkR1csHost& R) {
   const u8* q = hdr + 36;
   memcpy(&R.n_wires, q, 4); memcpy(&R.n_pub_out, q + 4, 4); memcpy(&R.n_pub_in, q + 8, 4); memcpy(&R.n_prv_in, q + 12, 4);
   memcpy(&R.n_labels, q + 16, 8); memcpy(&R.n_constraints, q + 24, 4);
+  // every linear combination takes at least its 4-byte term count: bound the header's claim by
+  // the section that is actually there before sizing anything from it
+  if (3ull * R.n_constraints * 4 > cons_len) return fail("constraint count exceeds the constraint section");
   R.row_ptr.assign(1, 0);
   R.row_ptr.reserve(3ull * R.n_constraints + 1);
   u64 cp = 0;

@@ -20,8 +20,17 @@ extern "C" {
 
 int zkwg_r1cs_load(const uint8_t* bytes, uint64_t len, int device, zkwg_r1cs_t** out) {
   if (!bytes || !out) return ZKWG_RC_BAD_ARG;
-  zkwg_r1cs* r = new zkwg_r1cs();
-  if (!zk_r1cs_parse(bytes, len, r->h)) { delete r; return ZKWG_RC_BAD_CONFIG; }
+  zkwg_r1cs* r = nullptr;
+  try {   // no C++ exception may cross the C ABI
+    r = new zkwg_r1cs();
+    if (!zk_r1cs_parse(bytes, len, r->h)) { delete r; return ZKWG_RC_BAD_CONFIG; }
+  } catch (const std::bad_alloc&) {
+    delete r;
+    return ZKWG_RC_OOM;
+  } catch (const std::exception&) {
+    delete r;
+    return ZKWG_RC_BAD_CONFIG;
+  }
   if (device >= 0) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete r; return ZKWG_RC_NO_DEVICE; }

@@ -137,6 +137,9 @@ struct ZkRsaLayout {
   ZkFpMulLayout mul[17];       // doublers[0..15], adder
 };
 
+// record field index of the generic-input-path range flags (include/zkwg.h ZKWG_IN_RANGE_FLAGS)
+#define ZK_IN_RANGE_FLAGS 12
+
 struct ZkSched {
   u32 main_kind;
   u32 n, k;
@@ -145,7 +148,7 @@ struct ZkSched {
   u32 total_blocks;      // sum of nblocks
   u32 hstates_per_email; // sum of (nblocks+1)
   u32 in_stride;         // bytes per input record
-  u32 in_off[12];        // enum zkwg_input_field -> byte offset
+  u32 in_off[13];        // enum zkwg_input_field -> byte offset (12 = ZK_IN_RANGE_FLAGS)
   u32 n_public;
   u32 nsegs;
   u32 portion;           // witness slots expanded by one workgroup of zk_expand

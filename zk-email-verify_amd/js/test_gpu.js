@@ -47,5 +47,47 @@ function shaPad(msg, max) {  // packages/helpers/src/sha-utils.ts:88-111
     const bad = w.slice(); bad[7] = 2n;
     await assert.rejects(r1.checkConstraints(bad), /Constraint doesn't match \(constraint 6\)/);
   }
+  // ---- EmailVerifier(576,192,121,17,0,0,0,0): the north_star host path Node -> N-API -> C-ABI -> HIP.
+  // Mirrors packages/circuits/tests/email-verifier.test.ts:43 (calculateWitness), :61-79 (tampered input
+  // -> "Assert Failed"); the witness is pinned by the SHA-256 of the literal oracle's witness
+  // (tests/golden/ev_576_192_case.json, made by tests/golden/make_ev_case.py).
+  {
+    const fs = require('fs');
+    const path = require('path');
+    const kase = JSON.parse(fs.readFileSync(path.join(__dirname, '..', '..', 'tests', 'golden', 'ev_576_192_case.json')));
+    const ev = new z.Circuit({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody }, 0);
+    assert.strictEqual(ev.witnessLen, kase.witnessLen);
+    const evc = new z.WitnessCalculator(ev);
+    const w = await evc.calculateWitness(kase.input, true);
+    assert.strictEqual(w.length, kase.witnessLen);
+    assert.strictEqual(w[0], 1n);
+    assert.strictEqual(w[1].toString(), kase.pubkeyHash);   // assertOut(witness, {pubkeyHash}) of :188-207
+    assert.strictEqual(w[2].toString(), kase.shaHi);
+    assert.strictEqual(w[3].toString(), kase.shaLo);
+    const bin = await evc.calculateBinWitness(kase.input);
+    assert.strictEqual(crypto.createHash('sha256').update(bin).digest('hex'), kase.witnessSha256);
+    const wt = await evc.calculateWTNSBin(kase.input);
+    assert.strictEqual(Buffer.from(wt.slice(0, 4)).toString(), 'wtns');
+    assert.strictEqual(wt.length, ev.wtnsSize);
+    // email-verifier.test.ts:61-79: an invalid (tampered) header byte must throw "Assert Failed"
+    const tampered = Object.assign({}, kase.input, { emailHeader: kase.input.emailHeader.slice() });
+    tampered.emailHeader[10] = String(Number(tampered.emailHeader[10]) ^ 1);
+    await assert.rejects(evc.calculateWitness(tampered), /Assert Failed/);
+    // :81-102 style: non-zero byte in the padding after emailHeaderLength
+    const padded = Object.assign({}, kase.input, { emailHeader: kase.input.emailHeader.slice() });
+    padded.emailHeader[kase.maxHeader - 1] = '1';
+    await assert.rejects(evc.calculateWitness(padded), /Assert Failed/);
+    // generic input path: values that are not bytes / do not fit the packed record reach the circuit's own
+    // range checks (Num2Bits(8) lib/sha.circom:27; Num2Bits(10) email-verifier.circom:58) -> "Assert Failed"
+    const big = Object.assign({}, kase.input, { emailHeader: kase.input.emailHeader.slice() });
+    big.emailHeader[0] = '256';
+    await assert.rejects(evc.calculateWitness(big), /Assert Failed/);
+    const neg = Object.assign({}, kase.input, { emailHeaderLength: (z.FIELD_MODULUS - 1n).toString() });
+    await assert.rejects(evc.calculateWitness(neg), /Assert Failed/);
+    // batch: one bad email never aborts the others
+    const b3 = await evc.calculateBatch([kase.input, tampered, big, kase.input]);
+    assert.deepStrictEqual(Array.from(b3.status), [0, 4, 4, 0]);
+    assert.ok(Buffer.from(b3.wtns[0]).equals(Buffer.from(bin)) && Buffer.from(b3.wtns[3]).equals(Buffer.from(bin)));
+  }
   console.log('js gpu ok');
 })().catch((e) => { console.error(e); process.exit(1); });

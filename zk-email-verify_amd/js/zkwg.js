@@ -17,7 +17,7 @@ const addon = require(path.join(__dirname, 'zkwg_addon.node'));
 
 const FIELD_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
 const MAIN_EMAIL_VERIFIER = 0, MAIN_SHA256_BYTES = 1, MAIN_RSA_VERIFIER = 2;
-const IN = { HEADER: 0, BODY: 1, PRECOMPUTED_SHA: 2, PUBKEY: 3, SIGNATURE: 4, MESSAGE: 5, HEADER_LEN: 6, BODY_LEN: 7, BODY_HASH_INDEX: 8, HEADER_MASK: 9, BODY_MASK: 10, DECODED_BODY: 11 };
+const IN = { HEADER: 0, BODY: 1, PRECOMPUTED_SHA: 2, PUBKEY: 3, SIGNATURE: 4, MESSAGE: 5, HEADER_LEN: 6, BODY_LEN: 7, BODY_HASH_INDEX: 8, HEADER_MASK: 9, BODY_MASK: 10, DECODED_BODY: 11, RANGE_FLAGS: 12 };
 
 function norm(v) {
   let x = BigInt(v) % FIELD_MODULUS;
@@ -65,19 +65,27 @@ class Circuit {
     if (nset !== want) throw new Error('Not all inputs have been set. Only ' + nset + ' out of ' + want);
     const rec = Buffer.alloc(this.inputStride);
     const off = this.offsets;
+    const handle = this.handle;
+    // A value that does not fit its packed slot goes through the generic 32-byte-per-signal path
+    // (addon.packField -> zkwg_pack_field): the record keeps the low bits and a range flag, and the
+    // circuit's own range check of that signal then fails the email with "Assert Failed" -- what
+    // circom_runtime does for the same input (SURVEY.md 8b2/8b3).
+    const generic = (field, vals) => {
+      const buf = Buffer.alloc(32 * vals.length);
+      vals.forEach((v, i) => { let x = v; for (let k = 0; k < 4; ++k) { buf.writeBigUInt64LE(x & 0xffffffffffffffffn, 32 * i + 8 * k); x >>= 64n; } });
+      addon.packField(handle, rec, field, 0, buf);
+    };
     const bytes = (field, vals, what) => {
-      vals.forEach((v, i) => {
-        if (v > 255n) throw new Error(what + ': value ' + v + ' does not fit the packed byte input path');
-        rec[off[field] + i] = Number(v);
-      });
+      if (vals.some((v) => v > 255n)) return generic(field, vals);
+      vals.forEach((v, i) => { rec[off[field] + i] = Number(v); });
     };
     const u32 = (field, v, what) => {
-      if (v >> 32n) throw new Error(what + ': value does not fit the packed u32 input path');
+      if (v >> 32n) return generic(field, [v]);
       rec.writeUInt32LE(Number(v), off[field]);
     };
     const limbs = (field, vals, what) => {
+      if (vals.some((v) => (v >> 128n) !== 0n)) return generic(field, vals);
       vals.forEach((v, i) => {
-        if (v >> 128n) throw new Error(what + ': limb does not fit the packed 128-bit input path');
         rec.writeBigUInt64LE(v & 0xffffffffffffffffn, off[field] + 16 * i);
         rec.writeBigUInt64LE(v >> 64n, off[field] + 16 * i + 8);
       });
@@ -111,7 +119,9 @@ class WitnessCalculator {
     if (r.status[0] !== 0) throw new Error(addon.strerror(r.status[0]));
     return r.witness;
   }
-  /** -> Promise<bigint[]>  (circom_runtime calculateWitness) */
+  /** -> Promise<bigint[]>  (circom_runtime calculateWitness).  `sanityCheck` is accepted for signature
+   * compatibility: circom_runtime uses it to turn the WASM's `assert` instructions on; here every
+   * `===` / assert of the circuit is always evaluated (a failing email always reports "Assert Failed"). */
   async calculateWitness(input, sanityCheck) { return addon.witnessToBigInts(await this._one(input, false)); }
   /** -> Promise<Uint8Array> of 32*W bytes (circom_runtime calculateBinWitness) */
   async calculateBinWitness(input, sanityCheck) { return this._one(input, false); }

@@ -210,6 +210,25 @@ static napi_value WitnessToBigInts(napi_env env, napi_callback_info info) {
   return arr;
 }
 
+/* packField(circuit, record: Buffer, field, first, values32: Buffer) -- generic 32-byte-per-signal input
+ * path of include/zkwg.h (zkwg_pack_field): values that do not fit their packed slot raise the range flag */
+static napi_value PackField(napi_env env, napi_callback_info info) {
+  size_t argc = 5; napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkwg_circuit_t* c = unwrap(env, argv[0]);
+  if (!c) return NULL;
+  void* rec = NULL; size_t rec_len = 0; void* vals = NULL; size_t vals_len = 0;
+  int32_t field = 0; double first = 0;
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &rec, &rec_len));
+  NAPI_OK(napi_get_value_int32(env, argv[2], &field));
+  NAPI_OK(napi_get_value_double(env, argv[3], &first));
+  NAPI_OK(napi_get_buffer_info(env, argv[4], &vals, &vals_len));
+  if (rec_len < zkwg_input_stride(c) || vals_len % 32 != 0) { napi_throw_range_error(env, NULL, "zkwg: packField buffer sizes"); return NULL; }
+  int rc = zkwg_pack_field(c, (uint8_t*)rec, field, (uint64_t)first, (const uint8_t*)vals, vals_len / 32);
+  if (rc != ZKWG_RC_OK) { napi_throw_error(env, NULL, zkwg_strerror(rc)); return NULL; }
+  return NULL;
+}
+
 static napi_value StrError(napi_env env, napi_callback_info info) {
   size_t argc = 1; napi_value argv[1]; int32_t code = 0; napi_value s;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -289,6 +308,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"calculateBatch", NULL, CalculateBatch, NULL, NULL, NULL, napi_default, NULL},
       {"witnessToBigInts", NULL, WitnessToBigInts, NULL, NULL, NULL, napi_default, NULL},
       {"strerror", NULL, StrError, NULL, NULL, NULL, napi_default, NULL},
+      {"packField", NULL, PackField, NULL, NULL, NULL, napi_default, NULL},
       {"symText", NULL, SymText, NULL, NULL, NULL, napi_default, NULL},
       {"r1csLoad", NULL, R1csLoad, NULL, NULL, NULL, napi_default, NULL},
       {"r1csCheck", NULL, R1csCheck, NULL, NULL, NULL, napi_default, NULL},

@@ -44,6 +44,12 @@ def _limbs_bytes(vals, n_limbs=17):
     return bytes(out)
 
 
+# CircuitInput signal name -> packed record field (include/zkwg.h enum zkwg_input_field)
+_FIELD_OF = {"emailHeader": 0, "paddedIn": 0, "emailBody": 1, "precomputedSHA": 2, "pubkey": 3, "modulus": 3,
+             "signature": 4, "message": 5, "emailHeaderLength": 6, "paddedInLength": 6, "emailBodyLength": 7,
+             "bodyHashIndex": 8, "headerMask": 9, "bodyMask": 10, "decodedEmailBodyIn": 11}
+
+
 class Circuit:
     """A compiled circuit handle (`component main = ...` with its template parameters)."""
 
@@ -120,16 +126,28 @@ class Circuit:
         if len(flat) != len(sizes):
             raise ZkwgError(f"Not all inputs have been set. Only {len(flat)} out of {len(sizes)}")
 
+        # A value that does not fit its packed slot goes through the generic 32-byte-per-signal path
+        # (zkwg_pack_field, after the packed fields are written): the record keeps its low bits plus a
+        # range flag and the circuit's own range check of that signal fails the email ("Assert Failed"),
+        # as circom_runtime does for the same input.
+        generic = []
+
         def as_bytes(vals, what):
-            for v in vals:
-                if v > 255:
-                    raise ZkwgError(f"{what}: value {v} does not fit the packed byte input path")
+            if any(v > 255 for v in vals):
+                generic.append((_FIELD_OF[what], vals))
+                return bytes(v & 0xFF for v in vals)
             return bytes(vals)
 
         def as_u32(v, what):
             if v >> 32:
-                raise ZkwgError(f"{what}: value does not fit the packed u32 input path")
+                generic.append((_FIELD_OF[what], [v]))
+                return v & 0xFFFFFFFF
             return v
+
+        def as_limbs(vals, what):
+            if any(v >> 128 for v in vals):
+                generic.append((_FIELD_OF[what], vals))
+            return _limbs_bytes([v & ((1 << 128) - 1) for v in vals])
 
         c = self.cfg
         rec = (C.c_uint8 * self.in_stride)()
@@ -139,12 +157,12 @@ class Circuit:
             header = as_bytes(flat["paddedIn"], "paddedIn")
             hlen = as_u32(flat["paddedInLength"][0], "paddedInLength")
         elif c.main_kind == MAIN_RSA_VERIFIER:
-            msg = _limbs_bytes(flat["message"]); sig = _limbs_bytes(flat["signature"])
-            pub = _limbs_bytes(flat["modulus"])
+            msg = as_limbs(flat["message"], "message"); sig = as_limbs(flat["signature"], "signature")
+            pub = as_limbs(flat["modulus"], "modulus")
         else:
             header = as_bytes(flat["emailHeader"], "emailHeader")
             hlen = as_u32(flat["emailHeaderLength"][0], "emailHeaderLength")
-            pub = _limbs_bytes(flat["pubkey"]); sig = _limbs_bytes(flat["signature"])
+            pub = as_limbs(flat["pubkey"], "pubkey"); sig = as_limbs(flat["signature"], "signature")
             if not c.ignore_body_hash_check:
                 body = as_bytes(flat["emailBody"], "emailBody")
                 blen = as_u32(flat["emailBodyLength"][0], "emailBodyLength")
@@ -157,6 +175,9 @@ class Circuit:
             _check(self.lib.zkwg_pack_masks(self.h, rec, hm, bm))
         if c.main_kind == MAIN_EMAIL_VERIFIER and c.remove_soft_line_breaks:
             _check(self.lib.zkwg_pack_decoded_body(self.h, rec, as_bytes(flat["decodedEmailBodyIn"], "decodedEmailBodyIn")))
+        for field, vals in generic:
+            buf = b"".join(int(v).to_bytes(32, "little") for v in vals)
+            _check(self.lib.zkwg_pack_field(self.h, rec, field, 0, buf, len(vals)))
         return bytes(rec)
 
     # -- batch calculation -------------------------------------------------------------------
@@ -168,6 +189,36 @@ class Circuit:
         out = (C.c_uint8 * (n * self.witness_bytes))() if want_witness else None
         _check(self.lib.zkwg_calculate_batch(self.h, records, n, out, self.witness_bytes, status, max_tile))
         return (bytes(out) if want_witness else None), list(status)
+
+    def time_host_path(self, records, n, max_tile=64, pinned=True, repeats=2):
+        """Seconds of one zkwg_calculate_batch call that delivers n witnesses to host memory
+        (pinned via zkwg_alloc_pinned, or pageable); the first call (staging-buffer allocation) is
+        not the one reported."""
+        import time
+        nbytes = n * self.witness_bytes
+        status = (C.c_int32 * n)()
+        ptr = None
+        if pinned:
+            self.lib.zkwg_alloc_pinned.restype = C.c_void_p
+            ptr = self.lib.zkwg_alloc_pinned(nbytes)
+            if not ptr:
+                raise ZkwgError("zkwg_alloc_pinned failed")
+            out = C.cast(ptr, C.POINTER(C.c_uint8))
+        else:
+            out = (C.c_uint8 * nbytes)()
+        try:
+            dt = None
+            for _ in range(max(1, repeats)):
+                t0 = time.perf_counter()
+                _check(self.lib.zkwg_calculate_batch(self.h, records, n, out, self.witness_bytes, status, max_tile))
+                dt = time.perf_counter() - t0
+            if any(status):
+                raise ZkwgError("host path: a synthetic email did not verify")
+            return dt
+        finally:
+            if ptr:
+                self.lib.zkwg_free_pinned.argtypes = [C.c_void_p]
+                self.lib.zkwg_free_pinned(ptr)
 
     def calculate_batch_device(self, d_in, n, d_out, d_status, d_scratch, stream=None):
         """Device-resident launch; arguments are torch CUDA tensors (plumbing only)."""

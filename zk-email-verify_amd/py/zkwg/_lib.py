@@ -34,7 +34,8 @@ class DkimBatch(C.Structure):
 
 MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER = 0, 1, 2
 (IN_HEADER, IN_BODY, IN_PRECOMPUTED_SHA, IN_PUBKEY, IN_SIGNATURE, IN_MESSAGE,
- IN_HEADER_LEN, IN_BODY_LEN, IN_BODY_HASH_INDEX, IN_HEADER_MASK, IN_BODY_MASK, IN_DECODED_BODY) = range(12)
+ IN_HEADER_LEN, IN_BODY_LEN, IN_BODY_HASH_INDEX, IN_HEADER_MASK, IN_BODY_MASK, IN_DECODED_BODY,
+ IN_RANGE_FLAGS) = range(13)
 
 _lib = None
 
@@ -69,6 +70,7 @@ def load():
         "zkwg_input_offset": (u64, [vp, i32]),
         "zkwg_scratch_bytes": (u64, [vp, u64]),
         "zkwg_pack_input": (i32, [vp, vp, vp, u32, vp, u32, vp, vp, vp, vp, u32]),
+        "zkwg_pack_field": (i32, [vp, vp, i32, u64, vp, u64]),
         "zkwg_pack_masks": (i32, [vp, vp, vp, vp]),
         "zkwg_pack_decoded_body": (i32, [vp, vp, vp]),
         "zkwg_calculate_batch": (i32, [vp, vp, u64, vp, u64, vp, u64]),
@@ -106,7 +108,7 @@ def load():
 EXPORTS = [
     "zkwg_abi_version", "zkwg_strerror", "zkwg_circuit_create", "zkwg_circuit_create_sym", "zkwg_last_error", "zkwg_circuit_destroy",
     "zkwg_witness_len", "zkwg_witness_bytes", "zkwg_num_public", "zkwg_input_stride",
-    "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_pack_input", "zkwg_pack_masks", "zkwg_pack_decoded_body", "zkwg_calculate_batch",
+    "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_pack_input", "zkwg_pack_field", "zkwg_pack_masks", "zkwg_pack_decoded_body", "zkwg_calculate_batch",
     "zkwg_generate_inputs_device", "zkwg_alloc_pinned", "zkwg_free_pinned", "zkwg_calculate_batch_device", "zkwg_prepare_device", "zkwg_expand_device", "zkwg_set_prepare_throttle", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_timing_summary", "zkwg_num_kernels",
     "zkwg_kernel_name", "zkwg_kernel_slots", "zkwg_wtns_size", "zkwg_write_wtns", "zkwg_write_sym",
     "zkwg_r1cs_load", "zkwg_r1cs_destroy", "zkwg_r1cs_info", "zkwg_check_constraints_device", "zkwg_check_constraints",
