@@ -24,7 +24,7 @@ struct zkwg_circuit {
   int device;
   Fr* d_invtab;
   std::vector<std::string> sym_names;  // layout SYM: witness index -> name
-  Fr* d_pos;      // Poseidon(9): C[680] then M[100]
+  Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
   Fr* d_pos_rs;   // removeSoftLineBreaks: Poseidon(16) then Poseidon(2) sparse-round tables
   ZkSeg* d_segs;
@@ -159,15 +159,16 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     c->cfg.layout = ZKWG_LAYOUT_SYM;
   }
   // kernel table (launch order)
-  c->n_kernels = 5;
+  c->n_kernels = 6;
   c->kname[0] = "zk_sha_chain"; c->kslots[0] = 0;
   c->kname[1] = "zk_sha_trace"; c->kslots[1] = 0;
   c->kname[2] = "zk_misc_ev"; c->kslots[2] = 0;
   c->kname[3] = "zk_rsa"; c->kslots[3] = 0;
+  c->kname[4] = "zk_poseidon9"; c->kslots[4] = 0;
   if (c->s.rslb) {
-    c->n_kernels = 7;
-    c->kname[4] = "zk_rslb_chunks"; c->kslots[4] = 0;
-    c->kname[5] = "zk_rslb_chain"; c->kslots[5] = 0;
+    c->n_kernels = 8;
+    c->kname[5] = "zk_rslb_chunks"; c->kslots[5] = 0;
+    c->kname[6] = "zk_rslb_chain"; c->kslots[6] = 0;
   }
   c->kname[c->n_kernels - 1] = "zk_expand"; c->kslots[c->n_kernels - 1] = c->s.W;
   if (device >= 0) {
@@ -185,11 +186,11 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
          hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(ZkSeg), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(c->d_first_seg, c->first_seg.data(), c->first_seg.size() * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess;
     if (ok && c->s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER) {
-      std::vector<Fr> C, M;
+      std::vector<Fr> C, M, t10;
       build_poseidon_constants(10, 8, 60, C, M);
-      C.insert(C.end(), M.begin(), M.end());
-      ok = hipMalloc((void**)&c->d_pos, C.size() * sizeof(Fr)) == hipSuccess &&
-           hipMemcpy(c->d_pos, C.data(), C.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
+      ok = zk_build_poseidon_sparse(10, 60, C, M, t10) &&
+           hipMalloc((void**)&c->d_pos, t10.size() * sizeof(Fr)) == hipSuccess &&
+           hipMemcpy(c->d_pos, t10.data(), t10.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok && c->s.rslb) {
       std::vector<Fr> C, M, t16, t2;
@@ -432,7 +433,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.frv = (Fr*)scr;
   B.invtab = c->d_invtab;
   B.pos_c = c->d_pos;
-  B.pos_m = c->d_pos ? c->d_pos + 680 : nullptr;
+  B.pos_m = nullptr;
   B.pos16 = c->d_pos_rs;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
@@ -491,6 +492,9 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     }
     hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), dyn, st, s, B);
   }
+  if (tm) hipEventRecord(evs[++ki], st);
+  if (s.rsa.present && s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER)
+    hipLaunchKernelGGL(zk_poseidon9, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
   if (s.rslb) {
     // removeSoftLineBreaks: chunk hashes (one lane per 16-byte chunk), then the serial merge chain + scans
     if (tm) hipEventRecord(evs[++ki], st);

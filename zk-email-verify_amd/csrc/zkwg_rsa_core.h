@@ -47,6 +47,7 @@ struct ZkRsaLds {           // per-wave working set (LDS on the GPU)
   u64 a121[ZK_RSA_K][2], b121[ZK_RSA_K][2], p121[ZK_RSA_K][2], q121[ZK_RSA_K][2], r121[ZK_RSA_K][2];
   u64 s121[ZK_RSA_K][2], m121[ZK_RSA_K][2];  // signature, message
   u256s tt[33];
+  u256s tq[33];             // device path: column sums of p*q (tt holds those of a*b)
   u32 L;                    // bit length of the modulus
   u32 ok;                   // assertion flag (0 = some constraint failed)
 };

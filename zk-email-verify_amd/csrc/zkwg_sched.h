@@ -218,8 +218,8 @@ struct ZkBufs {
   u32* small;            // image: small integers  [n_emails][img_small]
   Fr* frv;               // image: field elements  [n_emails][img_fr]
   const Fr* invtab;      // d^-1 for d in [-inv_half, inv_half]
-  const Fr* pos_c;       // Poseidon(9) round constants (Montgomery form), 680
-  const Fr* pos_m;       // Poseidon(9) MDS matrix (Montgomery form), 10 x 10 row-major
+  const Fr* pos_c;       // Poseidon(9) sparse-round table (zkwg_poseidon_sparse.h layout, t = 10, R_P = 60)
+  const Fr* pos_m;       // unused (kept for layout stability)
   const Fr* pos16;       // Poseidon(16) sparse-round table (zkwg_poseidon_sparse.h), removeSoftLineBreaks only
   const Fr* pos2;        // Poseidon(2)  sparse-round table
   const ZkSeg* segs;     // segment table
