@@ -383,7 +383,17 @@ def cpu_baseline(c, args, fields, distinct):
     figure.  Every witness is fully written to host memory, like the GPU path writes HBM."""
     from oracle import coracle
     lib, build = coracle.load_native()
-    cores = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    quota = None
+    try:   # cgroup v2 CPU quota: "<quota> <period>" or "max <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(q) // int(per))
+    except (OSError, ValueError):
+        pass
+    if quota is not None:
+        cores = min(cores, quota)   # more runnable threads than the quota only get throttled
     n = args.cpu_sample if args.cpu_sample > 0 else 8 * cores
     reps = (n + distinct - 1) // distinct
 
@@ -406,6 +416,7 @@ def cpu_baseline(c, args, fields, distinct):
     assert st1 == [0] * n1
     return {"value": round(n / sec, 2), "unit": "witnesses/s", "cores": cores, "kind": "port",
             "single_thread": round(n1 / sec1, 2), "build": build,
+            "host": f"{logical} logical CPUs, cgroup CPU quota {quota if quota is not None else 'none'}; threads used = cores",
             "sample": f"{n} emails ({n // cores} per thread) of the same synthetic workload, C oracle (oracle/c), OpenMP over "
                       f"emails, per-thread witness buffers pre-touched, every witness fully written to host memory; "
                       f"single_thread = {n1} emails on one core"}
