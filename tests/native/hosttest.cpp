@@ -96,3 +96,5 @@ uint32_t ht_regex_scan(const uint8_t* msg, uint32_t n, uint32_t* rev, uint32_t* 
 void ht_fr_mul(const void* a, const void* b, void* out) { *(Fr*)out = fr_mul_std(*(const Fr*)a, *(const Fr*)b); }
 void ht_fr_inv(const void* a, void* out) { *(Fr*)out = fr_inv_std(*(const Fr*)a); }
 }
+#include "zkwg_fr_inv.h"
+extern "C" void ht_fr_inv_by(const void* a, void* out) { *(Fr*)out = fr_inv_by(*(const Fr*)a); }

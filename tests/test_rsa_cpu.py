@@ -73,3 +73,19 @@ def test_rsa_2048_synthetic_key():
     ok, wit = run_host_rsa(msg, limbs(sig), limbs(key["n"]))
     assert ok == 1
     assert wit == oracle_rsa(msg, limbs(sig), limbs(key["n"]))
+
+
+def test_safegcd_inverse_matches_fermat():
+    # zkwg_fr_inv.h (Bernstein-Yang division steps, 30-bit limbs): the per-lane inversion of zk_rsa
+    import random
+    lib = hosttest.load()
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    rng = random.Random(1)
+    cases = [0, 1, 2, 3, P - 1, P - 2, (P + 1) // 2, 1 << 253, (1 << 121) - 1]
+    cases += [rng.randrange(P) for _ in range(1500)] + [rng.randrange(1 << 122) for _ in range(300)]
+    cases += [P - rng.randrange(1, 1 << 122) for _ in range(300)]
+    for x in cases:
+        a = (C.c_uint8 * 32)(*x.to_bytes(32, "little"))
+        o = (C.c_uint8 * 32)()
+        lib.ht_fr_inv_by(a, o)
+        assert int.from_bytes(bytes(o), "little") == (pow(x, P - 2, P) if x else 0), x

@@ -41,12 +41,12 @@ struct zkwg_circuit {
   hipEvent_t rs_dep[ZK_RS_SLOTS], rs_done[ZK_RS_SLOTS];
   const void* rs_scr[ZK_RS_SLOTS];
   int rs_next, rs_sync, rs_nside;
-  // zk_poseidon9 (one lane per email: ~3.5 ms of latency, a handful of wavefronts) runs beside the other
-  // prepare kernels on a low-priority side stream; the caller's stream joins it at the end of prepare.
+  // zk_poseidon9 (one lane per email: ~3.5 ms of latency, a handful of wavefronts) can run beside the
+  // other prepare kernels on a low-priority side stream, joined at the end of prepare (off by default).
   hipStream_t pos_stream[ZK_POS_STREAMS];
   hipEvent_t pos_dep[ZK_POS_RING], pos_done[ZK_POS_RING];
   u64 pos_calls;
-  int pos_side;   // 0: launch zk_poseidon9 on the caller's stream (ZKWG_POS_SIDE=0)
+  int pos_side;   // 1: fork zk_poseidon9 onto a side stream (ZKWG_POS_SIDE=1); default 0 = caller's stream
   u32 xcd_remap;  // zk_expand workgroup -> portion mapping (ZKWG_XCD_REMAP)
   // host-buffer path: cached device staging buffers (double-buffered witnesses)
   std::mutex hb_mutex;
@@ -156,6 +156,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   if (const char* v = getenv("ZKWG_EMAILS_PER_WG")) c->emails_per_wg = std::max(1, atoi(v));
   if (portion < 64 || portion > (1u << 20)) portion = ZK_PORTION_DEFAULT;
   if (!build_sched(*cfg, c->s, c->segs, c->first_seg, portion)) { g_last_error = "unsupported circuit configuration"; delete c; return ZKWG_RC_BAD_CONFIG; }
+  if (getenv("ZKWG_DEBUG_SKIP_INV") && atoi(getenv("ZKWG_DEBUG_SKIP_INV")) && c->s.rsa.present) c->s.rsa.present = 2;  // profiling only
   if (sym_text) {
     ZkSymLayout L;
     if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L) || !zk_remap_segments(c->s, c->segs, c->first_seg, L)) {
@@ -245,7 +246,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
         hipEventCreateWithFlags(&c->pos_done[i], hipEventDisableTiming);
       }
       c->pos_calls = 0;
-      c->pos_side = getenv("ZKWG_POS_SIDE") ? atoi(getenv("ZKWG_POS_SIDE")) : 1;
+      c->pos_side = getenv("ZKWG_POS_SIDE") ? atoi(getenv("ZKWG_POS_SIDE")) : 0;   // measured: inline is faster in the pipeline
     }
     for (int i = 0; i < 2; ++i) { hipEventCreateWithFlags(&c->hb_done[i], hipEventDisableTiming); hipEventCreateWithFlags(&c->hb_copied[i], hipEventDisableTiming); }
     for (int r = 0; r < ZK_EV_RING; ++r) {

@@ -13,12 +13,14 @@
 //                       correction from a 33-step chain on 64-bit scalars fed by v_readlane
 //   BigLessThan gates   prefix AND / OR over ballot masks
 //   Horner values       P(x) once per email, A(x), B(x) re-used from the previous FpMul's R(x)
-//   IsEqual inverses    one local Montgomery-trick batch per lane without domain conversions
+//   IsEqual inverses    one local Montgomery-trick batch per lane without domain conversions; the one
+//                       inversion per lane is Bernstein-Yang safegcd (no data-dependent control flow)
 //
 // Reference gate sequence: packages/circuits/lib/rsa.circom:13-181, lib/fp.circom:16-81,
 // lib/bigint.circom:16-94, lib/bigint-func.circom (long_div / poly_interp hints).
 #pragma once
 #include "zkwg_rsa_core.h"
+#include "zkwg_fr_inv.h"
 
 #if defined(__HIPCC__)
 
@@ -397,46 +399,6 @@ __device__ inline void zkw_fpmul_emit(ZkRsaLds& S, const ZkFpMulLayout& F, u64* 
   if (!lt) bad = true;
 }
 
-// a^{-1} mod r for a in standard form, every lane its own value, no data-dependent control flow
-// divergence: fixed 2 x 254 + 2 iterations of the binary extended Euclid step with selects.
-__device__ inline Fr zkw_inv_ct(const Fr& a) {
-  const Fr Pm = fr_p();
-  Fr u = a, v = Pm, x1 = fr_from_u64(1), x2 = fr_zero();
-  auto shr1 = [](Fr& x, u64 top) {
-    x.l[0] = (x.l[0] >> 1) | (x.l[1] << 63);
-    x.l[1] = (x.l[1] >> 1) | (x.l[2] << 63);
-    x.l[2] = (x.l[2] >> 1) | (x.l[3] << 63);
-    x.l[3] = (x.l[3] >> 1) | (top << 63);
-  };
-  auto sel = [](bool c, const Fr& a_, const Fr& b_) {
-    return Fr{{c ? a_.l[0] : b_.l[0], c ? a_.l[1] : b_.l[1], c ? a_.l[2] : b_.l[2], c ? a_.l[3] : b_.l[3]}};
-  };
-  // invariant: x1 * a = u, x2 * a = v (mod r); gcd(u, v) = 1.  Each iteration removes one bit of u + v.
-#pragma unroll 1
-  for (int it = 0; it < 2 * 254 + 2; ++it) {
-    const bool ue = !(u.l[0] & 1), ve = !(v.l[0] & 1);
-    const bool ugev = fr_geq(u, v);
-    // cases: u even -> halve u; else v even -> halve v; else u >= v -> u = (u - v) / 2; else v = (v - u) / 2
-    const bool touch_u = ue || (!ve && ugev);
-    u64 bw;
-    const Fr du = fr_sub_raw(u, v, bw), dv = fr_sub_raw(v, u, bw);
-    const Fr dx1 = fr_sub(x1, x2), dx2 = fr_sub(x2, x1);
-    const bool stop = fr_is_zero(u) || fr_is_zero(v);
-    Fr nu = sel(ue, u, du), nx1 = sel(ue, x1, dx1);
-    Fr nv = sel(ve, v, dv), nx2 = sel(ve, x2, dx2);
-    // halve the touched pair
-    Fr hu = nu, hx1 = nx1, hv = nv, hx2 = nx2;
-    shr1(hu, 0); shr1(hv, 0);
-    { u64 top = 0; Fr t = hx1; if (t.l[0] & 1) t = fr_add_raw(t, Pm, top); shr1(t, top); hx1 = t; }
-    { u64 top = 0; Fr t = hx2; if (t.l[0] & 1) t = fr_add_raw(t, Pm, top); shr1(t, top); hx2 = t; }
-    const bool tu = touch_u && !stop, tv = !touch_u && !stop;
-    u = sel(tu, hu, u); x1 = sel(tu, hx1, x1);
-    v = sel(tv, hv, v); x2 = sel(tv, hx2, x2);
-  }
-  const Fr one = fr_from_u64(1);
-  return fr_eq(u, one) ? x1 : x2;
-}
-
 // The 18 x 17 IsEqual differences of one email, inverted in place: each lane batches its 4..5 values
 // with Montgomery's trick.  Products are taken with fr_mont_mul on STANDARD-form values; the stray
 // R^-1 factors cancel between the prefix products and the back-substitution, so no
@@ -473,7 +435,7 @@ __device__ inline void zkw_invert_all(const ZkRsaLayout& R, Fr* frv) {
     }
   }
   // y = A_n = prod v * R^-(n-1);  y^-1 = prod v^-1 * R^(n-1)
-  Fr inv = have ? zkw_inv_ct(acc) : fr_zero();
+  Fr inv = have ? fr_inv_by(acc) : fr_zero();   // safegcd: no data-dependent control flow (zkwg_fr_inv.h)
   bool last_done = false;   // walking back: the first non-zero value met from the top is the chain's last
 #pragma unroll
   for (int k = 4; k >= 0; --k) {
@@ -611,7 +573,7 @@ __device__ inline void zkw_rsa_email(ZkRsaLds& S, const ZkRsaLayout& R, const u8
     vR = vRn;
     ZK_SYNC();
   }
-  zkw_invert_all(R, frv);
+  if (R.present != 2) zkw_invert_all(R, frv);   // present == 2: profiling knob ZKWG_DEBUG_SKIP_INV (witness then wrong)
   // bigPow.out[i] === padder.out[i] (lib/rsa.circom:43-45): expected EMSA-PKCS1-v1_5 value, limb per lane.
   // ones run: bit i (>= 416) is 1 iff m8(i) + 8 <= hb (m8 = i rounded up to a multiple of 8, hb = highest
   // set modulus bit)  <=>  i <= 8 * floor((hb - 8) / 8)
