@@ -46,13 +46,15 @@ class Pipeline:
     sub-batch's witnesses are streamed out tile by tile ("expand", the HBM-bound kernel) on
     another; images are ring-buffered, witnesses go to a 2-tile ring in HBM."""
 
-    def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=4, exp_prio=-1):
+    def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=4, exp_prio=-1,
+                 montgomery=False):
         self.torch, self.c, self.dev, self.d_in = torch, c, dev, d_in
         self.batch, self.tile, self.prep = batch, tile, prep
         assert batch % prep == 0 and prep % tile == 0
         self.nsub, self.tiles_per_sub = batch // prep, prep // tile
         self.ntiles = batch // tile
         self.rsa_throttle = rsa_throttle
+        self.expand = c.expand_montgomery_device if montgomery else c.expand_device
         self.d_out = [torch.empty(tile * c.witness_bytes, dtype=torch.uint8, device=dev) for _ in range(min(2, self.ntiles))]
         self.d_status = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.R = max(2, ring)
@@ -84,7 +86,7 @@ class Pipeline:
             with torch.cuda.stream(self.s_exp):
                 for t in range(self.tiles_per_sub):
                     o = self.d_out[(sb * self.tiles_per_sub + t) % len(self.d_out)]
-                    c.expand_device(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp)
+                    self.expand(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp)
                     self.d_rows[lo + t * self.tile:lo + (t + 1) * self.tile].copy_(o.view(self.tile, c.witness_bytes)[:, :128])
             self.ev_exp[b].record(self.s_exp)
             self.j = j + 1
@@ -190,6 +192,8 @@ def main():
     ap.add_argument("--pmc-traffic", type=int, default=1, help="collect roofline.traffic with rocprofv3 --pmc child passes (N=1)")
     ap.add_argument("--pmc-timeout", type=int, default=240)
     ap.add_argument("--other-configs", type=int, default=1, help="also measure configs[1], configs[4] and the delivered rate (N=1)")
+    ap.add_argument("--montgomery", type=int, default=0,
+                    help="1: witnesses written in Montgomery form by the fused expand (prover hand-off variant)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -232,7 +236,7 @@ def main():
     _, d_in, fields = resident_inputs(torch, c, dev, 0x5A4B + rank, distinct, args.batch, args.body_len)
     prio = int(os.environ.get("ZKWG_BENCH_EXP_PRIO", "-1"))
     pl = Pipeline(torch, c, dev, d_in, args.batch, tile, prep, ring=args.ring, prep_streams=args.prep_streams,
-                  rsa_throttle=args.rsa_throttle, exp_prio=prio)
+                  rsa_throttle=args.rsa_throttle, exp_prio=prio, montgomery=bool(args.montgomery))
     from zkwg import shard
     state = {"table": None}
 
@@ -294,7 +298,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 (BN254 Fr, 4x64-bit limbs) / u32 bit-vectors", "data": "synthetic",
             "config": {"workload": f"EmailVerifier({args.max_header},{args.max_body},121,17,0,0,0,{args.remove_soft_line_breaks}) batch={args.batch}/GPU, "
-                                   f"{args.body_len} B bodies, witnesses device-resident",
+                                   f"{args.body_len} B bodies, witnesses device-resident" + (", Montgomery form" if args.montgomery else ""),
                        "batch_per_gpu": args.batch, "tile": tile, "witness_len": c.W,
                        "witness_bytes": c.witness_bytes, "layout": "kept-v1", "parallelism": f"shard x{world}, result-table gather" + (f" + {args.gather_wtns} wtns/rank/step gathered" if args.gather_wtns and world > 1 else " only")},
             "roofline": {"bound": "hbm", "kernel": "zk_expand", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -345,6 +349,21 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         torch.cuda.empty_cache()
     except Exception as e:  # a side measurement must not lose the headline line
         out["configs[1] batch=256"] = {"error": repr(e)[:200]}
+    # prover hand-off: the same pipeline with Montgomery-form output written by the fused expand
+    try:
+        _, d_in, _ = resident_inputs(torch, c, dev, 0x5A4B + 404, 64, 2048, args.body_len)
+        pl = Pipeline(torch, c, dev, d_in, 2048, 512, 1024, ring=2, rsa_throttle=args.rsa_throttle, montgomery=True)
+        c.set_timing(True)
+        dt = timed(torch, pl.step, steps=3, warmup=1)
+        _, avg, n, gbs = expand_roofline(c, 512)
+        c.set_timing(False)
+        assert int(pl.d_status.abs().sum().item()) == 0
+        out["Montgomery-form output (fused hand-off)"] = {"value": round(2048 * 3 / dt, 1), "unit": "witnesses/s", "steps": 3,
+                                                           "zk_expand_GBps": round(gbs, 1), "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4)}
+        del pl, d_in
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["Montgomery-form output (fused hand-off)"] = {"error": repr(e)[:200]}
     # delivered to host (PCIe-inclusive): zkwg_calculate_batch with a pinned destination, double-buffered tiles
     try:
         n, t = 192, 64

@@ -241,7 +241,7 @@ int zkwg_set_prepare_throttle(zkwg_circuit_t* c, int rsa_wavefronts_per_cu);
 int zkwg_set_timing(zkwg_circuit_t* c, int enable);
 int zkwg_last_kernel_ms(zkwg_circuit_t* c, int which, float* ms);
 /* Sum of kernel `which`'s durations over the launches recorded since zkwg_set_timing(c, 1)
- * (at most the last 64 launches), and how many launches that sum covers. */
+ * (at most the last 512 launches), and how many launches that sum covers. */
 int zkwg_timing_summary(zkwg_circuit_t* c, int which, float* total_ms, uint32_t* launches);
 int zkwg_num_kernels(const zkwg_circuit_t* c);
 const char* zkwg_kernel_name(const zkwg_circuit_t* c, int which);
@@ -283,6 +283,14 @@ int zkwg_check_constraints(zkwg_r1cs_t* r, const uint8_t* witness, uint64_t n, u
  * zkwg_expand_device left it; this converts n_values 32-byte field elements in place between the
  * `.wtns` standard form and Montgomery form (x * 2^256 mod r), whichever its NTT / MSM kernels want. */
 int zkwg_convert_montgomery_device(void* d_values, uint64_t n_values, int to_montgomery, void* hip_stream);
+/* The fused form: zkwg_expand_device that writes every witness value directly as x * 2^256 mod r
+ * (0 -> 0, 1 -> R, values below 2^16 from a table, the rest one Montgomery product) -- the witness
+ * is still written exactly once and never read back, so handing it to a device prover costs no extra
+ * HBM pass.  Same arguments and layout as zkwg_expand_device; bit-identical to zkwg_expand_device
+ * followed by zkwg_convert_montgomery_device(.., 1, ..).  Needs the default portion size. */
+int zkwg_expand_montgomery_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails,
+                                  const void* d_scratch, uint64_t first, uint64_t count, void* d_out_wtns,
+                                  uint64_t out_stride, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -170,3 +170,33 @@ def test_prover_handoff_montgomery_round_trip():
     zkwg.convert_montgomery_device(d, c.W, False)
     torch.cuda.synchronize()
     assert d.cpu().numpy().tobytes() == wit
+
+
+def test_fused_montgomery_expand_equals_expand_then_convert():
+    """zkwg_expand_montgomery_device: bit-identical to zkwg_expand_device followed by the
+    in-place conversion, for EmailVerifier(1024,1536) (every segment type) and the Fr-rich RSA main."""
+    import torch
+    import zkwg
+    from zkwg import synth
+    dev = torch.device("cuda:0")
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=1024, max_body=1536, device=0)
+    n = 6
+    recs, _ = synth.packed_batch(c, seed=61, n=n, body_len=700)
+    d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).view(n, c.in_stride).to(dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_scr = torch.empty(c.scratch_bytes(n), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream()
+    c.prepare_device(d_in, n, d_st, d_scr, st)
+    a = torch.empty(n * c.witness_bytes, dtype=torch.uint8, device=dev)
+    b = torch.full((n * c.witness_bytes,), 0xA5, dtype=torch.uint8, device=dev)
+    c.expand_device(d_in, n, d_scr, 0, n, a, st)
+    zkwg.convert_montgomery_device(a, n * c.W, True, st)
+    c.expand_montgomery_device(d_in, n, d_scr, 0, n, b, st)
+    torch.cuda.synchronize()
+    assert d_st.cpu().tolist() == [0] * n
+    assert torch.equal(a, b)
+    # a sub-range of the batch (first / count) lands at the start of the output
+    b2 = torch.empty(2 * c.witness_bytes, dtype=torch.uint8, device=dev)
+    c.expand_montgomery_device(d_in, n, d_scr, 3, 2, b2, st)
+    torch.cuda.synchronize()
+    assert torch.equal(b2, a[3 * c.witness_bytes:5 * c.witness_bytes])

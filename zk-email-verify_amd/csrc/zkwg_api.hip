@@ -26,6 +26,7 @@ struct zkwg_circuit {
   int device;
   Fr* d_invtab;
   std::vector<std::string> sym_names;  // layout SYM: witness index -> name
+  Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
   Fr* d_pos_rs;   // removeSoftLineBreaks: Poseidon(16) then Poseidon(2) sparse-round tables
@@ -285,7 +286,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
-    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos); hipFree(c->d_pos_rs);
+    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); }
     hipStreamDestroy(c->copy_stream);
@@ -456,6 +457,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.invtab = c->d_invtab;
   B.pos_c = c->d_pos;
   B.pos_m = nullptr;
+  B.rtab = c->d_rtab;
   B.pos16 = c->d_pos_rs;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
@@ -560,8 +562,8 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
   return ZKWG_RC_OK;
 }
 
-int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const void* d_scratch, uint64_t first,
-                       uint64_t count, void* d_out, uint64_t out_stride, void* hip_stream) {
+static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const void* d_scratch, uint64_t first,
+                       uint64_t count, void* d_out, uint64_t out_stride, void* hip_stream, bool mont) {
   if (!c || !d_in || !d_out || !d_scratch) return ZKWG_RC_BAD_ARG;
   if (c->device < 0) return ZKWG_RC_NO_DEVICE;
   if (count == 0) return ZKWG_RC_OK;
@@ -572,6 +574,18 @@ int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   ZkDeviceGuard dg(c->device);
   if (!dg.ok) return ZKWG_RC_HIP_ERROR;
   hipStream_t st = (hipStream_t)hip_stream;
+  if (mont) {
+    if (s.portion > ZK_PORTION_DEFAULT) return ZKWG_RC_BAD_CONFIG;   // the LDS stage holds 2048 slots
+    if (!c->d_rtab) {
+      // v * R mod r for v < 65536 (2 MiB), built once per handle
+      std::vector<Fr> tab(65536);
+      Fr acc = fr_zero();
+      const Fr Rm = fr_R();
+      for (u32 v = 0; v < 65536; ++v) { tab[v] = acc; acc = fr_add(acc, Rm); }
+      if (hipMalloc((void**)&c->d_rtab, tab.size() * sizeof(Fr)) != hipSuccess) return ZKWG_RC_OOM;
+      if (hipMemcpy(c->d_rtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+    }
+  }
   ZkBufs B;
   fill_bufs(c, B, d_in, n, (void*)d_scratch);
   B.wit = (uint4*)d_out;
@@ -583,16 +597,26 @@ int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   const bool tm = c->timing != 0;
   hipEvent_t* evs = c->ev[c->launches % ZK_EV_RING];
   if (tm) hipEventRecord(evs[0], st);
-  B.emails_per_wg = (u32)c->emails_per_wg;
+  B.emails_per_wg = mont ? 1u : (u32)c->emails_per_wg;
   const u64 units = ((count + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions;
   const dim3 grid((u32)units);
-  if (c->expand_threads == 64) hipLaunchKernelGGL(zk_expand_wave, dim3((u32)((units + 3) / 4)), dim3(256), 0, st, s, B);
+  if (mont) hipLaunchKernelGGL(zk_expand_mont_256, grid, dim3(256), 0, st, s, B);
+  else if (c->expand_threads == 64) hipLaunchKernelGGL(zk_expand_wave, dim3((u32)((units + 3) / 4)), dim3(256), 0, st, s, B);
   else if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
   else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
   else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);
   if (tm) { hipEventRecord(evs[1], st); c->ev_valid = true; c->launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;
+}
+
+int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const void* d_scratch, uint64_t first,
+                       uint64_t count, void* d_out, uint64_t out_stride, void* hip_stream) {
+  return expand_impl(c, d_in, n, d_scratch, first, count, d_out, out_stride, hip_stream, false);
+}
+int zkwg_expand_montgomery_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const void* d_scratch, uint64_t first,
+                                  uint64_t count, void* d_out, uint64_t out_stride, void* hip_stream) {
+  return expand_impl(c, d_in, n, d_scratch, first, count, d_out, out_stride, hip_stream, true);
 }
 
 int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_out,

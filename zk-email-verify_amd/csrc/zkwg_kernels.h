@@ -9,6 +9,7 @@ __global__ void zk_expand_256(ZkSched s, ZkBufs B);  // zkwg_kernels_expand.hip
 __global__ void zk_expand_512(ZkSched s, ZkBufs B);
 __global__ void zk_expand_1024(ZkSched s, ZkBufs B);
 __global__ void zk_expand_wave(ZkSched s, ZkBufs B);
+__global__ void zk_expand_mont_256(ZkSched s, ZkBufs B);  // fused standard -> Montgomery output
 __global__ void zk_rsa(ZkSched s, ZkBufs B);         // zkwg_kernels_rsa.hip
 __global__ void zk_poseidon9(ZkSched s, ZkBufs B);   // zkwg_kernels_rsa.hip
 __global__ void zk_misc_ev(ZkSched s, ZkBufs B);     // zkwg_kernels_misc.hip

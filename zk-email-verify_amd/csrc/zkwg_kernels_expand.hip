@@ -21,8 +21,15 @@
 // WAVE_MODE = false: one workgroup per (portion, email group), threads interleaved over the portion.
 // WAVE_MODE = true : one WAVEFRONT per (portion, email group): every wave writes its own contiguous
 //                    portion (1 KiB per store instruction, back to back), 4 such waves per workgroup.
-template <int ZK_BLOCK_THREADS, bool WAVE_MODE>
+//
+// MONT = true (prover hand-off): the same portion is first expanded into LDS (64 KiB =
+// 2048 slots, standard form, the identical segment code) and then streamed to HBM as x * 2^256 mod r:
+// 0 -> 0, 1 -> R (constants), values below 2^16 from a table of v * R, anything else one Montgomery
+// product by R^2.  Still one write per witness byte and no read of the witness: a device prover (MSM /
+// NTT kernels want Montgomery scalars) costs no extra HBM pass.
+template <int ZK_BLOCK_THREADS, bool WAVE_MODE, bool MONT = false>
 __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B) {
+  __shared__ uint4 stage[MONT ? 2 * ZK_PORTION_DEFAULT : 1];
   constexpr u32 ZK_EXPAND_THREADS = WAVE_MODE ? 64u : (u32)ZK_BLOCK_THREADS;
   constexpr u32 UNITS_PER_BLOCK = WAVE_MODE ? (u32)ZK_BLOCK_THREADS / 64u : 1u;
   // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Give every XCD a contiguous run of units:
@@ -59,7 +66,9 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
     const u32 nch = (u32)(hi - lo) * 2;          // chunks to write
    for (u32 el = el0; el < el1; ++el) {
     const u32 e = el + B.e_first;                // email index inside the prepared batch
-    uint4* __restrict__ dst = B.wit + ((u64)el * s.W + lo) * 2;
+    uint4* __restrict__ dst;
+    if constexpr (MONT) dst = stage + (lo - slot0) * 2;
+    else dst = B.wit + ((u64)el * s.W + lo) * 2;
     const u8* __restrict__ rec = B.in + (u64)e * s.in_stride;
     const u64* __restrict__ bits = B.bits + (u64)e * s.img_bits;
     const u32* __restrict__ small = B.small + (u64)e * s.img_small;
@@ -397,10 +406,36 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
     }
    }
   }
+  if constexpr (MONT) {
+    // phase 2: LDS (standard form) -> HBM (Montgomery form); emails_per_wg is 1 in this mode
+    __syncthreads();
+    const u32 nsl = (u32)(slot1 - slot0);
+    uint4* __restrict__ out = B.wit + ((u64)el0 * s.W + slot0) * 2;
+    const uint4* __restrict__ rtab = (const uint4*)B.rtab;      // v * R mod r for v < 65536
+    const Fr Rm = fr_R();
+    for (u32 c = tid; c < 2 * nsl; c += ZK_EXPAND_THREADS) {
+      const u32 sl = c >> 1, hf = c & 1u;
+      const uint4 a = stage[2 * sl], b = stage[2 * sl + 1];
+      uint4 v;
+      if ((b.x | b.y | b.z | b.w | a.y | a.z | a.w) == 0u && a.x < 65536u) {
+        if (a.x == 0u) v = zk_zero4();
+        else if (a.x == 1u) v = hf ? make_uint4((u32)Rm.l[2], (u32)(Rm.l[2] >> 32), (u32)Rm.l[3], (u32)(Rm.l[3] >> 32))
+                                   : make_uint4((u32)Rm.l[0], (u32)(Rm.l[0] >> 32), (u32)Rm.l[1], (u32)(Rm.l[1] >> 32));
+        else v = rtab[2 * a.x + hf];
+      } else {
+        const Fr x{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
+        const Fr m = fr_to_mont(x);
+        v = hf ? make_uint4((u32)m.l[2], (u32)(m.l[2] >> 32), (u32)m.l[3], (u32)(m.l[3] >> 32))
+               : make_uint4((u32)m.l[0], (u32)(m.l[0] >> 32), (u32)m.l[1], (u32)(m.l[1] >> 32));
+      }
+      out[c] = v;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand_256(ZkSched s, ZkBufs B) { zk_expand_body<256, false>(s, B); }
 __global__ __launch_bounds__(512) void zk_expand_512(ZkSched s, ZkBufs B) { zk_expand_body<512, false>(s, B); }
 __global__ __launch_bounds__(1024) void zk_expand_1024(ZkSched s, ZkBufs B) { zk_expand_body<1024, false>(s, B); }
 __global__ __launch_bounds__(256) void zk_expand_wave(ZkSched s, ZkBufs B) { zk_expand_body<256, true>(s, B); }
+__global__ __launch_bounds__(256) void zk_expand_mont_256(ZkSched s, ZkBufs B) { zk_expand_body<256, false, true>(s, B); }
 

@@ -222,6 +222,7 @@ struct ZkBufs {
   const Fr* pos_m;       // unused (kept for layout stability)
   const Fr* pos16;       // Poseidon(16) sparse-round table (zkwg_poseidon_sparse.h), removeSoftLineBreaks only
   const Fr* pos2;        // Poseidon(2)  sparse-round table
+  const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
   const ZkSeg* segs;     // segment table
   const u32* first_seg;  // first segment overlapping each portion
   uint4* wit;            // output witnesses

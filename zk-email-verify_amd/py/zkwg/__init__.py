@@ -238,6 +238,12 @@ class Circuit:
         _check(self.lib.zkwg_expand_device(self.h, d_in.data_ptr(), n, d_scratch.data_ptr(), first, count,
                                            d_out.data_ptr(), self.witness_bytes, sp))
 
+    def expand_montgomery_device(self, d_in, n, d_scratch, first, count, d_out, stream=None):
+        """Phase 2 with Montgomery-form output (x * 2^256 mod r): the fused prover hand-off."""
+        sp = stream.cuda_stream if stream is not None else 0
+        _check(self.lib.zkwg_expand_montgomery_device(self.h, d_in.data_ptr(), n, d_scratch.data_ptr(), first, count,
+                                                      d_out.data_ptr(), self.witness_bytes, sp))
+
     def scratch_bytes(self, n):
         return self.lib.zkwg_scratch_bytes(self.h, n)
 
