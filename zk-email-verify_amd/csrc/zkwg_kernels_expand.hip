@@ -29,7 +29,8 @@
 // NTT kernels want Montgomery scalars) costs no extra HBM pass.
 template <int ZK_BLOCK_THREADS, bool WAVE_MODE, bool MONT = false>
 __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B) {
-  __shared__ uint4 stage[MONT ? 2 * ZK_PORTION_DEFAULT : 1];
+  constexpr u32 ZK_MONT_SUB = 512u;          // slots staged in LDS at a time (16 KiB: occupancy stays at 8 workgroups per CU)
+  __shared__ uint4 stage[MONT ? 2 * ZK_MONT_SUB : 1];
   constexpr u32 ZK_EXPAND_THREADS = WAVE_MODE ? 64u : (u32)ZK_BLOCK_THREADS;
   constexpr u32 UNITS_PER_BLOCK = WAVE_MODE ? (u32)ZK_BLOCK_THREADS / 64u : 1u;
   // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Give every XCD a contiguous run of units:
@@ -52,14 +53,19 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
   const u32 el0 = g * E;                                   // first email (launch-local index)
   const u32 el1 = min(el0 + E, B.n_emails - B.e_first);    // one past the last
   if (el0 >= el1) return;
-  const u64 slot0 = (u64)p * s.portion;
-  const u64 slot1 = min(s.W, slot0 + s.portion);
+  const u64 pslot0 = (u64)p * s.portion;
+  const u64 pslot1 = min(s.W, pslot0 + s.portion);
   const uint4* __restrict__ invtab = (const uint4*)B.invtab;
   const u32 tid = WAVE_MODE ? (threadIdx.x & 63u) : threadIdx.x;
 
+  // standard output: one pass over the whole portion; Montgomery output: sub-portions of ZK_MONT_SUB slots
+  u64 slot0 = pslot0;
+  do {
+  const u64 slot1 = MONT ? min(pslot1, slot0 + ZK_MONT_SUB) : pslot1;
   for (u32 si = B.first_seg[p]; si < s.nsegs; ++si) {
     const ZkSeg sg = B.segs[si];
     if (sg.slot >= slot1) break;
+    if (MONT && sg.slot + sg.nslots <= slot0) continue;
     const u64 lo = max(sg.slot, slot0);
     const u64 hi = min(sg.slot + sg.nslots, slot1);
     const u32 r0 = (u32)(lo - sg.slot) + sg.r0;  // first element of the logical array handled here
@@ -413,24 +419,31 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
     uint4* __restrict__ out = B.wit + ((u64)el0 * s.W + slot0) * 2;
     const uint4* __restrict__ rtab = (const uint4*)B.rtab;      // v * R mod r for v < 65536
     const Fr Rm = fr_R();
-    for (u32 c = tid; c < 2 * nsl; c += ZK_EXPAND_THREADS) {
-      const u32 sl = c >> 1, hf = c & 1u;
+    // one slot per thread (the Montgomery product, where one is needed, is computed once)
+    for (u32 sl = tid; sl < nsl; sl += ZK_EXPAND_THREADS) {
       const uint4 a = stage[2 * sl], b = stage[2 * sl + 1];
-      uint4 v;
+      uint4 v0, v1;
       if ((b.x | b.y | b.z | b.w | a.y | a.z | a.w) == 0u && a.x < 65536u) {
-        if (a.x == 0u) v = zk_zero4();
-        else if (a.x == 1u) v = hf ? make_uint4((u32)Rm.l[2], (u32)(Rm.l[2] >> 32), (u32)Rm.l[3], (u32)(Rm.l[3] >> 32))
-                                   : make_uint4((u32)Rm.l[0], (u32)(Rm.l[0] >> 32), (u32)Rm.l[1], (u32)(Rm.l[1] >> 32));
-        else v = rtab[2 * a.x + hf];
+        if (a.x == 0u) { v0 = zk_zero4(); v1 = zk_zero4(); }
+        else if (a.x == 1u) {
+          v0 = make_uint4((u32)Rm.l[0], (u32)(Rm.l[0] >> 32), (u32)Rm.l[1], (u32)(Rm.l[1] >> 32));
+          v1 = make_uint4((u32)Rm.l[2], (u32)(Rm.l[2] >> 32), (u32)Rm.l[3], (u32)(Rm.l[3] >> 32));
+        } else { v0 = rtab[2 * a.x]; v1 = rtab[2 * a.x + 1]; }
       } else {
         const Fr x{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
         const Fr m = fr_to_mont(x);
-        v = hf ? make_uint4((u32)m.l[2], (u32)(m.l[2] >> 32), (u32)m.l[3], (u32)(m.l[3] >> 32))
-               : make_uint4((u32)m.l[0], (u32)(m.l[0] >> 32), (u32)m.l[1], (u32)(m.l[1] >> 32));
+        v0 = make_uint4((u32)m.l[0], (u32)(m.l[0] >> 32), (u32)m.l[1], (u32)(m.l[1] >> 32));
+        v1 = make_uint4((u32)m.l[2], (u32)(m.l[2] >> 32), (u32)m.l[3], (u32)(m.l[3] >> 32));
       }
-      out[c] = v;
+      out[2 * sl] = v0;
+      out[2 * sl + 1] = v1;
     }
+    __syncthreads();   // the stage is rewritten by the next sub-portion
+    slot0 += ZK_MONT_SUB;
+  } else {
+    break;             // standard output: the whole portion in one pass
   }
+  } while (slot0 < pslot1);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand_256(ZkSched s, ZkBufs B) { zk_expand_body<256, false>(s, B); }
