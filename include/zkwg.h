@@ -292,6 +292,24 @@ int zkwg_expand_montgomery_device(zkwg_circuit_t* c, const void* d_packed_inputs
                                   const void* d_scratch, uint64_t first, uint64_t count, void* d_out_wtns,
                                   uint64_t out_stride, void* hip_stream);
 
+/* ---- multi-GPU (BASELINE.json configs[3]) -------------------------------------------
+ * Emails are independent: the batch is cut into n_dev contiguous shards (zkwg_shard_range), shard i runs on
+ * devices[i] through its own handle and host thread, and its witnesses reach `out_wtns` over that GPU's own
+ * PCIe link -- no data-path collective.  The only exchange is the 100-byte/email result table
+ * {status i32 LE, pubkeyHash, shaHi, shaLo (32-byte LE each)} gathered on devices[0] over RCCL / xGMI
+ * (ncclGroupStart + ncclSend / ncclRecv) and copied to `table` (n x 100 bytes, may be NULL; then RCCL is
+ * not touched).  For the other mains the 96 bytes are w[1..3] of the witness.  librccl.so is opened with
+ * dlopen, and only when n_dev > 1. */
+typedef struct zkwg_multi zkwg_multi_t;
+void zkwg_shard_range(uint64_t n_emails, int n_shards, int i, uint64_t* first, uint64_t* count);
+int zkwg_multi_create(const zkwg_config* cfg, const int* devices, int n_dev, zkwg_multi_t** out);
+void zkwg_multi_destroy(zkwg_multi_t* m);
+int zkwg_multi_devices(const zkwg_multi_t* m);
+zkwg_circuit_t* zkwg_multi_circuit(zkwg_multi_t* m, int i);   /* the handle of shard i (geometry, packing) */
+int zkwg_calculate_batch_multi(zkwg_multi_t* m, const uint8_t* packed_inputs, uint64_t n_emails,
+                               uint8_t* out_wtns, uint64_t out_stride, int32_t* status, uint8_t* table,
+                               uint64_t max_tile);
+
 #ifdef __cplusplus
 }
 #endif

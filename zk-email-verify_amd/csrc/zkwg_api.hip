@@ -7,6 +7,9 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <thread>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <algorithm>
 #include "../../include/zkwg.h"
 #include "zkwg_kernels.h"
@@ -648,8 +651,10 @@ static int ensure_host_path_buffers(zkwg_circuit* c, u64 tile) {
   return ZKWG_RC_OK;
 }
 
-int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
-                         uint64_t out_stride, int32_t* status, uint64_t max_tile) {
+// d_rows (optional, device memory of the handle's GPU): n x 96 bytes, w[1..3] of every email
+// (pubkeyHash, shaHi, shaLo for the EmailVerifier main) captured tile by tile for the result table.
+static int calculate_batch_impl(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
+                                uint64_t out_stride, int32_t* status, uint64_t max_tile, uint8_t* d_rows) {
   if (!c || !packed || !status) return ZKWG_RC_BAD_ARG;
   if (c->device < 0) return ZKWG_RC_NO_DEVICE;
   if (n == 0) return ZKWG_RC_OK;
@@ -676,6 +681,7 @@ int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, u
     if (hipMemcpyAsync(c->hb_in, packed + base * c->s.in_stride, cnt * c->s.in_stride, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
     rc = zkwg_calculate_batch_device(c, c->hb_in, cnt, c->hb_out[b], wbytes, c->hb_status[b], c->hb_scr, st);
     if (rc != ZKWG_RC_OK) break;
+    if (d_rows && hipMemcpy2DAsync(d_rows + base * 96, 96, c->hb_out[b] + 32, wbytes, 96, cnt, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
     if (hipEventRecord(c->hb_done[b], st) != hipSuccess || hipStreamWaitEvent(cs, c->hb_done[b], 0) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
     if (out_wtns) {
       hipError_t e = (out_stride == wbytes)
@@ -689,6 +695,11 @@ int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, u
   if (hipStreamSynchronize(st) != hipSuccess) rc = rc == ZKWG_RC_OK ? ZKWG_RC_HIP_ERROR : rc;
   if (hipStreamSynchronize(cs) != hipSuccess) rc = rc == ZKWG_RC_OK ? ZKWG_RC_HIP_ERROR : rc;
   return rc;
+}
+
+int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
+                         uint64_t out_stride, int32_t* status, uint64_t max_tile) {
+  return calculate_batch_impl(c, packed, n, out_wtns, out_stride, status, max_tile, nullptr);
 }
 
 int zkwg_generate_inputs_device(zkwg_circuit_t* c, const zkwg_dkim_batch* b, uint64_t n, void* d_records,
@@ -767,6 +778,141 @@ uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap) {
     case ZKWG_MAIN_EMAIL_VERIFIER: zk_walk_main_ev(w, tmp); break;
   }
   return pos;
+}
+
+// ------------------------------------------------------------------ multi-device
+// One handle + one host thread per GPU, contiguous shards, no data-path collective.  The only exchange is
+// the gather of the 100-byte/email result table {status, pubkeyHash, shaHi, shaLo} on devices[0] over
+// RCCL (ncclGroupStart + ncclSend / ncclRecv over xGMI).  RCCL is opened with dlopen when n_dev > 1, so a
+// single-GPU deployment carries no dependency on it.
+struct zkwg_multi {
+  std::vector<zkwg_circuit_t*> h;
+  std::vector<int> dev;
+  std::vector<ncclComm_t> comm;
+  void* rccl = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+};
+
+void zkwg_shard_range(uint64_t n, int n_shards, int i, uint64_t* first, uint64_t* count) {
+  // contiguous ranges whose sizes differ by at most one (the first n % n_shards shards take the extra email)
+  if (n_shards <= 0 || i < 0 || i >= n_shards) { if (first) *first = 0; if (count) *count = 0; return; }
+  const uint64_t q = n / (uint64_t)n_shards, r = n % (uint64_t)n_shards;
+  const uint64_t f = (uint64_t)i * q + std::min<uint64_t>((uint64_t)i, r);
+  if (first) *first = f;
+  if (count) *count = q + ((uint64_t)i < r ? 1 : 0);
+}
+
+void zkwg_multi_destroy(zkwg_multi_t* m) {
+  if (!m) return;
+  for (auto cm : m->comm) if (cm && m->CommDestroy) m->CommDestroy(cm);
+  for (auto c : m->h) zkwg_circuit_destroy(c);
+  if (m->rccl) dlclose(m->rccl);
+  delete m;
+}
+
+int zkwg_multi_create(const zkwg_config* cfg, const int* devices, int n_dev, zkwg_multi_t** out) {
+  if (!cfg || !devices || n_dev <= 0 || !out) return ZKWG_RC_BAD_ARG;
+  zkwg_multi* m = new zkwg_multi();
+  int rc = ZKWG_RC_OK;
+  for (int i = 0; i < n_dev && rc == ZKWG_RC_OK; ++i) {
+    zkwg_circuit_t* c = nullptr;
+    rc = zkwg_circuit_create(cfg, devices[i], &c);
+    if (rc == ZKWG_RC_OK) { m->h.push_back(c); m->dev.push_back(devices[i]); }
+  }
+  if (rc == ZKWG_RC_OK && n_dev > 1) {
+    m->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!m->rccl) m->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!m->rccl) { g_last_error = "librccl.so could not be loaded (needed for the result-table gather with n_dev > 1)"; rc = ZKWG_RC_BAD_CONFIG; }
+    else {
+      m->CommInitAll = (decltype(m->CommInitAll))dlsym(m->rccl, "ncclCommInitAll");
+      m->CommDestroy = (decltype(m->CommDestroy))dlsym(m->rccl, "ncclCommDestroy");
+      m->GroupStart = (decltype(m->GroupStart))dlsym(m->rccl, "ncclGroupStart");
+      m->GroupEnd = (decltype(m->GroupEnd))dlsym(m->rccl, "ncclGroupEnd");
+      m->Send = (decltype(m->Send))dlsym(m->rccl, "ncclSend");
+      m->Recv = (decltype(m->Recv))dlsym(m->rccl, "ncclRecv");
+      if (!m->CommInitAll || !m->CommDestroy || !m->GroupStart || !m->GroupEnd || !m->Send || !m->Recv) {
+        g_last_error = "librccl.so lacks a required symbol"; rc = ZKWG_RC_BAD_CONFIG;
+      } else {
+        m->comm.assign(n_dev, nullptr);
+        if (m->CommInitAll(m->comm.data(), n_dev, devices) != ncclSuccess) { m->comm.clear(); g_last_error = "ncclCommInitAll failed"; rc = ZKWG_RC_HIP_ERROR; }
+      }
+    }
+  }
+  if (rc != ZKWG_RC_OK) { zkwg_multi_destroy(m); return rc; }
+  *out = m;
+  return ZKWG_RC_OK;
+}
+int zkwg_multi_devices(const zkwg_multi_t* m) { return m ? (int)m->h.size() : 0; }
+zkwg_circuit_t* zkwg_multi_circuit(zkwg_multi_t* m, int i) { return (m && i >= 0 && i < (int)m->h.size()) ? m->h[i] : nullptr; }
+
+int zkwg_calculate_batch_multi(zkwg_multi_t* m, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
+                               uint64_t out_stride, int32_t* status, uint8_t* table, uint64_t max_tile) {
+  if (!m || !packed || !status || m->h.empty()) return ZKWG_RC_BAD_ARG;
+  if (n == 0) return ZKWG_RC_OK;
+  const int nd = (int)m->h.size();
+  const uint64_t in_stride = zkwg_input_stride(m->h[0]);
+  std::vector<uint8_t*> d_rows(nd, nullptr), d_tab(nd, nullptr);
+  std::vector<int32_t*> d_st(nd, nullptr);
+  std::vector<int> rcs(nd, ZKWG_RC_OK);
+  std::vector<uint64_t> first(nd), cnt(nd);
+  for (int i = 0; i < nd; ++i) zkwg_shard_range(n, nd, i, &first[i], &cnt[i]);
+  auto worker = [&](int i) {
+    if (cnt[i] == 0) return;
+    if (hipSetDevice(m->dev[i]) != hipSuccess) { rcs[i] = ZKWG_RC_HIP_ERROR; return; }
+    if (table && hipMalloc((void**)&d_rows[i], cnt[i] * 96) != hipSuccess) { rcs[i] = ZKWG_RC_OOM; return; }
+    rcs[i] = calculate_batch_impl(m->h[i], packed + first[i] * in_stride, cnt[i],
+                                  out_wtns ? out_wtns + first[i] * out_stride : nullptr, out_stride, status + first[i],
+                                  max_tile, d_rows[i]);
+    if (rcs[i] != ZKWG_RC_OK || !table) return;
+    // device-side table rows of this shard: {status i32, 96 bytes}
+    if (hipMalloc((void**)&d_tab[i], cnt[i] * 100) != hipSuccess || hipMalloc((void**)&d_st[i], cnt[i] * 4) != hipSuccess) { rcs[i] = ZKWG_RC_OOM; return; }
+    hipStream_t st = m->h[i]->own_stream;
+    bool ok = hipMemcpyAsync(d_st[i], status + first[i], cnt[i] * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemcpy2DAsync(d_tab[i], 100, d_st[i], 4, 4, cnt[i], hipMemcpyDeviceToDevice, st) == hipSuccess &&
+              hipMemcpy2DAsync(d_tab[i] + 4, 100, d_rows[i], 96, 96, cnt[i], hipMemcpyDeviceToDevice, st) == hipSuccess &&
+              hipStreamSynchronize(st) == hipSuccess;
+    if (!ok) rcs[i] = ZKWG_RC_HIP_ERROR;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int i = 1; i < nd; ++i) th.emplace_back(worker, i);
+    worker(0);
+    for (auto& t : th) t.join();
+  }
+  int rc = ZKWG_RC_OK;
+  for (int i = 0; i < nd; ++i) if (rcs[i] != ZKWG_RC_OK) rc = rcs[i];
+  if (rc == ZKWG_RC_OK && table) {
+    // gather on devices[0]: rank i sends its rows, rank 0 receives them at the shard's offset
+    uint8_t* d_all = nullptr;
+    if (hipSetDevice(m->dev[0]) != hipSuccess || hipMalloc((void**)&d_all, n * 100) != hipSuccess) rc = ZKWG_RC_OOM;
+    if (rc == ZKWG_RC_OK) {
+      hipStream_t s0 = m->h[0]->own_stream;
+      bool ok = cnt[0] == 0 || hipMemcpyAsync(d_all, d_tab[0], cnt[0] * 100, hipMemcpyDeviceToDevice, s0) == hipSuccess;
+      if (nd > 1) {
+        ok = ok && m->GroupStart() == ncclSuccess;
+        for (int i = 1; i < nd && ok; ++i) {
+          if (cnt[i] == 0) continue;
+          ok = m->Recv(d_all + first[i] * 100, cnt[i] * 100, ncclUint8, i, m->comm[0], s0) == ncclSuccess &&
+               m->Send(d_tab[i], cnt[i] * 100, ncclUint8, 0, m->comm[i], m->h[i]->own_stream) == ncclSuccess;
+        }
+        ok = ok && m->GroupEnd() == ncclSuccess;
+        for (int i = 1; i < nd && ok; ++i) { hipSetDevice(m->dev[i]); ok = hipStreamSynchronize(m->h[i]->own_stream) == hipSuccess; }
+        hipSetDevice(m->dev[0]);
+      }
+      ok = ok && hipMemcpyAsync(table, d_all, n * 100, hipMemcpyDeviceToHost, s0) == hipSuccess && hipStreamSynchronize(s0) == hipSuccess;
+      if (!ok) rc = ZKWG_RC_HIP_ERROR;
+    }
+    if (d_all) hipFree(d_all);
+  }
+  for (int i = 0; i < nd; ++i) {
+    if (d_rows[i] || d_tab[i] || d_st[i]) { hipSetDevice(m->dev[i]); hipFree(d_rows[i]); hipFree(d_tab[i]); hipFree(d_st[i]); }
+  }
+  return rc;
 }
 
 }  // extern "C"

@@ -88,6 +88,18 @@ function shaPad(msg, max) {  // packages/helpers/src/sha-utils.ts:88-111
     const b3 = await evc.calculateBatch([kase.input, tampered, big, kase.input]);
     assert.deepStrictEqual(Array.from(b3.status), [0, 4, 4, 0]);
     assert.ok(Buffer.from(b3.wtns[0]).equals(Buffer.from(bin)) && Buffer.from(b3.wtns[3]).equals(Buffer.from(bin)));
+    // multi-GPU entry (zkwg_calculate_batch_multi) with one device: same witnesses + the gathered result table
+    const mc = new z.MultiCalculator({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody }, [0]);
+    assert.strictEqual(mc.nDevices, 1);
+    const m3 = await mc.calculateBatch([kase.input, tampered, kase.input]);
+    assert.deepStrictEqual(Array.from(m3.status), [0, 4, 0]);
+    assert.ok(Buffer.from(m3.wtns[0]).equals(Buffer.from(bin)) && Buffer.from(m3.wtns[2]).equals(Buffer.from(bin)));
+    assert.deepStrictEqual(m3.table.map((t) => t.status), [0, 4, 0]);
+    for (const i of [0, 2]) {
+      assert.strictEqual(m3.table[i].pubkeyHash.toString(), kase.pubkeyHash);
+      assert.strictEqual(m3.table[i].shaHi.toString(), kase.shaHi);
+      assert.strictEqual(m3.table[i].shaLo.toString(), kase.shaLo);
+    }
   }
   console.log('js gpu ok');
 })().catch((e) => { console.error(e); process.exit(1); });

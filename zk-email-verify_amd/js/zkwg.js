@@ -137,6 +137,28 @@ class WitnessCalculator {
   }
 }
 
+/** Batch calculation sharded over several GPUs of one node (include/zkwg.h zkwg_multi_*): contiguous
+ * shards, one handle + host thread per GPU, witnesses leave through each GPU's own PCIe link; the
+ * 100-byte/email result table {status, pubkeyHash, shaHi, shaLo} is gathered on devices[0] over RCCL. */
+class MultiCalculator {
+  /** opts as for Circuit; devices: GPU ordinals, e.g. [0,1,2,3,4,5,6,7] */
+  constructor(opts, devices) {
+    this.circuit = new Circuit(opts, -1);                 // layout-only handle: packing + geometry
+    this.handle = addon.createMulti(this.circuit.opts, devices);
+    this.nDevices = addon.multiDevices(this.handle);
+  }
+  /** inputs[] -> Promise<{wtns: Buffer[], status: Int32Array, table: {status, pubkeyHash, shaHi, shaLo}[]}> */
+  async calculateBatch(inputs, wantWitness) {
+    const recs = Buffer.concat(inputs.map((i) => this.circuit.pack(i)));
+    const r = await addon.calculateBatchMulti(this.handle, recs, wantWitness !== false);
+    const wb = this.circuit.witnessBytes;
+    const wtns = r.witness ? inputs.map((_, i) => r.witness.slice(i * wb, (i + 1) * wb)) : [];
+    const le = (b, o) => { let x = 0n; for (let k = 31; k >= 0; --k) x = (x << 8n) | BigInt(b[o + k]); return x; };
+    const table = inputs.map((_, i) => ({ status: r.table.readInt32LE(100 * i), pubkeyHash: le(r.table, 100 * i + 4), shaHi: le(r.table, 100 * i + 36), shaLo: le(r.table, 100 * i + 68) }));
+    return { wtns, status: r.status, table };
+  }
+}
+
 /** snarkjs-shaped `wtns.calculate(input, circuitOrWasm, wtnsFileName | {type:"mem"})`.  The second
  * argument is a zkwg Circuit (where the reference passes the path of the circom WASM). */
 const wtns = {
@@ -177,4 +199,4 @@ function symbols(circuit) {
   return names;
 }
 
-module.exports = { symbols, R1cs, Circuit, WitnessCalculator, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };
+module.exports = { symbols, R1cs, Circuit, WitnessCalculator, MultiCalculator, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };

@@ -108,6 +108,8 @@ typedef struct {
   napi_deferred deferred;
   napi_ref in_ref;
   zkwg_circuit_t* c;
+  zkwg_multi_t* multi;  /* non-NULL: shard over its devices (zkwg_calculate_batch_multi), c = shard 0's handle */
+  uint8_t* table;       /* multi: n x 100 bytes gathered result table (malloc'ed) */
   const uint8_t* in;
   uint64_t n;
   uint8_t* out;      /* malloc'ed: n * witness_bytes (NULL if want_witness == 0) */
@@ -123,7 +125,13 @@ static void calc_execute(napi_env env, void* data) {
   j->status = (int32_t*)calloc(j->n, sizeof(int32_t));
   if (j->want_witness) j->out = (uint8_t*)malloc(j->n * wb);
   if (!j->status || (j->want_witness && !j->out)) { j->rc = ZKWG_RC_OOM; return; }
-  j->rc = zkwg_calculate_batch(j->c, j->in, j->n, j->out, wb, j->status, 0);
+  if (j->multi) {
+    j->table = (uint8_t*)malloc(j->n * 100);
+    if (!j->table) { j->rc = ZKWG_RC_OOM; return; }
+    j->rc = zkwg_calculate_batch_multi(j->multi, j->in, j->n, j->out, wb, j->status, j->table, 0);
+  } else {
+    j->rc = zkwg_calculate_batch(j->c, j->in, j->n, j->out, wb, j->status, 0);
+  }
 }
 
 static void free_cb(napi_env env, void* data, void* hint) { free(data); }
@@ -156,12 +164,18 @@ static void calc_complete(napi_env env, napi_status st, void* data) {
       j->out = NULL;
       napi_set_named_property(env, obj, "witness", wit);
     }
+    if (j->table) {
+      napi_value tb;
+      napi_create_external_buffer(env, j->n * 100, j->table, free_cb, NULL, &tb);
+      j->table = NULL;
+      napi_set_named_property(env, obj, "table", tb);
+    }
     result = obj;
   }
   if (err) napi_reject_deferred(env, j->deferred, err); else napi_resolve_deferred(env, j->deferred, result);
   napi_delete_reference(env, j->in_ref);
   napi_delete_async_work(env, j->work);
-  free(j->status); free(j->out); free(j);
+  free(j->status); free(j->out); free(j->table); free(j);
 }
 
 /* calculateBatch(circuit, recordsBuffer, wantWitness, asWtns) -> Promise<{status: Int32Array, witness?: Buffer}> */
@@ -189,6 +203,82 @@ static napi_value CalculateBatch(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_create_async_work(env, NULL, name, calc_execute, calc_complete, j, &j->work));
   NAPI_OK(napi_queue_async_work(env, j->work));
   return promise;
+}
+
+/* ---- multi-GPU (zkwg_multi_*) ------------------------------------------------------------------ */
+static void multi_finalize(napi_env env, void* data, void* hint) { zkwg_multi_destroy((zkwg_multi_t*)data); }
+
+/* createMulti(opts, devices: number[]) -> external */
+static napi_value CreateMulti(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkwg_config cfg; memset(&cfg, 0, sizeof(cfg));
+  get_u32(env, argv[0], "mainKind", &cfg.main_kind, 0);
+  get_u32(env, argv[0], "maxHeader", &cfg.max_header, 1024);
+  get_u32(env, argv[0], "maxBody", &cfg.max_body, 1536);
+  get_u32(env, argv[0], "n", &cfg.n, 121);
+  get_u32(env, argv[0], "k", &cfg.k, 17);
+  get_u32(env, argv[0], "ignoreBodyHashCheck", &cfg.ignore_body_hash_check, 0);
+  get_u32(env, argv[0], "enableHeaderMasking", &cfg.enable_header_masking, 0);
+  get_u32(env, argv[0], "enableBodyMasking", &cfg.enable_body_masking, 0);
+  get_u32(env, argv[0], "removeSoftLineBreaks", &cfg.remove_soft_line_breaks, 0);
+  uint32_t nd = 0;
+  NAPI_OK(napi_get_array_length(env, argv[1], &nd));
+  if (nd == 0 || nd > 64) { napi_throw_range_error(env, NULL, "zkwg: devices must list 1..64 GPUs"); return NULL; }
+  int devs[64];
+  for (uint32_t i = 0; i < nd; ++i) {
+    napi_value v; int32_t d = 0;
+    NAPI_OK(napi_get_element(env, argv[1], i, &v));
+    NAPI_OK(napi_get_value_int32(env, v, &d));
+    devs[i] = d;
+  }
+  zkwg_multi_t* m = NULL;
+  int rc = zkwg_multi_create(&cfg, devs, (int)nd, &m);
+  if (rc != ZKWG_RC_OK) {
+    char msg[512];
+    snprintf(msg, sizeof(msg), "%s%s%s", zkwg_strerror(rc), rc == ZKWG_RC_BAD_CONFIG ? ": " : "", rc == ZKWG_RC_BAD_CONFIG ? zkwg_last_error() : "");
+    napi_throw_error(env, NULL, msg);
+    return NULL;
+  }
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, m, multi_finalize, NULL, &ext));
+  return ext;
+}
+
+/* calculateBatchMulti(multi, recordsBuffer, wantWitness) -> Promise<{status, witness?, table}> */
+static napi_value CalculateBatchMulti(napi_env env, napi_callback_info info) {
+  size_t argc = 3; napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  void* p = NULL;
+  if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p) { napi_throw_type_error(env, NULL, "zkwg: multi handle expected"); return NULL; }
+  zkwg_multi_t* m = (zkwg_multi_t*)p;
+  zkwg_circuit_t* c = zkwg_multi_circuit(m, 0);
+  void* data; size_t len;
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &len));
+  const uint64_t stride = zkwg_input_stride(c);
+  if (len == 0 || len % stride) { napi_throw_range_error(env, NULL, "zkwg: records buffer is not a whole number of input records"); return NULL; }
+  calc_job* j = (calc_job*)calloc(1, sizeof(calc_job));
+  j->c = c; j->multi = m; j->in = (const uint8_t*)data; j->n = len / stride;
+  bool b = true;
+  if (argc > 2) napi_get_value_bool(env, argv[2], &b);
+  j->want_witness = b ? 1 : 0;
+  napi_value promise, name;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_reference(env, argv[1], 1, &j->in_ref));
+  NAPI_OK(napi_create_string_utf8(env, "zkwg.calculateBatchMulti", NAPI_AUTO_LENGTH, &name));
+  NAPI_OK(napi_create_async_work(env, NULL, name, calc_execute, calc_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+/* multiInfo(multi) -> same object as info() for shard 0's handle, plus nDevices */
+static napi_value MultiCircuit0(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  void* p = NULL;
+  if (napi_get_value_external(env, argv[0], &p) != napi_ok || !p) { napi_throw_type_error(env, NULL, "zkwg: multi handle expected"); return NULL; }
+  napi_value v;
+  NAPI_OK(napi_create_int32(env, zkwg_multi_devices((zkwg_multi_t*)p), &v));
+  return v;
 }
 
 /* witnessToBigInts(buffer) -> bigint[]   (32-byte LE words -> napi_create_bigint_words) */
@@ -309,6 +399,9 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"witnessToBigInts", NULL, WitnessToBigInts, NULL, NULL, NULL, napi_default, NULL},
       {"strerror", NULL, StrError, NULL, NULL, NULL, napi_default, NULL},
       {"packField", NULL, PackField, NULL, NULL, NULL, napi_default, NULL},
+      {"createMulti", NULL, CreateMulti, NULL, NULL, NULL, napi_default, NULL},
+      {"calculateBatchMulti", NULL, CalculateBatchMulti, NULL, NULL, NULL, napi_default, NULL},
+      {"multiDevices", NULL, MultiCircuit0, NULL, NULL, NULL, napi_default, NULL},
       {"symText", NULL, SymText, NULL, NULL, NULL, napi_default, NULL},
       {"r1csLoad", NULL, R1csLoad, NULL, NULL, NULL, napi_default, NULL},
       {"r1csCheck", NULL, R1csCheck, NULL, NULL, NULL, napi_default, NULL},

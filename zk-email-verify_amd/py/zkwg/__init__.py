@@ -288,6 +288,51 @@ class Circuit:
         return out
 
 
+class MultiCircuit:
+    """The batch sharded over several GPUs of one node through the C-ABI (include/zkwg.h zkwg_multi_*):
+    contiguous shards, one handle + host thread per GPU, the 100-byte result table gathered on devices[0]
+    over RCCL.  `circuit` is a layout-only handle for packing and geometry."""
+
+    def __init__(self, devices, **circuit_kwargs):
+        self.circuit = Circuit(device=-1, **circuit_kwargs)
+        self.lib = self.circuit.lib
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.lib.zkwg_multi_create(C.byref(self.circuit.cfg), devs, len(devices), C.byref(h))
+        if rc != 0:
+            raise ZkwgError(self.lib.zkwg_strerror(rc).decode() + ": " + self.lib.zkwg_last_error().decode())
+        self.h = h
+        self.n_devices = self.lib.zkwg_multi_devices(h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.zkwg_multi_destroy(self.h)
+            self.h = None
+
+    def calculate_batch_host(self, records, want_witness=True, max_tile=0):
+        """-> (witness bytes or None, status list, table rows [(status, pubkeyHash, shaHi, shaLo)])"""
+        c = self.circuit
+        n = len(records) // c.in_stride
+        status = (C.c_int32 * n)()
+        out = (C.c_uint8 * (n * c.witness_bytes))() if want_witness else None
+        table = (C.c_uint8 * (n * 100))()
+        _check(self.lib.zkwg_calculate_batch_multi(self.h, records, n, out, c.witness_bytes, status, table, max_tile))
+        tb = bytes(table)
+        rows = [(int.from_bytes(tb[100 * i:100 * i + 4], "little", signed=True),
+                 int.from_bytes(tb[100 * i + 4:100 * i + 36], "little"),
+                 int.from_bytes(tb[100 * i + 36:100 * i + 68], "little"),
+                 int.from_bytes(tb[100 * i + 68:100 * i + 100], "little")) for i in range(n)]
+        return (bytes(out) if want_witness else None), list(status), rows
+
+
+def shard_range(n, n_shards, i):
+    """C-ABI zkwg_shard_range: (first, count) of shard i."""
+    lib = _lib.load()
+    f, c = C.c_uint64(), C.c_uint64()
+    lib.zkwg_shard_range(n, n_shards, i, C.byref(f), C.byref(c))
+    return f.value, c.value
+
+
 def convert_montgomery_device(d_values, n_values, to_montgomery=True, stream=None):
     """In-place standard <-> Montgomery form of n_values field elements in a torch CUDA uint8 tensor
     (prover hand-off, zkwg_convert_montgomery_device)."""

@@ -97,6 +97,12 @@ def load():
         "zkwg_check_constraints_device": (i32, [vp, vp, u64, u64, vp, vp]),
         "zkwg_check_constraints": (i32, [vp, vp, u64, u64, C.POINTER(C.c_uint64)]),
         "zkwg_convert_montgomery_device": (i32, [vp, u64, i32, vp]),
+        "zkwg_shard_range": (None, [u64, i32, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "zkwg_multi_create": (i32, [C.POINTER(Config), C.POINTER(C.c_int), i32, C.POINTER(vp)]),
+        "zkwg_multi_destroy": (None, [vp]),
+        "zkwg_multi_devices": (i32, [vp]),
+        "zkwg_multi_circuit": (vp, [vp, i32]),
+        "zkwg_calculate_batch_multi": (i32, [vp, vp, u64, vp, u64, vp, vp, u64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
@@ -113,5 +119,6 @@ EXPORTS = [
     "zkwg_generate_inputs_device", "zkwg_alloc_pinned", "zkwg_free_pinned", "zkwg_calculate_batch_device", "zkwg_prepare_device", "zkwg_expand_device", "zkwg_expand_montgomery_device", "zkwg_set_prepare_throttle", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_timing_summary", "zkwg_num_kernels",
     "zkwg_kernel_name", "zkwg_kernel_slots", "zkwg_wtns_size", "zkwg_write_wtns", "zkwg_write_sym",
     "zkwg_r1cs_load", "zkwg_r1cs_destroy", "zkwg_r1cs_info", "zkwg_check_constraints_device", "zkwg_check_constraints",
-    "zkwg_convert_montgomery_device",
+    "zkwg_convert_montgomery_device", "zkwg_shard_range", "zkwg_multi_create", "zkwg_multi_destroy", "zkwg_multi_devices",
+    "zkwg_multi_circuit", "zkwg_calculate_batch_multi",
 ]
