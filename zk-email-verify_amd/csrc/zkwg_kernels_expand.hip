@@ -21,16 +21,45 @@
 // WAVE_MODE = false: one workgroup per (portion, email group), threads interleaved over the portion.
 // WAVE_MODE = true : one WAVEFRONT per (portion, email group): every wave writes its own contiguous
 //                    portion (1 KiB per store instruction, back to back), 4 such waves per workgroup.
+#define ZK_FOR_CHUNKS(c) \
+  for (u32 c = MONT ? 2u * tid : tid; c < nch; c = MONT ? ((c & 1u) ? c + 2u * ZK_EXPAND_THREADS - 1u : c + 1u) : c + ZK_EXPAND_THREADS)
+#define ZK_STORE(c, v) do { if constexpr (MONT) zk_mont_put(dst, c, v, vkeep, rtab); else dst[c] = (v); } while (0)
+
+// the rare general case (a genuine field element: inverses, v_ab, carries ...): one Montgomery product;
+// kept out of line so that the 20 store sites of the kernel stay small
+__device__ __noinline__ void zk_mont_general(uint4* __restrict__ dst2, uint4 a, uint4 b) {
+  const Fr x{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
+  const Fr m = fr_to_mont(x);
+  dst2[0] = make_uint4((u32)m.l[0], (u32)(m.l[0] >> 32), (u32)m.l[1], (u32)(m.l[1] >> 32));
+  dst2[1] = make_uint4((u32)m.l[2], (u32)(m.l[2] >> 32), (u32)m.l[3], (u32)(m.l[3] >> 32));
+}
+// Montgomery-form output of one slot: `lo` / `hi` are its two standard-form halves
+__device__ __forceinline__ void zk_mont_put(uint4* __restrict__ dst, u32 c, const uint4& v, uint4& vkeep,
+                                            const uint4* __restrict__ rtab) {
+  if (!(c & 1u)) { vkeep = v; return; }
+  const uint4 a = vkeep, b = v;
+  uint4 v0, v1;
+  if ((b.x | b.y | b.z | b.w | a.y | a.z | a.w) == 0u && a.x < 65536u) {
+    if (a.x == 0u) { v0 = zk_zero4(); v1 = zk_zero4(); }
+    else if (a.x == 1u) {
+      const Fr Rm = fr_R();
+      v0 = make_uint4((u32)Rm.l[0], (u32)(Rm.l[0] >> 32), (u32)Rm.l[1], (u32)(Rm.l[1] >> 32));
+      v1 = make_uint4((u32)Rm.l[2], (u32)(Rm.l[2] >> 32), (u32)Rm.l[3], (u32)(Rm.l[3] >> 32));
+    } else { v0 = rtab[2 * a.x]; v1 = rtab[2 * a.x + 1]; }
+  } else {
+    zk_mont_general(dst + (c - 1), a, b);
+    return;
+  }
+  dst[c - 1] = v0;
+  dst[c] = v1;
+}
 //
-// MONT = true (prover hand-off): the same portion is first expanded into LDS (64 KiB =
-// 2048 slots, standard form, the identical segment code) and then streamed to HBM as x * 2^256 mod r:
-// 0 -> 0, 1 -> R (constants), values below 2^16 from a table of v * R, anything else one Montgomery
-// product by R^2.  Still one write per witness byte and no read of the witness: a device prover (MSM /
+// MONT = true (prover hand-off): the identical segment code, but a thread produces both
+// halves of a slot and writes them as x * 2^256 mod r: 0 -> 0, 1 -> R (constants), values below 2^16
+// from a table of v * R, anything else one Montgomery product by R^2.  Still one write per witness byte and no read of the witness: a device prover (MSM /
 // NTT kernels want Montgomery scalars) costs no extra HBM pass.
 template <int ZK_BLOCK_THREADS, bool WAVE_MODE, bool MONT = false>
 __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B) {
-  constexpr u32 ZK_MONT_SUB = 512u;          // slots staged in LDS at a time (16 KiB: occupancy stays at 8 workgroups per CU)
-  __shared__ uint4 stage[MONT ? 2 * ZK_MONT_SUB : 1];
   constexpr u32 ZK_EXPAND_THREADS = WAVE_MODE ? 64u : (u32)ZK_BLOCK_THREADS;
   constexpr u32 UNITS_PER_BLOCK = WAVE_MODE ? (u32)ZK_BLOCK_THREADS / 64u : 1u;
   // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Give every XCD a contiguous run of units:
@@ -53,28 +82,26 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
   const u32 el0 = g * E;                                   // first email (launch-local index)
   const u32 el1 = min(el0 + E, B.n_emails - B.e_first);    // one past the last
   if (el0 >= el1) return;
-  const u64 pslot0 = (u64)p * s.portion;
-  const u64 pslot1 = min(s.W, pslot0 + s.portion);
+  const u64 slot0 = (u64)p * s.portion;
+  const u64 slot1 = min(s.W, slot0 + s.portion);
   const uint4* __restrict__ invtab = (const uint4*)B.invtab;
   const u32 tid = WAVE_MODE ? (threadIdx.x & 63u) : threadIdx.x;
 
-  // standard output: one pass over the whole portion; Montgomery output: sub-portions of ZK_MONT_SUB slots
-  u64 slot0 = pslot0;
-  do {
-  const u64 slot1 = MONT ? min(pslot1, slot0 + ZK_MONT_SUB) : pslot1;
+  // Montgomery output: a thread handles the two 16-byte chunks of a slot back to back (ZK_FOR_CHUNKS), keeps the
+  // low half in `vkeep` and converts + stores the pair when the high half arrives (zk_mont_put)
+  uint4 vkeep = zk_zero4();
+  const uint4* __restrict__ rtab = (const uint4*)B.rtab;      // v * R mod r for v < 65536
+  (void)vkeep; (void)rtab;
   for (u32 si = B.first_seg[p]; si < s.nsegs; ++si) {
     const ZkSeg sg = B.segs[si];
     if (sg.slot >= slot1) break;
-    if (MONT && sg.slot + sg.nslots <= slot0) continue;
     const u64 lo = max(sg.slot, slot0);
     const u64 hi = min(sg.slot + sg.nslots, slot1);
     const u32 r0 = (u32)(lo - sg.slot) + sg.r0;  // first element of the logical array handled here
     const u32 nch = (u32)(hi - lo) * 2;          // chunks to write
    for (u32 el = el0; el < el1; ++el) {
     const u32 e = el + B.e_first;                // email index inside the prepared batch
-    uint4* __restrict__ dst;
-    if constexpr (MONT) dst = stage + (lo - slot0) * 2;
-    else dst = B.wit + ((u64)el * s.W + lo) * 2;
+    uint4* __restrict__ dst = B.wit + ((u64)el * s.W + lo) * 2;
     const u8* __restrict__ rec = B.in + (u64)e * s.in_stride;
     const u64* __restrict__ bits = B.bits + (u64)e * s.img_bits;
     const u32* __restrict__ small = B.small + (u64)e * s.img_small;
@@ -82,30 +109,30 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
 
     switch (sg.type) {
       case ZSEG_SMALL:
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) v.x = small[sg.src + r0 + (c >> 1)];
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       case ZSEG_FR: {
         const uint4* src = (const uint4*)(frv + sg.src + r0);
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) dst[c] = src[c];
+        ZK_FOR_CHUNKS(c) { const uint4 v = src[c]; ZK_STORE(c, v); }
         break;
       }
       case ZSEG_BITS:
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) {
             u32 r = r0 + (c >> 1);
             u32 g = r / sg.a, bit = r - g * sg.a;
             v.x = (u32)(bits[sg.src + g * sg.b + (bit >> 6)] >> (bit & 63)) & 1u;
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       case ZSEG_SHA_SP:
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) {
             u32 r = r0 + (c >> 1);
@@ -113,11 +140,11 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             u32 sub = min(q >> 5, 4u);
             v.x = (u32)(bits[sg.src + i * 5 + sub] >> (q - sub * 32)) & 1u;
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       case ZSEG_SHA_T1:
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) {
             u32 r = r0 + (c >> 1);
@@ -125,11 +152,11 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             u32 sub = min(q >> 5, 3u);
             v.x = (u32)(bits[sg.src + i * 4 + sub] >> (q - sub * 32)) & 1u;
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       case ZSEG_SHA_T2:
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) {
             u32 r = r0 + (c >> 1);
@@ -137,12 +164,12 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             u32 sub = min(q >> 5, 4u);
             v.x = (u32)(bits[sg.src + i * 5 + sub] >> (q - sub * 32)) & 1u;
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       case ZSEG_ISZ: {
         const int half_tab = (int)s.inv_half;
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           u32 r = r0 + (c >> 1);
           int d = (int)small[sg.src + (r >> 1)];
           uint4 v = zk_zero4();
@@ -152,7 +179,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             d = max(-half_tab, min(half_tab, d));
             v = invtab[(u32)(d + half_tab) * 2 + (c & 1u)];
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       }
@@ -161,7 +188,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
         const u32 NB = sg.a, per = 3 * NB;
         const int idx = (int)small[sg.src];
         const int half_tab = (int)s.inv_half;
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           u32 r = r0 + (c >> 1), hf = c & 1u;
           u32 k = r / per, q = r - k * per;
           uint4 v = zk_zero4();
@@ -177,52 +204,52 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
               v = invtab[(u32)(d + half_tab) * 2 + hf];
             }
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       }
       case ZSEG_IN8:
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) v.x = rec[sg.src + r0 + (c >> 1)];
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       case ZSEG_IN8MASK:
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) { const u32 r = r0 + (c >> 1); v.x = (u32)rec[sg.src + r] * (u32)rec[sg.a + r]; }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       case ZSEG_IN8BITS:
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) {
             u32 r = r0 + (c >> 1);
             v.x = (u32)(rec[sg.src + (r >> 3)] >> (r & 7)) & 1u;
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       case ZSEG_LIMB:
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) v = *(const uint4*)(rec + sg.src + 16 * (r0 + (c >> 1)));
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       case ZSEG_LTBITS: {
         const long long base = (long long)(int)small[sg.src] + (1ll << sg.a);
         const u32 per = sg.a + 1;
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) {
             u32 r = r0 + (c >> 1);
             u32 i = r / per, bit = r - i * per;
             v.x = (u32)((u64)(base - (long long)i) >> bit) & 1u;
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       }
@@ -232,7 +259,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
         const u32 bl = sg.a, per = 6 + bl + 1, N = sg.c;
         const int start = (int)small[sg.src];
         const int half_tab = (int)s.inv_half;
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           u32 r = r0 + (c >> 1), hf = c & 1u;
           u32 i, q;
           if (r < per - 2) {  // index 0 has no "previous" IsZero
@@ -257,14 +284,14 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             long long val = (long long)start + 43 + (1ll << bl) - (long long)i;
             v.x = (u32)((u64)val >> (q - 6)) & 1u;
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       }
       case ZSEG_VSHIFT: {
         const u32 N = sg.a;
         const u32 shift = small[sg.src];
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           uint4 v = zk_zero4();
           if (!(c & 1u)) {
             u32 r = r0 + (c >> 1);
@@ -272,7 +299,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             u32 sh = shift & ((2u << j) - 1u);
             v.x = small[sg.b + (i + sh) % N];
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       }
@@ -280,7 +307,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
       case ZSEG_B64: {
         const int half_tab = (int)s.inv_half;
         const u32 per = sg.type == ZSEG_B64 ? 68u : 6u;
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+        ZK_FOR_CHUNKS(c) {
           u32 r = r0 + (c >> 1), hf = c & 1u;
           u32 g = r / per, q = r - g * per;
           const int ch = (int)small[sg.src + g];
@@ -312,7 +339,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
               v = invtab[(u32)(d + half_tab) * 2 + hf];
             }
           }
-          dst[c] = v;
+          ZK_STORE(c, v);
         }
         break;
       }
@@ -327,7 +354,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
         const u32 pb = sg.b, pc = sg.c;
         // PER = kept slots per position (compile time); f(i, q, word) -> small value (high half is zero)
 #define ZK_DFA_LOOP(PER, IDX_OFF, EXPR)                                                   \
-        for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {                              \
+        ZK_FOR_CHUNKS(c) {                              \
           uint4 v = zk_zero4();                                                           \
           if (!(c & 1u)) {                                                                \
             const u32 r = r0 + (c >> 1);                                                  \
@@ -337,18 +364,18 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             (void)b; (void)st; (void)nx; (void)sn; (void)q;                               \
             v.x = (EXPR);                                                                 \
           }                                                                               \
-          dst[c] = v;                                                                     \
+          ZK_STORE(c, v);                                                                     \
         }
         switch (sg.a) {
           case ZDFA_EQ:
-            for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+            ZK_FOR_CHUNKS(c) {
               const u32 r = r0 + (c >> 1), hf = c & 1u;
               const u32 i = r >> 1;
               int d = (int)pb - (int)(pos[i] & 255u);          // isz.in = in[1] - in[0] = ch - in[i]
               uint4 v = zk_zero4();
               if (!(r & 1u)) { if (!hf) v.x = (d == 0); }
               else { d = max(-half_tab, min(half_tab, d)); v = invtab[(u32)(d + half_tab) * 2 + hf]; }
-              dst[c] = v;
+              ZK_STORE(c, v);
             }
             break;
           case ZDFA_LT: ZK_DFA_LOOP(9u, 0u, ((pc ? pb + b : pb - b) >> q) & 1u) break;
@@ -377,17 +404,17 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
         const u8* __restrict__ enc = rec + sg.src;
         const int half_tab = (int)s.inv_half;
         if (sg.a == ZRS_EQ) {
-          for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          ZK_FOR_CHUNKS(c) {
             const u32 r = r0 + (c >> 1), hf = c & 1u;
             int d = (int)sg.c - (int)enc[(r >> 1) + sg.b];   // isz.in = in[1] - in[0]
             uint4 v = zk_zero4();
             if (!(r & 1u)) { if (!hf) v.x = (d == 0); }
             else { d = max(-half_tab, min(half_tab, d)); v = invtab[(u32)(d + half_tab) * 2 + hf]; }
-            dst[c] = v;
+            ZK_STORE(c, v);
           }
         } else {
           const u32 M = sg.b;
-          for (u32 c = tid; c < nch; c += ZK_EXPAND_THREADS) {
+          ZK_FOR_CHUNKS(c) {
             uint4 v = zk_zero4();
             if (!(c & 1u)) {
               const u32 r = r0 + (c >> 1);
@@ -402,7 +429,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
                 v.x = z ? 0u : (u32)enc[r];
               }
             }
-            dst[c] = v;
+            ZK_STORE(c, v);
           }
         }
         break;
@@ -412,43 +439,11 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
     }
    }
   }
-  if constexpr (MONT) {
-    // phase 2: LDS (standard form) -> HBM (Montgomery form); emails_per_wg is 1 in this mode
-    __syncthreads();
-    const u32 nsl = (u32)(slot1 - slot0);
-    uint4* __restrict__ out = B.wit + ((u64)el0 * s.W + slot0) * 2;
-    const uint4* __restrict__ rtab = (const uint4*)B.rtab;      // v * R mod r for v < 65536
-    const Fr Rm = fr_R();
-    // one slot per thread (the Montgomery product, where one is needed, is computed once)
-    for (u32 sl = tid; sl < nsl; sl += ZK_EXPAND_THREADS) {
-      const uint4 a = stage[2 * sl], b = stage[2 * sl + 1];
-      uint4 v0, v1;
-      if ((b.x | b.y | b.z | b.w | a.y | a.z | a.w) == 0u && a.x < 65536u) {
-        if (a.x == 0u) { v0 = zk_zero4(); v1 = zk_zero4(); }
-        else if (a.x == 1u) {
-          v0 = make_uint4((u32)Rm.l[0], (u32)(Rm.l[0] >> 32), (u32)Rm.l[1], (u32)(Rm.l[1] >> 32));
-          v1 = make_uint4((u32)Rm.l[2], (u32)(Rm.l[2] >> 32), (u32)Rm.l[3], (u32)(Rm.l[3] >> 32));
-        } else { v0 = rtab[2 * a.x]; v1 = rtab[2 * a.x + 1]; }
-      } else {
-        const Fr x{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
-        const Fr m = fr_to_mont(x);
-        v0 = make_uint4((u32)m.l[0], (u32)(m.l[0] >> 32), (u32)m.l[1], (u32)(m.l[1] >> 32));
-        v1 = make_uint4((u32)m.l[2], (u32)(m.l[2] >> 32), (u32)m.l[3], (u32)(m.l[3] >> 32));
-      }
-      out[2 * sl] = v0;
-      out[2 * sl + 1] = v1;
-    }
-    __syncthreads();   // the stage is rewritten by the next sub-portion
-    slot0 += ZK_MONT_SUB;
-  } else {
-    break;             // standard output: the whole portion in one pass
-  }
-  } while (slot0 < pslot1);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand_256(ZkSched s, ZkBufs B) { zk_expand_body<256, false>(s, B); }
 __global__ __launch_bounds__(512) void zk_expand_512(ZkSched s, ZkBufs B) { zk_expand_body<512, false>(s, B); }
 __global__ __launch_bounds__(1024) void zk_expand_1024(ZkSched s, ZkBufs B) { zk_expand_body<1024, false>(s, B); }
 __global__ __launch_bounds__(256) void zk_expand_wave(ZkSched s, ZkBufs B) { zk_expand_body<256, true>(s, B); }
-__global__ __launch_bounds__(256) void zk_expand_mont_256(ZkSched s, ZkBufs B) { zk_expand_body<256, false, true>(s, B); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void zk_expand_mont_256(ZkSched s, ZkBufs B) { zk_expand_body<256, false, true>(s, B); }
 

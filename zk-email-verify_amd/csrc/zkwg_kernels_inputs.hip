@@ -46,8 +46,10 @@ __global__ __launch_bounds__(64) void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8
   for (u32 i = lane; i < s.in_stride; i += 64) rec[i] = 0;
   __syncthreads();
   // sha256Pad(headers, maxHeadersLength): message | 0x80 | zeros | 64-bit BE bit length, zero padded to max
-  const u32 hpad = ((hl + 9 + 63) / 64) * 64;
-  if (hpad > N || hl > D.header_stride) { if (lane == 0) err = 1; }   // "Padding to max length did not complete properly!"
+  const u64 hpad64 = (((u64)hl + 9 + 63) / 64) * 64;      // 64-bit: a huge length must not wrap
+  const bool hdr_ok = hpad64 <= N && hl <= D.header_stride;
+  const u32 hpad = hdr_ok ? (u32)hpad64 : 0u;
+  if (!hdr_ok) { if (lane == 0) err = 1; }   // "Padding to max length did not complete properly!"
   else {
     for (u32 i = lane; i < hl; i += 64) rec[s.in_off[0] + i] = hdr[i];
     if (lane == 0) {
@@ -63,10 +65,13 @@ __global__ __launch_bounds__(64) void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8
     const u8* body = D.bodies + (u64)e * D.body_stride;
     const u32 bl = D.body_len[e];
     // bodyHashIndex = headers.toString().indexOf(bodyHash)   (-1 -> 0xffffffff)
+    // (not on the device: the getAdjustedSelector fallback of input-generators.ts:44-105,224-227 for a
+    //  selector that spans a "=\r\n" soft break -- such emails return err 3 here and go through the host
+    //  mirror zkwg.inputs, which implements it)
     if (lane == 0) {
       const u8* bh = D.body_hash_b64 + (u64)e * 44;
       u32 idx = 0xffffffffu;
-      for (u32 i = 0; i + 44 <= hl && idx == 0xffffffffu; ++i) {
+      for (u32 i = 0; hdr_ok && i + 44 <= hl && idx == 0xffffffffu; ++i) {   // never read past the header slot
         u32 k = 0;
         while (k < 44 && hdr[i + k] == bh[k]) ++k;
         if (k == 44) idx = i;
@@ -74,7 +79,8 @@ __global__ __launch_bounds__(64) void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8
       *(u32*)(rec + s.in_off[8]) = idx;
     }
     // padded body (virtual): body | 0x80 | zeros | length, length bpad = 64-multiple
-    const u32 bpad = ((bl + 9 + 63) / 64) * 64;
+    const bool body_ok = bl <= D.body_stride && (u64)bl + 9 + 63 < (1ull << 32);
+    const u32 bpad = body_ok ? ((bl + 9 + 63) / 64) * 64 : 0u;
     auto padded = [&](u32 i) -> u32 {
       if (i < bl) return body[i];
       if (i == bl) return 0x80u;
@@ -84,7 +90,8 @@ __global__ __launch_bounds__(64) void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8
     if (lane == 0) {
       // findIndexInUint8Array (sha-utils.ts:9-24), literally: on a mismatch j restarts at 0 and i advances
       u32 sel_idx = 0;
-      if (D.selector_len) {
+      if (!body_ok) err = 4;                                  // body longer than its slot: nothing is read from it
+      if (D.selector_len && body_ok) {
         const u32 total = max(M, ((bl + 63 + 65) / 64) * 64);  // bodyPadded length (input-generators.ts:219-221)
         u32 i = 0, j = 0;
         sel_idx = 0xffffffffu;
@@ -96,10 +103,7 @@ __global__ __launch_bounds__(64) void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8
         if (sel_idx == 0xffffffffu) err = 3;                // "SHA precompute selector ... not found in the body"
       }
       u32 cut = sel_idx == 0xffffffffu ? 0 : (sel_idx / 64) * 64;
-      if (!err) {
-        if (bl > D.body_stride) err = 4;
-        else if (bpad - cut > M) err = 2;                   // "Remaining body ... is longer than max"
-      }
+      if (!err && bpad - cut > M) err = 2;                  // "Remaining body ... is longer than max"
       cut_sh = cut;
       // partialSha(precomputeText): SHA-256 state after body[0..cut)
       u32 st[8];
