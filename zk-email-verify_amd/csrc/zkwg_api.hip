@@ -32,6 +32,7 @@ struct zkwg_circuit {
   Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
+  u32 pos_dense_off;
   Fr* d_pos_rs;   // removeSoftLineBreaks: Poseidon(16) then Poseidon(2) sparse-round tables
   ZkSeg* d_segs;
   u32* d_first_seg;
@@ -201,8 +202,11 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     if (ok && c->s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER) {
       std::vector<Fr> C, M, t10;
       build_poseidon_constants(10, 8, 60, C, M);
-      ok = zk_build_poseidon_sparse(10, 60, C, M, t10) &&
-           hipMalloc((void**)&c->d_pos, t10.size() * sizeof(Fr)) == hipSuccess &&
+      ok = zk_build_poseidon_sparse(10, 60, C, M, t10);
+      c->pos_dense_off = (u32)t10.size();
+      t10.insert(t10.end(), C.begin(), C.end());     // dense tables for zk_poseidon9_wave
+      t10.insert(t10.end(), M.begin(), M.end());
+      ok = ok && hipMalloc((void**)&c->d_pos, t10.size() * sizeof(Fr)) == hipSuccess &&
            hipMemcpy(c->d_pos, t10.data(), t10.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (ok && c->s.rslb) {
@@ -459,7 +463,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.frv = (Fr*)scr;
   B.invtab = c->d_invtab;
   B.pos_c = c->d_pos;
-  B.pos_m = nullptr;
+  B.pos_m = c->d_pos ? c->d_pos + c->pos_dense_off : nullptr;
   B.rtab = c->d_rtab;
   B.pos16 = c->d_pos_rs;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
@@ -506,7 +510,8 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     c->pos_calls++;
     hipEventRecord(c->pos_dep[pos_slot], st);
     hipStreamWaitEvent(ps, c->pos_dep[pos_slot], 0);
-    hipLaunchKernelGGL(zk_poseidon9, dim3((ne + 63) / 64), dim3(64), 0, ps, s, B);
+    if (ne < 1024) hipLaunchKernelGGL(zk_poseidon9_wave, dim3(ne), dim3(64), 0, ps, s, B);
+    else hipLaunchKernelGGL(zk_poseidon9, dim3((ne + 63) / 64), dim3(64), 0, ps, s, B);
     hipEventRecord(c->pos_done[pos_slot], ps);
   }
   if (tm) hipEventRecord(evs[ki], st);
@@ -533,7 +538,11 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), dyn, st, s, B);
   }
   if (tm) hipEventRecord(evs[++ki], st);
-  if (pos9 && pos_slot < 0) hipLaunchKernelGGL(zk_poseidon9, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
+  if (pos9 && pos_slot < 0) {
+    // one lane per email once the batch supplies >= 16 wavefronts of them; one wavefront per email below
+    if (ne < 1024) hipLaunchKernelGGL(zk_poseidon9_wave, dim3(ne), dim3(64), 0, st, s, B);
+    else hipLaunchKernelGGL(zk_poseidon9, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
+  }
   if (pos_slot >= 0) hipStreamWaitEvent(st, c->pos_done[pos_slot], 0);   // join
   if (s.rslb) {
     // removeSoftLineBreaks: chunk hashes (one lane per 16-byte chunk), then the serial merge chain + scans

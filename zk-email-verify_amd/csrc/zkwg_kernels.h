@@ -12,6 +12,7 @@ __global__ void zk_expand_wave(ZkSched s, ZkBufs B);
 __global__ void zk_expand_mont_256(ZkSched s, ZkBufs B);  // fused standard -> Montgomery output
 __global__ void zk_rsa(ZkSched s, ZkBufs B);         // zkwg_kernels_rsa.hip
 __global__ void zk_poseidon9(ZkSched s, ZkBufs B);   // zkwg_kernels_rsa.hip
+__global__ void zk_poseidon9_wave(ZkSched s, ZkBufs B);
 __global__ void zk_misc_ev(ZkSched s, ZkBufs B);     // zkwg_kernels_misc.hip
 __global__ void zk_rslb_chunks(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip
 __global__ void zk_rslb_chain(ZkSched s, ZkBufs B);

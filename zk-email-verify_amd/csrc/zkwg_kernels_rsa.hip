@@ -7,6 +7,7 @@
 #include "zkwg_kernels.h"
 #include "zkwg_rsa_wave.h"
 #include "zkwg_poseidon_sparse.h"
+#include "zkwg_poseidon_core.h"
 
 __global__ __launch_bounds__(64) void zk_rsa(ZkSched s, ZkBufs B) {
   __shared__ ZkRsaLds S;
@@ -52,4 +53,25 @@ __global__ __launch_bounds__(64) void zk_poseidon9(ZkSched s, ZkBufs B) {
   Fr tmp[10];
   const Fr h = zk_poseidon_sparse<10>(stl, 64, B.pos_c, 60, frv + s.f_pos, tmp, 1);
   frv[s.f_out] = h;
+}
+
+// Small batches (a few hundred emails): one lane per email leaves the chip empty and costs ~3.6 ms of
+// latency; here one WAVEFRONT per email runs the dense rounds wave-collectively (zkwg_poseidon_core.h,
+// ~0.7 ms, 12 x the multiplier issues -- irrelevant when the batch cannot fill the chip anyway).
+// B.pos_m: C[680] then M[100] in Montgomery form.
+__global__ __launch_bounds__(64) void zk_poseidon9_wave(ZkSched s, ZkBufs B) {
+  __shared__ ZkPosLds PS;
+  __shared__ u64 limb[ZK_RSA_K][2];
+  const u32 e = blockIdx.x;
+  if (e >= B.n_emails) return;
+  const u8* rec = B.in + (u64)e * s.in_stride;
+  Fr* frv = B.frv + (u64)e * s.img_fr;
+  const u64 top_mask = (1ull << 57) - 1;
+  if (threadIdx.x < ZK_RSA_K) {
+    const u64* pm = (const u64*)(rec + s.rsa.in_mod + 16 * threadIdx.x);
+    limb[threadIdx.x][0] = pm[0];
+    limb[threadIdx.x][1] = pm[1] & top_mask;
+  }
+  __syncthreads();
+  zk_poseidon_large(PS, limb, B.pos_m, B.pos_m + 680, frv + s.f_pos, frv + s.f_out);
 }

@@ -219,7 +219,7 @@ struct ZkBufs {
   Fr* frv;               // image: field elements  [n_emails][img_fr]
   const Fr* invtab;      // d^-1 for d in [-inv_half, inv_half]
   const Fr* pos_c;       // Poseidon(9) sparse-round table (zkwg_poseidon_sparse.h layout, t = 10, R_P = 60)
-  const Fr* pos_m;       // unused (kept for layout stability)
+  const Fr* pos_m;       // Poseidon(9) dense tables for the wave-collective small-batch kernel: C[680], M[100] (Montgomery)
   const Fr* pos16;       // Poseidon(16) sparse-round table (zkwg_poseidon_sparse.h), removeSoftLineBreaks only
   const Fr* pos2;        // Poseidon(2)  sparse-round table
   const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
