@@ -132,6 +132,23 @@ int zkwg_circuit_create(const zkwg_config* cfg, int device, zkwg_circuit_t** out
  * On ZKWG_RC_BAD_CONFIG, zkwg_last_error() says which signal did not match.  cfg->layout is ignored. */
 int zkwg_circuit_create_sym(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
                             const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out);
+/* Complete witnesses for a circuit compiled without full simplification (the reference documents
+ * `circom ... --O0`, docs/zk-email-docs/UsageGuide/README.md:56-64): besides the `.sym` file the compiler's
+ * `.r1cs` is given.  Signals this library's schedule produces are written at their `.sym` index by
+ * zk_expand; every other signal the file numbers (aliases, constants, linear combinations -- 2.4 M of the
+ * 3.1 M signals of EmailVerifier(576,192) at O0) is derived from the LINEAR constraints of the `.r1cs`
+ * (triangular elimination at creation; one extra kernel, zk_linear_fill, after zk_expand).  Creation fails
+ * with zkwg_last_error naming the first signal that is neither produced nor linearly defined (a quadratic
+ * signal of a template this schedule does not implement, e.g. zk-regex's real BodyHashRegex).  Multi-
+ * dimensional signal names (`a[t][k]`) are accepted by both `.sym` entry points. */
+int zkwg_circuit_create_full(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
+                             const char* alias_text, uint64_t alias_len, const uint8_t* r1cs, uint64_t r1cs_len,
+                             zkwg_circuit_t** out);
+uint64_t zkwg_linear_rows(const zkwg_circuit_t* c);                       /* derived signals of such a handle */
+/* `.sym` layouts: out[s] = witness index of the default (kept-v1) layout's slot s, 0xffffffff if the file
+ * eliminated it; returns the number of kept-v1 slots (0 for a handle without a `.sym`). */
+uint64_t zkwg_layout_map(const zkwg_circuit_t* c, uint32_t* out, uint64_t cap);
+int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness); /* layout-only handles: host evaluation */
 const char* zkwg_last_error(void);   /* detail of the calling thread's last ZKWG_RC_BAD_CONFIG */
 void zkwg_circuit_destroy(zkwg_circuit_t* c);
 

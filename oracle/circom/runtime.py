@@ -151,7 +151,7 @@ def _nest(flat, dims, start=0):
 # --------------------------------------------------------------------------- runtime objects
 class Sig:
     """One declared signal (array) of a template instance."""
-    __slots__ = ("name", "kind", "dims", "strides", "size", "vals", "how")
+    __slots__ = ("name", "kind", "dims", "strides", "size", "vals", "how", "base")
 
     def __init__(self, name, kind, dims):
         self.name = name
@@ -166,6 +166,7 @@ class Sig:
         self.size = size
         self.vals = [None] * size
         self.how = None  # optional per-element provenance ('<==' / '<--'), filled when tracking
+        self.base = 0    # first temporary wire id of this signal (constraint generation, symbolic.py)
 
 
 class Inst:
@@ -261,6 +262,7 @@ class Program:
         self.soft_failures = None   # list -> collect `===`/assert failures instead of raising
         self.logs = []
         self.anon_serial = 0
+        self.next_wire = 1          # temporary wire ids in declaration order (0 = the constant 1)
         if main_file is not None:
             self.load(main_file)
 
@@ -780,6 +782,8 @@ class Program:
                 if name in inst.sigs:
                     raise CircomError(f"{inst.name}: signal {name} declared twice")
                 s = Sig(name, kind, dims)
+                s.base = prog.next_wire
+                prog.next_wire += s.size
                 inst.sigs[name] = s
                 made.append(s)
                 if kind == "in":

@@ -16,6 +16,7 @@
 #include "zkwg_layout.h"
 #include "zkwg_build.h"
 #include "zkwg_poseidon_sparse.h"
+#include "zkwg_full.h"
 
 #define ZK_MAX_KERNELS 8
 #define ZK_RS_SLOTS 16
@@ -29,6 +30,10 @@ struct zkwg_circuit {
   int device;
   Fr* d_invtab;
   std::vector<std::string> sym_names;  // layout SYM: witness index -> name
+  // linear completion plan of a fully numbered (O0 / O1) circuit (zkwg_full.h); null for compact layouts
+  u64* d_lin_row; u32* d_lin_dst; u32* d_lin_src; Fr* d_lin_coef; u8* d_lin_kind; u64 lin_rows;
+  std::vector<u32> kept_dst;   // `.sym` layouts: kept-v1 slot -> witness index (0xffffffff = dropped by the file)
+  ZkLinPlan lin_host;   // kept for layout-only handles (tests evaluate it on the host)
   Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
@@ -141,7 +146,8 @@ static thread_local std::string g_last_error;
 const char* zkwg_last_error(void) { return g_last_error.c_str(); }
 
 static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_text, uint64_t sym_len,
-                       const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out) {
+                       const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out,
+                       const uint8_t* r1cs = nullptr, uint64_t r1cs_len = 0) {
   if (!cfg_in || !out) return ZKWG_RC_BAD_ARG;
   zkwg_config cfg_copy = *cfg_in;
   cfg_copy.layout = ZKWG_LAYOUT_KEPT_V1;
@@ -164,12 +170,25 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   if (getenv("ZKWG_DEBUG_SKIP_INV") && atoi(getenv("ZKWG_DEBUG_SKIP_INV")) && c->s.rsa.present) c->s.rsa.present = 2;  // profiling only
   if (sym_text) {
     ZkSymLayout L;
+    L.allow_holes = r1cs != nullptr;
     if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L) || !zk_remap_segments(c->s, c->segs, c->first_seg, L)) {
       g_last_error = L.err.empty() ? std::string(".sym layout does not tile the witness") : L.err;
       delete c;
       return ZKWG_RC_BAD_CONFIG;
     }
+    if (r1cs) {
+      // every signal the schedule does not produce must follow from the circuit's own linear constraints
+      ZkR1csHost R;
+      std::string err;
+      std::vector<u8> produced(L.W, 0);
+      for (u64 i = 0; i < L.W; ++i) produced[i] = L.hole[i] ? 0 : 1;
+      if (!zk_r1cs_parse(r1cs, r1cs_len, R)) err = "the .r1cs file could not be parsed";
+      else if (R.n_wires != L.W) err = "the .r1cs has " + std::to_string(R.n_wires) + " wires, the .sym file numbers " + std::to_string(L.W);
+      else zk_linear_plan(R, produced, c->lin_host, err);
+      if (!err.empty()) { g_last_error = err; delete c; return ZKWG_RC_BAD_CONFIG; }
+    }
     c->sym_names.swap(L.names);
+    c->kept_dst.swap(L.dst);
     c->cfg.layout = ZKWG_LAYOUT_SYM;
   }
   // kernel table (launch order)
@@ -199,6 +218,22 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     ok = ok && hipMemcpy(c->d_invtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(ZkSeg), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(c->d_first_seg, c->first_seg.data(), c->first_seg.size() * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && c->lin_host.n_rows()) {
+      const ZkLinPlan& Pn = c->lin_host;
+      const size_t nt = std::max<size_t>(Pn.src.size(), 1);
+      c->lin_rows = Pn.n_rows();
+      ok = hipMalloc((void**)&c->d_lin_row, Pn.row_ptr.size() * 8) == hipSuccess &&
+           hipMalloc((void**)&c->d_lin_dst, Pn.dst.size() * 4) == hipSuccess &&
+           hipMalloc((void**)&c->d_lin_src, nt * 4) == hipSuccess &&
+           hipMalloc((void**)&c->d_lin_coef, nt * sizeof(Fr)) == hipSuccess &&
+           hipMalloc((void**)&c->d_lin_kind, nt) == hipSuccess &&
+           hipMemcpy(c->d_lin_row, Pn.row_ptr.data(), Pn.row_ptr.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+           hipMemcpy(c->d_lin_dst, Pn.dst.data(), Pn.dst.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+           hipMemcpy(c->d_lin_src, Pn.src.data(), Pn.src.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+           hipMemcpy(c->d_lin_coef, Pn.coef.data(), Pn.coef.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess &&
+           hipMemcpy(c->d_lin_kind, Pn.kind.data(), Pn.kind.size(), hipMemcpyHostToDevice) == hipSuccess;
+      if (ok) { ZkLinPlan empty; std::swap(c->lin_host, empty); }   // the device copy is the one used
+    }
     if (ok && c->s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER) {
       std::vector<Fr> C, M, t10;
       build_poseidon_constants(10, 8, 60, C, M);
@@ -268,9 +303,10 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
 
 // no C++ exception may cross the C ABI (ctypes / N-API callers would abort)
 static int create_guarded(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
-                          const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out) {
+                          const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out,
+                          const uint8_t* r1cs = nullptr, uint64_t r1cs_len = 0) {
   try {
-    return create_impl(cfg, device, sym_text, sym_len, alias_text, alias_len, out);
+    return create_impl(cfg, device, sym_text, sym_len, alias_text, alias_len, out, r1cs, r1cs_len);
   } catch (const std::bad_alloc&) {
     g_last_error = "out of host memory while building the circuit";
     return ZKWG_RC_OOM;
@@ -289,11 +325,33 @@ int zkwg_circuit_create_sym(const zkwg_config* cfg, int device, const char* sym_
   return create_guarded(cfg, device, sym_text, sym_len, alias_text, alias_len, out);
 }
 
+int zkwg_circuit_create_full(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
+                             const char* alias_text, uint64_t alias_len, const uint8_t* r1cs, uint64_t r1cs_len,
+                             zkwg_circuit_t** out) {
+  if (!sym_text || !r1cs) return ZKWG_RC_BAD_ARG;
+  return create_guarded(cfg, device, sym_text, sym_len, alias_text, alias_len, out, r1cs, r1cs_len);
+}
+// layout-only handles (device < 0): evaluate the linear completion of one host witness in place (tests)
+int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness) {
+  if (!c || !witness) return ZKWG_RC_BAD_ARG;
+  const ZkLinPlan& Pn = c->lin_host;
+  for (u64 r = 0; r < Pn.n_rows(); ++r)
+    ((Fr*)witness)[Pn.dst[r]] = zk_linear_row(Pn.row_ptr.data(), Pn.src.data(), Pn.coef.data(), Pn.kind.data(), r, (const Fr*)witness);
+  return ZKWG_RC_OK;
+}
+uint64_t zkwg_layout_map(const zkwg_circuit_t* c, uint32_t* out, uint64_t cap) {
+  if (!c) return 0;
+  if (out) for (u64 i = 0; i < c->kept_dst.size() && i < cap; ++i) out[i] = c->kept_dst[i];
+  return c->kept_dst.size();
+}
+uint64_t zkwg_linear_rows(const zkwg_circuit_t* c) { return c ? (c->lin_rows ? c->lin_rows : c->lin_host.n_rows()) : 0; }
+
 void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab);
+    hipFree(c->d_lin_row); hipFree(c->d_lin_dst); hipFree(c->d_lin_src); hipFree(c->d_lin_coef); hipFree(c->d_lin_kind);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); }
     hipStreamDestroy(c->copy_stream);
@@ -618,6 +676,13 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
   else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);
   if (tm) { hipEventRecord(evs[1], st); c->ev_valid = true; c->launches++; }
+  if (c->lin_rows) {
+    // fully numbered circuit: derive the signals the schedule does not produce from the ones just written
+    if (mont) return ZKWG_RC_BAD_CONFIG;
+    hipLaunchKernelGGL(zk_linear_fill, dim3((u32)((c->lin_rows + 255) / 256), (u32)count), dim3(256), 0, st,
+                       c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, c->lin_rows, (u8*)d_out,
+                       out_stride);
+  }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;
 }

@@ -126,6 +126,34 @@ struct ZkSymLayout {
   std::vector<std::string> names;  // witness index -> name (as in the file)
   u64 W = 0;
   std::string err;
+  bool allow_holes = false;        // true: signals the schedule does not produce become holes (linear completion)
+  std::vector<u8> hole;            // witness index -> 1 if not produced by the schedule
+  u64 n_holes = 0;
+};
+// circom writes multi-dimensional signals as name[i][j]; this schedule names every signal array by its flattened
+// index.  Pre-pass over the file: the extent of every dimension of every signal array (all elements are listed,
+// eliminated ones with index -1), so that the second pass can flatten.  Only the LAST path component (the signal)
+// is flattened; component arrays keep their indices.
+struct ZkSymDims {
+  std::unordered_map<std::string, std::vector<u32>> ext;   // "path.signal" -> extents (only for >= 2 dims)
+  static bool split(const char* p, const char* e, const char*& base_end, u32* idx, int& nd) {
+    // name = path '.' signal ( '[' n ']' )*   -- parse the trailing index groups of the last component
+    nd = 0;
+    const char* q = e;
+    u32 tmp[8];
+    while (q > p && q[-1] == ']') {
+      const char* r = q - 1;
+      while (r > p && r[-1] != '[') --r;
+      if (r <= p) break;
+      if (nd >= 8) return false;
+      tmp[nd++] = (u32)strtoul(r, nullptr, 10);
+      q = r - 1;
+    }
+    // the groups must belong to the last component: no '.' after q
+    base_end = q;
+    for (int i = 0; i < nd; ++i) idx[i] = tmp[nd - 1 - i];
+    return true;
+  }
 };
 static inline void zk_collect_names(ZkSched tmp, std::vector<std::string>& names) {
   ZkWalker w;
@@ -166,6 +194,26 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
   L.names.push_back("one");
   u64 unmatched = 0, dup = 0, maxw = 0, nlines = 0;
   std::string first_unmatched;
+  // pass 1: extents of multi-dimensional signal arrays
+  ZkSymDims D;
+  for (u64 i = 0; i < len;) {
+    u64 j = i;
+    while (j < len && text[j] != '\n') ++j;
+    const char* p = text + i;
+    const char* e = text + j;
+    while (e > p && (e[-1] == '\r' || e[-1] == ' ')) --e;
+    i = j + 1;
+    const char* c1 = (const char*)memchr(p, ',', e - p);
+    const char* c2 = c1 ? (const char*)memchr(c1 + 1, ',', e - c1 - 1) : nullptr;
+    const char* c3 = c2 ? (const char*)memchr(c2 + 1, ',', e - c2 - 1) : nullptr;
+    if (!c3) continue;
+    const char* be; u32 idx[8]; int nd;
+    if (!ZkSymDims::split(c3 + 1, e, be, idx, nd) || nd < 2) continue;
+    auto& ex = D.ext[std::string(c3 + 1, be)];
+    if (ex.size() < (size_t)nd) ex.resize(nd, 0);
+    for (int k = 0; k < nd; ++k) ex[k] = std::max(ex[k], idx[k] + 1);
+  }
+  std::vector<std::pair<u64, std::string>> holes;   // (witness index, name) of signals this schedule does not produce
   for (u64 i = 0; i < len;) {
     u64 j = i;
     while (j < len && text[j] != '\n') ++j;
@@ -184,10 +232,32 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
     if (widx < 0) continue;   // eliminated signal
     std::string name(c3 + 1, e);
     if (widx == 0) continue;  // the constant-one wire (never listed by circom; tolerated)
+    {
+      // flatten name[i][j].. of a multi-dimensional signal to name[flat]
+      const char* be; u32 idx[8]; int nd;
+      if (ZkSymDims::split(c3 + 1, e, be, idx, nd) && nd >= 2) {
+        auto dit = D.ext.find(std::string(c3 + 1, be));
+        if (dit != D.ext.end() && dit->second.size() == (size_t)nd) {
+          u64 flat = 0;
+          for (int k = 0; k < nd; ++k) flat = flat * dit->second[k] + idx[k];
+          name = std::string(c3 + 1, be) + "[" + std::to_string(flat) + "]";
+        }
+      }
+    }
     auto it = slot_of.find(name);
-    if (it == slot_of.end()) { if (!unmatched++) first_unmatched = name; continue; }
+    if (it == slot_of.end()) {
+      if (L.allow_holes) {
+        if ((u64)widx >= (1ull << 31)) { L.err = "witness index out of range"; return false; }
+        holes.emplace_back((u64)widx, std::string(c3 + 1, e));
+        if ((u64)widx > maxw) maxw = (u64)widx;
+        continue;
+      }
+      if (!unmatched++) first_unmatched = name;
+      continue;
+    }
     // a layout can only re-order / drop this schedule's own signals: indices beyond its length are bogus
-    if ((u64)widx >= ours.size()) { L.err = "witness index " + std::to_string(widx) + " exceeds the schedule's witness length"; return false; }
+    if (!L.allow_holes && (u64)widx >= ours.size()) { L.err = "witness index " + std::to_string(widx) + " exceeds the schedule's witness length"; return false; }
+    if ((u64)widx >= (1ull << 31)) { L.err = "witness index out of range"; return false; }
     if (L.dst[it->second] != 0xffffffffu && L.dst[it->second] != (u32)widx) { ++dup; continue; }
     L.dst[it->second] = (u32)widx;
     if ((u64)widx > maxw) maxw = (u64)widx;
@@ -200,11 +270,20 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
   }
   if (dup) { L.err = std::to_string(dup) + " name(s) listed with two different witness indices"; return false; }
   L.W = maxw + 1;
-  // the kept indices must tile [0, W) exactly once
+  L.hole.assign(L.W, 0);
+  if (L.names.size() < L.W) L.names.resize(L.W);
+  for (auto& h : holes) {
+    if (L.hole[h.first]) { L.err = "witness index " + std::to_string(h.first) + " assigned to two signals"; return false; }
+    L.hole[h.first] = 1;
+    L.names[h.first].swap(h.second);
+  }
+  L.n_holes = holes.size();
+  // the kept indices (and the holes) must tile [0, W) exactly once
   std::vector<u8> seen(L.W, 0);
+  for (u64 i = 0; i < L.W; ++i) seen[i] = L.hole[i];
   for (u32 d : L.dst) {
     if (d == 0xffffffffu) continue;
-    if (seen[d]) { L.err = "witness index " + std::to_string(d) + " assigned to two signals"; return false; }
+    if (d >= L.W || seen[d]) { L.err = "witness index " + std::to_string(d) + " assigned to two signals"; return false; }
     seen[d] = 1;
   }
   for (u64 i = 0; i < L.W; ++i)
@@ -223,6 +302,15 @@ static bool zk_remap_segments(ZkSched& s, std::vector<ZkSeg>& segs, std::vector<
       u32 j = i + 1;
       while (j < g.nslots && L.dst[g.slot + j] == d + (j - i)) ++j;
       out.push_back(ZkSeg{d, j - i, g.type, g.src, g.a, g.b, g.c, g.r0 + i, 0});
+      i = j;
+    }
+  }
+  if (L.n_holes) {
+    for (u64 i = 0; i < L.W;) {
+      if (!L.hole[i]) { ++i; continue; }
+      u64 j = i + 1;
+      while (j < L.W && L.hole[j] && j - i < 0x7fffffffull) ++j;
+      out.push_back(ZkSeg{i, (u32)(j - i), ZSEG_HOLE, 0, 0, 0, 0, 0, 0});
       i = j;
     }
   }

@@ -49,7 +49,8 @@ enum ZkSegType : u32 {
   ZSEG_DFA = 16,    // BodyHashRegex DFA circuit arrays: a = ZkDfaKind, b/c = parameters, src = small idx of the per-position words (then class masks, primitive masks)
   ZSEG_IN8MASK = 17,// ByteMask: in[src + r] * in[a + r]   (data byte times mask byte)
   ZSEG_RSLB = 18,   // RemoveSoftLineBreaks byte-derived arrays over in[src ..]: a = ZkRslbKind, b/c = parameters
-  ZSEG_NTYPES = 19
+  ZSEG_HOLE = 19,   // signals this schedule does not produce: left to the linear completion pass (zkwg_full.h)
+  ZSEG_NTYPES = 20
 };
 
 // ZSEG_RSLB kinds (helpers/remove-soft-line-breaks.circom:14-126); enc = the emailBody bytes at src

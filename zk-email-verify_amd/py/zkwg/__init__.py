@@ -55,9 +55,12 @@ class Circuit:
 
     def __init__(self, main_kind=MAIN_EMAIL_VERIFIER, max_header=1024, max_body=1536, n=121, k=17,
                  ignore_body_hash_check=0, device=0, enable_header_masking=0, enable_body_masking=0,
-                 remove_soft_line_breaks=0, sym=None, sym_alias=None):
+                 remove_soft_line_breaks=0, sym=None, sym_alias=None, r1cs=None):
         """sym: text of the compiled circuit's `.sym` file -> the witness follows ITS indices
-        (zkwg_circuit_create_sym); sym_alias: optional "ours=theirs" rename rules, one per line."""
+        (zkwg_circuit_create_sym); sym_alias: optional "ours=theirs" rename rules, one per line;
+        r1cs: bytes of the compiled circuit's `.r1cs` -> complete witness of a circuit compiled with
+        --O0 / --O1: signals the schedule does not produce are derived from its linear constraints
+        (zkwg_circuit_create_full)."""
         self.lib = _lib.load()
         self.cfg = Config(main_kind, max_header, max_body, n, k, ignore_body_hash_check, enable_header_masking,
                           enable_body_masking, remove_soft_line_breaks, 0)
@@ -67,7 +70,12 @@ class Circuit:
         else:
             sb = sym.encode() if isinstance(sym, str) else bytes(sym)
             ab = None if sym_alias is None else (sym_alias.encode() if isinstance(sym_alias, str) else bytes(sym_alias))
-            rc = self.lib.zkwg_circuit_create_sym(C.byref(self.cfg), device, sb, len(sb), ab, len(ab) if ab else 0, C.byref(h))
+            if r1cs is None:
+                rc = self.lib.zkwg_circuit_create_sym(C.byref(self.cfg), device, sb, len(sb), ab, len(ab) if ab else 0, C.byref(h))
+            else:
+                rb = bytes(r1cs)
+                rc = self.lib.zkwg_circuit_create_full(C.byref(self.cfg), device, sb, len(sb), ab, len(ab) if ab else 0,
+                                                       rb, len(rb), C.byref(h))
         if rc == -1:
             raise ZkwgError(f"{self.lib.zkwg_strerror(rc).decode()}: {self.lib.zkwg_last_error().decode()}")
         _check(rc)
@@ -275,6 +283,19 @@ class Circuit:
         out = (C.c_uint8 * size)()
         _check(self.lib.zkwg_write_wtns(self.h, witness_bytes, out, size))
         return bytes(out)
+
+    def layout_map(self):
+        """`.sym` layouts: list, per slot of the default (kept-v1) layout, of its witness index (None = eliminated)."""
+        n = self.lib.zkwg_layout_map(self.h, None, 0)
+        out = (C.c_uint32 * n)()
+        self.lib.zkwg_layout_map(self.h, out, n)
+        return [None if v == 0xFFFFFFFF else v for v in out]
+
+    def linear_complete_host(self, witness):
+        """layout-only handle of a fully numbered circuit: derive the non-produced signals of one host witness
+        (bytearray of 32 W bytes whose produced slots are filled) in place."""
+        arr = (C.c_uint8 * len(witness)).from_buffer(witness)
+        _check(self.lib.zkwg_linear_complete_host(self.h, arr))
 
     def symbols(self):
         """[(slot, name)] of the layout (the .sym table)."""
