@@ -60,7 +60,16 @@ static napi_value CreateCircuit(napi_env env, napi_callback_info info) {
   char* sym = NULL; size_t sym_len = 0; char* alias = NULL; size_t alias_len = 0;
   get_str(env, argv[0], "sym", &sym, &sym_len);
   get_str(env, argv[0], "symAlias", &alias, &alias_len);
-  int rc = sym ? zkwg_circuit_create_sym(&cfg, device, sym, sym_len, alias, alias_len, &c)
+  /* optional `r1cs` (Buffer with the compiled circuit's .r1cs): complete witness of an O0 / O1 build */
+  void* r1cs = NULL; size_t r1cs_len = 0;
+  {
+    bool has = false; napi_value v; bool isbuf = false;
+    if (napi_has_named_property(env, argv[0], "r1cs", &has) == napi_ok && has &&
+        napi_get_named_property(env, argv[0], "r1cs", &v) == napi_ok && napi_is_buffer(env, v, &isbuf) == napi_ok && isbuf)
+      napi_get_buffer_info(env, v, &r1cs, &r1cs_len);
+  }
+  int rc = sym ? (r1cs ? zkwg_circuit_create_full(&cfg, device, sym, sym_len, alias, alias_len, (const uint8_t*)r1cs, r1cs_len, &c)
+                       : zkwg_circuit_create_sym(&cfg, device, sym, sym_len, alias, alias_len, &c))
                : zkwg_circuit_create(&cfg, device, &c);
   free(sym); free(alias);
   if (rc != ZKWG_RC_OK) {
