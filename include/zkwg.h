@@ -309,6 +309,63 @@ int zkwg_expand_montgomery_device(zkwg_circuit_t* c, const void* d_packed_inputs
                                   const void* d_scratch, uint64_t first, uint64_t count, void* d_out_wtns,
                                   uint64_t out_stride, void* hip_stream);
 
+/* ---- the compact image as a device-side interchange format --------------------------
+ * zkwg_prepare_device leaves, per email, a compact IMAGE in the scratch buffer (~0.45 MB instead of the 57 MB
+ * witness of EmailVerifier(1024,1536)): `bits` (u64 words of LSB-first bit groups), `small` (u32 values) and
+ * `fr` (32-byte standard-form field elements).  Together with the email's packed input record and the circuit's
+ * static SEGMENT TABLE it determines every witness slot: zk_expand is nothing but the evaluation of that table.
+ * A device consumer that can evaluate the table itself (an MSM that treats bit / byte scalars specially, a
+ * constraint checker ...) therefore never needs the 32-byte-per-signal witness in HBM.
+ *
+ * Scratch layout for a batch of n emails (all offsets in bytes, 256-byte aligned; zkwg_image_layout):
+ *   hstates  u32[n][hstate_words]   SHA-256 chaining states (internal to the prepare kernels)
+ *   bits     u64[n][bits_words]
+ *   small    u32[n][small_words]
+ *   fr       u8 [n][fr_elems][32]
+ * Segment semantics (slot = witness index, r = r0 + (slot - first_slot), rec = the email's input record):
+ *   see enum zkwg_segment_type; the per-type comments state how slot r derives from image / record.
+ *   Inverses of small integers d (|d| <= zkwg_inverse_table_half) are d^-1 mod r (0 for d = 0).
+ * The table follows the handle's layout (kept-v1 or a `.sym` order); ZKWG_SEG_HOLE only occurs for
+ * zkwg_circuit_create_full handles (slots derived afterwards from the `.r1cs`). */
+enum zkwg_segment_type {
+  ZKWG_SEG_SMALL = 0,    /* small[src + r]                                                            */
+  ZKWG_SEG_FR = 1,       /* fr[src + r]                                                               */
+  ZKWG_SEG_BITS = 2,     /* groups of a bits in b words: bit (r % a) of bits[src + (r / a) * b ...]    */
+  ZKWG_SEG_SHA_SP = 3,   /* 162-slot periods over 5 words (32,32,32,32,34 bits): SigmaPlus instances  */
+  ZKWG_SEG_SHA_T1 = 4,   /* 131-slot periods over 4 words (32,32,32,35): T1 instances                 */
+  ZKWG_SEG_SHA_T2 = 5,   /* 161-slot periods over 5 words (32,32,32,32,33): T2 instances              */
+  ZKWG_SEG_ISZ = 6,      /* IsZero pairs: d = (i32)small[src + r/2]; even r: d == 0, odd r: d^-1       */
+  ZKWG_SEG_SEL = 7,      /* 256 x ItemAtIndex(a): idx = (i32)small[src], digest words small[b..b+8)    */
+  ZKWG_SEG_IN8 = 8,      /* rec[src + r]                                                              */
+  ZKWG_SEG_IN8BITS = 9,  /* bit (r & 7) of rec[src + r/8]                                             */
+  ZKWG_SEG_LIMB = 10,    /* 16-byte LE limb rec[src + 16 r]                                           */
+  ZKWG_SEG_LTBITS = 11,  /* bits of (i32)small[src] + 2^a - i, i = r / (a+1), bit r % (a+1)            */
+  ZKWG_SEG_REGSEL = 12,  /* SelectRegexReveal comparators (see csrc/zkwg_sched.h)                      */
+  ZKWG_SEG_VSHIFT = 13,  /* VarShiftLeft.tmp[j][i] = small[b + (i + (small[src] & (2^(j+1)-1))) % a]    */
+  ZKWG_SEG_B64BITS = 14, /* 6 bits of the Base64 value of char small[src + r/6]                        */
+  ZKWG_SEG_B64 = 15,     /* Base64Lookup internals of char small[src + r/68]                           */
+  ZKWG_SEG_DFA = 16,     /* BodyHashRegex DFA circuit arrays (a = kind, b/c = parameters)              */
+  ZKWG_SEG_IN8MASK = 17, /* rec[src + r] * rec[a + r]                                                  */
+  ZKWG_SEG_RSLB = 18,    /* RemoveSoftLineBreaks byte-derived arrays over rec[src ..]                  */
+  ZKWG_SEG_HOLE = 19     /* not produced by the schedule (zkwg_circuit_create_full: derived later)     */
+};
+typedef struct zkwg_segment {
+  uint64_t slot;     /* first witness slot */
+  uint32_t nslots;
+  uint32_t type;     /* enum zkwg_segment_type */
+  uint32_t src, a, b, c;
+  uint32_t r0;       /* index of the first element inside the logical array */
+  uint32_t pad;
+} zkwg_segment;
+typedef struct zkwg_image_layout_t {
+  uint64_t hstate_words, bits_words, small_words, fr_elems;   /* per email */
+  uint64_t off_hstates, off_bits, off_small, off_fr;          /* byte offsets in the scratch buffer of n emails */
+  uint64_t total_bytes;                                       /* = zkwg_scratch_bytes(c, n) */
+} zkwg_image_layout_t;
+int zkwg_image_layout(const zkwg_circuit_t* c, uint64_t n_emails, zkwg_image_layout_t* out);
+uint64_t zkwg_segment_table(const zkwg_circuit_t* c, zkwg_segment* out, uint64_t cap);   /* returns the segment count */
+uint32_t zkwg_inverse_table_half(const zkwg_circuit_t* c);
+
 /* ---- multi-GPU (BASELINE.json configs[3]) -------------------------------------------
  * Emails are independent: the batch is cut into n_dev contiguous shards (zkwg_shard_range), shard i runs on
  * devices[i] through its own handle and host thread, and its witnesses reach `out_wtns` over that GPU's own

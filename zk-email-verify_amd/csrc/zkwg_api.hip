@@ -301,6 +301,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   return ZKWG_RC_OK;
 }
 
+static u64 align256(u64 x) { return (x + 255) & ~255ull; }
 // no C++ exception may cross the C ABI (ctypes / N-API callers would abort)
 static int create_guarded(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
                           const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out,
@@ -339,6 +340,25 @@ int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness) {
     ((Fr*)witness)[Pn.dst[r]] = zk_linear_row(Pn.row_ptr.data(), Pn.src.data(), Pn.coef.data(), Pn.kind.data(), r, (const Fr*)witness);
   return ZKWG_RC_OK;
 }
+int zkwg_image_layout(const zkwg_circuit_t* c, uint64_t n, zkwg_image_layout_t* o) {
+  if (!c || !o) return ZKWG_RC_BAD_ARG;
+  const ZkSched& s = c->s;
+  o->hstate_words = (u64)s.hstates_per_email * 8; o->bits_words = s.img_bits; o->small_words = s.img_small; o->fr_elems = s.img_fr;
+  u64 off = 0;
+  o->off_hstates = off; off += align256(n * (u64)s.hstates_per_email * 32);
+  o->off_bits = off; off += align256(n * (u64)s.img_bits * 8);
+  o->off_small = off; off += align256(n * (u64)s.img_small * 4);
+  o->off_fr = off; off += align256(n * (u64)s.img_fr * 32) + 256;
+  o->total_bytes = off;
+  return ZKWG_RC_OK;
+}
+uint64_t zkwg_segment_table(const zkwg_circuit_t* c, zkwg_segment* out, uint64_t cap) {
+  if (!c) return 0;
+  static_assert(sizeof(zkwg_segment) == sizeof(ZkSeg), "public segment struct must mirror ZkSeg");
+  if (out) memcpy(out, c->segs.data(), std::min<u64>(cap, c->segs.size()) * sizeof(ZkSeg));
+  return c->segs.size();
+}
+uint32_t zkwg_inverse_table_half(const zkwg_circuit_t* c) { return c ? c->s.inv_half : 0; }
 uint64_t zkwg_layout_map(const zkwg_circuit_t* c, uint32_t* out, uint64_t cap) {
   if (!c) return 0;
   if (out) for (u64 i = 0; i < c->kept_dst.size() && i < cap; ++i) out[i] = c->kept_dst[i];
@@ -381,7 +401,6 @@ uint64_t zkwg_input_offset(const zkwg_circuit_t* c, int field) {
   if (field < 0 || field >= ZKWG_IN_NFIELDS) return (uint64_t)-1;
   return c->s.in_off[field];
 }
-static u64 align256(u64 x) { return (x + 255) & ~255ull; }
 uint64_t zkwg_scratch_bytes(const zkwg_circuit_t* c, uint64_t n) {
   const ZkSched& s = c->s;
   return align256(n * (u64)s.hstates_per_email * 32) + align256(n * (u64)s.img_bits * 8) +

@@ -284,6 +284,22 @@ class Circuit:
         _check(self.lib.zkwg_write_wtns(self.h, witness_bytes, out, size))
         return bytes(out)
 
+    def image_layout(self, n):
+        """Scratch layout of a prepared batch of n emails (include/zkwg.h zkwg_image_layout): dict of the
+        per-email sizes and the byte offsets of the hstates / bits / small / fr arrays."""
+        out = (C.c_uint64 * 9)()
+        _check(self.lib.zkwg_image_layout(self.h, n, out))
+        keys = ("hstate_words", "bits_words", "small_words", "fr_elems", "off_hstates", "off_bits", "off_small", "off_fr", "total_bytes")
+        return dict(zip(keys, [int(x) for x in out]))
+
+    def segment_table(self):
+        """[(slot, nslots, type, src, a, b, c, r0)] -- the static table zk_expand evaluates (zkwg_segment_table)."""
+        n = self.lib.zkwg_segment_table(self.h, None, 0)
+        raw = (C.c_uint8 * (40 * n))()
+        self.lib.zkwg_segment_table(self.h, raw, n)
+        import struct
+        return [struct.unpack_from("<QIIIIIIII", raw, 40 * i)[:8] for i in range(n)]
+
     def layout_map(self):
         """`.sym` layouts: list, per slot of the default (kept-v1) layout, of its witness index (None = eliminated)."""
         n = self.lib.zkwg_layout_map(self.h, None, 0)
