@@ -34,6 +34,7 @@ struct zkwg_circuit {
   u64* d_lin_row; u32* d_lin_dst; u32* d_lin_src; Fr* d_lin_coef; u8* d_lin_kind; u64 lin_rows;
   std::vector<u32> kept_dst;   // `.sym` layouts: kept-v1 slot -> witness index (0xffffffff = dropped by the file)
   ZkLinPlan lin_host;   // kept for layout-only handles (tests evaluate it on the host)
+  Fr* d_invtab_m; // fused Montgomery output: inverse table in Montgomery form (built with d_rtab)
   Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
@@ -370,7 +371,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
-    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab);
+    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
     hipFree(c->d_lin_row); hipFree(c->d_lin_dst); hipFree(c->d_lin_src); hipFree(c->d_lin_coef); hipFree(c->d_lin_kind);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); }
@@ -542,6 +543,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.pos_c = c->d_pos;
   B.pos_m = c->d_pos ? c->d_pos + c->pos_dense_off : nullptr;
   B.rtab = c->d_rtab;
+  B.invtab_m = c->d_invtab_m;
   B.pos16 = c->d_pos_rs;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
@@ -673,6 +675,11 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
       for (u32 v = 0; v < 65536; ++v) { tab[v] = acc; acc = fr_add(acc, Rm); }
       if (hipMalloc((void**)&c->d_rtab, tab.size() * sizeof(Fr)) != hipSuccess) return ZKWG_RC_OOM;
       if (hipMemcpy(c->d_rtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+      std::vector<Fr> inv;
+      build_inv_table(s.inv_half, inv);
+      for (Fr& x : inv) x = fr_to_mont(x);
+      if (hipMalloc((void**)&c->d_invtab_m, inv.size() * sizeof(Fr)) != hipSuccess) return ZKWG_RC_OOM;
+      if (hipMemcpy(c->d_invtab_m, inv.data(), inv.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) return ZKWG_RC_HIP_ERROR;
     }
   }
   ZkBufs B;

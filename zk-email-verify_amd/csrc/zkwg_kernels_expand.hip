@@ -23,7 +23,7 @@
 //                    portion (1 KiB per store instruction, back to back), 4 such waves per workgroup.
 #define ZK_FOR_CHUNKS(c) \
   for (u32 c = MONT ? 2u * tid : tid; c < nch; c = MONT ? ((c & 1u) ? c + 2u * ZK_EXPAND_THREADS - 1u : c + 1u) : c + ZK_EXPAND_THREADS)
-#define ZK_STORE(c, v) do { if constexpr (MONT) zk_mont_put(dst, c, v, vkeep, rtab); else dst[c] = (v); } while (0)
+#define ZK_STORE(c, v) do { if constexpr (MONT) zk_mont_put(dst, c, v, vkeep, rtab, pm); else dst[c] = (v); } while (0)
 
 // the rare general case (a genuine field element: inverses, v_ab, carries ...): one Montgomery product;
 // kept out of line so that the 20 store sites of the kernel stay small
@@ -34,10 +34,12 @@ __device__ __noinline__ void zk_mont_general(uint4* __restrict__ dst2, uint4 a, 
   dst2[1] = make_uint4((u32)m.l[2], (u32)(m.l[2] >> 32), (u32)m.l[3], (u32)(m.l[3] >> 32));
 }
 // Montgomery-form output of one slot: `lo` / `hi` are its two standard-form halves
+// (`pm`: both halves already are Montgomery form -- they came from the Montgomery-form inverse table)
 __device__ __forceinline__ void zk_mont_put(uint4* __restrict__ dst, u32 c, const uint4& v, uint4& vkeep,
-                                            const uint4* __restrict__ rtab) {
+                                            const uint4* __restrict__ rtab, bool& pm) {
   if (!(c & 1u)) { vkeep = v; return; }
   const uint4 a = vkeep, b = v;
+  if (pm) { pm = false; dst[c - 1] = a; dst[c] = b; return; }
   uint4 v0, v1;
   if ((b.x | b.y | b.z | b.w | a.y | a.z | a.w) == 0u && a.x < 65536u) {
     if (a.x == 0u) { v0 = zk_zero4(); v1 = zk_zero4(); }
@@ -84,7 +86,10 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
   if (el0 >= el1) return;
   const u64 slot0 = (u64)p * s.portion;
   const u64 slot1 = min(s.W, slot0 + s.portion);
-  const uint4* __restrict__ invtab = (const uint4*)B.invtab;
+  // Montgomery output: inverses of small integers come from a Montgomery-form copy of the table
+  const uint4* __restrict__ invtab = (const uint4*)(MONT ? B.invtab_m : B.invtab);
+  bool pm = false;
+  (void)pm;
   const u32 tid = WAVE_MODE ? (threadIdx.x & 63u) : threadIdx.x;
 
   // Montgomery output: a thread handles the two 16-byte chunks of a slot back to back (ZK_FOR_CHUNKS), keeps the
@@ -177,7 +182,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             if (!(c & 1u)) v.x = (d == 0);
           } else {
             d = max(-half_tab, min(half_tab, d));
-            v = invtab[(u32)(d + half_tab) * 2 + (c & 1u)];
+            pm = MONT; v = invtab[(u32)(d + half_tab) * 2 + (c & 1u)];
           }
           ZK_STORE(c, v);
         }
@@ -201,7 +206,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             } else {
               int d = idx - (int)j;  // isz.in = index - j
               d = max(-half_tab, min(half_tab, d));
-              v = invtab[(u32)(d + half_tab) * 2 + hf];
+              pm = MONT; v = invtab[(u32)(d + half_tab) * 2 + hf];
             }
           }
           ZK_STORE(c, v);
@@ -278,7 +283,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
               if (!hf) v.x = (d == 0);
             } else {
               d = max(-half_tab, min(half_tab, d));
-              v = invtab[(u32)(d + half_tab) * 2 + hf];
+              pm = MONT; v = invtab[(u32)(d + half_tab) * 2 + hf];
             }
           } else if (!hf) {
             long long val = (long long)start + 43 + (1ll << bl) - (long long)i;
@@ -336,7 +341,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
               if (!hf) v.x = (d == 0);
             } else {
               d = max(-half_tab, min(half_tab, d));
-              v = invtab[(u32)(d + half_tab) * 2 + hf];
+              pm = MONT; v = invtab[(u32)(d + half_tab) * 2 + hf];
             }
           }
           ZK_STORE(c, v);
@@ -374,7 +379,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
               int d = (int)pb - (int)(pos[i] & 255u);          // isz.in = in[1] - in[0] = ch - in[i]
               uint4 v = zk_zero4();
               if (!(r & 1u)) { if (!hf) v.x = (d == 0); }
-              else { d = max(-half_tab, min(half_tab, d)); v = invtab[(u32)(d + half_tab) * 2 + hf]; }
+              else { d = max(-half_tab, min(half_tab, d)); pm = MONT; v = invtab[(u32)(d + half_tab) * 2 + hf]; }
               ZK_STORE(c, v);
             }
             break;
@@ -409,7 +414,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
             int d = (int)sg.c - (int)enc[(r >> 1) + sg.b];   // isz.in = in[1] - in[0]
             uint4 v = zk_zero4();
             if (!(r & 1u)) { if (!hf) v.x = (d == 0); }
-            else { d = max(-half_tab, min(half_tab, d)); v = invtab[(u32)(d + half_tab) * 2 + hf]; }
+            else { d = max(-half_tab, min(half_tab, d)); pm = MONT; v = invtab[(u32)(d + half_tab) * 2 + hf]; }
             ZK_STORE(c, v);
           }
         } else {

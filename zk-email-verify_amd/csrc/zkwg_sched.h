@@ -223,6 +223,7 @@ struct ZkBufs {
   const Fr* pos_m;       // Poseidon(9) dense tables for the wave-collective small-batch kernel: C[680], M[100] (Montgomery)
   const Fr* pos16;       // Poseidon(16) sparse-round table (zkwg_poseidon_sparse.h), removeSoftLineBreaks only
   const Fr* pos2;        // Poseidon(2)  sparse-round table
+  const Fr* invtab_m;    // zk_expand_mont: the inverse table in Montgomery form
   const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
   const ZkSeg* segs;     // segment table
   const u32* first_seg;  // first segment overlapping each portion
