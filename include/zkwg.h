@@ -148,6 +148,27 @@ uint64_t zkwg_linear_rows(const zkwg_circuit_t* c);                       /* der
 /* `.sym` layouts: out[s] = witness index of the default (kept-v1) layout's slot s, 0xffffffff if the file
  * eliminated it; returns the number of kept-v1 slots (0 for a handle without a `.sym`). */
 uint64_t zkwg_layout_map(const zkwg_circuit_t* c, uint32_t* out, uint64_t cap);
+/* BodyHashRegex from the template text.  EmailVerifier takes its regex circuit from the generated file
+ * `@zk-email/zk-regex-circom/circuits/common/body_hash_regex.circom` (packages/circuits/email-verifier.circom:5,
+ * 126-127), which is not part of the reference tree.  zkwg_circuit_create builds zkwg's own DFA circuit for that
+ * regex; this entry builds the schedule FROM a supplied template instead: the file (and what it includes --
+ * regex_helpers.circom, circomlib's comparators/gates/bitify; circomlib falls back to the restatement carried by
+ * the library) is parsed and elaborated for msg_bytes = max_header, every hint / quadratic signal becomes a gate
+ * evaluated on the device (kernel zk_net_eval), linear signals are substituted away.  Signal names follow the
+ * compiler's (anonymous components `<T>_<line>_<offset>`), so a `.sym` (and `.r1cs`, see
+ * zkwg_circuit_create_full) of the same circuit can be passed along; both may be NULL for the compact layout.
+ * Supported subset and limits: zk-email-verify_amd/csrc/zkwg_circom.h. */
+typedef struct zkwg_regex_source {
+  const char* circom_path;    /* the generated template file                                              */
+  const char* include_dirs;   /* ':'-separated directories searched for include "..." (may be NULL)       */
+  const char* template_name;  /* NULL: "BodyHashRegex"; instantiated as template_name(max_header)(header) */
+} zkwg_regex_source;
+int zkwg_circuit_create_regex(const zkwg_config* cfg, int device, const zkwg_regex_source* regex,
+                              const char* sym_text, uint64_t sym_len, const char* alias_text, uint64_t alias_len,
+                              const uint8_t* r1cs, uint64_t r1cs_len, zkwg_circuit_t** out);
+/* out[0..8): kept signals, temporaries, gates, assertion gates, chunks, 64-gate steps, LDS words that hold gate
+ * values, gates on the evaluator's 64-bit path (handles created by zkwg_circuit_create_regex) */
+int zkwg_regex_info(const zkwg_circuit_t* c, uint64_t out[8]);
 int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness); /* layout-only handles: host evaluation */
 const char* zkwg_last_error(void);   /* detail of the calling thread's last ZKWG_RC_BAD_CONFIG */
 void zkwg_circuit_destroy(zkwg_circuit_t* c);
@@ -347,7 +368,8 @@ enum zkwg_segment_type {
   ZKWG_SEG_DFA = 16,     /* BodyHashRegex DFA circuit arrays (a = kind, b/c = parameters)              */
   ZKWG_SEG_IN8MASK = 17, /* rec[src + r] * rec[a + r]                                                  */
   ZKWG_SEG_RSLB = 18,    /* RemoveSoftLineBreaks byte-derived arrays over rec[src ..]                  */
-  ZKWG_SEG_HOLE = 19     /* not produced by the schedule (zkwg_circuit_create_full: derived later)     */
+  ZKWG_SEG_HOLE = 19,    /* not produced by the schedule (zkwg_circuit_create_full: derived later)     */
+  ZKWG_SEG_NET = 20      /* loaded regex template: slot r = small[src + r] decoded: 31-bit signed integer, bit 31 = inverse of it */
 };
 typedef struct zkwg_segment {
   uint64_t slot;     /* first witness slot */

@@ -45,6 +45,18 @@ def load():
     lib.ht_poseidon_sparse.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ht_r1cs_first_bad.restype = C.c_longlong
     lib.ht_r1cs_first_bad.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p]
+    lib.ht_net_load.restype = C.c_void_p
+    lib.ht_net_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32]
+    lib.ht_net_destroy.argtypes = [C.c_void_p]
+    lib.ht_net_error.restype = C.c_char_p
+    lib.ht_net_error.argtypes = [C.c_void_p]
+    lib.ht_net_names.restype = C.c_char_p
+    lib.ht_net_names.argtypes = [C.c_void_p]
+    for f in ("ht_net_kept", "ht_net_inv_need"):
+        getattr(lib, f).restype = C.c_uint32
+        getattr(lib, f).argtypes = [C.c_void_p]
+    lib.ht_net_eval.restype = C.c_int
+    lib.ht_net_eval.argtypes = [C.c_void_p] * 5
     lib.ht_regex_scan.restype = C.c_uint32
     lib.ht_regex_scan.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     return lib
@@ -189,3 +201,39 @@ def expand(lib, h, rec, bits, small, frv):
             out[s.slot + rr] = v
     assert all(x is not None for x in out)
     return out
+
+
+class LoadedRegex:
+    """A regex template loaded by the product's front end (zkwg_circom.h) and evaluated on the host with
+    the code zk_net_eval runs on the device (zkwg_net_core.h)."""
+
+    def __init__(self, path, n, include_dirs=(), template="BodyHashRegex"):
+        self.lib = load()
+        self.h = self.lib.ht_net_load(str(path).encode(), ":".join(str(d) for d in include_dirs).encode(), template.encode(), n)
+        err = self.lib.ht_net_error(self.h)
+        if err is not None:
+            raise ValueError(err.decode())
+        self.n = n
+        self.kept = self.lib.ht_net_kept(self.h)
+        self.names = self.lib.ht_net_names(self.h).decode().split("\n")[:-1]
+        assert len(self.names) == self.kept
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ht_net_destroy(self.h)
+            self.h = None
+
+    def evaluate(self, msg):
+        """-> (ok, {name: field element}, match, reveal list)"""
+        msg = bytes(msg) + bytes(self.n - len(msg))
+        words = (C.c_uint32 * self.kept)()
+        match = C.c_uint32(0xffffffff)
+        reveal = (C.c_uint32 * self.n)()
+        ok = self.lib.ht_net_eval(self.h, msg, words, C.byref(match), reveal)
+        vals = {}
+        for nm, w in zip(self.names, words):
+            d = w & 0x7fffffff
+            if d & 0x40000000:
+                d -= 1 << 31
+            vals[nm] = pow(d, -1, P) if (w >> 31) and d else d % P
+        return bool(ok), vals, match.value, list(reveal)

@@ -98,3 +98,41 @@ void ht_fr_inv(const void* a, void* out) { *(Fr*)out = fr_inv_std(*(const Fr*)a)
 }
 #include "zkwg_fr_inv.h"
 extern "C" void ht_fr_inv_by(const void* a, void* out) { *(Fr*)out = fr_inv_by(*(const Fr*)a); }
+// Loaded regex template (zkwg_circom.h) + the gate evaluator shared with zk_net_eval (zkwg_net_core.h)
+#include "zkwg_net_core.h"
+struct HTNet { zkc::Net net; std::string err; std::string names; };
+extern "C" {
+void* ht_net_load(const char* path, const char* include_dirs, const char* tname, uint32_t n) {
+  HTNet* h = new HTNet();
+  if (!zkc::load(path, include_dirs ? include_dirs : "", tname, {(zkc::i64)n}, h->net, h->err)) h->net.n_kept = 0xffffffffu;
+  else for (auto& nm : h->net.names) { h->names += nm; h->names += '\n'; }
+  return h;
+}
+void ht_net_destroy(void* p) { delete (HTNet*)p; }
+const char* ht_net_error(void* p) { return ((HTNet*)p)->net.n_kept == 0xffffffffu ? ((HTNet*)p)->err.c_str() : nullptr; }
+uint32_t ht_net_kept(void* p) { return ((HTNet*)p)->net.n_kept; }
+uint32_t ht_net_inv_need(void* p) { return ((HTNet*)p)->net.inv_need; }
+const char* ht_net_names(void* p) { return ((HTNet*)p)->names.c_str(); }
+// evaluates the gate list exactly as the kernel does (same cache simulation); words[n_kept], reveal[n]
+int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, uint32_t* reveal) {
+  const zkc::Net& N = ((HTNet*)p)->net;
+  std::vector<int> lds(N.lds_words, 0x55555555);
+  for (u32 i = 0; i < N.n_in; ++i) lds[N.n_pins + i] = msg[i];
+  lds[N.n_pins + N.n_in] = 0;
+  std::vector<u32> img(N.n_kept + N.n_temp, 0xdeadbeefu);
+  bool ok = true;
+  size_t g = 0;
+  std::vector<int> snap;
+  for (u32 st = 0; st < N.n_steps; ++st) {
+    snap = lds;   // the lanes of a step read before any of them writes
+    const bool general = N.step_count[st] & 0x8000u, half = N.step_count[st] & 0x4000u;
+    for (u32 lane = 0; lane < (N.step_count[st] & 0x7fu); ++lane, ++g) {
+      if (general) ok &= zk_net_record(&N.records[g * 16], snap.data(), lds.data(), img.data(), match, reveal, (long long)std::max<u32>(N.inv_need + 1, 256));
+      else if (half) zk_net_record32<true>(&N.records[g * 16], snap.data(), lds.data(), img.data());
+      else zk_net_record32<false>(&N.records[g * 16], snap.data(), lds.data(), img.data());
+    }
+  }
+  memcpy(words, img.data(), (size_t)N.n_kept * 4);
+  return ok ? 1 : 0;
+}
+}

@@ -1,0 +1,230 @@
+"""BodyHashRegex compiled from a circom template by the product (zkwg_circuit_create_regex).
+
+The reference takes its regex circuit from a generated file of the zk-regex package
+(packages/circuits/email-verifier.circom:5,126-127) that is not in the reference tree.  The product can
+build the schedule from such a file (zk-email-verify_amd/csrc/zkwg_circom.h: parser, elaboration into a
+gate list; zkwg_net_core.h / zk_net_eval: evaluation).  Checked here against the circom interpreter of
+oracle/circom, which executes the very same files:
+
+* the stand-in template of oracle/circom/lib (same circuit as the built-in one): same signal set and
+  names as the built-in schedule, every kept value equal to the interpreter's;
+* tests/golden/regex_style/simple_regex.circom, written in the style of zk-regex's generated code
+  (anonymous components with array literals, quadratic component inputs, late declarations): names incl.
+  the compiler's `<T>_<line>_<offset>[k]`, values, and the kept set (hints + quadratic definitions, from the
+  symbolic interpreter) agree;
+* GPU: EmailVerifier(576,192) with the loaded template equals the built-in circuit slot by slot and the
+  interpreter fixture byte for byte; the style template's region equals the interpreter on the device.
+"""
+import json
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import hosttest
+from conftest import ROOT
+
+P = hosttest.P
+STAND_IN = os.path.join(ROOT, "oracle", "circom", "lib", "@zk-email", "zk-regex-circom", "circuits", "common",
+                        "body_hash_regex.circom")
+STYLE = os.path.join(ROOT, "tests", "golden", "regex_style", "simple_regex.circom")
+FX = os.path.join(ROOT, "tests", "golden", "circom_ev_576_192.npz")
+HDR = b"from:a@b.c\r\ndkim-signature:v=1; a=rsa-sha256; bh=AbCd+/09=; b=xyz\r\nto:x"
+
+
+def _flat_name(name, s, j):
+    base = name[:name.rindex("." + s.name)] + "." + s.name
+    return base + (f"[{j}]" if s.dims else "")
+
+
+def _interpret(path, template, n, msg, symbolic=False):
+    """-> ({flattened name: value}, {flattened names of hint / quadratically defined signals} or None, root)"""
+    from oracle.circom import ev
+    from oracle.circom.runtime import Program, iter_signals
+    kept = None
+    if symbolic:
+        from oracle.circom.symbolic import SymProgram, Q
+
+        class Rec(SymProgram):
+            def __init__(self, *a, **kw):
+                super().__init__(*a, **kw)
+                self.quad = set()
+
+            def _store(self, inst, s, idx, v, how):
+                super()._store(inst, s, idx, v, how)
+                flat = sum(int(getattr(i, "v", i)) * st for i, st in zip(idx, s.strides))
+                items = v if isinstance(v, (list, tuple)) else [v]
+                from oracle.circom.runtime import _flatten
+                for j, x in enumerate(_flatten(list(items), [])):
+                    if how == "<--" or ((how == "<==" or how == "in<==") and type(x) is Q):
+                        self.quad.add((id(s), flat + j))
+        p = Rec(None, ev.include_paths())
+    else:
+        p = Program(None, ev.include_paths())
+    p.load(path)
+    root = p.run({"msg": list(msg) + [0] * (n - len(msg))}, main=(template, [n]))
+    vals = {}
+    if symbolic:
+        kept = set()
+    for name, v, s, j in iter_signals(root):
+        fn = _flat_name(name, s, j)
+        vals[fn] = v
+        if symbolic and (id(s), j) in p.quad:
+            kept.add(fn)
+    return vals, kept, root
+
+
+def test_stand_in_template_through_the_product_loader_equals_the_interpreter():
+    n = 192
+    R = hosttest.LoadedRegex(STAND_IN, n)
+    ref, kept, root = _interpret(STAND_IN, "BodyHashRegex", n, HDR, symbolic=True)
+    ok, vals, match, rev = R.evaluate(HDR)
+    assert ok and match == 1 == root.sigs["out"].vals[0]
+    assert rev == root.sigs["reveal0"].vals and bytes(x for x in rev if x) == b"AbCd+/09="
+    assert {"main" + k for k in vals} == kept            # hints + quadratic definitions, nothing else
+    assert all(ref["main" + k] == v for k, v in vals.items())
+    # a header without a body hash: the circuit itself holds, the match output is 0
+    bad = b"from:a@b.c\r\ndkim-signature:v=1; a=rsa-sha256; b=xyz\r\n"
+    ref2, _, root2 = _interpret(STAND_IN, "BodyHashRegex", n, bad)
+    ok, vals, match, rev = R.evaluate(bad)
+    assert ok and match == 0 and not any(rev)
+    assert all(ref2["main" + k] == v for k, v in vals.items())
+
+
+def test_loaded_stand_in_names_equal_the_built_in_schedule():
+    import zkwg
+    c0 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=-1)
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=-1, regex=STAND_IN)
+    assert c.W == c0.W
+    a = [n for _, n in c0.symbols()]
+    b = [n for _, n in c.symbols()]
+    assert sorted(a) == sorted(b)
+    # the template's region is laid out in the compiler's order (creation order), not kind-major
+    assert a != b
+    info = c.regex_info()
+    assert info["kept"] == sum(1 for n in a if ".anon_BodyHashRegex." in n)
+    assert info["gates_64bit"] <= 576 + 2 and info["lds_value_words"] < 8192   # only the outputs and one assertion need 64 bits
+    # the fixture's `.sym` (interpreter order) is a valid layout for the loaded circuit too
+    fx = np.load(FX)
+    o0 = fx["o0_index"]
+    order = np.argsort(o0, kind="stable")
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    text = "".join(f"{int(o0[s])},{int(rank[s])},0,{name}\n" for s, name in c0.symbols()[1:])
+    cs = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=-1, regex=STAND_IN, sym=text)
+    assert cs.W == c0.W
+
+
+def test_zk_regex_style_template_names_values_and_kept_set():
+    n = 64
+    R = hosttest.LoadedRegex(STYLE, n, template="SimpleRegex")
+    rng = random.Random(5)
+    msgs = [b"xxabcde abbe ae abcdbcde!", b"", b"abe", b"a" * 64, bytes(rng.choice(b"abcdeab ") for _ in range(64)),
+            bytes(rng.randrange(256) for _ in range(64))]
+    for k, msg in enumerate(msgs):
+        ref, kept, root = _interpret(STYLE, "SimpleRegex", n, msg, symbolic=(k == 0))
+        ok, vals, match, rev = R.evaluate(msg)
+        assert ok
+        assert match == root.sigs["out"].vals[0]
+        assert rev == root.sigs["reveal0"].vals
+        if kept is not None:
+            assert {"main" + q for q in vals} == kept
+            assert any("MultiOR_" in q and "[" in q.split("MultiOR_")[1] for q in vals)   # compiler-style anonymous names
+            assert bytes(x if x else 46 for x in rev[:len(msg)]) == b"...bcd...bb......bcdbcd.."
+        bad = [q for q, v in vals.items() if ref["main" + q] != v]
+        assert not bad, (k, bad[:5])
+
+
+def test_loader_errors_name_the_place(tmp_path):
+    def load(text, template="T"):
+        f = tmp_path / "t.circom"
+        f.write_text(text)
+        return hosttest.LoadedRegex(str(f), 8, template=template)
+    head = "pragma circom 2.1.5;\ninclude \"circomlib/circuits/comparators.circom\";\n"
+    with pytest.raises(ValueError, match=r"t\.circom:5: unsupported hint"):
+        load(head + "template T(n) { signal input msg[n]; signal output out; signal output reveal0[n];\n"
+             "signal x;\nx <-- msg[0] * msg[1];\nout <== x; for (var i = 0; i < n; i++) { reveal0[i] <== msg[i]; } }\n")
+    with pytest.raises(ValueError, match="degree 3"):
+        load(head + "template T(n) { signal input msg[n]; signal output out; signal output reveal0[n];\n"
+             "out <== msg[0] * msg[1] * msg[2]; for (var i = 0; i < n; i++) { reveal0[i] <== msg[i]; } }\n")
+    with pytest.raises(ValueError, match="not found"):
+        load("include \"nowhere/else.circom\";\ntemplate T(n) { signal input msg[n]; }\n")
+    with pytest.raises(ValueError, match="no template named"):
+        load(head + "template U(n) { signal input msg[n]; }\n")
+    with pytest.raises(ValueError, match="never received all its inputs"):
+        load(head + "template T(n) { signal input msg[n]; signal output out; signal output reveal0[n];\n"
+             "component z = IsZero(); out <== msg[0]; for (var i = 0; i < n; i++) { reveal0[i] <== msg[i]; } }\n")
+    # a template that is fine: linear outputs only, nothing kept
+    R = load(head + "template T(n) { signal input msg[n]; signal output out; signal output reveal0[n];\n"
+             "out <== msg[0] + 1; for (var i = 0; i < n; i++) { reveal0[i] <== 2 * msg[i]; } }\n")
+    ok, vals, match, rev = R.evaluate(bytes(range(8)))
+    assert ok and not vals and match == 1 and rev == [2 * i for i in range(8)]
+    # the C ABI refuses a template that does not fit the configuration
+    import zkwg
+    with pytest.raises(zkwg.ZkwgError, match="regex template"):
+        zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=-1, regex=str(tmp_path / "missing.circom"))
+
+
+def _by_name(c, wit):
+    return {name: wit[32 * i:32 * i + 32] for i, name in c.symbols()}
+
+
+@pytest.mark.gpu
+def test_gpu_loaded_template_equals_built_in_circuit_and_interpreter_fixture():
+    import zkwg
+    fx = np.load(FX)
+    inp = json.loads(bytes(fx["inputs"]).decode())
+    c0 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0)
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0, regex=STAND_IN)
+    # the valid email, the same email with a header byte changed (regex still matches, signature does not)
+    # and one whose bh= tag is broken (no match)
+    t1 = dict(inp); t1["emailHeader"] = list(inp["emailHeader"]); t1["emailHeader"][5] = str(int(t1["emailHeader"][5]) ^ 1)
+    hdr = bytes(int(x) for x in inp["emailHeader"])
+    k = hdr.index(b"bh=")
+    t2 = dict(inp); t2["emailHeader"] = list(inp["emailHeader"]); t2["emailHeader"][k] = str(ord("x"))
+    recs = b"".join(c.pack(x) for x in (inp, t1, t2))
+    w0, s0 = c0.calculate_batch_host(recs)
+    w1, s1 = c.calculate_batch_host(recs)
+    assert s0 == s1 == [0, 4, 4]
+    for e in range(3):
+        a = _by_name(c0, w0[e * c0.witness_bytes:(e + 1) * c0.witness_bytes])
+        b = _by_name(c, w1[e * c.witness_bytes:(e + 1) * c.witness_bytes])
+        bad = [n for n in a if a[n] != b[n]]
+        assert not bad, (e, len(bad), bad[:5])
+    # interpreter order, byte for byte
+    o0 = fx["o0_index"]
+    order = np.argsort(o0, kind="stable")
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    text = "".join(f"{int(o0[s])},{int(rank[s])},0,{name}\n" for s, name in c0.symbols()[1:])
+    cs = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0, regex=STAND_IN, sym=text)
+    wit, status = cs.calculate_batch_host(cs.pack(inp))
+    assert status == [0]
+    assert wit == zlib.decompress(bytes(fx["witness"]))
+
+
+@pytest.mark.gpu
+def test_gpu_zk_regex_style_template_region_equals_the_interpreter():
+    import zkwg
+    fx = np.load(FX)
+    inp = json.loads(bytes(fx["inputs"]).decode())
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0, regex=STYLE,
+                     regex_template="SimpleRegex")
+    rng = random.Random(11)
+    msgs = [bytes(rng.choice(b"abcdeab e") for _ in range(576)), b"xxabcde abbe ae abcdbcde!" + bytes(551)]
+    recs = b""
+    for m in msgs:
+        x = dict(inp)
+        x["emailHeader"] = [str(b) for b in m]
+        recs += c.pack(x)
+    wit, status = c.calculate_batch_host(recs)
+    assert status == [4, 4]          # the rest of EmailVerifier rejects these headers; the region is still complete
+    for e, m in enumerate(msgs):
+        ref, _, _ = _interpret(STYLE, "SimpleRegex", 576, m)
+        got = _by_name(c, wit[e * c.witness_bytes:(e + 1) * c.witness_bytes])
+        region = {n: v for n, v in got.items() if n.startswith("main.anon_BodyHashRegex.")}
+        assert len(region) == c.regex_info()["kept"]
+        bad = [n for n, v in region.items() if int.from_bytes(v, "little") != ref["main" + n[len("main.anon_BodyHashRegex"):]]]
+        assert not bad, (e, len(bad), bad[:5])

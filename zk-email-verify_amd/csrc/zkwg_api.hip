@@ -18,7 +18,7 @@
 #include "zkwg_poseidon_sparse.h"
 #include "zkwg_full.h"
 
-#define ZK_MAX_KERNELS 8
+#define ZK_MAX_KERNELS 9
 #define ZK_RS_SLOTS 16
 #define ZK_POS_STREAMS 4
 #define ZK_POS_RING 64
@@ -35,6 +35,10 @@ struct zkwg_circuit {
   std::vector<u32> kept_dst;   // `.sym` layouts: kept-v1 slot -> witness index (0xffffffff = dropped by the file)
   ZkLinPlan lin_host;   // kept for layout-only handles (tests evaluate it on the host)
   Fr* d_invtab_m; // fused Montgomery output: inverse table in Montgomery form (built with d_rtab)
+  // BodyHashRegex loaded from a circom template (zkwg_circuit_create_regex): gate list on the device
+  zkc::Net net;
+  bool has_net;
+  u32* d_net_records; unsigned short* d_net_counts;
   Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
@@ -148,7 +152,7 @@ const char* zkwg_last_error(void) { return g_last_error.c_str(); }
 
 static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_text, uint64_t sym_len,
                        const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out,
-                       const uint8_t* r1cs = nullptr, uint64_t r1cs_len = 0) {
+                       const uint8_t* r1cs = nullptr, uint64_t r1cs_len = 0, const zkwg_regex_source* regex = nullptr) {
   if (!cfg_in || !out) return ZKWG_RC_BAD_ARG;
   zkwg_config cfg_copy = *cfg_in;
   cfg_copy.layout = ZKWG_LAYOUT_KEPT_V1;
@@ -167,12 +171,30 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   if (const char* v = getenv("ZKWG_RSA_WGS_PER_CU")) c->rsa_wgs_per_cu = atoi(v);
   if (const char* v = getenv("ZKWG_EMAILS_PER_WG")) c->emails_per_wg = std::max(1, atoi(v));
   if (portion < 64 || portion > (1u << 20)) portion = ZK_PORTION_DEFAULT;
-  if (!build_sched(*cfg, c->s, c->segs, c->first_seg, portion)) { g_last_error = "unsupported circuit configuration"; delete c; return ZKWG_RC_BAD_CONFIG; }
+  c->has_net = false;
+  if (regex) {
+    // the regex circuit is compiled from the supplied template text (zkwg_circom.h)
+    if (!regex->circom_path || cfg->main_kind != ZKWG_MAIN_EMAIL_VERIFIER || cfg->ignore_body_hash_check) {
+      g_last_error = "a regex template needs an EmailVerifier configuration with the body-hash check";
+      delete c;
+      return ZKWG_RC_BAD_CONFIG;
+    }
+    std::string err;
+    if (!zkc::load(regex->circom_path, regex->include_dirs ? regex->include_dirs : "",
+                   regex->template_name ? regex->template_name : "BodyHashRegex", {(zkc::i64)cfg->max_header}, c->net, err)) {
+      g_last_error = "regex template: " + err;
+      delete c;
+      return ZKWG_RC_BAD_CONFIG;
+    }
+    c->has_net = true;
+  }
+  const zkc::Net* net = c->has_net ? &c->net : nullptr;
+  if (!build_sched(*cfg, c->s, c->segs, c->first_seg, portion, net)) { g_last_error = "unsupported circuit configuration"; delete c; return ZKWG_RC_BAD_CONFIG; }
   if (getenv("ZKWG_DEBUG_SKIP_INV") && atoi(getenv("ZKWG_DEBUG_SKIP_INV")) && c->s.rsa.present) c->s.rsa.present = 2;  // profiling only
   if (sym_text) {
     ZkSymLayout L;
     L.allow_holes = r1cs != nullptr;
-    if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L) || !zk_remap_segments(c->s, c->segs, c->first_seg, L)) {
+    if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net) || !zk_remap_segments(c->s, c->segs, c->first_seg, L)) {
       g_last_error = L.err.empty() ? std::string(".sym layout does not tile the witness") : L.err;
       delete c;
       return ZKWG_RC_BAD_CONFIG;
@@ -193,16 +215,17 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     c->cfg.layout = ZKWG_LAYOUT_SYM;
   }
   // kernel table (launch order)
-  c->n_kernels = 6;
-  c->kname[0] = "zk_sha_chain"; c->kslots[0] = 0;
-  c->kname[1] = "zk_sha_trace"; c->kslots[1] = 0;
-  c->kname[2] = "zk_misc_ev"; c->kslots[2] = 0;
-  c->kname[3] = "zk_rsa"; c->kslots[3] = 0;
-  c->kname[4] = "zk_poseidon9"; c->kslots[4] = 0;
-  if (c->s.rslb) {
-    c->n_kernels = 8;
-    c->kname[5] = "zk_rslb_chunks"; c->kslots[5] = 0;
-    c->kname[6] = "zk_rslb_chain"; c->kslots[6] = 0;
+  {
+    int k = 0;
+    c->kname[k++] = "zk_sha_chain";
+    c->kname[k++] = "zk_sha_trace";
+    if (c->s.net_mode) c->kname[k++] = "zk_net_eval";
+    c->kname[k++] = "zk_misc_ev";
+    c->kname[k++] = "zk_rsa";
+    c->kname[k++] = "zk_poseidon9";
+    if (c->s.rslb) { c->kname[k++] = "zk_rslb_chunks"; c->kname[k++] = "zk_rslb_chain"; }
+    c->n_kernels = k + 1;
+    for (int i = 0; i < k; ++i) c->kslots[i] = 0;
   }
   c->kname[c->n_kernels - 1] = "zk_expand"; c->kslots[c->n_kernels - 1] = c->s.W;
   if (device >= 0) {
@@ -219,6 +242,13 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     ok = ok && hipMemcpy(c->d_invtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(ZkSeg), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(c->d_first_seg, c->first_seg.data(), c->first_seg.size() * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && c->has_net) {
+      ok = hipMalloc((void**)&c->d_net_records, c->net.records.size() * 4) == hipSuccess &&
+           hipMemcpy(c->d_net_records, c->net.records.data(), c->net.records.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+           hipMalloc((void**)&c->d_net_counts, c->net.step_count.size() * 2 + 64) == hipSuccess &&
+           hipMemcpy(c->d_net_counts, c->net.step_count.data(), c->net.step_count.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+      if (ok) std::vector<u32>().swap(c->net.records);
+    }
     if (ok && c->lin_host.n_rows()) {
       const ZkLinPlan& Pn = c->lin_host;
       const size_t nt = std::max<size_t>(Pn.src.size(), 1);
@@ -306,9 +336,9 @@ static u64 align256(u64 x) { return (x + 255) & ~255ull; }
 // no C++ exception may cross the C ABI (ctypes / N-API callers would abort)
 static int create_guarded(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
                           const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out,
-                          const uint8_t* r1cs = nullptr, uint64_t r1cs_len = 0) {
+                          const uint8_t* r1cs = nullptr, uint64_t r1cs_len = 0, const zkwg_regex_source* regex = nullptr) {
   try {
-    return create_impl(cfg, device, sym_text, sym_len, alias_text, alias_len, out, r1cs, r1cs_len);
+    return create_impl(cfg, device, sym_text, sym_len, alias_text, alias_len, out, r1cs, r1cs_len, regex);
   } catch (const std::bad_alloc&) {
     g_last_error = "out of host memory while building the circuit";
     return ZKWG_RC_OOM;
@@ -332,6 +362,21 @@ int zkwg_circuit_create_full(const zkwg_config* cfg, int device, const char* sym
                              zkwg_circuit_t** out) {
   if (!sym_text || !r1cs) return ZKWG_RC_BAD_ARG;
   return create_guarded(cfg, device, sym_text, sym_len, alias_text, alias_len, out, r1cs, r1cs_len);
+}
+int zkwg_circuit_create_regex(const zkwg_config* cfg, int device, const zkwg_regex_source* regex,
+                              const char* sym_text, uint64_t sym_len, const char* alias_text, uint64_t alias_len,
+                              const uint8_t* r1cs, uint64_t r1cs_len, zkwg_circuit_t** out) {
+  if (!regex || !regex->circom_path) return ZKWG_RC_BAD_ARG;
+  if (r1cs && !sym_text) return ZKWG_RC_BAD_ARG;
+  return create_guarded(cfg, device, sym_text, sym_len, alias_text, alias_len, out, r1cs, r1cs_len, regex);
+}
+int zkwg_regex_info(const zkwg_circuit_t* c, uint64_t out[8]) {
+  if (!c || !out) return ZKWG_RC_BAD_ARG;
+  if (!c->has_net) return ZKWG_RC_BAD_CONFIG;
+  const zkc::Net& n = c->net;
+  out[0] = n.n_kept; out[1] = n.n_temp; out[2] = n.n_gates; out[3] = n.n_asserts;
+  out[4] = n.n_chunks; out[5] = n.n_steps; out[6] = n.n_pins; out[7] = n.n_general;
+  return ZKWG_RC_OK;
 }
 // layout-only handles (device < 0): evaluate the linear completion of one host witness in place (tests)
 int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness) {
@@ -373,6 +418,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     hipSetDevice(c->device);
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
     hipFree(c->d_lin_row); hipFree(c->d_lin_dst); hipFree(c->d_lin_src); hipFree(c->d_lin_coef); hipFree(c->d_lin_kind);
+    hipFree(c->d_net_records); hipFree(c->d_net_counts);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); }
     hipStreamDestroy(c->copy_stream);
@@ -544,6 +590,8 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.pos_m = c->d_pos ? c->d_pos + c->pos_dense_off : nullptr;
   B.rtab = c->d_rtab;
   B.invtab_m = c->d_invtab_m;
+  B.net_records = c->d_net_records;
+  B.net_counts = c->d_net_counts;
   B.pos16 = c->d_pos_rs;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
@@ -604,6 +652,11 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     hipLaunchKernelGGL(zk_sha_trace, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
   }
   if (tm) hipEventRecord(evs[++ki], st);
+  if (s.net_mode) {
+    // the regex circuit of a loaded template: gate list, one wavefront per email (LDS: value cache + message bytes)
+    hipLaunchKernelGGL(zk_net_eval, dim3(ne), dim3(64), 4u * s.net_lds_words + 16, st, s, B);
+    if (tm) hipEventRecord(evs[++ki], st);
+  }
   if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 7 * s.fr[0].max_bytes + 64 + ZK_DFA_STATES * 256 + 16, st, s, B);
   if (tm) hipEventRecord(evs[++ki], st);
   if (s.rsa.present) {
@@ -854,6 +907,7 @@ int zkwg_write_wtns(const zkwg_circuit_t* c, const uint8_t* witness, uint8_t* ou
 uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap) {
   ZkSched tmp = c->s;
   ZkWalker w;
+  w.net = c->has_net ? &c->net : nullptr;
   w.names = true;
   u64 pos = 0;
   auto put = [&](u64 slot, const std::string& name) {

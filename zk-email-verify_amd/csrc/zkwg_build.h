@@ -10,7 +10,7 @@
 #include "zkwg_layout.h"
 
 static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& segs,
-                        std::vector<u32>& first_seg, u32 portion = ZK_PORTION_DEFAULT) {
+                        std::vector<u32>& first_seg, u32 portion = ZK_PORTION_DEFAULT, const zkc::Net* net = nullptr) {
   memset(&s, 0, sizeof(s));
   if (cfg.layout != ZKWG_LAYOUT_KEPT_V1) return false;
   if (cfg.remove_soft_line_breaks && (cfg.main_kind != ZKWG_MAIN_EMAIL_VERIFIER || cfg.ignore_body_hash_check)) return false;
@@ -57,7 +57,10 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
   };
 
   ZkWalker w;
+  w.net = net;
+  if (net && (cfg.main_kind != ZKWG_MAIN_EMAIL_VERIFIER || cfg.ignore_body_hash_check || net->n_in != cfg.max_header)) return false;
   u64 max_small = 256;  // largest |d| whose inverse zk_expand looks up
+  if (net) max_small = std::max<u64>(max_small, (u64)net->inv_need + 1);
   switch (cfg.main_kind) {
     case ZKWG_MAIN_SHA256_BYTES:
       if (cfg.max_header == 0) return false;
@@ -155,8 +158,9 @@ struct ZkSymDims {
     return true;
   }
 };
-static inline void zk_collect_names(ZkSched tmp, std::vector<std::string>& names) {
+static inline void zk_collect_names(ZkSched tmp, std::vector<std::string>& names, const zkc::Net* net = nullptr) {
   ZkWalker w;
+  w.net = net;
   w.names = true;
   names.assign(tmp.W, std::string());
   w.sink = [&](u64 slot, const std::string& name) { if (slot < names.size()) names[slot] = name; };
@@ -166,9 +170,10 @@ static inline void zk_collect_names(ZkSched tmp, std::vector<std::string>& names
     default: zk_walk_main_ev(w, tmp); break;
   }
 }
-static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const char* alias, u64 alias_len, ZkSymLayout& L) {
+static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const char* alias, u64 alias_len, ZkSymLayout& L,
+                          const zkc::Net* net = nullptr) {
   std::vector<std::string> ours;
-  zk_collect_names(s, ours);
+  zk_collect_names(s, ours, net);
   // rename rules
   std::vector<std::pair<std::string, std::string>> rules;
   for (u64 i = 0; alias && i < alias_len;) {

@@ -1,0 +1,1633 @@
+// Regex-circuit loader: a circom-2 front end for templates of the kind zk-regex generates.
+//
+// EmailVerifier instantiates `BodyHashRegex(maxHeadersLength)` from the npm package
+// @zk-email/zk-regex-circom (packages/circuits/email-verifier.circom:5,126-127); that generated file is not
+// part of the reference tree.  Instead of hard-wiring one circuit, the schedule can be built FROM the
+// template text: this header parses the supplied `.circom` file (and what it includes), elaborates the
+// template for the concrete `msg_bytes`, and lowers every signal that carries information -- hints (`<--`)
+// and signals assigned a quadratic expression, the kept-v1 rule of zkwg_layout.h -- into a gate list over
+// small integers.  zk_net_eval (zkwg_kernels_net.hip) evaluates that list per email, zk_expand's ZSEG_NET
+// streams the values out.  Linear signals are substituted away (they are what `--O1/--O2` removes; an O0 build
+// gets them back from the `.r1cs`, zkwg_full.h).
+//
+// Language subset: templates with integer parameters, `signal` / `component` / `var` declarations (arrays,
+// initialisers), `for` / `while` / `if`, `<==` `==>` `<--` `===`, component arrays, anonymous components
+// `T(p)(in...)` named `<T>_<line>_<offset>` like the compiler's syntax-sugar remover, array literals, integer
+// `var` arithmetic.  Hints must have one of circomlib's two shapes: `(x >> k) & 1` (Num2Bits) and
+// `x != 0 ? 1/x : 0` (IsZero).  Values are small signed integers (|v| < 2^30, checked by interval analysis at
+// load time) or the inverse of one; anything else is refused with file:line.
+// circomlib's comparators / gates / bitify are read from the include path when present and otherwise
+// taken from the restatement at the end of this file ([EXT] circomlib 2.0.5).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace zkc {
+
+typedef long long i64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+struct Error { std::string msg; };
+[[noreturn]] static inline void fail(const std::string& m) { throw Error{m}; }
+
+// ------------------------------------------------------------------------------------------------ lexer
+enum { T_ID, T_NUM, T_STR, T_OP, T_EOF };
+struct Tok { int kind; std::string s; int line; int pos; };
+
+static inline void lex(const std::string& text, const std::string& fname, std::vector<Tok>& out) {
+  static const char* ops3[] = {"<==", "==>", "<--", "-->", "===", "**=", "<<=", ">>="};
+  static const char* ops2[] = {"++", "--", "+=", "-=", "*=", "/=", "\\=", "%=", "&=", "|=", "^=", "==", "!=",
+                               "<=", ">=", "&&", "||", "<<", ">>", "**"};
+  size_t i = 0, n = text.size();
+  int line = 1;
+  while (i < n) {
+    char c = text[i];
+    if (c == '\n') { ++line; ++i; continue; }
+    if (c == ' ' || c == '\t' || c == '\r') { ++i; continue; }
+    if (c == '/' && i + 1 < n && text[i + 1] == '/') { while (i < n && text[i] != '\n') ++i; continue; }
+    if (c == '/' && i + 1 < n && text[i + 1] == '*') {
+      i += 2;
+      while (i + 1 < n && !(text[i] == '*' && text[i + 1] == '/')) { if (text[i] == '\n') ++line; ++i; }
+      i += 2;
+      continue;
+    }
+    if (isalpha((unsigned char)c) || c == '_' || c == '$') {
+      size_t j = i;
+      while (j < n && (isalnum((unsigned char)text[j]) || text[j] == '_' || text[j] == '$')) ++j;
+      out.push_back(Tok{T_ID, text.substr(i, j - i), line, (int)i});
+      i = j;
+      continue;
+    }
+    if (isdigit((unsigned char)c)) {
+      size_t j = i;
+      if (c == '0' && j + 1 < n && (text[j + 1] == 'x' || text[j + 1] == 'X')) { j += 2; while (j < n && isxdigit((unsigned char)text[j])) ++j; }
+      else while (j < n && isdigit((unsigned char)text[j])) ++j;
+      out.push_back(Tok{T_NUM, text.substr(i, j - i), line, (int)i});
+      i = j;
+      continue;
+    }
+    if (c == '"') {
+      size_t j = i + 1;
+      while (j < n && text[j] != '"') ++j;
+      out.push_back(Tok{T_STR, text.substr(i + 1, j - i - 1), line, (int)i});
+      i = j + 1;
+      continue;
+    }
+    bool done = false;
+    for (const char* o : ops3) if (text.compare(i, 3, o) == 0) { out.push_back(Tok{T_OP, o, line, (int)i}); i += 3; done = true; break; }
+    if (done) continue;
+    for (const char* o : ops2) if (text.compare(i, 2, o) == 0) { out.push_back(Tok{T_OP, o, line, (int)i}); i += 2; done = true; break; }
+    if (done) continue;
+    if (strchr("+-*/\\%&|^~!<>=?:;,.()[]{}", c)) { out.push_back(Tok{T_OP, std::string(1, c), line, (int)i}); ++i; continue; }
+    fail(fname + ":" + std::to_string(line) + ": unexpected character '" + std::string(1, c) + "'");
+  }
+  out.push_back(Tok{T_EOF, "", line, (int)n});
+}
+
+// ------------------------------------------------------------------------------------------------ AST
+enum NodeKind {
+  N_NUM, N_ID, N_INDEX, N_MEMBER, N_CALL, N_ANON, N_ARR, N_BIN, N_UN, N_TERN,
+  S_BLOCK, S_SIGNAL, S_COMP, S_VAR, S_FOR, S_WHILE, S_IF, S_RET, S_ASSERT, S_LOG, S_ASSIGN, S_CONSTR, S_NOP,
+  N_DECL, N_LIST
+};
+struct Node {
+  int k = S_NOP;
+  std::string s;          // identifier / operator / signal kind
+  i64 n = 0;              // N_NUM value
+  bool big = false;       // N_NUM does not fit 62 bits (only legal where it is never evaluated)
+  std::vector<Node*> c;   // children
+  int line = 0, pos = 0;
+  const std::string* file = nullptr;
+};
+
+struct Template { std::string name; std::vector<std::string> params; Node* body = nullptr; const std::string* file = nullptr; };
+
+struct Parser {
+  std::vector<Tok> t;
+  size_t i = 0;
+  const std::string* file;
+  std::deque<Node>& pool;
+  Parser(std::deque<Node>& p, const std::string* f) : file(f), pool(p) {}
+
+  Node* mk(int k, const Tok& at) { pool.emplace_back(); Node* n = &pool.back(); n->k = k; n->line = at.line; n->pos = at.pos; n->file = file; return n; }
+  const Tok& cur() const { return t[i]; }
+  bool at(const char* s) const { return (t[i].kind == T_OP || t[i].kind == T_ID) && t[i].s == s; }
+  bool accept(const char* s) { if (at(s)) { ++i; return true; } return false; }
+  [[noreturn]] void err(const std::string& m) const { fail(*file + ":" + std::to_string(t[i].line) + ": " + m + " (at '" + t[i].s + "')"); }
+  void expect(const char* s) { if (!accept(s)) err(std::string("expected '") + s + "'"); }
+  std::string ident() { if (t[i].kind != T_ID) err("expected an identifier"); return t[i++].s; }
+
+  // ---- expressions (precedence climbing)
+  Node* expression() { return ternary(); }
+  Node* ternary() {
+    Node* c = binary(0);
+    if (at("?")) {
+      Node* n = mk(N_TERN, cur());
+      ++i;
+      Node* a = ternary();
+      expect(":");
+      Node* b = ternary();
+      n->c = {c, a, b};
+      return n;
+    }
+    return c;
+  }
+  static int level_of(const std::string& op) {
+    static const std::vector<std::vector<const char*>> L = {
+        {"||"}, {"&&"}, {"==", "!=", "<", ">", "<=", ">="}, {"|"}, {"^"}, {"&"}, {"<<", ">>"}, {"+", "-"}, {"*", "/", "\\", "%"}, {"**"}};
+    for (size_t l = 0; l < L.size(); ++l) for (const char* o : L[l]) if (op == o) return (int)l;
+    return -1;
+  }
+  Node* binary(int lvl) {
+    if (lvl > 9) return unary();
+    Node* l = binary(lvl + 1);
+    while (t[i].kind == T_OP && level_of(t[i].s) == lvl) {
+      Node* n = mk(N_BIN, cur());
+      n->s = t[i++].s;
+      Node* r = binary(lvl + 1);
+      n->c = {l, r};
+      l = n;
+    }
+    return l;
+  }
+  Node* unary() {
+    if (t[i].kind == T_OP && (t[i].s == "-" || t[i].s == "!" || t[i].s == "~")) {
+      Node* n = mk(N_UN, cur());
+      n->s = t[i++].s;
+      n->c = {unary()};
+      return n;
+    }
+    return postfix();
+  }
+  Node* list_until(const char* close) {
+    Node* l = mk(N_LIST, cur());
+    while (!at(close)) {
+      l->c.push_back(expression());
+      if (!accept(",")) break;
+    }
+    expect(close);
+    return l;
+  }
+  Node* postfix() {
+    Node* b = nullptr;
+    if (t[i].kind == T_NUM) {
+      b = mk(N_NUM, cur());
+      const std::string& s = t[i].s;
+      unsigned long long v = 0;
+      bool big = false;
+      if (s.size() > 2 && (s[1] == 'x' || s[1] == 'X')) { if (s.size() > 17) big = true; else v = strtoull(s.c_str() + 2, nullptr, 16); }
+      else { if (s.size() > 18) big = true; else v = strtoull(s.c_str(), nullptr, 10); }
+      if (v >> 62) big = true;
+      b->n = (i64)v; b->big = big; b->s = s;
+      ++i;
+    } else if (at("(")) {
+      ++i;
+      b = expression();
+      expect(")");
+    } else if (at("[")) {
+      Node* n = mk(N_ARR, cur());
+      ++i;
+      Node* l = list_until("]");
+      n->c = l->c;
+      b = n;
+    } else if (t[i].kind == T_ID) {
+      Tok id = t[i++];
+      if (at("(")) {
+        ++i;
+        Node* args = list_until(")");
+        if (at("(")) {           // anonymous component T(params)(inputs)
+          ++i;
+          Node* ins = list_until(")");
+          Node* n = mk(N_ANON, id);
+          n->s = id.s;
+          n->c = {args, ins};
+          b = n;
+        } else {
+          Node* n = mk(N_CALL, id);
+          n->s = id.s;
+          n->c = args->c;
+          b = n;
+        }
+      } else {
+        b = mk(N_ID, id);
+        b->s = id.s;
+      }
+    } else err("expected an expression");
+    for (;;) {
+      if (at("[")) {
+        Node* n = mk(N_INDEX, cur());
+        ++i;
+        Node* e = expression();
+        expect("]");
+        n->c = {b, e};
+        b = n;
+      } else if (at(".")) {
+        Node* n = mk(N_MEMBER, cur());
+        ++i;
+        n->s = ident();
+        n->c = {b};
+        b = n;
+      } else break;
+    }
+    return b;
+  }
+
+  // ---- statements
+  Node* block() {
+    Node* n = mk(S_BLOCK, cur());
+    expect("{");
+    while (!at("}")) n->c.push_back(statement());
+    expect("}");
+    return n;
+  }
+  Node* decls(int kind, const std::string& skind) {
+    Node* n = mk(kind, cur());
+    n->s = skind;
+    for (;;) {
+      Node* d = mk(N_DECL, cur());
+      d->s = ident();
+      Node* dims = mk(N_LIST, cur());
+      while (at("[")) { ++i; dims->c.push_back(expression()); expect("]"); }
+      Node* init = nullptr;
+      std::string op;
+      if (at("=") || at("<==") || at("<--")) { op = t[i++].s; init = expression(); }
+      d->c = {dims};
+      if (init) { d->c.push_back(init); Node* o = mk(N_ID, cur()); o->s = op; d->c.push_back(o); }
+      n->c.push_back(d);
+      if (!accept(",")) break;
+    }
+    return n;
+  }
+  Node* simple() {   // assignment / constraint / increment (no trailing ';')
+    Tok at0 = cur();
+    Node* l = expression();
+    if (t[i].kind == T_OP) {
+      const std::string op = t[i].s;
+      if (op == "++" || op == "--") {
+        ++i;
+        Node* one = mk(N_NUM, at0); one->n = 1;
+        Node* n = mk(S_ASSIGN, at0); n->s = op == "++" ? "+=" : "-="; n->c = {l, one};
+        return n;
+      }
+      if (op == "===") { ++i; Node* r = expression(); Node* n = mk(S_CONSTR, at0); n->c = {l, r}; return n; }
+      if (op == "==>" || op == "-->") {
+        ++i;
+        Node* r = expression();
+        Node* n = mk(S_ASSIGN, at0); n->s = op == "==>" ? "<==" : "<--"; n->c = {r, l};
+        return n;
+      }
+      static const char* as[] = {"=", "<==", "<--", "+=", "-=", "*=", "/=", "\\=", "%=", "**=", "<<=", ">>=", "&=", "|=", "^="};
+      for (const char* a : as) if (op == a) {
+        ++i;
+        Node* r = expression();
+        Node* n = mk(S_ASSIGN, at0); n->s = op; n->c = {l, r};
+        return n;
+      }
+    }
+    Node* n = mk(S_NOP, at0);   // expression statement without effect
+    return n;
+  }
+  Node* statement() {
+    if (at("{")) return block();
+    if (at("signal")) {
+      ++i;
+      std::string kind = "mid";
+      if (accept("input")) kind = "in"; else if (accept("output")) kind = "out";
+      if (at("{")) { while (!at("}")) ++i; ++i; }   // tags
+      Node* n = decls(S_SIGNAL, kind);
+      expect(";");
+      return n;
+    }
+    if (at("component")) { ++i; Node* n = decls(S_COMP, ""); expect(";"); return n; }
+    if (at("var")) { ++i; Node* n = decls(S_VAR, ""); expect(";"); return n; }
+    if (at("for")) {
+      Node* n = mk(S_FOR, cur());
+      ++i;
+      expect("(");
+      Node* init;
+      if (at("var")) { ++i; init = decls(S_VAR, ""); } else init = simple();
+      expect(";");
+      Node* cond = expression();
+      expect(";");
+      Node* step = simple();
+      expect(")");
+      Node* body = statement();
+      n->c = {init, cond, step, body};
+      return n;
+    }
+    if (at("while")) {
+      Node* n = mk(S_WHILE, cur());
+      ++i;
+      expect("(");
+      Node* cond = expression();
+      expect(")");
+      n->c = {cond, statement()};
+      return n;
+    }
+    if (at("if")) {
+      Node* n = mk(S_IF, cur());
+      ++i;
+      expect("(");
+      Node* cond = expression();
+      expect(")");
+      Node* a = statement();
+      n->c = {cond, a};
+      if (accept("else")) n->c.push_back(statement());
+      return n;
+    }
+    if (at("return")) { Node* n = mk(S_RET, cur()); ++i; n->c = {expression()}; expect(";"); return n; }
+    if (at("assert")) { Node* n = mk(S_ASSERT, cur()); ++i; expect("("); n->c = {expression()}; expect(")"); expect(";"); return n; }
+    if (at("log")) {
+      Node* n = mk(S_LOG, cur());
+      ++i;
+      expect("(");
+      int depth = 1;
+      while (depth > 0 && t[i].kind != T_EOF) { if (at("(")) ++depth; else if (at(")")) --depth; ++i; }
+      expect(";");
+      return n;
+    }
+    Node* n = simple();
+    expect(";");
+    return n;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ values
+struct Lin {
+  i64 c0 = 0;
+  std::vector<std::pair<u32, i64>> t;   // (source, coefficient), sorted by source
+  bool sig = false;                     // derived from a signal: degree 1 for the compiler even when its value is a constant
+  bool is_const() const { return t.empty() && !sig; }
+};
+static const u32 SRC_INPUT = 0x80000000u;   // source = message byte (index in the low bits)
+static const i64 COEF_LIMIT = (i64)1 << 40;
+
+static inline i64 chk(__int128 v, const char* what) {
+  if (v >= (__int128)COEF_LIMIT || v <= -(__int128)COEF_LIMIT) fail(std::string("constant out of range in ") + what);
+  return (i64)v;
+}
+static inline Lin lin_const(i64 c) { Lin l; l.c0 = c; return l; }
+static inline Lin lin_add(const Lin& x, const Lin& y, i64 sy = 1) {
+  Lin r;
+  r.sig = x.sig || y.sig;
+  r.c0 = chk((__int128)x.c0 + (__int128)sy * y.c0, "a sum");
+  r.t.reserve(x.t.size() + y.t.size());
+  size_t i = 0, j = 0;
+  while (i < x.t.size() || j < y.t.size()) {
+    if (j == y.t.size() || (i < x.t.size() && x.t[i].first < y.t[j].first)) r.t.push_back(x.t[i++]);
+    else if (i == x.t.size() || y.t[j].first < x.t[i].first) { r.t.emplace_back(y.t[j].first, chk((__int128)sy * y.t[j].second, "a sum")); ++j; }
+    else {
+      i64 c = chk((__int128)x.t[i].second + (__int128)sy * y.t[j].second, "a sum");
+      if (c) r.t.emplace_back(x.t[i].first, c);
+      ++i; ++j;
+    }
+  }
+  return r;
+}
+static inline Lin lin_scale(const Lin& x, i64 k) {
+  Lin r;
+  if (k == 0) return r;
+  r.sig = x.sig;
+  r.c0 = chk((__int128)x.c0 * k, "a product");
+  for (auto& p : x.t) r.t.emplace_back(p.first, chk((__int128)p.second * k, "a product"));
+  return r;
+}
+static inline bool lin_eq(const Lin& x, const Lin& y) { return x.c0 == y.c0 && x.t == y.t; }
+// x == k * y for some integer k?
+static inline bool lin_multiple(const Lin& x, const Lin& y, i64& k) {
+  if (y.t.empty()) {
+    if (!x.t.empty()) return false;
+    if (y.c0 == 0) { k = 0; return x.c0 == 0; }
+    if (x.c0 % y.c0) return false;
+    k = x.c0 / y.c0;
+    return true;
+  }
+  if (x.t.size() != y.t.size()) return false;
+  if (x.t[0].second % y.t[0].second) return false;
+  k = x.t[0].second / y.t[0].second;
+  return lin_eq(x, lin_scale(y, k));
+}
+
+enum { V_UNSET, V_LIN, V_QUAD, V_ARR };
+struct Val {
+  int k = V_UNSET;
+  Lin a, b, c;              // V_LIN: a    V_QUAD: a * b + c
+  std::vector<Val> arr;     // V_ARR
+  static Val lin(const Lin& l) { Val v; v.k = V_LIN; v.a = l; return v; }
+  static Val num(i64 n) { return lin(lin_const(n)); }
+  bool is_const() const { return k == V_LIN && a.is_const(); }
+};
+
+// ------------------------------------------------------------------------------------------------ gates
+enum GateOp : u32 {
+  G_NOP = 0,
+  G_QUAD = 1,    // v = A * B + C
+  G_INV0 = 2,    // v = A == 0 ? 0 : 1 / A           (stored as the integer A with the inverse flag)
+  G_BIT = 3,     // v = (A >> k) & 1
+  G_NEZ = 4,     // v = k * (A != 0) + C             (IsZero.out = -in * inv + 1 and relatives)
+  G_LIN = 5,     // v = A                            (materialised long linear form; not a signal of the layout)
+  G_ASSERT = 6,  // A * B + C == 0
+  G_OUT = 7      // small[dst] = A                   (template outputs handed to the rest of the schedule)
+};
+struct Inst;
+struct Gate {
+  u32 op = G_NOP;
+  i64 k = 0;
+  Lin f[3];
+  Inst* owner = nullptr;   // kept signal: the component, signal and flat index it belongs to
+  u32 sig = 0, flat = 0;
+  i64 lo = 0, hi = 0;      // value interval
+  u32 slot = 0xffffffffu;  // layout slot inside the region (kept gates first, then temporaries)
+  u32 out_index = 0;       // G_OUT: index in the output list
+  const Node* at = nullptr;
+};
+
+struct SigArr {
+  std::string name;
+  int kind = 0;                 // 0 out, 1 in, 2 mid
+  std::vector<u32> dims;
+  std::vector<Lin> val;
+  std::vector<u8> set;
+  std::vector<int> gate;        // gate id when the signal itself is a gate (kept), else -1
+  u32 size() const { u32 n = 1; for (u32 d : dims) n *= d; return n; }
+};
+struct CompArr { std::vector<u32> dims; std::vector<Inst*> inst; };
+struct VarArr { std::vector<u32> dims; std::vector<Val> v; };
+
+struct Inst {
+  const Template* tmpl = nullptr;
+  std::vector<i64> args;
+  std::string name;             // name inside the parent ("eq[0][5]", "MultiOR_351_24[3]")
+  Inst* parent = nullptr;
+  std::vector<Inst*> subs;      // creation order
+  std::vector<SigArr> sigs;     // declaration order
+  std::map<std::string, u32> sig_of;
+  std::map<std::string, CompArr> comps;
+  u32 pending = 0;              // input elements not assigned yet
+  bool ran = false, running = false;
+};
+
+struct Frame {
+  Inst* inst;
+  std::map<std::string, VarArr> vars;
+  std::vector<int> loops;       // iteration counters of the enclosing loops (innermost last)
+};
+
+// ------------------------------------------------------------------------------------------------ result
+struct Net {
+  u32 n_in = 0;                      // message bytes
+  u32 n_kept = 0, n_temp = 0;        // region = kept slots, then temporaries
+  u32 inv_need = 0;                  // largest |x| whose inverse a kept signal may hold (interval bound, capped at 2^16;
+                                     // the evaluator rejects an email whose value exceeds the table)
+  u32 n_out = 0;                     // outputs: [0] = first scalar output, then the elements of the first array output
+  u32 lds_log2 = 0;                  // (unused)
+  u32 n_pins = 0;                    // LDS words holding gate values (allocated by liveness)
+  u32 lds_words = 0;                 // LDS image of the evaluator: values, message bytes, a zero word, a scratch word
+  u32 n_general = 0;                 // gates on the evaluator's 64-bit path (the 32-bit path is not provably exact for them)
+  std::vector<u32> records;          // 16 words per gate, in execution order (zkwg_net_core.h)
+  std::vector<uint16_t> step_count;  // gates per step (<= 64, one per lane) | 0x8000 general path | 0x4000 term slots 0..3 only;
+                                     // padded to a multiple of 64 steps plus one block
+  u32 n_steps = 0;
+  std::vector<std::string> names;    // kept slot -> name relative to the component (".eq[0][5].isz.inv")
+  std::vector<u8> boolean;           // kept slot -> 1 if its interval is [0, 1]
+  // statistics
+  u32 n_gates = 0, n_asserts = 0, n_chunks = 0;
+  u64 lds_hits = 0, pin_reads = 0;   // operand reads
+};
+// record / term encoding shared with the kernel
+static const u32 VAL_INVERSE = 0x80000000u; // stored word: inverse of the 31-bit two's-complement integer in the low bits
+
+// ------------------------------------------------------------------------------------------------ elaboration
+struct Elab {
+  std::deque<Node> pool;
+  std::deque<std::string> files;
+  std::deque<Inst> insts;
+  std::map<std::string, Template> templates;
+  std::set<std::string> functions;
+  std::set<std::string> included;
+  std::vector<std::string> include_dirs;
+  std::vector<Gate> gates;
+  std::vector<i64> in_lo, in_hi;
+  u32 n_in = 0;
+  u32 max_terms = 32;
+
+  // ---- sources
+  static const char* builtin_source(const std::string& base);
+  bool read_file(const std::string& path, std::string& text) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    text = ss.str();
+    return true;
+  }
+  static std::string dir_of(const std::string& p) { size_t k = p.find_last_of('/'); return k == std::string::npos ? std::string(".") : p.substr(0, k); }
+  static std::string base_of(const std::string& p) { size_t k = p.find_last_of('/'); return k == std::string::npos ? p : p.substr(k + 1); }
+  void load_text(const std::string& text, const std::string& fname, const std::string& dir) {
+    files.push_back(fname);
+    const std::string* fp = &files.back();
+    Parser P(pool, fp);
+    lex(text, fname, P.t);
+    while (P.cur().kind != T_EOF) {
+      if (P.accept("pragma")) { while (!P.at(";")) ++P.i; ++P.i; continue; }
+      if (P.accept("include")) {
+        if (P.cur().kind != T_STR) P.err("expected a file name");
+        std::string inc = P.t[P.i++].s;
+        P.expect(";");
+        load_include(inc, dir);
+        continue;
+      }
+      if (P.at("template")) {
+        ++P.i;
+        while (P.at("custom") || P.at("parallel")) ++P.i;
+        Template T;
+        T.name = P.ident();
+        T.file = fp;
+        P.expect("(");
+        while (!P.at(")")) { T.params.push_back(P.ident()); if (!P.accept(",")) break; }
+        P.expect(")");
+        T.body = P.block();
+        templates[T.name] = T;
+        continue;
+      }
+      if (P.at("function")) {
+        ++P.i;
+        std::string nm = P.ident();
+        P.expect("(");
+        while (!P.at(")")) { P.ident(); if (!P.accept(",")) break; }
+        P.expect(")");
+        P.block();
+        functions.insert(nm);
+        continue;
+      }
+      if (P.at("component")) {   // `component main ... = T(...);`
+        while (!P.at(";")) ++P.i;
+        ++P.i;
+        continue;
+      }
+      P.err("expected a template, function or include");
+    }
+  }
+  void load_include(const std::string& inc, const std::string& from_dir) {
+    std::vector<std::string> cands;
+    cands.push_back(from_dir + "/" + inc);
+    for (auto& d : include_dirs) cands.push_back(d + "/" + inc);
+    for (auto& p : cands) {
+      std::string text;
+      if (read_file(p, text)) {
+        if (!included.insert(base_of(p) + "#" + std::to_string(text.size())).second) return;
+        load_text(text, p, dir_of(p));
+        return;
+      }
+    }
+    // circomlib: the restatement carried by this library
+    const std::string base = base_of(inc);
+    if (const char* src = builtin_source(base)) {
+      if (!included.insert("builtin:" + base).second) return;
+      load_text(src, "<zkwg circomlib>/" + base, "<zkwg circomlib>");
+      return;
+    }
+    fail("include \"" + inc + "\" not found (searched " + from_dir + " and the include directories)");
+  }
+
+  // ---- helpers
+  std::string where(const Node* n) const { return (n && n->file ? *n->file : std::string("?")) + ":" + std::to_string(n ? n->line : 0); }
+  [[noreturn]] void err(const Node* n, const std::string& m) const { fail(where(n) + ": " + m); }
+
+  i64 const_of(const Val& v, const Node* n, const char* what) const {
+    if (!v.is_const()) err(n, std::string(what) + " must be a compile-time constant");
+    return v.a.c0;
+  }
+
+  // ---- arithmetic on values
+  Val v_add(const Val& x, const Val& y, i64 sy, const Node* n) const {
+    if (x.k == V_LIN && y.k == V_LIN) return Val::lin(lin_add(x.a, y.a, sy));
+    if (x.k == V_QUAD && y.k == V_LIN) { Val r = x; r.c = lin_add(x.c, y.a, sy); return r; }
+    if (x.k == V_LIN && y.k == V_QUAD) { Val r; r.k = V_QUAD; r.a = lin_scale(y.a, sy); r.b = y.b; r.c = lin_add(x.a, y.c, sy); return r; }
+    err(n, "unsupported operands of + / - (sum of two products, or an array)");
+  }
+  Val v_mul(const Val& x, const Val& y, const Node* n) const {
+    if (x.k == V_LIN && y.k == V_LIN) {
+      if (x.a.is_const()) return Val::lin(lin_scale(y.a, x.a.c0));
+      if (y.a.is_const()) return Val::lin(lin_scale(x.a, y.a.c0));
+      Val r; r.k = V_QUAD; r.a = x.a; r.b = y.a;
+      return r;
+    }
+    if (x.k == V_QUAD && y.is_const()) { Val r = x; r.a = lin_scale(x.a, y.a.c0); r.c = lin_scale(x.c, y.a.c0); return r; }
+    if (y.k == V_QUAD && x.is_const()) return v_mul(y, x, n);
+    err(n, "expression of degree 3 or an array operand of *");
+  }
+
+  // ---- instances
+  Inst* instantiate(const std::string& tname, const std::vector<i64>& args, const std::string& name, Inst* parent, const Node* at) {
+    auto it = templates.find(tname);
+    if (it == templates.end()) err(at, "unknown template " + tname);
+    const Template& T = it->second;
+    if (args.size() != T.params.size()) err(at, tname + ": " + std::to_string(args.size()) + " parameters given, " + std::to_string(T.params.size()) + " declared");
+    insts.emplace_back();
+    Inst* in = &insts.back();
+    in->tmpl = &T; in->args = args; in->name = name; in->parent = parent;
+    if (parent) parent->subs.push_back(in);
+    // declare the input signals (their extents may depend on the parameters and on leading `var`s)
+    Frame f{in, {}, {}};
+    for (size_t p = 0; p < T.params.size(); ++p) f.vars[T.params[p]] = VarArr{{}, {Val::num(args[p])}};
+    for (Node* st : T.body->c) {
+      if (st->k == S_VAR) { try { exec(st, f); } catch (Error&) {} }
+      else if (st->k == S_SIGNAL && st->s == "in") declare_signals(st, f, true);
+    }
+    for (auto& s : in->sigs) in->pending += s.size();
+    return in;
+  }
+  void maybe_run(Inst* in, const Node* at) {
+    if (!in->ran && in->pending == 0) run(in, at);
+  }
+  void run(Inst* in, const Node* at) {
+    if (in->running) err(at, "recursive component execution");
+    in->running = true;
+    Frame f{in, {}, {}};
+    const Template& T = *in->tmpl;
+    for (size_t p = 0; p < T.params.size(); ++p) f.vars[T.params[p]] = VarArr{{}, {Val::num(in->args[p])}};
+    exec(T.body, f);
+    in->running = false;
+    in->ran = true;
+  }
+
+  void declare_signals(Node* st, Frame& f, bool prepass) {
+    const int kind = st->s == "out" ? 0 : (st->s == "in" ? 1 : 2);
+    for (Node* d : st->c) {
+      if (f.inst->sig_of.count(d->s)) {
+        if (kind == 1 && !prepass) continue;   // inputs were declared when the component was created
+        err(d, "signal " + d->s + " declared twice");
+      }
+      SigArr S;
+      S.name = d->s; S.kind = kind;
+      for (Node* e : d->c[0]->c) {
+        i64 v = const_of(eval(e, f), e, "a signal array extent");
+        if (v < 0 || v > (1 << 28)) err(e, "signal array extent out of range");
+        S.dims.push_back((u32)v);
+      }
+      const u32 n = S.size();
+      S.val.resize(n); S.set.assign(n, 0); S.gate.assign(n, -1);
+      f.inst->sig_of[S.name] = (u32)f.inst->sigs.size();
+      f.inst->sigs.push_back(std::move(S));
+    }
+  }
+
+  // ---- references
+  struct Ref {
+    int kind = 0;          // 1 var, 2 signal, 3 component
+    VarArr* var = nullptr;
+    Inst* inst = nullptr;  // signal owner
+    u32 sig = 0;
+    CompArr* comp = nullptr;
+    std::string comp_name;
+    std::vector<i64> idx;
+  };
+  static u32 flat_index(const std::vector<u32>& dims, const std::vector<i64>& idx, size_t n_idx, u32& remaining) {
+    u32 flat = 0;
+    remaining = 1;
+    for (size_t d = 0; d < dims.size(); ++d) {
+      if (d < n_idx) flat = flat * dims[d] + (u32)idx[d];
+      else { flat *= dims[d]; remaining *= dims[d]; }
+    }
+    return flat;
+  }
+  Ref resolve(Node* n, Frame& f) {
+    // flatten the accessor chain
+    std::vector<Node*> chain;
+    Node* p = n;
+    while (p->k == N_INDEX || p->k == N_MEMBER) { chain.push_back(p); p = p->c[0]; }
+    if (p->k != N_ID) err(n, "not an assignable expression");
+    std::reverse(chain.begin(), chain.end());
+    Ref r;
+    size_t ci = 0;
+    auto take_indices = [&](size_t max_n, std::vector<i64>& out) {
+      while (ci < chain.size() && chain[ci]->k == N_INDEX && out.size() < max_n) {
+        out.push_back(const_of(eval(chain[ci]->c[1], f), chain[ci], "an index"));
+        ++ci;
+      }
+    };
+    auto vi = f.vars.find(p->s);
+    if (vi != f.vars.end()) {
+      r.kind = 1; r.var = &vi->second;
+      take_indices(vi->second.dims.size(), r.idx);
+      if (ci != chain.size()) err(n, "too many indices for variable " + p->s);
+      for (size_t d = 0; d < r.idx.size(); ++d) if (r.idx[d] < 0 || r.idx[d] >= (i64)vi->second.dims[d]) err(n, "index out of bounds for " + p->s);
+      return r;
+    }
+    auto si = f.inst->sig_of.find(p->s);
+    if (si != f.inst->sig_of.end()) {
+      r.kind = 2; r.inst = f.inst; r.sig = si->second;
+      SigArr& S = f.inst->sigs[r.sig];
+      take_indices(S.dims.size(), r.idx);
+      if (ci != chain.size()) err(n, "too many indices for signal " + p->s);
+      for (size_t d = 0; d < r.idx.size(); ++d) if (r.idx[d] < 0 || r.idx[d] >= (i64)S.dims[d]) err(n, "index out of bounds for signal " + p->s);
+      return r;
+    }
+    auto cit = f.inst->comps.find(p->s);
+    if (cit != f.inst->comps.end()) {
+      CompArr& C = cit->second;
+      std::vector<i64> cidx;
+      take_indices(C.dims.size(), cidx);
+      if (cidx.size() != C.dims.size()) err(n, "component array " + p->s + " needs " + std::to_string(C.dims.size()) + " indices");
+      u32 rem, flat = flat_index(C.dims, cidx, cidx.size(), rem);
+      for (size_t d = 0; d < cidx.size(); ++d) if (cidx[d] < 0 || cidx[d] >= (i64)C.dims[d]) err(n, "index out of bounds for component " + p->s);
+      if (ci == chain.size()) {
+        r.kind = 3; r.comp = &C; r.comp_name = p->s; r.idx = cidx;
+        return r;
+      }
+      if (chain[ci]->k != N_MEMBER) err(n, "expected .signal after component " + p->s);
+      Inst* in = C.inst[flat];
+      if (!in) err(n, "component " + p->s + " used before it is created");
+      const std::string& sname = chain[ci]->s;
+      ++ci;
+      auto s2 = in->sig_of.find(sname);
+      if (s2 == in->sig_of.end()) {
+        if (!in->ran) err(n, "signal " + sname + " of component " + p->s + " read before the component has run (or it is not an input)");
+        err(n, "component " + p->s + " (" + in->tmpl->name + ") has no signal " + sname);
+      }
+      r.kind = 2; r.inst = in; r.sig = s2->second;
+      SigArr& S = in->sigs[r.sig];
+      take_indices(S.dims.size(), r.idx);
+      if (ci != chain.size()) err(n, "too many indices for " + p->s + "." + sname);
+      for (size_t d = 0; d < r.idx.size(); ++d) if (r.idx[d] < 0 || r.idx[d] >= (i64)S.dims[d]) err(n, "index out of bounds for " + p->s + "." + sname);
+      return r;
+    }
+    err(n, "unknown identifier " + p->s);
+  }
+  Val read_sig_range(Inst* in, SigArr& S, u32 flat, u32 count, size_t dim, const Node* n) {
+    if (dim == S.dims.size()) {
+      if (!S.set[flat]) err(n, "signal " + path_of(in) + "." + S.name + " read before it is assigned");
+      Val v = Val::lin(S.val[flat]);
+      v.a.sig = true;
+      return v;
+    }
+    Val v;
+    v.k = V_ARR;
+    const u32 sub = count / S.dims[dim];
+    for (u32 i = 0; i < S.dims[dim]; ++i) v.arr.push_back(read_sig_range(in, S, flat + i * sub, sub, dim + 1, n));
+    return v;
+  }
+  Val read_var_range(VarArr& V, u32 flat, u32 count, size_t dim) {
+    if (dim == V.dims.size()) return V.v[flat];
+    Val v;
+    v.k = V_ARR;
+    const u32 sub = count / V.dims[dim];
+    for (u32 i = 0; i < V.dims[dim]; ++i) v.arr.push_back(read_var_range(V, flat + i * sub, sub, dim + 1));
+    return v;
+  }
+  Val read(const Ref& r, const Node* n) {
+    if (r.kind == 1) {
+      u32 rem, flat = flat_index(r.var->dims, r.idx, r.idx.size(), rem);
+      Val v = read_var_range(*r.var, flat, rem, r.idx.size());
+      if (v.k == V_UNSET) err(n, "variable read before it is assigned");
+      return v;
+    }
+    if (r.kind == 2) {
+      SigArr& S = r.inst->sigs[r.sig];
+      u32 rem, flat = flat_index(S.dims, r.idx, r.idx.size(), rem);
+      return read_sig_range(r.inst, S, flat, rem, r.idx.size(), n);
+    }
+    err(n, "a component is not a value");
+  }
+
+  // ---- gates
+  std::string path_of(const Inst* in) const {
+    std::string p;
+    for (const Inst* q = in; q && q->parent; q = q->parent) p = "." + q->name + p;
+    return p;
+  }
+  void interval_of(const Lin& l, i64& lo, i64& hi) const {
+    __int128 a = l.c0, b = l.c0;
+    for (auto& t : l.t) {
+      i64 slo, shi;
+      if (t.first & SRC_INPUT) { slo = in_lo[t.first & 0x3fffffffu]; shi = in_hi[t.first & 0x3fffffffu]; }
+      else { slo = gates[t.first].lo; shi = gates[t.first].hi; }
+      if (t.second >= 0) { a += (__int128)t.second * slo; b += (__int128)t.second * shi; }
+      else { a += (__int128)t.second * shi; b += (__int128)t.second * slo; }
+    }
+    const __int128 L = (__int128)1 << 60;
+    lo = (i64)std::max<__int128>(a, -L);
+    hi = (i64)std::min<__int128>(b, L);
+  }
+  void no_inverse_sources(const Lin& l, const Node* at) const {
+    for (auto& t : l.t) if (!(t.first & SRC_INPUT) && gates[t.first].op == G_INV0) err(at, "an inverse hint is used outside the IsZero pattern (in * inv)");
+  }
+  u32 add_gate(Gate g, const Node* at) {
+    g.at = at;
+    i64 lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    const int nf = (g.op == G_QUAD || g.op == G_ASSERT) ? 3 : (g.op == G_NEZ ? 2 : 1);
+    for (int i = 0; i < nf; ++i) { no_inverse_sources(g.f[i], at); interval_of(g.f[i], lo[i], hi[i]); }
+    if (g.op == G_NEZ && !g.f[1].t.empty()) err(at, "internal: indicator gate with a non-constant offset");
+    switch (g.op) {
+      case G_QUAD: case G_ASSERT: {
+        __int128 c[4] = {(__int128)lo[0] * lo[1], (__int128)lo[0] * hi[1], (__int128)hi[0] * lo[1], (__int128)hi[0] * hi[1]};
+        __int128 a = std::min(std::min(c[0], c[1]), std::min(c[2], c[3])) + lo[2];
+        __int128 b = std::max(std::max(c[0], c[1]), std::max(c[2], c[3])) + hi[2];
+        const __int128 L = (__int128)1 << 60;
+        g.lo = (i64)std::max<__int128>(a, -L); g.hi = (i64)std::min<__int128>(b, L);
+        break;
+      }
+      case G_INV0: g.lo = lo[0]; g.hi = hi[0]; break;      // interval of the inverted integer
+      case G_BIT: g.lo = 0; g.hi = 1; break;
+      case G_NEZ: g.lo = std::min<i64>(0, g.k) + lo[1]; g.hi = std::max<i64>(0, g.k) + hi[1]; break;
+      default: g.lo = lo[0]; g.hi = hi[0]; break;
+    }
+    // intervals ignore correlations (a long chain of boolean recurrences widens them without bound): they only
+    // classify signals and size the inverse table; the evaluator checks the 31-bit range of every value at run time
+    const i64 LIM = ((i64)1 << 30) - 1;
+    g.lo = std::max(g.lo, -LIM); g.hi = std::min(g.hi, LIM);
+    gates.push_back(std::move(g));
+    return (u32)gates.size() - 1;
+  }
+  static Lin lin_gate(u32 g) { Lin l; l.t.emplace_back(g, 1); return l; }
+
+  // the value a signal takes when assigned `v` with <== (kept signals become gates)
+  void assign_signal(Inst* in, u32 sig, u32 flat, const Val& v, const Node* at, Frame& f) {
+    SigArr& S = in->sigs[sig];
+    if (S.set[flat]) err(at, "signal " + path_of(in) + "." + S.name + " assigned twice");
+    if (v.k == V_LIN) {
+      if (v.a.t.size() > max_terms) {
+        Gate g; g.op = G_LIN; g.f[0] = v.a;
+        S.val[flat] = lin_gate(add_gate(std::move(g), at));
+      } else S.val[flat] = v.a;
+    } else if (v.k == V_QUAD) {
+      Gate g;
+      g.owner = in; g.sig = sig; g.flat = flat;
+      // in * inv patterns: one factor is an inverse hint of L, the other a multiple of L
+      const Lin* fa = &v.a; const Lin* fb = &v.b;
+      auto inv_of = [&](const Lin& l) -> const Gate* {
+        if (l.c0 == 0 && l.t.size() == 1 && !(l.t[0].first & SRC_INPUT) && gates[l.t[0].first].op == G_INV0) return &gates[l.t[0].first];
+        return nullptr;
+      };
+      const Gate* ig = inv_of(*fb);
+      if (!ig) { ig = inv_of(*fa); std::swap(fa, fb); }
+      if (ig) {
+        const i64 ci = fb->t[0].second;
+        i64 k;
+        if (lin_multiple(*fa, ig->f[0], k)) {
+          g.op = G_NEZ; g.k = chk((__int128)k * ci, "in * inv"); g.f[0] = ig->f[0]; g.f[1] = lin_const(v.c.c0);
+          if (!v.c.t.empty()) {   // k * (x != 0) + (non-constant): the indicator becomes a temporary
+            Gate t; t.op = G_NEZ; t.k = g.k; t.f[0] = g.f[0];
+            g.op = G_LIN; g.k = 0; g.f[0] = lin_add(lin_gate(add_gate(std::move(t), at)), v.c);
+            g.f[1] = Lin();
+          }
+        } else err(at, "product with an inverse hint that is not of the form (k * x) * inverse(x)");
+      } else {
+        g.op = G_QUAD; g.f[0] = v.a; g.f[1] = v.b; g.f[2] = v.c;
+        for (int i = 0; i < 3; ++i) if (g.f[i].t.size() > max_terms) { Gate t; t.op = G_LIN; t.f[0] = g.f[i]; g.f[i] = lin_gate(add_gate(std::move(t), at)); }
+      }
+      const u32 id = add_gate(std::move(g), at);
+      S.val[flat] = lin_gate(id);
+      S.gate[flat] = (int)id;
+    } else err(at, "cannot assign this value to a signal");
+    S.set[flat] = 1;
+    (void)f;
+    if (S.kind == 1 && in->pending > 0) { --in->pending; }
+  }
+  void assign_signal_range(Inst* in, u32 sig, u32 flat, u32 count, size_t dim, const Val& v, const Node* at, Frame& f) {
+    SigArr& S = in->sigs[sig];
+    if (dim == S.dims.size()) { assign_signal(in, sig, flat, v, at, f); return; }
+    if (v.k != V_ARR || v.arr.size() != S.dims[dim]) err(at, "array shape mismatch in assignment to " + S.name);
+    const u32 sub = count / S.dims[dim];
+    for (u32 i = 0; i < S.dims[dim]; ++i) assign_signal_range(in, sig, flat + i * sub, sub, dim + 1, v.arr[i], at, f);
+  }
+  void constrain_assign(const Ref& r, const Val& v, const Node* at, Frame& f) {
+    SigArr& S = r.inst->sigs[r.sig];
+    if (r.inst != f.inst && S.kind != 1) err(at, "only the inputs of a sub-component can be assigned");
+    u32 rem, flat = flat_index(S.dims, r.idx, r.idx.size(), rem);
+    assign_signal_range(r.inst, r.sig, flat, rem, r.idx.size(), v, at, f);
+    if (r.inst != f.inst) maybe_run(r.inst, at);
+  }
+  // `lhs <-- hint`
+  void hint_assign(const Ref& r, Node* rhs, const Node* at, Frame& f) {
+    SigArr& S = r.inst->sigs[r.sig];
+    if (r.idx.size() != S.dims.size()) err(at, "hints assign one signal at a time");
+    u32 rem, flat = flat_index(S.dims, r.idx, r.idx.size(), rem);
+    if (S.set[flat]) err(at, "signal " + S.name + " assigned twice");
+    Gate g;
+    g.owner = r.inst; g.sig = r.sig; g.flat = flat;
+    Node* e = rhs;
+    // (x >> k) & 1
+    auto strip = [](Node* n) { return n; };
+    (void)strip;
+    if (e->k == N_BIN && e->s == "&" && e->c[1]->k == N_NUM && e->c[1]->n == 1 && e->c[0]->k == N_BIN && e->c[0]->s == ">>") {
+      Val x = eval(e->c[0]->c[0], f);
+      Val k = eval(e->c[0]->c[1], f);
+      if (x.k != V_LIN) err(at, "the operand of a bit-extraction hint must be linear");
+      g.op = G_BIT; g.f[0] = x.a; g.k = const_of(k, at, "the shift of a bit-extraction hint");
+      if (g.k < 0 || g.k > 30) err(at, "bit index out of range");
+    } else if (e->k == N_TERN && e->c[0]->k == N_BIN && e->c[0]->s == "!=" && e->c[0]->c[1]->k == N_NUM && e->c[0]->c[1]->n == 0 &&
+               e->c[1]->k == N_BIN && e->c[1]->s == "/" && e->c[1]->c[0]->k == N_NUM && e->c[1]->c[0]->n == 1 &&
+               e->c[2]->k == N_NUM && e->c[2]->n == 0) {
+      Val x = eval(e->c[0]->c[0], f);
+      Val y = eval(e->c[1]->c[1], f);
+      if (x.k != V_LIN || y.k != V_LIN || !lin_eq(x.a, y.a)) err(at, "inverse hint must have the shape x != 0 ? 1/x : 0");
+      g.op = G_INV0; g.f[0] = x.a;
+    } else err(at, "unsupported hint: only (x >> k) & 1 and x != 0 ? 1/x : 0 are known");
+    const u32 id = add_gate(std::move(g), at);
+    S.val[flat] = lin_gate(id);
+    S.gate[flat] = (int)id;
+    S.set[flat] = 1;
+  }
+  // sum_k 2^k * bit_k(F) - F == 0 with bit gates of one form F covering bits 0..n-1 and F provably in [0, 2^n):
+  // Num2Bits' closing constraint, true for every input
+  bool bit_sum_holds(const Lin& d) const {
+    const Lin* F = nullptr;
+    Lin rest = d;
+    rest.t.clear();
+    unsigned long long seen = 0;
+    u32 nbits = 0;
+    for (auto& t : d.t) {
+      const bool is_bit = !(t.first & SRC_INPUT) && gates[t.first].op == G_BIT;
+      if (!is_bit) { rest.t.push_back(t); continue; }
+      const Gate& g = gates[t.first];
+      if (!F) F = &g.f[0];
+      else if (!lin_eq(*F, g.f[0])) return false;
+      if (g.k < 0 || g.k > 40 || t.second != ((i64)1 << g.k) || (seen >> g.k & 1)) return false;
+      seen |= 1ull << g.k;
+      ++nbits;
+    }
+    if (!F || seen != (nbits >= 64 ? ~0ull : (1ull << nbits) - 1)) return false;
+    if (!lin_eq(rest, lin_scale(*F, -1))) return false;
+    i64 lo, hi;
+    interval_of(*F, lo, hi);
+    return lo >= 0 && hi < ((i64)1 << nbits);
+  }
+  void constrain(const Val& l, const Val& r, const Node* at) {
+    Val d = v_add(l, r, -1, at);
+    Gate g;
+    g.op = G_ASSERT;
+    if (d.k == V_LIN) {
+      if (d.a.t.empty()) { if (d.a.c0 != 0) err(at, "constraint between constants does not hold"); return; }
+      if (bit_sum_holds(d.a)) return;
+      g.f[2] = d.a;
+      if (g.f[2].t.size() > max_terms) { Gate t; t.op = G_LIN; t.f[0] = g.f[2]; g.f[2] = lin_gate(add_gate(std::move(t), at)); }
+    } else if (d.k == V_QUAD) {
+      // bit * (bit - 1) and in * IsZero(in).out hold by construction
+      auto single = [&](const Lin& x, u32& gid) { if (x.c0 == 0 && x.t.size() == 1 && x.t[0].second == 1 && !(x.t[0].first & SRC_INPUT)) { gid = x.t[0].first; return true; } return false; };
+      u32 ga;
+      if (d.c.t.empty() && d.c.c0 == 0) {
+        if (single(d.a, ga) && gates[ga].op == G_BIT && lin_eq(d.b, lin_add(d.a, lin_const(-1)))) return;
+        for (int sw = 0; sw < 2; ++sw) {
+          const Lin& x = sw ? d.b : d.a; const Lin& y = sw ? d.a : d.b;
+          u32 gy;
+          i64 k;
+          if (single(y, gy) && gates[gy].op == G_NEZ && gates[gy].k == -1 && gates[gy].f[1].t.empty() && gates[gy].f[1].c0 == 1 &&
+              lin_multiple(x, gates[gy].f[0], k)) return;
+        }
+      }
+      g.f[0] = d.a; g.f[1] = d.b; g.f[2] = d.c;
+    } else err(at, "unsupported constraint");
+    add_gate(std::move(g), at);
+  }
+
+  // ---- expressions
+  Val eval(Node* n, Frame& f) {
+    switch (n->k) {
+      case N_NUM:
+        if (n->big) err(n, "integer literal too large for this loader");
+        return Val::num(n->n);
+      case N_ID: case N_INDEX: case N_MEMBER: return read(resolve(n, f), n);
+      case N_ARR: { Val v; v.k = V_ARR; for (Node* e : n->c) v.arr.push_back(eval(e, f)); return v; }
+      case N_UN: {
+        Val x = eval(n->c[0], f);
+        if (n->s == "-") {
+          if (x.k == V_LIN) return Val::lin(lin_scale(x.a, -1));
+          if (x.k == V_QUAD) { Val r = x; r.a = lin_scale(x.a, -1); r.c = lin_scale(x.c, -1); return r; }
+          err(n, "unsupported operand of unary -");
+        }
+        if (n->s == "!") return Val::num(const_of(x, n, "the operand of !") == 0);
+        err(n, "unsupported unary operator " + n->s);
+      }
+      case N_TERN: {
+        const i64 c = const_of(eval(n->c[0], f), n, "the condition of ?:");
+        return eval(c ? n->c[1] : n->c[2], f);
+      }
+      case N_BIN: {
+        const std::string& op = n->s;
+        if (op == "&&") { if (!const_of(eval(n->c[0], f), n, "an operand of &&")) return Val::num(0); return Val::num(const_of(eval(n->c[1], f), n, "an operand of &&") != 0); }
+        if (op == "||") { if (const_of(eval(n->c[0], f), n, "an operand of ||")) return Val::num(1); return Val::num(const_of(eval(n->c[1], f), n, "an operand of ||") != 0); }
+        Val x = eval(n->c[0], f), y = eval(n->c[1], f);
+        if (op == "+") return v_add(x, y, 1, n);
+        if (op == "-") return v_add(x, y, -1, n);
+        if (op == "*") return v_mul(x, y, n);
+        const i64 a = const_of(x, n, ("the left operand of " + op).c_str()), b = const_of(y, n, ("the right operand of " + op).c_str());
+        if (op == "==") return Val::num(a == b);
+        if (op == "!=") return Val::num(a != b);
+        if (op == "<") return Val::num(a < b);
+        if (op == ">") return Val::num(a > b);
+        if (op == "<=") return Val::num(a <= b);
+        if (op == ">=") return Val::num(a >= b);
+        if (op == "\\") { if (b == 0 || a < 0 || b < 0) err(n, "integer division needs non-negative operands"); return Val::num(a / b); }
+        if (op == "/") { if (b == 0 || a % b) err(n, "field division of constants that is not exact"); return Val::num(a / b); }
+        if (op == "%") { if (b <= 0 || a < 0) err(n, "% needs non-negative operands"); return Val::num(a % b); }
+        if (op == "<<") { if (b < 0 || b > 39 || a < 0) err(n, "shift out of range"); return Val::num(chk((__int128)a << b, "a shift")); }
+        if (op == ">>") { if (b < 0 || a < 0) err(n, "shift out of range"); return Val::num(b > 62 ? 0 : a >> b); }
+        if (op == "&") { if (a < 0 || b < 0) err(n, "& needs non-negative operands"); return Val::num(a & b); }
+        if (op == "|") { if (a < 0 || b < 0) err(n, "| needs non-negative operands"); return Val::num(a | b); }
+        if (op == "^") { if (a < 0 || b < 0) err(n, "^ needs non-negative operands"); return Val::num(a ^ b); }
+        if (op == "**") { if (b < 0 || b > 62) err(n, "exponent out of range"); __int128 r = 1; for (i64 i = 0; i < b; ++i) { r *= a; chk(r, "a power"); } return Val::num((i64)r); }
+        err(n, "unsupported operator " + op);
+      }
+      case N_CALL:
+        if (templates.count(n->s)) err(n, "a template instantiation is only valid on the right of `component x =`");
+        err(n, "functions are not supported by this loader (" + n->s + ")");
+      case N_ANON: return eval_anon(n, f);
+      default: err(n, "not an expression");
+    }
+  }
+  Val eval_anon(Node* n, Frame& f) {
+    std::vector<i64> args;
+    for (Node* a : n->c[0]->c) args.push_back(const_of(eval(a, f), a, "a template parameter"));
+    std::vector<Val> ins;
+    for (Node* a : n->c[1]->c) ins.push_back(eval(a, f));
+    std::string name = n->s + "_" + std::to_string(n->line) + "_" + std::to_string(n->pos);
+    if (!f.loops.empty()) name += "[" + std::to_string(f.loops.back()) + "]";
+    Inst* in = instantiate(n->s, args, name, f.inst, n);
+    std::vector<u32> inputs;
+    for (u32 s = 0; s < in->sigs.size(); ++s) if (in->sigs[s].kind == 1) inputs.push_back(s);
+    if (inputs.size() != ins.size()) err(n, n->s + ": " + std::to_string(ins.size()) + " inputs given, the template declares " + std::to_string(inputs.size()));
+    for (size_t k = 0; k < inputs.size(); ++k) assign_signal_range(in, inputs[k], 0, in->sigs[inputs[k]].size(), 0, ins[k], n, f);
+    maybe_run(in, n);
+    if (!in->ran) err(n, "anonymous component did not receive all its inputs");
+    std::vector<Val> outs;
+    for (auto& S : in->sigs) if (S.kind == 0) outs.push_back(read_sig_range(in, S, 0, S.size(), 0, n));
+    if (outs.size() == 1) return outs[0];
+    Val v; v.k = V_ARR; v.arr = outs;
+    return v;
+  }
+
+  // ---- statements
+  void declare_var(Node* d, Frame& f) {
+    VarArr V;
+    for (Node* e : d->c[0]->c) {
+      i64 v = const_of(eval(e, f), e, "a variable array extent");
+      if (v < 0 || v > (1 << 24)) err(e, "variable array extent out of range");
+      V.dims.push_back((u32)v);
+    }
+    u32 n = 1;
+    for (u32 x : V.dims) n *= x;
+    V.v.assign(n, V.dims.empty() ? Val() : Val::num(0));
+    if (d->c.size() > 1) {
+      Val init = eval(d->c[1], f);
+      if (V.dims.empty()) V.v[0] = init;
+      else {
+        std::function<void(const Val&, u32, u32, size_t)> fill = [&](const Val& v, u32 flat, u32 count, size_t dim) {
+          if (dim == V.dims.size()) { V.v[flat] = v; return; }
+          if (v.k != V_ARR || v.arr.size() != V.dims[dim]) err(d, "array shape mismatch in the initialiser of " + d->s);
+          const u32 sub = count / V.dims[dim];
+          for (u32 i = 0; i < V.dims[dim]; ++i) fill(v.arr[i], flat + i * sub, sub, dim + 1);
+        };
+        fill(init, 0, n, 0);
+      }
+    } else if (V.dims.empty()) V.v[0] = Val::num(0);
+    f.vars[d->s] = std::move(V);
+  }
+  void create_component(Frame& f, CompArr& C, const std::string& cname, const std::vector<i64>& idx, Node* rhs) {
+    if (rhs->k != N_CALL || !templates.count(rhs->s)) err(rhs, "expected a template instantiation");
+    std::vector<i64> args;
+    for (Node* a : rhs->c) args.push_back(const_of(eval(a, f), a, "a template parameter"));
+    u32 rem, flat = flat_index(C.dims, idx, idx.size(), rem);
+    if (C.inst[flat]) err(rhs, "component " + cname + " created twice");
+    std::string name = cname;
+    for (i64 i : idx) name += "[" + std::to_string(i) + "]";
+    Inst* in = instantiate(rhs->s, args, name, f.inst, rhs);
+    C.inst[flat] = in;
+    maybe_run(in, rhs);
+  }
+  void exec(Node* n, Frame& f) {
+    switch (n->k) {
+      case S_NOP: case S_LOG: return;
+      case S_BLOCK: for (Node* s : n->c) exec(s, f); return;
+      case S_SIGNAL:
+        declare_signals(n, f, false);
+        for (Node* d : n->c) if (d->c.size() > 1) {
+          Ref r; r.kind = 2; r.inst = f.inst; r.sig = f.inst->sig_of[d->s];
+          if (d->c[2]->s == "<--") hint_assign(r, d->c[1], d, f);
+          else constrain_assign(r, eval(d->c[1], f), d, f);
+        }
+        return;
+      case S_VAR: for (Node* d : n->c) declare_var(d, f); return;
+      case S_COMP:
+        for (Node* d : n->c) {
+          if (f.inst->comps.count(d->s) || f.inst->sig_of.count(d->s)) err(d, d->s + " declared twice");
+          CompArr C;
+          for (Node* e : d->c[0]->c) {
+            i64 v = const_of(eval(e, f), e, "a component array extent");
+            if (v < 0 || v > (1 << 26)) err(e, "component array extent out of range");
+            C.dims.push_back((u32)v);
+          }
+          u32 cnt = 1;
+          for (u32 x : C.dims) cnt *= x;
+          C.inst.assign(cnt, nullptr);
+          f.inst->comps[d->s] = std::move(C);
+          if (d->c.size() > 1) create_component(f, f.inst->comps[d->s], d->s, {}, d->c[1]);
+        }
+        return;
+      case S_IF: {
+        const i64 c = const_of(eval(n->c[0], f), n, "the condition of if");
+        if (c) exec(n->c[1], f);
+        else if (n->c.size() > 2) exec(n->c[2], f);
+        return;
+      }
+      case S_FOR: {
+        exec(n->c[0], f);
+        f.loops.push_back(0);
+        u64 guard = 0;
+        while (const_of(eval(n->c[1], f), n, "the loop condition")) {
+          exec(n->c[3], f);
+          exec(n->c[2], f);
+          ++f.loops.back();
+          if (++guard > (1ull << 28)) err(n, "loop does not terminate");
+        }
+        f.loops.pop_back();
+        return;
+      }
+      case S_WHILE: {
+        f.loops.push_back(0);
+        u64 guard = 0;
+        while (const_of(eval(n->c[0], f), n, "the loop condition")) {
+          exec(n->c[1], f);
+          ++f.loops.back();
+          if (++guard > (1ull << 28)) err(n, "loop does not terminate");
+        }
+        f.loops.pop_back();
+        return;
+      }
+      case S_ASSERT: if (!const_of(eval(n->c[0], f), n, "an assert")) err(n, "assert failed while loading the template"); return;
+      case S_RET: err(n, "return outside a function");
+      case S_CONSTR: constrain(eval(n->c[0], f), eval(n->c[1], f), n); return;
+      case S_ASSIGN: {
+        Ref r = resolve(n->c[0], f);
+        const std::string& op = n->s;
+        if (r.kind == 3) {
+          if (op != "=") err(n, "components are created with =");
+          create_component(f, *r.comp, r.comp_name, r.idx, n->c[1]);
+          return;
+        }
+        if (r.kind == 2) {
+          if (op == "<==") constrain_assign(r, eval(n->c[1], f), n, f);
+          else if (op == "<--") {
+            hint_assign(r, n->c[1], n, f);
+            if (r.inst != f.inst) { SigArr& S = r.inst->sigs[r.sig]; if (S.kind == 1 && r.inst->pending) { --r.inst->pending; maybe_run(r.inst, n); } }
+          }
+          else err(n, "signals are assigned with <== or <--");
+          return;
+        }
+        // variable
+        if (r.idx.size() != r.var->dims.size()) {
+          if (op != "=") err(n, "compound assignment to an array");
+          Val v = eval(n->c[1], f);
+          u32 rem, flat = flat_index(r.var->dims, r.idx, r.idx.size(), rem);
+          std::function<void(const Val&, u32, u32, size_t)> fill = [&](const Val& x, u32 fl, u32 count, size_t dim) {
+            if (dim == r.var->dims.size()) { r.var->v[fl] = x; return; }
+            if (x.k != V_ARR || x.arr.size() != r.var->dims[dim]) err(n, "array shape mismatch");
+            const u32 sub = count / r.var->dims[dim];
+            for (u32 i = 0; i < r.var->dims[dim]; ++i) fill(x.arr[i], fl + i * sub, sub, dim + 1);
+          };
+          fill(v, flat, rem, r.idx.size());
+          return;
+        }
+        u32 rem, flat = flat_index(r.var->dims, r.idx, r.idx.size(), rem);
+        Val& dst = r.var->v[flat];
+        Val v = eval(n->c[1], f);
+        if (op == "=") { dst = v; return; }
+        if (dst.k == V_UNSET) err(n, "variable used before it is assigned");
+        if (op == "+=") { dst = v_add(dst, v, 1, n); return; }
+        if (op == "-=") { dst = v_add(dst, v, -1, n); return; }
+        if (op == "*=") { dst = v_mul(dst, v, n); return; }
+        Node tmp;
+        tmp.k = N_BIN; tmp.s = op.substr(0, op.size() - 1); tmp.line = n->line; tmp.file = n->file;
+        Node l, rr;
+        l.k = N_NUM; l.n = const_of(dst, n, "the variable"); rr.k = N_NUM; rr.n = const_of(v, n, "the operand");
+        tmp.c = {&l, &rr};
+        dst = eval(&tmp, f);
+        return;
+      }
+      default: err(n, "unsupported statement");
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------ lowering
+  void layout_walk(Inst* in, u32& next, std::vector<std::string>* names) {
+    const std::string p = path_of(in);
+    for (int kind = 0; kind < 3; ++kind)
+      for (auto& S : in->sigs) if (S.kind == kind)
+        for (u32 i = 0; i < S.size(); ++i) if (S.gate[i] >= 0) {
+          gates[S.gate[i]].slot = next++;
+          if (names) names->push_back(p + "." + S.name + (S.dims.empty() ? std::string() : "[" + std::to_string(i) + "]"));
+        }
+    for (Inst* s : in->subs) layout_walk(s, next, names);
+  }
+
+  void build(const std::string& path, const std::string& tname, const std::vector<i64>& args, Net& net) {
+    std::string text;
+    if (!read_file(path, text)) fail("cannot read " + path);
+    included.insert(base_of(path) + "#" + std::to_string(text.size()));
+    load_text(text, path, dir_of(path));
+    auto it = templates.find(tname);
+    if (it == templates.end()) fail(path + ": no template named " + tname);
+    Inst* top = instantiate(tname, args, "", nullptr, it->second.body);
+    // the message bytes
+    std::vector<u32> inputs;
+    for (u32 s = 0; s < top->sigs.size(); ++s) if (top->sigs[s].kind == 1) inputs.push_back(s);
+    if (inputs.size() != 1 || top->sigs[inputs[0]].dims.size() != 1) fail(tname + ": expected exactly one input signal array (the message bytes)");
+    SigArr& M = top->sigs[inputs[0]];
+    n_in = M.size();
+    in_lo.assign(n_in, 0); in_hi.assign(n_in, 255);
+    for (u32 i = 0; i < n_in; ++i) { M.val[i].t.emplace_back(SRC_INPUT | i, 1); M.set[i] = 1; }
+    top->pending = 0;
+    run(top, it->second.body);
+    // outputs
+    std::vector<const SigArr*> outs;
+    for (auto& S : top->sigs) if (S.kind == 0) outs.push_back(&S);
+    const SigArr* o_match = nullptr; const SigArr* o_reveal = nullptr;
+    for (const SigArr* S : outs) { if (S->dims.empty() && !o_match) o_match = S; else if (S->dims.size() == 1 && !o_reveal) o_reveal = S; }
+    if (!o_match || !o_reveal || o_reveal->size() != n_in) fail(tname + ": expected a scalar output (match) and an output array of the message length (reveal)");
+    std::vector<Lin> out_forms;
+    if (!o_match->set[0]) fail(tname + ": output " + o_match->name + " is not assigned");
+    out_forms.push_back(o_match->val[0]);
+    for (u32 i = 0; i < n_in; ++i) { if (!o_reveal->set[i]) fail(tname + ": output " + o_reveal->name + " is not fully assigned"); out_forms.push_back(o_reveal->val[i]); }
+    for (u32 i = 0; i < out_forms.size(); ++i) { Gate g; g.op = G_OUT; g.f[0] = out_forms[i]; g.out_index = i; add_gate(std::move(g), it->second.body); }
+    // every component must have run
+    for (auto& in : insts) if (!in.ran) fail("component " + path_of(&in) + " (" + in.tmpl->name + ") never received all its inputs");
+
+    // layout: kept signals in the compiler's numbering order (outputs, inputs, intermediates; sub-components in creation order)
+    u32 next = 0;
+    net.names.clear();
+    layout_walk(top, next, &net.names);
+    net.n_kept = next;
+    for (auto& g : gates) if (!g.owner && g.op != G_ASSERT && g.op != G_OUT) g.slot = next++;
+    legalize(next);
+    net.n_temp = next - net.n_kept;
+    net.n_in = n_in;
+    net.n_out = (u32)out_forms.size();
+    net.boolean.assign(net.n_kept, 0);
+    for (auto& g : gates) {
+      if (g.op == G_INV0) net.inv_need = std::max<u32>(net.inv_need, (u32)std::min<i64>(std::max<i64>(std::llabs(g.lo), std::llabs(g.hi)), 1 << 16));
+      if (g.slot < net.n_kept && g.op != G_INV0 && g.lo >= 0 && g.hi <= 1) net.boolean[g.slot] = 1;
+    }
+    if (next >= 0x1fffffffu) fail("the circuit is too large");
+    emit(net);
+  }
+
+  // Operand limits of a record (zkwg_net_core.h): a product has <= 2 + 2 + 4 terms (A, B, C), every other gate
+  // one sum of <= 8 terms; half of that when a coefficient does not fit 16 bits.  Longer sums are cut into partial
+  // sums (temporaries).  Terms are grouped by the level at which they become available, so that a partial sum is
+  // ready as early as possible (the 27-term sum of a MultiNOR over one byte's transitions costs no extra level).
+  void legalize(u32& next_slot) {
+    std::vector<Gate> old;
+    old.swap(gates);
+    std::vector<u32> remap(old.size(), 0), level;
+    auto lvl = [&](u32 src) { return (src & SRC_INPUT) ? 0u : level[src]; };
+    auto is_wide = [](const Lin& l) { for (auto& t : l.t) if (t.second < -32768 || t.second > 32767) return true; return false; };
+    auto push = [&](Gate&& g) {
+      u32 lv = 0;
+      const int nf = (g.op == G_QUAD || g.op == G_ASSERT) ? 3 : (g.op == G_NEZ ? 2 : 1);
+      for (int i = 0; i < nf; ++i) for (auto& t : g.f[i].t) lv = std::max(lv, lvl(t.first));
+      gates.push_back(std::move(g));
+      level.push_back(lv + 1);
+      return (u32)gates.size() - 1;
+    };
+    std::function<void(Lin&, u32, const Gate&)> shrink = [&](Lin& f, u32 limit, const Gate& like) {
+      while (f.t.size() > limit) {
+        std::stable_sort(f.t.begin(), f.t.end(), [&](const std::pair<u32, i64>& x, const std::pair<u32, i64>& y) { return lvl(x.first) < lvl(y.first); });
+        // one partial sum of the earliest terms
+        size_t take = std::min<size_t>(8, f.t.size() - limit + 1);
+        Lin part;
+        part.t.assign(f.t.begin(), f.t.begin() + take);
+        if (is_wide(part) && take > 4) { take = 4; part.t.resize(4); }
+        std::sort(part.t.begin(), part.t.end());
+        Gate pg;
+        pg.op = G_LIN; pg.f[0] = part; pg.at = like.at;
+        i64 lo, hi;
+        interval_of(part, lo, hi);
+        pg.lo = lo; pg.hi = hi;
+        pg.slot = next_slot++;
+        const u32 id = push(std::move(pg));
+        f.t.erase(f.t.begin(), f.t.begin() + take);
+        f.t.emplace_back(id, 1);
+      }
+      std::sort(f.t.begin(), f.t.end());
+    };
+    for (u32 gi = 0; gi < old.size(); ++gi) {
+      Gate g = std::move(old[gi]);
+      const int nf = (g.op == G_QUAD || g.op == G_ASSERT) ? 3 : (g.op == G_NEZ ? 2 : 1);
+      for (int i = 0; i < nf; ++i) {
+        for (auto& t : g.f[i].t) if (!(t.first & SRC_INPUT)) t.first = remap[t.first];
+        std::sort(g.f[i].t.begin(), g.f[i].t.end());
+      }
+      bool wide = false;
+      for (int i = 0; i < nf; ++i) wide = wide || is_wide(g.f[i]);
+      if (g.op == G_QUAD || g.op == G_ASSERT) {
+        shrink(g.f[0], wide ? 1 : 2, g); shrink(g.f[1], wide ? 1 : 2, g); shrink(g.f[2], wide ? 2 : 4, g);
+      } else shrink(g.f[0], wide ? 4 : 8, g);
+      remap[gi] = push(std::move(g));
+    }
+  }
+
+  // Evaluation schedule.  Gates are list-scheduled into chunks of mutually independent gates inside a sliding
+  // window (so the comparators of the next message byte fill the chunks of the current byte's state recurrence);
+  // a chunk is executed in steps of up to 64 gates, one per lane.  Where an operand lives is decided here, by
+  // simulating the evaluator's direct-mapped value cache: the cache (recent values) or a pinned region for values
+  // that are read long after they were produced (backward chains over the whole message).
+  void emit(Net& net) {
+    std::vector<u32> chunk_of(gates.size(), 0);
+    std::vector<std::vector<u32>> steps;
+    net.n_gates = (u32)gates.size();
+    auto nforms = [](const Gate& g) { return (g.op == G_QUAD || g.op == G_ASSERT) ? 3 : (g.op == G_NEZ ? 2 : 1); };
+    auto close = [&](std::vector<u32>& order) {
+      for (size_t b = 0; b < order.size(); b += 64) steps.emplace_back(order.begin() + b, order.begin() + std::min(order.size(), b + 64));
+      if (!order.empty()) ++net.n_chunks;
+    };
+    const u32 window = 6;
+    std::deque<std::vector<u32>> open;
+    u32 base = 1;
+    for (u32 gi = 0; gi < gates.size(); ++gi) {
+      const Gate& g = gates[gi];
+      u32 c = base;
+      for (int i = 0; i < nforms(g); ++i)
+        for (auto& t : g.f[i].t) if (!(t.first & SRC_INPUT)) c = std::max(c, chunk_of[t.first] + 1);
+      if (g.op == G_OUT) c = std::max<u32>(c, base + (u32)open.size());   // outputs last
+      while (c >= base + open.size()) open.emplace_back();
+      while (open.size() > window + 1) { close(open.front()); open.pop_front(); ++base; }
+      chunk_of[gi] = c;
+      open[c - base].push_back(gi);
+    }
+    while (!open.empty()) { close(open.front()); open.pop_front(); }
+    // LDS words by liveness: a value gets a word when it is produced and gives it back after its last reader
+    // (a step reads before it writes, so the word of a value last read in step t can be rewritten in step t).
+    // Values nobody reads (most kept signals: they only go to the witness) get no word at all.
+    std::vector<u32> step_of(gates.size(), 0), last_use(gates.size(), 0);
+    for (u32 t = 0; t < steps.size(); ++t) for (u32 gi : steps[t]) step_of[gi] = t;
+    std::vector<u8> used(gates.size(), 0);
+    for (u32 t = 0; t < steps.size(); ++t)
+      for (u32 gi : steps[t]) {
+        const Gate& g = gates[gi];
+        for (int i = 0; i < nforms(g); ++i)
+          for (auto& tm : g.f[i].t) if (!(tm.first & SRC_INPUT)) { used[tm.first] = 1; last_use[tm.first] = std::max(last_use[tm.first], t); }
+      }
+    std::vector<u32> word_of(gates.size(), 0xffffffffu), free_words;
+    std::vector<std::pair<u32, u32>> live;   // min-heap on (last use, word)
+    auto cmp = [](const std::pair<u32, u32>& x, const std::pair<u32, u32>& y) { return x.first > y.first; };
+    u32 hwm = 0;
+    for (u32 t = 0; t < steps.size(); ++t) {
+      while (!live.empty() && live.front().first <= t) { free_words.push_back(live.front().second); std::pop_heap(live.begin(), live.end(), cmp); live.pop_back(); }
+      for (u32 gi : steps[t]) {
+        if (!used[gi]) continue;
+        u32 w;
+        if (!free_words.empty()) { w = free_words.back(); free_words.pop_back(); } else w = hwm++;
+        word_of[gi] = w;
+        live.emplace_back(last_use[gi], w);
+        std::push_heap(live.begin(), live.end(), cmp);
+      }
+    }
+    // LDS words: [values | message bytes | 0 | scratch]
+    const u32 lds_msg = hwm, lds_zero = lds_msg + n_in, lds_dummy = lds_zero + 1;
+    net.n_pins = hwm;
+    net.lds_words = lds_dummy + 1;
+    if (net.lds_words > 16000) fail("the template keeps " + std::to_string(hwm) + " values alive at once; the evaluator's LDS image would exceed 64 KiB");
+    // records
+    net.records.clear(); net.step_count.clear();
+    auto span = [&](u32 src, i64& lo, i64& hi) { if (src & SRC_INPUT) { lo = in_lo[src & 0x1fffffffu]; hi = in_hi[src & 0x1fffffffu]; } else { lo = gates[src].lo; hi = gates[src].hi; } };
+    for (auto& st : steps) {
+      uint16_t general = 0, half = 0x4000;
+      for (u32 gi : st) {
+        const Gate& g = gates[gi];
+        const int nf = nforms(g);
+        bool wide = false;
+        for (int i = 0; i < nf; ++i) for (auto& t : g.f[i].t) wide = wide || t.second < -8191 || t.second > 8191;
+        // the 32-bit path of the evaluator is exact when the value intervals prove it: operands and results below
+        // 2^20 in magnitude, every sum of products below 2^30; everything else takes the 64-bit path
+        bool exact32 = !wide && g.op != G_ASSERT && g.op != G_OUT;
+        const i64 B20 = (i64)1 << 20;
+        __int128 mag[3] = {0, 0, 0};
+        for (int i = 0; i < nf && exact32; ++i) {
+          mag[i] = g.f[i].c0 < 0 ? -(__int128)g.f[i].c0 : g.f[i].c0;
+          for (auto& t : g.f[i].t) {
+            i64 lo, hi;
+            span(t.first, lo, hi);
+            const i64 m = std::max<i64>(std::llabs(lo), std::llabs(hi));
+            if (m >= B20) exact32 = false;
+            mag[i] += (__int128)(t.second < 0 ? -t.second : t.second) * m;
+          }
+          if (mag[i] >= ((__int128)1 << 30)) exact32 = false;
+        }
+        if (exact32 && g.op == G_QUAD && (mag[0] * mag[1] + mag[2] >= ((__int128)1 << 30) || mag[0] >= (1 << 23) || mag[1] >= (1 << 23))) exact32 = false;
+        if (exact32 && g.op == G_NEZ && (std::llabs(g.k) >= B20)) exact32 = false;
+        if (exact32 && g.op == G_BIT) { i64 lo, hi; interval_of(g.f[0], lo, hi); if (lo < 0) exact32 = false; }
+        if (exact32 && g.op == G_INV0 && std::max<i64>(std::llabs(g.lo), std::llabs(g.hi)) > (i64)net.inv_need) exact32 = false;
+        if (!exact32) { general = 0x8000; ++net.n_general; }
+        auto where = [&](u32 src) -> u32 {
+          if (src & SRC_INPUT) return lds_msg + (src & 0x1fffffffu);
+          if (word_of[src] == 0xffffffffu) fail("internal: operand without an LDS word");
+          return word_of[src];
+        };
+        u32 r[16] = {0};
+        r[0] = g.op | ((u32)(g.op == G_BIT ? g.k : 0) << 4) | (wide ? 1u << 9 : 0u);
+        r[1] = g.op == G_OUT ? g.out_index : (g.op == G_ASSERT ? 0u : g.slot);
+        r[2] = (u32)(int32_t)(g.op == G_NEZ ? g.k : 0);
+        r[3] = (g.op == G_OUT || g.op == G_ASSERT || g.op == G_INV0 || word_of[gi] == 0xffffffffu) ? lds_dummy : word_of[gi];
+        if (g.op == G_ASSERT) ++net.n_asserts;
+        // term slots: narrow 0,1 = A  2,3 = B  4..7 = C;  wide 0 = A  1 = B  2,3 = C;  a single sum fills them in order
+        std::vector<std::pair<u32, i64>> slots(wide ? 4 : 8, std::make_pair(lds_zero, (i64)0));
+        auto place = [&](const Lin& f, u32 first, u32 count) {
+          if (f.t.size() > count) fail("internal: operand limit exceeded");
+          for (size_t q = 0; q < f.t.size(); ++q) { slots[first + q] = std::make_pair(where(f.t[q].first), f.t[q].second); ++net.lds_hits; }
+        };
+        if (g.op == G_QUAD || g.op == G_ASSERT) {
+          place(g.f[0], 0, wide ? 1 : 2); place(g.f[1], wide ? 1 : 2, wide ? 1 : 2); place(g.f[2], wide ? 2 : 4, wide ? 2 : 4);
+          r[4] = (u32)(int32_t)g.f[0].c0; r[5] = (u32)(int32_t)g.f[1].c0; r[6] = (u32)(int32_t)g.f[2].c0;
+        } else {
+          place(g.f[0], 0, wide ? 4 : 8);
+          r[4] = (u32)(int32_t)g.f[0].c0;
+          if (g.op == G_NEZ) r[6] = (u32)(int32_t)g.f[1].c0;
+        }
+        for (size_t q = 4; q < slots.size(); ++q) if (slots[q].second != 0) half = 0;
+        for (size_t q = 0; q < slots.size(); ++q) {
+          if (wide) { r[8 + 2 * q] = slots[q].first; r[9 + 2 * q] = (u32)(int32_t)slots[q].second; }
+          else r[8 + q] = (slots[q].first << 2) | ((u32)(int32_t)slots[q].second << 18);   // LDS byte offset | coefficient
+        }
+        net.records.insert(net.records.end(), r, r + 16);
+      }
+      net.step_count.push_back((uint16_t)(st.size() | general | (general ? 0 : half)));
+    }
+    net.n_steps = (u32)steps.size();
+    while (net.step_count.size() % 64) net.step_count.push_back(0);   // the evaluator works in blocks of 64 steps
+    for (int i = 0; i < 64; ++i) net.step_count.push_back(0);         // (and looks one block ahead)
+    net.records.insert(net.records.end(), 64 * 16, 0u);   // the evaluator's lanes always load 64 records
+    if (net.records.size() >= 0xffffffffull) fail("the gate list is too large");
+  }
+};
+
+// circomlib 2.0.5 comparators / gates / bitify ([EXT], restated from their published definitions,
+// SURVEY.md Appendix A.1); used only when the include path does not supply the files.
+inline const char* Elab::builtin_source(const std::string& base) {
+  if (base == "comparators.circom") return R"CIRCOM(
+include "bitify.circom";
+template IsZero() {
+    signal input in;
+    signal output out;
+    signal inv;
+    inv <-- in!=0 ? 1/in : 0;
+    out <== -in*inv +1;
+    in*out === 0;
+}
+template IsEqual() {
+    signal input in[2];
+    signal output out;
+    component isz = IsZero();
+    in[1] - in[0] ==> isz.in;
+    isz.out ==> out;
+}
+template LessThan(n) {
+    assert(n <= 252);
+    signal input in[2];
+    signal output out;
+    component n2b = Num2Bits(n+1);
+    n2b.in <== in[0]+ (1<<n) - in[1];
+    out <== 1-n2b.out[n];
+}
+template LessEqThan(n) {
+    signal input in[2];
+    signal output out;
+    component lt = LessThan(n);
+    lt.in[0] <== in[0];
+    lt.in[1] <== in[1]+1;
+    lt.out ==> out;
+}
+template GreaterThan(n) {
+    signal input in[2];
+    signal output out;
+    component lt = LessThan(n);
+    lt.in[0] <== in[1];
+    lt.in[1] <== in[0];
+    lt.out ==> out;
+}
+template GreaterEqThan(n) {
+    signal input in[2];
+    signal output out;
+    component lt = LessThan(n);
+    lt.in[0] <== in[1];
+    lt.in[1] <== in[0]+1;
+    lt.out ==> out;
+}
+)CIRCOM";
+  if (base == "bitify.circom") return R"CIRCOM(
+template Num2Bits(n) {
+    signal input in;
+    signal output out[n];
+    var lc1=0;
+    var e2=1;
+    for (var i = 0; i<n; i++) {
+        out[i] <-- (in >> i) & 1;
+        out[i] * (out[i] -1 ) === 0;
+        lc1 += out[i] * e2;
+        e2 = e2+e2;
+    }
+    lc1 === in;
+}
+)CIRCOM";
+  if (base == "gates.circom") return R"CIRCOM(
+template XOR() {
+    signal input a;
+    signal input b;
+    signal output out;
+    out <== a + b - 2*a*b;
+}
+template AND() {
+    signal input a;
+    signal input b;
+    signal output out;
+    out <== a*b;
+}
+template OR() {
+    signal input a;
+    signal input b;
+    signal output out;
+    out <== a + b - a*b;
+}
+template NOT() {
+    signal input in;
+    signal output out;
+    out <== 1 + in - 2*in;
+}
+template NAND() {
+    signal input a;
+    signal input b;
+    signal output out;
+    out <== 1 - a*b;
+}
+template NOR() {
+    signal input a;
+    signal input b;
+    signal output out;
+    out <== a*b + 1 - a - b;
+}
+template MultiAND(n) {
+    signal input in[n];
+    signal output out;
+    component and1;
+    component and2;
+    component ands[2];
+    if (n==1) {
+        out <== in[0];
+    } else if (n==2) {
+        and1 = AND();
+        and1.a <== in[0];
+        and1.b <== in[1];
+        out <== and1.out;
+    } else {
+        and2 = AND();
+        var n1 = n\2;
+        var n2 = n-n\2;
+        ands[0] = MultiAND(n1);
+        ands[1] = MultiAND(n2);
+        var i;
+        for (i=0; i<n1; i++) ands[0].in[i] <== in[i];
+        for (i=0; i<n2; i++) ands[1].in[i] <== in[n1+i];
+        and2.a <== ands[0].out;
+        and2.b <== ands[1].out;
+        out <== and2.out;
+    }
+}
+)CIRCOM";
+  if (base == "binsum.circom" || base == "aliascheck.circom" || base == "compconstant.circom" || base == "sign.circom" ||
+      base == "mux1.circom")
+    return "\n";
+  return nullptr;
+}
+
+// Load `tname(args...)` from `path`; include directories separated by ':'.
+static inline bool load(const std::string& path, const std::string& include_dirs, const std::string& tname,
+                        const std::vector<i64>& args, Net& net, std::string& err) {
+  try {
+    Elab E;
+    std::stringstream ss(include_dirs);
+    std::string d;
+    while (std::getline(ss, d, ':')) if (!d.empty()) E.include_dirs.push_back(d);
+    E.build(path, tname, args, net);
+    return true;
+  } catch (Error& e) {
+    err = e.msg;
+    return false;
+  } catch (std::exception& e) {
+    err = e.what();
+    return false;
+  }
+}
+
+}  // namespace zkc

@@ -14,6 +14,7 @@ __global__ void zk_rsa(ZkSched s, ZkBufs B);         // zkwg_kernels_rsa.hip
 __global__ void zk_poseidon9(ZkSched s, ZkBufs B);   // zkwg_kernels_rsa.hip
 __global__ void zk_poseidon9_wave(ZkSched s, ZkBufs B);
 __global__ void zk_misc_ev(ZkSched s, ZkBufs B);     // zkwg_kernels_misc.hip
+__global__ void zk_net_eval(ZkSched s, ZkBufs B);    // zkwg_kernels_net.hip
 __global__ void zk_rslb_chunks(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip
 __global__ void zk_rslb_chain(ZkSched s, ZkBufs B);
 __global__ void zk_r1cs_check(const u64* row_ptr, const u32* wire, const Fr* coef, const u8* kind, u32 m,

@@ -439,6 +439,28 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
         }
         break;
       }
+      case ZSEG_NET: {
+        // gate values of a loaded regex template (zkwg_net_core.h): 31-bit signed integer, or the inverse
+        // of one (bit 31) from the table; a negative integer -m is the field element r - m
+        const int half_tab = (int)s.inv_half;
+        ZK_FOR_CHUNKS(c) {
+          const u32 w = small[sg.src + r0 + (c >> 1)];
+          const u32 hf = c & 1u;
+          int d = (int)(w << 1) >> 1;
+          uint4 v = zk_zero4();
+          if (w & 0x80000000u) {
+            d = max(-half_tab, min(half_tab, d));
+            pm = MONT; v = invtab[(u32)(d + half_tab) * 2 + hf];
+          } else if (d >= 0) {
+            if (!hf) v.x = (u32)d;
+          } else {
+            v = hf ? make_uint4(0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u)
+                   : make_uint4(0xf0000001u - (u32)(-d), 0x43e1f593u, 0x79b97091u, 0x2833e848u);
+          }
+          ZK_STORE(c, v);
+        }
+        break;
+      }
       default:
         break;
     }

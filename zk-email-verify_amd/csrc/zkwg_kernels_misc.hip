@@ -39,11 +39,20 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
   for (u32 i = lane; i < N; i += 64) { rev[i] = 0; hdr[i] = rec[s.fr[0].in_data + i]; }
   __syncthreads();
   const u32 start = *(const u32*)(rec + s.in_off[8]);  // bodyHashIndex
+  if (s.net_mode) {
+    // loaded template: zk_net_eval (launched before this kernel) left reveal0 and the match output in the image
+    for (u32 i = lane; i < N; i += 64) rev[i] = small[s.m_rev + i];
+    __syncthreads();
+  }
   if (lane == 0) {
-    // BodyHashRegex DFA scan (zkwg_regex_core.h): states, live chain, helper signals, reveal0
-    const u32 acc_count = zk_bh_dfa_scan(hdr, N, delta_l, stl, live, small + s.m_dfa_own, rev);
-    if (acc_count == 0) atomicAnd(&ok_sh, 0u);                      // bhRegexMatch === 1
-    small[s.m_dfa_acc] = acc_count;
+    if (s.net_mode) {
+      if (small[s.m_net_out] != 1u) atomicAnd(&ok_sh, 0u);          // bhRegexMatch === 1
+    } else {
+      // BodyHashRegex DFA scan (zkwg_regex_core.h): states, live chain, helper signals, reveal0
+      const u32 acc_count = zk_bh_dfa_scan(hdr, N, delta_l, stl, live, small + s.m_dfa_own, rev);
+      if (acc_count == 0) atomicAnd(&ok_sh, 0u);                    // bhRegexMatch === 1
+      small[s.m_dfa_acc] = acc_count;
+    }
     small[s.m_bh_idx] = start;
     bits[s.b_shift] = start;
     u32 blh = 0;
@@ -52,9 +61,9 @@ __global__ __launch_bounds__(64) void zk_misc_ev(ZkSched s, ZkBufs B) {
     if ((u64)start + 43 >= (1ull << s.sel_bits)) atomicAnd(&ok_sh, 0u);  // GreaterThan(bl) Num2Bits at i = 0
   }
   __syncthreads();
-  for (u32 i = lane; i < N; i += 64) small[s.m_rev + i] = rev[i];
+  if (!s.net_mode) for (u32 i = lane; i < N; i += 64) small[s.m_rev + i] = rev[i];
   // per-position words for zk_expand's ZSEG_DFA: in | st<<8 | nx<<16 | st_next<<24, class mask, prim mask
-  for (u32 i = lane; i < N + 2; i += 64) {
+  for (u32 i = lane; !s.net_mode && i < N + 2; i += 64) {
     const u32 b = i == 0 ? 255u : (i <= N ? hdr[i - 1] : 0u);
     const u32 st = stl[i];
     const u32 nx = (st && i <= N) ? ZKM_DELTA[st][b] : 255u;

@@ -1,0 +1,86 @@
+// zk_net_eval -- BodyHashRegex from a loaded circom template (zkwg_circom.h): one wavefront per email
+// walks the gate list, up to 64 gates (one per lane) per step; the gates of a step are mutually
+// independent and only read values of earlier steps.  Results go to the email's image (zk_expand's
+// ZSEG_NET streams them out) and, when a later gate reads them, to an LDS word the loader assigned by
+// liveness; an operand is an LDS offset, the image is write-only.  Steps whose records the loader proved
+// exact in 32 bits take a branch-free 32-bit path (zk_net_record32), the others the 64-bit one.  One
+// wavefront per SIMD is the normal occupancy (1,024 emails per prepare launch), so memory latency is
+// hidden by software pipelining: the 64-byte records are fetched ZKN_DEPTH steps ahead into a register ring.
+// Memory order: a wavefront's LDS accesses execute in program order and a step never needs a value of
+// its own step, so no barrier is required between steps.
+#include "zkwg_dev.h"
+#include "zkwg_kernels.h"
+#include "zkwg_net_core.h"
+
+#define ZKN_DEPTH 8
+
+__global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
+  const u32 e = blockIdx.x;
+  if (e >= B.n_emails) return;
+  const u32 lane = threadIdx.x;
+  extern __shared__ u32 dyn_lds[];
+  int* lds = (int*)dyn_lds;
+  const u32 msg_base = s.net_pins;     // [gate values | message bytes | 0 | scratch]
+  const u32 N = s.fr[0].max_bytes;
+  const u8* rec = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
+  for (u32 i = lane; i < N; i += 64) lds[msg_base + i] = (int)rec[i];
+  if (lane == 0) lds[msg_base + N] = 0;
+  const u32 scratch = msg_base + N + 1u;
+  __syncthreads();
+  u32* small = B.small + (u64)e * s.img_small;
+  u32* img = small + s.m_net;
+  const uint4* __restrict__ R = (const uint4*)B.net_records;
+  const unsigned short* __restrict__ CNT = B.net_counts;
+  const u32 nsteps = s.net_steps;
+  const long long inv_limit = (long long)s.inv_half;
+  bool ok = true;
+
+  // Register ring of records, ZKN_DEPTH steps ahead.  Steps come in blocks of 64 (the loader pads the last block
+  // with empty steps): the gate counts of a block sit in one VGPR (lane j = step j; bit 15 = the step holds a
+  // record for the general path, bit 14 = only the term slots 0..3 are used); the fetch side runs ZKN_DEPTH steps ahead and reads the next block's counts
+  // during the last ZKN_DEPTH steps of a block.
+  uint4 ring[ZKN_DEPTH][4];
+  u32 fetch_base = 0;                   // record index of the next step to fetch
+  const u32 nblocks = (nsteps + 63u) / 64u;
+  u32 cnt_cur = CNT[lane], cnt_next = nblocks > 1 ? CNT[64 + lane] : 0u;
+  // every lane loads (lanes past the step's count get records of later steps and are neutralised when executed):
+  // no control flow around the loads, so the compiler's s_waitcnt bookkeeping keeps the ring's distance
+  auto fetch = [&](u32 n, uint4* dst) {
+    const uint4* p = R + ((u64)fetch_base + lane) * 4;
+    dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2]; dst[3] = p[3];
+    fetch_base += n & 0x7fu;
+  };
+#pragma unroll
+  for (int d = 0; d < ZKN_DEPTH; ++d) fetch(__builtin_amdgcn_readlane(cnt_cur, d), ring[d]);
+  for (u32 blk = 0; blk < nblocks; ++blk) {
+    for (u32 j = 0; j < 64u / ZKN_DEPTH; ++j) {
+      const bool last = j == 64u / ZKN_DEPTH - 1u;
+#pragma unroll
+      for (int d = 0; d < ZKN_DEPTH; ++d) {
+        const u32 cn = __builtin_amdgcn_readlane(cnt_cur, j * ZKN_DEPTH + d);
+        const u32 n = cn & 0x7fu;
+        if (cn & 0x8000u) {
+          if (lane < n) {
+            const u32 r[16] = {ring[d][0].x, ring[d][0].y, ring[d][0].z, ring[d][0].w, ring[d][1].x, ring[d][1].y, ring[d][1].z, ring[d][1].w,
+                               ring[d][2].x, ring[d][2].y, ring[d][2].z, ring[d][2].w, ring[d][3].x, ring[d][3].y, ring[d][3].z, ring[d][3].w};
+            ok &= zk_net_record(r, lds, lds, img, small + s.m_net_out, small + s.m_rev, inv_limit);
+          }
+        } else {
+          // all 64 lanes run the record they hold; the lanes past the count write to scratch words
+          const bool act = lane < n;
+          const u32 r[16] = {ring[d][0].x, act ? ring[d][0].y : s.net_total, ring[d][0].z, act ? ring[d][0].w : scratch,
+                             ring[d][1].x, ring[d][1].y, ring[d][1].z, ring[d][1].w,
+                             ring[d][2].x, ring[d][2].y, ring[d][2].z, ring[d][2].w, ring[d][3].x, ring[d][3].y, ring[d][3].z, ring[d][3].w};
+          if (cn & 0x4000u) zk_net_record32<true>(r, lds, lds, img); else zk_net_record32<false>(r, lds, lds, img);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // refill this ring entry with the step ZKN_DEPTH ahead
+        const u32 fn = last ? __builtin_amdgcn_readlane(cnt_next, d) : __builtin_amdgcn_readlane(cnt_cur, (j + 1u) * ZKN_DEPTH + d);
+        fetch(fn, ring[d]);
+      }
+    }
+    cnt_cur = cnt_next;
+    cnt_next = blk + 2 < nblocks ? CNT[(u64)(blk + 2) * 64 + lane] : 0u;
+  }
+  if (__ballot(!ok) != 0ull && lane == 0) B.status[e] = 4;
+}

@@ -18,8 +18,10 @@
 #include <functional>
 #include "zkwg_sched.h"
 #include "zkwg_bh_dfa.h"
+#include "zkwg_circom.h"
 
 struct ZkWalker {
+  const zkc::Net* net = nullptr;   // BodyHashRegex loaded from a circom template (else the built-in zkwg v1 circuit)
   u64 cur = 0;        // next free slot (advanced by one/arr/skip)
   u64 seg_cur = 0;    // next slot not yet covered by a segment (advanced by seg)
   bool names = false; // emit names?
@@ -248,6 +250,15 @@ static inline void zk_walk_main_rsa(ZkWalker& w, ZkSched& s) {
 static inline void zk_alloc_bh_regex(ZkWalker& w, ZkSched& s, u32 N) {
   const u32 nb = N + 1;
   s.m_rev = w.alloc_small(N);
+  if (w.net) {   // loaded template: gate values (kept signals, then temporaries) + the match output
+    s.net_mode = 1;
+    s.net_kept = w.net->n_kept; s.net_total = w.net->n_kept + w.net->n_temp;
+    s.net_steps = w.net->n_steps; s.net_pins = w.net->n_pins; s.net_lds_words = w.net->lds_words;
+    s.m_net = w.alloc_small(s.net_total + 1);   // + a scratch word for the evaluator's idle lanes
+    s.m_net_out = w.alloc_small(1);
+    s.m_dfa_own = s.m_dfa_st = s.m_dfa_cm = s.m_dfa_pm = s.m_dfa_acc = 0;
+    return;
+  }
   s.m_dfa_own = w.alloc_small(2 * nb + ZK_DFA_NPUBLIC * N + N);
   s.m_dfa_st = w.alloc_small(nb + 1);
   s.m_dfa_cm = w.alloc_small(nb + 1);
@@ -256,6 +267,12 @@ static inline void zk_alloc_bh_regex(ZkWalker& w, ZkSched& s, u32 N) {
 }
 static inline void zk_walk_bh_regex(ZkWalker& w, const std::string& p, const ZkSched& s, u32 N) {
   const u32 nb = N + 1;
+  if (w.net) {   // the kept signals of the loaded template, in the compiler's numbering order (zkwg_circom.h layout_walk)
+    w.seg(ZSEG_NET, w.net->n_kept, s.m_net);
+    if (!w.names) w.skip(w.net->n_kept);
+    else for (u32 i = 0; i < w.net->n_kept; ++i) w.one(p + w.net->names[i]);
+    return;
+  }
   auto arr2 = [&](const std::string& base, u32 k, u32 n, const char* a, const char* b) {
     if (!w.names) { w.skip(2 * (u64)n); return; }
     for (u32 i = 0; i < n; ++i) {

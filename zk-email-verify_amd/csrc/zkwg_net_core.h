@@ -1,0 +1,98 @@
+// Gate-list evaluation of a loaded regex template (zkwg_circom.h): one gate record.
+//
+// Shared by the device kernel zk_net_eval and the host mirror used by the CPU tests.  Values are small
+// signed integers; a kept signal is stored in the image as a 31-bit two's-complement word, the inverse
+// hint of IsZero as the integer it inverts with bit 31 set (zk_expand's ZSEG_NET looks the inverse up).
+// Every operand is a word of the evaluator's LDS image [gate values | message bytes | 0 | scratch]; the
+// loader assigned the value words by liveness, the image in global memory is write-only.
+//
+// Record (16 words):  [0] op | k << 4 | wide << 9        [1] destination slot (output index for ZKN_OUT)
+//                     [2] aux (ZKN_NEZ factor)           [3] LDS word of the value (the scratch word if nobody reads it)
+//                     [4..6] constants c0A, c0B, c0C     [7] 0
+//                     [8..15] operand terms: narrow = 8 x (LDS byte offset | coefficient << 18), wide = 4 x (LDS word, coefficient)
+// Term roles:  narrow 0,1 -> A   2,3 -> B   4..7 -> C        wide 0 -> A   1 -> B   2,3 -> C
+//   ZKN_QUAD / ZKN_ASSERT:  A * B + C  (A = c0A + its terms ...)          every other op:  L = c0A + all terms
+//   ZKN_NEZ: aux * (L != 0) + c0C     ZKN_BIT: (L >> k) & 1     ZKN_INV0: the inverse of L (0 for 0)
+// Unused terms point at the zero word with coefficient 0.
+#pragma once
+#include "zkwg_fr.h"
+
+#define ZKN_VAL_INVERSE 0x80000000u
+enum ZkNetOp : u32 { ZKN_NOP = 0, ZKN_QUAD = 1, ZKN_INV0 = 2, ZKN_BIT = 3, ZKN_NEZ = 4, ZKN_LIN = 5, ZKN_ASSERT = 6, ZKN_OUT = 7 };
+
+ZK_HD int zk_net_decode(u32 w) { return (int)(w << 1) >> 1; }   // 31-bit two's complement
+
+// General path, exact in 64 bits: every record type.  `lds_r` / `lds`: the evaluator's LDS image for reads /
+// writes (the same memory on the device, where the 64 lanes of a step read before any of them writes; the
+// sequential host mirror reads a snapshot taken at the start of the step); `img`: the region in the email's image.
+// Returns false when an assertion of the template fails or a value leaves its range.
+ZK_HD bool zk_net_record(const u32* r, const int* lds_r, int* lds, u32* img, u32* out_match, u32* out_reveal, long long inv_limit) {
+  const u32 op = r[0] & 15u;
+  const bool wide = (r[0] >> 9) & 1u;
+  long long p[8];
+#pragma unroll
+  for (u32 t = 0; t < 8; ++t) {
+    u32 idx;
+    int cf;
+    if (wide) { idx = t < 4 ? r[8 + 2 * t] : 0u; cf = t < 4 ? (int)r[9 + 2 * t] : 0; }
+    else { idx = (r[8 + t] & 0x3ffffu) >> 2; cf = (int)r[8 + t] >> 18; }
+    p[t] = (long long)cf * lds_r[idx];
+  }
+  long long a, b, c;
+  if (wide) { a = p[0]; b = p[1]; c = p[2] + p[3]; }
+  else { a = p[0] + p[1]; b = p[2] + p[3]; c = (p[4] + p[5]) + (p[6] + p[7]); }
+  const long long L = (int)r[4] + a + b + c;
+  a += (int)r[4]; b += (int)r[5]; c += (int)r[6];
+  const u32 dst = r[1];
+  long long v = L;
+  bool ok = true;
+  if (op == ZKN_QUAD || op == ZKN_ASSERT) {
+    ok = a > -(1ll << 31) && a < (1ll << 31) && b > -(1ll << 31) && b < (1ll << 31);
+    v = a * b + c;
+  } else if (op == ZKN_NEZ) v = (L != 0 ? (long long)(int)r[2] : 0ll) + (int)r[6];
+  else if (op == ZKN_BIT) { ok = L >= 0; v = (L >> ((r[0] >> 4) & 31u)) & 1; }   // a negative operand is a 254-bit field element: Num2Bits rejects it
+  if (op == ZKN_NOP) return true;
+  if (op == ZKN_ASSERT) return ok && v == 0;
+  if (op == ZKN_OUT) {
+    if (dst == 0) *out_match = (u32)L; else out_reveal[dst - 1] = (u32)L;
+    return true;
+  }
+  if (op == ZKN_INV0) {
+    img[dst] = L == 0 ? 0u : (ZKN_VAL_INVERSE | ((u32)L & 0x7fffffffu));
+    return L >= -inv_limit && L <= inv_limit;   // the inverse table of zk_expand covers [-inv_half, inv_half]
+  }
+  ok = ok && v > -(1ll << 30) && v < (1ll << 30);
+  img[dst] = (u32)v & 0x7fffffffu;
+  lds[r[3]] = (int)v;
+  return ok;
+}
+
+// 32-bit path for the steps whose records the loader proved exact in 32 bits (value intervals): narrow terms,
+// ops QUAD / NEZ / BIT / LIN / INV0, no range checks left to make; all candidate values are computed and
+// selected, so the lanes of a step do not diverge.  Same arithmetic as zk_net_record.
+// (products of 24-bit operands: the loader bounds coefficients by 2^13, operand values by 2^20 and the factors
+// of a product by 2^23.)  HALF: the step uses the term slots 0..3 only.
+ZK_HD int zk_mul24(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __mul24(a, b);
+#else
+  return a * b;
+#endif
+}
+template <bool HALF>
+ZK_HD void zk_net_record32(const u32* r, const int* lds_r, int* lds, u32* img) {
+  const u32 op = r[0] & 15u;
+  int p[8];
+#pragma unroll
+  for (u32 t = 0; t < 8; ++t) p[t] = (HALF && t >= 4) ? 0 : zk_mul24((int)r[8 + t] >> 18, *(const int*)((const char*)lds_r + (r[8 + t] & 0x3ffffu)));
+  const int sa = p[0] + p[1], sb = p[2] + p[3], sc = (p[4] + p[5]) + (p[6] + p[7]);
+  const int L = (int)r[4] + sa + sb + sc;
+  const int a = sa + (int)r[4], b = sb + (int)r[5], c = sc + (int)r[6];
+  const int vq = zk_mul24(a, b) + c;
+  const int vn = (L != 0 ? (int)r[2] : 0) + (int)r[6];
+  const int vb = (L >> ((r[0] >> 4) & 31u)) & 1;
+  const int v = op == ZKN_QUAD ? vq : (op == ZKN_NEZ ? vn : (op == ZKN_BIT ? vb : L));
+  const bool inv = op == ZKN_INV0;
+  img[r[1]] = inv ? (L == 0 ? 0u : (ZKN_VAL_INVERSE | ((u32)L & 0x7fffffffu))) : ((u32)v & 0x7fffffffu);
+  lds[r[3]] = v;   // (the scratch word for ZKN_INV0 and for values nobody reads)
+}

@@ -50,7 +50,8 @@ enum ZkSegType : u32 {
   ZSEG_IN8MASK = 17,// ByteMask: in[src + r] * in[a + r]   (data byte times mask byte)
   ZSEG_RSLB = 18,   // RemoveSoftLineBreaks byte-derived arrays over in[src ..]: a = ZkRslbKind, b/c = parameters
   ZSEG_HOLE = 19,   // signals this schedule does not produce: left to the linear completion pass (zkwg_full.h)
-  ZSEG_NTYPES = 20
+  ZSEG_NET = 20,    // gate values of a loaded regex template (zkwg_circom.h): slot r = decode(small[src + r]): 31-bit signed integer, or its inverse (bit 31)
+  ZSEG_NTYPES = 21
 };
 
 // ZSEG_RSLB kinds (helpers/remove-soft-line-breaks.circom:14-126); enc = the emailBody bytes at src
@@ -180,6 +181,15 @@ struct ZkSched {
   u32 m_dfa_pm;          // small: per position, primitive-test truth mask of in[i]
   u32 m_dfa_own;         // small: live_c1[nb], live_t[nb], prev_states0[NP][N], is_reveal0[N]
   u32 m_dfa_acc;         // small: number of positions in the accept state
+  // BodyHashRegex loaded from a circom template (zkwg_circom.h): gate list evaluated by zk_net_eval
+  u32 net_mode;          // 1: the regex circuit comes from a loaded template (the m_dfa_* fields are unused)
+  u32 m_net;             // small: gate values, kept signals first (net_kept), then temporaries
+  u32 m_net_out;         // small: the template's scalar output (bhRegexMatch)
+  u32 net_kept;          // kept signals (= witness slots of the region)
+  u32 net_total;         // kept + temporaries
+  u32 net_steps;         // 64-record steps of the gate list
+  u32 net_pins;          // zk_net_eval's LDS image: words holding gate values (then the message bytes, a zero, a scratch word)
+  u32 net_lds_words;     // zk_net_eval's LDS image: total words
   // RemoveSoftLineBreaks(max_body) (template flag removeSoftLineBreaks, email-verifier.circom:148-156)
   u32 rslb;              // 1: present
   u32 rs_nch;            // 2 * max_body / 16 Poseidon(16) chunks of PoseidonModular(2 * max_body)
@@ -224,6 +234,8 @@ struct ZkBufs {
   const Fr* pos16;       // Poseidon(16) sparse-round table (zkwg_poseidon_sparse.h), removeSoftLineBreaks only
   const Fr* pos2;        // Poseidon(2)  sparse-round table
   const Fr* invtab_m;    // zk_expand_mont: the inverse table in Montgomery form
+  const u32* net_records; // loaded regex template: 16 words per gate in execution order (zkwg_net_core.h)
+  const unsigned short* net_counts;   // loaded regex template: gates per step | flags
   const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
   const ZkSeg* segs;     // segment table
   const u32* first_seg;  // first segment overlapping each portion

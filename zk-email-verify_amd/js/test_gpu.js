@@ -101,5 +101,24 @@ function shaPad(msg, max) {  // packages/helpers/src/sha-utils.ts:88-111
       assert.strictEqual(m3.table[i].shaLo.toString(), kase.shaLo);
     }
   }
+  // ---- BodyHashRegex compiled from a template file (zkwg_circuit_create_regex): the stand-in for zk-regex's
+  // body_hash_regex.circom describes the same circuit as the built-in one, so every signal must agree by name
+  {
+    const fs = require('fs');
+    const path = require('path');
+    const kase = JSON.parse(fs.readFileSync(path.join(__dirname, '..', '..', 'tests', 'golden', 'ev_576_192_case.json')));
+    const tmpl = path.join(__dirname, '..', '..', 'oracle', 'circom', 'lib', '@zk-email', 'zk-regex-circom', 'circuits', 'common', 'body_hash_regex.circom');
+    const ev0 = new z.Circuit({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody }, 0);
+    const ev1 = new z.Circuit({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody, regex: tmpl }, 0);
+    assert.strictEqual(ev1.witnessLen, ev0.witnessLen);
+    const w0 = await new z.WitnessCalculator(ev0).calculateWitness(kase.input);
+    const w1 = await new z.WitnessCalculator(ev1).calculateWitness(kase.input);
+    const s0 = z.symbols(ev0), s1 = z.symbols(ev1);   // names[slot]
+    const byName = new Map();
+    for (let i = 1; i < s0.length; ++i) byName.set(s0[i], w0[i]);
+    assert.strictEqual(s1.length, kase.witnessLen);
+    for (let i = 1; i < s1.length; ++i) assert.strictEqual(w1[i], byName.get(s1[i]), s1[i]);
+    assert.throws(() => new z.Circuit({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody, regex: tmpl + '.missing' }, 0), /regex template/);
+  }
   console.log('js gpu ok');
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -28,7 +28,9 @@ function norm(v) {
 class Circuit {
   /** opts: {mainKind, maxHeader, maxBody, n, k, ignoreBodyHashCheck, enableHeaderMasking, enableBodyMasking, removeSoftLineBreaks, sym, symAlias}
    *  sym: text of the compiled circuit's `.sym` file -> the witness follows its indices (zkwg_circuit_create_sym);
-   *  r1cs: Buffer with its `.r1cs` -> complete witness of an --O0 / --O1 build (zkwg_circuit_create_full); device < 0 = layout-only handle */
+   *  r1cs: Buffer with its `.r1cs` -> complete witness of an --O0 / --O1 build (zkwg_circuit_create_full); device < 0 = layout-only handle;
+   *  regex (+ regexIncludeDirs, regexTemplate): path of a zk-regex style `body_hash_regex.circom` -> BodyHashRegex is compiled
+   *  from the template text instead of zkwg's built-in circuit (zkwg_circuit_create_regex) */
   constructor(opts, device) {
     this.opts = Object.assign({ mainKind: MAIN_EMAIL_VERIFIER, maxHeader: 1024, maxBody: 1536, n: 121, k: 17, ignoreBodyHashCheck: 0, enableHeaderMasking: 0, enableBodyMasking: 0, removeSoftLineBreaks: 0 }, opts || {});
     this.handle = addon.createCircuit(this.opts, device === undefined ? 0 : device);

@@ -68,10 +68,21 @@ static napi_value CreateCircuit(napi_env env, napi_callback_info info) {
         napi_get_named_property(env, argv[0], "r1cs", &v) == napi_ok && napi_is_buffer(env, v, &isbuf) == napi_ok && isbuf)
       napi_get_buffer_info(env, v, &r1cs, &r1cs_len);
   }
-  int rc = sym ? (r1cs ? zkwg_circuit_create_full(&cfg, device, sym, sym_len, alias, alias_len, (const uint8_t*)r1cs, r1cs_len, &c)
-                       : zkwg_circuit_create_sym(&cfg, device, sym, sym_len, alias, alias_len, &c))
-               : zkwg_circuit_create(&cfg, device, &c);
-  free(sym); free(alias);
+  /* optional `regex` (path of a zk-regex style body_hash_regex.circom), `regexIncludeDirs` (':'-separated),
+   * `regexTemplate`: BodyHashRegex is compiled from the template text (zkwg_circuit_create_regex) */
+  char* regex = NULL; size_t regex_len = 0; char* rdirs = NULL; size_t rdirs_len = 0; char* rtmpl = NULL; size_t rtmpl_len = 0;
+  get_str(env, argv[0], "regex", &regex, &regex_len);
+  get_str(env, argv[0], "regexIncludeDirs", &rdirs, &rdirs_len);
+  get_str(env, argv[0], "regexTemplate", &rtmpl, &rtmpl_len);
+  int rc;
+  if (regex) {
+    zkwg_regex_source src = {regex, rdirs, rtmpl};
+    rc = zkwg_circuit_create_regex(&cfg, device, &src, sym, sym_len, alias, alias_len, (const uint8_t*)r1cs, r1cs_len, &c);
+  } else
+    rc = sym ? (r1cs ? zkwg_circuit_create_full(&cfg, device, sym, sym_len, alias, alias_len, (const uint8_t*)r1cs, r1cs_len, &c)
+                     : zkwg_circuit_create_sym(&cfg, device, sym, sym_len, alias, alias_len, &c))
+             : zkwg_circuit_create(&cfg, device, &c);
+  free(sym); free(alias); free(regex); free(rdirs); free(rtmpl);
   if (rc != ZKWG_RC_OK) {
     char msg[512];
     snprintf(msg, sizeof(msg), "%s%s%s", zkwg_strerror(rc), rc == ZKWG_RC_BAD_CONFIG ? ": " : "", rc == ZKWG_RC_BAD_CONFIG ? zkwg_last_error() : "");

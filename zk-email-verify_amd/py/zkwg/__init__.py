@@ -55,8 +55,12 @@ class Circuit:
 
     def __init__(self, main_kind=MAIN_EMAIL_VERIFIER, max_header=1024, max_body=1536, n=121, k=17,
                  ignore_body_hash_check=0, device=0, enable_header_masking=0, enable_body_masking=0,
-                 remove_soft_line_breaks=0, sym=None, sym_alias=None, r1cs=None):
-        """sym: text of the compiled circuit's `.sym` file -> the witness follows ITS indices
+                 remove_soft_line_breaks=0, sym=None, sym_alias=None, r1cs=None, regex=None, regex_include_dirs=(),
+                 regex_template=None):
+        """regex: path of a zk-regex style template (`body_hash_regex.circom`): BodyHashRegex is compiled from that
+        file instead of zkwg's built-in DFA circuit (zkwg_circuit_create_regex; regex_include_dirs: where its
+        includes are searched; regex_template: template name, default BodyHashRegex).
+        sym: text of the compiled circuit's `.sym` file -> the witness follows ITS indices
         (zkwg_circuit_create_sym); sym_alias: optional "ours=theirs" rename rules, one per line;
         r1cs: bytes of the compiled circuit's `.r1cs` -> complete witness of a circuit compiled with
         --O0 / --O1: signals the schedule does not produce are derived from its linear constraints
@@ -65,7 +69,15 @@ class Circuit:
         self.cfg = Config(main_kind, max_header, max_body, n, k, ignore_body_hash_check, enable_header_masking,
                           enable_body_masking, remove_soft_line_breaks, 0)
         h = C.c_void_p()
-        if sym is None:
+        if regex is not None:
+            src = _lib.RegexSource(str(regex).encode(), ":".join(str(d) for d in regex_include_dirs).encode(),
+                                   regex_template.encode() if regex_template else None)
+            sb = None if sym is None else (sym.encode() if isinstance(sym, str) else bytes(sym))
+            ab = None if sym_alias is None else (sym_alias.encode() if isinstance(sym_alias, str) else bytes(sym_alias))
+            rb = None if r1cs is None else bytes(r1cs)
+            rc = self.lib.zkwg_circuit_create_regex(C.byref(self.cfg), device, C.byref(src), sb, len(sb) if sb else 0,
+                                                    ab, len(ab) if ab else 0, rb, len(rb) if rb else 0, C.byref(h))
+        elif sym is None:
             rc = self.lib.zkwg_circuit_create(C.byref(self.cfg), device, C.byref(h))
         else:
             sb = sym.encode() if isinstance(sym, str) else bytes(sym)
@@ -86,6 +98,13 @@ class Circuit:
         self.witness_bytes = self.lib.zkwg_witness_bytes(h)
         self.n_public = self.lib.zkwg_num_public(h)
         self.in_stride = self.lib.zkwg_input_stride(h)
+
+    def regex_info(self):
+        """loaded regex template: gate-list statistics (zkwg_regex_info)"""
+        out = (C.c_uint64 * 8)()
+        _check(self.lib.zkwg_regex_info(self.h, out))
+        keys = ("kept", "temporaries", "gates", "asserts", "chunks", "steps", "lds_value_words", "gates_64bit")
+        return dict(zip(keys, [int(x) for x in out]))
 
     def close(self):
         if getattr(self, "h", None):

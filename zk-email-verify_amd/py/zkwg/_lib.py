@@ -10,6 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libzkwg.so"))
 
 
+class RegexSource(C.Structure):   # zkwg_regex_source
+    _fields_ = [("circom_path", C.c_char_p), ("include_dirs", C.c_char_p), ("template_name", C.c_char_p)]
+
+
 class Config(C.Structure):
     _fields_ = [
         ("main_kind", C.c_uint32),
@@ -62,6 +66,8 @@ def load():
         "zkwg_circuit_create": (i32, [C.POINTER(Config), i32, C.POINTER(vp)]),
         "zkwg_circuit_create_sym": (i32, [C.POINTER(Config), i32, C.c_char_p, u64, C.c_char_p, u64, C.POINTER(vp)]),
         "zkwg_circuit_create_full": (i32, [C.POINTER(Config), i32, C.c_char_p, u64, C.c_char_p, u64, vp, u64, C.POINTER(vp)]),
+        "zkwg_circuit_create_regex": (i32, [C.POINTER(Config), i32, C.POINTER(RegexSource), C.c_char_p, u64, C.c_char_p, u64, vp, u64, C.POINTER(vp)]),
+        "zkwg_regex_info": (i32, [vp, vp]),
         "zkwg_linear_rows": (u64, [vp]),
         "zkwg_layout_map": (u64, [vp, vp, u64]),
         "zkwg_image_layout": (i32, [vp, u64, vp]),
@@ -120,7 +126,7 @@ def load():
 
 
 EXPORTS = [
-    "zkwg_abi_version", "zkwg_strerror", "zkwg_circuit_create", "zkwg_circuit_create_sym", "zkwg_circuit_create_full", "zkwg_linear_rows", "zkwg_layout_map", "zkwg_image_layout", "zkwg_segment_table", "zkwg_inverse_table_half", "zkwg_linear_complete_host", "zkwg_last_error", "zkwg_circuit_destroy",
+    "zkwg_abi_version", "zkwg_strerror", "zkwg_circuit_create", "zkwg_circuit_create_sym", "zkwg_circuit_create_full", "zkwg_circuit_create_regex", "zkwg_regex_info", "zkwg_linear_rows", "zkwg_layout_map", "zkwg_image_layout", "zkwg_segment_table", "zkwg_inverse_table_half", "zkwg_linear_complete_host", "zkwg_last_error", "zkwg_circuit_destroy",
     "zkwg_witness_len", "zkwg_witness_bytes", "zkwg_num_public", "zkwg_input_stride",
     "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_pack_input", "zkwg_pack_field", "zkwg_pack_masks", "zkwg_pack_decoded_body", "zkwg_calculate_batch",
     "zkwg_generate_inputs_device", "zkwg_alloc_pinned", "zkwg_free_pinned", "zkwg_calculate_batch_device", "zkwg_prepare_device", "zkwg_expand_device", "zkwg_expand_montgomery_device", "zkwg_set_prepare_throttle", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_timing_summary", "zkwg_num_kernels",
