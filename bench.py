@@ -371,6 +371,28 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         torch.cuda.empty_cache()
     except Exception as e:
         out["Montgomery-form output (fused hand-off)"] = {"error": repr(e)[:200]}
+    # BodyHashRegex compiled from a template file instead of the built-in DFA circuit (zkwg_circuit_create_regex,
+    # DESIGN.md section 18): the stand-in for zk-regex's generated body_hash_regex.circom shipped with the package
+    try:
+        tmpl = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zk-email-verify_amd", "data", "templates",
+                            "zk-regex-circom", "circuits", "common", "body_hash_regex.circom")
+        if not args.regex and os.path.exists(tmpl):
+            cr = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank, regex=tmpl)
+            _, d_in, _ = resident_inputs(torch, cr, dev, 0x5A4B + 505, 64, 4096, args.body_len)
+            pl = Pipeline(torch, cr, dev, d_in, 4096, 512, 2048, ring=2, rsa_throttle=args.rsa_throttle)
+            cr.set_timing(True)
+            dt = timed(torch, pl.step, steps=2, warmup=1)
+            summ = cr.timing_summary()
+            cr.set_timing(False)
+            assert int(pl.d_status.abs().sum().item()) == 0
+            out["BodyHashRegex compiled from the template file"] = {
+                "value": round(4096 * 2 / dt, 1), "unit": "witnesses/s", "steps": 2,
+                "zk_net_eval_ms_per_2048_emails": round(summ["zk_net_eval"][0] / max(summ["zk_net_eval"][1], 1), 3),
+                "gate_list": cr.regex_info()}
+            del pl, d_in, cr
+            torch.cuda.empty_cache()
+    except Exception as e:
+        out["BodyHashRegex compiled from the template file"] = {"error": repr(e)[:200]}
     # delivered to host (PCIe-inclusive): zkwg_calculate_batch with a pinned destination, double-buffered tiles
     try:
         n, t = 192, 64

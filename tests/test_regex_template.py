@@ -93,6 +93,13 @@ def test_stand_in_template_through_the_product_loader_equals_the_interpreter():
     assert all(ref2["main" + k] == v for k, v in vals.items())
 
 
+def test_product_side_copy_of_the_stand_in_is_current():
+    base = os.path.join(ROOT, "zk-email-verify_amd", "data", "templates", "zk-regex-circom", "circuits")
+    lib = os.path.dirname(os.path.dirname(STAND_IN))
+    for rel in ("regex_helpers.circom", os.path.join("common", "body_hash_regex.circom")):
+        assert open(os.path.join(base, rel)).read() == open(os.path.join(lib, rel)).read(), rel
+
+
 def test_loaded_stand_in_names_equal_the_built_in_schedule():
     import zkwg
     c0 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=-1)
