@@ -1349,11 +1349,9 @@ struct Elab {
     std::vector<std::vector<u32>> steps;
     net.n_gates = (u32)gates.size();
     auto nforms = [](const Gate& g) { return (g.op == G_QUAD || g.op == G_ASSERT) ? 3 : (g.op == G_NEZ ? 2 : 1); };
-    auto close = [&](std::vector<u32>& order) {
-      for (size_t b = 0; b < order.size(); b += 64) steps.emplace_back(order.begin() + b, order.begin() + std::min(order.size(), b + 64));
-      if (!order.empty()) ++net.n_chunks;
-    };
-    const u32 window = 6;
+    // list scheduling straight into steps of <= 64 gates: a gate goes to the earliest open step after all its operands
+    // that still has a free lane; `window` + 1 steps stay open, older ones are closed in order
+    const u32 window = 12;
     std::deque<std::vector<u32>> open;
     u32 base = 1;
     for (u32 gi = 0; gi < gates.size(); ++gi) {
@@ -1362,12 +1360,22 @@ struct Elab {
       for (int i = 0; i < nforms(g); ++i)
         for (auto& t : g.f[i].t) if (!(t.first & SRC_INPUT)) c = std::max(c, chunk_of[t.first] + 1);
       if (g.op == G_OUT) c = std::max<u32>(c, base + (u32)open.size());   // outputs last
-      while (c >= base + open.size()) open.emplace_back();
-      while (open.size() > window + 1) { close(open.front()); open.pop_front(); ++base; }
+      for (;;) {
+        while (c >= base + open.size()) open.emplace_back();
+        if (open[c - base].size() < 64) break;
+        ++c;
+      }
       chunk_of[gi] = c;
       open[c - base].push_back(gi);
+      while (open.size() > window + 1) { steps.push_back(std::move(open.front())); open.pop_front(); ++base; }
     }
-    while (!open.empty()) { close(open.front()); open.pop_front(); }
+    while (!open.empty()) { steps.push_back(std::move(open.front())); open.pop_front(); }
+    {
+      std::vector<std::vector<u32>> nonempty;
+      for (auto& st : steps) if (!st.empty()) nonempty.push_back(std::move(st));
+      steps.swap(nonempty);
+    }
+    net.n_chunks = (u32)steps.size();
     // LDS words by liveness: a value gets a word when it is produced and gives it back after its last reader
     // (a step reads before it writes, so the word of a value last read in step t can be rewritten in step t).
     // Values nobody reads (most kept signals: they only go to the witness) get no word at all.
