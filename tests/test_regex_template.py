@@ -235,3 +235,142 @@ def test_gpu_zk_regex_style_template_region_equals_the_interpreter():
         assert len(region) == c.regex_info()["kept"]
         bad = [n for n, v in region.items() if int.from_bytes(v, "little") != ref["main" + n[len("main.anon_BodyHashRegex"):]]]
         assert not bad, (e, len(bad), bad[:5])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Differential fuzz: random templates in the supported subset, product loader + evaluator vs the interpreter
+def _fuzz_template(rng, n):
+    """-> circom text of `template Fuzz(msg_bytes)` (one input array, a scalar and an array output)."""
+    L = ['pragma circom 2.1.5;', 'include "./helpers.circom";', '',
+         'function twice_plus(x, y) { var r = 2 * x; r += y; return r; }', '',
+         'template Fuzz(msg_bytes) {', '    signal input msg[msg_bytes];', '    signal output out;']
+    bools, bytes_, k = [], [f"msg[{i}]" for i in range(n)], [0]
+
+    def fresh(p):
+        k[0] += 1
+        return f"{p}{k[0]}"
+
+    def lin_bool():
+        a = rng.choice(bools)
+        return a if rng.random() < 0.6 else f"(1 - {a})"
+
+    for _ in range(rng.randrange(10, 24)):
+        kind = rng.choice(["eq", "lt", "isz", "and", "or", "quad", "mor", "lin", "not", "nor"] if bools else ["eq", "lt", "isz"])
+        if kind == "eq":
+            c = fresh("eq")
+            b = rng.choice(bytes_)
+            other = str(rng.choice([0, 97, 255, rng.randrange(256)])) if rng.random() < 0.7 else rng.choice(bytes_)
+            L += [f"    component {c} = IsEqual();", f"    {c}.in[0] <== {b};", f"    {c}.in[1] <== {other};"]
+            bools.append(f"{c}.out")
+        elif kind == "lt":
+            c = fresh("lt")
+            t = rng.choice(["LessThan", "LessEqThan", "GreaterThan", "GreaterEqThan"])
+            bits = rng.choice([7, 8, 9, 12])   # 7: Num2Bits(8) rejects operands from 128 up -> assertion paths
+            a, b = rng.choice(bytes_), (str(rng.randrange(256)) if rng.random() < 0.6 else rng.choice(bytes_))
+            if rng.random() < 0.5:
+                a, b = b, a
+            L += [f"    component {c} = {t}({bits});", f"    {c}.in[0] <== {a};", f"    {c}.in[1] <== {b};"]
+            bools.append(f"{c}.out")
+        elif kind == "isz":
+            c = fresh("iz")
+            a, b = rng.choice(bytes_), rng.choice(bytes_)
+            L += [f"    component {c} = IsZero();", f"    {c}.in <== {a} - {b} + {rng.choice([0, 0, 1, -3])};"]
+            bools.append(f"{c}.out")
+        elif kind in ("and", "or"):
+            s = fresh("g")
+            T = "AND" if kind == "and" else rng.choice(["OR", "XOR", "NAND"])
+            L.append(f"    signal {s} <== {T}()({lin_bool()}, {lin_bool()});")
+            bools.append(s)
+        elif kind == "not":
+            s = fresh("nt")
+            L.append(f"    signal {s} <== NOT()({rng.choice(bools)});")
+            bools.append(s)
+        elif kind == "quad":
+            s = fresh("q")
+            L.append(f"    signal {s} <== {lin_bool()} * {lin_bool()} + {rng.choice(['0', lin_bool() + ' - ' + lin_bool() + ' * 0'])};")
+            if rng.random() < 0.5:
+                r = fresh("rb")
+                L.append(f"    signal {r} <== {rng.choice(bytes_)} * {s};")
+                bytes_.append(r)
+        elif kind == "mor":
+            m = rng.randrange(2, 41)
+            s = fresh("mo")
+            items = ", ".join(rng.choice(bools) if rng.random() < 0.8 else f"{rng.choice(bools)} * {rng.choice(bools)}" for _ in range(m))
+            L.append(f"    signal {s} <== {rng.choice(['MultiOR', 'MultiNOR'])}({m})([{items}]);")
+            bools.append(s)
+        elif kind == "nor":
+            s = fresh("oa")
+            L.append(f"    signal {s} <== ORAnd()([{lin_bool()}, {lin_bool()}, {lin_bool()}]);")
+            bools.append(s)
+        elif kind == "lin":
+            s = fresh("l")
+            L.append(f"    signal {s} <== {rng.choice(bools)} + twice_plus(1, 0) * {rng.choice(bools)} - {rng.choice(bools)} + {rng.randrange(4)};")
+    # a recurrence over the message (component arrays, loop-indexed anonymous components)
+    c0, c1 = rng.randrange(256), rng.randrange(97, 101)
+    L += ["    signal st[msg_bytes + 1];", "    st[0] <== 0;", "    component hit[msg_bytes];", "    signal run[msg_bytes];",
+          "    for (var i = 0; i < msg_bytes; i++) {", "        hit[i] = IsEqual();", "        hit[i].in[0] <== msg[i];",
+          f"        hit[i].in[1] <== {c1};",
+          f"        run[i] <== OR()(st[i] * hit[i].out, IsEqual()([msg[i], {c0}]));",
+          "        st[i + 1] <== run[i];", "    }",
+          f"    out <== MultiOR(msg_bytes + {len(bools[:3])})([{', '.join(['st[' + str(i + 1) + ']' for i in range(n)] + bools[:3])}]);",
+          "    signal output reveal0[msg_bytes];", "    for (var i = 0; i < msg_bytes; i++) {",
+          f"        reveal0[i] <== msg[i] * {rng.choice(['run[i]', 'st[i]', '(1 - run[i])'])};", "    }", "}"]
+    return "\n".join(L) + "\n"
+
+
+def test_random_templates_product_loader_equals_the_interpreter(tmp_path):
+    import shutil
+    from oracle.circom.runtime import AssertFailed
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "regex_style", "helpers.circom"), tmp_path / "helpers.circom")
+    rng = random.Random(20260925)
+    n_fail = 0
+    for case in range(12):
+        n = rng.choice([3, 8, 17])
+        f = tmp_path / f"fuzz{case}.circom"
+        f.write_text(_fuzz_template(rng, n))
+        R = hosttest.LoadedRegex(str(f), n, template="Fuzz")
+        for trial in range(3):
+            msg = bytes(rng.choice([0, 97, 98, 99, 100, 255, rng.randrange(256)]) for _ in range(n))
+            try:
+                ref, kept, root = _interpret(str(f), "Fuzz", n, msg, symbolic=(trial == 0))
+            except AssertFailed:
+                ok, _, _, _ = R.evaluate(msg)
+                assert not ok, (case, trial)
+                n_fail += 1
+                continue
+            ok, vals, match, rev = R.evaluate(msg)
+            assert ok, (case, trial)
+            if kept is not None:
+                assert {"main" + q for q in vals} == kept, (case, sorted(kept ^ {"main" + q for q in vals})[:5])
+            bad = [q for q, v in vals.items() if ref["main" + q] != v]
+            assert not bad, (case, trial, bad[:5])
+            assert match == root.sigs["out"].vals[0] and rev == root.sigs["reveal0"].vals
+    assert 0 < n_fail < 30
+
+
+@pytest.mark.gpu
+def test_gpu_random_templates_region_equals_the_interpreter(tmp_path):
+    import shutil
+    import zkwg
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "regex_style", "helpers.circom"), tmp_path / "helpers.circom")
+    fx = np.load(FX)
+    inp = json.loads(bytes(fx["inputs"]).decode())
+    rng = random.Random(77)
+    for case in range(2):
+        f = tmp_path / f"fuzz{case}.circom"
+        f.write_text(_fuzz_template(rng, 576))
+        c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0, regex=str(f), regex_template="Fuzz")
+        msgs = [bytes(rng.choice([0, 33, 97, 98, 99, 100, 255, rng.randrange(128)]) for _ in range(576)) for _ in range(3)]
+        recs = b""
+        for m in msgs:
+            x = dict(inp)
+            x["emailHeader"] = [str(b) for b in m]
+            recs += c.pack(x)
+        wit, status = c.calculate_batch_host(recs)
+        for e, m in enumerate(msgs):
+            ref, _, _ = _interpret(str(f), "Fuzz", 576, m)
+            got = _by_name(c, wit[e * c.witness_bytes:(e + 1) * c.witness_bytes])
+            region = {n: v for n, v in got.items() if n.startswith("main.anon_BodyHashRegex.")}
+            assert len(region) == c.regex_info()["kept"]
+            bad = [n for n, v in region.items() if int.from_bytes(v, "little") != ref["main" + n[len("main.anon_BodyHashRegex"):]]]
+            assert not bad, (case, e, len(bad), bad[:5])

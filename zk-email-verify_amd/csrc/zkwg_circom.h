@@ -10,7 +10,7 @@
 // streams the values out.  Linear signals are substituted away (they are what `--O1/--O2` removes; an O0 build
 // gets them back from the `.r1cs`, zkwg_full.h).
 //
-// Language subset: templates with integer parameters, `signal` / `component` / `var` declarations (arrays,
+// Language subset: templates with integer parameters, integer functions, `signal` / `component` / `var` declarations (arrays,
 // initialisers), `for` / `while` / `if`, `<==` `==>` `<--` `===`, component arrays, anonymous components
 // `T(p)(in...)` named `<T>_<line>_<offset>` like the compiler's syntax-sugar remover, array literals, integer
 // `var` arithmetic.  Hints must have one of circomlib's two shapes: `(x >> k) & 1` (Num2Bits) and
@@ -510,12 +510,14 @@ struct Net {
 static const u32 VAL_INVERSE = 0x80000000u; // stored word: inverse of the 31-bit two's-complement integer in the low bits
 
 // ------------------------------------------------------------------------------------------------ elaboration
+struct ReturnValue { Val v; };
 struct Elab {
+  int call_depth = 0;
   std::deque<Node> pool;
   std::deque<std::string> files;
   std::deque<Inst> insts;
   std::map<std::string, Template> templates;
-  std::set<std::string> functions;
+  std::map<std::string, Template> functions;   // integer functions (evaluated on compile-time constants)
   std::set<std::string> included;
   std::vector<std::string> include_dirs;
   std::vector<Gate> gates;
@@ -564,12 +566,14 @@ struct Elab {
       }
       if (P.at("function")) {
         ++P.i;
-        std::string nm = P.ident();
+        Template F;
+        F.name = P.ident();
+        F.file = fp;
         P.expect("(");
-        while (!P.at(")")) { P.ident(); if (!P.accept(",")) break; }
+        while (!P.at(")")) { F.params.push_back(P.ident()); if (!P.accept(",")) break; }
         P.expect(")");
-        P.block();
-        functions.insert(nm);
+        F.body = P.block();
+        functions[F.name] = F;
         continue;
       }
       if (P.at("component")) {   // `component main ... = T(...);`
@@ -727,6 +731,7 @@ struct Elab {
       for (size_t d = 0; d < r.idx.size(); ++d) if (r.idx[d] < 0 || r.idx[d] >= (i64)vi->second.dims[d]) err(n, "index out of bounds for " + p->s);
       return r;
     }
+    if (!f.inst) err(n, "unknown identifier " + p->s + " (functions only see their parameters and variables)");
     auto si = f.inst->sig_of.find(p->s);
     if (si != f.inst->sig_of.end()) {
       r.kind = 2; r.inst = f.inst; r.sig = si->second;
@@ -1042,9 +1047,24 @@ struct Elab {
         if (op == "**") { if (b < 0 || b > 62) err(n, "exponent out of range"); __int128 r = 1; for (i64 i = 0; i < b; ++i) { r *= a; chk(r, "a power"); } return Val::num((i64)r); }
         err(n, "unsupported operator " + op);
       }
-      case N_CALL:
+      case N_CALL: {
         if (templates.count(n->s)) err(n, "a template instantiation is only valid on the right of `component x =`");
-        err(n, "functions are not supported by this loader (" + n->s + ")");
+        auto fi = functions.find(n->s);
+        if (fi == functions.end()) err(n, "unknown function " + n->s);
+        const Template& F = fi->second;
+        if (n->c.size() != F.params.size()) err(n, n->s + ": wrong number of arguments");
+        Frame ff{nullptr, {}, {}};
+        for (size_t p = 0; p < F.params.size(); ++p) {
+          Val a = eval(n->c[p], f);
+          if (a.k == V_QUAD) err(n, "function argument of degree 2");
+          ff.vars[F.params[p]] = VarArr{{}, {a}};
+        }
+        if (++call_depth > 64) err(n, "function recursion too deep");
+        Val ret;
+        try { exec(F.body, ff); --call_depth; err(n, "function " + n->s + " ended without return"); }
+        catch (ReturnValue& r) { --call_depth; ret = r.v; }
+        return ret;
+      }
       case N_ANON: return eval_anon(n, f);
       default: err(n, "not an expression");
     }
@@ -1113,6 +1133,7 @@ struct Elab {
       case S_NOP: case S_LOG: return;
       case S_BLOCK: for (Node* s : n->c) exec(s, f); return;
       case S_SIGNAL:
+        if (!f.inst) err(n, "signal declared inside a function");
         declare_signals(n, f, false);
         for (Node* d : n->c) if (d->c.size() > 1) {
           Ref r; r.kind = 2; r.inst = f.inst; r.sig = f.inst->sig_of[d->s];
@@ -1122,6 +1143,7 @@ struct Elab {
         return;
       case S_VAR: for (Node* d : n->c) declare_var(d, f); return;
       case S_COMP:
+        if (!f.inst) err(n, "component declared inside a function");
         for (Node* d : n->c) {
           if (f.inst->comps.count(d->s) || f.inst->sig_of.count(d->s)) err(d, d->s + " declared twice");
           CompArr C;
@@ -1168,8 +1190,13 @@ struct Elab {
         return;
       }
       case S_ASSERT: if (!const_of(eval(n->c[0], f), n, "an assert")) err(n, "assert failed while loading the template"); return;
-      case S_RET: err(n, "return outside a function");
-      case S_CONSTR: constrain(eval(n->c[0], f), eval(n->c[1], f), n); return;
+      case S_RET:
+        if (f.inst) err(n, "return outside a function");
+        throw ReturnValue{eval(n->c[0], f)};
+      case S_CONSTR:
+        if (!f.inst) err(n, "constraint inside a function");
+        constrain(eval(n->c[0], f), eval(n->c[1], f), n);
+        return;
       case S_ASSIGN: {
         Ref r = resolve(n->c[0], f);
         const std::string& op = n->s;
