@@ -31,6 +31,13 @@ def test_ev_small_batch_bit_exact(ignore):
         assert w == comp.witness_kept(main)
         # outputs first: pubkeyHash, shaHi, shaLo (email-verifier.test.ts:188-207 checks w[1])
         assert (w[1], w[2], w[3]) == main.o
+        # the same through the circom_tester surface: assertOut(witness, {pubkeyHash: ...}) (:204-206)
+        c.assertOut(w, {"pubkeyHash": main.o[0], "shaHi": str(main.o[1])})
+        c.assertOut(wb, {"shaLo": main.o[2], "pubkey": inp["pubkey"]})
+        with pytest.raises(AssertionError, match=r"main\.shaHi: expected 5"):
+            c.assertOut(w, {"shaHi": 5})
+        with pytest.raises(AssertionError, match="Output variable not defined: main.nope"):
+            c.assertOut(w, {"nope": 0})
 
 
 def test_ev_tamper_cases_assert_failed():

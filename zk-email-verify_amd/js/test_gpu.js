@@ -88,6 +88,15 @@ function shaPad(msg, max) {  // packages/helpers/src/sha-utils.ts:88-111
     const b3 = await evc.calculateBatch([kase.input, tampered, big, kase.input]);
     assert.deepStrictEqual(Array.from(b3.status), [0, 4, 4, 0]);
     assert.ok(Buffer.from(b3.wtns[0]).equals(Buffer.from(bin)) && Buffer.from(b3.wtns[3]).equals(Buffer.from(bin)));
+    // circom_tester surface (email-verifier.test.ts:188-207): assertOut(witness, {pubkeyHash}) via loadSymbols
+    const t = await z.tester({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody }, 0);
+    const tw = await t.calculateWitness(kase.input);
+    await t.assertOut(tw, { pubkeyHash: kase.pubkeyHash, shaHi: kase.shaHi, shaLo: BigInt(kase.shaLo) });
+    await t.assertOut(tw, { pubkey: kase.input.pubkey });           // arrays element-wise
+    await assert.rejects(t.assertOut(tw, { shaHi: '1' }), /main\.shaHi: expected 1/);
+    await assert.rejects(t.assertOut(tw, { nothing: 0 }), /Output variable not defined: main\.nothing/);
+    await assert.rejects(t.checkConstraints(tw), /no constraint system loaded/);
+    assert.strictEqual(t.symbols['main.pubkeyHash'].varIdx, 1);
     // multi-GPU entry (zkwg_calculate_batch_multi) with one device: same witnesses + the gathered result table
     const mc = new z.MultiCalculator({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody }, [0]);
     assert.strictEqual(mc.nDevices, 1);

@@ -162,6 +162,51 @@ class MultiCalculator {
   }
 }
 
+/** circom_tester-shaped handle: what `wasm_tester(circuitPath, {include, ...})` returns in the reference's tests
+ * (packages/circuits/tests/email-verifier.test.ts:21-31): `calculateWitness(input, sanityCheck)`,
+ * `checkConstraints(witness)`, `assertOut(witness, {name: value | array})`, `loadSymbols()` / `.symbols`
+ * (`{ "main.x[3]": {labelIdx, varIdx, componentIdx} }`).  `opts` as for Circuit plus `r1csFile` (Buffer with the
+ * circuit's `.r1cs`; without it checkConstraints has nothing to check against and throws). */
+class Tester {
+  constructor(opts, device) {
+    this.circuit = new Circuit(opts, device);
+    this.wc = new WitnessCalculator(this.circuit);
+    this.symbols = null;
+    this.constraints = opts && opts.r1csFile ? new R1cs(opts.r1csFile, device) : null;
+  }
+  async calculateWitness(input, sanityCheck) { return this.wc.calculateWitness(input, sanityCheck); }
+  async loadSymbols() {
+    if (this.symbols) return;
+    this.symbols = {};
+    for (const line of addon.symText(this.circuit.handle).split('\n')) {
+      if (!line) continue;
+      const p = line.split(',');
+      this.symbols[p.slice(3).join(',')] = { labelIdx: Number(p[0]), varIdx: Number(p[1]), componentIdx: Number(p[2]) };
+    }
+  }
+  async checkConstraints(witness) {
+    if (!this.constraints) throw new Error('zkwg: no constraint system loaded (pass r1csFile)');
+    return this.constraints.checkConstraints(witness);
+  }
+  /** compares `main.<name>` (arrays element-wise) with the witness; throws like circom_tester on the first difference */
+  async assertOut(actualOut, expectedOut) {
+    await this.loadSymbols();
+    const self = this;
+    const check = (prefix, e) => {
+      if (Array.isArray(e)) { for (let i = 0; i < e.length; i++) check(prefix + '[' + i + ']', e[i]); return; }
+      if (typeof e === 'object' && e !== null && e.constructor.name === 'Object') { for (const k of Object.keys(e)) check(prefix + '.' + k, e[k]); return; }
+      const sym = self.symbols[prefix];
+      if (sym === undefined) throw new Error('Output variable not defined: ' + prefix);
+      const got = actualOut[sym.varIdx].toString(), want = e.toString();
+      if (got !== want) throw new Error(prefix + ': expected ' + want + ', the witness has ' + got);
+    };
+    check('main', expectedOut);
+  }
+}
+/** `wasm_tester` counterpart: the reference passes the path of a `.circom` main file; here the circuit is named by
+ * its template parameters (opts) */
+async function tester(opts, device) { return new Tester(opts, device); }
+
 /** snarkjs-shaped `wtns.calculate(input, circuitOrWasm, wtnsFileName | {type:"mem"})`.  The second
  * argument is a zkwg Circuit (where the reference passes the path of the circom WASM). */
 const wtns = {
@@ -202,4 +247,4 @@ function symbols(circuit) {
   return names;
 }
 
-module.exports = { symbols, R1cs, Circuit, WitnessCalculator, MultiCalculator, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };
+module.exports = { symbols, R1cs, Circuit, WitnessCalculator, MultiCalculator, Tester, tester, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };

@@ -344,6 +344,41 @@ class Circuit:
         return out
 
 
+    def loadSymbols(self):
+        """circom_tester `loadSymbols()`: {"main.x[3]": {"labelIdx", "varIdx", "componentIdx"}}
+        (packages/circuits/tests/email-verifier.test.ts:204-206 reaches it through assertOut)."""
+        if getattr(self, "_symbols", None) is None:
+            need = self.lib.zkwg_write_sym(self.h, None, 0)
+            buf = C.create_string_buffer(need)
+            self.lib.zkwg_write_sym(self.h, buf, need)
+            self._symbols = {}
+            for line in buf.raw[:need].decode().splitlines():
+                a, b, c, name = line.split(",", 3)
+                self._symbols[name] = {"labelIdx": int(a), "varIdx": int(b), "componentIdx": int(c)}
+        return self._symbols
+
+    def assertOut(self, witness, expected):
+        """circom_tester `assertOut(witness, {name: value | list})`: compares `main.<name>` (lists element-wise) with the
+        witness (list of ints or the 32-byte-per-signal buffer); raises AssertionError on the first difference."""
+        sym = self.loadSymbols()
+        get = (lambda i: int.from_bytes(witness[32 * i:32 * i + 32], "little")) if isinstance(witness, (bytes, bytearray, memoryview)) else (lambda i: int(witness[i]))
+
+        def check(prefix, e):
+            if isinstance(e, (list, tuple)):
+                for i, x in enumerate(e):
+                    check(f"{prefix}[{i}]", x)
+            elif isinstance(e, dict):
+                for k, x in e.items():
+                    check(f"{prefix}.{k}", x)
+            else:
+                if prefix not in sym:
+                    raise AssertionError("Output variable not defined: " + prefix)
+                got, want = get(sym[prefix]["varIdx"]), int(e) % 21888242871839275222246405745257275088548364400416034343698204186575808495617
+                if got != want:
+                    raise AssertionError(f"{prefix}: expected {want}, the witness has {got}")
+        check("main", expected)
+
+
 class MultiCircuit:
     """The batch sharded over several GPUs of one node through the C-ABI (include/zkwg.h zkwg_multi_*):
     contiguous shards, one handle + host thread per GPU, the 100-byte result table gathered on devices[0]
