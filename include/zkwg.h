@@ -134,10 +134,12 @@ int zkwg_circuit_create_sym(const zkwg_config* cfg, int device, const char* sym_
                             const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out);
 /* Complete witnesses for a circuit compiled without full simplification (the reference documents
  * `circom ... --O0`, docs/zk-email-docs/UsageGuide/README.md:56-64): besides the `.sym` file the compiler's
- * `.r1cs` is given.  Signals this library's schedule produces are written at their `.sym` index by
- * zk_expand; every other signal the file numbers (aliases, constants, linear combinations -- 2.4 M of the
- * 3.1 M signals of EmailVerifier(576,192) at O0) is derived from the LINEAR constraints of the `.r1cs`
- * (triangular elimination at creation; one extra kernel, zk_linear_fill, after zk_expand).  Creation fails
+ * `.r1cs` is given.  Every signal the file numbers beyond the ones this library's schedule produces (aliases,
+ * constants, linear combinations -- 2.4 M of the 3.1 M signals of EmailVerifier(576,192) at O0) is derived from
+ * the LINEAR constraints of the `.r1cs` (triangular elimination at creation).  On the device zk_expand writes
+ * the compact witness into a staging buffer of the handle and zk_o0_gather / zk_o0_rows_* write the file's wires
+ * from it (launches of one handle must therefore be stream-ordered; Montgomery-form output is not offered for
+ * such handles).  19 k complete witnesses/s for EmailVerifier(576,192), DESIGN.md section 16.  Creation fails
  * with zkwg_last_error naming the first signal that is neither produced nor linearly defined (a quadratic
  * signal of a template this schedule does not implement, e.g. zk-regex's real BodyHashRegex).  Multi-
  * dimensional signal names (`a[t][k]`) are accepted by both `.sym` entry points. */

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <map>
 #include <thread>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -19,6 +20,7 @@
 #include "zkwg_full.h"
 
 #define ZK_MAX_KERNELS 9
+#define ZK_O0_SHORT_ROW 8   // linear rows up to this many terms are evaluated inside zk_o0_gather, longer ones by zk_o0_rows
 #define ZK_RS_SLOTS 16
 #define ZK_POS_STREAMS 4
 #define ZK_POS_RING 64
@@ -34,6 +36,11 @@ struct zkwg_circuit {
   u64* d_lin_row; u32* d_lin_dst; u32* d_lin_src; Fr* d_lin_coef; u8* d_lin_kind; u64 lin_rows;
   std::vector<u32> kept_dst;   // `.sym` layouts: kept-v1 slot -> witness index (0xffffffff = dropped by the file)
   ZkLinPlan lin_host;   // kept for layout-only handles (tests evaluate it on the host)
+  // fully numbered circuits: zk_expand fills a kept-v1 staging buffer, zk_o0_gather writes the file's wires from it
+  u64 full_W;                      // wires of the `.sym` / `.r1cs` (0: not a fully numbered circuit)
+  std::vector<u32> o0_short; u64 n_o0_short;
+  std::vector<u32> o0_desc, o0_src, o0_long;   // wire -> kept-v1 slot | 0x80000000 + row | 0xfffffffe (long row);  row terms as kept-v1 slots;  the long rows
+  u32* d_o0_desc; u32* d_o0_long; u64 n_o0_long; u8* d_stage; u64 stage_bytes;
   Fr* d_invtab_m; // fused Montgomery output: inverse table in Montgomery form (built with d_rtab)
   // BodyHashRegex loaded from a circom template (zkwg_circuit_create_regex): gate list on the device
   zkc::Net net;
@@ -194,7 +201,10 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   if (sym_text) {
     ZkSymLayout L;
     L.allow_holes = r1cs != nullptr;
-    if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net) || !zk_remap_segments(c->s, c->segs, c->first_seg, L)) {
+    // a compact `.sym` (no .r1cs): zk_expand writes the file's order directly (segments remapped).  A fully numbered
+    // circuit (.r1cs given): zk_expand keeps producing the compact kept-v1 witness into a staging buffer and
+    // zk_o0_gather writes every wire of the file from it (aliases copy, the other derived signals are linear rows)
+    if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net) || (!r1cs && !zk_remap_segments(c->s, c->segs, c->first_seg, L))) {
       g_last_error = L.err.empty() ? std::string(".sym layout does not tile the witness") : L.err;
       delete c;
       return ZKWG_RC_BAD_CONFIG;
@@ -208,6 +218,54 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       if (!zk_r1cs_parse(r1cs, r1cs_len, R)) err = "the .r1cs file could not be parsed";
       else if (R.n_wires != L.W) err = "the .r1cs has " + std::to_string(R.n_wires) + " wires, the .sym file numbers " + std::to_string(L.W);
       else zk_linear_plan(R, produced, c->lin_host, err);
+      if (err.empty()) {
+        // wire -> where its value comes from: a kept-v1 slot (bit 31 clear) or a linear row over kept-v1 slots
+        const ZkLinPlan& Pn = c->lin_host;
+        std::vector<u32> inv(L.W, 0xffffffffu);
+        for (u64 slot = 0; slot < L.dst.size(); ++slot) if (L.dst[slot] != 0xffffffffu) inv[L.dst[slot]] = (u32)slot;
+        c->o0_desc.assign(L.W, 0xffffffffu);
+        for (u64 w = 0; w < L.W; ++w) if (!L.hole[w]) c->o0_desc[w] = inv[w];
+        c->o0_src.resize(Pn.src.size());
+        for (size_t t = 0; t < Pn.src.size() && err.empty(); ++t) {
+          c->o0_src[t] = inv[Pn.src[t]];
+          if (c->o0_src[t] == 0xffffffffu) err = "internal: a linear row reads a wire the schedule does not produce";
+        }
+        for (u64 r = 0; r < Pn.n_rows(); ++r) {
+          const u64 a = Pn.row_ptr[r], b = Pn.row_ptr[r + 1];
+          if (b - a == 1 && Pn.kind[a] == ZK_COEF_ONE) c->o0_desc[Pn.dst[r]] = c->o0_src[a];   // alias: zk_o0_gather copies
+          else { c->o0_desc[Pn.dst[r]] = 0xfffffffeu; (b - a > ZK_O0_SHORT_ROW ? c->o0_long : c->o0_short).push_back((u32)r); }   // zk_o0_rows
+        }
+        c->n_o0_short = c->o0_short.size();
+        c->o0_long.insert(c->o0_long.begin(), c->o0_short.begin(), c->o0_short.end());   // [short rows | long rows]
+        std::vector<u32>().swap(c->o0_short);
+        for (u64 w = 0; w < L.W && err.empty(); ++w)
+          if (c->o0_desc[w] == 0xffffffffu || (!(c->o0_desc[w] >> 31) && c->o0_desc[w] >= c->s.W)) err = "internal: wire " + std::to_string(w) + " has no source";
+        if (Pn.n_rows() >= 0x7fffffffull || c->s.W >= 0x7fffffffull) err = "circuit too large for the O0 gather table";
+        c->full_W = L.W;
+        if (getenv("ZKWG_DEBUG_PLAN")) {
+          u64 hist[8] = {0}, terms = 0, longest = 0;
+          for (u64 r = 0; r < Pn.n_rows(); ++r) {
+            const u64 n = Pn.row_ptr[r + 1] - Pn.row_ptr[r];
+            terms += n; longest = std::max(longest, n);
+            ++hist[n == 0 ? 0 : n == 1 ? 1 : n == 2 ? 2 : n <= 4 ? 3 : n <= 16 ? 4 : n <= 64 ? 5 : n <= 256 ? 6 : 7];
+          }
+          std::map<std::string, std::pair<u64, u64>> by;   // template-ish key -> (rows, terms) of the long rows
+          for (u64 r = 0; r < Pn.n_rows(); ++r) {
+            const u64 n = Pn.row_ptr[r + 1] - Pn.row_ptr[r];
+            if (n <= 8) continue;
+            std::string nm = L.names[Pn.dst[r]], key;
+            for (char ch : nm) if (!isdigit((unsigned char)ch)) key += ch;
+            by[key].first++; by[key].second += n;
+          }
+          std::vector<std::pair<u64, std::string>> top;
+          for (auto& kv : by) top.emplace_back(kv.second.second, kv.first + " rows=" + std::to_string(kv.second.first));
+          std::sort(top.rbegin(), top.rend());
+          for (size_t i = 0; i < top.size() && i < 14; ++i) fprintf(stderr, "[zkwg]   %llu terms: %s\n", (unsigned long long)top[i].first, top[i].second.c_str());
+          fprintf(stderr, "[zkwg] O0 plan: %llu rows, %llu terms, longest %llu; rows with 0/1/2/3-4/5-16/17-64/65-256/>256 terms: %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                  (unsigned long long)Pn.n_rows(), (unsigned long long)terms, (unsigned long long)longest, (unsigned long long)hist[0], (unsigned long long)hist[1],
+                  (unsigned long long)hist[2], (unsigned long long)hist[3], (unsigned long long)hist[4], (unsigned long long)hist[5], (unsigned long long)hist[6], (unsigned long long)hist[7]);
+        }
+      }
       if (!err.empty()) { g_last_error = err; delete c; return ZKWG_RC_BAD_CONFIG; }
     }
     c->sym_names.swap(L.names);
@@ -227,7 +285,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     c->n_kernels = k + 1;
     for (int i = 0; i < k; ++i) c->kslots[i] = 0;
   }
-  c->kname[c->n_kernels - 1] = "zk_expand"; c->kslots[c->n_kernels - 1] = c->s.W;
+  c->kname[c->n_kernels - 1] = "zk_expand"; c->kslots[c->n_kernels - 1] = c->full_W ? c->full_W : c->s.W;   // (+ zk_o0_gather for a fully numbered circuit)
   if (device >= 0) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return ZKWG_RC_NO_DEVICE; }
@@ -256,14 +314,18 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       ok = hipMalloc((void**)&c->d_lin_row, Pn.row_ptr.size() * 8) == hipSuccess &&
            hipMalloc((void**)&c->d_lin_dst, Pn.dst.size() * 4) == hipSuccess &&
            hipMalloc((void**)&c->d_lin_src, nt * 4) == hipSuccess &&
+           hipMalloc((void**)&c->d_o0_desc, c->o0_desc.size() * 4) == hipSuccess &&
+           hipMemcpy(c->d_o0_desc, c->o0_desc.data(), c->o0_desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+           hipMalloc((void**)&c->d_o0_long, std::max<size_t>(c->o0_long.size(), 1) * 4) == hipSuccess &&
+           hipMemcpy(c->d_o0_long, c->o0_long.data(), c->o0_long.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
            hipMalloc((void**)&c->d_lin_coef, nt * sizeof(Fr)) == hipSuccess &&
            hipMalloc((void**)&c->d_lin_kind, nt) == hipSuccess &&
            hipMemcpy(c->d_lin_row, Pn.row_ptr.data(), Pn.row_ptr.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
            hipMemcpy(c->d_lin_dst, Pn.dst.data(), Pn.dst.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-           hipMemcpy(c->d_lin_src, Pn.src.data(), Pn.src.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+           hipMemcpy(c->d_lin_src, c->o0_src.data(), c->o0_src.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
            hipMemcpy(c->d_lin_coef, Pn.coef.data(), Pn.coef.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess &&
            hipMemcpy(c->d_lin_kind, Pn.kind.data(), Pn.kind.size(), hipMemcpyHostToDevice) == hipSuccess;
-      if (ok) { ZkLinPlan empty; std::swap(c->lin_host, empty); }   // the device copy is the one used
+      if (ok) { ZkLinPlan empty; std::swap(c->lin_host, empty); c->n_o0_long = c->o0_long.size(); std::vector<u32>().swap(c->o0_desc); std::vector<u32>().swap(c->o0_src); std::vector<u32>().swap(c->o0_long); }   // the device copies are the ones used
     }
     if (ok && c->s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER) {
       std::vector<Fr> C, M, t10;
@@ -418,7 +480,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     hipSetDevice(c->device);
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
     hipFree(c->d_lin_row); hipFree(c->d_lin_dst); hipFree(c->d_lin_src); hipFree(c->d_lin_coef); hipFree(c->d_lin_kind);
-    hipFree(c->d_net_records); hipFree(c->d_net_counts);
+    hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_o0_desc); hipFree(c->d_o0_long); hipFree(c->d_stage);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); }
     hipStreamDestroy(c->copy_stream);
@@ -440,8 +502,9 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   delete c;
 }
 
-uint64_t zkwg_witness_len(const zkwg_circuit_t* c) { return c->s.W; }
-uint64_t zkwg_witness_bytes(const zkwg_circuit_t* c) { return c->s.W * 32; }
+static inline u64 out_W(const zkwg_circuit* c) { return c->full_W ? c->full_W : c->s.W; }   // witness length the caller sees
+uint64_t zkwg_witness_len(const zkwg_circuit_t* c) { return out_W(c); }
+uint64_t zkwg_witness_bytes(const zkwg_circuit_t* c) { return out_W(c) * 32; }
 uint32_t zkwg_num_public(const zkwg_circuit_t* c) { return c->s.n_public; }
 uint64_t zkwg_input_stride(const zkwg_circuit_t* c) { return c->s.in_stride; }
 uint64_t zkwg_input_offset(const zkwg_circuit_t* c, int field) {
@@ -712,7 +775,7 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   if (c->device < 0) return ZKWG_RC_NO_DEVICE;
   if (count == 0) return ZKWG_RC_OK;
   const ZkSched& s = c->s;
-  if (first + count > n || out_stride != s.W * 32 || count * (u64)s.nportions > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
+  if (first + count > n || out_stride != out_W(c) * 32 || count * (u64)s.nportions > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
   if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_out & 15)) return ZKWG_RC_BAD_ARG;
   std::lock_guard<std::mutex> lock(c->dev_mutex);
   ZkDeviceGuard dg(c->device);
@@ -735,9 +798,21 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
       if (hipMemcpy(c->d_invtab_m, inv.data(), inv.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) return ZKWG_RC_HIP_ERROR;
     }
   }
+  if (c->full_W) {
+    // fully numbered circuit: the kept-v1 witnesses of this launch go to a staging buffer of the handle
+    if (mont) return ZKWG_RC_BAD_CONFIG;
+    const u64 need = count * s.W * 32;
+    if (c->stage_bytes < need) {
+      hipStreamSynchronize(st);
+      hipFree(c->d_stage);
+      c->d_stage = nullptr; c->stage_bytes = 0;
+      if (hipMalloc((void**)&c->d_stage, need) != hipSuccess) return ZKWG_RC_OOM;
+      c->stage_bytes = need;
+    }
+  }
   ZkBufs B;
   fill_bufs(c, B, d_in, n, (void*)d_scratch);
-  B.wit = (uint4*)d_out;
+  B.wit = c->full_W ? (uint4*)c->d_stage : (uint4*)d_out;
   B.e_first = (u32)first;
   B.n_emails = (u32)(first + count);
   if (s.rslb && !c->rs_sync)   // the merge chain of this scratch buffer may still be running on the side stream
@@ -754,14 +829,23 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   else if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
   else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
   else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);
-  if (tm) { hipEventRecord(evs[1], st); c->ev_valid = true; c->launches++; }
-  if (c->lin_rows) {
-    // fully numbered circuit: derive the signals the schedule does not produce from the ones just written
-    if (mont) return ZKWG_RC_BAD_CONFIG;
-    hipLaunchKernelGGL(zk_linear_fill, dim3((u32)((c->lin_rows + 255) / 256), (u32)count), dim3(256), 0, st,
-                       c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, c->lin_rows, (u8*)d_out,
-                       out_stride);
+  if (c->full_W) {
+    // every wire of the compiled circuit from the staged kept-v1 witness: aliases copy, the rest are linear rows
+    const u64 chunks = c->full_W * 2;
+    hipLaunchKernelGGL(zk_o0_gather, dim3((u32)((chunks + 255) / 256), (u32)count), dim3(256), 0, st, c->d_o0_desc,
+                       c->full_W, (const u8*)c->d_stage, s.W * 32, (u8*)d_out, out_stride);
+    // the other derived signals: 4 lanes per row up to ZK_O0_SHORT_ROW terms, 16 lanes per row beyond (running sums, Bits2Num ...)
+    if (c->n_o0_short)
+      hipLaunchKernelGGL(zk_o0_rows_4, dim3((u32)((c->n_o0_short + 63) / 64), (u32)count), dim3(256), 0, st, c->d_o0_long, (u32)c->n_o0_short,
+                         c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, (const u8*)c->d_stage, s.W * 32,
+                         (u8*)d_out, out_stride);
+    if (c->n_o0_long > c->n_o0_short)
+      hipLaunchKernelGGL(zk_o0_rows_16, dim3((u32)((c->n_o0_long - c->n_o0_short + 15) / 16), (u32)count), dim3(256), 0, st,
+                         c->d_o0_long + c->n_o0_short, (u32)(c->n_o0_long - c->n_o0_short),
+                         c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, (const u8*)c->d_stage, s.W * 32,
+                         (u8*)d_out, out_stride);
   }
+  if (tm) { hipEventRecord(evs[1], st); c->ev_valid = true; c->launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;
 }
@@ -792,7 +876,7 @@ static int ensure_host_path_buffers(zkwg_circuit* c, u64 tile) {
   c->hb_in = c->hb_out[0] = c->hb_out[1] = c->hb_scr = nullptr;
   c->hb_status[0] = c->hb_status[1] = nullptr;
   c->hb_tile = 0;
-  const u64 wbytes = c->s.W * 32;
+  const u64 wbytes = out_W(c) * 32;
   if (hipMalloc((void**)&c->hb_in, tile * c->s.in_stride) != hipSuccess ||
       hipMalloc((void**)&c->hb_out[0], tile * wbytes) != hipSuccess ||
       hipMalloc((void**)&c->hb_out[1], tile * wbytes) != hipSuccess ||
@@ -811,7 +895,7 @@ static int calculate_batch_impl(zkwg_circuit_t* c, const uint8_t* packed, uint64
   if (!c || !packed || !status) return ZKWG_RC_BAD_ARG;
   if (c->device < 0) return ZKWG_RC_NO_DEVICE;
   if (n == 0) return ZKWG_RC_OK;
-  const u64 wbytes = c->s.W * 32;
+  const u64 wbytes = out_W(c) * 32;
   if (out_wtns && out_stride < wbytes) return ZKWG_RC_BAD_ARG;
   std::lock_guard<std::mutex> lock(c->hb_mutex);   // one host-path call at a time per handle
   if (hipSetDevice(c->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
@@ -884,7 +968,7 @@ void* zkwg_alloc_pinned(uint64_t bytes) {
 }
 void zkwg_free_pinned(void* p) { if (p) hipHostFree(p); }
 
-uint64_t zkwg_wtns_size(const zkwg_circuit_t* c) { return 12 + 12 + 40 + 12 + c->s.W * 32; }
+uint64_t zkwg_wtns_size(const zkwg_circuit_t* c) { return 12 + 12 + 40 + 12 + out_W(c) * 32; }
 
 int zkwg_write_wtns(const zkwg_circuit_t* c, const uint8_t* witness, uint8_t* out, uint64_t cap) {
   if (!c || !witness || !out) return ZKWG_RC_BAD_ARG;
@@ -898,9 +982,9 @@ int zkwg_write_wtns(const zkwg_circuit_t* c, const uint8_t* witness, uint8_t* ou
   w32(32);
   const u64 prime[4] = {ZK_P0, ZK_P1, ZK_P2, ZK_P3};
   memcpy(p, prime, 32); p += 32;
-  w32((u32)c->s.W);
-  w32(2); w64(c->s.W * 32);
-  memcpy(p, witness, c->s.W * 32);
+  w32((u32)out_W(c));
+  w32(2); w64(out_W(c) * 32);
+  memcpy(p, witness, out_W(c) * 32);
   return ZKWG_RC_OK;
 }
 

@@ -7,12 +7,13 @@
 // (which names are ours) and the `.r1cs`, this file derives, once per circuit, for every signal the
 // schedule does not produce a row   w[dst] = c0 + sum_k coef_k * w[src_k]   whose sources are signals the
 // schedule does produce -- by triangular elimination over the linear constraints (a constraint with one
-// unknown wire defines it), then substitution down to produced wires.  zk_linear_fill evaluates the rows
-// on the device after zk_expand.  Reference: the compile line the reference documents is `circom ... --O0`
+// unknown wire defines it), then substitution down to produced wires.  zk_o0_gather / zk_o0_rows evaluate
+// the rows on the device after zk_expand.  Reference: the compile line the reference documents is `circom ... --O0`
 // (docs/zk-email-docs/UsageGuide/README.md:56-64); `.sym` / `.r1cs` are what `circom_tester` loads
 // (packages/circuits/tests/email-verifier.test.ts:21-31,44,204-206).
 #pragma once
 #include <algorithm>
+#include <queue>
 #include <string>
 #include <vector>
 #include "zkwg_r1cs.h"
@@ -21,7 +22,7 @@ struct ZkLinPlan {
   std::vector<u64> row_ptr;   // rows + 1
   std::vector<u32> dst;       // witness index written by the row
   std::vector<u32> src;       // term sources (witness indices produced by the schedule; 0 = the constant 1)
-  std::vector<Fr> coef;       // term coefficients, Montgomery form
+  std::vector<Fr> coef;       // term coefficients, STANDARD form (most operands are 0 or 1: no product needed)
   std::vector<u8> kind;       // ZK_COEF_ONE / MINUS_ONE / GENERIC
   u64 n_rows() const { return dst.size(); }
 };
@@ -32,6 +33,7 @@ static inline bool zk_linear_plan(const ZkR1csHost& R, const std::vector<u8>& pr
   if (produced.size() < nw) { err = "the .sym file lists fewer signals than the .r1cs has wires"; return false; }
   auto row = [&](u64 lc, u64& a, u64& b) { a = R.row_ptr[lc]; b = R.row_ptr[lc + 1]; };
   const Fr zero = fr_zero();
+  const Fr unit_m = fr_R(), neg_unit_m = fr_neg(fr_R());
   // linear constraints: A or B empty -> C = 0;  A (or B) a pure constant k -> k * B - C = 0
   struct Lin { std::vector<u32> w; std::vector<Fr> c; };   // sum c_i w_i = 0 (Montgomery coefficients)
   std::vector<Lin> lin;
@@ -70,12 +72,15 @@ static inline bool zk_linear_plan(const ZkR1csHost& R, const std::vector<u8>& pr
   struct Def { std::vector<u32> w; std::vector<Fr> c; };
   std::vector<Def> def(nw);
   std::vector<u32> order;
-  std::vector<u32> queue;
-  for (u32 li = 0; li < lin.size(); ++li) if (unk[li] == 1) queue.push_back(li);
+  // shortest constraint first: a wire that is both an alias of a produced signal and a member of a long sum
+  // (the bits under a Num2Bits / BinSum closing constraint) must be defined by the alias, not by solving the sum for it
+  typedef std::pair<u32, u32> QE;   // (terms of the constraint, index)
+  std::priority_queue<QE, std::vector<QE>, std::greater<QE>> queue;
+  for (u32 li = 0; li < lin.size(); ++li) if (unk[li] == 1) queue.emplace((u32)lin[li].w.size(), li);
   std::vector<std::pair<u32, Fr>> acc;
   while (!queue.empty()) {
-    const u32 li = queue.back();
-    queue.pop_back();
+    const u32 li = queue.top().second;
+    queue.pop();
     if (unk[li] != 1) continue;
     const Lin& L = lin[li];
     // the single unknown (it may appear more than once in the combination)
@@ -86,7 +91,8 @@ static inline bool zk_linear_plan(const ZkR1csHost& R, const std::vector<u8>& pr
     if (u == 0xffffffffu) continue;
     if (fr_is_zero(cu)) { unk[li] = 0; continue; }           // cancels out: not a definition
     // u = -(1 / cu) * sum_{others} c_w * w, with derived wires substituted by their definitions
-    const Fr f = fr_neg(fr_mont_inv(cu));                     // Montgomery form
+    // -(1 / cu), Montgomery form; the coefficient of an alias / sum member is almost always +-1
+    const Fr f = fr_eq(cu, unit_m) ? neg_unit_m : (fr_eq(cu, neg_unit_m) ? unit_m : fr_neg(fr_mont_inv(cu)));
     acc.clear();
     for (size_t t = 0; t < L.w.size(); ++t) {
       const u32 w = L.w[t];
@@ -108,7 +114,7 @@ static inline bool zk_linear_plan(const ZkR1csHost& R, const std::vector<u8>& pr
     order.push_back(u);
     for (u32 k = deg[u]; k < deg[u + 1]; ++k) {
       const u32 lj = occ[k];
-      if (unk[lj] > 0 && --unk[lj] == 1) queue.push_back(lj);
+      if (unk[lj] > 0 && --unk[lj] == 1) queue.emplace((u32)lin[lj].w.size(), lj);
     }
   }
   for (u64 w = 0; w < nw; ++w)
@@ -122,7 +128,7 @@ static inline bool zk_linear_plan(const ZkR1csHost& R, const std::vector<u8>& pr
     const Def& D = def[u];
     for (size_t t = 0; t < D.w.size(); ++t) {
       P.src.push_back(D.w[t]);
-      P.coef.push_back(D.c[t]);
+      P.coef.push_back(fr_from_mont(D.c[t]));
       P.kind.push_back(fr_eq(D.c[t], one_m) ? ZK_COEF_ONE : (fr_eq(D.c[t], minus_one_m) ? ZK_COEF_MINUS_ONE : ZK_COEF_GENERIC));
     }
     P.dst.push_back(u);
@@ -131,7 +137,7 @@ static inline bool zk_linear_plan(const ZkR1csHost& R, const std::vector<u8>& pr
   return true;
 }
 
-// one row for one witness (standard-form values); host mirror of zk_linear_fill for the CPU tests
+// one row for one witness (standard-form values); shared by zk_o0_gather and the host evaluation of the CPU tests
 ZK_HD Fr zk_linear_row(const u64* __restrict__ row_ptr, const u32* __restrict__ src, const Fr* __restrict__ coef,
                        const u8* __restrict__ kind, u64 r, const Fr* __restrict__ w) {
   Fr acc = fr_zero();
@@ -140,7 +146,11 @@ ZK_HD Fr zk_linear_row(const u64* __restrict__ row_ptr, const u32* __restrict__ 
     const u8 k = kind[t];
     if (k == ZK_COEF_ONE) acc = fr_add(acc, x);
     else if (k == ZK_COEF_MINUS_ONE) acc = fr_sub(acc, x);
-    else acc = fr_add(acc, fr_mont_mul(x, coef[t]));   // standard * Montgomery -> standard
+    else if (!fr_is_zero(x)) {
+      // generic coefficient (powers of two of Bits2Num ...): the operand is almost always a bit
+      const bool one = x.l[0] == 1 && (x.l[1] | x.l[2] | x.l[3]) == 0;
+      acc = fr_add(acc, one ? coef[t] : fr_mont_mul(fr_to_mont(x), coef[t]));
+    }
   }
   return acc;
 }

@@ -17,15 +17,64 @@ __global__ __launch_bounds__(256) void zk_r1cs_check(const u64* __restrict__ row
   if (!zk_r1cs_check_one(row_ptr, wire, coef, kind, i, w)) atomicMin(first_bad + e, (unsigned long long)i);
 }
 
-// zk_linear_fill -- the signals a compiled circuit numbers but the schedule does not produce (aliases, constants,
-// linear combinations; zkwg_full.h): w[dst] = sum coef * w[src] over wires zk_expand has already written.
-// One thread per (row, witness); rows are sorted by destination.
-__global__ __launch_bounds__(256) void zk_linear_fill(const u64* __restrict__ row_ptr, const u32* __restrict__ dst,
-                                                      const u32* __restrict__ src, const Fr* __restrict__ coef,
-                                                      const u8* __restrict__ kind, u64 n_rows, u8* __restrict__ wit,
-                                                      u64 stride) {
-  const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (r >= n_rows) return;
-  Fr* w = (Fr*)(wit + (u64)blockIdx.y * stride);
-  w[dst[r]] = zk_linear_row(row_ptr, src, coef, kind, r, w);
+// zk_o0_gather -- the witness of a fully numbered (`--O0` / `--O1`) circuit from the compact kept-v1 witness zk_expand
+// staged: desc[w] names, for every wire of the compiled circuit, the kept-v1 slot it copies (produced signals and
+// their aliases: 95 % of the wires); the other wires are linear rows written by zk_o0_rows.  One 16-byte chunk per
+// lane, consecutive lanes write consecutive chunks; the reads follow the circuit's own locality (the compiler numbers
+// a component's signals together).
+__global__ __launch_bounds__(256) void zk_o0_gather(const u32* __restrict__ desc, u64 n_wires, const u8* __restrict__ kept,
+                                                    u64 kept_stride, u8* __restrict__ out, u64 out_stride) {
+  const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * n_wires) return;
+  const u32 d = desc[c >> 1];
+  if (d == 0xfffffffeu) return;   // a linear row: zk_o0_rows writes it
+  const uint4* __restrict__ kw = (const uint4*)(kept + (u64)blockIdx.y * kept_stride);
+  uint4* __restrict__ o = (uint4*)(out + (u64)blockIdx.y * out_stride);
+  o[c] = kw[(u64)d * 2 + ((u32)c & 1u)];
+}
+
+// zk_o0_rows -- the derived signals that are not plain aliases (zkwg_full.h): LANES lanes per row stride over its
+// terms, the partial sums are folded with shuffles, lane 0 of the group writes the wire.  Same arithmetic as
+// zk_linear_row.  4 lanes for the short rows (negations, constants times a signal, sums of a few terms), 16 for the
+// long ones (running sums of MultiOR / CalculateTotal chains flattened over produced signals, Bits2Num outputs ...).
+template <int LANES>
+__device__ __forceinline__ void zk_o0_rows_body(const u32* __restrict__ rows, u32 n_rows, const u64* __restrict__ row_ptr,
+                                                const u32* __restrict__ dst, const u32* __restrict__ src,
+                                                const Fr* __restrict__ coef, const u8* __restrict__ kind,
+                                                const u8* __restrict__ kept, u64 kept_stride, u8* __restrict__ out, u64 out_stride) {
+  const u32 g = blockIdx.x * (256u / LANES) + threadIdx.x / LANES, l = threadIdx.x % LANES;
+  const bool live = g < n_rows;
+  const u32 r = live ? rows[g] : 0u;
+  const Fr* __restrict__ w = (const Fr*)(kept + (u64)blockIdx.y * kept_stride);
+  Fr acc = fr_zero();
+  if (live)
+    for (u64 t = row_ptr[r] + l; t < row_ptr[r + 1]; t += LANES) {
+      const Fr x = w[src[t]];
+      const u8 k = kind[t];
+      if (k == ZK_COEF_ONE) acc = fr_add(acc, x);
+      else if (k == ZK_COEF_MINUS_ONE) acc = fr_sub(acc, x);
+      else if (!fr_is_zero(x)) {
+        const bool one = x.l[0] == 1 && (x.l[1] | x.l[2] | x.l[3]) == 0;
+        acc = fr_add(acc, one ? coef[t] : fr_mont_mul(fr_to_mont(x), coef[t]));
+      }
+    }
+#pragma unroll
+  for (int off = LANES / 2; off >= 1; off >>= 1) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32 lo = __shfl_down((u32)acc.l[i], off, LANES), hi = __shfl_down((u32)(acc.l[i] >> 32), off, LANES);
+      o.l[i] = (u64)lo | ((u64)hi << 32);
+    }
+    acc = fr_add(acc, o);
+  }
+  if (live && l == 0) ((Fr*)(out + (u64)blockIdx.y * out_stride))[dst[r]] = acc;
+}
+__global__ __launch_bounds__(256) void zk_o0_rows_4(const u32* rows, u32 n_rows, const u64* row_ptr, const u32* dst, const u32* src, const Fr* coef,
+                                                    const u8* kind, const u8* kept, u64 kept_stride, u8* out, u64 out_stride) {
+  zk_o0_rows_body<4>(rows, n_rows, row_ptr, dst, src, coef, kind, kept, kept_stride, out, out_stride);
+}
+__global__ __launch_bounds__(256) void zk_o0_rows_16(const u32* rows, u32 n_rows, const u64* row_ptr, const u32* dst, const u32* src, const Fr* coef,
+                                                     const u8* kind, const u8* kept, u64 kept_stride, u8* out, u64 out_stride) {
+  zk_o0_rows_body<16>(rows, n_rows, row_ptr, dst, src, coef, kind, kept, kept_stride, out, out_stride);
 }
