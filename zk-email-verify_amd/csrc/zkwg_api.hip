@@ -803,7 +803,7 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
     if (mont) return ZKWG_RC_BAD_CONFIG;
     const u64 need = count * s.W * 32;
     if (c->stage_bytes < need) {
-      hipStreamSynchronize(st);
+      hipDeviceSynchronize();   // (grow-only, rare) no launch of any stream may still read the old buffer
       hipFree(c->d_stage);
       c->d_stage = nullptr; c->stage_bytes = 0;
       if (hipMalloc((void**)&c->d_stage, need) != hipSuccess) return ZKWG_RC_OOM;
