@@ -88,6 +88,29 @@ function shaPad(msg, max) {  // packages/helpers/src/sha-utils.ts:88-111
     const b3 = await evc.calculateBatch([kase.input, tampered, big, kase.input]);
     assert.deepStrictEqual(Array.from(b3.status), [0, 4, 4, 0]);
     assert.ok(Buffer.from(b3.wtns[0]).equals(Buffer.from(bin)) && Buffer.from(b3.wtns[3]).equals(Buffer.from(bin)));
+    // wtnsFromBin (JS-side container) == the C ABI's zkwg_write_wtns
+    assert.ok(ev.wtnsFromBin(Buffer.from(bin)).equals(Buffer.from(wt)));
+    // the documented CLI (docs/zk-email-docs/UsageGuide/README.md:132-140): node generate_witness.js <circuit> input.json witness.wtns
+    {
+      const os = require('os');
+      const cp = require('child_process');
+      const dir = fs.mkdtempSync(path.join(os.tmpdir(), 'zkwg-'));
+      const cli = path.join(__dirname, 'generate_witness.js');
+      const spec = `EmailVerifier(${kase.maxHeader},${kase.maxBody},121,17,0,0,0,0)`;
+      fs.writeFileSync(path.join(dir, 'input.json'), JSON.stringify(kase.input));
+      cp.execFileSync(process.execPath, [cli, spec, path.join(dir, 'input.json'), path.join(dir, 'witness.wtns')]);
+      assert.ok(fs.readFileSync(path.join(dir, 'witness.wtns')).equals(Buffer.from(wt)));
+      fs.writeFileSync(path.join(dir, 'bad.json'), JSON.stringify(tampered));
+      const r1 = cp.spawnSync(process.execPath, [cli, spec, path.join(dir, 'bad.json'), path.join(dir, 'bad.wtns')], { encoding: 'utf8' });
+      assert.strictEqual(r1.status, 1);
+      assert.ok(/Assert Failed/.test(r1.stderr));
+      fs.writeFileSync(path.join(dir, 'batch.json'), JSON.stringify([kase.input, tampered, kase.input]));
+      const r2 = cp.spawnSync(process.execPath, [cli, JSON.stringify({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody }), path.join(dir, 'batch.json'), path.join(dir, 'w.wtns')], { encoding: 'utf8' });
+      assert.strictEqual(r2.status, 1);
+      assert.ok(/email 1: Error: Assert Failed/.test(r2.stderr));
+      assert.ok(fs.readFileSync(path.join(dir, 'w_0.wtns')).equals(Buffer.from(wt)) && fs.readFileSync(path.join(dir, 'w_2.wtns')).equals(Buffer.from(wt)));
+      assert.ok(!fs.existsSync(path.join(dir, 'w_1.wtns')));
+    }
     // circom_tester surface (email-verifier.test.ts:188-207): assertOut(witness, {pubkeyHash}) via loadSymbols
     const t = await z.tester({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody }, 0);
     const tw = await t.calculateWitness(kase.input);

@@ -37,6 +37,22 @@ class Circuit {
     Object.assign(this, addon.info(this.handle));
   }
 
+  /** 32-byte-per-signal witness -> `.wtns` file bytes (snarkjs wtns v2: header section with n8 = 32, the prime, the
+   *  witness length; then the values, little-endian, non-Montgomery) */
+  wtnsFromBin(bin) {
+    const W = this.witnessLen;
+    if (bin.length !== 32 * W) throw new Error('zkwg: witness buffer has the wrong length');
+    const head = Buffer.alloc(12 + 12 + 40 + 12);
+    head.write('wtns', 0, 'latin1'); head.writeUInt32LE(2, 4); head.writeUInt32LE(2, 8);
+    head.writeUInt32LE(1, 12); head.writeBigUInt64LE(40n, 16);
+    head.writeUInt32LE(32, 24);
+    let p = FIELD_MODULUS;
+    for (let i = 0; i < 32; ++i) { head[28 + i] = Number(p & 0xffn); p >>= 8n; }
+    head.writeUInt32LE(W, 60);
+    head.writeUInt32LE(2, 64); head.writeBigUInt64LE(BigInt(32 * W), 68);
+    return Buffer.concat([head, Buffer.from(bin)]);
+  }
+
   signalSizes() {
     const o = this.opts;
     if (o.mainKind === MAIN_SHA256_BYTES) return { paddedIn: o.maxHeader, paddedInLength: 1 };
