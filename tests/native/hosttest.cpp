@@ -125,11 +125,10 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
   std::vector<int> snap;
   for (u32 st = 0; st < N.n_steps; ++st) {
     snap = lds;   // the lanes of a step read before any of them writes
-    const bool general = N.step_count[st] & 0x8000u, half = N.step_count[st] & 0x4000u;
+    const bool general = N.step_count[st] & 0x8000u;
     for (u32 lane = 0; lane < (N.step_count[st] & 0x7fu); ++lane, ++g) {
       if (general) ok &= zk_net_record(&N.records[g * 16], snap.data(), lds.data(), img.data(), match, reveal, (long long)std::max<u32>(N.inv_need + 1, 256));
-      else if (half) zk_net_record32<true>(&N.records[g * 16], snap.data(), lds.data(), img.data());
-      else zk_net_record32<false>(&N.records[g * 16], snap.data(), lds.data(), img.data());
+      else zk_net_record32(&N.records[g * 16], snap.data(), lds.data(), img.data());
     }
   }
   memcpy(words, img.data(), (size_t)N.n_kept * 4);

@@ -45,7 +45,7 @@ struct zkwg_circuit {
   // BodyHashRegex loaded from a circom template (zkwg_circuit_create_regex): gate list on the device
   zkc::Net net;
   bool has_net;
-  u32* d_net_records; unsigned short* d_net_counts;
+  u32* d_net_records; u32* d_net_counts;
   Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
@@ -303,8 +303,8 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     if (ok && c->has_net) {
       ok = hipMalloc((void**)&c->d_net_records, c->net.records.size() * 4) == hipSuccess &&
            hipMemcpy(c->d_net_records, c->net.records.data(), c->net.records.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-           hipMalloc((void**)&c->d_net_counts, c->net.step_count.size() * 2 + 64) == hipSuccess &&
-           hipMemcpy(c->d_net_counts, c->net.step_count.data(), c->net.step_count.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+           hipMalloc((void**)&c->d_net_counts, c->net.step_count.size() * 4 + 64) == hipSuccess &&
+           hipMemcpy(c->d_net_counts, c->net.step_count.data(), c->net.step_count.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
       if (ok) std::vector<u32>().swap(c->net.records);
     }
     if (ok && c->lin_host.n_rows()) {

@@ -497,8 +497,8 @@ struct Net {
   u32 lds_words = 0;                 // LDS image of the evaluator: values, message bytes, a zero word, a scratch word
   u32 n_general = 0;                 // gates on the evaluator's 64-bit path (the 32-bit path is not provably exact for them)
   std::vector<u32> records;          // 16 words per gate, in execution order (zkwg_net_core.h)
-  std::vector<uint16_t> step_count;  // gates per step (<= 64, one per lane) | 0x8000 general path | 0x4000 term slots 0..3 only;
-                                     // padded to a multiple of 64 steps plus one block
+  std::vector<u32> step_count;       // gates per step (<= 64, one per lane) | 0x8000 general path | 0x4000 term slots 0..3 only;
+                                     // padded with empty steps (the evaluator reads the counts three groups of 8 ahead)
   u32 n_steps = 0;
   std::vector<std::string> names;    // kept slot -> name relative to the component (".eq[0][5].isz.inv")
   std::vector<u8> boolean;           // kept slot -> 1 if its interval is [0, 1]
@@ -1381,12 +1381,13 @@ struct Elab {
     const u32 window = 12;
     std::deque<std::vector<u32>> open;
     u32 base = 1;
+    std::vector<u32> outs;
     for (u32 gi = 0; gi < gates.size(); ++gi) {
       const Gate& g = gates[gi];
+      if (g.op == G_OUT) { outs.push_back(gi); continue; }   // the outputs go last, 64 per step (they take the 64-bit path)
       u32 c = base;
       for (int i = 0; i < nforms(g); ++i)
         for (auto& t : g.f[i].t) if (!(t.first & SRC_INPUT)) c = std::max(c, chunk_of[t.first] + 1);
-      if (g.op == G_OUT) c = std::max<u32>(c, base + (u32)open.size());   // outputs last
       for (;;) {
         while (c >= base + open.size()) open.emplace_back();
         if (open[c - base].size() < 64) break;
@@ -1397,6 +1398,7 @@ struct Elab {
       while (open.size() > window + 1) { steps.push_back(std::move(open.front())); open.pop_front(); ++base; }
     }
     while (!open.empty()) { steps.push_back(std::move(open.front())); open.pop_front(); }
+    for (size_t b = 0; b < outs.size(); b += 64) steps.emplace_back(outs.begin() + b, outs.begin() + std::min(outs.size(), b + 64));
     {
       std::vector<std::vector<u32>> nonempty;
       for (auto& st : steps) if (!st.empty()) nonempty.push_back(std::move(st));
@@ -1439,7 +1441,7 @@ struct Elab {
     net.records.clear(); net.step_count.clear();
     auto span = [&](u32 src, i64& lo, i64& hi) { if (src & SRC_INPUT) { lo = in_lo[src & 0x1fffffffu]; hi = in_hi[src & 0x1fffffffu]; } else { lo = gates[src].lo; hi = gates[src].hi; } };
     for (auto& st : steps) {
-      uint16_t general = 0, half = 0x4000;
+      u32 general = 0, half = 0x4000;
       for (u32 gi : st) {
         const Gate& g = gates[gi];
         const int nf = nforms(g);
@@ -1498,11 +1500,17 @@ struct Elab {
         }
         net.records.insert(net.records.end(), r, r + 16);
       }
-      net.step_count.push_back((uint16_t)(st.size() | general | (general ? 0 : half)));
+      net.step_count.push_back((u32)st.size() | general | (general ? 0u : half));
     }
     net.n_steps = (u32)steps.size();
-    while (net.step_count.size() % 64) net.step_count.push_back(0);   // the evaluator works in blocks of 64 steps
-    for (int i = 0; i < 64; ++i) net.step_count.push_back(0);         // (and looks one block ahead)
+    if (getenv("ZKWG_DEBUG_NET")) {
+      u64 n_half = 0, n_full = 0, n_gen = 0, g_half = 0, g_full = 0;
+      for (u32 c : net.step_count) { if (c & 0x8000) ++n_gen; else if (c & 0x4000) { ++n_half; g_half += c & 0x7f; } else { ++n_full; g_full += c & 0x7f; } }
+      fprintf(stderr, "[zkwg] gate list: %llu steps with <= 4 terms (%llu gates), %llu with up to 8 (%llu gates), %llu on the 64-bit path\n",
+              (unsigned long long)n_half, (unsigned long long)g_half, (unsigned long long)n_full, (unsigned long long)g_full, (unsigned long long)n_gen);
+    }
+    while (net.step_count.size() % 8) net.step_count.push_back(0);    // the evaluator works in groups of 8 steps
+    for (int i = 0; i < 32; ++i) net.step_count.push_back(0);         // (and reads the counts up to three groups ahead)
     net.records.insert(net.records.end(), 64 * 16, 0u);   // the evaluator's lanes always load 64 records
     if (net.records.size() >= 0xffffffffull) fail("the gate list is too large");
   }

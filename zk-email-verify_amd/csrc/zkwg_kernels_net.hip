@@ -30,19 +30,18 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   u32* small = B.small + (u64)e * s.img_small;
   u32* img = small + s.m_net;
   const uint4* __restrict__ R = (const uint4*)B.net_records;
-  const unsigned short* __restrict__ CNT = B.net_counts;
+  const u32* __restrict__ CNT = B.net_counts;
   const u32 nsteps = s.net_steps;
   const long long inv_limit = (long long)s.inv_half;
   bool ok = true;
 
-  // Register ring of records, ZKN_DEPTH steps ahead.  Steps come in blocks of 64 (the loader pads the last block
-  // with empty steps): the gate counts of a block sit in one VGPR (lane j = step j; bit 15 = the step holds a
-  // record for the general path, bit 14 = only the term slots 0..3 are used); the fetch side runs ZKN_DEPTH steps ahead and reads the next block's counts
-  // during the last ZKN_DEPTH steps of a block.
+  // Register ring of records, ZKN_DEPTH steps ahead.  Steps come in groups of ZKN_DEPTH (the loader pads the list with
+  // empty steps); the gate counts (bit 15 = the step holds a record for the 64-bit path) are wave-uniform and read
+  // with scalar loads, one group ahead of the fetch side, which itself runs one group ahead of the execute side.
+  // (Counts fetched with vector loads and v_readlane made the compiler wait for vmcnt(0) at the top of every group.)
   uint4 ring[ZKN_DEPTH][4];
   u32 fetch_base = 0;                   // record index of the next step to fetch
-  const u32 nblocks = (nsteps + 63u) / 64u;
-  u32 cnt_cur = CNT[lane], cnt_next = nblocks > 1 ? CNT[64 + lane] : 0u;
+  const u32 ngroups = (nsteps + ZKN_DEPTH - 1u) / ZKN_DEPTH;
   // every lane loads (lanes past the step's count get records of later steps and are neutralised when executed):
   // no control flow around the loads, so the compiler's s_waitcnt bookkeeping keeps the ring's distance
   auto fetch = [&](u32 n, uint4* dst) {
@@ -50,37 +49,38 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
     dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2]; dst[3] = p[3];
     fetch_base += n & 0x7fu;
   };
+  u32 cur[ZKN_DEPTH], nxt[ZKN_DEPTH];
 #pragma unroll
-  for (int d = 0; d < ZKN_DEPTH; ++d) fetch(__builtin_amdgcn_readlane(cnt_cur, d), ring[d]);
-  for (u32 blk = 0; blk < nblocks; ++blk) {
-    for (u32 j = 0; j < 64u / ZKN_DEPTH; ++j) {
-      const bool last = j == 64u / ZKN_DEPTH - 1u;
+  for (int d = 0; d < ZKN_DEPTH; ++d) { cur[d] = CNT[d]; nxt[d] = CNT[ZKN_DEPTH + d]; }
 #pragma unroll
-      for (int d = 0; d < ZKN_DEPTH; ++d) {
-        const u32 cn = __builtin_amdgcn_readlane(cnt_cur, j * ZKN_DEPTH + d);
-        const u32 n = cn & 0x7fu;
-        if (cn & 0x8000u) {
-          if (lane < n) {
-            const u32 r[16] = {ring[d][0].x, ring[d][0].y, ring[d][0].z, ring[d][0].w, ring[d][1].x, ring[d][1].y, ring[d][1].z, ring[d][1].w,
-                               ring[d][2].x, ring[d][2].y, ring[d][2].z, ring[d][2].w, ring[d][3].x, ring[d][3].y, ring[d][3].z, ring[d][3].w};
-            ok &= zk_net_record(r, lds, lds, img, small + s.m_net_out, small + s.m_rev, inv_limit);
-          }
-        } else {
-          // all 64 lanes run the record they hold; the lanes past the count write to scratch words
-          const bool act = lane < n;
-          const u32 r[16] = {ring[d][0].x, act ? ring[d][0].y : s.net_total, ring[d][0].z, act ? ring[d][0].w : scratch,
-                             ring[d][1].x, ring[d][1].y, ring[d][1].z, ring[d][1].w,
+  for (int d = 0; d < ZKN_DEPTH; ++d) fetch(cur[d], ring[d]);
+  for (u32 g = 0; g < ngroups; ++g) {
+    u32 nn[ZKN_DEPTH];
+#pragma unroll
+    for (int d = 0; d < ZKN_DEPTH; ++d) nn[d] = CNT[(g + 2u) * ZKN_DEPTH + d];   // two groups ahead (padded)
+#pragma unroll
+    for (int d = 0; d < ZKN_DEPTH; ++d) {
+      const u32 cn = cur[d];
+      const u32 n = cn & 0x7fu;
+      if (cn & 0x8000u) {
+        if (lane < n) {
+          const u32 r[16] = {ring[d][0].x, ring[d][0].y, ring[d][0].z, ring[d][0].w, ring[d][1].x, ring[d][1].y, ring[d][1].z, ring[d][1].w,
                              ring[d][2].x, ring[d][2].y, ring[d][2].z, ring[d][2].w, ring[d][3].x, ring[d][3].y, ring[d][3].z, ring[d][3].w};
-          if (cn & 0x4000u) zk_net_record32<true>(r, lds, lds, img); else zk_net_record32<false>(r, lds, lds, img);
+          ok &= zk_net_record(r, lds, lds, img, small + s.m_net_out, small + s.m_rev, inv_limit);
         }
-        __builtin_amdgcn_wave_barrier();
-        // refill this ring entry with the step ZKN_DEPTH ahead
-        const u32 fn = last ? __builtin_amdgcn_readlane(cnt_next, d) : __builtin_amdgcn_readlane(cnt_cur, (j + 1u) * ZKN_DEPTH + d);
-        fetch(fn, ring[d]);
+      } else {
+        // all 64 lanes run the record they hold; the lanes past the count write to scratch words
+        const bool act = lane < n;
+        const u32 r[16] = {ring[d][0].x, act ? ring[d][0].y : s.net_total, ring[d][0].z, act ? ring[d][0].w : scratch,
+                           ring[d][1].x, ring[d][1].y, ring[d][1].z, ring[d][1].w,
+                           ring[d][2].x, ring[d][2].y, ring[d][2].z, ring[d][2].w, ring[d][3].x, ring[d][3].y, ring[d][3].z, ring[d][3].w};
+        zk_net_record32(r, lds, lds, img);
       }
+      __builtin_amdgcn_wave_barrier();
+      fetch(nxt[d], ring[d]);   // refill this ring entry with the step ZKN_DEPTH ahead
     }
-    cnt_cur = cnt_next;
-    cnt_next = blk + 2 < nblocks ? CNT[(u64)(blk + 2) * 64 + lane] : 0u;
+#pragma unroll
+    for (int d = 0; d < ZKN_DEPTH; ++d) { cur[d] = nxt[d]; nxt[d] = nn[d]; }
   }
   if (__ballot(!ok) != 0ull && lane == 0) B.status[e] = 4;
 }

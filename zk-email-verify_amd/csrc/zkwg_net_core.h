@@ -71,7 +71,9 @@ ZK_HD bool zk_net_record(const u32* r, const int* lds_r, int* lds, u32* img, u32
 // ops QUAD / NEZ / BIT / LIN / INV0, no range checks left to make; all candidate values are computed and
 // selected, so the lanes of a step do not diverge.  Same arithmetic as zk_net_record.
 // (products of 24-bit operands: the loader bounds coefficients by 2^13, operand values by 2^20 and the factors
-// of a product by 2^23.)  HALF: the step uses the term slots 0..3 only.
+// of a product by 2^23.)  One straight-line body for every op -- v = X * Y + Z with the three picked by selects --
+// so that the compiler emits no branch: a branch around the stores made its s_waitcnt bookkeeping fall back to
+// vmcnt(0) in every step, which serialised the record prefetch of zk_net_eval.
 ZK_HD int zk_mul24(int a, int b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __mul24(a, b);
@@ -79,20 +81,19 @@ ZK_HD int zk_mul24(int a, int b) {
   return a * b;
 #endif
 }
-template <bool HALF>
 ZK_HD void zk_net_record32(const u32* r, const int* lds_r, int* lds, u32* img) {
   const u32 op = r[0] & 15u;
   int p[8];
 #pragma unroll
-  for (u32 t = 0; t < 8; ++t) p[t] = (HALF && t >= 4) ? 0 : zk_mul24((int)r[8 + t] >> 18, *(const int*)((const char*)lds_r + (r[8 + t] & 0x3ffffu)));
+  for (u32 t = 0; t < 8; ++t) p[t] = zk_mul24((int)r[8 + t] >> 18, *(const int*)((const char*)lds_r + (r[8 + t] & 0x3ffffu)));
   const int sa = p[0] + p[1], sb = p[2] + p[3], sc = (p[4] + p[5]) + (p[6] + p[7]);
   const int L = (int)r[4] + sa + sb + sc;
-  const int a = sa + (int)r[4], b = sb + (int)r[5], c = sc + (int)r[6];
-  const int vq = zk_mul24(a, b) + c;
-  const int vn = (L != 0 ? (int)r[2] : 0) + (int)r[6];
-  const int vb = (L >> ((r[0] >> 4) & 31u)) & 1;
-  const int v = op == ZKN_QUAD ? vq : (op == ZKN_NEZ ? vn : (op == ZKN_BIT ? vb : L));
-  const bool inv = op == ZKN_INV0;
-  img[r[1]] = inv ? (L == 0 ? 0u : (ZKN_VAL_INVERSE | ((u32)L & 0x7fffffffu))) : ((u32)v & 0x7fffffffu);
+  const bool quad = op == ZKN_QUAD, nez = op == ZKN_NEZ, bit = op == ZKN_BIT;
+  const int X = quad ? sa + (int)r[4] : (nez ? (int)(L != 0) : (bit ? (L >> ((r[0] >> 4) & 31u)) & 1 : L));
+  const int Y = quad ? sb + (int)r[5] : (nez ? (int)r[2] : 1);
+  const int Z = quad ? sc + (int)r[6] : (nez ? (int)r[6] : 0);
+  const int v = zk_mul24(X, Y) + Z;
+  const u32 inv = L == 0 ? 0u : (ZKN_VAL_INVERSE | ((u32)L & 0x7fffffffu));
+  img[r[1]] = op == ZKN_INV0 ? inv : ((u32)v & 0x7fffffffu);
   lds[r[3]] = v;   // (the scratch word for ZKN_INV0 and for values nobody reads)
 }

@@ -235,7 +235,7 @@ struct ZkBufs {
   const Fr* pos2;        // Poseidon(2)  sparse-round table
   const Fr* invtab_m;    // zk_expand_mont: the inverse table in Montgomery form
   const u32* net_records; // loaded regex template: 16 words per gate in execution order (zkwg_net_core.h)
-  const unsigned short* net_counts;   // loaded regex template: gates per step | flags
+  const u32* net_counts;  // loaded regex template: gates per step | flags (0x8000: 64-bit path)
   const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
   const ZkSeg* segs;     // segment table
   const u32* first_seg;  // first segment overlapping each portion
