@@ -59,6 +59,19 @@ def test_device_input_generation_with_selector_and_errors():
     d = dict(ds[0], body=b"x" * 640 + b"aaab" + b"y" * 100)
     _, st = zkwg.generate_inputs_device(c, [d], selector="aab")
     assert st == [3]
+    # getAdjustedSelector (input-generators.ts:44-105, 224-227): the selector spans a "=\r\n" soft line break of the
+    # quoted-printable body -- found in the cleaned content, mapped back, searched for as the body's own bytes
+    soft = []
+    for i, at in enumerate((700, 703, 707, 640)):
+        d = synth.synthetic_dkim_result(14, i, body_len=900)
+        body = bytearray(d["body"])
+        body[at - 3:at + 8] = (b"ZKMARKER")[:i + 2] + b"=\r\n" + (b"ZKMARKER")[i + 2:]
+        soft.append(dict(d, body=bytes(body)))
+    recs, st = zkwg.generate_inputs_device(c, soft, selector="ZKMARKER")
+    assert st == [0] * 4
+    host = recs.cpu().numpy()
+    for i, d in enumerate(soft):
+        assert host[i].tobytes() == _host_record(c, d, N, M, "ZKMARKER"), i
 
 
 def test_device_input_generation_remove_soft_line_breaks():

@@ -65,9 +65,6 @@ __global__ __launch_bounds__(64) void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8
     const u8* body = D.bodies + (u64)e * D.body_stride;
     const u32 bl = D.body_len[e];
     // bodyHashIndex = headers.toString().indexOf(bodyHash)   (-1 -> 0xffffffff)
-    // (not on the device: the getAdjustedSelector fallback of input-generators.ts:44-105,224-227 for a
-    //  selector that spans a "=\r\n" soft break -- such emails return err 3 here and go through the host
-    //  mirror zkwg.inputs, which implements it)
     if (lane == 0) {
       const u8* bh = D.body_hash_b64 + (u64)e * 44;
       u32 idx = 0xffffffffu;
@@ -100,7 +97,44 @@ __global__ __launch_bounds__(64) void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8
           else j = 0;
           ++i;
         }
-        if (sel_idx == 0xffffffffu) err = 3;                // "SHA precompute selector ... not found in the body"
+        if (sel_idx == 0xffffffffu) {
+          // getAdjustedSelector (input-generators.ts:44-105, 224-227): a selector that is not in the body as it
+          // stands may span a "=\r\n" soft line break.  It is then looked up in the body with the soft breaks removed
+          // (removeSoftLineBreaks of the PADDED body, :127-158), mapped back, and the body's own bytes from there on
+          // -- selector length + 3 of them -- become the selector of the search above.
+          const u32 L = D.selector_len;
+          bool in_body = false;                              // bodyString.includes(selector): a general substring search
+          for (u32 a = 0; !in_body && a + L <= bl; ++a) {
+            u32 k = 0;
+            while (k < L && body[a + k] == D.selector[k]) ++k;
+            in_body = k == L;
+          }
+          auto sb = [&](u64 k) -> bool { return k + 2 < total && padded((u32)k) == 61u && padded((u32)k + 1) == 13u && padded((u32)k + 2) == 10u; };
+          u32 orig = 0xffffffffu;
+          for (u32 a = 0; !in_body && a < total && orig == 0xffffffffu; ++a) {
+            if (sb(a) || (a >= 1 && sb(a - 1)) || (a >= 2 && sb(a - 2))) continue;   // not a byte of the cleaned content
+            u32 k = 0, q = a;
+            while (k < L && q < total) {                     // cleanString.indexOf(selector) starting at clean position of `a`
+              if (sb(q)) { q += 3; continue; }
+              if (padded(q) != D.selector[k]) break;
+              ++k; ++q;
+            }
+            if (k == L) orig = a;
+          }
+          u8 adj[160];
+          u32 al = 0;
+          if (orig != 0xffffffffu && L + 3 <= sizeof(adj) && orig < bl) {
+            al = min(L + 3, bl - orig);                      // bodyString.slice(originalIndex, originalIndex + selector.length + 3)
+            for (u32 k = 0; k < al; ++k) adj[k] = body[orig + k];
+            i = 0; j = 0;
+            while (i < total) {                              // generatePartialSHA's findIndexInUint8Array with the adjusted selector
+              if (padded(i) == adj[j]) { ++j; if (j == al) { sel_idx = i - j + 1; break; } }
+              else j = 0;
+              ++i;
+            }
+          }
+          if (sel_idx == 0xffffffffu) err = 3;              // "SHA precompute selector ... not found in the body"
+        }
       }
       u32 cut = sel_idx == 0xffffffffu ? 0 : (sel_idx / 64) * 64;
       if (!err && bpad - cut > M) err = 2;                  // "Remaining body ... is longer than max"
