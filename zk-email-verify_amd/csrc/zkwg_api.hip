@@ -798,10 +798,16 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
       if (hipMemcpy(c->d_invtab_m, inv.data(), inv.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) return ZKWG_RC_HIP_ERROR;
     }
   }
+  // Fully numbered circuit: zk_expand writes the kept-v1 witnesses into a staging buffer of the handle and the gather
+  // kernels produce the file's wires from it.  (ZKWG_O0_STAGE_MB cuts the launch into sub-tiles whose staging fits that
+  // many MB -- sized to the 256 MB Infinity Cache it measured SLOWER: 15.4 k witnesses/s at 160 MB, 11.9 k at 64 MB
+  // against 19.4 k for the whole launch at once, EmailVerifier(576,192).)
+  u64 sub = count;
   if (c->full_W) {
-    // fully numbered circuit: the kept-v1 witnesses of this launch go to a staging buffer of the handle
     if (mont) return ZKWG_RC_BAD_CONFIG;
-    const u64 need = count * s.W * 32;
+    if (const char* v = getenv("ZKWG_O0_STAGE_MB"))
+      sub = std::min<u64>(count, std::max<u64>(1, ((u64)std::max(1, atoi(v)) << 20) / (s.W * 32)));
+    const u64 need = sub * s.W * 32;
     if (c->stage_bytes < need) {
       hipDeviceSynchronize();   // (grow-only, rare) no launch of any stream may still read the old buffer
       hipFree(c->d_stage);
@@ -812,9 +818,6 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   }
   ZkBufs B;
   fill_bufs(c, B, d_in, n, (void*)d_scratch);
-  B.wit = c->full_W ? (uint4*)c->d_stage : (uint4*)d_out;
-  B.e_first = (u32)first;
-  B.n_emails = (u32)(first + count);
   if (s.rslb && !c->rs_sync)   // the merge chain of this scratch buffer may still be running on the side stream
     for (int i = 0; i < ZK_RS_SLOTS; ++i)
       if (c->rs_scr[i] == d_scratch) hipStreamWaitEvent(st, c->rs_done[i], 0);
@@ -822,28 +825,35 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   hipEvent_t* evs = c->ev[c->launches % ZK_EV_RING];
   if (tm) hipEventRecord(evs[0], st);
   B.emails_per_wg = mont ? 1u : (u32)c->emails_per_wg;
-  const u64 units = ((count + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions;
-  const dim3 grid((u32)units);
-  if (mont) hipLaunchKernelGGL(zk_expand_mont_256, grid, dim3(256), 0, st, s, B);
-  else if (c->expand_threads == 64) hipLaunchKernelGGL(zk_expand_wave, dim3((u32)((units + 3) / 4)), dim3(256), 0, st, s, B);
-  else if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
-  else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
-  else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);
-  if (c->full_W) {
-    // every wire of the compiled circuit from the staged kept-v1 witness: aliases copy, the rest are linear rows
-    const u64 chunks = c->full_W * 2;
-    hipLaunchKernelGGL(zk_o0_gather, dim3((u32)((chunks + 255) / 256), (u32)count), dim3(256), 0, st, c->d_o0_desc,
-                       c->full_W, (const u8*)c->d_stage, s.W * 32, (u8*)d_out, out_stride);
-    // the other derived signals: 4 lanes per row up to ZK_O0_SHORT_ROW terms, 16 lanes per row beyond (running sums, Bits2Num ...)
-    if (c->n_o0_short)
-      hipLaunchKernelGGL(zk_o0_rows_4, dim3((u32)((c->n_o0_short + 63) / 64), (u32)count), dim3(256), 0, st, c->d_o0_long, (u32)c->n_o0_short,
-                         c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, (const u8*)c->d_stage, s.W * 32,
-                         (u8*)d_out, out_stride);
-    if (c->n_o0_long > c->n_o0_short)
-      hipLaunchKernelGGL(zk_o0_rows_16, dim3((u32)((c->n_o0_long - c->n_o0_short + 15) / 16), (u32)count), dim3(256), 0, st,
-                         c->d_o0_long + c->n_o0_short, (u32)(c->n_o0_long - c->n_o0_short),
-                         c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, (const u8*)c->d_stage, s.W * 32,
-                         (u8*)d_out, out_stride);
+  for (u64 off = 0; off < count; off += sub) {
+    const u64 cnt = std::min(sub, count - off);
+    u8* out_sub = (u8*)d_out + off * out_stride;
+    B.wit = c->full_W ? (uint4*)c->d_stage : (uint4*)out_sub;
+    B.e_first = (u32)(first + off);
+    B.n_emails = (u32)(first + off + cnt);
+    const u64 units = ((cnt + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions;
+    const dim3 grid((u32)units);
+    if (mont) hipLaunchKernelGGL(zk_expand_mont_256, grid, dim3(256), 0, st, s, B);
+    else if (c->expand_threads == 64) hipLaunchKernelGGL(zk_expand_wave, dim3((u32)((units + 3) / 4)), dim3(256), 0, st, s, B);
+    else if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
+    else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
+    else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);
+    if (c->full_W) {
+      // every wire of the compiled circuit from the staged kept-v1 witness: aliases copy, the rest are linear rows
+      const u64 chunks = c->full_W * 2;
+      hipLaunchKernelGGL(zk_o0_gather, dim3((u32)((chunks + 255) / 256), (u32)cnt), dim3(256), 0, st, c->d_o0_desc,
+                         c->full_W, (const u8*)c->d_stage, s.W * 32, out_sub, out_stride);
+      // the other derived signals: 4 lanes per row up to ZK_O0_SHORT_ROW terms, 16 lanes per row beyond (running sums, Bits2Num ...)
+      if (c->n_o0_short)
+        hipLaunchKernelGGL(zk_o0_rows_4, dim3((u32)((c->n_o0_short + 63) / 64), (u32)cnt), dim3(256), 0, st, c->d_o0_long, (u32)c->n_o0_short,
+                           c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, (const u8*)c->d_stage, s.W * 32,
+                           out_sub, out_stride);
+      if (c->n_o0_long > c->n_o0_short)
+        hipLaunchKernelGGL(zk_o0_rows_16, dim3((u32)((c->n_o0_long - c->n_o0_short + 15) / 16), (u32)cnt), dim3(256), 0, st,
+                           c->d_o0_long + c->n_o0_short, (u32)(c->n_o0_long - c->n_o0_short),
+                           c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, (const u8*)c->d_stage, s.W * 32,
+                           out_sub, out_stride);
+    }
   }
   if (tm) { hipEventRecord(evs[1], st); c->ev_valid = true; c->launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
