@@ -424,3 +424,52 @@ def test_single_wire_corruptions_are_all_detected():
         o = slot_of[n[:-4] + ".out"]
         assert int.from_bytes(w0[32 * o:32 * o + 32], "little") == 1, n
     assert len(missed) < k // 4
+
+
+@pytest.mark.gpu
+def test_prover_first_stage_evaluations_on_device_witnesses():
+    """zkwg_r1cs_evaluate_device: A.w, B.w, C.w of every constraint -- what `groth16.prove` computes first from the
+    witness (second half of fullProve, packages/helpers/src/chunked-zkey.ts:80) -- on device-resident witnesses, in
+    standard form and, for a witness in Montgomery form, in Montgomery form (no conversion pass)."""
+    import random
+    import torch
+    import zkwg
+    R = 1 << 256
+    # (1) a random system against Python integers, both forms
+    NW, M = 3000, 20000
+    cons, w = ru.random_system(21, NW, M)
+    r = zkwg.R1cs(ru.write_r1cs(NW, cons), device=0)
+    ev = lambda d, ww: sum(c * ww[k] for k, c in d.items()) % ru.P
+    exp = [[ev(t[j], w) for t in cons] for j in range(3)]
+    stride = 32 * NW
+    d_std = torch.frombuffer(bytearray(_blob(w)), dtype=torch.uint8).to("cuda:0")
+    d_mont = torch.frombuffer(bytearray(_blob([v * R % ru.P for v in w])), dtype=torch.uint8).to("cuda:0")
+    for d, scale in ((d_std, 1), (d_mont, R)):
+        out = bytes(r.evaluate_device(d, 1, stride).cpu().numpy().tobytes())
+        got = [int.from_bytes(out[32 * i:32 * i + 32], "little") for i in range(3 * M)]
+        assert got == [v * scale % ru.P for j in range(3) for v in exp[j]]
+    # (2) real witnesses: RSAVerifier65537 main, kept-v1 constraint system, witness written in Montgomery form by the
+    # fused expand; a * b = c holds for every constraint of every email (in Montgomery form: aR * bR = cR * R)
+    c = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=0)
+    cs = zkwg.WitnessCalculator(c).constraint_system()
+    from test_rsa_cpu import KAT_MSG, KAT_PUB, KAT_SIG, limbs
+    rec = c.pack({"signature": limbs(KAT_SIG), "modulus": limbs(KAT_PUB), "message": KAT_MSG})
+    n = 3
+    d_in = torch.frombuffer(bytearray(rec * n), dtype=torch.uint8).to("cuda:0")
+    d_status = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    d_scr = torch.empty(c.scratch_bytes(n), dtype=torch.uint8, device="cuda:0")
+    d_wit = torch.empty(n * c.witness_bytes, dtype=torch.uint8, device="cuda:0")
+    s = torch.cuda.current_stream()
+    c.prepare_device(d_in, n, d_status, d_scr, s)
+    c.expand_montgomery_device(d_in, n, d_scr, 0, n, d_wit, s)
+    abc = cs.evaluate_device(d_wit, n, c.witness_bytes, s)
+    torch.cuda.synchronize()
+    assert d_status.cpu().tolist() == [0] * n
+    m = cs.n_constraints
+    raw = abc[1].cpu().numpy().tobytes()
+    rng = random.Random(2)
+    for i in [0, 1, m - 1] + [rng.randrange(m) for _ in range(300)]:
+        a, b, cc = (int.from_bytes(raw[32 * (j * m + i):32 * (j * m + i) + 32], "little") for j in range(3))
+        assert a * b % ru.P == cc * R % ru.P, i
+    assert bytes(abc[0].cpu().numpy().tobytes()) == raw == bytes(abc[2].cpu().numpy().tobytes())
+    assert any(raw[32 * i:32 * i + 32] != bytes(32) for i in range(m))

@@ -1,0 +1,49 @@
+"""Rate of the first Groth16 prover stage on device-resident witnesses (zkwg_r1cs_evaluate_device, DESIGN.md
+section 15): EmailVerifier(576,192), the kept-v1 constraint system exported by zkwg.r1cs, witnesses written in
+Montgomery form by the fused expand and never leaving the device."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "zk-email-verify_amd", "py"))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import zkwg
+    import bench
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0)
+    t0 = time.time()
+    cs = zkwg.WitnessCalculator(c).constraint_system()
+    t_cs = time.time() - t0
+    n = 256
+    _, d_in, _ = bench.resident_inputs(torch, c, dev, 0x5A4B + 31, 64, n, 60)
+    d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_scr = torch.empty(c.scratch_bytes(n), dtype=torch.uint8, device=dev)
+    d_wit = torch.empty(n * c.witness_bytes, dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream()
+    c.prepare_device(d_in, n, d_status, d_scr, s)
+    c.expand_montgomery_device(d_in, n, d_scr, 0, n, d_wit, s)
+    torch.cuda.synchronize()
+    assert int(d_status.abs().sum().item()) == 0
+    cs.evaluate_device(d_wit, n, c.witness_bytes, s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        out = cs.evaluate_device(d_wit, n, c.witness_bytes, s)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({"circuit": "EmailVerifier(576,192,121,17,0,0,0,0) kept-v1", "constraints": cs.n_constraints, "witnesses": n,
+                      "ms_per_launch": round(dt * 1e3, 3), "witnesses_per_s": round(n / dt, 1),
+                      "evaluations_per_s": round(3 * cs.n_constraints * n / dt, 1),
+                      "GBps_written": round(96 * cs.n_constraints * n / dt / 1e9, 1), "r1cs_export_s": round(t_cs, 1)}))
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,22 @@ int zkwg_check_constraints_device(zkwg_r1cs_t* r, const void* d_witness, uint64_
   return hipGetLastError() == hipSuccess ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
 }
 
+int zkwg_r1cs_evaluate_device(zkwg_r1cs_t* r, const void* d_witness, uint64_t n, uint64_t stride, void* d_abc,
+                              uint64_t abc_stride, void* hip_stream) {
+  if (!r || !d_witness || !d_abc) return ZKWG_RC_BAD_ARG;
+  if (r->device < 0) return ZKWG_RC_NO_DEVICE;
+  if (n == 0) return ZKWG_RC_OK;
+  const u32 m = r->h.n_constraints;
+  if (stride < 32ull * r->h.n_wires || (stride & 15) || abc_stride < 96ull * m || (abc_stride & 15)) return ZKWG_RC_BAD_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  for (u64 lo = 0; m && lo < n; lo += 32768) {   // grid.y is limited to 65535
+    const u32 cnt = (u32)std::min<u64>(32768, n - lo);
+    hipLaunchKernelGGL(zk_r1cs_eval, dim3((u32)((3ull * m + 255) / 256), cnt), dim3(256), 0, st, r->d_row, r->d_wire, r->d_coef,
+                       r->d_kind, m, (const u8*)d_witness + lo * stride, stride, (u8*)d_abc + lo * abc_stride, abc_stride);
+  }
+  return hipGetLastError() == hipSuccess ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
+}
+
 int zkwg_check_constraints(zkwg_r1cs_t* r, const uint8_t* witness, uint64_t n, uint64_t stride, uint64_t* first_bad) {
   if (!r || !witness || !first_bad) return ZKWG_RC_BAD_ARG;
   if (r->device < 0) return ZKWG_RC_NO_DEVICE;

@@ -107,6 +107,7 @@ def load():
         "zkwg_r1cs_load": (i32, [vp, u64, i32, C.POINTER(vp)]),
         "zkwg_r1cs_destroy": (None, [vp]),
         "zkwg_r1cs_info": (i32, [vp, C.POINTER(C.c_uint64)]),
+        "zkwg_r1cs_evaluate_device": (i32, [vp, vp, u64, u64, vp, u64, vp]),
         "zkwg_check_constraints_device": (i32, [vp, vp, u64, u64, vp, vp]),
         "zkwg_check_constraints": (i32, [vp, vp, u64, u64, C.POINTER(C.c_uint64)]),
         "zkwg_convert_montgomery_device": (i32, [vp, u64, i32, vp]),
@@ -131,7 +132,7 @@ EXPORTS = [
     "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_pack_input", "zkwg_pack_field", "zkwg_pack_masks", "zkwg_pack_decoded_body", "zkwg_calculate_batch",
     "zkwg_generate_inputs_device", "zkwg_alloc_pinned", "zkwg_free_pinned", "zkwg_calculate_batch_device", "zkwg_prepare_device", "zkwg_expand_device", "zkwg_expand_montgomery_device", "zkwg_set_prepare_throttle", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_timing_summary", "zkwg_num_kernels",
     "zkwg_kernel_name", "zkwg_kernel_slots", "zkwg_wtns_size", "zkwg_write_wtns", "zkwg_write_sym",
-    "zkwg_r1cs_load", "zkwg_r1cs_destroy", "zkwg_r1cs_info", "zkwg_check_constraints_device", "zkwg_check_constraints",
+    "zkwg_r1cs_load", "zkwg_r1cs_destroy", "zkwg_r1cs_info", "zkwg_check_constraints_device", "zkwg_r1cs_evaluate_device", "zkwg_check_constraints",
     "zkwg_convert_montgomery_device", "zkwg_shard_range", "zkwg_multi_create", "zkwg_multi_destroy", "zkwg_multi_devices",
     "zkwg_multi_circuit", "zkwg_calculate_batch_multi",
 ]
