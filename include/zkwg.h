@@ -320,10 +320,11 @@ int zkwg_check_constraints(zkwg_r1cs_t* r, const uint8_t* witness, uint64_t n, u
  * witness: the evaluations A.w, B.w, C.w of every constraint; second half of `fullProve`,
  * packages/helpers/src/chunked-zkey.ts:80): d_abc[e] receives 3 * nConstraints field elements -- the A values, then
  * B, then C -- `abc_stride` (>= 96 * nConstraints) bytes apart.  A witness in Montgomery form
- * (zkwg_expand_montgomery_device) yields evaluations in Montgomery form, a standard-form witness standard-form ones;
- * nothing is converted or copied to the host.  The NTT / MSM stages are not part of this library. */
-int zkwg_r1cs_evaluate_device(zkwg_r1cs_t* r, const void* d_witness, uint64_t n, uint64_t stride, void* d_abc,
-                              uint64_t abc_stride, void* hip_stream);
+ * (zkwg_expand_montgomery_device; pass montgomery = 1) yields evaluations in Montgomery form, a standard-form witness
+ * (montgomery = 0) standard-form ones; nothing is converted or copied to the host.  The flag only selects a shortcut
+ * (a Montgomery-form 0 or 1 needs no product); the arithmetic is the same.  NTT / MSM are not part of this library. */
+int zkwg_r1cs_evaluate_device(zkwg_r1cs_t* r, const void* d_witness, uint64_t n, uint64_t stride, int montgomery,
+                              void* d_abc, uint64_t abc_stride, void* hip_stream);
 
 /* ---- prover hand-off -------------------------------------------------------------
  * The step after this path is `groth16.prove(zkey, wtns)` (second half of fullProve,

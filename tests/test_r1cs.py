@@ -444,8 +444,8 @@ def test_prover_first_stage_evaluations_on_device_witnesses():
     stride = 32 * NW
     d_std = torch.frombuffer(bytearray(_blob(w)), dtype=torch.uint8).to("cuda:0")
     d_mont = torch.frombuffer(bytearray(_blob([v * R % ru.P for v in w])), dtype=torch.uint8).to("cuda:0")
-    for d, scale in ((d_std, 1), (d_mont, R)):
-        out = bytes(r.evaluate_device(d, 1, stride).cpu().numpy().tobytes())
+    for d, scale, mont in ((d_std, 1, False), (d_mont, R, True), (d_mont, R, False)):
+        out = bytes(r.evaluate_device(d, 1, stride, montgomery=mont).cpu().numpy().tobytes())
         got = [int.from_bytes(out[32 * i:32 * i + 32], "little") for i in range(3 * M)]
         assert got == [v * scale % ru.P for j in range(3) for v in exp[j]]
     # (2) real witnesses: RSAVerifier65537 main, kept-v1 constraint system, witness written in Montgomery form by the
@@ -462,7 +462,7 @@ def test_prover_first_stage_evaluations_on_device_witnesses():
     s = torch.cuda.current_stream()
     c.prepare_device(d_in, n, d_status, d_scr, s)
     c.expand_montgomery_device(d_in, n, d_scr, 0, n, d_wit, s)
-    abc = cs.evaluate_device(d_wit, n, c.witness_bytes, s)
+    abc = cs.evaluate_device(d_wit, n, c.witness_bytes, s, montgomery=True)
     torch.cuda.synchronize()
     assert d_status.cpu().tolist() == [0] * n
     m = cs.n_constraints

@@ -31,12 +31,12 @@ def main():
     c.expand_montgomery_device(d_in, n, d_scr, 0, n, d_wit, s)
     torch.cuda.synchronize()
     assert int(d_status.abs().sum().item()) == 0
-    cs.evaluate_device(d_wit, n, c.witness_bytes, s)
+    cs.evaluate_device(d_wit, n, c.witness_bytes, s, montgomery=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        out = cs.evaluate_device(d_wit, n, c.witness_bytes, s)
+        out = cs.evaluate_device(d_wit, n, c.witness_bytes, s, montgomery=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(json.dumps({"circuit": "EmailVerifier(576,192,121,17,0,0,0,0) kept-v1", "constraints": cs.n_constraints, "witnesses": n,

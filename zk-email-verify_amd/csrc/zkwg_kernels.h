@@ -20,7 +20,7 @@ __global__ void zk_rslb_chain(ZkSched s, ZkBufs B);
 __global__ void zk_r1cs_check(const u64* row_ptr, const u32* wire, const Fr* coef, const u8* kind, u32 m,
                               const u8* wit, u64 stride, unsigned long long* first_bad);  // zkwg_kernels_r1cs.hip
 __global__ void zk_r1cs_eval(const u64* row_ptr, const u32* wire, const Fr* coef, const u8* kind, u32 m, const u8* wit, u64 stride,
-                             u8* out, u64 out_stride);  // zkwg_kernels_r1cs.hip
+                             u8* out, u64 out_stride, int mont);  // zkwg_kernels_r1cs.hip
 __global__ void zk_o0_gather(const u32* desc, u64 n_wires, const u8* kept, u64 kept_stride, u8* out, u64 out_stride);  // zkwg_kernels_r1cs.hip
 __global__ void zk_o0_rows_4(const u32* rows, u32 n_rows, const u64* row_ptr, const u32* dst, const u32* src, const Fr* coef, const u8* kind,
                              const u8* kept, u64 kept_stride, u8* out, u64 out_stride);

@@ -24,14 +24,14 @@ __global__ __launch_bounds__(256) void zk_r1cs_check(const u64* __restrict__ row
 // in Montgomery form -- coefficient (Montgomery) x value (Montgomery) -> Montgomery -- with no conversion pass.
 __global__ __launch_bounds__(256) void zk_r1cs_eval(const u64* __restrict__ row_ptr, const u32* __restrict__ wire,
                                                     const Fr* __restrict__ coef, const u8* __restrict__ kind, u32 m,
-                                                    const u8* __restrict__ wit, u64 stride, u8* __restrict__ out, u64 out_stride) {
+                                                    const u8* __restrict__ wit, u64 stride, u8* __restrict__ out, u64 out_stride, int mont) {
   const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;   // A rows, B rows, C rows
   if (t >= 3ull * m) return;
   const u32 which = (u32)(t / m);
   const u64 i = t - (u64)which * m;
   const Fr* w = (const Fr*)(wit + (u64)blockIdx.y * stride);
   bool canon = true;
-  ((Fr*)(out + (u64)blockIdx.y * out_stride))[t] = zk_r1cs_lc(row_ptr, wire, coef, kind, 3 * i + which, w, &canon);
+  ((Fr*)(out + (u64)blockIdx.y * out_stride))[t] = zk_r1cs_lc(row_ptr, wire, coef, kind, 3 * i + which, w, &canon, mont != 0);
 }
 
 // zk_o0_gather -- the witness of a fully numbered (`--O0` / `--O1`) circuit from the compact kept-v1 witness zk_expand

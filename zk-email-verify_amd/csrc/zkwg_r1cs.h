@@ -88,16 +88,21 @@ static inline bool zk_r1cs_parse(const u8* p, u64 len, ZkR1csHost& R) {
 
 // sum_t coef_t * w[wire_t] over one linear combination, standard form (w: standard-form witness, 32 B/slot)
 // *canon is cleared when a witness value is not reduced (>= r): such a witness is rejected
+// (mont_witness: the witness is in Montgomery form, so is the result; a value 0 or R -- most signals are bits --
+// then needs no product: R * c = the stored coefficient)
 ZK_HD Fr zk_r1cs_lc(const u64* __restrict__ row_ptr, const u32* __restrict__ wire, const Fr* __restrict__ coef,
-                    const u8* __restrict__ kind, u64 lc, const Fr* __restrict__ w, bool* canon) {
+                    const u8* __restrict__ kind, u64 lc, const Fr* __restrict__ w, bool* canon, bool mont_witness = false) {
   Fr acc = fr_zero();
+  const Fr unit = fr_R();
   for (u64 t = row_ptr[lc]; t < row_ptr[lc + 1]; ++t) {
     const Fr x = w[wire[t]];
     if (fr_geq(x, fr_p())) { *canon = false; continue; }
     const u8 k = kind[t];
     if (k == ZK_COEF_ONE) acc = fr_add(acc, x);
     else if (k == ZK_COEF_MINUS_ONE) acc = fr_sub(acc, x);
-    else acc = fr_add(acc, fr_mont_mul(x, coef[t]));   // standard * Montgomery -> standard
+    else if (mont_witness && fr_is_zero(x)) continue;
+    else if (mont_witness && fr_eq(x, unit)) acc = fr_add(acc, coef[t]);
+    else acc = fr_add(acc, fr_mont_mul(x, coef[t]));   // standard * Montgomery -> standard (Montgomery * Montgomery -> Montgomery)
   }
   return acc;
 }

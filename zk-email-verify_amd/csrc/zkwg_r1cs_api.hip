@@ -82,8 +82,8 @@ int zkwg_check_constraints_device(zkwg_r1cs_t* r, const void* d_witness, uint64_
   return hipGetLastError() == hipSuccess ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
 }
 
-int zkwg_r1cs_evaluate_device(zkwg_r1cs_t* r, const void* d_witness, uint64_t n, uint64_t stride, void* d_abc,
-                              uint64_t abc_stride, void* hip_stream) {
+int zkwg_r1cs_evaluate_device(zkwg_r1cs_t* r, const void* d_witness, uint64_t n, uint64_t stride, int montgomery,
+                              void* d_abc, uint64_t abc_stride, void* hip_stream) {
   if (!r || !d_witness || !d_abc) return ZKWG_RC_BAD_ARG;
   if (r->device < 0) return ZKWG_RC_NO_DEVICE;
   if (n == 0) return ZKWG_RC_OK;
@@ -93,7 +93,7 @@ int zkwg_r1cs_evaluate_device(zkwg_r1cs_t* r, const void* d_witness, uint64_t n,
   for (u64 lo = 0; m && lo < n; lo += 32768) {   // grid.y is limited to 65535
     const u32 cnt = (u32)std::min<u64>(32768, n - lo);
     hipLaunchKernelGGL(zk_r1cs_eval, dim3((u32)((3ull * m + 255) / 256), cnt), dim3(256), 0, st, r->d_row, r->d_wire, r->d_coef,
-                       r->d_kind, m, (const u8*)d_witness + lo * stride, stride, (u8*)d_abc + lo * abc_stride, abc_stride);
+                       r->d_kind, m, (const u8*)d_witness + lo * stride, stride, (u8*)d_abc + lo * abc_stride, abc_stride, montgomery ? 1 : 0);
   }
   return hipGetLastError() == hipSuccess ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
 }

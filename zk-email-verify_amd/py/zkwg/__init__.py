@@ -473,14 +473,15 @@ class R1cs:
         _check(self.lib.zkwg_check_constraints_device(self.h, d_witness.data_ptr(), n, stride, bad.data_ptr(), st))
         return [None if b == -1 else int(b) for b in bad.cpu().tolist()]
 
-    def evaluate_device(self, d_witness, n, stride, stream=None):
+    def evaluate_device(self, d_witness, n, stride, stream=None, montgomery=False):
         """First Groth16 prover stage on device-resident witnesses (zkwg_r1cs_evaluate_device): a torch uint8 CUDA
         tensor [n, 3 * n_constraints * 32] with the A, B, C evaluations of every constraint (Montgomery form in ->
         Montgomery form out)."""
         import torch
         out = torch.empty((n, 96 * self.n_constraints), dtype=torch.uint8, device=d_witness.device)
         st = stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        _check(self.lib.zkwg_r1cs_evaluate_device(self.h, d_witness.data_ptr(), n, stride, out.data_ptr(), 96 * self.n_constraints, st))
+        _check(self.lib.zkwg_r1cs_evaluate_device(self.h, d_witness.data_ptr(), n, stride, 1 if montgomery else 0, out.data_ptr(),
+                                                  96 * self.n_constraints, st))
         return out
 
     def checkConstraints(self, witness):

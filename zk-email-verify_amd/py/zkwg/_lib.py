@@ -107,7 +107,7 @@ def load():
         "zkwg_r1cs_load": (i32, [vp, u64, i32, C.POINTER(vp)]),
         "zkwg_r1cs_destroy": (None, [vp]),
         "zkwg_r1cs_info": (i32, [vp, C.POINTER(C.c_uint64)]),
-        "zkwg_r1cs_evaluate_device": (i32, [vp, vp, u64, u64, vp, u64, vp]),
+        "zkwg_r1cs_evaluate_device": (i32, [vp, vp, u64, u64, i32, vp, u64, vp]),
         "zkwg_check_constraints_device": (i32, [vp, vp, u64, u64, vp, vp]),
         "zkwg_check_constraints": (i32, [vp, vp, u64, u64, C.POINTER(C.c_uint64)]),
         "zkwg_convert_montgomery_device": (i32, [vp, u64, i32, vp]),
