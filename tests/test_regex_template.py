@@ -374,3 +374,20 @@ def test_gpu_random_templates_region_equals_the_interpreter(tmp_path):
             assert len(region) == c.regex_info()["kept"]
             bad = [n for n, v in region.items() if int.from_bytes(v, "little") != ref["main" + n[len("main.anon_BodyHashRegex"):]]]
             assert not bad, (case, e, len(bad), bad[:5])
+
+
+def test_subset_coverage_template_equals_the_interpreter():
+    """tests/golden/regex_style/coverage.circom: parameterised and recursive helper templates, if / else on parameters,
+    while, var arrays, integer functions with loops, ==> / array-valued anonymous outputs, multi-dimensional signals."""
+    f = os.path.join(ROOT, "tests", "golden", "regex_style", "coverage.circom")
+    rng = random.Random(8)
+    for n in (1, 2, 7, 33):
+        R = hosttest.LoadedRegex(f, n, template="Coverage")
+        for trial in range(2):
+            msg = bytes(rng.randrange(256) for _ in range(n))
+            ref, kept, root = _interpret(f, "Coverage", n, msg, symbolic=(trial == 0))
+            ok, vals, match, rev = R.evaluate(msg)
+            assert ok and match == root.sigs["out"].vals[0] and rev == root.sigs["reveal0"].vals
+            if kept is not None:
+                assert {"main" + q for q in vals} == kept
+            assert not [q for q, v in vals.items() if ref["main" + q] != v]
