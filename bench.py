@@ -47,7 +47,7 @@ class Pipeline:
     another; images are ring-buffered, witnesses go to a 2-tile ring in HBM."""
 
     def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=4, exp_prio=-1,
-                 montgomery=False):
+                 montgomery=False, out_align=0):
         self.torch, self.c, self.dev, self.d_in = torch, c, dev, d_in
         self.batch, self.tile, self.prep = batch, tile, prep
         assert batch % prep == 0 and prep % tile == 0
@@ -55,7 +55,9 @@ class Pipeline:
         self.ntiles = batch // tile
         self.rsa_throttle = rsa_throttle
         self.expand = c.expand_montgomery_device if montgomery else c.expand_device
-        self.d_out = [torch.empty(tile * c.witness_bytes, dtype=torch.uint8, device=dev) for _ in range(min(2, self.ntiles))]
+        # distance between consecutive witnesses in the HBM ring (out_align > 0: padded to a multiple of it)
+        self.stride = c.witness_bytes if not out_align or montgomery else (c.witness_bytes + out_align - 1) // out_align * out_align
+        self.d_out = [torch.empty(tile * self.stride, dtype=torch.uint8, device=dev) for _ in range(min(2, self.ntiles))]
         self.d_status = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.R = max(2, ring)
         self.d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(self.R)]
@@ -86,8 +88,11 @@ class Pipeline:
             with torch.cuda.stream(self.s_exp):
                 for t in range(self.tiles_per_sub):
                     o = self.d_out[(sb * self.tiles_per_sub + t) % len(self.d_out)]
-                    self.expand(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp)
-                    self.d_rows[lo + t * self.tile:lo + (t + 1) * self.tile].copy_(o.view(self.tile, c.witness_bytes)[:, :128])
+                    if self.stride != c.witness_bytes:
+                        self.expand(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp, out_stride=self.stride)
+                    else:
+                        self.expand(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp)
+                    self.d_rows[lo + t * self.tile:lo + (t + 1) * self.tile].copy_(o.view(self.tile, self.stride)[:, :128])
             self.ev_exp[b].record(self.s_exp)
             self.j = j + 1
 
@@ -196,6 +201,8 @@ def main():
     ap.add_argument("--other-configs", type=int, default=1, help="also measure configs[1], configs[4] and the delivered rate (N=1)")
     ap.add_argument("--montgomery", type=int, default=0,
                     help="1: witnesses written in Montgomery form by the fused expand (prover hand-off variant)")
+    ap.add_argument("--out-align", type=int, default=0,
+                    help="pad the distance between consecutive witnesses in the HBM ring to a multiple of this many bytes (0 = back to back)")
     ap.add_argument("--regex", default=None,
                     help="path of a zk-regex style body_hash_regex.circom: BodyHashRegex is compiled from it (zkwg_circuit_create_regex)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -242,7 +249,7 @@ def main():
     _, d_in, fields = resident_inputs(torch, c, dev, 0x5A4B + rank, distinct, args.batch, args.body_len)
     prio = int(os.environ.get("ZKWG_BENCH_EXP_PRIO", "-1"))
     pl = Pipeline(torch, c, dev, d_in, args.batch, tile, prep, ring=args.ring, prep_streams=args.prep_streams,
-                  rsa_throttle=args.rsa_throttle, exp_prio=prio, montgomery=bool(args.montgomery))
+                  rsa_throttle=args.rsa_throttle, exp_prio=prio, montgomery=bool(args.montgomery), out_align=args.out_align)
     from zkwg import shard
     state = {"table": None}
 
@@ -256,7 +263,7 @@ def main():
             state["table"] = shard.gather_table(dist, table, args.batch * world, rank, world) if dist is not None else table
             if dist is not None and args.gather_wtns > 0:
                 k = min(args.gather_wtns, tile)
-                src = pl.last_tile().view(tile, c.witness_bytes)[:k]
+                src = pl.last_tile().view(tile, pl.stride)[:k, :c.witness_bytes].contiguous()
                 if backend != "nccl":
                     src = src.cpu()
                 shard.gather_witnesses(dist, src, rank, world, sink=(lambda r, off, t: None))

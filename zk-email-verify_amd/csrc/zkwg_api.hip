@@ -660,6 +660,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.segs = c->d_segs;
   B.first_seg = c->d_first_seg;
   B.wit = nullptr;
+  B.wit_stride16 = 0;
   B.status = nullptr;
   B.n_emails = (u32)n;
   B.e_first = 0;
@@ -775,7 +776,7 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   if (c->device < 0) return ZKWG_RC_NO_DEVICE;
   if (count == 0) return ZKWG_RC_OK;
   const ZkSched& s = c->s;
-  if (first + count > n || out_stride != out_W(c) * 32 || count * (u64)s.nportions > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
+  if (first + count > n || out_stride < out_W(c) * 32 || (out_stride & 15) || count * (u64)s.nportions > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
   if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_out & 15)) return ZKWG_RC_BAD_ARG;
   std::lock_guard<std::mutex> lock(c->dev_mutex);
   ZkDeviceGuard dg(c->device);
@@ -829,6 +830,7 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
     const u64 cnt = std::min(sub, count - off);
     u8* out_sub = (u8*)d_out + off * out_stride;
     B.wit = c->full_W ? (uint4*)c->d_stage : (uint4*)out_sub;
+    B.wit_stride16 = c->full_W ? s.W * 2 : out_stride / 16;
     B.e_first = (u32)(first + off);
     B.n_emails = (u32)(first + off + cnt);
     const u64 units = ((cnt + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions;

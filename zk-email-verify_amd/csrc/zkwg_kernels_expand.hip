@@ -106,7 +106,7 @@ __device__ __forceinline__ void zk_expand_body(const ZkSched& s, const ZkBufs& B
     const u32 nch = (u32)(hi - lo) * 2;          // chunks to write
    for (u32 el = el0; el < el1; ++el) {
     const u32 e = el + B.e_first;                // email index inside the prepared batch
-    uint4* __restrict__ dst = B.wit + ((u64)el * s.W + lo) * 2;
+    uint4* __restrict__ dst = B.wit + (u64)el * B.wit_stride16 + lo * 2;
     const u8* __restrict__ rec = B.in + (u64)e * s.in_stride;
     const u64* __restrict__ bits = B.bits + (u64)e * s.img_bits;
     const u32* __restrict__ small = B.small + (u64)e * s.img_small;

@@ -240,6 +240,7 @@ struct ZkBufs {
   const ZkSeg* segs;     // segment table
   const u32* first_seg;  // first segment overlapping each portion
   uint4* wit;            // output witnesses
+  u64 wit_stride16;      // distance between consecutive witnesses in 16-byte units (>= 2 W; a caller may pad it)
   int* status;           // per-email status
   u32 n_emails;          // emails covered by the image arrays / this launch
   u32 e_first;           // zk_expand: first email to expand (wit points at its witness)

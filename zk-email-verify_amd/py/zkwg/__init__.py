@@ -259,11 +259,12 @@ class Circuit:
         sp = stream.cuda_stream if stream is not None else 0
         _check(self.lib.zkwg_prepare_device(self.h, d_in.data_ptr(), n, d_status.data_ptr(), d_scratch.data_ptr(), sp))
 
-    def expand_device(self, d_in, n, d_scratch, first, count, d_out, stream=None):
-        """Phase 2: stream the witnesses of emails [first, first+count) into d_out."""
+    def expand_device(self, d_in, n, d_scratch, first, count, d_out, stream=None, out_stride=None):
+        """Phase 2: stream the witnesses of emails [first, first+count) into d_out (`out_stride` bytes apart, default
+        back to back; a caller may pad the distance, e.g. to a multiple of 4 KiB)."""
         sp = stream.cuda_stream if stream is not None else 0
         _check(self.lib.zkwg_expand_device(self.h, d_in.data_ptr(), n, d_scratch.data_ptr(), first, count,
-                                           d_out.data_ptr(), self.witness_bytes, sp))
+                                           d_out.data_ptr(), out_stride or self.witness_bytes, sp))
 
     def expand_montgomery_device(self, d_in, n, d_scratch, first, count, d_out, stream=None):
         """Phase 2 with Montgomery-form output (x * 2^256 mod r): the fused prover hand-off."""
