@@ -267,6 +267,7 @@ int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_packed_inputs, 
  * (it waits for the chain), so keep at most 16 scratch buffers in flight per handle. */
 int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails, void* d_status,
                         void* d_scratch, void* hip_stream);
+/* (out_stride: distance between consecutive witnesses in d_out_wtns, >= 32 * W and a multiple of 16) */
 int zkwg_expand_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails, const void* d_scratch,
                        uint64_t first, uint64_t count, void* d_out_wtns, uint64_t out_stride, void* hip_stream);
 
