@@ -1,5 +1,5 @@
 """Throughput of complete `--O0`-numbered witnesses (zkwg_circuit_create_full) for
-EmailVerifier(576,192): zk_expand into the `.sym` order + zk_linear_fill for the 2.4 M derived signals.
+EmailVerifier(576,192) -- or `bench_full.py 1024 1536` -- : zk_expand into a staging buffer, zk_o0_gather / zk_o0_rows.
 Needs oracle/_ref/o0_ev_576_192.* (built by __graft_entry__.build() where /root/reference exists; travels to
 the GPU box) -- a measurement aid, not part of the product."""
 import gzip
@@ -17,7 +17,8 @@ def main():
     import torch
     import zkwg
     import bench
-    base = os.path.join(ROOT, "oracle", "_ref", "o0_ev_576_192")
+    N, M = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (576, 192)
+    base = os.path.join(ROOT, "oracle", "_ref", f"o0_ev_{N}_{M}")
     meta = json.load(open(base + ".json"))
     sym = gzip.open(base + ".sym.gz", "rb").read()
     r1cs = gzip.open(base + ".r1cs.gz", "rb").read()
@@ -26,11 +27,11 @@ def main():
     out = {}
     for name, kw in (("kept-v1", {}), ("complete O0", dict(sym=sym, sym_alias=meta["alias"], r1cs=r1cs))):
         t0 = time.time()
-        c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0, **kw)
+        c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, **kw)
         t_create = time.time() - t0
-        batch, tile = 2048, 256
-        _, d_in, _ = bench.resident_inputs(torch, c, dev, 0x5A4B + 9, 64, batch, 60)
-        pl = bench.Pipeline(torch, c, dev, d_in, batch, tile, 1024, ring=2)
+        batch, tile = (2048, 256) if N <= 576 else (1024, 128)
+        _, d_in, _ = bench.resident_inputs(torch, c, dev, 0x5A4B + 9, 64, batch, 60 if M <= 192 else 1024)
+        pl = bench.Pipeline(torch, c, dev, d_in, batch, tile, min(1024, batch), ring=2)
         c.set_timing(True)
         dt = bench.timed(torch, pl.step, steps=3, warmup=1)
         summ = c.timing_summary()
