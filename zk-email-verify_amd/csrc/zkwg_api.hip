@@ -843,7 +843,7 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
     if (c->full_W) {
       // every wire of the compiled circuit from the staged kept-v1 witness: aliases copy, the rest are linear rows
       const u64 chunks = c->full_W * 2;
-      hipLaunchKernelGGL(zk_o0_gather, dim3((u32)((chunks + 255) / 256), (u32)cnt), dim3(256), 0, st, c->d_o0_desc,
+      hipLaunchKernelGGL(zk_o0_gather, dim3((u32)((chunks + 1023) / 1024), (u32)cnt), dim3(256), 0, st, c->d_o0_desc,   // 4 chunks per thread
                          c->full_W, (const u8*)c->d_stage, s.W * 32, out_sub, out_stride);
       // the other derived signals: 4 lanes per row up to ZK_O0_SHORT_ROW terms, 16 lanes per row beyond (running sums, Bits2Num ...)
       if (c->n_o0_short)

@@ -39,15 +39,25 @@ __global__ __launch_bounds__(256) void zk_r1cs_eval(const u64* __restrict__ row_
 // their aliases: 95 % of the wires); the other wires are linear rows written by zk_o0_rows.  One 16-byte chunk per
 // lane, consecutive lanes write consecutive chunks; the reads follow the circuit's own locality (the compiler numbers
 // a component's signals together).
+#define ZK_O0_UNROLL 4   // chunks per thread: the table reads, then the gathers, then the stores of all of them are in flight together
 __global__ __launch_bounds__(256) void zk_o0_gather(const u32* __restrict__ desc, u64 n_wires, const u8* __restrict__ kept,
                                                     u64 kept_stride, u8* __restrict__ out, u64 out_stride) {
-  const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * n_wires) return;
-  const u32 d = desc[c >> 1];
-  if (d == 0xfffffffeu) return;   // a linear row: zk_o0_rows writes it
   const uint4* __restrict__ kw = (const uint4*)(kept + (u64)blockIdx.y * kept_stride);
   uint4* __restrict__ o = (uint4*)(out + (u64)blockIdx.y * out_stride);
-  o[c] = kw[(u64)d * 2 + ((u32)c & 1u)];
+  const u64 c0 = (u64)blockIdx.x * (256 * ZK_O0_UNROLL) + threadIdx.x;
+  u32 d[ZK_O0_UNROLL];
+#pragma unroll
+  for (int k = 0; k < ZK_O0_UNROLL; ++k) {
+    const u64 c = c0 + (u64)k * 256;
+    d[k] = c < 2 * n_wires ? desc[c >> 1] : 0xfffffffeu;
+  }
+  uint4 v[ZK_O0_UNROLL];
+#pragma unroll
+  for (int k = 0; k < ZK_O0_UNROLL; ++k)
+    if (d[k] != 0xfffffffeu) v[k] = kw[(u64)d[k] * 2 + ((u32)(c0 + (u64)k * 256) & 1u)];
+#pragma unroll
+  for (int k = 0; k < ZK_O0_UNROLL; ++k)
+    if (d[k] != 0xfffffffeu) o[c0 + (u64)k * 256] = v[k];   // (0xfffffffe: a linear row, zk_o0_rows writes it)
 }
 
 // zk_o0_rows -- the derived signals that are not plain aliases (zkwg_full.h): LANES lanes per row stride over its
