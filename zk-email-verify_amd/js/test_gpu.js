@@ -139,7 +139,7 @@ function shaPad(msg, max) {  // packages/helpers/src/sha-utils.ts:88-111
     const fs = require('fs');
     const path = require('path');
     const kase = JSON.parse(fs.readFileSync(path.join(__dirname, '..', '..', 'tests', 'golden', 'ev_576_192_case.json')));
-    const tmpl = path.join(__dirname, '..', '..', 'oracle', 'circom', 'lib', '@zk-email', 'zk-regex-circom', 'circuits', 'common', 'body_hash_regex.circom');
+    const tmpl = path.join(__dirname, '..', 'data', 'templates', 'zk-regex-circom', 'circuits', 'common', 'body_hash_regex.circom');
     const ev0 = new z.Circuit({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody }, 0);
     const ev1 = new z.Circuit({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody, regex: tmpl }, 0);
     assert.strictEqual(ev1.witnessLen, ev0.witnessLen);
