@@ -391,3 +391,15 @@ def test_subset_coverage_template_equals_the_interpreter():
             if kept is not None:
                 assert {"main" + q for q in vals} == kept
             assert not [q for q, v in vals.items() if ref["main" + q] != v]
+
+
+def test_circomlib_from_the_include_path_equals_the_built_in_restatement():
+    """The loader reads circomlib's comparators / gates / bitify from the include path when they are there (here: the
+    oracle's restatement under oracle/circom/lib, written separately -- it also holds Num2Bits_strict, AliasCheck,
+    CompConstant ... which must parse) and falls back to the text carried by the library otherwise: same result."""
+    lib = os.path.join(ROOT, "oracle", "circom", "lib")
+    for f, t, n in ((STYLE, "SimpleRegex", 48), (os.path.join(ROOT, "tests", "golden", "regex_style", "coverage.circom"), "Coverage", 20)):
+        a = hosttest.LoadedRegex(f, n, template=t)
+        b = hosttest.LoadedRegex(f, n, include_dirs=[lib], template=t)
+        msg = bytes((7 * i + 3) % 256 for i in range(n))
+        assert a.names == b.names and a.evaluate(msg) == b.evaluate(msg)
