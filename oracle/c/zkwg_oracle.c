@@ -455,7 +455,7 @@ static fe poseidon_t(W* w, unsigned t, const fe* inputs) {
   free(pbuf);
   return stt[0];
 }
-/* PoseidonModular(n) (utils/hash.circom:50-84), n % 16 == 0 here */
+/* PoseidonModular(n) (utils/hash.circom:49-82), n % 16 == 0 here */
 static fe poseidon_modular(W* w, const fe* in, unsigned n) {
   fe out = fe_u64(0);
   for (unsigned i = 0; i < n / 16; ++i) {

@@ -611,7 +611,7 @@ def Slice(n, start, end, in_):
 
 
 def PoseidonModular(numElements, in_):
-    """utils/hash.circom:50-84: Poseidon(16) per chunk, chained through Poseidon(2)."""
+    """utils/hash.circom:49-82: Poseidon(16) per chunk, chained through Poseidon(2)."""
     from . import poseidon as pos
     c = Comp(f"PoseidonModular({numElements})")
     out = c.out("out")

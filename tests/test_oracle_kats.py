@@ -148,7 +148,7 @@ def test_remove_soft_line_breaks_test_ts():
 
 def test_poseidon16_known_vector_and_modular_chain():
     # circomlibjs' own test vector for 16 inputs pins the regenerated t = 17 constants used by
-    # PoseidonModular (utils/hash.circom:50-84); the chain mirrors helpers/src/hash.ts:19-52.
+    # PoseidonModular (utils/hash.circom:49-82); the chain mirrors helpers/src/hash.ts:19-52.
     from oracle.pyref import poseidon
     assert poseidon.poseidon_hash(list(range(1, 17))) == \
         9989051620750914585850546081941653841776809718687451684622678807385399211877

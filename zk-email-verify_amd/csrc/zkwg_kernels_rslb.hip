@@ -1,6 +1,6 @@
 // RemoveSoftLineBreaks(maxBody) witness values (template flag removeSoftLineBreaks,
 // packages/circuits/email-verifier.circom:148-156, helpers/remove-soft-line-breaks.circom:14-126):
-//   r = PoseidonModular(2*maxBody)(encoded || decoded)   (utils/hash.circom:50-84)
+//   r = PoseidonModular(2*maxBody)(encoded || decoded)   (utils/hash.circom:49-82)
 //   random-linear-combination sums sumEnc / sumDec over powers of r, final IsEqual.
 // This is the one genuinely Fr-heavy block of the path (about 1.2 M field products per email at
 // maxBody = 1536), and it is embarrassingly parallel in its first stage:

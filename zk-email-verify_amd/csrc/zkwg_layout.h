@@ -351,7 +351,7 @@ static inline void zk_walk_bh_regex(ZkWalker& w, const std::string& p, const ZkS
 
 // ------------------------------------------------------------------ RemoveSoftLineBreaks
 // helpers/remove-soft-line-breaks.circom:14-126 as `main.qpEncodingChecker` (email-verifier.circom:148-156);
-// PoseidonModular / Poseidon from utils/hash.circom:50-84 and circomlib poseidon.circom [EXT].
+// PoseidonModular / Poseidon from utils/hash.circom:49-82 and circomlib poseidon.circom [EXT].
 static inline void zk_alloc_rslb(ZkWalker& w, ZkSched& s, u32 M) {
   s.rs_nch = 2 * M / 16;
   s.f_rs_chunk = w.alloc_fr(s.rs_nch);

@@ -1,4 +1,4 @@
-// Poseidon(t-1) for PoseidonModular (packages/circuits/utils/hash.circom:50-84; circomlib
+// Poseidon(t-1) for PoseidonModular (packages/circuits/utils/hash.circom:49-82; circomlib
 // poseidon.circom [EXT]): x^5 S-box over BN254 Fr, 8 full + R_P partial rounds, one permutation per
 // LANE (not per wave): RemoveSoftLineBreaks hashes 2*maxBody/16 independent 16-element chunks per
 // email, so the batch supplies hundreds of thousands of independent permutations.

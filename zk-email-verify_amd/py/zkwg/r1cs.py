@@ -785,7 +785,7 @@ def remove_soft_line_breaks(g, pre, enc, dec):
     Returns isValid as a linear combination."""
     M = len(enc)
     slot = g.slot
-    # r = PoseidonModular(2M)(encoded || decoded) (utils/hash.circom:50-84)
+    # r = PoseidonModular(2M)(encoded || decoded) (utils/hash.circom:49-82)
     data = list(enc) + list(dec)
     r = None
     for c in range(len(data) // 16):
