@@ -172,6 +172,9 @@ int zkwg_circuit_create_regex(const zkwg_config* cfg, int device, const zkwg_reg
  * values, gates on the evaluator's 64-bit path (handles created by zkwg_circuit_create_regex) */
 int zkwg_regex_info(const zkwg_circuit_t* c, uint64_t out[8]);
 int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness); /* layout-only handles: host evaluation */
+/* layout-only handles of a fully numbered circuit: what zk_o0_gather / zk_o0_rows do on the device, on the host --
+ * `out` (32 * zkwg_witness_len bytes) from one compact kept-v1 witness (the default layout of the same configuration) */
+int zkwg_o0_gather_host(const zkwg_circuit_t* c, const uint8_t* kept_witness, uint8_t* out);
 const char* zkwg_last_error(void);   /* detail of the calling thread's last ZKWG_RC_BAD_CONFIG */
 void zkwg_circuit_destroy(zkwg_circuit_t* c);
 

@@ -47,6 +47,7 @@ def test_rsa_main_complete_witness_from_sym_and_r1cs_on_the_host():
     assert st == [0]
     full = _host_complete(c, wit[0])
     assert hashlib.sha256(full).hexdigest() == meta["witness_sha256"]
+    assert c.o0_gather_host(wit[0]) == full      # the wire table + rows the device kernels use (zk_o0_gather / zk_o0_rows)
     for k, v in meta["sample"].items():
         assert int.from_bytes(full[32 * int(k):32 * int(k) + 32], "little") == int(v)
     # without the .r1cs the same file is refused: it numbers signals the schedule does not produce
@@ -84,6 +85,7 @@ def test_email_verifier_complete_witness_on_the_host():
     wit, st, W = coracle.calculate(0, 576, 192, 0, [meta["inputs"]], threads=1)
     assert st == [0] and W == 735631
     assert hashlib.sha256(_host_complete(c, wit[0])).hexdigest() == meta["witness_sha256"]
+    assert hashlib.sha256(c.o0_gather_host(wit[0])).hexdigest() == meta["witness_sha256"]
 
 
 @pytest.mark.gpu

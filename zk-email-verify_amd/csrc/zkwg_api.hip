@@ -448,6 +448,22 @@ int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness) {
     ((Fr*)witness)[Pn.dst[r]] = zk_linear_row(Pn.row_ptr.data(), Pn.src.data(), Pn.coef.data(), Pn.kind.data(), r, (const Fr*)witness);
   return ZKWG_RC_OK;
 }
+// layout-only handles: the device path of a fully numbered circuit (zk_o0_gather / zk_o0_rows) on the host -- every
+// wire of the file from one compact kept-v1 witness through the wire table (tests)
+int zkwg_o0_gather_host(const zkwg_circuit_t* c, const uint8_t* kept_witness, uint8_t* out) {
+  if (!c || !kept_witness || !out) return ZKWG_RC_BAD_ARG;
+  if (!c->full_W || c->o0_desc.size() != c->full_W) return ZKWG_RC_BAD_CONFIG;
+  const ZkLinPlan& Pn = c->lin_host;
+  const Fr* kw = (const Fr*)kept_witness;
+  Fr* o = (Fr*)out;
+  for (u64 w = 0; w < c->full_W; ++w) {
+    const u32 d = c->o0_desc[w];
+    if (d != 0xfffffffeu) o[w] = kw[d];
+  }
+  for (u32 r : c->o0_long)   // [short rows | long rows]
+    o[Pn.dst[r]] = zk_linear_row(Pn.row_ptr.data(), c->o0_src.data(), Pn.coef.data(), Pn.kind.data(), r, kw);
+  return ZKWG_RC_OK;
+}
 int zkwg_image_layout(const zkwg_circuit_t* c, uint64_t n, zkwg_image_layout_t* o) {
   if (!c || !o) return ZKWG_RC_BAD_ARG;
   const ZkSched& s = c->s;

@@ -327,6 +327,13 @@ class Circuit:
         self.lib.zkwg_layout_map(self.h, out, n)
         return [None if v == 0xFFFFFFFF else v for v in out]
 
+    def o0_gather_host(self, kept_witness):
+        """layout-only handle of a fully numbered circuit: the complete witness from one kept-v1 witness through the
+        wire table the device kernels use (zkwg_o0_gather_host)."""
+        out = (C.c_uint8 * self.witness_bytes)()
+        _check(self.lib.zkwg_o0_gather_host(self.h, bytes(kept_witness), out))
+        return bytes(out)
+
     def linear_complete_host(self, witness):
         """layout-only handle of a fully numbered circuit: derive the non-produced signals of one host witness
         (bytearray of 32 W bytes whose produced slots are filled) in place."""

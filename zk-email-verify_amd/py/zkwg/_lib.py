@@ -74,6 +74,7 @@ def load():
         "zkwg_segment_table": (u64, [vp, vp, u64]),
         "zkwg_inverse_table_half": (u32, [vp]),
         "zkwg_linear_complete_host": (i32, [vp, vp]),
+        "zkwg_o0_gather_host": (i32, [vp, vp, vp]),
         "zkwg_last_error": (C.c_char_p, []),
         "zkwg_circuit_destroy": (None, [vp]),
         "zkwg_witness_len": (u64, [vp]),
@@ -127,7 +128,7 @@ def load():
 
 
 EXPORTS = [
-    "zkwg_abi_version", "zkwg_strerror", "zkwg_circuit_create", "zkwg_circuit_create_sym", "zkwg_circuit_create_full", "zkwg_circuit_create_regex", "zkwg_regex_info", "zkwg_linear_rows", "zkwg_layout_map", "zkwg_image_layout", "zkwg_segment_table", "zkwg_inverse_table_half", "zkwg_linear_complete_host", "zkwg_last_error", "zkwg_circuit_destroy",
+    "zkwg_abi_version", "zkwg_strerror", "zkwg_circuit_create", "zkwg_circuit_create_sym", "zkwg_circuit_create_full", "zkwg_circuit_create_regex", "zkwg_regex_info", "zkwg_linear_rows", "zkwg_layout_map", "zkwg_image_layout", "zkwg_segment_table", "zkwg_inverse_table_half", "zkwg_linear_complete_host", "zkwg_o0_gather_host", "zkwg_last_error", "zkwg_circuit_destroy",
     "zkwg_witness_len", "zkwg_witness_bytes", "zkwg_num_public", "zkwg_input_stride",
     "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_pack_input", "zkwg_pack_field", "zkwg_pack_masks", "zkwg_pack_decoded_body", "zkwg_calculate_batch",
     "zkwg_generate_inputs_device", "zkwg_alloc_pinned", "zkwg_free_pinned", "zkwg_calculate_batch_device", "zkwg_prepare_device", "zkwg_expand_device", "zkwg_expand_montgomery_device", "zkwg_set_prepare_throttle", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_timing_summary", "zkwg_num_kernels",
