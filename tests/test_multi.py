@@ -63,3 +63,92 @@ def test_multi_one_device_equals_single_device_path_and_table():
     # table only (no witnesses delivered)
     _, st2, rows2 = mc.calculate_batch_host(recs, want_witness=False)
     assert st2 == status and rows2[0] == rows[0]
+
+
+def _stub_lib():
+    """tests/native/librccl_stub.so: the six RCCL entry points over hipMemcpyAsync (built by __graft_entry__.build())."""
+    import subprocess
+    so = os.path.join(ROOT, "tests", "native", "librccl_stub.so")
+    src = os.path.join(ROOT, "tests", "native", "rccl_stub.cpp")
+    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-shared", "-fPIC", "-x", "hip",
+                               "--offload-arch=gfx950", src, "-o", so])
+    return so
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [11, 1, 2])
+def test_multi_two_shards_on_one_gpu_gather_through_the_rccl_entry_points(n, monkeypatch):
+    """The n_dev > 1 branch of zkwg_calculate_batch_multi (a host thread per shard, ncclGroupStart / ncclRecv /
+    ncclSend / ncclGroupEnd gather of the result table on devices[0]) with devices = [0, 0] and ZKWG_RCCL_LIB
+    pointing at the hipMemcpyAsync stand-in: uneven shards (11 -> 6 + 5), an empty shard (1 -> 1 + 0) and
+    one email each.  Witnesses, statuses and the gathered table equal the single-device path."""
+    import zkwg
+    so = _stub_lib()
+    monkeypatch.setenv("ZKWG_RCCL_LIB", so)
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", "ev_576_192_case.json")))
+    N, M = case["maxHeader"], case["maxBody"]
+    mc = zkwg.MultiCircuit([0, 0], main_kind=zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M)
+    assert mc.n_devices == 2
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    good = c.pack(case["input"])
+    bad_inp = dict(case["input"], emailHeader=list(case["input"]["emailHeader"]))
+    bad_inp["emailHeader"][10] = str(int(bad_inp["emailHeader"][10]) ^ 1)
+    bad = c.pack(bad_inp)
+    # tampered emails on both sides of the shard boundary (n = 11: shards [0,6) and [6,11))
+    recs = b"".join(bad if i in (2, 7) else good for i in range(n))
+    expect = [4 if i in (2, 7) else 0 for i in range(n)]
+    stub = C.CDLL(so)
+    stub.zk_stub_pairs.restype = C.c_ulong
+    pairs0 = stub.zk_stub_pairs()
+    wit, status, rows = mc.calculate_batch_host(recs, max_tile=4)
+    wit1, status1 = c.calculate_batch_host(recs)
+    assert status == status1 == expect
+    wb = c.witness_bytes
+    for i in range(n):
+        assert rows[i][0] == expect[i]
+        if expect[i] == 0:
+            assert wit[i * wb:(i + 1) * wb] == wit1[i * wb:(i + 1) * wb]
+            assert hashlib.sha256(wit[i * wb:(i + 1) * wb]).hexdigest() == case["witnessSha256"]
+            assert rows[i] == (0, int(case["pubkeyHash"]), int(case["shaHi"]), int(case["shaLo"]))
+    # the rows of shard 1 really travelled through the send/recv pair (none for an empty second shard)
+    assert stub.zk_stub_pairs() - pairs0 == (1 if n >= 2 else 0)
+    # table only
+    _, st2, rows2 = mc.calculate_batch_host(recs, want_witness=False)
+    assert st2 == status and rows2 == rows
+
+
+def test_multi_create_reports_a_missing_rccl_library(monkeypatch):
+    """n_dev > 1 with ZKWG_RCCL_LIB naming a file that does not exist: a clean error, no crash (CPU: creation
+    already fails for lack of a GPU; both are ZkwgError)."""
+    import zkwg
+    monkeypatch.setenv("ZKWG_RCCL_LIB", "/nonexistent/librccl.so")
+    with pytest.raises(zkwg.ZkwgError):
+        zkwg.MultiCircuit([0, 0], main_kind=zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """bench.py's N > 1 path end to end on one GPU: two torch.distributed ranks forced onto cuda:0, gloo instead of
+    RCCL (two ranks cannot share a GPU under RCCL), result-table gather + 2 gathered witnesses per rank and step
+    inside the timed region.  The driver's 8-GPU run must not be the first execution of this code."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ZKWG_BENCH_FORCE_DEVICE="0", ZKWG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "512", "--steps", "1",
+           "--warmup", "1", "--gather-wtns", "2", "--distinct", "64", "--cpu-sample", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["steps"] == 1 and res["scaling"] == "weak"
+    assert res["config"]["batch_per_gpu"] == 512
+    assert res["value"] > 0
+    assert res["gathered_table"] == {"rows": 1024, "status_nonzero": 0, "rows_with_outputs": 1024}
+    assert "2 wtns/rank/step gathered" in res["config"]["parallelism"]

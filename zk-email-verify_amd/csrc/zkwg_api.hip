@@ -10,7 +10,6 @@
 #include <map>
 #include <thread>
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <algorithm>
 #include "../../include/zkwg.h"
 #include "zkwg_kernels.h"
@@ -88,6 +87,7 @@ struct zkwg_circuit {
   u64 prep_launches;
   bool ev_valid, prep_valid;
   int expand_threads;
+  int expand_v2;   // 1 (default): LDS-staged zk_expand2; 0: the direct-store kernels of rounds 1-2 (ZKWG_EXPAND_V=1)
   int emails_per_wg;
   int rsa_wgs_per_cu;
 };
@@ -130,6 +130,7 @@ static void build_inv_table(u32 inv_half, std::vector<Fr>& tab) {
   }
 }
 
+static u64 align256(u64 x) { return (x + 255) & ~255ull; }
 extern "C" int zk_misc_init_tables(void);
 
 extern "C" {
@@ -172,6 +173,8 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   c->expand_threads = 256;
   if (const char* v = getenv("ZKWG_PORTION")) portion = (u32)atoi(v);
   if (const char* v = getenv("ZKWG_EXPAND_THREADS")) c->expand_threads = atoi(v);
+  c->expand_v2 = getenv("ZKWG_EXPAND_V") ? (atoi(getenv("ZKWG_EXPAND_V")) != 1) : 1;
+  if (c->expand_v2 && portion > 8192) portion = 8192;   // 4 bytes of LDS per slot
   c->emails_per_wg = 1;
   c->xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
   c->rsa_wgs_per_cu = 0;
@@ -394,7 +397,6 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   return ZKWG_RC_OK;
 }
 
-static u64 align256(u64 x) { return (x + 255) & ~255ull; }
 // no C++ exception may cross the C ABI (ctypes / N-API callers would abort)
 static int create_guarded(const zkwg_config* cfg, int device, const char* sym_text, uint64_t sym_len,
                           const char* alias_text, uint64_t alias_len, zkwg_circuit_t** out,
@@ -464,16 +466,26 @@ int zkwg_o0_gather_host(const zkwg_circuit_t* c, const uint8_t* kept_witness, ui
     o[Pn.dst[r]] = zk_linear_row(Pn.row_ptr.data(), c->o0_src.data(), Pn.coef.data(), Pn.kind.data(), r, kw);
   return ZKWG_RC_OK;
 }
+// scratch buffer of an n-email batch: [SHA chaining states | bits | small | fr (+256) | Montgomery copies (fr + limbs)]
+struct ZkScratchLayout { u64 off_hst, off_bits, off_small, off_fr, off_frm, total; };
+static ZkScratchLayout scratch_layout(const ZkSched& s, u64 n) {
+  ZkScratchLayout L;
+  u64 off = 0;
+  L.off_hst = off; off += align256(n * (u64)s.hstates_per_email * 32);
+  L.off_bits = off; off += align256(n * (u64)s.img_bits * 8);
+  L.off_small = off; off += align256(n * (u64)s.img_small * 4);
+  L.off_fr = off; off += align256(n * (u64)s.img_fr * 32) + 256;
+  L.off_frm = off; off += align256(n * (u64)(s.img_fr + ZK_MONT_LIMBS) * 32);
+  L.total = off;
+  return L;
+}
 int zkwg_image_layout(const zkwg_circuit_t* c, uint64_t n, zkwg_image_layout_t* o) {
   if (!c || !o) return ZKWG_RC_BAD_ARG;
   const ZkSched& s = c->s;
   o->hstate_words = (u64)s.hstates_per_email * 8; o->bits_words = s.img_bits; o->small_words = s.img_small; o->fr_elems = s.img_fr;
-  u64 off = 0;
-  o->off_hstates = off; off += align256(n * (u64)s.hstates_per_email * 32);
-  o->off_bits = off; off += align256(n * (u64)s.img_bits * 8);
-  o->off_small = off; off += align256(n * (u64)s.img_small * 4);
-  o->off_fr = off; off += align256(n * (u64)s.img_fr * 32) + 256;
-  o->total_bytes = off;
+  const ZkScratchLayout L = scratch_layout(s, n);
+  o->off_hstates = L.off_hst; o->off_bits = L.off_bits; o->off_small = L.off_small; o->off_fr = L.off_fr;
+  o->total_bytes = L.total;
   return ZKWG_RC_OK;
 }
 uint64_t zkwg_segment_table(const zkwg_circuit_t* c, zkwg_segment* out, uint64_t cap) {
@@ -527,11 +539,7 @@ uint64_t zkwg_input_offset(const zkwg_circuit_t* c, int field) {
   if (field < 0 || field >= ZKWG_IN_NFIELDS) return (uint64_t)-1;
   return c->s.in_off[field];
 }
-uint64_t zkwg_scratch_bytes(const zkwg_circuit_t* c, uint64_t n) {
-  const ZkSched& s = c->s;
-  return align256(n * (u64)s.hstates_per_email * 32) + align256(n * (u64)s.img_bits * 8) +
-         align256(n * (u64)s.img_small * 4) + align256(n * (u64)s.img_fr * 32) + 256;
-}
+uint64_t zkwg_scratch_bytes(const zkwg_circuit_t* c, uint64_t n) { return scratch_layout(c->s, n).total; }
 
 int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header, uint32_t header_len,
                     const uint8_t* body, uint32_t body_len, const uint8_t* pre, const uint8_t* pubkey,
@@ -659,11 +667,14 @@ int zkwg_timing_summary(zkwg_circuit_t* c, int which, float* total_ms, uint32_t*
 static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n, void* d_scratch) {
   const ZkSched& s = c->s;
   u8* scr = (u8*)d_scratch;
+  const ZkScratchLayout L = scratch_layout(s, n);
   B.in = (const u8*)d_in;
-  B.hst = (u32*)scr; scr += align256(n * (u64)s.hstates_per_email * 32);
-  B.bits = (u64*)scr; scr += align256(n * (u64)s.img_bits * 8);
-  B.small = (u32*)scr; scr += align256(n * (u64)s.img_small * 4);
-  B.frv = (Fr*)scr;
+  B.hst = (u32*)(scr + L.off_hst);
+  B.bits = (u64*)(scr + L.off_bits);
+  B.small = (u32*)(scr + L.off_small);
+  B.frv = (Fr*)(scr + L.off_fr);
+  B.frm = (Fr*)(scr + L.off_frm);
+  B.pflags = c->d_first_seg ? c->d_first_seg + s.nportions : nullptr;
   B.invtab = c->d_invtab;
   B.pos_c = c->d_pos;
   B.pos_m = c->d_pos ? c->d_pos + c->pos_dense_off : nullptr;
@@ -799,20 +810,25 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   if (!dg.ok) return ZKWG_RC_HIP_ERROR;
   hipStream_t st = (hipStream_t)hip_stream;
   if (mont) {
-    if (s.portion > ZK_PORTION_DEFAULT) return ZKWG_RC_BAD_CONFIG;   // the LDS stage holds 2048 slots
-    if (!c->d_rtab) {
-      // v * R mod r for v < 65536 (2 MiB), built once per handle
+    if (!c->expand_v2 && s.portion > ZK_PORTION_DEFAULT) return ZKWG_RC_BAD_CONFIG;
+    if (!c->d_rtab || !c->d_invtab_m) {
+      // v * R mod r for v < 65536 (2 MiB) and the inverse table in Montgomery form, built once per handle and
+      // published together (a half-built pair must never be seen by a later call)
       std::vector<Fr> tab(65536);
       Fr acc = fr_zero();
       const Fr Rm = fr_R();
       for (u32 v = 0; v < 65536; ++v) { tab[v] = acc; acc = fr_add(acc, Rm); }
-      if (hipMalloc((void**)&c->d_rtab, tab.size() * sizeof(Fr)) != hipSuccess) return ZKWG_RC_OOM;
-      if (hipMemcpy(c->d_rtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) return ZKWG_RC_HIP_ERROR;
       std::vector<Fr> inv;
       build_inv_table(s.inv_half, inv);
       for (Fr& x : inv) x = fr_to_mont(x);
-      if (hipMalloc((void**)&c->d_invtab_m, inv.size() * sizeof(Fr)) != hipSuccess) return ZKWG_RC_OOM;
-      if (hipMemcpy(c->d_invtab_m, inv.data(), inv.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+      Fr *d_r = nullptr, *d_i = nullptr;
+      int rc = ZKWG_RC_OK;
+      if (hipMalloc((void**)&d_r, tab.size() * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&d_i, inv.size() * sizeof(Fr)) != hipSuccess) rc = ZKWG_RC_OOM;
+      else if (hipMemcpy(d_r, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy(d_i, inv.data(), inv.size() * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
+      if (rc != ZKWG_RC_OK) { hipFree(d_r); hipFree(d_i); return rc; }
+      hipFree(c->d_rtab); hipFree(c->d_invtab_m);
+      c->d_rtab = d_r; c->d_invtab_m = d_i;
     }
   }
   // Fully numbered circuit: zk_expand writes the kept-v1 witnesses into a staging buffer of the handle and the gather
@@ -851,7 +867,15 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
     B.n_emails = (u32)(first + off + cnt);
     const u64 units = ((cnt + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions;
     const dim3 grid((u32)units);
-    if (mont) hipLaunchKernelGGL(zk_expand_mont_256, grid, dim3(256), 0, st, s, B);
+    if (c->expand_v2) {
+      // LDS-staged kernel (zkwg_kernels_expand2.hip): 4 bytes of LDS per slot of the portion
+      if (mont) {
+        const u64 conv = cnt * (u64)(s.img_fr + ZK_MONT_LIMBS);
+        hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, s, B);
+        hipLaunchKernelGGL(zk_expand2_mont, grid, dim3(256), s.portion * 4u, st, s, B);
+      } else hipLaunchKernelGGL(zk_expand2, grid, dim3(256), s.portion * 4u, st, s, B);
+    }
+    else if (mont) hipLaunchKernelGGL(zk_expand_mont_256, grid, dim3(256), 0, st, s, B);
     else if (c->expand_threads == 64) hipLaunchKernelGGL(zk_expand_wave, dim3((u32)((units + 3) / 4)), dim3(256), 0, st, s, B);
     else if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
     else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
@@ -1049,19 +1073,23 @@ uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap) {
 // ------------------------------------------------------------------ multi-device
 // One handle + one host thread per GPU, contiguous shards, no data-path collective.  The only exchange is
 // the gather of the 100-byte/email result table {status, pubkeyHash, shaHi, shaLo} on devices[0] over
-// RCCL (ncclGroupStart + ncclSend / ncclRecv over xGMI).  RCCL is opened with dlopen when n_dev > 1, so a
-// single-GPU deployment carries no dependency on it.
+// RCCL (ncclGroupStart + ncclSend / ncclRecv over xGMI).  RCCL is opened with dlopen when n_dev > 1 (and its header
+// is not included), so a single-GPU deployment carries no dependency on it.
+// The few RCCL declarations the gather needs (the library is opened with dlopen, so a single-GPU deployment
+// neither links nor includes RCCL): nccl.h's ncclComm_t, ncclResult_t (0 = ncclSuccess), ncclDataType_t (1 = ncclUint8).
+typedef struct ncclComm* zk_nccl_comm_t;
+enum { ZK_NCCL_SUCCESS = 0, ZK_NCCL_UINT8 = 1 };
 struct zkwg_multi {
   std::vector<zkwg_circuit_t*> h;
   std::vector<int> dev;
-  std::vector<ncclComm_t> comm;
+  std::vector<zk_nccl_comm_t> comm;
   void* rccl = nullptr;
-  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*CommInitAll)(zk_nccl_comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(zk_nccl_comm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, zk_nccl_comm_t, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, zk_nccl_comm_t, hipStream_t) = nullptr;
 };
 
 void zkwg_shard_range(uint64_t n, int n_shards, int i, uint64_t* first, uint64_t* count) {
@@ -1091,9 +1119,15 @@ int zkwg_multi_create(const zkwg_config* cfg, const int* devices, int n_dev, zkw
     if (rc == ZKWG_RC_OK) { m->h.push_back(c); m->dev.push_back(devices[i]); }
   }
   if (rc == ZKWG_RC_OK && n_dev > 1) {
-    m->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!m->rccl) m->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!m->rccl) { g_last_error = "librccl.so could not be loaded (needed for the result-table gather with n_dev > 1)"; rc = ZKWG_RC_BAD_CONFIG; }
+    // ZKWG_RCCL_LIB names the library (a deployment's own build; the single-GPU test of this branch loads a
+    // stand-in that implements the six calls with hipMemcpyAsync, tests/native/rccl_stub.cpp)
+    const char* lib = getenv("ZKWG_RCCL_LIB");
+    if (lib && *lib) m->rccl = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
+    else {
+      m->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+      if (!m->rccl) m->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!m->rccl) { g_last_error = std::string(lib && *lib ? lib : "librccl.so") + " could not be loaded (needed for the result-table gather with n_dev > 1)"; rc = ZKWG_RC_BAD_CONFIG; }
     else {
       m->CommInitAll = (decltype(m->CommInitAll))dlsym(m->rccl, "ncclCommInitAll");
       m->CommDestroy = (decltype(m->CommDestroy))dlsym(m->rccl, "ncclCommDestroy");
@@ -1105,7 +1139,7 @@ int zkwg_multi_create(const zkwg_config* cfg, const int* devices, int n_dev, zkw
         g_last_error = "librccl.so lacks a required symbol"; rc = ZKWG_RC_BAD_CONFIG;
       } else {
         m->comm.assign(n_dev, nullptr);
-        if (m->CommInitAll(m->comm.data(), n_dev, devices) != ncclSuccess) { m->comm.clear(); g_last_error = "ncclCommInitAll failed"; rc = ZKWG_RC_HIP_ERROR; }
+        if (m->CommInitAll(m->comm.data(), n_dev, devices) != ZK_NCCL_SUCCESS) { m->comm.clear(); g_last_error = "ncclCommInitAll failed"; rc = ZKWG_RC_HIP_ERROR; }
       }
     }
   }
@@ -1144,6 +1178,8 @@ int zkwg_calculate_batch_multi(zkwg_multi_t* m, const uint8_t* packed, uint64_t 
               hipStreamSynchronize(st) == hipSuccess;
     if (!ok) rcs[i] = ZKWG_RC_HIP_ERROR;
   };
+  int caller_dev = -1;
+  if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;   // worker(0) and the gather change the calling thread's device
   {
     std::vector<std::thread> th;
     for (int i = 1; i < nd; ++i) th.emplace_back(worker, i);
@@ -1159,18 +1195,22 @@ int zkwg_calculate_batch_multi(zkwg_multi_t* m, const uint8_t* packed, uint64_t 
     if (rc == ZKWG_RC_OK) {
       hipStream_t s0 = m->h[0]->own_stream;
       bool ok = cnt[0] == 0 || hipMemcpyAsync(d_all, d_tab[0], cnt[0] * 100, hipMemcpyDeviceToDevice, s0) == hipSuccess;
-      if (nd > 1) {
-        ok = ok && m->GroupStart() == ncclSuccess;
-        for (int i = 1; i < nd && ok; ++i) {
-          if (cnt[i] == 0) continue;
-          ok = m->Recv(d_all + first[i] * 100, cnt[i] * 100, ncclUint8, i, m->comm[0], s0) == ncclSuccess &&
-               m->Send(d_tab[i], cnt[i] * 100, ncclUint8, 0, m->comm[i], m->h[i]->own_stream) == ncclSuccess;
+      if (nd > 1 && ok) {
+        ok = m->GroupStart() == ZK_NCCL_SUCCESS;
+        if (ok) {
+          // once a group is open it is always closed, whatever the calls inside returned
+          for (int i = 1; i < nd && ok; ++i) {
+            if (cnt[i] == 0) continue;
+            ok = m->Recv(d_all + first[i] * 100, cnt[i] * 100, ZK_NCCL_UINT8, i, m->comm[0], s0) == ZK_NCCL_SUCCESS &&
+                 m->Send(d_tab[i], cnt[i] * 100, ZK_NCCL_UINT8, 0, m->comm[i], m->h[i]->own_stream) == ZK_NCCL_SUCCESS;
+          }
+          ok = (m->GroupEnd() == ZK_NCCL_SUCCESS) && ok;
         }
-        ok = ok && m->GroupEnd() == ncclSuccess;
-        for (int i = 1; i < nd && ok; ++i) { hipSetDevice(m->dev[i]); ok = hipStreamSynchronize(m->h[i]->own_stream) == hipSuccess; }
-        hipSetDevice(m->dev[0]);
+        for (int i = 1; i < nd; ++i) { if (hipSetDevice(m->dev[i]) != hipSuccess || hipStreamSynchronize(m->h[i]->own_stream) != hipSuccess) ok = false; }
+        if (hipSetDevice(m->dev[0]) != hipSuccess) ok = false;
       }
-      ok = ok && hipMemcpyAsync(table, d_all, n * 100, hipMemcpyDeviceToHost, s0) == hipSuccess && hipStreamSynchronize(s0) == hipSuccess;
+      ok = ok && hipMemcpyAsync(table, d_all, n * 100, hipMemcpyDeviceToHost, s0) == hipSuccess;
+      if (hipStreamSynchronize(s0) != hipSuccess) ok = false;
       if (!ok) rc = ZKWG_RC_HIP_ERROR;
     }
     if (d_all) hipFree(d_all);
@@ -1178,6 +1218,7 @@ int zkwg_calculate_batch_multi(zkwg_multi_t* m, const uint8_t* packed, uint64_t 
   for (int i = 0; i < nd; ++i) {
     if (d_rows[i] || d_tab[i] || d_st[i]) { hipSetDevice(m->dev[i]); hipFree(d_rows[i]); hipFree(d_tab[i]); hipFree(d_st[i]); }
   }
+  if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
   return rc;
 }
 

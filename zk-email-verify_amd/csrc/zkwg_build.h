@@ -9,6 +9,50 @@
 #include "../../include/zkwg.h"
 #include "zkwg_layout.h"
 
+// Tables derived from the final segment list: the first segment of every portion, the per-segment reciprocal of
+// the type's period (so that zk_expand divides with one multiply; only set when exact over the segment's range)
+// and the per-portion flags of zk_expand's store phase.
+static inline bool zk_seg_is_immediate(const ZkSeg& g) {
+  switch (g.type) {
+    case ZSEG_BITS: case ZSEG_SHA_SP: case ZSEG_SHA_T1: case ZSEG_SHA_T2: case ZSEG_IN8: case ZSEG_IN8MASK:
+    case ZSEG_IN8BITS: case ZSEG_LTBITS: case ZSEG_B64BITS: case ZSEG_HOLE: return true;
+    case ZSEG_DFA: return g.a != ZDFA_EQ;
+    case ZSEG_RSLB: return g.a != ZRS_EQ;
+    default: return false;
+  }
+}
+static inline u32 zk_seg_period(const ZkSeg& g) {
+  switch (g.type) {
+    case ZSEG_BITS: return g.a;
+    case ZSEG_SEL: return 3u * g.a;
+    case ZSEG_LTBITS: return g.a + 1u;
+    case ZSEG_REGSEL: return g.a + 7u;
+    case ZSEG_VSHIFT: return g.a;
+    default: return 0;
+  }
+}
+static inline void zk_finish_tables(ZkSched& s, std::vector<ZkSeg>& segs, std::vector<u32>& first_seg) {
+  for (ZkSeg& g : segs) {
+    g.pad = 0;
+    const u64 d = zk_seg_period(g);
+    if (d < 2) continue;
+    const u64 rmax = (u64)g.r0 + g.nslots;
+    if ((d & (d - 1)) == 0) { g.pad = (u32)((1ull << 32) / d); continue; }
+    const u64 m = (1ull << 32) / d + 1, e = m * d - (1ull << 32);
+    if (rmax * e < (1ull << 32)) g.pad = (u32)m;
+  }
+  first_seg.assign((size_t)s.nportions * 2, 0);   // [first segment of portion p | flags of portion p]
+  u32 si = 0;
+  for (u32 p = 0; p < s.nportions; ++p) {
+    const u64 slot0 = (u64)p * s.portion, slot1 = std::min<u64>(s.W, slot0 + s.portion);
+    while (si + 1 < s.nsegs && segs[si].slot + segs[si].nslots <= slot0) ++si;
+    first_seg[p] = si;
+    bool pure = true;
+    for (u32 j = si; j < s.nsegs && segs[j].slot < slot1; ++j) pure = pure && zk_seg_is_immediate(segs[j]);
+    first_seg[s.nportions + p] = pure ? 1u : 0u;
+  }
+}
+
 static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& segs,
                         std::vector<u32>& first_seg, u32 portion = ZK_PORTION_DEFAULT, const zkc::Net* net = nullptr) {
   memset(&s, 0, sizeof(s));
@@ -104,13 +148,7 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
   s.nsegs = (u32)segs.size();
   s.portion = portion;
   s.nportions = (u32)((s.W + portion - 1) / portion);
-  first_seg.assign(s.nportions, 0);
-  u32 si = 0;
-  for (u32 p = 0; p < s.nportions; ++p) {
-    u64 slot0 = (u64)p * portion;
-    while (si + 1 < s.nsegs && segs[si].slot + segs[si].nslots <= slot0) ++si;
-    first_seg[p] = si;
-  }
+  zk_finish_tables(s, segs, first_seg);
   return true;
 }
 
@@ -327,13 +365,7 @@ static bool zk_remap_segments(ZkSched& s, std::vector<ZkSeg>& segs, std::vector<
   s.W = L.W;
   s.nsegs = (u32)segs.size();
   s.nportions = (u32)((s.W + s.portion - 1) / s.portion);
-  first_seg.assign(s.nportions, 0);
-  u32 si = 0;
-  for (u32 p = 0; p < s.nportions; ++p) {
-    const u64 slot0 = (u64)p * s.portion;
-    while (si + 1 < s.nsegs && segs[si].slot + segs[si].nslots <= slot0) ++si;
-    first_seg[p] = si;
-  }
+  zk_finish_tables(s, segs, first_seg);
   return true;
 }
 

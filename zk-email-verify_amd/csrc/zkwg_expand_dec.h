@@ -1,0 +1,301 @@
+// Slot decoders of zk_expand: how one witness slot derives from the compact image / input record.
+//
+// A decoder maps (segment, logical index r) to a 32-bit CODE:
+//   bit 31 clear : the slot's value is the code itself (a non-negative integer below 2^31) -- > 95 % of the
+//                  EmailVerifier witness (single bits, bytes, counters);
+//   bit 31 set   : a reference, type in bits 30..28, payload in bits 27..0 -- the 32 bytes are fetched by the
+//                  store loop (genuine field elements, table inverses, 128-bit limbs ...).
+// zk_expand runs the decoders into LDS (4 bytes per slot) and then streams the portion out with a
+// fill-shaped store loop; the numbered-circuit (`--O0`) expansion calls the same decoders per wire through
+// a descriptor table (zkwg_o0.h).  Segment semantics: zkwg_sched.h (enum ZkSegType).
+#pragma once
+#include "zkwg_dev.h"
+#include "zkwg_bh_dfa.h"
+
+#define ZK_REF 0x80000000u
+#define ZK_REF_FRV (ZK_REF | (0u << 28))   // frv[payload]            (32 bytes)
+#define ZK_REF_INV (ZK_REF | (1u << 28))   // invtab[payload]         (d^-1, payload = d + inv_half)
+#define ZK_REF_LIMB (ZK_REF | (2u << 28))  // 16-byte limb at rec + payload, high half zero
+#define ZK_REF_RAW (ZK_REF | (3u << 28))   // small[payload] as a raw 32-bit value (bit 31 may be set)
+#define ZK_REF_NEG (ZK_REF | (4u << 28))   // small[payload] is a signed word w, d = (i32)(w << 1) >> 1 < 0: the slot is r + d
+#define ZK_REF_TYPE(code) (((code) >> 28) & 7u)
+#define ZK_REF_PAYLOAD(code) ((code) & 0x0fffffffu)
+
+struct ZkCtx {
+  const u8* __restrict__ rec;
+  const u64* __restrict__ bits;
+  const u32* __restrict__ small;
+  int half;           // inverse table covers [-half, half]
+  u32 m_dfa_cm, m_dfa_pm;
+};
+
+__device__ __forceinline__ u32 zk_udiv(u32 r, u32 d, u32 magic) { return magic ? __umulhi(r, magic) : r / d; }
+__device__ __forceinline__ u32 zk_inv_code(int d, int half) { return ZK_REF_INV | (u32)(max(-half, min(half, d)) + half); }
+__device__ __forceinline__ u32 zk_raw_code(u32 v, u32 idx) { return (v >> 31) ? (ZK_REF_RAW | idx) : v; }
+
+struct ZkDecSmall {
+  const u32* __restrict__ p; u32 base;
+  __device__ ZkDecSmall(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), base(sg.src) {}
+  __device__ u32 operator()(u32 r) const { return zk_raw_code(p[base + r], base + r); }
+};
+struct ZkDecFr {
+  u32 base;
+  __device__ ZkDecFr(const ZkSeg& sg, const ZkCtx&) : base(sg.src) {}
+  __device__ u32 operator()(u32 r) const { return ZK_REF_FRV | (base + r); }
+};
+struct ZkDecBits {
+  const u64* __restrict__ p; u32 a, b, magic;
+  __device__ ZkDecBits(const ZkSeg& sg, const ZkCtx& cx) : p(cx.bits + sg.src), a(sg.a), b(sg.b), magic(sg.pad) {}
+  __device__ u32 operator()(u32 r) const {
+    const u32 g = zk_udiv(r, a, magic), bit = r - g * a;
+    return (u32)(p[g * b + (bit >> 6)] >> (bit & 63)) & 1u;
+  }
+};
+// Sha256compression periods: PER slots over WORDS words, the last word takes the tail
+template <u32 PER, u32 WORDS>
+struct ZkDecSha {
+  const u64* __restrict__ p;
+  __device__ ZkDecSha(const ZkSeg& sg, const ZkCtx& cx) : p(cx.bits + sg.src) {}
+  __device__ u32 operator()(u32 r) const {
+    const u32 i = r / PER, q = r - i * PER;
+    const u32 sub = min(q >> 5, WORDS - 1u);
+    return (u32)(p[i * WORDS + sub] >> (q - sub * 32u)) & 1u;
+  }
+};
+struct ZkDecIsz {
+  const u32* __restrict__ p; int half;
+  __device__ ZkDecIsz(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small + sg.src), half(cx.half) {}
+  __device__ u32 operator()(u32 r) const {
+    const int d = (int)p[r >> 1];
+    return (r & 1u) ? zk_inv_code(d, half) : (u32)(d == 0);
+  }
+};
+struct ZkDecSel {
+  // 256 x ItemAtIndex(NB): per output bit k: nums[NB], then NB x (isz.out, isz.inv)
+  const u32* __restrict__ dig; u32 NB, per, magic; int idx, half;
+  __device__ ZkDecSel(const ZkSeg& sg, const ZkCtx& cx)
+      : dig(cx.small + sg.b), NB(sg.a), per(3u * sg.a), magic(sg.pad), idx((int)cx.small[sg.src]), half(cx.half) {}
+  __device__ u32 operator()(u32 r) const {
+    const u32 k = zk_udiv(r, per, magic), q = r - k * per;
+    if (q < NB) return ((int)q == idx) ? ((dig[k >> 5] >> (31u - (k & 31u))) & 1u) : 0u;
+    const u32 t = q - NB, j = t >> 1;
+    return (t & 1u) ? zk_inv_code(idx - (int)j, half) : (u32)((int)j == idx);
+  }
+};
+struct ZkDecIn8 {
+  const u8* __restrict__ p;
+  __device__ ZkDecIn8(const ZkSeg& sg, const ZkCtx& cx) : p(cx.rec + sg.src) {}
+  __device__ u32 operator()(u32 r) const { return p[r]; }
+};
+struct ZkDecIn8Mask {
+  const u8* __restrict__ p; const u8* __restrict__ m;
+  __device__ ZkDecIn8Mask(const ZkSeg& sg, const ZkCtx& cx) : p(cx.rec + sg.src), m(cx.rec + sg.a) {}
+  __device__ u32 operator()(u32 r) const { return (u32)p[r] * (u32)m[r]; }
+};
+struct ZkDecIn8Bits {
+  const u8* __restrict__ p;
+  __device__ ZkDecIn8Bits(const ZkSeg& sg, const ZkCtx& cx) : p(cx.rec + sg.src) {}
+  __device__ u32 operator()(u32 r) const { return (u32)(p[r >> 3] >> (r & 7u)) & 1u; }
+};
+struct ZkDecLimb {
+  u32 base;
+  __device__ ZkDecLimb(const ZkSeg& sg, const ZkCtx&) : base(sg.src) {}
+  __device__ u32 operator()(u32 r) const { return ZK_REF_LIMB | (base + 16u * r); }
+};
+struct ZkDecLtBits {
+  long long base; u32 per, magic;
+  __device__ ZkDecLtBits(const ZkSeg& sg, const ZkCtx& cx)
+      : base((long long)(int)cx.small[sg.src] + (1ll << sg.a)), per(sg.a + 1u), magic(sg.pad) {}
+  __device__ u32 operator()(u32 r) const {
+    const u32 i = zk_udiv(r, per, magic), bit = r - i * per;
+    return (u32)((u64)(base - (long long)i) >> bit) & 1u;
+  }
+};
+struct ZkDecRegSel {
+  // SelectRegexReveal (utils/regex.circom:31-37): per index i: IsEqual(i,start) (out,inv),
+  // IsZero(in[i]) (out,inv), [i>0: IsZero(in[i-1]) (out,inv)], GreaterThan(bl)(i, start+43) bits
+  const u32* __restrict__ rev; u32 bl, per, N, magic; int start, half;
+  __device__ ZkDecRegSel(const ZkSeg& sg, const ZkCtx& cx)
+      : rev(cx.small + sg.b), bl(sg.a), per(6u + sg.a + 1u), N(sg.c), magic(sg.pad), start((int)cx.small[sg.src]), half(cx.half) {}
+  __device__ u32 operator()(u32 r) const {
+    u32 i, q;
+    if (r < per - 2u) {  // index 0 has no "previous" IsZero
+      i = 0; q = r < 4u ? r : r + 2u;
+    } else {
+      const u32 rr = r - (per - 2u), t = zk_udiv(rr, per, magic);
+      i = 1u + t; q = rr - t * per;
+    }
+    if (q < 6u) {
+      int d;
+      if (q < 2u) d = start - (int)i;                       // isz.in = in[1] - in[0] = startIndex - i
+      else if (q < 4u) d = (int)rev[i < N ? i : N - 1u];
+      else d = (int)rev[i ? i - 1u : 0u];
+      return (q & 1u) ? zk_inv_code(d, half) : (u32)(d == 0);
+    }
+    const long long val = (long long)start + 43 + (1ll << bl) - (long long)i;
+    return (u32)((u64)val >> (q - 6u)) & 1u;
+  }
+};
+struct ZkDecVShift {
+  const u32* __restrict__ small; u32 N, b, shift, magic;
+  __device__ ZkDecVShift(const ZkSeg& sg, const ZkCtx& cx) : small(cx.small), N(sg.a), b(sg.b), shift(cx.small[sg.src]), magic(sg.pad) {}
+  __device__ u32 operator()(u32 r) const {
+    const u32 j = zk_udiv(r, N, magic), i = r - j * N;
+    const u32 sh = shift & ((2u << j) - 1u);
+    const u32 idx = b + (i + sh) % N;
+    return zk_raw_code(small[idx], idx);
+  }
+};
+template <bool FULL>   // FULL: Base64Lookup internals (68 slots per char), else the 6 value bits
+struct ZkDecB64 {
+  const u32* __restrict__ chars; int half;
+  __device__ ZkDecB64(const ZkSeg& sg, const ZkCtx& cx) : chars(cx.small + sg.src), half(cx.half) {}
+  __device__ u32 operator()(u32 r) const {
+    constexpr u32 per = FULL ? 68u : 6u;
+    const u32 g = r / per, q = r - g * per;
+    const int ch = (int)chars[g];
+    // lib/base64.circom:71-128
+    const u32 rAZ = (ch >= 65 && ch <= 90), raz = (ch >= 97 && ch <= 122), r09 = (ch >= 48 && ch <= 57);
+    const u32 sAZ = rAZ * (u32)(ch - 65);
+    const u32 saz = sAZ + raz * (u32)(ch - 71);
+    const u32 s09 = saz + r09 * (u32)(ch + 4);
+    const u32 spl = s09 + (ch == 43) * (u32)(ch + 19);
+    const u32 ssl = spl + (ch == 47) * (u32)(ch + 16);
+    if (!FULL) return (ssl >> q) & 1u;
+    if (q < 8u) {
+      const u32 mids[8] = {rAZ, sAZ, raz, saz, r09, s09, spl, ssl};
+      return mids[q];
+    }
+    if (q < 62u) {
+      const u32 k = (q - 8u) / 9u, bit = (q - 8u) - k * 9u;
+      // le_Z: in+256-91, ge_A: 64+256-in, le_z: in+256-123, ge_a: 96+256-in, le_9: in+256-58, ge_0: 47+256-in
+      const int vals[6] = {ch + 256 - 91, 64 + 256 - ch, ch + 256 - 123, 96 + 256 - ch, ch + 256 - 58, 47 + 256 - ch};
+      return ((u32)vals[k] >> bit) & 1u;
+    }
+    const u32 k = (q - 62u) >> 1;
+    const int d = ch - (k == 0 ? 43 : (k == 1 ? 47 : 61));
+    return ((q - 62u) & 1u) ? zk_inv_code(d, half) : (u32)(d == 0);
+  }
+};
+// BodyHashRegex DFA circuit arrays (zkwg_layout.h zk_walk_bh_regex): one entry per position i of
+// in[] = [255, header...].  zk_misc_ev left one word per position: in | st<<8 | nx<<16 | st_next<<24
+// (nx = the transition out of a non-zero state, 255 = none) plus the class / primitive truth masks.
+struct ZkDecDfa {
+  const u32* __restrict__ pos; const u32* __restrict__ cmask; const u32* __restrict__ pmask;
+  u32 kind, pb, pc; int half;
+  __device__ ZkDecDfa(const ZkSeg& sg, const ZkCtx& cx)
+      : pos(cx.small + sg.src), cmask(cx.small + cx.m_dfa_cm), pmask(cx.small + cx.m_dfa_pm), kind(sg.a), pb(sg.b), pc(sg.c), half(cx.half) {}
+  __device__ u32 operator()(u32 r) const {
+    if (kind == ZDFA_EQ) {
+      const int d = (int)pb - (int)(pos[r >> 1] & 255u);          // isz.in = in[1] - in[0] = ch - in[i]
+      return (r & 1u) ? zk_inv_code(d, half) : (u32)(d == 0);
+    }
+    u32 i, q, off = 0;
+    if (kind == ZDFA_LT) { i = r / 9u; q = r - i * 9u; }
+    else if (kind == ZDFA_RNG || kind == ZDFA_AND) { i = r; q = 0; }
+    else { i = r >> 1; q = r & 1u; if (kind == ZDFA_SUB) off = 1; }
+    const u32 w0 = pos[i + off];
+    const u32 b = w0 & 255u, st = (w0 >> 8) & 255u, nx = (w0 >> 16) & 255u, sn = w0 >> 24;
+    switch (kind) {
+      case ZDFA_LT: return ((pc ? pb + b : pb - b) >> q) & 1u;
+      case ZDFA_RNG: return (u32)(b >= pb && b <= pc);
+      case ZDFA_CLS: return (u32)(q == 0) ^ (u32)(__builtin_popcount(pmask[i] & pc) != 0);
+      case ZDFA_AND: return (u32)(pb ? (st == pb) : (nx == 255u)) & ((cmask[i] >> pc) & 1u);
+      case ZDFA_TMP: return (u32)(q == 0) ^ (u32)(nx == pb);
+      case ZDFA_FZE: return (u32)(q == 0) ^ (u32)(nx != 255u);
+      case ZDFA_ST: return (u32)(q == 0) ^ (u32)(sn == pb);
+      case ZDFA_SUB: {
+        // message index i: transition st[i+1] -> st[i+2] = (st, sn) of word i+1
+        const u32 key = st | (sn << 8);
+        bool hit = false;
+#pragma unroll
+        for (u32 k = 0; k < ZK_DFA_NPUBLIC; ++k) hit = hit || key == (ZK_DFA_PUBLIC[k][0] | ((u32)ZK_DFA_PUBLIC[k][1] << 8));
+        return (u32)(q == 0) ^ (u32)hit;
+      }
+      default: return 0u;
+    }
+  }
+};
+// RemoveSoftLineBreaks arrays derived from the emailBody bytes alone
+// (helpers/remove-soft-line-breaks.circom:47-91): "=\r\n" at j  <=>  isSoftBreak[j]
+struct ZkDecRslb {
+  const u8* __restrict__ enc; u32 kind, b, c; int half;
+  __device__ ZkDecRslb(const ZkSeg& sg, const ZkCtx& cx) : enc(cx.rec + sg.src), kind(sg.a), b(sg.b), c(sg.c), half(cx.half) {}
+  __device__ u32 operator()(u32 r) const {
+    if (kind == ZRS_EQ) {
+      const int d = (int)c - (int)enc[(r >> 1) + b];   // isz.in = in[1] - in[0]
+      return (r & 1u) ? zk_inv_code(d, half) : (u32)(d == 0);
+    }
+    if (kind == ZRS_TSB) return (u32)(enc[r] == 61u) & (u32)(enc[r + 1] == 13u);
+    if (kind == ZRS_SB) return (u32)(enc[r] == 61u) & (u32)(enc[r + 1] == 13u) & (u32)(enc[r + 2] == 10u);
+    // processed[r]: zero inside a soft break starting at r, r-1 or r-2 (starts only below M-2)
+    bool z = false;
+#pragma unroll
+    for (u32 k = 0; k < 3; ++k)
+      if (r >= k && r - k + 2 < b) { const u32 j = r - k; z = z || (enc[j] == 61u && enc[j + 1] == 13u && enc[j + 2] == 10u); }
+    return z ? 0u : (u32)enc[r];
+  }
+};
+// gate values of a loaded regex template (zkwg_net_core.h): 31-bit signed integer, or the inverse
+// of one (bit 31) from the table; a negative integer -m is the field element r - m
+struct ZkDecNet {
+  const u32* __restrict__ p; u32 base; int half;
+  __device__ ZkDecNet(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), base(sg.src), half(cx.half) {}
+  __device__ u32 operator()(u32 r) const {
+    const u32 w = p[base + r];
+    const int d = (int)(w << 1) >> 1;
+    if (w & 0x80000000u) return zk_inv_code(d, half);
+    return d >= 0 ? (u32)d : (ZK_REF_NEG | (base + r));
+  }
+};
+
+// one slot of any segment (the numbered-circuit expansion and the linear-row kernel reach slots one by one)
+__device__ inline u32 zk_decode_any(const ZkSeg& sg, u32 r, const ZkCtx& cx) {
+  switch (sg.type) {
+    case ZSEG_SMALL: return ZkDecSmall(sg, cx)(r);
+    case ZSEG_FR: return ZkDecFr(sg, cx)(r);
+    case ZSEG_BITS: return ZkDecBits(sg, cx)(r);
+    case ZSEG_SHA_SP: return ZkDecSha<ZK_SP_SLOTS, 5>(sg, cx)(r);
+    case ZSEG_SHA_T1: return ZkDecSha<ZK_T1_SLOTS, 4>(sg, cx)(r);
+    case ZSEG_SHA_T2: return ZkDecSha<ZK_T2_SLOTS, 5>(sg, cx)(r);
+    case ZSEG_ISZ: return ZkDecIsz(sg, cx)(r);
+    case ZSEG_SEL: return ZkDecSel(sg, cx)(r);
+    case ZSEG_IN8: return ZkDecIn8(sg, cx)(r);
+    case ZSEG_IN8MASK: return ZkDecIn8Mask(sg, cx)(r);
+    case ZSEG_IN8BITS: return ZkDecIn8Bits(sg, cx)(r);
+    case ZSEG_LIMB: return ZkDecLimb(sg, cx)(r);
+    case ZSEG_LTBITS: return ZkDecLtBits(sg, cx)(r);
+    case ZSEG_REGSEL: return ZkDecRegSel(sg, cx)(r);
+    case ZSEG_VSHIFT: return ZkDecVShift(sg, cx)(r);
+    case ZSEG_B64BITS: return ZkDecB64<false>(sg, cx)(r);
+    case ZSEG_B64: return ZkDecB64<true>(sg, cx)(r);
+    case ZSEG_DFA: return ZkDecDfa(sg, cx)(r);
+    case ZSEG_RSLB: return ZkDecRslb(sg, cx)(r);
+    case ZSEG_NET: return ZkDecNet(sg, cx)(r);
+    default: return 0u;
+  }
+}
+
+// ---------------------------------------------------------------- store side
+// the 16-byte half `hf` of the slot a reference code names
+struct ZkRefSrc {
+  const uint4* __restrict__ frv;     // the email's field elements (Montgomery output: their Montgomery copies)
+  const uint4* __restrict__ invtab;  // inverse table (Montgomery output: the Montgomery-form copy)
+  const u8* __restrict__ rec;
+  const u32* __restrict__ small;
+};
+__device__ __forceinline__ uint4 zk_ref_half(u32 code, u32 hf, const ZkRefSrc& R) {
+  const u32 p = ZK_REF_PAYLOAD(code);
+  switch (ZK_REF_TYPE(code)) {
+    case 0: return R.frv[2u * p + hf];
+    case 1: return R.invtab[2u * p + hf];
+    case 2: return hf ? zk_zero4() : *(const uint4*)(R.rec + p);
+    case 3: return hf ? zk_zero4() : zk_small(R.small[p]);
+    default: {
+      const u32 w = R.small[p];
+      const u32 m = (u32)(-((int)(w << 1) >> 1));
+      return hf ? make_uint4(0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u)
+                : make_uint4(0xf0000001u - m, 0x43e1f593u, 0x79b97091u, 0x2833e848u);
+    }
+  }
+}

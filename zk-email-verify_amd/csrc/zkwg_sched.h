@@ -83,8 +83,9 @@ struct ZkSeg {
   u32 a, b, c; // type parameters
   u32 r0;      // index of the segment's first element inside the logical array (0 unless a `.sym`
                // remap split the array: zkwg_build.h zk_remap_segments)
-  u32 pad;
+  u32 pad;     // kernel-private: reciprocal of the type's period (zkwg_build.h zk_finish_tables), 0 = divide
 };
+#define ZK_MONT_LIMBS 51u   // 128-bit limbs of an input record (pubkey, signature, message: 3 x 17)
 
 #define ZK_PORTION_DEFAULT 2048u  // witness slots expanded by one workgroup of zk_expand
 
@@ -237,6 +238,8 @@ struct ZkBufs {
   const u32* net_records; // loaded regex template: 16 words per gate in execution order (zkwg_net_core.h)
   const u32* net_counts;  // loaded regex template: gates per step | flags (0x8000: 64-bit path)
   const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
+  Fr* frm;               // Montgomery-form output: per email, Montgomery copies of its img_fr field elements, then of the record's ZK_MONT_LIMBS limbs
+  const u32* pflags;     // per portion: bit 0 = every slot is immediate-valued (no references, zkwg_expand_dec.h)
   const ZkSeg* segs;     // segment table
   const u32* first_seg;  // first segment overlapping each portion
   uint4* wit;            // output witnesses
