@@ -47,7 +47,7 @@ class Pipeline:
     another; images are ring-buffered, witnesses go to a 2-tile ring in HBM."""
 
     def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=4, exp_prio=-1,
-                 montgomery=False, out_align=0):
+                 montgomery=False, out_align=0, serial=False, prep_cus=0, prep_cu_stride=1):
         self.torch, self.c, self.dev, self.d_in = torch, c, dev, d_in
         self.batch, self.tile, self.prep = batch, tile, prep
         assert batch % prep == 0 and prep % tile == 0
@@ -64,6 +64,28 @@ class Pipeline:
         # several prepare streams let the latency-bound prepare kernels of consecutive SMALL sub-batches overlap
         self.s_preps = [torch.cuda.Stream(device=dev, priority=0) for _ in range(max(1, prep_streams))]
         self.s_exp = torch.cuda.Stream(device=dev, priority=exp_prio)
+        self.serial = serial
+        self._masked = []
+        if prep_cus > 0:
+            # the prepare kernels on `prep_cus` compute units only (CU-masked HIP stream), zk_expand on the others
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            words = (ncu + 31) // 32
+            sel = set(range(prep_cus)) if prep_cu_stride <= 1 else set(i * prep_cu_stride for i in range(prep_cus) if i * prep_cu_stride < ncu)
+
+            def mask(keep):
+                m = [0] * words
+                for i in range(ncu):
+                    if keep(i):
+                        m[i // 32] |= 1 << (i % 32)
+                return (ctypes.c_uint32 * words)(*m), words
+            mp, w = mask(lambda i: i in sel)
+            me, _ = mask(lambda i: i not in sel)
+            sp = c.lib.zkwg_stream_create_masked(dev.index, mp, w)
+            se = c.lib.zkwg_stream_create_masked(dev.index, me, w)
+            assert sp and se, "hipExtStreamCreateWithCUMask failed"
+            self._masked = [sp, se]
+            self.s_preps = [torch.cuda.ExternalStream(sp, device=dev)]
+            self.s_exp = torch.cuda.ExternalStream(se, device=dev)
         self.ev_prep = [torch.cuda.Event() for _ in range(self.R)]
         self.ev_exp = [torch.cuda.Event() for _ in range(self.R)]
         self.j = 0
@@ -94,6 +116,9 @@ class Pipeline:
                         self.expand(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp)
                     self.d_rows[lo + t * self.tile:lo + (t + 1) * self.tile].copy_(o.view(self.tile, self.stride)[:, :128])
             self.ev_exp[b].record(self.s_exp)
+            if self.serial:
+                for sp in self.s_preps:
+                    sp.wait_event(self.ev_exp[b])
             self.j = j + 1
 
     def last_tile(self):
@@ -205,6 +230,11 @@ def main():
                     help="pad the distance between consecutive witnesses in the HBM ring to a multiple of this many bytes (0 = back to back)")
     ap.add_argument("--regex", default=None,
                     help="path of a zk-regex style body_hash_regex.circom: BodyHashRegex is compiled from it (zkwg_circuit_create_regex)")
+    ap.add_argument("--no-overlap", type=int, default=0,
+                    help="1: measurement aid -- every prepare waits for the previous sub-batch's expands, so zk_expand runs alone on the chip")
+    ap.add_argument("--prep-cus", type=int, default=0,
+                    help="> 0: the prepare kernels run on this many compute units only (CU-masked stream), zk_expand on the others")
+    ap.add_argument("--prep-cu-stride", type=int, default=1, help="with --prep-cus: take every stride-th CU instead of the first ones")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -249,7 +279,8 @@ def main():
     _, d_in, fields = resident_inputs(torch, c, dev, 0x5A4B + rank, distinct, args.batch, args.body_len)
     prio = int(os.environ.get("ZKWG_BENCH_EXP_PRIO", "-1"))
     pl = Pipeline(torch, c, dev, d_in, args.batch, tile, prep, ring=args.ring, prep_streams=args.prep_streams,
-                  rsa_throttle=args.rsa_throttle, exp_prio=prio, montgomery=bool(args.montgomery), out_align=args.out_align)
+                  rsa_throttle=args.rsa_throttle, exp_prio=prio, montgomery=bool(args.montgomery), out_align=args.out_align,
+                  serial=bool(args.no_overlap), prep_cus=args.prep_cus, prep_cu_stride=args.prep_cu_stride)
     from zkwg import shard
     state = {"table": None}
 
@@ -436,6 +467,27 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
                                                   "sample": f"{n} emails through zkwg_calculate_batch, tiles of {t}, PCIe-inclusive"}
     except Exception as e:
         out["delivered to pinned host memory"] = {"error": repr(e)[:200]}
+    # the same delivery with the expansion on the HOST (zkwg_set_host_expand): only the 0.45 MB image crosses PCIe, the
+    # witness bytes are written by the host cores (non-temporal stores) -- bounded by host DRAM bandwidth instead
+    try:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                cores = min(cores, max(1, int(q) // int(per)))
+        except (OSError, ValueError):
+            pass
+        n, t = 192, 64
+        h_in, _, _ = resident_inputs(torch, c, dev, 0x5A4B + 202, 64, n, args.body_len)
+        recs = bytes(h_in.repeat(3, 1)[:n].contiguous().numpy().tobytes())
+        c.set_host_expand(cores)
+        sec = c.time_host_path(recs, n, max_tile=t, pinned=True)
+        c.set_host_expand(0)
+        out["delivered to host memory, expanded on the host"] = {
+            "value": round(n / sec, 1), "unit": "witnesses/s", "GBps_written_by_host": round(n * c.witness_bytes / sec / 1e9, 2), "host_threads": cores,
+            "sample": f"{n} emails through zkwg_calculate_batch with zkwg_set_host_expand({cores}), tiles of {t}: D2H of the 0.45 MB image per email"}
+    except Exception as e:
+        out["delivered to host memory, expanded on the host"] = {"error": repr(e)[:200]}
     # configs[4]: maxBody = 65536 (SHA-dominated), batch 1024, bodies 32K..65K-72; fewer steps
     try:
         c5 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=1024, max_body=65536, device=local_rank)

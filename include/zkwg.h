@@ -53,7 +53,10 @@
 extern "C" {
 #endif
 
-#define ZKWG_ABI_VERSION 1
+/* 2 (round 3): ZKWG_IN_NFIELDS = 13 (the record's former padding word is ZKWG_IN_RANGE_FLAGS: hand-built records must
+ * zero it, a non-zero word fails the email); zkwg_expand_device accepts out_stride >= 32 W (multiple of 16);
+ * zkwg_scratch_bytes includes the Montgomery-copy area; zkwg_segment.pad is kernel-private. */
+#define ZKWG_ABI_VERSION 2
 
 /* `component main = ...` choices (the reference's own test mains). */
 enum zkwg_main_kind {
@@ -243,6 +246,27 @@ typedef struct zkwg_dkim_batch {
 } zkwg_dkim_batch;
 int zkwg_generate_inputs_device(zkwg_circuit_t* c, const zkwg_dkim_batch* batch, uint64_t n_emails,
                                 void* d_records, void* d_gen_status, void* hip_stream);
+
+/* Host expansion (the delivered-to-host rate; the consumer is snarkjs on the host,
+ * packages/helpers/src/chunked-zkey.ts:80-84).  A witness crosses PCIe at 32 bytes per signal (56.9 MB per email) although
+ * its information is the 0.45 MB image the prepare kernels leave.  zkwg_expand_host runs the segment decoders of
+ * zk_expand on the host (same source, csrc/zkwg_expand_dec.h) over an image that was copied to host memory:
+ * `records` = the n packed input records, `scratch_host` = a host copy of the scratch buffer of
+ * zkwg_prepare_device(c, ., n, ...) (zkwg_scratch_bytes(c, n) bytes; only the image arrays are read), emails
+ * [first, first + count) go to `out` (16-byte aligned), written with non-temporal stores by `threads` host threads.
+ * Not available for zkwg_circuit_create_full handles (their row results are computed on the device).
+ * zkwg_set_host_expand(c, threads > 0) makes zkwg_calculate_batch use this route: per tile H2D records -> prepare
+ * kernels -> D2H of the image, the host expanding tile t while the device prepares tile t + 1 (0 = device expansion + D2H
+ * of the witnesses, the default).  Both routes give identical bytes. */
+int zkwg_expand_host(const zkwg_circuit_t* c, const uint8_t* records, uint64_t n_emails, const uint8_t* scratch_host,
+                     uint64_t first, uint64_t count, uint8_t* out, uint64_t out_stride, int threads);
+int zkwg_set_host_expand(zkwg_circuit_t* c, int threads);
+
+/* A HIP stream (returned as void*, NULL on failure) restricted to the compute units whose bit is set in `mask`
+ * (`words` x 32 bits, CU i = bit i; hipExtStreamCreateWithCUMask).  Optional tuning aid: the prepare kernels are latency-bound
+ * and few; confined to a few CUs they do not take wave slots from zk_expand on the others (bench.py --prep-cus). */
+void* zkwg_stream_create_masked(int device, const uint32_t* mask, int words);
+void zkwg_stream_destroy(void* stream);
 
 /* Page-locked host memory for `out_wtns` (optional): with it the D2H copy of one tile overlaps the
  * kernels of the next tile. */

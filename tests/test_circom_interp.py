@@ -37,7 +37,10 @@ def by_name(root, prog):
 
 
 def test_stand_in_regex_file_is_current():
-    from oracle.circom import gen_body_hash_regex
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_body_hash_regex", os.path.join(ROOT, "tools", "gen_body_hash_regex.py"))
+    gen_body_hash_regex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen_body_hash_regex)
     assert gen_body_hash_regex.main(["--check"]) == 0
 
 

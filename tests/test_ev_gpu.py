@@ -104,3 +104,37 @@ def test_ev_with_sha_precompute_selector_bit_exact():
     assert inp["precomputedSHA"] != [str(b) for b in bytes.fromhex("6a09e667bb67ae853c6ef372a54ff53a510e527f9b05688c1f83d9ab5be0cd19")]
     w = wc.calculateWitness(inp)
     assert w == comp.witness_kept(_oracle_ev(N, M, 0, inp))
+
+
+@pytest.mark.parametrize("variant", ["g16", "lane", "wave"])
+def test_pubkey_hash_kernels_agree_with_the_oracle(variant, monkeypatch):
+    """PoseidonLarge(121,17) -> Poseidon(9) (utils/hash.circom:15-39) has three device kernels: 16 lanes per email
+    (zk_poseidon9_g16, the default from 1,024 emails), one lane per email (round 2's) and one wavefront per email
+    (small batches).  Each is forced here on a 7-email batch with different keys; the 420 S-box signals and
+    pubkeyHash sit inside the witness that is compared with the oracle."""
+    import zkwg
+    from oracle.pyref import comp
+    if variant == "g16":
+        monkeypatch.setenv("ZKWG_POS_WAVE_BELOW", "0")
+    elif variant == "lane":
+        monkeypatch.setenv("ZKWG_POS_WAVE_BELOW", "0")
+        monkeypatch.setenv("ZKWG_POS_LANE", "1")
+    from oracle.pyref import poseidon as pos
+    N, M = 576, 192
+    c, wc = _circuit(N, M, 1)
+    ins = [_inputs(N, M, 1, index=10 + i, body_len=50) for i in range(7)]
+    for i, inp in enumerate(ins[3:], 1):    # emails 3..6: other moduli (the signature no longer verifies; the hash is still defined)
+        inp["pubkey"] = [str((int(v) + 977 * i * (k + 1)) % (1 << 121)) for k, v in enumerate(inp["pubkey"])]
+    wits, status = wc.calculateBatch(ins)
+    hashes = set()
+    for n, (inp, wb, st) in enumerate(zip(ins, wits, status)):
+        w = zkwg.witness_ints(wb)
+        limbs = [int(v) for v in inp["pubkey"]]
+        merged = [limbs[2 * k] + (limbs[2 * k + 1] << 121) for k in range(8)] + [limbs[16]]
+        assert w[1] == pos.poseidon_hash(merged), (variant, n)      # pubkeyHash is the first output
+        hashes.add(w[1])
+        if n < 3:
+            assert st == 0 and w == comp.witness_kept(_oracle_ev(N, M, 1, inp))   # incl. the 420 S-box signals
+        else:
+            assert st == 4
+    assert len(hashes) == 5

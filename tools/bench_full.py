@@ -29,7 +29,7 @@ def main():
         t0 = time.time()
         c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, **kw)
         t_create = time.time() - t0
-        batch, tile = (2048, 256) if N <= 576 else (1024, 128)
+        batch, tile = (2048, 256) if N <= 576 else (512, 128)
         _, d_in, _ = bench.resident_inputs(torch, c, dev, 0x5A4B + 9, 64, batch, 60 if M <= 192 else 1024)
         pl = bench.Pipeline(torch, c, dev, d_in, batch, tile, min(1024, batch), ring=2)
         c.set_timing(True)

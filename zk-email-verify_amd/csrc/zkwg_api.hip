@@ -17,9 +17,14 @@
 #include "zkwg_build.h"
 #include "zkwg_poseidon_sparse.h"
 #include "zkwg_full.h"
+#include "zkwg_o0.h"
+#include "zkwg_expand_dec.h"
+#define ZK_FR_LANES 8u   // lanes per group of zk_o0_rows_fr (zkwg_kernels_expand3.hip)
+#include <atomic>
+#include <emmintrin.h>
 
 #define ZK_MAX_KERNELS 9
-#define ZK_O0_SHORT_ROW 8   // linear rows up to this many terms are evaluated inside zk_o0_gather, longer ones by zk_o0_rows
+#define ZK_O0_SHORT_ROW 8   // host evaluation of the plan (tests): rows up to this many terms are listed first
 #define ZK_RS_SLOTS 16
 #define ZK_POS_STREAMS 4
 #define ZK_POS_RING 64
@@ -32,14 +37,15 @@ struct zkwg_circuit {
   Fr* d_invtab;
   std::vector<std::string> sym_names;  // layout SYM: witness index -> name
   // linear completion plan of a fully numbered (O0 / O1) circuit (zkwg_full.h); null for compact layouts
-  u64* d_lin_row; u32* d_lin_dst; u32* d_lin_src; Fr* d_lin_coef; u8* d_lin_kind; u64 lin_rows;
+  u64 lin_rows;
   std::vector<u32> kept_dst;   // `.sym` layouts: kept-v1 slot -> witness index (0xffffffff = dropped by the file)
   ZkLinPlan lin_host;   // kept for layout-only handles (tests evaluate it on the host)
-  // fully numbered circuits: zk_expand fills a kept-v1 staging buffer, zk_o0_gather writes the file's wires from it
+  // fully numbered circuits (`--O0` / `--O1`): zk_expand_o0 writes every wire of the file straight from the image (zkwg_o0.h)
   u64 full_W;                      // wires of the `.sym` / `.r1cs` (0: not a fully numbered circuit)
   std::vector<u32> o0_short; u64 n_o0_short;
-  std::vector<u32> o0_desc, o0_src, o0_long;   // wire -> kept-v1 slot | 0x80000000 + row | 0xfffffffe (long row);  row terms as kept-v1 slots;  the long rows
-  u32* d_o0_desc; u32* d_o0_long; u64 n_o0_long; u8* d_stage; u64 stage_bytes;
+  std::vector<u32> o0_desc, o0_src, o0_long;   // host evaluation (layout-only handles): wire -> kept-v1 slot | 0xfffffffe (row);  row terms as kept-v1 slots;  the rows
+  ZkO0Tables o0t;                  // per-wire descriptors + small / field rows (host copy; moved to the device for device handles)
+  ZkO0Dev o0d;                     // device pointers of the same
   Fr* d_invtab_m; // fused Montgomery output: inverse table in Montgomery form (built with d_rtab)
   // BodyHashRegex loaded from a circom template (zkwg_circuit_create_regex): gate list on the device
   zkc::Net net;
@@ -52,6 +58,13 @@ struct zkwg_circuit {
   Fr* d_pos_rs;   // removeSoftLineBreaks: Poseidon(16) then Poseidon(2) sparse-round tables
   ZkSeg* d_segs;
   u32* d_first_seg;
+  ZkPortionEntry* d_ent;   // zk_expand: one entry per piece of 256 K slots (zkwg_build.h zk_build_entries)
+  u32 n_ent;
+  std::vector<Fr> invtab_host;   // zkwg_expand_host: the inverse table on the host
+  int host_expand_threads;       // > 0: zkwg_calculate_batch expands on the host (zkwg_set_host_expand)
+  u8* hx_img[2]; u64 hx_bytes;   // pinned staging of downloaded images (host expansion)
+  int o0_emails_per_wg;          // emails per workgroup of zk_expand3_o0 (ZKWG_O0_EMAILS_PER_WG, default 4)
+  int x3_k, x3_k_o0;       // slots per thread of zk_expand3 (kept-v1 / sym layouts) and zk_expand3_o0: 1, 2 or 4 (ZKWG_X3_K, ZKWG_X3_K_O0)
   std::vector<ZkSeg> segs;
   std::vector<u32> first_seg;
   hipStream_t own_stream, copy_stream;
@@ -68,6 +81,8 @@ struct zkwg_circuit {
   hipEvent_t pos_dep[ZK_POS_RING], pos_done[ZK_POS_RING];
   u64 pos_calls;
   int pos_side;   // 1: fork zk_poseidon9 onto a side stream (ZKWG_POS_SIDE=1); default 0 = caller's stream
+  int pos_lane;   // 1: the lane-per-email zk_poseidon9 of round 2 instead of zk_poseidon9_g16 (ZKWG_POS_LANE=1)
+  int pos_wave_below;   // batches below this many emails use the wavefront-per-email kernel (ZKWG_POS_WAVE_BELOW, default 1024)
   u32 xcd_remap;  // zk_expand workgroup -> portion mapping (ZKWG_XCD_REMAP)
   // host-buffer path: cached device staging buffers (double-buffered witnesses)
   std::mutex hb_mutex;
@@ -87,7 +102,7 @@ struct zkwg_circuit {
   u64 prep_launches;
   bool ev_valid, prep_valid;
   int expand_threads;
-  int expand_v2;   // 1 (default): LDS-staged zk_expand2; 0: the direct-store kernels of rounds 1-2 (ZKWG_EXPAND_V=1)
+  int expand_v;    // 3 (default): zk_expand3, one 8 KiB piece per workgroup; 2: LDS-staged 64 KiB portions; 1: the direct-store kernels of rounds 1-2 (ZKWG_EXPAND_V)
   int emails_per_wg;
   int rsa_wgs_per_cu;
 };
@@ -131,6 +146,20 @@ static void build_inv_table(u32 inv_half, std::vector<Fr>& tab) {
 }
 
 static u64 align256(u64 x) { return (x + 255) & ~255ull; }
+// host expansion helpers (zkwg_expand_host below)
+static inline void zk_host_put(u8* dst, u32 code, const ZkRefSrc& R) {
+  uint4 lo, hi;
+  if (!(code >> 31)) { lo = make_uint4(code, 0, 0, 0); hi = make_uint4(0, 0, 0, 0); }
+  else { lo = zk_ref_half(code, 0u, R); hi = zk_ref_half(code, 1u, R); }
+  _mm_stream_si128((__m128i*)dst, _mm_set_epi32((int)lo.w, (int)lo.z, (int)lo.y, (int)lo.x));
+  _mm_stream_si128((__m128i*)(dst + 16), _mm_set_epi32((int)hi.w, (int)hi.z, (int)hi.y, (int)hi.x));
+}
+template <class DEC>
+static void zk_host_segment(const ZkSeg& sg, const ZkCtx& cx, const ZkRefSrc& R, u32 r0, u32 n, u8* dst) {
+  const DEC dec(sg, cx);
+  for (u32 i = 0; i < n; ++i) zk_host_put(dst + 32ull * i, dec(r0 + i), R);
+}
+
 extern "C" int zk_misc_init_tables(void);
 
 extern "C" {
@@ -173,8 +202,13 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   c->expand_threads = 256;
   if (const char* v = getenv("ZKWG_PORTION")) portion = (u32)atoi(v);
   if (const char* v = getenv("ZKWG_EXPAND_THREADS")) c->expand_threads = atoi(v);
-  c->expand_v2 = getenv("ZKWG_EXPAND_V") ? (atoi(getenv("ZKWG_EXPAND_V")) != 1) : 1;
-  if (c->expand_v2 && portion > 8192) portion = 8192;   // 4 bytes of LDS per slot
+  c->expand_v = getenv("ZKWG_EXPAND_V") ? atoi(getenv("ZKWG_EXPAND_V")) : 3;
+  if (c->expand_v < 1 || c->expand_v > 3) c->expand_v = 3;
+  auto pick_k = [](const char* name, int dflt, bool k8 = false) { const char* v = getenv(name); const int k = v ? atoi(v) : dflt; return (k == 1 || k == 2 || k == 4 || (k8 && k == 8)) ? k : dflt; };
+  c->x3_k = pick_k("ZKWG_X3_K", 4, true);
+  c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 4);
+  c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 4;
+  if (c->expand_v == 2 && portion > 8192) portion = 8192;   // 4 bytes of LDS per slot
   c->emails_per_wg = 1;
   c->xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
   c->rsa_wgs_per_cu = 0;
@@ -245,6 +279,13 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
           if (c->o0_desc[w] == 0xffffffffu || (!(c->o0_desc[w] >> 31) && c->o0_desc[w] >= c->s.W)) err = "internal: wire " + std::to_string(w) + " has no source";
         if (Pn.n_rows() >= 0x7fffffffull || c->s.W >= 0x7fffffffull) err = "circuit too large for the O0 gather table";
         c->full_W = L.W;
+        c->lin_rows = Pn.n_rows();
+        if (err.empty()) zk_o0_build(c->s, c->segs, Pn, c->o0_desc, c->o0_src, c->o0t, err);
+        if (getenv("ZKWG_DEBUG_PLAN"))
+          fprintf(stderr, "[zkwg] O0 tables: %llu wires, %llu alias rows, %llu constant rows, %llu small rows (%llu terms in %llu groups), %llu field rows (%llu terms in %llu groups); %llu terms before chaining\n",
+                  (unsigned long long)L.W, (unsigned long long)c->o0t.n_alias, (unsigned long long)c->o0t.n_const, (unsigned long long)c->o0t.n_small(),
+                  (unsigned long long)c->o0t.s_coef.size(), (unsigned long long)(c->o0t.s_group.size() - 1), (unsigned long long)c->o0t.n_fr(),
+                  (unsigned long long)c->o0t.f_kind.size(), (unsigned long long)(c->o0t.f_group.size() - 1), (unsigned long long)c->o0t.terms_before_chaining);
         if (getenv("ZKWG_DEBUG_PLAN")) {
           u64 hist[8] = {0}, terms = 0, longest = 0;
           for (u64 r = 0; r < Pn.n_rows(); ++r) {
@@ -288,6 +329,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     c->n_kernels = k + 1;
     for (int i = 0; i < k; ++i) c->kslots[i] = 0;
   }
+  build_inv_table(c->s.inv_half, c->invtab_host);   // (also the host expansion's table)
   c->kname[c->n_kernels - 1] = "zk_expand"; c->kslots[c->n_kernels - 1] = c->full_W ? c->full_W : c->s.W;   // (+ zk_o0_gather for a fully numbered circuit)
   if (device >= 0) {
     int ndev = 0;
@@ -295,11 +337,17 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     if (hipSetDevice(device) != hipSuccess) { delete c; return ZKWG_RC_HIP_ERROR; }
     c->device = device;
     if (zk_misc_init_tables() != 0) { delete c; return ZKWG_RC_HIP_ERROR; }
-    std::vector<Fr> tab;
-    build_inv_table(c->s.inv_half, tab);
+    std::vector<Fr>& tab = c->invtab_host;
     bool ok = hipMalloc((void**)&c->d_invtab, tab.size() * sizeof(Fr)) == hipSuccess &&
               hipMalloc((void**)&c->d_segs, c->segs.size() * sizeof(ZkSeg)) == hipSuccess &&
               hipMalloc((void**)&c->d_first_seg, c->first_seg.size() * sizeof(u32)) == hipSuccess;
+    {
+      std::vector<ZkPortionEntry> ent;
+      zk_build_entries(c->s.W, c->segs, ent, 256u * (u32)c->x3_k);
+      c->n_ent = (u32)ent.size();
+      ok = ok && hipMalloc((void**)&c->d_ent, ent.size() * sizeof(ZkPortionEntry)) == hipSuccess &&
+           hipMemcpy(c->d_ent, ent.data(), ent.size() * sizeof(ZkPortionEntry), hipMemcpyHostToDevice) == hipSuccess;
+    }
     ok = ok && hipMemcpy(c->d_invtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(ZkSeg), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(c->d_first_seg, c->first_seg.data(), c->first_seg.size() * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess;
@@ -310,25 +358,45 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
            hipMemcpy(c->d_net_counts, c->net.step_count.data(), c->net.step_count.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
       if (ok) std::vector<u32>().swap(c->net.records);
     }
-    if (ok && c->lin_host.n_rows()) {
-      const ZkLinPlan& Pn = c->lin_host;
-      const size_t nt = std::max<size_t>(Pn.src.size(), 1);
-      c->lin_rows = Pn.n_rows();
-      ok = hipMalloc((void**)&c->d_lin_row, Pn.row_ptr.size() * 8) == hipSuccess &&
-           hipMalloc((void**)&c->d_lin_dst, Pn.dst.size() * 4) == hipSuccess &&
-           hipMalloc((void**)&c->d_lin_src, nt * 4) == hipSuccess &&
-           hipMalloc((void**)&c->d_o0_desc, c->o0_desc.size() * 4) == hipSuccess &&
-           hipMemcpy(c->d_o0_desc, c->o0_desc.data(), c->o0_desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-           hipMalloc((void**)&c->d_o0_long, std::max<size_t>(c->o0_long.size(), 1) * 4) == hipSuccess &&
-           hipMemcpy(c->d_o0_long, c->o0_long.data(), c->o0_long.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-           hipMalloc((void**)&c->d_lin_coef, nt * sizeof(Fr)) == hipSuccess &&
-           hipMalloc((void**)&c->d_lin_kind, nt) == hipSuccess &&
-           hipMemcpy(c->d_lin_row, Pn.row_ptr.data(), Pn.row_ptr.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
-           hipMemcpy(c->d_lin_dst, Pn.dst.data(), Pn.dst.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-           hipMemcpy(c->d_lin_src, c->o0_src.data(), c->o0_src.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-           hipMemcpy(c->d_lin_coef, Pn.coef.data(), Pn.coef.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess &&
-           hipMemcpy(c->d_lin_kind, Pn.kind.data(), Pn.kind.size(), hipMemcpyHostToDevice) == hipSuccess;
-      if (ok) { ZkLinPlan empty; std::swap(c->lin_host, empty); c->n_o0_long = c->o0_long.size(); std::vector<u32>().swap(c->o0_desc); std::vector<u32>().swap(c->o0_src); std::vector<u32>().swap(c->o0_long); }   // the device copies are the ones used
+    if (ok && c->full_W) {
+      // numbered circuit: descriptors + row tables on the device (the host copies of the plan are dropped)
+      ZkO0Tables& T = c->o0t;
+      ZkO0Dev& O = c->o0d;
+      auto up = [&](const void* src, size_t bytes, void** dst) {
+        *dst = nullptr;
+        if (!ok) return;
+        ok = hipMalloc(dst, std::max<size_t>(bytes, 16)) == hipSuccess && (bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess);
+      };
+      up(T.desc.data(), T.desc.size() * 4, (void**)&O.desc);
+      up(T.s_ptr.data(), T.s_ptr.size() * 8, (void**)&O.s_ptr);
+      up(T.s_term.data(), T.s_term.size() * 4, (void**)&O.s_term);
+      up(T.s_coef.data(), T.s_coef.size() * 4, (void**)&O.s_coef);
+      up(T.s_chain.data(), T.s_chain.size(), (void**)&O.s_chain);
+      {
+        // small rows: the groups of one row (a thread each) and the chains (a wavefront each)
+        std::vector<u32> single, chains;
+        for (size_t g = 0; g + 1 < T.s_group.size(); ++g) {
+          const u32 a = T.s_group[g], b = T.s_group[g + 1];
+          if (b - a == 1) single.push_back(a); else { chains.push_back(a); chains.push_back(b - a); }
+        }
+        up(single.data(), single.size() * 4, (void**)&O.s_single);
+        up(chains.data(), chains.size() * 4, (void**)&O.s_chains);
+        O.n_small_single = (u32)single.size(); O.n_small_chains = (u32)(chains.size() / 2);
+      }
+      up(T.f_ptr.data(), T.f_ptr.size() * 8, (void**)&O.f_ptr);
+      up(T.f_term.data(), T.f_term.size() * 4, (void**)&O.f_term);
+      up(T.f_coef.data(), T.f_coef.size() * sizeof(Fr), (void**)&O.f_coef);
+      up(T.f_kind.data(), T.f_kind.size(), (void**)&O.f_kind);
+      up(T.f_chain.data(), T.f_chain.size(), (void**)&O.f_chain);
+      up(T.f_group.data(), T.f_group.size() * 4, (void**)&O.f_group);
+      O.W = c->full_W; O.nportions = (u32)((c->full_W + 256u * c->x3_k_o0 - 1) / (256u * c->x3_k_o0)); O.small_base = T.small_base; O.fr_base = T.fr_base;
+      O.emails_per_wg = (u32)c->o0_emails_per_wg;
+      O.n_fr_groups = (u32)(T.f_group.size() - 1);
+      if (ok) {
+        ZkLinPlan empty; std::swap(c->lin_host, empty);
+        std::vector<u32>().swap(c->o0_desc); std::vector<u32>().swap(c->o0_src); std::vector<u32>().swap(c->o0_long);
+        { ZkO0Tables keep; keep.small_base = T.small_base; keep.fr_base = T.fr_base; keep.n_alias = T.n_alias; keep.n_const = T.n_const; std::swap(T, keep); }
+      }
     }
     if (ok && c->s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER) {
       std::vector<Fr> C, M, t10;
@@ -337,6 +405,16 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       c->pos_dense_off = (u32)t10.size();
       t10.insert(t10.end(), C.begin(), C.end());     // dense tables for zk_poseidon9_wave
       t10.insert(t10.end(), M.begin(), M.end());
+      {
+        // additive constants of the sparse rounds in Montgomery form (zk_poseidon9_g16 keeps its state in Montgomery form)
+        const u32 T = 10, RP = 60;
+        const size_t c_part = 4 * T + T * T, c_last = c_part + RP * T + RP * (2 * T - 1) + T * T;
+        std::vector<Fr> cm;
+        for (u32 i = 0; i < 4 * T; ++i) cm.push_back(fr_to_mont(t10[i]));
+        for (u32 i = 0; i < RP * T; ++i) cm.push_back(fr_to_mont(t10[c_part + i]));
+        for (u32 i = 0; i < 4 * T; ++i) cm.push_back(fr_to_mont(t10[c_last + i]));
+        t10.insert(t10.end(), cm.begin(), cm.end());
+      }
       ok = ok && hipMalloc((void**)&c->d_pos, t10.size() * sizeof(Fr)) == hipSuccess &&
            hipMemcpy(c->d_pos, t10.data(), t10.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
     }
@@ -353,7 +431,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     }
     if (!ok) {
       hipFree(c->d_pos); hipFree(c->d_pos_rs);
-      hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg);
+      hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_ent);
       delete c;
       return ZKWG_RC_OOM;
     }
@@ -386,6 +464,8 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       }
       c->pos_calls = 0;
       c->pos_side = getenv("ZKWG_POS_SIDE") ? atoi(getenv("ZKWG_POS_SIDE")) : 0;   // measured: inline is faster in the pipeline
+      c->pos_lane = getenv("ZKWG_POS_LANE") ? atoi(getenv("ZKWG_POS_LANE")) : 0;
+      c->pos_wave_below = getenv("ZKWG_POS_WAVE_BELOW") ? atoi(getenv("ZKWG_POS_WAVE_BELOW")) : 1024;
     }
     for (int i = 0; i < 2; ++i) { hipEventCreateWithFlags(&c->hb_done[i], hipEventDisableTiming); hipEventCreateWithFlags(&c->hb_copied[i], hipEventDisableTiming); }
     for (int r = 0; r < ZK_EV_RING; ++r) {
@@ -446,6 +526,7 @@ int zkwg_regex_info(const zkwg_circuit_t* c, uint64_t out[8]) {
 int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness) {
   if (!c || !witness) return ZKWG_RC_BAD_ARG;
   const ZkLinPlan& Pn = c->lin_host;
+  if (c->lin_rows && !Pn.n_rows()) return ZKWG_RC_BAD_CONFIG;   // a device handle keeps its plan on the device only
   for (u64 r = 0; r < Pn.n_rows(); ++r)
     ((Fr*)witness)[Pn.dst[r]] = zk_linear_row(Pn.row_ptr.data(), Pn.src.data(), Pn.coef.data(), Pn.kind.data(), r, (const Fr*)witness);
   return ZKWG_RC_OK;
@@ -506,11 +587,12 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
-    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
-    hipFree(c->d_lin_row); hipFree(c->d_lin_dst); hipFree(c->d_lin_src); hipFree(c->d_lin_coef); hipFree(c->d_lin_kind);
-    hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_o0_desc); hipFree(c->d_o0_long); hipFree(c->d_stage);
+    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
+    hipFree((void*)c->o0d.desc); hipFree((void*)c->o0d.s_ptr); hipFree((void*)c->o0d.s_term); hipFree((void*)c->o0d.s_coef); hipFree((void*)c->o0d.s_chain); hipFree((void*)c->o0d.s_single); hipFree((void*)c->o0d.s_chains);
+    hipFree((void*)c->o0d.f_ptr); hipFree((void*)c->o0d.f_term); hipFree((void*)c->o0d.f_coef); hipFree((void*)c->o0d.f_kind); hipFree((void*)c->o0d.f_chain); hipFree((void*)c->o0d.f_group);
+    hipFree(c->d_net_records); hipFree(c->d_net_counts);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
-    for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); }
+    for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); if (c->hx_img[i]) hipHostFree(c->hx_img[i]); }
     hipStreamDestroy(c->copy_stream);
     hipStreamDestroy(c->own_stream);
     for (int i = 0; i < ZK_POS_STREAMS; ++i) { hipStreamSynchronize(c->pos_stream[i]); hipStreamDestroy(c->pos_stream[i]); }
@@ -695,6 +777,19 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.xcd_remap = c->xcd_remap;
 }
 
+static void fill_x3(const zkwg_circuit* c, const ZkBufs& B, ZkX3& A) {
+  const ZkSched& s = c->s;
+  A.in = B.in; A.bits = B.bits; A.small = B.small; A.frv = B.frv; A.invtab = B.invtab;
+  A.ent = c->d_ent; A.segs = c->d_segs; A.wit = B.wit;
+  A.frm = B.frm; A.invtab_m = B.invtab_m; A.rtab = B.rtab;
+  A.frm_w = B.frm; A.small_w = B.small; A.frv_w = B.frv;
+  A.wit_stride16 = B.wit_stride16; A.W = s.W;
+  A.in_stride = s.in_stride; A.img_bits = s.img_bits; A.img_small = s.img_small; A.img_fr = s.img_fr; A.inv_half = s.inv_half;
+  A.m_dfa_cm = s.m_dfa_cm; A.m_dfa_pm = s.m_dfa_pm;
+  A.nportions = c->n_ent; A.nsegs = s.nsegs; A.e_first = B.e_first; A.n_count = B.n_emails - B.e_first;
+  A.xcd_remap = c->xcd_remap ? 1u : 0u; A.limb_off = s.in_off[ZKWG_IN_PUBKEY];
+}
+
 int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_status, void* d_scratch,
                         void* hip_stream) {
   if (!c || !d_in || !d_status || !d_scratch) return ZKWG_RC_BAD_ARG;
@@ -728,8 +823,9 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     c->pos_calls++;
     hipEventRecord(c->pos_dep[pos_slot], st);
     hipStreamWaitEvent(ps, c->pos_dep[pos_slot], 0);
-    if (ne < 1024) hipLaunchKernelGGL(zk_poseidon9_wave, dim3(ne), dim3(64), 0, ps, s, B);
-    else hipLaunchKernelGGL(zk_poseidon9, dim3((ne + 63) / 64), dim3(64), 0, ps, s, B);
+    if ((int)ne < c->pos_wave_below) hipLaunchKernelGGL(zk_poseidon9_wave, dim3(ne), dim3(64), 0, ps, s, B);
+    else if (c->pos_lane) hipLaunchKernelGGL(zk_poseidon9, dim3((ne + 63) / 64), dim3(64), 0, ps, s, B);
+    else hipLaunchKernelGGL(zk_poseidon9_g16, dim3((ne + 3) / 4), dim3(64), 0, ps, s, B);
     hipEventRecord(c->pos_done[pos_slot], ps);
   }
   if (tm) hipEventRecord(evs[ki], st);
@@ -763,8 +859,9 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
   if (tm) hipEventRecord(evs[++ki], st);
   if (pos9 && pos_slot < 0) {
     // one lane per email once the batch supplies >= 16 wavefronts of them; one wavefront per email below
-    if (ne < 1024) hipLaunchKernelGGL(zk_poseidon9_wave, dim3(ne), dim3(64), 0, st, s, B);
-    else hipLaunchKernelGGL(zk_poseidon9, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
+    if ((int)ne < c->pos_wave_below) hipLaunchKernelGGL(zk_poseidon9_wave, dim3(ne), dim3(64), 0, st, s, B);
+    else if (c->pos_lane) hipLaunchKernelGGL(zk_poseidon9, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
+    else hipLaunchKernelGGL(zk_poseidon9_g16, dim3((ne + 3) / 4), dim3(64), 0, st, s, B);
   }
   if (pos_slot >= 0) hipStreamWaitEvent(st, c->pos_done[pos_slot], 0);   // join
   if (s.rslb) {
@@ -810,7 +907,7 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   if (!dg.ok) return ZKWG_RC_HIP_ERROR;
   hipStream_t st = (hipStream_t)hip_stream;
   if (mont) {
-    if (!c->expand_v2 && s.portion > ZK_PORTION_DEFAULT) return ZKWG_RC_BAD_CONFIG;
+    if (c->expand_v == 1 && s.portion > ZK_PORTION_DEFAULT) return ZKWG_RC_BAD_CONFIG;
     if (!c->d_rtab || !c->d_invtab_m) {
       // v * R mod r for v < 65536 (2 MiB) and the inverse table in Montgomery form, built once per handle and
       // published together (a half-built pair must never be seen by a later call)
@@ -831,24 +928,9 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
       c->d_rtab = d_r; c->d_invtab_m = d_i;
     }
   }
-  // Fully numbered circuit: zk_expand writes the kept-v1 witnesses into a staging buffer of the handle and the gather
-  // kernels produce the file's wires from it.  (ZKWG_O0_STAGE_MB cuts the launch into sub-tiles whose staging fits that
-  // many MB -- sized to the 256 MB Infinity Cache it measured SLOWER: 15.4 k witnesses/s at 160 MB, 11.9 k at 64 MB
-  // against 19.4 k for the whole launch at once, EmailVerifier(576,192).)
-  u64 sub = count;
-  if (c->full_W) {
-    if (mont) return ZKWG_RC_BAD_CONFIG;
-    if (const char* v = getenv("ZKWG_O0_STAGE_MB"))
-      sub = std::min<u64>(count, std::max<u64>(1, ((u64)std::max(1, atoi(v)) << 20) / (s.W * 32)));
-    const u64 need = sub * s.W * 32;
-    if (c->stage_bytes < need) {
-      hipDeviceSynchronize();   // (grow-only, rare) no launch of any stream may still read the old buffer
-      hipFree(c->d_stage);
-      c->d_stage = nullptr; c->stage_bytes = 0;
-      if (hipMalloc((void**)&c->d_stage, need) != hipSuccess) return ZKWG_RC_OOM;
-      c->stage_bytes = need;
-    }
-  }
+  // sub-launches: the O0 row kernels index emails with blockIdx.y; zk_expand3's grid is pieces x emails
+  u64 sub = c->full_W ? std::min<u64>(count, 32768) : count;
+  { const u64 per = c->full_W ? c->o0d.nportions : c->n_ent; if (per) sub = std::min<u64>(sub, std::max<u64>(1, 0x7fffffffull / per)); }
   ZkBufs B;
   fill_bufs(c, B, d_in, n, (void*)d_scratch);
   if (s.rslb && !c->rs_sync)   // the merge chain of this scratch buffer may still be running on the side stream
@@ -861,17 +943,46 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   for (u64 off = 0; off < count; off += sub) {
     const u64 cnt = std::min(sub, count - off);
     u8* out_sub = (u8*)d_out + off * out_stride;
-    B.wit = c->full_W ? (uint4*)c->d_stage : (uint4*)out_sub;
-    B.wit_stride16 = c->full_W ? s.W * 2 : out_stride / 16;
+    B.wit = (uint4*)out_sub;
+    B.wit_stride16 = out_stride / 16;
     B.e_first = (u32)(first + off);
     B.n_emails = (u32)(first + off + cnt);
+    ZkX3 A;
+    fill_x3(c, B, A);
+    const u64 conv = cnt * (u64)(s.img_fr + ZK_MONT_LIMBS);
+    if (c->full_W) {
+      // numbered circuit (`--O0` / `--O1`), one pass: the rows that are real sums go into the image extensions of these
+      // emails, then every wire is written from its descriptor (zkwg_o0.h) -- no staging buffer, no gather
+      const ZkO0Dev& O = c->o0d;
+      if (O.n_small_single) hipLaunchKernelGGL(zk_o0_rows_small, dim3((O.n_small_single + 255) / 256, (u32)cnt), dim3(256), 0, st, A, O);
+      if (O.n_small_chains) hipLaunchKernelGGL(zk_o0_chains_small, dim3(O.n_small_chains, (u32)cnt), dim3(64), 0, st, A, O);
+      if (O.n_fr_groups) hipLaunchKernelGGL(zk_o0_rows_fr, dim3((O.n_fr_groups * ZK_FR_LANES + 255) / 256, (u32)cnt), dim3(256), 0, st, A, O);
+      const u64 units = ((cnt + O.emails_per_wg - 1) / O.emails_per_wg) * (u64)O.nportions;
+      if (units > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
+      if (mont) hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, A);
+      const dim3 g3((u32)units), b3(256);
+#define ZK_LAUNCH_O0(K) do { if (mont) hipLaunchKernelGGL(zk_expand3_o0_mont_k##K, g3, b3, 0, st, A, O); else hipLaunchKernelGGL(zk_expand3_o0_k##K, g3, b3, 0, st, A, O); } while (0)
+      if (c->x3_k_o0 == 1) ZK_LAUNCH_O0(1); else if (c->x3_k_o0 == 2) ZK_LAUNCH_O0(2); else ZK_LAUNCH_O0(4);
+#undef ZK_LAUNCH_O0
+      continue;
+    }
+    if (c->expand_v == 3) {
+      // one piece of 256 K slots per workgroup (zkwg_kernels_expand3.hip)
+      const u64 units3 = cnt * (u64)c->n_ent;
+      if (units3 > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
+      if (mont) hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, A);
+      const dim3 g3((u32)units3), b3(256);
+#define ZK_LAUNCH_X3(K) do { if (mont) hipLaunchKernelGGL(zk_expand3_mont_k##K, g3, b3, 0, st, A); else hipLaunchKernelGGL(zk_expand3_k##K, g3, b3, 0, st, A); } while (0)
+      if (c->x3_k == 1) ZK_LAUNCH_X3(1); else if (c->x3_k == 2) ZK_LAUNCH_X3(2); else if (c->x3_k == 8) ZK_LAUNCH_X3(8); else ZK_LAUNCH_X3(4);
+#undef ZK_LAUNCH_X3
+      continue;
+    }
     const u64 units = ((cnt + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions;
     const dim3 grid((u32)units);
-    if (c->expand_v2) {
+    if (c->expand_v == 2) {
       // LDS-staged kernel (zkwg_kernels_expand2.hip): 4 bytes of LDS per slot of the portion
       if (mont) {
-        const u64 conv = cnt * (u64)(s.img_fr + ZK_MONT_LIMBS);
-        hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, s, B);
+        hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, A);
         hipLaunchKernelGGL(zk_expand2_mont, grid, dim3(256), s.portion * 4u, st, s, B);
       } else hipLaunchKernelGGL(zk_expand2, grid, dim3(256), s.portion * 4u, st, s, B);
     }
@@ -880,22 +991,6 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
     else if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
     else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
     else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);
-    if (c->full_W) {
-      // every wire of the compiled circuit from the staged kept-v1 witness: aliases copy, the rest are linear rows
-      const u64 chunks = c->full_W * 2;
-      hipLaunchKernelGGL(zk_o0_gather, dim3((u32)((chunks + 1023) / 1024), (u32)cnt), dim3(256), 0, st, c->d_o0_desc,   // 4 chunks per thread
-                         c->full_W, (const u8*)c->d_stage, s.W * 32, out_sub, out_stride);
-      // the other derived signals: 4 lanes per row up to ZK_O0_SHORT_ROW terms, 16 lanes per row beyond (running sums, Bits2Num ...)
-      if (c->n_o0_short)
-        hipLaunchKernelGGL(zk_o0_rows_4, dim3((u32)((c->n_o0_short + 63) / 64), (u32)cnt), dim3(256), 0, st, c->d_o0_long, (u32)c->n_o0_short,
-                           c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, (const u8*)c->d_stage, s.W * 32,
-                           out_sub, out_stride);
-      if (c->n_o0_long > c->n_o0_short)
-        hipLaunchKernelGGL(zk_o0_rows_16, dim3((u32)((c->n_o0_long - c->n_o0_short + 15) / 16), (u32)cnt), dim3(256), 0, st,
-                           c->d_o0_long + c->n_o0_short, (u32)(c->n_o0_long - c->n_o0_short),
-                           c->d_lin_row, c->d_lin_dst, c->d_lin_src, c->d_lin_coef, c->d_lin_kind, (const u8*)c->d_stage, s.W * 32,
-                           out_sub, out_stride);
-    }
   }
   if (tm) { hipEventRecord(evs[1], st); c->ev_valid = true; c->launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
@@ -986,8 +1081,133 @@ static int calculate_batch_impl(zkwg_circuit_t* c, const uint8_t* packed, uint64
   return rc;
 }
 
+
+// ------------------------------------------------------------------ host expansion (the delivered rate)
+// A witness delivered to HOST memory crosses PCIe at 32 bytes per signal (56.9 MB per email, ~55 GB/s: 963 witnesses/s).
+// Its information is the 0.45 MB image.  zkwg_expand_host runs the same segment decoders (zkwg_expand_dec.h, compiled
+// for the host) over a downloaded image and writes the witness straight into the caller's buffer with non-temporal
+// stores, on `threads` host threads -- the expansion then costs host memory bandwidth instead of PCIe.  Bit-identical
+// to zk_expand by construction (same decoders), checked in tests/test_host_expand.py.
+int zkwg_expand_host(const zkwg_circuit_t* c, const uint8_t* records, uint64_t n, const uint8_t* scratch_host, uint64_t first,
+                     uint64_t count, uint8_t* out, uint64_t out_stride, int threads) {
+  if (!c || !records || !scratch_host || !out) return ZKWG_RC_BAD_ARG;
+  if (c->full_W) return ZKWG_RC_BAD_CONFIG;      // numbered circuits: their row results are computed on the device
+  const ZkSched& s = c->s;
+  if (first + count > n || out_stride < s.W * 32 || (out_stride & 15) || ((uintptr_t)out & 15)) return ZKWG_RC_BAD_ARG;
+  const ZkScratchLayout L = scratch_layout(s, n);
+  const u64* bits = (const u64*)(scratch_host + L.off_bits);
+  const u32* small = (const u32*)(scratch_host + L.off_small);
+  const Fr* frv = (const Fr*)(scratch_host + L.off_fr);
+  const u64 CH = 1u << 16;                                   // slots per work item
+  const u64 per = (s.W + CH - 1) / CH, items = count * per;
+  std::atomic<u64> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const u64 it = next.fetch_add(1);
+      if (it >= items) break;
+      const u64 el = it / per, slot0 = (it % per) * CH, slot1 = std::min<u64>(s.W, slot0 + CH), e = first + el;
+      ZkCtx cx;
+      cx.rec = records + e * s.in_stride; cx.bits = bits + e * s.img_bits; cx.small = small + e * s.img_small;
+      cx.half = (int)s.inv_half; cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm;
+      ZkRefSrc R;
+      R.frv = (const uint4*)(frv + e * s.img_fr); R.invtab = (const uint4*)c->invtab_host.data(); R.rec = cx.rec; R.small = cx.small;
+      u8* w = out + el * out_stride;
+      size_t lo = 0, hi = c->segs.size();
+      while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (c->segs[mid].slot <= slot0) lo = mid; else hi = mid; }
+      for (size_t si = lo; si < c->segs.size() && c->segs[si].slot < slot1; ++si) {
+        const ZkSeg& sg = c->segs[si];
+        const u64 a = std::max<u64>(sg.slot, slot0), b = std::min<u64>(sg.slot + sg.nslots, slot1);
+        const u32 r0 = (u32)(a - sg.slot) + sg.r0, cnt = (u32)(b - a);
+        u8* dst = w + 32 * a;
+        switch (sg.type) {
+#define ZK_X(T, D) case T: zk_host_segment<D>(sg, cx, R, r0, cnt, dst); break;
+          ZK_FOR_SEG_TYPES(ZK_X)
+#undef ZK_X
+          default: memset(dst, 0, 32ull * cnt); break;
+        }
+      }
+    }
+    _mm_sfence();
+  };
+  const int T = std::max(1, threads);
+  std::vector<std::thread> th;
+  for (int i = 1; i < T; ++i) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  return ZKWG_RC_OK;
+}
+int zkwg_set_host_expand(zkwg_circuit_t* c, int threads) {
+  if (!c || threads < 0) return ZKWG_RC_BAD_ARG;
+  std::lock_guard<std::mutex> lock(c->hb_mutex);
+  c->host_expand_threads = threads;
+  return ZKWG_RC_OK;
+}
+
+// zkwg_calculate_batch with the expansion on the host: per tile H2D records -> prepare kernels -> D2H of the image
+// (0.45 MB per email instead of 56.9 MB of witness) into pinned staging; the host threads expand tile t into the
+// caller's buffer while the device prepares tile t + 1.
+static int calculate_batch_hostexpand(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
+                                      uint64_t out_stride, int32_t* status, uint64_t max_tile) {
+  const ZkSched& s = c->s;
+  if (hipSetDevice(c->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  const u64 tile = std::min<u64>(max_tile ? max_tile : 256, n);
+  const u64 scr_bytes = zkwg_scratch_bytes(c, tile);
+  // device: records + scratch + status for two tiles in flight
+  u8 *d_in[2] = {nullptr, nullptr}, *d_scr[2] = {nullptr, nullptr};
+  int* d_st[2] = {nullptr, nullptr};
+  int rc = ZKWG_RC_OK;
+  if (c->hx_bytes < scr_bytes) {
+    for (int i = 0; i < 2; ++i) { if (c->hx_img[i]) hipHostFree(c->hx_img[i]); c->hx_img[i] = nullptr; }
+    c->hx_bytes = 0;
+    for (int i = 0; i < 2; ++i) if (hipHostMalloc((void**)&c->hx_img[i], scr_bytes, hipHostMallocDefault) != hipSuccess) rc = ZKWG_RC_OOM;
+    if (rc == ZKWG_RC_OK) c->hx_bytes = scr_bytes;
+  }
+  for (int i = 0; i < 2 && rc == ZKWG_RC_OK; ++i)
+    if (hipMalloc((void**)&d_in[i], tile * s.in_stride) != hipSuccess || hipMalloc((void**)&d_scr[i], scr_bytes) != hipSuccess ||
+        hipMalloc((void**)&d_st[i], tile * sizeof(int)) != hipSuccess) rc = ZKWG_RC_OOM;
+  hipStream_t st = c->own_stream;
+  const ZkScratchLayout L = scratch_layout(s, tile);
+  const u64 img_lo = L.off_bits, img_hi = L.off_frm;          // the image arrays (not the SHA chaining states / Montgomery copies)
+  auto submit = [&](u64 t) -> int {
+    const u64 base = t * tile, cnt = std::min<u64>(tile, n - base);
+    const int b = (int)(t & 1);
+    if (hipMemcpyAsync(d_in[b], packed + base * s.in_stride, cnt * s.in_stride, hipMemcpyHostToDevice, st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+    // NB the scratch layout depends on the batch size: every tile is prepared as a batch of `tile` emails (the last one
+    // over stale records beyond cnt -- their images are never expanded)
+    int r = zkwg_prepare_device(c, d_in[b], tile, d_st[b], d_scr[b], st);
+    if (r != ZKWG_RC_OK) return r;
+    if (s.rslb && !c->rs_sync)
+      for (int i = 0; i < ZK_RS_SLOTS; ++i) if (c->rs_scr[i] == d_scr[b]) hipStreamWaitEvent(st, c->rs_done[i], 0);
+    if (hipMemcpyAsync(c->hx_img[b] + img_lo, d_scr[b] + img_lo, img_hi - img_lo, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(status + base, d_st[b], cnt * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipEventRecord(c->hb_done[b], st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+    return ZKWG_RC_OK;
+  };
+  const u64 ntiles = (n + tile - 1) / tile;
+  if (rc == ZKWG_RC_OK) rc = submit(0);
+  for (u64 t = 0; rc == ZKWG_RC_OK && t < ntiles; ++t) {
+    if (t + 1 < ntiles) rc = submit(t + 1);                     // the device works on tile t + 1 ...
+    if (rc != ZKWG_RC_OK) break;
+    const int b = (int)(t & 1);
+    if (hipEventSynchronize(c->hb_done[b]) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
+    const u64 base = t * tile, cnt = std::min<u64>(tile, n - base);
+    // ... while the host expands tile t (records: the caller's own buffer, indexed from the tile's first email)
+    // (the image was laid out for a batch of `tile` emails: zkwg_expand_host derives the same layout from its n argument;
+    //  only the records of the cnt emails it expands are read)
+    rc = zkwg_expand_host(c, packed + base * s.in_stride, tile, c->hx_img[b], 0, cnt, out_wtns + base * out_stride, out_stride,
+                          c->host_expand_threads);
+  }
+  if (hipStreamSynchronize(st) != hipSuccess && rc == ZKWG_RC_OK) rc = ZKWG_RC_HIP_ERROR;
+  for (int i = 0; i < 2; ++i) { hipFree(d_in[i]); hipFree(d_scr[i]); hipFree(d_st[i]); }
+  return rc;
+}
+
 int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
                          uint64_t out_stride, int32_t* status, uint64_t max_tile) {
+  if (c && c->device >= 0 && c->host_expand_threads > 0 && out_wtns && packed && status && n && !c->full_W && out_stride >= out_W(c) * 32 && !(out_stride & 15) && !((uintptr_t)out_wtns & 15)) {
+    std::lock_guard<std::mutex> lock(c->hb_mutex);
+    return calculate_batch_hostexpand(c, packed, n, out_wtns, out_stride, status, max_tile);
+  }
   return calculate_batch_impl(c, packed, n, out_wtns, out_stride, status, max_tile, nullptr);
 }
 
@@ -1019,6 +1239,19 @@ void* zkwg_alloc_pinned(uint64_t bytes) {
   return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
 }
 void zkwg_free_pinned(void* p) { if (p) hipHostFree(p); }
+
+
+// A stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): bit i of `mask` enables CU i.
+// bench.py uses it to keep the latency-bound prepare kernels off the CUs zk_expand streams from.
+void* zkwg_stream_create_masked(int device, const uint32_t* mask, int words) {
+  if (!mask || words <= 0) return nullptr;
+  ZkDeviceGuard dg(device);
+  if (!dg.ok) return nullptr;
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask) != hipSuccess) return nullptr;
+  return (void*)st;
+}
+void zkwg_stream_destroy(void* stream) { if (stream) hipStreamDestroy((hipStream_t)stream); }
 
 uint64_t zkwg_wtns_size(const zkwg_circuit_t* c) { return 12 + 12 + 40 + 12 + out_W(c) * 32; }
 

@@ -12,25 +12,6 @@
 // Tables derived from the final segment list: the first segment of every portion, the per-segment reciprocal of
 // the type's period (so that zk_expand divides with one multiply; only set when exact over the segment's range)
 // and the per-portion flags of zk_expand's store phase.
-static inline bool zk_seg_is_immediate(const ZkSeg& g) {
-  switch (g.type) {
-    case ZSEG_BITS: case ZSEG_SHA_SP: case ZSEG_SHA_T1: case ZSEG_SHA_T2: case ZSEG_IN8: case ZSEG_IN8MASK:
-    case ZSEG_IN8BITS: case ZSEG_LTBITS: case ZSEG_B64BITS: case ZSEG_HOLE: return true;
-    case ZSEG_DFA: return g.a != ZDFA_EQ;
-    case ZSEG_RSLB: return g.a != ZRS_EQ;
-    default: return false;
-  }
-}
-static inline u32 zk_seg_period(const ZkSeg& g) {
-  switch (g.type) {
-    case ZSEG_BITS: return g.a;
-    case ZSEG_SEL: return 3u * g.a;
-    case ZSEG_LTBITS: return g.a + 1u;
-    case ZSEG_REGSEL: return g.a + 7u;
-    case ZSEG_VSHIFT: return g.a;
-    default: return 0;
-  }
-}
 static inline void zk_finish_tables(ZkSched& s, std::vector<ZkSeg>& segs, std::vector<u32>& first_seg) {
   for (ZkSeg& g : segs) {
     g.pad = 0;
@@ -53,6 +34,23 @@ static inline void zk_finish_tables(ZkSched& s, std::vector<ZkSeg>& segs, std::v
   }
 }
 
+// one entry per `piece`-slot piece of the witness (zkwg_sched.h ZkPortionEntry)
+static inline void zk_build_entries(u64 W, const std::vector<ZkSeg>& segs, std::vector<ZkPortionEntry>& ent, u32 piece) {
+  const u64 np = (W + piece - 1) / piece;
+  ent.assign(np, ZkPortionEntry{});
+  size_t si = 0;
+  for (u64 p = 0; p < np; ++p) {
+    const u64 slot0 = p * piece, slot1 = std::min<u64>(W, slot0 + piece);
+    while (si + 1 < segs.size() && segs[si].slot + segs[si].nslots <= slot0) ++si;
+    const ZkSeg& g = segs[si];
+    ZkPortionEntry& e = ent[p];
+    e.first_seg = (u32)si;
+    if (g.slot <= slot0 && slot1 <= g.slot + g.nslots) {
+      e.type = g.type; e.src = g.src; e.a = g.a; e.b = g.b; e.c = g.c; e.magic = g.pad;
+      e.r_start = (u32)(slot0 - g.slot) + g.r0;
+    } else e.type = ZSEG_NTYPES;
+  }
+}
 static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& segs,
                         std::vector<u32>& first_seg, u32 portion = ZK_PORTION_DEFAULT, const zkc::Net* net = nullptr) {
   memset(&s, 0, sizeof(s));

@@ -12,8 +12,8 @@ __device__ __forceinline__ void zk_st16(uint4* p, uint4 v) {
   __builtin_nontemporal_store(x, reinterpret_cast<zk_u32x4*>(p));
 }
 
-__device__ __forceinline__ uint4 zk_small(u32 v) { return make_uint4(v, 0u, 0u, 0u); }
-__device__ __forceinline__ uint4 zk_zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+__host__ __device__ __forceinline__ uint4 zk_small(u32 v) { return make_uint4(v, 0u, 0u, 0u); }
+__host__ __device__ __forceinline__ uint4 zk_zero4() { return make_uint4(0u, 0u, 0u, 0u); }
 __device__ __forceinline__ uint4 zk_fr_half(const Fr& a, u32 half) {
   u64 x = a.l[half * 2], y = a.l[half * 2 + 1];
   return make_uint4((u32)x, (u32)(x >> 32), (u32)y, (u32)(y >> 32));

@@ -12,12 +12,16 @@
 #include "zkwg_dev.h"
 #include "zkwg_bh_dfa.h"
 
+// the decoders also run on the host (zkwg_expand_host: witnesses expanded in host memory from a downloaded image)
+#define ZK_DEC __host__ __device__
+
 #define ZK_REF 0x80000000u
 #define ZK_REF_FRV (ZK_REF | (0u << 28))   // frv[payload]            (32 bytes)
 #define ZK_REF_INV (ZK_REF | (1u << 28))   // invtab[payload]         (d^-1, payload = d + inv_half)
 #define ZK_REF_LIMB (ZK_REF | (2u << 28))  // 16-byte limb at rec + payload, high half zero
 #define ZK_REF_RAW (ZK_REF | (3u << 28))   // small[payload] as a raw 32-bit value (bit 31 may be set)
 #define ZK_REF_NEG (ZK_REF | (4u << 28))   // small[payload] is a signed word w, d = (i32)(w << 1) >> 1 < 0: the slot is r + d
+#define ZK_REF_I64 (ZK_REF | (5u << 28))   // (small[payload], small[payload + 1]) is a signed 64-bit integer v: the slot is v mod r
 #define ZK_REF_TYPE(code) (((code) >> 28) & 7u)
 #define ZK_REF_PAYLOAD(code) ((code) & 0x0fffffffu)
 
@@ -29,24 +33,25 @@ struct ZkCtx {
   u32 m_dfa_cm, m_dfa_pm;
 };
 
-__device__ __forceinline__ u32 zk_udiv(u32 r, u32 d, u32 magic) { return magic ? __umulhi(r, magic) : r / d; }
-__device__ __forceinline__ u32 zk_inv_code(int d, int half) { return ZK_REF_INV | (u32)(max(-half, min(half, d)) + half); }
-__device__ __forceinline__ u32 zk_raw_code(u32 v, u32 idx) { return (v >> 31) ? (ZK_REF_RAW | idx) : v; }
+ZK_DEC __forceinline__ u32 zk_udiv(u32 r, u32 d, u32 magic) { return magic ? (u32)(((u64)r * magic) >> 32) : r / d; }
+ZK_DEC __forceinline__ u32 zk_inv_code(int d, int half) { const int c = d < -half ? -half : (d > half ? half : d); return ZK_REF_INV | (u32)(c + half); }
+ZK_DEC __forceinline__ u32 zk_raw_code(u32 v, u32 idx) { return (v >> 31) ? (ZK_REF_RAW | idx) : v; }
+ZK_DEC __forceinline__ u32 zk_minu(u32 a, u32 b) { return a < b ? a : b; }
 
 struct ZkDecSmall {
   const u32* __restrict__ p; u32 base;
-  __device__ ZkDecSmall(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), base(sg.src) {}
-  __device__ u32 operator()(u32 r) const { return zk_raw_code(p[base + r], base + r); }
+  ZK_DEC ZkDecSmall(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), base(sg.src) {}
+  ZK_DEC u32 operator()(u32 r) const { return zk_raw_code(p[base + r], base + r); }
 };
 struct ZkDecFr {
   u32 base;
-  __device__ ZkDecFr(const ZkSeg& sg, const ZkCtx&) : base(sg.src) {}
-  __device__ u32 operator()(u32 r) const { return ZK_REF_FRV | (base + r); }
+  ZK_DEC ZkDecFr(const ZkSeg& sg, const ZkCtx&) : base(sg.src) {}
+  ZK_DEC u32 operator()(u32 r) const { return ZK_REF_FRV | (base + r); }
 };
 struct ZkDecBits {
   const u64* __restrict__ p; u32 a, b, magic;
-  __device__ ZkDecBits(const ZkSeg& sg, const ZkCtx& cx) : p(cx.bits + sg.src), a(sg.a), b(sg.b), magic(sg.pad) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC ZkDecBits(const ZkSeg& sg, const ZkCtx& cx) : p(cx.bits + sg.src), a(sg.a), b(sg.b), magic(sg.pad) {}
+  ZK_DEC u32 operator()(u32 r) const {
     const u32 g = zk_udiv(r, a, magic), bit = r - g * a;
     return (u32)(p[g * b + (bit >> 6)] >> (bit & 63)) & 1u;
   }
@@ -55,17 +60,17 @@ struct ZkDecBits {
 template <u32 PER, u32 WORDS>
 struct ZkDecSha {
   const u64* __restrict__ p;
-  __device__ ZkDecSha(const ZkSeg& sg, const ZkCtx& cx) : p(cx.bits + sg.src) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC ZkDecSha(const ZkSeg& sg, const ZkCtx& cx) : p(cx.bits + sg.src) {}
+  ZK_DEC u32 operator()(u32 r) const {
     const u32 i = r / PER, q = r - i * PER;
-    const u32 sub = min(q >> 5, WORDS - 1u);
+    const u32 sub = zk_minu(q >> 5, WORDS - 1u);
     return (u32)(p[i * WORDS + sub] >> (q - sub * 32u)) & 1u;
   }
 };
 struct ZkDecIsz {
   const u32* __restrict__ p; int half;
-  __device__ ZkDecIsz(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small + sg.src), half(cx.half) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC ZkDecIsz(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small + sg.src), half(cx.half) {}
+  ZK_DEC u32 operator()(u32 r) const {
     const int d = (int)p[r >> 1];
     return (r & 1u) ? zk_inv_code(d, half) : (u32)(d == 0);
   }
@@ -73,9 +78,9 @@ struct ZkDecIsz {
 struct ZkDecSel {
   // 256 x ItemAtIndex(NB): per output bit k: nums[NB], then NB x (isz.out, isz.inv)
   const u32* __restrict__ dig; u32 NB, per, magic; int idx, half;
-  __device__ ZkDecSel(const ZkSeg& sg, const ZkCtx& cx)
+  ZK_DEC ZkDecSel(const ZkSeg& sg, const ZkCtx& cx)
       : dig(cx.small + sg.b), NB(sg.a), per(3u * sg.a), magic(sg.pad), idx((int)cx.small[sg.src]), half(cx.half) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC u32 operator()(u32 r) const {
     const u32 k = zk_udiv(r, per, magic), q = r - k * per;
     if (q < NB) return ((int)q == idx) ? ((dig[k >> 5] >> (31u - (k & 31u))) & 1u) : 0u;
     const u32 t = q - NB, j = t >> 1;
@@ -84,29 +89,29 @@ struct ZkDecSel {
 };
 struct ZkDecIn8 {
   const u8* __restrict__ p;
-  __device__ ZkDecIn8(const ZkSeg& sg, const ZkCtx& cx) : p(cx.rec + sg.src) {}
-  __device__ u32 operator()(u32 r) const { return p[r]; }
+  ZK_DEC ZkDecIn8(const ZkSeg& sg, const ZkCtx& cx) : p(cx.rec + sg.src) {}
+  ZK_DEC u32 operator()(u32 r) const { return p[r]; }
 };
 struct ZkDecIn8Mask {
   const u8* __restrict__ p; const u8* __restrict__ m;
-  __device__ ZkDecIn8Mask(const ZkSeg& sg, const ZkCtx& cx) : p(cx.rec + sg.src), m(cx.rec + sg.a) {}
-  __device__ u32 operator()(u32 r) const { return (u32)p[r] * (u32)m[r]; }
+  ZK_DEC ZkDecIn8Mask(const ZkSeg& sg, const ZkCtx& cx) : p(cx.rec + sg.src), m(cx.rec + sg.a) {}
+  ZK_DEC u32 operator()(u32 r) const { return (u32)p[r] * (u32)m[r]; }
 };
 struct ZkDecIn8Bits {
   const u8* __restrict__ p;
-  __device__ ZkDecIn8Bits(const ZkSeg& sg, const ZkCtx& cx) : p(cx.rec + sg.src) {}
-  __device__ u32 operator()(u32 r) const { return (u32)(p[r >> 3] >> (r & 7u)) & 1u; }
+  ZK_DEC ZkDecIn8Bits(const ZkSeg& sg, const ZkCtx& cx) : p(cx.rec + sg.src) {}
+  ZK_DEC u32 operator()(u32 r) const { return (u32)(p[r >> 3] >> (r & 7u)) & 1u; }
 };
 struct ZkDecLimb {
   u32 base;
-  __device__ ZkDecLimb(const ZkSeg& sg, const ZkCtx&) : base(sg.src) {}
-  __device__ u32 operator()(u32 r) const { return ZK_REF_LIMB | (base + 16u * r); }
+  ZK_DEC ZkDecLimb(const ZkSeg& sg, const ZkCtx&) : base(sg.src) {}
+  ZK_DEC u32 operator()(u32 r) const { return ZK_REF_LIMB | (base + 16u * r); }
 };
 struct ZkDecLtBits {
   long long base; u32 per, magic;
-  __device__ ZkDecLtBits(const ZkSeg& sg, const ZkCtx& cx)
+  ZK_DEC ZkDecLtBits(const ZkSeg& sg, const ZkCtx& cx)
       : base((long long)(int)cx.small[sg.src] + (1ll << sg.a)), per(sg.a + 1u), magic(sg.pad) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC u32 operator()(u32 r) const {
     const u32 i = zk_udiv(r, per, magic), bit = r - i * per;
     return (u32)((u64)(base - (long long)i) >> bit) & 1u;
   }
@@ -115,9 +120,9 @@ struct ZkDecRegSel {
   // SelectRegexReveal (utils/regex.circom:31-37): per index i: IsEqual(i,start) (out,inv),
   // IsZero(in[i]) (out,inv), [i>0: IsZero(in[i-1]) (out,inv)], GreaterThan(bl)(i, start+43) bits
   const u32* __restrict__ rev; u32 bl, per, N, magic; int start, half;
-  __device__ ZkDecRegSel(const ZkSeg& sg, const ZkCtx& cx)
+  ZK_DEC ZkDecRegSel(const ZkSeg& sg, const ZkCtx& cx)
       : rev(cx.small + sg.b), bl(sg.a), per(6u + sg.a + 1u), N(sg.c), magic(sg.pad), start((int)cx.small[sg.src]), half(cx.half) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC u32 operator()(u32 r) const {
     u32 i, q;
     if (r < per - 2u) {  // index 0 has no "previous" IsZero
       i = 0; q = r < 4u ? r : r + 2u;
@@ -138,8 +143,8 @@ struct ZkDecRegSel {
 };
 struct ZkDecVShift {
   const u32* __restrict__ small; u32 N, b, shift, magic;
-  __device__ ZkDecVShift(const ZkSeg& sg, const ZkCtx& cx) : small(cx.small), N(sg.a), b(sg.b), shift(cx.small[sg.src]), magic(sg.pad) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC ZkDecVShift(const ZkSeg& sg, const ZkCtx& cx) : small(cx.small), N(sg.a), b(sg.b), shift(cx.small[sg.src]), magic(sg.pad) {}
+  ZK_DEC u32 operator()(u32 r) const {
     const u32 j = zk_udiv(r, N, magic), i = r - j * N;
     const u32 sh = shift & ((2u << j) - 1u);
     const u32 idx = b + (i + sh) % N;
@@ -149,8 +154,8 @@ struct ZkDecVShift {
 template <bool FULL>   // FULL: Base64Lookup internals (68 slots per char), else the 6 value bits
 struct ZkDecB64 {
   const u32* __restrict__ chars; int half;
-  __device__ ZkDecB64(const ZkSeg& sg, const ZkCtx& cx) : chars(cx.small + sg.src), half(cx.half) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC ZkDecB64(const ZkSeg& sg, const ZkCtx& cx) : chars(cx.small + sg.src), half(cx.half) {}
+  ZK_DEC u32 operator()(u32 r) const {
     constexpr u32 per = FULL ? 68u : 6u;
     const u32 g = r / per, q = r - g * per;
     const int ch = (int)chars[g];
@@ -183,9 +188,9 @@ struct ZkDecB64 {
 struct ZkDecDfa {
   const u32* __restrict__ pos; const u32* __restrict__ cmask; const u32* __restrict__ pmask;
   u32 kind, pb, pc; int half;
-  __device__ ZkDecDfa(const ZkSeg& sg, const ZkCtx& cx)
+  ZK_DEC ZkDecDfa(const ZkSeg& sg, const ZkCtx& cx)
       : pos(cx.small + sg.src), cmask(cx.small + cx.m_dfa_cm), pmask(cx.small + cx.m_dfa_pm), kind(sg.a), pb(sg.b), pc(sg.c), half(cx.half) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC u32 operator()(u32 r) const {
     if (kind == ZDFA_EQ) {
       const int d = (int)pb - (int)(pos[r >> 1] & 255u);          // isz.in = in[1] - in[0] = ch - in[i]
       return (r & 1u) ? zk_inv_code(d, half) : (u32)(d == 0);
@@ -220,8 +225,8 @@ struct ZkDecDfa {
 // (helpers/remove-soft-line-breaks.circom:47-91): "=\r\n" at j  <=>  isSoftBreak[j]
 struct ZkDecRslb {
   const u8* __restrict__ enc; u32 kind, b, c; int half;
-  __device__ ZkDecRslb(const ZkSeg& sg, const ZkCtx& cx) : enc(cx.rec + sg.src), kind(sg.a), b(sg.b), c(sg.c), half(cx.half) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC ZkDecRslb(const ZkSeg& sg, const ZkCtx& cx) : enc(cx.rec + sg.src), kind(sg.a), b(sg.b), c(sg.c), half(cx.half) {}
+  ZK_DEC u32 operator()(u32 r) const {
     if (kind == ZRS_EQ) {
       const int d = (int)c - (int)enc[(r >> 1) + b];   // isz.in = in[1] - in[0]
       return (r & 1u) ? zk_inv_code(d, half) : (u32)(d == 0);
@@ -240,8 +245,8 @@ struct ZkDecRslb {
 // of one (bit 31) from the table; a negative integer -m is the field element r - m
 struct ZkDecNet {
   const u32* __restrict__ p; u32 base; int half;
-  __device__ ZkDecNet(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), base(sg.src), half(cx.half) {}
-  __device__ u32 operator()(u32 r) const {
+  ZK_DEC ZkDecNet(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), base(sg.src), half(cx.half) {}
+  ZK_DEC u32 operator()(u32 r) const {
     const u32 w = p[base + r];
     const int d = (int)(w << 1) >> 1;
     if (w & 0x80000000u) return zk_inv_code(d, half);
@@ -249,30 +254,38 @@ struct ZkDecNet {
   }
 };
 
-// one slot of any segment (the numbered-circuit expansion and the linear-row kernel reach slots one by one)
-__device__ inline u32 zk_decode_any(const ZkSeg& sg, u32 r, const ZkCtx& cx) {
+// every segment type with its decoder: ZK_FOR_SEG_TYPES(X) expands X(type, Decoder) once per type
+#define ZK_FOR_SEG_TYPES(X)                                                                                           \
+  X(ZSEG_SMALL, ZkDecSmall) X(ZSEG_FR, ZkDecFr) X(ZSEG_BITS, ZkDecBits)                                                \
+  X(ZSEG_SHA_SP, ZkDecSha<ZK_SP_SLOTS ZK_COMMA 5>) X(ZSEG_SHA_T1, ZkDecSha<ZK_T1_SLOTS ZK_COMMA 4>)                    \
+  X(ZSEG_SHA_T2, ZkDecSha<ZK_T2_SLOTS ZK_COMMA 5>) X(ZSEG_ISZ, ZkDecIsz) X(ZSEG_SEL, ZkDecSel) X(ZSEG_IN8, ZkDecIn8)   \
+  X(ZSEG_IN8MASK, ZkDecIn8Mask) X(ZSEG_IN8BITS, ZkDecIn8Bits) X(ZSEG_LIMB, ZkDecLimb) X(ZSEG_LTBITS, ZkDecLtBits)      \
+  X(ZSEG_REGSEL, ZkDecRegSel) X(ZSEG_VSHIFT, ZkDecVShift) X(ZSEG_B64BITS, ZkDecB64<false>) X(ZSEG_B64, ZkDecB64<true>) \
+  X(ZSEG_DFA, ZkDecDfa) X(ZSEG_RSLB, ZkDecRslb) X(ZSEG_NET, ZkDecNet)
+#define ZK_COMMA ,
+
+// one slot of any segment (pieces that straddle segments, the numbered-circuit expansion and the linear-row kernels
+// reach slots one by one)
+ZK_DEC inline u32 zk_decode_any(const ZkSeg& sg, u32 r, const ZkCtx& cx) {
   switch (sg.type) {
-    case ZSEG_SMALL: return ZkDecSmall(sg, cx)(r);
-    case ZSEG_FR: return ZkDecFr(sg, cx)(r);
-    case ZSEG_BITS: return ZkDecBits(sg, cx)(r);
-    case ZSEG_SHA_SP: return ZkDecSha<ZK_SP_SLOTS, 5>(sg, cx)(r);
-    case ZSEG_SHA_T1: return ZkDecSha<ZK_T1_SLOTS, 4>(sg, cx)(r);
-    case ZSEG_SHA_T2: return ZkDecSha<ZK_T2_SLOTS, 5>(sg, cx)(r);
-    case ZSEG_ISZ: return ZkDecIsz(sg, cx)(r);
-    case ZSEG_SEL: return ZkDecSel(sg, cx)(r);
-    case ZSEG_IN8: return ZkDecIn8(sg, cx)(r);
-    case ZSEG_IN8MASK: return ZkDecIn8Mask(sg, cx)(r);
-    case ZSEG_IN8BITS: return ZkDecIn8Bits(sg, cx)(r);
-    case ZSEG_LIMB: return ZkDecLimb(sg, cx)(r);
-    case ZSEG_LTBITS: return ZkDecLtBits(sg, cx)(r);
-    case ZSEG_REGSEL: return ZkDecRegSel(sg, cx)(r);
-    case ZSEG_VSHIFT: return ZkDecVShift(sg, cx)(r);
-    case ZSEG_B64BITS: return ZkDecB64<false>(sg, cx)(r);
-    case ZSEG_B64: return ZkDecB64<true>(sg, cx)(r);
-    case ZSEG_DFA: return ZkDecDfa(sg, cx)(r);
-    case ZSEG_RSLB: return ZkDecRslb(sg, cx)(r);
-    case ZSEG_NET: return ZkDecNet(sg, cx)(r);
-    default: return 0u;
+#define ZK_X(T, D) case T: return D(sg, cx)(r);
+    ZK_FOR_SEG_TYPES(ZK_X)
+#undef ZK_X
+    default: return 0u;   // ZSEG_HOLE: nothing produces these slots
+  }
+}
+// K slots r0 + i0, r0 + i0 + 64, ... of ONE segment (slots at or beyond `n` give 0): the type switch is taken once and the
+// K decodes are straight-line code, so their image reads are in flight together
+template <int K>
+__device__ __forceinline__ void zk_decode_k(const ZkSeg& sg, u32 r0, u32 i0, u32 n, const ZkCtx& cx, u32 (&code)[K]) {
+  switch (sg.type) {
+#define ZK_X(T, D) case T: { const D dec(sg, cx); _Pragma("unroll") for (int k = 0; k < K; ++k) { const u32 i = i0 + 64u * (u32)k; code[k] = i < n ? dec(r0 + i) : 0u; } break; }
+    ZK_FOR_SEG_TYPES(ZK_X)
+#undef ZK_X
+    default:
+#pragma unroll
+      for (int k = 0; k < K; ++k) code[k] = 0u;
+      break;
   }
 }
 
@@ -284,18 +297,26 @@ struct ZkRefSrc {
   const u8* __restrict__ rec;
   const u32* __restrict__ small;
 };
-__device__ __forceinline__ uint4 zk_ref_half(u32 code, u32 hf, const ZkRefSrc& R) {
+ZK_DEC __forceinline__ uint4 zk_ref_half(u32 code, u32 hf, const ZkRefSrc& R) {
   const u32 p = ZK_REF_PAYLOAD(code);
   switch (ZK_REF_TYPE(code)) {
     case 0: return R.frv[2u * p + hf];
     case 1: return R.invtab[2u * p + hf];
     case 2: return hf ? zk_zero4() : *(const uint4*)(R.rec + p);
     case 3: return hf ? zk_zero4() : zk_small(R.small[p]);
-    default: {
+    case 4: {
       const u32 w = R.small[p];
       const u32 m = (u32)(-((int)(w << 1) >> 1));
       return hf ? make_uint4(0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u)
                 : make_uint4(0xf0000001u - m, 0x43e1f593u, 0x79b97091u, 0x2833e848u);
+    }
+    default: {
+      const long long v = (long long)((u64)R.small[p] | ((u64)R.small[p + 1] << 32));
+      if (v >= 0) return hf ? zk_zero4() : make_uint4((u32)v, (u32)((u64)v >> 32), 0u, 0u);
+      // r - m, m = -v < 2^63: a borrow out of the low limb stops in the next one (r's second limb is not 0)
+      const u64 m = (u64)(-v), l0 = 0x43e1f593f0000001ull - m, l1 = 0x2833e84879b97091ull - (m > 0x43e1f593f0000001ull ? 1ull : 0ull);
+      return hf ? make_uint4(0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u)
+                : make_uint4((u32)l0, (u32)(l0 >> 32), (u32)l1, (u32)(l1 >> 32));
     }
   }
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "zkwg_sched.h"
+#include "zkwg_o0.h"
 
 __global__ void zk_sha_chain(ZkSched s, ZkBufs B);   // zkwg_kernels_sha.hip
 __global__ void zk_sha_trace(ZkSched s, ZkBufs B);   // zkwg_kernels_sha.hip
@@ -10,12 +11,12 @@ __global__ void zk_expand_512(ZkSched s, ZkBufs B);
 __global__ void zk_expand_1024(ZkSched s, ZkBufs B);
 __global__ void zk_expand_wave(ZkSched s, ZkBufs B);
 __global__ void zk_expand_mont_256(ZkSched s, ZkBufs B);  // fused standard -> Montgomery output
-__global__ void zk_expand2(ZkSched s, ZkBufs B);       // zkwg_kernels_expand2.hip (LDS-staged; the default)
+__global__ void zk_expand2(ZkSched s, ZkBufs B);       // zkwg_kernels_expand2.hip (LDS-staged, 64 KiB portions)
 __global__ void zk_expand2_mont(ZkSched s, ZkBufs B);
-__global__ void zk_image_to_mont(ZkSched s, ZkBufs B);
 __global__ void zk_rsa(ZkSched s, ZkBufs B);         // zkwg_kernels_rsa.hip
 __global__ void zk_poseidon9(ZkSched s, ZkBufs B);   // zkwg_kernels_rsa.hip
 __global__ void zk_poseidon9_wave(ZkSched s, ZkBufs B);
+__global__ void zk_poseidon9_g16(ZkSched s, ZkBufs B);
 __global__ void zk_misc_ev(ZkSched s, ZkBufs B);     // zkwg_kernels_misc.hip
 __global__ void zk_net_eval(ZkSched s, ZkBufs B);    // zkwg_kernels_net.hip
 __global__ void zk_rslb_chunks(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip
@@ -24,10 +25,15 @@ __global__ void zk_r1cs_check(const u64* row_ptr, const u32* wire, const Fr* coe
                               const u8* wit, u64 stride, unsigned long long* first_bad);  // zkwg_kernels_r1cs.hip
 __global__ void zk_r1cs_eval(const u64* row_ptr, const u32* wire, const Fr* coef, const u8* kind, u32 m, const u8* wit, u64 stride,
                              u8* out, u64 out_stride, int mont);  // zkwg_kernels_r1cs.hip
-__global__ void zk_o0_gather(const u32* desc, u64 n_wires, const u8* kept, u64 kept_stride, u8* out, u64 out_stride);  // zkwg_kernels_r1cs.hip
-__global__ void zk_o0_rows_4(const u32* rows, u32 n_rows, const u64* row_ptr, const u32* dst, const u32* src, const Fr* coef, const u8* kind,
-                             const u8* kept, u64 kept_stride, u8* out, u64 out_stride);
-__global__ void zk_o0_rows_16(const u32* rows, u32 n_rows, const u64* row_ptr, const u32* dst, const u32* src, const Fr* coef, const u8* kind,
-                              const u8* kept, u64 kept_stride, u8* out, u64 out_stride);
+// zkwg_kernels_expand3.hip: one piece of 256 K slots per workgroup (K = 1, 2, 4), standard / Montgomery form, kept-v1 / numbered circuits
+#define ZK_X3_DECL(K) \
+  __global__ void zk_expand3_k##K(ZkX3 A); __global__ void zk_expand3_mont_k##K(ZkX3 A); \
+  __global__ void zk_expand3_o0_k##K(ZkX3 A, ZkO0Dev O); __global__ void zk_expand3_o0_mont_k##K(ZkX3 A, ZkO0Dev O);
+ZK_X3_DECL(1) ZK_X3_DECL(2) ZK_X3_DECL(4)
+__global__ void zk_expand3_k8(ZkX3 A); __global__ void zk_expand3_mont_k8(ZkX3 A);
+__global__ void zk_image_to_mont(ZkX3 A);
+__global__ void zk_o0_rows_small(ZkX3 A, ZkO0Dev O);
+__global__ void zk_o0_chains_small(ZkX3 A, ZkO0Dev O);
+__global__ void zk_o0_rows_fr(ZkX3 A, ZkO0Dev O);
 __global__ void zk_mont_convert(Fr* v, u64 n, int to_mont);  // zkwg_kernels_handoff.hip
 __global__ void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8* recs, int* gen_status, u32 n);  // zkwg_kernels_inputs.hip

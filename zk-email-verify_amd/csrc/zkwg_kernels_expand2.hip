@@ -34,26 +34,9 @@ __device__ __forceinline__ void zk_fill_codes(u32* __restrict__ code, const ZkSe
 
 __device__ __forceinline__ void zk_decode_segment(u32* __restrict__ code, const ZkSeg& sg, const ZkCtx& cx, u32 r0, u32 n, u32 tid) {
   switch (sg.type) {
-    case ZSEG_SMALL: zk_fill_codes<ZkDecSmall>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_FR: zk_fill_codes<ZkDecFr>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_BITS: zk_fill_codes<ZkDecBits>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_SHA_SP: zk_fill_codes<ZkDecSha<ZK_SP_SLOTS, 5>>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_SHA_T1: zk_fill_codes<ZkDecSha<ZK_T1_SLOTS, 4>>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_SHA_T2: zk_fill_codes<ZkDecSha<ZK_T2_SLOTS, 5>>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_ISZ: zk_fill_codes<ZkDecIsz>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_SEL: zk_fill_codes<ZkDecSel>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_IN8: zk_fill_codes<ZkDecIn8>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_IN8MASK: zk_fill_codes<ZkDecIn8Mask>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_IN8BITS: zk_fill_codes<ZkDecIn8Bits>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_LIMB: zk_fill_codes<ZkDecLimb>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_LTBITS: zk_fill_codes<ZkDecLtBits>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_REGSEL: zk_fill_codes<ZkDecRegSel>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_VSHIFT: zk_fill_codes<ZkDecVShift>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_B64BITS: zk_fill_codes<ZkDecB64<false>>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_B64: zk_fill_codes<ZkDecB64<true>>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_DFA: zk_fill_codes<ZkDecDfa>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_RSLB: zk_fill_codes<ZkDecRslb>(code, sg, cx, r0, n, tid); break;
-    case ZSEG_NET: zk_fill_codes<ZkDecNet>(code, sg, cx, r0, n, tid); break;
+#define ZK_X(T, D) case T: zk_fill_codes<D>(code, sg, cx, r0, n, tid); break;
+    ZK_FOR_SEG_TYPES(ZK_X)
+#undef ZK_X
     default:   // ZSEG_HOLE: nothing produces these slots
       for (u32 i = tid; i < n; i += ZK_X2_THREADS) code[i] = 0u;
       break;
@@ -169,20 +152,58 @@ __device__ __forceinline__ void zk_store_mont(uint4* __restrict__ dst, const u32
   }
 }
 
-// ---------------------------------------------------------------- the kernel
+// store phase of one portion of one email (the codes of its slots are in LDS)
 template <bool MONT>
-__device__ __forceinline__ void zk_expand2_body(const ZkSched& s, const ZkBufs& B, u32* __restrict__ code) {
-  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  Give every XCD a contiguous run of units:
-  // xcd_remap = 1: one run per XCD over the whole launch; K > 1: runs of K workgroups inside groups of 8 K.
+__device__ __forceinline__ void zk_store_phase(const ZkSched& s, const ZkBufs& B, const ZkCtx& cx, u32 e, uint4* __restrict__ dst,
+                                               const u32* __restrict__ code, u32 nch, u32 tid, bool pure) {
+  if constexpr (MONT) {
+    ZkMontSrc M;
+    M.R.frv = (const uint4*)(B.frm + (u64)e * (s.img_fr + ZK_MONT_LIMBS));
+    M.R.invtab = (const uint4*)B.invtab_m;
+    M.R.rec = cx.rec; M.R.small = cx.small;
+    M.rtab = (const uint4*)B.rtab;
+    M.limb_base = s.img_fr; M.limb_off = s.in_off[3];   // ZKWG_IN_PUBKEY: pubkey, signature, message limbs are contiguous
+    zk_store_mont(dst, code, nch, tid, M, pure);
+  } else if (pure) {
+    zk_store_pure(dst, code, nch, tid);
+  } else {
+    ZkRefSrc R;
+    R.frv = (const uint4*)(B.frv + (u64)e * s.img_fr);
+    R.invtab = (const uint4*)B.invtab;
+    R.rec = cx.rec; R.small = cx.small;
+    zk_store_general(dst, code, nch, tid, R, (const uint4*)(B.invtab + s.inv_half));   // (d = 0)^-1 := 0: 32 zero bytes
+  }
+}
+
+// XCD-aware workgroup -> unit mapping.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give every
+// XCD a contiguous run of units: xcd_remap = 1: one run per XCD over the whole launch; K > 1: runs of K workgroups
+// inside groups of 8 K.
+__device__ __forceinline__ u32 zk_xcd_unit(u32 xcd_remap) {
   u32 blk = blockIdx.x;
-  if (B.xcd_remap == 1u) {
+  if (xcd_remap == 1u) {
     const u32 per = gridDim.x >> 3;
     if (blk < per * 8u) blk = (blk & 7u) * per + (blk >> 3);
-  } else if (B.xcd_remap > 1u) {
-    const u32 K = B.xcd_remap, G = 8u * K;
+  } else if (xcd_remap > 1u) {
+    const u32 K = xcd_remap, G = 8u * K;
     const u32 g = blk / G, r = blk - g * G;
     if ((g + 1u) * G <= gridDim.x) blk = g * G + (r & 7u) * K + (r >> 3);
   }
+  return blk;
+}
+__device__ __forceinline__ ZkCtx zk_email_ctx(const ZkSched& s, const ZkBufs& B, u32 e) {
+  ZkCtx cx;
+  cx.rec = B.in + (u64)e * s.in_stride;
+  cx.bits = B.bits + (u64)e * s.img_bits;
+  cx.small = B.small + (u64)e * s.img_small;
+  cx.half = (int)s.inv_half;
+  cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm;
+  return cx;
+}
+
+// ---------------------------------------------------------------- the kernel
+template <bool MONT>
+__device__ __forceinline__ void zk_expand2_body(const ZkSched& s, const ZkBufs& B, u32* __restrict__ code) {
+  const u32 blk = zk_xcd_unit(B.xcd_remap);
   // workgroup (p, g): portion p of the emails [g*E, g*E+E) of this launch
   const u32 p = blk % s.nportions;
   const u32 g = blk / s.nportions;
@@ -196,15 +217,9 @@ __device__ __forceinline__ void zk_expand2_body(const ZkSched& s, const ZkBufs& 
   const u32 tid = threadIdx.x;
   const u32 si0 = B.first_seg[p];
   const bool pure = (B.pflags[p] & 1u) != 0u;
-  const uint4* __restrict__ zero16 = (const uint4*)(B.invtab + s.inv_half);   // (d = 0)^-1 := 0: 32 zero bytes
   for (u32 el = el0; el < el1; ++el) {
     const u32 e = el + B.e_first;                // email index inside the prepared batch
-    ZkCtx cx;
-    cx.rec = B.in + (u64)e * s.in_stride;
-    cx.bits = B.bits + (u64)e * s.img_bits;
-    cx.small = B.small + (u64)e * s.img_small;
-    cx.half = (int)s.inv_half;
-    cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm;
+    const ZkCtx cx = zk_email_ctx(s, B, e);
     for (u32 si = si0; si < s.nsegs; ++si) {
       const ZkSeg sg = B.segs[si];
       if (sg.slot >= slot1) break;
@@ -213,24 +228,7 @@ __device__ __forceinline__ void zk_expand2_body(const ZkSched& s, const ZkBufs& 
       zk_decode_segment(code + (u32)(lo - slot0), sg, cx, (u32)(lo - sg.slot) + sg.r0, (u32)(hi - lo), tid);
     }
     __syncthreads();
-    uint4* __restrict__ dst = B.wit + (u64)el * B.wit_stride16 + slot0 * 2;
-    if constexpr (MONT) {
-      ZkMontSrc M;
-      M.R.frv = (const uint4*)(B.frm + (u64)e * (s.img_fr + ZK_MONT_LIMBS));
-      M.R.invtab = (const uint4*)B.invtab_m;
-      M.R.rec = cx.rec; M.R.small = cx.small;
-      M.rtab = (const uint4*)B.rtab;
-      M.limb_base = s.img_fr; M.limb_off = s.in_off[3];   // ZKWG_IN_PUBKEY: pubkey, signature, message limbs are contiguous
-      zk_store_mont(dst, code, nch, tid, M, pure);
-    } else if (pure) {
-      zk_store_pure(dst, code, nch, tid);
-    } else {
-      ZkRefSrc R;
-      R.frv = (const uint4*)(B.frv + (u64)e * s.img_fr);
-      R.invtab = (const uint4*)B.invtab;
-      R.rec = cx.rec; R.small = cx.small;
-      zk_store_general(dst, code, nch, tid, R, zero16);
-    }
+    zk_store_phase<MONT>(s, B, cx, e, B.wit + (u64)el * B.wit_stride16 + slot0 * 2, code, nch, tid, pure);
     if (el + 1 < el1) __syncthreads();
   }
 }
@@ -244,19 +242,3 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
   zk_expand2_body<true>(s, B, zk_x2_code);
 }
 
-// Montgomery-form copies of what the references of one email name: its img_fr field elements, then the
-// ZK_MONT_LIMBS 128-bit limbs of the record (pubkey, signature, message) -- one product each, once per batch.
-__global__ __launch_bounds__(256) void zk_image_to_mont(ZkSched s, ZkBufs B) {
-  const u32 per = s.img_fr + ZK_MONT_LIMBS;
-  const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
-  const u64 total = (u64)(B.n_emails - B.e_first) * per;
-  if (i >= total) return;
-  const u32 e = B.e_first + (u32)(i / per), j = (u32)(i % per);
-  Fr x;
-  if (j < s.img_fr) x = B.frv[(u64)e * s.img_fr + j];
-  else {
-    const u64* l = (const u64*)(B.in + (u64)e * s.in_stride + s.in_off[3] + 16u * (j - s.img_fr));
-    x = Fr{{l[0], l[1], 0, 0}};
-  }
-  B.frm[(u64)e * per + j] = fr_to_mont(x);
-}

@@ -1,0 +1,350 @@
+// zk_expand (one-shot) -- the streaming expansion kernel, the HBM-write-bound kernel of the path.
+//
+// Every witness element is a 32-byte little-endian field element, but > 95 % of the EmailVerifier witness is single
+// bits and nearly all the rest fits 31 bits.  The prepare kernels leave a compact per-email IMAGE; this kernel
+// expands image + input record into the `.wtns` data section (the witness vector of
+// `circuit.calculateWitness(input)`, packages/circuits/tests/email-verifier.test.ts:43).
+//
+// Shape (measured, tools/storebench2.hip / DESIGN.md section 5): HBM takes plain 16-byte stores fastest when every
+// workgroup writes ONE small contiguous piece and exits -- 8 KiB per 256-thread workgroup reaches 6.8-6.9 TB/s even
+// with two dependent loads in front of the stores, 64 KiB per workgroup 5.8-6.1 -- because the chip then writes one
+// dense window that sweeps the buffer in address (= dispatch) order.  So:
+//   * one workgroup = 256 K consecutive slots (8 K KiB, K = 1, 2 or 4) of one witness, K slots per thread whose image
+//     reads are all in flight together, no loop, no LDS, no barrier;
+//   * the workgroup's prologue is one 32-byte table entry (ZkPortionEntry, built on the host): for the > 90 % of
+//     pieces that lie inside a single segment it carries the segment's parameters and the piece's offset, so the
+//     dependent chain in front of the stores is entry -> image word -> store; pieces that straddle segments walk the
+//     segment table (a handful of entries);
+//   * a lane decodes its slot into a 32-bit code (zkwg_expand_dec.h: the value, or a reference to 32 bytes held
+//     elsewhere); the two lanes that store the slot's halves fetch the code with a wavefront shuffle, so each
+//     wavefront store instruction covers 1 KiB of contiguous HBM and every witness byte is written exactly once;
+//   * each XCD streams through its own contiguous share of the launch (blockIdx remap).
+//
+// MONT (prover hand-off): values leave as x * 2^256 mod r: 0 -> 0, 1 -> R, v < 2^16 -> table; references
+// resolve to Montgomery-form copies (zk_image_to_mont, the Montgomery inverse table): no field product in this kernel.
+// O0 (`circom --O0` / `--O1` builds, zkwg_o0.h): the code of a wire comes from its 8-byte descriptor instead of the
+// segment arithmetic -- same store side.
+#include "zkwg_expand_dec.h"
+#include "zkwg_kernels.h"
+#include "zkwg_o0.h"
+
+__device__ __forceinline__ uint4 zk_fr_half4(const Fr& m, u32 hf) {
+  const u64 x = m.l[2 * hf], y = m.l[2 * hf + 1];
+  return make_uint4((u32)x, (u32)(x >> 32), (u32)y, (u32)(y >> 32));
+}
+// Montgomery form of the rare values no table holds
+__device__ __noinline__ uint4 zk_mont_slow(u32 code, u32 hf, const ZkX3& A, const ZkRefSrc& R) {
+  if (!(code >> 31)) return zk_fr_half4(fr_to_mont(Fr{{(u64)code, 0, 0, 0}}), hf);   // an immediate >= 2^16
+  // RAW / NEG / I64: standard-form value first (zk_ref_half), then one product
+  const uint4 a = zk_ref_half(code, 0u, R), b = zk_ref_half(code, 1u, R);
+  const Fr x{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
+  return zk_fr_half4(fr_to_mont(x), hf);
+}
+// the 16-byte half `hf` of the slot whose code is `code`
+template <bool MONT>
+__device__ __forceinline__ uint4 zk_slot_half(u32 code, u32 hf, const ZkX3& A, const ZkRefSrc& R) {
+  if constexpr (!MONT) {
+    return (code >> 31) ? zk_ref_half(code, hf, R) : zk_small(hf ? 0u : code);
+  } else {
+    if (!(code >> 31)) {
+      if (code <= 1u) return code ? zk_fr_half4(fr_R(), hf) : zk_zero4();   // R = 2^256 mod r
+      if (code < 65536u) return ((const uint4*)A.rtab)[2u * code + hf];
+      return zk_mont_slow(code, hf, A, R);
+    }
+    const u32 t = ZK_REF_TYPE(code), p = ZK_REF_PAYLOAD(code);
+    if (t == 0u) return R.frv[2u * p + hf];                                       // Montgomery copy of the image's fr
+    if (t == 1u) return R.invtab[2u * p + hf];                                    // Montgomery inverse table
+    if (t == 2u) return R.frv[2u * (A.img_fr + ((p - A.limb_off) >> 4)) + hf];    // converted limb
+    return zk_mont_slow(code, hf, A, R);
+  }
+}
+
+__device__ __forceinline__ u32 zk_x3_unit(u32 xcd_remap) {
+  u32 blk = blockIdx.x;
+  if (xcd_remap) {
+    const u32 per = gridDim.x >> 3;
+    if (blk < per * 8u) blk = (blk & 7u) * per + (blk >> 3);
+  }
+  return blk;
+}
+__device__ __forceinline__ ZkCtx zk_x3_ctx(const ZkX3& A, u32 e) {
+  ZkCtx cx;
+  cx.rec = A.in + (u64)e * A.in_stride;
+  cx.bits = A.bits + (u64)e * A.img_bits;
+  cx.small = A.small + (u64)e * A.img_small;
+  cx.half = (int)A.inv_half;
+  cx.m_dfa_cm = A.m_dfa_cm; cx.m_dfa_pm = A.m_dfa_pm;
+  return cx;
+}
+// store side: wavefront w owns the 64 K consecutive slots [64 K w, 64 K (w + 1)) of the piece (K = slots per lane);
+// lane l holds the codes of slots 64 k + l (k < K).  Chunk 64 j + l (j < 2 K) of the wavefront's 2 K KiB belongs to
+// slot 32 j + (l >> 1): register j / 2, fetched from lane 32 (j & 1) + (l >> 1) with one wavefront shuffle.
+template <bool MONT, int K>
+__device__ __forceinline__ void zk_x3_store(const ZkX3& A, const ZkCtx& cx, u32 e, u32 el, u64 slot0, u32 nsl, const u32 (&code)[K]) {
+  const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, hf = lane & 1u;
+  ZkRefSrc R;
+  R.frv = MONT ? (const uint4*)(A.frm + (u64)e * (A.img_fr + ZK_MONT_LIMBS)) : (const uint4*)(A.frv + (u64)e * A.img_fr);
+  R.invtab = (const uint4*)(MONT ? A.invtab_m : A.invtab);
+  R.rec = cx.rec; R.small = cx.small;
+  const u32 w0 = 64u * K * wv;                                        // first slot of this wavefront inside the piece
+  uint4* __restrict__ dst = A.wit + (u64)el * A.wit_stride16 + (slot0 + w0) * 2u;
+  const u32 left = nsl > w0 ? (nsl - w0) * 2u : 0u;                   // chunks of this wavefront inside the witness
+  uint4 v[2 * K];
+#pragma unroll
+  for (int j = 0; j < 2 * K; ++j) {
+    const u32 c = __shfl(code[j >> 1], 32u * (j & 1) + (lane >> 1));
+    v[j] = zk_slot_half<MONT>(c, hf, A, R);
+  }
+#pragma unroll
+  for (int j = 0; j < 2 * K; ++j)
+    if (64u * j + lane < left) dst[64u * j + lane] = v[j];
+}
+
+template <bool MONT, int K>
+__device__ __forceinline__ void zk_expand3_body(const ZkX3& A) {
+  constexpr u32 SLOTS = 256u * K;
+  const u32 unit = zk_x3_unit(A.xcd_remap);
+  const u32 p = unit % A.nportions, el = unit / A.nportions;   // piece p of email el (launch-local)
+  const u32 e = el + A.e_first;
+  const u64 slot0 = (u64)p * SLOTS;
+  const u32 nsl = (u32)min((u64)SLOTS, A.W - slot0);
+  const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const ZkCtx cx = zk_x3_ctx(A, e);
+  const ZkPortionEntry en = A.ent[p];
+  u32 code[K];
+  if (en.type < ZSEG_NTYPES) {
+    // the whole piece lies inside one segment: its parameters came with the entry
+    ZkSeg sg;
+    sg.slot = 0; sg.nslots = 0; sg.type = en.type; sg.src = en.src; sg.a = en.a; sg.b = en.b; sg.c = en.c; sg.r0 = 0; sg.pad = en.magic;
+    zk_decode_k<K>(sg, en.r_start, 64u * K * wv + lane, nsl, cx, code);
+  } else {
+    // the piece straddles segments: find each slot's
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const u32 i = 64u * K * wv + 64u * k + lane;
+      code[k] = 0u;
+      if (i < nsl) {
+        const u64 slot = slot0 + i;
+        for (u32 si = en.first_seg; si < A.nsegs; ++si) {
+          const ZkSeg sg = A.segs[si];
+          if (sg.slot > slot) break;
+          if (slot < sg.slot + sg.nslots) { code[k] = zk_decode_any(sg, (u32)(slot - sg.slot) + sg.r0, cx); break; }
+        }
+      }
+    }
+  }
+  zk_x3_store<MONT, K>(A, cx, e, el, slot0, nsl, code);
+}
+#define ZK_X3_KERNELS(K)                                                                                                                  \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_k##K(ZkX3 A) { zk_expand3_body<false, K>(A); }    \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_mont_k##K(ZkX3 A) { zk_expand3_body<true, K>(A); }
+ZK_X3_KERNELS(1)
+ZK_X3_KERNELS(2)
+ZK_X3_KERNELS(4)
+ZK_X3_KERNELS(8)
+
+// Montgomery-form copies of what the references of one email name: its img_fr field elements, then the
+// ZK_MONT_LIMBS 128-bit limbs of the record (pubkey, signature, message) -- one product each, once per expansion.
+__global__ __launch_bounds__(256) void zk_image_to_mont(ZkX3 A) {
+  const u32 per = A.img_fr + ZK_MONT_LIMBS;
+  const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+  if (i >= (u64)A.n_count * per) return;
+  const u32 e = A.e_first + (u32)(i / per), j = (u32)(i % per);
+  Fr x;
+  if (j < A.img_fr) x = A.frv[(u64)e * A.img_fr + j];
+  else {
+    const u64* l = (const u64*)(A.in + (u64)e * A.in_stride + A.limb_off + 16u * (j - A.img_fr));
+    x = Fr{{l[0], l[1], 0, 0}};
+  }
+  A.frm_w[(u64)e * per + j] = fr_to_mont(x);
+}
+
+// ---------------------------------------------------------------- numbered circuits (`--O0` / `--O1`), one pass
+__device__ __noinline__ u32 zk_decode_generic(const ZkSeg* __restrict__ sg, u32 r, const ZkCtx& cx) { return zk_decode_any(*sg, r, cx); }
+// the code of one wire from its descriptor (zkwg_o0.h)
+__device__ __forceinline__ u32 zk_desc_decode(u32 a, u32 b, const ZkCtx& cx, const ZkSeg* __restrict__ segs) {
+  switch (a >> 28) {
+    case ZK_D_IMM: return b;
+    case ZK_D_BIT64: return (u32)(cx.bits[b] >> (a & 63u)) & 1u;
+    case ZK_D_BIT8: return (u32)(cx.rec[b] >> (a & 7u)) & 1u;
+    case ZK_D_BYTE: return cx.rec[b];
+    case ZK_D_SMALLRAW: return zk_raw_code(cx.small[b], b);
+    case ZK_D_SMALLS: { const u32 lo = cx.small[b], hi = cx.small[b + 1]; return (hi == 0u && !(lo >> 31)) ? lo : (ZK_REF_I64 | b); }
+    default: return zk_decode_generic(segs + (a & 0xffffffu), b, cx);
+  }
+}
+// descriptors of kind GENERIC (the comparator / selector / regex regions: ~10 % of the wires of EmailVerifier, in
+// contiguous stretches): decoded by their segment's own arithmetic.  Lanes are binned by segment: the wavefront takes
+// the segment of its first pending lane, loads it once (uniform) and every lane of that segment decodes with the type
+// switch taken uniformly -- instead of one out-of-line call per lane with a per-lane segment fetch.
+__device__ __forceinline__ u32 zk_generic_binned(uint2 d, u32 code, const ZkCtx& cx, const ZkSeg* __restrict__ segs) {
+  const bool gen = (d.x >> 28) == ZK_D_GENERIC;
+  u64 pending = __builtin_amdgcn_ballot_w64(gen);
+  while (pending) {
+    const int leader = __builtin_ctzll(pending);
+    const u32 si = (u32)__builtin_amdgcn_readlane((int)(d.x & 0xffffffu), leader);
+    const ZkSeg sg = segs[si];
+    const bool mine = gen && (d.x & 0xffffffu) == si;
+    if (mine) code = zk_decode_any(sg, d.y, cx);
+    pending &= ~__builtin_amdgcn_ballot_w64(mine);
+  }
+  return code;
+}
+template <bool MONT, int K>
+__device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev& O) {
+  constexpr u32 SLOTS = 256u * K;
+  const u32 unit = zk_x3_unit(A.xcd_remap);
+  const u32 p = unit % O.nportions, g = unit / O.nportions;     // piece p of the emails [g E, g E + E) of this launch
+  const u64 slot0 = (u64)p * SLOTS;
+  const u32 nsl = (u32)min((u64)SLOTS, O.W - slot0);
+  const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  // the descriptors of this thread's K wires: loaded once, reused for every email of the group (8 bytes per wire
+  // against 32 bytes written per wire and email)
+  uint2 d[K];
+  bool any_generic = false;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const u32 i = 64u * K * wv + 64u * k + lane;
+    d[k] = i < nsl ? O.desc[slot0 + i] : make_uint2(0u, 0u);
+    any_generic = any_generic || (d[k].x >> 28) == ZK_D_GENERIC;
+  }
+  const bool wave_generic = __builtin_amdgcn_ballot_w64(any_generic) != 0ull;
+  const u32 el1 = min((g + 1u) * O.emails_per_wg, A.n_count);
+  for (u32 el = g * O.emails_per_wg; el < el1; ++el) {
+    const u32 e = el + A.e_first;
+    const ZkCtx cx = zk_x3_ctx(A, e);
+    u32 code[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) code[k] = (d[k].x >> 28) == ZK_D_GENERIC ? 0u : zk_desc_decode(d[k].x, d[k].y, cx, A.segs);
+    if (wave_generic) {
+      // one copy of the binned decode: the K (descriptor, code) pairs rotate through position 0
+#pragma unroll 1
+      for (int it = 0; it < K; ++it) {
+        code[0] = zk_generic_binned(d[0], code[0], cx, A.segs);
+        const uint2 d0 = d[0]; const u32 c0 = code[0];
+#pragma unroll
+        for (int k = 0; k + 1 < K; ++k) { d[k] = d[k + 1]; code[k] = code[k + 1]; }
+        d[K - 1] = d0; code[K - 1] = c0;
+      }
+    }
+    zk_x3_store<MONT, K>(A, cx, e, el, slot0, nsl, code);
+  }
+}
+#define ZK_X3_O0_KERNELS(K)                                                                                                                                     \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, K>(A, O); }      \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_mont_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, K>(A, O); }
+ZK_X3_O0_KERNELS(1)
+ZK_X3_O0_KERNELS(2)
+ZK_X3_O0_KERNELS(4)
+
+// the value of a code as a signed integer (small rows: every source is small-ranged by construction)
+__device__ __forceinline__ long long zk_code_int(u32 code, const ZkCtx& cx) {
+  if (!(code >> 31)) return (long long)code;
+  const u32 p = ZK_REF_PAYLOAD(code), w = cx.small[p];
+  switch (ZK_REF_TYPE(code)) {
+    case 3: return (long long)w;                                                   // RAW
+    case 4: return (long long)((int)(w << 1) >> 1);                                // NEG
+    default: return (long long)((u64)w | ((u64)cx.small[p + 1] << 32));            // I64 (no other reference is small-ranged)
+  }
+}
+// rows whose sources, coefficients and result are small integers: 64-bit integer arithmetic
+__device__ __forceinline__ long long zk_small_row_terms(const ZkO0Dev& O, u32 j, const ZkCtx& cx, const ZkSeg* __restrict__ segs) {
+  long long acc = 0;
+  for (u64 t = O.s_ptr[j]; t < O.s_ptr[j + 1]; ++t) {
+    const uint2 d = O.s_term[t];
+    acc += (long long)O.s_coef[t] * zk_code_int(zk_desc_decode(d.x, d.y, cx, segs), cx);
+  }
+  return acc;
+}
+// one thread per row that is a group of its own
+__global__ __launch_bounds__(256) void zk_o0_rows_small(ZkX3 A, ZkO0Dev O) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= O.n_small_single) return;
+  const u32 j = O.s_single[i];
+  const u32 e = A.e_first + blockIdx.y;
+  const ZkCtx cx = zk_x3_ctx(A, e);
+  const long long acc = zk_small_row_terms(O, j, cx, A.segs);
+  u32* out = A.small_w + (u64)e * A.img_small + O.small_base;
+  out[2u * j] = (u32)(u64)acc;
+  out[2u * j + 1u] = (u32)((u64)acc >> 32);
+}
+// one wavefront per chain (zkwg_o0.h: every row continues the sum of the row before it -- the running sums of
+// MultiOR / CalculateTotal / popcount chains): lane = row, each lane sums the terms its row adds, an inclusive prefix
+// sum over the wavefront (shuffles) turns them into the rows' values, 64 rows per round
+__global__ __launch_bounds__(64) void zk_o0_chains_small(ZkX3 A, ZkO0Dev O) {
+  const uint2 ch = O.s_chains[blockIdx.x];
+  const u32 e = A.e_first + blockIdx.y, lane = threadIdx.x;
+  const ZkCtx cx = zk_x3_ctx(A, e);
+  u32* out = A.small_w + (u64)e * A.img_small + O.small_base;
+  long long carry = 0;
+  for (u32 base = 0; base < ch.y; base += 64u) {
+    const bool live = base + lane < ch.y;
+    const u32 j = ch.x + base + lane;
+    long long v = live ? zk_small_row_terms(O, j, cx, A.segs) : 0;
+#pragma unroll
+    for (u32 d = 1; d < 64u; d <<= 1) {
+      const u32 lo = __shfl_up((u32)(u64)v, d), hi = __shfl_up((u32)((u64)v >> 32), d);
+      if (lane >= d) v += (long long)((u64)lo | ((u64)hi << 32));
+    }
+    v += carry;
+    if (live) { out[2u * j] = (u32)(u64)v; out[2u * j + 1u] = (u32)((u64)v >> 32); }
+    carry = (long long)((u64)(u32)__shfl((u32)(u64)v, 63) | ((u64)(u32)__shfl((u32)((u64)v >> 32), 63) << 32));
+  }
+}
+// the other rows: arithmetic mod r (zk_linear_row's), sources decoded from the image
+__device__ __forceinline__ Fr zk_code_value(u32 code, const ZkRefSrc& R) {
+  if (!(code >> 31)) return Fr{{(u64)code, 0, 0, 0}};
+  const uint4 a = zk_ref_half(code, 0u, R), b = zk_ref_half(code, 1u, R);
+  return Fr{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
+}
+// 8 lanes per group: the lanes split each row's terms, the partial sums are folded with shuffles, lane 0 carries a
+// chain's running value from row to row
+#define ZK_FR_LANES 8u
+__global__ __launch_bounds__(256) void zk_o0_rows_fr(ZkX3 A, ZkO0Dev O) {
+  const u32 g = blockIdx.x * (256u / ZK_FR_LANES) + threadIdx.x / ZK_FR_LANES, l = threadIdx.x % ZK_FR_LANES;
+  const bool live = g < O.n_fr_groups;
+  const u32 e = A.e_first + blockIdx.y;
+  const ZkCtx cx = zk_x3_ctx(A, e);
+  ZkRefSrc R;
+  R.frv = (const uint4*)(A.frv + (u64)e * A.img_fr);
+  R.invtab = (const uint4*)A.invtab;
+  R.rec = cx.rec; R.small = cx.small;
+  const u32 j0 = live ? O.f_group[g] : 0u, j1 = live ? O.f_group[g + 1] : 0u;
+  // every lane of the wavefront runs the same number of rounds (shuffles inside): the longest group of the wavefront
+  u32 rows = j1 - j0;
+#pragma unroll
+  for (u32 d = 32; d >= ZK_FR_LANES; d >>= 1) rows = max(rows, (u32)__shfl_xor((int)rows, (int)d));
+  Fr run = fr_zero();
+  for (u32 q = 0; q < rows; ++q) {
+    const u32 j = j0 + q;
+    const bool on = j < j1;
+    Fr acc = fr_zero();
+    if (on)
+      for (u64 t = O.f_ptr[j] + l; t < O.f_ptr[j + 1]; t += ZK_FR_LANES) {
+        const uint2 d = O.f_term[t];
+        const Fr x = zk_code_value(zk_desc_decode(d.x, d.y, cx, A.segs), R);
+        const u8 k = O.f_kind[t];
+        if (k == ZK_COEF_ONE) acc = fr_add(acc, x);
+        else if (k == ZK_COEF_MINUS_ONE) acc = fr_sub(acc, x);
+        else if (!fr_is_zero(x)) {
+          // generic coefficient (powers of two of Bits2Num ...): the operand is almost always a bit
+          const bool one = x.l[0] == 1 && (x.l[1] | x.l[2] | x.l[3]) == 0;
+          acc = fr_add(acc, one ? O.f_coef[t] : fr_mont_mul(fr_to_mont(x), O.f_coef[t]));
+        }
+      }
+#pragma unroll
+    for (u32 off = ZK_FR_LANES / 2; off >= 1; off >>= 1) {
+      Fr o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32 lo = __shfl_down((u32)acc.l[i], off, ZK_FR_LANES), hi = __shfl_down((u32)(acc.l[i] >> 32), off, ZK_FR_LANES);
+        o.l[i] = (u64)lo | ((u64)hi << 32);
+      }
+      acc = fr_add(acc, o);
+    }
+    if (on && l == 0) {
+      run = O.f_chain[j] ? fr_add(run, acc) : acc;
+      A.frv_w[(u64)e * A.img_fr + O.fr_base + j] = run;
+    }
+  }
+}

@@ -1,0 +1,211 @@
+// One-pass witnesses of a fully numbered circuit (`circom --O0` / `--O1`, the build the reference documents:
+// docs/zk-email-docs/UsageGuide/README.md:56-64).
+//
+// Such a build numbers every alias, constant and linear combination (9.26 M wires for EmailVerifier(1024,1536)
+// against the 1.78 M signals that carry information).  zkwg_full.h derives, from the circuit's own `.sym` + `.r1cs`,
+// for every wire either the kept-v1 slot it copies or a linear row over kept-v1 slots.  This file lowers that once
+// per circuit into what the device needs to write the file's witness directly from the compact image, with no
+// staging buffer and no second pass:
+//   * an 8-byte DESCRIPTOR per wire: how the wire's value derives from image / record -- the segment arithmetic of
+//     its kept-v1 slot resolved at build time to (array, index, shift) for the bit- and byte-valued 95 %, a
+//     (segment, index) pair for the rest;
+//   * the rows that are real sums (negations, constant multiples, Bits2Num outputs, running sums), split by a static
+//     interval analysis into SMALL rows (sources and coefficients small integers, |result| < 2^30: evaluated in
+//     64-bit integers, 4 bytes of image each) and FIELD rows (anything else: evaluated mod r, 32 bytes each); their
+//     results extend the email's `small` / `fr` image arrays and are referenced by descriptors like any other value.
+// zk_o0_rows_small / zk_o0_rows_fr fill those image extensions for the emails about to be expanded; zk_expand3_o0
+// (zkwg_kernels_expand3.hip) is zk_expand3 with each lane's code coming from its wire's descriptor.
+#pragma once
+#include "zkwg_sched.h"
+#include "zkwg_r1cs.h"
+
+enum ZkDescKind : u32 {
+  ZK_D_IMM = 0,       // b = the code itself (a constant, or a reference known at build time)
+  ZK_D_BIT64 = 1,     // bit (a & 63) of bits[b]
+  ZK_D_BIT8 = 2,      // bit (a & 7) of rec[b]
+  ZK_D_BYTE = 3,      // rec[b]
+  ZK_D_SMALLRAW = 4,  // small[b], raw 32-bit value
+  ZK_D_SMALLS = 5,    // (small[b], small[b+1]) as a signed 64-bit integer v (results of small rows): 0 <= v < 2^31 -> v, else the field element v mod r
+  ZK_D_GENERIC = 6    // slot b of kept-v1 segment (a & 0xffffff): decoded by the segment's own arithmetic
+};
+
+#if !defined(ZKWG_O0_DEVICE_ONLY)
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "zkwg_full.h"
+
+struct ZkO0Tables {
+  std::vector<u32> desc;       // 2 words per wire
+  u32 small_base = 0, fr_base = 0;   // first row result inside the (extended) small / fr image arrays
+  // Rows are evaluated in GROUPS by one thread each: a group is one row, or a CHAIN of consecutive rows in which every
+  // row's terms include all the terms of the row before it (the running sums of MultiOR / CalculateTotal / IsZero
+  // popcount chains, which the elimination of zkwg_full.h flattened to O(n^2) terms): a chained row only lists the
+  // terms it adds and continues from its predecessor's result.
+  // small rows: result j -> small[small_base + 2 j .. +2) as a signed 64-bit integer
+  std::vector<u64> s_ptr; std::vector<u32> s_term; std::vector<int32_t> s_coef; std::vector<u8> s_chain; std::vector<u32> s_group;
+  // field rows: result j -> fr[fr_base + j]
+  std::vector<u64> f_ptr; std::vector<u32> f_term; std::vector<Fr> f_coef; std::vector<u8> f_kind; std::vector<u8> f_chain; std::vector<u32> f_group;
+  u64 n_small() const { return s_ptr.empty() ? 0 : s_ptr.size() - 1; }
+  u64 n_fr() const { return f_ptr.empty() ? 0 : f_ptr.size() - 1; }
+  u64 n_alias = 0, n_const = 0, terms_before_chaining = 0;
+};
+
+// static value range of slot r of a kept-v1 segment; false = a field element (no small bound)
+static inline bool zk_slot_range(const ZkSeg& g, u32 r, long long& lo, long long& hi) {
+  lo = 0; hi = 1;
+  switch (g.type) {
+    case ZSEG_BITS: case ZSEG_SHA_SP: case ZSEG_SHA_T1: case ZSEG_SHA_T2: case ZSEG_IN8BITS: case ZSEG_LTBITS: case ZSEG_B64BITS:
+      return true;
+    case ZSEG_IN8: hi = 255; return true;
+    case ZSEG_IN8MASK: hi = 255 * 255; return true;
+    case ZSEG_SMALL: case ZSEG_VSHIFT: hi = 0xffffffffll; return true;
+    case ZSEG_ISZ: return !(r & 1u);
+    case ZSEG_SEL: { const u32 per = 3u * g.a, q = r % per; if (q < g.a) return true; return !((q - g.a) & 1u); }
+    case ZSEG_REGSEL: {
+      const u32 per = 6u + g.a + 1u;
+      u32 q;
+      if (r < per - 2u) q = r < 4u ? r : r + 2u; else q = (r - (per - 2u)) % per;
+      return q >= 6u || !(q & 1u);
+    }
+    case ZSEG_B64: { const u32 q = r % 68u; if (q < 8u) { hi = 255; return true; } if (q < 62u) return true; return !((q - 62u) & 1u); }
+    case ZSEG_DFA: return g.a != ZDFA_EQ || !(r & 1u);
+    case ZSEG_RSLB: if (g.a == ZRS_EQ) return !(r & 1u); if (g.a == ZRS_PROC) hi = 255; return true;
+    default: return false;   // FR, LIMB, NET, HOLE
+  }
+}
+
+static inline void zk_o0_slot_desc(const std::vector<ZkSeg>& segs, u64 slot, u32 out[2], u32* seg_index = nullptr, u32* seg_r = nullptr) {
+  // the segment holding kept-v1 slot `slot`
+  size_t lo = 0, hi = segs.size();
+  while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (segs[mid].slot <= slot) lo = mid; else hi = mid; }
+  const ZkSeg& g = segs[lo];
+  const u32 r = (u32)(slot - g.slot) + g.r0;
+  if (seg_index) *seg_index = (u32)lo;
+  if (seg_r) *seg_r = r;
+  auto bit64 = [&](u32 word, u32 sh) { out[0] = (ZK_D_BIT64 << 28) | sh; out[1] = word; };
+  switch (g.type) {
+    case ZSEG_BITS: { const u32 grp = r / g.a, bit = r % g.a; bit64(g.src + grp * g.b + (bit >> 6), bit & 63u); return; }
+    case ZSEG_SHA_SP: { const u32 i = r / ZK_SP_SLOTS, q = r % ZK_SP_SLOTS, sub = std::min(q >> 5, 4u); bit64(g.src + i * 5 + sub, q - sub * 32); return; }
+    case ZSEG_SHA_T1: { const u32 i = r / ZK_T1_SLOTS, q = r % ZK_T1_SLOTS, sub = std::min(q >> 5, 3u); bit64(g.src + i * 4 + sub, q - sub * 32); return; }
+    case ZSEG_SHA_T2: { const u32 i = r / ZK_T2_SLOTS, q = r % ZK_T2_SLOTS, sub = std::min(q >> 5, 4u); bit64(g.src + i * 5 + sub, q - sub * 32); return; }
+    case ZSEG_IN8BITS: out[0] = (ZK_D_BIT8 << 28) | (r & 7u); out[1] = g.src + (r >> 3); return;
+    case ZSEG_IN8: out[0] = ZK_D_BYTE << 28; out[1] = g.src + r; return;
+    case ZSEG_SMALL: out[0] = ZK_D_SMALLRAW << 28; out[1] = g.src + r; return;
+    case ZSEG_FR: out[0] = ZK_D_IMM << 28; out[1] = 0x80000000u | (0u << 28) | (g.src + r); return;          // ZK_REF_FRV
+    case ZSEG_LIMB: out[0] = ZK_D_IMM << 28; out[1] = 0x80000000u | (2u << 28) | (g.src + 16u * r); return;  // ZK_REF_LIMB
+    default: out[0] = (ZK_D_GENERIC << 28) | (u32)lo; out[1] = r; return;
+  }
+}
+static inline bool zk_o0_desc_immediate(const u32 d[2], const std::vector<ZkSeg>& segs) {
+  switch (d[0] >> 28) {
+    case ZK_D_IMM: return !(d[1] >> 31);
+    case ZK_D_BIT64: case ZK_D_BIT8: case ZK_D_BYTE: return true;
+    case ZK_D_GENERIC: return zk_seg_is_immediate(segs[d[0] & 0xffffffu]);
+    default: return false;
+  }
+}
+
+// desc_slot[w]: kept-v1 slot wire w copies, or 0xfffffffe when w is the destination of a row of `P` that is not a plain
+// alias; term_slot[t]: kept-v1 slot of term t's source.  Extends s.img_small / s.img_fr by the row results.
+static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const ZkLinPlan& P, const std::vector<u32>& desc_slot,
+                               const std::vector<u32>& term_slot, ZkO0Tables& T, std::string& err) {
+  const u64 W = desc_slot.size();
+  if (segs.size() >= (1u << 24)) { err = "too many segments for the O0 descriptor table"; return false; }
+  T.desc.assign(2 * W, 0);
+  T.small_base = s.img_small; T.fr_base = s.img_fr;
+  T.s_ptr.assign(1, 0); T.f_ptr.assign(1, 0);
+  for (u64 w = 0; w < W; ++w)
+    if (desc_slot[w] != 0xfffffffeu) zk_o0_slot_desc(segs, desc_slot[w], &T.desc[2 * w]);
+  const Fr p = fr_p();
+  // the previous row of each class in full (chain detection)
+  std::vector<u32> prev_s_t, prev_f_t; std::vector<int32_t> prev_s_c; std::vector<Fr> prev_f_c;
+  std::vector<u32> td; std::vector<int32_t> cs;
+  const size_t CHAIN_MIN = 4;   // shorter shared prefixes are cheaper to recompute than to serialise
+  for (u64 r = 0; r < P.n_rows(); ++r) {
+    const u64 a = P.row_ptr[r], b = P.row_ptr[r + 1];
+    const u32 dst = P.dst[r];
+    if (desc_slot[dst] != 0xfffffffeu) { ++T.n_alias; continue; }   // plain alias: already described through its source
+    if (a == b) { T.desc[2 * dst] = ZK_D_IMM << 28; T.desc[2 * dst + 1] = 0; ++T.n_const; continue; }
+    // interval analysis: small iff every source is small-ranged, every coefficient a small signed integer and the sum stays below 2^62
+    bool small = true;
+    __int128 lo = 0, hi = 0;
+    td.clear(); cs.clear();
+    for (u64 t = a; t < b; ++t) {
+      u32 d[2], si, sr;
+      zk_o0_slot_desc(segs, term_slot[t], d, &si, &sr);
+      td.push_back(d[0]); td.push_back(d[1]);
+      long long l, h;
+      if (!small || !zk_slot_range(segs[si], sr, l, h)) { small = false; continue; }
+      const Fr& c = P.coef[t];
+      long long k;
+      if (!(c.l[1] | c.l[2] | c.l[3]) && c.l[0] < (1ull << 30)) k = (long long)c.l[0];
+      else {
+        u64 bw; const Fr n = fr_sub_raw(p, c, bw);
+        if (!(n.l[1] | n.l[2] | n.l[3]) && n.l[0] < (1ull << 30)) k = -(long long)n.l[0]; else { small = false; continue; }
+      }
+      const __int128 x = (__int128)k * l, y = (__int128)k * h;
+      lo += x < y ? x : y; hi += x < y ? y : x;
+      if (lo < -((__int128)1 << 62) || hi > ((__int128)1 << 62)) small = false;
+      cs.push_back((int32_t)k);
+    }
+    const size_t nt = b - a;
+    T.terms_before_chaining += nt;
+    // chained: every term of the previous row of the class (same source, same coefficient) is also a term of this one, in
+    // the same order -- the row then only lists the others and continues from its predecessor's result.  `rest` = the
+    // indices of this row's own terms.
+    std::vector<u32> rest;
+    auto subseq = [&](const std::vector<u32>& pt, size_t np, auto same_coef) {
+      rest.clear();
+      if (np < CHAIN_MIN || nt <= np) return false;
+      size_t q = 0;
+      for (size_t i = 0; i < nt; ++i) {
+        if (q < np && pt[2 * q] == td[2 * i] && pt[2 * q + 1] == td[2 * i + 1] && same_coef(q, i)) ++q;
+        else { if (rest.size() >= nt - np) return false; rest.push_back((u32)i); }
+      }
+      return q == np;
+    };
+    if (small) {
+      const bool ch = subseq(prev_s_t, prev_s_c.size(), [&](size_t q, size_t i) { return prev_s_c[q] == cs[i]; });
+      if (!ch) { rest.resize(nt); for (size_t i = 0; i < nt; ++i) rest[i] = (u32)i; }
+      for (u32 i : rest) { T.s_term.push_back(td[2 * i]); T.s_term.push_back(td[2 * i + 1]); T.s_coef.push_back(cs[i]); }
+      T.s_chain.push_back(ch ? 1 : 0);
+      if (!ch) T.s_group.push_back((u32)T.n_small());
+      T.s_ptr.push_back(T.s_coef.size());
+      T.desc[2 * dst] = ZK_D_SMALLS << 28; T.desc[2 * dst + 1] = T.small_base + 2u * (u32)(T.s_ptr.size() - 2);
+      prev_s_t = td; prev_s_c = cs;
+    } else {
+      std::vector<Fr> fc(P.coef.begin() + a, P.coef.begin() + b);   // standard form, like zk_linear_row
+      const bool ch = subseq(prev_f_t, prev_f_c.size(), [&](size_t q, size_t i) { return fr_eq(prev_f_c[q], fc[i]); });
+      if (!ch) { rest.resize(nt); for (size_t i = 0; i < nt; ++i) rest[i] = (u32)i; }
+      for (u32 i : rest) { T.f_term.push_back(td[2 * i]); T.f_term.push_back(td[2 * i + 1]); T.f_coef.push_back(fc[i]); T.f_kind.push_back(P.kind[a + i]); }
+      T.f_chain.push_back(ch ? 1 : 0);
+      if (!ch) T.f_group.push_back((u32)T.n_fr());
+      T.f_ptr.push_back(T.f_kind.size());
+      T.desc[2 * dst] = ZK_D_IMM << 28; T.desc[2 * dst + 1] = 0x80000000u | (T.fr_base + (u32)(T.f_ptr.size() - 2));   // ZK_REF_FRV
+      prev_f_t = td; prev_f_c.swap(fc);
+    }
+  }
+  T.s_group.push_back((u32)T.n_small());
+  T.f_group.push_back((u32)T.n_fr());
+  if ((u64)T.small_base + 2 * T.n_small() >= (1u << 28) || (u64)T.fr_base + T.n_fr() >= (1u << 28)) { err = "circuit too large for the O0 row tables"; return false; }
+  s.img_small = (u32)((T.small_base + 2 * T.n_small() + 3u) & ~3ull);
+  s.img_fr = (u32)(T.fr_base + T.n_fr());
+  return true;
+}
+#endif  // host tables
+
+#if defined(__HIPCC__)
+// device-side tables of a numbered circuit (kernel argument, by value)
+struct ZkO0Dev {
+  const uint2* desc;       // per wire
+  u64 W;                   // wires
+  u32 nportions;           // pieces of 256 K wires
+  u32 emails_per_wg;       // a workgroup expands its piece for this many emails (the descriptors are loaded once)
+  u32 small_base, fr_base;
+  const u64* s_ptr; const uint2* s_term; const int* s_coef; const u8* s_chain;
+  const u32* s_single; u32 n_small_single;       // small rows that are groups of their own (one thread each)
+  const uint2* s_chains; u32 n_small_chains;     // (first row, rows) of the chains (one wavefront each: prefix sum over the rows)
+  const u64* f_ptr; const uint2* f_term; const Fr* f_coef; const u8* f_kind; const u8* f_chain; const u32* f_group; u32 n_fr_groups;
+};
+#endif

@@ -90,13 +90,19 @@ static inline bool zk_r1cs_parse(const u8* p, u64 len, ZkR1csHost& R) {
 // *canon is cleared when a witness value is not reduced (>= r): such a witness is rejected
 // (mont_witness: the witness is in Montgomery form, so is the result; a value 0 or R -- most signals are bits --
 // then needs no product: R * c = the stored coefficient)
+// (reduce: a value >= r is reduced mod r instead of being skipped -- the prover-side evaluation must not drop terms)
 ZK_HD Fr zk_r1cs_lc(const u64* __restrict__ row_ptr, const u32* __restrict__ wire, const Fr* __restrict__ coef,
-                    const u8* __restrict__ kind, u64 lc, const Fr* __restrict__ w, bool* canon, bool mont_witness = false) {
+                    const u8* __restrict__ kind, u64 lc, const Fr* __restrict__ w, bool* canon, bool mont_witness = false,
+                    bool reduce = false) {
   Fr acc = fr_zero();
   const Fr unit = fr_R();
   for (u64 t = row_ptr[lc]; t < row_ptr[lc + 1]; ++t) {
-    const Fr x = w[wire[t]];
-    if (fr_geq(x, fr_p())) { *canon = false; continue; }
+    Fr x = w[wire[t]];
+    if (fr_geq(x, fr_p())) {
+      *canon = false;
+      if (!reduce) continue;
+      while (fr_geq(x, fr_p())) { u64 bw; x = fr_sub_raw(x, fr_p(), bw); }   // at most 5 rounds: 2^256 < 6 r
+    }
     const u8 k = kind[t];
     if (k == ZK_COEF_ONE) acc = fr_add(acc, x);
     else if (k == ZK_COEF_MINUS_ONE) acc = fr_sub(acc, x);

@@ -87,6 +87,35 @@ struct ZkSeg {
 };
 #define ZK_MONT_LIMBS 51u   // 128-bit limbs of an input record (pubkey, signature, message: 3 x 17)
 
+// segments whose slots are all immediate-valued (zkwg_expand_dec.h: no references), and the period a segment's decoder divides by
+ZK_HD bool zk_seg_is_immediate(const ZkSeg& g) {
+  switch (g.type) {
+    case ZSEG_BITS: case ZSEG_SHA_SP: case ZSEG_SHA_T1: case ZSEG_SHA_T2: case ZSEG_IN8: case ZSEG_IN8MASK:
+    case ZSEG_IN8BITS: case ZSEG_LTBITS: case ZSEG_B64BITS: case ZSEG_HOLE: return true;
+    case ZSEG_DFA: return g.a != ZDFA_EQ;
+    case ZSEG_RSLB: return g.a != ZRS_EQ;
+    default: return false;
+  }
+}
+ZK_HD u32 zk_seg_period(const ZkSeg& g) {
+  switch (g.type) {
+    case ZSEG_BITS: return g.a;
+    case ZSEG_SEL: return 3u * g.a;
+    case ZSEG_LTBITS: return g.a + 1u;
+    case ZSEG_REGSEL: return g.a + 7u;
+    case ZSEG_VSHIFT: return g.a;
+    default: return 0;
+  }
+}
+
+// zk_expand works in pieces of 256 K slots (K = 1, 2, 4: 8 K KiB of output), one per workgroup.  One table entry per piece:
+// a piece inside a single segment carries that segment's parameters (type < ZSEG_NTYPES) and the logical index of its
+// first slot; a piece that straddles segments (type = ZSEG_NTYPES) names the first segment to look at.
+struct ZkPortionEntry {
+  u32 type, src, a, b, c, magic;
+  u32 r_start;
+  u32 first_seg;
+};
 #define ZK_PORTION_DEFAULT 2048u  // witness slots expanded by one workgroup of zk_expand
 
 struct ZkShaFrame {      // one Sha256Bytes / Sha256BytesPartial instance
@@ -249,5 +278,17 @@ struct ZkBufs {
   u32 e_first;           // zk_expand: first email to expand (wit points at its witness)
   u32 emails_per_wg;     // zk_expand: emails handled by one workgroup (same portion of each)
   u32 xcd_remap;         // zk_expand: 1 = workgroup -> unit mapping that gives each of the 8 XCDs one contiguous range
+};
+
+// Arguments of zk_expand (by value; deliberately small: a workgroup lives for one 8 KiB piece)
+struct ZkX3 {
+  const u8* in; const u64* bits; const u32* small; const Fr* frv; const Fr* invtab;
+  const ZkPortionEntry* ent; const ZkSeg* segs;
+  uint4* wit;
+  const Fr* frm; const Fr* invtab_m; const Fr* rtab;   // Montgomery-form output only
+  Fr* frm_w; u32* small_w; Fr* frv_w;                  // writable views (zk_image_to_mont, the O0 row kernels)
+  u64 wit_stride16, W;
+  u32 in_stride, img_bits, img_small, img_fr, inv_half, m_dfa_cm, m_dfa_pm;
+  u32 nportions, nsegs, e_first, n_count, xcd_remap, limb_off;   // nportions: pieces per witness (of 256 K slots)
 };
 #endif

@@ -1,5 +1,5 @@
 // zkwg stand-in for @zk-email/zk-regex-circom/circuits/regex_helpers.circom (see
-// oracle/circom/gen_body_hash_regex.py; the real file is absent offline).
+// tools/gen_body_hash_regex.py; the real file is absent offline).
 pragma circom 2.1.5;
 
 include "circomlib/circuits/comparators.circom";

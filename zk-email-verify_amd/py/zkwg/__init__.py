@@ -217,6 +217,18 @@ class Circuit:
         _check(self.lib.zkwg_calculate_batch(self.h, records, n, out, self.witness_bytes, status, max_tile))
         return (bytes(out) if want_witness else None), list(status)
 
+    def set_host_expand(self, threads):
+        """threads > 0: calculate_batch_host expands on the host from the downloaded image (zkwg_set_host_expand); 0: on the device."""
+        _check(self.lib.zkwg_set_host_expand(self.h, int(threads)))
+
+    def expand_host(self, records, n, scratch_host, first, count, threads=1):
+        """zkwg_expand_host: witnesses of emails [first, first+count) from a host copy of the scratch buffer -> bytes"""
+        out = (C.c_uint8 * (count * self.witness_bytes + 16))()
+        addr = C.addressof(out)
+        off = (-addr) % 16
+        _check(self.lib.zkwg_expand_host(self.h, records, n, scratch_host, first, count, C.c_void_p(addr + off), self.witness_bytes, threads))
+        return bytes(memoryview(out)[off:off + count * self.witness_bytes])
+
     def time_host_path(self, records, n, max_tile=64, pinned=True, repeats=2):
         """Seconds of one zkwg_calculate_batch call that delivers n witnesses to host memory
         (pinned via zkwg_alloc_pinned, or pageable); the first call (staging-buffer allocation) is
