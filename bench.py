@@ -46,7 +46,7 @@ class Pipeline:
     sub-batch's witnesses are streamed out tile by tile ("expand", the HBM-bound kernel) on
     another; images are ring-buffered, witnesses go to a 2-tile ring in HBM."""
 
-    def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=4, exp_prio=-1,
+    def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=0, exp_prio=-1,
                  montgomery=False, out_align=0, serial=False, prep_cus=0, prep_cu_stride=1):
         self.torch, self.c, self.dev, self.d_in = torch, c, dev, d_in
         self.batch, self.tile, self.prep = batch, tile, prep
@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--prep-batch", type=int, default=0,
                     help="emails per prepare launch (pipeline granularity); 0 = 1024, or 2048 with --regex (zk_net_eval is one "
                          "wavefront per email: two per SIMD hide its latencies)")
-    ap.add_argument("--rsa-throttle", type=int, default=4, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap)")
+    ap.add_argument("--rsa-throttle", type=int, default=0, help="resident zk_rsa wavefronts per CU while overlapped (0 = no cap, the default since round 3)")
     ap.add_argument("--remove-soft-line-breaks", type=int, default=0,
                     help="template flag removeSoftLineBreaks (flag-variant measurement; the headline config keeps 0)")
     ap.add_argument("--prep-streams", type=int, default=1, help="streams the prepare launches alternate over")
@@ -456,6 +456,28 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
             torch.cuda.empty_cache()
     except Exception as e:
         out["BodyHashRegex compiled from the template file"] = {"error": repr(e)[:200]}
+    # the same with a template of the real circuit's size: every transition owns its comparators (~500 kept signals per header
+    # byte, W = 2.05 M -- zk-regex's generated body_hash_regex.circom is cited at 617,597 constraints, email-verifier.circom:124)
+    try:
+        tmpl = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "regex_style", "body_hash_regex_unshared.circom")
+        if not args.regex and os.path.exists(tmpl):
+            cr = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank, regex=tmpl)
+            _, d_in, _ = resident_inputs(torch, cr, dev, 0x5A4B + 606, 64, 4096, args.body_len)
+            pl = Pipeline(torch, cr, dev, d_in, 4096, 512, 2048, ring=2, rsa_throttle=args.rsa_throttle)
+            cr.set_timing(True)
+            dt = timed(torch, pl.step, steps=2, warmup=1)
+            summ = cr.timing_summary()
+            _, avg, nl, gbs = expand_roofline(cr, 512)
+            cr.set_timing(False)
+            assert int(pl.d_status.abs().sum().item()) == 0
+            out["BodyHashRegex from a template of the real circuit's size (unshared comparators)"] = {
+                "value": round(4096 * 2 / dt, 1), "unit": "witnesses/s", "steps": 2, "witness_len": cr.W,
+                "zk_net_eval_ms_per_2048_emails": round(summ["zk_net_eval"][0] / max(summ["zk_net_eval"][1], 1), 3),
+                "zk_expand_GBps": round(gbs, 1), "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4), "gate_list": cr.regex_info()}
+            del pl, d_in, cr
+            torch.cuda.empty_cache()
+    except Exception as e:
+        out["BodyHashRegex from a template of the real circuit's size (unshared comparators)"] = {"error": repr(e)[:200]}
     # delivered to host (PCIe-inclusive): zkwg_calculate_batch with a pinned destination, double-buffered tiles
     try:
         n, t = 192, 64
@@ -488,6 +510,40 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
             "sample": f"{n} emails through zkwg_calculate_batch with zkwg_set_host_expand({cores}), tiles of {t}: D2H of the 0.45 MB image per email"}
     except Exception as e:
         out["delivered to host memory, expanded on the host"] = {"error": repr(e)[:200]}
+    # complete witnesses of the circuit compiled the way the reference documents (`circom --O0`,
+    # docs/zk-email-docs/UsageGuide/README.md:59-64): every alias / constant / linear signal numbered, written in ONE pass
+    # from the image (zkwg_circuit_create_full; artefacts = interpreter-generated .sym / .r1cs under artifacts/)
+    try:
+        import gzip
+        art = os.path.join(os.path.dirname(os.path.abspath(__file__)), "artifacts")
+        tag = next((t for t in ((args.max_header, args.max_body), (576, 192)) if os.path.exists(os.path.join(art, f"o0_ev_{t[0]}_{t[1]}.json"))), None)
+        if tag is not None:
+            base = os.path.join(art, f"o0_ev_{tag[0]}_{tag[1]}")
+            meta = json.load(open(base + ".json"))
+            t0 = time.time()
+            co = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=tag[0], max_body=tag[1], device=local_rank,
+                              sym=gzip.open(base + ".sym.gz", "rb").read(), sym_alias=meta["alias"], r1cs=gzip.open(base + ".r1cs.gz", "rb").read())
+            t_create = time.time() - t0
+            bo, to = (512, 128) if tag[0] > 576 else (2048, 256)
+            _, d_in, _ = resident_inputs(torch, co, dev, 0x5A4B + 707, 64, bo, args.body_len if tag[1] >= args.body_len + 64 else 60)
+            pl = Pipeline(torch, co, dev, d_in, bo, to, min(1024, bo), ring=2, rsa_throttle=args.rsa_throttle)
+            co.set_timing(True)
+            dt = timed(torch, pl.step, steps=3, warmup=1)
+            _, avg, nl, gbs = expand_roofline(co, to)
+            co.set_timing(False)
+            assert int(pl.d_status.abs().sum().item()) == 0
+            kept_W = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=tag[0], max_body=tag[1], device=-1).W
+            out[f"complete --O0 witnesses, EmailVerifier({tag[0]},{tag[1]})"] = {
+                "value": round(bo * 3 / dt, 1), "unit": "witnesses/s", "steps": 3, "witness_len": co.W, "witness_bytes": co.witness_bytes,
+                "raw_GBps_whole_job": round(bo * 3 * co.witness_bytes / dt / 1e9, 1), "raw_frac": round(bo * 3 * co.witness_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "zk_expand_raw_GBps": round(gbs, 1),
+                "frac_on_W_alg": round(bo * 3 * (32 * kept_W) / dt / 1e9 / HBM_PEAK_GBS, 4), "W_alg": kept_W,
+                "handle_create_s": round(t_create, 1),
+                "note": "one pass: row kernels + zk_expand3_o0 (per-wire descriptors); raw = the bytes actually written; frac_on_W_alg grades the same time on the kept-v1 (information-carrying) signals only (SURVEY.md 8d3)"}
+            del pl, d_in, co
+            torch.cuda.empty_cache()
+    except Exception as e:
+        out["complete --O0 witnesses"] = {"error": repr(e)[:300]}
     # configs[4]: maxBody = 65536 (SHA-dominated), batch 1024, bodies 32K..65K-72; fewer steps
     try:
         c5 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=1024, max_body=65536, device=local_rank)

@@ -19,15 +19,15 @@ struct HT {
 extern "C" {
 void* ht_create(const zkwg_config* cfg) {
   HT* h = new HT();
-  if (!build_sched(*cfg, h->s, h->segs, h->first)) { delete h; return nullptr; }
+  if (!build_sched(*cfg, h->s, h->segs)) { delete h; return nullptr; }
   return h;
 }
 // `.sym`-ordered variant of the same schedule (zkwg_build.h zk_sym_layout + zk_remap_segments)
 void* ht_create_sym(const zkwg_config* cfg, const char* sym, uint64_t len) {
   HT* h = new HT();
   ZkSymLayout L;
-  if (!build_sched(*cfg, h->s, h->segs, h->first) || !zk_sym_layout(h->s, sym, len, nullptr, 0, L) ||
-      !zk_remap_segments(h->s, h->segs, h->first, L)) { delete h; return nullptr; }
+  if (!build_sched(*cfg, h->s, h->segs) || !zk_sym_layout(h->s, sym, len, nullptr, 0, L) ||
+      !zk_remap_segments(h->s, h->segs, L)) { delete h; return nullptr; }
   return h;
 }
 void ht_destroy(void* p) { delete (HT*)p; }
@@ -119,6 +119,8 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
   std::vector<int> lds(N.lds_words, 0x55555555);
   for (u32 i = 0; i < N.n_in; ++i) lds[N.n_pins + i] = msg[i];
   lds[N.n_pins + N.n_in] = 0;
+  for (u32 i = 0; i < N.n_in; ++i)          // the evaluator's prologue: per byte its mask words (byte-local frontier bits)
+    for (u32 m = 0; m < N.mask_words; ++m) lds[N.lds_masks + i * N.mask_words + m] = (int)N.mask_tab[(size_t)msg[i] * N.mask_words + m];
   std::vector<u32> img(N.n_kept + N.n_temp, 0xdeadbeefu);
   bool ok = true;
   size_t g = 0;
@@ -132,6 +134,11 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
     }
   }
   memcpy(words, img.data(), (size_t)N.n_kept * 4);
+  // byte-local kept signals are not evaluated: zk_expand reads their function tables (ZkDecNet, zkwg_expand_dec.h)
+  for (u32 r = 0; r < N.n_kept; ++r) {
+    const u32 d = N.slot_desc[r];
+    if (d >> 31) words[r] = N.fn_tab[((d >> 16) & 0x7fffu) * 256u + msg[d & 0xffffu]];
+  }
   return ok ? 1 : 0;
 }
 }

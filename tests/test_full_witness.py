@@ -4,7 +4,7 @@ The artefacts -- `.r1cs`, `.sym`, rename rules, input, digest of the complete wi
 interpreter executing the reference's UNMODIFIED sources with constraint generation (oracle/circom/symbolic.py,
 oracle/circom/o0_artifacts.py): the RSAVerifier65537(121,17) main (`tests/test-circuits/rsa-test.circom`,
 205,713 signals / 208,463 constraints) is committed under tests/golden/, EmailVerifier(576,192)
-(3,113,238 / 3,131,414) is generated into oracle/_ref/ by __graft_entry__.build() where /root/reference exists.
+(3,113,238 / 3,131,414) is generated into artifacts/ by __graft_entry__.build() where /root/reference exists.
 The product is handed only the `.sym` + `.r1cs` pair: it emits the signals its schedule produces at their `.sym`
 index and derives every other one from the linear constraints of the `.r1cs`.  Also: the device witness satisfies
 that `.r1cs` -- a constraint system that does NOT come from zkwg's own derivation (zkwg.r1cs)."""
@@ -24,7 +24,7 @@ def _load(base):
 
 
 RSA = os.path.join(ROOT, "tests", "golden", "o0_rsa")
-EV = os.path.join(ROOT, "oracle", "_ref", "o0_ev_576_192")
+EV = os.path.join(ROOT, "artifacts", "o0_ev_576_192")
 
 
 def _host_complete(c, kept_bytes):
@@ -75,7 +75,7 @@ def test_rsa_fixture_is_what_the_interpreter_generates(tmp_path):
     assert gzip.open(str(tmp_path / "o0_rsa.r1cs.gz")).read() == gzip.open(RSA + ".r1cs.gz").read()
 
 
-@pytest.mark.skipif(not os.path.exists(EV + ".json"), reason="oracle/_ref/o0_ev_576_192.* not built (needs /root/reference)")
+@pytest.mark.skipif(not os.path.exists(EV + ".json"), reason="artifacts/o0_ev_576_192.* not built (needs /root/reference)")
 def test_email_verifier_complete_witness_on_the_host():
     import zkwg
     from oracle import coracle
@@ -112,7 +112,7 @@ STAND_IN = os.path.join(ROOT, "zk-email-verify_amd", "data", "templates", "zk-re
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(EV + ".json"), reason="oracle/_ref/o0_ev_576_192.* not built (needs /root/reference)")
+@pytest.mark.skipif(not os.path.exists(EV + ".json"), reason="artifacts/o0_ev_576_192.* not built (needs /root/reference)")
 @pytest.mark.parametrize("regex", [None, STAND_IN], ids=["built-in regex", "regex from the template file"])
 def test_email_verifier_complete_witness_on_the_gpu_and_it_satisfies_the_r1cs(regex):
     """(second case: the route INTEGRATION.md section 3 describes for the real artefacts -- the regex template, the

@@ -1,6 +1,6 @@
 """tests/intake.py (the one-command intake for real circom / snarkjs artefacts) on the artefacts this repo can make
 offline: the interpreter-generated `--O0` files of the RSA main (tests/golden/o0_rsa.*) and of EmailVerifier(576,192)
-(oracle/_ref, built where /root/reference exists).  A `.wtns` written from the interpreter's values stands in for the
+(artifacts/, built where /root/reference exists).  A `.wtns` written from the interpreter's values stands in for the
 snarkjs file; a corrupted copy must be reported at the right signal."""
 import gzip
 import json
@@ -95,14 +95,14 @@ def test_intake_full_flow_on_the_gpu_from_a_saved_interpreter_run(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not (REF and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "o0_ev_576_192.json"))),
-                    reason="needs /root/reference (interpreter) and oracle/_ref/o0_ev_576_192.*")
+@pytest.mark.skipif(not (REF and os.path.exists(os.path.join(ROOT, "artifacts", "o0_ev_576_192.json"))),
+                    reason="needs /root/reference (interpreter) and artifacts/o0_ev_576_192.*")
 def test_intake_full_flow_on_the_email_verifier_artefacts(tmp_path):
     import intake
     tmpl_root = os.path.join(ROOT, "oracle", "circom", "lib")     # node_modules-shaped: @zk-email/zk-regex-circom + circomlib
     rep_path = tmp_path / "rep.json"
-    rc = intake.main(["--node-modules", tmpl_root, "--build-dir", os.path.join(ROOT, "oracle", "_ref"), "--name", "o0_ev_576_192",
-                      "--input", os.path.join(ROOT, "oracle", "_ref", "o0_ev_576_192.json"), "--max-header", "576", "--max-body", "192",
+    rc = intake.main(["--node-modules", tmpl_root, "--build-dir", os.path.join(ROOT, "artifacts"), "--name", "o0_ev_576_192",
+                      "--input", os.path.join(ROOT, "artifacts", "o0_ev_576_192.json"), "--max-header", "576", "--max-body", "192",
                       "--device", "0", "--json", str(rep_path)])
     rep = json.load(open(rep_path))
     assert rc == 0, rep

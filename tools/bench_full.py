@@ -1,6 +1,6 @@
 """Throughput of complete `--O0`-numbered witnesses (zkwg_circuit_create_full) for
 EmailVerifier(576,192) -- or `bench_full.py 1024 1536` -- : zk_expand into a staging buffer, zk_o0_gather / zk_o0_rows.
-Needs oracle/_ref/o0_ev_576_192.* (built by __graft_entry__.build() where /root/reference exists; travels to
+Needs artifacts/o0_ev_576_192.* (built by __graft_entry__.build() where /root/reference exists; travels to
 the GPU box) -- a measurement aid, not part of the product."""
 import gzip
 import json
@@ -18,7 +18,7 @@ def main():
     import zkwg
     import bench
     N, M = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (576, 192)
-    base = os.path.join(ROOT, "oracle", "_ref", f"o0_ev_{N}_{M}")
+    base = os.path.join(ROOT, "artifacts", f"o0_ev_{N}_{M}")
     meta = json.load(open(base + ".json"))
     sym = gzip.open(base + ".sym.gz", "rb").read()
     r1cs = gzip.open(base + ".r1cs.gz", "rb").read()

@@ -50,23 +50,21 @@ struct zkwg_circuit {
   // BodyHashRegex loaded from a circom template (zkwg_circuit_create_regex): gate list on the device
   zkc::Net net;
   bool has_net;
-  u32* d_net_records; u32* d_net_counts;
+  u32* d_net_records; u32* d_net_counts; u32* d_net_mask_tab; u32* d_net_fn; u32* d_net_desc;
   Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
   u32 pos_dense_off;
   Fr* d_pos_rs;   // removeSoftLineBreaks: Poseidon(16) then Poseidon(2) sparse-round tables
   ZkSeg* d_segs;
-  u32* d_first_seg;
   ZkPortionEntry* d_ent;   // zk_expand: one entry per piece of 256 K slots (zkwg_build.h zk_build_entries)
   u32 n_ent;
   std::vector<Fr> invtab_host;   // zkwg_expand_host: the inverse table on the host
   int host_expand_threads;       // > 0: zkwg_calculate_batch expands on the host (zkwg_set_host_expand)
   u8* hx_img[2]; u64 hx_bytes;   // pinned staging of downloaded images (host expansion)
-  int o0_emails_per_wg;          // emails per workgroup of zk_expand3_o0 (ZKWG_O0_EMAILS_PER_WG, default 4)
+  int o0_emails_per_wg;          // emails per workgroup of zk_expand3_o0 (ZKWG_O0_EMAILS_PER_WG, default 8)
   int x3_k, x3_k_o0;       // slots per thread of zk_expand3 (kept-v1 / sym layouts) and zk_expand3_o0: 1, 2 or 4 (ZKWG_X3_K, ZKWG_X3_K_O0)
   std::vector<ZkSeg> segs;
-  std::vector<u32> first_seg;
   hipStream_t own_stream, copy_stream;
   // removeSoftLineBreaks: the serial merge chain (zk_rslb_chain, ~16 waves per 1024 emails, latency-bound)
   // runs on a side stream so that the caller's stream can go on with the next batch; zkwg_expand_device
@@ -101,9 +99,6 @@ struct zkwg_circuit {
   u64 launches;   // expand launches recorded since timing was enabled
   u64 prep_launches;
   bool ev_valid, prep_valid;
-  int expand_threads;
-  int expand_v;    // 3 (default): zk_expand3, one 8 KiB piece per workgroup; 2: LDS-staged 64 KiB portions; 1: the direct-store kernels of rounds 1-2 (ZKWG_EXPAND_V)
-  int emails_per_wg;
   int rsa_wgs_per_cu;
 };
 
@@ -198,23 +193,13 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   c->cfg = *cfg;
   c->device = -1;
   // tuning knobs (DESIGN.md "zk_expand geometry"): slots per workgroup and threads per workgroup
-  u32 portion = ZK_PORTION_DEFAULT;
-  c->expand_threads = 256;
-  if (const char* v = getenv("ZKWG_PORTION")) portion = (u32)atoi(v);
-  if (const char* v = getenv("ZKWG_EXPAND_THREADS")) c->expand_threads = atoi(v);
-  c->expand_v = getenv("ZKWG_EXPAND_V") ? atoi(getenv("ZKWG_EXPAND_V")) : 3;
-  if (c->expand_v < 1 || c->expand_v > 3) c->expand_v = 3;
   auto pick_k = [](const char* name, int dflt, bool k8 = false) { const char* v = getenv(name); const int k = v ? atoi(v) : dflt; return (k == 1 || k == 2 || k == 4 || (k8 && k == 8)) ? k : dflt; };
   c->x3_k = pick_k("ZKWG_X3_K", 4, true);
   c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 4);
-  c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 4;
-  if (c->expand_v == 2 && portion > 8192) portion = 8192;   // 4 bytes of LDS per slot
-  c->emails_per_wg = 1;
+  c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 8;
   c->xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
   c->rsa_wgs_per_cu = 0;
   if (const char* v = getenv("ZKWG_RSA_WGS_PER_CU")) c->rsa_wgs_per_cu = atoi(v);
-  if (const char* v = getenv("ZKWG_EMAILS_PER_WG")) c->emails_per_wg = std::max(1, atoi(v));
-  if (portion < 64 || portion > (1u << 20)) portion = ZK_PORTION_DEFAULT;
   c->has_net = false;
   if (regex) {
     // the regex circuit is compiled from the supplied template text (zkwg_circom.h)
@@ -233,7 +218,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     c->has_net = true;
   }
   const zkc::Net* net = c->has_net ? &c->net : nullptr;
-  if (!build_sched(*cfg, c->s, c->segs, c->first_seg, portion, net)) { g_last_error = "unsupported circuit configuration"; delete c; return ZKWG_RC_BAD_CONFIG; }
+  if (!build_sched(*cfg, c->s, c->segs, net)) { g_last_error = "unsupported circuit configuration"; delete c; return ZKWG_RC_BAD_CONFIG; }
   if (getenv("ZKWG_DEBUG_SKIP_INV") && atoi(getenv("ZKWG_DEBUG_SKIP_INV")) && c->s.rsa.present) c->s.rsa.present = 2;  // profiling only
   if (sym_text) {
     ZkSymLayout L;
@@ -241,7 +226,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     // a compact `.sym` (no .r1cs): zk_expand writes the file's order directly (segments remapped).  A fully numbered
     // circuit (.r1cs given): zk_expand keeps producing the compact kept-v1 witness into a staging buffer and
     // zk_o0_gather writes every wire of the file from it (aliases copy, the other derived signals are linear rows)
-    if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net) || (!r1cs && !zk_remap_segments(c->s, c->segs, c->first_seg, L))) {
+    if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net) || (!r1cs && !zk_remap_segments(c->s, c->segs, L))) {
       g_last_error = L.err.empty() ? std::string(".sym layout does not tile the witness") : L.err;
       delete c;
       return ZKWG_RC_BAD_CONFIG;
@@ -339,8 +324,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     if (zk_misc_init_tables() != 0) { delete c; return ZKWG_RC_HIP_ERROR; }
     std::vector<Fr>& tab = c->invtab_host;
     bool ok = hipMalloc((void**)&c->d_invtab, tab.size() * sizeof(Fr)) == hipSuccess &&
-              hipMalloc((void**)&c->d_segs, c->segs.size() * sizeof(ZkSeg)) == hipSuccess &&
-              hipMalloc((void**)&c->d_first_seg, c->first_seg.size() * sizeof(u32)) == hipSuccess;
+              hipMalloc((void**)&c->d_segs, c->segs.size() * sizeof(ZkSeg)) == hipSuccess;
     {
       std::vector<ZkPortionEntry> ent;
       zk_build_entries(c->s.W, c->segs, ent, 256u * (u32)c->x3_k);
@@ -349,13 +333,17 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
            hipMemcpy(c->d_ent, ent.data(), ent.size() * sizeof(ZkPortionEntry), hipMemcpyHostToDevice) == hipSuccess;
     }
     ok = ok && hipMemcpy(c->d_invtab, tab.data(), tab.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(ZkSeg), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(c->d_first_seg, c->first_seg.data(), c->first_seg.size() * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess;
+         hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(ZkSeg), hipMemcpyHostToDevice) == hipSuccess;
     if (ok && c->has_net) {
       ok = hipMalloc((void**)&c->d_net_records, c->net.records.size() * 4) == hipSuccess &&
            hipMemcpy(c->d_net_records, c->net.records.data(), c->net.records.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
            hipMalloc((void**)&c->d_net_counts, c->net.step_count.size() * 4 + 64) == hipSuccess &&
            hipMemcpy(c->d_net_counts, c->net.step_count.data(), c->net.step_count.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+      auto upw = [&](const std::vector<u32>& v, u32** dst) {
+        if (!ok) return;
+        ok = hipMalloc((void**)dst, std::max<size_t>(v.size(), 4) * 4) == hipSuccess && (v.empty() || hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
+      };
+      upw(c->net.mask_tab, &c->d_net_mask_tab); upw(c->net.fn_tab, &c->d_net_fn); upw(c->net.slot_desc, &c->d_net_desc);
       if (ok) std::vector<u32>().swap(c->net.records);
     }
     if (ok && c->full_W) {
@@ -431,7 +419,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     }
     if (!ok) {
       hipFree(c->d_pos); hipFree(c->d_pos_rs);
-      hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_ent);
+      hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent);
       delete c;
       return ZKWG_RC_OOM;
     }
@@ -587,10 +575,10 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
-    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_first_seg); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
+    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
     hipFree((void*)c->o0d.desc); hipFree((void*)c->o0d.s_ptr); hipFree((void*)c->o0d.s_term); hipFree((void*)c->o0d.s_coef); hipFree((void*)c->o0d.s_chain); hipFree((void*)c->o0d.s_single); hipFree((void*)c->o0d.s_chains);
     hipFree((void*)c->o0d.f_ptr); hipFree((void*)c->o0d.f_term); hipFree((void*)c->o0d.f_coef); hipFree((void*)c->o0d.f_kind); hipFree((void*)c->o0d.f_chain); hipFree((void*)c->o0d.f_group);
-    hipFree(c->d_net_records); hipFree(c->d_net_counts);
+    hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_fn); hipFree(c->d_net_desc);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); if (c->hx_img[i]) hipHostFree(c->hx_img[i]); }
     hipStreamDestroy(c->copy_stream);
@@ -756,7 +744,6 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.small = (u32*)(scr + L.off_small);
   B.frv = (Fr*)(scr + L.off_fr);
   B.frm = (Fr*)(scr + L.off_frm);
-  B.pflags = c->d_first_seg ? c->d_first_seg + s.nportions : nullptr;
   B.invtab = c->d_invtab;
   B.pos_c = c->d_pos;
   B.pos_m = c->d_pos ? c->d_pos + c->pos_dense_off : nullptr;
@@ -764,16 +751,15 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.invtab_m = c->d_invtab_m;
   B.net_records = c->d_net_records;
   B.net_counts = c->d_net_counts;
+  B.net_mask_tab = c->d_net_mask_tab; B.net_fn = c->d_net_fn; B.net_desc = c->d_net_desc;
   B.pos16 = c->d_pos_rs;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
-  B.first_seg = c->d_first_seg;
   B.wit = nullptr;
   B.wit_stride16 = 0;
   B.status = nullptr;
   B.n_emails = (u32)n;
   B.e_first = 0;
-  B.emails_per_wg = 1;
   B.xcd_remap = c->xcd_remap;
 }
 
@@ -785,9 +771,10 @@ static void fill_x3(const zkwg_circuit* c, const ZkBufs& B, ZkX3& A) {
   A.frm_w = B.frm; A.small_w = B.small; A.frv_w = B.frv;
   A.wit_stride16 = B.wit_stride16; A.W = s.W;
   A.in_stride = s.in_stride; A.img_bits = s.img_bits; A.img_small = s.img_small; A.img_fr = s.img_fr; A.inv_half = s.inv_half;
-  A.m_dfa_cm = s.m_dfa_cm; A.m_dfa_pm = s.m_dfa_pm;
+  A.m_dfa_cm = s.m_dfa_cm; A.m_dfa_pm = s.m_dfa_pm; A.m_dfa_st = s.m_dfa_st;
   A.nportions = c->n_ent; A.nsegs = s.nsegs; A.e_first = B.e_first; A.n_count = B.n_emails - B.e_first;
-  A.xcd_remap = c->xcd_remap ? 1u : 0u; A.limb_off = s.in_off[ZKWG_IN_PUBKEY];
+  A.xcd_remap = c->xcd_remap ? 1u : 0u; A.limb_off = s.in_off[ZKWG_IN_PUBKEY]; A.hdr_off = s.in_off[ZKWG_IN_HEADER];
+  A.net_fn = B.net_fn; A.net_desc = B.net_desc;
 }
 
 int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_status, void* d_scratch,
@@ -900,14 +887,13 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   if (c->device < 0) return ZKWG_RC_NO_DEVICE;
   if (count == 0) return ZKWG_RC_OK;
   const ZkSched& s = c->s;
-  if (first + count > n || out_stride < out_W(c) * 32 || (out_stride & 15) || count * (u64)s.nportions > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
+  if (first + count > n || out_stride < out_W(c) * 32 || (out_stride & 15)) return ZKWG_RC_BAD_ARG;
   if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_out & 15)) return ZKWG_RC_BAD_ARG;
   std::lock_guard<std::mutex> lock(c->dev_mutex);
   ZkDeviceGuard dg(c->device);
   if (!dg.ok) return ZKWG_RC_HIP_ERROR;
   hipStream_t st = (hipStream_t)hip_stream;
   if (mont) {
-    if (c->expand_v == 1 && s.portion > ZK_PORTION_DEFAULT) return ZKWG_RC_BAD_CONFIG;
     if (!c->d_rtab || !c->d_invtab_m) {
       // v * R mod r for v < 65536 (2 MiB) and the inverse table in Montgomery form, built once per handle and
       // published together (a half-built pair must never be seen by a later call)
@@ -939,7 +925,6 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
   const bool tm = c->timing != 0;
   hipEvent_t* evs = c->ev[c->launches % ZK_EV_RING];
   if (tm) hipEventRecord(evs[0], st);
-  B.emails_per_wg = mont ? 1u : (u32)c->emails_per_wg;
   for (u64 off = 0; off < count; off += sub) {
     const u64 cnt = std::min(sub, count - off);
     u8* out_sub = (u8*)d_out + off * out_stride;
@@ -966,7 +951,7 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
 #undef ZK_LAUNCH_O0
       continue;
     }
-    if (c->expand_v == 3) {
+    {
       // one piece of 256 K slots per workgroup (zkwg_kernels_expand3.hip)
       const u64 units3 = cnt * (u64)c->n_ent;
       if (units3 > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
@@ -975,22 +960,7 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
 #define ZK_LAUNCH_X3(K) do { if (mont) hipLaunchKernelGGL(zk_expand3_mont_k##K, g3, b3, 0, st, A); else hipLaunchKernelGGL(zk_expand3_k##K, g3, b3, 0, st, A); } while (0)
       if (c->x3_k == 1) ZK_LAUNCH_X3(1); else if (c->x3_k == 2) ZK_LAUNCH_X3(2); else if (c->x3_k == 8) ZK_LAUNCH_X3(8); else ZK_LAUNCH_X3(4);
 #undef ZK_LAUNCH_X3
-      continue;
     }
-    const u64 units = ((cnt + B.emails_per_wg - 1) / B.emails_per_wg) * s.nportions;
-    const dim3 grid((u32)units);
-    if (c->expand_v == 2) {
-      // LDS-staged kernel (zkwg_kernels_expand2.hip): 4 bytes of LDS per slot of the portion
-      if (mont) {
-        hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, A);
-        hipLaunchKernelGGL(zk_expand2_mont, grid, dim3(256), s.portion * 4u, st, s, B);
-      } else hipLaunchKernelGGL(zk_expand2, grid, dim3(256), s.portion * 4u, st, s, B);
-    }
-    else if (mont) hipLaunchKernelGGL(zk_expand_mont_256, grid, dim3(256), 0, st, s, B);
-    else if (c->expand_threads == 64) hipLaunchKernelGGL(zk_expand_wave, dim3((u32)((units + 3) / 4)), dim3(256), 0, st, s, B);
-    else if (c->expand_threads == 1024) hipLaunchKernelGGL(zk_expand_1024, grid, dim3(1024), 0, st, s, B);
-    else if (c->expand_threads == 512) hipLaunchKernelGGL(zk_expand_512, grid, dim3(512), 0, st, s, B);
-    else hipLaunchKernelGGL(zk_expand_256, grid, dim3(256), 0, st, s, B);
   }
   if (tm) { hipEventRecord(evs[1], st); c->ev_valid = true; c->launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
@@ -1108,7 +1078,8 @@ int zkwg_expand_host(const zkwg_circuit_t* c, const uint8_t* records, uint64_t n
       const u64 el = it / per, slot0 = (it % per) * CH, slot1 = std::min<u64>(s.W, slot0 + CH), e = first + el;
       ZkCtx cx;
       cx.rec = records + e * s.in_stride; cx.bits = bits + e * s.img_bits; cx.small = small + e * s.img_small;
-      cx.half = (int)s.inv_half; cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm;
+      cx.half = (int)s.inv_half; cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm; cx.m_dfa_st = s.m_dfa_st;
+      cx.net_desc = c->net.slot_desc.data(); cx.net_fn = c->net.fn_tab.data(); cx.hdr_off = s.in_off[ZKWG_IN_HEADER];
       ZkRefSrc R;
       R.frv = (const uint4*)(frv + e * s.img_fr); R.invtab = (const uint4*)c->invtab_host.data(); R.rec = cx.rec; R.small = cx.small;
       u8* w = out + el * out_stride;

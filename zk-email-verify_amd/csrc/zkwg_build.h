@@ -9,10 +9,9 @@
 #include "../../include/zkwg.h"
 #include "zkwg_layout.h"
 
-// Tables derived from the final segment list: the first segment of every portion, the per-segment reciprocal of
-// the type's period (so that zk_expand divides with one multiply; only set when exact over the segment's range)
-// and the per-portion flags of zk_expand's store phase.
-static inline void zk_finish_tables(ZkSched& s, std::vector<ZkSeg>& segs, std::vector<u32>& first_seg) {
+// Derived from the final segment list: the per-segment reciprocal of the type's period (so that zk_expand divides with
+// one multiply; only set when exact over the segment's range).
+static inline void zk_finish_tables(std::vector<ZkSeg>& segs) {
   for (ZkSeg& g : segs) {
     g.pad = 0;
     const u64 d = zk_seg_period(g);
@@ -21,16 +20,6 @@ static inline void zk_finish_tables(ZkSched& s, std::vector<ZkSeg>& segs, std::v
     if ((d & (d - 1)) == 0) { g.pad = (u32)((1ull << 32) / d); continue; }
     const u64 m = (1ull << 32) / d + 1, e = m * d - (1ull << 32);
     if (rmax * e < (1ull << 32)) g.pad = (u32)m;
-  }
-  first_seg.assign((size_t)s.nportions * 2, 0);   // [first segment of portion p | flags of portion p]
-  u32 si = 0;
-  for (u32 p = 0; p < s.nportions; ++p) {
-    const u64 slot0 = (u64)p * s.portion, slot1 = std::min<u64>(s.W, slot0 + s.portion);
-    while (si + 1 < s.nsegs && segs[si].slot + segs[si].nslots <= slot0) ++si;
-    first_seg[p] = si;
-    bool pure = true;
-    for (u32 j = si; j < s.nsegs && segs[j].slot < slot1; ++j) pure = pure && zk_seg_is_immediate(segs[j]);
-    first_seg[s.nportions + p] = pure ? 1u : 0u;
   }
 }
 
@@ -51,8 +40,7 @@ static inline void zk_build_entries(u64 W, const std::vector<ZkSeg>& segs, std::
     } else e.type = ZSEG_NTYPES;
   }
 }
-static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& segs,
-                        std::vector<u32>& first_seg, u32 portion = ZK_PORTION_DEFAULT, const zkc::Net* net = nullptr) {
+static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& segs, const zkc::Net* net = nullptr) {
   memset(&s, 0, sizeof(s));
   if (cfg.layout != ZKWG_LAYOUT_KEPT_V1) return false;
   if (cfg.remove_soft_line_breaks && (cfg.main_kind != ZKWG_MAIN_EMAIL_VERIFIER || cfg.ignore_body_hash_check)) return false;
@@ -144,9 +132,7 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
   s.img_fr = w.nfr + 1;
   segs = std::move(w.segs);
   s.nsegs = (u32)segs.size();
-  s.portion = portion;
-  s.nportions = (u32)((s.W + portion - 1) / portion);
-  zk_finish_tables(s, segs, first_seg);
+  zk_finish_tables(segs);
   return true;
 }
 
@@ -333,7 +319,7 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
 }
 // Re-target the segment table: split every kept-v1 segment into maximal runs whose destinations are
 // consecutive, carry the run's offset inside the logical array in ZkSeg::r0, sort by destination.
-static bool zk_remap_segments(ZkSched& s, std::vector<ZkSeg>& segs, std::vector<u32>& first_seg, const ZkSymLayout& L) {
+static bool zk_remap_segments(ZkSched& s, std::vector<ZkSeg>& segs, const ZkSymLayout& L) {
   std::vector<ZkSeg> out;
   for (const ZkSeg& g : segs) {
     u32 i = 0;
@@ -362,8 +348,7 @@ static bool zk_remap_segments(ZkSched& s, std::vector<ZkSeg>& segs, std::vector<
   segs.swap(out);
   s.W = L.W;
   s.nsegs = (u32)segs.size();
-  s.nportions = (u32)((s.W + s.portion - 1) / s.portion);
-  zk_finish_tables(s, segs, first_seg);
+  zk_finish_tables(segs);
   return true;
 }
 

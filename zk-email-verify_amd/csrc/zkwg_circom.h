@@ -500,6 +500,17 @@ struct Net {
   std::vector<u32> step_count;       // gates per step (<= 64, one per lane) | 0x8000 general path | 0x4000 term slots 0..3 only;
                                      // padded with empty steps (the evaluator reads the counts three groups of 8 ahead)
   u32 n_steps = 0;
+  // Byte-local signals (zkwg_circom.h localize): a signal whose value depends on ONE message byte only (the character
+  // comparators of a regex circuit: IsEqual / LessThan internals, range ANDs, class ORs -- most of its signals) is a
+  // function of that byte.  Such gates are not evaluated per email: zk_expand reads `fn_tab` (the stored word for each
+  // of the 256 byte values, one table per distinct function), and the boolean ones a per-email gate does read come from
+  // a per-position mask word the evaluator builds with one lookup of `mask_tab` per message byte.
+  std::vector<u32> fn_tab;           // n_fn x 256 stored words
+  std::vector<u32> slot_desc;        // per kept slot: 0 = evaluated (the word is in the image), else 0x80000000 | fn << 16 | byte index
+  std::vector<u32> mask_tab;         // 256 x mask_words: bit b of word m = truth of frontier function 23 m + b on that byte value
+  u32 mask_words = 0;                // mask words per message byte (0: nothing was localised)
+  u32 lds_masks = 0;                 // first LDS word of the evaluator's mask region (n_in x mask_words words)
+  u32 n_local = 0, n_frontier = 0;   // statistics: gates removed from the evaluator / served from the masks
   std::vector<std::string> names;    // kept slot -> name relative to the component (".eq[0][5].isz.inv")
   std::vector<u8> boolean;           // kept slot -> 1 if its interval is [0, 1]
   // statistics
@@ -507,6 +518,7 @@ struct Net {
   u64 lds_hits = 0, pin_reads = 0;   // operand reads
 };
 // record / term encoding shared with the kernel
+static const u32 ZKC_MASK_BITS = 23;         // frontier bits per mask word (the evaluator's 32-bit path multiplies signed 24-bit operands)
 static const u32 VAL_INVERSE = 0x80000000u; // stored word: inverse of the 31-bit two's-complement integer in the low bits
 
 // ------------------------------------------------------------------------------------------------ elaboration
@@ -521,6 +533,9 @@ struct Elab {
   std::set<std::string> included;
   std::vector<std::string> include_dirs;
   std::vector<Gate> gates;
+  std::vector<u8> g_skip;            // localize(): the gate is not evaluated per email
+  std::vector<int> g_front;          // localize(): >= 0: the gate is the bit of that index of its byte's mask words
+  std::vector<long long> g_sup;      // localize(): the message byte a gate depends on (-1 none, -2 several)
   std::vector<i64> in_lo, in_hi;
   u32 n_in = 0;
   u32 max_terms = 32;
@@ -1308,6 +1323,7 @@ struct Elab {
       if (g.slot < net.n_kept && g.op != G_INV0 && g.lo >= 0 && g.hi <= 1) net.boolean[g.slot] = 1;
     }
     if (next >= 0x1fffffffu) fail("the circuit is too large");
+    localize(net);
     emit(net);
   }
 
@@ -1366,6 +1382,133 @@ struct Elab {
     }
   }
 
+  // Byte-local gates leave the evaluator (Net::fn_tab / mask_tab).  support: -1 = no message byte, i >= 0 = byte i only,
+  // -2 = several.  A gate with single support is LOCAL unless it is an assertion or an output.  What a per-email gate
+  // reads from a local gate: a boolean becomes a FRONTIER bit (one of its byte's mask bits); anything else keeps the
+  // local gate (and its cone) in the evaluator.  Local gates are identified up to the byte they look at by a structural
+  // signature, so one 256-entry table serves the same comparator at every position.
+  void localize(Net& net) {
+    const u32 n = (u32)gates.size();
+    g_skip.assign(n, 0); g_front.assign(n, -1); g_sup.assign(n, -1);
+    net.slot_desc.assign(net.n_kept, 0);
+    if (getenv("ZKWG_NET_LOCALIZE") && !atoi(getenv("ZKWG_NET_LOCALIZE"))) return;
+    auto nforms = [](const Gate& g) { return (g.op == G_QUAD || g.op == G_ASSERT) ? 3 : (g.op == G_NEZ ? 2 : 1); };
+    std::vector<long long> sup(n, -1);
+    std::vector<u64> sig(n, 0);
+    auto mix = [](u64 h, u64 v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdull; };
+    for (u32 g = 0; g < n; ++g) {
+      const Gate& G = gates[g];
+      long long sp = -1;
+      u64 h = mix(G.op, (u64)G.k);
+      for (int i = 0; i < nforms(G); ++i) {
+        h = mix(h, (u64)G.f[i].c0 + 17u * i);
+        for (auto& t : G.f[i].t) {
+          const long long ts = (t.first & SRC_INPUT) ? (long long)(t.first & 0x1fffffffu) : sup[t.first];
+          if (ts == -2 || (ts >= 0 && sp >= 0 && ts != sp)) sp = -2; else if (ts >= 0 && sp != -2) sp = ts;
+          h = mix(mix(h, (u64)t.second), (t.first & SRC_INPUT) ? 0x5bd1e995u : sig[t.first]);
+        }
+      }
+      sup[g] = sp; sig[g] = h;
+    }
+    g_sup = sup;
+    std::vector<u8> local(n, 0), need(n, 0), front(n, 0);
+    for (u32 g = 0; g < n; ++g) local[g] = sup[g] >= 0 && gates[g].op != G_ASSERT && gates[g].op != G_OUT;
+    // value of a local gate for byte value v (the arithmetic of zk_net_record): memoised over its cone
+    std::vector<long long> memo(n, 0); std::vector<u32> stamp(n, 0); u32 now = 0;
+    std::function<long long(u32, long long, u32&)> eval = [&](u32 g, long long v, u32& word) -> long long {
+      if (stamp[g] == now) { word = 0; return memo[g]; }
+      const Gate& G = gates[g];
+      long long f[3] = {0, 0, 0};
+      for (int i = 0; i < nforms(G); ++i) {
+        f[i] = G.f[i].c0;
+        for (auto& t : G.f[i].t) { u32 w; f[i] += t.second * ((t.first & SRC_INPUT) ? v : eval(t.first, v, w)); }
+      }
+      long long r = f[0];
+      if (G.op == G_QUAD) r = f[0] * f[1] + f[2];
+      else if (G.op == G_NEZ) r = (f[0] != 0 ? G.k : 0) + f[1];
+      else if (G.op == G_BIT) r = f[0] < 0 ? -1 : ((f[0] >> G.k) & 1);
+      word = G.op == G_INV0 ? (f[0] == 0 ? 0u : (VAL_INVERSE | ((u32)f[0] & 0x7fffffffu))) : ((u32)r & 0x7fffffffu);
+      stamp[g] = now; memo[g] = r;
+      return r;
+    };
+    // tables per signature (representative = first gate with it)
+    std::map<u64, std::vector<u32>> words_of;       // stored words for v = 0 .. 255
+    std::map<u64, bool> plain_of;                   // every value a plain non-negative 30-bit integer or an inverse in range
+    auto table = [&](u32 g) -> const std::vector<u32>& {
+      auto it = words_of.find(sig[g]);
+      if (it != words_of.end()) return it->second;
+      std::vector<u32> w(256);
+      bool plain = true;
+      for (u32 v = 0; v < 256; ++v) {
+        ++now;
+        u32 word = 0;
+        const long long r = eval(g, (long long)v, word);
+        // (eval returns word = 0 for a memo hit; the top-level call is never one)
+        w[v] = word;
+        if (gates[g].op == G_INV0) { const int d = (int)(word << 1) >> 1; if (std::llabs((long long)d) > (long long)net.inv_need) plain = false; }
+        else if (r < 0 || r >= (1ll << 30)) plain = false;
+      }
+      plain_of[sig[g]] = plain;
+      return words_of.emplace(sig[g], std::move(w)).first->second;
+    };
+    // needed gates: everything that is not local; then what they read
+    std::vector<u32> work;
+    for (u32 g = 0; g < n; ++g) if (!local[g]) { need[g] = 1; work.push_back(g); }
+    // local kept gates whose table holds a value zk_expand could not decode stay in the evaluator
+    for (u32 g = 0; g < n; ++g)
+      if (local[g] && gates[g].slot < net.n_kept) { table(g); if (!plain_of[sig[g]]) { need[g] = 1; work.push_back(g); } }
+    while (!work.empty()) {
+      const u32 g = work.back(); work.pop_back();
+      const Gate& G = gates[g];
+      for (int i = 0; i < nforms(G); ++i)
+        for (auto& t : G.f[i].t) {
+          if (t.first & SRC_INPUT) continue;
+          const u32 sgi = t.first;
+          if (!local[sgi] || need[sgi] || front[sgi]) continue;
+          const Gate& S = gates[sgi];
+          if (S.op != G_INV0 && S.lo >= 0 && S.hi <= 1) front[sgi] = 1;
+          else { need[sgi] = 1; work.push_back(sgi); }
+        }
+    }
+    // frontier functions -> mask bits
+    std::map<u64, u32> bit_of;
+    for (u32 g = 0; g < n; ++g) if (front[g] && !bit_of.count(sig[g])) { const u32 b = (u32)bit_of.size(); bit_of[sig[g]] = b; }
+    net.mask_words = (u32)((bit_of.size() + ZKC_MASK_BITS - 1) / ZKC_MASK_BITS);
+    net.mask_tab.assign((size_t)256 * net.mask_words, 0);
+    for (u32 g = 0; g < n; ++g) {
+      if (!front[g]) continue;
+      const u32 b = bit_of[sig[g]];
+      g_front[g] = (int)b;
+      ++net.n_frontier;
+    }
+    for (auto& kv : bit_of) {
+      // a representative of the signature
+      u32 rep = 0;
+      while (!(front[rep] && sig[rep] == kv.first)) ++rep;
+      const std::vector<u32>& w = table(rep);
+      for (u32 v = 0; v < 256; ++v) if (w[v] & 1u) net.mask_tab[(size_t)v * net.mask_words + kv.second / ZKC_MASK_BITS] |= 1u << (kv.second % ZKC_MASK_BITS);
+    }
+    // local gates that are neither needed nor frontier: not evaluated; the kept ones get a function table
+    std::map<u64, u32> fn_of;
+    for (u32 g = 0; g < n; ++g) {
+      if (!local[g] || need[g]) continue;
+      if (!front[g]) { g_skip[g] = 1; ++net.n_local; }
+      const Gate& G = gates[g];
+      if (G.slot >= net.n_kept || front[g]) continue;     // (a frontier gate still writes its word to the image)
+      auto it = fn_of.find(sig[g]);
+      if (it == fn_of.end()) {
+        const std::vector<u32>& w = table(g);
+        it = fn_of.emplace(sig[g], (u32)(net.fn_tab.size() / 256)).first;
+        net.fn_tab.insert(net.fn_tab.end(), w.begin(), w.end());
+      }
+      if (it->second >= 0x7fffu || sup[g] >= 0x10000) fail("too many distinct byte-local functions in the regex template");
+      net.slot_desc[G.slot] = 0x80000000u | (it->second << 16) | (u32)sup[g];
+    }
+    if (getenv("ZKWG_DEBUG_NET"))
+      fprintf(stderr, "[zkwg] byte-local gates: %u of %u leave the evaluator (%zu function tables), %u served from %u mask word(s) per byte (%zu frontier functions)\n",
+              net.n_local, n, net.fn_tab.size() / 256, net.n_frontier, net.mask_words, bit_of.size());
+  }
+
   // Evaluation schedule.  Gates are list-scheduled into chunks of mutually independent gates inside a sliding
   // window (so the comparators of the next message byte fill the chunks of the current byte's state recurrence);
   // a chunk is executed in steps of up to 64 gates, one per lane.  Where an operand lives is decided here, by
@@ -1379,18 +1522,21 @@ struct Elab {
     // list scheduling straight into steps of <= 64 gates: a gate goes to the earliest open step after all its operands
     // that still has a free lane; `window` + 1 steps stay open, older ones are closed in order
     const u32 window = 12;
+    const u32 step_lanes = getenv("ZKWG_NET_LANES") ? (u32)atoi(getenv("ZKWG_NET_LANES")) : 64u;
     std::deque<std::vector<u32>> open;
     u32 base = 1;
     std::vector<u32> outs;
     for (u32 gi = 0; gi < gates.size(); ++gi) {
       const Gate& g = gates[gi];
       if (g.op == G_OUT) { outs.push_back(gi); continue; }   // the outputs go last, 64 per step (they take the 64-bit path)
+      if (g_skip[gi]) continue;                              // byte-local: not evaluated per email (localize)
       u32 c = base;
-      for (int i = 0; i < nforms(g); ++i)
-        for (auto& t : g.f[i].t) if (!(t.first & SRC_INPUT)) c = std::max(c, chunk_of[t.first] + 1);
+      if (g_front[gi] < 0)                                   // (a frontier gate only reads its byte's mask word)
+        for (int i = 0; i < nforms(g); ++i)
+          for (auto& t : g.f[i].t) if (!(t.first & SRC_INPUT)) c = std::max(c, chunk_of[t.first] + 1);
       for (;;) {
         while (c >= base + open.size()) open.emplace_back();
-        if (open[c - base].size() < 64) break;
+        if (open[c - base].size() < step_lanes) break;
         ++c;
       }
       chunk_of[gi] = c;
@@ -1398,7 +1544,7 @@ struct Elab {
       while (open.size() > window + 1) { steps.push_back(std::move(open.front())); open.pop_front(); ++base; }
     }
     while (!open.empty()) { steps.push_back(std::move(open.front())); open.pop_front(); }
-    for (size_t b = 0; b < outs.size(); b += 64) steps.emplace_back(outs.begin() + b, outs.begin() + std::min(outs.size(), b + 64));
+    for (size_t b = 0; b < outs.size(); b += step_lanes) steps.emplace_back(outs.begin() + b, outs.begin() + std::min(outs.size(), b + step_lanes));
     {
       std::vector<std::vector<u32>> nonempty;
       for (auto& st : steps) if (!st.empty()) nonempty.push_back(std::move(st));
@@ -1414,6 +1560,7 @@ struct Elab {
     for (u32 t = 0; t < steps.size(); ++t)
       for (u32 gi : steps[t]) {
         const Gate& g = gates[gi];
+        if (g_front[gi] >= 0) continue;
         for (int i = 0; i < nforms(g); ++i)
           for (auto& tm : g.f[i].t) if (!(tm.first & SRC_INPUT)) { used[tm.first] = 1; last_use[tm.first] = std::max(last_use[tm.first], t); }
       }
@@ -1432,10 +1579,11 @@ struct Elab {
         std::push_heap(live.begin(), live.end(), cmp);
       }
     }
-    // LDS words: [values | message bytes | 0 | scratch]
+    // LDS words: [values | message bytes | 0 | scratch | masks: mask_words per message byte]
     const u32 lds_msg = hwm, lds_zero = lds_msg + n_in, lds_dummy = lds_zero + 1;
     net.n_pins = hwm;
-    net.lds_words = lds_dummy + 1;
+    net.lds_masks = lds_dummy + 1;
+    net.lds_words = net.lds_masks + n_in * net.mask_words;
     if (net.lds_words > 16000) fail("the template keeps " + std::to_string(hwm) + " values alive at once; the evaluator's LDS image would exceed 64 KiB");
     // records
     net.records.clear(); net.step_count.clear();
@@ -1443,6 +1591,21 @@ struct Elab {
     for (auto& st : steps) {
       u32 general = 0, half = 0x4000;
       for (u32 gi : st) {
+        if (g_front[gi] >= 0) {
+          // frontier gate: bit (index % ZKC_MASK_BITS) of mask word (index / ZKC_MASK_BITS) of its byte, as a BIT record
+          const Gate& g = gates[gi];
+          const long long byte = g_sup[gi];
+          if (byte < 0) fail("internal: frontier gate without a message byte");
+          const u32 b = (u32)g_front[gi], wordi = net.lds_masks + (u32)byte * net.mask_words + b / ZKC_MASK_BITS;
+          u32 r[16] = {0};
+          r[0] = G_BIT | ((b % ZKC_MASK_BITS) << 4);
+          r[1] = g.slot;
+          r[3] = word_of[gi] == 0xffffffffu ? lds_dummy : word_of[gi];
+          for (u32 q = 0; q < 8; ++q) r[8 + q] = (lds_zero << 2);
+          r[8] = (wordi << 2) | (1u << 18);
+          net.records.insert(net.records.end(), r, r + 16);
+          continue;
+        }
         const Gate& g = gates[gi];
         const int nf = nforms(g);
         bool wide = false;

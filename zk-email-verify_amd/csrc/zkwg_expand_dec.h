@@ -30,7 +30,10 @@ struct ZkCtx {
   const u64* __restrict__ bits;
   const u32* __restrict__ small;
   int half;           // inverse table covers [-half, half]
-  u32 m_dfa_cm, m_dfa_pm;
+  u32 m_dfa_cm, m_dfa_pm, m_dfa_st;   // small[] offsets of the DFA class masks, primitive masks and per-position words
+  const u32* __restrict__ net_desc;   // loaded regex template: per kept slot 0 = the evaluator's word in the image, else 0x80000000 | fn << 16 | byte index
+  const u32* __restrict__ net_fn;     // ... byte-local function tables (256 stored words each)
+  u32 hdr_off;                        // record offset of the header bytes (the regex's message)
 };
 
 ZK_DEC __forceinline__ u32 zk_udiv(u32 r, u32 d, u32 magic) { return magic ? (u32)(((u64)r * magic) >> 32) : r / d; }
@@ -185,40 +188,54 @@ struct ZkDecB64 {
 // BodyHashRegex DFA circuit arrays (zkwg_layout.h zk_walk_bh_regex): one entry per position i of
 // in[] = [255, header...].  zk_misc_ev left one word per position: in | st<<8 | nx<<16 | st_next<<24
 // (nx = the transition out of a non-zero state, 255 = none) plus the class / primitive truth masks.
+// value of a DFA-array element (kind, sub-slot q) from the position word w0 (of position i, i + 1 for ZDFA_SUB) and
+// the position's mask word mw (primitive masks for ZDFA_CLS, class masks for ZDFA_AND; unused otherwise)
+ZK_DEC __forceinline__ u32 zk_dfa_value_w(u32 kind, u32 q, u32 pb, u32 pc, u32 w0, u32 mw, int half) {
+  const u32 b = w0 & 255u, st = (w0 >> 8) & 255u, nx = (w0 >> 16) & 255u, sn = w0 >> 24;
+  switch (kind) {
+    case ZDFA_EQ: {
+      const int d = (int)pb - (int)b;          // isz.in = in[1] - in[0] = ch - in[i]
+      return q ? zk_inv_code(d, half) : (u32)(d == 0);
+    }
+    case ZDFA_LT: return ((pc ? pb + b : pb - b) >> q) & 1u;
+    case ZDFA_RNG: return (u32)(b >= pb && b <= pc);
+    case ZDFA_CLS: return (u32)(q == 0) ^ (u32)(__builtin_popcount(mw & pc) != 0);
+    case ZDFA_AND: return (u32)(pb ? (st == pb) : (nx == 255u)) & ((mw >> pc) & 1u);
+    case ZDFA_TMP: return (u32)(q == 0) ^ (u32)(nx == pb);
+    case ZDFA_FZE: return (u32)(q == 0) ^ (u32)(nx != 255u);
+    case ZDFA_ST: return (u32)(q == 0) ^ (u32)(sn == pb);
+    case ZDFA_SUB: {
+      // message index i: transition st[i+1] -> st[i+2] = (st, sn) of word i+1
+      const u32 key = st | (sn << 8);
+      bool hit = false;
+#pragma unroll
+      for (u32 k = 0; k < ZK_DFA_NPUBLIC; ++k) hit = hit || key == (ZK_DFA_PUBLIC[k][0] | ((u32)ZK_DFA_PUBLIC[k][1] << 8));
+      return (u32)(q == 0) ^ (u32)hit;
+    }
+    default: return 0u;
+  }
+}
+ZK_DEC __forceinline__ u32 zk_dfa_value(u32 kind, u32 i, u32 q, u32 pb, u32 pc, const u32* __restrict__ pos, const u32* __restrict__ cmask,
+                                        const u32* __restrict__ pmask, int half) {
+  const u32 w0 = pos[i + (kind == ZDFA_SUB ? 1u : 0u)];
+  const u32 mw = kind == ZDFA_CLS ? pmask[i] : (kind == ZDFA_AND ? cmask[i] : 0u);
+  return zk_dfa_value_w(kind, q, pb, pc, w0, mw, half);
+}
+// (position, sub-slot) of element r of a DFA array of the given kind
+ZK_DEC __forceinline__ void zk_dfa_index(u32 kind, u32 r, u32& i, u32& q) {
+  if (kind == ZDFA_LT) { i = r / 9u; q = r - i * 9u; }
+  else if (kind == ZDFA_RNG || kind == ZDFA_AND) { i = r; q = 0; }
+  else { i = r >> 1; q = r & 1u; }
+}
 struct ZkDecDfa {
   const u32* __restrict__ pos; const u32* __restrict__ cmask; const u32* __restrict__ pmask;
   u32 kind, pb, pc; int half;
   ZK_DEC ZkDecDfa(const ZkSeg& sg, const ZkCtx& cx)
       : pos(cx.small + sg.src), cmask(cx.small + cx.m_dfa_cm), pmask(cx.small + cx.m_dfa_pm), kind(sg.a), pb(sg.b), pc(sg.c), half(cx.half) {}
   ZK_DEC u32 operator()(u32 r) const {
-    if (kind == ZDFA_EQ) {
-      const int d = (int)pb - (int)(pos[r >> 1] & 255u);          // isz.in = in[1] - in[0] = ch - in[i]
-      return (r & 1u) ? zk_inv_code(d, half) : (u32)(d == 0);
-    }
-    u32 i, q, off = 0;
-    if (kind == ZDFA_LT) { i = r / 9u; q = r - i * 9u; }
-    else if (kind == ZDFA_RNG || kind == ZDFA_AND) { i = r; q = 0; }
-    else { i = r >> 1; q = r & 1u; if (kind == ZDFA_SUB) off = 1; }
-    const u32 w0 = pos[i + off];
-    const u32 b = w0 & 255u, st = (w0 >> 8) & 255u, nx = (w0 >> 16) & 255u, sn = w0 >> 24;
-    switch (kind) {
-      case ZDFA_LT: return ((pc ? pb + b : pb - b) >> q) & 1u;
-      case ZDFA_RNG: return (u32)(b >= pb && b <= pc);
-      case ZDFA_CLS: return (u32)(q == 0) ^ (u32)(__builtin_popcount(pmask[i] & pc) != 0);
-      case ZDFA_AND: return (u32)(pb ? (st == pb) : (nx == 255u)) & ((cmask[i] >> pc) & 1u);
-      case ZDFA_TMP: return (u32)(q == 0) ^ (u32)(nx == pb);
-      case ZDFA_FZE: return (u32)(q == 0) ^ (u32)(nx != 255u);
-      case ZDFA_ST: return (u32)(q == 0) ^ (u32)(sn == pb);
-      case ZDFA_SUB: {
-        // message index i: transition st[i+1] -> st[i+2] = (st, sn) of word i+1
-        const u32 key = st | (sn << 8);
-        bool hit = false;
-#pragma unroll
-        for (u32 k = 0; k < ZK_DFA_NPUBLIC; ++k) hit = hit || key == (ZK_DFA_PUBLIC[k][0] | ((u32)ZK_DFA_PUBLIC[k][1] << 8));
-        return (u32)(q == 0) ^ (u32)hit;
-      }
-      default: return 0u;
-    }
+    u32 i, q;
+    zk_dfa_index(kind, r, i, q);
+    return zk_dfa_value(kind, i, q, pb, pc, pos, cmask, pmask, half);
   }
 };
 // RemoveSoftLineBreaks arrays derived from the emailBody bytes alone
@@ -244,13 +261,16 @@ struct ZkDecRslb {
 // gate values of a loaded regex template (zkwg_net_core.h): 31-bit signed integer, or the inverse
 // of one (bit 31) from the table; a negative integer -m is the field element r - m
 struct ZkDecNet {
-  const u32* __restrict__ p; u32 base; int half;
-  ZK_DEC ZkDecNet(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), base(sg.src), half(cx.half) {}
+  const u32* __restrict__ p; const u32* __restrict__ desc; const u32* __restrict__ fn; const u8* __restrict__ msg; u32 base; int half;
+  ZK_DEC ZkDecNet(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), desc(cx.net_desc), fn(cx.net_fn), msg(cx.rec + cx.hdr_off), base(sg.src), half(cx.half) {}
   ZK_DEC u32 operator()(u32 r) const {
-    const u32 w = p[base + r];
-    const int d = (int)(w << 1) >> 1;
-    if (w & 0x80000000u) return zk_inv_code(d, half);
-    return d >= 0 ? (u32)d : (ZK_REF_NEG | (base + r));
+    // a byte-local signal (a function of one message byte: the comparators of the regex circuit) comes from its
+    // function table, everything else from the word the evaluator left in the image
+    const u32 d = desc[r];
+    const u32 w = (d >> 31) ? fn[((d >> 16) & 0x7fffu) * 256u + msg[d & 0xffffu]] : p[base + r];
+    const int v = (int)(w << 1) >> 1;
+    if (w & 0x80000000u) return zk_inv_code(v, half);
+    return v >= 0 ? (u32)v : (ZK_REF_NEG | (base + r));   // (negative values only come from the image: localize keeps them there)
   }
 };
 

@@ -6,13 +6,6 @@
 
 __global__ void zk_sha_chain(ZkSched s, ZkBufs B);   // zkwg_kernels_sha.hip
 __global__ void zk_sha_trace(ZkSched s, ZkBufs B);   // zkwg_kernels_sha.hip
-__global__ void zk_expand_256(ZkSched s, ZkBufs B);  // zkwg_kernels_expand.hip
-__global__ void zk_expand_512(ZkSched s, ZkBufs B);
-__global__ void zk_expand_1024(ZkSched s, ZkBufs B);
-__global__ void zk_expand_wave(ZkSched s, ZkBufs B);
-__global__ void zk_expand_mont_256(ZkSched s, ZkBufs B);  // fused standard -> Montgomery output
-__global__ void zk_expand2(ZkSched s, ZkBufs B);       // zkwg_kernels_expand2.hip (LDS-staged, 64 KiB portions)
-__global__ void zk_expand2_mont(ZkSched s, ZkBufs B);
 __global__ void zk_rsa(ZkSched s, ZkBufs B);         // zkwg_kernels_rsa.hip
 __global__ void zk_poseidon9(ZkSched s, ZkBufs B);   // zkwg_kernels_rsa.hip
 __global__ void zk_poseidon9_wave(ZkSched s, ZkBufs B);

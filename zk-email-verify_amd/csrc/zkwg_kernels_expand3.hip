@@ -73,7 +73,8 @@ __device__ __forceinline__ ZkCtx zk_x3_ctx(const ZkX3& A, u32 e) {
   cx.bits = A.bits + (u64)e * A.img_bits;
   cx.small = A.small + (u64)e * A.img_small;
   cx.half = (int)A.inv_half;
-  cx.m_dfa_cm = A.m_dfa_cm; cx.m_dfa_pm = A.m_dfa_pm;
+  cx.m_dfa_cm = A.m_dfa_cm; cx.m_dfa_pm = A.m_dfa_pm; cx.m_dfa_st = A.m_dfa_st;
+  cx.net_desc = A.net_desc; cx.net_fn = A.net_fn; cx.hdr_off = A.hdr_off;
   return cx;
 }
 // store side: wavefront w owns the 64 K consecutive slots [64 K w, 64 K (w + 1)) of the piece (K = slots per lane);
@@ -170,25 +171,43 @@ __device__ __forceinline__ u32 zk_desc_decode(u32 a, u32 b, const ZkCtx& cx, con
     case ZK_D_BYTE: return cx.rec[b];
     case ZK_D_SMALLRAW: return zk_raw_code(cx.small[b], b);
     case ZK_D_SMALLS: { const u32 lo = cx.small[b], hi = cx.small[b + 1]; return (hi == 0u && !(lo >> 31)) ? lo : (ZK_REF_I64 | b); }
+    case ZK_D_DFA: return zk_dfa_value((a >> 24) & 15u, (a >> 9) & 0x7ffu, (a >> 20) & 15u, a & 511u, b, cx.small + cx.m_dfa_st, cx.small + cx.m_dfa_cm, cx.small + cx.m_dfa_pm, cx.half);
     default: return zk_decode_generic(segs + (a & 0xffffffu), b, cx);
   }
 }
-// descriptors of kind GENERIC (the comparator / selector / regex regions: ~10 % of the wires of EmailVerifier, in
-// contiguous stretches): decoded by their segment's own arithmetic.  Lanes are binned by segment: the wavefront takes
-// the segment of its first pending lane, loads it once (uniform) and every lane of that segment decodes with the type
-// switch taken uniformly -- instead of one out-of-line call per lane with a per-lane segment fetch.
-__device__ __forceinline__ u32 zk_generic_binned(uint2 d, u32 code, const ZkCtx& cx, const ZkSeg* __restrict__ segs) {
-  const bool gen = (d.x >> 28) == ZK_D_GENERIC;
-  u64 pending = __builtin_amdgcn_ballot_w64(gen);
-  while (pending) {
-    const int leader = __builtin_ctzll(pending);
-    const u32 si = (u32)__builtin_amdgcn_readlane((int)(d.x & 0xffffffu), leader);
-    const ZkSeg sg = segs[si];
-    const bool mine = gen && (d.x & 0xffffffu) == si;
-    if (mine) code = zk_decode_any(sg, d.y, cx);
-    pending &= ~__builtin_amdgcn_ballot_w64(mine);
+// What a descriptor reads, resolved once per workgroup: one 64-bit word of `bits`, one byte of the record, two words of
+// `small` (index 0 of each array when the kind does not use it).  Per email the lane then issues all its loads back to
+// back -- nothing between them depends on a loaded value -- and only afterwards turns them into codes.
+struct ZkO0Pre { u32 i64, i8, i32, i32b; };
+__device__ __forceinline__ ZkO0Pre zk_o0_pre(uint2 d, const ZkX3& A) {
+  ZkO0Pre p{0u, 0u, 0u, 0u};
+  switch (d.x >> 28) {
+    case ZK_D_BIT64: p.i64 = d.y; break;
+    case ZK_D_BIT8: case ZK_D_BYTE: p.i8 = d.y; break;
+    case ZK_D_SMALLRAW: p.i32 = d.y; break;
+    case ZK_D_SMALLS: p.i32 = d.y; p.i32b = d.y + 1u; break;
+    case ZK_D_DFA: {
+      const u32 dk = (d.x >> 24) & 15u, i = (d.x >> 9) & 0x7ffu;
+      p.i32 = A.m_dfa_st + i + (dk == ZDFA_SUB ? 1u : 0u);
+      p.i32b = dk == ZDFA_CLS ? A.m_dfa_pm + i : (dk == ZDFA_AND ? A.m_dfa_cm + i : 0u);
+      break;
+    }
+    default: break;
   }
-  return code;
+  return p;
+}
+__device__ __forceinline__ u32 zk_o0_combine(uint2 d, const ZkO0Pre& p, u64 w64, u32 w8, u32 w32, u32 w32b, int half) {
+  const u32 a = d.x, b = d.y;
+  switch (a >> 28) {
+    case ZK_D_IMM: return b;
+    case ZK_D_BIT64: return (u32)(w64 >> (a & 63u)) & 1u;
+    case ZK_D_BIT8: return (w8 >> (a & 7u)) & 1u;
+    case ZK_D_BYTE: return w8;
+    case ZK_D_SMALLRAW: return zk_raw_code(w32, b);
+    case ZK_D_SMALLS: return (w32b == 0u && !(w32 >> 31)) ? w32 : (ZK_REF_I64 | b);
+    case ZK_D_DFA: return zk_dfa_value_w((a >> 24) & 15u, (a >> 20) & 15u, a & 511u, b, w32, w32b, half);
+    default: return 0u;   // ZK_D_GENERIC: second pass
+  }
 }
 template <bool MONT, int K>
 __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev& O) {
@@ -201,11 +220,13 @@ __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev&
   // the descriptors of this thread's K wires: loaded once, reused for every email of the group (8 bytes per wire
   // against 32 bytes written per wire and email)
   uint2 d[K];
+  ZkO0Pre pre[K];
   bool any_generic = false;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const u32 i = 64u * K * wv + 64u * k + lane;
     d[k] = i < nsl ? O.desc[slot0 + i] : make_uint2(0u, 0u);
+    pre[k] = zk_o0_pre(d[k], A);
     any_generic = any_generic || (d[k].x >> 28) == ZK_D_GENERIC;
   }
   const bool wave_generic = __builtin_amdgcn_ballot_w64(any_generic) != 0ull;
@@ -213,19 +234,17 @@ __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev&
   for (u32 el = g * O.emails_per_wg; el < el1; ++el) {
     const u32 e = el + A.e_first;
     const ZkCtx cx = zk_x3_ctx(A, e);
+    u64 w64[K]; u32 w8[K], w32[K], w32b[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { w64[k] = cx.bits[pre[k].i64]; w8[k] = cx.rec[pre[k].i8]; w32[k] = cx.small[pre[k].i32]; w32b[k] = cx.small[pre[k].i32b]; }
     u32 code[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) code[k] = (d[k].x >> 28) == ZK_D_GENERIC ? 0u : zk_desc_decode(d[k].x, d[k].y, cx, A.segs);
+    for (int k = 0; k < K; ++k) code[k] = zk_o0_combine(d[k], pre[k], w64[k], w8[k], w32[k], w32b[k], cx.half);
     if (wave_generic) {
-      // one copy of the binned decode: the K (descriptor, code) pairs rotate through position 0
-#pragma unroll 1
-      for (int it = 0; it < K; ++it) {
-        code[0] = zk_generic_binned(d[0], code[0], cx, A.segs);
-        const uint2 d0 = d[0]; const u32 c0 = code[0];
+      // the few wires decoded by their segment's own arithmetic (selectors, comparators: ~1.5 % of EmailVerifier's)
 #pragma unroll
-        for (int k = 0; k + 1 < K; ++k) { d[k] = d[k + 1]; code[k] = code[k + 1]; }
-        d[K - 1] = d0; code[K - 1] = c0;
-      }
+      for (int k = 0; k < K; ++k)
+        if ((d[k].x >> 28) == ZK_D_GENERIC) code[k] = zk_decode_generic(A.segs + (d[k].x & 0xffffffu), d[k].y, cx);
     }
     zk_x3_store<MONT, K>(A, cx, e, el, slot0, nsl, code);
   }

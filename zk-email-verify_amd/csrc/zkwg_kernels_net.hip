@@ -20,10 +20,17 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   const u32 lane = threadIdx.x;
   extern __shared__ u32 dyn_lds[];
   int* lds = (int*)dyn_lds;
-  const u32 msg_base = s.net_pins;     // [gate values | message bytes | 0 | scratch]
+  const u32 msg_base = s.net_pins;     // [gate values | message bytes | 0 | scratch | masks]
   const u32 N = s.fr[0].max_bytes;
   const u8* rec = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
-  for (u32 i = lane; i < N; i += 64) lds[msg_base + i] = (int)rec[i];
+  // message bytes, and per byte its mask words: the truth of every byte-local boolean a per-email gate reads
+  // (zkwg_circom.h localize), one table lookup per byte and word
+  const u32 MW = s.net_mask_words;
+  for (u32 i = lane; i < N; i += 64) {
+    const u32 b = rec[i];
+    lds[msg_base + i] = (int)b;
+    for (u32 m = 0; m < MW; ++m) lds[s.net_lds_masks + i * MW + m] = (int)B.net_mask_tab[b * MW + m];
+  }
   if (lane == 0) lds[msg_base + N] = 0;
   const u32 scratch = msg_base + N + 1u;
   __syncthreads();

@@ -26,7 +26,8 @@ enum ZkDescKind : u32 {
   ZK_D_BYTE = 3,      // rec[b]
   ZK_D_SMALLRAW = 4,  // small[b], raw 32-bit value
   ZK_D_SMALLS = 5,    // (small[b], small[b+1]) as a signed 64-bit integer v (results of small rows): 0 <= v < 2^31 -> v, else the field element v mod r
-  ZK_D_GENERIC = 6    // slot b of kept-v1 segment (a & 0xffffff): decoded by the segment's own arithmetic
+  ZK_D_GENERIC = 6,   // slot b of kept-v1 segment (a & 0xffffff): decoded by the segment's own arithmetic
+  ZK_D_DFA = 7        // BodyHashRegex DFA array element: a = kind << 28 | ZkDfaKind << 24 | q << 20 | position << 9 | param b, b = param c
 };
 
 #if !defined(ZKWG_O0_DEVICE_ONLY)
@@ -94,6 +95,14 @@ static inline void zk_o0_slot_desc(const std::vector<ZkSeg>& segs, u64 slot, u32
     case ZSEG_SMALL: out[0] = ZK_D_SMALLRAW << 28; out[1] = g.src + r; return;
     case ZSEG_FR: out[0] = ZK_D_IMM << 28; out[1] = 0x80000000u | (0u << 28) | (g.src + r); return;          // ZK_REF_FRV
     case ZSEG_LIMB: out[0] = ZK_D_IMM << 28; out[1] = 0x80000000u | (2u << 28) | (g.src + 16u * r); return;  // ZK_REF_LIMB
+    case ZSEG_DFA: {
+      // the bulk of the non-bit wires of EmailVerifier: pre-resolved so that zk_expand3_o0 decodes them in line
+      const u32 kind = g.a;
+      u32 i, q;
+      if (kind == ZDFA_LT) { i = r / 9u; q = r % 9u; } else if (kind == ZDFA_RNG || kind == ZDFA_AND) { i = r; q = 0; } else { i = r >> 1; q = r & 1u; }
+      if (i < 2048u && g.b < 512u && kind < 16u) { out[0] = (ZK_D_DFA << 28) | (kind << 24) | (q << 20) | (i << 9) | g.b; out[1] = g.c; return; }
+      out[0] = (ZK_D_GENERIC << 28) | (u32)lo; out[1] = r; return;
+    }
     default: out[0] = (ZK_D_GENERIC << 28) | (u32)lo; out[1] = r; return;
   }
 }
@@ -102,6 +111,7 @@ static inline bool zk_o0_desc_immediate(const u32 d[2], const std::vector<ZkSeg>
     case ZK_D_IMM: return !(d[1] >> 31);
     case ZK_D_BIT64: case ZK_D_BIT8: case ZK_D_BYTE: return true;
     case ZK_D_GENERIC: return zk_seg_is_immediate(segs[d[0] & 0xffffffu]);
+    case ZK_D_DFA: return ((d[0] >> 24) & 15u) != ZDFA_EQ;
     default: return false;
   }
 }
@@ -188,6 +198,14 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
   }
   T.s_group.push_back((u32)T.n_small());
   T.f_group.push_back((u32)T.n_fr());
+  if (getenv("ZKWG_DEBUG_PLAN")) {
+    u64 kinds[8] = {0}, by_type[ZSEG_NTYPES + 1] = {0};
+    for (u64 w = 0; w < W; ++w) { const u32 k = T.desc[2 * w] >> 28; ++kinds[k & 7]; if (k == ZK_D_GENERIC) ++by_type[segs[T.desc[2 * w] & 0xffffffu].type]; }
+    fprintf(stderr, "[zkwg] O0 descriptors: imm %llu bit64 %llu bit8 %llu byte %llu smallraw %llu smalls %llu dfa %llu generic %llu; generic by segment type:",
+            (unsigned long long)kinds[0], (unsigned long long)kinds[1], (unsigned long long)kinds[2], (unsigned long long)kinds[3], (unsigned long long)kinds[4], (unsigned long long)kinds[5], (unsigned long long)kinds[7], (unsigned long long)kinds[6]);
+    for (u32 t = 0; t <= ZSEG_NTYPES; ++t) if (by_type[t]) fprintf(stderr, " %u:%llu", t, (unsigned long long)by_type[t]);
+    fprintf(stderr, "\n");
+  }
   if ((u64)T.small_base + 2 * T.n_small() >= (1u << 28) || (u64)T.fr_base + T.n_fr() >= (1u << 28)) { err = "circuit too large for the O0 row tables"; return false; }
   s.img_small = (u32)((T.small_base + 2 * T.n_small() + 3u) & ~3ull);
   s.img_fr = (u32)(T.fr_base + T.n_fr());

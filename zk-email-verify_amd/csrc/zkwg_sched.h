@@ -116,7 +116,6 @@ struct ZkPortionEntry {
   u32 r_start;
   u32 first_seg;
 };
-#define ZK_PORTION_DEFAULT 2048u  // witness slots expanded by one workgroup of zk_expand
 
 struct ZkShaFrame {      // one Sha256Bytes / Sha256BytesPartial instance
   u32 max_bytes;         // maxByteLength
@@ -183,8 +182,6 @@ struct ZkSched {
   u32 in_off[13];        // enum zkwg_input_field -> byte offset (12 = ZK_IN_RANGE_FLAGS)
   u32 n_public;
   u32 nsegs;
-  u32 portion;           // witness slots expanded by one workgroup of zk_expand
-  u32 nportions;         // ceil(W / portion)
   u32 img_bits;          // u64 words per email
   u32 img_small;         // u32 words per email
   u32 img_fr;            // Fr elements per email
@@ -220,6 +217,8 @@ struct ZkSched {
   u32 net_steps;         // 64-record steps of the gate list
   u32 net_pins;          // zk_net_eval's LDS image: words holding gate values (then the message bytes, a zero, a scratch word)
   u32 net_lds_words;     // zk_net_eval's LDS image: total words
+  u32 net_lds_masks;     // zk_net_eval's LDS image: first word of the per-byte mask region (byte-local frontier bits, zkwg_circom.h localize)
+  u32 net_mask_words;    // mask words per message byte (0: none)
   // RemoveSoftLineBreaks(max_body) (template flag removeSoftLineBreaks, email-verifier.circom:148-156)
   u32 rslb;              // 1: present
   u32 rs_nch;            // 2 * max_body / 16 Poseidon(16) chunks of PoseidonModular(2 * max_body)
@@ -266,17 +265,17 @@ struct ZkBufs {
   const Fr* invtab_m;    // zk_expand_mont: the inverse table in Montgomery form
   const u32* net_records; // loaded regex template: 16 words per gate in execution order (zkwg_net_core.h)
   const u32* net_counts;  // loaded regex template: gates per step | flags (0x8000: 64-bit path)
+  const u32* net_mask_tab; // loaded regex template: 256 x net_mask_words frontier masks by byte value
+  const u32* net_fn;      // loaded regex template: byte-local function tables (256 stored words each)
+  const u32* net_desc;    // loaded regex template: per kept slot 0 (evaluated) or 0x80000000 | fn << 16 | byte index
   const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
   Fr* frm;               // Montgomery-form output: per email, Montgomery copies of its img_fr field elements, then of the record's ZK_MONT_LIMBS limbs
-  const u32* pflags;     // per portion: bit 0 = every slot is immediate-valued (no references, zkwg_expand_dec.h)
   const ZkSeg* segs;     // segment table
-  const u32* first_seg;  // first segment overlapping each portion
   uint4* wit;            // output witnesses
   u64 wit_stride16;      // distance between consecutive witnesses in 16-byte units (>= 2 W; a caller may pad it)
   int* status;           // per-email status
   u32 n_emails;          // emails covered by the image arrays / this launch
   u32 e_first;           // zk_expand: first email to expand (wit points at its witness)
-  u32 emails_per_wg;     // zk_expand: emails handled by one workgroup (same portion of each)
   u32 xcd_remap;         // zk_expand: 1 = workgroup -> unit mapping that gives each of the 8 XCDs one contiguous range
 };
 
@@ -287,8 +286,9 @@ struct ZkX3 {
   uint4* wit;
   const Fr* frm; const Fr* invtab_m; const Fr* rtab;   // Montgomery-form output only
   Fr* frm_w; u32* small_w; Fr* frv_w;                  // writable views (zk_image_to_mont, the O0 row kernels)
+  const u32* net_fn; const u32* net_desc;              // loaded regex template: byte-local function tables / per-slot descriptors
   u64 wit_stride16, W;
-  u32 in_stride, img_bits, img_small, img_fr, inv_half, m_dfa_cm, m_dfa_pm;
-  u32 nportions, nsegs, e_first, n_count, xcd_remap, limb_off;   // nportions: pieces per witness (of 256 K slots)
+  u32 in_stride, img_bits, img_small, img_fr, inv_half, m_dfa_cm, m_dfa_pm, m_dfa_st;
+  u32 nportions, nsegs, e_first, n_count, xcd_remap, limb_off, hdr_off;   // nportions: pieces per witness (of 256 K slots)
 };
 #endif

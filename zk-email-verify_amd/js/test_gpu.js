@@ -88,6 +88,12 @@ function shaPad(msg, max) {  // packages/helpers/src/sha-utils.ts:88-111
     const b3 = await evc.calculateBatch([kase.input, tampered, big, kase.input]);
     assert.deepStrictEqual(Array.from(b3.status), [0, 4, 4, 0]);
     assert.ok(Buffer.from(b3.wtns[0]).equals(Buffer.from(bin)) && Buffer.from(b3.wtns[3]).equals(Buffer.from(bin)));
+    // the same batch with the expansion on the host (zkwg_set_host_expand): identical bytes and statuses
+    ev.setHostExpand(4);
+    const b4 = await evc.calculateBatch([kase.input, tampered, big, kase.input]);
+    ev.setHostExpand(0);
+    assert.deepStrictEqual(Array.from(b4.status), [0, 4, 4, 0]);
+    assert.ok(Buffer.from(b4.wtns[0]).equals(Buffer.from(bin)) && Buffer.from(b4.wtns[3]).equals(Buffer.from(bin)));
     // wtnsFromBin (JS-side container) == the C ABI's zkwg_write_wtns
     assert.ok(ev.wtnsFromBin(Buffer.from(bin)).equals(Buffer.from(wt)));
     // the documented CLI (docs/zk-email-docs/UsageGuide/README.md:132-140): node generate_witness.js <circuit> input.json witness.wtns

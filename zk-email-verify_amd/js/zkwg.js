@@ -37,6 +37,11 @@ class Circuit {
     Object.assign(this, addon.info(this.handle));
   }
 
+  /** threads > 0: batches delivered to host memory are expanded BY the host from the 0.45 MB image each email's compute
+   *  kernels leave (zkwg_set_host_expand) -- what a host-side snarkjs prover (chunked-zkey.ts:80-84) consumes, without
+   *  pushing 56.9 MB per email through PCIe; 0 (default): expanded on the device, then copied */
+  setHostExpand(threads) { addon.setHostExpand(this.handle, threads | 0); }
+
   /** 32-byte-per-signal witness -> `.wtns` file bytes (snarkjs wtns v2: header section with n8 = 32, the prime, the
    *  witness length; then the values, little-endian, non-Montgomery) */
   wtnsFromBin(bin) {

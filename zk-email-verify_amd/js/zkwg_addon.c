@@ -339,6 +339,20 @@ static napi_value PackField(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+// setHostExpand(circuit, threads): threads > 0 -> calculateBatch expands the witnesses on the host from the downloaded
+// image (zkwg_set_host_expand: 0.45 MB per email over PCIe instead of 56.9 MB); 0 -> on the device (default)
+static napi_value SetHostExpand(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkwg_circuit_t* c = unwrap(env, argv[0]);
+  if (!c) return NULL;
+  int32_t threads = 0;
+  NAPI_OK(napi_get_value_int32(env, argv[1], &threads));
+  int rc = zkwg_set_host_expand(c, threads);
+  if (rc != ZKWG_RC_OK) { napi_throw_error(env, NULL, zkwg_strerror(rc)); return NULL; }
+  return NULL;
+}
+
 static napi_value StrError(napi_env env, napi_callback_info info) {
   size_t argc = 1; napi_value argv[1]; int32_t code = 0; napi_value s;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -419,6 +433,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"witnessToBigInts", NULL, WitnessToBigInts, NULL, NULL, NULL, napi_default, NULL},
       {"strerror", NULL, StrError, NULL, NULL, NULL, napi_default, NULL},
       {"packField", NULL, PackField, NULL, NULL, NULL, napi_default, NULL},
+      {"setHostExpand", NULL, SetHostExpand, NULL, NULL, NULL, napi_default, NULL},
       {"createMulti", NULL, CreateMulti, NULL, NULL, NULL, napi_default, NULL},
       {"calculateBatchMulti", NULL, CalculateBatchMulti, NULL, NULL, NULL, napi_default, NULL},
       {"multiDevices", NULL, MultiCircuit0, NULL, NULL, NULL, napi_default, NULL},
