@@ -19,6 +19,21 @@ class Seg(C.Structure):
                 ("r0", C.c_uint32), ("pad", C.c_uint32)]
 
 
+_WSO = os.path.join(ROOT, "tests", "native", "libzkwg_wavetest.so")
+
+
+def load_wave():
+    """tests/native/wavetest.cpp: csrc/zkwg_rsa_wave.h -- the RSA path the device runs -- on a 64-fiber wavefront (wavesim.h)"""
+    src = [os.path.join(ROOT, "tests", "native", f) for f in ("wavetest.cpp", "wavesim.h")]
+    deps = src + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
+    if not os.path.exists(_WSO) or any(os.path.getmtime(d) > os.path.getmtime(_WSO) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", _CSRC, "-I", os.path.join(ROOT, "tests", "native"), src[0], "-o", _WSO])
+    lib = C.CDLL(_WSO)
+    lib.wt_run_rsa.restype = C.c_int
+    lib.wt_run_rsa.argtypes = [C.c_void_p] * 6 + [C.POINTER(C.c_uint64)]
+    return lib
+
+
 def load():
     deps = [_SRC] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
     if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):

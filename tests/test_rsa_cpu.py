@@ -18,7 +18,9 @@ KAT_PUB = 1067736870781090075950283660849703221479070866351760679181616367563547
 KAT_MSG = [1156466847851242602709362303526378170, 191372789510123109308037416804949834, 7204] + [0] * 14
 
 
-def run_host_rsa(message, sig, mod):
+def run_host_rsa(message, sig, mod, wave=False):
+    """wave=False: zkwg_rsa_core.h, the phase-sequential restatement; wave=True: zkwg_rsa_wave.h, the algorithm the device
+    runs (ballot look-ahead, shuffles, lane-parallel Knuth D, safegcd), on the 64-fiber wavefront of tests/native/wavesim.h"""
     lib = hosttest.load()
     cfg = Config(MAIN_RSA_VERIFIER, 0, 0, 121, 17, 0, 0, 0, 0, 0)
     h = lib.ht_create(C.byref(cfg))
@@ -35,7 +37,12 @@ def run_host_rsa(message, sig, mod):
     small = (C.c_uint32 * lib.ht_img_small(h))()
     frv = (C.c_uint8 * (32 * lib.ht_img_fr(h)))()
     small[lib.ht_m_one(h)] = 1
-    ok = lib.ht_run_rsa(h, rec, None, bits, small, frv)
+    if wave:
+        n = C.c_uint64()
+        ok = hosttest.load_wave().wt_run_rsa(C.byref(cfg), rec, None, bits, small, frv, C.byref(n))
+        assert 1000 < n.value < 10_000_000      # it really went through the cross-lane exchanges
+    else:
+        ok = lib.ht_run_rsa(h, rec, None, bits, small, frv)
     wit = hosttest.expand(lib, h, rec, bits, small, frv)
     lib.ht_destroy(h)
     return ok, wit
@@ -89,3 +96,27 @@ def test_safegcd_inverse_matches_fermat():
         o = (C.c_uint8 * 32)()
         lib.ht_fr_inv_by(a, o)
         assert int.from_bytes(bytes(o), "little") == (pow(x, P - 2, P) if x else 0), x
+
+
+def test_device_rsa_algorithm_on_a_simulated_wavefront_matches_oracle():
+    """csrc/zkwg_rsa_wave.h -- what zk_rsa runs on the GPU, not the phase-sequential restatement -- compiled for the host on
+    a 64-fiber wavefront (tests/native/wavesim.h: ballots, readlane, shuffles as exchange points): the reference's 1,024-bit
+    KAT (packages/circuits/tests/rsa.test.ts:64-103; exercises long_div's k-- path and RSAPad's leading zeros), its
+    wrong-message negative (:105-144) and a 2,048-bit synthetic signature, every kept signal against the oracle."""
+    import hashlib
+    from zkwg.synth import test_key, pkcs1_sign_digest
+    ok, wit = run_host_rsa(KAT_MSG, limbs(KAT_SIG), limbs(KAT_PUB), wave=True)
+    assert ok == 1 and wit == oracle_rsa(KAT_MSG, limbs(KAT_SIG), limbs(KAT_PUB))
+    m2 = list(KAT_MSG)
+    m2[0] += 1
+    ok, _ = run_host_rsa(m2, limbs(KAT_SIG), limbs(KAT_PUB), wave=True)
+    assert ok == 0
+    key = test_key()
+    digest = hashlib.sha256(b"zkwg synthetic header").digest()
+    sig = pkcs1_sign_digest(key, digest)
+    msg = limbs(int.from_bytes(digest, "big"))
+    ok, wit = run_host_rsa(msg, limbs(sig), limbs(key["n"]), wave=True)
+    assert ok == 1 and wit == oracle_rsa(msg, limbs(sig), limbs(key["n"]))
+    # and it agrees with the phase-sequential core signal for signal
+    ok2, wit2 = run_host_rsa(msg, limbs(sig), limbs(key["n"]))
+    assert ok2 == 1 and wit2 == wit

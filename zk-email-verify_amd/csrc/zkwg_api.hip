@@ -828,7 +828,10 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
   if (tm) hipEventRecord(evs[++ki], st);
   if (s.net_mode) {
     // the regex circuit of a loaded template: gate list, one wavefront per email (LDS: value cache + message bytes)
-    hipLaunchKernelGGL(zk_net_eval, dim3(ne), dim3(64), 4u * s.net_lds_words + 16, st, s, B);
+    const u32 ew = 64u / std::max(16u, s.net_lanes);   // emails per wavefront
+    if (4u * s.net_lds_words * ew + 16 > 48u * 1024u)   // (gfx950: 160 KB of LDS per CU; the default per-workgroup cap is lower)
+      hipFuncSetAttribute((const void*)zk_net_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u * s.net_lds_words * ew + 16));
+    hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
     if (tm) hipEventRecord(evs[++ki], st);
   }
   if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 7 * s.fr[0].max_bytes + 64 + ZK_DFA_STATES * 256 + 16, st, s, B);

@@ -511,6 +511,7 @@ struct Net {
   u32 mask_words = 0;                // mask words per message byte (0: nothing was localised)
   u32 lds_masks = 0;                 // first LDS word of the evaluator's mask region (n_in x mask_words words)
   u32 n_local = 0, n_frontier = 0;   // statistics: gates removed from the evaluator / served from the masks
+  u32 lanes = 64;                    // lanes per email of zk_net_eval = gates per step (64 / lanes emails share a wavefront)
   std::vector<std::string> names;    // kept slot -> name relative to the component (".eq[0][5].isz.inv")
   std::vector<u8> boolean;           // kept slot -> 1 if its interval is [0, 1]
   // statistics
@@ -1522,7 +1523,11 @@ struct Elab {
     // list scheduling straight into steps of <= 64 gates: a gate goes to the earliest open step after all its operands
     // that still has a free lane; `window` + 1 steps stay open, older ones are closed in order
     const u32 window = 12;
-    const u32 step_lanes = getenv("ZKWG_NET_LANES") ? (u32)atoi(getenv("ZKWG_NET_LANES")) : 64u;
+    // gates per step = lanes per email of zk_net_eval: with the byte-local gates gone (localize) a step holds ~15 gates, and
+    // 32 lanes per step cost +2 % steps (16: +27 %) -- two emails share a wavefront
+    u32 step_lanes = getenv("ZKWG_NET_LANES") ? (u32)atoi(getenv("ZKWG_NET_LANES")) : 32u;
+    if (step_lanes != 16 && step_lanes != 32 && step_lanes != 64) step_lanes = 32;
+    net.lanes = step_lanes;
     std::deque<std::vector<u32>> open;
     u32 base = 1;
     std::vector<u32> outs;

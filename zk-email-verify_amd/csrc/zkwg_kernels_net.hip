@@ -1,5 +1,5 @@
-// zk_net_eval -- BodyHashRegex from a loaded circom template (zkwg_circom.h): one wavefront per email
-// walks the gate list, up to 64 gates (one per lane) per step; the gates of a step are mutually
+// zk_net_eval -- BodyHashRegex from a loaded circom template (zkwg_circom.h): net_lanes (32 by default) lanes per
+// email -- two emails per wavefront -- walk the gate list, up to net_lanes gates (one per lane) per step; the gates of a step are mutually
 // independent and only read values of earlier steps.  Results go to the email's image (zk_expand's
 // ZSEG_NET streams them out) and, when a later gate reads them, to an LDS word the loader assigned by
 // liveness; an operand is an LDS offset, the image is write-only.  Steps whose records the loader proved
@@ -15,23 +15,28 @@
 #define ZKN_DEPTH 8
 
 __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
-  const u32 e = blockIdx.x;
-  if (e >= B.n_emails) return;
-  const u32 lane = threadIdx.x;
+  // s.net_lanes (16 / 32 / 64) lanes per email: 64 / net_lanes emails share the wavefront, each with its own LDS image;
+  // the lanes of all of them run the same record stream (the records of a step are fetched once per lane index)
+  const u32 L = s.net_lanes, EW = 64u / L;
+  const u32 lane = threadIdx.x, sub = lane / L, gl = lane % L;
+  const u32 e_raw = blockIdx.x * EW + sub;
+  if (blockIdx.x * EW >= B.n_emails) return;
+  const bool live = e_raw < B.n_emails;
+  const u32 e = live ? e_raw : B.n_emails - 1u;      // an idle sub-group shadows the last email (same values, same stores)
   extern __shared__ u32 dyn_lds[];
-  int* lds = (int*)dyn_lds;
+  int* lds = (int*)dyn_lds + sub * s.net_lds_words;
   const u32 msg_base = s.net_pins;     // [gate values | message bytes | 0 | scratch | masks]
   const u32 N = s.fr[0].max_bytes;
   const u8* rec = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
   // message bytes, and per byte its mask words: the truth of every byte-local boolean a per-email gate reads
   // (zkwg_circom.h localize), one table lookup per byte and word
   const u32 MW = s.net_mask_words;
-  for (u32 i = lane; i < N; i += 64) {
+  for (u32 i = gl; i < N; i += L) {
     const u32 b = rec[i];
     lds[msg_base + i] = (int)b;
     for (u32 m = 0; m < MW; ++m) lds[s.net_lds_masks + i * MW + m] = (int)B.net_mask_tab[b * MW + m];
   }
-  if (lane == 0) lds[msg_base + N] = 0;
+  if (gl == 0) lds[msg_base + N] = 0;
   const u32 scratch = msg_base + N + 1u;
   __syncthreads();
   u32* small = B.small + (u64)e * s.img_small;
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   // every lane loads (lanes past the step's count get records of later steps and are neutralised when executed):
   // no control flow around the loads, so the compiler's s_waitcnt bookkeeping keeps the ring's distance
   auto fetch = [&](u32 n, uint4* dst) {
-    const uint4* p = R + ((u64)fetch_base + lane) * 4;
+    const uint4* p = R + ((u64)fetch_base + gl) * 4;
     dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2]; dst[3] = p[3];
     fetch_base += n & 0x7fu;
   };
@@ -70,14 +75,14 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
       const u32 cn = cur[d];
       const u32 n = cn & 0x7fu;
       if (cn & 0x8000u) {
-        if (lane < n) {
+        if (gl < n) {
           const u32 r[16] = {ring[d][0].x, ring[d][0].y, ring[d][0].z, ring[d][0].w, ring[d][1].x, ring[d][1].y, ring[d][1].z, ring[d][1].w,
                              ring[d][2].x, ring[d][2].y, ring[d][2].z, ring[d][2].w, ring[d][3].x, ring[d][3].y, ring[d][3].z, ring[d][3].w};
           ok &= zk_net_record(r, lds, lds, img, small + s.m_net_out, small + s.m_rev, inv_limit);
         }
       } else {
-        // all 64 lanes run the record they hold; the lanes past the count write to scratch words
-        const bool act = lane < n;
+        // all lanes run the record they hold; the lanes past the count write to scratch words
+        const bool act = gl < n;
         const u32 r[16] = {ring[d][0].x, act ? ring[d][0].y : s.net_total, ring[d][0].z, act ? ring[d][0].w : scratch,
                            ring[d][1].x, ring[d][1].y, ring[d][1].z, ring[d][1].w,
                            ring[d][2].x, ring[d][2].y, ring[d][2].z, ring[d][2].w, ring[d][3].x, ring[d][3].y, ring[d][3].z, ring[d][3].w};
@@ -89,5 +94,7 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
 #pragma unroll
     for (int d = 0; d < ZKN_DEPTH; ++d) { cur[d] = nxt[d]; nxt[d] = nn[d]; }
   }
-  if (__ballot(!ok) != 0ull && lane == 0) B.status[e] = 4;
+  const u64 bad = __ballot(!ok);
+  const u64 mine = (L == 64u ? ~0ull : ((1ull << L) - 1ull)) << (sub * L);
+  if ((bad & mine) != 0ull && gl == 0 && live) B.status[e] = 4;
 }

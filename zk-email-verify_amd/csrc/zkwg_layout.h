@@ -254,7 +254,7 @@ static inline void zk_alloc_bh_regex(ZkWalker& w, ZkSched& s, u32 N) {
     s.net_mode = 1;
     s.net_kept = w.net->n_kept; s.net_total = w.net->n_kept + w.net->n_temp;
     s.net_steps = w.net->n_steps; s.net_pins = w.net->n_pins; s.net_lds_words = w.net->lds_words;
-    s.net_lds_masks = w.net->lds_masks; s.net_mask_words = w.net->mask_words;
+    s.net_lds_masks = w.net->lds_masks; s.net_mask_words = w.net->mask_words; s.net_lanes = w.net->lanes;
     s.m_net = w.alloc_small(s.net_total + 1);   // + a scratch word for the evaluator's idle lanes
     s.m_net_out = w.alloc_small(1);
     s.m_dfa_own = s.m_dfa_st = s.m_dfa_cm = s.m_dfa_pm = s.m_dfa_acc = 0;

@@ -23,6 +23,12 @@
 #define ZK_SEQ if (ZK_LANE() == 0u)
 #define ZK_SYNC() __syncthreads()
 #define ZK_DEV __device__
+#elif defined(ZKWG_WAVESIM)   // tests/native/wavesim.h: the 64 lanes as fibers of one host thread
+#define ZK_LANE() zk_wavesim_lane()
+#define ZK_PAR_FOR(i, n) for (u32 i = ZK_LANE(); i < (u32)(n); i += 64u)
+#define ZK_SEQ if (ZK_LANE() == 0u)
+#define ZK_SYNC() zk_wavesim_sync()
+#define ZK_DEV
 #else
 #define ZK_PAR_FOR(i, n) for (u32 i = 0; i < (u32)(n); ++i)
 #define ZK_SEQ

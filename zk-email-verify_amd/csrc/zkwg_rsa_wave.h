@@ -22,7 +22,11 @@
 #include "zkwg_rsa_core.h"
 #include "zkwg_fr_inv.h"
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) || defined(ZKWG_WAVESIM)
+#if defined(ZKWG_WAVESIM)   // host build on a simulated wavefront (tests/native/wavesim.h supplies __ballot, __shfl ...)
+#define __device__
+#define __forceinline__ inline
+#endif
 
 __device__ __forceinline__ u64 zkw_ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ u32 zkw_rl(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
@@ -598,4 +602,4 @@ __device__ inline void zkw_rsa_email(ZkRsaLds& S, const ZkRsaLayout& R, const u8
   ZK_SYNC();
 }
 
-#endif  // __HIPCC__
+#endif  // __HIPCC__ || ZKWG_WAVESIM

@@ -219,6 +219,7 @@ struct ZkSched {
   u32 net_lds_words;     // zk_net_eval's LDS image: total words
   u32 net_lds_masks;     // zk_net_eval's LDS image: first word of the per-byte mask region (byte-local frontier bits, zkwg_circom.h localize)
   u32 net_mask_words;    // mask words per message byte (0: none)
+  u32 net_lanes;         // lanes per email of zk_net_eval (64 / net_lanes emails per wavefront)
   // RemoveSoftLineBreaks(max_body) (template flag removeSoftLineBreaks, email-verifier.circom:148-156)
   u32 rslb;              // 1: present
   u32 rs_nch;            // 2 * max_body / 16 Poseidon(16) chunks of PoseidonModular(2 * max_body)
