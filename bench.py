@@ -47,7 +47,7 @@ class Pipeline:
     another; images are ring-buffered, witnesses go to a 2-tile ring in HBM."""
 
     def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=0, exp_prio=-1,
-                 montgomery=False, out_align=0, serial=False, prep_cus=0, prep_cu_stride=1):
+                 montgomery=False, out_align=0, serial=False, prep_cus=0, prep_cu_stride=1, prep_prio=0):
         self.torch, self.c, self.dev, self.d_in = torch, c, dev, d_in
         self.batch, self.tile, self.prep = batch, tile, prep
         assert batch % prep == 0 and prep % tile == 0
@@ -62,7 +62,7 @@ class Pipeline:
         self.R = max(2, ring)
         self.d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(self.R)]
         # several prepare streams let the latency-bound prepare kernels of consecutive SMALL sub-batches overlap
-        self.s_preps = [torch.cuda.Stream(device=dev, priority=0) for _ in range(max(1, prep_streams))]
+        self.s_preps = [torch.cuda.Stream(device=dev, priority=prep_prio) for _ in range(max(1, prep_streams))]
         self.s_exp = torch.cuda.Stream(device=dev, priority=exp_prio)
         self.serial = serial
         self._masked = []

@@ -195,7 +195,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   // tuning knobs (DESIGN.md "zk_expand geometry"): slots per workgroup and threads per workgroup
   auto pick_k = [](const char* name, int dflt, bool k8 = false) { const char* v = getenv(name); const int k = v ? atoi(v) : dflt; return (k == 1 || k == 2 || k == 4 || (k8 && k == 8)) ? k : dflt; };
   c->x3_k = pick_k("ZKWG_X3_K", 4, true);
-  c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 4);
+  c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 2);
   c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 8;
   c->xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
   c->rsa_wgs_per_cu = 0;
@@ -362,12 +362,14 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       up(T.s_chain.data(), T.s_chain.size(), (void**)&O.s_chain);
       {
         // small rows: the groups of one row (a thread each) and the chains (a wavefront each)
-        std::vector<u32> single, chains;
+        std::vector<u32> single, lng, chains;
         for (size_t g = 0; g + 1 < T.s_group.size(); ++g) {
           const u32 a = T.s_group[g], b = T.s_group[g + 1];
-          if (b - a == 1) single.push_back(a); else { chains.push_back(a); chains.push_back(b - a); }
+          if (b - a == 1) (T.s_ptr[a + 1] - T.s_ptr[a] > ZK_ROW_LONG ? lng : single).push_back(a); else { chains.push_back(a); chains.push_back(b - a); }
         }
         up(single.data(), single.size() * 4, (void**)&O.s_single);
+        up(lng.data(), lng.size() * 4, (void**)&O.s_long);
+        O.n_small_long = (u32)lng.size();
         up(chains.data(), chains.size() * 4, (void**)&O.s_chains);
         O.n_small_single = (u32)single.size(); O.n_small_chains = (u32)(chains.size() / 2);
       }
@@ -377,6 +379,9 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       up(T.f_kind.data(), T.f_kind.size(), (void**)&O.f_kind);
       up(T.f_chain.data(), T.f_chain.size(), (void**)&O.f_chain);
       up(T.f_group.data(), T.f_group.size() * 4, (void**)&O.f_group);
+      up(T.gen_seg.data(), T.gen_seg.size() * 4, (void**)&O.gen_seg);
+      up(T.gen_r.data(), T.gen_r.size() * 4, (void**)&O.gen_r);
+      O.n_gen = (u32)T.gen_seg.size(); O.gen_base = T.gen_base;
       O.W = c->full_W; O.nportions = (u32)((c->full_W + 256u * c->x3_k_o0 - 1) / (256u * c->x3_k_o0)); O.small_base = T.small_base; O.fr_base = T.fr_base;
       O.emails_per_wg = (u32)c->o0_emails_per_wg;
       O.n_fr_groups = (u32)(T.f_group.size() - 1);
@@ -576,8 +581,8 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (c->device >= 0) {
     hipSetDevice(c->device);
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
-    hipFree((void*)c->o0d.desc); hipFree((void*)c->o0d.s_ptr); hipFree((void*)c->o0d.s_term); hipFree((void*)c->o0d.s_coef); hipFree((void*)c->o0d.s_chain); hipFree((void*)c->o0d.s_single); hipFree((void*)c->o0d.s_chains);
-    hipFree((void*)c->o0d.f_ptr); hipFree((void*)c->o0d.f_term); hipFree((void*)c->o0d.f_coef); hipFree((void*)c->o0d.f_kind); hipFree((void*)c->o0d.f_chain); hipFree((void*)c->o0d.f_group);
+    hipFree((void*)c->o0d.desc); hipFree((void*)c->o0d.s_ptr); hipFree((void*)c->o0d.s_term); hipFree((void*)c->o0d.s_coef); hipFree((void*)c->o0d.s_chain); hipFree((void*)c->o0d.s_single); hipFree((void*)c->o0d.s_long); hipFree((void*)c->o0d.s_chains);
+    hipFree((void*)c->o0d.f_ptr); hipFree((void*)c->o0d.f_term); hipFree((void*)c->o0d.f_coef); hipFree((void*)c->o0d.f_kind); hipFree((void*)c->o0d.f_chain); hipFree((void*)c->o0d.f_group); hipFree((void*)c->o0d.gen_seg); hipFree((void*)c->o0d.gen_r);
     hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_fn); hipFree(c->d_net_desc);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); if (c->hx_img[i]) hipHostFree(c->hx_img[i]); }
@@ -777,6 +782,27 @@ static void fill_x3(const zkwg_circuit* c, const ZkBufs& B, ZkX3& A) {
   A.net_fn = B.net_fn; A.net_desc = B.net_desc;
 }
 
+// the linear rows of a numbered (`--O0`) circuit that are real sums, for emails [B.e_first, B.n_emails): results go into the image
+// extensions (zkwg_o0.h).  Launched at the end of zkwg_prepare_device -- so that in a two-stream pipeline they overlap the
+// previous sub-batch's expansion -- or, when the removeSoftLineBreaks chain still writes field elements on its side stream,
+// in front of the expansion that waits for it.
+static void launch_o0_rows(const zkwg_circuit* c, const ZkBufs& B, hipStream_t st) {
+  const ZkO0Dev& O = c->o0d;
+  ZkX3 A;
+  fill_x3(c, B, A);
+  const u32 total = B.n_emails - B.e_first;
+  for (u32 off = 0; off < total; off += 32768u) {   // the kernels index emails with blockIdx.y
+    const u32 cnt = std::min(32768u, total - off);
+    A.e_first = B.e_first + off; A.n_count = cnt;
+    // zk_o0_generic first: the rows read the codes it leaves
+    if (O.n_gen) hipLaunchKernelGGL(zk_o0_generic, dim3((O.n_gen + 255) / 256, cnt), dim3(256), 0, st, A, O);
+    if (O.n_small_single) hipLaunchKernelGGL(zk_o0_rows_small, dim3((O.n_small_single + 255) / 256, (cnt + ZK_ROW_EMAILS - 1) / ZK_ROW_EMAILS), dim3(256), 0, st, A, O);
+    if (O.n_small_long) hipLaunchKernelGGL(zk_o0_rows_small_long, dim3((O.n_small_long + 3) / 4, (cnt + ZK_ROW_EMAILS - 1) / ZK_ROW_EMAILS), dim3(256), 0, st, A, O);
+    if (O.n_small_chains) hipLaunchKernelGGL(zk_o0_chains_small, dim3(O.n_small_chains, cnt), dim3(64), 0, st, A, O);
+    if (O.n_fr_groups) hipLaunchKernelGGL(zk_o0_rows_fr, dim3((O.n_fr_groups * ZK_FR_LANES + 255) / 256, cnt), dim3(256), 0, st, A, O);
+  }
+}
+
 int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_status, void* d_scratch,
                         void* hip_stream) {
   if (!c || !d_in || !d_status || !d_scratch) return ZKWG_RC_BAD_ARG;
@@ -879,6 +905,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       return ZKWG_RC_OK;
     }
   }
+  if (c->full_W && !(s.rslb && !c->rs_sync)) launch_o0_rows(c, B, st);   // (timed with the last prepare kernel)
   if (tm) { hipEventRecord(evs[++ki], st); c->prep_valid = true; c->prep_launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;
@@ -942,9 +969,7 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
       // numbered circuit (`--O0` / `--O1`), one pass: the rows that are real sums go into the image extensions of these
       // emails, then every wire is written from its descriptor (zkwg_o0.h) -- no staging buffer, no gather
       const ZkO0Dev& O = c->o0d;
-      if (O.n_small_single) hipLaunchKernelGGL(zk_o0_rows_small, dim3((O.n_small_single + 255) / 256, (u32)cnt), dim3(256), 0, st, A, O);
-      if (O.n_small_chains) hipLaunchKernelGGL(zk_o0_chains_small, dim3(O.n_small_chains, (u32)cnt), dim3(64), 0, st, A, O);
-      if (O.n_fr_groups) hipLaunchKernelGGL(zk_o0_rows_fr, dim3((O.n_fr_groups * ZK_FR_LANES + 255) / 256, (u32)cnt), dim3(256), 0, st, A, O);
+      if (s.rslb && !c->rs_sync) launch_o0_rows(c, B, st);   // (otherwise zkwg_prepare_device already ran them)
       const u64 units = ((cnt + O.emails_per_wg - 1) / O.emails_per_wg) * (u64)O.nportions;
       if (units > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
       if (mont) hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, A);

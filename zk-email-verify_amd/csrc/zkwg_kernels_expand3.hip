@@ -161,7 +161,6 @@ __global__ __launch_bounds__(256) void zk_image_to_mont(ZkX3 A) {
 }
 
 // ---------------------------------------------------------------- numbered circuits (`--O0` / `--O1`), one pass
-__device__ __noinline__ u32 zk_decode_generic(const ZkSeg* __restrict__ sg, u32 r, const ZkCtx& cx) { return zk_decode_any(*sg, r, cx); }
 // the code of one wire from its descriptor (zkwg_o0.h)
 __device__ __forceinline__ u32 zk_desc_decode(u32 a, u32 b, const ZkCtx& cx, const ZkSeg* __restrict__ segs) {
   switch (a >> 28) {
@@ -170,9 +169,10 @@ __device__ __forceinline__ u32 zk_desc_decode(u32 a, u32 b, const ZkCtx& cx, con
     case ZK_D_BIT8: return (u32)(cx.rec[b] >> (a & 7u)) & 1u;
     case ZK_D_BYTE: return cx.rec[b];
     case ZK_D_SMALLRAW: return zk_raw_code(cx.small[b], b);
+    case ZK_D_CODEW: return cx.small[b];
     case ZK_D_SMALLS: { const u32 lo = cx.small[b], hi = cx.small[b + 1]; return (hi == 0u && !(lo >> 31)) ? lo : (ZK_REF_I64 | b); }
     case ZK_D_DFA: return zk_dfa_value((a >> 24) & 15u, (a >> 9) & 0x7ffu, (a >> 20) & 15u, a & 511u, b, cx.small + cx.m_dfa_st, cx.small + cx.m_dfa_cm, cx.small + cx.m_dfa_pm, cx.half);
-    default: return zk_decode_generic(segs + (a & 0xffffffu), b, cx);
+    default: return 0u;   // (no wire keeps kind GENERIC: zk_o0_build turns them into CODEW)
   }
 }
 // What a descriptor reads, resolved once per workgroup: one 64-bit word of `bits`, one byte of the record, two words of
@@ -184,7 +184,7 @@ __device__ __forceinline__ ZkO0Pre zk_o0_pre(uint2 d, const ZkX3& A) {
   switch (d.x >> 28) {
     case ZK_D_BIT64: p.i64 = d.y; break;
     case ZK_D_BIT8: case ZK_D_BYTE: p.i8 = d.y; break;
-    case ZK_D_SMALLRAW: p.i32 = d.y; break;
+    case ZK_D_SMALLRAW: case ZK_D_CODEW: p.i32 = d.y; break;
     case ZK_D_SMALLS: p.i32 = d.y; p.i32b = d.y + 1u; break;
     case ZK_D_DFA: {
       const u32 dk = (d.x >> 24) & 15u, i = (d.x >> 9) & 0x7ffu;
@@ -204,9 +204,10 @@ __device__ __forceinline__ u32 zk_o0_combine(uint2 d, const ZkO0Pre& p, u64 w64,
     case ZK_D_BIT8: return (w8 >> (a & 7u)) & 1u;
     case ZK_D_BYTE: return w8;
     case ZK_D_SMALLRAW: return zk_raw_code(w32, b);
+    case ZK_D_CODEW: return w32;
     case ZK_D_SMALLS: return (w32b == 0u && !(w32 >> 31)) ? w32 : (ZK_REF_I64 | b);
     case ZK_D_DFA: return zk_dfa_value_w((a >> 24) & 15u, (a >> 20) & 15u, a & 511u, b, w32, w32b, half);
-    default: return 0u;   // ZK_D_GENERIC: second pass
+    default: return 0u;
   }
 }
 template <bool MONT, int K>
@@ -221,15 +222,12 @@ __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev&
   // against 32 bytes written per wire and email)
   uint2 d[K];
   ZkO0Pre pre[K];
-  bool any_generic = false;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const u32 i = 64u * K * wv + 64u * k + lane;
     d[k] = i < nsl ? O.desc[slot0 + i] : make_uint2(0u, 0u);
     pre[k] = zk_o0_pre(d[k], A);
-    any_generic = any_generic || (d[k].x >> 28) == ZK_D_GENERIC;
   }
-  const bool wave_generic = __builtin_amdgcn_ballot_w64(any_generic) != 0ull;
   const u32 el1 = min((g + 1u) * O.emails_per_wg, A.n_count);
   for (u32 el = g * O.emails_per_wg; el < el1; ++el) {
     const u32 e = el + A.e_first;
@@ -240,12 +238,6 @@ __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev&
     u32 code[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) code[k] = zk_o0_combine(d[k], pre[k], w64[k], w8[k], w32[k], w32b[k], cx.half);
-    if (wave_generic) {
-      // the few wires decoded by their segment's own arithmetic (selectors, comparators: ~1.5 % of EmailVerifier's)
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-        if ((d[k].x >> 28) == ZK_D_GENERIC) code[k] = zk_decode_generic(A.segs + (d[k].x & 0xffffffu), d[k].y, cx);
-    }
     zk_x3_store<MONT, K>(A, cx, e, el, slot0, nsl, code);
   }
 }
@@ -256,6 +248,17 @@ ZK_X3_O0_KERNELS(1)
 ZK_X3_O0_KERNELS(2)
 ZK_X3_O0_KERNELS(4)
 
+// wires whose value comes from their segment's own arithmetic (ItemAtIndex selectors, comparators, Base64 ...: 1.5 % of the
+// wires of EmailVerifier): their codes, once per email, into small[gen_base + g] -- the streaming kernel then reads them like
+// any other small word and carries no segment decoder (126 -> 60 VGPRs)
+__global__ __launch_bounds__(256) void zk_o0_generic(ZkX3 A, ZkO0Dev O) {
+  const u32 g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= O.n_gen) return;
+  const u32 e = A.e_first + blockIdx.y;
+  const ZkCtx cx = zk_x3_ctx(A, e);
+  const ZkSeg sg = A.segs[O.gen_seg[g]];
+  A.small_w[(u64)e * A.img_small + O.gen_base + g] = zk_decode_any(sg, O.gen_r[g], cx);
+}
 // the value of a code as a signed integer (small rows: every source is small-ranged by construction)
 __device__ __forceinline__ long long zk_code_int(u32 code, const ZkCtx& cx) {
   if (!(code >> 31)) return (long long)code;
@@ -275,17 +278,62 @@ __device__ __forceinline__ long long zk_small_row_terms(const ZkO0Dev& O, u32 j,
   }
   return acc;
 }
-// one thread per row that is a group of its own
+// one thread per row that is a group of its own, for ZK_ROW_EMAILS emails: the row's table entries (pointer, terms,
+// coefficients) are read once, and per term the image loads of all the emails are issued back to back before any of
+// them is used -- the kernel is a chain of dependent loads, so what counts is how many are in flight
+// terms t0 + first, t0 + first + step, ... of row j for the emails el0 .. el0 + ZK_ROW_EMAILS - 1 of the launch
+__device__ __forceinline__ void zk_row_accumulate(const ZkX3& A, const ZkO0Dev& O, u32 j, u32 el0, u32 first, u32 step, long long acc[ZK_ROW_EMAILS]) {
+  const u32 last = A.n_count - 1u;
+#pragma unroll
+  for (int k = 0; k < ZK_ROW_EMAILS; ++k) acc[k] = 0;
+  const u64 t1 = O.s_ptr[j + 1];
+  for (u64 t = O.s_ptr[j] + first; t < t1; t += step) {
+    const uint2 d = O.s_term[t];
+    const long long cf = (long long)O.s_coef[t];
+    const ZkO0Pre pre = zk_o0_pre(d, A);
+    u64 w64[ZK_ROW_EMAILS]; u32 w8[ZK_ROW_EMAILS], w32[ZK_ROW_EMAILS], w32b[ZK_ROW_EMAILS];
+#pragma unroll
+    for (int k = 0; k < ZK_ROW_EMAILS; ++k) {
+      const ZkCtx cx = zk_x3_ctx(A, A.e_first + min(el0 + (u32)k, last));
+      w64[k] = cx.bits[pre.i64]; w8[k] = cx.rec[pre.i8]; w32[k] = cx.small[pre.i32]; w32b[k] = cx.small[pre.i32b];
+    }
+#pragma unroll
+    for (int k = 0; k < ZK_ROW_EMAILS; ++k) {
+      const ZkCtx cx = zk_x3_ctx(A, A.e_first + min(el0 + (u32)k, last));
+      acc[k] += cf * zk_code_int(zk_o0_combine(d, pre, w64[k], w8[k], w32[k], w32b[k], cx.half), cx);
+    }
+  }
+}
+__device__ __forceinline__ void zk_row_store(const ZkX3& A, const ZkO0Dev& O, u32 j, u32 el0, const long long acc[ZK_ROW_EMAILS]) {
+#pragma unroll
+  for (int k = 0; k < ZK_ROW_EMAILS; ++k)
+    if (el0 + (u32)k < A.n_count)
+      *(uint2*)(A.small_w + (u64)(A.e_first + el0 + k) * A.img_small + O.small_base + 2u * j) = make_uint2((u32)(u64)acc[k], (u32)((u64)acc[k] >> 32));
+}
 __global__ __launch_bounds__(256) void zk_o0_rows_small(ZkX3 A, ZkO0Dev O) {
   const u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= O.n_small_single) return;
-  const u32 j = O.s_single[i];
-  const u32 e = A.e_first + blockIdx.y;
-  const ZkCtx cx = zk_x3_ctx(A, e);
-  const long long acc = zk_small_row_terms(O, j, cx, A.segs);
-  u32* out = A.small_w + (u64)e * A.img_small + O.small_base;
-  out[2u * j] = (u32)(u64)acc;
-  out[2u * j + 1u] = (u32)((u64)acc >> 32);
+  const u32 j = O.s_single[i], el0 = blockIdx.y * ZK_ROW_EMAILS;
+  long long acc[ZK_ROW_EMAILS];
+  zk_row_accumulate(A, O, j, el0, 0u, 1u, acc);
+  zk_row_store(A, O, j, el0, acc);
+}
+// rows of more than ZK_ROW_LONG terms (up to 1,633 in EmailVerifier: the sums over a whole header): one wavefront per
+// row, the lanes stride over the terms, a butterfly adds the partial sums
+__global__ __launch_bounds__(256) void zk_o0_rows_small_long(ZkX3 A, ZkO0Dev O) {
+  const u32 i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (i >= O.n_small_long) return;
+  const u32 j = O.s_long[i], el0 = blockIdx.y * ZK_ROW_EMAILS;
+  long long acc[ZK_ROW_EMAILS];
+  zk_row_accumulate(A, O, j, el0, lane, 64u, acc);
+#pragma unroll
+  for (int k = 0; k < ZK_ROW_EMAILS; ++k)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const u32 lo = __shfl_xor((u32)(u64)acc[k], d), hi = __shfl_xor((u32)((u64)acc[k] >> 32), d);
+      acc[k] += (long long)((u64)lo | ((u64)hi << 32));
+    }
+  if (lane == 0) zk_row_store(A, O, j, el0, acc);
 }
 // one wavefront per chain (zkwg_o0.h: every row continues the sum of the row before it -- the running sums of
 // MultiOR / CalculateTotal / popcount chains): lane = row, each lane sums the terms its row adds, an inclusive prefix

@@ -19,6 +19,7 @@
 #include "zkwg_sched.h"
 #include "zkwg_r1cs.h"
 
+#define ZK_ROW_LONG 16u   // terms from which a row of its own gets a wavefront instead of a thread
 enum ZkDescKind : u32 {
   ZK_D_IMM = 0,       // b = the code itself (a constant, or a reference known at build time)
   ZK_D_BIT64 = 1,     // bit (a & 63) of bits[b]
@@ -27,6 +28,7 @@ enum ZkDescKind : u32 {
   ZK_D_SMALLRAW = 4,  // small[b], raw 32-bit value
   ZK_D_SMALLS = 5,    // (small[b], small[b+1]) as a signed 64-bit integer v (results of small rows): 0 <= v < 2^31 -> v, else the field element v mod r
   ZK_D_GENERIC = 6,   // slot b of kept-v1 segment (a & 0xffffff): decoded by the segment's own arithmetic
+  ZK_D_CODEW = 8,     // small[b] holds the wire's code itself (left there by zk_o0_generic for the wires of kind GENERIC)
   ZK_D_DFA = 7        // BodyHashRegex DFA array element: a = kind << 28 | ZkDfaKind << 24 | q << 20 | position << 9 | param b, b = param c
 };
 
@@ -34,6 +36,7 @@ enum ZkDescKind : u32 {
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <unordered_map>
 #include "zkwg_full.h"
 
 struct ZkO0Tables {
@@ -50,6 +53,10 @@ struct ZkO0Tables {
   u64 n_small() const { return s_ptr.empty() ? 0 : s_ptr.size() - 1; }
   u64 n_fr() const { return f_ptr.empty() ? 0 : f_ptr.size() - 1; }
   u64 n_alias = 0, n_const = 0, terms_before_chaining = 0;
+  // wires of kind GENERIC (decoded by their segment's own arithmetic: selectors, comparators ...): a pre-pass kernel leaves
+  // their codes in small[gen_base + g], so that the streaming kernel itself carries no segment decoder
+  u32 gen_base = 0;
+  std::vector<u32> gen_seg, gen_r;
 };
 
 // static value range of slot r of a kept-v1 segment; false = a field element (no small bound)
@@ -106,16 +113,6 @@ static inline void zk_o0_slot_desc(const std::vector<ZkSeg>& segs, u64 slot, u32
     default: out[0] = (ZK_D_GENERIC << 28) | (u32)lo; out[1] = r; return;
   }
 }
-static inline bool zk_o0_desc_immediate(const u32 d[2], const std::vector<ZkSeg>& segs) {
-  switch (d[0] >> 28) {
-    case ZK_D_IMM: return !(d[1] >> 31);
-    case ZK_D_BIT64: case ZK_D_BIT8: case ZK_D_BYTE: return true;
-    case ZK_D_GENERIC: return zk_seg_is_immediate(segs[d[0] & 0xffffffu]);
-    case ZK_D_DFA: return ((d[0] >> 24) & 15u) != ZDFA_EQ;
-    default: return false;
-  }
-}
-
 // desc_slot[w]: kept-v1 slot wire w copies, or 0xfffffffe when w is the destination of a row of `P` that is not a plain
 // alias; term_slot[t]: kept-v1 slot of term t's source.  Extends s.img_small / s.img_fr by the row results.
 static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const ZkLinPlan& P, const std::vector<u32>& desc_slot,
@@ -123,10 +120,27 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
   const u64 W = desc_slot.size();
   if (segs.size() >= (1u << 24)) { err = "too many segments for the O0 descriptor table"; return false; }
   T.desc.assign(2 * W, 0);
-  T.small_base = s.img_small; T.fr_base = s.img_fr;
+  T.fr_base = s.img_fr;
   T.s_ptr.assign(1, 0); T.f_ptr.assign(1, 0);
+  // slots whose value comes from their segment's own arithmetic (kind GENERIC), as wires or as terms of rows: numbered
+  // first -- zk_o0_generic leaves their codes in small[gen_base + g], every later reader sees kind CODEW
+  T.gen_base = s.img_small;
+  std::unordered_map<u32, u32> gen_of;
+  auto note_generic = [&](u32 slot) {
+    u32 d[2], si, sr;
+    zk_o0_slot_desc(segs, slot, d, &si, &sr);
+    if ((d[0] >> 28) == ZK_D_GENERIC && gen_of.emplace(slot, (u32)T.gen_seg.size()).second) { T.gen_seg.push_back(si); T.gen_r.push_back(sr); }
+  };
+  for (u64 w = 0; w < W; ++w) if (desc_slot[w] != 0xfffffffeu) note_generic(desc_slot[w]);
+  for (u64 r = 0; r < P.n_rows(); ++r)
+    if (desc_slot[P.dst[r]] == 0xfffffffeu) for (u64 t = P.row_ptr[r]; t < P.row_ptr[r + 1]; ++t) note_generic(term_slot[t]);
+  T.small_base = (T.gen_base + (u32)T.gen_seg.size() + 1u) & ~1u;
+  auto describe = [&](u32 slot, u32 d[2], u32* si, u32* sr) {
+    zk_o0_slot_desc(segs, slot, d, si, sr);
+    if ((d[0] >> 28) == ZK_D_GENERIC) { d[0] = (u32)ZK_D_CODEW << 28; d[1] = T.gen_base + gen_of.at(slot); }
+  };
   for (u64 w = 0; w < W; ++w)
-    if (desc_slot[w] != 0xfffffffeu) zk_o0_slot_desc(segs, desc_slot[w], &T.desc[2 * w]);
+    if (desc_slot[w] != 0xfffffffeu) describe(desc_slot[w], &T.desc[2 * w], nullptr, nullptr);
   const Fr p = fr_p();
   // the previous row of each class in full (chain detection)
   std::vector<u32> prev_s_t, prev_f_t; std::vector<int32_t> prev_s_c; std::vector<Fr> prev_f_c;
@@ -143,7 +157,7 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
     td.clear(); cs.clear();
     for (u64 t = a; t < b; ++t) {
       u32 d[2], si, sr;
-      zk_o0_slot_desc(segs, term_slot[t], d, &si, &sr);
+      describe(term_slot[t], d, &si, &sr);
       td.push_back(d[0]); td.push_back(d[1]);
       long long l, h;
       if (!small || !zk_slot_range(segs[si], sr, l, h)) { small = false; continue; }
@@ -200,7 +214,8 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
   T.f_group.push_back((u32)T.n_fr());
   if (getenv("ZKWG_DEBUG_PLAN")) {
     u64 kinds[8] = {0}, by_type[ZSEG_NTYPES + 1] = {0};
-    for (u64 w = 0; w < W; ++w) { const u32 k = T.desc[2 * w] >> 28; ++kinds[k & 7]; if (k == ZK_D_GENERIC) ++by_type[segs[T.desc[2 * w] & 0xffffffu].type]; }
+    for (u64 w = 0; w < W; ++w) { const u32 k = T.desc[2 * w] >> 28; ++kinds[k == ZK_D_CODEW ? 6 : (k & 7)]; }
+    for (u32 sg : T.gen_seg) ++by_type[segs[sg].type];
     fprintf(stderr, "[zkwg] O0 descriptors: imm %llu bit64 %llu bit8 %llu byte %llu smallraw %llu smalls %llu dfa %llu generic %llu; generic by segment type:",
             (unsigned long long)kinds[0], (unsigned long long)kinds[1], (unsigned long long)kinds[2], (unsigned long long)kinds[3], (unsigned long long)kinds[4], (unsigned long long)kinds[5], (unsigned long long)kinds[7], (unsigned long long)kinds[6]);
     for (u32 t = 0; t <= ZSEG_NTYPES; ++t) if (by_type[t]) fprintf(stderr, " %u:%llu", t, (unsigned long long)by_type[t]);
@@ -223,7 +238,9 @@ struct ZkO0Dev {
   u32 small_base, fr_base;
   const u64* s_ptr; const uint2* s_term; const int* s_coef; const u8* s_chain;
   const u32* s_single; u32 n_small_single;       // small rows that are groups of their own (one thread each)
+  const u32* s_long; u32 n_small_long;           // ... those of more than ZK_ROW_LONG terms (one wavefront each)
   const uint2* s_chains; u32 n_small_chains;     // (first row, rows) of the chains (one wavefront each: prefix sum over the rows)
+  const u32* gen_seg; const u32* gen_r; u32 n_gen, gen_base;   // wires decoded by zk_o0_generic into small[gen_base ..]
   const u64* f_ptr; const uint2* f_term; const Fr* f_coef; const u8* f_kind; const u8* f_chain; const u32* f_group; u32 n_fr_groups;
 };
 #endif
