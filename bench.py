@@ -47,7 +47,7 @@ class Pipeline:
     another; images are ring-buffered, witnesses go to a 2-tile ring in HBM."""
 
     def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=0, exp_prio=-1,
-                 montgomery=False, out_align=0, serial=False, prep_cus=0, prep_cu_stride=1, prep_prio=0):
+                 montgomery=False, out_align=0, serial=False, prep_cus=0, prep_cu_stride=1, prep_prio=0, abc=False):
         self.torch, self.c, self.dev, self.d_in = torch, c, dev, d_in
         self.batch, self.tile, self.prep = batch, tile, prep
         assert batch % prep == 0 and prep % tile == 0
@@ -57,6 +57,11 @@ class Pipeline:
         self.expand = c.expand_montgomery_device if montgomery else c.expand_device
         # distance between consecutive witnesses in the HBM ring (out_align > 0: padded to a multiple of it)
         self.stride = c.witness_bytes if not out_align or montgomery else (c.witness_bytes + out_align - 1) // out_align * out_align
+        self.unit_bytes = c.witness_bytes
+        if abc:
+            # the prover's first stage instead of the witness: A.w | B.w | C.w of the attached constraint system (zkwg_expand_abc_device)
+            self.expand = lambda d_in, n, scr, first, count, o, st: c.expand_abc_device(d_in, n, scr, first, count, o, st, montgomery=montgomery)
+            self.stride = self.unit_bytes = c.abc_bytes
         self.d_out = [torch.empty(tile * self.stride, dtype=torch.uint8, device=dev) for _ in range(min(2, self.ntiles))]
         self.d_status = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.R = max(2, ring)
@@ -110,7 +115,7 @@ class Pipeline:
             with torch.cuda.stream(self.s_exp):
                 for t in range(self.tiles_per_sub):
                     o = self.d_out[(sb * self.tiles_per_sub + t) % len(self.d_out)]
-                    if self.stride != c.witness_bytes:
+                    if self.stride != self.unit_bytes:
                         self.expand(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp, out_stride=self.stride)
                     else:
                         self.expand(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp)

@@ -368,6 +368,18 @@ int zkwg_convert_montgomery_device(void* d_values, uint64_t n_values, int to_mon
 int zkwg_expand_montgomery_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails,
                                   const void* d_scratch, uint64_t first, uint64_t count, void* d_out_wtns,
                                   uint64_t out_stride, void* hip_stream);
+/* The same prover stage without a 32-byte witness in between: the constraint system `r1cs` (its wires = the handle's
+ * witness layout; built-in or `.sym` layouts, not the fully numbered ones) is attached to the handle once -- BEFORE the
+ * first zkwg_scratch_bytes / zkwg_prepare_device call that should serve it, the compact image grows by the results of the
+ * combinations that are genuine sums -- and zkwg_expand_abc_device then writes A.w | B.w | C.w (3 * nConstraints values,
+ * `abc_stride` >= zkwg_abc_bytes apart) of emails [first, first + count) straight from the prepared image: a combination
+ * that is one wire is written like that wire, sums of bits and small integers are 64-bit integer rows, only the rest is
+ * arithmetic mod r.  Bit-identical to zkwg_r1cs_evaluate_device on the expanded witness (montgomery = 1: to that of the
+ * Montgomery-form witness).  Replaces the head of snarkjs' groth16.prove (packages/helpers/src/chunked-zkey.ts:80). */
+int zkwg_circuit_attach_r1cs(zkwg_circuit_t* c, const uint8_t* r1cs, uint64_t len);
+uint64_t zkwg_abc_bytes(const zkwg_circuit_t* c);
+int zkwg_expand_abc_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails, const void* d_scratch,
+                           uint64_t first, uint64_t count, int montgomery, void* d_abc, uint64_t abc_stride, void* hip_stream);
 
 /* ---- the compact image as a device-side interchange format --------------------------
  * zkwg_prepare_device leaves, per email, a compact IMAGE in the scratch buffer (~0.45 MB instead of the 57 MB

@@ -473,3 +473,63 @@ def test_prover_first_stage_evaluations_on_device_witnesses():
         assert a * b % ru.P == cc * R % ru.P, i
     assert bytes(abc[0].cpu().numpy().tobytes()) == raw == bytes(abc[2].cpu().numpy().tobytes())
     assert any(raw[32 * i:32 * i + 32] != bytes(32) for i in range(m))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("main", ["rsa", "email"])
+def test_prover_first_stage_from_the_compact_image(main):
+    """zkwg_circuit_attach_r1cs + zkwg_expand_abc_device: A.w | B.w | C.w written from the prepared image (descriptors +
+    integer / field rows, no 32-byte witness read) are byte-identical to zkwg_r1cs_evaluate_device on the expanded
+    witness, in standard and in Montgomery form; the witness of the same handle is unchanged by the attachment."""
+    import torch
+    import zkwg
+    dev = torch.device("cuda", 0)
+    if main == "rsa":
+        mk = lambda: zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=0)
+        from test_rsa_cpu import KAT_MSG, KAT_PUB, KAT_SIG, limbs
+        c0 = mk()
+        rec = c0.pack({"signature": limbs(KAT_SIG), "modulus": limbs(KAT_PUB), "message": KAT_MSG})
+        n = 3
+        d_in = torch.frombuffer(bytearray(rec * n), dtype=torch.uint8).to(dev)
+    else:
+        from zkwg import synth
+        mk = lambda: zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0)
+        c0 = mk()
+        n = 11
+        recs, _ = synth.packed_batch(c0, seed=0xABC, n=n, body_len=60)
+        d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(dev)
+    cs = zkwg.WitnessCalculator(c0).constraint_system()
+    s = torch.cuda.current_stream()
+
+    def witnesses(c, mont):
+        d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_scr = torch.empty(c.scratch_bytes(n), dtype=torch.uint8, device=dev)
+        d_wit = torch.empty(n * c.witness_bytes, dtype=torch.uint8, device=dev)
+        c.prepare_device(d_in, n, d_status, d_scr, s)
+        (c.expand_montgomery_device if mont else c.expand_device)(d_in, n, d_scr, 0, n, d_wit, s)
+        torch.cuda.synchronize()
+        assert d_status.cpu().tolist() == [0] * n
+        return d_wit, d_scr
+
+    c1 = mk()
+    before = c1.scratch_bytes(n)
+    c1.attach_r1cs(cs)
+    assert c1.abc_bytes == 96 * cs.n_constraints and c1.scratch_bytes(n) > before
+    with pytest.raises(zkwg.ZkwgError):
+        c1.attach_r1cs(cs)                     # one system per handle
+    for mont in (False, True):
+        w0, _ = witnesses(c0, mont)
+        w1, scr = witnesses(c1, mont)
+        assert torch.equal(w0, w1)
+        want = cs.evaluate_device(w0, n, c0.witness_bytes, s, montgomery=mont)
+        got = torch.full((n, c1.abc_bytes + 64), 0xEE, dtype=torch.uint8, device=dev)   # (padded stride: the tail stays untouched)
+        c1.expand_abc_device(d_in, n, scr, 0, n, got, s, montgomery=mont, out_stride=c1.abc_bytes + 64)
+        torch.cuda.synchronize()
+        assert torch.equal(got[:, :c1.abc_bytes], want)
+        assert bool((got[:, c1.abc_bytes:] == 0xEE).all())
+        # a sub-range of the batch
+        part = torch.empty((2, c1.abc_bytes), dtype=torch.uint8, device=dev)
+        c1.expand_abc_device(d_in, n, scr, 1, 2, part, s, montgomery=mont)
+        torch.cuda.synchronize()
+        assert torch.equal(part, want[1:3])
+    assert any(int(x) for x in want[0, :4096].cpu().tolist())

@@ -45,7 +45,10 @@ struct zkwg_circuit {
   std::vector<u32> o0_short; u64 n_o0_short;
   std::vector<u32> o0_desc, o0_src, o0_long;   // host evaluation (layout-only handles): wire -> kept-v1 slot | 0xfffffffe (row);  row terms as kept-v1 slots;  the rows
   ZkO0Tables o0t;                  // per-wire descriptors + small / field rows (host copy; moved to the device for device handles)
-  ZkO0Dev o0d;                     // device pointers of the same
+  ZkO0Dev o0d{};                   // device pointers of the same
+  u64 abc_m = 0;                   // constraints of the attached system (zkwg_circuit_attach_r1cs; 0: none)
+  ZkO0Tables abct;                 // its 3 m linear combinations as descriptors + rows over the image, like o0t
+  ZkO0Dev abcd{};
   Fr* d_invtab_m; // fused Montgomery output: inverse table in Montgomery form (built with d_rtab)
   // BodyHashRegex loaded from a circom template (zkwg_circuit_create_regex): gate list on the device
   zkc::Net net;
@@ -157,6 +160,52 @@ static void zk_host_segment(const ZkSeg& sg, const ZkCtx& cx, const ZkRefSrc& R,
 
 extern "C" int zk_misc_init_tables(void);
 
+// descriptor + row tables of a numbered layout (zkwg_o0.h) onto the device; the host copy keeps its counters only
+static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W) {
+  bool ok = true;
+  memset(&O, 0, sizeof(O));
+  auto up = [&](const void* src, size_t bytes, void** dst) {
+    *dst = nullptr;
+    if (!ok) return;
+    ok = hipMalloc(dst, std::max<size_t>(bytes, 16)) == hipSuccess && (bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess);
+  };
+  up(T.desc.data(), T.desc.size() * 4, (void**)&O.desc);
+  up(T.s_ptr.data(), T.s_ptr.size() * 8, (void**)&O.s_ptr);
+  up(T.s_term.data(), T.s_term.size() * 4, (void**)&O.s_term);
+  up(T.s_coef.data(), T.s_coef.size() * 4, (void**)&O.s_coef);
+  up(T.s_chain.data(), T.s_chain.size(), (void**)&O.s_chain);
+  {
+    // small rows: the groups of one row (a thread each, a wavefront for the long ones) and the chains (a wavefront each)
+    std::vector<u32> single, lng, chains;
+    for (size_t g = 0; g + 1 < T.s_group.size(); ++g) {
+      const u32 a = T.s_group[g], b = T.s_group[g + 1];
+      if (b - a == 1) (T.s_ptr[a + 1] - T.s_ptr[a] > ZK_ROW_LONG ? lng : single).push_back(a); else { chains.push_back(a); chains.push_back(b - a); }
+    }
+    up(single.data(), single.size() * 4, (void**)&O.s_single);
+    up(lng.data(), lng.size() * 4, (void**)&O.s_long);
+    up(chains.data(), chains.size() * 4, (void**)&O.s_chains);
+    O.n_small_single = (u32)single.size(); O.n_small_long = (u32)lng.size(); O.n_small_chains = (u32)(chains.size() / 2);
+  }
+  up(T.f_ptr.data(), T.f_ptr.size() * 8, (void**)&O.f_ptr);
+  up(T.f_term.data(), T.f_term.size() * 4, (void**)&O.f_term);
+  up(T.f_coef.data(), T.f_coef.size() * sizeof(Fr), (void**)&O.f_coef);
+  up(T.f_kind.data(), T.f_kind.size(), (void**)&O.f_kind);
+  up(T.f_chain.data(), T.f_chain.size(), (void**)&O.f_chain);
+  up(T.f_group.data(), T.f_group.size() * 4, (void**)&O.f_group);
+  up(T.gen_seg.data(), T.gen_seg.size() * 4, (void**)&O.gen_seg);
+  up(T.gen_r.data(), T.gen_r.size() * 4, (void**)&O.gen_r);
+  O.n_gen = (u32)T.gen_seg.size(); O.gen_base = T.gen_base;
+  O.W = W; O.nportions = (u32)((W + 256u * c->x3_k_o0 - 1) / (256u * c->x3_k_o0)); O.small_base = T.small_base; O.fr_base = T.fr_base;
+  O.emails_per_wg = (u32)c->o0_emails_per_wg;
+  O.n_fr_groups = (u32)(T.f_group.size() - 1);
+  if (ok) { ZkO0Tables keep; keep.small_base = T.small_base; keep.fr_base = T.fr_base; keep.gen_base = T.gen_base; keep.n_alias = T.n_alias; keep.n_const = T.n_const; std::swap(T, keep); }
+  return ok;
+}
+static void free_o0(ZkO0Dev& O) {
+  hipFree((void*)O.desc); hipFree((void*)O.s_ptr); hipFree((void*)O.s_term); hipFree((void*)O.s_coef); hipFree((void*)O.s_chain); hipFree((void*)O.s_single); hipFree((void*)O.s_long); hipFree((void*)O.s_chains);
+  hipFree((void*)O.f_ptr); hipFree((void*)O.f_term); hipFree((void*)O.f_coef); hipFree((void*)O.f_kind); hipFree((void*)O.f_chain); hipFree((void*)O.f_group); hipFree((void*)O.gen_seg); hipFree((void*)O.gen_r);
+  memset(&O, 0, sizeof(O));
+}
 extern "C" {
 
 int zkwg_abi_version(void) { return ZKWG_ABI_VERSION; }
@@ -348,47 +397,10 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     }
     if (ok && c->full_W) {
       // numbered circuit: descriptors + row tables on the device (the host copies of the plan are dropped)
-      ZkO0Tables& T = c->o0t;
-      ZkO0Dev& O = c->o0d;
-      auto up = [&](const void* src, size_t bytes, void** dst) {
-        *dst = nullptr;
-        if (!ok) return;
-        ok = hipMalloc(dst, std::max<size_t>(bytes, 16)) == hipSuccess && (bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess);
-      };
-      up(T.desc.data(), T.desc.size() * 4, (void**)&O.desc);
-      up(T.s_ptr.data(), T.s_ptr.size() * 8, (void**)&O.s_ptr);
-      up(T.s_term.data(), T.s_term.size() * 4, (void**)&O.s_term);
-      up(T.s_coef.data(), T.s_coef.size() * 4, (void**)&O.s_coef);
-      up(T.s_chain.data(), T.s_chain.size(), (void**)&O.s_chain);
-      {
-        // small rows: the groups of one row (a thread each) and the chains (a wavefront each)
-        std::vector<u32> single, lng, chains;
-        for (size_t g = 0; g + 1 < T.s_group.size(); ++g) {
-          const u32 a = T.s_group[g], b = T.s_group[g + 1];
-          if (b - a == 1) (T.s_ptr[a + 1] - T.s_ptr[a] > ZK_ROW_LONG ? lng : single).push_back(a); else { chains.push_back(a); chains.push_back(b - a); }
-        }
-        up(single.data(), single.size() * 4, (void**)&O.s_single);
-        up(lng.data(), lng.size() * 4, (void**)&O.s_long);
-        O.n_small_long = (u32)lng.size();
-        up(chains.data(), chains.size() * 4, (void**)&O.s_chains);
-        O.n_small_single = (u32)single.size(); O.n_small_chains = (u32)(chains.size() / 2);
-      }
-      up(T.f_ptr.data(), T.f_ptr.size() * 8, (void**)&O.f_ptr);
-      up(T.f_term.data(), T.f_term.size() * 4, (void**)&O.f_term);
-      up(T.f_coef.data(), T.f_coef.size() * sizeof(Fr), (void**)&O.f_coef);
-      up(T.f_kind.data(), T.f_kind.size(), (void**)&O.f_kind);
-      up(T.f_chain.data(), T.f_chain.size(), (void**)&O.f_chain);
-      up(T.f_group.data(), T.f_group.size() * 4, (void**)&O.f_group);
-      up(T.gen_seg.data(), T.gen_seg.size() * 4, (void**)&O.gen_seg);
-      up(T.gen_r.data(), T.gen_r.size() * 4, (void**)&O.gen_r);
-      O.n_gen = (u32)T.gen_seg.size(); O.gen_base = T.gen_base;
-      O.W = c->full_W; O.nportions = (u32)((c->full_W + 256u * c->x3_k_o0 - 1) / (256u * c->x3_k_o0)); O.small_base = T.small_base; O.fr_base = T.fr_base;
-      O.emails_per_wg = (u32)c->o0_emails_per_wg;
-      O.n_fr_groups = (u32)(T.f_group.size() - 1);
+      ok = upload_o0(c, c->o0t, c->o0d, c->full_W);
       if (ok) {
         ZkLinPlan empty; std::swap(c->lin_host, empty);
         std::vector<u32>().swap(c->o0_desc); std::vector<u32>().swap(c->o0_src); std::vector<u32>().swap(c->o0_long);
-        { ZkO0Tables keep; keep.small_base = T.small_base; keep.fr_base = T.fr_base; keep.n_alias = T.n_alias; keep.n_const = T.n_const; std::swap(T, keep); }
       }
     }
     if (ok && c->s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER) {
@@ -581,8 +593,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (c->device >= 0) {
     hipSetDevice(c->device);
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
-    hipFree((void*)c->o0d.desc); hipFree((void*)c->o0d.s_ptr); hipFree((void*)c->o0d.s_term); hipFree((void*)c->o0d.s_coef); hipFree((void*)c->o0d.s_chain); hipFree((void*)c->o0d.s_single); hipFree((void*)c->o0d.s_long); hipFree((void*)c->o0d.s_chains);
-    hipFree((void*)c->o0d.f_ptr); hipFree((void*)c->o0d.f_term); hipFree((void*)c->o0d.f_coef); hipFree((void*)c->o0d.f_kind); hipFree((void*)c->o0d.f_chain); hipFree((void*)c->o0d.f_group); hipFree((void*)c->o0d.gen_seg); hipFree((void*)c->o0d.gen_r);
+    free_o0(c->o0d); free_o0(c->abcd);
     hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_fn); hipFree(c->d_net_desc);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); if (c->hx_img[i]) hipHostFree(c->hx_img[i]); }
@@ -786,8 +797,7 @@ static void fill_x3(const zkwg_circuit* c, const ZkBufs& B, ZkX3& A) {
 // extensions (zkwg_o0.h).  Launched at the end of zkwg_prepare_device -- so that in a two-stream pipeline they overlap the
 // previous sub-batch's expansion -- or, when the removeSoftLineBreaks chain still writes field elements on its side stream,
 // in front of the expansion that waits for it.
-static void launch_o0_rows(const zkwg_circuit* c, const ZkBufs& B, hipStream_t st) {
-  const ZkO0Dev& O = c->o0d;
+static void launch_o0_rows(const zkwg_circuit* c, const ZkO0Dev& O, const ZkBufs& B, hipStream_t st) {
   ZkX3 A;
   fill_x3(c, B, A);
   const u32 total = B.n_emails - B.e_first;
@@ -905,19 +915,25 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       return ZKWG_RC_OK;
     }
   }
-  if (c->full_W && !(s.rslb && !c->rs_sync)) launch_o0_rows(c, B, st);   // (timed with the last prepare kernel)
+  if (!(s.rslb && !c->rs_sync)) {   // (timed with the last prepare kernel)
+    if (c->full_W) launch_o0_rows(c, c->o0d, B, st);
+    if (c->abc_m) launch_o0_rows(c, c->abcd, B, st);
+  }
   if (tm) { hipEventRecord(evs[++ki], st); c->prep_valid = true; c->prep_launches++; }
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   return ZKWG_RC_OK;
 }
 
 static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const void* d_scratch, uint64_t first,
-                       uint64_t count, void* d_out, uint64_t out_stride, void* hip_stream, bool mont) {
+                       uint64_t count, void* d_out, uint64_t out_stride, void* hip_stream, bool mont, bool abc = false) {
   if (!c || !d_in || !d_out || !d_scratch) return ZKWG_RC_BAD_ARG;
   if (c->device < 0) return ZKWG_RC_NO_DEVICE;
   if (count == 0) return ZKWG_RC_OK;
   const ZkSched& s = c->s;
-  if (first + count > n || out_stride < out_W(c) * 32 || (out_stride & 15)) return ZKWG_RC_BAD_ARG;
+  if (abc && !c->abc_m) return ZKWG_RC_BAD_CONFIG;
+  // the descriptor table written from: the attached system's A.w | B.w | C.w, a numbered circuit's wires, or none (kept-v1 pieces)
+  const ZkO0Dev* OD = abc ? &c->abcd : (c->full_W ? &c->o0d : nullptr);
+  if (first + count > n || out_stride < (abc ? 3 * c->abc_m : out_W(c)) * 32 || (out_stride & 15)) return ZKWG_RC_BAD_ARG;
   if (((uintptr_t)d_scratch & 255) || ((uintptr_t)d_out & 15)) return ZKWG_RC_BAD_ARG;
   std::lock_guard<std::mutex> lock(c->dev_mutex);
   ZkDeviceGuard dg(c->device);
@@ -945,8 +961,8 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
     }
   }
   // sub-launches: the O0 row kernels index emails with blockIdx.y; zk_expand3's grid is pieces x emails
-  u64 sub = c->full_W ? std::min<u64>(count, 32768) : count;
-  { const u64 per = c->full_W ? c->o0d.nportions : c->n_ent; if (per) sub = std::min<u64>(sub, std::max<u64>(1, 0x7fffffffull / per)); }
+  u64 sub = OD ? std::min<u64>(count, 32768) : count;
+  { const u64 per = OD ? OD->nportions : c->n_ent; if (per) sub = std::min<u64>(sub, std::max<u64>(1, 0x7fffffffull / per)); }
   ZkBufs B;
   fill_bufs(c, B, d_in, n, (void*)d_scratch);
   if (s.rslb && !c->rs_sync)   // the merge chain of this scratch buffer may still be running on the side stream
@@ -965,11 +981,11 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
     ZkX3 A;
     fill_x3(c, B, A);
     const u64 conv = cnt * (u64)(s.img_fr + ZK_MONT_LIMBS);
-    if (c->full_W) {
+    if (OD) {
       // numbered circuit (`--O0` / `--O1`), one pass: the rows that are real sums go into the image extensions of these
       // emails, then every wire is written from its descriptor (zkwg_o0.h) -- no staging buffer, no gather
-      const ZkO0Dev& O = c->o0d;
-      if (s.rslb && !c->rs_sync) launch_o0_rows(c, B, st);   // (otherwise zkwg_prepare_device already ran them)
+      const ZkO0Dev& O = *OD;
+      if (s.rslb && !c->rs_sync) launch_o0_rows(c, O, B, st);   // (otherwise zkwg_prepare_device already ran them)
       const u64 units = ((cnt + O.emails_per_wg - 1) / O.emails_per_wg) * (u64)O.nportions;
       if (units > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
       if (mont) hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, A);
@@ -1002,6 +1018,67 @@ int zkwg_expand_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
 int zkwg_expand_montgomery_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const void* d_scratch, uint64_t first,
                                   uint64_t count, void* d_out, uint64_t out_stride, void* hip_stream) {
   return expand_impl(c, d_in, n, d_scratch, first, count, d_out, out_stride, hip_stream, true);
+}
+
+// ---- the first Groth16 prover stage from the compact image -------------------------------------------
+// A.w, B.w, C.w of every constraint are linear combinations over the witness, exactly like the wires of a numbered
+// circuit that are sums of others: the 3 m combinations become one more descriptor table (zkwg_o0.h) over the image --
+// a combination that is one wire copies that wire's descriptor, one of bits / small integers with small coefficients is
+// a 64-bit integer row, the rest are rows mod r -- and zk_expand3_o0 streams them out.  No 32-byte witness is read.
+int zkwg_circuit_attach_r1cs(zkwg_circuit_t* c, const uint8_t* r1cs, uint64_t len) {
+  if (!c || !r1cs) return ZKWG_RC_BAD_ARG;
+  if (c->full_W || c->abc_m) { g_last_error = "attach_r1cs: the handle is a numbered circuit or already has a constraint system"; return ZKWG_RC_BAD_CONFIG; }
+  std::lock_guard<std::mutex> lock(c->dev_mutex);
+  try {
+    ZkR1csHost R;
+    if (!zk_r1cs_parse(r1cs, len, R)) { g_last_error = "the .r1cs file could not be parsed: " + R.err; return ZKWG_RC_BAD_CONFIG; }
+    if (R.n_wires != c->s.W) { g_last_error = "the .r1cs has " + std::to_string(R.n_wires) + " wires, the witness layout " + std::to_string(c->s.W); return ZKWG_RC_BAD_CONFIG; }
+    const u64 m = R.n_constraints;
+    if (3 * m >= 0x7fffffffull) { g_last_error = "too many constraints"; return ZKWG_RC_BAD_CONFIG; }
+    // output order: the A values, then B, then C (zkwg_r1cs_evaluate_device's)
+    ZkLinPlan P;
+    std::vector<u32> desc_slot(3 * m);
+    P.row_ptr.assign(1, 0);
+    P.src.reserve(R.wire.size()); P.coef.reserve(R.wire.size()); P.kind.reserve(R.wire.size());
+    for (u32 which = 0; which < 3; ++which)
+      for (u64 i = 0; i < m; ++i) {
+        const u64 a = R.row_ptr[3 * i + which], b = R.row_ptr[3 * i + which + 1];
+        for (u64 t = a; t < b; ++t) {
+          if (R.wire[t] >= c->s.W) { g_last_error = "the .r1cs names a wire outside the witness"; return ZKWG_RC_BAD_CONFIG; }
+          P.src.push_back(R.wire[t]); P.coef.push_back(fr_from_mont(R.coef[t])); P.kind.push_back(R.kind[t]);
+        }
+        P.row_ptr.push_back(P.src.size());
+        const u64 dst = (u64)which * m + i;
+        P.dst.push_back((u32)dst);
+        desc_slot[dst] = (b - a == 1 && R.kind[a] == ZK_COEF_ONE) ? R.wire[a] : 0xfffffffeu;
+      }
+    std::string err;
+    ZkSched s2 = c->s;   // (the image grows by the row results: committed only when everything succeeded)
+    if (!zk_o0_build(s2, c->segs, P, desc_slot, P.src, c->abct, err)) { g_last_error = err; return ZKWG_RC_BAD_CONFIG; }
+    if (getenv("ZKWG_DEBUG_PLAN"))
+      fprintf(stderr, "[zkwg] A.w|B.w|C.w tables: %llu combinations, %llu single wires, %llu empty, %llu small rows (%llu terms), %llu field rows (%llu terms), %llu pre-decoded slots; image %u -> %u small words, %u -> %u field elements\n",
+              (unsigned long long)(3 * m), (unsigned long long)c->abct.n_alias, (unsigned long long)c->abct.n_const, (unsigned long long)c->abct.n_small(),
+              (unsigned long long)c->abct.s_coef.size(), (unsigned long long)c->abct.n_fr(), (unsigned long long)c->abct.f_kind.size(),
+              (unsigned long long)c->abct.gen_seg.size(), c->s.img_small, s2.img_small, c->s.img_fr, s2.img_fr);
+    if (c->device >= 0) {
+      ZkDeviceGuard dg(c->device);
+      if (!dg.ok) return ZKWG_RC_HIP_ERROR;
+      if (!upload_o0(c, c->abct, c->abcd, 3 * m)) { free_o0(c->abcd); return ZKWG_RC_OOM; }
+    }
+    c->s = s2;
+    c->abc_m = m;
+  } catch (const std::bad_alloc&) {
+    return ZKWG_RC_OOM;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return ZKWG_RC_BAD_CONFIG;
+  }
+  return ZKWG_RC_OK;
+}
+uint64_t zkwg_abc_bytes(const zkwg_circuit_t* c) { return c ? 96 * c->abc_m : 0; }
+int zkwg_expand_abc_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const void* d_scratch, uint64_t first, uint64_t count,
+                           int montgomery, void* d_abc, uint64_t abc_stride, void* hip_stream) {
+  return expand_impl(c, d_in, n, d_scratch, first, count, d_abc, abc_stride, hip_stream, montgomery != 0, true);
 }
 
 int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_out,

@@ -284,6 +284,23 @@ class Circuit:
         _check(self.lib.zkwg_expand_montgomery_device(self.h, d_in.data_ptr(), n, d_scratch.data_ptr(), first, count,
                                                       d_out.data_ptr(), self.witness_bytes, sp))
 
+    def attach_r1cs(self, r1cs):
+        """Attach a constraint system over this handle's witness layout (bytes of an `.r1cs`, or a zkwg.R1cs) so that
+        expand_abc_device can write A.w | B.w | C.w from the compact image (zkwg_circuit_attach_r1cs).  Call it before
+        sizing scratch buffers: the image grows."""
+        data = r1cs.data if isinstance(r1cs, R1cs) else bytes(r1cs)
+        _check(self.lib.zkwg_circuit_attach_r1cs(self.h, data, len(data)))
+
+    @property
+    def abc_bytes(self):
+        return self.lib.zkwg_abc_bytes(self.h)
+
+    def expand_abc_device(self, d_in, n, d_scratch, first, count, d_out, stream=None, montgomery=False, out_stride=None):
+        """A.w | B.w | C.w of emails [first, first + count) of a prepared batch, from the image (zkwg_expand_abc_device)."""
+        sp = stream.cuda_stream if stream is not None else 0
+        _check(self.lib.zkwg_expand_abc_device(self.h, d_in.data_ptr(), n, d_scratch.data_ptr(), first, count, 1 if montgomery else 0,
+                                               d_out.data_ptr(), out_stride or self.abc_bytes, sp))
+
     def scratch_bytes(self, n):
         return self.lib.zkwg_scratch_bytes(self.h, n)
 
@@ -458,6 +475,7 @@ class R1cs:
     def __init__(self, data, device=0):
         self.lib = _lib.load()
         data = bytes(data)
+        self.data = data
         h = C.c_void_p()
         _check(self.lib.zkwg_r1cs_load(data, len(data), device, C.byref(h)))
         self.h = h
