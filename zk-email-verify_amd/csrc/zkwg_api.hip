@@ -174,6 +174,7 @@ static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W) {
   up(T.s_term.data(), T.s_term.size() * 4, (void**)&O.s_term);
   up(T.s_coef.data(), T.s_coef.size() * 4, (void**)&O.s_coef);
   up(T.s_chain.data(), T.s_chain.size(), (void**)&O.s_chain);
+  up(T.s_out.data(), T.s_out.size() * 4, (void**)&O.s_out);
   {
     // small rows: the groups of one row (a thread each, a wavefront for the long ones) and the chains (a wavefront each)
     std::vector<u32> single, lng, chains;
@@ -189,6 +190,7 @@ static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W) {
   up(T.f_ptr.data(), T.f_ptr.size() * 8, (void**)&O.f_ptr);
   up(T.f_term.data(), T.f_term.size() * 4, (void**)&O.f_term);
   up(T.f_coef.data(), T.f_coef.size() * sizeof(Fr), (void**)&O.f_coef);
+  up(T.f_coefm.data(), T.f_coefm.size() * sizeof(Fr), (void**)&O.f_coefm);
   up(T.f_kind.data(), T.f_kind.size(), (void**)&O.f_kind);
   up(T.f_chain.data(), T.f_chain.size(), (void**)&O.f_chain);
   up(T.f_group.data(), T.f_group.size() * 4, (void**)&O.f_group);
@@ -197,13 +199,13 @@ static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W) {
   O.n_gen = (u32)T.gen_seg.size(); O.gen_base = T.gen_base;
   O.W = W; O.nportions = (u32)((W + 256u * c->x3_k_o0 - 1) / (256u * c->x3_k_o0)); O.small_base = T.small_base; O.fr_base = T.fr_base;
   O.emails_per_wg = (u32)c->o0_emails_per_wg;
-  O.n_fr_groups = (u32)(T.f_group.size() - 1);
+  O.n_fr_groups = (u32)T.n_fr();   // (field rows are never chained: one group each)
   if (ok) { ZkO0Tables keep; keep.small_base = T.small_base; keep.fr_base = T.fr_base; keep.gen_base = T.gen_base; keep.n_alias = T.n_alias; keep.n_const = T.n_const; std::swap(T, keep); }
   return ok;
 }
 static void free_o0(ZkO0Dev& O) {
-  hipFree((void*)O.desc); hipFree((void*)O.s_ptr); hipFree((void*)O.s_term); hipFree((void*)O.s_coef); hipFree((void*)O.s_chain); hipFree((void*)O.s_single); hipFree((void*)O.s_long); hipFree((void*)O.s_chains);
-  hipFree((void*)O.f_ptr); hipFree((void*)O.f_term); hipFree((void*)O.f_coef); hipFree((void*)O.f_kind); hipFree((void*)O.f_chain); hipFree((void*)O.f_group); hipFree((void*)O.gen_seg); hipFree((void*)O.gen_r);
+  hipFree((void*)O.desc); hipFree((void*)O.s_ptr); hipFree((void*)O.s_term); hipFree((void*)O.s_coef); hipFree((void*)O.s_chain); hipFree((void*)O.s_out); hipFree((void*)O.s_single); hipFree((void*)O.s_long); hipFree((void*)O.s_chains);
+  hipFree((void*)O.f_ptr); hipFree((void*)O.f_term); hipFree((void*)O.f_coef); hipFree((void*)O.f_coefm); hipFree((void*)O.f_kind); hipFree((void*)O.f_chain); hipFree((void*)O.f_group); hipFree((void*)O.gen_seg); hipFree((void*)O.gen_r);
   memset(&O, 0, sizeof(O));
 }
 extern "C" {
@@ -809,7 +811,7 @@ static void launch_o0_rows(const zkwg_circuit* c, const ZkO0Dev& O, const ZkBufs
     if (O.n_small_single) hipLaunchKernelGGL(zk_o0_rows_small, dim3((O.n_small_single + 255) / 256, (cnt + ZK_ROW_EMAILS - 1) / ZK_ROW_EMAILS), dim3(256), 0, st, A, O);
     if (O.n_small_long) hipLaunchKernelGGL(zk_o0_rows_small_long, dim3((O.n_small_long + 3) / 4, (cnt + ZK_ROW_EMAILS - 1) / ZK_ROW_EMAILS), dim3(256), 0, st, A, O);
     if (O.n_small_chains) hipLaunchKernelGGL(zk_o0_chains_small, dim3(O.n_small_chains, cnt), dim3(64), 0, st, A, O);
-    if (O.n_fr_groups) hipLaunchKernelGGL(zk_o0_rows_fr, dim3((O.n_fr_groups * ZK_FR_LANES + 255) / 256, cnt), dim3(256), 0, st, A, O);
+    if (O.n_fr_groups) hipLaunchKernelGGL(zk_o0_rows_fr, dim3((O.n_fr_groups * ZK_FR_LANES + 255) / 256, (cnt + ZK_FR_EMAILS - 1) / ZK_FR_EMAILS), dim3(256), 0, st, A, O);
   }
 }
 

@@ -30,6 +30,7 @@ __global__ void zk_o0_chains_small(ZkX3 A, ZkO0Dev O);
 __global__ void zk_o0_generic(ZkX3 A, ZkO0Dev O);
 __global__ void zk_o0_rows_small_long(ZkX3 A, ZkO0Dev O);
 #define ZK_ROW_EMAILS 8   // emails per thread of zk_o0_rows_small
+#define ZK_FR_EMAILS 4    // emails per lane of zk_o0_rows_fr
 __global__ void zk_o0_rows_fr(ZkX3 A, ZkO0Dev O);
 __global__ void zk_mont_convert(Fr* v, u64 n, int to_mont);  // zkwg_kernels_handoff.hip
 __global__ void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8* recs, int* gen_status, u32 n);  // zkwg_kernels_inputs.hip

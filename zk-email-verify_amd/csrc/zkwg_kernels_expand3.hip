@@ -55,6 +55,30 @@ __device__ __forceinline__ uint4 zk_slot_half(u32 code, u32 hf, const ZkX3& A, c
     if (t == 0u) return R.frv[2u * p + hf];                                       // Montgomery copy of the image's fr
     if (t == 1u) return R.invtab[2u * p + hf];                                    // Montgomery inverse table
     if (t == 2u) return R.frv[2u * (A.img_fr + ((p - A.limb_off) >> 4)) + hf];    // converted limb
+    // integers of the image (RAW / NEG / I64: results of integer rows, negative small values): |v| < 2^16 -> the table,
+    // r - table[|v|] for a negative one (the A.w / B.w / C.w of bit constraints are full of -1 and -2)
+    {
+      const u32 w = R.small[p];
+      long long v;
+      if (t == 3u) v = (long long)w; else if (t == 4u) v = (long long)((int)(w << 1) >> 1); else v = (long long)((u64)w | ((u64)R.small[p + 1] << 32));
+      const u64 m = v < 0 ? (u64)(-v) : (u64)v;
+      if (m < 65536u) {
+        const uint4* tb = (const uint4*)A.rtab + 2u * (u32)m;
+        if (v >= 0) return tb[hf];
+        // r - x, x = m R mod r, 0 < x < r: low half with its borrow, high half minus that borrow
+        const uint4 xl = tb[0];
+        const u64 x0 = (u64)xl.x | ((u64)xl.y << 32), x1 = (u64)xl.z | ((u64)xl.w << 32);
+        const u64 r0 = ZK_P0, r1 = ZK_P1, r2 = ZK_P2, r3 = ZK_P3;
+        const u64 d0 = r0 - x0, b0 = r0 < x0 ? 1ull : 0ull;
+        const u64 d1 = r1 - x1 - b0, b1 = (r1 < x1 || (r1 == x1 && b0)) ? 1ull : 0ull;
+        if (!hf) return make_uint4((u32)d0, (u32)(d0 >> 32), (u32)d1, (u32)(d1 >> 32));
+        const uint4 xh = tb[1];
+        const u64 x2 = (u64)xh.x | ((u64)xh.y << 32), x3 = (u64)xh.z | ((u64)xh.w << 32);
+        const u64 d2 = r2 - x2 - b1, b2 = (r2 < x2 || (r2 == x2 && b1)) ? 1ull : 0ull;
+        const u64 d3 = r3 - x3 - b2;
+        return make_uint4((u32)d2, (u32)(d2 >> 32), (u32)d3, (u32)(d3 >> 32));
+      }
+    }
     return zk_mont_slow(code, hf, A, R);
   }
 }
@@ -166,10 +190,12 @@ __device__ __forceinline__ u32 zk_desc_decode(u32 a, u32 b, const ZkCtx& cx, con
   switch (a >> 28) {
     case ZK_D_IMM: return b;
     case ZK_D_BIT64: return (u32)(cx.bits[b] >> (a & 63u)) & 1u;
+    case ZK_D_BITRUN: return (u32)(cx.bits[b] >> (a & 63u)) & ((2u << ((a >> 6) & 31u)) - 1u);
     case ZK_D_BIT8: return (u32)(cx.rec[b] >> (a & 7u)) & 1u;
     case ZK_D_BYTE: return cx.rec[b];
     case ZK_D_SMALLRAW: return zk_raw_code(cx.small[b], b);
     case ZK_D_CODEW: return cx.small[b];
+    case ZK_D_SMALLN: { const u32 w = cx.small[b]; return (w >> 31) ? (ZK_REF_NEG | b) : w; }
     case ZK_D_SMALLS: { const u32 lo = cx.small[b], hi = cx.small[b + 1]; return (hi == 0u && !(lo >> 31)) ? lo : (ZK_REF_I64 | b); }
     case ZK_D_DFA: return zk_dfa_value((a >> 24) & 15u, (a >> 9) & 0x7ffu, (a >> 20) & 15u, a & 511u, b, cx.small + cx.m_dfa_st, cx.small + cx.m_dfa_cm, cx.small + cx.m_dfa_pm, cx.half);
     default: return 0u;   // (no wire keeps kind GENERIC: zk_o0_build turns them into CODEW)
@@ -182,9 +208,9 @@ struct ZkO0Pre { u32 i64, i8, i32, i32b; };
 __device__ __forceinline__ ZkO0Pre zk_o0_pre(uint2 d, const ZkX3& A) {
   ZkO0Pre p{0u, 0u, 0u, 0u};
   switch (d.x >> 28) {
-    case ZK_D_BIT64: p.i64 = d.y; break;
+    case ZK_D_BIT64: case ZK_D_BITRUN: p.i64 = d.y; break;
     case ZK_D_BIT8: case ZK_D_BYTE: p.i8 = d.y; break;
-    case ZK_D_SMALLRAW: case ZK_D_CODEW: p.i32 = d.y; break;
+    case ZK_D_SMALLRAW: case ZK_D_CODEW: case ZK_D_SMALLN: p.i32 = d.y; break;
     case ZK_D_SMALLS: p.i32 = d.y; p.i32b = d.y + 1u; break;
     case ZK_D_DFA: {
       const u32 dk = (d.x >> 24) & 15u, i = (d.x >> 9) & 0x7ffu;
@@ -201,10 +227,12 @@ __device__ __forceinline__ u32 zk_o0_combine(uint2 d, const ZkO0Pre& p, u64 w64,
   switch (a >> 28) {
     case ZK_D_IMM: return b;
     case ZK_D_BIT64: return (u32)(w64 >> (a & 63u)) & 1u;
+    case ZK_D_BITRUN: return (u32)(w64 >> (a & 63u)) & ((2u << ((a >> 6) & 31u)) - 1u);
     case ZK_D_BIT8: return (w8 >> (a & 7u)) & 1u;
     case ZK_D_BYTE: return w8;
     case ZK_D_SMALLRAW: return zk_raw_code(w32, b);
     case ZK_D_CODEW: return w32;
+    case ZK_D_SMALLN: return (w32 >> 31) ? (ZK_REF_NEG | b) : w32;
     case ZK_D_SMALLS: return (w32b == 0u && !(w32 >> 31)) ? w32 : (ZK_REF_I64 | b);
     case ZK_D_DFA: return zk_dfa_value_w((a >> 24) & 15u, (a >> 20) & 15u, a & 511u, b, w32, w32b, half);
     default: return 0u;
@@ -290,25 +318,50 @@ __device__ __forceinline__ void zk_row_accumulate(const ZkX3& A, const ZkO0Dev& 
   for (u64 t = O.s_ptr[j] + first; t < t1; t += step) {
     const uint2 d = O.s_term[t];
     const long long cf = (long long)O.s_coef[t];
-    const ZkO0Pre pre = zk_o0_pre(d, A);
-    u64 w64[ZK_ROW_EMAILS]; u32 w8[ZK_ROW_EMAILS], w32[ZK_ROW_EMAILS], w32b[ZK_ROW_EMAILS];
+    // (neighbouring rows have the same shape, so the kinds are all but uniform over a wavefront: each kind issues only
+    // the loads it needs, for all the emails back to back)
+    const u32 kind = d.x >> 28;
+    if (kind == ZK_D_BIT64 || kind == ZK_D_BITRUN) {
+      u64 w[ZK_ROW_EMAILS];
 #pragma unroll
-    for (int k = 0; k < ZK_ROW_EMAILS; ++k) {
-      const ZkCtx cx = zk_x3_ctx(A, A.e_first + min(el0 + (u32)k, last));
-      w64[k] = cx.bits[pre.i64]; w8[k] = cx.rec[pre.i8]; w32[k] = cx.small[pre.i32]; w32b[k] = cx.small[pre.i32b];
-    }
+      for (int k = 0; k < ZK_ROW_EMAILS; ++k) w[k] = A.bits[(u64)(A.e_first + min(el0 + (u32)k, last)) * A.img_bits + d.y];
+      const u32 mask = kind == ZK_D_BIT64 ? 1u : (2u << ((d.x >> 6) & 31u)) - 1u;
 #pragma unroll
-    for (int k = 0; k < ZK_ROW_EMAILS; ++k) {
-      const ZkCtx cx = zk_x3_ctx(A, A.e_first + min(el0 + (u32)k, last));
-      acc[k] += cf * zk_code_int(zk_o0_combine(d, pre, w64[k], w8[k], w32[k], w32b[k], cx.half), cx);
+      for (int k = 0; k < ZK_ROW_EMAILS; ++k) acc[k] += cf * (long long)((u32)(w[k] >> (d.x & 63u)) & mask);
+    } else if (kind == ZK_D_IMM) {
+#pragma unroll
+      for (int k = 0; k < ZK_ROW_EMAILS; ++k) acc[k] += cf * (long long)d.y;   // (a reference is never small-ranged)
+    } else if (kind == ZK_D_BIT8 || kind == ZK_D_BYTE) {
+      u32 w[ZK_ROW_EMAILS];
+#pragma unroll
+      for (int k = 0; k < ZK_ROW_EMAILS; ++k) w[k] = A.in[(u64)(A.e_first + min(el0 + (u32)k, last)) * A.in_stride + d.y];
+#pragma unroll
+      for (int k = 0; k < ZK_ROW_EMAILS; ++k) acc[k] += cf * (long long)(kind == ZK_D_BYTE ? w[k] : (w[k] >> (d.x & 7u)) & 1u);
+    } else {
+      const ZkO0Pre pre = zk_o0_pre(d, A);
+      u32 w32[ZK_ROW_EMAILS], w32b[ZK_ROW_EMAILS];
+#pragma unroll
+      for (int k = 0; k < ZK_ROW_EMAILS; ++k) {
+        const u32* sm = A.small + (u64)(A.e_first + min(el0 + (u32)k, last)) * A.img_small;
+        w32[k] = sm[pre.i32]; w32b[k] = sm[pre.i32b];
+      }
+#pragma unroll
+      for (int k = 0; k < ZK_ROW_EMAILS; ++k) {
+        const ZkCtx cx = zk_x3_ctx(A, A.e_first + min(el0 + (u32)k, last));
+        acc[k] += cf * zk_code_int(zk_o0_combine(d, pre, 0ull, 0u, w32[k], w32b[k], cx.half), cx);
+      }
     }
   }
 }
+__device__ __forceinline__ void zk_row_put(u32* __restrict__ small_e, u32 where, long long v) {
+  if (where >> 31) *(uint2*)(small_e + (where & 0x7fffffffu)) = make_uint2((u32)(u64)v, (u32)((u64)v >> 32));
+  else small_e[where] = (u32)(u64)v;   // (range within +-2^30: bit 31 is the sign)
+}
 __device__ __forceinline__ void zk_row_store(const ZkX3& A, const ZkO0Dev& O, u32 j, u32 el0, const long long acc[ZK_ROW_EMAILS]) {
+  const u32 where = O.s_out[j];
 #pragma unroll
   for (int k = 0; k < ZK_ROW_EMAILS; ++k)
-    if (el0 + (u32)k < A.n_count)
-      *(uint2*)(A.small_w + (u64)(A.e_first + el0 + k) * A.img_small + O.small_base + 2u * j) = make_uint2((u32)(u64)acc[k], (u32)((u64)acc[k] >> 32));
+    if (el0 + (u32)k < A.n_count) zk_row_put(A.small_w + (u64)(A.e_first + el0 + k) * A.img_small, where, acc[k]);
 }
 __global__ __launch_bounds__(256) void zk_o0_rows_small(ZkX3 A, ZkO0Dev O) {
   const u32 i = blockIdx.x * 256u + threadIdx.x;
@@ -342,19 +395,35 @@ __global__ __launch_bounds__(64) void zk_o0_chains_small(ZkX3 A, ZkO0Dev O) {
   const uint2 ch = O.s_chains[blockIdx.x];
   const u32 e = A.e_first + blockIdx.y, lane = threadIdx.x;
   const ZkCtx cx = zk_x3_ctx(A, e);
-  u32* out = A.small_w + (u64)e * A.img_small + O.small_base;
+  u32* out = A.small_w + (u64)e * A.img_small;
   long long carry = 0;
+  // the first row carries the whole sum so far (up to 1,625 terms in EmailVerifier's constraint system): when it is long
+  // the lanes share its terms instead of leaving them to lane 0
+  const u64 h0 = O.s_ptr[ch.x], h1 = O.s_ptr[ch.x + 1];
+  const bool coop = h1 - h0 > 32u;
+  long long head = 0;
+  if (coop) {
+    for (u64 t = h0 + lane; t < h1; t += 64u) {
+      const uint2 d = O.s_term[t];
+      head += (long long)O.s_coef[t] * zk_code_int(zk_desc_decode(d.x, d.y, cx, A.segs), cx);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const u32 lo = __shfl_xor((u32)(u64)head, d), hi = __shfl_xor((u32)((u64)head >> 32), d);
+      head += (long long)((u64)lo | ((u64)hi << 32));
+    }
+  }
   for (u32 base = 0; base < ch.y; base += 64u) {
     const bool live = base + lane < ch.y;
     const u32 j = ch.x + base + lane;
-    long long v = live ? zk_small_row_terms(O, j, cx, A.segs) : 0;
+    long long v = !live ? 0 : (coop && base + lane == 0u) ? head : zk_small_row_terms(O, j, cx, A.segs);
 #pragma unroll
     for (u32 d = 1; d < 64u; d <<= 1) {
       const u32 lo = __shfl_up((u32)(u64)v, d), hi = __shfl_up((u32)((u64)v >> 32), d);
       if (lane >= d) v += (long long)((u64)lo | ((u64)hi << 32));
     }
     v += carry;
-    if (live) { out[2u * j] = (u32)(u64)v; out[2u * j + 1u] = (u32)((u64)v >> 32); }
+    if (live) zk_row_put(out, O.s_out[j], v);
     carry = (long long)((u64)(u32)__shfl((u32)(u64)v, 63) | ((u64)(u32)__shfl((u32)((u64)v >> 32), 63) << 32));
   }
 }
@@ -364,54 +433,65 @@ __device__ __forceinline__ Fr zk_code_value(u32 code, const ZkRefSrc& R) {
   const uint4 a = zk_ref_half(code, 0u, R), b = zk_ref_half(code, 1u, R);
   return Fr{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
 }
-// 8 lanes per group: the lanes split each row's terms, the partial sums are folded with shuffles, lane 0 carries a
-// chain's running value from row to row
+// 8 lanes per row and ZK_FR_EMAILS emails per lane: the lanes split the row's terms; per term the descriptor, kind and
+// coefficient are read once and the image loads of all the emails are issued back to back (the kernel is a chain of
+// dependent loads: what counts is how many are in flight); the partial sums are folded with shuffles
 #define ZK_FR_LANES 8u
 __global__ __launch_bounds__(256) void zk_o0_rows_fr(ZkX3 A, ZkO0Dev O) {
-  const u32 g = blockIdx.x * (256u / ZK_FR_LANES) + threadIdx.x / ZK_FR_LANES, l = threadIdx.x % ZK_FR_LANES;
-  const bool live = g < O.n_fr_groups;
-  const u32 e = A.e_first + blockIdx.y;
-  const ZkCtx cx = zk_x3_ctx(A, e);
-  ZkRefSrc R;
-  R.frv = (const uint4*)(A.frv + (u64)e * A.img_fr);
-  R.invtab = (const uint4*)A.invtab;
-  R.rec = cx.rec; R.small = cx.small;
-  const u32 j0 = live ? O.f_group[g] : 0u, j1 = live ? O.f_group[g + 1] : 0u;
-  // every lane of the wavefront runs the same number of rounds (shuffles inside): the longest group of the wavefront
-  u32 rows = j1 - j0;
+  const u32 j = blockIdx.x * (256u / ZK_FR_LANES) + threadIdx.x / ZK_FR_LANES, l = threadIdx.x % ZK_FR_LANES;
+  const bool live = j < O.n_fr_groups;
+  const u32 el0 = blockIdx.y * ZK_FR_EMAILS, last = A.n_count - 1u;
+  Fr acc[ZK_FR_EMAILS];
 #pragma unroll
-  for (u32 d = 32; d >= ZK_FR_LANES; d >>= 1) rows = max(rows, (u32)__shfl_xor((int)rows, (int)d));
-  Fr run = fr_zero();
-  for (u32 q = 0; q < rows; ++q) {
-    const u32 j = j0 + q;
-    const bool on = j < j1;
-    Fr acc = fr_zero();
-    if (on)
-      for (u64 t = O.f_ptr[j] + l; t < O.f_ptr[j + 1]; t += ZK_FR_LANES) {
-        const uint2 d = O.f_term[t];
-        const Fr x = zk_code_value(zk_desc_decode(d.x, d.y, cx, A.segs), R);
-        const u8 k = O.f_kind[t];
-        if (k == ZK_COEF_ONE) acc = fr_add(acc, x);
-        else if (k == ZK_COEF_MINUS_ONE) acc = fr_sub(acc, x);
-        else if (!fr_is_zero(x)) {
-          // generic coefficient (powers of two of Bits2Num ...): the operand is almost always a bit
-          const bool one = x.l[0] == 1 && (x.l[1] | x.l[2] | x.l[3]) == 0;
-          acc = fr_add(acc, one ? O.f_coef[t] : fr_mont_mul(fr_to_mont(x), O.f_coef[t]));
-        }
+  for (int k = 0; k < ZK_FR_EMAILS; ++k) acc[k] = fr_zero();
+  if (live) {
+    const u64 t1 = O.f_ptr[j + 1];
+    for (u64 t = O.f_ptr[j] + l; t < t1; t += ZK_FR_LANES) {
+      const uint2 d = O.f_term[t];
+      const u8 kd = O.f_kind[t];
+      const ZkO0Pre pre = zk_o0_pre(d, A);
+      u64 w64[ZK_FR_EMAILS]; u32 w8[ZK_FR_EMAILS], w32[ZK_FR_EMAILS], w32b[ZK_FR_EMAILS];
+#pragma unroll
+      for (int k = 0; k < ZK_FR_EMAILS; ++k) {
+        const ZkCtx cx = zk_x3_ctx(A, A.e_first + min(el0 + (u32)k, last));
+        w64[k] = cx.bits[pre.i64]; w8[k] = cx.rec[pre.i8]; w32[k] = cx.small[pre.i32]; w32b[k] = cx.small[pre.i32b];
       }
+      Fr cf = fr_zero(), cfm = fr_zero();   // the coefficient, and its Montgomery form (x * cf = mont_mul(x, cf R))
+      if (kd != ZK_COEF_ONE && kd != ZK_COEF_MINUS_ONE) { cf = O.f_coef[t]; cfm = O.f_coefm[t]; }
+#pragma unroll
+      for (int k = 0; k < ZK_FR_EMAILS; ++k) {
+        const u32 e = A.e_first + min(el0 + (u32)k, last);
+        const ZkCtx cx = zk_x3_ctx(A, e);
+        const u32 code = zk_o0_combine(d, pre, w64[k], w8[k], w32[k], w32b[k], cx.half);
+        if (code == 0u) continue;
+        Fr x;
+        if (!(code >> 31)) x = Fr{{(u64)code, 0, 0, 0}};
+        else {
+          ZkRefSrc R;
+          R.frv = (const uint4*)(A.frv + (u64)e * A.img_fr);
+          R.invtab = (const uint4*)A.invtab;
+          R.rec = cx.rec; R.small = cx.small;
+          x = zk_code_value(code, R);
+        }
+        if (kd == ZK_COEF_ONE) acc[k] = fr_add(acc[k], x);
+        else if (kd == ZK_COEF_MINUS_ONE) acc[k] = fr_sub(acc[k], x);
+        else if (code == 1u) acc[k] = fr_add(acc[k], cf);   // (powers of two of Bits2Num ...: the operand is almost always a bit)
+        else if (!fr_is_zero(x)) acc[k] = fr_add(acc[k], fr_mont_mul(x, cfm));
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ZK_FR_EMAILS; ++k) {
 #pragma unroll
     for (u32 off = ZK_FR_LANES / 2; off >= 1; off >>= 1) {
       Fr o;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const u32 lo = __shfl_down((u32)acc.l[i], off, ZK_FR_LANES), hi = __shfl_down((u32)(acc.l[i] >> 32), off, ZK_FR_LANES);
+        const u32 lo = __shfl_down((u32)acc[k].l[i], off, ZK_FR_LANES), hi = __shfl_down((u32)(acc[k].l[i] >> 32), off, ZK_FR_LANES);
         o.l[i] = (u64)lo | ((u64)hi << 32);
       }
-      acc = fr_add(acc, o);
+      acc[k] = fr_add(acc[k], o);
     }
-    if (on && l == 0) {
-      run = O.f_chain[j] ? fr_add(run, acc) : acc;
-      A.frv_w[(u64)e * A.img_fr + O.fr_base + j] = run;
-    }
+    if (live && l == 0 && el0 + (u32)k <= last) A.frv_w[(u64)(A.e_first + el0 + k) * A.img_fr + O.fr_base + j] = acc[k];
   }
 }

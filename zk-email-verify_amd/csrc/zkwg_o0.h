@@ -28,6 +28,8 @@ enum ZkDescKind : u32 {
   ZK_D_SMALLRAW = 4,  // small[b], raw 32-bit value
   ZK_D_SMALLS = 5,    // (small[b], small[b+1]) as a signed 64-bit integer v (results of small rows): 0 <= v < 2^31 -> v, else the field element v mod r
   ZK_D_GENERIC = 6,   // slot b of kept-v1 segment (a & 0xffffff): decoded by the segment's own arithmetic
+  ZK_D_SMALLN = 9,    // small[b] as a signed integer of 31 bits (results of small rows whose range is that narrow): bit 31 clear -> the value, set -> r - |v|
+  ZK_D_BITRUN = 10,   // row terms only: bits (a & 63) .. (a & 63) + ((a >> 6) & 31) of bits[b] as an integer (a run of a Bits2Num sum)
   ZK_D_CODEW = 8,     // small[b] holds the wire's code itself (left there by zk_o0_generic for the wires of kind GENERIC)
   ZK_D_DFA = 7        // BodyHashRegex DFA array element: a = kind << 28 | ZkDfaKind << 24 | q << 20 | position << 9 | param b, b = param c
 };
@@ -48,8 +50,10 @@ struct ZkO0Tables {
   // terms it adds and continues from its predecessor's result.
   // small rows: result j -> small[small_base + 2 j .. +2) as a signed 64-bit integer
   std::vector<u64> s_ptr; std::vector<u32> s_term; std::vector<int32_t> s_coef; std::vector<u8> s_chain; std::vector<u32> s_group;
+  std::vector<u32> s_out;     // per small row: word of `small` holding its result | bit 31: two words (64-bit integer)
+  u64 n_narrow = 0;
   // field rows: result j -> fr[fr_base + j]
-  std::vector<u64> f_ptr; std::vector<u32> f_term; std::vector<Fr> f_coef; std::vector<u8> f_kind; std::vector<u8> f_chain; std::vector<u32> f_group;
+  std::vector<u64> f_ptr; std::vector<u32> f_term; std::vector<Fr> f_coef, f_coefm; std::vector<u8> f_kind; std::vector<u8> f_chain; std::vector<u32> f_group;
   u64 n_small() const { return s_ptr.empty() ? 0 : s_ptr.size() - 1; }
   u64 n_fr() const { return f_ptr.empty() ? 0 : f_ptr.size() - 1; }
   u64 n_alias = 0, n_const = 0, terms_before_chaining = 0;
@@ -145,6 +149,7 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
   // the previous row of each class in full (chain detection)
   std::vector<u32> prev_s_t, prev_f_t; std::vector<int32_t> prev_s_c; std::vector<Fr> prev_f_c;
   std::vector<u32> td; std::vector<int32_t> cs;
+  std::vector<u32> s_dst;   // wire written by each small row
   const size_t CHAIN_MIN = 4;   // shorter shared prefixes are cheaper to recompute than to serialise
   for (u64 r = 0; r < P.n_rows(); ++r) {
     const u64 a = P.row_ptr[r], b = P.row_ptr[r + 1];
@@ -173,8 +178,30 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
       if (lo < -((__int128)1 << 62) || hi > ((__int128)1 << 62)) small = false;
       cs.push_back((int32_t)k);
     }
-    const size_t nt = b - a;
-    T.terms_before_chaining += nt;
+    T.terms_before_chaining += b - a;
+    std::vector<Fr> fc;   // field rows: coefficients in standard form, like zk_linear_row; kinds
+    std::vector<u8> fk;
+    if (!small) { fc.assign(P.coef.begin() + a, P.coef.begin() + b); fk.assign(P.kind.begin() + a, P.kind.begin() + b); }
+    {
+      // runs: consecutive terms that read consecutive bits of one word of `bits` with doubling coefficients -- the
+      // Sum 2^k b_k of Bits2Num / Num2Bits, most of the terms of a constraint system -- become one term: the bit field as an
+      // integer (up to 31 bits) times the first coefficient
+      const size_t n0 = b - a;
+      size_t o = 0;
+      for (size_t i = 0; i < n0;) {
+        size_t j = i;
+        if ((td[2 * i] >> 28) == ZK_D_BIT64)
+          while (j + 1 < n0 && j + 1 - i < 31 && td[2 * (j + 1)] == td[2 * j] + 1u && td[2 * (j + 1) + 1] == td[2 * i + 1] &&
+                 (small ? (cs[j + 1] == 2 * cs[j]) : fr_eq(fr_add(fc[j], fc[j]), fc[j + 1]))) ++j;
+        td[2 * o] = j > i ? (((u32)ZK_D_BITRUN << 28) | ((u32)(j - i) << 6) | (td[2 * i] & 63u)) : td[2 * i];
+        td[2 * o + 1] = td[2 * i + 1];
+        if (small) cs[o] = cs[i]; else { fc[o] = fc[i]; fk[o] = fk[i]; }
+        ++o; i = j + 1;
+      }
+      td.resize(2 * o);
+      if (small) cs.resize(o); else { fc.resize(o); fk.resize(o); }
+    }
+    const size_t nt = td.size() / 2;
     // chained: every term of the previous row of the class (same source, same coefficient) is also a term of this one, in
     // the same order -- the row then only lists the others and continues from its predecessor's result.  `rest` = the
     // indices of this row's own terms.
@@ -196,13 +223,18 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
       T.s_chain.push_back(ch ? 1 : 0);
       if (!ch) T.s_group.push_back((u32)T.n_small());
       T.s_ptr.push_back(T.s_coef.size());
-      T.desc[2 * dst] = ZK_D_SMALLS << 28; T.desc[2 * dst + 1] = T.small_base + 2u * (u32)(T.s_ptr.size() - 2);
+      // one word when the row's range allows it (most rows: sums of a few bits) -- half the traffic of the row results;
+      // the offsets are known once all rows are counted (patched below)
+      const bool narrow = lo >= -((__int128)1 << 30) && hi < ((__int128)1 << 30);
+      T.s_out.push_back(narrow ? 0u : 0x80000000u); s_dst.push_back(dst);
+      if (narrow) ++T.n_narrow;
       prev_s_t = td; prev_s_c = cs;
     } else {
-      std::vector<Fr> fc(P.coef.begin() + a, P.coef.begin() + b);   // standard form, like zk_linear_row
-      const bool ch = subseq(prev_f_t, prev_f_c.size(), [&](size_t q, size_t i) { return fr_eq(prev_f_c[q], fc[i]); });
+      // (field rows are not chained: none of EmailVerifier's continues its predecessor, and zk_o0_rows_fr then needs no
+      // running value -- its registers go to the emails it handles at once)
+      const bool ch = false;
       if (!ch) { rest.resize(nt); for (size_t i = 0; i < nt; ++i) rest[i] = (u32)i; }
-      for (u32 i : rest) { T.f_term.push_back(td[2 * i]); T.f_term.push_back(td[2 * i + 1]); T.f_coef.push_back(fc[i]); T.f_kind.push_back(P.kind[a + i]); }
+      for (u32 i : rest) { T.f_term.push_back(td[2 * i]); T.f_term.push_back(td[2 * i + 1]); T.f_coef.push_back(fc[i]); T.f_coefm.push_back(fr_to_mont(fc[i])); T.f_kind.push_back(fk[i]); }
       T.f_chain.push_back(ch ? 1 : 0);
       if (!ch) T.f_group.push_back((u32)T.n_fr());
       T.f_ptr.push_back(T.f_kind.size());
@@ -212,17 +244,50 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
   }
   T.s_group.push_back((u32)T.n_small());
   T.f_group.push_back((u32)T.n_fr());
+  {
+    // [narrow results, one word each | wide results, two words each (8-byte aligned)]
+    u32 nn = 0, nw = 0;
+    const u32 wide_base = T.small_base + (u32)((T.n_narrow + 1u) & ~1ull);
+    for (size_t j = 0; j < s_dst.size(); ++j) {
+      const bool wide = T.s_out[j] >> 31;
+      const u32 off = wide ? wide_base + 2u * nw++ : T.small_base + nn++;
+      T.s_out[j] = (wide ? 0x80000000u : 0u) | off;
+      T.desc[2 * (u64)s_dst[j]] = (u32)(wide ? ZK_D_SMALLS : ZK_D_SMALLN) << 28; T.desc[2 * (u64)s_dst[j] + 1] = off;
+    }
+  }
+  const u64 small_words = ((T.n_narrow + 1u) & ~1ull) + 2 * (T.n_small() - T.n_narrow);
   if (getenv("ZKWG_DEBUG_PLAN")) {
-    u64 kinds[8] = {0}, by_type[ZSEG_NTYPES + 1] = {0};
-    for (u64 w = 0; w < W; ++w) { const u32 k = T.desc[2 * w] >> 28; ++kinds[k == ZK_D_CODEW ? 6 : (k & 7)]; }
+    // chains: rows per chain, terms of the head row, terms the other rows add
+    u64 nch = 0, max_rows = 0, max_head = 0, tot_rows = 0, tot_head = 0, tot_rest = 0, max_rest = 0, hist[6] = {0};
+    for (size_t g = 0; g + 1 < T.s_group.size(); ++g) {
+      const u32 a = T.s_group[g], b = T.s_group[g + 1];
+      if (b - a == 1) continue;
+      ++nch; tot_rows += b - a; max_rows = std::max<u64>(max_rows, b - a);
+      const u64 head = T.s_ptr[a + 1] - T.s_ptr[a];
+      tot_head += head; max_head = std::max(max_head, head);
+      for (u32 j = a + 1; j < b; ++j) { const u64 n = T.s_ptr[j + 1] - T.s_ptr[j]; tot_rest += n; max_rest = std::max(max_rest, n); }
+      ++hist[b - a <= 4 ? 0 : b - a <= 16 ? 1 : b - a <= 64 ? 2 : b - a <= 256 ? 3 : b - a <= 1024 ? 4 : 5];
+    }
+    fprintf(stderr, "[zkwg] small chains: %llu (rows %llu, longest %llu; head terms %llu, longest %llu; added terms %llu, most per row %llu); chains of <=4/16/64/256/1024/more rows: %llu %llu %llu %llu %llu %llu; narrow results %llu of %llu\n",
+            (unsigned long long)nch, (unsigned long long)tot_rows, (unsigned long long)max_rows, (unsigned long long)tot_head, (unsigned long long)max_head,
+            (unsigned long long)tot_rest, (unsigned long long)max_rest, (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2],
+            (unsigned long long)hist[3], (unsigned long long)hist[4], (unsigned long long)hist[5], (unsigned long long)T.n_narrow, (unsigned long long)T.n_small());
+    u64 fh[6] = {0}, fone = 0, fmone = 0, fgen = 0;
+    for (size_t j = 0; j + 1 < T.f_ptr.size(); ++j) { const u64 n = T.f_ptr[j + 1] - T.f_ptr[j]; ++fh[n <= 4 ? 0 : n <= 16 ? 1 : n <= 64 ? 2 : n <= 256 ? 3 : n <= 1024 ? 4 : 5]; }
+    for (u8 k : T.f_kind) (k == ZK_COEF_ONE ? fone : k == ZK_COEF_MINUS_ONE ? fmone : fgen)++;
+    fprintf(stderr, "[zkwg] field rows of <=4/16/64/256/1024/more terms: %llu %llu %llu %llu %llu %llu; coefficients +1 %llu, -1 %llu, other %llu\n",
+            (unsigned long long)fh[0], (unsigned long long)fh[1], (unsigned long long)fh[2], (unsigned long long)fh[3], (unsigned long long)fh[4], (unsigned long long)fh[5],
+            (unsigned long long)fone, (unsigned long long)fmone, (unsigned long long)fgen);
+    u64 kinds[16] = {0}, by_type[ZSEG_NTYPES + 1] = {0};
+    for (u64 w = 0; w < W; ++w) { const u32 k = T.desc[2 * w] >> 28; ++kinds[k == ZK_D_CODEW ? 6 : (k == ZK_D_SMALLN ? 5 : k)]; }
     for (u32 sg : T.gen_seg) ++by_type[segs[sg].type];
     fprintf(stderr, "[zkwg] O0 descriptors: imm %llu bit64 %llu bit8 %llu byte %llu smallraw %llu smalls %llu dfa %llu generic %llu; generic by segment type:",
             (unsigned long long)kinds[0], (unsigned long long)kinds[1], (unsigned long long)kinds[2], (unsigned long long)kinds[3], (unsigned long long)kinds[4], (unsigned long long)kinds[5], (unsigned long long)kinds[7], (unsigned long long)kinds[6]);
     for (u32 t = 0; t <= ZSEG_NTYPES; ++t) if (by_type[t]) fprintf(stderr, " %u:%llu", t, (unsigned long long)by_type[t]);
     fprintf(stderr, "\n");
   }
-  if ((u64)T.small_base + 2 * T.n_small() >= (1u << 28) || (u64)T.fr_base + T.n_fr() >= (1u << 28)) { err = "circuit too large for the O0 row tables"; return false; }
-  s.img_small = (u32)((T.small_base + 2 * T.n_small() + 3u) & ~3ull);
+  if ((u64)T.small_base + small_words >= (1u << 28) || (u64)T.fr_base + T.n_fr() >= (1u << 28)) { err = "circuit too large for the O0 row tables"; return false; }
+  s.img_small = (u32)((T.small_base + small_words + 3u) & ~3ull);
   s.img_fr = (u32)(T.fr_base + T.n_fr());
   return true;
 }
@@ -236,11 +301,11 @@ struct ZkO0Dev {
   u32 nportions;           // pieces of 256 K wires
   u32 emails_per_wg;       // a workgroup expands its piece for this many emails (the descriptors are loaded once)
   u32 small_base, fr_base;
-  const u64* s_ptr; const uint2* s_term; const int* s_coef; const u8* s_chain;
+  const u64* s_ptr; const uint2* s_term; const int* s_coef; const u8* s_chain; const u32* s_out;
   const u32* s_single; u32 n_small_single;       // small rows that are groups of their own (one thread each)
   const u32* s_long; u32 n_small_long;           // ... those of more than ZK_ROW_LONG terms (one wavefront each)
   const uint2* s_chains; u32 n_small_chains;     // (first row, rows) of the chains (one wavefront each: prefix sum over the rows)
   const u32* gen_seg; const u32* gen_r; u32 n_gen, gen_base;   // wires decoded by zk_o0_generic into small[gen_base ..]
-  const u64* f_ptr; const uint2* f_term; const Fr* f_coef; const u8* f_kind; const u8* f_chain; const u32* f_group; u32 n_fr_groups;
+  const u64* f_ptr; const uint2* f_term; const Fr* f_coef; const Fr* f_coefm; const u8* f_kind; const u8* f_chain; const u32* f_group; u32 n_fr_groups;
 };
 #endif
