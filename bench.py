@@ -515,6 +515,31 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
             "sample": f"{n} emails through zkwg_calculate_batch with zkwg_set_host_expand({cores}), tiles of {t}: D2H of the 0.45 MB image per email"}
     except Exception as e:
         out["delivered to host memory, expanded on the host"] = {"error": repr(e)[:200]}
+    # prover stage 1 from the compact image: A.w | B.w | C.w of every constraint of EmailVerifier(576,192)
+    # written by zkwg_expand_abc_device -- no 32-byte witness in between
+    try:
+        ca = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=local_rank)
+        t0 = time.time()
+        cs = zkwg.WitnessCalculator(ca).constraint_system()
+        t_cs = time.time() - t0
+        ca.attach_r1cs(cs)
+        ba, ta = 2048, 256
+        _, d_in, _ = resident_inputs(torch, ca, dev, 0x5A4B + 808, 64, ba, 60)
+        res = {}
+        for mont in (False, True):
+            pl = Pipeline(torch, ca, dev, d_in, ba, ta, 1024, ring=2, montgomery=mont, abc=True)
+            dt = timed(torch, pl.step, steps=3, warmup=1)
+            assert int(pl.d_status.abs().sum().item()) == 0
+            res["montgomery" if mont else "standard"] = {"value": round(ba * 3 / dt, 1), "GBps_written": round(ba * 3 * ca.abc_bytes / dt / 1e9, 1)}
+            del pl
+            torch.cuda.empty_cache()
+        out["prover stage 1 from the image, EmailVerifier(576,192)"] = {
+            "unit": "witnesses/s (inputs -> A.w|B.w|C.w, witness generation included)", "constraints": cs.n_constraints, "abc_bytes": ca.abc_bytes,
+            **res, "image_bytes_per_email": ca.scratch_bytes(1), "r1cs_export_s": round(t_cs, 1), "steps": 3}
+        del d_in, ca, cs
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["prover stage 1 from the image, EmailVerifier(576,192)"] = {"error": repr(e)[:300]}
     # complete witnesses of the circuit compiled the way the reference documents (`circom --O0`,
     # docs/zk-email-docs/UsageGuide/README.md:59-64): every alias / constant / linear signal numbered, written in ONE pass
     # from the image (zkwg_circuit_create_full; artefacts = interpreter-generated .sym / .r1cs under artifacts/)

@@ -476,7 +476,7 @@ def test_prover_first_stage_evaluations_on_device_witnesses():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("main", ["rsa", "email"])
+@pytest.mark.parametrize("main", ["rsa", "email", "email_flags"])
 def test_prover_first_stage_from_the_compact_image(main):
     """zkwg_circuit_attach_r1cs + zkwg_expand_abc_device: A.w | B.w | C.w written from the prepared image (descriptors +
     integer / field rows, no 32-byte witness read) are byte-identical to zkwg_r1cs_evaluate_device on the expanded
@@ -491,6 +491,19 @@ def test_prover_first_stage_from_the_compact_image(main):
         rec = c0.pack({"signature": limbs(KAT_SIG), "modulus": limbs(KAT_PUB), "message": KAT_MSG})
         n = 3
         d_in = torch.frombuffer(bytearray(rec * n), dtype=torch.uint8).to(dev)
+    elif main == "email_flags":
+        # header / body masking and removeSoftLineBreaks = 1 (the merge chain on its side stream): the row kernels then run
+        # from the expand call
+        mk = lambda: zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0, enable_header_masking=1,
+                                  enable_body_masking=1, remove_soft_line_breaks=1)
+        c0 = mk()
+        inps, nxt = [], 0
+        for _ in range(3):
+            inp, idx = _flag_inputs(576, 192, nxt)
+            inps.append(inp)
+            nxt = idx + 1
+        n = len(inps)
+        d_in = torch.frombuffer(bytearray(b"".join(c0.pack(i) for i in inps)), dtype=torch.uint8).to(dev)
     else:
         from zkwg import synth
         mk = lambda: zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0)
@@ -533,3 +546,28 @@ def test_prover_first_stage_from_the_compact_image(main):
         torch.cuda.synchronize()
         assert torch.equal(part, want[1:3])
     assert any(int(x) for x in want[0, :4096].cpu().tolist())
+
+
+def test_attach_r1cs_host_logic():
+    """zkwg_circuit_attach_r1cs on a layout-only handle: the tables are built (the image grows by the row results), a
+    second system, a system over another layout and a fully numbered handle are refused, and without a device the
+    expansion itself reports NO_DEVICE instead of falling back to anything."""
+    import zkwg
+    c = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=-1)
+    cs = zkwg.WitnessCalculator(c).constraint_system()
+    assert c.abc_bytes == 0
+    lay0 = c.image_layout(4)
+    c.attach_r1cs(cs)
+    lay1 = c.image_layout(4)
+    assert c.abc_bytes == 96 * cs.n_constraints
+    assert lay1["small_words"] > lay0["small_words"] and lay1["fr_elems"] > lay0["fr_elems"] and lay1["bits_words"] == lay0["bits_words"]
+    assert c.scratch_bytes(4) == lay1["total_bytes"]
+    with pytest.raises(zkwg.ZkwgError):
+        c.attach_r1cs(cs)
+    other = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=64, max_body=0, device=-1)
+    with pytest.raises(zkwg.ZkwgError):
+        other.attach_r1cs(cs)                      # wire count of another layout
+    with pytest.raises(zkwg.ZkwgError):
+        other.attach_r1cs(b"not an r1cs file")
+    rc = c.lib.zkwg_expand_abc_device(c.h, 1, 1, 256, 0, 1, 0, 1, c.abc_bytes, None)
+    assert rc == -3        # ZKWG_RC_NO_DEVICE (include/zkwg.h)
