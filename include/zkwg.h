@@ -55,14 +55,18 @@ extern "C" {
 
 /* 2 (round 3): ZKWG_IN_NFIELDS = 13 (the record's former padding word is ZKWG_IN_RANGE_FLAGS: hand-built records must
  * zero it, a non-zero word fails the email); zkwg_expand_device accepts out_stride >= 32 W (multiple of 16);
- * zkwg_scratch_bytes includes the Montgomery-copy area; zkwg_segment.pad is kernel-private. */
+ * zkwg_scratch_bytes includes the Montgomery-copy area; zkwg_segment.pad is kernel-private.
+ * Added since without breaking 2: zkwg_expand_host / zkwg_set_host_expand, zkwg_circuit_attach_r1cs / zkwg_expand_abc_device /
+ * zkwg_abc_bytes, ZKWG_MAIN_FP_MUL. */
 #define ZKWG_ABI_VERSION 2
 
 /* `component main = ...` choices (the reference's own test mains). */
 enum zkwg_main_kind {
   ZKWG_MAIN_EMAIL_VERIFIER = 0, /* EmailVerifier(maxHeader,maxBody,n,k,ignoreBodyHashCheck,0,0,0), public [pubkey] */
   ZKWG_MAIN_SHA256_BYTES = 1,   /* Sha256Bytes(maxHeader), public [paddedIn, paddedInLength] (sha-test.circom) */
-  ZKWG_MAIN_RSA_VERIFIER = 2    /* RSAVerifier65537(n,k), public [modulus] (rsa-test.circom) */
+  ZKWG_MAIN_RSA_VERIFIER = 2,   /* RSAVerifier65537(n,k), public [modulus] (rsa-test.circom) */
+  ZKWG_MAIN_FP_MUL = 3          /* FpMul(n,k), n*k <= 62, 2 <= k <= 17: inputs a, b, p in the pubkey / signature / message slots of the
+                                   record (fp-mul-test.circom: FpMul(2,4); tests/fp-mul.test.ts:34-46) */
 };
 
 /* Witness layouts.  KEPT_V1 is the compact layout documented in DESIGN.md; SYM is KEPT_V1 re-ordered

@@ -55,6 +55,8 @@ def load():
     lib.ht_in_off.argtypes = [C.c_void_p, C.c_int]
     lib.ht_run_rsa.restype = C.c_int
     lib.ht_run_rsa.argtypes = [C.c_void_p] * 6
+    lib.ht_run_fpmul.restype = C.c_int
+    lib.ht_run_fpmul.argtypes = [C.c_void_p] * 5
     lib.ht_poseidon.argtypes = [C.c_void_p] * 3
     lib.ht_poseidon_sparse.restype = C.c_int
     lib.ht_poseidon_sparse.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]

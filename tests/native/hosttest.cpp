@@ -5,6 +5,7 @@
 #include <vector>
 #include "zkwg_build.h"
 #include "zkwg_rsa_core.h"
+#include "zkwg_fpmul_core.h"
 #include "zkwg_poseidon_core.h"
 #include "zkwg_poseidon_sparse.h"
 #include "zkwg_r1cs.h"
@@ -50,6 +51,12 @@ int ht_run_rsa(void* p, const uint8_t* rec, const uint32_t* digest, uint64_t* bi
   int ok = (int)S->ok;
   delete S;
   return ok;
+}
+// main = FpMul(n, k) with small parameters: the core zk_fpmul_small runs (zkwg_fpmul_core.h); returns the status
+int ht_run_fpmul(void* p, const uint8_t* rec, uint64_t* bits, uint32_t* small, void* frv) {
+  HT* h = (HT*)p;
+  if (!h->s.fpg.present) return -1;
+  return zk_fpmul_small_core(h->s.fpg, h->s.m_one, rec, bits, small, (Fr*)frv);
 }
 // PoseidonLarge(121,17) of 17 x 16-byte limbs: out420 = S-box signals, hash = pubkeyHash
 void ht_poseidon(const uint8_t* limbs, void* out420, void* hash) {

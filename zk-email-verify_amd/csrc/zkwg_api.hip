@@ -884,6 +884,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     }
     hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), dyn, st, s, B);
   }
+  if (s.fpg.present) hipLaunchKernelGGL(zk_fpmul_small, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // (timed in zk_rsa's slot)
   if (tm) hipEventRecord(evs[++ki], st);
   if (pos9 && pos_slot < 0) {
     // one lane per email once the batch supplies >= 16 wavefronts of them; one wavefront per email below
@@ -1376,6 +1377,7 @@ uint64_t zkwg_write_sym(const zkwg_circuit_t* c, char* out, uint64_t cap) {
   switch (tmp.main_kind) {
     case ZKWG_MAIN_SHA256_BYTES: zk_walk_main_sha(w, tmp); break;
     case ZKWG_MAIN_RSA_VERIFIER: zk_walk_main_rsa(w, tmp); break;
+    case ZKWG_MAIN_FP_MUL: zk_walk_main_fpmul(w, tmp, tmp.fpg.n, tmp.fpg.k); break;
     case ZKWG_MAIN_EMAIL_VERIFIER: zk_walk_main_ev(w, tmp); break;
   }
   return pos;

@@ -121,6 +121,12 @@ static bool build_sched(const zkwg_config& cfg, ZkSched& s, std::vector<ZkSeg>& 
       zk_walk_main_rsa(w, s);
       max_small = std::max<u64>(max_small, 2100);
       break;
+    case ZKWG_MAIN_FP_MUL:
+      // generic parameters, as long as the numbers fit machine words (zkwg_fpmul_core.h); (121, 17) lives in the RSA path
+      if (cfg.n < 1 || cfg.k < 2 || cfg.k > 17 || (u64)cfg.n * cfg.k > 62 || cfg.max_header || cfg.max_body) return false;
+      s.nframes = 0;
+      zk_walk_main_fpmul(w, s, cfg.n, cfg.k);
+      break;
     default:
       return false;
   }

@@ -7,6 +7,7 @@
 __global__ void zk_sha_chain(ZkSched s, ZkBufs B);   // zkwg_kernels_sha.hip
 __global__ void zk_sha_trace(ZkSched s, ZkBufs B);   // zkwg_kernels_sha.hip
 __global__ void zk_rsa(ZkSched s, ZkBufs B);         // zkwg_kernels_rsa.hip
+__global__ void zk_fpmul_small(ZkSched s, ZkBufs B);
 __global__ void zk_poseidon9(ZkSched s, ZkBufs B);   // zkwg_kernels_rsa.hip
 __global__ void zk_poseidon9_wave(ZkSched s, ZkBufs B);
 __global__ void zk_poseidon9_g16(ZkSched s, ZkBufs B);

@@ -8,6 +8,7 @@
 #include "zkwg_rsa_wave.h"
 #include "zkwg_poseidon_sparse.h"
 #include "zkwg_poseidon_core.h"
+#include "zkwg_fpmul_core.h"
 
 __global__ __launch_bounds__(64) void zk_rsa(ZkSched s, ZkBufs B) {
   __shared__ ZkRsaLds S;
@@ -180,4 +181,14 @@ __global__ __launch_bounds__(64) void zk_poseidon9_wave(ZkSched s, ZkBufs B) {
   }
   __syncthreads();
   zk_poseidon_large(PS, limb, B.pos_m, B.pos_m + 680, frv + s.f_pos, frv + s.f_out);
+}
+
+// main = FpMul(n, k) with small parameters (fp-mul-test.circom: FpMul(2,4)): one lane per email (zkwg_fpmul_core.h)
+__global__ __launch_bounds__(64) void zk_fpmul_small(ZkSched s, ZkBufs B) {
+  const u32 e = blockIdx.x * 64u + threadIdx.x;
+  if (e >= B.n_emails) return;
+  const u8* rec = B.in + (u64)e * s.in_stride;
+  int st = zk_fpmul_small_core(s.fpg, s.m_one, rec, B.bits + (u64)e * s.img_bits, B.small + (u64)e * s.img_small, B.frv + (u64)e * s.img_fr);
+  if (*(const u32*)(rec + s.in_off[ZK_IN_RANGE_FLAGS]) != 0) st = 4;   // generic input path: a value that did not fit its chunk
+  if (st) B.status[e] = st;
 }

@@ -243,6 +243,52 @@ static inline void zk_walk_main_rsa(ZkWalker& w, ZkSched& s) {
   s.n_public = 17;
 }
 
+// main = FpMul(n, k), no public inputs (packages/circuits/tests/test-circuits/fp-mul-test.circom:5; lib/fp.circom:16-81)
+static inline void zk_walk_main_fpmul(ZkWalker& w, ZkSched& s, u32 n, u32 k) {
+  ZkFpgLayout& F = s.fpg;
+  F.present = 1; F.n = n; F.k = k;
+  F.in_a = s.in_off[3]; F.in_b = s.in_off[4]; F.in_p = s.in_off[5];
+  u32 lk = 0; for (u32 t = k; t; t >>= 1) ++lk;          // log_ceil(k) of lib/bigint-func.circom:14-23
+  const u32 cb = n + lk + 5;                             // CheckCarryToZero: m + EPSILON - n bits per carry
+  s.m_one = w.alloc_small(1);
+  F.m_out = w.alloc_small(k);
+  F.f_main = w.alloc_fr(6 * k - 2);
+  F.b_qr = w.alloc_bits(2 * k);
+  F.b_lt = w.alloc_bits(k);
+  F.f_eq = w.alloc_fr(2 * k);
+  F.m_gates = w.alloc_small(3 * (k - 1));
+  F.f_carry = w.alloc_fr(2 * k - 1);
+  F.b_carry = w.alloc_bits(2 * k - 2);
+  w.seg(ZSEG_SMALL, 1 + k, s.m_one);                     // (m_one and m_out are consecutive)
+  w.one("one");
+  w.arr("main.out", k);
+  w.seg(ZSEG_LIMB, k, F.in_a); w.arr("main.a", k);
+  w.seg(ZSEG_LIMB, k, F.in_b); w.arr("main.b", k);
+  w.seg(ZSEG_LIMB, k, F.in_p); w.arr("main.p", k);
+  const std::string p = "main";
+  w.seg(ZSEG_FR, 6 * k - 2, F.f_main);
+  w.arr(p + ".v_ab", 2 * k - 1); w.arr(p + ".q", k); w.arr(p + ".r", k); w.arr(p + ".v_pq_r", 2 * k - 1);
+  w.seg(ZSEG_BITS, 2 * k * n, F.b_qr, n, 1);
+  for (u32 i = 0; i < k; ++i) w.arr(zk_idx(p + ".q_range_check", i) + ".out", n);
+  for (u32 i = 0; i < k; ++i) w.arr(zk_idx(p + ".r_range_check", i) + ".out", n);
+  w.seg(ZSEG_BITS, k * (n + 1), F.b_lt, n + 1, 1);
+  for (u32 i = 0; i < k; ++i) w.arr(zk_idx(p + ".r_p_lt_check.lt", i) + ".n2b.out", n + 1);
+  w.seg(ZSEG_FR, 2 * k, F.f_eq);
+  for (u32 i = 0; i < k; ++i) {
+    w.one(zk_idx(p + ".r_p_lt_check.eq", i) + ".isz.out");
+    w.one(zk_idx(p + ".r_p_lt_check.eq", i) + ".isz.inv");
+  }
+  w.seg(ZSEG_SMALL, 3 * (k - 1), F.m_gates);
+  for (u32 i = 0; i + 1 < k; ++i) w.one(zk_idx(p + ".r_p_lt_check.ors", i) + ".out");
+  for (u32 i = 0; i + 1 < k; ++i) w.one(zk_idx(p + ".r_p_lt_check.ands", i) + ".out");
+  for (u32 i = 0; i + 1 < k; ++i) w.one(zk_idx(p + ".r_p_lt_check.eq_ands", i) + ".out");
+  w.seg(ZSEG_FR, 2 * k - 1, F.f_carry);
+  w.arr(p + ".tCheck.carry", 2 * k - 1);
+  w.seg(ZSEG_BITS, (2 * k - 2) * cb, F.b_carry, cb, 1);
+  for (u32 i = 0; i + 2 < 2 * k; ++i) w.arr(zk_idx(p + ".tCheck.carryRangeChecks", i) + ".out", cb);
+  s.n_public = 0;
+}
+
 // ------------------------------------------------------------------ BodyHashRegex DFA circuit (zkwg v1)
 // [EXT] zk-regex's generated body_hash_regex.circom is absent; this is zkwg's own circuit of the same
 // style over the DFA tables of tools/gen_bh_dfa.py (restated literally in oracle/pyref/zkemail.py

@@ -155,6 +155,19 @@ struct ZkFpMulLayout {
   u32 f_carry;  // fr: carry[33]
   u32 b_carry;  // bits: 32 x 3 words (carry + 2^130)
 };
+// main = FpMul(n, k), n k <= 62 (tests/test-circuits/fp-mul-test.circom; zkwg_fpmul_core.h)
+struct ZkFpgLayout {
+  u32 present, n, k;
+  u32 in_a, in_b, in_p;  // record offsets of the k 16-byte chunks of a, b, p
+  u32 m_out;             // small: out[k]
+  u32 f_main;            // fr: v_ab[2k-1], q[k], r[k], v_pq_r[2k-1]
+  u32 b_qr;              // bits: q_range_check[k], r_range_check[k] (one word each)
+  u32 b_lt;              // bits: r_p_lt_check.lt[k].n2b (n + 1 bits, one word each)
+  u32 f_eq;              // fr: r_p_lt_check.eq[k] (isz.out, isz.inv)
+  u32 m_gates;           // small: ors, ands, eq_ands [k-1] each
+  u32 f_carry;           // fr: tCheck.carry[2k-1]
+  u32 b_carry;           // bits: tCheck.carryRangeChecks[2k-2] (one word each)
+};
 // RSAVerifier65537(121,17) (lib/rsa.circom:13-46)
 struct ZkRsaLayout {
   u32 present;                 // 0 = circuit has no RSA block
@@ -192,6 +205,7 @@ struct ZkSched {
   u32 m_one;             // small: constant 1
   u32 m_hdr_len;         // small: emailHeaderLength / paddedInLength
   ZkRsaLayout rsa;
+  ZkFpgLayout fpg;       // main = FpMul(n, k) with small parameters
   // EmailVerifier main (email-verifier.circom:42-174)
   u32 f_out;             // fr: pubkeyHash, shaHi, shaLo
   u32 f_pos;             // fr: 420 Poseidon S-box signals

@@ -21,6 +21,8 @@ function circuitOptions(arg) {
     if (p.length !== 8) throw new Error('EmailVerifier takes 8 parameters');
     return { mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: p[0], maxBody: p[1], n: p[2], k: p[3], ignoreBodyHashCheck: p[4], enableHeaderMasking: p[5], enableBodyMasking: p[6], removeSoftLineBreaks: p[7] };
   }
+  const f = /^FpMul\(\s*(\d+)\s*,\s*(\d+)\s*\)$/.exec(arg.trim());   // tests/test-circuits/fp-mul-test.circom: FpMul(2, 4)
+  if (f) return { mainKind: z.MAIN_FP_MUL, maxHeader: 0, maxBody: 0, n: Number(f[1]), k: Number(f[2]) };
   const text = fs.existsSync(arg) ? fs.readFileSync(arg, 'utf8') : arg;
   const o = JSON.parse(text);
   const base = fs.existsSync(arg) ? path.dirname(arg) : '.';

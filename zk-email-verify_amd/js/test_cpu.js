@@ -52,3 +52,16 @@ assert.strictEqual('decodedEmailBodyIn' in qp.signalSizes(), true);
 new z.WitnessCalculator(c).calculateWitness({ paddedIn: padded, paddedInLength: 64 }).then(
   () => { console.error('expected a no-device error'); process.exit(1); },
   (e) => { assert.ok(/no HIP device/.test(e.message)); console.log('js cpu ok W(sha128)=' + c.witnessLen + ' W(ev576/192)=' + ev.witnessLen); });
+// main = FpMul(2, 4) (packages/circuits/tests/test-circuits/fp-mul-test.circom:5): generic small parameters through the addon
+{
+  const f = new z.Circuit({ mainKind: z.MAIN_FP_MUL, maxHeader: 0, maxBody: 0, n: 2, k: 4 }, -1);
+  assert.strictEqual(f.numPublic, 0);
+  const names = z.symbols(f);
+  assert.deepStrictEqual(names.slice(0, 6), ['one', 'main.out[0]', 'main.out[1]', 'main.out[2]', 'main.out[3]', 'main.a[0]']);
+  const r = f.pack({ a: [1, 0, 1, 0], b: [0, 1, 1, 0], p: [1, 1, 1, 1] });   // tests/fp-mul.test.ts:35-39
+  assert.strictEqual(r.readUInt32LE(f.offsets[3]), 1);
+  assert.strictEqual(r.readUInt32LE(f.offsets[4] + 16), 1);
+  assert.strictEqual(r.readUInt32LE(f.offsets[5] + 48), 1);
+  assert.throws(() => f.pack({ a: [1, 0, 1], b: [0, 1, 1, 0], p: [1, 1, 1, 1] }), /Not enough values for input signal a/);
+  assert.throws(() => new z.Circuit({ mainKind: z.MAIN_FP_MUL, maxHeader: 0, maxBody: 0, n: 121, k: 17 }, -1));
+}

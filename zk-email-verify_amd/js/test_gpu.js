@@ -158,5 +158,14 @@ function shaPad(msg, max) {  // packages/helpers/src/sha-utils.ts:88-111
     for (let i = 1; i < s1.length; ++i) assert.strictEqual(w1[i], byName.get(s1[i]), s1[i]);
     assert.throws(() => new z.Circuit({ mainKind: z.MAIN_EMAIL_VERIFIER, maxHeader: kase.maxHeader, maxBody: kase.maxBody, regex: tmpl + '.missing' }, 0), /regex template/);
   }
+  {
+    // packages/circuits/tests/fp-mul.test.ts:34-46, the reference test as written: FpMul(2,4), 17 * 20 mod 85 = 0
+    const t = await z.tester({ mainKind: z.MAIN_FP_MUL, maxHeader: 0, maxBody: 0, n: 2, k: 4 }, 0);
+    const w = await t.calculateWitness({ a: [1, 0, 1, 0], b: [0, 1, 1, 0], p: [1, 1, 1, 1] });
+    await t.assertOut(w, { out: [0, 0, 0, 0] });
+    const w2 = await t.calculateWitness({ a: [3, 1, 0, 0], b: [2, 2, 0, 0], p: [1, 3, 1, 0] });   // 7 * 10 mod 29 = 12
+    await t.assertOut(w2, { out: [0, 3, 0, 0] });
+    await assert.rejects(t.calculateWitness({ a: [1, 0, 0, 0], b: [1, 0, 0, 0], p: [0, 0, 0, 0] }), /Assert Failed/);
+  }
   console.log('js gpu ok');
 })().catch((e) => { console.error(e); process.exit(1); });

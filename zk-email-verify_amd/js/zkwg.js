@@ -16,7 +16,7 @@ const path = require('path');
 const addon = require(path.join(__dirname, 'zkwg_addon.node'));
 
 const FIELD_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
-const MAIN_EMAIL_VERIFIER = 0, MAIN_SHA256_BYTES = 1, MAIN_RSA_VERIFIER = 2;
+const MAIN_EMAIL_VERIFIER = 0, MAIN_SHA256_BYTES = 1, MAIN_RSA_VERIFIER = 2, MAIN_FP_MUL = 3;
 const IN = { HEADER: 0, BODY: 1, PRECOMPUTED_SHA: 2, PUBKEY: 3, SIGNATURE: 4, MESSAGE: 5, HEADER_LEN: 6, BODY_LEN: 7, BODY_HASH_INDEX: 8, HEADER_MASK: 9, BODY_MASK: 10, DECODED_BODY: 11, RANGE_FLAGS: 12 };
 
 function norm(v) {
@@ -62,6 +62,7 @@ class Circuit {
     const o = this.opts;
     if (o.mainKind === MAIN_SHA256_BYTES) return { paddedIn: o.maxHeader, paddedInLength: 1 };
     if (o.mainKind === MAIN_RSA_VERIFIER) return { message: o.k, signature: o.k, modulus: o.k };
+    if (o.mainKind === MAIN_FP_MUL) return { a: o.k, b: o.k, p: o.k };   // FpMul(n, k) (tests/test-circuits/fp-mul-test.circom)
     const s = { emailHeader: o.maxHeader, emailHeaderLength: 1, pubkey: o.k, signature: o.k };
     if (o.enableHeaderMasking) s.headerMask = o.maxHeader;
     if (!o.ignoreBodyHashCheck) {
@@ -119,6 +120,9 @@ class Circuit {
       bytes(IN.HEADER, flat.paddedIn, 'paddedIn'); u32(IN.HEADER_LEN, flat.paddedInLength[0], 'paddedInLength');
     } else if (o.mainKind === MAIN_RSA_VERIFIER) {
       limbs(IN.MESSAGE, flat.message, 'message'); limbs(IN.SIGNATURE, flat.signature, 'signature'); limbs(IN.PUBKEY, flat.modulus, 'modulus');
+    } else if (o.mainKind === MAIN_FP_MUL) {
+      // the chunks of a, b, p travel in the pubkey / signature / message slots of the record (include/zkwg.h)
+      limbs(IN.PUBKEY, flat.a, 'a'); limbs(IN.SIGNATURE, flat.b, 'b'); limbs(IN.MESSAGE, flat.p, 'p');
     } else {
       bytes(IN.HEADER, flat.emailHeader, 'emailHeader'); u32(IN.HEADER_LEN, flat.emailHeaderLength[0], 'emailHeaderLength');
       limbs(IN.PUBKEY, flat.pubkey, 'pubkey'); limbs(IN.SIGNATURE, flat.signature, 'signature');
@@ -268,4 +272,4 @@ function symbols(circuit) {
   return names;
 }
 
-module.exports = { symbols, R1cs, Circuit, WitnessCalculator, MultiCalculator, Tester, tester, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER };
+module.exports = { symbols, R1cs, Circuit, WitnessCalculator, MultiCalculator, Tester, tester, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER, MAIN_FP_MUL };

@@ -14,7 +14,7 @@ is no CPU fallback (a missing library or GPU raises).
 import ctypes as C
 
 from . import _lib
-from ._lib import Config, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER
+from ._lib import Config, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER, MAIN_FP_MUL
 
 FIELD_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -45,8 +45,8 @@ def _limbs_bytes(vals, n_limbs=17):
 
 
 # CircuitInput signal name -> packed record field (include/zkwg.h enum zkwg_input_field)
-_FIELD_OF = {"emailHeader": 0, "paddedIn": 0, "emailBody": 1, "precomputedSHA": 2, "pubkey": 3, "modulus": 3,
-             "signature": 4, "message": 5, "emailHeaderLength": 6, "paddedInLength": 6, "emailBodyLength": 7,
+_FIELD_OF = {"emailHeader": 0, "paddedIn": 0, "emailBody": 1, "precomputedSHA": 2, "pubkey": 3, "modulus": 3, "a": 3,
+             "signature": 4, "b": 4, "message": 5, "p": 5, "emailHeaderLength": 6, "paddedInLength": 6, "emailBodyLength": 7,
              "bodyHashIndex": 8, "headerMask": 9, "bodyMask": 10, "decodedEmailBodyIn": 11}
 
 
@@ -124,6 +124,8 @@ class Circuit:
             return {"paddedIn": c.max_header, "paddedInLength": 1}
         if c.main_kind == MAIN_RSA_VERIFIER:
             return {"message": c.k, "signature": c.k, "modulus": c.k}
+        if c.main_kind == MAIN_FP_MUL:
+            return {"a": c.k, "b": c.k, "p": c.k}
         sizes = {"emailHeader": c.max_header, "emailHeaderLength": 1, "pubkey": c.k, "signature": c.k}
         if c.enable_header_masking:
             sizes["headerMask"] = c.max_header
@@ -174,7 +176,7 @@ class Circuit:
         def as_limbs(vals, what):
             if any(v >> 128 for v in vals):
                 generic.append((_FIELD_OF[what], vals))
-            return _limbs_bytes([v & ((1 << 128) - 1) for v in vals])
+            return _limbs_bytes([v & ((1 << 128) - 1) for v in vals] + [0] * (17 - len(vals)))
 
         c = self.cfg
         rec = (C.c_uint8 * self.in_stride)()
@@ -186,6 +188,9 @@ class Circuit:
         elif c.main_kind == MAIN_RSA_VERIFIER:
             msg = as_limbs(flat["message"], "message"); sig = as_limbs(flat["signature"], "signature")
             pub = as_limbs(flat["modulus"], "modulus")
+        elif c.main_kind == MAIN_FP_MUL:
+            # the chunks of a, b, p travel in the pubkey / signature / message slots of the record
+            pub = as_limbs(flat["a"], "a"); sig = as_limbs(flat["b"], "b"); msg = as_limbs(flat["p"], "p")
         else:
             header = as_bytes(flat["emailHeader"], "emailHeader")
             hlen = as_u32(flat["emailHeaderLength"][0], "emailHeaderLength")
@@ -575,6 +580,8 @@ class WitnessCalculator:
                 data = zr.write_r1cs(len(sym), zr.sha256_main_constraints(sym, cfg.max_header), 256, cfg.max_header + 1)
             elif cfg.main_kind == MAIN_RSA_VERIFIER:
                 data = zr.write_r1cs(len(sym), zr.rsa_main_constraints(sym), 0, 17, 34)
+            elif cfg.main_kind == MAIN_FP_MUL:
+                data = zr.write_r1cs(len(sym), zr.fp_mul_main_constraints(sym, cfg.n, cfg.k), cfg.k, 0, 3 * cfg.k)
             else:
                 data = zr.email_verifier_r1cs(sym, cfg.max_header, cfg.max_body, cfg.enable_header_masking,
                                               cfg.enable_body_masking, cfg.remove_soft_line_breaks, cfg.ignore_body_hash_check)

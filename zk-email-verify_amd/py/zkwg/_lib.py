@@ -36,7 +36,7 @@ class DkimBatch(C.Structure):
                 ("selector_len", C.c_uint32)]
 
 
-MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER = 0, 1, 2
+MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER, MAIN_FP_MUL = 0, 1, 2, 3
 (IN_HEADER, IN_BODY, IN_PRECOMPUTED_SHA, IN_PUBKEY, IN_SIGNATURE, IN_MESSAGE,
  IN_HEADER_LEN, IN_BODY_LEN, IN_BODY_HASH_INDEX, IN_HEADER_MASK, IN_BODY_MASK, IN_DECODED_BODY,
  IN_RANGE_FLAGS) = range(13)

@@ -241,11 +241,12 @@ def lc_scale(a, k):
 
 
 class RsaBuilder:
-    def __init__(self, slot_of, prefix):
+    def __init__(self, slot_of, prefix, n=N_, k=K_):
         self.slot = slot_of
         self.cons = []
         self.pre = prefix
         self._interp = None
+        self.n, self.k = n, k          # chunk bits / chunks of the big integers (lib/fp.circom, lib/bigint.circom are generic)
 
     def s(self, name):
         return self.slot[name]
@@ -287,8 +288,8 @@ class RsaBuilder:
         return wire(o)
 
     def big_less_than(self, pre, a, b):
-        k = K_
-        lt = [self.less_than(f"{pre}.lt[{i}]", N_, a[i], b[i]) for i in range(k)]
+        k = self.k
+        lt = [self.less_than(f"{pre}.lt[{i}]", self.n, a[i], b[i]) for i in range(k)]
         eq = [self.iszero(f"{pre}.eq[{i}].isz", lc_add(b[i], a[i], -1)) for i in range(k)]
         ors, eq_ands = [None] * (k - 1), [None] * (k - 1)
         for i in range(k - 2, -1, -1):
@@ -333,7 +334,8 @@ class RsaBuilder:
         return self._interp
 
     def fp_mul(self, pre, a, b, p):
-        k, m = K_, 2 * K_ - 1
+        k, m, N = self.k, 2 * self.k - 1, self.n
+        cb = N + k.bit_length() + 5    # CheckCarryToZero: m + EPSILON - n bits per carry, m = 2n + log_ceil(k) + 2 (131 for (121, 17))
         v_ab = self.arr(pre + ".v_ab", m)
         q = [wire(s) for s in self.arr(pre + ".q", k)]
         r = [wire(s) for s in self.arr(pre + ".r", k)]
@@ -341,9 +343,9 @@ class RsaBuilder:
         for x in range(m):
             self.cons.append((self.poly(a, x), self.poly(b, x), wire(v_ab[x])))
         for i in range(k):
-            self.num2bits(f"{pre}.q_range_check[{i}]", q[i], N_)
+            self.num2bits(f"{pre}.q_range_check[{i}]", q[i], N)
         for i in range(k):
-            self.num2bits(f"{pre}.r_range_check[{i}]", r[i], N_)
+            self.num2bits(f"{pre}.r_range_check[{i}]", r[i], N)
         self.lin(lc_add(self.big_less_than(pre + ".r_p_lt_check", r, p), const(-1)))
         for x in range(m):
             self.cons.append((self.poly(p, x), self.poly(q, x), lc_add(wire(v_pq_r[x]), self.poly(r, x), -1)))
@@ -359,8 +361,8 @@ class RsaBuilder:
         carry = self.arr(pre + ".tCheck.carry", m)
         for i in range(m - 1):
             lhs = t[i] if i == 0 else lc_add(t[i], wire(carry[i - 1]))
-            self.lin(lc_add(lhs, wire(carry[i]), -(1 << N_)))
-            self.num2bits(f"{pre}.tCheck.carryRangeChecks[{i}]", lc_add(wire(carry[i]), const(1 << 130)), 131)
+            self.lin(lc_add(lhs, wire(carry[i]), -(1 << N)))
+            self.num2bits(f"{pre}.tCheck.carryRangeChecks[{i}]", lc_add(wire(carry[i]), const(1 << (cb - 1))), cb)
         self.lin(lc_add(t[m - 1], wire(carry[m - 2])))
         return r
 
@@ -424,6 +426,18 @@ def rsa_main_constraints(symbols):
     b = RsaBuilder(slot_of, "main")
     arr = lambda nm: [wire(slot_of[f"main.{nm}[{i}]"]) for i in range(K_)]
     return b.rsa_verifier(arr("message"), arr("signature"), arr("modulus"))
+
+
+def fp_mul_main_constraints(symbols, n, k):
+    """`component main = FpMul(n, k)` (tests/test-circuits/fp-mul-test.circom:5: FpMul(2, 4)); out[i] <== r[i]."""
+    slot_of = {nm: s for s, nm in symbols}
+    b = RsaBuilder(slot_of, "main", n, k)
+    arr = lambda nm: [wire(slot_of[f"main.{nm}[{i}]"]) for i in range(k)]
+    r = b.fp_mul("main", arr("a"), arr("b"), arr("p"))
+    out = arr("out")
+    for i in range(k):
+        b.lin(lc_add(out[i], r[i], -1))
+    return b.cons
 
 
 # ------------------------------------------------------------------ EmailVerifier
