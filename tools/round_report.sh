@@ -7,7 +7,7 @@ TAG=${1:-r02_final}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 REPO=$PWD
-( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 ) > $OUT/${TAG}_pytest_gpu.txt
+( timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -5 ) > $OUT/${TAG}_pytest_gpu.txt
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 ) > $OUT/${TAG}_smoke.txt
 timeout 900 python bench.py 2>$OUT/${TAG}_bench.err | tail -1 > $OUT/${TAG}_bench.json
 ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- \
