@@ -173,7 +173,6 @@ static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W) {
   up(T.s_ptr.data(), T.s_ptr.size() * 8, (void**)&O.s_ptr);
   up(T.s_term.data(), T.s_term.size() * 4, (void**)&O.s_term);
   up(T.s_coef.data(), T.s_coef.size() * 4, (void**)&O.s_coef);
-  up(T.s_chain.data(), T.s_chain.size(), (void**)&O.s_chain);
   up(T.s_out.data(), T.s_out.size() * 4, (void**)&O.s_out);
   {
     // small rows: the groups of one row (a thread each, a wavefront for the long ones) and the chains (a wavefront each)
@@ -192,8 +191,6 @@ static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W) {
   up(T.f_coef.data(), T.f_coef.size() * sizeof(Fr), (void**)&O.f_coef);
   up(T.f_coefm.data(), T.f_coefm.size() * sizeof(Fr), (void**)&O.f_coefm);
   up(T.f_kind.data(), T.f_kind.size(), (void**)&O.f_kind);
-  up(T.f_chain.data(), T.f_chain.size(), (void**)&O.f_chain);
-  up(T.f_group.data(), T.f_group.size() * 4, (void**)&O.f_group);
   up(T.gen_seg.data(), T.gen_seg.size() * 4, (void**)&O.gen_seg);
   up(T.gen_r.data(), T.gen_r.size() * 4, (void**)&O.gen_r);
   O.n_gen = (u32)T.gen_seg.size(); O.gen_base = T.gen_base;
@@ -204,8 +201,8 @@ static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W) {
   return ok;
 }
 static void free_o0(ZkO0Dev& O) {
-  hipFree((void*)O.desc); hipFree((void*)O.s_ptr); hipFree((void*)O.s_term); hipFree((void*)O.s_coef); hipFree((void*)O.s_chain); hipFree((void*)O.s_out); hipFree((void*)O.s_single); hipFree((void*)O.s_long); hipFree((void*)O.s_chains);
-  hipFree((void*)O.f_ptr); hipFree((void*)O.f_term); hipFree((void*)O.f_coef); hipFree((void*)O.f_coefm); hipFree((void*)O.f_kind); hipFree((void*)O.f_chain); hipFree((void*)O.f_group); hipFree((void*)O.gen_seg); hipFree((void*)O.gen_r);
+  hipFree((void*)O.desc); hipFree((void*)O.s_ptr); hipFree((void*)O.s_term); hipFree((void*)O.s_coef); hipFree((void*)O.s_out); hipFree((void*)O.s_single); hipFree((void*)O.s_long); hipFree((void*)O.s_chains);
+  hipFree((void*)O.f_ptr); hipFree((void*)O.f_term); hipFree((void*)O.f_coef); hipFree((void*)O.f_coefm); hipFree((void*)O.f_kind); hipFree((void*)O.gen_seg); hipFree((void*)O.gen_r);
   memset(&O, 0, sizeof(O));
 }
 extern "C" {

@@ -22,6 +22,7 @@
 #define ZK_REF_RAW (ZK_REF | (3u << 28))   // small[payload] as a raw 32-bit value (bit 31 may be set)
 #define ZK_REF_NEG (ZK_REF | (4u << 28))   // small[payload] is a signed word w, d = (i32)(w << 1) >> 1 < 0: the slot is r + d
 #define ZK_REF_I64 (ZK_REF | (5u << 28))   // (small[payload], small[payload + 1]) is a signed 64-bit integer v: the slot is v mod r
+#define ZK_REF_MINUS (ZK_REF | (6u << 28)) // no load: the slot is r - payload, 0 < payload < 2^28 (small negative results: the -1 / -2 of bit constraints)
 #define ZK_REF_TYPE(code) (((code) >> 28) & 7u)
 #define ZK_REF_PAYLOAD(code) ((code) & 0x0fffffffu)
 
@@ -330,6 +331,9 @@ ZK_DEC __forceinline__ uint4 zk_ref_half(u32 code, u32 hf, const ZkRefSrc& R) {
       return hf ? make_uint4(0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u)
                 : make_uint4(0xf0000001u - m, 0x43e1f593u, 0x79b97091u, 0x2833e848u);
     }
+    case 6:
+      return hf ? make_uint4(0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u)
+                : make_uint4(0xf0000001u - p, 0x43e1f593u, 0x79b97091u, 0x2833e848u);
     default: {
       const long long v = (long long)((u64)R.small[p] | ((u64)R.small[p + 1] << 32));
       if (v >= 0) return hf ? zk_zero4() : make_uint4((u32)v, (u32)((u64)v >> 32), 0u, 0u);

@@ -58,9 +58,12 @@ __device__ __forceinline__ uint4 zk_slot_half(u32 code, u32 hf, const ZkX3& A, c
     // integers of the image (RAW / NEG / I64: results of integer rows, negative small values): |v| < 2^16 -> the table,
     // r - table[|v|] for a negative one (the A.w / B.w / C.w of bit constraints are full of -1 and -2)
     {
-      const u32 w = R.small[p];
       long long v;
-      if (t == 3u) v = (long long)w; else if (t == 4u) v = (long long)((int)(w << 1) >> 1); else v = (long long)((u64)w | ((u64)R.small[p + 1] << 32));
+      if (t == 6u) v = -(long long)p;
+      else {
+        const u32 w = R.small[p];
+        if (t == 3u) v = (long long)w; else if (t == 4u) v = (long long)((int)(w << 1) >> 1); else v = (long long)((u64)w | ((u64)R.small[p + 1] << 32));
+      }
       const u64 m = v < 0 ? (u64)(-v) : (u64)v;
       if (m < 65536u) {
         const uint4* tb = (const uint4*)A.rtab + 2u * (u32)m;
@@ -185,6 +188,17 @@ __global__ __launch_bounds__(256) void zk_image_to_mont(ZkX3 A) {
 }
 
 // ---------------------------------------------------------------- numbered circuits (`--O0` / `--O1`), one pass
+// codes of integer row results: a small non-negative value is an immediate, a small negative one the load-free r - m
+// (every bit constraint has a B side of 0 / -1: a reference into the image would put a dependent load in front of the store)
+__device__ __forceinline__ u32 zk_narrow_code(u32 w, u32 b) {
+  if (!(w >> 31)) return w;
+  return w > 0xf0000000u ? (ZK_REF_MINUS | (0u - w)) : (ZK_REF_NEG | b);
+}
+__device__ __forceinline__ u32 zk_wide_code(u32 lo, u32 hi, u32 b) {
+  if (hi == 0u && !(lo >> 31)) return lo;
+  if (hi == 0xffffffffu && lo > 0xf0000000u) return ZK_REF_MINUS | (0u - lo);
+  return ZK_REF_I64 | b;
+}
 // the code of one wire from its descriptor (zkwg_o0.h)
 __device__ __forceinline__ u32 zk_desc_decode(u32 a, u32 b, const ZkCtx& cx, const ZkSeg* __restrict__ segs) {
   switch (a >> 28) {
@@ -195,8 +209,8 @@ __device__ __forceinline__ u32 zk_desc_decode(u32 a, u32 b, const ZkCtx& cx, con
     case ZK_D_BYTE: return cx.rec[b];
     case ZK_D_SMALLRAW: return zk_raw_code(cx.small[b], b);
     case ZK_D_CODEW: return cx.small[b];
-    case ZK_D_SMALLN: { const u32 w = cx.small[b]; return (w >> 31) ? (ZK_REF_NEG | b) : w; }
-    case ZK_D_SMALLS: { const u32 lo = cx.small[b], hi = cx.small[b + 1]; return (hi == 0u && !(lo >> 31)) ? lo : (ZK_REF_I64 | b); }
+    case ZK_D_SMALLN: return zk_narrow_code(cx.small[b], b);
+    case ZK_D_SMALLS: return zk_wide_code(cx.small[b], cx.small[b + 1], b);
     case ZK_D_DFA: return zk_dfa_value((a >> 24) & 15u, (a >> 9) & 0x7ffu, (a >> 20) & 15u, a & 511u, b, cx.small + cx.m_dfa_st, cx.small + cx.m_dfa_cm, cx.small + cx.m_dfa_pm, cx.half);
     default: return 0u;   // (no wire keeps kind GENERIC: zk_o0_build turns them into CODEW)
   }
@@ -232,8 +246,8 @@ __device__ __forceinline__ u32 zk_o0_combine(uint2 d, const ZkO0Pre& p, u64 w64,
     case ZK_D_BYTE: return w8;
     case ZK_D_SMALLRAW: return zk_raw_code(w32, b);
     case ZK_D_CODEW: return w32;
-    case ZK_D_SMALLN: return (w32 >> 31) ? (ZK_REF_NEG | b) : w32;
-    case ZK_D_SMALLS: return (w32b == 0u && !(w32 >> 31)) ? w32 : (ZK_REF_I64 | b);
+    case ZK_D_SMALLN: return zk_narrow_code(w32, b);
+    case ZK_D_SMALLS: return zk_wide_code(w32, w32b, b);
     case ZK_D_DFA: return zk_dfa_value_w((a >> 24) & 15u, (a >> 20) & 15u, a & 511u, b, w32, w32b, half);
     default: return 0u;
   }
@@ -290,7 +304,9 @@ __global__ __launch_bounds__(256) void zk_o0_generic(ZkX3 A, ZkO0Dev O) {
 // the value of a code as a signed integer (small rows: every source is small-ranged by construction)
 __device__ __forceinline__ long long zk_code_int(u32 code, const ZkCtx& cx) {
   if (!(code >> 31)) return (long long)code;
-  const u32 p = ZK_REF_PAYLOAD(code), w = cx.small[p];
+  const u32 p = ZK_REF_PAYLOAD(code);
+  if (ZK_REF_TYPE(code) == 6u) return -(long long)p;                               // MINUS
+  const u32 w = cx.small[p];
   switch (ZK_REF_TYPE(code)) {
     case 3: return (long long)w;                                                   // RAW
     case 4: return (long long)((int)(w << 1) >> 1);                                // NEG

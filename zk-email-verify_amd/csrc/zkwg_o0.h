@@ -95,6 +95,7 @@ static inline void zk_o0_slot_desc(const std::vector<ZkSeg>& segs, u64 slot, u32
   const u32 r = (u32)(slot - g.slot) + g.r0;
   if (seg_index) *seg_index = (u32)lo;
   if (seg_r) *seg_r = r;
+  if (slot == 0) { out[0] = ZK_D_IMM << 28; out[1] = 1; return; }   // wire 0 of every circom witness: the constant 1 (the constant term of a combination)
   auto bit64 = [&](u32 word, u32 sh) { out[0] = (ZK_D_BIT64 << 28) | sh; out[1] = word; };
   switch (g.type) {
     case ZSEG_BITS: { const u32 grp = r / g.a, bit = r % g.a; bit64(g.src + grp * g.b + (bit >> 6), bit & 63u); return; }
@@ -165,7 +166,9 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
       describe(term_slot[t], d, &si, &sr);
       td.push_back(d[0]); td.push_back(d[1]);
       long long l, h;
-      if (!small || !zk_slot_range(segs[si], sr, l, h)) { small = false; continue; }
+      if (term_slot[t] == 0) l = h = 1;   // the constant term
+      else if (!small || !zk_slot_range(segs[si], sr, l, h)) { small = false; continue; }
+      if (!small) continue;
       const Fr& c = P.coef[t];
       long long k;
       if (!(c.l[1] | c.l[2] | c.l[3]) && c.l[0] < (1ull << 30)) k = (long long)c.l[0];
@@ -301,11 +304,11 @@ struct ZkO0Dev {
   u32 nportions;           // pieces of 256 K wires
   u32 emails_per_wg;       // a workgroup expands its piece for this many emails (the descriptors are loaded once)
   u32 small_base, fr_base;
-  const u64* s_ptr; const uint2* s_term; const int* s_coef; const u8* s_chain; const u32* s_out;
+  const u64* s_ptr; const uint2* s_term; const int* s_coef; const u32* s_out;
   const u32* s_single; u32 n_small_single;       // small rows that are groups of their own (one thread each)
   const u32* s_long; u32 n_small_long;           // ... those of more than ZK_ROW_LONG terms (one wavefront each)
   const uint2* s_chains; u32 n_small_chains;     // (first row, rows) of the chains (one wavefront each: prefix sum over the rows)
   const u32* gen_seg; const u32* gen_r; u32 n_gen, gen_base;   // wires decoded by zk_o0_generic into small[gen_base ..]
-  const u64* f_ptr; const uint2* f_term; const Fr* f_coef; const Fr* f_coefm; const u8* f_kind; const u8* f_chain; const u32* f_group; u32 n_fr_groups;
+  const u64* f_ptr; const uint2* f_term; const Fr* f_coef; const Fr* f_coefm; const u8* f_kind; u32 n_fr_groups;   // (n_fr_groups = field rows: each a group of its own)
 };
 #endif
