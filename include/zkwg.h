@@ -57,7 +57,7 @@ extern "C" {
  * zero it, a non-zero word fails the email); zkwg_expand_device accepts out_stride >= 32 W (multiple of 16);
  * zkwg_scratch_bytes includes the Montgomery-copy area; zkwg_segment.pad is kernel-private.
  * Added since without breaking 2: zkwg_expand_host / zkwg_set_host_expand, zkwg_circuit_attach_r1cs / zkwg_expand_abc_device /
- * zkwg_abc_bytes, ZKWG_MAIN_FP_MUL. */
+ * zkwg_expand_abc_host / zkwg_abc_bytes, ZKWG_MAIN_FP_MUL. */
 #define ZKWG_ABI_VERSION 2
 
 /* `component main = ...` choices (the reference's own test mains). */
@@ -384,6 +384,12 @@ int zkwg_circuit_attach_r1cs(zkwg_circuit_t* c, const uint8_t* r1cs, uint64_t le
 uint64_t zkwg_abc_bytes(const zkwg_circuit_t* c);
 int zkwg_expand_abc_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails, const void* d_scratch,
                            uint64_t first, uint64_t count, int montgomery, void* d_abc, uint64_t abc_stride, void* hip_stream);
+/* The same values (standard form) written by the host from a host copy of the scratch buffer, like zkwg_expand_host for the
+ * witness: rows_on_host = 0 -- the image was prepared by the device with the system already attached (only the image crosses
+ * PCIe); rows_on_host = 1 -- the row tables are evaluated on the host too (scratch_host is written; the complete path of a
+ * layout-only handle, used by the CPU tests).  out: 16-byte aligned, out_stride >= zkwg_abc_bytes. */
+int zkwg_expand_abc_host(const zkwg_circuit_t* c, const uint8_t* packed_inputs, uint64_t n_emails, uint8_t* scratch_host,
+                         uint64_t first, uint64_t count, int rows_on_host, uint8_t* out, uint64_t out_stride);
 
 /* ---- the compact image as a device-side interchange format --------------------------
  * zkwg_prepare_device leaves, per email, a compact IMAGE in the scratch buffer (~0.45 MB instead of the 57 MB

@@ -545,6 +545,17 @@ def test_prover_first_stage_from_the_compact_image(main):
         c1.expand_abc_device(d_in, n, scr, 1, 2, part, s, montgomery=mont)
         torch.cuda.synchronize()
         assert torch.equal(part, want[1:3])
+        if not mont:
+            # the same from a host copy of the device-prepared image (zkwg_expand_abc_host: only the image crosses PCIe)
+            import ctypes as C
+            h_scr = bytearray(scr.cpu().numpy().tobytes())
+            h_ptr = (C.c_uint8 * len(h_scr)).from_buffer(h_scr)
+            recs_h = bytes(d_in.cpu().numpy().tobytes())
+            host = c1.expand_abc_host(recs_h, n, h_ptr, 1, 2, rows_on_host=False)
+            assert host == bytes(want[1:3].cpu().numpy().tobytes())
+            if main == "rsa":
+                host2 = c1.expand_abc_host(recs_h, n, h_ptr, 0, 1, rows_on_host=True)     # rows recomputed on the host: same bytes
+                assert host2 == bytes(want[0:1].cpu().numpy().tobytes())
     assert any(int(x) for x in want[0, :4096].cpu().tolist())
 
 
@@ -571,3 +582,62 @@ def test_attach_r1cs_host_logic():
         other.attach_r1cs(b"not an r1cs file")
     rc = c.lib.zkwg_expand_abc_device(c.h, 1, 1, 256, 0, 1, 0, 1, c.abc_bytes, None)
     assert rc == -3        # ZKWG_RC_NO_DEVICE (include/zkwg.h)
+
+
+def _abc_on_the_host(c, cons, rec, run_core):
+    """A.w | B.w | C.w through zkwg_expand_abc_host with the row tables evaluated on the host, from the image the host
+    build of the compute core leaves; returns (got, want-from-oracle-free Python evaluation over `witness`)."""
+    import ctypes as C
+    lay = c.image_layout(1)
+    raw = (C.c_uint8 * (lay["total_bytes"] + 256))()
+    base = (-C.addressof(raw)) % 256
+    at = lambda off: C.c_void_p(C.addressof(raw) + base + off)
+    small = (C.c_uint32 * lay["small_words"]).from_address(at(lay["off_small"]).value)
+    run_core(at(lay["off_bits"]), at(lay["off_small"]), at(lay["off_fr"]), small)
+    out = c.expand_abc_host(rec, 1, C.c_void_p(C.addressof(raw) + base), 0, 1, rows_on_host=True)
+    m = len(cons)
+    assert len(out) == 96 * m
+    return [int.from_bytes(out[32 * i:32 * i + 32], "little") for i in range(3 * m)]
+
+
+def test_prover_first_stage_tables_evaluated_on_the_host():
+    """zk_o0_build's tables for an attached constraint system (descriptors, run-compressed terms, one-word / two-word
+    integer rows, chains, field rows, pre-decoded slots) checked without a GPU: zkwg_expand_abc_host evaluates them with the
+    kernels' own decode functions (csrc/zkwg_o0_dec.h) over the image the host build of the RSA / FpMul core produces;
+    expected = the combinations evaluated in Python integers over the oracle's witness."""
+    import ctypes as C
+    import zkwg
+    from zkwg import r1cs as zr
+    from zkwg._lib import Config, MAIN_RSA_VERIFIER, MAIN_FP_MUL
+    from test_rsa_cpu import KAT_MSG, KAT_PUB, KAT_SIG, limbs, oracle_rsa
+    lib = hosttest.load()
+    ev = lambda d, w: sum(cf * w[k] for k, cf in d.items()) % ru.P
+
+    def check(c, cons, rec, run_core, witness):
+        c.attach_r1cs(zr.write_r1cs(c.W, cons))
+        got = _abc_on_the_host(c, cons, rec, run_core)
+        want = [ev(t[j], witness) for j in range(3) for t in cons]
+        bad = [i for i in range(len(want)) if got[i] != want[i]]
+        assert not bad, (len(bad), bad[:5])
+        assert any(v > (1 << 200) for v in want) and any(0 < v < 1000 for v in want)     # negative / field values and small ones
+
+    # RSAVerifier65537(121,17): the reference's 1,024-bit known answer (rsa.test.ts:64-103)
+    c = zkwg.Circuit(zkwg.MAIN_RSA_VERIFIER, max_header=0, max_body=0, device=-1)
+    cons = zr.rsa_main_constraints(c.symbols())
+    rec = c.pack({"signature": limbs(KAT_SIG), "modulus": limbs(KAT_PUB), "message": KAT_MSG})
+    h = lib.ht_create(C.byref(Config(MAIN_RSA_VERIFIER, 0, 0, 121, 17, 0, 0, 0, 0, 0)))
+
+    def rsa_core(bits, small_p, frv, small):
+        small[lib.ht_m_one(h)] = 1
+        assert lib.ht_run_rsa(h, rec, None, bits, small_p, frv) == 1
+    check(c, cons, rec, rsa_core, oracle_rsa(KAT_MSG, limbs(KAT_SIG), limbs(KAT_PUB)))
+    lib.ht_destroy(h)
+    # FpMul(3,17) and the reference's FpMul(2,4) known answer (fp-mul.test.ts:34-46)
+    from test_fpmul import chunks, oracle_fpmul
+    for n, k, a, b, p in ((2, 4, [1, 0, 1, 0], [0, 1, 1, 0], [1, 1, 1, 1]), (3, 17, chunks(2 ** 50 - 3, 3, 17), chunks(2 ** 49 + 12345, 3, 17), chunks(2 ** 51 - 129, 3, 17))):
+        c = zkwg.Circuit(zkwg.MAIN_FP_MUL, max_header=0, max_body=0, n=n, k=k, device=-1)
+        cons = zr.fp_mul_main_constraints(c.symbols(), n, k)
+        rec = c.pack({"a": a, "b": b, "p": p})
+        h = lib.ht_create(C.byref(Config(MAIN_FP_MUL, 0, 0, n, k, 0, 0, 0, 0, 0)))
+        check(c, cons, rec, lambda bits, small_p, frv, small: lib.ht_run_fpmul(h, rec, bits, small_p, frv), oracle_fpmul(n, k, a, b, p)[0])
+        lib.ht_destroy(h)

@@ -18,6 +18,7 @@
 #include "zkwg_poseidon_sparse.h"
 #include "zkwg_full.h"
 #include "zkwg_o0.h"
+#include "zkwg_o0_dec.h"
 #include "zkwg_expand_dec.h"
 #define ZK_FR_LANES 8u   // lanes per group of zk_o0_rows_fr (zkwg_kernels_expand3.hip)
 #include <atomic>
@@ -161,7 +162,7 @@ static void zk_host_segment(const ZkSeg& sg, const ZkCtx& cx, const ZkRefSrc& R,
 extern "C" int zk_misc_init_tables(void);
 
 // descriptor + row tables of a numbered layout (zkwg_o0.h) onto the device; the host copy keeps its counters only
-static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W) {
+static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W, bool keep_host = false) {
   bool ok = true;
   memset(&O, 0, sizeof(O));
   auto up = [&](const void* src, size_t bytes, void** dst) {
@@ -197,7 +198,7 @@ static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W) {
   O.W = W; O.nportions = (u32)((W + 256u * c->x3_k_o0 - 1) / (256u * c->x3_k_o0)); O.small_base = T.small_base; O.fr_base = T.fr_base;
   O.emails_per_wg = (u32)c->o0_emails_per_wg;
   O.n_fr_groups = (u32)T.n_fr();   // (field rows are never chained: one group each)
-  if (ok) { ZkO0Tables keep; keep.small_base = T.small_base; keep.fr_base = T.fr_base; keep.gen_base = T.gen_base; keep.n_alias = T.n_alias; keep.n_const = T.n_const; std::swap(T, keep); }
+  if (ok && !keep_host) { ZkO0Tables keep; keep.small_base = T.small_base; keep.fr_base = T.fr_base; keep.gen_base = T.gen_base; keep.n_alias = T.n_alias; keep.n_const = T.n_const; std::swap(T, keep); }
   return ok;
 }
 static void free_o0(ZkO0Dev& O) {
@@ -1063,7 +1064,7 @@ int zkwg_circuit_attach_r1cs(zkwg_circuit_t* c, const uint8_t* r1cs, uint64_t le
     if (c->device >= 0) {
       ZkDeviceGuard dg(c->device);
       if (!dg.ok) return ZKWG_RC_HIP_ERROR;
-      if (!upload_o0(c, c->abct, c->abcd, 3 * m)) { free_o0(c->abcd); return ZKWG_RC_OOM; }
+      if (!upload_o0(c, c->abct, c->abcd, 3 * m, true)) { free_o0(c->abcd); return ZKWG_RC_OOM; }   // (the host copy serves zkwg_expand_abc_host)
     }
     c->s = s2;
     c->abc_m = m;
@@ -1079,6 +1080,59 @@ uint64_t zkwg_abc_bytes(const zkwg_circuit_t* c) { return c ? 96 * c->abc_m : 0;
 int zkwg_expand_abc_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, const void* d_scratch, uint64_t first, uint64_t count,
                            int montgomery, void* d_abc, uint64_t abc_stride, void* hip_stream) {
   return expand_impl(c, d_in, n, d_scratch, first, count, d_abc, abc_stride, hip_stream, montgomery != 0, true);
+}
+// The same values written by the host from a host copy of the scratch buffer (standard form): with `rows_on_host` = 0 the image
+// comes from zkwg_prepare_device of a handle that already had the system attached (its row results are in the image; only
+// the 4.4 MB image crosses PCIe instead of 72 MB of evaluations); with 1 the row tables are evaluated here as well -- the
+// whole path of a layout-only handle, which is how the CPU tests check zk_o0_build's tables without a GPU.
+int zkwg_expand_abc_host(const zkwg_circuit_t* c, const uint8_t* records, uint64_t n, uint8_t* scratch_host, uint64_t first,
+                         uint64_t count, int rows_on_host, uint8_t* out, uint64_t out_stride) {
+  if (!c || !records || !scratch_host || !out) return ZKWG_RC_BAD_ARG;
+  if (!c->abc_m || c->abct.desc.size() != 6 * c->abc_m) return ZKWG_RC_BAD_CONFIG;
+  const ZkSched& s = c->s;
+  const ZkO0Tables& T = c->abct;
+  const u64 W3 = 3 * c->abc_m;
+  if (first + count > n || out_stride < W3 * 32 || (out_stride & 15) || ((uintptr_t)out & 15)) return ZKWG_RC_BAD_ARG;
+  const ZkScratchLayout L = scratch_layout(s, n);
+  for (u64 el = 0; el < count; ++el) {
+    const u64 e = first + el;
+    u32* small_w = (u32*)(scratch_host + L.off_small) + e * s.img_small;
+    Fr* frv_w = (Fr*)(scratch_host + L.off_fr) + e * s.img_fr;
+    ZkCtx cx;
+    cx.rec = records + e * s.in_stride; cx.bits = (const u64*)(scratch_host + L.off_bits) + e * s.img_bits; cx.small = small_w;
+    cx.half = (int)s.inv_half; cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm; cx.m_dfa_st = s.m_dfa_st;
+    cx.net_desc = c->net.slot_desc.data(); cx.net_fn = c->net.fn_tab.data(); cx.hdr_off = s.in_off[ZKWG_IN_HEADER];
+    ZkRefSrc R;
+    R.frv = (const uint4*)frv_w; R.invtab = (const uint4*)c->invtab_host.data(); R.rec = cx.rec; R.small = cx.small;
+    if (rows_on_host) {
+      // zk_o0_generic, zk_o0_rows_small / _long / zk_o0_chains_small, zk_o0_rows_fr of zkwg_kernels_expand3.hip, one row at a time
+      for (size_t g = 0; g < T.gen_seg.size(); ++g) small_w[T.gen_base + g] = zk_decode_any(c->segs[T.gen_seg[g]], T.gen_r[g], cx);
+      long long prev = 0;
+      for (u64 j = 0; j < T.n_small(); ++j) {
+        long long acc = T.s_chain[j] ? prev : 0;
+        for (u64 t = T.s_ptr[j]; t < T.s_ptr[j + 1]; ++t)
+          acc += (long long)T.s_coef[t] * zk_code_int(zk_desc_decode(T.s_term[2 * t], T.s_term[2 * t + 1], cx), cx);
+        prev = acc;
+        const u32 where = T.s_out[j];
+        small_w[where & 0x7fffffffu] = (u32)(u64)acc;
+        if (where >> 31) small_w[(where & 0x7fffffffu) + 1] = (u32)((u64)acc >> 32);
+      }
+      for (u64 j = 0; j < T.n_fr(); ++j) {
+        Fr acc = fr_zero();
+        for (u64 t = T.f_ptr[j]; t < T.f_ptr[j + 1]; ++t) {
+          const Fr x = zk_code_value(zk_desc_decode(T.f_term[2 * t], T.f_term[2 * t + 1], cx), R);
+          if (T.f_kind[t] == ZK_COEF_ONE) acc = fr_add(acc, x);
+          else if (T.f_kind[t] == ZK_COEF_MINUS_ONE) acc = fr_sub(acc, x);
+          else acc = fr_add(acc, fr_mont_mul(x, T.f_coefm[t]));
+        }
+        frv_w[T.fr_base + j] = acc;
+      }
+    }
+    u8* w = out + el * out_stride;
+    for (u64 i = 0; i < W3; ++i) zk_host_put(w + 32 * i, zk_desc_decode(T.desc[2 * i], T.desc[2 * i + 1], cx), R);
+  }
+  _mm_sfence();
+  return ZKWG_RC_OK;
 }
 
 int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_out,

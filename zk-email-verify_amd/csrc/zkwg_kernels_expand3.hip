@@ -27,6 +27,7 @@
 #include "zkwg_expand_dec.h"
 #include "zkwg_kernels.h"
 #include "zkwg_o0.h"
+#include "zkwg_o0_dec.h"
 
 __device__ __forceinline__ uint4 zk_fr_half4(const Fr& m, u32 hf) {
   const u64 x = m.l[2 * hf], y = m.l[2 * hf + 1];
@@ -188,33 +189,6 @@ __global__ __launch_bounds__(256) void zk_image_to_mont(ZkX3 A) {
 }
 
 // ---------------------------------------------------------------- numbered circuits (`--O0` / `--O1`), one pass
-// codes of integer row results: a small non-negative value is an immediate, a small negative one the load-free r - m
-// (every bit constraint has a B side of 0 / -1: a reference into the image would put a dependent load in front of the store)
-__device__ __forceinline__ u32 zk_narrow_code(u32 w, u32 b) {
-  if (!(w >> 31)) return w;
-  return w > 0xf0000000u ? (ZK_REF_MINUS | (0u - w)) : (ZK_REF_NEG | b);
-}
-__device__ __forceinline__ u32 zk_wide_code(u32 lo, u32 hi, u32 b) {
-  if (hi == 0u && !(lo >> 31)) return lo;
-  if (hi == 0xffffffffu && lo > 0xf0000000u) return ZK_REF_MINUS | (0u - lo);
-  return ZK_REF_I64 | b;
-}
-// the code of one wire from its descriptor (zkwg_o0.h)
-__device__ __forceinline__ u32 zk_desc_decode(u32 a, u32 b, const ZkCtx& cx, const ZkSeg* __restrict__ segs) {
-  switch (a >> 28) {
-    case ZK_D_IMM: return b;
-    case ZK_D_BIT64: return (u32)(cx.bits[b] >> (a & 63u)) & 1u;
-    case ZK_D_BITRUN: return (u32)(cx.bits[b] >> (a & 63u)) & ((2u << ((a >> 6) & 31u)) - 1u);
-    case ZK_D_BIT8: return (u32)(cx.rec[b] >> (a & 7u)) & 1u;
-    case ZK_D_BYTE: return cx.rec[b];
-    case ZK_D_SMALLRAW: return zk_raw_code(cx.small[b], b);
-    case ZK_D_CODEW: return cx.small[b];
-    case ZK_D_SMALLN: return zk_narrow_code(cx.small[b], b);
-    case ZK_D_SMALLS: return zk_wide_code(cx.small[b], cx.small[b + 1], b);
-    case ZK_D_DFA: return zk_dfa_value((a >> 24) & 15u, (a >> 9) & 0x7ffu, (a >> 20) & 15u, a & 511u, b, cx.small + cx.m_dfa_st, cx.small + cx.m_dfa_cm, cx.small + cx.m_dfa_pm, cx.half);
-    default: return 0u;   // (no wire keeps kind GENERIC: zk_o0_build turns them into CODEW)
-  }
-}
 // What a descriptor reads, resolved once per workgroup: one 64-bit word of `bits`, one byte of the record, two words of
 // `small` (index 0 of each array when the kind does not use it).  Per email the lane then issues all its loads back to
 // back -- nothing between them depends on a loaded value -- and only afterwards turns them into codes.
@@ -301,24 +275,12 @@ __global__ __launch_bounds__(256) void zk_o0_generic(ZkX3 A, ZkO0Dev O) {
   const ZkSeg sg = A.segs[O.gen_seg[g]];
   A.small_w[(u64)e * A.img_small + O.gen_base + g] = zk_decode_any(sg, O.gen_r[g], cx);
 }
-// the value of a code as a signed integer (small rows: every source is small-ranged by construction)
-__device__ __forceinline__ long long zk_code_int(u32 code, const ZkCtx& cx) {
-  if (!(code >> 31)) return (long long)code;
-  const u32 p = ZK_REF_PAYLOAD(code);
-  if (ZK_REF_TYPE(code) == 6u) return -(long long)p;                               // MINUS
-  const u32 w = cx.small[p];
-  switch (ZK_REF_TYPE(code)) {
-    case 3: return (long long)w;                                                   // RAW
-    case 4: return (long long)((int)(w << 1) >> 1);                                // NEG
-    default: return (long long)((u64)w | ((u64)cx.small[p + 1] << 32));            // I64 (no other reference is small-ranged)
-  }
-}
 // rows whose sources, coefficients and result are small integers: 64-bit integer arithmetic
-__device__ __forceinline__ long long zk_small_row_terms(const ZkO0Dev& O, u32 j, const ZkCtx& cx, const ZkSeg* __restrict__ segs) {
+__device__ __forceinline__ long long zk_small_row_terms(const ZkO0Dev& O, u32 j, const ZkCtx& cx) {
   long long acc = 0;
   for (u64 t = O.s_ptr[j]; t < O.s_ptr[j + 1]; ++t) {
     const uint2 d = O.s_term[t];
-    acc += (long long)O.s_coef[t] * zk_code_int(zk_desc_decode(d.x, d.y, cx, segs), cx);
+    acc += (long long)O.s_coef[t] * zk_code_int(zk_desc_decode(d.x, d.y, cx), cx);
   }
   return acc;
 }
@@ -421,7 +383,7 @@ __global__ __launch_bounds__(64) void zk_o0_chains_small(ZkX3 A, ZkO0Dev O) {
   if (coop) {
     for (u64 t = h0 + lane; t < h1; t += 64u) {
       const uint2 d = O.s_term[t];
-      head += (long long)O.s_coef[t] * zk_code_int(zk_desc_decode(d.x, d.y, cx, A.segs), cx);
+      head += (long long)O.s_coef[t] * zk_code_int(zk_desc_decode(d.x, d.y, cx), cx);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -432,7 +394,7 @@ __global__ __launch_bounds__(64) void zk_o0_chains_small(ZkX3 A, ZkO0Dev O) {
   for (u32 base = 0; base < ch.y; base += 64u) {
     const bool live = base + lane < ch.y;
     const u32 j = ch.x + base + lane;
-    long long v = !live ? 0 : (coop && base + lane == 0u) ? head : zk_small_row_terms(O, j, cx, A.segs);
+    long long v = !live ? 0 : (coop && base + lane == 0u) ? head : zk_small_row_terms(O, j, cx);
 #pragma unroll
     for (u32 d = 1; d < 64u; d <<= 1) {
       const u32 lo = __shfl_up((u32)(u64)v, d), hi = __shfl_up((u32)((u64)v >> 32), d);
@@ -444,11 +406,6 @@ __global__ __launch_bounds__(64) void zk_o0_chains_small(ZkX3 A, ZkO0Dev O) {
   }
 }
 // the other rows: arithmetic mod r (zk_linear_row's), sources decoded from the image
-__device__ __forceinline__ Fr zk_code_value(u32 code, const ZkRefSrc& R) {
-  if (!(code >> 31)) return Fr{{(u64)code, 0, 0, 0}};
-  const uint4 a = zk_ref_half(code, 0u, R), b = zk_ref_half(code, 1u, R);
-  return Fr{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
-}
 // 8 lanes per row and ZK_FR_EMAILS emails per lane: the lanes split the row's terms; per term the descriptor, kind and
 // coefficient are read once and the image loads of all the emails are issued back to back (the kernel is a chain of
 // dependent loads: what counts is how many are in flight); the partial sums are folded with shuffles

@@ -306,6 +306,16 @@ class Circuit:
         _check(self.lib.zkwg_expand_abc_device(self.h, d_in.data_ptr(), n, d_scratch.data_ptr(), first, count, 1 if montgomery else 0,
                                                d_out.data_ptr(), out_stride or self.abc_bytes, sp))
 
+    def expand_abc_host(self, records, n, scratch_host, first, count, rows_on_host=False):
+        """zkwg_expand_abc_host: A.w | B.w | C.w of emails [first, first+count) from a host copy of the scratch buffer (a
+        ctypes array; written when rows_on_host) -> bytes"""
+        out = (C.c_uint8 * (count * self.abc_bytes + 16))()
+        addr = C.addressof(out)
+        off = (-addr) % 16
+        _check(self.lib.zkwg_expand_abc_host(self.h, records, n, scratch_host, first, count, 1 if rows_on_host else 0,
+                                             C.c_void_p(addr + off), self.abc_bytes))
+        return bytes(memoryview(out)[off:off + count * self.abc_bytes])
+
     def scratch_bytes(self, n):
         return self.lib.zkwg_scratch_bytes(self.h, n)
 
