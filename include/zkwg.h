@@ -390,6 +390,12 @@ int zkwg_expand_abc_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint6
  * layout-only handle, used by the CPU tests).  out: 16-byte aligned, out_stride >= zkwg_abc_bytes. */
 int zkwg_expand_abc_host(const zkwg_circuit_t* c, const uint8_t* packed_inputs, uint64_t n_emails, uint8_t* scratch_host,
                          uint64_t first, uint64_t count, int rows_on_host, uint8_t* out, uint64_t out_stride);
+/* Layout-only handles of a fully numbered circuit (zkwg_circuit_create_full with device < 0): the complete witness of emails
+ * [first, first + count) from a host copy of their images, evaluated through the same descriptor / row tables the device
+ * kernels read (scratch_host is written: the row results).  A test hook like zkwg_o0_gather_host; device handles keep these
+ * tables on the device only (BAD_CONFIG). */
+int zkwg_expand_full_host(const zkwg_circuit_t* c, const uint8_t* packed_inputs, uint64_t n_emails, uint8_t* scratch_host,
+                          uint64_t first, uint64_t count, uint8_t* out, uint64_t out_stride);
 
 /* ---- the compact image as a device-side interchange format --------------------------
  * zkwg_prepare_device leaves, per email, a compact IMAGE in the scratch buffer (~0.45 MB instead of the 57 MB

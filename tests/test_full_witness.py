@@ -47,7 +47,24 @@ def test_rsa_main_complete_witness_from_sym_and_r1cs_on_the_host():
     assert st == [0]
     full = _host_complete(c, wit[0])
     assert hashlib.sha256(full).hexdigest() == meta["witness_sha256"]
-    assert c.o0_gather_host(wit[0]) == full      # the wire table + rows the device kernels use (zk_o0_gather / zk_o0_rows)
+    assert c.o0_gather_host(wit[0]) == full      # the linear plan over the kept-v1 witness (round 2's gather tables)
+    # the tables the device kernels read since round 3 -- per-wire descriptors, integer / field rows, chains, pre-decoded
+    # slots (csrc/zkwg_o0.h) -- evaluated on the host by the kernels' own decode functions over the image the host build of
+    # the RSA core produces (zkwg_expand_full_host)
+    import ctypes as C
+    import hosttest
+    from zkwg._lib import Config, MAIN_RSA_VERIFIER
+    lib = hosttest.load()
+    h = lib.ht_create(C.byref(Config(MAIN_RSA_VERIFIER, 0, 0, 121, 17, 0, 0, 0, 0, 0)))
+    rec = c.pack({k: v for k, v in meta["inputs"].items()})
+    lay = c.image_layout(1)
+    raw = (C.c_uint8 * (lay["total_bytes"] + 256))()
+    base = (-C.addressof(raw)) % 256
+    at = lambda off: C.c_void_p(C.addressof(raw) + base + off)
+    (C.c_uint32 * lay["small_words"]).from_address(at(lay["off_small"]).value)[lib.ht_m_one(h)] = 1
+    assert lib.ht_run_rsa(h, rec, None, at(lay["off_bits"]), at(lay["off_small"]), at(lay["off_fr"])) == 1
+    lib.ht_destroy(h)
+    assert c.expand_full_host(rec, 1, at(0), 0, 1) == full
     for k, v in meta["sample"].items():
         assert int.from_bytes(full[32 * int(k):32 * int(k) + 32], "little") == int(v)
     # without the .r1cs the same file is refused: it numbers signals the schedule does not produce

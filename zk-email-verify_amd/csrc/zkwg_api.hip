@@ -1085,13 +1085,11 @@ int zkwg_expand_abc_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, cons
 // comes from zkwg_prepare_device of a handle that already had the system attached (its row results are in the image; only
 // the 4.4 MB image crosses PCIe instead of 72 MB of evaluations); with 1 the row tables are evaluated here as well -- the
 // whole path of a layout-only handle, which is how the CPU tests check zk_o0_build's tables without a GPU.
-int zkwg_expand_abc_host(const zkwg_circuit_t* c, const uint8_t* records, uint64_t n, uint8_t* scratch_host, uint64_t first,
-                         uint64_t count, int rows_on_host, uint8_t* out, uint64_t out_stride) {
+static int tables_host(const zkwg_circuit* c, const ZkO0Tables& T, u64 W3, const uint8_t* records, uint64_t n, uint8_t* scratch_host,
+                       uint64_t first, uint64_t count, int rows_on_host, uint8_t* out, uint64_t out_stride) {
   if (!c || !records || !scratch_host || !out) return ZKWG_RC_BAD_ARG;
-  if (!c->abc_m || c->abct.desc.size() != 6 * c->abc_m) return ZKWG_RC_BAD_CONFIG;
+  if (!W3 || T.desc.size() != 2 * W3) return ZKWG_RC_BAD_CONFIG;   // (a device handle of a numbered circuit keeps its tables on the device only)
   const ZkSched& s = c->s;
-  const ZkO0Tables& T = c->abct;
-  const u64 W3 = 3 * c->abc_m;
   if (first + count > n || out_stride < W3 * 32 || (out_stride & 15) || ((uintptr_t)out & 15)) return ZKWG_RC_BAD_ARG;
   const ZkScratchLayout L = scratch_layout(s, n);
   for (u64 el = 0; el < count; ++el) {
@@ -1133,6 +1131,18 @@ int zkwg_expand_abc_host(const zkwg_circuit_t* c, const uint8_t* records, uint64
   }
   _mm_sfence();
   return ZKWG_RC_OK;
+}
+int zkwg_expand_abc_host(const zkwg_circuit_t* c, const uint8_t* records, uint64_t n, uint8_t* scratch_host, uint64_t first,
+                         uint64_t count, int rows_on_host, uint8_t* out, uint64_t out_stride) {
+  if (!c) return ZKWG_RC_BAD_ARG;
+  return tables_host(c, c->abct, 3 * c->abc_m, records, n, scratch_host, first, count, rows_on_host, out, out_stride);
+}
+// layout-only handles of a numbered circuit (zkwg_circuit_create_full): the complete witness from one image, through the very
+// descriptor / row tables the device kernels read (tests)
+int zkwg_expand_full_host(const zkwg_circuit_t* c, const uint8_t* records, uint64_t n, uint8_t* scratch_host, uint64_t first,
+                          uint64_t count, uint8_t* out, uint64_t out_stride) {
+  if (!c) return ZKWG_RC_BAD_ARG;
+  return tables_host(c, c->o0t, c->full_W, records, n, scratch_host, first, count, 1, out, out_stride);
 }
 
 int zkwg_calculate_batch_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d_out,

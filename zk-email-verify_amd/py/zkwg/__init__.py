@@ -316,6 +316,14 @@ class Circuit:
                                              C.c_void_p(addr + off), self.abc_bytes))
         return bytes(memoryview(out)[off:off + count * self.abc_bytes])
 
+    def expand_full_host(self, records, n, scratch_host, first, count):
+        """zkwg_expand_full_host (layout-only handle of a numbered circuit): complete witnesses from host images -> bytes"""
+        out = (C.c_uint8 * (count * self.witness_bytes + 16))()
+        addr = C.addressof(out)
+        off = (-addr) % 16
+        _check(self.lib.zkwg_expand_full_host(self.h, records, n, scratch_host, first, count, C.c_void_p(addr + off), self.witness_bytes))
+        return bytes(memoryview(out)[off:off + count * self.witness_bytes])
+
     def scratch_bytes(self, n):
         return self.lib.zkwg_scratch_bytes(self.h, n)
 
