@@ -1,6 +1,7 @@
 """Throughput of complete `--O0`-numbered witnesses (zkwg_circuit_create_full) for
-EmailVerifier(576,192) -- or `bench_full.py 1024 1536` -- : zk_expand into a staging buffer, zk_o0_gather / zk_o0_rows.
-Needs artifacts/o0_ev_576_192.* (built by __graft_entry__.build() where /root/reference exists; travels to
+EmailVerifier(576,192) -- or `bench_full.py 1024 1536` -- : the row kernels at the end of prepare, then zk_expand3_o0 (one pass
+from per-wire descriptors), beside the kept-v1 witness of the same circuit.  ZKWG_BENCH_PRIO="expand,prepare" stream priorities,
+ZKWG_BENCH_PREP = emails per prepare launch.  Needs artifacts/o0_ev_576_192.* (built by __graft_entry__.build() where /root/reference exists; travels to
 the GPU box) -- a measurement aid, not part of the product."""
 import gzip
 import json
