@@ -30,13 +30,17 @@
 #include "zkwg_o0_dec.h"
 
 __device__ __forceinline__ uint4 zk_fr_half4(const Fr& m, u32 hf) {
-  const u64 x = m.l[2 * hf], y = m.l[2 * hf + 1];
+  const u64 x = hf ? m.l[2] : m.l[0], y = hf ? m.l[3] : m.l[1];   // (selects: a runtime index would put the element in scratch memory)
   return make_uint4((u32)x, (u32)(x >> 32), (u32)y, (u32)(y >> 32));
 }
-// Montgomery form of the rare values no table holds
-__device__ __noinline__ uint4 zk_mont_slow(u32 code, u32 hf, const ZkX3& A, const ZkRefSrc& R) {
+// Montgomery form of the rare values no table holds.  Out of line, with the reference sources passed BY VALUE: a reference
+// to the ZkRefSrc of the caller would force that struct into scratch memory -- 32 bytes per lane stored on every email
+// iteration whether or not the call happens (PMC: 1.39 x the algorithmic bytes written by the Montgomery kernels, r03_pmc_abc)
+__device__ __noinline__ uint4 zk_mont_slow(u32 code, u32 hf, const uint4* frv, const uint4* invtab, const u8* rec, const u32* small) {
   if (!(code >> 31)) return zk_fr_half4(fr_to_mont(Fr{{(u64)code, 0, 0, 0}}), hf);   // an immediate >= 2^16
   // RAW / NEG / I64: standard-form value first (zk_ref_half), then one product
+  ZkRefSrc R;
+  R.frv = frv; R.invtab = invtab; R.rec = rec; R.small = small;
   const uint4 a = zk_ref_half(code, 0u, R), b = zk_ref_half(code, 1u, R);
   const Fr x{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
   return zk_fr_half4(fr_to_mont(x), hf);
@@ -50,7 +54,7 @@ __device__ __forceinline__ uint4 zk_slot_half(u32 code, u32 hf, const ZkX3& A, c
     if (!(code >> 31)) {
       if (code <= 1u) return code ? zk_fr_half4(fr_R(), hf) : zk_zero4();   // R = 2^256 mod r
       if (code < 65536u) return ((const uint4*)A.rtab)[2u * code + hf];
-      return zk_mont_slow(code, hf, A, R);
+      return zk_mont_slow(code, hf, R.frv, R.invtab, R.rec, R.small);
     }
     const u32 t = ZK_REF_TYPE(code), p = ZK_REF_PAYLOAD(code);
     if (t == 0u) return R.frv[2u * p + hf];                                       // Montgomery copy of the image's fr
@@ -83,7 +87,7 @@ __device__ __forceinline__ uint4 zk_slot_half(u32 code, u32 hf, const ZkX3& A, c
         return make_uint4((u32)d2, (u32)(d2 >> 32), (u32)d3, (u32)(d3 >> 32));
       }
     }
-    return zk_mont_slow(code, hf, A, R);
+    return zk_mont_slow(code, hf, R.frv, R.invtab, R.rec, R.small);
   }
 }
 
