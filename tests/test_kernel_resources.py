@@ -1,0 +1,41 @@
+"""Compile-time properties of the streaming kernels that the roofline depends on (checked with the cross-compiler, no GPU):
+no scratch memory in any kernel of zkwg_kernels_expand3.hip -- a struct passed by reference to an out-of-line function once
+cost the Montgomery kernels 1.39 x their algorithmic HBM writes -- and the register budgets that give
+the standard-form kernels 8 wavefronts per SIMD."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "zk-email-verify_amd", "csrc")
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
+def test_streaming_kernels_use_no_scratch_memory_and_keep_their_occupancy(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", os.path.join(CSRC, "zkwg_kernels_expand3.hip"),
+                        "-o", str(tmp_path / "x3.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    info, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            info[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            info[cur][m.group(1).strip()] = int(m.group(2))
+    kernels = {k: v for k, v in info.items() if "zk_" in k}
+    assert len(kernels) >= 20, sorted(info)
+    for k, v in kernels.items():
+        assert v.get("ScratchSize") == 0, (k, v)
+    by = lambda frag: next(v for k, v in kernels.items() if frag in k)
+    # the headline kernel: <= 64 VGPRs = 8 wavefronts per SIMD; the descriptor-driven one at its default K = 2: at least 6
+    for frag in ("13zk_expand3_k4", "13zk_expand3_k2"):
+        assert by(frag)["VGPRs"] <= 64 and by(frag)["Occupancy"] == 8, (frag, by(frag))
+    assert by("16zk_expand3_o0_k2")["VGPRs"] <= 80 and by("16zk_expand3_o0_k2")["Occupancy"] >= 6, by("16zk_expand3_o0_k2")
