@@ -1055,17 +1055,19 @@ int zkwg_circuit_attach_r1cs(zkwg_circuit_t* c, const uint8_t* r1cs, uint64_t le
       }
     std::string err;
     ZkSched s2 = c->s;   // (the image grows by the row results: committed only when everything succeeded)
-    if (!zk_o0_build(s2, c->segs, P, desc_slot, P.src, c->abct, err)) { g_last_error = err; return ZKWG_RC_BAD_CONFIG; }
+    ZkO0Tables T;         // (built aside: a failed attachment leaves the handle as it was)
+    if (!zk_o0_build(s2, c->segs, P, desc_slot, P.src, T, err)) { g_last_error = err; return ZKWG_RC_BAD_CONFIG; }
     if (getenv("ZKWG_DEBUG_PLAN"))
       fprintf(stderr, "[zkwg] A.w|B.w|C.w tables: %llu combinations, %llu single wires, %llu empty, %llu small rows (%llu terms), %llu field rows (%llu terms), %llu pre-decoded slots; image %u -> %u small words, %u -> %u field elements\n",
-              (unsigned long long)(3 * m), (unsigned long long)c->abct.n_alias, (unsigned long long)c->abct.n_const, (unsigned long long)c->abct.n_small(),
-              (unsigned long long)c->abct.s_coef.size(), (unsigned long long)c->abct.n_fr(), (unsigned long long)c->abct.f_kind.size(),
-              (unsigned long long)c->abct.gen_seg.size(), c->s.img_small, s2.img_small, c->s.img_fr, s2.img_fr);
+              (unsigned long long)(3 * m), (unsigned long long)T.n_alias, (unsigned long long)T.n_const, (unsigned long long)T.n_small(),
+              (unsigned long long)T.s_coef.size(), (unsigned long long)T.n_fr(), (unsigned long long)T.f_kind.size(),
+              (unsigned long long)T.gen_seg.size(), c->s.img_small, s2.img_small, c->s.img_fr, s2.img_fr);
     if (c->device >= 0) {
       ZkDeviceGuard dg(c->device);
       if (!dg.ok) return ZKWG_RC_HIP_ERROR;
-      if (!upload_o0(c, c->abct, c->abcd, 3 * m, true)) { free_o0(c->abcd); return ZKWG_RC_OOM; }   // (the host copy serves zkwg_expand_abc_host)
+      if (!upload_o0(c, T, c->abcd, 3 * m, true)) { free_o0(c->abcd); return ZKWG_RC_OOM; }   // (the host copy serves zkwg_expand_abc_host)
     }
+    c->abct = std::move(T);
     c->s = s2;
     c->abc_m = m;
   } catch (const std::bad_alloc&) {
