@@ -1,0 +1,46 @@
+"""Golden digests of the prover's first stage (A.w | B.w | C.w, 32-byte little-endian values: the A values, then B, then C) for the
+reference's own known-answer inputs, computed WITHOUT the product: the combinations of zkwg.r1cs (derived from the reference
+templates) evaluated in Python integers over the oracle's witness.  Run from the repo root: python tests/golden/make_abc_digests.py"""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "zk-email-verify_amd", "py"))
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def digest(cons, w, montgomery=False):
+    sc = (1 << 256) if montgomery else 1
+    h = hashlib.sha256()
+    for j in range(3):
+        for t in cons:
+            h.update((sum(cf * w[k] for k, cf in t[j].items()) * sc % P).to_bytes(32, "little"))
+    return h.hexdigest()
+
+
+def main():
+    from oracle.pyref import zkemail as zk, comp
+    from zkwg import r1cs as zr
+    from test_rsa_cpu import KAT_MSG, KAT_PUB, KAT_SIG, limbs
+    out = {}
+    # packages/circuits/tests/rsa.test.ts:64-103
+    main_rsa = zk.RSAVerifier65537(121, 17, KAT_MSG, limbs(KAT_SIG), limbs(KAT_PUB), is_main=True)
+    cons = zr.rsa_main_constraints(comp.symbols_kept(main_rsa))
+    w = comp.witness_kept(main_rsa)
+    out["rsa_kat"] = {"constraints": len(cons), "standard": digest(cons, w), "montgomery": digest(cons, w, True)}
+    # packages/circuits/tests/fp-mul.test.ts:34-46
+    fp = zk.FpMul(2, 4, [1, 0, 1, 0], [0, 1, 1, 0], [1, 1, 1, 1])
+    fp.is_main = True
+    cons = zr.fp_mul_main_constraints(comp.symbols_kept(fp), 2, 4)
+    w = comp.witness_kept(fp)
+    out["fp_mul_2_4_kat"] = {"constraints": len(cons), "standard": digest(cons, w), "montgomery": digest(cons, w, True)}
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "abc_digests.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,9 @@ Num2Bits, a chain of Poseidon S-boxes, and large random satisfiable systems; exp
 pure-Python evaluator in the same file."""
 import ctypes as C
 
+import json
+import os
+
 import pytest
 
 import hosttest
@@ -540,6 +543,12 @@ def test_prover_first_stage_from_the_compact_image(main):
         torch.cuda.synchronize()
         assert torch.equal(got[:, :c1.abc_bytes], want)
         assert bool((got[:, c1.abc_bytes:] == 0xEE).all())
+        if main == "rsa":
+            # the committed digest of the reference's 1,024-bit RSA known answer (tests/golden/abc_digests.json: Python integers
+            # over the oracle's witness, no product code involved)
+            import hashlib
+            gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "abc_digests.json")))["rsa_kat"]
+            assert hashlib.sha256(got[0, :c1.abc_bytes].cpu().numpy().tobytes()).hexdigest() == gold["montgomery" if mont else "standard"]
         # a sub-range of the batch
         part = torch.empty((2, c1.abc_bytes), dtype=torch.uint8, device=dev)
         c1.expand_abc_device(d_in, n, scr, 1, 2, part, s, montgomery=mont)
@@ -613,12 +622,18 @@ def test_prover_first_stage_tables_evaluated_on_the_host():
     lib = hosttest.load()
     ev = lambda d, w: sum(cf * w[k] for k, cf in d.items()) % ru.P
 
-    def check(c, cons, rec, run_core, witness):
+    GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "abc_digests.json")))
+
+    def check(c, cons, rec, run_core, witness, golden=None):
         c.attach_r1cs(zr.write_r1cs(c.W, cons))
         got = _abc_on_the_host(c, cons, rec, run_core)
         want = [ev(t[j], witness) for j in range(3) for t in cons]
         bad = [i for i in range(len(want)) if got[i] != want[i]]
         assert not bad, (len(bad), bad[:5])
+        if golden is not None:       # tests/golden/abc_digests.json (make_abc_digests.py: Python integers over the oracle's witness)
+            import hashlib
+            assert hashlib.sha256(b"".join(v.to_bytes(32, "little") for v in got)).hexdigest() == GOLD[golden]["standard"]
+            assert GOLD[golden]["constraints"] == len(cons)
         assert any(v > (1 << 200) for v in want) and any(0 < v < 1000 for v in want)     # negative / field values and small ones
 
     # RSAVerifier65537(121,17): the reference's 1,024-bit known answer (rsa.test.ts:64-103)
@@ -630,7 +645,7 @@ def test_prover_first_stage_tables_evaluated_on_the_host():
     def rsa_core(bits, small_p, frv, small):
         small[lib.ht_m_one(h)] = 1
         assert lib.ht_run_rsa(h, rec, None, bits, small_p, frv) == 1
-    check(c, cons, rec, rsa_core, oracle_rsa(KAT_MSG, limbs(KAT_SIG), limbs(KAT_PUB)))
+    check(c, cons, rec, rsa_core, oracle_rsa(KAT_MSG, limbs(KAT_SIG), limbs(KAT_PUB)), golden="rsa_kat")
     lib.ht_destroy(h)
     # FpMul(3,17) and the reference's FpMul(2,4) known answer (fp-mul.test.ts:34-46)
     from test_fpmul import chunks, oracle_fpmul
@@ -639,5 +654,6 @@ def test_prover_first_stage_tables_evaluated_on_the_host():
         cons = zr.fp_mul_main_constraints(c.symbols(), n, k)
         rec = c.pack({"a": a, "b": b, "p": p})
         h = lib.ht_create(C.byref(Config(MAIN_FP_MUL, 0, 0, n, k, 0, 0, 0, 0, 0)))
-        check(c, cons, rec, lambda bits, small_p, frv, small: lib.ht_run_fpmul(h, rec, bits, small_p, frv), oracle_fpmul(n, k, a, b, p)[0])
+        check(c, cons, rec, lambda bits, small_p, frv, small: lib.ht_run_fpmul(h, rec, bits, small_p, frv), oracle_fpmul(n, k, a, b, p)[0],
+              golden="fp_mul_2_4_kat" if (n, k) == (2, 4) else None)
         lib.ht_destroy(h)
