@@ -1,5 +1,5 @@
 """Golden digests of the prover's first stage (A.w | B.w | C.w, 32-byte little-endian values: the A values, then B, then C) for the
-reference's own known-answer inputs, computed WITHOUT the product: the combinations of zkwg.r1cs (derived from the reference
+reference's own known-answer inputs (and of the kept-v1 witness of the FpMul(2,4) one), computed WITHOUT the product: the combinations of zkwg.r1cs (derived from the reference
 templates) evaluated in Python integers over the oracle's witness.  Run from the repo root: python tests/golden/make_abc_digests.py"""
 import hashlib
 import json
@@ -37,7 +37,8 @@ def main():
     fp.is_main = True
     cons = zr.fp_mul_main_constraints(comp.symbols_kept(fp), 2, 4)
     w = comp.witness_kept(fp)
-    out["fp_mul_2_4_kat"] = {"constraints": len(cons), "standard": digest(cons, w), "montgomery": digest(cons, w, True)}
+    out["fp_mul_2_4_kat"] = {"constraints": len(cons), "standard": digest(cons, w), "montgomery": digest(cons, w, True),
+                             "witness_len": len(w), "witness_sha256": hashlib.sha256(b"".join(int(v).to_bytes(32, "little") for v in w)).hexdigest()}
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "abc_digests.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -3,6 +3,9 @@
 (tests/fp-mul.test.ts:34-46: 17 * 20 mod 85 = 0) and random cases for several (n, k), every kept signal against the
 literal Python oracle; host build of the core here, the HIP kernel in the gpu test."""
 import ctypes as C
+import hashlib
+import json
+import os
 import random
 
 import pytest
@@ -11,6 +14,11 @@ import hosttest
 from zkwg._lib import Config, MAIN_FP_MUL
 
 PARAMS = [(2, 4), (3, 5), (8, 4), (15, 4), (31, 2), (1, 17), (3, 17)]
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "abc_digests.json")))["fp_mul_2_4_kat"]
+
+
+def _sha(values):
+    return hashlib.sha256(b"".join(int(v).to_bytes(32, "little") for v in values)).hexdigest()
 
 
 def chunks(x, n, k):
@@ -66,6 +74,7 @@ def test_reference_kat_fp_mul_2_4_host_core():
     assert st == 0 and wit == want
     out = [wit[s] for s, nm in sym if nm.startswith("main.out[")]
     assert out == [0, 0, 0, 0]
+    assert _sha(wit) == GOLD["witness_sha256"] and len(wit) == GOLD["witness_len"]      # committed digest of the oracle's witness
 
 
 def test_layout_names_match_the_oracle_walk():
@@ -161,6 +170,8 @@ def test_fp_mul_on_the_gpu_matches_oracle_and_constraints():
             got = [int.from_bytes(w[32 * i:32 * i + 32], "little") for i in range(c.W)]
             want, _ = oracle_fpmul(n, k, a, b, p)
             assert got == want, (n, k, e)
+            if (n, k) == (2, 4) and e == 0:
+                assert _sha(got) == GOLD["witness_sha256"]
         # the device witnesses satisfy the layout's constraint system (checked on the device), all but the rejected one
         cs = zkwg.WitnessCalculator(c).constraint_system()
         assert cs.first_violations_device(d_out, bad, c.witness_bytes) == [None] * bad
