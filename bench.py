@@ -6,7 +6,7 @@ resident in HBM: `EmailVerifier(1024,1536,121,17,0,0,0,0)`, 1 KB bodies, batch 4
 (BASELINE.json configs[2]), processed in tiles whose witnesses stay in HBM (a 2-tile ring that
 is overwritten; the host-delivered, PCIe-bound rate is reported beside it, never as `value`).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: bench.py starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line:
@@ -241,16 +241,36 @@ def main():
                     help="> 0: the prepare kernels run on this many compute units only (CU-masked stream), zk_expand on the others")
     ap.add_argument("--prep-cu-stride", type=int, default=1, help="with --prep-cus: take every stride-th CU instead of the first ones")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only rendezvous (gloo, no GPU needed): every rank joins, rank 0 prints {\"launch_check\": world} -- the "
+                         "CPU test of the self-launch below")
     args = ap.parse_args()
 
-    import torch
-    import zkwg
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on this
+        # node (free port, rendezvous on 127.0.0.1); the ranks re-enter main() with RANK / LOCAL_RANK / WORLD_SIZE set
+        return self_launch(args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree "
+                         f"(plain `python bench.py --gpus N` launches the N ranks itself)")
+    if args.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        import torch
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": world, "rank_sum": int(t.item()), "local_rank_env": local_rank}), flush=True)
+        dist.destroy_process_group()
+        return 0
+
+    import torch
+    import zkwg
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     # test hooks (single-GPU smoke of the N>1 code path): ZKWG_BENCH_FORCE_DEVICE puts every rank on one
@@ -403,6 +423,22 @@ def main():
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """Re-run this command line as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>`
+    and return its exit code (rank 0's JSON line goes to our stdout unchanged)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def other_configs(torch, zkwg, dev, local_rank, c, args):
@@ -641,4 +677,4 @@ def cpu_baseline(c, args, fields, distinct):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -127,21 +127,36 @@ def test_multi_create_reports_a_missing_rccl_library(monkeypatch):
         zkwg.MultiCircuit([0, 0], main_kind=zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192)
 
 
+def test_bench_launches_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no launcher on the command line and no WORLD_SIZE in the environment: bench.py
+    starts two ranks under torch.distributed.run itself (free port, 127.0.0.1) -- checked here on CPU with the
+    rendezvous-only mode (gloo); the GPU test below runs the real workload the same way."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line) == {"launch_check": 2, "rank_sum": 3, "local_rank_env": 0}
+    # a launcher whose world size disagrees with --gpus is still refused, with a message that says what to do
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], cwd=ROOT,
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "launches the N ranks itself" in r.stderr
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_on_one_gpu_over_gloo():
     """bench.py's N > 1 path end to end on one GPU: two torch.distributed ranks forced onto cuda:0, gloo instead of
     RCCL (two ranks cannot share a GPU under RCCL), result-table gather + 2 gathered witnesses per rank and step
     inside the timed region.  The driver's 8-GPU run must not be the first execution of this code."""
-    import socket
     import subprocess
     import sys
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, ZKWG_BENCH_FORCE_DEVICE="0", ZKWG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "512", "--steps", "1",
+    # plain `python bench.py --gpus 2` (what the driver's recorded N = 1 command line looks like with N changed): bench.py
+    # re-launches itself under torch.distributed.run, so this covers the launcher and the ranks' code path at once
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ZKWG_BENCH_FORCE_DEVICE="0", ZKWG_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "512", "--steps", "1",
            "--warmup", "1", "--gather-wtns", "2", "--distinct", "64", "--cpu-sample", "0"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
