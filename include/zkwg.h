@@ -58,7 +58,7 @@ extern "C" {
  * zkwg_scratch_bytes includes the Montgomery-copy area; zkwg_segment.pad is kernel-private.
  * Added since without breaking 2: zkwg_expand_host / zkwg_set_host_expand, zkwg_circuit_attach_r1cs / zkwg_expand_abc_device /
  * zkwg_expand_abc_host / zkwg_abc_bytes, ZKWG_MAIN_FP_MUL. */
-#define ZKWG_ABI_VERSION 2
+#define ZKWG_ABI_VERSION 3
 
 /* `component main = ...` choices (the reference's own test mains). */
 enum zkwg_main_kind {
@@ -143,10 +143,12 @@ int zkwg_circuit_create_sym(const zkwg_config* cfg, int device, const char* sym_
  * `circom ... --O0`, docs/zk-email-docs/UsageGuide/README.md:56-64): besides the `.sym` file the compiler's
  * `.r1cs` is given.  Every signal the file numbers beyond the ones this library's schedule produces (aliases,
  * constants, linear combinations -- 2.4 M of the 3.1 M signals of EmailVerifier(576,192) at O0) is derived from
- * the LINEAR constraints of the `.r1cs` (triangular elimination at creation).  On the device zk_expand writes
- * the compact witness into a staging buffer of the handle and zk_o0_gather / zk_o0_rows_* write the file's wires
- * from it (launches of one handle must therefore be stream-ordered; Montgomery-form output is not offered for
- * such handles).  19 k complete witnesses/s for EmailVerifier(576,192), DESIGN.md section 16.  Creation fails
+ * the LINEAR constraints of the `.r1cs` (triangular elimination at creation).  On the device the file's witness is
+ * written in ONE pass from the compact image (csrc/zkwg_o0.h): every wire has an 8-byte descriptor (the bit / byte /
+ * image word it copies, or the result of a row), the rows that are real sums are evaluated into extensions of the
+ * image by the row kernels at the end of zkwg_prepare_device, and zk_expand3_o0 streams all wires out -- no staging
+ * buffer, no gather, launches of one handle need no ordering beyond prepare-before-expand of the same scratch buffer,
+ * and Montgomery-form output works (zkwg_expand_montgomery_device).  Rates: DESIGN.md section 16.  Creation fails
  * with zkwg_last_error naming the first signal that is neither produced nor linearly defined (a quadratic
  * signal of a template this schedule does not implement, e.g. zk-regex's real BodyHashRegex).  Multi-
  * dimensional signal names (`a[t][k]`) are accepted by both `.sym` entry points. */
@@ -179,7 +181,7 @@ int zkwg_circuit_create_regex(const zkwg_config* cfg, int device, const zkwg_reg
  * values, gates on the evaluator's 64-bit path (handles created by zkwg_circuit_create_regex) */
 int zkwg_regex_info(const zkwg_circuit_t* c, uint64_t out[8]);
 int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness); /* layout-only handles: host evaluation */
-/* layout-only handles of a fully numbered circuit: what zk_o0_gather / zk_o0_rows do on the device, on the host --
+/* layout-only handles of a fully numbered circuit: the linear plan (copies + rows over the kept-v1 witness) on the host --
  * `out` (32 * zkwg_witness_len bytes) from one compact kept-v1 witness (the default layout of the same configuration) */
 int zkwg_o0_gather_host(const zkwg_circuit_t* c, const uint8_t* kept_witness, uint8_t* out);
 const char* zkwg_last_error(void);   /* detail of the calling thread's last ZKWG_RC_BAD_CONFIG */
@@ -306,6 +308,11 @@ int zkwg_expand_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t 
  * the previous batch, cap the resident zk_rsa wavefronts per CU (each holds 164 VGPRs) so that the
  * HBM-bound expand kernel keeps its occupancy.  0 = no cap (default; lowest prepare latency). */
 int zkwg_set_prepare_throttle(zkwg_circuit_t* c, int rsa_wavefronts_per_cu);
+/* Measurement aid (tools/beside.py): zkwg_prepare_device launches only the kernels whose bit is
+ * set -- bit 0 zk_sha_chain, 1 zk_sha_trace, 2 zk_net_eval, 3 zk_misc_ev, 4 zk_rsa, 5 zk_poseidon9*, 6 zk_rslb_chunks,
+ * 7 zk_rslb_chain, 8 the row kernels of numbered / constraint-attached handles.  Default 0xffffffff (everything); with a
+ * partial mask the images of the batch are NOT complete, so only timing may be taken from such a call. */
+int zkwg_set_prepare_mask(zkwg_circuit_t* c, uint32_t kernel_mask);
 
 /* Time the dominant kernel(s) of the last zkwg_calculate_batch_device call with
  * HIP events recorded on the launch stream.  Returns ms in *ms for kernel index
@@ -373,7 +380,9 @@ int zkwg_expand_montgomery_device(zkwg_circuit_t* c, const void* d_packed_inputs
                                   const void* d_scratch, uint64_t first, uint64_t count, void* d_out_wtns,
                                   uint64_t out_stride, void* hip_stream);
 /* The same prover stage without a 32-byte witness in between: the constraint system `r1cs` (its wires = the handle's
- * witness layout; built-in or `.sym` layouts, not the fully numbered ones) is attached to the handle once -- BEFORE the
+ * witness layout: built-in, `.sym`, or -- since ABI 3 -- a fully numbered handle of zkwg_circuit_create_full, whose system is
+ * the compiler's own `.r1cs`, the file a zkey is keyed to: every wire of every combination is substituted by the kept-v1
+ * signal(s) it derives from) is attached to the handle once -- BEFORE the
  * first zkwg_scratch_bytes / zkwg_prepare_device call that should serve it, the compact image grows by the results of the
  * combinations that are genuine sums -- and zkwg_expand_abc_device then writes A.w | B.w | C.w (3 * nConstraints values,
  * `abc_stride` >= zkwg_abc_bytes apart) of emails [first, first + count) straight from the prepared image: a combination
@@ -387,7 +396,9 @@ int zkwg_expand_abc_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint6
 /* The same values (standard form) written by the host from a host copy of the scratch buffer, like zkwg_expand_host for the
  * witness: rows_on_host = 0 -- the image was prepared by the device with the system already attached (only the image crosses
  * PCIe); rows_on_host = 1 -- the row tables are evaluated on the host too (scratch_host is written; the complete path of a
- * layout-only handle, used by the CPU tests).  out: 16-byte aligned, out_stride >= zkwg_abc_bytes. */
+ * layout-only handle, used by the CPU tests).  out: 16-byte aligned, out_stride >= zkwg_abc_bytes.
+ * (removeSoftLineBreaks handles: the row kernels follow the merge chain on its side stream, so the image is complete once that
+ * stream's work is -- i.e. after any expansion call on the scratch buffer has been ordered, or a device synchronisation.) */
 int zkwg_expand_abc_host(const zkwg_circuit_t* c, const uint8_t* packed_inputs, uint64_t n_emails, uint8_t* scratch_host,
                          uint64_t first, uint64_t count, int rows_on_host, uint8_t* out, uint64_t out_stride);
 /* Layout-only handles of a fully numbered circuit (zkwg_circuit_create_full with device < 0): the complete witness of emails

@@ -59,3 +59,51 @@ def random_system(seed, n_wires, m, max_terms=12):
         c[k] = (ev(a) * ev(b) - ev(c)) * pow(w[k], P - 2, P) % P
         cons.append((a, b, c))
     return cons, w
+
+
+def read_r1cs(data):
+    """iden3 `.r1cs` reader in plain Python (independent of the product's C++ parser): -> (header dict, constraints) with
+    constraints = [(A, B, C)], each a list of (wire, coefficient) pairs (integers mod P, as stored)."""
+    import struct
+    assert data[:4] == b"r1cs" and struct.unpack_from("<I", data, 4)[0] == 1
+    nsec = struct.unpack_from("<I", data, 8)[0]
+    pos = 12
+    sec = {}
+    for _ in range(nsec):
+        typ, size = struct.unpack_from("<IQ", data, pos)
+        sec[typ] = (pos + 12, size)
+        pos += 12 + size
+    o, _ = sec[1]
+    n8 = struct.unpack_from("<I", data, o)[0]
+    assert n8 == 32 and int.from_bytes(data[o + 4:o + 36], "little") == P
+    n_wires, n_pub_out, n_pub_in, n_prv_in = struct.unpack_from("<IIII", data, o + 36)
+    n_labels, m = struct.unpack_from("<QI", data, o + 52)
+    hdr = {"n_wires": n_wires, "n_pub_out": n_pub_out, "n_pub_in": n_pub_in, "n_prv_in": n_prv_in, "n_labels": n_labels, "n_constraints": m}
+    o, size = sec[2]
+    mv = memoryview(data)
+    cons = []
+    fb = int.from_bytes
+    for _ in range(m):
+        lcs = []
+        for _ in range(3):
+            n = fb(mv[o:o + 4], "little")
+            o += 4
+            lc = []
+            for _ in range(n):
+                lc.append((fb(mv[o:o + 4], "little"), fb(mv[o + 4:o + 36], "little")))
+                o += 36
+            lcs.append(lc)
+        cons.append(tuple(lcs))
+    assert o == sec[2][0] + size
+    return hdr, cons
+
+
+def abc_digest(cons, w, montgomery=False):
+    """SHA-256 of A.w | B.w | C.w (all A values, then B, then C; 32-byte little-endian) in Python integers."""
+    import hashlib
+    sc = (1 << 256) % P if montgomery else 1
+    h = hashlib.sha256()
+    for j in range(3):
+        for t in cons:
+            h.update((sum(cf * w[k] for k, cf in t[j]) * sc % P).to_bytes(32, "little"))
+    return h.hexdigest()

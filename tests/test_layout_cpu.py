@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libzkwg.so does not export {name}"
     assert set(_lib.EXPORTS) == declared
-    assert lib.zkwg_abi_version() == 2
+    assert lib.zkwg_abi_version() == 3
 
 
 def test_layout_only_handle_needs_no_gpu():

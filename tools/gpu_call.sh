@@ -1,0 +1,56 @@
+#!/bin/bash
+# One parameterised GPU call (replaces the per-call scripts of earlier rounds): run through gpurun from the repo root,
+#     gpurun --timeout 1500 -- 'bash tools/gpu_call.sh r04_a newtests beside bench'
+# Every step writes gpurun_out/<tag>_<step>.* and prints a short summary; summaries worth keeping are copied to profiles/.
+#   tests:<expr>  pytest -m gpu -k <expr>      alltests  the whole GPU suite      smoke  __graft_entry__.smoke()
+#   files:<a,b>   pytest -m gpu on these test files
+#   beside        tools/beside.py (which prepare kernel costs zk_expand how much)
+#   bench         the default bench.py line     benchq  the headline only (no PMC / other configs / CPU baseline)
+#   prof          rocprofv3 --kernel-trace --stats of the headline pipeline
+#   rslb          removeSoftLineBreaks = 1 variant      abc  tools/bench_abc.py      o0  tools/bench_full.py
+#   env:K=V       export K=V for the following steps
+TAG=$1; shift
+OUT=$PWD/gpurun_out; mkdir -p $OUT
+REPO=$PWD
+for step in "$@"; do
+  echo "=== $step"
+  case $step in
+    env:*) export "${step#env:}" ;;
+    tests:*) timeout 1500 python -m pytest tests -m gpu -x -q -k "${step#tests:}" 2>&1 | tail -6 | tee $OUT/${TAG}_tests.txt ;;
+    files:*) timeout 1500 python -m pytest $(echo "${step#files:}" | tr ',' ' ') -m gpu -x -q 2>&1 | tail -6 | tee $OUT/${TAG}_tests.txt ;;
+    alltests) timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee $OUT/${TAG}_pytest_gpu.txt ;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/${TAG}_smoke.txt ;;
+    beside) timeout 600 python tools/beside.py --out $OUT/${TAG}_beside.json 2>&1 | tail -20 ;;
+    beside:*) timeout 600 python tools/beside.py --modes "${step#beside:}" --out $OUT/${TAG}_beside.json 2>&1 | tail -20 ;;
+    bench) timeout 1200 python bench.py 2>$OUT/${TAG}_bench.err | tail -1 > $OUT/${TAG}_bench.json
+           python - <<PY
+import json
+try:
+    d = json.loads(open("$OUT/${TAG}_bench.json").read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print("value", d["value"], "frac", r["frac"], "alone", r.get("alone_frac"), "fill", r.get("box_fill_GBps"), "traffic x", r.get("traffic_over_algorithmic"), d.get("cpu_baseline", {}).get("value"))
+    print(d["kernel_ms_per_launch"])
+    for k, v in d.get("other_configs", {}).items():
+        print(" ", k, {a: b for a, b in v.items() if a not in ("note", "sample", "gate_list", "unit")})
+except Exception as e:
+    print("bench failed:", e); print(open("$OUT/${TAG}_bench.err").read()[-1500:])
+PY
+           ;;
+    benchq) timeout 600 python bench.py --steps 8 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 2>$OUT/${TAG}_benchq.err | tail -1 | tee $OUT/${TAG}_benchq.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('headline', d['value'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['kernel_ms_per_launch'])" ;;
+    benchq:*) timeout 600 python bench.py --steps 8 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 ${step#benchq:} 2>$OUT/${TAG}_benchq.err | tail -1 | tee -a $OUT/${TAG}_benchq_variants.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('headline ${step#benchq:}', d['value'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['kernel_ms_per_launch'])" ;;
+    prof) ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- \
+              python $REPO/bench.py --steps 5 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.log )
+          S=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_kernel_stats.csv && head -16 $S
+          rm -rf $OUT/${TAG}_prof ;;
+    rslb) timeout 600 python bench.py --remove-soft-line-breaks 1 --batch 4096 --tile 256 --prep-batch 4096 --ring 4 --steps 12 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 2>/dev/null | tail -1 | tee $OUT/${TAG}_rslb.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('rslb', d['value'], d['kernel_ms_per_launch'])" ;;
+    abc) timeout 900 python tools/bench_abc.py 2>/dev/null | tail -1 | tee $OUT/${TAG}_abc.json | cut -c1-600 ;;
+    o0) timeout 900 python tools/bench_full.py 2>/dev/null | tail -1 | tee $OUT/${TAG}_o0.json | cut -c1-600 ;;
+    *) echo "unknown step $step" ;;
+  esac
+done

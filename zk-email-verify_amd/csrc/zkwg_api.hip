@@ -104,6 +104,7 @@ struct zkwg_circuit {
   u64 prep_launches;
   bool ev_valid, prep_valid;
   int rsa_wgs_per_cu;
+  u32 prep_mask = 0xffffffffu;   // zkwg_set_prepare_mask (measurement aid)
 };
 
 // inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
@@ -273,8 +274,8 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     ZkSymLayout L;
     L.allow_holes = r1cs != nullptr;
     // a compact `.sym` (no .r1cs): zk_expand writes the file's order directly (segments remapped).  A fully numbered
-    // circuit (.r1cs given): zk_expand keeps producing the compact kept-v1 witness into a staging buffer and
-    // zk_o0_gather writes every wire of the file from it (aliases copy, the other derived signals are linear rows)
+    // circuit (.r1cs given): every wire of the file gets a descriptor over the compact image or a linear row over
+    // kept-v1 slots (zkwg_full.h -> zkwg_o0.h); zk_expand3_o0 writes the file's witness in one pass
     if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net) || (!r1cs && !zk_remap_segments(c->s, c->segs, L))) {
       g_last_error = L.err.empty() ? std::string(".sym layout does not tile the witness") : L.err;
       delete c;
@@ -303,7 +304,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
         }
         for (u64 r = 0; r < Pn.n_rows(); ++r) {
           const u64 a = Pn.row_ptr[r], b = Pn.row_ptr[r + 1];
-          if (b - a == 1 && Pn.kind[a] == ZK_COEF_ONE) c->o0_desc[Pn.dst[r]] = c->o0_src[a];   // alias: zk_o0_gather copies
+          if (b - a == 1 && Pn.kind[a] == ZK_COEF_ONE) c->o0_desc[Pn.dst[r]] = c->o0_src[a];   // alias: the wire copies its source's descriptor
           else { c->o0_desc[Pn.dst[r]] = 0xfffffffeu; (b - a > ZK_O0_SHORT_ROW ? c->o0_long : c->o0_short).push_back((u32)r); }   // zk_o0_rows
         }
         c->n_o0_short = c->o0_short.size();
@@ -364,7 +365,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     for (int i = 0; i < k; ++i) c->kslots[i] = 0;
   }
   build_inv_table(c->s.inv_half, c->invtab_host);   // (also the host expansion's table)
-  c->kname[c->n_kernels - 1] = "zk_expand"; c->kslots[c->n_kernels - 1] = c->full_W ? c->full_W : c->s.W;   // (+ zk_o0_gather for a fully numbered circuit)
+  c->kname[c->n_kernels - 1] = "zk_expand"; c->kslots[c->n_kernels - 1] = c->full_W ? c->full_W : c->s.W;   // (zk_expand3_o0 for a fully numbered circuit)
   if (device >= 0) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) { delete c; return ZKWG_RC_NO_DEVICE; }
@@ -536,7 +537,7 @@ int zkwg_linear_complete_host(const zkwg_circuit_t* c, uint8_t* witness) {
     ((Fr*)witness)[Pn.dst[r]] = zk_linear_row(Pn.row_ptr.data(), Pn.src.data(), Pn.coef.data(), Pn.kind.data(), r, (const Fr*)witness);
   return ZKWG_RC_OK;
 }
-// layout-only handles: the device path of a fully numbered circuit (zk_o0_gather / zk_o0_rows) on the host -- every
+// layout-only handles: the linear plan of a fully numbered circuit (copies + rows over the kept-v1 witness) on the host -- every
 // wire of the file from one compact kept-v1 witness through the wire table (tests)
 int zkwg_o0_gather_host(const zkwg_circuit_t* c, const uint8_t* kept_witness, uint8_t* out) {
   if (!c || !kept_witness || !out) return ZKWG_RC_BAD_ARG;
@@ -696,6 +697,12 @@ int zkwg_set_prepare_throttle(zkwg_circuit_t* c, int rsa_wavefronts_per_cu) {
   c->rsa_wgs_per_cu = rsa_wavefronts_per_cu;
   return ZKWG_RC_OK;
 }
+int zkwg_set_prepare_mask(zkwg_circuit_t* c, uint32_t kernel_mask) {
+  if (!c) return ZKWG_RC_BAD_ARG;
+  std::lock_guard<std::mutex> lock(c->dev_mutex);
+  c->prep_mask = kernel_mask;
+  return ZKWG_RC_OK;
+}
 int zkwg_set_timing(zkwg_circuit_t* c, int enable) {
   if (!c) return ZKWG_RC_BAD_ARG;
   std::lock_guard<std::mutex> lock(c->dev_mutex);
@@ -795,8 +802,8 @@ static void fill_x3(const zkwg_circuit* c, const ZkBufs& B, ZkX3& A) {
 
 // the linear rows of a numbered (`--O0`) circuit that are real sums, for emails [B.e_first, B.n_emails): results go into the image
 // extensions (zkwg_o0.h).  Launched at the end of zkwg_prepare_device -- so that in a two-stream pipeline they overlap the
-// previous sub-batch's expansion -- or, when the removeSoftLineBreaks chain still writes field elements on its side stream,
-// in front of the expansion that waits for it.
+// previous sub-batch's expansion -- on the caller's stream, or behind the removeSoftLineBreaks chain on its side stream (the
+// chain writes field elements the rows read; the expansion waits for that stream anyway).
 static void launch_o0_rows(const zkwg_circuit* c, const ZkO0Dev& O, const ZkBufs& B, hipStream_t st) {
   ZkX3 A;
   fill_x3(c, B, A);
@@ -836,7 +843,8 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
   if (hipMemsetAsync(B.status, 0, n * sizeof(int), st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   int ki = 0;
   hipEvent_t* evs = c->pev[c->prep_launches % ZK_EV_RING];
-  const bool pos9 = s.rsa.present && s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER;
+  const u32 pm = c->prep_mask;
+  const bool pos9 = s.rsa.present && s.main_kind == ZKWG_MAIN_EMAIL_VERIFIER && (pm & 32u);
   int pos_slot = -1;
   if (pos9 && c->pos_side) {
     // fork: zk_poseidon9 only reads the input record; it overlaps the SHA / regex / RSA kernels (with timing
@@ -852,12 +860,12 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     hipEventRecord(c->pos_done[pos_slot], ps);
   }
   if (tm) hipEventRecord(evs[ki], st);
-  if (s.nframes) {
+  if (s.nframes && (pm & 1u)) {
     u32 threads = ne * s.nframes;
     hipLaunchKernelGGL(zk_sha_chain, dim3((threads + 63) / 64), dim3(64), 0, st, s, B);
   }
   if (tm) hipEventRecord(evs[++ki], st);
-  if (s.nframes) {
+  if (s.nframes && (pm & 2u)) {
     u64 units = (u64)ne * s.total_blocks;
     hipLaunchKernelGGL(zk_sha_trace, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
   }
@@ -867,12 +875,12 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     const u32 ew = 64u / std::max(16u, s.net_lanes);   // emails per wavefront
     if (4u * s.net_lds_words * ew + 16 > 48u * 1024u)   // (gfx950: 160 KB of LDS per CU; the default per-workgroup cap is lower)
       hipFuncSetAttribute((const void*)zk_net_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u * s.net_lds_words * ew + 16));
-    hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
+    if (pm & 4u) hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
     if (tm) hipEventRecord(evs[++ki], st);
   }
-  if (s.body) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 7 * s.fr[0].max_bytes + 64 + ZK_DFA_STATES * 256 + 16, st, s, B);
+  if (s.body && (pm & 8u)) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 7 * s.fr[0].max_bytes + 64 + ZK_DFA_STATES * 256 + 16, st, s, B);
   if (tm) hipEventRecord(evs[++ki], st);
-  if (s.rsa.present) {
+  if (s.rsa.present && (pm & 16u)) {
     // optional throttle: pad the workgroup's LDS claim so that only `rsa_wgs_per_cu` RSA wavefronts
     // (164 VGPRs each) are resident per CU, leaving registers/slots to a concurrently running zk_expand
     u32 dyn = 0;
@@ -882,7 +890,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     }
     hipLaunchKernelGGL(zk_rsa, dim3(ne), dim3(64), dyn, st, s, B);
   }
-  if (s.fpg.present) hipLaunchKernelGGL(zk_fpmul_small, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // (timed in zk_rsa's slot)
+  if (s.fpg.present && (pm & 16u)) hipLaunchKernelGGL(zk_fpmul_small, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // (timed in zk_rsa's slot)
   if (tm) hipEventRecord(evs[++ki], st);
   if (pos9 && pos_slot < 0) {
     // one lane per email once the batch supplies >= 16 wavefronts of them; one wavefront per email below
@@ -895,10 +903,10 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     // removeSoftLineBreaks: chunk hashes (one lane per 16-byte chunk), then the serial merge chain + scans
     if (tm) hipEventRecord(evs[++ki], st);
     const u64 units = (u64)ne * s.rs_nch;
-    hipLaunchKernelGGL(zk_rslb_chunks, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
+    if (pm & 64u) hipLaunchKernelGGL(zk_rslb_chunks, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
     if (tm) hipEventRecord(evs[++ki], st);
     if (c->rs_sync) {
-      hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
+      if (pm & 128u) hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
     } else {
       int slot = -1;
       for (int i = 0; i < ZK_RS_SLOTS; ++i) if (c->rs_scr[i] == d_scratch) slot = i;
@@ -909,14 +917,18 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       // ZKWG_RSLB_SIDE_STREAMS raises it (together with GPU_MAX_HW_QUEUES).
       hipStream_t ss = c->side_stream[slot % c->rs_nside];
       hipStreamWaitEvent(ss, c->rs_dep[slot], 0);
-      hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B);
+      if (pm & 128u) hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B);
+      if (pm & 256u) {   // the rows read the chain's field elements: they follow it on the side stream
+        if (c->full_W) launch_o0_rows(c, c->o0d, B, ss);
+        if (c->abc_m) launch_o0_rows(c, c->abcd, B, ss);
+      }
       hipEventRecord(c->rs_done[slot], ss);
       if (tm) { hipEventRecord(evs[++ki], ss); c->prep_valid = true; c->prep_launches++; }
       if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
       return ZKWG_RC_OK;
     }
   }
-  if (!(s.rslb && !c->rs_sync)) {   // (timed with the last prepare kernel)
+  if (!(s.rslb && !c->rs_sync) && (pm & 256u)) {   // (timed with the last prepare kernel)
     if (c->full_W) launch_o0_rows(c, c->o0d, B, st);
     if (c->abc_m) launch_o0_rows(c, c->abcd, B, st);
   }
@@ -986,7 +998,6 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
       // numbered circuit (`--O0` / `--O1`), one pass: the rows that are real sums go into the image extensions of these
       // emails, then every wire is written from its descriptor (zkwg_o0.h) -- no staging buffer, no gather
       const ZkO0Dev& O = *OD;
-      if (s.rslb && !c->rs_sync) launch_o0_rows(c, O, B, st);   // (otherwise zkwg_prepare_device already ran them)
       const u64 units = ((cnt + O.emails_per_wg - 1) / O.emails_per_wg) * (u64)O.nportions;
       if (units > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
       if (mont) hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, A);
@@ -1028,31 +1039,87 @@ int zkwg_expand_montgomery_device(zkwg_circuit_t* c, const void* d_in, uint64_t 
 // a 64-bit integer row, the rest are rows mod r -- and zk_expand3_o0 streams them out.  No 32-byte witness is read.
 int zkwg_circuit_attach_r1cs(zkwg_circuit_t* c, const uint8_t* r1cs, uint64_t len) {
   if (!c || !r1cs) return ZKWG_RC_BAD_ARG;
-  if (c->full_W || c->abc_m) { g_last_error = "attach_r1cs: the handle is a numbered circuit or already has a constraint system"; return ZKWG_RC_BAD_CONFIG; }
+  // lock order of the host-buffer path: hb_mutex, then dev_mutex.  Both are held: the attachment grows the image layout (c->s)
+  // that the host-path calls read under hb_mutex and the device entry points under dev_mutex.
+  std::lock_guard<std::mutex> hb_lock(c->hb_mutex);
   std::lock_guard<std::mutex> lock(c->dev_mutex);
+  if (c->abc_m) { g_last_error = "attach_r1cs: the handle already has a constraint system"; return ZKWG_RC_BAD_CONFIG; }
   try {
     ZkR1csHost R;
     if (!zk_r1cs_parse(r1cs, len, R)) { g_last_error = "the .r1cs file could not be parsed: " + R.err; return ZKWG_RC_BAD_CONFIG; }
-    if (R.n_wires != c->s.W) { g_last_error = "the .r1cs has " + std::to_string(R.n_wires) + " wires, the witness layout " + std::to_string(c->s.W); return ZKWG_RC_BAD_CONFIG; }
+    // A numbered handle (zkwg_circuit_create_full) is keyed to the compiler's `.r1cs` -- the system a zkey carries
+    // (packages/helpers/src/chunked-zkey.ts:80-84): its wires are the file's, not kept-v1 slots.
+    const bool numbered = c->full_W != 0;
+    const u64 n_wires = numbered ? c->full_W : c->s.W;
+    if (R.n_wires != n_wires) { g_last_error = "the .r1cs has " + std::to_string(R.n_wires) + " wires, the witness layout " + std::to_string(n_wires); return ZKWG_RC_BAD_CONFIG; }
     const u64 m = R.n_constraints;
     if (3 * m >= 0x7fffffffull) { g_last_error = "too many constraints"; return ZKWG_RC_BAD_CONFIG; }
+    // numbered: wire -> kept-v1 slot it copies, or its definition over kept-v1 slots (the linear plan of zkwg_full.h, derived
+    // again from this file: the handle dropped its host copy after building the device tables)
+    std::vector<u32> inv;
+    std::vector<u64> row_of;
+    ZkLinPlan Pn;
+    if (numbered) {
+      if (c->kept_dst.empty()) { g_last_error = "attach_r1cs: the numbered handle has no layout map"; return ZKWG_RC_BAD_CONFIG; }
+      inv.assign(n_wires, 0xffffffffu);
+      for (u64 slot = 0; slot < c->kept_dst.size(); ++slot) if (c->kept_dst[slot] != 0xffffffffu && c->kept_dst[slot] < n_wires) inv[c->kept_dst[slot]] = (u32)slot;
+      std::vector<u8> produced(n_wires, 0);
+      for (u64 w = 0; w < n_wires; ++w) produced[w] = inv[w] != 0xffffffffu;
+      std::string perr;
+      if (!zk_linear_plan(R, produced, Pn, perr)) { g_last_error = perr; return ZKWG_RC_BAD_CONFIG; }
+      row_of.assign(n_wires, ~0ull);
+      for (u64 r = 0; r < Pn.n_rows(); ++r) row_of[Pn.dst[r]] = r;
+    }
     // output order: the A values, then B, then C (zkwg_r1cs_evaluate_device's)
     ZkLinPlan P;
     std::vector<u32> desc_slot(3 * m);
     P.row_ptr.assign(1, 0);
     P.src.reserve(R.wire.size()); P.coef.reserve(R.wire.size()); P.kind.reserve(R.wire.size());
+    const Fr one_m = fr_R(), minus_one_m = fr_neg(fr_R());
+    std::vector<std::pair<u32, Fr>> acc;
     for (u32 which = 0; which < 3; ++which)
       for (u64 i = 0; i < m; ++i) {
         const u64 a = R.row_ptr[3 * i + which], b = R.row_ptr[3 * i + which + 1];
-        for (u64 t = a; t < b; ++t) {
-          if (R.wire[t] >= c->s.W) { g_last_error = "the .r1cs names a wire outside the witness"; return ZKWG_RC_BAD_CONFIG; }
-          P.src.push_back(R.wire[t]); P.coef.push_back(fr_from_mont(R.coef[t])); P.kind.push_back(R.kind[t]);
+        const u64 dst = (u64)which * m + i;
+        const u64 t0 = P.src.size();
+        if (!numbered) {
+          for (u64 t = a; t < b; ++t) {
+            if (R.wire[t] >= n_wires) { g_last_error = "the .r1cs names a wire outside the witness"; return ZKWG_RC_BAD_CONFIG; }
+            P.src.push_back(R.wire[t]); P.coef.push_back(fr_from_mont(R.coef[t])); P.kind.push_back(R.kind[t]);
+          }
+        } else {
+          // substitute every wire by its kept-v1 source(s), merge equal slots (Montgomery coefficients throughout)
+          acc.clear();
+          for (u64 t = a; t < b; ++t) {
+            const u32 w = R.wire[t];
+            if (w >= n_wires) { g_last_error = "the .r1cs names a wire outside the witness"; return ZKWG_RC_BAD_CONFIG; }
+            if (inv[w] != 0xffffffffu) { acc.emplace_back(inv[w], R.coef[t]); continue; }
+            const u64 r = row_of[w];
+            if (r == ~0ull) { g_last_error = "internal: wire " + std::to_string(w) + " has neither a slot nor a definition"; return ZKWG_RC_BAD_CONFIG; }
+            for (u64 q = Pn.row_ptr[r]; q < Pn.row_ptr[r + 1]; ++q) {
+              const u32 sl = inv[Pn.src[q]];
+              if (sl == 0xffffffffu) { g_last_error = "internal: a linear row reads a wire the schedule does not produce"; return ZKWG_RC_BAD_CONFIG; }
+              const u8 k = Pn.kind[q];
+              acc.emplace_back(sl, k == ZK_COEF_ONE ? R.coef[t] : (k == ZK_COEF_MINUS_ONE ? fr_neg(R.coef[t]) : fr_mont_mul(R.coef[t], fr_to_mont(Pn.coef[q]))));
+            }
+          }
+          if (acc.size() > 1) std::stable_sort(acc.begin(), acc.end(), [](const std::pair<u32, Fr>& x, const std::pair<u32, Fr>& y) { return x.first < y.first; });
+          for (size_t t = 0; t < acc.size();) {
+            Fr sum = acc[t].second;
+            size_t q = t + 1;
+            while (q < acc.size() && acc[q].first == acc[t].first) { sum = fr_add(sum, acc[q].second); ++q; }
+            if (!fr_is_zero(sum)) {
+              P.src.push_back(acc[t].first); P.coef.push_back(fr_from_mont(sum));
+              P.kind.push_back(fr_eq(sum, one_m) ? ZK_COEF_ONE : (fr_eq(sum, minus_one_m) ? ZK_COEF_MINUS_ONE : ZK_COEF_GENERIC));
+            }
+            t = q;
+          }
         }
         P.row_ptr.push_back(P.src.size());
-        const u64 dst = (u64)which * m + i;
         P.dst.push_back((u32)dst);
-        desc_slot[dst] = (b - a == 1 && R.kind[a] == ZK_COEF_ONE) ? R.wire[a] : 0xfffffffeu;
+        desc_slot[dst] = (P.src.size() - t0 == 1 && P.kind[t0] == ZK_COEF_ONE) ? P.src[t0] : 0xfffffffeu;
       }
+    { ZkLinPlan e; std::swap(Pn, e); std::vector<u64>().swap(row_of); std::vector<u32>().swap(inv); }
     std::string err;
     ZkSched s2 = c->s;   // (the image grows by the row results: committed only when everything succeeded)
     ZkO0Tables T;         // (built aside: a failed attachment leaves the handle as it was)
@@ -1070,6 +1137,18 @@ int zkwg_circuit_attach_r1cs(zkwg_circuit_t* c, const uint8_t* r1cs, uint64_t le
     c->abct = std::move(T);
     c->s = s2;
     c->abc_m = m;
+    // the cached staging buffers of the host-buffer path were sized for the old image layout (zkwg_scratch_bytes grew):
+    // drop them, the next zkwg_calculate_batch allocates them again
+    if (c->device >= 0 && (c->hb_tile || c->hx_bytes)) {
+      ZkDeviceGuard dg(c->device);
+      hipDeviceSynchronize();
+      hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
+      c->hb_in = c->hb_out[0] = c->hb_out[1] = c->hb_scr = nullptr;
+      c->hb_status[0] = c->hb_status[1] = nullptr;
+      c->hb_tile = 0;
+      for (int i = 0; i < 2; ++i) { if (c->hx_img[i]) hipHostFree(c->hx_img[i]); c->hx_img[i] = nullptr; }
+      c->hx_bytes = 0;
+    }
   } catch (const std::bad_alloc&) {
     return ZKWG_RC_OOM;
   } catch (const std::exception& e) {

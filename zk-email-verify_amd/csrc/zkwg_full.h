@@ -7,8 +7,8 @@
 // (which names are ours) and the `.r1cs`, this file derives, once per circuit, for every signal the
 // schedule does not produce a row   w[dst] = c0 + sum_k coef_k * w[src_k]   whose sources are signals the
 // schedule does produce -- by triangular elimination over the linear constraints (a constraint with one
-// unknown wire defines it), then substitution down to produced wires.  zk_o0_gather / zk_o0_rows evaluate
-// the rows on the device after zk_expand.  Reference: the compile line the reference documents is `circom ... --O0`
+// unknown wire defines it), then substitution down to produced wires.  zkwg_o0.h lowers the rows to the
+// descriptor / row tables that the row kernels and zk_expand3_o0 evaluate on the device.  Reference: the compile line the reference documents is `circom ... --O0`
 // (docs/zk-email-docs/UsageGuide/README.md:56-64); `.sym` / `.r1cs` are what `circom_tester` loads
 // (packages/circuits/tests/email-verifier.test.ts:21-31,44,204-206).
 #pragma once
@@ -137,7 +137,7 @@ static inline bool zk_linear_plan(const ZkR1csHost& R, const std::vector<u8>& pr
   return true;
 }
 
-// one row for one witness (standard-form values); shared by zk_o0_gather and the host evaluation of the CPU tests
+// one row for one witness (standard-form values); used by the host evaluation of the CPU tests
 ZK_HD Fr zk_linear_row(const u64* __restrict__ row_ptr, const u32* __restrict__ src, const Fr* __restrict__ coef,
                        const u8* __restrict__ kind, u64 r, const Fr* __restrict__ w) {
   Fr acc = fr_zero();

@@ -330,6 +330,10 @@ class Circuit:
     def set_prepare_throttle(self, rsa_wavefronts_per_cu):
         _check(self.lib.zkwg_set_prepare_throttle(self.h, rsa_wavefronts_per_cu))
 
+    def set_prepare_mask(self, mask):
+        """measurement aid: launch only the prepare kernels whose bit is set (include/zkwg.h zkwg_set_prepare_mask)"""
+        _check(self.lib.zkwg_set_prepare_mask(self.h, mask & 0xFFFFFFFF))
+
     def set_timing(self, on):
         _check(self.lib.zkwg_set_timing(self.h, 1 if on else 0))
 
