@@ -47,7 +47,7 @@ class Pipeline:
     another; images are ring-buffered, witnesses go to a 2-tile ring in HBM."""
 
     def __init__(self, torch, c, dev, d_in, batch, tile, prep, ring=2, prep_streams=1, rsa_throttle=0, exp_prio=-1,
-                 montgomery=False, out_align=0, serial=False, prep_cus=0, prep_cu_stride=1, prep_prio=0, abc=False):
+                 montgomery=False, out_align=0, serial=False, prep_cus=0, prep_cu_stride=1, prep_prio=0, abc=False, place=True):
         self.torch, self.c, self.dev, self.d_in = torch, c, dev, d_in
         self.batch, self.tile, self.prep = batch, tile, prep
         assert batch % prep == 0 and prep % tile == 0
@@ -62,10 +62,24 @@ class Pipeline:
             # the prover's first stage instead of the witness: A.w | B.w | C.w of the attached constraint system (zkwg_expand_abc_device)
             self.expand = lambda d_in, n, scr, first, count, o, st: c.expand_abc_device(d_in, n, scr, first, count, o, st, montgomery=montgomery)
             self.stride = self.unit_bytes = c.abc_bytes
-        self.d_out = [torch.empty(tile * self.stride, dtype=torch.uint8, device=dev) for _ in range(min(2, self.ntiles))]
         self.d_status = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.R = max(2, ring)
         self.d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(self.R)]
+        self.placement = None
+        if place:
+            # the output ring goes where HBM takes zk_expand's stores fastest (zkwg.placement): the first
+            # sub-batch is prepared once, the real expansion of one tile is timed into each candidate buffer, the best are kept
+            from zkwg import placement
+            cur = torch.cuda.current_stream()
+            c.set_prepare_throttle(0)
+            c.prepare_device(d_in[:prep], prep, self.d_status[:prep], self.d_scr[0], cur)
+            kw = {} if self.stride == self.unit_bytes else {"out_stride": self.stride}
+            self.d_out, self.placement = placement.choose_tiles(
+                torch, dev, tile * self.stride, min(2, self.ntiles),
+                lambda buf: self.expand(d_in[:prep], prep, self.d_scr[0], 0, tile, buf, cur, **kw))
+            torch.cuda.synchronize()
+        else:
+            self.d_out = [torch.empty(tile * self.stride, dtype=torch.uint8, device=dev) for _ in range(min(2, self.ntiles))]
         # several prepare streams let the latency-bound prepare kernels of consecutive SMALL sub-batches overlap
         self.s_preps = [torch.cuda.Stream(device=dev, priority=prep_prio) for _ in range(max(1, prep_streams))]
         self.s_exp = torch.cuda.Stream(device=dev, priority=exp_prio)
@@ -240,6 +254,9 @@ def main():
     ap.add_argument("--prep-cus", type=int, default=0,
                     help="> 0: the prepare kernels run on this many compute units only (CU-masked stream), zk_expand on the others")
     ap.add_argument("--prep-cu-stride", type=int, default=1, help="with --prep-cus: take every stride-th CU instead of the first ones")
+    ap.add_argument("--place-ring", type=int, default=1,
+                    help="1 (default): allocate spare candidate tiles at set-up, time zk_expand into each and keep the output ring where "
+                         "HBM takes its stores fastest (zkwg.placement); 0: the first two allocations, wherever they land")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous (gloo, no GPU needed): every rank joins, rank 0 prints {\"launch_check\": world} -- the "
@@ -305,7 +322,7 @@ def main():
     prio = int(os.environ.get("ZKWG_BENCH_EXP_PRIO", "-1"))
     pl = Pipeline(torch, c, dev, d_in, args.batch, tile, prep, ring=args.ring, prep_streams=args.prep_streams,
                   rsa_throttle=args.rsa_throttle, exp_prio=prio, montgomery=bool(args.montgomery), out_align=args.out_align,
-                  serial=bool(args.no_overlap), prep_cus=args.prep_cus, prep_cu_stride=args.prep_cu_stride)
+                  serial=bool(args.no_overlap), prep_cus=args.prep_cus, prep_cu_stride=args.prep_cu_stride, place=bool(args.place_ring))
     from zkwg import shard
     state = {"table": None}
 
@@ -355,6 +372,20 @@ def main():
         dt = float(tt.item())
     summ, ex_avg, ex_launches, achieved = expand_roofline(c, tile)
     c.set_timing(False)
+    alone = None
+    if world == 1 and not args.no_overlap:
+        # the same kernel with the chip to itself (every prepare waits for the previous sub-batch's expansions): what the
+        # prepare kernels beside the stream cost it -- reported as roofline.alone_frac, outside the timed region
+        pl.serial = True
+        pl.step()
+        torch.cuda.synchronize()
+        c.set_timing(True)
+        pl.step()
+        torch.cuda.synchronize()
+        _, a_avg, a_n, a_gbs = expand_roofline(c, tile)
+        c.set_timing(False)
+        pl.serial = False
+        alone = (a_avg, a_gbs, a_n)
 
     if rank == 0:
         total_emails = args.batch * world * args.steps
@@ -377,6 +408,7 @@ def main():
                          "bytes_per_launch": bytes_per_email * tile, "avg_launch_ms": round(ex_avg, 4),
                          "launches_timed": ex_launches, "launches_total": args.steps * (args.batch // tile)},
             "kernel_ms_per_launch": kernels_ms,
+            "ring_placement": pl.placement,
             "fr_field_ops_per_s": round(value * c.W, 1),
         }
         tb = state["table"]
@@ -386,6 +418,9 @@ def main():
             st = tb[:, :4].contiguous().view(torch.int32).view(-1)
             res["gathered_table"] = {"rows": int(tb.shape[0]), "status_nonzero": int((st != 0).sum().item()),
                                      "rows_with_outputs": int((tb[:, 4:].to(torch.int32).sum(dim=1) != 0).sum().item())}
+        if alone is not None:
+            res["roofline"]["alone_frac"] = round(alone[1] / HBM_PEAK_GBS, 4)
+            res["roofline"]["alone_launch_ms"] = round(alone[0], 4)
         single = world == 1
         # same-box ceiling: a plain fill (torch.fill_, 16-byte stores) of the very buffer zk_expand just wrote,
         # so that box-to-box variance of the HBM write rate shows beside the fraction of the spec peak

@@ -11,7 +11,8 @@ events on the expand stream) is recorded for each:
     only K     kernel K alone beside the stream -> cost of K by itself
 
 The images the expansions read stay valid throughout: the warm-up steps run the full prepare into every scratch buffer of
-the ring, a masked prepare then rewrites a subset of the same values.
+the ring, a masked prepare then rewrites a subset of the same values.  All configurations run on ONE pipeline (same output
+ring, same scratch buffers): the store rate depends on the placement of the ring (zkwg.placement), not only on the neighbours.
 
     python tools/beside.py [--steps 3] [--out gpurun_out/beside.json]
 """
@@ -46,29 +47,31 @@ def main():
     bpe = 32 * c.W + c.in_stride
     res = {"workload": f"EmailVerifier(1024,1536) batch {args.batch}, tile {args.tile}, prepare sub-batch {args.prep_batch}", "rows": []}
 
+    # ONE pipeline for every configuration: the rate HBM takes the stores at depends on where the output ring was placed
+    # (zkwg.placement), so configurations are only comparable on the same buffers
+    pl = bench.Pipeline(torch, c, dev, d_in, args.batch, args.tile, args.prep_batch)
+    res["ring_placement"] = pl.placement
+    for _ in range(2):
+        pl.step()
+    torch.cuda.synchronize()
+    assert int(pl.d_status.abs().sum().item()) == 0
+
     def run(label, mask, serial=False):
-        pl = bench.Pipeline(torch, c, dev, d_in, args.batch, args.tile, args.prep_batch, serial=serial)
-        c.set_prepare_mask(0xFFFFFFFF)
-        for _ in range(2):
-            pl.step()
-        torch.cuda.synchronize()
-        assert int(pl.d_status.abs().sum().item()) == 0
+        pl.serial = serial
         c.set_prepare_mask(mask)
         pl.step()                      # one step in the measured configuration before timing starts
         torch.cuda.synchronize()
-        pl.j = 2                       # (keep the ring's wait logic in its steady state)
         c.set_timing(True)
         dt = bench.timed(torch, pl.step, steps=args.steps, warmup=0)
         summ, avg, n, gbs = bench.expand_roofline(c, args.tile)
         c.set_timing(False)
         c.set_prepare_mask(0xFFFFFFFF)
+        pl.serial = False
         row = {"config": label, "zk_expand_ms": round(avg, 4), "GBps": round(gbs, 1), "frac": round(gbs / bench.HBM_PEAK_GBS, 4),
                "witnesses_per_s": round(args.batch * args.steps / dt, 1),
                "prepare_ms_per_launch": {k: round(v[0] / max(v[1], 1), 3) for k, v in summ.items() if k != "zk_expand"}}
         res["rows"].append(row)
         print(json.dumps(row), flush=True)
-        del pl
-        torch.cuda.empty_cache()
 
     modes = args.modes.split(",")
     if "all" in modes:

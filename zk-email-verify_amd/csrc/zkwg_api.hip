@@ -796,7 +796,7 @@ static void fill_x3(const zkwg_circuit* c, const ZkBufs& B, ZkX3& A) {
   A.in_stride = s.in_stride; A.img_bits = s.img_bits; A.img_small = s.img_small; A.img_fr = s.img_fr; A.inv_half = s.inv_half;
   A.m_dfa_cm = s.m_dfa_cm; A.m_dfa_pm = s.m_dfa_pm; A.m_dfa_st = s.m_dfa_st;
   A.nportions = c->n_ent; A.nsegs = s.nsegs; A.e_first = B.e_first; A.n_count = B.n_emails - B.e_first;
-  A.xcd_remap = c->xcd_remap ? 1u : 0u; A.limb_off = s.in_off[ZKWG_IN_PUBKEY]; A.hdr_off = s.in_off[ZKWG_IN_HEADER];
+  A.xcd_remap = c->xcd_remap; A.limb_off = s.in_off[ZKWG_IN_PUBKEY]; A.hdr_off = s.in_off[ZKWG_IN_HEADER];
   A.net_fn = B.net_fn; A.net_desc = B.net_desc;
 }
 

@@ -92,10 +92,16 @@ __device__ __forceinline__ uint4 zk_slot_half(u32 code, u32 hf, const ZkX3& A, c
 }
 
 __device__ __forceinline__ u32 zk_x3_unit(u32 xcd_remap) {
+  // workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  1: each XCD streams through one contiguous eighth of the
+  // whole launch; G > 1: through a contiguous run of G pieces inside each group of 8 G pieces (the eight streams then stay
+  // within 8 G pieces of each other); 0: plain order
   u32 blk = blockIdx.x;
-  if (xcd_remap) {
+  if (xcd_remap == 1u) {
     const u32 per = gridDim.x >> 3;
     if (blk < per * 8u) blk = (blk & 7u) * per + (blk >> 3);
+  } else if (xcd_remap > 1u) {
+    const u32 G = xcd_remap, grp = blk / (8u * G), r = blk - grp * 8u * G;
+    if ((grp + 1u) * 8u * G <= gridDim.x) blk = grp * 8u * G + (r & 7u) * G + (r >> 3);
   }
   return blk;
 }
