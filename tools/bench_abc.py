@@ -51,7 +51,7 @@ def main():
     batch, tile, prep = 2048, 256, 1024
     _, d_in2, _ = bench.resident_inputs(torch, c2, dev, 0x5A4B + 32, 64, batch, 60)
     for mont in (True, False):
-        pl = bench.Pipeline(torch, c2, dev, d_in2, batch, tile, prep, ring=2, montgomery=mont, abc=True)
+        pl = bench.Pipeline(torch, c2, dev, d_in2, batch, tile, prep, ring=2, montgomery=mont, abc=True, serial=bool(int(os.environ.get('ZKWG_BENCH_SERIAL', '0'))))
         c2.set_timing(True)
         dtp = bench.timed(torch, pl.step, steps=3, warmup=1)
         summ = c2.timing_summary()

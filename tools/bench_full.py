@@ -33,7 +33,7 @@ def main():
         batch, tile = (2048, 256) if N <= 576 else (512, 128)
         _, d_in, _ = bench.resident_inputs(torch, c, dev, 0x5A4B + 9, 64, batch, 60 if M <= 192 else 1024)
         prio = [int(x) for x in os.environ.get("ZKWG_BENCH_PRIO", "-1,0").split(",")]   # (expand, prepare) stream priorities
-        pl = bench.Pipeline(torch, c, dev, d_in, batch, tile, min(int(os.environ.get("ZKWG_BENCH_PREP", "1024")), batch), ring=2, exp_prio=prio[0], prep_prio=prio[1])
+        pl = bench.Pipeline(torch, c, dev, d_in, batch, tile, min(int(os.environ.get("ZKWG_BENCH_PREP", "1024")), batch), ring=2, exp_prio=prio[0], prep_prio=prio[1], serial=bool(int(os.environ.get('ZKWG_BENCH_SERIAL', '0'))))
         c.set_timing(True)
         dt = bench.timed(torch, pl.step, steps=3, warmup=1)
         summ = c.timing_summary()

@@ -20,7 +20,6 @@
 #include "zkwg_o0.h"
 #include "zkwg_o0_dec.h"
 #include "zkwg_expand_dec.h"
-#define ZK_FR_LANES 8u   // lanes per group of zk_o0_rows_fr (zkwg_kernels_expand3.hip)
 #include <atomic>
 #include <emmintrin.h>
 
@@ -66,7 +65,8 @@ struct zkwg_circuit {
   std::vector<Fr> invtab_host;   // zkwg_expand_host: the inverse table on the host
   int host_expand_threads;       // > 0: zkwg_calculate_batch expands on the host (zkwg_set_host_expand)
   u8* hx_img[2]; u64 hx_bytes;   // pinned staging of downloaded images (host expansion)
-  int o0_emails_per_wg;          // emails per workgroup of zk_expand3_o0 (ZKWG_O0_EMAILS_PER_WG, default 8)
+  int o0_emails_per_wg;          // emails per workgroup of zk_expand3_o0 (ZKWG_O0_EMAILS_PER_WG, default 16)
+  int o0_pipe;                   // 1: the software-pipelined variant of zk_expand3_o0 (ZKWG_O0_PIPE, default 1)
   int x3_k, x3_k_o0;       // slots per thread of zk_expand3 (kept-v1 / sym layouts) and zk_expand3_o0: 1, 2 or 4 (ZKWG_X3_K, ZKWG_X3_K_O0)
   std::vector<ZkSeg> segs;
   hipStream_t own_stream, copy_stream;
@@ -172,6 +172,7 @@ static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W, bool ke
     ok = hipMalloc(dst, std::max<size_t>(bytes, 16)) == hipSuccess && (bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess);
   };
   up(T.desc.data(), T.desc.size() * 4, (void**)&O.desc);
+  up(T.aff.data(), T.aff.size() * 4, (void**)&O.aff);
   up(T.s_ptr.data(), T.s_ptr.size() * 8, (void**)&O.s_ptr);
   up(T.s_term.data(), T.s_term.size() * 4, (void**)&O.s_term);
   up(T.s_coef.data(), T.s_coef.size() * 4, (void**)&O.s_coef);
@@ -203,7 +204,7 @@ static bool upload_o0(zkwg_circuit* c, ZkO0Tables& T, ZkO0Dev& O, u64 W, bool ke
   return ok;
 }
 static void free_o0(ZkO0Dev& O) {
-  hipFree((void*)O.desc); hipFree((void*)O.s_ptr); hipFree((void*)O.s_term); hipFree((void*)O.s_coef); hipFree((void*)O.s_out); hipFree((void*)O.s_single); hipFree((void*)O.s_long); hipFree((void*)O.s_chains);
+  hipFree((void*)O.desc); hipFree((void*)O.aff); hipFree((void*)O.s_ptr); hipFree((void*)O.s_term); hipFree((void*)O.s_coef); hipFree((void*)O.s_out); hipFree((void*)O.s_single); hipFree((void*)O.s_long); hipFree((void*)O.s_chains);
   hipFree((void*)O.f_ptr); hipFree((void*)O.f_term); hipFree((void*)O.f_coef); hipFree((void*)O.f_coefm); hipFree((void*)O.f_kind); hipFree((void*)O.gen_seg); hipFree((void*)O.gen_r);
   memset(&O, 0, sizeof(O));
 }
@@ -245,8 +246,9 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   // tuning knobs (DESIGN.md "zk_expand geometry"): slots per workgroup and threads per workgroup
   auto pick_k = [](const char* name, int dflt, bool k8 = false) { const char* v = getenv(name); const int k = v ? atoi(v) : dflt; return (k == 1 || k == 2 || k == 4 || (k8 && k == 8)) ? k : dflt; };
   c->x3_k = pick_k("ZKWG_X3_K", 4, true);
-  c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 2);
-  c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 8;
+  c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 1);   // (round 4: 8 KiB pieces, 53 VGPRs = 8 wavefronts per SIMD, software-pipelined over the group's emails)
+  c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 16;
+  c->o0_pipe = getenv("ZKWG_O0_PIPE") ? atoi(getenv("ZKWG_O0_PIPE")) : 1;
   c->xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
   c->rsa_wgs_per_cu = 0;
   if (const char* v = getenv("ZKWG_RSA_WGS_PER_CU")) c->rsa_wgs_per_cu = atoi(v);
@@ -816,7 +818,7 @@ static void launch_o0_rows(const zkwg_circuit* c, const ZkO0Dev& O, const ZkBufs
     if (O.n_small_single) hipLaunchKernelGGL(zk_o0_rows_small, dim3((O.n_small_single + 255) / 256, (cnt + ZK_ROW_EMAILS - 1) / ZK_ROW_EMAILS), dim3(256), 0, st, A, O);
     if (O.n_small_long) hipLaunchKernelGGL(zk_o0_rows_small_long, dim3((O.n_small_long + 3) / 4, (cnt + ZK_ROW_EMAILS - 1) / ZK_ROW_EMAILS), dim3(256), 0, st, A, O);
     if (O.n_small_chains) hipLaunchKernelGGL(zk_o0_chains_small, dim3(O.n_small_chains, cnt), dim3(64), 0, st, A, O);
-    if (O.n_fr_groups) hipLaunchKernelGGL(zk_o0_rows_fr, dim3((O.n_fr_groups * ZK_FR_LANES + 255) / 256, (cnt + ZK_FR_EMAILS - 1) / ZK_FR_EMAILS), dim3(256), 0, st, A, O);
+    if (O.n_fr_groups) hipLaunchKernelGGL(zk_o0_rows_fr, dim3(O.n_fr_groups, (cnt + 63u) / 64u), dim3(64), 0, st, A, O);   // a wavefront = one row x 64 emails
   }
 }
 
@@ -1002,7 +1004,8 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
       if (units > 0x7fffffffull) return ZKWG_RC_BAD_ARG;
       if (mont) hipLaunchKernelGGL(zk_image_to_mont, dim3((u32)((conv + 255) / 256)), dim3(256), 0, st, A);
       const dim3 g3((u32)units), b3(256);
-#define ZK_LAUNCH_O0(K) do { if (mont) hipLaunchKernelGGL(zk_expand3_o0_mont_k##K, g3, b3, 0, st, A, O); else hipLaunchKernelGGL(zk_expand3_o0_k##K, g3, b3, 0, st, A, O); } while (0)
+#define ZK_LAUNCH_O0(K) do { if (c->o0_pipe) { if (mont) hipLaunchKernelGGL(zk_expand3_o0p_mont_k##K, g3, b3, 0, st, A, O); else hipLaunchKernelGGL(zk_expand3_o0p_k##K, g3, b3, 0, st, A, O); } \
+                             else { if (mont) hipLaunchKernelGGL(zk_expand3_o0_mont_k##K, g3, b3, 0, st, A, O); else hipLaunchKernelGGL(zk_expand3_o0_k##K, g3, b3, 0, st, A, O); } } while (0)
       if (c->x3_k_o0 == 1) ZK_LAUNCH_O0(1); else if (c->x3_k_o0 == 2) ZK_LAUNCH_O0(2); else ZK_LAUNCH_O0(4);
 #undef ZK_LAUNCH_O0
       continue;
@@ -1208,7 +1211,7 @@ static int tables_host(const zkwg_circuit* c, const ZkO0Tables& T, u64 W3, const
       }
     }
     u8* w = out + el * out_stride;
-    for (u64 i = 0; i < W3; ++i) zk_host_put(w + 32 * i, zk_desc_decode(T.desc[2 * i], T.desc[2 * i + 1], cx), R);
+    for (u64 i = 0; i < W3; ++i) zk_host_put(w + 32 * i, zk_wire_code(T.desc[2 * i], T.desc[2 * i + 1], T.aff.data(), cx), R);
   }
   _mm_sfence();
   return ZKWG_RC_OK;

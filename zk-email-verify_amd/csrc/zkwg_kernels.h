@@ -22,7 +22,8 @@ __global__ void zk_r1cs_eval(const u64* row_ptr, const u32* wire, const Fr* coef
 // zkwg_kernels_expand3.hip: one piece of 256 K slots per workgroup (K = 1, 2, 4), standard / Montgomery form, kept-v1 / numbered circuits
 #define ZK_X3_DECL(K) \
   __global__ void zk_expand3_k##K(ZkX3 A); __global__ void zk_expand3_mont_k##K(ZkX3 A); \
-  __global__ void zk_expand3_o0_k##K(ZkX3 A, ZkO0Dev O); __global__ void zk_expand3_o0_mont_k##K(ZkX3 A, ZkO0Dev O);
+  __global__ void zk_expand3_o0_k##K(ZkX3 A, ZkO0Dev O); __global__ void zk_expand3_o0_mont_k##K(ZkX3 A, ZkO0Dev O); \
+  __global__ void zk_expand3_o0p_k##K(ZkX3 A, ZkO0Dev O); __global__ void zk_expand3_o0p_mont_k##K(ZkX3 A, ZkO0Dev O);
 ZK_X3_DECL(1) ZK_X3_DECL(2) ZK_X3_DECL(4)
 __global__ void zk_expand3_k8(ZkX3 A); __global__ void zk_expand3_mont_k8(ZkX3 A);
 __global__ void zk_image_to_mont(ZkX3 A);
@@ -31,7 +32,6 @@ __global__ void zk_o0_chains_small(ZkX3 A, ZkO0Dev O);
 __global__ void zk_o0_generic(ZkX3 A, ZkO0Dev O);
 __global__ void zk_o0_rows_small_long(ZkX3 A, ZkO0Dev O);
 #define ZK_ROW_EMAILS 8   // emails per thread of zk_o0_rows_small
-#define ZK_FR_EMAILS 4    // emails per lane of zk_o0_rows_fr
 __global__ void zk_o0_rows_fr(ZkX3 A, ZkO0Dev O);
 __global__ void zk_mont_convert(Fr* v, u64 n, int to_mont);  // zkwg_kernels_handoff.hip
 __global__ void zk_gen_inputs(ZkSched s, ZkDkimBatch D, u8* recs, int* gen_status, u32 n);  // zkwg_kernels_inputs.hip

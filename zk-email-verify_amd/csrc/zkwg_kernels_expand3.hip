@@ -236,7 +236,7 @@ __device__ __forceinline__ u32 zk_o0_combine(uint2 d, const ZkO0Pre& p, u64 w64,
     default: return 0u;
   }
 }
-template <bool MONT, int K>
+template <bool MONT, int K, bool PIPE>
 __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev& O) {
   constexpr u32 SLOTS = 256u * K;
   const u32 unit = zk_x3_unit(A.xcd_remap);
@@ -247,29 +247,56 @@ __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev&
   // the descriptors of this thread's K wires: loaded once, reused for every email of the group (8 bytes per wire
   // against 32 bytes written per wire and email)
   uint2 d[K];
+  u32 aff[K];               // ZK_D_AFF wires: c0 | c1 << 16 applied to the source's value (0x00010000 = identity: every other wire)
   ZkO0Pre pre[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const u32 i = 64u * K * wv + 64u * k + lane;
     d[k] = i < nsl ? O.desc[slot0 + i] : make_uint2(0u, 0u);
+    aff[k] = 0x00010000u;
+    if ((d[k].x >> 28) == ZK_D_AFF) { const uint4 a = O.aff[d[k].y]; d[k] = make_uint2(a.x, a.y); aff[k] = a.z; }
     pre[k] = zk_o0_pre(d[k], A);
   }
-  const u32 el1 = min((g + 1u) * O.emails_per_wg, A.n_count);
-  for (u32 el = g * O.emails_per_wg; el < el1; ++el) {
-    const u32 e = el + A.e_first;
-    const ZkCtx cx = zk_x3_ctx(A, e);
-    u64 w64[K]; u32 w8[K], w32[K], w32b[K];
+  // The loop over the group's emails is software-pipelined: the image words of email i + 1 are requested before email i is
+  // turned into codes and stored (the stores may alias the image as far as the compiler knows, so it would not hoist the
+  // loads itself), otherwise every email pays the load latency in front of its stores.
+  const u32 el0 = g * O.emails_per_wg, el1 = min((g + 1u) * O.emails_per_wg, A.n_count);
+  u64 w64[K], n64[K]; u32 w8[K], w32[K], w32b[K], n8[K], n32[K], n32b[K];
+  if (el0 < el1) {
+    const ZkCtx cx = zk_x3_ctx(A, el0 + A.e_first);
 #pragma unroll
     for (int k = 0; k < K; ++k) { w64[k] = cx.bits[pre[k].i64]; w8[k] = cx.rec[pre[k].i8]; w32[k] = cx.small[pre[k].i32]; w32b[k] = cx.small[pre[k].i32b]; }
+  }
+  for (u32 el = el0; el < el1; ++el) {
+    const u32 e = el + A.e_first;
+    const ZkCtx cx = zk_x3_ctx(A, e);
+    if constexpr (PIPE) {
+      const ZkCtx nx = zk_x3_ctx(A, min(el + 1u, el1 - 1u) + A.e_first);
+#pragma unroll
+      for (int k = 0; k < K; ++k) { n64[k] = nx.bits[pre[k].i64]; n8[k] = nx.rec[pre[k].i8]; n32[k] = nx.small[pre[k].i32]; n32b[k] = nx.small[pre[k].i32b]; }
+    }
     u32 code[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) code[k] = zk_o0_combine(d[k], pre[k], w64[k], w8[k], w32[k], w32b[k], cx.half);
+    for (int k = 0; k < K; ++k) {
+      code[k] = zk_o0_combine(d[k], pre[k], w64[k], w8[k], w32[k], w32b[k], cx.half);
+      if (aff[k] != 0x00010000u) code[k] = zk_aff_apply(aff[k], code[k], cx);
+    }
     zk_x3_store<MONT, K>(A, cx, e, el, slot0, nsl, code);
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) { w64[k] = n64[k]; w8[k] = n8[k]; w32[k] = n32[k]; w32b[k] = n32b[k]; }
+    } else if (el + 1u < el1) {
+      const ZkCtx nx = zk_x3_ctx(A, el + 1u + A.e_first);
+#pragma unroll
+      for (int k = 0; k < K; ++k) { w64[k] = nx.bits[pre[k].i64]; w8[k] = nx.rec[pre[k].i8]; w32[k] = nx.small[pre[k].i32]; w32b[k] = nx.small[pre[k].i32b]; }
+    }
   }
 }
 #define ZK_X3_O0_KERNELS(K)                                                                                                                                     \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, K>(A, O); }      \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_mont_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, K>(A, O); }
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, K, false>(A, O); }      \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_mont_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, K, false>(A, O); } \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0p_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, K, true>(A, O); }      \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0p_mont_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, K, true>(A, O); }
 ZK_X3_O0_KERNELS(1)
 ZK_X3_O0_KERNELS(2)
 ZK_X3_O0_KERNELS(4)
@@ -415,66 +442,48 @@ __global__ __launch_bounds__(64) void zk_o0_chains_small(ZkX3 A, ZkO0Dev O) {
     carry = (long long)((u64)(u32)__shfl((u32)(u64)v, 63) | ((u64)(u32)__shfl((u32)((u64)v >> 32), 63) << 32));
   }
 }
-// the other rows: arithmetic mod r (zk_linear_row's), sources decoded from the image
-// 8 lanes per row and ZK_FR_EMAILS emails per lane: the lanes split the row's terms; per term the descriptor, kind and
-// coefficient are read once and the image loads of all the emails are issued back to back (the kernel is a chain of
-// dependent loads: what counts is how many are in flight); the partial sums are folded with shuffles
-#define ZK_FR_LANES 8u
-__global__ __launch_bounds__(256) void zk_o0_rows_fr(ZkX3 A, ZkO0Dev O) {
-  const u32 j = blockIdx.x * (256u / ZK_FR_LANES) + threadIdx.x / ZK_FR_LANES, l = threadIdx.x % ZK_FR_LANES;
-  const bool live = j < O.n_fr_groups;
-  const u32 el0 = blockIdx.y * ZK_FR_EMAILS, last = A.n_count - 1u;
-  Fr acc[ZK_FR_EMAILS];
-#pragma unroll
-  for (int k = 0; k < ZK_FR_EMAILS; ++k) acc[k] = fr_zero();
-  if (live) {
-    const u64 t1 = O.f_ptr[j + 1];
-    for (u64 t = O.f_ptr[j] + l; t < t1; t += ZK_FR_LANES) {
-      const uint2 d = O.f_term[t];
-      const u8 kd = O.f_kind[t];
-      const ZkO0Pre pre = zk_o0_pre(d, A);
-      u64 w64[ZK_FR_EMAILS]; u32 w8[ZK_FR_EMAILS], w32[ZK_FR_EMAILS], w32b[ZK_FR_EMAILS];
-#pragma unroll
-      for (int k = 0; k < ZK_FR_EMAILS; ++k) {
-        const ZkCtx cx = zk_x3_ctx(A, A.e_first + min(el0 + (u32)k, last));
-        w64[k] = cx.bits[pre.i64]; w8[k] = cx.rec[pre.i8]; w32[k] = cx.small[pre.i32]; w32b[k] = cx.small[pre.i32b];
-      }
-      Fr cf = fr_zero(), cfm = fr_zero();   // the coefficient, and its Montgomery form (x * cf = mont_mul(x, cf R))
-      if (kd != ZK_COEF_ONE && kd != ZK_COEF_MINUS_ONE) { cf = O.f_coef[t]; cfm = O.f_coefm[t]; }
-#pragma unroll
-      for (int k = 0; k < ZK_FR_EMAILS; ++k) {
-        const u32 e = A.e_first + min(el0 + (u32)k, last);
-        const ZkCtx cx = zk_x3_ctx(A, e);
-        const u32 code = zk_o0_combine(d, pre, w64[k], w8[k], w32[k], w32b[k], cx.half);
-        if (code == 0u) continue;
-        Fr x;
-        if (!(code >> 31)) x = Fr{{(u64)code, 0, 0, 0}};
-        else {
-          ZkRefSrc R;
-          R.frv = (const uint4*)(A.frv + (u64)e * A.img_fr);
-          R.invtab = (const uint4*)A.invtab;
-          R.rec = cx.rec; R.small = cx.small;
-          x = zk_code_value(code, R);
-        }
-        if (kd == ZK_COEF_ONE) acc[k] = fr_add(acc[k], x);
-        else if (kd == ZK_COEF_MINUS_ONE) acc[k] = fr_sub(acc[k], x);
-        else if (code == 1u) acc[k] = fr_add(acc[k], cf);   // (powers of two of Bits2Num ...: the operand is almost always a bit)
-        else if (!fr_is_zero(x)) acc[k] = fr_add(acc[k], fr_mont_mul(x, cfm));
-      }
+// the other rows: arithmetic mod r (zk_linear_row's), sources decoded from the image.
+// One wavefront = one row for 64 emails (lane = email).  Everything the row's table holds -- term pointer, descriptor, kind,
+// coefficient -- is wave-uniform: loaded once per wavefront through the scalar path, every branch on it is uniform, and the
+// coefficient sits in scalar registers where the multiplier reads it.  What differs per lane is the operand, fetched from
+// that email's image.  Products with a generic coefficient are accumulated unreduced (17 x 32-bit limbs, fr_wide_mac:
+// 64 multiplier issues instead of the 128 of a Montgomery product) and reduced once per 16 terms; coefficients of +-1 and
+// bit operands are plain modular additions.  Rows that read the same operands (the 33 evaluation points of one FpMul, the
+// rows of one interpolation matrix) are neighbours in the table: each XCD takes one contiguous range of rows, so they
+// share its L2.  (Round 3: 8 lanes per row chasing dependent loads, 128 bytes of table per term and lane: 15.7 ms per
+// 1,024 emails of EmailVerifier(576,192)'s constraint system, 84 k products per email.)
+__global__ __launch_bounds__(64) void zk_o0_rows_fr(ZkX3 A, ZkO0Dev O) {
+  u32 blk = blockIdx.x;
+  { const u32 per = gridDim.x >> 3; if (blk < per * 8u) blk = (blk & 7u) * per + (blk >> 3); }
+  const u32 j = __builtin_amdgcn_readfirstlane(blk);
+  const u32 lane = threadIdx.x, el = blockIdx.y * 64u + lane, last = A.n_count - 1u;
+  const u32 e = A.e_first + min(el, last);
+  const ZkCtx cx = zk_x3_ctx(A, e);
+  ZkRefSrc R;
+  R.frv = (const uint4*)(A.frv + (u64)e * A.img_fr);
+  R.invtab = (const uint4*)A.invtab;
+  R.rec = cx.rec; R.small = cx.small;
+  FrWide w;
+  fr_wide_zero(w);
+  u32 nw = 0;
+  Fr s = fr_zero();
+  const u64 t0 = O.f_ptr[j], t1 = O.f_ptr[j + 1];
+  for (u64 t = t0; t < t1; ++t) {
+    const uint2 d = O.f_term[t];
+    const u32 kd = O.f_kind[t], dk = d.x >> 28;
+    const u32 code = zk_desc_decode(d.x, d.y, cx);
+    if (kd == ZK_COEF_ONE) { s = fr_add(s, zk_code_value(code, R)); continue; }
+    if (kd == ZK_COEF_MINUS_ONE) { s = fr_sub(s, zk_code_value(code, R)); continue; }
+    if (dk == ZK_D_BIT64 || dk == ZK_D_BIT8) {
+      // a bit times a coefficient (the powers of two of Bits2Num ...): add the coefficient or not
+      const Fr cf = O.f_coef[t];
+      if (code) s = fr_add(s, cf);
+      continue;
     }
+    const Fr cfm = O.f_coefm[t];
+    fr_wide_mac(w, zk_code_value(code, R), cfm);
+    if (++nw == 16u) { s = fr_add(s, fr_wide_redc(w)); fr_wide_zero(w); nw = 0; }
   }
-#pragma unroll
-  for (int k = 0; k < ZK_FR_EMAILS; ++k) {
-#pragma unroll
-    for (u32 off = ZK_FR_LANES / 2; off >= 1; off >>= 1) {
-      Fr o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const u32 lo = __shfl_down((u32)acc[k].l[i], off, ZK_FR_LANES), hi = __shfl_down((u32)(acc[k].l[i] >> 32), off, ZK_FR_LANES);
-        o.l[i] = (u64)lo | ((u64)hi << 32);
-      }
-      acc[k] = fr_add(acc[k], o);
-    }
-    if (live && l == 0 && el0 + (u32)k <= last) A.frv_w[(u64)(A.e_first + el0 + k) * A.img_fr + O.fr_base + j] = acc[k];
-  }
+  if (nw) s = fr_add(s, fr_wide_redc(w));
+  if (el <= last) A.frv_w[(u64)e * A.img_fr + O.fr_base + j] = s;
 }

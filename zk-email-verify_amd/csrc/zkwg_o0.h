@@ -31,6 +31,8 @@ enum ZkDescKind : u32 {
   ZK_D_SMALLN = 9,    // small[b] as a signed integer of 31 bits (results of small rows whose range is that narrow): bit 31 clear -> the value, set -> r - |v|
   ZK_D_BITRUN = 10,   // row terms only: bits (a & 63) .. (a & 63) + ((a >> 6) & 31) of bits[b] as an integer (a run of a Bits2Num sum)
   ZK_D_CODEW = 8,     // small[b] holds the wire's code itself (left there by zk_o0_generic for the wires of kind GENERIC)
+  ZK_D_AFF = 11,      // b = entry of the affine table {source descriptor (2 words), c0 | c1 << 16 (two int16), 0}: the wire is c0 + c1 * source -- a row with ONE
+                      // source (the `b - 1` of every bit constraint's B side, `1 - x`, `c - byte` ...), evaluated in line by the streaming kernel
   ZK_D_DFA = 7        // BodyHashRegex DFA array element: a = kind << 28 | ZkDfaKind << 24 | q << 20 | position << 9 | param b, b = param c
 };
 
@@ -57,6 +59,8 @@ struct ZkO0Tables {
   u64 n_small() const { return s_ptr.empty() ? 0 : s_ptr.size() - 1; }
   u64 n_fr() const { return f_ptr.empty() ? 0 : f_ptr.size() - 1; }
   u64 n_alias = 0, n_const = 0, terms_before_chaining = 0;
+  std::vector<u32> aff;        // 4 words per entry (ZK_D_AFF)
+  u64 n_aff() const { return aff.size() / 4; }
   // wires of kind GENERIC (decoded by their segment's own arithmetic: selectors, comparators ...): a pre-pass kernel leaves
   // their codes in small[gen_base + g], so that the streaming kernel itself carries no segment decoder
   u32 gen_base = 0;
@@ -181,6 +185,29 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
       if (lo < -((__int128)1 << 62) || hi > ((__int128)1 << 62)) small = false;
       cs.push_back((int32_t)k);
     }
+    if (small && b - a <= 2 && !getenv("ZKWG_O0_NO_AFF")) {
+      // one source (+ a constant): no row -- the streaming kernel computes c0 + c1 * source from the source's own descriptor
+      int src = -1;
+      long long c0 = 0;
+      bool ok = true;
+      for (u64 t = a; t < b; ++t) {
+        if (term_slot[t] == 0) c0 += cs[t - a];
+        else if (src < 0) src = (int)(t - a);
+        else ok = false;
+      }
+      if (ok && src >= 0) {
+        u32 d[2], si, sr;
+        describe(term_slot[a + src], d, &si, &sr);
+        long long l, h;
+        const long long c1 = cs[src];
+        if (zk_slot_range(segs[si], sr, l, h) && l >= 0 && h < (1ll << 30) && c0 > -32768 && c0 < 32768 && c1 > -32768 && c1 < 32768 &&
+            lo > -((__int128)1 << 27) && hi < ((__int128)1 << 27) && T.aff.size() / 4 < (1u << 28)) {
+          T.desc[2 * dst] = (u32)ZK_D_AFF << 28; T.desc[2 * dst + 1] = (u32)(T.aff.size() / 4);
+          T.aff.push_back(d[0]); T.aff.push_back(d[1]); T.aff.push_back((u32)(uint16_t)(int16_t)c0 | ((u32)(uint16_t)(int16_t)c1 << 16)); T.aff.push_back(0u);
+          continue;
+        }
+      }
+    }
     T.terms_before_chaining += b - a;
     std::vector<Fr> fc;   // field rows: coefficients in standard form, like zk_linear_row; kinds
     std::vector<u8> fk;
@@ -219,6 +246,21 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
       }
       return q == np;
     };
+    if (small && getenv("ZKWG_DEBUG_FORMS")) {
+      // histogram of the small rows' shapes: "<terms>: kind*coef ..." (debug aid for choosing in-line descriptor kinds)
+      static std::unordered_map<std::string, u64> forms;
+      static u64 seen = 0;
+      std::string key = std::to_string(nt) + ":";
+      if (nt <= 3) for (size_t i = 0; i < nt; ++i) key += " k" + std::to_string(td[2 * i] >> 28) + ((td[2 * i] >> 28) == ZK_D_IMM ? "(" + std::to_string(td[2 * i + 1]) + ")" : "") + "*" + std::to_string(cs[i]);
+      ++forms[key];
+      if (++seen % 100000 == 0 || r + 1 == P.n_rows()) {
+        std::vector<std::pair<u64, std::string>> top;
+        for (auto& kv : forms) top.emplace_back(kv.second, kv.first);
+        std::sort(top.rbegin(), top.rend());
+        fprintf(stderr, "[zkwg] small-row forms after %llu rows:\n", (unsigned long long)seen);
+        for (size_t i = 0; i < top.size() && i < 24; ++i) fprintf(stderr, "[zkwg]   %8llu  %s\n", (unsigned long long)top[i].first, top[i].second.c_str());
+      }
+    }
     if (small) {
       const bool ch = subseq(prev_s_t, prev_s_c.size(), [&](size_t q, size_t i) { return prev_s_c[q] == cs[i]; });
       if (!ch) { rest.resize(nt); for (size_t i = 0; i < nt; ++i) rest[i] = (u32)i; }
@@ -300,6 +342,7 @@ static inline bool zk_o0_build(ZkSched& s, const std::vector<ZkSeg>& segs, const
 // device-side tables of a numbered circuit (kernel argument, by value)
 struct ZkO0Dev {
   const uint2* desc;       // per wire
+  const uint4* aff;        // ZK_D_AFF entries
   u64 W;                   // wires
   u32 nportions;           // pieces of 256 K wires
   u32 emails_per_wg;       // a workgroup expands its piece for this many emails (the descriptors are loaded once)

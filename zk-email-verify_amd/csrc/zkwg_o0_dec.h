@@ -50,3 +50,17 @@ ZK_DEC __forceinline__ Fr zk_code_value(u32 code, const ZkRefSrc& R) {
   const uint4 a = zk_ref_half(code, 0u, R), b = zk_ref_half(code, 1u, R);
   return Fr{{(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), (u64)b.x | ((u64)b.y << 32), (u64)b.z | ((u64)b.w << 32)}};
 }
+
+// ZK_D_AFF: c0 + c1 * source (zkwg_o0.h), `code` = the source's code
+ZK_DEC __forceinline__ u32 zk_aff_apply(u32 packed, u32 code, const ZkCtx& cx) {
+  const long long sv = (code >> 31) ? zk_code_int(code, cx) : (long long)code;
+  const long long v = (long long)(short)(packed & 0xffffu) + (long long)(short)(packed >> 16) * sv;
+  return v >= 0 ? (u32)v : (ZK_REF_MINUS | (u32)(-v));
+}
+// the code of wire (a, b) of a descriptor table whose affine entries are `aff` (host evaluation; the streaming kernel resolves
+// the entry once per workgroup instead)
+ZK_DEC __forceinline__ u32 zk_wire_code(u32 a, u32 b, const u32* aff, const ZkCtx& cx) {
+  if ((a >> 28) != ZK_D_AFF) return zk_desc_decode(a, b, cx);
+  const u32* e = aff + 4ull * b;
+  return zk_aff_apply(e[2], zk_desc_decode(e[0], e[1], cx), cx);
+}
