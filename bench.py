@@ -565,6 +565,25 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
                                                   "sample": f"{n} emails through zkwg_calculate_batch, tiles of {t}, PCIe-inclusive"}
     except Exception as e:
         out["delivered to pinned host memory"] = {"error": repr(e)[:200]}
+    # the device-resident pipeline BELOW the C-ABI (zkwg_calculate_batch_resident: what a Node host without torch drives, and what
+    # zkwg_calculate_batch_multi runs on every GPU when no witness is asked back): records from host memory, statuses + result
+    # table back, witnesses into the handle's own placed two-tile ring
+    try:
+        n = args.batch
+        h_in, _, _ = resident_inputs(torch, c, dev, 0x5A4B + 909, 64, n, args.body_len)
+        recs = bytes(h_in.repeat((n + 63) // 64, 1)[:n].contiguous().numpy().tobytes())
+        st, _ = c.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)     # (allocates and places the ring)
+        assert not any(st)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            st, tb = c.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)
+        sec = (time.perf_counter() - t0) / reps
+        out["C-ABI resident pipeline (zkwg_calculate_batch_resident)"] = {
+            "value": round(n / sec, 1), "unit": "witnesses/s", "ring_placement": c.resident_placement(),
+            "sample": f"{n} emails per call from host records (H2D of the records, statuses and the 100-byte table back included), {reps} calls"}
+    except Exception as e:
+        out["C-ABI resident pipeline (zkwg_calculate_batch_resident)"] = {"error": repr(e)[:200]}
     # the same delivery with the expansion on the HOST (zkwg_set_host_expand): only the 0.45 MB image crosses PCIe, the
     # witness bytes are written by the host cores (non-temporal stores) -- bounded by host DRAM bandwidth instead
     try:

@@ -253,6 +253,26 @@ typedef struct zkwg_dkim_batch {
 int zkwg_generate_inputs_device(zkwg_circuit_t* c, const zkwg_dkim_batch* batch, uint64_t n_emails,
                                 void* d_records, void* d_gen_status, void* hip_stream);
 
+/* Device-resident batch below the boundary: for a host without a tensor library (the Node host of the
+ * reference) that feeds a device-side consumer.  The records go to the device once; the compute kernels of sub-batch i + 1
+ * (`prep` emails, default 1024) run on one internal stream while sub-batch i is expanded tile by tile (`tile` emails, default
+ * 512) on another; witnesses are written into a ring of TWO tiles in HBM that is overwritten as the batch proceeds -- the
+ * ring is placed where HBM takes the stores fastest (once per handle: the first tile's expansion is timed into spare
+ * candidate buffers, zkwg_resident_placement reports the timings; ZKWG_PLACE_RING=0 disables).  After each tile's expansion
+ * has been enqueued `consumer` (may be NULL) is called on the calling thread with the tile's device pointer, the distance
+ * between consecutive witnesses, the index of its first email, its email count and the HIP stream the expansion was
+ * enqueued on: work the consumer enqueues on that stream sees the complete tile and finishes before the ring slot is reused
+ * (a GPU prover's entry point; packages/helpers/src/chunked-zkey.ts:80-84 is the call it completes).  What comes back to the
+ * host: status[n] and, if `table` is given, n rows of 100 bytes {status i32, pubkeyHash, shaHi, shaLo} -- never the witnesses
+ * (56.9 MB each: use zkwg_calculate_batch for that, PCIe-bound).  zkwg_calculate_batch_multi with out_wtns = NULL runs this
+ * on every device. */
+typedef void (*zkwg_tile_fn)(void* user, int device, const void* d_tile, uint64_t witness_stride, uint64_t first_email,
+                             uint64_t count, void* hip_stream);
+int zkwg_calculate_batch_resident(zkwg_circuit_t* c, const uint8_t* packed_inputs, uint64_t n_emails, int32_t* status,
+                                  uint8_t* table, uint64_t tile, uint64_t prep, zkwg_tile_fn consumer, void* user);
+int zkwg_resident_placement(const zkwg_circuit_t* c, float* ms, int cap, int kept[2]);
+
+
 /* Host expansion (the delivered-to-host rate; the consumer is snarkjs on the host,
  * packages/helpers/src/chunked-zkey.ts:80-84).  A witness crosses PCIe at 32 bytes per signal (56.9 MB per email) although
  * its information is the 0.45 MB image the prepare kernels leave.  zkwg_expand_host runs the segment decoders of
@@ -379,6 +399,27 @@ int zkwg_convert_montgomery_device(void* d_values, uint64_t n_values, int to_mon
 int zkwg_expand_montgomery_device(zkwg_circuit_t* c, const void* d_packed_inputs, uint64_t n_emails,
                                   const void* d_scratch, uint64_t first, uint64_t count, void* d_out_wtns,
                                   uint64_t out_stride, void* hip_stream);
+/* ---- prover stage 2 (SURVEY.md 8f4 "next"): the transforms between A.w | B.w | C.w and the H multi-exponentiation ----------
+ * snarkjs groth16_prove.js [EXT, pinned in yarn.lock:7767-7800; ffjavascript F1Field]: A = ifft(A.w), Aodd = A[i] * inc^i,
+ * Aodd_T = fft(Aodd) (likewise B, C), P_T = Aodd_T * Bodd_T - Codd_T on the domain of 2^power >= nConstraints + nPublic + 1
+ * points, inc = the primitive 2^(power+1)-th root w[power + 1] (w[28] = 5^((r-1)/2^28), w[i] = w[i+1]^2).  Everything is in
+ * Montgomery form (x * 2^256 mod r), as zkwg_expand_abc_device(montgomery = 1) writes it and as an MSM wants it.
+ * zkwg_ntt_create builds the twiddle and coset tables of one domain size (2 x 32 bytes x 2^log2_n on the device).
+ * zkwg_h_evaluations_device: d_abc = n_emails records of A.w | B.w | C.w (n_constraints values each, abc_stride bytes apart,
+ * e.g. straight from zkwg_expand_abc_device); d_work = zkwg_ntt_work_bytes(plan, n_emails) bytes of scratch; d_out receives
+ * 2^log2_n values per email, out_stride bytes apart.  n_emails <= 21845 per call.  Arithmetic-bound (~12 Montgomery products
+ * per element and transform), not HBM-bound: DESIGN.md section 22.
+ * zkwg_ntt_transform_device: stand-alone in-place transforms of n_polys arrays (natural order in and out; inverse includes
+ * 1 / n) -- ffjavascript's Fr.fft / Fr.ifft on Montgomery-form data. */
+typedef struct zkwg_ntt zkwg_ntt_t;
+int zkwg_ntt_create(int device, uint32_t log2_n, zkwg_ntt_t** out);
+void zkwg_ntt_destroy(zkwg_ntt_t* plan);
+uint64_t zkwg_ntt_domain(const zkwg_ntt_t* plan);
+uint64_t zkwg_ntt_work_bytes(const zkwg_ntt_t* plan, uint64_t n_emails);
+int zkwg_ntt_transform_device(zkwg_ntt_t* plan, void* d_data, uint64_t n_polys, int inverse, void* hip_stream);
+int zkwg_h_evaluations_device(zkwg_ntt_t* plan, const void* d_abc, uint64_t abc_stride, uint64_t n_constraints, uint64_t n_emails,
+                              void* d_work, void* d_out, uint64_t out_stride, void* hip_stream);
+
 /* The same prover stage without a 32-byte witness in between: the constraint system `r1cs` (its wires = the handle's
  * witness layout: built-in, `.sym`, or -- since ABI 3 -- a fully numbered handle of zkwg_circuit_create_full, whose system is
  * the compiler's own `.r1cs`, the file a zkey is keyed to: every wire of every combination is substituted by the kept-v1

@@ -167,3 +167,49 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert res["value"] > 0
     assert res["gathered_table"] == {"rows": 1024, "status_nonzero": 0, "rows_with_outputs": 1024}
     assert "2 wtns/rank/step gathered" in res["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_resident_pipeline_below_the_boundary_matches_the_host_path():
+    """zkwg_calculate_batch_resident: records in, statuses + the result table out, witnesses into the
+    handle's placed two-tile ring; the consumer callback sees every tile on the expansion stream.  Statuses and table rows
+    equal the host-buffer path's; the tiles the consumer copies out on that stream are the host path's witnesses byte for byte."""
+    import ctypes as C
+    import zkwg
+    from zkwg import synth
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192, device=0)
+    n = 23
+    recs, _ = synth.packed_batch(c, seed=0x77, n=n, body_len=70)
+    recs = bytearray(recs)
+    off = c.lib.zkwg_input_offset(c.h, zkwg._lib.IN_SIGNATURE)
+    for bad in (4, 17):                       # tampered signatures on both sides of a tile boundary
+        recs[bad * c.in_stride + off] ^= 1
+    recs = bytes(recs)
+    wit, st_host = c.calculate_batch_host(recs)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    wb = c.witness_bytes
+    seen, got = [], bytearray(n * wb)
+    buf = (C.c_uint8 * len(got)).from_buffer(got)
+
+    def consumer(dev, d_tile, stride, first, count, stream):
+        assert dev == 0 and stride == wb
+        seen.append((first, count))
+        # a stream-ordered consumer: copy the tile out ON THE EXPANSION STREAM (2 = hipMemcpyDeviceToHost)
+        assert hip.hipMemcpyAsync(C.addressof(buf) + first * wb, d_tile, count * wb, 2, stream) == 0
+        assert hip.hipStreamSynchronize(stream) == 0
+    status, table = c.calculate_batch_resident(recs, tile=8, prep=16, consumer=consumer)
+    assert status == st_host and [i for i, x in enumerate(status) if x] == [4, 17]
+    assert seen == [(0, 8), (8, 8), (16, 7)]
+    for i in range(n):
+        row = table[100 * i:100 * i + 100]
+        assert int.from_bytes(row[:4], "little", signed=True) == status[i]
+        if status[i] == 0:
+            assert row[4:] == wit[i * wb + 32:i * wb + 128]
+            assert bytes(got[i * wb:(i + 1) * wb]) == wit[i * wb:(i + 1) * wb]
+    pl = c.resident_placement()
+    assert len(pl["ms_per_tile"]) >= 2 and all(k >= 0 for k in pl["kept"])
+    # a second call reuses the ring; a larger tile re-places it
+    status2, _ = c.calculate_batch_resident(recs, tile=16, prep=16, want_table=False)
+    assert status2 == status

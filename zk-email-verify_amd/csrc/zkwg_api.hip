@@ -105,6 +105,14 @@ struct zkwg_circuit {
   bool ev_valid, prep_valid;
   int rsa_wgs_per_cu;
   u32 prep_mask = 0xffffffffu;   // zkwg_set_prepare_mask (measurement aid)
+  // device-resident pipeline (zkwg_calculate_batch_resident): buffers cached in the handle, under hb_mutex
+  u8* rp_in = nullptr; u64 rp_in_cap = 0;
+  u8* rp_scr[2] = {nullptr, nullptr}; u64 rp_scr_bytes = 0;
+  u8* rp_out[2] = {nullptr, nullptr}; u64 rp_tile_bytes = 0;
+  int* rp_status = nullptr; u64 rp_n_cap = 0;
+  hipStream_t rp_exp = nullptr;
+  hipEvent_t rp_prep_done[2] = {nullptr, nullptr}, rp_exp_done[2] = {nullptr, nullptr};
+  float rp_place_ms[8] = {0}; int rp_place_n = 0, rp_place_kept[2] = {-1, -1};
 };
 
 // inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
@@ -599,6 +607,9 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     free_o0(c->o0d); free_o0(c->abcd);
     hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_fn); hipFree(c->d_net_desc);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
+    hipFree(c->rp_in); hipFree(c->rp_scr[0]); hipFree(c->rp_scr[1]); hipFree(c->rp_out[0]); hipFree(c->rp_out[1]); hipFree(c->rp_status);
+    if (c->rp_exp) hipStreamDestroy(c->rp_exp);
+    for (int i = 0; i < 2; ++i) { if (c->rp_prep_done[i]) hipEventDestroy(c->rp_prep_done[i]); if (c->rp_exp_done[i]) hipEventDestroy(c->rp_exp_done[i]); }
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); if (c->hx_img[i]) hipHostFree(c->hx_img[i]); }
     hipStreamDestroy(c->copy_stream);
     hipStreamDestroy(c->own_stream);
@@ -908,7 +919,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     if (pm & 64u) hipLaunchKernelGGL(zk_rslb_chunks, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
     if (tm) hipEventRecord(evs[++ki], st);
     if (c->rs_sync) {
-      if (pm & 128u) hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);
+      if (pm & 128u) { hipLaunchKernelGGL(zk_rslb_merge, dim3((ne + 64u / ZK_RS_MERGE_LANES - 1u) / (64u / ZK_RS_MERGE_LANES)), dim3(64), 0, st, s, B); hipLaunchKernelGGL(zk_rslb_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B); }
     } else {
       int slot = -1;
       for (int i = 0; i < ZK_RS_SLOTS; ++i) if (c->rs_scr[i] == d_scratch) slot = i;
@@ -919,7 +930,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       // ZKWG_RSLB_SIDE_STREAMS raises it (together with GPU_MAX_HW_QUEUES).
       hipStream_t ss = c->side_stream[slot % c->rs_nside];
       hipStreamWaitEvent(ss, c->rs_dep[slot], 0);
-      if (pm & 128u) hipLaunchKernelGGL(zk_rslb_chain, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B);
+      if (pm & 128u) { hipLaunchKernelGGL(zk_rslb_merge, dim3((ne + 64u / ZK_RS_MERGE_LANES - 1u) / (64u / ZK_RS_MERGE_LANES)), dim3(64), 0, ss, s, B); hipLaunchKernelGGL(zk_rslb_scan, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B); }
       if (pm & 256u) {   // the rows read the chain's field elements: they follow it on the side stream
         if (c->full_W) launch_o0_rows(c, c->o0d, B, ss);
         if (c->abc_m) launch_o0_rows(c, c->abcd, B, ss);
@@ -1151,6 +1162,12 @@ int zkwg_circuit_attach_r1cs(zkwg_circuit_t* c, const uint8_t* r1cs, uint64_t le
       c->hb_tile = 0;
       for (int i = 0; i < 2; ++i) { if (c->hx_img[i]) hipHostFree(c->hx_img[i]); c->hx_img[i] = nullptr; }
       c->hx_bytes = 0;
+    }
+    if (c->device >= 0 && c->rp_scr_bytes) {
+      ZkDeviceGuard dg(c->device);
+      hipDeviceSynchronize();
+      hipFree(c->rp_scr[0]); hipFree(c->rp_scr[1]);
+      c->rp_scr[0] = c->rp_scr[1] = nullptr; c->rp_scr_bytes = 0;
     }
   } catch (const std::bad_alloc&) {
     return ZKWG_RC_OOM;
@@ -1435,6 +1452,152 @@ int zkwg_calculate_batch(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, u
   return calculate_batch_impl(c, packed, n, out_wtns, out_stride, status, max_tile, nullptr);
 }
 
+// ------------------------------------------------------------------ device-resident pipeline below the boundary
+// What bench.py's Pipeline does, for hosts without torch (the Node host of BASELINE.json's north_star): records go to the
+// device once, the prepare kernels of sub-batch i + 1 run on one stream while sub-batch i is expanded tile by tile on another,
+// witnesses are written into a two-tile ring in HBM -- placed where HBM takes the stores fastest (the
+// real expansion is timed into spare candidate tiles once per handle) -- and handed to `consumer` (a device-side prover)
+// stream-ordered; only the statuses and the three public outputs per email come back.  d_rows: optional device buffer,
+// n x 96 bytes (the multi-device path gathers them over RCCL).
+static int calculate_batch_resident_impl(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, int32_t* status, uint64_t tile_req,
+                                         uint64_t prep_req, uint8_t* d_rows, zkwg_tile_fn consumer, void* user) {
+  if (!c || !packed || !status) return ZKWG_RC_BAD_ARG;
+  if (c->device < 0) return ZKWG_RC_NO_DEVICE;
+  if (n == 0) return ZKWG_RC_OK;
+  std::lock_guard<std::mutex> lock(c->hb_mutex);
+  if (hipSetDevice(c->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  const u64 wbytes = out_W(c) * 32, in_stride = c->s.in_stride;
+  u64 tile = std::min<u64>(tile_req ? tile_req : 512, n);
+  u64 prep = std::max<u64>(tile, std::min<u64>(prep_req ? prep_req : 1024, n));
+  prep = prep / tile * tile;
+  // fit: two output tiles, two scratch buffers, the records
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  const u64 held = 2 * c->rp_tile_bytes + 2 * c->rp_scr_bytes + c->rp_in_cap * in_stride;
+  while (tile > 1 && 2 * tile * wbytes + 2 * zkwg_scratch_bytes(c, prep) + n * in_stride > (u64)((free_b + held) * 0.9)) { tile = (tile + 1) / 2; prep = std::max(tile, prep / 2 / tile * tile); }
+  auto ensure = [&](void** p, u64& have, u64 want) -> bool {
+    if (have >= want) return true;
+    hipFree(*p); *p = nullptr; have = 0;
+    if (hipMalloc(p, want) != hipSuccess) return false;
+    have = want;
+    return true;
+  };
+  if (!c->rp_exp) {
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&c->rp_exp, hipStreamNonBlocking, hi) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+    for (int i = 0; i < 2; ++i) { hipEventCreateWithFlags(&c->rp_prep_done[i], hipEventDisableTiming); hipEventCreateWithFlags(&c->rp_exp_done[i], hipEventDisableTiming); }
+  }
+  {
+    u64 cap = c->rp_in_cap * in_stride;
+    if (!ensure((void**)&c->rp_in, cap, n * in_stride)) return ZKWG_RC_OOM;
+    c->rp_in_cap = cap / in_stride;
+    u64 sc = c->rp_n_cap * sizeof(int);
+    if (!ensure((void**)&c->rp_status, sc, n * sizeof(int))) return ZKWG_RC_OOM;
+    c->rp_n_cap = sc / sizeof(int);
+    const u64 scr_b = zkwg_scratch_bytes(c, prep);
+    if (c->rp_scr_bytes < scr_b) {
+      hipFree(c->rp_scr[0]); hipFree(c->rp_scr[1]); c->rp_scr[0] = c->rp_scr[1] = nullptr; c->rp_scr_bytes = 0;
+      if (hipMalloc((void**)&c->rp_scr[0], scr_b) != hipSuccess || hipMalloc((void**)&c->rp_scr[1], scr_b) != hipSuccess) return ZKWG_RC_OOM;
+      c->rp_scr_bytes = scr_b;
+    }
+  }
+  hipStream_t P = c->own_stream, E = c->rp_exp;
+  if (hipMemcpyAsync(c->rp_in, packed, n * in_stride, hipMemcpyHostToDevice, P) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  const u64 tile_bytes = tile * wbytes;
+  bool place = c->rp_tile_bytes < tile_bytes;      // (a larger tile: the ring is allocated again, and placed again)
+  if (place) { hipFree(c->rp_out[0]); hipFree(c->rp_out[1]); c->rp_out[0] = c->rp_out[1] = nullptr; c->rp_tile_bytes = 0; }
+  int rc = ZKWG_RC_OK;
+  u64 ring = 0;
+  const u64 nsub = (n + prep - 1) / prep;
+  for (u64 sb = 0; sb < nsub && rc == ZKWG_RC_OK; ++sb) {
+    const u64 lo = sb * prep, cnt = std::min<u64>(prep, n - lo);
+    const int b = (int)(sb & 1);
+    if (sb >= 2) hipStreamWaitEvent(P, c->rp_exp_done[b], 0);      // scratch buffer b is free again
+    rc = zkwg_prepare_device(c, c->rp_in + lo * in_stride, cnt, c->rp_status + lo, c->rp_scr[b], P);
+    if (rc != ZKWG_RC_OK) break;
+    hipEventRecord(c->rp_prep_done[b], P);
+    hipStreamWaitEvent(E, c->rp_prep_done[b], 0);
+    if (place) {
+      // once per handle (and tile size): spare candidate tiles, the first tile's real expansion timed into each, the two
+      // fastest kept (zkwg.placement / DESIGN.md section 5)
+      place = false;
+      const bool want = !(getenv("ZKWG_PLACE_RING") && atoi(getenv("ZKWG_PLACE_RING")) == 0);
+      hipMemGetInfo(&free_b, &total_b);
+      const u64 reserve = 8ull << 30;
+      int ncand = want ? (int)std::min<u64>(7, free_b > reserve ? (free_b - reserve) / tile_bytes : 0) : 2;
+      ncand = std::max(ncand, 2);
+      std::vector<u8*> cand;
+      for (int i = 0; i < ncand; ++i) { u8* p = nullptr; if (hipMalloc((void**)&p, tile_bytes) != hipSuccess) break; cand.push_back(p); }
+      if (cand.size() < 2) { for (u8* p : cand) hipFree(p); rc = ZKWG_RC_OOM; break; }
+      std::vector<float> ms(cand.size(), 0.f);
+      if (cand.size() > 2) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        const u64 k0 = std::min<u64>(tile, cnt);
+        for (size_t i = 0; i < cand.size() && rc == ZKWG_RC_OK; ++i) {
+          rc = zkwg_expand_device(c, c->rp_in + lo * in_stride, cnt, c->rp_scr[b], 0, k0, cand[i], wbytes, E);   // first touch
+          hipEventRecord(e0, E);
+          for (int r = 0; r < 2 && rc == ZKWG_RC_OK; ++r) rc = zkwg_expand_device(c, c->rp_in + lo * in_stride, cnt, c->rp_scr[b], 0, k0, cand[i], wbytes, E);
+          hipEventRecord(e1, E);
+          if (hipEventSynchronize(e1) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
+          hipEventElapsedTime(&ms[i], e0, e1);
+          ms[i] *= 0.5f;
+        }
+        hipEventDestroy(e0); hipEventDestroy(e1);
+      }
+      std::vector<int> order(cand.size());
+      for (size_t i = 0; i < cand.size(); ++i) order[i] = (int)i;
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ms[x] < ms[y]; });
+      c->rp_place_n = (int)std::min<size_t>(cand.size(), 8);
+      for (int i = 0; i < c->rp_place_n; ++i) c->rp_place_ms[i] = ms[i];
+      for (int k = 0; k < 2; ++k) { c->rp_out[k] = cand[order[k]]; c->rp_place_kept[k] = order[k]; cand[order[k]] = nullptr; }
+      for (u8* p : cand) if (p) hipFree(p);
+      c->rp_tile_bytes = tile_bytes;
+      if (rc != ZKWG_RC_OK) break;
+    }
+    for (u64 first = 0; first < cnt && rc == ZKWG_RC_OK; first += tile, ++ring) {
+      const u64 count = std::min<u64>(tile, cnt - first);
+      u8* o = c->rp_out[ring & 1];
+      rc = zkwg_expand_device(c, c->rp_in + lo * in_stride, cnt, c->rp_scr[b], first, count, o, wbytes, E);
+      if (rc != ZKWG_RC_OK) break;
+      if (d_rows && hipMemcpy2DAsync(d_rows + (lo + first) * 96, 96, o + 32, wbytes, 96, count, hipMemcpyDeviceToDevice, E) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
+      if (consumer) consumer(user, c->device, o, wbytes, lo + first, count, (void*)E);
+    }
+    hipEventRecord(c->rp_exp_done[b], E);
+  }
+  if (rc == ZKWG_RC_OK && hipMemcpyAsync(status, c->rp_status, n * sizeof(int), hipMemcpyDeviceToHost, E) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
+  if (hipStreamSynchronize(P) != hipSuccess && rc == ZKWG_RC_OK) rc = ZKWG_RC_HIP_ERROR;
+  if (hipStreamSynchronize(E) != hipSuccess && rc == ZKWG_RC_OK) rc = ZKWG_RC_HIP_ERROR;
+  return rc;
+}
+
+int zkwg_calculate_batch_resident(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, int32_t* status, uint8_t* table,
+                                  uint64_t tile, uint64_t prep, zkwg_tile_fn consumer, void* user) {
+  if (!c || !packed || !status) return ZKWG_RC_BAD_ARG;
+  if (c->device < 0) return ZKWG_RC_NO_DEVICE;
+  if (n == 0) return ZKWG_RC_OK;
+  ZkDeviceGuard dg(c->device);
+  if (!dg.ok) return ZKWG_RC_HIP_ERROR;
+  u8* d_rows = nullptr;
+  if (table && hipMalloc((void**)&d_rows, n * 96) != hipSuccess) return ZKWG_RC_OOM;
+  int rc = calculate_batch_resident_impl(c, packed, n, status, tile, prep, d_rows, consumer, user);
+  if (rc == ZKWG_RC_OK && table) {
+    std::vector<u8> rows(n * 96);
+    if (hipMemcpy(rows.data(), d_rows, n * 96, hipMemcpyDeviceToHost) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
+    else for (u64 i = 0; i < n; ++i) { memcpy(table + 100 * i, status + i, 4); memcpy(table + 100 * i + 4, rows.data() + 96 * i, 96); }
+  }
+  hipFree(d_rows);
+  return rc;
+}
+// candidate tiles the ring was chosen from (average milliseconds of one tile's expansion into each; kept[2] = the chosen)
+int zkwg_resident_placement(const zkwg_circuit_t* c, float* ms, int cap, int kept[2]) {
+  if (!c) return 0;
+  for (int i = 0; i < c->rp_place_n && i < cap; ++i) if (ms) ms[i] = c->rp_place_ms[i];
+  if (kept) { kept[0] = c->rp_place_kept[0]; kept[1] = c->rp_place_kept[1]; }
+  return c->rp_place_n;
+}
+
 int zkwg_generate_inputs_device(zkwg_circuit_t* c, const zkwg_dkim_batch* b, uint64_t n, void* d_records,
                                 void* d_gen_status, void* hip_stream) {
   if (!c || !b || !d_records || !d_gen_status) return ZKWG_RC_BAD_ARG;
@@ -1623,9 +1786,11 @@ int zkwg_calculate_batch_multi(zkwg_multi_t* m, const uint8_t* packed, uint64_t 
     if (cnt[i] == 0) return;
     if (hipSetDevice(m->dev[i]) != hipSuccess) { rcs[i] = ZKWG_RC_HIP_ERROR; return; }
     if (table && hipMalloc((void**)&d_rows[i], cnt[i] * 96) != hipSuccess) { rcs[i] = ZKWG_RC_OOM; return; }
-    rcs[i] = calculate_batch_impl(m->h[i], packed + first[i] * in_stride, cnt[i],
-                                  out_wtns ? out_wtns + first[i] * out_stride : nullptr, out_stride, status + first[i],
-                                  max_tile, d_rows[i]);
+    // out_wtns = NULL: nothing but the result table leaves the GPUs -- the device-resident two-stream pipeline (witnesses into
+    // each GPU's own placed ring); otherwise each shard's witnesses leave through that GPU's PCIe link
+    if (!out_wtns) rcs[i] = calculate_batch_resident_impl(m->h[i], packed + first[i] * in_stride, cnt[i], status + first[i], max_tile, 0, d_rows[i], nullptr, nullptr);
+    else rcs[i] = calculate_batch_impl(m->h[i], packed + first[i] * in_stride, cnt[i], out_wtns + first[i] * out_stride, out_stride, status + first[i],
+                                       max_tile, d_rows[i]);
     if (rcs[i] != ZKWG_RC_OK || !table) return;
     // device-side table rows of this shard: {status i32, 96 bytes}
     if (hipMalloc((void**)&d_tab[i], cnt[i] * 100) != hipSuccess || hipMalloc((void**)&d_st[i], cnt[i] * 4) != hipSuccess) { rcs[i] = ZKWG_RC_OOM; return; }

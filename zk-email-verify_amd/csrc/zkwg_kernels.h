@@ -14,7 +14,9 @@ __global__ void zk_poseidon9_g16(ZkSched s, ZkBufs B);
 __global__ void zk_misc_ev(ZkSched s, ZkBufs B);     // zkwg_kernels_misc.hip
 __global__ void zk_net_eval(ZkSched s, ZkBufs B);    // zkwg_kernels_net.hip
 __global__ void zk_rslb_chunks(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip
-__global__ void zk_rslb_chain(ZkSched s, ZkBufs B);
+#define ZK_RS_MERGE_LANES 4u   // lanes per email of zk_rslb_merge (3 state elements + 1 converter)
+__global__ void zk_rslb_merge(ZkSched s, ZkBufs B);
+__global__ void zk_rslb_scan(ZkSched s, ZkBufs B);
 __global__ void zk_r1cs_check(const u64* row_ptr, const u32* wire, const Fr* coef, const u8* kind, u32 m,
                               const u8* wit, u64 stride, unsigned long long* first_bad);  // zkwg_kernels_r1cs.hip
 __global__ void zk_r1cs_eval(const u64* row_ptr, const u32* wire, const Fr* coef, const u8* kind, u32 m, const u8* wit, u64 stride,

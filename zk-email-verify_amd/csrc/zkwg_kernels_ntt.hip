@@ -1,0 +1,199 @@
+// Batched BN254-Fr number-theoretic transforms for the step that follows A.w | B.w | C.w in `snarkjs.groth16.prove`
+// (reference call site: packages/helpers/src/chunked-zkey.ts:80-84; SURVEY.md 8f4 "hand-off into the prover"): per proof
+// three inverse transforms, the coset shift, three forward transforms and a(x) b(x) - c(x) on a domain of 2^20 .. 2^22
+// points -- 6 x 2^L x L / 2 butterflies of one Montgomery product each.  Unlike everything else on the path this is
+// ARITHMETIC-bound: ~70 M products per EmailVerifier(576,192) proof against ~0.8 GB of HBM traffic; the roofline is the
+// issue rate of v_mad_u64_u32 (a Montgomery product = 128 of them: ~77 G products/s per MI355X), not HBM.  No MFMA: the
+// products are 254-bit modular integers.
+//
+// Structure (all values in Montgomery form, in place in a work buffer of n = 2^L elements per polynomial):
+//   * decimation in frequency (natural order in, bit-reversed out) for the inverse transforms, decimation in time
+//     (bit-reversed in, natural out) for the forward ones: no permutation pass between them, and the coset scaling
+//     inc^i / n is a table indexed by bit-reversed position, fused into the last inverse pass;
+//   * each transform is a few passes over HBM ("four-step" recursion): COLUMN passes run 2^g-point sub-transforms (g <= 8)
+//     on 4 neighbouring columns of a block at a time in LDS, followed (DIF) or preceded (DIT) by the block twiddle
+//     w_N^(column * frequency); the last / first pass transforms contiguous 2^10-element rows in LDS;
+//   * one workgroup = 1,024 elements = 32 KiB of LDS + its twiddles: 3 workgroups per CU, 2-3 wavefronts per SIMD so that
+//     the dependent multiply-add chains of one wavefront hide behind another's.
+#include "zkwg_kernels.h"
+
+#define ZK_NTT_C 4u   // columns per workgroup of a column pass (128 contiguous bytes per row access)
+
+__device__ __forceinline__ u32 zk_bitrev(u32 x, u32 bits) { return bits ? (__brev(x) >> (32u - bits)) : 0u; }
+// w^e for the transform's direction: tw[k] = w^k, k < n; the inverse direction reads w^(n - e)
+__device__ __forceinline__ Fr zk_ntt_tw(const Fr* __restrict__ tw, u64 n, u64 e, bool inv) {
+  e &= n - 1u;
+  return tw[inv ? ((n - e) & (n - 1u)) : e];
+}
+
+// One column pass.  Block size N = 2^lb (the sub-problem of this recursion level), sub-transform size G = 2^g over the rows
+// r of a column: element index = block * N + r * (N >> g) + c.  DIF: sub-transform, then y *= w_N^(c * bitrev_g(r)).
+// DIT: y *= w_N^(c * bitrev_g(r)) first, then the sub-transform.  `src` may differ from `dst` (first inverse pass: reads
+// A.w | B.w | C.w, `valid` elements per polynomial, zero beyond) -- polynomial q = blockIdx.y: src + (q / 3) * src_es + (q % 3) * src_ps.
+template <bool DIT>
+__global__ __launch_bounds__(256) void zk_ntt_col(const Fr* __restrict__ src, u64 src_es, u64 src_ps, u64 valid, Fr* __restrict__ dst,
+                                                   const Fr* __restrict__ tw, u32 L, u32 lb, u32 g, u32 inv) {
+  extern __shared__ Fr lds[];
+  const u64 n = 1ull << L;
+  const u32 G = 1u << g, C = ZK_NTT_C;
+  Fr* y = lds;                 // [G][C]
+  Fr* twl = lds + G * C;       // w_G^k, k < G / 2 (direction applied)
+  const u32 cols_per_block = 1u << (lb - g);
+  const u64 cid0 = (u64)blockIdx.x * C;
+  const u64 block = cid0 >> (lb - g);
+  const u32 c0 = (u32)(cid0 & (cols_per_block - 1u));
+  const u64 q = blockIdx.y;
+  const Fr* s = src + (q / 3u) * src_es + (q % 3u) * src_ps;
+  Fr* d = dst + q * n;
+  const u64 base = block << lb;
+  const bool invb = inv != 0;
+  for (u32 k = threadIdx.x; k < G / 2u; k += 256u) twl[k] = zk_ntt_tw(tw, n, (u64)k << (L - g), invb);
+  for (u32 t = threadIdx.x; t < G * C; t += 256u) {
+    const u32 r = t / C, cc = t % C;
+    const u64 idx = base + ((u64)r << (lb - g)) + c0 + cc;
+    Fr v = idx < valid ? s[idx] : fr_zero();
+    if (DIT) v = fr_mont_mul(v, zk_ntt_tw(tw, n, ((u64)(c0 + cc) * zk_bitrev(r, g)) << (L - lb), invb));
+    y[t] = v;
+  }
+  __syncthreads();
+  for (u32 st = 0; st < g; ++st) {
+    const u32 half = DIT ? (1u << st) : (G >> (st + 1u));
+    for (u32 b = threadIdx.x; b < (G / 2u) * C; b += 256u) {
+      const u32 cc = b % C, pi = b / C;
+      const u32 i = (pi / half) * 2u * half + (pi % half), j = i + half;
+      const u32 k = DIT ? (pi % half) * (G / (2u * half)) : ((pi % half) << st);
+      const Fr a = y[i * C + cc], bb = y[j * C + cc];
+      if (DIT) {
+        const Fr tt = fr_mont_mul(bb, twl[k]);
+        y[i * C + cc] = fr_add(a, tt);
+        y[j * C + cc] = fr_sub(a, tt);
+      } else {
+        y[i * C + cc] = fr_add(a, bb);
+        y[j * C + cc] = fr_mont_mul(fr_sub(a, bb), twl[k]);
+      }
+    }
+    __syncthreads();
+  }
+  for (u32 t = threadIdx.x; t < G * C; t += 256u) {
+    const u32 r = t / C, cc = t % C;
+    const u64 idx = base + ((u64)r << (lb - g)) + c0 + cc;
+    Fr v = y[t];
+    if (!DIT) v = fr_mont_mul(v, zk_ntt_tw(tw, n, ((u64)(c0 + cc) * zk_bitrev(r, g)) << (L - lb), invb));
+    d[idx] = v;
+  }
+}
+
+// The row pass: contiguous blocks of G = 2^g elements (g <= 10), 1,024 elements per workgroup.  DIF (inverse direction of the
+// pipeline): optional multiplication by scale[position] on the way out (coset shift and 1 / n).  `src` / `valid` as above.
+template <bool DIT>
+__global__ __launch_bounds__(256) void zk_ntt_row(const Fr* __restrict__ src, u64 src_es, u64 src_ps, u64 valid, Fr* __restrict__ dst,
+                                                   const Fr* __restrict__ tw, const Fr* __restrict__ scale, Fr uni, u32 use_uni, u32 L, u32 g, u32 inv) {
+  extern __shared__ Fr lds[];
+  const u64 n = 1ull << L;
+  const u32 G = 1u << g;
+  const u32 TILE = n < 1024u ? (u32)n : 1024u;
+  Fr* y = lds;                 // [TILE]
+  Fr* twl = lds + TILE;        // w_G^k, k < G / 2
+  const u64 q = blockIdx.y;
+  const Fr* s = src + (q / 3u) * src_es + (q % 3u) * src_ps;
+  Fr* d = dst + q * n;
+  const u64 base = (u64)blockIdx.x * TILE;
+  const bool invb = inv != 0;
+  for (u32 k = threadIdx.x; k < G / 2u; k += 256u) twl[k] = zk_ntt_tw(tw, n, (u64)k << (L - g), invb);
+  for (u32 t = threadIdx.x; t < TILE; t += 256u) y[t] = base + t < valid ? s[base + t] : fr_zero();
+  __syncthreads();
+  for (u32 st = 0; st < g; ++st) {
+    const u32 half = DIT ? (1u << st) : (G >> (st + 1u));
+    for (u32 pi = threadIdx.x; pi < TILE / 2u; pi += 256u) {
+      const u32 i = (pi / half) * 2u * half + (pi % half), j = i + half;
+      const u32 k = DIT ? (pi % half) * (G / (2u * half)) : ((pi % half) << st);
+      const Fr a = y[i], bb = y[j];
+      if (DIT) {
+        const Fr tt = fr_mont_mul(bb, twl[k]);
+        y[i] = fr_add(a, tt);
+        y[j] = fr_sub(a, tt);
+      } else {
+        y[i] = fr_add(a, bb);
+        y[j] = fr_mont_mul(fr_sub(a, bb), twl[k]);
+      }
+    }
+    __syncthreads();
+  }
+  for (u32 t = threadIdx.x; t < TILE; t += 256u) {
+    Fr v = y[t];
+    if (scale) v = fr_mont_mul(v, scale[base + t]);
+    else if (use_uni) v = fr_mont_mul(v, uni);     // (stand-alone inverse transform: 1 / n)
+    d[base + t] = v;
+  }
+}
+
+// out[k] = a[k] b[k] - c[k]  (joinABC of groth16_prove.js), polynomials of email e at work + (3 e + {0, 1, 2}) n
+__global__ __launch_bounds__(256) void zk_ntt_join(const Fr* __restrict__ work, Fr* __restrict__ out, u64 n, u64 out_es) {
+  const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const u64 e = blockIdx.y;
+  const Fr* w = work + 3u * e * n;
+  out[e * out_es + i] = fr_sub(fr_mont_mul(w[i], w[n + i]), w[2u * n + i]);
+}
+// in-place bit-reversal permutation of n_polys arrays of 2^L elements (stand-alone transforms only: the pipeline needs none)
+__global__ __launch_bounds__(256) void zk_ntt_bitrev(Fr* __restrict__ data, u32 L) {
+  const u64 n = 1ull << L;
+  const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const u64 j = (u64)zk_bitrev((u32)i, L);
+  if (i < j) {
+    Fr* p = data + (u64)blockIdx.y * n;
+    const Fr a = p[i], b = p[j];
+    p[i] = b; p[j] = a;
+  }
+}
+
+// ---- launch helpers (called from zkwg_ntt_api.hip) ---------------------------------------------------------------
+// passes of one transform: column passes (block size 2^lb, 2^g-point sub-transforms), then the row pass (DIF), or the
+// reverse (DIT)
+extern "C" int zk_ntt_launch(int dit, const Fr* src, u64 src_es, u64 src_ps, u64 valid, Fr* work, const Fr* tw, const Fr* scale, const Fr* uni_host,
+                             u32 L, u32 n_polys, u32 inv, hipStream_t st) {
+  const Fr uni = uni_host ? *uni_host : fr_zero();
+  const u32 use_uni = uni_host ? 1u : 0u;
+  const u32 g_row = L < 10u ? L : 10u;
+  u32 gs[8], ng = 0;
+  {
+    const u32 R = L - g_row;
+    const u32 np = (R + 7u) / 8u;
+    for (u32 i = 0; i < np; ++i) gs[ng++] = R / np + (i < R % np ? 1u : 0u);
+  }
+  const u64 n = 1ull << L;
+  const u32 tile = n < 1024u ? (u32)n : 1024u;
+  const size_t row_lds = (tile + (1u << g_row) / 2u) * sizeof(Fr);
+  const dim3 rgrid((u32)(n / tile), n_polys);
+  if (!dit) {
+    const Fr* s = src; u64 es = src_es, ps = src_ps, v = valid;
+    u32 lb = L;
+    for (u32 i = 0; i < ng; ++i) {
+      const u32 g = gs[i];
+      const size_t lds = ((1u << g) * ZK_NTT_C + (1u << g) / 2u) * sizeof(Fr);
+      hipLaunchKernelGGL((zk_ntt_col<false>), dim3((u32)(n >> g) / ZK_NTT_C, n_polys), dim3(256), lds, st, s, es, ps, v, work, tw, L, lb, g, inv);
+      s = work; es = 3u * n; ps = n; v = n;
+      lb -= g;
+    }
+    hipLaunchKernelGGL((zk_ntt_row<false>), rgrid, dim3(256), row_lds, st, s, es, ps, v, work, tw, scale, uni, use_uni, L, g_row, inv);
+  } else {
+    hipLaunchKernelGGL((zk_ntt_row<true>), rgrid, dim3(256), row_lds, st, src, src_es, src_ps, valid, work, tw, (const Fr*)nullptr, uni, 0u, L, g_row, inv);
+    u32 lb = g_row;
+    for (u32 i = ng; i-- > 0;) {
+      const u32 g = gs[i];
+      lb += g;
+      const size_t lds = ((1u << g) * ZK_NTT_C + (1u << g) / 2u) * sizeof(Fr);
+      hipLaunchKernelGGL((zk_ntt_col<true>), dim3((u32)(n >> g) / ZK_NTT_C, n_polys), dim3(256), lds, st, (const Fr*)work, 3u * n, n, n, work, tw, L, lb, g, inv);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int zk_ntt_join_launch(const Fr* work, Fr* out, u64 n, u64 out_es, u32 n_emails, hipStream_t st) {
+  hipLaunchKernelGGL(zk_ntt_join, dim3((u32)((n + 255u) / 256u), n_emails), dim3(256), 0, st, work, out, n, out_es);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int zk_ntt_bitrev_launch(Fr* data, u32 L, u32 n_polys, hipStream_t st) {
+  hipLaunchKernelGGL(zk_ntt_bitrev, dim3((u32)(((1ull << L) + 255u) / 256u), n_polys), dim3(256), 0, st, data, L);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

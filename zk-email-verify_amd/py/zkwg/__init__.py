@@ -324,6 +324,25 @@ class Circuit:
         _check(self.lib.zkwg_expand_full_host(self.h, records, n, scratch_host, first, count, C.c_void_p(addr + off), self.witness_bytes))
         return bytes(memoryview(out)[off:off + count * self.witness_bytes])
 
+    def calculate_batch_resident(self, records, tile=0, prep=0, consumer=None, want_table=True):
+        """zkwg_calculate_batch_resident: the device-resident two-stream pipeline below the boundary.  `consumer(device, d_tile,
+        witness_stride, first_email, count, hip_stream)` (optional) is called once per expanded tile.  -> (status list, table
+        bytes (n x 100) or None)"""
+        n = len(records) // self.in_stride
+        status = (C.c_int32 * n)()
+        table = (C.c_uint8 * (100 * n))() if want_table else None
+        cb_t = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p)
+        cb = cb_t((lambda user, dev, tile_p, stride, first, count, stream: consumer(dev, tile_p, stride, first, count, stream))) if consumer else None
+        _check(self.lib.zkwg_calculate_batch_resident(self.h, records, n, status, table, tile, prep,
+                                                       C.cast(cb, C.c_void_p) if cb else None, None))
+        return list(status), (bytes(table) if want_table else None)
+
+    def resident_placement(self):
+        ms = (C.c_float * 8)()
+        kept = (C.c_int * 2)()
+        k = self.lib.zkwg_resident_placement(self.h, ms, 8, kept)
+        return {"ms_per_tile": [round(ms[i], 3) for i in range(k)], "kept": list(kept)}
+
     def scratch_bytes(self, n):
         return self.lib.zkwg_scratch_bytes(self.h, n)
 
@@ -441,6 +460,39 @@ class Circuit:
                 if got != want:
                     raise AssertionError(f"{prefix}: expected {want}, the witness has {got}")
         check("main", expected)
+
+
+def _stream_ptr(stream):
+    return stream.cuda_stream if stream is not None else 0
+
+
+class Ntt:
+    """Plan of the transform stage that follows A.w | B.w | C.w in groth16.prove (include/zkwg.h "prover stage 2"):
+    domain of 2^log2_n points, everything in Montgomery form on the device."""
+
+    def __init__(self, log2_n, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _check(self.lib.zkwg_ntt_create(device, log2_n, C.byref(h)))
+        self.h = h
+        self.log2_n, self.n, self.device = log2_n, 1 << log2_n, device
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.zkwg_ntt_destroy(self.h)
+            self.h = None
+
+    def work_bytes(self, n_emails):
+        return self.lib.zkwg_ntt_work_bytes(self.h, n_emails)
+
+    def transform_device(self, d_data, n_polys, inverse=False, stream=None):
+        """in place: n_polys arrays of 2^log2_n Montgomery-form elements, natural order in and out (Fr.fft / Fr.ifft)"""
+        _check(self.lib.zkwg_ntt_transform_device(self.h, d_data.data_ptr(), n_polys, 1 if inverse else 0, _stream_ptr(stream)))
+
+    def h_evaluations_device(self, d_abc, abc_stride, n_constraints, n_emails, d_work, d_out, out_stride=None, stream=None):
+        """a(x) b(x) - c(x) on the odd coset for n_emails records of A.w | B.w | C.w (Montgomery form) -> d_out"""
+        _check(self.lib.zkwg_h_evaluations_device(self.h, d_abc.data_ptr(), abc_stride, n_constraints, n_emails, d_work.data_ptr(),
+                                                  d_out.data_ptr(), out_stride if out_stride else 32 * self.n, _stream_ptr(stream)))
 
 
 class MultiCircuit:

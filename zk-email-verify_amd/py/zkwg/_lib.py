@@ -128,6 +128,14 @@ def load():
         "zkwg_multi_devices": (i32, [vp]),
         "zkwg_multi_circuit": (vp, [vp, i32]),
         "zkwg_calculate_batch_multi": (i32, [vp, vp, u64, vp, u64, vp, vp, u64]),
+        "zkwg_ntt_create": (i32, [i32, C.c_uint32, C.POINTER(vp)]),
+        "zkwg_ntt_destroy": (None, [vp]),
+        "zkwg_ntt_domain": (u64, [vp]),
+        "zkwg_ntt_work_bytes": (u64, [vp, u64]),
+        "zkwg_ntt_transform_device": (i32, [vp, vp, u64, i32, vp]),
+        "zkwg_h_evaluations_device": (i32, [vp, vp, u64, u64, u64, vp, vp, u64, vp]),
+        "zkwg_calculate_batch_resident": (i32, [vp, vp, u64, vp, vp, u64, u64, vp, vp]),
+        "zkwg_resident_placement": (i32, [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
@@ -145,5 +153,6 @@ EXPORTS = [
     "zkwg_kernel_name", "zkwg_kernel_slots", "zkwg_wtns_size", "zkwg_write_wtns", "zkwg_write_sym",
     "zkwg_r1cs_load", "zkwg_r1cs_destroy", "zkwg_r1cs_info", "zkwg_check_constraints_device", "zkwg_r1cs_evaluate_device", "zkwg_check_constraints",
     "zkwg_convert_montgomery_device", "zkwg_shard_range", "zkwg_multi_create", "zkwg_multi_destroy", "zkwg_multi_devices",
-    "zkwg_multi_circuit", "zkwg_calculate_batch_multi",
+    "zkwg_multi_circuit", "zkwg_calculate_batch_multi", "zkwg_calculate_batch_resident", "zkwg_resident_placement",
+    "zkwg_ntt_create", "zkwg_ntt_destroy", "zkwg_ntt_domain", "zkwg_ntt_work_bytes", "zkwg_ntt_transform_device", "zkwg_h_evaluations_device",
 ]
