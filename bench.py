@@ -630,6 +630,32 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         torch.cuda.empty_cache()
     except Exception as e:
         out["prover stage 1 from the image, EmailVerifier(576,192)"] = {"error": repr(e)[:300]}
+    # prover stage 2 (SURVEY.md 8f4 "next"): the transforms groth16.prove runs on A.w | B.w | C.w -- 3 inverse + 3 forward
+    # NTTs on the 2^20 domain and a b - c per email (zkwg_h_evaluations_device); ARITHMETIC-bound, so its roofline is the
+    # issue rate of the 32 x 32 + 64 multiply-add a Montgomery product is made of, not HBM
+    try:
+        L, m, E = 20, 753807, 16
+        plan = zkwg.Ntt(L, device=local_rank)
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        d_abc = torch.randint(0, 1 << 62, (E, 12 * m), dtype=torch.int64, device=dev, generator=g)
+        d_abc[:, 3::4] >>= 4
+        d_work = torch.empty(plan.work_bytes(E), dtype=torch.uint8, device=dev)
+        d_out = torch.empty(E * 32 * (1 << L), dtype=torch.uint8, device=dev)
+        run = lambda: plan.h_evaluations_device(d_abc.view(torch.uint8), 96 * m, m, E, d_work, d_out)
+        sec = timed(torch, run, steps=3, warmup=1) / 3
+        n = 1 << L
+        products = 6 * (n * L // 2 + 2 * n) + 4 * n
+        peak = 256 * 4 * 4 * 2.4e9 / 128
+        out["prover stage 2: H evaluations (3 ifft + coset shift + 3 fft + a b - c), 2^20 domain"] = {
+            "value": round(E / sec, 1), "unit": "emails/s", "montgomery_products_per_email": products,
+            "products_per_s": round(E * products / sec), "issue_roofline_products_per_s": round(peak),
+            "frac_of_issue_roofline": round(E * products / sec / peak, 4), "emails_per_call": E,
+            "note": "roofline = v_mad_u64_u32 issue: 128 per Montgomery product, 4 lanes per cycle and SIMD, 1,024 SIMDs at 2.4 GHz"}
+        del d_abc, d_work, d_out, plan
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["prover stage 2: H evaluations"] = {"error": repr(e)[:200]}
     # complete witnesses of the circuit compiled the way the reference documents (`circom --O0`,
     # docs/zk-email-docs/UsageGuide/README.md:59-64): every alias / constant / linear signal numbered, written in ONE pass
     # from the image (zkwg_circuit_create_full; artefacts = interpreter-generated .sym / .r1cs under artifacts/)

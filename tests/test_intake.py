@@ -1,4 +1,4 @@
-"""tests/intake.py (the one-command intake for real circom / snarkjs artefacts) on the artefacts this repo can make
+"""tools/intake.py (the one-command intake for real circom / snarkjs artefacts) on the artefacts this repo can make
 offline: the interpreter-generated `--O0` files of the RSA main (tests/golden/o0_rsa.*) and of EmailVerifier(576,192)
 (artifacts/, built where /root/reference exists).  A `.wtns` written from the interpreter's values stands in for the
 snarkjs file; a corrupted copy must be reported at the right signal."""
@@ -9,7 +9,11 @@ import struct
 
 import pytest
 
+import sys
+
 from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))      # the intake tool is a user tool (tools/intake.py), imported here as a module
 
 REF = os.path.isdir("/root/reference/packages/circuits")
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -67,7 +71,7 @@ def test_intake_on_the_rsa_artefacts_without_a_gpu(tmp_path):
 @pytest.mark.gpu
 def test_intake_full_flow_on_the_gpu_from_a_saved_interpreter_run(tmp_path):
     """Steps 2-5 on a box without /root/reference: the interpreter's run of the RSA main comes from
-    tests/golden/intake_rsa_interpreter.npz (made here by `tests/intake.py ... --dump-interpreter`); the product handle is
+    tests/golden/intake_rsa_interpreter.npz (made here by `tools/intake.py ... --dump-interpreter`); the product handle is
     built from the `.sym` + `.r1cs`, its DEVICE witness is compared with the interpreter's and with a `.wtns`, and
     checkConstraints runs on the device."""
     import intake

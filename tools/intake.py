@@ -7,7 +7,7 @@ and a snarkjs `.wtns` for one `input.json` (the reference's compile line: docs/z
 `snarkjs wtns calculate`: :132-140; `loadSymbols`: packages/circuits/tests/email-verifier.test.ts:204-206).  The day they
 exist:
 
-    python tests/intake.py --node-modules NM --build-dir BUILD --input input.json [--wtns witness.wtns]
+    python tools/intake.py --node-modules NM --build-dir BUILD --input input.json [--wtns witness.wtns]
                            [--max-header 1024 --max-body 1536] [--main-kind ev|rsa] [--device 0|-1]
 
 does, in order, and reports the FIRST difference of every comparison by signal name:
