@@ -85,6 +85,35 @@ def main():
         for k, bit in KERNELS.items():
             run("only " + k, bit)
         run("no prepare kernels", 0)
+    if "cumask" in modes:
+        # the prepare kernels confined to a few compute units (CU-masked streams, zkwg_stream_create_masked), zk_expand on the
+        # others -- on the SAME ring as the rows above (round 3's verdict on this knob, "not robust", was taken across allocations)
+        import ctypes
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (ncu + 31) // 32
+        keep_p, keep_e = pl.s_preps, pl.s_exp
+
+        def mask(keep):
+            m = [0] * words
+            for i in range(ncu):
+                if keep(i):
+                    m[i // 32] |= 1 << (i % 32)
+            return (ctypes.c_uint32 * words)(*m), words
+        for n_cu, stride, share in ((32, 8, False), (64, 4, False), (32, 1, False), (16, 8, False), (32, 8, True), (64, 4, True)):
+            sel = set(i * stride for i in range(n_cu) if i * stride < ncu)
+            mp, w = mask(lambda i: i in sel)
+            me, _ = mask(lambda i: share or i not in sel)        # share: zk_expand may use every CU, only the prepare side is confined
+            sp = c.lib.zkwg_stream_create_masked(0, mp, w)
+            se = c.lib.zkwg_stream_create_masked(0, me, w)
+            assert sp and se
+            pl.s_preps = [torch.cuda.ExternalStream(sp, device=dev)]
+            pl.s_exp = torch.cuda.ExternalStream(se, device=dev)
+            torch.cuda.synchronize()
+            run(f"prepare on {n_cu} CUs (every {stride}th), zk_expand on {'all' if share else 'the others'}", 0xFFFFFFFF)
+            torch.cuda.synchronize()
+            pl.s_preps, pl.s_exp = keep_p, keep_e
+            c.lib.zkwg_stream_destroy(sp)
+            c.lib.zkwg_stream_destroy(se)
     if "all" in modes:
         run("all (again)", 0xFFFFFFFF)
     if args.out:

@@ -66,7 +66,7 @@ struct zkwg_circuit {
   int host_expand_threads;       // > 0: zkwg_calculate_batch expands on the host (zkwg_set_host_expand)
   u8* hx_img[2]; u64 hx_bytes;   // pinned staging of downloaded images (host expansion)
   int o0_emails_per_wg;          // emails per workgroup of zk_expand3_o0 (ZKWG_O0_EMAILS_PER_WG, default 16)
-  int o0_pipe;                   // 1: the software-pipelined variant of zk_expand3_o0 (ZKWG_O0_PIPE, default 1)
+  int o0_pipe;                   // zk_expand3_o0 variant (ZKWG_O0_PIPE): 0 plain, 1 one email ahead, 2 (default) batches of 4 emails + short paths for uniform pieces, 3 double-buffered batches
   int x3_k, x3_k_o0;       // slots per thread of zk_expand3 (kept-v1 / sym layouts) and zk_expand3_o0: 1, 2 or 4 (ZKWG_X3_K, ZKWG_X3_K_O0)
   std::vector<ZkSeg> segs;
   hipStream_t own_stream, copy_stream;
@@ -256,7 +256,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   c->x3_k = pick_k("ZKWG_X3_K", 4, true);
   c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 1);   // (round 4: 8 KiB pieces, 53 VGPRs = 8 wavefronts per SIMD, software-pipelined over the group's emails)
   c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 16;
-  c->o0_pipe = getenv("ZKWG_O0_PIPE") ? atoi(getenv("ZKWG_O0_PIPE")) : 1;
+  c->o0_pipe = getenv("ZKWG_O0_PIPE") ? atoi(getenv("ZKWG_O0_PIPE")) : 2;
   c->xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
   c->rsa_wgs_per_cu = 0;
   if (const char* v = getenv("ZKWG_RSA_WGS_PER_CU")) c->rsa_wgs_per_cu = atoi(v);
@@ -1017,7 +1017,9 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
       const dim3 g3((u32)units), b3(256);
 #define ZK_LAUNCH_O0(K) do { if (c->o0_pipe) { if (mont) hipLaunchKernelGGL(zk_expand3_o0p_mont_k##K, g3, b3, 0, st, A, O); else hipLaunchKernelGGL(zk_expand3_o0p_k##K, g3, b3, 0, st, A, O); } \
                              else { if (mont) hipLaunchKernelGGL(zk_expand3_o0_mont_k##K, g3, b3, 0, st, A, O); else hipLaunchKernelGGL(zk_expand3_o0_k##K, g3, b3, 0, st, A, O); } } while (0)
-      if (c->x3_k_o0 == 1) ZK_LAUNCH_O0(1); else if (c->x3_k_o0 == 2) ZK_LAUNCH_O0(2); else ZK_LAUNCH_O0(4);
+      if (c->x3_k_o0 == 1 && c->o0_pipe == 2) { if (mont) hipLaunchKernelGGL(zk_expand3_o0b_mont_k1, g3, b3, 0, st, A, O); else hipLaunchKernelGGL(zk_expand3_o0b_k1, g3, b3, 0, st, A, O); }
+      else if (c->x3_k_o0 == 1 && c->o0_pipe == 3) { if (mont) hipLaunchKernelGGL(zk_expand3_o0c_mont_k1, g3, b3, 0, st, A, O); else hipLaunchKernelGGL(zk_expand3_o0c_k1, g3, b3, 0, st, A, O); }
+      else if (c->x3_k_o0 == 1) ZK_LAUNCH_O0(1); else if (c->x3_k_o0 == 2) ZK_LAUNCH_O0(2); else ZK_LAUNCH_O0(4);
 #undef ZK_LAUNCH_O0
       continue;
     }

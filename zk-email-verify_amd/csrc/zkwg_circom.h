@@ -1452,6 +1452,25 @@ struct Elab {
       plain_of[sig[g]] = plain;
       return words_of.emplace(sig[g], std::move(w)).first->second;
     };
+    // The signature is a 64-bit structural hash, not a proof of equality: every local gate that shares a table with an earlier
+    // one is checked against that table on a few byte values (its own cone evaluated), and a template on which two different
+    // functions collide is refused rather than given a wrong witness.
+    {
+      std::map<u64, u32> first_of;
+      static const u32 probes[6] = {0u, 10u, 59u, 61u, 97u, 255u};
+      for (u32 g = 0; g < n; ++g) {
+        if (!local[g]) continue;
+        auto it = first_of.find(sig[g]);
+        if (it == first_of.end()) { first_of.emplace(sig[g], g); continue; }
+        const std::vector<u32>& w = table(it->second);
+        for (u32 v : probes) {
+          ++now;
+          u32 word = 0;
+          eval(g, (long long)((v + 7u * g) & 255u), word);
+          if (word != w[(v + 7u * g) & 255u]) fail("two different byte-local functions of the regex template share a structural signature (hash collision)");
+        }
+      }
+    }
     // needed gates: everything that is not local; then what they read
     std::vector<u32> work;
     for (u32 g = 0; g < n; ++g) if (!local[g]) { need[g] = 1; work.push_back(g); }
@@ -1589,6 +1608,8 @@ struct Elab {
     net.n_pins = hwm;
     net.lds_masks = lds_dummy + 1;
     net.lds_words = net.lds_masks + n_in * net.mask_words;
+    if (4ull * net.lds_words * (64u / net.lanes) + 16u > 150u * 1024u)
+      fail("the evaluator's LDS image (" + std::to_string(net.lds_words) + " words per email, " + std::to_string(64u / net.lanes) + " emails per wavefront) would exceed the 160 KB of a gfx950 CU: set ZKWG_NET_LANES=64");
     if (net.lds_words > 16000) fail("the template keeps " + std::to_string(hwm) + " values alive at once; the evaluator's LDS image would exceed 64 KiB");
     // records
     net.records.clear(); net.step_count.clear();

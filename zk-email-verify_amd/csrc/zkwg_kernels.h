@@ -29,6 +29,8 @@ __global__ void zk_r1cs_eval(const u64* row_ptr, const u32* wire, const Fr* coef
 ZK_X3_DECL(1) ZK_X3_DECL(2) ZK_X3_DECL(4)
 __global__ void zk_expand3_k8(ZkX3 A); __global__ void zk_expand3_mont_k8(ZkX3 A);
 __global__ void zk_image_to_mont(ZkX3 A);
+__global__ void zk_expand3_o0b_k1(ZkX3 A, ZkO0Dev O); __global__ void zk_expand3_o0b_mont_k1(ZkX3 A, ZkO0Dev O);
+__global__ void zk_expand3_o0c_k1(ZkX3 A, ZkO0Dev O); __global__ void zk_expand3_o0c_mont_k1(ZkX3 A, ZkO0Dev O);
 __global__ void zk_o0_rows_small(ZkX3 A, ZkO0Dev O);
 __global__ void zk_o0_chains_small(ZkX3 A, ZkO0Dev O);
 __global__ void zk_o0_generic(ZkX3 A, ZkO0Dev O);

@@ -236,7 +236,8 @@ __device__ __forceinline__ u32 zk_o0_combine(uint2 d, const ZkO0Pre& p, u64 w64,
     default: return 0u;
   }
 }
-template <bool MONT, int K, bool PIPE>
+#define ZK_O0_BATCH 4
+template <bool MONT, int K, int PIPE>
 __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev& O) {
   constexpr u32 SLOTS = 256u * K;
   const u32 unit = zk_x3_unit(A.xcd_remap);
@@ -261,6 +262,97 @@ __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev&
   // turned into codes and stored (the stores may alias the image as far as the compiler knows, so it would not hoist the
   // loads itself), otherwise every email pays the load latency in front of its stores.
   const u32 el0 = g * O.emails_per_wg, el1 = min((g + 1u) * O.emails_per_wg, A.n_count);
+  if constexpr (PIPE >= 2) {
+    // The kernel is bound by VALU issue, not by HBM (per email and wavefront ~250 instructions: four loads, a switch over the
+    // descriptor kinds that executes every kind present in the wavefront, shuffles, the store-side switch): so pieces whose
+    // wires are all of one simple kind -- workgroup-uniform, decided once -- take a short path.  Constants (the C side of every
+    // bit constraint, aliases of the constant wire: a fifth of an A.w | B.w | C.w record) need no load at all; single bits and bit
+    // fields (the SHA regions: three quarters of an `--O0` witness) need one.
+    bool only_imm = true, only_bits = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const u32 kd = d[k].x >> 28;
+      const bool plain = aff[k] == 0x00010000u;
+      only_imm = only_imm && plain && kd == ZK_D_IMM;
+      only_bits = only_bits && plain && (kd == ZK_D_IMM || kd == ZK_D_BIT64 || kd == ZK_D_BITRUN);
+    }
+    const int cls = __syncthreads_and(only_imm ? 1 : 0) ? 0 : (__syncthreads_and(only_bits ? 1 : 0) ? 1 : 2);
+    if (cls == 0) {
+      u32 code[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) code[k] = d[k].y;
+      for (u32 el = el0; el < el1; ++el) {
+        const u32 e = el + A.e_first;
+        zk_x3_store<MONT, K>(A, zk_x3_ctx(A, e), e, el, slot0, nsl, code);
+      }
+      return;
+    }
+    if (cls == 1) {
+      constexpr int NB = ZK_O0_BATCH;
+      u32 sh[K], mk[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const u32 kd = d[k].x >> 28;
+        sh[k] = d[k].x & 63u;
+        mk[k] = kd == ZK_D_BIT64 ? 1u : (kd == ZK_D_BITRUN ? (2u << ((d[k].x >> 6) & 31u)) - 1u : 0u);   // 0: a constant (IMM)
+      }
+      for (u32 el = el0; el < el1; el += NB) {
+        u64 b64[NB][K];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const u64* bits = A.bits + (u64)(min(el + (u32)q, el1 - 1u) + A.e_first) * A.img_bits;
+#pragma unroll
+          for (int k = 0; k < K; ++k) b64[q][k] = bits[pre[k].i64];
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          if (el + (u32)q >= el1) break;
+          const u32 e = el + q + A.e_first;
+          u32 code[K];
+#pragma unroll
+          for (int k = 0; k < K; ++k) code[k] = mk[k] ? ((u32)(b64[q][k] >> sh[k]) & mk[k]) : d[k].y;
+          zk_x3_store<MONT, K>(A, zk_x3_ctx(A, e), e, el + q, slot0, nsl, code);
+        }
+      }
+      return;
+    }
+    // batches of ZK_O0_BATCH emails: the image words of the whole batch are requested back to back (4 x the loads in flight),
+    // then the batch is turned into codes and stored email by email; PIPE == 3 requests the next batch before storing this one
+    constexpr int NB = ZK_O0_BATCH;
+    u64 b64[NB][K], c64[NB][K]; u32 b8[NB][K], b32[NB][K], b32b[NB][K], c8[NB][K], c32[NB][K], c32b[NB][K];
+    auto fetch = [&](u32 first, u64 (&x64)[NB][K], u32 (&x8)[NB][K], u32 (&x32)[NB][K], u32 (&x32b)[NB][K]) {
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const ZkCtx cx = zk_x3_ctx(A, min(first + (u32)q, el1 - 1u) + A.e_first);
+#pragma unroll
+        for (int k = 0; k < K; ++k) { x64[q][k] = cx.bits[pre[k].i64]; x8[q][k] = cx.rec[pre[k].i8]; x32[q][k] = cx.small[pre[k].i32]; x32b[q][k] = cx.small[pre[k].i32b]; }
+      }
+    };
+    if (el0 < el1) fetch(el0, b64, b8, b32, b32b);
+    for (u32 el = el0; el < el1; el += NB) {
+      if constexpr (PIPE == 3) fetch(min(el + NB, el1 - 1u), c64, c8, c32, c32b);
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        if (el + (u32)q >= el1) break;
+        const u32 e = el + q + A.e_first;
+        const ZkCtx cx = zk_x3_ctx(A, e);
+        u32 code[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          code[k] = zk_o0_combine(d[k], pre[k], b64[q][k], b8[q][k], b32[q][k], b32b[q][k], cx.half);
+          if (aff[k] != 0x00010000u) code[k] = zk_aff_apply(aff[k], code[k], cx);
+        }
+        zk_x3_store<MONT, K>(A, cx, e, el + q, slot0, nsl, code);
+      }
+      if constexpr (PIPE == 3) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+          for (int k = 0; k < K; ++k) { b64[q][k] = c64[q][k]; b8[q][k] = c8[q][k]; b32[q][k] = c32[q][k]; b32b[q][k] = c32b[q][k]; }
+      } else if (el + NB < el1) fetch(el + NB, b64, b8, b32, b32b);
+    }
+    return;
+  }
   u64 w64[K], n64[K]; u32 w8[K], w32[K], w32b[K], n8[K], n32[K], n32b[K];
   if (el0 < el1) {
     const ZkCtx cx = zk_x3_ctx(A, el0 + A.e_first);
@@ -270,7 +362,7 @@ __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev&
   for (u32 el = el0; el < el1; ++el) {
     const u32 e = el + A.e_first;
     const ZkCtx cx = zk_x3_ctx(A, e);
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 1) {
       const ZkCtx nx = zk_x3_ctx(A, min(el + 1u, el1 - 1u) + A.e_first);
 #pragma unroll
       for (int k = 0; k < K; ++k) { n64[k] = nx.bits[pre[k].i64]; n8[k] = nx.rec[pre[k].i8]; n32[k] = nx.small[pre[k].i32]; n32b[k] = nx.small[pre[k].i32b]; }
@@ -282,7 +374,7 @@ __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev&
       if (aff[k] != 0x00010000u) code[k] = zk_aff_apply(aff[k], code[k], cx);
     }
     zk_x3_store<MONT, K>(A, cx, e, el, slot0, nsl, code);
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 1) {
 #pragma unroll
       for (int k = 0; k < K; ++k) { w64[k] = n64[k]; w8[k] = n8[k]; w32[k] = n32[k]; w32b[k] = n32b[k]; }
     } else if (el + 1u < el1) {
@@ -293,13 +385,18 @@ __device__ __forceinline__ void zk_expand3_o0_body(const ZkX3& A, const ZkO0Dev&
   }
 }
 #define ZK_X3_O0_KERNELS(K)                                                                                                                                     \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, K, false>(A, O); }      \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_mont_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, K, false>(A, O); } \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0p_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, K, true>(A, O); }      \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0p_mont_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, K, true>(A, O); }
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, K, 0>(A, O); }      \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0_mont_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, K, 0>(A, O); } \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0p_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, K, 1>(A, O); }      \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0p_mont_k##K(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, K, 1>(A, O); }
 ZK_X3_O0_KERNELS(1)
 ZK_X3_O0_KERNELS(2)
 ZK_X3_O0_KERNELS(4)
+// K = 1 in batches of 4 emails (PIPE 2: loads of a batch together; 3: and the next batch requested before this one is stored)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0b_k1(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, 1, 2>(A, O); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0b_mont_k1(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, 1, 2>(A, O); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0c_k1(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<false, 1, 3>(A, O); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void zk_expand3_o0c_mont_k1(ZkX3 A, ZkO0Dev O) { zk_expand3_o0_body<true, 1, 3>(A, O); }
 
 // wires whose value comes from their segment's own arithmetic (ItemAtIndex selectors, comparators, Base64 ...: 1.5 % of the
 // wires of EmailVerifier): their codes, once per email, into small[gen_base + g] -- the streaming kernel then reads them like
