@@ -72,6 +72,18 @@ def main():
     assert hdr["n_wires"] == len(wk)
     out["ev_test_eml_576_192_kept"] = {"constraints": len(cons), "wires": len(wk), "standard": ru.abc_digest(cons, wk), "montgomery": ru.abc_digest(cons, wk, True),
                                        "witness_sha256": hashlib.sha256(b"".join(int(v).to_bytes(32, "little") for v in wk)).hexdigest()}
+    # all template flags at once (header / body masks, removeSoftLineBreaks = 1): the first valid synthetic input of
+    # tests/test_r1cs._flag_inputs(576, 192) -- the kept-v1 system of zkwg.r1cs over the oracle's witness
+    from test_r1cs import _flag_inputs
+    finp, _ = _flag_inputs(576, 192, 0)
+    fi = {k: [int(x) for x in v] if isinstance(v, list) else int(v) for k, v in finp.items()}
+    main_f = zk.EmailVerifier(576, 192, 121, 17, 0, fi, body_hash_regex=lambda m: zk.BodyHashRegexV1(576, m),
+                              enableHeaderMasking=1, enableBodyMasking=1, removeSoftLineBreaks=1)
+    symf, wf = comp.symbols_kept(main_f), comp.witness_kept(main_f)
+    hdr, cons = ru.read_r1cs(zr.email_verifier_r1cs(symf, 576, 192, 1, 1, 1))
+    assert hdr["n_wires"] == len(wf)
+    out["ev_flags_576_192_kept"] = {"constraints": len(cons), "wires": len(wf), "standard": ru.abc_digest(cons, wf), "montgomery": ru.abc_digest(cons, wf, True),
+                                    "witness_sha256": hashlib.sha256(b"".join(int(v).to_bytes(32, "little") for v in wf)).hexdigest()}
     art = os.path.join(ROOT, "artifacts", "o0_ev_576_192.r1cs.gz")
     if os.path.exists(art):
         w, sha = complete(ev.email_verifier(576, 192), inp)

@@ -549,6 +549,15 @@ def test_prover_first_stage_from_the_compact_image(main):
             import hashlib
             gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "abc_digests.json")))["rsa_kat"]
             assert hashlib.sha256(got[0, :c1.abc_bytes].cpu().numpy().tobytes()).hexdigest() == gold["montgomery" if mont else "standard"]
+        if main == "email_flags":
+            # all template flags (masks + removeSoftLineBreaks): digest from Python integers over the ORACLE's witness of the first
+            # input (tests/golden/make_abc_digests.py "ev_flags_576_192_kept"), not from zk_r1cs_eval
+            import hashlib
+            gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "abc_digests.json")))["ev_flags_576_192_kept"]
+            assert cs.n_constraints == gold["constraints"]
+            if not mont:
+                assert hashlib.sha256(w0[:c0.witness_bytes].cpu().numpy().tobytes()).hexdigest() == gold["witness_sha256"]
+            assert hashlib.sha256(got[0, :c1.abc_bytes].cpu().numpy().tobytes()).hexdigest() == gold["montgomery" if mont else "standard"]
         # a sub-range of the batch
         part = torch.empty((2, c1.abc_bytes), dtype=torch.uint8, device=dev)
         c1.expand_abc_device(d_in, n, scr, 1, 2, part, s, montgomery=mont)

@@ -8,6 +8,7 @@
 #   bench         the default bench.py line     benchq  the headline only (no PMC / other configs / CPU baseline)
 #   prof          rocprofv3 --kernel-trace --stats of the headline pipeline
 #   rslb          removeSoftLineBreaks = 1 variant      abc  tools/bench_abc.py      o0  tools/bench_full.py
+#   pmc:<tool.py> per-kernel HBM traffic of a tool (two rocprofv3 --pmc passes)
 #   env:K=V       export K=V for the following steps
 TAG=$1; shift
 OUT=$PWD/gpurun_out; mkdir -p $OUT
@@ -51,6 +52,30 @@ import json,sys
 d=json.loads(sys.stdin.readline()); print('rslb', d['value'], d['kernel_ms_per_launch'])" ;;
     abc) timeout 900 python tools/bench_abc.py 2>/dev/null | tail -1 | tee $OUT/${TAG}_abc.json | cut -c1-600 ;;
     o0) timeout 900 python tools/bench_full.py 2>/dev/null | tail -1 | tee $OUT/${TAG}_o0.json | cut -c1-600 ;;
+    pmc:*) # per-kernel HBM traffic of a tool: two separate rocprofv3 --pmc passes (WRITE_SIZE, FETCH_SIZE; KiB units, FETCH x 2 on gfx950)
+      TOOL=${step#pmc:}
+      for CTR in WRITE_SIZE FETCH_SIZE; do
+        ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT/${TAG}_pmc_$CTR -- python $REPO/$TOOL > /dev/null 2> $OUT/${TAG}_pmc_$CTR.log )
+      done
+      python - <<PY
+import csv, glob, json
+agg = {}
+for ctr, scale in (("WRITE_SIZE", 1024.0), ("FETCH_SIZE", 2048.0)):
+    f = glob.glob("$OUT/${TAG}_pmc_%s/**/*counter_collection.csv" % ctr, recursive=True)
+    if not f:
+        print("no counter file for", ctr); continue
+    for r in csv.DictReader(open(f[0])):
+        if r.get("Counter_Name", ctr) != ctr: continue
+        k = r["Kernel_Name"].split("(")[0]
+        a = agg.setdefault(k, {"launches": 0, "WRITE_SIZE": 0.0, "FETCH_SIZE": 0.0, "n": {"WRITE_SIZE": 0, "FETCH_SIZE": 0}})
+        a[ctr] += float(r["Counter_Value"]) * scale; a["n"][ctr] += 1
+out = {k: {"launches": v["n"]["WRITE_SIZE"], "write_GB_per_launch": v["WRITE_SIZE"] / max(v["n"]["WRITE_SIZE"], 1) / 1e9,
+           "fetch_GB_per_launch_corrected_x2": v["FETCH_SIZE"] / max(v["n"]["FETCH_SIZE"], 1) / 1e9} for k, v in agg.items() if k.startswith("zk_")}
+json.dump(out, open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["write_GB_per_launch"] * kv[1]["launches"])[:14]:
+    print("%-28s launches %4d  write %8.3f GB  fetch %8.3f GB per launch" % (k, v["launches"], v["write_GB_per_launch"], v["fetch_GB_per_launch_corrected_x2"]))
+PY
+      rm -rf $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_FETCH_SIZE ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -11,6 +11,7 @@
 #include <thread>
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include "../../include/zkwg.h"
 #include "zkwg_kernels.h"
 #include "zkwg_layout.h"
@@ -278,6 +279,14 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     c->has_net = true;
   }
   const zkc::Net* net = c->has_net ? &c->net : nullptr;
+  const bool dbg_t = getenv("ZKWG_DEBUG_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto phase = [&](const char* what) {
+    if (!dbg_t) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[zkwg] create: %-28s %7.2f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   if (!build_sched(*cfg, c->s, c->segs, net)) { g_last_error = "unsupported circuit configuration"; delete c; return ZKWG_RC_BAD_CONFIG; }
   if (getenv("ZKWG_DEBUG_SKIP_INV") && atoi(getenv("ZKWG_DEBUG_SKIP_INV")) && c->s.rsa.present) c->s.rsa.present = 2;  // profiling only
   if (sym_text) {
@@ -286,6 +295,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     // a compact `.sym` (no .r1cs): zk_expand writes the file's order directly (segments remapped).  A fully numbered
     // circuit (.r1cs given): every wire of the file gets a descriptor over the compact image or a linear row over
     // kept-v1 slots (zkwg_full.h -> zkwg_o0.h); zk_expand3_o0 writes the file's witness in one pass
+    phase("schedule");
     if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net) || (!r1cs && !zk_remap_segments(c->s, c->segs, L))) {
       g_last_error = L.err.empty() ? std::string(".sym layout does not tile the witness") : L.err;
       delete c;
@@ -297,9 +307,11 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       std::string err;
       std::vector<u8> produced(L.W, 0);
       for (u64 i = 0; i < L.W; ++i) produced[i] = L.hole[i] ? 0 : 1;
+      phase(".sym layout");
       if (!zk_r1cs_parse(r1cs, r1cs_len, R)) err = "the .r1cs file could not be parsed";
       else if (R.n_wires != L.W) err = "the .r1cs has " + std::to_string(R.n_wires) + " wires, the .sym file numbers " + std::to_string(L.W);
-      else zk_linear_plan(R, produced, c->lin_host, err);
+      else { phase(".r1cs parse"); zk_linear_plan(R, produced, c->lin_host, err); }
+      phase("linear plan");
       if (err.empty()) {
         // wire -> where its value comes from: a kept-v1 slot (bit 31 clear) or a linear row over kept-v1 slots
         const ZkLinPlan& Pn = c->lin_host;
@@ -325,7 +337,9 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
         if (Pn.n_rows() >= 0x7fffffffull || c->s.W >= 0x7fffffffull) err = "circuit too large for the O0 gather table";
         c->full_W = L.W;
         c->lin_rows = Pn.n_rows();
+        phase("wire table");
         if (err.empty()) zk_o0_build(c->s, c->segs, Pn, c->o0_desc, c->o0_src, c->o0t, err);
+        phase("descriptor / row tables");
         if (getenv("ZKWG_DEBUG_PLAN"))
           fprintf(stderr, "[zkwg] O0 tables: %llu wires, %llu alias rows, %llu constant rows, %llu small rows (%llu terms in %llu groups), %llu field rows (%llu terms in %llu groups); %llu terms before chaining\n",
                   (unsigned long long)L.W, (unsigned long long)c->o0t.n_alias, (unsigned long long)c->o0t.n_const, (unsigned long long)c->o0t.n_small(),
