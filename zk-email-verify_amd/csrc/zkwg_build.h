@@ -8,6 +8,7 @@
 #include <unordered_map>
 #include "../../include/zkwg.h"
 #include "zkwg_layout.h"
+#include "zkwg_par.h"
 
 // Derived from the final segment list: the per-segment reciprocal of the type's period (so that zk_expand divides with
 // one multiply; only set when exact over the segment's range).
@@ -225,77 +226,115 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
   L.dst[0] = 0;
   L.names.clear();
   L.names.push_back("one");
-  u64 unmatched = 0, dup = 0, maxw = 0, nlines = 0;
+  u64 unmatched = 0, dup = 0, maxw = 0;
   std::string first_unmatched;
+  // The file has one line per signal of the compiled circuit (9.3 M lines, 0.86 GB for EmailVerifier(1024,1536) at --O0):
+  // both passes run on threads over chunks cut at line boundaries; the per-chunk results are merged in file order.
+  const unsigned T = len > (8u << 20) ? zk_host_threads() : 1u;
+  std::vector<u64> cut(T + 1, len);
+  cut[0] = 0;
+  for (unsigned i = 1; i < T; ++i) {
+    u64 at = len * i / T;
+    while (at < len && text[at] != '\n') ++at;
+    cut[i] = at < len ? at + 1 : len;
+  }
+  for (unsigned i = 1; i <= T; ++i) cut[i] = std::max(cut[i], cut[i - 1]);
   // pass 1: extents of multi-dimensional signal arrays
   ZkSymDims D;
-  for (u64 i = 0; i < len;) {
-    u64 j = i;
-    while (j < len && text[j] != '\n') ++j;
-    const char* p = text + i;
-    const char* e = text + j;
-    while (e > p && (e[-1] == '\r' || e[-1] == ' ')) --e;
-    i = j + 1;
-    const char* c1 = (const char*)memchr(p, ',', e - p);
-    const char* c2 = c1 ? (const char*)memchr(c1 + 1, ',', e - c1 - 1) : nullptr;
-    const char* c3 = c2 ? (const char*)memchr(c2 + 1, ',', e - c2 - 1) : nullptr;
-    if (!c3) continue;
-    const char* be; u32 idx[8]; int nd;
-    if (!ZkSymDims::split(c3 + 1, e, be, idx, nd) || nd < 2) continue;
-    auto& ex = D.ext[std::string(c3 + 1, be)];
-    if (ex.size() < (size_t)nd) ex.resize(nd, 0);
-    for (int k = 0; k < nd; ++k) ex[k] = std::max(ex[k], idx[k] + 1);
+  {
+    std::vector<std::unordered_map<std::string, std::vector<u32>>> part(T);
+    zk_parallel_chunks(T, [&](unsigned ci, unsigned) {
+      auto& ext = part[ci];
+      for (u64 i = cut[ci]; i < cut[ci + 1];) {
+        u64 j = i;
+        while (j < cut[ci + 1] && text[j] != '\n') ++j;
+        const char* p = text + i;
+        const char* e = text + j;
+        while (e > p && (e[-1] == '\r' || e[-1] == ' ')) --e;
+        i = j + 1;
+        if (e - p < 4 || e[-1] != ']') continue;                 // (only names that end in an index can be multi-dimensional)
+        const char* c1 = (const char*)memchr(p, ',', e - p);
+        const char* c2 = c1 ? (const char*)memchr(c1 + 1, ',', e - c1 - 1) : nullptr;
+        const char* c3 = c2 ? (const char*)memchr(c2 + 1, ',', e - c2 - 1) : nullptr;
+        if (!c3) continue;
+        const char* be; u32 idx[8]; int nd;
+        if (!ZkSymDims::split(c3 + 1, e, be, idx, nd) || nd < 2) continue;
+        auto& ex = ext[std::string(c3 + 1, be)];
+        if (ex.size() < (size_t)nd) ex.resize(nd, 0);
+        for (int k = 0; k < nd; ++k) ex[k] = std::max(ex[k], idx[k] + 1);
+      }
+    });
+    for (auto& m : part)
+      for (auto& kv : m) {
+        auto& ex = D.ext[kv.first];
+        if (ex.size() < kv.second.size()) ex.resize(kv.second.size(), 0);
+        for (size_t k = 0; k < kv.second.size(); ++k) ex[k] = std::max(ex[k], kv.second[k]);
+      }
   }
-  std::vector<std::pair<u64, std::string>> holes;   // (witness index, name) of signals this schedule does not produce
-  for (u64 i = 0; i < len;) {
-    u64 j = i;
-    while (j < len && text[j] != '\n') ++j;
-    // labelIdx,witnessIdx,componentIdx,name
-    const char* p = text + i;
-    const char* e = text + j;
-    while (e > p && (e[-1] == '\r' || e[-1] == ' ')) --e;
-    i = j + 1;
-    if (p == e) continue;
-    ++nlines;
-    const char* c1 = (const char*)memchr(p, ',', e - p);
-    const char* c2 = c1 ? (const char*)memchr(c1 + 1, ',', e - c1 - 1) : nullptr;
-    const char* c3 = c2 ? (const char*)memchr(c2 + 1, ',', e - c2 - 1) : nullptr;
-    if (!c3) { L.err = "malformed .sym line " + std::to_string(nlines); return false; }
-    const long long widx = strtoll(c1 + 1, nullptr, 10);
-    if (widx < 0) continue;   // eliminated signal
-    std::string name(c3 + 1, e);
-    if (widx == 0) continue;  // the constant-one wire (never listed by circom; tolerated)
-    {
-      // flatten name[i][j].. of a multi-dimensional signal to name[flat]
-      const char* be; u32 idx[8]; int nd;
-      if (ZkSymDims::split(c3 + 1, e, be, idx, nd) && nd >= 2) {
-        auto dit = D.ext.find(std::string(c3 + 1, be));
-        if (dit != D.ext.end() && dit->second.size() == (size_t)nd) {
-          u64 flat = 0;
-          for (int k = 0; k < nd; ++k) flat = flat * dit->second[k] + idx[k];
-          name = std::string(c3 + 1, be) + "[" + std::to_string(flat) + "]";
+  // pass 2: every listed signal -> (witness index, kept-v1 slot or none, name)
+  struct Hit { u32 widx, slot; std::string name; };
+  std::vector<std::vector<Hit>> hits(T);
+  std::vector<std::string> errs(T);
+  zk_parallel_chunks(T, [&](unsigned ci, unsigned) {
+    auto& out = hits[ci];
+    out.reserve((cut[ci + 1] - cut[ci]) / 64);
+    for (u64 i = cut[ci]; i < cut[ci + 1];) {
+      u64 j = i;
+      while (j < cut[ci + 1] && text[j] != '\n') ++j;
+      // labelIdx,witnessIdx,componentIdx,name
+      const char* p = text + i;
+      const char* e = text + j;
+      while (e > p && (e[-1] == '\r' || e[-1] == ' ')) --e;
+      const u64 line_at = i;
+      i = j + 1;
+      if (p == e) continue;
+      const char* c1 = (const char*)memchr(p, ',', e - p);
+      const char* c2 = c1 ? (const char*)memchr(c1 + 1, ',', e - c1 - 1) : nullptr;
+      const char* c3 = c2 ? (const char*)memchr(c2 + 1, ',', e - c2 - 1) : nullptr;
+      if (!c3) { errs[ci] = "malformed .sym line at byte " + std::to_string(line_at); return; }
+      const long long widx = strtoll(c1 + 1, nullptr, 10);
+      if (widx <= 0) continue;   // eliminated signal (-1) / the constant-one wire (never listed by circom; tolerated)
+      if ((u64)widx >= (1ull << 31)) { errs[ci] = "witness index out of range"; return; }
+      std::string name(c3 + 1, e);
+      bool flattened = false;
+      if (e[-1] == ']') {
+        // flatten name[i][j].. of a multi-dimensional signal to name[flat]
+        const char* be; u32 idx[8]; int nd;
+        if (ZkSymDims::split(c3 + 1, e, be, idx, nd) && nd >= 2) {
+          auto dit = D.ext.find(std::string(c3 + 1, be));
+          if (dit != D.ext.end() && dit->second.size() == (size_t)nd) {
+            u64 flat = 0;
+            for (int k = 0; k < nd; ++k) flat = flat * dit->second[k] + idx[k];
+            name = std::string(c3 + 1, be) + "[" + std::to_string(flat) + "]";
+            flattened = true;
+          }
         }
       }
+      auto it = slot_of.find(name);
+      if (it == slot_of.end()) {
+        if (flattened) name.assign(c3 + 1, e);      // a signal the schedule does not produce keeps the file's spelling
+        out.push_back(Hit{(u32)widx, 0xffffffffu, std::move(name)});
+      } else out.push_back(Hit{(u32)widx, it->second, std::move(name)});
     }
-    auto it = slot_of.find(name);
-    if (it == slot_of.end()) {
-      if (L.allow_holes) {
-        if ((u64)widx >= (1ull << 31)) { L.err = "witness index out of range"; return false; }
-        holes.emplace_back((u64)widx, std::string(c3 + 1, e));
-        if ((u64)widx > maxw) maxw = (u64)widx;
+  });
+  for (auto& er : errs) if (!er.empty()) { L.err = er; return false; }
+  std::vector<std::pair<u64, std::string>> holes;   // (witness index, name) of signals this schedule does not produce
+  for (auto& part : hits) for (Hit& h : part) if ((u64)h.widx > maxw) maxw = h.widx;
+  L.names.resize(maxw + 1);
+  for (auto& part : hits) {
+    for (Hit& h : part) {
+      if (h.slot == 0xffffffffu) {
+        if (L.allow_holes) { holes.emplace_back((u64)h.widx, std::move(h.name)); continue; }
+        if (!unmatched++) first_unmatched = h.name;
         continue;
       }
-      if (!unmatched++) first_unmatched = name;
-      continue;
+      // a layout can only re-order / drop this schedule's own signals: indices beyond its length are bogus
+      if (!L.allow_holes && (u64)h.widx >= ours.size()) { L.err = "witness index " + std::to_string(h.widx) + " exceeds the schedule's witness length"; return false; }
+      if (L.dst[h.slot] != 0xffffffffu && L.dst[h.slot] != h.widx) { ++dup; continue; }
+      L.dst[h.slot] = h.widx;
+      L.names[h.widx] = std::move(h.name);
     }
-    // a layout can only re-order / drop this schedule's own signals: indices beyond its length are bogus
-    if (!L.allow_holes && (u64)widx >= ours.size()) { L.err = "witness index " + std::to_string(widx) + " exceeds the schedule's witness length"; return false; }
-    if ((u64)widx >= (1ull << 31)) { L.err = "witness index out of range"; return false; }
-    if (L.dst[it->second] != 0xffffffffu && L.dst[it->second] != (u32)widx) { ++dup; continue; }
-    L.dst[it->second] = (u32)widx;
-    if ((u64)widx > maxw) maxw = (u64)widx;
-    if (L.names.size() <= (u64)widx) L.names.resize((u64)widx + 1);
-    L.names[(u64)widx] = name;
+    std::vector<Hit>().swap(part);
   }
   if (unmatched) {
     L.err = std::to_string(unmatched) + " signal(s) kept by the .sym file are not produced by this schedule (first: " + first_unmatched + ")";

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 #include "zkwg_fr.h"
+#include "zkwg_par.h"
 
 enum ZkCoefKind : u8 { ZK_COEF_GENERIC = 0, ZK_COEF_ONE = 1, ZK_COEF_MINUS_ONE = 2 };
 
@@ -60,29 +61,45 @@ static inline bool zk_r1cs_parse(const u8* p, u64 len, ZkR1csHost& R) {
   // every linear combination takes at least its 4-byte term count: bound the header's claim by
   // the section that is actually there before sizing anything from it
   if (3ull * R.n_constraints * 4 > cons_len) return fail("constraint count exceeds the constraint section");
-  R.row_ptr.assign(1, 0);
-  R.row_ptr.reserve(3ull * R.n_constraints + 1);
+  // pass 1 (sequential, cheap): where every linear combination starts; pass 2 (threads): wires, coefficients, classes
+  const u64 n_lc = 3ull * R.n_constraints;
+  R.row_ptr.assign(n_lc + 1, 0);
+  std::vector<u64> off(n_lc);
   u64 cp = 0;
-  const Fr one_m = fr_R(), minus_one_m = fr_neg(fr_R());
-  for (u64 lc = 0; lc < 3ull * R.n_constraints; ++lc) {
+  for (u64 lc = 0; lc < n_lc; ++lc) {
     if (cp + 4 > cons_len) return fail("truncated constraint section");
     u32 nt;
     memcpy(&nt, cons + cp, 4);
     cp += 4;
     if ((u64)nt * 36 > cons_len - cp) return fail("truncated linear combination");
-    for (u32 t = 0; t < nt; ++t) {
-      u32 w; Fr v;
-      memcpy(&w, cons + cp, 4); memcpy(v.l, cons + cp + 4, 32);
-      cp += 36;
-      if (w >= R.n_wires) return fail("wire index out of range");
-      if (fr_geq(v, prime)) return fail("coefficient not reduced");
-      const Fr vm = fr_to_mont(v);
-      R.wire.push_back(w);
-      R.coef.push_back(vm);
-      R.kind.push_back(fr_eq(vm, one_m) ? ZK_COEF_ONE : (fr_eq(vm, minus_one_m) ? ZK_COEF_MINUS_ONE : ZK_COEF_GENERIC));
-    }
-    R.row_ptr.push_back(R.wire.size());
+    off[lc] = cp;
+    R.row_ptr[lc + 1] = R.row_ptr[lc] + nt;
+    cp += (u64)nt * 36;
   }
+  const u64 total = R.row_ptr[n_lc];
+  R.wire.resize(total); R.coef.resize(total); R.kind.resize(total);
+  const Fr one_m = fr_R(), minus_one_m = fr_neg(fr_R());
+  const Fr one_s = fr_from_u64(1), minus_one_s = fr_neg(fr_from_u64(1));
+  const unsigned T = n_lc > (1u << 16) ? zk_host_threads() : 1u;
+  std::vector<int> bad(T, 0);
+  zk_parallel_chunks(T, [&](unsigned ci, unsigned nc) {
+    const u64 lo = n_lc * ci / nc, hi = n_lc * (ci + 1) / nc;
+    for (u64 lc = lo; lc < hi; ++lc) {
+      const u8* q = cons + off[lc];
+      for (u64 t = R.row_ptr[lc]; t < R.row_ptr[lc + 1]; ++t, q += 36) {
+        u32 w; Fr v;
+        memcpy(&w, q, 4); memcpy(v.l, q + 4, 32);
+        if (w >= R.n_wires) { bad[ci] = 1; return; }
+        if (fr_geq(v, prime)) { bad[ci] = 2; return; }
+        // (nearly every coefficient of a circom system is 1 or -1: no product for those)
+        const u8 kd = fr_eq(v, one_s) ? ZK_COEF_ONE : (fr_eq(v, minus_one_s) ? ZK_COEF_MINUS_ONE : ZK_COEF_GENERIC);
+        R.wire[t] = w;
+        R.coef[t] = kd == ZK_COEF_ONE ? one_m : (kd == ZK_COEF_MINUS_ONE ? minus_one_m : fr_to_mont(v));
+        R.kind[t] = kd;
+      }
+    }
+  });
+  for (int b : bad) { if (b == 1) return fail("wire index out of range"); if (b == 2) return fail("coefficient not reduced"); }
   return true;
 }
 
