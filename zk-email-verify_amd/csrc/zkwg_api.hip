@@ -1429,8 +1429,10 @@ static int calculate_batch_hostexpand(zkwg_circuit_t* c, const uint8_t* packed, 
     const u64 base = t * tile, cnt = std::min<u64>(tile, n - base);
     const int b = (int)(t & 1);
     if (hipMemcpyAsync(d_in[b], packed + base * s.in_stride, cnt * s.in_stride, hipMemcpyHostToDevice, st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
-    // NB the scratch layout depends on the batch size: every tile is prepared as a batch of `tile` emails (the last one
-    // over stale records beyond cnt -- their images are never expanded)
+    // NB the scratch layout depends on the batch size: every tile is prepared as a batch of `tile` emails; the records beyond
+    // cnt of a partial last tile are zeroed (their images are never expanded, but the kernels must not chew on
+    // uninitialised device memory: ADVICE r3)
+    if (cnt < tile && hipMemsetAsync(d_in[b] + cnt * s.in_stride, 0, (tile - cnt) * s.in_stride, st) != hipSuccess) return ZKWG_RC_HIP_ERROR;
     int r = zkwg_prepare_device(c, d_in[b], tile, d_st[b], d_scr[b], st);
     if (r != ZKWG_RC_OK) return r;
     if (s.rslb && !c->rs_sync)
