@@ -31,6 +31,8 @@ def load_wave():
     lib = C.CDLL(_WSO)
     lib.wt_run_rsa.restype = C.c_int
     lib.wt_run_rsa.argtypes = [C.c_void_p] * 6 + [C.POINTER(C.c_uint64)]
+    lib.wt_run_rslb_merge.restype = C.c_int
+    lib.wt_run_rslb_merge.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     return lib
 
 

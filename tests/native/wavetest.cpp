@@ -26,3 +26,24 @@ int wt_run_rsa(const zkwg_config* cfg, const uint8_t* rec, const uint32_t* diges
   return ok;
 }
 }
+
+// ---- removeSoftLineBreaks: the Poseidon(2) merge chain exactly as the kernel zk_rslb_merge runs it (csrc/zkwg_rslb_wave.h:
+// 4 lanes per email, Montgomery-form state, one product per step for all lanes), on the simulated wavefront.
+#include "zkwg_rslb_wave.h"
+extern "C" {
+// frv: n_emails x img_fr field elements (standard form, 32 bytes each) with the chunk digests at f_rs_chunk .. + rs_nch;
+// on return the merge permutations' S-box signals sit at f_rs_hash + zk_rs_chunk_off(c) + 612 (c >= 1) and r at f_rs_chunk.
+int wt_run_rslb_merge(uint32_t n_emails, uint32_t rs_nch, void* frv, uint32_t img_fr, uint32_t f_rs_chunk, uint32_t f_rs_hash, uint64_t* exchanges) {
+  std::vector<Fr> C, M, t2;
+  build_poseidon_constants(3, 8, 57, C, M);
+  if (!zk_build_poseidon_sparse(3, 57, C, M, t2)) return -1;
+  const uint32_t per = 64u / ZK_RS_MERGE_LANES;
+  uint64_t n = 0;
+  ZkRsMergeLds* S = new ZkRsMergeLds();
+  for (uint32_t block = 0; block * per < n_emails; ++block)
+    n += wavesim::run([&] { zk_rslb_merge_wave(*S, t2.data(), (Fr*)frv, block, n_emails, img_fr, rs_nch, f_rs_chunk, f_rs_hash); });
+  delete S;
+  if (exchanges) *exchanges = n;
+  return 0;
+}
+}

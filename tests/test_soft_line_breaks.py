@@ -160,3 +160,45 @@ def test_all_flags_together_on_gpu():
     assert W == c.W and status == ostatus == [0, 0, 0]
     wb = c.witness_bytes
     assert [wit[i * wb:(i + 1) * wb] == owit[i] for i in range(3)] == [True] * 3
+
+
+def test_device_merge_chain_on_a_simulated_wavefront_matches_the_oracle():
+    """csrc/zkwg_rslb_wave.h -- the body of the kernel zk_rslb_merge: the Poseidon(2) merge chain of PoseidonModular
+    (utils/hash.circom:76-80) with 4 lanes per email, Montgomery-form state and lane 3 converting the S-box signals -- compiled
+    for the host on the 64-fiber wavefront of tests/native/wavesim.h (the workgroup barrier is an exchange point).  20 emails
+    (one full wavefront of 16 + a partial one), 4 chunk digests each: r and all 3 x 243 S-box signals per email against the
+    oracle's textbook Poseidon(2)."""
+    import ctypes as C
+    import random
+    import hosttest
+    from oracle.pyref import poseidon
+    from oracle.pyref.comp import witness_kept
+    lib = hosttest.load_wave()
+    rng = random.Random(11)
+    n, nch = 20, 4
+    P16, P2 = 612, 243
+    off = lambda c: 0 if c == 0 else P16 + (c - 1) * (P16 + P2)          # zk_rs_chunk_off
+    f_chunk, f_hash = 5, 16
+    img_fr = f_hash + off(nch - 1) + P16 + P2 + 3
+    dig = [[rng.randrange(poseidon.P) for _ in range(nch)] for _ in range(n)]
+    buf = bytearray(n * img_fr * 32)
+    for e in range(n):
+        for c in range(nch):
+            o = 32 * (e * img_fr + f_chunk + c)
+            buf[o:o + 32] = dig[e][c].to_bytes(32, "little")
+    raw = (C.c_uint8 * len(buf)).from_buffer(buf)
+    ex = C.c_uint64()
+    assert lib.wt_run_rslb_merge(n, nch, raw, img_fr, f_chunk, f_hash, C.byref(ex)) == 0
+    assert ex.value > 500           # barriers = exchange points: the lanes really ran in lockstep
+    get = lambda e, i: int.from_bytes(buf[32 * (e * img_fr + i):32 * (e * img_fr + i) + 32], "little")
+    for e in range(n):
+        out = dig[e][0]
+        for c in range(1, nch):
+            comp = poseidon.Poseidon(2, [out, dig[e][c]])
+            kept = witness_kept(comp)[1:]
+            assert len(kept) == P2
+            base = f_hash + off(c) + P16
+            assert [get(e, base + i) for i in range(P2)] == kept, (e, c)
+            out = comp.o
+        assert get(e, f_chunk) == out                                     # r, where zk_rslb_scan reads it
+        assert [get(e, f_chunk + c) for c in range(1, nch)] == dig[e][1:]  # the other digests are untouched

@@ -14,7 +14,7 @@ __global__ void zk_poseidon9_g16(ZkSched s, ZkBufs B);
 __global__ void zk_misc_ev(ZkSched s, ZkBufs B);     // zkwg_kernels_misc.hip
 __global__ void zk_net_eval(ZkSched s, ZkBufs B);    // zkwg_kernels_net.hip
 __global__ void zk_rslb_chunks(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip
-#define ZK_RS_MERGE_LANES 4u   // lanes per email of zk_rslb_merge (3 state elements + 1 converter)
+#include "zkwg_rslb_wave.h"   // ZK_RS_MERGE_LANES
 __global__ void zk_rslb_merge(ZkSched s, ZkBufs B);
 __global__ void zk_rslb_scan(ZkSched s, ZkBufs B);
 __global__ void zk_r1cs_check(const u64* row_ptr, const u32* wire, const Fr* coef, const u8* kind, u32 m,
