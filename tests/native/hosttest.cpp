@@ -126,8 +126,16 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
   std::vector<int> lds(N.lds_words, 0x55555555);
   for (u32 i = 0; i < N.n_in; ++i) lds[N.n_pins + i] = msg[i];
   lds[N.n_pins + N.n_in] = 0;
-  for (u32 i = 0; i < N.n_in; ++i)          // the evaluator's prologue: per byte its mask words (byte-local frontier bits)
-    for (u32 m = 0; m < N.mask_words; ++m) lds[N.lds_masks + i * N.mask_words + m] = (int)N.mask_tab[(size_t)msg[i] * N.mask_words + m];
+  // zk_net_scan: the chain state entering every position (zkwg_circom.h chainize)
+  std::vector<u8> state(N.n_in + 1, 0);
+  for (u32 i = 0; i < N.chain_end; ++i) state[i + 1] = N.chain_delta[((size_t)N.chain_class[i] * N.chain_smax + state[i]) * 256 + msg[i]];
+  const u32 MS = N.mask_words + N.chain_mask_words;
+  for (u32 i = 0; i < N.n_in; ++i) {        // the evaluator's prologue: per byte its mask words (byte-local frontier bits, then the chain's)
+    for (u32 m = 0; m < N.mask_words; ++m) lds[N.lds_masks + i * MS + m] = (int)N.mask_tab[(size_t)msg[i] * N.mask_words + m];
+    for (u32 m = 0; m < N.chain_mask_words; ++m)
+      lds[N.lds_masks + i * MS + N.mask_words + m] =
+          i < N.chain_end ? (int)N.chain_mask[(((size_t)N.chain_class[i] * N.chain_smax + state[i]) * 256 + msg[i]) * N.chain_mask_words + m] : 0;
+  }
   std::vector<u32> img(N.n_kept + N.n_temp, 0xdeadbeefu);
   bool ok = true;
   size_t g = 0;
@@ -141,10 +149,11 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
     }
   }
   memcpy(words, img.data(), (size_t)N.n_kept * 4);
-  // byte-local kept signals are not evaluated: zk_expand reads their function tables (ZkDecNet, zkwg_expand_dec.h)
+  // byte-local kept signals are not gates of the list: zk_net_fill (zkwg_kernels_net.hip) writes their words from the function tables
   for (u32 r = 0; r < N.n_kept; ++r) {
     const u32 d = N.slot_desc[r];
-    if (d >> 31) words[r] = N.fn_tab[((d >> 16) & 0x7fffu) * 256u + msg[d & 0xffffu]];
+    if (zk_net_desc_is_chain(d)) words[r] = zk_net_chain_word(d, N.chain_tab.data(), N.chain_smax, state.data(), msg);
+    else if (d >> 31) words[r] = zk_net_local_word(d, N.fn_tab.data(), msg);
   }
   return ok ? 1 : 0;
 }

@@ -55,6 +55,7 @@ struct zkwg_circuit {
   zkc::Net net;
   bool has_net;
   u32* d_net_records; u32* d_net_counts; u32* d_net_mask_tab; u32* d_net_fn; u32* d_net_desc;
+  u8* d_net_cclass; u8* d_net_cdelta; u32* d_net_cmask; u32* d_net_ctab;
   Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
@@ -418,6 +419,13 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
         ok = hipMalloc((void**)dst, std::max<size_t>(v.size(), 4) * 4) == hipSuccess && (v.empty() || hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
       };
       upw(c->net.mask_tab, &c->d_net_mask_tab); upw(c->net.fn_tab, &c->d_net_fn); upw(c->net.slot_desc, &c->d_net_desc);
+      upw(c->net.chain_mask, &c->d_net_cmask); upw(c->net.chain_tab, &c->d_net_ctab);
+      auto upb = [&](const std::vector<u8>& v, u8** dst) {
+        if (!ok) return;
+        ok = hipMalloc((void**)dst, std::max<size_t>(v.size(), 16)) == hipSuccess && (v.empty() || hipMemcpy(*dst, v.data(), v.size(), hipMemcpyHostToDevice) == hipSuccess);
+      };
+      upb(c->net.chain_class, &c->d_net_cclass); upb(c->net.chain_delta, &c->d_net_cdelta);
+      if (ok) { std::vector<u32>().swap(c->net.chain_tab); std::vector<u32>().swap(c->net.chain_mask); }
       if (ok) std::vector<u32>().swap(c->net.records);
     }
     if (ok && c->full_W) {
@@ -620,6 +628,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
     free_o0(c->o0d); free_o0(c->abcd);
     hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_fn); hipFree(c->d_net_desc);
+    hipFree(c->d_net_cclass); hipFree(c->d_net_cdelta); hipFree(c->d_net_cmask); hipFree(c->d_net_ctab);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     hipFree(c->rp_in); hipFree(c->rp_scr[0]); hipFree(c->rp_scr[1]); hipFree(c->rp_out[0]); hipFree(c->rp_out[1]); hipFree(c->rp_status);
     if (c->rp_exp) hipStreamDestroy(c->rp_exp);
@@ -802,6 +811,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.net_records = c->d_net_records;
   B.net_counts = c->d_net_counts;
   B.net_mask_tab = c->d_net_mask_tab; B.net_fn = c->d_net_fn; B.net_desc = c->d_net_desc;
+  B.net_cclass = c->d_net_cclass; B.net_cdelta = c->d_net_cdelta; B.net_cmask = c->d_net_cmask; B.net_ctab = c->d_net_ctab;
   B.pos16 = c->d_pos_rs;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
@@ -823,8 +833,7 @@ static void fill_x3(const zkwg_circuit* c, const ZkBufs& B, ZkX3& A) {
   A.in_stride = s.in_stride; A.img_bits = s.img_bits; A.img_small = s.img_small; A.img_fr = s.img_fr; A.inv_half = s.inv_half;
   A.m_dfa_cm = s.m_dfa_cm; A.m_dfa_pm = s.m_dfa_pm; A.m_dfa_st = s.m_dfa_st;
   A.nportions = c->n_ent; A.nsegs = s.nsegs; A.e_first = B.e_first; A.n_count = B.n_emails - B.e_first;
-  A.xcd_remap = c->xcd_remap; A.limb_off = s.in_off[ZKWG_IN_PUBKEY]; A.hdr_off = s.in_off[ZKWG_IN_HEADER];
-  A.net_fn = B.net_fn; A.net_desc = B.net_desc;
+  A.xcd_remap = c->xcd_remap; A.limb_off = s.in_off[ZKWG_IN_PUBKEY];
 }
 
 // the linear rows of a numbered (`--O0`) circuit that are real sums, for emails [B.e_first, B.n_emails): results go into the image
@@ -902,7 +911,11 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     const u32 ew = 64u / std::max(16u, s.net_lanes);   // emails per wavefront
     if (4u * s.net_lds_words * ew + 16 > 48u * 1024u)   // (gfx950: 160 KB of LDS per CU; the default per-workgroup cap is lower)
       hipFuncSetAttribute((const void*)zk_net_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u * s.net_lds_words * ew + 16));
-    if (pm & 4u) hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
+    if (pm & 4u) {
+      if (s.net_chain_end) hipLaunchKernelGGL(zk_net_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // chain states first: the list's mask words need them
+      hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
+      hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (ne + 7) / 8), dim3(256), 0, st, s, B);   // byte-local slots (timed with the evaluator)
+    }
     if (tm) hipEventRecord(evs[++ki], st);
   }
   if (s.body && (pm & 8u)) hipLaunchKernelGGL(zk_misc_ev, dim3(ne), dim3(64), 7 * s.fr[0].max_bytes + 64 + ZK_DFA_STATES * 256 + 16, st, s, B);
@@ -1216,7 +1229,6 @@ static int tables_host(const zkwg_circuit* c, const ZkO0Tables& T, u64 W3, const
     ZkCtx cx;
     cx.rec = records + e * s.in_stride; cx.bits = (const u64*)(scratch_host + L.off_bits) + e * s.img_bits; cx.small = small_w;
     cx.half = (int)s.inv_half; cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm; cx.m_dfa_st = s.m_dfa_st;
-    cx.net_desc = c->net.slot_desc.data(); cx.net_fn = c->net.fn_tab.data(); cx.hdr_off = s.in_off[ZKWG_IN_HEADER];
     ZkRefSrc R;
     R.frv = (const uint4*)frv_w; R.invtab = (const uint4*)c->invtab_host.data(); R.rec = cx.rec; R.small = cx.small;
     if (rows_on_host) {
@@ -1365,8 +1377,7 @@ int zkwg_expand_host(const zkwg_circuit_t* c, const uint8_t* records, uint64_t n
       ZkCtx cx;
       cx.rec = records + e * s.in_stride; cx.bits = bits + e * s.img_bits; cx.small = small + e * s.img_small;
       cx.half = (int)s.inv_half; cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm; cx.m_dfa_st = s.m_dfa_st;
-      cx.net_desc = c->net.slot_desc.data(); cx.net_fn = c->net.fn_tab.data(); cx.hdr_off = s.in_off[ZKWG_IN_HEADER];
-      ZkRefSrc R;
+        ZkRefSrc R;
       R.frv = (const uint4*)(frv + e * s.img_fr); R.invtab = (const uint4*)c->invtab_host.data(); R.rec = cx.rec; R.small = cx.small;
       u8* w = out + el * out_stride;
       size_t lo = 0, hi = c->segs.size();

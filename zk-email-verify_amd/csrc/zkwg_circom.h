@@ -19,6 +19,7 @@
 // circomlib's comparators / gates / bitify are read from the include path when present and otherwise
 // taken from the restatement at the end of this file ([EXT] circomlib 2.0.5).
 #pragma once
+#include <chrono>
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -502,15 +503,30 @@ struct Net {
   u32 n_steps = 0;
   // Byte-local signals (zkwg_circom.h localize): a signal whose value depends on ONE message byte only (the character
   // comparators of a regex circuit: IsEqual / LessThan internals, range ANDs, class ORs -- most of its signals) is a
-  // function of that byte.  Such gates are not evaluated per email: zk_expand reads `fn_tab` (the stored word for each
-  // of the 256 byte values, one table per distinct function), and the boolean ones a per-email gate does read come from
+  // function of that byte.  Such gates are not gates of the list: zk_net_fill writes their words from `fn_tab` (the stored word for
+  // each of the 256 byte values, one table per distinct function), and the boolean ones a per-email gate does read come from
   // a per-position mask word the evaluator builds with one lookup of `mask_tab` per message byte.
   std::vector<u32> fn_tab;           // n_fn x 256 stored words
-  std::vector<u32> slot_desc;        // per kept slot: 0 = evaluated (the word is in the image), else 0x80000000 | fn << 16 | byte index
+  std::vector<u32> slot_desc;        // per kept slot: 0 = evaluated (the word is in the image), 0x80000000 | fn << 16 | byte index
+                                     // (byte-local), or 0xC0000000 | table << 16 | position (chain_tab)
   std::vector<u32> mask_tab;         // 256 x mask_words: bit b of word m = truth of frontier function 23 m + b on that byte value
   u32 mask_words = 0;                // mask words per message byte (0: nothing was localised)
   u32 lds_masks = 0;                 // first LDS word of the evaluator's mask region (n_in x mask_words words)
   u32 n_local = 0, n_frontier = 0;   // statistics: gates removed from the evaluator / served from the masks
+  // State recurrence collapsed to a scan (zkwg_circom.h chainize): the gates that depend on the bytes 0 .. i through a bounded set of
+  // carried values (the state vector of a regex circuit: AND -> MultiOR -> states[i + 1]) are functions of (state entering byte i,
+  // byte i), the state being the index of the carried valuation among the reachable ones.  zk_net_scan walks
+  // state' = chain_delta[class of i][state][byte] per email; zk_net_fill writes the kept ones' words from chain_tab; the boolean ones
+  // a gate of the list still reads are bits of chain_mask[class][state][byte].
+  u32 chain_end = 0;                 // positions [0, chain_end) are covered (0: no chain was found)
+  u32 chain_smax = 0;                // rows of every table: the largest number of reachable states at any position
+  u32 chain_classes = 0;             // distinct (block structure, reachable set) pairs; a periodic circuit has a handful
+  u32 chain_mask_words = 0;          // mask words per position served from chain_mask (after the mask_words byte-local ones)
+  std::vector<u8> chain_class;       // [n_in] class of a position (positions >= chain_end: 0, unused)
+  std::vector<u8> chain_delta;       // [classes][smax][256]
+  std::vector<u32> chain_mask;       // [classes][smax][256][chain_mask_words]
+  std::vector<u32> chain_tab;        // [tables][smax][256] stored words
+  u32 n_chain = 0, n_chain_front = 0;   // statistics: gates served from the chain tables / of those, read by the list through mask bits
   u32 lanes = 64;                    // lanes per email of zk_net_eval = gates per step (64 / lanes emails share a wavefront)
   std::vector<std::string> names;    // kept slot -> name relative to the component (".eq[0][5].isz.inv")
   std::vector<u8> boolean;           // kept slot -> 1 if its interval is [0, 1]
@@ -537,6 +553,8 @@ struct Elab {
   std::vector<u8> g_skip;            // localize(): the gate is not evaluated per email
   std::vector<int> g_front;          // localize(): >= 0: the gate is the bit of that index of its byte's mask words
   std::vector<long long> g_sup;      // localize(): the message byte a gate depends on (-1 none, -2 several)
+  std::vector<u8> g_chain;           // chainize(): the gate is a function of (chain state, byte) at its position
+  std::vector<int> g_fpos;           // frontier gates: the position whose mask words hold their bit
   std::vector<i64> in_lo, in_hi;
   u32 n_in = 0;
   u32 max_terms = 32;
@@ -1390,7 +1408,7 @@ struct Elab {
   // signature, so one 256-entry table serves the same comparator at every position.
   void localize(Net& net) {
     const u32 n = (u32)gates.size();
-    g_skip.assign(n, 0); g_front.assign(n, -1); g_sup.assign(n, -1);
+    g_skip.assign(n, 0); g_front.assign(n, -1); g_sup.assign(n, -1); g_chain.assign(n, 0); g_fpos.assign(n, -1);
     net.slot_desc.assign(net.n_kept, 0);
     if (getenv("ZKWG_NET_LOCALIZE") && !atoi(getenv("ZKWG_NET_LOCALIZE"))) return;
     auto nforms = [](const Gate& g) { return (g.op == G_QUAD || g.op == G_ASSERT) ? 3 : (g.op == G_NEZ ? 2 : 1); };
@@ -1471,9 +1489,12 @@ struct Elab {
         }
       }
     }
-    // needed gates: everything that is not local; then what they read
+    // the state recurrence, if the circuit has one, becomes a scan (chainize below): its gates leave the list
+    std::vector<int> cbit(n, -1);
+    chainize(net, sup, sig, local, eval, now, cbit);
+    // needed gates: everything that is neither local nor served from the chain tables; then what they read
     std::vector<u32> work;
-    for (u32 g = 0; g < n; ++g) if (!local[g]) { need[g] = 1; work.push_back(g); }
+    for (u32 g = 0; g < n; ++g) if (!local[g] && !g_chain[g]) { need[g] = 1; work.push_back(g); }
     // local kept gates whose table holds a value zk_expand could not decode stay in the evaluator
     for (u32 g = 0; g < n; ++g)
       if (local[g] && gates[g].slot < net.n_kept) { table(g); if (!plain_of[sig[g]]) { need[g] = 1; work.push_back(g); } }
@@ -1498,9 +1519,11 @@ struct Elab {
     for (u32 g = 0; g < n; ++g) {
       if (!front[g]) continue;
       const u32 b = bit_of[sig[g]];
-      g_front[g] = (int)b;
+      g_front[g] = (int)b; g_fpos[g] = (int)sup[g];
       ++net.n_frontier;
     }
+    // chain gates the list reads: bits of the chain mask words, which follow the byte-local ones in every position's mask region
+    for (u32 g = 0; g < n; ++g) if (cbit[g] >= 0) g_front[g] = (int)(net.mask_words * ZKC_MASK_BITS) + cbit[g];
     for (auto& kv : bit_of) {
       // a representative of the signature
       u32 rep = 0;
@@ -1529,6 +1552,298 @@ struct Elab {
               net.n_local, n, net.fn_tab.size() / 256, net.n_frontier, net.mask_words, bit_of.size());
   }
 
+  // The state recurrence of a regex circuit as a scan.  position(g) = the largest message byte g depends on; the gates with
+  // several bytes in their support whose position is i form block i.  A block reads its own byte, the byte-local gates of that byte,
+  // constants, and a bounded set of values of earlier positions (S_i: states[i][*] of a zk-regex circuit) -- so every gate of the
+  // block is a function of (valuation of S_i, byte i), and the valuation of S_{i+1} another.  The reachable valuations are
+  // enumerated from the (empty) S_0 over all 256 byte values, numbered in sorted order (the state), and the block is tabulated:
+  // delta (next state), the stored words of its kept gates, the mask bits of the boolean ones the list still reads.  Positions
+  // whose block descriptor (gates, operands named by their role, byte-local operands by signature) and reachable set equal the
+  // previous position's share its tables by construction -- a periodic circuit is tabulated at a handful of positions.  Chains
+  // that run backwards over the message land in the block of the last byte (their support is everything); that block and all
+  // after the first oversized one stay in the list and read the chain through mask bits.  Anything the scheme cannot express
+  // (a chain gate reading an earlier raw byte, a non-boolean chain value read by the list, more than 255 states, values
+  // outside the stored range) makes chainize return false with nothing changed: the list then evaluates the recurrence as before.
+  typedef std::function<long long(u32, long long, u32&)> LocalEval;
+  bool chainize(Net& net, const std::vector<long long>& sup, const std::vector<u64>& sig, const std::vector<u8>& local,
+                LocalEval& eval, u32& now, std::vector<int>& cbit) {
+    if (getenv("ZKWG_NET_CHAIN") && !atoi(getenv("ZKWG_NET_CHAIN"))) return false;
+    const u32 n = (u32)gates.size(), N = n_in;
+    const bool dbg = getenv("ZKWG_DEBUG_NET") != nullptr;
+    auto nforms = [](const Gate& g) { return (g.op == G_QUAD || g.op == G_ASSERT) ? 3 : (g.op == G_NEZ ? 2 : 1); };
+    auto give_up = [&](const char* why) { if (dbg) fprintf(stderr, "[zkwg] chain: not collapsed (%s)\n", why); return false; };
+    if (N < 16) return give_up("short message");
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (dbg) fprintf(stderr, "[zkwg] chain: %.2f s at %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), what); };
+    std::vector<int> pos(n, -1);
+    for (u32 g = 0; g < n; ++g) {
+      if (sup[g] >= 0) { pos[g] = (int)sup[g]; continue; }
+      if (sup[g] != -2) continue;
+      int p = -1;
+      for (int i = 0; i < nforms(gates[g]); ++i)
+        for (auto& t : gates[g].f[i].t) p = std::max(p, (t.first & SRC_INPUT) ? (int)(t.first & 0x1fffffffu) : pos[t.first]);
+      pos[g] = p;
+    }
+    std::vector<u8> cand(n, 0);
+    std::vector<u32> cnt(N, 0);
+    for (u32 g = 0; g < n; ++g)
+      if (sup[g] == -2 && gates[g].op != G_ASSERT && gates[g].op != G_OUT && pos[g] >= 0 && pos[g] < (int)N) { cand[g] = 1; ++cnt[pos[g]]; }
+    std::vector<u32> nz;
+    for (u32 c : cnt) if (c) nz.push_back(c);
+    if (nz.size() < 8) return give_up("no per-position blocks");
+    std::nth_element(nz.begin(), nz.begin() + nz.size() / 2, nz.end());
+    const u32 med = nz[nz.size() / 2];
+    u32 end = N;
+    for (u32 i = 0; i < N; ++i) if (cnt[i] > 4 * med + 16) { end = i; break; }
+    if (end < 8) return give_up("the blocks are not bounded");
+    for (u32 g = 0; g < n; ++g) if (cand[g] && pos[g] >= (int)end) cand[g] = 0;
+    // Which candidates really are chain gates.  A gate of the list may read the chain only through booleans (mask bits), and a chain
+    // gate may not read the list: a candidate on the wrong side of either rule joins the list (the partial sums of a MultiOR over
+    // every position's accept state, for instance -- a counter, not a state), until nothing changes.  Operands precede their
+    // readers in the gate order, so a descending pass settles the first rule and an ascending one the second.
+    auto boolean = [&](const Gate& O) { return O.op != G_INV0 && O.lo >= 0 && O.hi <= 1; };
+    for (bool changed = true; changed;) {
+      changed = false;
+      for (u32 g = n; g-- > 0;) {
+        if (local[g] || cand[g] || sup[g] == -1) continue;
+        for (int i = 0; i < nforms(gates[g]); ++i)
+          for (auto& t : gates[g].f[i].t)
+            if (!(t.first & SRC_INPUT) && cand[t.first] && !boolean(gates[t.first])) { cand[t.first] = 0; changed = true; }
+      }
+      for (u32 g = 0; g < n; ++g) {
+        if (!cand[g]) continue;
+        for (int i = 0; i < nforms(gates[g]) && cand[g]; ++i)
+          for (auto& t : gates[g].f[i].t)
+            if ((t.first & SRC_INPUT) ? (int)(t.first & 0x1fffffffu) != pos[g] : (sup[t.first] != -1 && !cand[t.first] && !local[t.first])) {
+              cand[g] = 0; changed = true; break;      // (an earlier raw byte is not part of the state either)
+            }
+      }
+    }
+    // what a chain gate reads, and until which position a value of an earlier position is read (carried)
+    std::vector<int> last(n, -1);
+    for (u32 g = 0; g < n; ++g) {
+      if (!cand[g]) continue;
+      for (int i = 0; i < nforms(gates[g]); ++i)
+        for (auto& t : gates[g].f[i].t) {
+          if (t.first & SRC_INPUT) continue;
+          const u32 o = t.first;
+          if (sup[o] == -1) continue;
+          if (pos[o] < pos[g]) last[o] = std::max(last[o], pos[g]);
+        }
+    }
+    // chain gates the list reads: mask bits
+    std::vector<u8> cf(n, 0);
+    for (u32 g = 0; g < n; ++g) {
+      if (local[g] || cand[g]) continue;
+      for (int i = 0; i < nforms(gates[g]); ++i)
+        for (auto& t : gates[g].f[i].t)
+          if (!(t.first & SRC_INPUT) && cand[t.first]) cf[t.first] = 1;
+    }
+    lap("roles settled");
+    std::vector<std::vector<u32>> blk(end), carry(end);
+    for (u32 g = 0; g < n; ++g) {
+      if (pos[g] < 0 || pos[g] >= (int)end) continue;
+      if (cand[g]) blk[pos[g]].push_back(g);
+      if ((cand[g] || local[g]) && last[g] > pos[g]) carry[pos[g]].push_back(g);
+    }
+    // operand roles inside a position
+    enum : i64 { R_CONST = 0, R_STATE = 1, R_BLOCK = 2, R_LOCAL = 3, R_BYTE = 4 };
+    // A class = one block descriptor.  Its tables are rows indexed by the state, and the state is the index of the carried
+    // valuation in ONE dictionary for the whole message (discovery order; the empty valuation entering position 0 is state 0), so a
+    // class is valid at every position with its descriptor whatever the set of states reachable there; rows are tabulated when a
+    // position first reaches them.
+    struct Class {
+      std::vector<i64> desc;
+      std::vector<u8> have;                     // [state]: row tabulated
+      std::vector<std::vector<u8>> delta;       // [state][256]
+      std::vector<std::vector<u32>> words;      // [state][block gate * 256 + byte]
+      u32 nblock = 0;
+    };
+    std::vector<Class> classes;
+    std::map<std::vector<i64>, u32> id_of;      // valuation -> state
+    std::vector<std::vector<i64>> val_of;       // state -> valuation
+    id_of.emplace(std::vector<i64>(), 0u); val_of.emplace_back();
+    net.chain_class.assign(N, 0);
+    std::vector<u32> reach(1, 0u), prev_reach;  // states entering the position (sorted)
+    std::vector<u32> S;                         // carried gates entering the position, in order
+    std::vector<u32> cls_of(end, 0);
+    std::vector<i64> role(n, -1), ridx(n, 0);   // scratch: role of a gate at the current position
+    u32 max_bits = 0;
+    for (u32 i = 0; i < end; ++i) {
+      const std::vector<u32>& B = blk[i];
+      std::vector<u32> L, touched;
+      auto set_role = [&](u32 g, i64 r, i64 ix) { role[g] = r; ridx[g] = ix; touched.push_back(g); };
+      for (u32 k = 0; k < S.size(); ++k) set_role(S[k], R_STATE, k);
+      for (u32 k = 0; k < B.size(); ++k) set_role(B[k], R_BLOCK, k);
+      auto local_ref = [&](u32 g) { if (role[g] < 0) { set_role(g, R_LOCAL, (i64)L.size()); L.push_back(g); } };
+      // carried set leaving the position
+      std::vector<u32> Sn;
+      for (u32 g : S) if (last[g] > (int)i) Sn.push_back(g);
+      for (u32 g : carry[i]) Sn.push_back(g);
+      // descriptor
+      std::vector<i64> D;
+      D.push_back((i64)S.size()); D.push_back((i64)B.size()); D.push_back((i64)Sn.size());
+      bool ok = true;
+      u32 nbits = 0;
+      for (u32 g : B) {
+        const Gate& G = gates[g];
+        D.push_back((i64)G.op); D.push_back(G.k); D.push_back((G.slot < net.n_kept ? 1 : 0) | (cf[g] ? 2 : 0));
+        if (cf[g]) ++nbits;
+        for (int f = 0; f < nforms(G); ++f) {
+          D.push_back(G.f[f].c0); D.push_back((i64)G.f[f].t.size());
+          for (auto& t : G.f[f].t) {
+            D.push_back(t.second);
+            if (t.first & SRC_INPUT) { D.push_back(R_BYTE); D.push_back(0); continue; }
+            const u32 o = t.first;
+            if (sup[o] == -1) { ++now; u32 w; D.push_back(R_CONST); D.push_back(eval(o, 0, w)); continue; }
+            if (role[o] < 0) { if (local[o] && pos[o] == (int)i) local_ref(o); else { ok = false; continue; } }
+            D.push_back(role[o]); D.push_back(role[o] == R_LOCAL ? (i64)sig[o] : ridx[o]);
+          }
+        }
+      }
+      for (u32 g : Sn) {
+        if (role[g] < 0) { if (local[g] && pos[g] == (int)i) local_ref(g); else ok = false; }
+        if (role[g] >= 0) { D.push_back(role[g]); D.push_back(role[g] == R_LOCAL ? (i64)sig[g] : ridx[g]); }
+      }
+      if (!ok) return give_up("internal: a chain operand without a role");
+      max_bits = std::max(max_bits, nbits);
+      int use = -1;
+      if (i > 0 && classes[cls_of[i - 1]].desc == D) use = (int)cls_of[i - 1];
+      for (size_t c = 0; use < 0 && c < classes.size(); ++c) if (classes[c].desc == D) use = (int)c;
+      if (use < 0) {
+        if (classes.size() >= 255) return give_up("more than 255 position classes");
+        use = (int)classes.size();
+        classes.emplace_back();
+        classes.back().desc = D; classes.back().nblock = (u32)B.size();
+        if (dbg) fprintf(stderr, "[zkwg] chain: position %u opens class %d: %zu carried in, %zu gates, %zu carried out, %zu byte-local operands\n", i, use, S.size(), B.size(), Sn.size(), L.size());
+      }
+      cls_of[i] = (u32)use;
+      net.chain_class[i] = (u8)use;
+      const bool same = i > 0 && cls_of[i - 1] == (u32)use && reach == prev_reach;   // same function, same states: same successors
+      if (!same) {
+        Class& C = classes[use];
+        std::vector<u32> todo;
+        for (u32 st : reach) if (st >= C.have.size() || !C.have[st]) todo.push_back(st);
+        if (!todo.empty()) {
+          // byte-local operands per byte value
+          std::vector<std::vector<long long>> LV(L.size(), std::vector<long long>(256));
+          for (u32 b = 0; b < 256; ++b) { ++now; for (size_t l = 0; l < L.size(); ++l) { u32 w; LV[l][b] = eval(L[l], (long long)b, w); } }
+          std::map<u32, long long> consts;
+          for (u32 g : B)
+            for (int q = 0; q < nforms(gates[g]); ++q)
+              for (auto& t : gates[g].f[q].t)
+                if (!(t.first & SRC_INPUT) && sup[t.first] == -1 && !consts.count(t.first)) { ++now; u32 w; consts[t.first] = eval(t.first, 0, w); }
+          std::vector<long long> bv(B.size());
+          std::vector<i64> nv;
+          for (u32 st : todo) {
+            if (C.have.size() <= st) { C.have.resize(st + 1, 0); C.delta.resize(st + 1); C.words.resize(st + 1); }
+            C.have[st] = 1; C.delta[st].assign(256, 0); C.words[st].assign(B.size() * 256, 0);
+            const std::vector<i64> sv = val_of[st];
+            if (sv.size() != S.size()) return give_up("internal: a state of another shape reaches the position");
+            for (u32 b = 0; b < 256; ++b) {
+              auto value_of = [&](u32 o) -> long long {
+                switch (role[o]) { case R_STATE: return sv[ridx[o]]; case R_BLOCK: return bv[ridx[o]]; default: return LV[ridx[o]][b]; }
+              };
+              for (u32 k = 0; k < B.size(); ++k) {
+                const Gate& G = gates[B[k]];
+                long long f[3] = {0, 0, 0};
+                for (int q = 0; q < nforms(G); ++q) {
+                  f[q] = G.f[q].c0;
+                  for (auto& t : G.f[q].t)
+                    f[q] += t.second * ((t.first & SRC_INPUT) ? (long long)b : (sup[t.first] == -1 ? consts[t.first] : value_of(t.first)));
+                }
+                long long r = f[0];
+                if (G.op == G_QUAD) r = f[0] * f[1] + f[2];
+                else if (G.op == G_NEZ) r = (f[0] != 0 ? G.k : 0) + f[1];
+                else if (G.op == G_BIT) r = f[0] < 0 ? -1 : ((f[0] >> G.k) & 1);
+                u32 word;
+                if (G.op == G_INV0) {
+                  if (std::llabs(f[0]) > (long long)net.inv_need) return give_up("an inverse hint of the chain is outside the table");
+                  word = f[0] == 0 ? 0u : (VAL_INVERSE | ((u32)f[0] & 0x7fffffffu));
+                } else {
+                  if (r <= -(1ll << 30) || r >= (1ll << 30)) return give_up("a chain value is outside the stored range");
+                  word = (u32)r & 0x7fffffffu;
+                }
+                bv[k] = r;
+                C.words[st][(size_t)k * 256 + b] = word;
+              }
+              nv.clear();
+              for (u32 g : Sn) nv.push_back((i64)value_of(g));
+              auto it = id_of.find(nv);
+              if (it == id_of.end()) {
+                if (val_of.size() >= 255) return give_up("more than 255 chain states");
+                it = id_of.emplace(nv, (u32)val_of.size()).first;
+                val_of.push_back(nv);
+              }
+              C.delta[st][b] = (u8)it->second;
+            }
+          }
+        }
+        std::vector<u8> seen(256, 0);
+        for (u32 st : reach) for (u32 b = 0; b < 256; ++b) seen[C.delta[st][b]] = 1;
+        prev_reach.swap(reach);
+        reach.clear();
+        for (u32 q = 0; q < 256; ++q) if (seen[q]) reach.push_back(q);
+      }
+      S.swap(Sn);
+      for (u32 g : touched) role[g] = -1;
+    }
+    lap("positions walked");
+    // tables
+    const u32 smax = (u32)val_of.size();
+    const u32 mw2 = (max_bits + ZKC_MASK_BITS - 1) / ZKC_MASK_BITS;
+    net.chain_end = end; net.chain_smax = smax; net.chain_classes = (u32)classes.size(); net.chain_mask_words = mw2;
+    net.chain_delta.assign((size_t)classes.size() * smax * 256, 0);
+    net.chain_mask.assign((size_t)classes.size() * smax * 256 * mw2, 0);
+    for (size_t c = 0; c < classes.size(); ++c)
+      for (u32 st = 0; st < classes[c].have.size(); ++st)
+        if (classes[c].have[st]) std::copy(classes[c].delta[st].begin(), classes[c].delta[st].end(), net.chain_delta.begin() + ((size_t)c * smax + st) * 256);
+    std::map<std::vector<u32>, u32> tab_of;     // table content -> index
+    std::vector<std::vector<int>> fn_of(classes.size());   // [class][block index] -> table (filled on demand)
+    std::vector<u8> masked(classes.size(), 0);
+    for (u32 i = 0; i < end; ++i) {
+      const u32 c = cls_of[i];
+      const Class& C = classes[c];
+      if (fn_of[c].empty()) fn_of[c].assign(blk[i].size(), -1);
+      u32 bit = 0;
+      for (u32 k = 0; k < blk[i].size(); ++k) {
+        const u32 g = blk[i][k];
+        g_chain[g] = 1; ++net.n_chain;
+        if (cf[g]) {
+          // bit `bit` of the position's chain mask words; the gate stays in the list as a BIT record (and writes its own word)
+          cbit[g] = (int)bit; g_fpos[g] = (int)i; ++net.n_chain_front;
+          if (!masked[c])
+            for (u32 st = 0; st < C.have.size(); ++st)
+              if (C.have[st])
+                for (u32 b = 0; b < 256; ++b)
+                  if (C.words[st][(size_t)k * 256 + b] & 1u) net.chain_mask[(((size_t)c * smax + st) * 256 + b) * mw2 + bit / ZKC_MASK_BITS] |= 1u << (bit % ZKC_MASK_BITS);
+          ++bit;
+          continue;
+        }
+        if (gates[g].slot >= net.n_kept) continue;
+        if (fn_of[c][k] < 0) {
+          std::vector<u32> w((size_t)smax * 256, 0);
+          for (u32 st = 0; st < C.have.size(); ++st)
+            if (C.have[st]) std::copy(C.words[st].begin() + (size_t)k * 256, C.words[st].begin() + (size_t)(k + 1) * 256, w.begin() + (size_t)st * 256);
+          auto it = tab_of.find(w);
+          if (it == tab_of.end()) {
+            it = tab_of.emplace(w, (u32)(net.chain_tab.size() / ((size_t)smax * 256))).first;
+            net.chain_tab.insert(net.chain_tab.end(), w.begin(), w.end());
+          }
+          fn_of[c][k] = (int)it->second;
+        }
+        if (fn_of[c][k] >= 0x3fff || i >= 0x10000) fail("too many distinct chain tables in the regex template");
+        net.slot_desc[gates[g].slot] = 0xC0000000u | ((u32)fn_of[c][k] << 16) | i;
+      }
+      masked[c] = 1;
+    }
+    lap("tables built");
+    if (dbg)
+      fprintf(stderr, "[zkwg] chain: positions [0, %u) collapsed: %u gates (%u read by the list through %u mask word(s)), %zu classes, <= %u states, %zu tables (%.1f MB)\n",
+              end, net.n_chain, net.n_chain_front, mw2, classes.size(), smax, net.chain_tab.size() / ((size_t)smax * 256), net.chain_tab.size() * 4 / 1e6);
+    return true;
+  }
+
   // Evaluation schedule.  Gates are list-scheduled into chunks of mutually independent gates inside a sliding
   // window (so the comparators of the next message byte fill the chunks of the current byte's state recurrence);
   // a chunk is executed in steps of up to 64 gates, one per lane.  Where an operand lives is decided here, by
@@ -1554,6 +1869,7 @@ struct Elab {
       const Gate& g = gates[gi];
       if (g.op == G_OUT) { outs.push_back(gi); continue; }   // the outputs go last, 64 per step (they take the 64-bit path)
       if (g_skip[gi]) continue;                              // byte-local: not evaluated per email (localize)
+      if (g_chain[gi] && g_front[gi] < 0) continue;          // a function of (chain state, byte): served from the chain tables (chainize)
       u32 c = base;
       if (g_front[gi] < 0)                                   // (a frontier gate only reads its byte's mask word)
         for (int i = 0; i < nforms(g); ++i)
@@ -1607,7 +1923,7 @@ struct Elab {
     const u32 lds_msg = hwm, lds_zero = lds_msg + n_in, lds_dummy = lds_zero + 1;
     net.n_pins = hwm;
     net.lds_masks = lds_dummy + 1;
-    net.lds_words = net.lds_masks + n_in * net.mask_words;
+    net.lds_words = net.lds_masks + n_in * (net.mask_words + net.chain_mask_words);
     if (4ull * net.lds_words * (64u / net.lanes) + 16u > 150u * 1024u)
       fail("the evaluator's LDS image (" + std::to_string(net.lds_words) + " words per email, " + std::to_string(64u / net.lanes) + " emails per wavefront) would exceed the 160 KB of a gfx950 CU: set ZKWG_NET_LANES=64");
     if (net.lds_words > 16000) fail("the template keeps " + std::to_string(hwm) + " values alive at once; the evaluator's LDS image would exceed 64 KiB");
@@ -1620,9 +1936,9 @@ struct Elab {
         if (g_front[gi] >= 0) {
           // frontier gate: bit (index % ZKC_MASK_BITS) of mask word (index / ZKC_MASK_BITS) of its byte, as a BIT record
           const Gate& g = gates[gi];
-          const long long byte = g_sup[gi];
+          const long long byte = g_fpos[gi];
           if (byte < 0) fail("internal: frontier gate without a message byte");
-          const u32 b = (u32)g_front[gi], wordi = net.lds_masks + (u32)byte * net.mask_words + b / ZKC_MASK_BITS;
+          const u32 b = (u32)g_front[gi], wordi = net.lds_masks + (u32)byte * (net.mask_words + net.chain_mask_words) + b / ZKC_MASK_BITS;
           u32 r[16] = {0};
           r[0] = G_BIT | ((b % ZKC_MASK_BITS) << 4);
           r[1] = g.slot;

@@ -32,9 +32,6 @@ struct ZkCtx {
   const u32* __restrict__ small;
   int half;           // inverse table covers [-half, half]
   u32 m_dfa_cm, m_dfa_pm, m_dfa_st;   // small[] offsets of the DFA class masks, primitive masks and per-position words
-  const u32* __restrict__ net_desc;   // loaded regex template: per kept slot 0 = the evaluator's word in the image, else 0x80000000 | fn << 16 | byte index
-  const u32* __restrict__ net_fn;     // ... byte-local function tables (256 stored words each)
-  u32 hdr_off;                        // record offset of the header bytes (the regex's message)
 };
 
 ZK_DEC __forceinline__ u32 zk_udiv(u32 r, u32 d, u32 magic) { return magic ? (u32)(((u64)r * magic) >> 32) : r / d; }
@@ -260,18 +257,16 @@ struct ZkDecRslb {
   }
 };
 // gate values of a loaded regex template (zkwg_net_core.h): 31-bit signed integer, or the inverse
-// of one (bit 31) from the table; a negative integer -m is the field element r - m
+// of one (bit 31) from the table; a negative integer -m is the field element r - m.  Every slot of the region is a word of
+// the image: the evaluator's (zk_net_eval) or, for a byte-local signal, zk_net_fill's.
 struct ZkDecNet {
-  const u32* __restrict__ p; const u32* __restrict__ desc; const u32* __restrict__ fn; const u8* __restrict__ msg; u32 base; int half;
-  ZK_DEC ZkDecNet(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), desc(cx.net_desc), fn(cx.net_fn), msg(cx.rec + cx.hdr_off), base(sg.src), half(cx.half) {}
+  const u32* __restrict__ p; u32 base; int half;
+  ZK_DEC ZkDecNet(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), base(sg.src), half(cx.half) {}
   ZK_DEC u32 operator()(u32 r) const {
-    // a byte-local signal (a function of one message byte: the comparators of the regex circuit) comes from its
-    // function table, everything else from the word the evaluator left in the image
-    const u32 d = desc[r];
-    const u32 w = (d >> 31) ? fn[((d >> 16) & 0x7fffu) * 256u + msg[d & 0xffffu]] : p[base + r];
+    const u32 w = p[base + r];
     const int v = (int)(w << 1) >> 1;
     if (w & 0x80000000u) return zk_inv_code(v, half);
-    return v >= 0 ? (u32)v : (ZK_REF_NEG | (base + r));   // (negative values only come from the image: localize keeps them there)
+    return v >= 0 ? (u32)v : (ZK_REF_NEG | (base + r));
   }
 };
 

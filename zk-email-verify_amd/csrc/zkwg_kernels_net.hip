@@ -30,11 +30,19 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   const u8* rec = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
   // message bytes, and per byte its mask words: the truth of every byte-local boolean a per-email gate reads
   // (zkwg_circom.h localize), one table lookup per byte and word
-  const u32 MW = s.net_mask_words;
+  // ... and, when the state recurrence was collapsed (zkwg_circom.h chainize), the chain's mask words: the truth of every boolean
+  // of the chain a gate of the list reads, by (class of the position, state entering it -- zk_net_scan, byte)
+  const u32 MW = s.net_mask_words, MW2 = s.net_chain_mw, MS = MW + MW2;
+  const u8* cstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st);
   for (u32 i = gl; i < N; i += L) {
     const u32 b = rec[i];
     lds[msg_base + i] = (int)b;
-    for (u32 m = 0; m < MW; ++m) lds[s.net_lds_masks + i * MW + m] = (int)B.net_mask_tab[b * MW + m];
+    for (u32 m = 0; m < MW; ++m) lds[s.net_lds_masks + i * MS + m] = (int)B.net_mask_tab[b * MW + m];
+    if (MW2) {
+      const bool in_chain = i < s.net_chain_end;
+      const u32 row = in_chain ? (((u32)B.net_cclass[i] * s.net_chain_smax + cstate[i]) * 256u + b) * MW2 : 0u;
+      for (u32 m = 0; m < MW2; ++m) lds[s.net_lds_masks + i * MS + MW + m] = in_chain ? (int)B.net_cmask[row + m] : 0;
+    }
   }
   if (gl == 0) lds[msg_base + N] = 0;
   const u32 scratch = msg_base + N + 1u;
@@ -97,4 +105,51 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   const u64 bad = __ballot(!ok);
   const u64 mine = (L == 64u ? ~0ull : ((1ull << L) - 1ull)) << (sub * L);
   if ((bad & mine) != 0ull && gl == 0 && live) B.status[e] = 4;
+}
+
+// zk_net_fill -- the words of the byte-local kept signals, written beside the evaluator's.  A workgroup covers 1,024 slots of
+// ZKN_FILL_EMAILS emails: a thread reads 4 slot descriptors once and writes the 4 words of each email, consecutive lanes
+// consecutive words.  zk_expand's ZSEG_NET then reads every slot of the region from the image with one load, like any other
+// segment of small values; resolving descriptor -> message byte -> table inside zk_expand instead (three dependent loads per
+// slot, a divergent branch) cost the store stream 10 % of its rate on its own (profiles/r04: 4.96 -> 4.52 ms per 512 witnesses).
+// (One thread per slot and email -- 578 k tiny workgroups per 1,024 emails -- took 10 ms beside the high-priority store stream.)
+#define ZKN_FILL_EMAILS 8
+__global__ __launch_bounds__(256) void zk_net_fill(ZkSched s, ZkBufs B) {
+  const u32 r0 = blockIdx.x * 1024u + threadIdx.x, e0 = blockIdx.y * ZKN_FILL_EMAILS;
+  u32 d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const u32 r = r0 + 256u * (u32)k; d[k] = r < s.net_kept ? B.net_desc[r] : 0u; }
+  if (!((d[0] | d[1] | d[2] | d[3]) >> 31)) return;
+  for (u32 e = e0; e < e0 + ZKN_FILL_EMAILS && e < B.n_emails; ++e) {
+    const u8* msg = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
+    u32* img = B.small + (u64)e * s.img_small + s.m_net;
+    const u8* cstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (d[k] >> 31)
+        img[r0 + 256u * (u32)k] = zk_net_desc_is_chain(d[k]) ? zk_net_chain_word(d[k], B.net_ctab, s.net_chain_smax, cstate, msg) : zk_net_local_word(d[k], B.net_fn, msg);
+  }
+}
+
+// zk_net_scan -- the collapsed state recurrence (zkwg_circom.h chainize): one lane per email walks
+// state' = delta[class of the position][state][byte] over the covered positions and leaves the state ENTERING every position in
+// the image, one byte each.  1,024 dependent table lookups per email (the tables stay in the vector cache: a few KB per class).
+__global__ __launch_bounds__(64) void zk_net_scan(ZkSched s, ZkBufs B) {
+  const u32 e = blockIdx.x * 64u + threadIdx.x;
+  if (e >= B.n_emails) return;
+  const u8* msg = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
+  u32* out = B.small + (u64)e * s.img_small + s.m_net_st;
+  const u32 end = s.net_chain_end, smax = s.net_chain_smax;
+  u32 st = 0;
+  for (u32 i = 0; i <= end; i += 4) {
+    u32 b[4], packed = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) b[k] = i + k < end ? (u32)msg[i + k] : 0u;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+      packed |= st << (8u * k);
+      if (i + k < end) st = B.net_cdelta[((u32)B.net_cclass[i + k] * smax + st) * 256u + b[k]];
+    }
+    out[i >> 2] = packed;
+  }
 }

@@ -22,6 +22,18 @@ enum ZkNetOp : u32 { ZKN_NOP = 0, ZKN_QUAD = 1, ZKN_INV0 = 2, ZKN_BIT = 3, ZKN_N
 
 ZK_HD int zk_net_decode(u32 w) { return (int)(w << 1) >> 1; }   // 31-bit two's complement
 
+// A byte-local kept signal (a function of one message byte: the comparators of the regex circuit; zkwg_circom.h localize) is
+// not a gate of the list: its stored word comes from a 256-entry function table.  d = Net::slot_desc of the slot
+// (0x80000000 | function << 16 | byte index; 0 = a gate of the list writes the word).
+ZK_HD u32 zk_net_local_word(u32 d, const u32* fn_tab, const u8* msg) { return fn_tab[((d >> 16) & 0x7fffu) * 256u + msg[d & 0xffffu]]; }
+// A kept signal of the collapsed state recurrence (zkwg_circom.h chainize; d = 0xC0000000 | table << 16 | position): a function of
+// the chain state entering its position (zk_net_scan) and that position's byte.
+ZK_HD u32 zk_net_chain_word(u32 d, const u32* chain_tab, u32 smax, const u8* state, const u8* msg) {
+  const u32 pos = d & 0xffffu;
+  return chain_tab[(((d >> 16) & 0x3fffu) * smax + state[pos]) * 256u + msg[pos]];
+}
+ZK_HD bool zk_net_desc_is_chain(u32 d) { return (d >> 30) == 3u; }
+
 // General path, exact in 64 bits: every record type.  `lds_r` / `lds`: the evaluator's LDS image for reads /
 // writes (the same memory on the device, where the 64 lanes of a step read before any of them writes; the
 // sequential host mirror reads a snapshot taken at the start of the step); `img`: the region in the email's image.

@@ -234,6 +234,11 @@ struct ZkSched {
   u32 net_lds_masks;     // zk_net_eval's LDS image: first word of the per-byte mask region (byte-local frontier bits, zkwg_circom.h localize)
   u32 net_mask_words;    // mask words per message byte (0: none)
   u32 net_lanes;         // lanes per email of zk_net_eval (64 / net_lanes emails per wavefront)
+  // the state recurrence of the template collapsed to a scan (zkwg_circom.h chainize; 0 positions: none)
+  u32 net_chain_end;     // positions [0, net_chain_end) are covered
+  u32 net_chain_smax;    // rows (states) of every chain table
+  u32 net_chain_mw;      // mask words per position served from the chain (after the net_mask_words byte-local ones)
+  u32 m_net_st;          // small: the chain state entering every position, one byte each (zk_net_scan)
   // RemoveSoftLineBreaks(max_body) (template flag removeSoftLineBreaks, email-verifier.circom:148-156)
   u32 rslb;              // 1: present
   u32 rs_nch;            // 2 * max_body / 16 Poseidon(16) chunks of PoseidonModular(2 * max_body)
@@ -282,7 +287,11 @@ struct ZkBufs {
   const u32* net_counts;  // loaded regex template: gates per step | flags (0x8000: 64-bit path)
   const u32* net_mask_tab; // loaded regex template: 256 x net_mask_words frontier masks by byte value
   const u32* net_fn;      // loaded regex template: byte-local function tables (256 stored words each)
-  const u32* net_desc;    // loaded regex template: per kept slot 0 (evaluated) or 0x80000000 | fn << 16 | byte index
+  const u32* net_desc;    // loaded regex template: per kept slot 0 (evaluated), 0x80000000 | fn << 16 | byte index, or 0xC0000000 | table << 16 | position
+  const u8* net_cclass;   // chain: class of every position
+  const u8* net_cdelta;   // chain: [class][state][byte] next state
+  const u32* net_cmask;   // chain: [class][state][byte][net_chain_mw] mask words
+  const u32* net_ctab;    // chain: [table][state][byte] stored words
   const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
   Fr* frm;               // Montgomery-form output: per email, Montgomery copies of its img_fr field elements, then of the record's ZK_MONT_LIMBS limbs
   const ZkSeg* segs;     // segment table
@@ -301,9 +310,8 @@ struct ZkX3 {
   uint4* wit;
   const Fr* frm; const Fr* invtab_m; const Fr* rtab;   // Montgomery-form output only
   Fr* frm_w; u32* small_w; Fr* frv_w;                  // writable views (zk_image_to_mont, the O0 row kernels)
-  const u32* net_fn; const u32* net_desc;              // loaded regex template: byte-local function tables / per-slot descriptors
   u64 wit_stride16, W;
   u32 in_stride, img_bits, img_small, img_fr, inv_half, m_dfa_cm, m_dfa_pm, m_dfa_st;
-  u32 nportions, nsegs, e_first, n_count, xcd_remap, limb_off, hdr_off;   // nportions: pieces per witness (of 256 K slots)
+  u32 nportions, nsegs, e_first, n_count, xcd_remap, limb_off;   // nportions: pieces per witness (of 256 K slots)
 };
 #endif
