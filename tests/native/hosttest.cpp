@@ -126,15 +126,22 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
   std::vector<int> lds(N.lds_words, 0x55555555);
   for (u32 i = 0; i < N.n_in; ++i) lds[N.n_pins + i] = msg[i];
   lds[N.n_pins + N.n_in] = 0;
-  // zk_net_scan: the chain state entering every position (zkwg_circom.h chainize)
-  std::vector<u8> state(N.n_in + 1, 0);
-  for (u32 i = 0; i < N.chain_end; ++i) state[i + 1] = N.chain_delta[((size_t)N.chain_class[i] * N.chain_smax + state[i]) * 256 + msg[i]];
-  const u32 MS = N.mask_words + N.chain_mask_words;
-  for (u32 i = 0; i < N.n_in; ++i) {        // the evaluator's prologue: per byte its mask words (byte-local frontier bits, then the chain's)
-    for (u32 m = 0; m < N.mask_words; ++m) lds[N.lds_masks + i * MS + m] = (int)N.mask_tab[(size_t)msg[i] * N.mask_words + m];
-    for (u32 m = 0; m < N.chain_mask_words; ++m)
-      lds[N.lds_masks + i * MS + N.mask_words + m] =
-          i < N.chain_end ? (int)N.chain_mask[(((size_t)N.chain_class[i] * N.chain_smax + state[i]) * 256 + msg[i]) * N.chain_mask_words + m] : 0;
+  // zk_net_scan: the chain states entering every position (zkwg_circom.h chain_pass)
+  ZkNetChains K;
+  K.n_in = N.n_in;
+  K.f_end = N.chain.end; K.f_smax = N.chain.smax; K.f_mw = N.chain.mask_words;
+  K.b_end = N.bchain.end; K.b_smax = N.bchain.smax; K.b_mw = N.bchain.mask_words; K.b_fdim = N.bchain.fdim;
+  K.f_cls = N.chain.cls.data(); K.f_delta = N.chain.delta.data(); K.f_mask = N.chain.mask.data(); K.f_tab = N.chain.tab.data();
+  K.b_cls = N.bchain.cls.data(); K.b_delta = N.bchain.delta.data(); K.b_mask = N.bchain.mask.data(); K.b_tab = N.bchain.tab.data();
+  std::vector<u8> fstate(N.n_in + 4, 0), bstate(N.n_in + 4, 0);
+  zk_net_scan_states(K, msg, fstate.data(), bstate.data());
+  const u32 MS = N.mask_words + K.f_mw + K.b_mw;
+  for (u32 i = 0; i < N.n_in; ++i) {        // the evaluator's prologue: per byte its mask words (byte-local frontier bits, then the chains')
+    int* mw = &lds[N.lds_masks + i * MS];
+    for (u32 m = 0; m < N.mask_words; ++m) mw[m] = (int)N.mask_tab[(size_t)msg[i] * N.mask_words + m];
+    for (u32 m = 0; m < K.f_mw; ++m) mw[N.mask_words + m] = i < K.f_end ? (int)K.f_mask[(size_t)zk_net_fwd_row(K, i, fstate.data(), msg) * K.f_mw + m] : 0;
+    for (u32 m = 0; m < K.b_mw; ++m)
+      mw[N.mask_words + K.f_mw + m] = i + K.b_end >= N.n_in ? (int)K.b_mask[(size_t)zk_net_bwd_row(K, i, fstate.data(), bstate.data(), msg) * K.b_mw + m] : 0;
   }
   std::vector<u32> img(N.n_kept + N.n_temp, 0xdeadbeefu);
   bool ok = true;
@@ -152,7 +159,7 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
   // byte-local kept signals are not gates of the list: zk_net_fill (zkwg_kernels_net.hip) writes their words from the function tables
   for (u32 r = 0; r < N.n_kept; ++r) {
     const u32 d = N.slot_desc[r];
-    if (zk_net_desc_is_chain(d)) words[r] = zk_net_chain_word(d, N.chain_tab.data(), N.chain_smax, state.data(), msg);
+    if (zk_net_desc_is_chain(d)) words[r] = zk_net_chain_word(d, K, fstate.data(), bstate.data(), msg);
     else if (d >> 31) words[r] = zk_net_local_word(d, N.fn_tab.data(), msg);
   }
   return ok ? 1 : 0;

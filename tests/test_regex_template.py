@@ -213,6 +213,34 @@ def test_gpu_loaded_template_equals_built_in_circuit_and_interpreter_fixture():
 
 
 @pytest.mark.gpu
+def test_gpu_loaded_template_at_bench_size_equals_built_in_circuit_on_the_real_email():
+    """EmailVerifier(1024,1536) -- the size the bench runs, where both recurrences of the template (the forward state chain and the
+    backward `live` chain) are served from scan tables (zkwg_circom.h chain_pass) -- on the reference's own email and two tampered
+    copies: every signal equals the built-in circuit's, by name."""
+    import zkwg
+    import real_email
+    inp = real_email.ev_inputs("test_eml", 1024, 1536)
+    c0 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=1024, max_body=1536, device=0)
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=1024, max_body=1536, device=0, regex=STAND_IN)
+    hdr = bytes(int(x) for x in inp["emailHeader"])
+    k = hdr.index(b"bh=")
+    t1 = dict(inp); t1["emailHeader"] = list(inp["emailHeader"]); t1["emailHeader"][7] = str(int(t1["emailHeader"][7]) ^ 2)
+    t2 = dict(inp); t2["emailHeader"] = list(inp["emailHeader"]); t2["emailHeader"][k] = str(ord("x"))
+    recs = b"".join(c.pack(x) for x in (inp, t1, t2))
+    w0, s0 = c0.calculate_batch_host(recs)
+    w1, s1 = c.calculate_batch_host(recs)
+    assert s0 == s1 and s0[0] == 0
+    n0, n1 = [nm for _, nm in c0.symbols()], [nm for _, nm in c.symbols()]
+    assert sorted(n0) == sorted(n1)
+    at1 = {nm: i for i, nm in c.symbols()}
+    for e in range(3):
+        a = w0[e * c0.witness_bytes:(e + 1) * c0.witness_bytes]
+        b = w1[e * c.witness_bytes:(e + 1) * c.witness_bytes]
+        bad = [nm for i, nm in c0.symbols() if a[32 * i:32 * i + 32] != b[32 * at1[nm]:32 * at1[nm] + 32]]
+        assert not bad, (e, len(bad), bad[:5])
+
+
+@pytest.mark.gpu
 def test_gpu_zk_regex_style_template_region_equals_the_interpreter():
     import zkwg
     fx = np.load(FX)

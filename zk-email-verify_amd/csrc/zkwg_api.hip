@@ -55,7 +55,7 @@ struct zkwg_circuit {
   zkc::Net net;
   bool has_net;
   u32* d_net_records; u32* d_net_counts; u32* d_net_mask_tab; u32* d_net_fn; u32* d_net_desc;
-  u8* d_net_cclass; u8* d_net_cdelta; u32* d_net_cmask; u32* d_net_ctab;
+  u8* d_net_cclass; u8* d_net_cdelta; u32* d_net_cmask; u32* d_net_ctab; u8* d_net_bclass; u8* d_net_bdelta; u32* d_net_bmask; u32* d_net_btab;
   Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
@@ -419,13 +419,15 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
         ok = hipMalloc((void**)dst, std::max<size_t>(v.size(), 4) * 4) == hipSuccess && (v.empty() || hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
       };
       upw(c->net.mask_tab, &c->d_net_mask_tab); upw(c->net.fn_tab, &c->d_net_fn); upw(c->net.slot_desc, &c->d_net_desc);
-      upw(c->net.chain_mask, &c->d_net_cmask); upw(c->net.chain_tab, &c->d_net_ctab);
+      upw(c->net.chain.mask, &c->d_net_cmask); upw(c->net.chain.tab, &c->d_net_ctab);
+      upw(c->net.bchain.mask, &c->d_net_bmask); upw(c->net.bchain.tab, &c->d_net_btab);
       auto upb = [&](const std::vector<u8>& v, u8** dst) {
         if (!ok) return;
         ok = hipMalloc((void**)dst, std::max<size_t>(v.size(), 16)) == hipSuccess && (v.empty() || hipMemcpy(*dst, v.data(), v.size(), hipMemcpyHostToDevice) == hipSuccess);
       };
-      upb(c->net.chain_class, &c->d_net_cclass); upb(c->net.chain_delta, &c->d_net_cdelta);
-      if (ok) { std::vector<u32>().swap(c->net.chain_tab); std::vector<u32>().swap(c->net.chain_mask); }
+      upb(c->net.chain.cls, &c->d_net_cclass); upb(c->net.chain.delta, &c->d_net_cdelta);
+      upb(c->net.bchain.cls, &c->d_net_bclass); upb(c->net.bchain.delta, &c->d_net_bdelta);
+      if (ok) for (zkc::ChainTab* t : {&c->net.chain, &c->net.bchain}) { std::vector<u32>().swap(t->tab); std::vector<u32>().swap(t->mask); }
       if (ok) std::vector<u32>().swap(c->net.records);
     }
     if (ok && c->full_W) {
@@ -629,6 +631,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     free_o0(c->o0d); free_o0(c->abcd);
     hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_fn); hipFree(c->d_net_desc);
     hipFree(c->d_net_cclass); hipFree(c->d_net_cdelta); hipFree(c->d_net_cmask); hipFree(c->d_net_ctab);
+    hipFree(c->d_net_bclass); hipFree(c->d_net_bdelta); hipFree(c->d_net_bmask); hipFree(c->d_net_btab);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     hipFree(c->rp_in); hipFree(c->rp_scr[0]); hipFree(c->rp_scr[1]); hipFree(c->rp_out[0]); hipFree(c->rp_out[1]); hipFree(c->rp_status);
     if (c->rp_exp) hipStreamDestroy(c->rp_exp);
@@ -812,6 +815,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.net_counts = c->d_net_counts;
   B.net_mask_tab = c->d_net_mask_tab; B.net_fn = c->d_net_fn; B.net_desc = c->d_net_desc;
   B.net_cclass = c->d_net_cclass; B.net_cdelta = c->d_net_cdelta; B.net_cmask = c->d_net_cmask; B.net_ctab = c->d_net_ctab;
+  B.net_bclass = c->d_net_bclass; B.net_bdelta = c->d_net_bdelta; B.net_bmask = c->d_net_bmask; B.net_btab = c->d_net_btab;
   B.pos16 = c->d_pos_rs;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
@@ -912,9 +916,10 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     if (4u * s.net_lds_words * ew + 16 > 48u * 1024u)   // (gfx950: 160 KB of LDS per CU; the default per-workgroup cap is lower)
       hipFuncSetAttribute((const void*)zk_net_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u * s.net_lds_words * ew + 16));
     if (pm & 4u) {
-      if (s.net_chain_end) hipLaunchKernelGGL(zk_net_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // chain states first: the list's mask words need them
-      hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
-      hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (ne + 7) / 8), dim3(256), 0, st, s, B);   // byte-local slots (timed with the evaluator)
+      static const int skip = getenv("ZKWG_DEBUG_NET_SKIP") ? atoi(getenv("ZKWG_DEBUG_NET_SKIP")) : 0;   // (timing experiments only: wrong witnesses)
+      if (s.net_chain_end && !(skip & 1)) hipLaunchKernelGGL(zk_net_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // chain states first: the list's mask words need them
+      if (!(skip & 2)) hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
+      if (!(skip & 4)) hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (ne + 7) / 8), dim3(256), 0, st, s, B);   // byte-local slots (timed with the evaluator)
     }
     if (tm) hipEventRecord(evs[++ki], st);
   }

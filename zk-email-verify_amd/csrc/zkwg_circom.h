@@ -487,6 +487,19 @@ struct Frame {
 };
 
 // ------------------------------------------------------------------------------------------------ result
+struct ChainTab {
+  u32 end = 0;                       // positions covered, in walking order: bytes [0, end) forward, [n_in - end, n_in) backward (0: no chain)
+  u32 smax = 0;                      // states: rows of every table
+  u32 classes = 0;                   // distinct block descriptors; a periodic circuit has a handful
+  u32 mask_words = 0;                // mask words per position served from `mask`
+  u32 fdim = 1;                      // symbols per position = fdim x 256 (backward pass: fdim = the forward chain's states)
+  std::vector<u8> cls;               // [n_in] class of a message byte (bytes outside the chain: 0, unused)
+  std::vector<u8> delta;             // [classes][smax][fdim][256] next state
+  std::vector<u32> mask;             // [classes][smax][fdim][256][mask_words]
+  std::vector<u32> tab;              // [tables][smax][fdim][256] stored words
+  std::vector<u32> reach_bits;       // [n_in][8] host only: the states that can enter a byte (the backward pass walks consistent symbols only)
+  u32 n_gates = 0, n_front = 0;      // statistics: gates served from the tables / of those, read by the list through mask bits
+};
 struct Net {
   u32 n_in = 0;                      // message bytes
   u32 n_kept = 0, n_temp = 0;        // region = kept slots, then temporaries
@@ -508,25 +521,18 @@ struct Net {
   // a per-position mask word the evaluator builds with one lookup of `mask_tab` per message byte.
   std::vector<u32> fn_tab;           // n_fn x 256 stored words
   std::vector<u32> slot_desc;        // per kept slot: 0 = evaluated (the word is in the image), 0x80000000 | fn << 16 | byte index
-                                     // (byte-local), or 0xC0000000 | table << 16 | position (chain_tab)
+                                     // (byte-local), 0xC0000000 | table << 16 | byte index (chain.tab) or 0xE0000000 | ... (bchain.tab)
   std::vector<u32> mask_tab;         // 256 x mask_words: bit b of word m = truth of frontier function 23 m + b on that byte value
   u32 mask_words = 0;                // mask words per message byte (0: nothing was localised)
   u32 lds_masks = 0;                 // first LDS word of the evaluator's mask region (n_in x mask_words words)
   u32 n_local = 0, n_frontier = 0;   // statistics: gates removed from the evaluator / served from the masks
-  // State recurrence collapsed to a scan (zkwg_circom.h chainize): the gates that depend on the bytes 0 .. i through a bounded set of
+  // Recurrences collapsed to scans (zkwg_circom.h chain_pass): the gates that depend on the bytes 0 .. i through a bounded set of
   // carried values (the state vector of a regex circuit: AND -> MultiOR -> states[i + 1]) are functions of (state entering byte i,
   // byte i), the state being the index of the carried valuation among the reachable ones.  zk_net_scan walks
-  // state' = chain_delta[class of i][state][byte] per email; zk_net_fill writes the kept ones' words from chain_tab; the boolean ones
-  // a gate of the list still reads are bits of chain_mask[class][state][byte].
-  u32 chain_end = 0;                 // positions [0, chain_end) are covered (0: no chain was found)
-  u32 chain_smax = 0;                // rows of every table: the largest number of reachable states at any position
-  u32 chain_classes = 0;             // distinct (block structure, reachable set) pairs; a periodic circuit has a handful
-  u32 chain_mask_words = 0;          // mask words per position served from chain_mask (after the mask_words byte-local ones)
-  std::vector<u8> chain_class;       // [n_in] class of a position (positions >= chain_end: 0, unused)
-  std::vector<u8> chain_delta;       // [classes][smax][256]
-  std::vector<u32> chain_mask;       // [classes][smax][256][chain_mask_words]
-  std::vector<u32> chain_tab;        // [tables][smax][256] stored words
-  u32 n_chain = 0, n_chain_front = 0;   // statistics: gates served from the chain tables / of those, read by the list through mask bits
+  // state' = delta[class of i][state][byte] per email; zk_net_fill writes the kept ones' words from tab; the boolean ones a gate
+  // of the list still reads are bits of mask[class][state][byte].  `bchain`: what then still runs backwards over the message
+  // (is_consecutive / live chains), the same with symbols (forward state, byte).
+  ChainTab chain, bchain;
   u32 lanes = 64;                    // lanes per email of zk_net_eval = gates per step (64 / lanes emails share a wavefront)
   std::vector<std::string> names;    // kept slot -> name relative to the component (".eq[0][5].isz.inv")
   std::vector<u8> boolean;           // kept slot -> 1 if its interval is [0, 1]
@@ -553,7 +559,7 @@ struct Elab {
   std::vector<u8> g_skip;            // localize(): the gate is not evaluated per email
   std::vector<int> g_front;          // localize(): >= 0: the gate is the bit of that index of its byte's mask words
   std::vector<long long> g_sup;      // localize(): the message byte a gate depends on (-1 none, -2 several)
-  std::vector<u8> g_chain;           // chainize(): the gate is a function of (chain state, byte) at its position
+  std::vector<u8> g_chain;           // chain_pass(): 1 / 2: the gate is a function of (forward / backward chain state, symbol) at its position
   std::vector<int> g_fpos;           // frontier gates: the position whose mask words hold their bit
   std::vector<i64> in_lo, in_hi;
   u32 n_in = 0;
@@ -1489,9 +1495,17 @@ struct Elab {
         }
       }
     }
-    // the state recurrence, if the circuit has one, becomes a scan (chainize below): its gates leave the list
-    std::vector<int> cbit(n, -1);
-    chainize(net, sup, sig, local, eval, now, cbit);
+    // the recurrences, if the circuit has them, become scans (chain_pass below): their gates leave the list
+    std::vector<int> cbit(n, -1), cbit2(n, -1);
+    if (chain_pass(net, 0, sup, sig, local, eval, now, cbit, cbit2) && chain_pass(net, 1, sup, sig, local, eval, now, cbit2, cbit)) {
+      // forward-chain booleans that only the backward chain read are no longer read by the list: they keep their table, not their bit record
+      std::vector<u8> read(n, 0);
+      for (u32 g = 0; g < n; ++g) {
+        if (local[g] || g_chain[g]) continue;
+        for (int i = 0; i < nforms(gates[g]); ++i) for (auto& t : gates[g].f[i].t) if (!(t.first & SRC_INPUT)) read[t.first] = 1;
+      }
+      for (u32 g = 0; g < n; ++g) if (cbit[g] >= 0 && !read[g]) { cbit[g] = -1; --net.chain.n_front; }
+    }
     // needed gates: everything that is neither local nor served from the chain tables; then what they read
     std::vector<u32> work;
     for (u32 g = 0; g < n; ++g) if (!local[g] && !g_chain[g]) { need[g] = 1; work.push_back(g); }
@@ -1523,7 +1537,10 @@ struct Elab {
       ++net.n_frontier;
     }
     // chain gates the list reads: bits of the chain mask words, which follow the byte-local ones in every position's mask region
-    for (u32 g = 0; g < n; ++g) if (cbit[g] >= 0) g_front[g] = (int)(net.mask_words * ZKC_MASK_BITS) + cbit[g];
+    for (u32 g = 0; g < n; ++g) {
+      if (cbit[g] >= 0) g_front[g] = (int)(net.mask_words * ZKC_MASK_BITS) + cbit[g];
+      if (cbit2[g] >= 0) g_front[g] = (int)((net.mask_words + net.chain.mask_words) * ZKC_MASK_BITS) + cbit2[g];
+    }
     for (auto& kv : bit_of) {
       // a representative of the signature
       u32 rep = 0;
@@ -1544,7 +1561,7 @@ struct Elab {
         it = fn_of.emplace(sig[g], (u32)(net.fn_tab.size() / 256)).first;
         net.fn_tab.insert(net.fn_tab.end(), w.begin(), w.end());
       }
-      if (it->second >= 0x7fffu || sup[g] >= 0x10000) fail("too many distinct byte-local functions in the regex template");
+      if (it->second >= 0x1fffu || sup[g] >= 0x10000) fail("too many distinct byte-local functions in the regex template");   // (bits 29, 30 of a descriptor tell the chains' slots)
       net.slot_desc[G.slot] = 0x80000000u | (it->second << 16) | (u32)sup[g];
     }
     if (getenv("ZKWG_DEBUG_NET"))
@@ -1552,73 +1569,114 @@ struct Elab {
               net.n_local, n, net.fn_tab.size() / 256, net.n_frontier, net.mask_words, bit_of.size());
   }
 
-  // The state recurrence of a regex circuit as a scan.  position(g) = the largest message byte g depends on; the gates with
-  // several bytes in their support whose position is i form block i.  A block reads its own byte, the byte-local gates of that byte,
-  // constants, and a bounded set of values of earlier positions (S_i: states[i][*] of a zk-regex circuit) -- so every gate of the
-  // block is a function of (valuation of S_i, byte i), and the valuation of S_{i+1} another.  The reachable valuations are
-  // enumerated from the (empty) S_0 over all 256 byte values, numbered in sorted order (the state), and the block is tabulated:
-  // delta (next state), the stored words of its kept gates, the mask bits of the boolean ones the list still reads.  Positions
-  // whose block descriptor (gates, operands named by their role, byte-local operands by signature) and reachable set equal the
-  // previous position's share its tables by construction -- a periodic circuit is tabulated at a handful of positions.  Chains
+  // The recurrences of a regex circuit as scans.
+  //
+  // Forward pass.  position(g) = the largest message byte g depends on; the gates with several bytes in their support whose position
+  // is i form block i.  A block reads its own byte, the byte-local gates of that byte, constants, and a bounded set of values of
+  // earlier positions (S_i: states[i][*] of a zk-regex circuit) -- so every gate of the block is a function of (valuation of S_i,
+  // byte i), and the valuation of S_{i+1} another.  The reachable valuations are enumerated from the (empty) S_0 over all 256 byte
+  // values and numbered (the state), and the block is tabulated: delta (next state), the stored words of its kept gates, the mask
+  // bits of the boolean ones the list still reads.  Positions with the same block descriptor (gates, operands named by their role,
+  // byte-local operands by signature) share a class of tables -- a periodic circuit is tabulated at a handful of positions.  Chains
   // that run backwards over the message land in the block of the last byte (their support is everything); that block and all
-  // after the first oversized one stay in the list and read the chain through mask bits.  Anything the scheme cannot express
-  // (a chain gate reading an earlier raw byte, a non-boolean chain value read by the list, more than 255 states, values
-  // outside the stored range) makes chainize return false with nothing changed: the list then evaluates the recurrence as before.
+  // after the first oversized one are left to
+  //
+  // the backward pass: the same construction on the mirrored message over what is left of the list, whose leaves now include the
+  // forward chain's booleans -- the symbol a position contributes is (forward state entering it, its byte), so the tables get one
+  // more dimension.  (zk-regex's is_consecutive chain, the stand-in's `live` chain.)
+  //
+  // Anything the scheme cannot express (a non-boolean chain value read by the list, more than 255 states, values outside the stored
+  // range) makes a pass return false with nothing changed: the list then evaluates those gates as before.
   typedef std::function<long long(u32, long long, u32&)> LocalEval;
-  bool chainize(Net& net, const std::vector<long long>& sup, const std::vector<u64>& sig, const std::vector<u8>& local,
-                LocalEval& eval, u32& now, std::vector<int>& cbit) {
-    if (getenv("ZKWG_NET_CHAIN") && !atoi(getenv("ZKWG_NET_CHAIN"))) return false;
+  // Whether a chain value the list reads is boolean is first taken on trust (value intervals cannot prove it for a recurrence: they
+  // widen at every step) and verified on the tabulated values -- a gate found otherwise joins `nonbool` and the pass is repeated;
+  // when that makes the state space explode (a counter taken for a state), the pass falls back to what the intervals prove.
+  bool chain_pass(Net& net, int pass, const std::vector<long long>& sup, const std::vector<u64>& sig, const std::vector<u8>& local,
+                  LocalEval& eval, u32& now, std::vector<int>& cbit, const std::vector<int>& cbit_fwd) {
+    if (getenv("ZKWG_NET_CHAIN") && atoi(getenv("ZKWG_NET_CHAIN")) <= pass) return false;
+    std::vector<u8> nonbool(gates.size(), 0);
+    for (int round = 0; round < 6; ++round) {
+      const int r = chain_try(net, pass, /*trust=*/true, nonbool, sup, sig, local, eval, now, cbit, cbit_fwd);
+      if (r == 1) return true;
+      if (r == 0) break;
+    }
+    std::fill(nonbool.begin(), nonbool.end(), 0);
+    return chain_try(net, pass, /*trust=*/false, nonbool, sup, sig, local, eval, now, cbit, cbit_fwd) == 1;
+  }
+  // -> 1 collapsed, 0 not (nothing changed), 2 `nonbool` grew: try again
+  int chain_try(Net& net, int pass, bool trust, std::vector<u8>& nonbool, const std::vector<long long>& sup, const std::vector<u64>& sig,
+                const std::vector<u8>& local, LocalEval& eval, u32& now, std::vector<int>& cbit, const std::vector<int>& cbit_fwd) {
     const u32 n = (u32)gates.size(), N = n_in;
-    const bool dbg = getenv("ZKWG_DEBUG_NET") != nullptr;
+    const bool dbg = getenv("ZKWG_DEBUG_NET") != nullptr, bwd = pass == 1;
+    const char* tag = bwd ? "backward chain" : "chain";
+    ChainTab& T = bwd ? net.bchain : net.chain;
+    const ChainTab& F = net.chain;                      // (backward pass: the forward tables supply the leaves' values)
+    const u32 fdim = bwd ? std::max<u32>(F.smax, 1) : 1u;
     auto nforms = [](const Gate& g) { return (g.op == G_QUAD || g.op == G_ASSERT) ? 3 : (g.op == G_NEZ ? 2 : 1); };
-    auto give_up = [&](const char* why) { if (dbg) fprintf(stderr, "[zkwg] chain: not collapsed (%s)\n", why); return false; };
+    auto give_up = [&](const char* why) { if (dbg) fprintf(stderr, "[zkwg] %s: not collapsed%s (%s)\n", tag, trust ? " on trust" : "", why); return 0; };
     if (N < 16) return give_up("short message");
-    const auto t_start = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) { if (dbg) fprintf(stderr, "[zkwg] chain: %.2f s at %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), what); };
+    if (bwd && !F.end) return give_up("no forward chain");
+    auto tp = [&](int p) { return bwd ? (int)N - 1 - p : p; };      // position in walking order <-> message byte
+    // leaves: byte-local gates, and in the backward pass the forward chain's mask bits (functions of the position's symbol)
+    std::vector<u8> leaf(n, 0);
     std::vector<int> pos(n, -1);
     for (u32 g = 0; g < n; ++g) {
-      if (sup[g] >= 0) { pos[g] = (int)sup[g]; continue; }
+      if (local[g]) { leaf[g] = 1; pos[g] = tp((int)sup[g]); continue; }
+      if (bwd && g_chain[g]) { if (cbit_fwd[g] >= 0) { leaf[g] = 2; pos[g] = tp(g_fpos[g]); } continue; }
       if (sup[g] != -2) continue;
       int p = -1;
       for (int i = 0; i < nforms(gates[g]); ++i)
-        for (auto& t : gates[g].f[i].t) p = std::max(p, (t.first & SRC_INPUT) ? (int)(t.first & 0x1fffffffu) : pos[t.first]);
+        for (auto& t : gates[g].f[i].t) p = std::max(p, (t.first & SRC_INPUT) ? tp((int)(t.first & 0x1fffffffu)) : pos[t.first]);
       pos[g] = p;
     }
     std::vector<u8> cand(n, 0);
-    std::vector<u32> cnt(N, 0);
     for (u32 g = 0; g < n; ++g)
-      if (sup[g] == -2 && gates[g].op != G_ASSERT && gates[g].op != G_OUT && pos[g] >= 0 && pos[g] < (int)N) { cand[g] = 1; ++cnt[pos[g]]; }
-    std::vector<u32> nz;
-    for (u32 c : cnt) if (c) nz.push_back(c);
-    if (nz.size() < 8) return give_up("no per-position blocks");
-    std::nth_element(nz.begin(), nz.begin() + nz.size() / 2, nz.end());
-    const u32 med = nz[nz.size() / 2];
+      if (sup[g] == -2 && !g_chain[g] && gates[g].op != G_ASSERT && gates[g].op != G_OUT && pos[g] >= 0 && pos[g] < (int)N) cand[g] = 1;
+    // Which candidates really are chain gates.  A gate of the list may read the chain only through booleans (mask bits); a chain gate
+    // may not read the list, nor a raw byte of another position, nor a value from more than ZKC_CHAIN_REACH positions back (bounded
+    // memory: what runs against the walking direction sits at the last position and reads the whole message): a candidate on the
+    // wrong side of a rule joins the list (the partial sums of a MultiOR over every position's accept state, for instance -- a
+    // counter, not a state), until nothing changes.  Operands precede their readers in the gate order, so a descending pass
+    // settles the first rule and an ascending one the others.  Then the positions are cut at the first block that is still far
+    // larger than the typical one.
+    auto boolean = [&](u32 o) { const Gate& O = gates[o]; return O.op != G_INV0 && !nonbool[o] && (trust || (O.lo >= 0 && O.hi <= 1)); };
+    auto in_list = [&](u32 g) { return !local[g] && !cand[g] && !g_chain[g] && sup[g] != -1; };
+    const int ZKC_CHAIN_REACH = 4;
     u32 end = N;
-    for (u32 i = 0; i < N; ++i) if (cnt[i] > 4 * med + 16) { end = i; break; }
-    if (end < 8) return give_up("the blocks are not bounded");
-    for (u32 g = 0; g < n; ++g) if (cand[g] && pos[g] >= (int)end) cand[g] = 0;
-    // Which candidates really are chain gates.  A gate of the list may read the chain only through booleans (mask bits), and a chain
-    // gate may not read the list: a candidate on the wrong side of either rule joins the list (the partial sums of a MultiOR over
-    // every position's accept state, for instance -- a counter, not a state), until nothing changes.  Operands precede their
-    // readers in the gate order, so a descending pass settles the first rule and an ascending one the second.
-    auto boolean = [&](const Gate& O) { return O.op != G_INV0 && O.lo >= 0 && O.hi <= 1; };
-    for (bool changed = true; changed;) {
-      changed = false;
-      for (u32 g = n; g-- > 0;) {
-        if (local[g] || cand[g] || sup[g] == -1) continue;
-        for (int i = 0; i < nforms(gates[g]); ++i)
-          for (auto& t : gates[g].f[i].t)
-            if (!(t.first & SRC_INPUT) && cand[t.first] && !boolean(gates[t.first])) { cand[t.first] = 0; changed = true; }
-      }
-      for (u32 g = 0; g < n; ++g) {
-        if (!cand[g]) continue;
-        for (int i = 0; i < nforms(gates[g]) && cand[g]; ++i)
-          for (auto& t : gates[g].f[i].t)
-            if ((t.first & SRC_INPUT) ? (int)(t.first & 0x1fffffffu) != pos[g] : (sup[t.first] != -1 && !cand[t.first] && !local[t.first])) {
-              cand[g] = 0; changed = true; break;      // (an earlier raw byte is not part of the state either)
+    for (;;) {
+      for (bool changed = true; changed;) {
+        changed = false;
+        for (u32 g = n; g-- > 0;) {
+          if (!in_list(g)) continue;
+          for (int i = 0; i < nforms(gates[g]); ++i)
+            for (auto& t : gates[g].f[i].t)
+              if (!(t.first & SRC_INPUT) && cand[t.first] && !boolean(t.first)) { cand[t.first] = 0; changed = true; }
+        }
+        for (u32 g = 0; g < n; ++g) {
+          if (!cand[g]) continue;
+          for (int i = 0; i < nforms(gates[g]) && cand[g]; ++i)
+            for (auto& t : gates[g].f[i].t) {
+              bool bad;
+              if (t.first & SRC_INPUT) bad = tp((int)(t.first & 0x1fffffffu)) != pos[g];
+              else if (sup[t.first] == -1) bad = false;
+              else bad = (!cand[t.first] && !leaf[t.first]) || pos[t.first] < pos[g] - ZKC_CHAIN_REACH;
+              if (bad) { cand[g] = 0; changed = true; break; }
             }
+        }
       }
+      std::vector<u32> cnt(N, 0), nz;
+      for (u32 g = 0; g < n; ++g) if (cand[g]) ++cnt[pos[g]];
+      for (u32 c : cnt) if (c) nz.push_back(c);
+      if (nz.size() < 8) return give_up("no per-position blocks");
+      std::nth_element(nz.begin(), nz.begin() + nz.size() / 2, nz.end());
+      const u32 med = nz[nz.size() / 2];
+      u32 cut = end;
+      for (u32 i = 0; i < end; ++i) if (cnt[i] > 4 * med + 16) { cut = i; break; }
+      if (cut == end) break;
+      end = cut;
+      for (u32 g = 0; g < n; ++g) if (cand[g] && pos[g] >= (int)end) cand[g] = 0;
     }
+    if (end < 8) return give_up("the blocks are not bounded");
     // what a chain gate reads, and until which position a value of an earlier position is read (carried)
     std::vector<int> last(n, -1);
     for (u32 g = 0; g < n; ++g) {
@@ -1634,48 +1692,56 @@ struct Elab {
     // chain gates the list reads: mask bits
     std::vector<u8> cf(n, 0);
     for (u32 g = 0; g < n; ++g) {
-      if (local[g] || cand[g]) continue;
+      if (!in_list(g)) continue;
       for (int i = 0; i < nforms(gates[g]); ++i)
         for (auto& t : gates[g].f[i].t)
           if (!(t.first & SRC_INPUT) && cand[t.first]) cf[t.first] = 1;
     }
-    lap("roles settled");
     std::vector<std::vector<u32>> blk(end), carry(end);
+    u32 n_cand = 0;
     for (u32 g = 0; g < n; ++g) {
       if (pos[g] < 0 || pos[g] >= (int)end) continue;
-      if (cand[g]) blk[pos[g]].push_back(g);
-      if ((cand[g] || local[g]) && last[g] > pos[g]) carry[pos[g]].push_back(g);
+      if (cand[g]) { blk[pos[g]].push_back(g); ++n_cand; }
+      if ((cand[g] || leaf[g]) && last[g] > pos[g]) carry[pos[g]].push_back(g);
     }
+    if (!n_cand) return give_up("nothing to collapse");
     // operand roles inside a position
-    enum : i64 { R_CONST = 0, R_STATE = 1, R_BLOCK = 2, R_LOCAL = 3, R_BYTE = 4 };
+    enum : i64 { R_CONST = 0, R_STATE = 1, R_BLOCK = 2, R_LOCAL = 3, R_BYTE = 4, R_FWD = 5 };
     // A class = one block descriptor.  Its tables are rows indexed by the state, and the state is the index of the carried
-    // valuation in ONE dictionary for the whole message (discovery order; the empty valuation entering position 0 is state 0), so a
-    // class is valid at every position with its descriptor whatever the set of states reachable there; rows are tabulated when a
-    // position first reaches them.
+    // valuation in ONE dictionary for the whole message (discovery order; the empty valuation entering the first position is
+    // state 0), so a class is valid at every position with its descriptor whatever the set of states reachable there; rows are
+    // tabulated when a position first reaches them.  A row has fdim x 256 entries: one per symbol (forward state, byte).
     struct Class {
       std::vector<i64> desc;
       std::vector<u8> have;                     // [state]: row tabulated
-      std::vector<std::vector<u8>> delta;       // [state][256]
-      std::vector<std::vector<u32>> words;      // [state][block gate * 256 + byte]
-      u32 nblock = 0;
+      std::vector<std::vector<u8>> delta;       // [state][symbol]
+      std::vector<std::vector<u32>> words;      // [state][block gate * symbols + symbol]
+      std::vector<std::vector<u8>> valid;       // [state][symbol]: the symbol can follow the state (backward pass; forward: all)
     };
+    const u32 NSYM = fdim * 256;
     std::vector<Class> classes;
     std::map<std::vector<i64>, u32> id_of;      // valuation -> state
     std::vector<std::vector<i64>> val_of;       // state -> valuation
-    id_of.emplace(std::vector<i64>(), 0u); val_of.emplace_back();
-    net.chain_class.assign(N, 0);
+    // (backward pass: a valuation ends with the forward state entering the NEXT byte, -1 = any: the symbol (f, b) of a byte can only
+    // precede it if the forward chain steps from f to that state on b -- without this the tables would be enumerated over
+    // combinations that never occur, and values that are boolean on every real message would not look it)
+    { std::vector<i64> v0; if (bwd) v0.push_back(-1); id_of.emplace(v0, 0u); val_of.push_back(v0); }
+    std::vector<u8> class_at(N, 0);
+    std::vector<u32> reach_bits((size_t)N * 8, 0);
     std::vector<u32> reach(1, 0u), prev_reach;  // states entering the position (sorted)
     std::vector<u32> S;                         // carried gates entering the position, in order
     std::vector<u32> cls_of(end, 0);
     std::vector<i64> role(n, -1), ridx(n, 0);   // scratch: role of a gate at the current position
     u32 max_bits = 0;
     for (u32 i = 0; i < end; ++i) {
+      const u32 at = (u32)tp((int)i);           // the message byte of this position
       const std::vector<u32>& B = blk[i];
       std::vector<u32> L, touched;
       auto set_role = [&](u32 g, i64 r, i64 ix) { role[g] = r; ridx[g] = ix; touched.push_back(g); };
       for (u32 k = 0; k < S.size(); ++k) set_role(S[k], R_STATE, k);
       for (u32 k = 0; k < B.size(); ++k) set_role(B[k], R_BLOCK, k);
-      auto local_ref = [&](u32 g) { if (role[g] < 0) { set_role(g, R_LOCAL, (i64)L.size()); L.push_back(g); } };
+      auto leaf_ref = [&](u32 g) { if (role[g] < 0) { set_role(g, leaf[g] == 2 ? R_FWD : R_LOCAL, (i64)L.size()); L.push_back(g); } };
+      auto leaf_name = [&](u32 g) -> i64 { return leaf[g] == 2 ? ((i64)F.cls[at] << 32 | (i64)cbit_fwd[g]) : (i64)sig[g]; };
       // carried set leaving the position
       std::vector<u32> Sn;
       for (u32 g : S) if (last[g] > (int)i) Sn.push_back(g);
@@ -1685,6 +1751,10 @@ struct Elab {
       D.push_back((i64)S.size()); D.push_back((i64)B.size()); D.push_back((i64)Sn.size());
       bool ok = true;
       u32 nbits = 0;
+      auto name_operand = [&](u32 o) {
+        if (role[o] < 0) { if (leaf[o] && pos[o] == (int)i) leaf_ref(o); else { ok = false; return; } }
+        D.push_back(role[o]); D.push_back(role[o] == R_LOCAL || role[o] == R_FWD ? leaf_name(o) : ridx[o]);
+      };
       for (u32 g : B) {
         const Gate& G = gates[g];
         D.push_back((i64)G.op); D.push_back(G.k); D.push_back((G.slot < net.n_kept ? 1 : 0) | (cf[g] ? 2 : 0));
@@ -1694,17 +1764,12 @@ struct Elab {
           for (auto& t : G.f[f].t) {
             D.push_back(t.second);
             if (t.first & SRC_INPUT) { D.push_back(R_BYTE); D.push_back(0); continue; }
-            const u32 o = t.first;
-            if (sup[o] == -1) { ++now; u32 w; D.push_back(R_CONST); D.push_back(eval(o, 0, w)); continue; }
-            if (role[o] < 0) { if (local[o] && pos[o] == (int)i) local_ref(o); else { ok = false; continue; } }
-            D.push_back(role[o]); D.push_back(role[o] == R_LOCAL ? (i64)sig[o] : ridx[o]);
+            if (sup[t.first] == -1) { ++now; u32 w; D.push_back(R_CONST); D.push_back(eval(t.first, 0, w)); continue; }
+            name_operand(t.first);
           }
         }
       }
-      for (u32 g : Sn) {
-        if (role[g] < 0) { if (local[g] && pos[g] == (int)i) local_ref(g); else ok = false; }
-        if (role[g] >= 0) { D.push_back(role[g]); D.push_back(role[g] == R_LOCAL ? (i64)sig[g] : ridx[g]); }
-      }
+      for (u32 g : Sn) name_operand(g);
       if (!ok) return give_up("internal: a chain operand without a role");
       max_bits = std::max(max_bits, nbits);
       int use = -1;
@@ -1714,20 +1779,29 @@ struct Elab {
         if (classes.size() >= 255) return give_up("more than 255 position classes");
         use = (int)classes.size();
         classes.emplace_back();
-        classes.back().desc = D; classes.back().nblock = (u32)B.size();
-        if (dbg) fprintf(stderr, "[zkwg] chain: position %u opens class %d: %zu carried in, %zu gates, %zu carried out, %zu byte-local operands\n", i, use, S.size(), B.size(), Sn.size(), L.size());
+        classes.back().desc = D;
+        if (dbg && classes.size() <= 4)
+          fprintf(stderr, "[zkwg] %s: byte %u opens class %d: %zu carried in, %zu gates, %zu carried out, %zu leaves\n", tag, at, use, S.size(), B.size(), Sn.size(), L.size());
       }
       cls_of[i] = (u32)use;
-      net.chain_class[i] = (u8)use;
+      class_at[at] = (u8)use;
+      for (u32 st : reach) reach_bits[(size_t)at * 8 + st / 32] |= 1u << (st % 32);
       const bool same = i > 0 && cls_of[i - 1] == (u32)use && reach == prev_reach;   // same function, same states: same successors
       if (!same) {
         Class& C = classes[use];
         std::vector<u32> todo;
         for (u32 st : reach) if (st >= C.have.size() || !C.have[st]) todo.push_back(st);
         if (!todo.empty()) {
-          // byte-local operands per byte value
-          std::vector<std::vector<long long>> LV(L.size(), std::vector<long long>(256));
-          for (u32 b = 0; b < 256; ++b) { ++now; for (size_t l = 0; l < L.size(); ++l) { u32 w; LV[l][b] = eval(L[l], (long long)b, w); } }
+          // leaves per symbol: byte-local gates by the byte, forward-chain bits by (forward state, byte)
+          std::vector<std::vector<long long>> LV(L.size());
+          for (size_t l = 0; l < L.size(); ++l) LV[l].assign(leaf[L[l]] == 2 ? NSYM : 256, 0);
+          for (u32 b = 0; b < 256; ++b) { ++now; for (size_t l = 0; l < L.size(); ++l) if (leaf[L[l]] != 2) { u32 w; LV[l][b] = eval(L[l], (long long)b, w); } }
+          for (size_t l = 0; l < L.size(); ++l)
+            if (leaf[L[l]] == 2) {
+              const u32 bit = (u32)cbit_fwd[L[l]];
+              for (u32 y = 0; y < NSYM; ++y)
+                LV[l][y] = (F.mask[(((size_t)F.cls[at] * F.smax + y / 256) * 256 + y % 256) * F.mask_words + bit / ZKC_MASK_BITS] >> (bit % ZKC_MASK_BITS)) & 1u;
+            }
           std::map<u32, long long> consts;
           for (u32 g : B)
             for (int q = 0; q < nforms(gates[g]); ++q)
@@ -1736,13 +1810,23 @@ struct Elab {
           std::vector<long long> bv(B.size());
           std::vector<i64> nv;
           for (u32 st : todo) {
-            if (C.have.size() <= st) { C.have.resize(st + 1, 0); C.delta.resize(st + 1); C.words.resize(st + 1); }
-            C.have[st] = 1; C.delta[st].assign(256, 0); C.words[st].assign(B.size() * 256, 0);
+            if (C.have.size() <= st) { C.have.resize(st + 1, 0); C.delta.resize(st + 1); C.words.resize(st + 1); C.valid.resize(st + 1); }
+            C.have[st] = 1; C.delta[st].assign(NSYM, 0); C.words[st].assign(B.size() * NSYM, 0); C.valid[st].assign(NSYM, 0);
             const std::vector<i64> sv = val_of[st];
-            if (sv.size() != S.size()) return give_up("internal: a state of another shape reaches the position");
-            for (u32 b = 0; b < 256; ++b) {
+            if (sv.size() != S.size() + (bwd ? 1 : 0)) return give_up("internal: a state of another shape reaches the position");
+            for (u32 y = 0; y < NSYM; ++y) {
+              const u32 b = y % 256;
+              if (bwd) {
+                const u32 f = y / 256;
+                if (at >= F.end) { if (f) continue; }
+                else {
+                  if (!((F.reach_bits[(size_t)at * 8 + f / 32] >> (f % 32)) & 1u)) continue;
+                  if (sv.back() >= 0 && (i64)F.delta[((size_t)F.cls[at] * F.smax + f) * 256 + b] != sv.back()) continue;
+                }
+              }
+              C.valid[st][y] = 1;
               auto value_of = [&](u32 o) -> long long {
-                switch (role[o]) { case R_STATE: return sv[ridx[o]]; case R_BLOCK: return bv[ridx[o]]; default: return LV[ridx[o]][b]; }
+                switch (role[o]) { case R_STATE: return sv[ridx[o]]; case R_BLOCK: return bv[ridx[o]]; case R_FWD: return LV[ridx[o]][y]; default: return LV[ridx[o]][b]; }
               };
               for (u32 k = 0; k < B.size(); ++k) {
                 const Gate& G = gates[B[k]];
@@ -1765,22 +1849,24 @@ struct Elab {
                   word = (u32)r & 0x7fffffffu;
                 }
                 bv[k] = r;
-                C.words[st][(size_t)k * 256 + b] = word;
+                C.words[st][(size_t)k * NSYM + y] = word;
               }
               nv.clear();
               for (u32 g : Sn) nv.push_back((i64)value_of(g));
+              if (bwd) nv.push_back(at < F.end ? (i64)(y / 256) : -1);
               auto it = id_of.find(nv);
               if (it == id_of.end()) {
                 if (val_of.size() >= 255) return give_up("more than 255 chain states");
                 it = id_of.emplace(nv, (u32)val_of.size()).first;
                 val_of.push_back(nv);
               }
-              C.delta[st][b] = (u8)it->second;
+              C.delta[st][y] = (u8)it->second;
             }
           }
         }
+        // successors over the symbols that can occur (backward pass: every forward state -- a superset)
         std::vector<u8> seen(256, 0);
-        for (u32 st : reach) for (u32 b = 0; b < 256; ++b) seen[C.delta[st][b]] = 1;
+        for (u32 st : reach) for (u32 y = 0; y < NSYM; ++y) if (C.valid[st][y]) seen[C.delta[st][y]] = 1;
         prev_reach.swap(reach);
         reach.clear();
         for (u32 q = 0; q < 256; ++q) if (seen[q]) reach.push_back(q);
@@ -1788,60 +1874,97 @@ struct Elab {
       S.swap(Sn);
       for (u32 g : touched) role[g] = -1;
     }
-    lap("positions walked");
-    // tables
-    const u32 smax = (u32)val_of.size();
-    const u32 mw2 = (max_bits + ZKC_MASK_BITS - 1) / ZKC_MASK_BITS;
-    net.chain_end = end; net.chain_smax = smax; net.chain_classes = (u32)classes.size(); net.chain_mask_words = mw2;
-    net.chain_delta.assign((size_t)classes.size() * smax * 256, 0);
-    net.chain_mask.assign((size_t)classes.size() * smax * 256 * mw2, 0);
+    // the booleans taken on trust
+    if (trust) {
+      bool grew = false;
+      for (u32 i = 0; i < end; ++i) {
+        const Class& C = classes[cls_of[i]];
+        for (u32 k = 0; k < blk[i].size(); ++k) {
+          if (!cf[blk[i][k]]) continue;
+          bool bad = false;
+          for (u32 st = 0; st < C.have.size() && !bad; ++st)
+            if (C.have[st]) for (u32 y = 0; y < NSYM; ++y) if (C.valid[st][y] && C.words[st][(size_t)k * NSYM + y] > 1u) { bad = true; break; }
+          if (bad) { nonbool[blk[i][k]] = 1; grew = true; }
+        }
+      }
+      if (grew) { if (dbg) fprintf(stderr, "[zkwg] %s: a value the list reads is not boolean; again without it\n", tag); return 2; }
+      for (u32 i = 0; i < end; ++i) for (u32 g : blk[i]) if (cf[g]) { gates[g].lo = 0; gates[g].hi = 1; }   // (verified over every reachable state)
+    }
+    // tables, indexed by the CORE state: the carried values without the forward state that only pruned the enumeration (what a
+    // block computes depends on the values and the symbol alone, so rows of states with the same core agree wherever both are valid)
+    std::vector<u32> core_of(val_of.size());
+    {
+      std::map<std::vector<i64>, u32> core_id;
+      for (size_t st = 0; st < val_of.size(); ++st) {
+        std::vector<i64> v = val_of[st];
+        if (bwd) v.pop_back();
+        core_of[st] = core_id.emplace(v, (u32)core_id.size()).first->second;
+      }
+    }
+    const u32 smax = *std::max_element(core_of.begin(), core_of.end()) + 1;
+    const u32 mw = (max_bits + ZKC_MASK_BITS - 1) / ZKC_MASK_BITS;
+    {
+      // the tables are looked up once per slot and email: they have to stay cache-sized
+      size_t kept_gates = 0;
+      for (size_t c = 0; c < classes.size(); ++c) kept_gates += classes[c].words.empty() ? 0 : classes[c].words.back().size() / NSYM;
+      if ((kept_gates * 4 + classes.size() * (1 + 4 * mw)) * smax * NSYM > (64u << 20)) return give_up("the tables would not stay in the cache");
+    }
+    T.end = end; T.smax = smax; T.classes = (u32)classes.size(); T.mask_words = mw; T.fdim = fdim;
+    T.cls = class_at; T.reach_bits = reach_bits;
+    T.delta.assign((size_t)classes.size() * smax * NSYM, 0);
+    T.mask.assign((size_t)classes.size() * smax * NSYM * mw, 0);
     for (size_t c = 0; c < classes.size(); ++c)
       for (u32 st = 0; st < classes[c].have.size(); ++st)
-        if (classes[c].have[st]) std::copy(classes[c].delta[st].begin(), classes[c].delta[st].end(), net.chain_delta.begin() + ((size_t)c * smax + st) * 256);
+        if (classes[c].have[st])
+          for (u32 y = 0; y < NSYM; ++y)
+            if (classes[c].valid[st][y]) T.delta[((size_t)c * smax + core_of[st]) * NSYM + y] = (u8)core_of[classes[c].delta[st][y]];
     std::map<std::vector<u32>, u32> tab_of;     // table content -> index
     std::vector<std::vector<int>> fn_of(classes.size());   // [class][block index] -> table (filled on demand)
     std::vector<u8> masked(classes.size(), 0);
+    const size_t tab_words = (size_t)smax * NSYM;
     for (u32 i = 0; i < end; ++i) {
-      const u32 c = cls_of[i];
+      const u32 c = cls_of[i], at = (u32)tp((int)i);
       const Class& C = classes[c];
       if (fn_of[c].empty()) fn_of[c].assign(blk[i].size(), -1);
       u32 bit = 0;
       for (u32 k = 0; k < blk[i].size(); ++k) {
         const u32 g = blk[i][k];
-        g_chain[g] = 1; ++net.n_chain;
+        g_chain[g] = (u8)(1 + pass); ++T.n_gates;
         if (cf[g]) {
-          // bit `bit` of the position's chain mask words; the gate stays in the list as a BIT record (and writes its own word)
-          cbit[g] = (int)bit; g_fpos[g] = (int)i; ++net.n_chain_front;
+          // bit `bit` of the position's chain mask words
+          cbit[g] = (int)bit; g_fpos[g] = (int)at; ++T.n_front;
           if (!masked[c])
             for (u32 st = 0; st < C.have.size(); ++st)
               if (C.have[st])
-                for (u32 b = 0; b < 256; ++b)
-                  if (C.words[st][(size_t)k * 256 + b] & 1u) net.chain_mask[(((size_t)c * smax + st) * 256 + b) * mw2 + bit / ZKC_MASK_BITS] |= 1u << (bit % ZKC_MASK_BITS);
+                for (u32 y = 0; y < NSYM; ++y)
+                  if (C.valid[st][y] && (C.words[st][(size_t)k * NSYM + y] & 1u))
+                    T.mask[(((size_t)c * smax + core_of[st]) * NSYM + y) * mw + bit / ZKC_MASK_BITS] |= 1u << (bit % ZKC_MASK_BITS);
           ++bit;
-          continue;
         }
         if (gates[g].slot >= net.n_kept) continue;
+        // (a gate the list reads keeps a BIT record there, which writes the same word; it gets its table all the same, so that it can
+        // leave the list when a later pass takes its readers)
         if (fn_of[c][k] < 0) {
-          std::vector<u32> w((size_t)smax * 256, 0);
+          std::vector<u32> w(tab_words, 0);
           for (u32 st = 0; st < C.have.size(); ++st)
-            if (C.have[st]) std::copy(C.words[st].begin() + (size_t)k * 256, C.words[st].begin() + (size_t)(k + 1) * 256, w.begin() + (size_t)st * 256);
+            if (C.have[st])
+              for (u32 y = 0; y < NSYM; ++y) if (C.valid[st][y]) w[(size_t)core_of[st] * NSYM + y] = C.words[st][(size_t)k * NSYM + y];
           auto it = tab_of.find(w);
           if (it == tab_of.end()) {
-            it = tab_of.emplace(w, (u32)(net.chain_tab.size() / ((size_t)smax * 256))).first;
-            net.chain_tab.insert(net.chain_tab.end(), w.begin(), w.end());
+            it = tab_of.emplace(w, (u32)(T.tab.size() / tab_words)).first;
+            T.tab.insert(T.tab.end(), w.begin(), w.end());
           }
           fn_of[c][k] = (int)it->second;
         }
-        if (fn_of[c][k] >= 0x3fff || i >= 0x10000) fail("too many distinct chain tables in the regex template");
-        net.slot_desc[gates[g].slot] = 0xC0000000u | ((u32)fn_of[c][k] << 16) | i;
+        if (fn_of[c][k] >= 0x1fff || at >= 0x10000) fail("too many distinct chain tables in the regex template");
+        net.slot_desc[gates[g].slot] = (bwd ? 0xE0000000u : 0xC0000000u) | ((u32)fn_of[c][k] << 16) | at;
       }
       masked[c] = 1;
     }
-    lap("tables built");
     if (dbg)
-      fprintf(stderr, "[zkwg] chain: positions [0, %u) collapsed: %u gates (%u read by the list through %u mask word(s)), %zu classes, <= %u states, %zu tables (%.1f MB)\n",
-              end, net.n_chain, net.n_chain_front, mw2, classes.size(), smax, net.chain_tab.size() / ((size_t)smax * 256), net.chain_tab.size() * 4 / 1e6);
-    return true;
+      fprintf(stderr, "[zkwg] %s: %u positions collapsed: %u gates (%u read by the list through %u mask word(s)), %zu classes, <= %u states x %u symbols, %zu tables (%.1f MB)\n",
+              tag, end, T.n_gates, T.n_front, mw, classes.size(), smax, NSYM, T.tab.size() / tab_words, T.tab.size() * 4 / 1e6);
+    return 1;
   }
 
   // Evaluation schedule.  Gates are list-scheduled into chunks of mutually independent gates inside a sliding
@@ -1849,7 +1972,7 @@ struct Elab {
   // a chunk is executed in steps of up to 64 gates, one per lane.  Where an operand lives is decided here, by
   // simulating the evaluator's direct-mapped value cache: the cache (recent values) or a pinned region for values
   // that are read long after they were produced (backward chains over the whole message).
-  void emit(Net& net) {
+  void emit(Net& net, u32 force_lanes = 0) {
     std::vector<u32> chunk_of(gates.size(), 0);
     std::vector<std::vector<u32>> steps;
     net.n_gates = (u32)gates.size();
@@ -1859,8 +1982,13 @@ struct Elab {
     const u32 window = 12;
     // gates per step = lanes per email of zk_net_eval: with the byte-local gates gone (localize) a step holds ~15 gates, and
     // 32 lanes per step cost +2 % steps (16: +27 %) -- two emails share a wavefront
-    u32 step_lanes = getenv("ZKWG_NET_LANES") ? (u32)atoi(getenv("ZKWG_NET_LANES")) : 32u;
-    if (step_lanes != 16 && step_lanes != 32 && step_lanes != 64) step_lanes = 32;
+    // -- and once the state recurrence is served from tables (chain_pass) what is left are a few gates per position:
+    // 16 lanes, four emails per wavefront, when four LDS images fit
+    const u32 mask_stride = net.mask_words + net.chain.mask_words + net.bchain.mask_words;
+    const u32 lanes_default = (net.chain.end && 16ull * (n_in * (1 + mask_stride) + 4096) < 150u * 1024u) ? 16u : 32u;
+    u32 step_lanes = getenv("ZKWG_NET_LANES") ? (u32)atoi(getenv("ZKWG_NET_LANES")) : lanes_default;
+    if (step_lanes != 16 && step_lanes != 32 && step_lanes != 64) step_lanes = lanes_default;
+    if (force_lanes) step_lanes = force_lanes;
     net.lanes = step_lanes;
     std::deque<std::vector<u32>> open;
     u32 base = 1;
@@ -1869,7 +1997,7 @@ struct Elab {
       const Gate& g = gates[gi];
       if (g.op == G_OUT) { outs.push_back(gi); continue; }   // the outputs go last, 64 per step (they take the 64-bit path)
       if (g_skip[gi]) continue;                              // byte-local: not evaluated per email (localize)
-      if (g_chain[gi] && g_front[gi] < 0) continue;          // a function of (chain state, byte): served from the chain tables (chainize)
+      if (g_chain[gi] && g_front[gi] < 0) continue;          // a function of (chain state, symbol): served from the chain tables (chain_pass)
       u32 c = base;
       if (g_front[gi] < 0)                                   // (a frontier gate only reads its byte's mask word)
         for (int i = 0; i < nforms(g); ++i)
@@ -1923,7 +2051,8 @@ struct Elab {
     const u32 lds_msg = hwm, lds_zero = lds_msg + n_in, lds_dummy = lds_zero + 1;
     net.n_pins = hwm;
     net.lds_masks = lds_dummy + 1;
-    net.lds_words = net.lds_masks + n_in * (net.mask_words + net.chain_mask_words);
+    net.lds_words = net.lds_masks + n_in * mask_stride;
+    if (4ull * net.lds_words * (64u / net.lanes) + 16u > 150u * 1024u && net.lanes == 16 && !getenv("ZKWG_NET_LANES")) return emit(net, 32);
     if (4ull * net.lds_words * (64u / net.lanes) + 16u > 150u * 1024u)
       fail("the evaluator's LDS image (" + std::to_string(net.lds_words) + " words per email, " + std::to_string(64u / net.lanes) + " emails per wavefront) would exceed the 160 KB of a gfx950 CU: set ZKWG_NET_LANES=64");
     if (net.lds_words > 16000) fail("the template keeps " + std::to_string(hwm) + " values alive at once; the evaluator's LDS image would exceed 64 KiB");
@@ -1938,7 +2067,7 @@ struct Elab {
           const Gate& g = gates[gi];
           const long long byte = g_fpos[gi];
           if (byte < 0) fail("internal: frontier gate without a message byte");
-          const u32 b = (u32)g_front[gi], wordi = net.lds_masks + (u32)byte * (net.mask_words + net.chain_mask_words) + b / ZKC_MASK_BITS;
+          const u32 b = (u32)g_front[gi], wordi = net.lds_masks + (u32)byte * mask_stride + b / ZKC_MASK_BITS;
           u32 r[16] = {0};
           r[0] = G_BIT | ((b % ZKC_MASK_BITS) << 4);
           r[1] = g.slot;

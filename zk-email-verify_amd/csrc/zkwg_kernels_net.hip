@@ -14,6 +14,16 @@
 
 #define ZKN_DEPTH 8
 
+__device__ __forceinline__ ZkNetChains zk_net_chains(const ZkSched& s, const ZkBufs& B) {
+  ZkNetChains K;
+  K.n_in = s.fr[0].max_bytes;
+  K.f_end = s.net_chain_end; K.f_smax = s.net_chain_smax; K.f_mw = s.net_chain_mw;
+  K.b_end = s.net_bchain_end; K.b_smax = s.net_bchain_smax; K.b_mw = s.net_bchain_mw; K.b_fdim = s.net_bchain_fdim;
+  K.f_cls = B.net_cclass; K.f_delta = B.net_cdelta; K.f_mask = B.net_cmask; K.f_tab = B.net_ctab;
+  K.b_cls = B.net_bclass; K.b_delta = B.net_bdelta; K.b_mask = B.net_bmask; K.b_tab = B.net_btab;
+  return K;
+}
+
 __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   // s.net_lanes (16 / 32 / 64) lanes per email: 64 / net_lanes emails share the wavefront, each with its own LDS image;
   // the lanes of all of them run the same record stream (the records of a step are fetched once per lane index)
@@ -30,18 +40,26 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   const u8* rec = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
   // message bytes, and per byte its mask words: the truth of every byte-local boolean a per-email gate reads
   // (zkwg_circom.h localize), one table lookup per byte and word
-  // ... and, when the state recurrence was collapsed (zkwg_circom.h chainize), the chain's mask words: the truth of every boolean
-  // of the chain a gate of the list reads, by (class of the position, state entering it -- zk_net_scan, byte)
-  const u32 MW = s.net_mask_words, MW2 = s.net_chain_mw, MS = MW + MW2;
-  const u8* cstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st);
+  // ... and, when recurrences were collapsed (zkwg_circom.h chain_pass), the chains' mask words: the truth of every boolean of a
+  // chain a gate of the list reads, by (class of the position, state entering it -- zk_net_scan, symbol)
+  const ZkNetChains K = zk_net_chains(s, B);
+  const u32 MW = s.net_mask_words, MS = MW + K.f_mw + K.b_mw;
+  const u8* fstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st);
+  const u8* bstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_bst);
   for (u32 i = gl; i < N; i += L) {
     const u32 b = rec[i];
     lds[msg_base + i] = (int)b;
-    for (u32 m = 0; m < MW; ++m) lds[s.net_lds_masks + i * MS + m] = (int)B.net_mask_tab[b * MW + m];
-    if (MW2) {
-      const bool in_chain = i < s.net_chain_end;
-      const u32 row = in_chain ? (((u32)B.net_cclass[i] * s.net_chain_smax + cstate[i]) * 256u + b) * MW2 : 0u;
-      for (u32 m = 0; m < MW2; ++m) lds[s.net_lds_masks + i * MS + MW + m] = in_chain ? (int)B.net_cmask[row + m] : 0;
+    int* mw = &lds[s.net_lds_masks + i * MS];
+    for (u32 m = 0; m < MW; ++m) mw[m] = (int)B.net_mask_tab[b * MW + m];
+    if (K.f_mw) {
+      const bool in = i < K.f_end;
+      const u32 row = in ? zk_net_fwd_row(K, i, fstate, rec) * K.f_mw : 0u;
+      for (u32 m = 0; m < K.f_mw; ++m) mw[MW + m] = in ? (int)K.f_mask[row + m] : 0;
+    }
+    if (K.b_mw) {
+      const bool in = i + K.b_end >= N;
+      const u32 row = in ? zk_net_bwd_row(K, i, fstate, bstate, rec) * K.b_mw : 0u;
+      for (u32 m = 0; m < K.b_mw; ++m) mw[MW + K.f_mw + m] = in ? (int)K.b_mask[row + m] : 0;
     }
   }
   if (gl == 0) lds[msg_base + N] = 0;
@@ -120,36 +138,76 @@ __global__ __launch_bounds__(256) void zk_net_fill(ZkSched s, ZkBufs B) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) { const u32 r = r0 + 256u * (u32)k; d[k] = r < s.net_kept ? B.net_desc[r] : 0u; }
   if (!((d[0] | d[1] | d[2] | d[3]) >> 31)) return;
-  for (u32 e = e0; e < e0 + ZKN_FILL_EMAILS && e < B.n_emails; ++e) {
+  const ZkNetChains K = zk_net_chains(s, B);
+  // branch-free: every slot forms one table address (function table, forward or backward chain table -- an evaluated slot reads
+  // word 0 of the function tables and stores nothing), so the 4 x 2 lookups of an iteration are in flight together
+  const u32* tabp[4]; u32 pos[4], mul_f[4], mul_b[4], base[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u32 t = d[k] >> 29;                       // 4, 5: byte-local   6: forward chain   7: backward chain   0: evaluated
+    pos[k] = t >= 4u ? (d[k] & 0xffffu) : 0u;
+    const u32 tab13 = (d[k] >> 16) & 0x1fffu, fn15 = (d[k] >> 16) & 0x7fffu;
+    tabp[k] = t == 7u ? K.b_tab : (t == 6u ? K.f_tab : B.net_fn);
+    base[k] = t == 7u ? tab13 * K.b_smax * K.b_fdim * 256u : (t == 6u ? tab13 * K.f_smax * 256u : (t >= 4u ? fn15 * 256u : 0u));
+    mul_f[k] = t == 7u ? (pos[k] < K.f_end ? 256u : 0u) : (t == 6u ? 256u : 0u);    // weight of the forward state in the address
+    mul_b[k] = t == 7u ? K.b_fdim * 256u : 0u;                                       // weight of the backward state
+  }
+  auto one = [&](u32 e, u32 (&w)[4]) {
     const u8* msg = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
-    u32* img = B.small + (u64)e * s.img_small + s.m_net;
-    const u8* cstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st);
+    const u8* fstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st);
+    const u8* bstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_bst);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (d[k] >> 31)
-        img[r0 + 256u * (u32)k] = zk_net_desc_is_chain(d[k]) ? zk_net_chain_word(d[k], B.net_ctab, s.net_chain_smax, cstate, msg) : zk_net_local_word(d[k], B.net_fn, msg);
+      w[k] = tabp[k][base[k] + mul_b[k] * bstate[pos[k]] + mul_f[k] * fstate[pos[k]] + ((d[k] >> 31) ? (u32)msg[pos[k]] : 0u)];
+  };
+  auto put = [&](u32 e, const u32 (&w)[4]) {
+    u32* img = B.small + (u64)e * s.img_small + s.m_net;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (d[k] >> 31) img[r0 + 256u * (u32)k] = w[k];
+  };
+  const u32 e1 = e0 + ZKN_FILL_EMAILS < B.n_emails ? e0 + ZKN_FILL_EMAILS : B.n_emails;
+  u32 e = e0;
+  for (; e + 2 <= e1; e += 2) {
+    u32 wa[4], wb[4];
+    one(e, wa); one(e + 1, wb);
+    put(e, wa); put(e + 1, wb);
   }
+  if (e < e1) { u32 wa[4]; one(e, wa); put(e, wa); }
 }
 
-// zk_net_scan -- the collapsed state recurrence (zkwg_circom.h chainize): one lane per email walks
-// state' = delta[class of the position][state][byte] over the covered positions and leaves the state ENTERING every position in
-// the image, one byte each.  1,024 dependent table lookups per email (the tables stay in the vector cache: a few KB per class).
+// zk_net_scan -- the collapsed recurrences (zkwg_circom.h chain_pass): one lane per email walks
+// state' = delta[class of the position][state][symbol] forward over the bytes the forward chain covers, then backward over those of
+// the backward chain (whose symbol includes the forward state), and leaves the state ENTERING every position in the image, one
+// byte each.  ~2 N dependent table lookups per email (the tables stay in the cache: a few KB per class).
 __global__ __launch_bounds__(64) void zk_net_scan(ZkSched s, ZkBufs B) {
   const u32 e = blockIdx.x * 64u + threadIdx.x;
   if (e >= B.n_emails) return;
+  const ZkNetChains K = zk_net_chains(s, B);
   const u8* msg = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
-  u32* out = B.small + (u64)e * s.img_small + s.m_net_st;
-  const u32 end = s.net_chain_end, smax = s.net_chain_smax;
+  u32* fout = B.small + (u64)e * s.img_small + s.m_net_st;
   u32 st = 0;
-  for (u32 i = 0; i <= end; i += 4) {
+  for (u32 i = 0; i <= K.f_end && K.f_end; i += 4) {
     u32 b[4], packed = 0;
 #pragma unroll
-    for (u32 k = 0; k < 4; ++k) b[k] = i + k < end ? (u32)msg[i + k] : 0u;
+    for (u32 k = 0; k < 4; ++k) b[k] = i + k < K.f_end ? (u32)msg[i + k] : 0u;
 #pragma unroll
     for (u32 k = 0; k < 4; ++k) {
       packed |= st << (8u * k);
-      if (i + k < end) st = B.net_cdelta[((u32)B.net_cclass[i + k] * smax + st) * 256u + b[k]];
+      if (i + k < K.f_end) st = K.f_delta[((u32)K.f_cls[i + k] * K.f_smax + st) * 256u + b[k]];
     }
-    out[i >> 2] = packed;
+    fout[i >> 2] = packed;
+  }
+  if (!K.b_end) return;
+  u32* bout = B.small + (u64)e * s.img_small + s.m_net_bst;
+  const u8* fstate = (const u8*)fout;     // (this lane's own stores: program order)
+  const u32 lo = K.n_in - K.b_end;
+  u32 packed = 0;
+  st = 0;
+  for (u32 t = 0; t < K.b_end; ++t) {
+    const u32 p = K.n_in - 1u - t;
+    packed |= st << (8u * (p & 3u));
+    const u32 f = p < K.f_end ? (u32)fstate[p] : 0u;
+    st = K.b_delta[(((u32)K.b_cls[p] * K.b_smax + st) * K.b_fdim + f) * 256u + msg[p]];
+    if ((p & 3u) == 0u || p == lo) { bout[p >> 2] = packed; packed = 0; }
   }
 }

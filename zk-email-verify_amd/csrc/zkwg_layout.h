@@ -303,8 +303,11 @@ static inline void zk_alloc_bh_regex(ZkWalker& w, ZkSched& s, u32 N) {
     s.net_lds_masks = w.net->lds_masks; s.net_mask_words = w.net->mask_words; s.net_lanes = w.net->lanes;
     s.m_net = w.alloc_small(s.net_total + 1);   // + a scratch word for the evaluator's idle lanes
     s.m_net_out = w.alloc_small(1);
-    s.net_chain_end = w.net->chain_end; s.net_chain_smax = w.net->chain_smax; s.net_chain_mw = w.net->chain_mask_words;
-    s.m_net_st = w.net->chain_end ? w.alloc_small(N / 4 + 2) : 0;
+    s.net_chain_end = w.net->chain.end; s.net_chain_smax = w.net->chain.smax; s.net_chain_mw = w.net->chain.mask_words;
+    s.net_bchain_end = w.net->bchain.end; s.net_bchain_smax = w.net->bchain.smax; s.net_bchain_mw = w.net->bchain.mask_words;
+    s.net_bchain_fdim = w.net->bchain.fdim;
+    s.m_net_st = w.net->chain.end ? w.alloc_small(N / 4 + 2) : 0;
+    s.m_net_bst = w.net->bchain.end ? w.alloc_small(N / 4 + 2) : 0;
     s.m_dfa_own = s.m_dfa_st = s.m_dfa_cm = s.m_dfa_pm = s.m_dfa_acc = 0;
     return;
   }

@@ -26,13 +26,45 @@ ZK_HD int zk_net_decode(u32 w) { return (int)(w << 1) >> 1; }   // 31-bit two's 
 // not a gate of the list: its stored word comes from a 256-entry function table.  d = Net::slot_desc of the slot
 // (0x80000000 | function << 16 | byte index; 0 = a gate of the list writes the word).
 ZK_HD u32 zk_net_local_word(u32 d, const u32* fn_tab, const u8* msg) { return fn_tab[((d >> 16) & 0x7fffu) * 256u + msg[d & 0xffffu]]; }
-// A kept signal of the collapsed state recurrence (zkwg_circom.h chainize; d = 0xC0000000 | table << 16 | position): a function of
-// the chain state entering its position (zk_net_scan) and that position's byte.
-ZK_HD u32 zk_net_chain_word(u32 d, const u32* chain_tab, u32 smax, const u8* state, const u8* msg) {
-  const u32 pos = d & 0xffffu;
-  return chain_tab[(((d >> 16) & 0x3fffu) * smax + state[pos]) * 256u + msg[pos]];
+// A kept signal of a collapsed recurrence (zkwg_circom.h chain_pass; d = 0xC0000000 | table << 16 | byte index for the forward
+// chain, 0xE0000000 | ... for the backward one): a function of the chain state entering its position (zk_net_scan) and the
+// position's symbol -- its byte, and for the backward chain also the forward state there.
+struct ZkNetChains {
+  u32 n_in;
+  u32 f_end, f_smax, f_mw;            // forward chain: bytes [0, f_end)
+  u32 b_end, b_smax, b_mw, b_fdim;    // backward chain: bytes [n_in - b_end, n_in); b_fdim = f_smax (or 1)
+  const u8 *f_cls, *f_delta, *b_cls, *b_delta;
+  const u32 *f_mask, *f_tab, *b_mask, *b_tab;
+};
+ZK_HD u32 zk_net_fwd_row(const ZkNetChains& K, u32 pos, const u8* fstate, const u8* msg) {
+  return ((u32)K.f_cls[pos] * K.f_smax + fstate[pos]) * 256u + msg[pos];
 }
-ZK_HD bool zk_net_desc_is_chain(u32 d) { return (d >> 30) == 3u; }
+ZK_HD u32 zk_net_bwd_row(const ZkNetChains& K, u32 pos, const u8* fstate, const u8* bstate, const u8* msg) {
+  const u32 f = pos < K.f_end ? (u32)fstate[pos] : 0u;
+  return (((u32)K.b_cls[pos] * K.b_smax + bstate[pos]) * K.b_fdim + f) * 256u + msg[pos];
+}
+ZK_HD u32 zk_net_chain_word(u32 d, const ZkNetChains& K, const u8* fstate, const u8* bstate, const u8* msg) {
+  const u32 pos = d & 0xffffu, tab = (d >> 16) & 0x1fffu;
+  if ((d >> 29) == 7u) {
+    const u32 f = pos < K.f_end ? (u32)fstate[pos] : 0u;
+    return K.b_tab[((tab * K.b_smax + bstate[pos]) * K.b_fdim + f) * 256u + msg[pos]];
+  }
+  return K.f_tab[(tab * K.f_smax + fstate[pos]) * 256u + msg[pos]];
+}
+// the scans: the state entering every position, one byte each (fstate[0 .. f_end], bstate[n_in - b_end .. n_in - 1])
+ZK_HD void zk_net_scan_states(const ZkNetChains& K, const u8* msg, u8* fstate, u8* bstate) {
+  u32 st = 0;
+  for (u32 i = 0; i < K.f_end; ++i) { fstate[i] = (u8)st; st = K.f_delta[((u32)K.f_cls[i] * K.f_smax + st) * 256u + msg[i]]; }
+  if (K.f_end) fstate[K.f_end] = (u8)st;
+  st = 0;
+  for (u32 t = 0; t < K.b_end; ++t) {
+    const u32 p = K.n_in - 1u - t;
+    bstate[p] = (u8)st;
+    const u32 f = p < K.f_end ? (u32)fstate[p] : 0u;
+    st = K.b_delta[(((u32)K.b_cls[p] * K.b_smax + st) * K.b_fdim + f) * 256u + msg[p]];
+  }
+}
+ZK_HD bool zk_net_desc_is_chain(u32 d) { return (d >> 30) == 3u; }   // (either chain)
 
 // General path, exact in 64 bits: every record type.  `lds_r` / `lds`: the evaluator's LDS image for reads /
 // writes (the same memory on the device, where the 64 lanes of a step read before any of them writes; the

@@ -234,11 +234,14 @@ struct ZkSched {
   u32 net_lds_masks;     // zk_net_eval's LDS image: first word of the per-byte mask region (byte-local frontier bits, zkwg_circom.h localize)
   u32 net_mask_words;    // mask words per message byte (0: none)
   u32 net_lanes;         // lanes per email of zk_net_eval (64 / net_lanes emails per wavefront)
-  // the state recurrence of the template collapsed to a scan (zkwg_circom.h chainize; 0 positions: none)
-  u32 net_chain_end;     // positions [0, net_chain_end) are covered
-  u32 net_chain_smax;    // rows (states) of every chain table
-  u32 net_chain_mw;      // mask words per position served from the chain (after the net_mask_words byte-local ones)
-  u32 m_net_st;          // small: the chain state entering every position, one byte each (zk_net_scan)
+  // the recurrences of the template collapsed to scans (zkwg_circom.h chain_pass; 0 positions: none)
+  u32 net_chain_end;     // forward chain: bytes [0, net_chain_end)
+  u32 net_chain_smax;    // its states (rows of every table)
+  u32 net_chain_mw;      // mask words per position served from it (after the net_mask_words byte-local ones)
+  u32 m_net_st;          // small: the forward state entering every position, one byte each (zk_net_scan)
+  u32 net_bchain_end;    // backward chain: bytes [N - net_bchain_end, N)
+  u32 net_bchain_smax, net_bchain_mw, net_bchain_fdim;   // its states, mask words (after the forward chain's), symbols / 256
+  u32 m_net_bst;         // small: the backward state entering every position
   // RemoveSoftLineBreaks(max_body) (template flag removeSoftLineBreaks, email-verifier.circom:148-156)
   u32 rslb;              // 1: present
   u32 rs_nch;            // 2 * max_body / 16 Poseidon(16) chunks of PoseidonModular(2 * max_body)
@@ -288,10 +291,14 @@ struct ZkBufs {
   const u32* net_mask_tab; // loaded regex template: 256 x net_mask_words frontier masks by byte value
   const u32* net_fn;      // loaded regex template: byte-local function tables (256 stored words each)
   const u32* net_desc;    // loaded regex template: per kept slot 0 (evaluated), 0x80000000 | fn << 16 | byte index, or 0xC0000000 | table << 16 | position
-  const u8* net_cclass;   // chain: class of every position
-  const u8* net_cdelta;   // chain: [class][state][byte] next state
-  const u32* net_cmask;   // chain: [class][state][byte][net_chain_mw] mask words
-  const u32* net_ctab;    // chain: [table][state][byte] stored words
+  const u8* net_cclass;   // forward chain: class of every position
+  const u8* net_cdelta;   // [class][state][byte] next state
+  const u32* net_cmask;   // [class][state][byte][net_chain_mw] mask words
+  const u32* net_ctab;    // [table][state][byte] stored words
+  const u8* net_bclass;   // backward chain: the same with symbols (forward state, byte)
+  const u8* net_bdelta;
+  const u32* net_bmask;
+  const u32* net_btab;
   const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
   Fr* frm;               // Montgomery-form output: per email, Montgomery copies of its img_fr field elements, then of the record's ZK_MONT_LIMBS limbs
   const ZkSeg* segs;     // segment table
