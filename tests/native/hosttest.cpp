@@ -133,16 +133,12 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
   K.b_end = N.bchain.end; K.b_smax = N.bchain.smax; K.b_mw = N.bchain.mask_words; K.b_fdim = N.bchain.fdim;
   K.f_cls = N.chain.cls.data(); K.f_delta = N.chain.delta.data(); K.f_mask = N.chain.mask.data(); K.f_tab = N.chain.tab.data();
   K.b_cls = N.bchain.cls.data(); K.b_delta = N.bchain.delta.data(); K.b_mask = N.bchain.mask.data(); K.b_tab = N.bchain.tab.data();
-  std::vector<u8> fstate(N.n_in + 4, 0), bstate(N.n_in + 4, 0);
-  zk_net_scan_states(K, msg, fstate.data(), bstate.data());
+  std::vector<u32> fwords(N.n_in / 4 + 2, 0xa5a5a5a5u), bwords(N.n_in / 4 + 2, 0xa5a5a5a5u);   // (as in the image: stale bytes where no chain wrote)
+  zk_net_scan_email(K, msg, fwords.data(), bwords.data());
+  const u8* fstate = (const u8*)fwords.data(); const u8* bstate = (const u8*)bwords.data();
   const u32 MS = N.mask_words + K.f_mw + K.b_mw;
-  for (u32 i = 0; i < N.n_in; ++i) {        // the evaluator's prologue: per byte its mask words (byte-local frontier bits, then the chains')
-    int* mw = &lds[N.lds_masks + i * MS];
-    for (u32 m = 0; m < N.mask_words; ++m) mw[m] = (int)N.mask_tab[(size_t)msg[i] * N.mask_words + m];
-    for (u32 m = 0; m < K.f_mw; ++m) mw[N.mask_words + m] = i < K.f_end ? (int)K.f_mask[(size_t)zk_net_fwd_row(K, i, fstate.data(), msg) * K.f_mw + m] : 0;
-    for (u32 m = 0; m < K.b_mw; ++m)
-      mw[N.mask_words + K.f_mw + m] = i + K.b_end >= N.n_in ? (int)K.b_mask[(size_t)zk_net_bwd_row(K, i, fstate.data(), bstate.data(), msg) * K.b_mw + m] : 0;
-  }
+  for (u32 i = 0; i < N.n_in; ++i)          // the evaluator's prologue: per byte its mask words (byte-local frontier bits, then the chains')
+    zk_net_mask_words(K, N.mask_words, N.mask_tab.data(), i, msg, fstate, bstate, &lds[N.lds_masks + i * MS]);
   std::vector<u32> img(N.n_kept + N.n_temp, 0xdeadbeefu);
   bool ok = true;
   size_t g = 0;
@@ -156,12 +152,16 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
     }
   }
   memcpy(words, img.data(), (size_t)N.n_kept * 4);
-  // byte-local kept signals are not gates of the list: zk_net_fill (zkwg_kernels_net.hip) writes their words from the function tables
-  for (u32 r = 0; r < N.n_kept; ++r) {
-    const u32 d = N.slot_desc[r];
-    if (zk_net_desc_is_chain(d)) words[r] = zk_net_chain_word(d, K, fstate.data(), bstate.data(), msg);
-    else if (d >> 31) words[r] = zk_net_local_word(d, N.fn_tab.data(), msg);
-  }
+  // byte-local and chain kept signals are not gates of the list: zk_net_fill (zkwg_kernels_net.hip) writes their words, thread by thread
+  for (u32 blk = 0; blk * 1024u < N.n_kept; ++blk)
+    for (u32 tid = 0; tid < 256; ++tid) {
+      ZkNetFillLane F;
+      const u32 r0 = blk * 1024u + tid;
+      if (!F.init(N.slot_desc.data(), N.n_kept, r0, N.fn_tab.data(), K)) continue;
+      u32 w[4];
+      F.load(msg, fstate, bstate, w);
+      F.store(words, r0, w);
+    }
   return ok ? 1 : 0;
 }
 }

@@ -87,6 +87,7 @@ struct zkwg_circuit {
   int pos_side;   // 1: fork zk_poseidon9 onto a side stream (ZKWG_POS_SIDE=1); default 0 = caller's stream
   int pos_lane;   // 1: the lane-per-email zk_poseidon9 of round 2 instead of zk_poseidon9_g16 (ZKWG_POS_LANE=1)
   int pos_wave_below;   // batches below this many emails use the wavefront-per-email kernel (ZKWG_POS_WAVE_BELOW, default 1024)
+  int net_fill_late;   // loaded regex template: zk_net_fill runs in front of every expansion, on its stream, instead of in prepare (ZKWG_NET_FILL_LATE)
   u32 xcd_remap;  // zk_expand workgroup -> portion mapping (ZKWG_XCD_REMAP)
   // host-buffer path: cached device staging buffers (double-buffered witnesses)
   std::mutex hb_mutex;
@@ -259,6 +260,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 1);   // (round 4: 8 KiB pieces, 53 VGPRs = 8 wavefronts per SIMD, software-pipelined over the group's emails)
   c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 16;
   c->o0_pipe = getenv("ZKWG_O0_PIPE") ? atoi(getenv("ZKWG_O0_PIPE")) : 2;
+  c->net_fill_late = getenv("ZKWG_NET_FILL_LATE") ? atoi(getenv("ZKWG_NET_FILL_LATE")) : 0;
   c->xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
   c->rsa_wgs_per_cu = 0;
   if (const char* v = getenv("ZKWG_RSA_WGS_PER_CU")) c->rsa_wgs_per_cu = atoi(v);
@@ -796,6 +798,9 @@ int zkwg_timing_summary(zkwg_circuit_t* c, int which, float* total_ms, uint32_t*
   return ZKWG_RC_OK;
 }
 
+// (opt-in, ZKWG_NET_FILL_LATE) the table-served slots of a loaded regex template are written in front of every expansion instead of
+// in prepare -- not for handles whose prepare already reads the region (the row kernels of numbered circuits / attached systems)
+static inline bool net_fill_late(const zkwg_circuit* c) { return c->net_fill_late && !c->full_W && !c->abc_m; }
 static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n, void* d_scratch) {
   const ZkSched& s = c->s;
   u8* scr = (u8*)d_scratch;
@@ -919,7 +924,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       static const int skip = getenv("ZKWG_DEBUG_NET_SKIP") ? atoi(getenv("ZKWG_DEBUG_NET_SKIP")) : 0;   // (timing experiments only: wrong witnesses)
       if (s.net_chain_end && !(skip & 1)) hipLaunchKernelGGL(zk_net_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // chain states first: the list's mask words need them
       if (!(skip & 2)) hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
-      if (!(skip & 4)) hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (ne + 7) / 8), dim3(256), 0, st, s, B);   // byte-local slots (timed with the evaluator)
+      if (!(skip & 4) && !net_fill_late(c)) hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (ne + 7) / 8), dim3(256), 0, st, s, B);   // byte-local slots (timed with the evaluator)
     }
     if (tm) hipEventRecord(evs[++ki], st);
   }
@@ -1038,6 +1043,10 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
     B.n_emails = (u32)(first + off + cnt);
     ZkX3 A;
     fill_x3(c, B, A);
+    // (opt-in) the table-served slots of a loaded regex template for exactly these emails, in front of their expansion and on its
+    // stream: a memory-bound kernel that then no longer runs beside the store stream
+    if (s.net_mode && net_fill_late(c))
+      hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (u32)((cnt + 7) / 8)), dim3(256), 0, st, s, B);
     const u64 conv = cnt * (u64)(s.img_fr + ZK_MONT_LIMBS);
     if (OD) {
       // numbered circuit (`--O0` / `--O1`), one pass: the rows that are real sums go into the image extensions of these
@@ -1422,6 +1431,7 @@ int zkwg_set_host_expand(zkwg_circuit_t* c, int threads) {
 static int calculate_batch_hostexpand(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
                                       uint64_t out_stride, int32_t* status, uint64_t max_tile) {
   const ZkSched& s = c->s;
+  if (s.net_mode && net_fill_late(c)) { g_last_error = "host expansion reads the image straight after prepare: unset ZKWG_NET_FILL_LATE"; return ZKWG_RC_BAD_CONFIG; }
   if (hipSetDevice(c->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   const u64 tile = std::min<u64>(max_tile ? max_tile : 256, n);
   const u64 scr_bytes = zkwg_scratch_bytes(c, tile);

@@ -47,20 +47,8 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   const u8* fstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st);
   const u8* bstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_bst);
   for (u32 i = gl; i < N; i += L) {
-    const u32 b = rec[i];
-    lds[msg_base + i] = (int)b;
-    int* mw = &lds[s.net_lds_masks + i * MS];
-    for (u32 m = 0; m < MW; ++m) mw[m] = (int)B.net_mask_tab[b * MW + m];
-    if (K.f_mw) {
-      const bool in = i < K.f_end;
-      const u32 row = in ? zk_net_fwd_row(K, i, fstate, rec) * K.f_mw : 0u;
-      for (u32 m = 0; m < K.f_mw; ++m) mw[MW + m] = in ? (int)K.f_mask[row + m] : 0;
-    }
-    if (K.b_mw) {
-      const bool in = i + K.b_end >= N;
-      const u32 row = in ? zk_net_bwd_row(K, i, fstate, bstate, rec) * K.b_mw : 0u;
-      for (u32 m = 0; m < K.b_mw; ++m) mw[MW + K.f_mw + m] = in ? (int)K.b_mask[row + m] : 0;
-    }
+    lds[msg_base + i] = (int)rec[i];
+    zk_net_mask_words(K, MW, B.net_mask_tab, i, rec, fstate, bstate, &lds[s.net_lds_masks + i * MS]);
   }
   if (gl == 0) lds[msg_base + N] = 0;
   const u32 scratch = msg_base + N + 1u;
@@ -133,38 +121,15 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
 // (One thread per slot and email -- 578 k tiny workgroups per 1,024 emails -- took 10 ms beside the high-priority store stream.)
 #define ZKN_FILL_EMAILS 8
 __global__ __launch_bounds__(256) void zk_net_fill(ZkSched s, ZkBufs B) {
-  const u32 r0 = blockIdx.x * 1024u + threadIdx.x, e0 = blockIdx.y * ZKN_FILL_EMAILS;
-  u32 d[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { const u32 r = r0 + 256u * (u32)k; d[k] = r < s.net_kept ? B.net_desc[r] : 0u; }
-  if (!((d[0] | d[1] | d[2] | d[3]) >> 31)) return;
+  const u32 r0 = blockIdx.x * 1024u + threadIdx.x, e0 = B.e_first + blockIdx.y * ZKN_FILL_EMAILS;   // emails [B.e_first, B.n_emails)
   const ZkNetChains K = zk_net_chains(s, B);
-  // branch-free: every slot forms one table address (function table, forward or backward chain table -- an evaluated slot reads
-  // word 0 of the function tables and stores nothing), so the 4 x 2 lookups of an iteration are in flight together
-  const u32* tabp[4]; u32 pos[4], mul_f[4], mul_b[4], base[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const u32 t = d[k] >> 29;                       // 4, 5: byte-local   6: forward chain   7: backward chain   0: evaluated
-    pos[k] = t >= 4u ? (d[k] & 0xffffu) : 0u;
-    const u32 tab13 = (d[k] >> 16) & 0x1fffu, fn15 = (d[k] >> 16) & 0x7fffu;
-    tabp[k] = t == 7u ? K.b_tab : (t == 6u ? K.f_tab : B.net_fn);
-    base[k] = t == 7u ? tab13 * K.b_smax * K.b_fdim * 256u : (t == 6u ? tab13 * K.f_smax * 256u : (t >= 4u ? fn15 * 256u : 0u));
-    mul_f[k] = t == 7u ? (pos[k] < K.f_end ? 256u : 0u) : (t == 6u ? 256u : 0u);    // weight of the forward state in the address
-    mul_b[k] = t == 7u ? K.b_fdim * 256u : 0u;                                       // weight of the backward state
-  }
+  ZkNetFillLane F;
+  if (!F.init(B.net_desc, s.net_kept, r0, B.net_fn, K)) return;
   auto one = [&](u32 e, u32 (&w)[4]) {
-    const u8* msg = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
-    const u8* fstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st);
-    const u8* bstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_bst);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      w[k] = tabp[k][base[k] + mul_b[k] * bstate[pos[k]] + mul_f[k] * fstate[pos[k]] + ((d[k] >> 31) ? (u32)msg[pos[k]] : 0u)];
+    F.load(B.in + (u64)e * s.in_stride + s.fr[0].in_data, (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st),
+           (const u8*)(B.small + (u64)e * s.img_small + s.m_net_bst), w);
   };
-  auto put = [&](u32 e, const u32 (&w)[4]) {
-    u32* img = B.small + (u64)e * s.img_small + s.m_net;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (d[k] >> 31) img[r0 + 256u * (u32)k] = w[k];
-  };
+  auto put = [&](u32 e, const u32 (&w)[4]) { F.store(B.small + (u64)e * s.img_small + s.m_net, r0, w); };
   const u32 e1 = e0 + ZKN_FILL_EMAILS < B.n_emails ? e0 + ZKN_FILL_EMAILS : B.n_emails;
   u32 e = e0;
   for (; e + 2 <= e1; e += 2) {
@@ -182,32 +147,6 @@ __global__ __launch_bounds__(256) void zk_net_fill(ZkSched s, ZkBufs B) {
 __global__ __launch_bounds__(64) void zk_net_scan(ZkSched s, ZkBufs B) {
   const u32 e = blockIdx.x * 64u + threadIdx.x;
   if (e >= B.n_emails) return;
-  const ZkNetChains K = zk_net_chains(s, B);
-  const u8* msg = B.in + (u64)e * s.in_stride + s.fr[0].in_data;
-  u32* fout = B.small + (u64)e * s.img_small + s.m_net_st;
-  u32 st = 0;
-  for (u32 i = 0; i <= K.f_end && K.f_end; i += 4) {
-    u32 b[4], packed = 0;
-#pragma unroll
-    for (u32 k = 0; k < 4; ++k) b[k] = i + k < K.f_end ? (u32)msg[i + k] : 0u;
-#pragma unroll
-    for (u32 k = 0; k < 4; ++k) {
-      packed |= st << (8u * k);
-      if (i + k < K.f_end) st = K.f_delta[((u32)K.f_cls[i + k] * K.f_smax + st) * 256u + b[k]];
-    }
-    fout[i >> 2] = packed;
-  }
-  if (!K.b_end) return;
-  u32* bout = B.small + (u64)e * s.img_small + s.m_net_bst;
-  const u8* fstate = (const u8*)fout;     // (this lane's own stores: program order)
-  const u32 lo = K.n_in - K.b_end;
-  u32 packed = 0;
-  st = 0;
-  for (u32 t = 0; t < K.b_end; ++t) {
-    const u32 p = K.n_in - 1u - t;
-    packed |= st << (8u * (p & 3u));
-    const u32 f = p < K.f_end ? (u32)fstate[p] : 0u;
-    st = K.b_delta[(((u32)K.b_cls[p] * K.b_smax + st) * K.b_fdim + f) * 256u + msg[p]];
-    if ((p & 3u) == 0u || p == lo) { bout[p >> 2] = packed; packed = 0; }
-  }
+  zk_net_scan_email(zk_net_chains(s, B), B.in + (u64)e * s.in_stride + s.fr[0].in_data, B.small + (u64)e * s.img_small + s.m_net_st,
+                    B.small + (u64)e * s.img_small + s.m_net_bst);
 }

@@ -51,19 +51,78 @@ ZK_HD u32 zk_net_chain_word(u32 d, const ZkNetChains& K, const u8* fstate, const
   }
   return K.f_tab[(tab * K.f_smax + fstate[pos]) * 256u + msg[pos]];
 }
-// the scans: the state entering every position, one byte each (fstate[0 .. f_end], bstate[n_in - b_end .. n_in - 1])
-ZK_HD void zk_net_scan_states(const ZkNetChains& K, const u8* msg, u8* fstate, u8* bstate) {
+// The bodies of zk_net_scan, zk_net_fill and zk_net_eval's mask prologue (zkwg_kernels_net.hip), shared with the host mirror of
+// the CPU tests (tests/native/hosttest.cpp runs exactly this code).
+//
+// zk_net_scan: the state entering every position, one byte each, packed four to a word
+// (fstate bytes [0 .. f_end], bstate bytes [n_in - b_end .. n_in - 1]).
+ZK_HD void zk_net_scan_email(const ZkNetChains& K, const u8* msg, u32* fout, u32* bout) {
   u32 st = 0;
-  for (u32 i = 0; i < K.f_end; ++i) { fstate[i] = (u8)st; st = K.f_delta[((u32)K.f_cls[i] * K.f_smax + st) * 256u + msg[i]]; }
-  if (K.f_end) fstate[K.f_end] = (u8)st;
+  for (u32 i = 0; i <= K.f_end && K.f_end; i += 4) {
+    u32 b[4], packed = 0;
+    for (u32 k = 0; k < 4; ++k) b[k] = i + k < K.f_end ? (u32)msg[i + k] : 0u;
+    for (u32 k = 0; k < 4; ++k) {
+      packed |= st << (8u * k);
+      if (i + k < K.f_end) st = K.f_delta[((u32)K.f_cls[i + k] * K.f_smax + st) * 256u + b[k]];
+    }
+    fout[i >> 2] = packed;
+  }
+  if (!K.b_end) return;
+  const u8* fstate = (const u8*)fout;     // (this lane's own stores: program order)
+  const u32 lo = K.n_in - K.b_end;
+  u32 packed = 0;
   st = 0;
   for (u32 t = 0; t < K.b_end; ++t) {
     const u32 p = K.n_in - 1u - t;
-    bstate[p] = (u8)st;
+    packed |= st << (8u * (p & 3u));
     const u32 f = p < K.f_end ? (u32)fstate[p] : 0u;
     st = K.b_delta[(((u32)K.b_cls[p] * K.b_smax + st) * K.b_fdim + f) * 256u + msg[p]];
+    if ((p & 3u) == 0u || p == lo) { bout[p >> 2] = packed; packed = 0; }
   }
 }
+// zk_net_eval's prologue: the mask words of position i (mw[0 .. MW + f_mw + b_mw)): the byte-local frontier bits, then the chains'
+ZK_HD void zk_net_mask_words(const ZkNetChains& K, u32 MW, const u32* mask_tab, u32 i, const u8* msg, const u8* fstate, const u8* bstate, int* mw) {
+  const u32 b = msg[i];
+  for (u32 m = 0; m < MW; ++m) mw[m] = (int)mask_tab[b * MW + m];
+  if (K.f_mw) {
+    const bool in = i < K.f_end;
+    const u32 row = in ? zk_net_fwd_row(K, i, fstate, msg) * K.f_mw : 0u;
+    for (u32 m = 0; m < K.f_mw; ++m) mw[MW + m] = in ? (int)K.f_mask[row + m] : 0;
+  }
+  if (K.b_mw) {
+    const bool in = i + K.b_end >= K.n_in;
+    const u32 row = in ? zk_net_bwd_row(K, i, fstate, bstate, msg) * K.b_mw : 0u;
+    for (u32 m = 0; m < K.b_mw; ++m) mw[MW + K.f_mw + m] = in ? (int)K.b_mask[row + m] : 0;
+  }
+}
+// zk_net_fill: one thread's four slots r0, r0 + 256, ... -- branch-free: every slot forms one table address (function table,
+// forward or backward chain table; an evaluated slot reads word 0 of the function tables and stores nothing), so the lookups of
+// several emails can be in flight together
+struct ZkNetFillLane {
+  u32 d[4], pos[4], mul_f[4], mul_b[4], base[4];
+  const u32* tabp[4];
+  ZK_HD bool init(const u32* desc, u32 n_kept, u32 r0, const u32* fn_tab, const ZkNetChains& K) {
+    for (int k = 0; k < 4; ++k) {
+      const u32 r = r0 + 256u * (u32)k;
+      d[k] = r < n_kept ? desc[r] : 0u;
+      const u32 t = d[k] >> 29;                       // 4: byte-local   6: forward chain   7: backward chain   0: evaluated
+      pos[k] = t >= 4u ? (d[k] & 0xffffu) : 0u;
+      const u32 tab13 = (d[k] >> 16) & 0x1fffu;
+      tabp[k] = t == 7u ? K.b_tab : (t == 6u ? K.f_tab : fn_tab);
+      base[k] = t == 7u ? tab13 * K.b_smax * K.b_fdim * 256u : (t == 6u ? tab13 * K.f_smax * 256u : (t >= 4u ? tab13 * 256u : 0u));
+      mul_f[k] = t == 7u ? (pos[k] < K.f_end ? 256u : 0u) : (t == 6u ? 256u : 0u);    // weight of the forward state in the address
+      mul_b[k] = t == 7u ? K.b_fdim * 256u : 0u;                                       // weight of the backward state
+    }
+    return ((d[0] | d[1] | d[2] | d[3]) >> 31) != 0u;
+  }
+  ZK_HD void load(const u8* msg, const u8* fstate, const u8* bstate, u32 (&w)[4]) const {
+    for (int k = 0; k < 4; ++k)
+      w[k] = tabp[k][base[k] + mul_b[k] * bstate[pos[k]] + mul_f[k] * fstate[pos[k]] + ((d[k] >> 31) ? (u32)msg[pos[k]] : 0u)];
+  }
+  ZK_HD void store(u32* img, u32 r0, const u32 (&w)[4]) const {
+    for (int k = 0; k < 4; ++k) if (d[k] >> 31) img[r0 + 256u * (u32)k] = w[k];
+  }
+};
 ZK_HD bool zk_net_desc_is_chain(u32 d) { return (d >> 30) == 3u; }   // (either chain)
 
 // General path, exact in 64 bits: every record type.  `lds_r` / `lds`: the evaluator's LDS image for reads /
