@@ -93,6 +93,43 @@ def test_stand_in_template_through_the_product_loader_equals_the_interpreter():
     assert all(ref2["main" + k] == v for k, v in vals.items())
 
 
+def _messages(n, seed, count):
+    """headers around HDR: the valid one, truncations, byte flips, splices of its own pieces, random bytes -- so that the scans
+    visit many (state, byte) pairs, restarts from state 0 and dead ends"""
+    rng = random.Random(seed)
+    out = [HDR, b"", HDR[:40], HDR * 2, b"\r\n" + HDR]
+    alphabet = b"abz09+/=;: \r\n-" + bytes([0, 255])
+    for _ in range(count):
+        m = bytearray(HDR)
+        for _ in range(rng.randrange(1, 6)):
+            k = rng.randrange(4)
+            if k == 0: m[rng.randrange(len(m))] = rng.choice(alphabet)
+            elif k == 1: del m[rng.randrange(len(m))]
+            elif k == 2: i = rng.randrange(len(m)); m[i:i] = HDR[rng.randrange(len(HDR)):][:rng.randrange(1, 30)]
+            else: i = rng.randrange(len(m)); m[i:i] = bytes(rng.choice(alphabet) for _ in range(rng.randrange(1, 8)))
+        out.append(bytes(m[:n]))
+    out.append(bytes(rng.randrange(256) for _ in range(n)))
+    return out
+
+
+@pytest.mark.parametrize("path,n", [(STAND_IN, 192), (STAND_IN, 1024),
+                                    (os.path.join(ROOT, "tests", "golden", "regex_style", "body_hash_regex_unshared.circom"), 256)])
+def test_chain_tables_give_the_same_values_as_the_plain_gate_list(monkeypatch, path, n):
+    """zkwg_circom.h chain_pass: with both recurrences served from scan tables (default), with the forward one only
+    (ZKWG_NET_CHAIN=1) and with every gate in the list (ZKWG_NET_CHAIN=0) the loader produces the same kept signals and the host
+    mirror of zk_net_scan / zk_net_fill / zk_net_eval the same values, outputs and assertion results on 60 mutated headers."""
+    regs = {}
+    for mode in ("0", "1", None):
+        if mode is None: monkeypatch.delenv("ZKWG_NET_CHAIN", raising=False)
+        else: monkeypatch.setenv("ZKWG_NET_CHAIN", mode)
+        regs[mode] = hosttest.LoadedRegex(path, n)
+    assert regs["0"].names == regs["1"].names == regs[None].names
+    for msg in _messages(n, 7 * n, 55):
+        ref = regs["0"].evaluate(msg)
+        assert regs["1"].evaluate(msg) == ref, msg
+        assert regs[None].evaluate(msg) == ref, msg
+
+
 def test_product_side_copy_of_the_stand_in_is_current():
     base = os.path.join(ROOT, "zk-email-verify_amd", "data", "templates", "zk-regex-circom", "circuits")
     lib = os.path.dirname(os.path.dirname(STAND_IN))

@@ -921,10 +921,9 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     if (4u * s.net_lds_words * ew + 16 > 48u * 1024u)   // (gfx950: 160 KB of LDS per CU; the default per-workgroup cap is lower)
       hipFuncSetAttribute((const void*)zk_net_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u * s.net_lds_words * ew + 16));
     if (pm & 4u) {
-      static const int skip = getenv("ZKWG_DEBUG_NET_SKIP") ? atoi(getenv("ZKWG_DEBUG_NET_SKIP")) : 0;   // (timing experiments only: wrong witnesses)
-      if (s.net_chain_end && !(skip & 1)) hipLaunchKernelGGL(zk_net_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // chain states first: the list's mask words need them
-      if (!(skip & 2)) hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
-      if (!(skip & 4) && !net_fill_late(c)) hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (ne + 7) / 8), dim3(256), 0, st, s, B);   // byte-local slots (timed with the evaluator)
+      if (s.net_chain_end) hipLaunchKernelGGL(zk_net_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // chain states first: the list's mask words need them
+      hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
+      if (!net_fill_late(c)) hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (ne + 7) / 8), dim3(256), 0, st, s, B);   // table-served slots (timed with the evaluator)
     }
     if (tm) hipEventRecord(evs[++ki], st);
   }
