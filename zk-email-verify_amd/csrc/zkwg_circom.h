@@ -1903,67 +1903,110 @@ struct Elab {
     }
     const u32 smax = *std::max_element(core_of.begin(), core_of.end()) + 1;
     const u32 mw = (max_bits + ZKC_MASK_BITS - 1) / ZKC_MASK_BITS;
+    // Classes -> groups.  Two descriptors can differ and still describe the same functions (the first positions of a message cut
+    // their long sums into partial sums differently: other temporaries, same signals); their cells -- (core state, symbol) ->
+    // next state, the kept gates' words in order, the list-read booleans in order -- then agree wherever both were tabulated, and
+    // one set of tables serves both (a cell only one of them reached is taken from that one: the other never looks it up).
+    struct Cells {
+      u32 nkept = 0, ncf = 0;
+      std::vector<u8> set, delta, cb;   // [core][symbol]; cb: [cf gate][core][symbol]
+      std::vector<u32> kw;              // [kept gate][core][symbol]
+    };
+    const size_t CELLS = (size_t)smax * NSYM;
+    std::vector<int> rep(classes.size(), -1);
+    for (u32 i = 0; i < end; ++i) if (rep[cls_of[i]] < 0) rep[cls_of[i]] = (int)i;
+    std::vector<Cells> groups;
+    std::vector<u32> group_of(classes.size(), 0);
+    for (size_t c = 0; c < classes.size(); ++c) {
+      const Class& C = classes[c];
+      const std::vector<u32>& Bk = blk[rep[c]];
+      Cells X;
+      for (u32 g : Bk) { if (gates[g].slot < net.n_kept) ++X.nkept; if (cf[g]) ++X.ncf; }
+      X.set.assign(CELLS, 0); X.delta.assign(CELLS, 0); X.kw.assign(X.nkept * CELLS, 0); X.cb.assign(X.ncf * CELLS, 0);
+      for (u32 st = 0; st < C.have.size(); ++st) {
+        if (!C.have[st]) continue;
+        for (u32 y = 0; y < NSYM; ++y) {
+          if (!C.valid[st][y]) continue;
+          const size_t cell = (size_t)core_of[st] * NSYM + y;
+          X.set[cell] = 1; X.delta[cell] = (u8)core_of[C.delta[st][y]];
+          u32 jk = 0, jq = 0;
+          for (u32 k = 0; k < Bk.size(); ++k) {
+            const u32 w = C.words[st][(size_t)k * NSYM + y];
+            if (gates[Bk[k]].slot < net.n_kept) X.kw[jk++ * CELLS + cell] = w;
+            if (cf[Bk[k]]) X.cb[jq++ * CELLS + cell] = (u8)(w & 1u);
+          }
+        }
+      }
+      int into = -1;
+      for (size_t gi = 0; gi < groups.size() && into < 0; ++gi) {
+        const Cells& G = groups[gi];
+        if (G.nkept != X.nkept || G.ncf != X.ncf) continue;
+        bool same = true;
+        for (size_t cell = 0; cell < CELLS && same; ++cell) {
+          if (!G.set[cell] || !X.set[cell]) continue;
+          same = G.delta[cell] == X.delta[cell];
+          for (u32 q = 0; q < X.nkept && same; ++q) same = G.kw[q * CELLS + cell] == X.kw[q * CELLS + cell];
+          for (u32 q = 0; q < X.ncf && same; ++q) same = G.cb[q * CELLS + cell] == X.cb[q * CELLS + cell];
+        }
+        if (same) into = (int)gi;
+      }
+      if (into < 0) { group_of[c] = (u32)groups.size(); groups.push_back(std::move(X)); continue; }
+      Cells& G = groups[into];
+      for (size_t cell = 0; cell < CELLS; ++cell) {
+        if (G.set[cell] || !X.set[cell]) continue;
+        G.set[cell] = 1; G.delta[cell] = X.delta[cell];
+        for (u32 q = 0; q < X.nkept; ++q) G.kw[q * CELLS + cell] = X.kw[q * CELLS + cell];
+        for (u32 q = 0; q < X.ncf; ++q) G.cb[q * CELLS + cell] = X.cb[q * CELLS + cell];
+      }
+      group_of[c] = (u32)into;
+    }
     {
       // the tables are looked up once per slot and email: they have to stay cache-sized
-      size_t kept_gates = 0;
-      for (size_t c = 0; c < classes.size(); ++c) kept_gates += classes[c].words.empty() ? 0 : classes[c].words.back().size() / NSYM;
-      if ((kept_gates * 4 + classes.size() * (1 + 4 * mw)) * smax * NSYM > (64u << 20)) return give_up("the tables would not stay in the cache");
+      size_t words = 0;
+      for (const Cells& G : groups) words += (size_t)G.nkept + 1 + mw;
+      if (words * CELLS * 4 > (64u << 20)) return give_up("the tables would not stay in the cache");
     }
-    T.end = end; T.smax = smax; T.classes = (u32)classes.size(); T.mask_words = mw; T.fdim = fdim;
-    T.cls = class_at; T.reach_bits = reach_bits;
-    T.delta.assign((size_t)classes.size() * smax * NSYM, 0);
-    T.mask.assign((size_t)classes.size() * smax * NSYM * mw, 0);
-    for (size_t c = 0; c < classes.size(); ++c)
-      for (u32 st = 0; st < classes[c].have.size(); ++st)
-        if (classes[c].have[st])
-          for (u32 y = 0; y < NSYM; ++y)
-            if (classes[c].valid[st][y]) T.delta[((size_t)c * smax + core_of[st]) * NSYM + y] = (u8)core_of[classes[c].delta[st][y]];
+    T.end = end; T.smax = smax; T.classes = (u32)groups.size(); T.mask_words = mw; T.fdim = fdim;
+    T.reach_bits = reach_bits;
+    T.cls.assign(N, 0);
+    T.delta.assign(groups.size() * CELLS, 0);
+    T.mask.assign(groups.size() * CELLS * mw, 0);
     std::map<std::vector<u32>, u32> tab_of;     // table content -> index
-    std::vector<std::vector<int>> fn_of(classes.size());   // [class][block index] -> table (filled on demand)
-    std::vector<u8> masked(classes.size(), 0);
-    const size_t tab_words = (size_t)smax * NSYM;
-    for (u32 i = 0; i < end; ++i) {
-      const u32 c = cls_of[i], at = (u32)tp((int)i);
-      const Class& C = classes[c];
-      if (fn_of[c].empty()) fn_of[c].assign(blk[i].size(), -1);
-      u32 bit = 0;
-      for (u32 k = 0; k < blk[i].size(); ++k) {
-        const u32 g = blk[i][k];
-        g_chain[g] = (u8)(1 + pass); ++T.n_gates;
-        if (cf[g]) {
-          // bit `bit` of the position's chain mask words
-          cbit[g] = (int)bit; g_fpos[g] = (int)at; ++T.n_front;
-          if (!masked[c])
-            for (u32 st = 0; st < C.have.size(); ++st)
-              if (C.have[st])
-                for (u32 y = 0; y < NSYM; ++y)
-                  if (C.valid[st][y] && (C.words[st][(size_t)k * NSYM + y] & 1u))
-                    T.mask[(((size_t)c * smax + core_of[st]) * NSYM + y) * mw + bit / ZKC_MASK_BITS] |= 1u << (bit % ZKC_MASK_BITS);
-          ++bit;
+    std::vector<std::vector<u32>> fn_of(groups.size());   // [group][kept gate] -> table
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      const Cells& G = groups[gi];
+      std::copy(G.delta.begin(), G.delta.end(), T.delta.begin() + gi * CELLS);
+      for (u32 q = 0; q < G.ncf; ++q)
+        for (size_t cell = 0; cell < CELLS; ++cell)
+          if (G.cb[q * CELLS + cell]) T.mask[(gi * CELLS + cell) * mw + q / ZKC_MASK_BITS] |= 1u << (q % ZKC_MASK_BITS);
+      for (u32 q = 0; q < G.nkept; ++q) {
+        std::vector<u32> w(G.kw.begin() + q * CELLS, G.kw.begin() + (q + 1) * CELLS);
+        auto it = tab_of.find(w);
+        if (it == tab_of.end()) {
+          it = tab_of.emplace(w, (u32)(T.tab.size() / CELLS)).first;
+          T.tab.insert(T.tab.end(), w.begin(), w.end());
         }
-        if (gates[g].slot >= net.n_kept) continue;
+        if (it->second >= 0x1fffu) fail("too many distinct chain tables in the regex template");
+        fn_of[gi].push_back(it->second);
+      }
+    }
+    const size_t tab_words = CELLS;
+    for (u32 i = 0; i < end; ++i) {
+      const u32 gi = group_of[cls_of[i]], at = (u32)tp((int)i);
+      if (at >= 0x10000) fail("the regex template's message is too long for the chain tables");
+      T.cls[at] = (u8)gi;
+      u32 jk = 0, jq = 0;
+      for (u32 g : blk[i]) {
+        g_chain[g] = (u8)(1 + pass); ++T.n_gates;
+        if (cf[g]) { cbit[g] = (int)jq++; g_fpos[g] = (int)at; ++T.n_front; }     // bit of the position's chain mask words
         // (a gate the list reads keeps a BIT record there, which writes the same word; it gets its table all the same, so that it can
         // leave the list when a later pass takes its readers)
-        if (fn_of[c][k] < 0) {
-          std::vector<u32> w(tab_words, 0);
-          for (u32 st = 0; st < C.have.size(); ++st)
-            if (C.have[st])
-              for (u32 y = 0; y < NSYM; ++y) if (C.valid[st][y]) w[(size_t)core_of[st] * NSYM + y] = C.words[st][(size_t)k * NSYM + y];
-          auto it = tab_of.find(w);
-          if (it == tab_of.end()) {
-            it = tab_of.emplace(w, (u32)(T.tab.size() / tab_words)).first;
-            T.tab.insert(T.tab.end(), w.begin(), w.end());
-          }
-          fn_of[c][k] = (int)it->second;
-        }
-        if (fn_of[c][k] >= 0x1fff || at >= 0x10000) fail("too many distinct chain tables in the regex template");
-        net.slot_desc[gates[g].slot] = (bwd ? 0xE0000000u : 0xC0000000u) | ((u32)fn_of[c][k] << 16) | at;
+        if (gates[g].slot < net.n_kept) net.slot_desc[gates[g].slot] = (bwd ? 0xE0000000u : 0xC0000000u) | (fn_of[gi][jk++] << 16) | at;
       }
-      masked[c] = 1;
     }
     if (dbg)
-      fprintf(stderr, "[zkwg] %s: %u positions collapsed: %u gates (%u read by the list through %u mask word(s)), %zu classes, <= %u states x %u symbols, %zu tables (%.1f MB)\n",
-              tag, end, T.n_gates, T.n_front, mw, classes.size(), smax, NSYM, T.tab.size() / tab_words, T.tab.size() * 4 / 1e6);
+      fprintf(stderr, "[zkwg] %s: %u positions collapsed: %u gates (%u read by the list through %u mask word(s)), %zu descriptors in %zu classes, <= %u states x %u symbols, %zu tables (%.1f MB)\n",
+              tag, end, T.n_gates, T.n_front, mw, classes.size(), groups.size(), smax, NSYM, T.tab.size() / tab_words, T.tab.size() * 4 / 1e6);
     return 1;
   }
 
