@@ -1,5 +1,6 @@
 // Host-side schedule construction: zkwg_config -> ZkSched + segment table.
 #pragma once
+#include <chrono>
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -201,8 +202,17 @@ static inline void zk_collect_names(ZkSched tmp, std::vector<std::string>& names
 }
 static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const char* alias, u64 alias_len, ZkSymLayout& L,
                           const zkc::Net* net = nullptr) {
+  const bool dbg_t = getenv("ZKWG_DEBUG_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!dbg_t) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[zkwg]   .sym layout: %-34s %6.2f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   std::vector<std::string> ours;
   zk_collect_names(s, ours, net);
+  lap("our names");
   // rename rules
   std::vector<std::pair<std::string, std::string>> rules;
   for (u64 i = 0; alias && i < alias_len;) {
@@ -222,6 +232,7 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
   std::unordered_map<std::string, u32> slot_of;
   slot_of.reserve(ours.size() * 2);
   for (u32 i = 1; i < ours.size(); ++i) slot_of.emplace(ours[i], i);
+  lap("rename + name -> slot map");
   L.dst.assign(ours.size(), 0xffffffffu);
   L.dst[0] = 0;
   L.names.clear();
@@ -271,6 +282,7 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
         for (size_t k = 0; k < kv.second.size(); ++k) ex[k] = std::max(ex[k], kv.second[k]);
       }
   }
+  lap("pass 1 (array extents)");
   // pass 2: every listed signal -> (witness index, kept-v1 slot or none, name)
   struct Hit { u32 widx, slot; std::string name; };
   std::vector<std::vector<Hit>> hits(T);
@@ -318,6 +330,7 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
     }
   });
   for (auto& er : errs) if (!er.empty()) { L.err = er; return false; }
+  lap("pass 2 (lookup)");
   std::vector<std::pair<u64, std::string>> holes;   // (witness index, name) of signals this schedule does not produce
   for (auto& part : hits) for (Hit& h : part) if ((u64)h.widx > maxw) maxw = h.widx;
   L.names.resize(maxw + 1);
@@ -336,6 +349,7 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
     }
     std::vector<Hit>().swap(part);
   }
+  lap("merge");
   if (unmatched) {
     L.err = std::to_string(unmatched) + " signal(s) kept by the .sym file are not produced by this schedule (first: " + first_unmatched + ")";
     return false;
@@ -360,6 +374,7 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
   }
   for (u64 i = 0; i < L.W; ++i)
     if (!seen[i]) { L.err = "witness index " + std::to_string(i) + " is not covered by the .sym file"; return false; }
+  lap("holes + tiling check");
   return true;
 }
 // Re-target the segment table: split every kept-v1 segment into maximal runs whose destinations are
