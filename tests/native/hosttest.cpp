@@ -165,3 +165,60 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
   return ok ? 1 : 0;
 }
 }
+
+// BN254 G1 building blocks of the multi-exponentiation row (zkwg_fq.h, zkwg_g1.h): every value crosses this boundary in STANDARD form,
+// 32-byte little-endian; points are x | y, infinity = all zeros
+#include "zkwg_g1.h"
+static G1Affine ht_pt_in(const uint8_t* p) {
+  G1Affine a;
+  memcpy(&a.x, p, 32); memcpy(&a.y, p + 32, 32);
+  if (g1_is_inf(a)) return a;
+  return G1Affine{fq_to_mont(a.x), fq_to_mont(a.y)};
+}
+static void ht_pt_out(const G1Xyzz& r, uint8_t* out) {
+  const G1Affine a = g1_to_affine(r);
+  const Fq x = g1_is_inf(a) ? a.x : fq_from_mont(a.x), y = g1_is_inf(a) ? a.y : fq_from_mont(a.y);
+  memcpy(out, &x, 32); memcpy(out + 32, &y, 32);
+}
+extern "C" {
+// Montgomery product on raw limbs through the 32-bit-limb path (the device's) or the 64-bit one
+void ht_fq_mont_mul(const void* a, const void* b, void* out, int path32) {
+  *(Fq*)out = path32 ? fq_mont_mul_32(*(const Fq*)a, *(const Fq*)b) : fq_mont_mul_64(*(const Fq*)a, *(const Fq*)b);
+}
+void ht_fq_op(int op, const void* a, const void* b, void* out) {   // standard form in and out: 0 add, 1 sub, 2 mul, 3 inv, 4 neg
+  const Fq x = fq_to_mont(*(const Fq*)a), y = fq_to_mont(*(const Fq*)b);
+  Fq r = op == 0 ? fq_add(x, y) : op == 1 ? fq_sub(x, y) : op == 2 ? fq_mont_mul(x, y) : op == 3 ? fq_mont_inv(x) : fq_neg(x);
+  *(Fq*)out = fq_from_mont(r);
+}
+// op 0: (a as accumulator) + b mixed; 1: a + b with both in XYZZ, b scaled to a non-trivial ZZ first; 2: 2 a (affine); 3: 2 a (XYZZ, scaled)
+void ht_g1_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* scale, uint8_t* out) {
+  const G1Affine A = ht_pt_in(a), B = ht_pt_in(b);
+  Fq s; memcpy(&s, scale, 32); s = fq_to_mont(s);
+  // the same point with ZZ = s^2, ZZZ = s^3: X = x s^2, Y = y s^3
+  auto scaled = [&](const G1Affine& p) {
+    if (g1_is_inf(p)) return g1_xyzz_inf();
+    const Fq s2 = fq_mont_sqr(s), s3 = fq_mont_mul(s2, s);
+    return G1Xyzz{fq_mont_mul(p.x, s2), fq_mont_mul(p.y, s3), s2, s3};
+  };
+  G1Xyzz r;
+  if (op == 0) r = g1_add_mixed(scaled(A), B);
+  else if (op == 1) r = g1_add(scaled(A), g1_add_mixed(g1_xyzz_inf(), B));
+  else if (op == 2) r = g1_dbl_affine(A);
+  else if (op == 4) r = g1_add(scaled(A), scaled(B));
+  else r = g1_dbl(scaled(A));
+  ht_pt_out(r, out);
+}
+int ht_g1_on_curve(const uint8_t* a) { return g1_on_curve(ht_pt_in(a)) ? 1 : 0; }
+// digits of one scalar: out[K]; returns the final carry (must be 0)
+uint32_t ht_msm_digits(const uint64_t* k, uint32_t c, int32_t* out) {
+  u32 carry = 0;
+  for (u32 w = 0; w < zk_msm_windows(c); ++w) out[w] = zk_msm_digit(k, w, c, carry);
+  return carry;
+}
+uint32_t ht_msm_windows(uint32_t c) { return zk_msm_windows(c); }
+void ht_msm(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t c, uint8_t* out) {
+  std::vector<G1Affine> P(n);
+  for (uint64_t i = 0; i < n; ++i) P[i] = ht_pt_in(points + 64 * i);
+  ht_pt_out(zk_msm_host(P.data(), scalars, n, c), out);
+}
+}
