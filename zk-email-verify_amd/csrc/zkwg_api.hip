@@ -299,21 +299,28 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     // circuit (.r1cs given): every wire of the file gets a descriptor over the compact image or a linear row over
     // kept-v1 slots (zkwg_full.h -> zkwg_o0.h); zk_expand3_o0 writes the file's witness in one pass
     phase("schedule");
-    if (!zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net) || (!r1cs && !zk_remap_segments(c->s, c->segs, L))) {
+    // the two files are independent until the linear plan: the .r1cs is parsed on its own thread(s) while the .sym is laid out
+    // (both are threaded inside; their serial stretches hide behind each other)
+    ZkR1csHost R;
+    bool r1cs_ok = true;
+    std::thread r1cs_thread;
+    if (r1cs) r1cs_thread = std::thread([&] { r1cs_ok = zk_r1cs_parse(r1cs, r1cs_len, R); });
+    const bool sym_ok = zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net);
+    if (r1cs_thread.joinable()) r1cs_thread.join();
+    if (!sym_ok || (!r1cs && !zk_remap_segments(c->s, c->segs, L))) {
       g_last_error = L.err.empty() ? std::string(".sym layout does not tile the witness") : L.err;
       delete c;
       return ZKWG_RC_BAD_CONFIG;
     }
     if (r1cs) {
       // every signal the schedule does not produce must follow from the circuit's own linear constraints
-      ZkR1csHost R;
       std::string err;
       std::vector<u8> produced(L.W, 0);
       for (u64 i = 0; i < L.W; ++i) produced[i] = L.hole[i] ? 0 : 1;
-      phase(".sym layout");
-      if (!zk_r1cs_parse(r1cs, r1cs_len, R)) err = "the .r1cs file could not be parsed";
+      phase(".sym layout | .r1cs parse");
+      if (!r1cs_ok) err = "the .r1cs file could not be parsed";
       else if (R.n_wires != L.W) err = "the .r1cs has " + std::to_string(R.n_wires) + " wires, the .sym file numbers " + std::to_string(L.W);
-      else { phase(".r1cs parse"); zk_linear_plan(R, produced, c->lin_host, err); }
+      else zk_linear_plan(R, produced, c->lin_host, err);
       phase("linear plan");
       if (err.empty()) {
         // wire -> where its value comes from: a kept-v1 slot (bit 31 clear) or a linear row over kept-v1 slots

@@ -224,14 +224,65 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
     if (eq != std::string::npos && eq > 0) rules.emplace_back(line.substr(0, eq), line.substr(eq + 1));
     i = j + 1;
   }
+  const unsigned TN = ours.size() > (1u << 16) ? zk_host_threads() : 1u;
   if (!rules.empty())
-    for (auto& nm : ours)
-      for (auto& r : rules)
-        for (size_t pos = nm.find(r.first); pos != std::string::npos; pos = nm.find(r.first, pos + r.second.size()))
-          nm.replace(pos, r.first.size(), r.second);
-  std::unordered_map<std::string, u32> slot_of;
-  slot_of.reserve(ours.size() * 2);
-  for (u32 i = 1; i < ours.size(); ++i) slot_of.emplace(ours[i], i);
+    zk_parallel_chunks(TN, [&](unsigned ci, unsigned nc) {
+      for (size_t k = ours.size() * ci / nc; k < ours.size() * (ci + 1) / nc; ++k) {
+        std::string& nm = ours[k];
+        for (auto& r : rules)
+          for (size_t pos = nm.find(r.first); pos != std::string::npos; pos = nm.find(r.first, pos + r.second.size()))
+            nm.replace(pos, r.first.size(), r.second);
+      }
+    });
+  // name -> kept-v1 slot: an open-addressing table of slot indices (0 = empty; the names themselves stay in `ours`), filled by all
+  // threads with compare-and-swap -- 1.8 M std::string keys in an unordered_map took 1.8 s on one core.  Of two slots with the
+  // same name the lower one wins, as with emplace in slot order.
+  struct NameTable {
+    std::vector<u32> cell;
+    u64 mask = 0;
+    const std::vector<std::string>* names = nullptr;
+    static u64 hash(const char* p, size_t n) {
+      u64 h = 0xcbf29ce484222325ull;
+      size_t i = 0;
+      for (; i + 8 <= n; i += 8) { u64 w; memcpy(&w, p + i, 8); h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; }
+      for (; i < n; ++i) h = (h ^ (u8)p[i]) * 0x100000001b3ull;
+      h ^= h >> 32; h *= 0x9e3779b97f4a7c15ull; h ^= h >> 29;
+      return h;
+    }
+    void init(const std::vector<std::string>& nm) {
+      names = &nm;
+      u64 cap = 1024;
+      while (cap < nm.size() * 2 + 2) cap <<= 1;
+      cell.assign(cap, 0u);
+      mask = cap - 1;
+    }
+    void insert(u32 slot) {
+      const std::string& k = (*names)[slot];
+      for (u64 at = hash(k.data(), k.size()) & mask;; at = (at + 1) & mask) {
+        u32 cur = __atomic_load_n(&cell[at], __ATOMIC_RELAXED);
+        if (cur == 0) {
+          if (__atomic_compare_exchange_n(&cell[at], &cur, slot, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return;
+        }
+        if ((*names)[cur] == k) {       // the same name twice: keep the lower slot
+          while (cur > slot && !__atomic_compare_exchange_n(&cell[at], &cur, slot, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+          return;
+        }
+      }
+    }
+    u32 find(const char* p, size_t n) const {       // -> slot, or 0xffffffff
+      for (u64 at = hash(p, n) & mask;; at = (at + 1) & mask) {
+        const u32 cur = cell[at];
+        if (cur == 0) return 0xffffffffu;
+        const std::string& k = (*names)[cur];
+        if (k.size() == n && memcmp(k.data(), p, n) == 0) return cur;
+      }
+    }
+  } slot_of;
+  slot_of.init(ours);
+  zk_parallel_chunks(TN, [&](unsigned ci, unsigned nc) {
+    for (size_t k = std::max<size_t>(1, ours.size() * ci / nc); k < ours.size() * (ci + 1) / nc; ++k)
+      if (!ours[k].empty()) slot_of.insert((u32)k);
+  });
   lap("rename + name -> slot map");
   L.dst.assign(ours.size(), 0xffffffffu);
   L.dst[0] = 0;
@@ -322,59 +373,69 @@ static bool zk_sym_layout(const ZkSched& s, const char* text, u64 len, const cha
           }
         }
       }
-      auto it = slot_of.find(name);
-      if (it == slot_of.end()) {
+      const u32 hit = name.empty() ? 0xffffffffu : slot_of.find(name.data(), name.size());
+      if (hit == 0xffffffffu) {
         if (flattened) name.assign(c3 + 1, e);      // a signal the schedule does not produce keeps the file's spelling
         out.push_back(Hit{(u32)widx, 0xffffffffu, std::move(name)});
-      } else out.push_back(Hit{(u32)widx, it->second, std::move(name)});
+      } else out.push_back(Hit{(u32)widx, hit, std::move(name)});
     }
   });
   for (auto& er : errs) if (!er.empty()) { L.err = er; return false; }
   lap("pass 2 (lookup)");
-  std::vector<std::pair<u64, std::string>> holes;   // (witness index, name) of signals this schedule does not produce
-  for (auto& part : hits) for (Hit& h : part) if ((u64)h.widx > maxw) maxw = h.widx;
-  L.names.resize(maxw + 1);
-  for (auto& part : hits) {
+  // merge, in file order: a light serial pass decides what every listed signal is (only indices and slots are touched), then the
+  // 9 M names move to their witness index on all threads -- every index is written by exactly one hit by then
+  {
+    std::vector<u64> mx(T, 0);
+    zk_parallel_chunks(T, [&](unsigned ci, unsigned) { u64 m = 0; for (const Hit& h : hits[ci]) m = std::max<u64>(m, h.widx); mx[ci] = m; });
+    for (u64 m : mx) maxw = std::max(maxw, m);
+  }
+  L.W = maxw + 1;
+  L.names.resize(L.W);
+  L.hole.assign(L.W, 0);
+  const u32 SKIP = 0xfffffffeu;              // (marks a hit whose name is not stored)
+  u64 n_holes = 0, hole_twice = 0xffffffffffffffffull;
+  for (auto& part : hits)
     for (Hit& h : part) {
       if (h.slot == 0xffffffffu) {
-        if (L.allow_holes) { holes.emplace_back((u64)h.widx, std::move(h.name)); continue; }
+        if (L.allow_holes) {
+          if (L.hole[h.widx]) { if (hole_twice == 0xffffffffffffffffull) hole_twice = h.widx; h.slot = SKIP; continue; }
+          L.hole[h.widx] = 1; ++n_holes;
+          continue;
+        }
         if (!unmatched++) first_unmatched = h.name;
+        h.slot = SKIP;
         continue;
       }
       // a layout can only re-order / drop this schedule's own signals: indices beyond its length are bogus
       if (!L.allow_holes && (u64)h.widx >= ours.size()) { L.err = "witness index " + std::to_string(h.widx) + " exceeds the schedule's witness length"; return false; }
-      if (L.dst[h.slot] != 0xffffffffu && L.dst[h.slot] != h.widx) { ++dup; continue; }
+      if (L.dst[h.slot] != 0xffffffffu) { if (L.dst[h.slot] != h.widx) ++dup; h.slot = SKIP; continue; }   // (listed twice: the first stands)
       L.dst[h.slot] = h.widx;
-      L.names[h.widx] = std::move(h.name);
     }
-    std::vector<Hit>().swap(part);
-  }
-  lap("merge");
+  lap("merge (indices)");
   if (unmatched) {
     L.err = std::to_string(unmatched) + " signal(s) kept by the .sym file are not produced by this schedule (first: " + first_unmatched + ")";
     return false;
   }
   if (dup) { L.err = std::to_string(dup) + " name(s) listed with two different witness indices"; return false; }
-  L.W = maxw + 1;
-  L.hole.assign(L.W, 0);
-  if (L.names.size() < L.W) L.names.resize(L.W);
-  for (auto& h : holes) {
-    if (L.hole[h.first]) { L.err = "witness index " + std::to_string(h.first) + " assigned to two signals"; return false; }
-    L.hole[h.first] = 1;
-    L.names[h.first].swap(h.second);
+  if (hole_twice != 0xffffffffffffffffull) { L.err = "witness index " + std::to_string(hole_twice) + " assigned to two signals"; return false; }
+  // the kept indices (and the holes) must tile [0, W) exactly once -- checked BEFORE the names move, so that no two hits share an index
+  {
+    std::vector<u8> seen(L.hole);
+    for (u32 d : L.dst) {
+      if (d == 0xffffffffu) continue;
+      if (d >= L.W || seen[d]) { L.err = "witness index " + std::to_string(d) + " assigned to two signals"; return false; }
+      seen[d] = 1;
+    }
+    for (u64 i = 0; i < L.W; ++i)
+      if (!seen[i]) { L.err = "witness index " + std::to_string(i) + " is not covered by the .sym file"; return false; }
   }
-  L.n_holes = holes.size();
-  // the kept indices (and the holes) must tile [0, W) exactly once
-  std::vector<u8> seen(L.W, 0);
-  for (u64 i = 0; i < L.W; ++i) seen[i] = L.hole[i];
-  for (u32 d : L.dst) {
-    if (d == 0xffffffffu) continue;
-    if (d >= L.W || seen[d]) { L.err = "witness index " + std::to_string(d) + " assigned to two signals"; return false; }
-    seen[d] = 1;
-  }
-  for (u64 i = 0; i < L.W; ++i)
-    if (!seen[i]) { L.err = "witness index " + std::to_string(i) + " is not covered by the .sym file"; return false; }
-  lap("holes + tiling check");
+  zk_parallel_chunks(T, [&](unsigned ci, unsigned) {
+    for (Hit& h : hits[ci]) if (h.slot != SKIP) L.names[h.widx] = std::move(h.name);
+    std::vector<Hit>().swap(hits[ci]);
+  });
+  L.names[0] = "one";
+  L.n_holes = n_holes;
+  lap("merge (names) + tiling check");
   return true;
 }
 // Re-target the segment table: split every kept-v1 segment into maximal runs whose destinations are
