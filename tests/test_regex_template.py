@@ -112,7 +112,7 @@ def _messages(n, seed, count):
     return out
 
 
-@pytest.mark.parametrize("path,n", [(STAND_IN, 192), (STAND_IN, 1024),
+@pytest.mark.parametrize("path,n", [(STAND_IN, 192), (STAND_IN, 576), (STAND_IN, 1024),
                                     (os.path.join(ROOT, "tests", "golden", "regex_style", "body_hash_regex_unshared.circom"), 256)])
 def test_chain_tables_give_the_same_values_as_the_plain_gate_list(monkeypatch, path, n):
     """zkwg_circom.h chain_pass: with both recurrences served from scan tables (default), with the forward one only
@@ -124,7 +124,7 @@ def test_chain_tables_give_the_same_values_as_the_plain_gate_list(monkeypatch, p
         else: monkeypatch.setenv("ZKWG_NET_CHAIN", mode)
         regs[mode] = hosttest.LoadedRegex(path, n)
     assert regs["0"].names == regs["1"].names == regs[None].names
-    for msg in _messages(n, 7 * n, 25 if n >= 1024 else 55):
+    for msg in _messages(n, 7 * n, 25 if n >= 576 else 55):
         ref = regs["0"].evaluate(msg)
         assert regs["1"].evaluate(msg) == ref, msg
         assert regs[None].evaluate(msg) == ref, msg
