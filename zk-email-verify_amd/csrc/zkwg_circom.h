@@ -1921,7 +1921,7 @@ struct Elab {
         core_of[st] = core_id.emplace(v, (u32)core_id.size()).first->second;
       }
     }
-    const u32 smax = *std::max_element(core_of.begin(), core_of.end()) + 1;
+    u32 smax = *std::max_element(core_of.begin(), core_of.end()) + 1;
     const u32 mw = (max_bits + ZKC_MASK_BITS - 1) / ZKC_MASK_BITS;
     // Classes -> groups.  Two descriptors can differ and still describe the same functions (the first positions of a message cut
     // their long sums into partial sums differently: other temporaries, same signals); their cells -- (core state, symbol) ->
@@ -1932,7 +1932,7 @@ struct Elab {
       std::vector<u8> set, delta, cb;   // [core][symbol]; cb: [cf gate][core][symbol]
       std::vector<u32> kw;              // [kept gate][core][symbol]
     };
-    const size_t CELLS = (size_t)smax * NSYM;
+    size_t CELLS = (size_t)smax * NSYM;
     std::vector<int> rep(classes.size(), -1);
     for (u32 i = 0; i < end; ++i) if (rep[cls_of[i]] < 0) rep[cls_of[i]] = (int)i;
     std::vector<Cells> groups;
@@ -1979,6 +1979,62 @@ struct Elab {
         for (u32 q = 0; q < X.ncf; ++q) G.cb[q * CELLS + cell] = X.cb[q * CELLS + cell];
       }
       group_of[c] = (u32)into;
+    }
+    // States that no table can tell apart are one state (Moore's partition refinement over all classes: same tabulated cells, same
+    // words and bits in them, successors in the same block).  The carried set often holds more than the automaton needs -- an
+    // intermediate of the next state beside the state itself -- and every valuation of it was numbered: 132 states for the 4-state
+    // automaton of tests/golden/regex_style/simple_regex.circom.  Fewer states = fewer rows here and fewer symbols per row in the
+    // backward pass.
+    {
+      std::vector<u32> block(smax, 0), next(smax, 0);
+      u32 n_blocks = 1;
+      for (int round = 0; round < 300; ++round) {
+        std::map<std::vector<u32>, u32> ids;
+        for (u32 st = 0; st < smax; ++st) {
+          std::vector<u32> key;
+          key.push_back(block[st]);
+          for (const Cells& G : groups)
+            for (u32 y = 0; y < NSYM; ++y) {
+              const size_t cell = (size_t)st * NSYM + y;
+              if (!G.set[cell]) { key.push_back(0xffffffffu); continue; }
+              key.push_back(block[G.delta[cell]]);
+              if (round == 0) {       // (the contents separate the states once; afterwards only the successors' blocks change)
+                for (u32 q = 0; q < G.nkept; ++q) key.push_back(G.kw[q * CELLS + cell]);
+                for (u32 q = 0; q < G.ncf; ++q) key.push_back(G.cb[q * CELLS + cell]);
+              }
+            }
+          next[st] = ids.emplace(std::move(key), (u32)ids.size()).first->second;
+        }
+        const bool stable = ids.size() == n_blocks && round > 0;
+        n_blocks = (u32)ids.size();
+        block.swap(next);
+        if (stable) break;
+      }
+      if (n_blocks < smax) {
+        // (blocks are numbered in state order, so state 0 -- the start -- stays 0)
+        const size_t NC = (size_t)n_blocks * NSYM;
+        for (Cells& G : groups) {
+          Cells H;
+          H.nkept = G.nkept; H.ncf = G.ncf;
+          H.set.assign(NC, 0); H.delta.assign(NC, 0); H.kw.assign(G.nkept * NC, 0); H.cb.assign(G.ncf * NC, 0);
+          for (u32 st = 0; st < smax; ++st)
+            for (u32 y = 0; y < NSYM; ++y) {
+              const size_t a = (size_t)st * NSYM + y, b = (size_t)block[st] * NSYM + y;
+              if (!G.set[a]) continue;
+              H.set[b] = 1; H.delta[b] = (u8)block[G.delta[a]];
+              for (u32 q = 0; q < G.nkept; ++q) H.kw[q * NC + b] = G.kw[q * CELLS + a];
+              for (u32 q = 0; q < G.ncf; ++q) H.cb[q * NC + b] = G.cb[q * CELLS + a];
+            }
+          G = std::move(H);
+        }
+        std::vector<u32> rb((size_t)N * 8, 0);
+        for (u32 at = 0; at < N; ++at)
+          for (u32 st = 0; st < smax && st < 256; ++st)
+            if ((reach_bits[(size_t)at * 8 + st / 32] >> (st % 32)) & 1u) rb[(size_t)at * 8 + block[st] / 32] |= 1u << (block[st] % 32);
+        if (!bwd) reach_bits.swap(rb);          // (recorded by precise state = core state in the forward pass; the backward pass reads them)
+        if (dbg) fprintf(stderr, "[zkwg] %s: %u states are %u\n", tag, smax, n_blocks);
+        smax = n_blocks; CELLS = NC;
+      }
     }
     {
       // the tables are looked up once per slot and email: they have to stay cache-sized
