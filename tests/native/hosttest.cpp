@@ -261,3 +261,35 @@ extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scal
   zk_msm_combine_thread(A);
   ht_pt_out(res[0], out);
 }
+
+// BN254 G2 building blocks (zkwg_g2.h): standard form across this boundary; a point is x.c0 | x.c1 | y.c0 | y.c1, zeros = infinity
+#include "zkwg_g2.h"
+static Fq2 ht_f2_in(const uint8_t* p) { Fq2 a; memcpy(&a.c0, p, 32); memcpy(&a.c1, p + 32, 32); return Fq2{fq_to_mont(a.c0), fq_to_mont(a.c1)}; }
+static void ht_f2_out(const Fq2& a, uint8_t* out) { const Fq x = fq_from_mont(a.c0), y = fq_from_mont(a.c1); memcpy(out, &x, 32); memcpy(out + 32, &y, 32); }
+static G2Affine ht_p2_in(const uint8_t* p) {
+  bool zero = true;
+  for (int i = 0; i < 128; ++i) zero = zero && p[i] == 0;
+  if (zero) return G2Affine{fq2_zero(), fq2_zero()};
+  return G2Affine{ht_f2_in(p), ht_f2_in(p + 64)};
+}
+extern "C" {
+void ht_fq2_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {   // 0 add, 1 sub, 2 mul, 3 sqr, 4 inv
+  const Fq2 x = ht_f2_in(a), y = ht_f2_in(b);
+  ht_f2_out(op == 0 ? fq2_add(x, y) : op == 1 ? fq2_sub(x, y) : op == 2 ? fq2_mul(x, y) : op == 3 ? fq2_sqr(x) : fq2_inv(x), out);
+}
+// op 0: scaled(a) + b mixed; 1: scaled(a) + scaled(b); 2: 2 a (affine); 3: 2 scaled(a)
+void ht_g2_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* scale, uint8_t* out) {
+  const G2Affine A = ht_p2_in(a), B = ht_p2_in(b);
+  const Fq2 s = ht_f2_in(scale);
+  auto scaled = [&](const G2Affine& p) {
+    if (g2_is_inf(p)) return g2_xyzz_inf();
+    const Fq2 s2 = fq2_sqr(s), s3 = fq2_mul(s2, s);
+    return G2Xyzz{fq2_mul(p.x, s2), fq2_mul(p.y, s3), s2, s3};
+  };
+  const G2Xyzz r = op == 0 ? g2_add_mixed(scaled(A), B) : op == 1 ? g2_add(scaled(A), scaled(B)) : op == 2 ? g2_dbl_affine(A) : g2_dbl(scaled(A));
+  const G2Affine q = g2_to_affine(r);
+  if (g2_is_inf(q)) { memset(out, 0, 128); return; }
+  ht_f2_out(q.x, out); ht_f2_out(q.y, out + 64);
+}
+int ht_g2_on_curve(const uint8_t* a) { return g2_on_curve(ht_p2_in(a)) ? 1 : 0; }
+}

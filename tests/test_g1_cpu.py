@@ -162,3 +162,45 @@ def test_device_msm_bodies_thread_by_thread_equal_the_oracle(n, c, mont):
     for shuffle in (0, 5):
         lib.ht_msm_device_mirror(buf, sc, C.c_uint64(n), c, mont, shuffle, out)
         assert _unpt(out.raw) == want, (n, c, mont, shuffle)
+
+def test_g2_arithmetic_against_the_oracle():
+    """zkwg_g2.h (Fq2 by Karatsuba, the XYZZ additions over the twist) against oracle/pyref/bn254_g2.py, which is pinned by the
+    EIP-197 generator: on the twist, r * G2 = O"""
+    from oracle.pyref import bn254_g2 as H
+    assert H.on_curve(H.G2) and H.mul(R, H.G2) is None and H.add(H.mul(R - 1, H.G2), H.G2) is None
+    lib = _lib()
+    for f in (lib.ht_fq2_op, lib.ht_g2_op):
+        f.restype = None
+    rng = random.Random(31)
+
+    def f2b(a):
+        return _b(a[0]) + _b(a[1])
+
+    def p2b(p):
+        return bytes(128) if p is None else f2b(p[0]) + f2b(p[1])
+
+    def unf2(b):
+        return (int.from_bytes(b[:32], "little"), int.from_bytes(b[32:64], "little"))
+
+    out = C.create_string_buffer(64)
+    for _ in range(100):
+        a, b = (rng.randrange(Q), rng.randrange(Q)), (rng.randrange(Q), rng.randrange(Q))
+        for op, want in ((0, H.f2_add(a, b)), (1, H.f2_sub(a, b)), (2, H.f2_mul(a, b)), (3, H.f2_mul(a, a)), (4, H.f2_inv(a))):
+            lib.ht_fq2_op(op, f2b(a), f2b(b), out)
+            assert unf2(out.raw) == want, op
+    pts = H.random_points(6, 2)
+    out = C.create_string_buffer(128)
+    for i, p in enumerate(pts):
+        q = pts[(i + 1) % len(pts)]
+        for a, b in ((p, q), (p, p), (p, H.neg(p)), (p, None), (None, q), (None, None)):
+            s = (rng.randrange(1, Q), rng.randrange(Q))
+            for op in (0, 1):
+                lib.ht_g2_op(op, p2b(a), p2b(b), f2b(s), out)
+                got = None if out.raw == bytes(128) else (unf2(out.raw[:64]), unf2(out.raw[64:]))
+                assert got == H.add(a, b), (op, i)
+            for op in (2, 3):
+                lib.ht_g2_op(op, p2b(a), p2b(b), f2b(s), out)
+                got = None if out.raw == bytes(128) else (unf2(out.raw[:64]), unf2(out.raw[64:]))
+                assert got == H.add(a, a), (op, i)
+        assert lib.ht_g2_on_curve(p2b(p)) == 1
+    assert lib.ht_g2_on_curve(p2b(((1, 0), (2, 0)))) == 0
