@@ -242,6 +242,12 @@ class LoadedRegex:
             self.lib.ht_net_destroy(self.h)
             self.h = None
 
+    def chain_info(self):
+        """-> (positions served from the forward chain tables, from the backward ones, steps left in the gate list)"""
+        out = (C.c_uint32 * 4)()
+        self.lib.ht_net_chain_info(C.c_void_p(self.h), out)
+        return int(out[0]), int(out[1]), int(out[2])
+
     def evaluate(self, msg):
         """-> (ok, {name: field element}, match, reveal list)"""
         msg = bytes(msg) + bytes(self.n - len(msg))

@@ -119,6 +119,11 @@ void ht_net_destroy(void* p) { delete (HTNet*)p; }
 const char* ht_net_error(void* p) { return ((HTNet*)p)->net.n_kept == 0xffffffffu ? ((HTNet*)p)->err.c_str() : nullptr; }
 uint32_t ht_net_kept(void* p) { return ((HTNet*)p)->net.n_kept; }
 uint32_t ht_net_inv_need(void* p) { return ((HTNet*)p)->net.inv_need; }
+// what the loader did with the recurrences: positions covered by the forward / backward chain tables, steps left in the gate list
+void ht_net_chain_info(void* p, uint32_t out[4]) {
+  const zkc::Net& N = ((HTNet*)p)->net;
+  out[0] = N.chain.end; out[1] = N.bchain.end; out[2] = N.n_steps; out[3] = N.chain.classes | (N.bchain.classes << 16);
+}
 const char* ht_net_names(void* p) { return ((HTNet*)p)->names.c_str(); }
 // evaluates the gate list exactly as the kernel does (same cache simulation); words[n_kept], reveal[n]
 int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, uint32_t* reveal) {

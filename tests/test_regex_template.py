@@ -130,6 +130,63 @@ def test_chain_tables_give_the_same_values_as_the_plain_gate_list(monkeypatch, p
         assert regs[None].evaluate(msg) == ref, msg
 
 
+def _chain_fuzz_template(rng):
+    """a random finite-state circuit in the regex style: S state bits stepped forward by comparators of the current byte, a chain
+    that runs backwards over the forward states, an accept counter, a reveal array"""
+    S, K = rng.randrange(2, 6), rng.randrange(2, 5)
+    consts = [rng.choice([97, 98, 99, 100, 59, 61]) for _ in range(K)]
+    L = ['pragma circom 2.1.5;', 'include "./helpers.circom";', '', 'template Fuzz(msg_bytes) {', '    signal input msg[msg_bytes];',
+         '    signal output out;', '    signal output reveal0[msg_bytes];', f'    component e[{K}][msg_bytes];',
+         f'    signal s[msg_bytes + 1][{S}];', '    signal b[msg_bytes + 1];']
+    for j in range(S):
+        L.append(f'    s[0][{j}] <== {1 if j == 0 else rng.randrange(2)};')
+    L.append('    for (var i = 0; i < msg_bytes; i++) {')
+    for k in range(K):
+        L += [f'        e[{k}][i] = IsEqual();', f'        e[{k}][i].in[0] <== msg[i];', f'        e[{k}][i].in[1] <== {consts[k]};']
+    for j in range(S):
+        a, b2, k1, k2 = rng.randrange(S), rng.randrange(S), rng.randrange(K), rng.randrange(K)
+        form = rng.randrange(3)
+        if form == 0:
+            L.append(f'        s[i + 1][{j}] <== OR()(AND()(s[i][{a}], e[{k1}][i].out), AND()(s[i][{b2}], e[{k2}][i].out));')
+        elif form == 1:
+            L.append(f'        s[i + 1][{j}] <== AND()(s[i][{a}], 1 - e[{k1}][i].out);')
+        else:
+            L.append(f'        s[i + 1][{j}] <== OR()(e[{k1}][i].out, s[i][{a}] * s[i][{b2}]);')
+    L.append('    }')
+    a, c = rng.randrange(S), rng.randrange(S)
+    L += ['    b[msg_bytes] <== 0;', '    for (var i = msg_bytes - 1; i >= 0; i--) {',
+          f'        b[i] <== OR()(AND()(b[i + 1], 1 - s[i + 1][{a}]), s[i + 1][{c}] * e[{rng.randrange(K)}][i].out);', '    }',
+          '    component acc = MultiOR(msg_bytes);', f'    for (var i = 0; i < msg_bytes; i++) acc.in[i] <== s[i + 1][{rng.randrange(S)}];',
+          '    out <== acc.out;', '    for (var i = 0; i < msg_bytes; i++) reveal0[i] <== msg[i] * b[i];', '}']
+    return "\n".join(L) + "\n"
+
+
+def test_random_finite_state_templates_chain_tables_against_the_plain_gate_list(tmp_path, monkeypatch):
+    """zkwg_circom.h chain_pass on circuits it has not seen: random state machines with a forward and a backward recurrence; the
+    loader's scan tables (default) and the plain gate list (ZKWG_NET_CHAIN=0) must agree on every kept signal, output and
+    assertion for random messages -- and most of these circuits must really be served from both sets of tables."""
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "regex_style", "helpers.circom"), tmp_path / "helpers.circom")
+    rng = random.Random(20260926)
+    both = 0
+    for case in range(10):
+        n = rng.choice([16, 24, 40])
+        f = tmp_path / f"chain{case}.circom"
+        f.write_text(_chain_fuzz_template(rng))
+        monkeypatch.setenv("ZKWG_NET_CHAIN", "0")
+        plain = hosttest.LoadedRegex(str(f), n, template="Fuzz")
+        monkeypatch.delenv("ZKWG_NET_CHAIN")
+        tab = hosttest.LoadedRegex(str(f), n, template="Fuzz")
+        assert plain.names == tab.names and plain.chain_info()[:2] == (0, 0)
+        fwd, bwd, steps = tab.chain_info()
+        both += fwd > 0 and bwd > 0
+        assert steps <= plain.chain_info()[2]
+        for _ in range(12):
+            msg = bytes(rng.choice([97, 98, 99, 100, 59, 61, 0, 255]) for _ in range(n))
+            assert tab.evaluate(msg) == plain.evaluate(msg), (case, msg)
+    assert both >= 5, both
+
+
 def test_product_side_copy_of_the_stand_in_is_current():
     base = os.path.join(ROOT, "zk-email-verify_amd", "data", "templates", "zk-regex-circom", "circuits")
     lib = os.path.dirname(os.path.dirname(STAND_IN))

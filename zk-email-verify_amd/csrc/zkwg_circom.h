@@ -1659,19 +1659,39 @@ struct Elab {
               bool bad;
               if (t.first & SRC_INPUT) bad = tp((int)(t.first & 0x1fffffffu)) != pos[g];
               else if (sup[t.first] == -1) bad = false;
-              else bad = (!cand[t.first] && !leaf[t.first]) || pos[t.first] < pos[g] - ZKC_CHAIN_REACH;
-              if (bad) { cand[g] = 0; changed = true; break; }
+              else {
+                const int po = pos[t.first], pg = pos[g];
+                bad = (!cand[t.first] && !leaf[t.first]) || (po < pg - ZKC_CHAIN_REACH && !(leaf[t.first] == 2 && po == 0))   // (the mirrored
+                      // walk starts where the forward pass took the first steps of this chain: their results may be read a little further on)
+                      // what runs the other way starts at the last position, and its first steps are within reach: there a byte-local
+                      // value of an earlier position is not taken (a forward gate has no use for one), so that this pass does not
+                      // swallow the head of the other pass's chain
+                      || (pg == (int)N - 1 && leaf[t.first] == 1 && po < pg);
+              }
+              if (bad) {
+                if (dbg && getenv("ZKWG_DEBUG_CHAIN_RULES") && gates[g].slot < net.names.size() && !(t.first & SRC_INPUT) && gates[t.first].slot < net.names.size())
+                  fprintf(stderr, "[zkwg] %s:   %s  reads  %s\n", tag, net.names[gates[g].slot].c_str(), net.names[gates[t.first].slot].c_str());
+                if (dbg && getenv("ZKWG_DEBUG_CHAIN_RULES"))
+                  fprintf(stderr, "[zkwg] %s: gate %u (op %u, pos %d, line %d) leaves: operand %s%u (pos %d, cand %d, leaf %d, chain %d)\n", tag, g, gates[g].op, pos[g],
+                          gates[g].at ? gates[g].at->line : -1, (t.first & SRC_INPUT) ? "byte " : "gate ", t.first & 0x1fffffffu,
+                          (t.first & SRC_INPUT) ? tp((int)(t.first & 0x1fffffffu)) : pos[t.first], (t.first & SRC_INPUT) ? 0 : (int)cand[t.first],
+                          (t.first & SRC_INPUT) ? 0 : (int)leaf[t.first], (t.first & SRC_INPUT) ? 0 : (int)g_chain[t.first]);
+                cand[g] = 0; changed = true; break;
+              }
             }
         }
       }
       std::vector<u32> cnt(N, 0), nz;
       for (u32 g = 0; g < n; ++g) if (cand[g]) ++cnt[pos[g]];
       for (u32 c : cnt) if (c) nz.push_back(c);
-      if (nz.size() < 8) return give_up("no per-position blocks");
+      if (nz.size() < 8) {
+        if (dbg) { u64 nc = 0; for (u32 g = 0; g < n; ++g) nc += cand[g]; fprintf(stderr, "[zkwg] %s: %llu candidates at %zu positions\n", tag, (unsigned long long)nc, nz.size()); }
+        return give_up("no per-position blocks");
+      }
       std::nth_element(nz.begin(), nz.begin() + nz.size() / 2, nz.end());
       const u32 med = nz[nz.size() / 2];
       u32 cut = end;
-      for (u32 i = 0; i < end; ++i) if (cnt[i] > 4 * med + 16) { cut = i; break; }
+      for (u32 i = bwd ? 2u : 0u; i < end; ++i) if (cnt[i] > 4 * med + 16) { cut = i; break; }   // (the mirrored walk starts with the block the forward pass left)
       if (cut == end) break;
       end = cut;
       for (u32 g = 0; g < n; ++g) if (cand[g] && pos[g] >= (int)end) cand[g] = 0;
