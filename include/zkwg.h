@@ -426,13 +426,15 @@ int zkwg_h_evaluations_device(zkwg_ntt_t* plan, const void* d_abc, uint64_t abc_
  * zkwg_h_evaluations_device as scalars (32 bytes each, standard or Montgomery form).  zkwg_msm_create uploads the bases of one
  * such sum (window_bits = 0: chosen from n); zkwg_msm_g1_device computes it for the n scalars at d_scalars, d_work =
  * zkwg_msm_work_bytes bytes of scratch (256-byte aligned), and returns the point as the zkey would store it (affine, Montgomery
- * form, 64 bytes; zeros = infinity).  Bucket method, signed windows, XYZZ accumulators: DESIGN.md section 23. */
+ * form, 64 bytes; zeros = infinity).  ones_apart = 1 for witness scalars (mostly 0 / 1: the bases with scalar 1 are summed by a
+ * plain reduction tree instead of all landing in one bucket).  Bucket method, signed windows, XYZZ accumulators: DESIGN.md section 23. */
 typedef struct zkwg_msm zkwg_msm_t;
 int zkwg_msm_create(int device, const uint8_t* bases, uint64_t n, int window_bits, zkwg_msm_t** out);
 void zkwg_msm_destroy(zkwg_msm_t* plan);
 uint64_t zkwg_msm_work_bytes(const zkwg_msm_t* plan);
 int zkwg_msm_window_bits(const zkwg_msm_t* plan);
-int zkwg_msm_g1_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_montgomery, void* d_work, uint8_t* out_xy, void* hip_stream);
+int zkwg_msm_g1_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_montgomery, int ones_apart, void* d_work, uint8_t* out_xy,
+                       void* hip_stream);
 
 /* The same prover stage without a 32-byte witness in between: the constraint system `r1cs` (its wires = the handle's
  * witness layout: built-in, `.sym`, or -- since ABI 3 -- a fully numbered handle of zkwg_circuit_create_full, whose system is

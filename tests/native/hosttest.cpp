@@ -232,7 +232,7 @@ void ht_msm(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t
 // thread by thread in the launch order of zk_msm_launch; `shuffle` permutes the thread order of the two atomic passes, as the
 // hardware may.  Scalars in standard form or (mont = 1) Montgomery form.
 #include "zkwg_msm_core.h"
-extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t c, int mont, uint32_t shuffle, uint8_t* out) {
+extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t c, int mont, uint32_t shuffle, int ones_apart, uint8_t* out) {
   std::vector<G1Affine> P(n);
   for (uint64_t i = 0; i < n; ++i) P[i] = ht_pt_in(points + 64 * i);
   std::vector<Fr> S(n);
@@ -244,6 +244,9 @@ extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scal
   std::vector<G1Xyzz> bucket(total), ns(2 * (size_t)half + 1), na(2 * (size_t)half + 1), window(A.K), res(1);
   A.count = count.data(); A.cursor = cursor.data(); A.entry = entry.data(); A.bucket = bucket.data();
   A.node_s = ns.data(); A.node_a = na.data(); A.window = window.data(); A.out = res.data();
+  const u32 half1 = (u32)((n + 63) / 64);
+  std::vector<G1Xyzz> ones(2 * (size_t)half1 + 1);
+  A.ones_apart = ones_apart ? 1u : 0u; A.ones = ones.data();
   std::vector<u32> order(n);
   for (u32 i = 0; i < n; ++i) order[i] = i;
   u64 x = 0x9e3779b97f4a7c15ull * (shuffle + 1);
@@ -262,6 +265,18 @@ extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scal
     for (u32 g = 0; g < A.K * n_out; ++g) zk_msm_reduce_thread(A, g, in_s, in_a, n_in, span, out_s, out_a);
     if (n_out == 1) break;
     in_s = out_s; in_a = out_a; n_in = n_out; span *= 32; flip ^= 1;
+  }
+  if (A.ones_apart) {     // as zk_msm_launch does
+    u32 m = half1, levels = 0;
+    for (u32 q = m; q > 1; q = (q + 63) / 64) ++levels;
+    G1Xyzz* cur = A.ones + ((levels & 1u) ? half1 : 0);
+    { ZkMsmArgs B = A; B.ones = cur; for (u32 t = 0; t < half1; ++t) zk_msm_ones_thread(B, t); }
+    while (m > 1) {
+      const u32 m2 = (m + 63) / 64;
+      G1Xyzz* nxt = cur == A.ones ? A.ones + half1 : A.ones;
+      for (u32 t = 0; t < m2; ++t) zk_msm_tree_thread(cur, m, nxt, t);
+      cur = nxt; m = m2;
+    }
   }
   zk_msm_combine_thread(A);
   ht_pt_out(res[0], out);

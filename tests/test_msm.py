@@ -26,7 +26,7 @@ def _case(n, seed, c=0, mont=False):
     d_s = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
     d_w = torch.empty(m.work_bytes() + 256, dtype=torch.uint8, device=dev)
     off = (-d_w.data_ptr()) % 256
-    got = m.g1_device(d_s, mont, d_w[off:])
+    got = m.g1_device(d_s, mont, d_w[off:], ones_apart=(n % 2 == 0))
     want = G.msm_buckets(pts, ks, 8)
     assert got == want, (n, c, mont)
 

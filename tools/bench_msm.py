@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--log2", type=int, default=20)
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--witness", type=int, default=0, help="1: witness-like scalars (90 %% bits, bytes, a few field elements), ones_apart")
     args = ap.parse_args()
     import torch
     import zkwg
@@ -34,13 +35,19 @@ def main():
     # scalars: random bytes with the top bits cleared (< 2^253 < r), declared to be in Montgomery form
     d_s = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev)
     d_s[:, 31] &= 0x1F
+    mont = True
+    if args.witness:
+        kind = torch.rand(n, device=dev)
+        d_s[kind < 0.97, 1:] = 0                       # bytes
+        d_s[kind < 0.90, 0] &= 1                       # bits
+        mont = False
     d_w = torch.empty(m.work_bytes() + 256, dtype=torch.uint8, device=dev)
     off = (-d_w.data_ptr()) % 256
-    m.g1_device(d_s, True, d_w[off:])
+    m.g1_device(d_s, mont, d_w[off:], ones_apart=bool(args.witness))
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(args.reps):
-        p = m.g1_device(d_s, True, d_w[off:])
+        p = m.g1_device(d_s, mont, d_w[off:], ones_apart=bool(args.witness))
     torch.cuda.synchronize()
     ms = (time.time() - t0) / args.reps * 1e3
     c = m.window_bits

@@ -13,7 +13,7 @@ struct zkwg_msm {
   u32 c, K, nb;
   G1Affine* d_bases;
 };
-struct ZkMsmWork { u64 count, cursor, entry, bucket, node_s, node_a, window, out, total; };
+struct ZkMsmWork { u64 count, cursor, entry, bucket, node_s, node_a, window, out, ones, total; };
 static ZkMsmWork msm_work(const zkwg_msm* p) {
   ZkMsmWork W;
   auto al = [](u64 x) { return (x + 255) & ~255ull; };
@@ -27,6 +27,7 @@ static ZkMsmWork msm_work(const zkwg_msm* p) {
   W.node_a = off; off += al(2 * half * sizeof(G1Xyzz));
   W.window = off; off += al((u64)p->K * sizeof(G1Xyzz));
   W.out = off; off += al(sizeof(G1Xyzz));
+  W.ones = off; off += al(2 * ((p->n + 63) / 64) * sizeof(G1Xyzz));
   W.total = off;
   return W;
 }
@@ -54,13 +55,14 @@ void zkwg_msm_destroy(zkwg_msm_t* p) {
 uint64_t zkwg_msm_work_bytes(const zkwg_msm_t* p) { return p ? msm_work(p).total : 0; }
 int zkwg_msm_window_bits(const zkwg_msm_t* p) { return p ? (int)p->c : 0; }
 
-int zkwg_msm_g1_device(zkwg_msm_t* p, const void* d_scalars, int scalars_montgomery, void* d_work, uint8_t* out_xy, void* hip_stream) {
+int zkwg_msm_g1_device(zkwg_msm_t* p, const void* d_scalars, int scalars_montgomery, int ones_apart, void* d_work, uint8_t* out_xy, void* hip_stream) {
   if (!p || !d_scalars || !d_work || !out_xy || ((uintptr_t)d_work & 255) || ((uintptr_t)d_scalars & 15)) return ZKWG_RC_BAD_ARG;
   if (hipSetDevice(p->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   const ZkMsmWork W = msm_work(p);
   u8* w = (u8*)d_work;
   ZkMsmArgs A;
   A.bases = p->d_bases; A.scalars = (const Fr*)d_scalars; A.n = (u32)p->n; A.c = p->c; A.K = p->K; A.nb = p->nb; A.scalars_mont = scalars_montgomery ? 1u : 0u;
+  A.ones_apart = ones_apart ? 1u : 0u; A.ones = (G1Xyzz*)(w + W.ones);
   A.count = (u32*)(w + W.count); A.cursor = (u32*)(w + W.cursor); A.entry = (u32*)(w + W.entry); A.bucket = (G1Xyzz*)(w + W.bucket);
   A.node_s = (G1Xyzz*)(w + W.node_s); A.node_a = (G1Xyzz*)(w + W.node_a); A.window = (G1Xyzz*)(w + W.window); A.out = (G1Xyzz*)(w + W.out);
   hipStream_t st = (hipStream_t)hip_stream;

@@ -21,6 +21,9 @@ struct ZkMsmArgs {
   const Fr* scalars;          // n scalars of this call
   u32 n, c, K, nb;            // points, window bits, windows, buckets per window = 2^(c-1)
   u32 scalars_mont;           // 1: the scalars are in Montgomery form (the H evaluations of zkwg_ntt_api.hip, a Montgomery witness)
+  u32 ones_apart;             // 1: scalars equal to 1 do not enter the buckets (a witness is mostly bits: they would all land in ONE
+                              // bucket of window 0); their bases are summed by zk_msm_ones + the 64-way tree and added at the end
+  G1Xyzz* ones;               // [2 x ceil(n / 64)] tree scratch of the ones' sum (ping-pong halves); ones[0] = the sum at the end
   u32* count;                 // [K * nb + 1] counters, then exclusive offsets (zk_msm_scan)
   u32* cursor;                // [K * nb] running write positions of zk_msm_scatter
   u32* entry;                 // [n * K] base index | sign << 31, grouped by bucket
@@ -38,9 +41,27 @@ struct ZkMsmArgs {
 
 // scalar i in standard form
 ZK_HD Fr zk_msm_scalar(const ZkMsmArgs& A, u32 i) { return A.scalars_mont ? fr_from_mont(A.scalars[i]) : A.scalars[i]; }
+ZK_HD bool zk_msm_is_one(const Fr& k) { return k.l[0] == 1 && (k.l[1] | k.l[2] | k.l[3]) == 0; }
+// the bases whose scalar is 1, 64 per thread (ones_apart); then zk_msm_tree_thread joins 64 partial sums per thread until one is left
+ZK_HD void zk_msm_ones_thread(const ZkMsmArgs& A, u32 t) {
+  const u32 lo = t * 64u, hi = lo + 64u < A.n ? lo + 64u : A.n;
+  if (lo >= A.n) return;
+  G1Xyzz acc = g1_xyzz_inf();
+  for (u32 i = lo; i < hi; ++i)
+    if (zk_msm_is_one(zk_msm_scalar(A, i))) acc = g1_add_mixed(acc, A.bases[i]);
+  A.ones[t] = acc;
+}
+ZK_HD void zk_msm_tree_thread(const G1Xyzz* in, u32 n_in, G1Xyzz* out, u32 t) {
+  const u32 lo = t * 64u, hi = lo + 64u < n_in ? lo + 64u : n_in;
+  if (lo >= n_in) return;
+  G1Xyzz acc = in[lo];
+  for (u32 i = lo + 1; i < hi; ++i) acc = g1_add(acc, in[i]);
+  out[t] = acc;
+}
 ZK_HD void zk_msm_count_thread(const ZkMsmArgs& A, u32 i) {
   if (i >= A.n || g1_is_inf(A.bases[i])) return;
   const Fr k = zk_msm_scalar(A, i);
+  if (A.ones_apart && zk_msm_is_one(k)) return;
   u32 carry = 0;
   for (u32 w = 0; w < A.K; ++w) {
     const int d = zk_msm_digit(k.l, w, A.c, carry);
@@ -68,6 +89,7 @@ ZK_HD void zk_msm_scan_thread(const ZkMsmArgs& A, u32 t, u32 threads, u32* parti
 ZK_HD void zk_msm_scatter_thread(const ZkMsmArgs& A, u32 i) {
   if (i >= A.n || g1_is_inf(A.bases[i])) return;
   const Fr k = zk_msm_scalar(A, i);
+  if (A.ones_apart && zk_msm_is_one(k)) return;
   u32 carry = 0;
   for (u32 w = 0; w < A.K; ++w) {
     const int d = zk_msm_digit(k.l, w, A.c, carry);
@@ -117,5 +139,6 @@ ZK_HD void zk_msm_combine_thread(const ZkMsmArgs& A) {
     for (u32 s = 0; s < A.c; ++s) total = g1_dbl(total);
     total = g1_add(total, A.window[w]);
   }
+  if (A.ones_apart) total = g1_add(total, A.ones[0]);
   A.out[0] = total;
 }

@@ -528,10 +528,11 @@ class Msm:
     def work_bytes(self):
         return self.lib.zkwg_msm_work_bytes(self.h)
 
-    def g1_device(self, d_scalars, montgomery, d_work, stream=None):
+    def g1_device(self, d_scalars, montgomery, d_work, stream=None, ones_apart=False):
         """sum_i scalar_i * base_i for the n 32-byte scalars at d_scalars (torch tensor) -> (x, y) standard-form integers or None"""
         out = (C.c_uint8 * 64)()
-        _check(self.lib.zkwg_msm_g1_device(self.h, d_scalars.data_ptr(), 1 if montgomery else 0, d_work.data_ptr(), out, _stream_ptr(stream)))
+        _check(self.lib.zkwg_msm_g1_device(self.h, d_scalars.data_ptr(), 1 if montgomery else 0, 1 if ones_apart else 0, d_work.data_ptr(), out,
+                                           _stream_ptr(stream)))
         raw = bytes(out)
         if raw == bytes(64):
             return None

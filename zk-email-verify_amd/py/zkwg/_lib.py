@@ -138,7 +138,7 @@ def load():
         "zkwg_msm_destroy": (None, [vp]),
         "zkwg_msm_work_bytes": (u64, [vp]),
         "zkwg_msm_window_bits": (i32, [vp]),
-        "zkwg_msm_g1_device": (i32, [vp, vp, i32, vp, vp, vp]),
+        "zkwg_msm_g1_device": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "zkwg_calculate_batch_resident": (i32, [vp, vp, u64, vp, vp, u64, u64, vp, vp]),
         "zkwg_resident_placement": (i32, [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]),
     }
