@@ -420,6 +420,22 @@ int zkwg_ntt_transform_device(zkwg_ntt_t* plan, void* d_data, uint64_t n_polys, 
 int zkwg_h_evaluations_device(zkwg_ntt_t* plan, const void* d_abc, uint64_t abc_stride, uint64_t n_constraints, uint64_t n_emails,
                               void* d_work, void* d_out, uint64_t out_stride, void* hip_stream);
 
+/* ---- prover stage 3: the G1 multi-exponentiations of groth16_prove.js -- DRAFT (branch next/msm) ----------
+ * pi_a, pib1, pi_c and resH are  sum_i scalar_i * base_i  over BN254 G1 with the zkey's bases (affine, x | y in Montgomery form,
+ * 64 bytes each, the point at infinity all zeros -- sections 5, 6, 8, 9 of the file) and the witness resp. the H evaluations of
+ * zkwg_h_evaluations_device as scalars (32 bytes each, standard or Montgomery form).  zkwg_msm_create uploads the bases of one
+ * such sum (window_bits = 0: chosen from n); zkwg_msm_g1_device computes it for the n scalars at d_scalars, d_work =
+ * zkwg_msm_work_bytes bytes of scratch (256-byte aligned), and returns the point as the zkey would store it (affine, Montgomery
+ * form, 64 bytes; zeros = infinity).  ones_apart = 1 for witness scalars (mostly 0 / 1: the bases with scalar 1 are summed by a
+ * plain reduction tree instead of all landing in one bucket).  Bucket method, signed windows, XYZZ accumulators: DESIGN.md section 23. */
+typedef struct zkwg_msm zkwg_msm_t;
+int zkwg_msm_create(int device, const uint8_t* bases, uint64_t n, int window_bits, zkwg_msm_t** out);
+void zkwg_msm_destroy(zkwg_msm_t* plan);
+uint64_t zkwg_msm_work_bytes(const zkwg_msm_t* plan);
+int zkwg_msm_window_bits(const zkwg_msm_t* plan);
+int zkwg_msm_g1_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_montgomery, int ones_apart, void* d_work, uint8_t* out_xy,
+                       void* hip_stream);
+
 /* The same prover stage without a 32-byte witness in between: the constraint system `r1cs` (its wires = the handle's
  * witness layout: built-in, `.sym`, or -- since ABI 3 -- a fully numbered handle of zkwg_circuit_create_full, whose system is
  * the compiler's own `.r1cs`, the file a zkey is keyed to: every wire of every combination is substituted by the kept-v1

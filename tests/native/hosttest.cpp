@@ -228,6 +228,60 @@ void ht_msm(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t
 }
 }
 
+// The device multi-exponentiation (zkwg_msm_core.h: the per-thread bodies of the kernels of zkwg_kernels_msm.hip), executed here
+// thread by thread in the launch order of zk_msm_launch; `shuffle` permutes the thread order of the two atomic passes, as the
+// hardware may.  Scalars in standard form or (mont = 1) Montgomery form.
+#include "zkwg_msm_core.h"
+extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t c, int mont, uint32_t shuffle, int ones_apart, uint8_t* out) {
+  std::vector<G1Affine> P(n);
+  for (uint64_t i = 0; i < n; ++i) P[i] = ht_pt_in(points + 64 * i);
+  std::vector<Fr> S(n);
+  for (uint64_t i = 0; i < n; ++i) { memcpy(&S[i], scalars + 4 * i, 32); if (mont) S[i] = fr_to_mont(S[i]); }
+  ZkMsmArgs A;
+  A.bases = P.data(); A.scalars = S.data(); A.n = (u32)n; A.c = c; A.K = zk_msm_windows(c); A.nb = 1u << (c - 1); A.scalars_mont = mont ? 1u : 0u;
+  const u32 total = A.K * A.nb, half = A.K * ((A.nb + 31) / 32);
+  std::vector<u32> count(total + 1, 0), cursor(total, 0), entry((size_t)n * A.K + 1, 0xdeadbeefu);
+  std::vector<G1Xyzz> bucket(total), ns(2 * (size_t)half + 1), na(2 * (size_t)half + 1), window(A.K), res(1);
+  A.count = count.data(); A.cursor = cursor.data(); A.entry = entry.data(); A.bucket = bucket.data();
+  A.node_s = ns.data(); A.node_a = na.data(); A.window = window.data(); A.out = res.data();
+  const u32 half1 = (u32)((n + 63) / 64);
+  std::vector<G1Xyzz> ones(2 * (size_t)half1 + 1);
+  A.ones_apart = ones_apart ? 1u : 0u; A.ones = ones.data();
+  std::vector<u32> order(n);
+  for (u32 i = 0; i < n; ++i) order[i] = i;
+  u64 x = 0x9e3779b97f4a7c15ull * (shuffle + 1);
+  if (shuffle) for (u64 i = n; i > 1; --i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(order[i - 1], order[x % i]); }
+  for (u32 i : order) zk_msm_count_thread(A, i);
+  std::vector<u32> partial(1025);
+  for (int phase = 0; phase < 2; ++phase) for (u32 t = 0; t < 1024; ++t) zk_msm_scan_thread(A, t, 1024u, partial.data(), phase);
+  for (u32 i : order) zk_msm_scatter_thread(A, i);
+  for (u32 b = 0; b < total; ++b) zk_msm_bucket_thread(A, b);
+  const G1Xyzz* in_s = A.bucket; const G1Xyzz* in_a = nullptr;
+  u32 n_in = A.nb, span = 1, flip = 0;
+  for (;;) {
+    const u32 n_out = (n_in + 31) / 32;
+    G1Xyzz* out_s = A.node_s + (size_t)flip * half;
+    G1Xyzz* out_a = A.node_a + (size_t)flip * half;
+    for (u32 g = 0; g < A.K * n_out; ++g) zk_msm_reduce_thread(A, g, in_s, in_a, n_in, span, out_s, out_a);
+    if (n_out == 1) break;
+    in_s = out_s; in_a = out_a; n_in = n_out; span *= 32; flip ^= 1;
+  }
+  if (A.ones_apart) {     // as zk_msm_launch does
+    u32 m = half1, levels = 0;
+    for (u32 q = m; q > 1; q = (q + 63) / 64) ++levels;
+    G1Xyzz* cur = A.ones + ((levels & 1u) ? half1 : 0);
+    { ZkMsmArgs B = A; B.ones = cur; for (u32 t = 0; t < half1; ++t) zk_msm_ones_thread(B, t); }
+    while (m > 1) {
+      const u32 m2 = (m + 63) / 64;
+      G1Xyzz* nxt = cur == A.ones ? A.ones + half1 : A.ones;
+      for (u32 t = 0; t < m2; ++t) zk_msm_tree_thread(cur, m, nxt, t);
+      cur = nxt; m = m2;
+    }
+  }
+  zk_msm_combine_thread(A);
+  ht_pt_out(res[0], out);
+}
+
 // BN254 G2 building blocks (zkwg_g2.h): standard form across this boundary; a point is x.c0 | x.c1 | y.c0 | y.c1, zeros = infinity
 #include "zkwg_g2.h"
 static Fq2 ht_f2_in(const uint8_t* p) { Fq2 a; memcpy(&a.c0, p, 32); memcpy(&a.c1, p + 32, 32); return Fq2{fq_to_mont(a.c0), fq_to_mont(a.c1)}; }

@@ -141,6 +141,52 @@ def test_device_path_compiles_for_gfx950_without_scratch(tmp_path):
     assert max(vgprs) <= 128, vgprs          # 4 wavefronts per SIMD
 
 
+@pytest.mark.parametrize("n,c,mont", [(1, 3, 0), (50, 4, 1), (700, 7, 0), (2000, 11, 1), (3000, 13, 0)])
+def test_device_msm_bodies_thread_by_thread_equal_the_oracle(n, c, mont):
+    """zkwg_msm_core.h -- count / scan / scatter / bucket sums / the 32-way reduction tree / window combination, the bodies of the
+    kernels of zkwg_kernels_msm.hip -- executed thread by thread on the host in launch order, with the atomic passes in a shuffled
+    thread order: equals the oracle's bucket method (c = 11, 13: two and three levels of the tree)."""
+    lib = _lib()
+    lib.ht_msm_device_mirror.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_char_p]
+    rng = random.Random(900 + n)
+    base = G.random_points(min(n, 48), n + 1)
+    pts = [base[rng.randrange(len(base))] if rng.random() < 0.93 else None for _ in range(n)]
+    if n > 4:
+        pts[1] = G.neg(pts[0]) if pts[0] else None
+    special = [R - 1, 0, 1, 1 << (c - 1), (1 << c) - 1, R - 2, 1 << 253]
+    ks = [special[i] if i < len(special) and i < n else rng.randrange(R) for i in range(n)]
+    buf = b"".join(_pt(p) for p in pts)
+    sc = (C.c_uint64 * (4 * n))(*[(k >> (64 * i)) & ((1 << 64) - 1) for k in ks for i in range(4)])
+    want = G.msm_buckets(pts, ks, 7) if n > 64 else G.msm_naive(pts, ks)
+    out = C.create_string_buffer(64)
+    for shuffle in (0, 5):
+        lib.ht_msm_device_mirror(buf, sc, C.c_uint64(n), c, mont, shuffle, 0, out)
+        assert _unpt(out.raw) == want, (n, c, mont, shuffle)
+
+
+@pytest.mark.parametrize("n,c", [(40, 4), (5000, 8), (9000, 10)])
+def test_device_msm_bodies_on_witness_like_scalars(n, c):
+    """scalars as a witness has them -- mostly 0 and 1, some bytes, a few field elements -- with ones_apart: the bases with scalar
+    1 go through zk_msm_ones + the 64-way tree (one, two and three levels here) instead of one bucket"""
+    lib = _lib()
+    lib.ht_msm_device_mirror.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_char_p]
+    rng = random.Random(1700 + n)
+    base = G.random_points(32, n + 3)
+    pts = [base[rng.randrange(len(base))] if rng.random() < 0.97 else None for _ in range(n)]
+    ks = [rng.choice([0, 1]) if rng.random() < 0.9 else (rng.randrange(256) if rng.random() < 0.7 else rng.randrange(R)) for _ in range(n)]
+    buf = b"".join(_pt(p) for p in pts)
+    sc = (C.c_uint64 * (4 * n))(*[(k >> (64 * i)) & ((1 << 64) - 1) for k in ks for i in range(4)])
+    # the oracle, folded over the 32 distinct bases
+    folded = {}
+    for p, k in zip(pts, ks):
+        if p is not None:
+            folded[p] = (folded.get(p, 0) + k) % R
+    want = G.msm_naive(list(folded), list(folded.values()))
+    out = C.create_string_buffer(64)
+    for apart in (1, 0):
+        lib.ht_msm_device_mirror(buf, sc, C.c_uint64(n), c, 1, 3, apart, out)
+        assert _unpt(out.raw) == want, (n, c, apart)
+
 def test_g2_arithmetic_against_the_oracle():
     """zkwg_g2.h (Fq2 by Karatsuba, the XYZZ additions over the twist) against oracle/pyref/bn254_g2.py, which is pinned by the
     EIP-197 generator: on the twist, r * G2 = O"""

@@ -1,0 +1,76 @@
+"""G1 multi-exponentiation on the device (include/zkwg.h "prover stage 3", DRAFT on branch next/msm) against the oracle
+(oracle/pyref/bn254_g1.py).  The kernel bodies are the ones tests/test_g1_cpu.py runs thread by thread on the host."""
+import random
+
+import pytest
+
+from oracle.pyref import bn254_g1 as G
+
+R = G.R
+
+
+def _case(n, seed, c=0, mont=False):
+    import torch
+    import zkwg
+    rng = random.Random(seed)
+    base = G.random_points(min(n, 64), seed)
+    pts = [base[rng.randrange(len(base))] if rng.random() < 0.95 else None for _ in range(n)]
+    if n > 4:
+        pts[1] = G.neg(pts[0]) if pts[0] else None
+    special = [R - 1, 0, 1, 2, R - 2, 1 << 253]
+    ks = [special[i] if i < len(special) and i < n else rng.randrange(R) for i in range(n)]
+    m = zkwg.Msm(zkwg.Msm.pack_bases(pts), device=0, window_bits=c)
+    enc = [(k << 256) % R if mont else k for k in ks]
+    buf = b"".join(int(k).to_bytes(32, "little") for k in enc)
+    dev = torch.device("cuda", 0)
+    d_s = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
+    d_w = torch.empty(m.work_bytes() + 256, dtype=torch.uint8, device=dev)
+    off = (-d_w.data_ptr()) % 256
+    got = m.g1_device(d_s, mont, d_w[off:], ones_apart=(n % 2 == 0))
+    want = G.msm_buckets(pts, ks, 8)
+    assert got == want, (n, c, mont)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,mont", [(1, 4, False), (300, 7, True), (5000, 0, False), (70000, 13, True)])
+def test_gpu_msm_equals_the_oracle(n, c, mont):
+    _case(n, 4000 + n, c, mont)
+
+
+@pytest.mark.gpu
+def test_gpu_msm_of_h_sized_input_is_linear():
+    """2^18 bases, random scalars: MSM(k) + MSM(k') = MSM(k + k') and MSM(2 k) = 2 MSM(k) (the oracle cannot finish this size)"""
+    import torch
+    import zkwg
+    n = 1 << 18
+    rng = random.Random(77)
+    base = G.random_points(256, 9)
+    pts = [base[i % 256] for i in range(n)]
+    m = zkwg.Msm(zkwg.Msm.pack_bases(pts), device=0)
+    dev = torch.device("cuda", 0)
+    d_w = torch.empty(m.work_bytes() + 256, dtype=torch.uint8, device=dev)
+    off = (-d_w.data_ptr()) % 256
+
+    def run(ks):
+        buf = b"".join(int(k).to_bytes(32, "little") for k in ks)
+        return m.g1_device(torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev), False, d_w[off:])
+    k1 = [rng.randrange(R) for _ in range(n)]
+    k2 = [rng.randrange(R) for _ in range(n)]
+    a, b = run(k1), run(k2)
+    assert run([(x + y) % R for x, y in zip(k1, k2)]) == G.add(a, b)
+    assert run([2 * x % R for x in k1]) == G.add(a, a)
+    # against the oracle through the structure of the bases: sum_i k_i base[i % 256] = sum_j (sum_{i = j mod 256} k_i) base[j]
+    folded = [sum(k1[j::256]) % R for j in range(256)]
+    assert a == G.msm_naive(base, folded)
+
+
+def test_library_exports_the_msm_entry_points_and_refuses_without_a_device():
+    import ctypes as C
+    import zkwg
+    from zkwg import _lib
+    lib = _lib.load()
+    for name in ("zkwg_msm_create", "zkwg_msm_destroy", "zkwg_msm_work_bytes", "zkwg_msm_window_bits", "zkwg_msm_g1_device"):
+        assert hasattr(lib, name)
+    h = C.c_void_p()
+    assert lib.zkwg_msm_create(-1, bytes(64), 1, 0, C.byref(h)) != 0          # no CPU fallback
+    assert zkwg.Msm.pack_bases([None, (1, 2)])[:64] == bytes(64)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Times the G1 multi-exponentiation (DRAFT) at the H stage's sizes: n = 2^log2 bases (multiples of 256 random
+points), random 254-bit scalars in Montgomery form as the transform stage leaves them.  Prints one JSON line; the roofline is
+multiplier issue: K * n mixed additions x 10 products + the reduction tree, against 76.8 G Montgomery products/s.
+
+    python tools/bench_msm.py [--log2 20] [--window 0] [--reps 3]
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "zk-email-verify_amd", "py"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2", type=int, default=20)
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--witness", type=int, default=0, help="1: witness-like scalars (90 %% bits, bytes, a few field elements), ones_apart")
+    args = ap.parse_args()
+    import torch
+    import zkwg
+    from oracle.pyref import bn254_g1 as G
+    n = 1 << args.log2
+    base = G.random_points(256, 1)
+    packed = zkwg.Msm.pack_bases(base)
+    m = zkwg.Msm(packed * (n // 256), device=0, window_bits=args.window)
+    dev = torch.device("cuda", 0)
+    # scalars: random bytes with the top bits cleared (< 2^253 < r), declared to be in Montgomery form
+    d_s = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev)
+    d_s[:, 31] &= 0x1F
+    mont = True
+    if args.witness:
+        kind = torch.rand(n, device=dev)
+        d_s[kind < 0.97, 1:] = 0                       # bytes
+        d_s[kind < 0.90, 0] &= 1                       # bits
+        mont = False
+    d_w = torch.empty(m.work_bytes() + 256, dtype=torch.uint8, device=dev)
+    off = (-d_w.data_ptr()) % 256
+    m.g1_device(d_s, mont, d_w[off:], ones_apart=bool(args.witness))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.reps):
+        p = m.g1_device(d_s, mont, d_w[off:], ones_apart=bool(args.witness))
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) / args.reps * 1e3
+    c = m.window_bits
+    K = (254 + c) // c
+    products = K * n * 10 + K * (1 << (c - 1)) * 3 * 14 + n
+    print(json.dumps({"n": n, "window_bits": c, "windows": K, "ms": round(ms, 3), "msm_per_s": round(1e3 / ms, 2),
+                      "G_products_per_s": round(products / ms / 1e6, 2), "frac_of_issue_roofline": round(products / ms / 1e6 / 76.8, 4),
+                      "on_curve": p is None or G.on_curve(p)}))
+
+
+if __name__ == "__main__":
+    main()

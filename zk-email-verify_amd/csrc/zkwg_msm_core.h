@@ -1,0 +1,144 @@
+// G1 multi-exponentiation on the device: the per-thread bodies of the kernels of zkwg_kernels_msm.hip, shared with the host
+// mirror of the CPU tests (tests/native/hosttest.cpp runs exactly these functions, thread by thread).  Bucket method with signed
+// c-bit windows (zkwg_g1.h), organised around one counting sort per call:
+//
+//   zk_msm_count    one thread per scalar: leave Montgomery form (one product), cut into K signed digits, count[window * nb + |d| - 1]++
+//   zk_msm_scan     exclusive prefix sums of the K * nb counters (one workgroup)
+//   zk_msm_scatter  one thread per scalar: the same digits again; entry[cursor[bucket]++] = base index | sign << 31
+//                   (the order inside a bucket depends on the atomics; the sum does not -- point addition is exact and commutative)
+//   zk_msm_buckets  one thread per bucket: its run of entries, accumulated with g1_add_mixed
+//   zk_msm_reduce   sum_b (b + 1) bucket[b] per window as a tree of 32-way groups: a node is (S, A) = (plain sum, weighted sum with
+//                   weights 1 .. span); 32 nodes of span s join into A = sum A_i + s * sum_i i S_i (running sum from the top, log2 s
+//                   doublings), S = sum S_i.  nb = 2^(c-1) buckets take ceil((c-1)/5) levels.
+//   zk_msm_combine  one thread: Horner over the windows, c doublings each
+//
+// DRAFT (branch next/msm, round 4): written and mirrored on the CPU after the round's GPU budget was spent; it has not run on a GPU.
+#pragma once
+#include "zkwg_g1.h"
+
+struct ZkMsmArgs {
+  const G1Affine* bases;      // n points, Montgomery form, (0, 0) = infinity
+  const Fr* scalars;          // n scalars of this call
+  u32 n, c, K, nb;            // points, window bits, windows, buckets per window = 2^(c-1)
+  u32 scalars_mont;           // 1: the scalars are in Montgomery form (the H evaluations of zkwg_ntt_api.hip, a Montgomery witness)
+  u32 ones_apart;             // 1: scalars equal to 1 do not enter the buckets (a witness is mostly bits: they would all land in ONE
+                              // bucket of window 0); their bases are summed by zk_msm_ones + the 64-way tree and added at the end
+  G1Xyzz* ones;               // [2 x ceil(n / 64)] tree scratch of the ones' sum (ping-pong halves); ones[0] = the sum at the end
+  u32* count;                 // [K * nb + 1] counters, then exclusive offsets (zk_msm_scan)
+  u32* cursor;                // [K * nb] running write positions of zk_msm_scatter
+  u32* entry;                 // [n * K] base index | sign << 31, grouped by bucket
+  G1Xyzz* bucket;             // [K * nb]
+  G1Xyzz* node_s; G1Xyzz* node_a;   // reduction tree scratch: [K * nb / 32 * 2] each (ping-pong halves)
+  G1Xyzz* window;             // [K] weighted bucket sums
+  G1Xyzz* out;                // [1]
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_MSM_ATOMIC_INC(p) atomicAdd((p), 1u)
+#else
+#define ZK_MSM_ATOMIC_INC(p) ((*(p))++)
+#endif
+
+// scalar i in standard form
+ZK_HD Fr zk_msm_scalar(const ZkMsmArgs& A, u32 i) { return A.scalars_mont ? fr_from_mont(A.scalars[i]) : A.scalars[i]; }
+ZK_HD bool zk_msm_is_one(const Fr& k) { return k.l[0] == 1 && (k.l[1] | k.l[2] | k.l[3]) == 0; }
+// the bases whose scalar is 1, 64 per thread (ones_apart); then zk_msm_tree_thread joins 64 partial sums per thread until one is left
+ZK_HD void zk_msm_ones_thread(const ZkMsmArgs& A, u32 t) {
+  const u32 lo = t * 64u, hi = lo + 64u < A.n ? lo + 64u : A.n;
+  if (lo >= A.n) return;
+  G1Xyzz acc = g1_xyzz_inf();
+  for (u32 i = lo; i < hi; ++i)
+    if (zk_msm_is_one(zk_msm_scalar(A, i))) acc = g1_add_mixed(acc, A.bases[i]);
+  A.ones[t] = acc;
+}
+ZK_HD void zk_msm_tree_thread(const G1Xyzz* in, u32 n_in, G1Xyzz* out, u32 t) {
+  const u32 lo = t * 64u, hi = lo + 64u < n_in ? lo + 64u : n_in;
+  if (lo >= n_in) return;
+  G1Xyzz acc = in[lo];
+  for (u32 i = lo + 1; i < hi; ++i) acc = g1_add(acc, in[i]);
+  out[t] = acc;
+}
+ZK_HD void zk_msm_count_thread(const ZkMsmArgs& A, u32 i) {
+  if (i >= A.n || g1_is_inf(A.bases[i])) return;
+  const Fr k = zk_msm_scalar(A, i);
+  if (A.ones_apart && zk_msm_is_one(k)) return;
+  u32 carry = 0;
+  for (u32 w = 0; w < A.K; ++w) {
+    const int d = zk_msm_digit(k.l, w, A.c, carry);
+    if (d) ZK_MSM_ATOMIC_INC(&A.count[w * A.nb + (u32)(d < 0 ? -d : d) - 1u]);
+  }
+}
+// one workgroup of `threads` threads (thread t of them): counts -> exclusive offsets in place, cursor = offsets; count[total] = entries.
+// Two phases separated by a barrier the caller supplies (host mirror: phase 0 for every t, then phase 1 for every t).
+ZK_HD void zk_msm_scan_thread(const ZkMsmArgs& A, u32 t, u32 threads, u32* partial /*[threads + 1]*/, int phase) {
+  const u32 total = A.K * A.nb, per = (total + threads - 1) / threads;
+  const u32 lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
+  if (phase == 0) {
+    u32 s = 0;
+    for (u32 k = lo; k < hi; ++k) s += A.count[k];
+    partial[t + 1] = s;
+    if (t == 0) partial[0] = 0;
+    return;
+  }
+  u32 base = 0;
+  for (u32 k = 0; k <= t; ++k) base += partial[k];      // (threads is small: 256 .. 1024)
+  for (u32 k = lo; k < hi; ++k) { const u32 v = A.count[k]; A.count[k] = base; A.cursor[k] = base; base += v; }
+  if (hi == total && lo < total) A.count[total] = base;
+  if (total == 0 && t == 0) A.count[0] = 0;
+}
+ZK_HD void zk_msm_scatter_thread(const ZkMsmArgs& A, u32 i) {
+  if (i >= A.n || g1_is_inf(A.bases[i])) return;
+  const Fr k = zk_msm_scalar(A, i);
+  if (A.ones_apart && zk_msm_is_one(k)) return;
+  u32 carry = 0;
+  for (u32 w = 0; w < A.K; ++w) {
+    const int d = zk_msm_digit(k.l, w, A.c, carry);
+    if (!d) continue;
+    const u32 b = w * A.nb + (u32)(d < 0 ? -d : d) - 1u;
+    const u32 at = ZK_MSM_ATOMIC_INC(&A.cursor[b]);
+    A.entry[at] = i | (d < 0 ? 0x80000000u : 0u);
+  }
+}
+ZK_HD void zk_msm_bucket_thread(const ZkMsmArgs& A, u32 b) {
+  if (b >= A.K * A.nb) return;
+  G1Xyzz acc = g1_xyzz_inf();
+  for (u32 k = A.count[b], e = A.count[b + 1]; k < e; ++k) {
+    const u32 v = A.entry[k];
+    G1Affine p = A.bases[v & 0x7fffffffu];
+    if (v >> 31) p.y = fq_neg(p.y);
+    acc = g1_add_mixed(acc, p);
+  }
+  A.bucket[b] = acc;
+}
+// one level of the reduction tree.  Nodes of the level below: `n_in` per window with span `span` (weights 1 .. span inside a node);
+// in_a == nullptr: the nodes are the buckets themselves (S = A = bucket, span 1).  Thread g builds node g of the level above
+// (`n_out` = ceil(n_in / 32) per window).  The last level (n_out == 1) writes the window's sum to A.window.
+ZK_HD void zk_msm_reduce_thread(const ZkMsmArgs& A, u32 g, const G1Xyzz* in_s, const G1Xyzz* in_a, u32 n_in, u32 span, G1Xyzz* out_s, G1Xyzz* out_a) {
+  const u32 n_out = (n_in + 31u) / 32u;
+  if (g >= A.K * n_out) return;
+  const u32 w = g / n_out, q = g - w * n_out;
+  const u32 lo = q * 32u, hi = lo + 32u < n_in ? lo + 32u : n_in;
+  const G1Xyzz* S = in_s + (size_t)w * n_in;
+  const G1Xyzz* Aw = (in_a ? in_a : in_s) + (size_t)w * n_in;
+  // sum_i i S_i for i = 1 .. m - 1 (running sum from the top), sum S_i, sum A_i
+  G1Xyzz run = g1_xyzz_inf(), acc = g1_xyzz_inf(), sum_a = g1_xyzz_inf();
+  for (u32 k = hi; k-- > lo;) {
+    sum_a = g1_add(sum_a, Aw[k]);
+    if (k > lo) { run = g1_add(run, S[k]); acc = g1_add(acc, run); }
+  }
+  const G1Xyzz sum_s = g1_add(run, S[lo]);
+  for (u32 s = span; s > 1; s >>= 1) acc = g1_dbl(acc);            // span is a power of two
+  const G1Xyzz node_a = g1_add(sum_a, acc);
+  if (n_out == 1) { A.window[w] = node_a; return; }
+  out_s[(size_t)w * n_out + q] = sum_s;
+  out_a[(size_t)w * n_out + q] = node_a;
+}
+ZK_HD void zk_msm_combine_thread(const ZkMsmArgs& A) {
+  G1Xyzz total = g1_xyzz_inf();
+  for (u32 w = A.K; w-- > 0;) {
+    for (u32 s = 0; s < A.c; ++s) total = g1_dbl(total);
+    total = g1_add(total, A.window[w]);
+  }
+  if (A.ones_apart) total = g1_add(total, A.ones[0]);
+  A.out[0] = total;
+}

@@ -495,6 +495,51 @@ class Ntt:
                                                   d_out.data_ptr(), out_stride if out_stride else 32 * self.n, _stream_ptr(stream)))
 
 
+class Msm:
+    """One G1 multi-exponentiation of groth16.prove (include/zkwg.h "prover stage 3", DRAFT): `bases` = n affine points as the zkey
+    stores them (x | y little-endian Montgomery limbs, 64 bytes each, zeros = infinity), resident on the device."""
+    Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+    def __init__(self, bases, device=0, window_bits=0):
+        self.lib = _lib.load()
+        assert len(bases) % 64 == 0
+        self.n = len(bases) // 64
+        h = C.c_void_p()
+        _check(self.lib.zkwg_msm_create(device, bytes(bases), self.n, window_bits, C.byref(h)))
+        self.h, self.device = h, device
+        self.window_bits = self.lib.zkwg_msm_window_bits(h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.zkwg_msm_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def pack_bases(points):
+        """[(x, y) | None] (standard-form integers) -> the zkey's byte layout (Montgomery form)"""
+        out = bytearray()
+        for p in points:
+            if p is None:
+                out += bytes(64)
+            else:
+                out += ((p[0] << 256) % Msm.Q).to_bytes(32, "little") + ((p[1] << 256) % Msm.Q).to_bytes(32, "little")
+        return bytes(out)
+
+    def work_bytes(self):
+        return self.lib.zkwg_msm_work_bytes(self.h)
+
+    def g1_device(self, d_scalars, montgomery, d_work, stream=None, ones_apart=False):
+        """sum_i scalar_i * base_i for the n 32-byte scalars at d_scalars (torch tensor) -> (x, y) standard-form integers or None"""
+        out = (C.c_uint8 * 64)()
+        _check(self.lib.zkwg_msm_g1_device(self.h, d_scalars.data_ptr(), 1 if montgomery else 0, 1 if ones_apart else 0, d_work.data_ptr(), out,
+                                           _stream_ptr(stream)))
+        raw = bytes(out)
+        if raw == bytes(64):
+            return None
+        rinv = pow(1 << 256, -1, Msm.Q)
+        return (int.from_bytes(raw[:32], "little") * rinv % Msm.Q, int.from_bytes(raw[32:], "little") * rinv % Msm.Q)
+
+
 class MultiCircuit:
     """The batch sharded over several GPUs of one node through the C-ABI (include/zkwg.h zkwg_multi_*):
     contiguous shards, one handle + host thread per GPU, the 100-byte result table gathered on devices[0]

@@ -134,6 +134,11 @@ def load():
         "zkwg_ntt_work_bytes": (u64, [vp, u64]),
         "zkwg_ntt_transform_device": (i32, [vp, vp, u64, i32, vp]),
         "zkwg_h_evaluations_device": (i32, [vp, vp, u64, u64, u64, vp, vp, u64, vp]),
+        "zkwg_msm_create": (i32, [i32, vp, u64, i32, C.POINTER(vp)]),
+        "zkwg_msm_destroy": (None, [vp]),
+        "zkwg_msm_work_bytes": (u64, [vp]),
+        "zkwg_msm_window_bits": (i32, [vp]),
+        "zkwg_msm_g1_device": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "zkwg_calculate_batch_resident": (i32, [vp, vp, u64, vp, vp, u64, u64, vp, vp]),
         "zkwg_resident_placement": (i32, [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]),
     }
@@ -155,4 +160,5 @@ EXPORTS = [
     "zkwg_convert_montgomery_device", "zkwg_shard_range", "zkwg_multi_create", "zkwg_multi_destroy", "zkwg_multi_devices",
     "zkwg_multi_circuit", "zkwg_calculate_batch_multi", "zkwg_calculate_batch_resident", "zkwg_resident_placement",
     "zkwg_ntt_create", "zkwg_ntt_destroy", "zkwg_ntt_domain", "zkwg_ntt_work_bytes", "zkwg_ntt_transform_device", "zkwg_h_evaluations_device",
+    "zkwg_msm_create", "zkwg_msm_destroy", "zkwg_msm_work_bytes", "zkwg_msm_window_bits", "zkwg_msm_g1_device",
 ]
