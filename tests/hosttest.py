@@ -255,6 +255,7 @@ class LoadedRegex:
         match = C.c_uint32(0xffffffff)
         reveal = (C.c_uint32 * self.n)()
         ok = self.lib.ht_net_eval(self.h, msg, words, C.byref(match), reveal)
+        assert ok >= 0, "the runs of the region do not tile it"
         vals = {}
         for nm, w in zip(self.names, words):
             d = w & 0x7fffffff

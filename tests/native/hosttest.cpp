@@ -136,8 +136,8 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
   K.n_in = N.n_in;
   K.f_end = N.chain.end; K.f_smax = N.chain.smax; K.f_mw = N.chain.mask_words;
   K.b_end = N.bchain.end; K.b_smax = N.bchain.smax; K.b_mw = N.bchain.mask_words; K.b_fdim = N.bchain.fdim;
-  K.f_cls = N.chain.cls.data(); K.f_delta = N.chain.delta.data(); K.f_mask = N.chain.mask.data(); K.f_tab = N.chain.tab.data();
-  K.b_cls = N.bchain.cls.data(); K.b_delta = N.bchain.delta.data(); K.b_mask = N.bchain.mask.data(); K.b_tab = N.bchain.tab.data();
+  K.f_cls = N.chain.cls.data(); K.f_delta = N.chain.delta.data(); K.f_mask = N.chain.mask.data();
+  K.b_cls = N.bchain.cls.data(); K.b_delta = N.bchain.delta.data(); K.b_mask = N.bchain.mask.data();
   std::vector<u32> fwords(N.n_in / 4 + 2, 0xa5a5a5a5u), bwords(N.n_in / 4 + 2, 0xa5a5a5a5u);   // (as in the image: stale bytes where no chain wrote)
   zk_net_scan_email(K, msg, fwords.data(), bwords.data());
   const u8* fstate = (const u8*)fwords.data(); const u8* bstate = (const u8*)bwords.data();
@@ -156,17 +156,25 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
       else zk_net_record32(&N.records[g * 16], snap.data(), lds.data(), img.data());
     }
   }
-  memcpy(words, img.data(), (size_t)N.n_kept * 4);
-  // byte-local and chain kept signals are not gates of the list: zk_net_fill (zkwg_kernels_net.hip) writes their words, thread by thread
-  for (u32 blk = 0; blk * 1024u < N.n_kept; ++blk)
-    for (u32 tid = 0; tid < 256; ++tid) {
-      ZkNetFillLane F;
-      const u32 r0 = blk * 1024u + tid;
-      if (!F.init(N.slot_desc.data(), N.n_kept, r0, N.fn_tab.data(), K)) continue;
-      u32 w[4];
-      F.load(msg, fstate, bstate, w);
-      F.store(words, r0, w);
+  // byte-local and chain kept signals are not gates of the list: zk_expand decodes them from the position words the evaluator's
+  // prologue leaves (zkwg_expand_dec.h ZkDecNetP / zkwg_net_core.h zk_netp_word) -- the same code, run over the region's runs
+  std::vector<u32> small(N.n_kept + N.n_in, 0);
+  memcpy(small.data(), img.data(), (size_t)N.n_kept * 4);
+  for (u32 i = 0; i < N.n_in; ++i) small[N.n_kept + i] = zk_net_pos_word(K, i, msg, fstate, bstate);
+  ZkNetDec D;
+  D.pd = N.pd.data(); D.tab = N.tabs.data();
+  D.offF = N.offF; D.offB = N.offB; D.nL = N.nL; D.nF = N.nF; D.nB = N.nB; D.b_fdim = N.bchain.fdim;
+  D.m_net = 0; D.m_net_pw = N.n_kept;
+  u32 covered = 0;
+  for (const zkc::Net::Run& R : N.runs) {
+    if (R.start != covered) return -1;      // the runs tile the region
+    for (u32 r = 0; r < R.nslots; ++r) {
+      const u32 i = r / R.period, q = r % R.period;
+      words[R.start + r] = zk_netp_word(D, N.pd[2 * (R.pd0 + q)], N.pd[2 * (R.pd0 + q) + 1], i, R.start + r, small.data());
     }
+    covered += R.nslots;
+  }
+  if (covered != N.n_kept) return -1;
   return ok ? 1 : 0;
 }
 }

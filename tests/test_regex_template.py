@@ -187,6 +187,62 @@ def test_random_finite_state_templates_chain_tables_against_the_plain_gate_list(
     assert both >= 5, both
 
 
+def _periodic_template(rng, P, X):
+    """a forward chain whose reachable states differ from position to position -- a counter modulo P carried in one-hot bits that
+    rotate by squaring, beside X comparator-driven bits that read it -- under a backward chain over all of them"""
+    S = P + X
+    L = ['pragma circom 2.1.5;', 'include "./helpers.circom";', '', 'template Fuzz(msg_bytes) {', '    signal input msg[msg_bytes];',
+         '    signal output out;', '    signal output reveal0[msg_bytes];', '    component e[2][msg_bytes];',
+         f'    signal s[msg_bytes + 1][{S}];', '    signal b[msg_bytes + 1];']
+    for j in range(S):
+        L.append(f'    s[0][{j}] <== {1 if j == 0 else 0};')
+    L.append('    for (var i = 0; i < msg_bytes; i++) {')
+    for k, ch in enumerate((97, 98)):
+        L += [f'        e[{k}][i] = IsEqual();', f'        e[{k}][i].in[0] <== msg[i];', f'        e[{k}][i].in[1] <== {ch};']
+    for j in range(P):
+        L.append(f'        s[i + 1][{j}] <== s[i][{(j + P - 1) % P}] * s[i][{(j + P - 1) % P}];')
+    for j in range(P, S):
+        a, b2, k1, k2, form = rng.randrange(S), rng.randrange(S), rng.randrange(2), rng.randrange(2), rng.randrange(3)
+        if form == 0:
+            L.append(f'        s[i + 1][{j}] <== OR()(AND()(s[i][{a}], e[{k1}][i].out), AND()(s[i][{b2}], e[{k2}][i].out));')
+        elif form == 1:
+            L.append(f'        s[i + 1][{j}] <== AND()(s[i][{a}], 1 - e[{k1}][i].out);')
+        else:
+            L.append(f'        s[i + 1][{j}] <== OR()(e[{k1}][i].out, s[i][{a}] * s[i][{b2}]);')
+    L.append('    }')
+    L += ['    b[msg_bytes] <== 0;', '    for (var i = msg_bytes - 1; i >= 0; i--) {',
+          f'        b[i] <== OR()(AND()(b[i + 1], 1 - s[i + 1][{rng.randrange(S)}]), s[i + 1][{rng.randrange(S)}] * e[{rng.randrange(2)}][i].out);', '    }',
+          '    component acc = MultiOR(msg_bytes);', f'    for (var i = 0; i < msg_bytes; i++) acc.in[i] <== s[i + 1][{rng.randrange(S)}];',
+          '    out <== acc.out;', '    for (var i = 0; i < msg_bytes; i++) reveal0[i] <== msg[i] * b[i];', '}']
+    return "\n".join(L) + "\n"
+
+
+def test_backward_tables_when_the_forward_states_differ_from_position_to_position(tmp_path, monkeypatch):
+    """which symbols (forward state, byte) can follow a backward state depends on the position; a row of a class
+    tabulated at the first position that reaches its state must not be taken for complete by later positions of the class where other
+    forward states occur (periodic / anchored automata).  Seeds 65 and 73 are two circuits of this family on which the round-4 loader
+    produced wrong witnesses (found by running this generator against it); the cells are now tabulated as positions need them."""
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "regex_style", "helpers.circom"), tmp_path / "helpers.circom")
+    served = 0
+    for seed in (65, 73, 5, 11, 140):
+        rng = random.Random(seed)
+        P, X, n = rng.choice([2, 3, 4]), rng.choice([1, 2, 3]), rng.choice([16, 24, 32])
+        f = tmp_path / f"periodic{seed}.circom"
+        f.write_text(_periodic_template(rng, P, X))
+        monkeypatch.setenv("ZKWG_NET_CHAIN", "0")
+        plain = hosttest.LoadedRegex(str(f), n, template="Fuzz")
+        monkeypatch.delenv("ZKWG_NET_CHAIN")
+        tab = hosttest.LoadedRegex(str(f), n, template="Fuzz")
+        assert plain.names == tab.names
+        fwd, bwd, _ = tab.chain_info()
+        served += fwd > 0 and bwd > 0
+        for _ in range(30):
+            msg = bytes(rng.choice([97, 98, 99, 0]) for _ in range(n))
+            assert tab.evaluate(msg) == plain.evaluate(msg), (seed, msg)
+    assert served >= 4, served
+
+
 def test_product_side_copy_of_the_stand_in_is_current():
     base = os.path.join(ROOT, "zk-email-verify_amd", "data", "templates", "zk-regex-circom", "circuits")
     lib = os.path.dirname(os.path.dirname(STAND_IN))

@@ -54,8 +54,10 @@ struct zkwg_circuit {
   // BodyHashRegex loaded from a circom template (zkwg_circuit_create_regex): gate list on the device
   zkc::Net net;
   bool has_net;
-  u32* d_net_records; u32* d_net_counts; u32* d_net_mask_tab; u32* d_net_fn; u32* d_net_desc;
-  u8* d_net_cclass; u8* d_net_cdelta; u32* d_net_cmask; u32* d_net_ctab; u8* d_net_bclass; u8* d_net_bdelta; u32* d_net_bmask; u32* d_net_btab;
+  u32* d_net_records; u32* d_net_counts; u32* d_net_mask_tab; u32* d_net_pd; u32* d_net_tabs;
+  ZkNetDec* d_netd;   // how zk_expand decodes the region (device copy); h_netd: the same with host pointers (host expansion)
+  ZkNetDec h_netd;
+  u8* d_net_cclass; u8* d_net_cdelta; u32* d_net_cmask; u8* d_net_bclass; u8* d_net_bdelta; u32* d_net_bmask;
   Fr* d_rtab;     // fused Montgomery output: v * R mod r for v < 65536 (built on first use)
   Fr* d_pos;      // Poseidon(9): sparse-round table (zk_build_poseidon_sparse(10, 60))
   u32 pos2_off;
@@ -87,7 +89,6 @@ struct zkwg_circuit {
   int pos_side;   // 1: fork zk_poseidon9 onto a side stream (ZKWG_POS_SIDE=1); default 0 = caller's stream
   int pos_lane;   // 1: the lane-per-email zk_poseidon9 of round 2 instead of zk_poseidon9_g16 (ZKWG_POS_LANE=1)
   int pos_wave_below;   // batches below this many emails use the wavefront-per-email kernel (ZKWG_POS_WAVE_BELOW, default 1024)
-  int net_fill_late;   // loaded regex template: zk_net_fill runs in front of every expansion, on its stream, instead of in prepare (ZKWG_NET_FILL_LATE)
   u32 xcd_remap;  // zk_expand workgroup -> portion mapping (ZKWG_XCD_REMAP)
   // host-buffer path: cached device staging buffers (double-buffered witnesses)
   std::mutex hb_mutex;
@@ -260,7 +261,6 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 1);   // (round 4: 8 KiB pieces, 53 VGPRs = 8 wavefronts per SIMD, software-pipelined over the group's emails)
   c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 16;
   c->o0_pipe = getenv("ZKWG_O0_PIPE") ? atoi(getenv("ZKWG_O0_PIPE")) : 2;
-  c->net_fill_late = getenv("ZKWG_NET_FILL_LATE") ? atoi(getenv("ZKWG_NET_FILL_LATE")) : 0;
   c->xcd_remap = getenv("ZKWG_XCD_REMAP") ? (u32)atoi(getenv("ZKWG_XCD_REMAP")) : 1u;
   c->rsa_wgs_per_cu = 0;
   if (const char* v = getenv("ZKWG_RSA_WGS_PER_CU")) c->rsa_wgs_per_cu = atoi(v);
@@ -291,6 +291,12 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     t_last = now;
   };
   if (!build_sched(*cfg, c->s, c->segs, net)) { g_last_error = "unsupported circuit configuration"; delete c; return ZKWG_RC_BAD_CONFIG; }
+  if (c->has_net) {   // how a slot of the template's region is decoded, with host pointers (host expansion, layout-only handles); the device copy follows
+    ZkNetDec& D = c->h_netd;
+    D.pd = c->net.pd.data(); D.tab = c->net.tabs.data();
+    D.offF = c->net.offF; D.offB = c->net.offB; D.nL = c->net.nL; D.nF = c->net.nF; D.nB = c->net.nB; D.b_fdim = c->net.bchain.fdim;
+    D.m_net = c->s.m_net; D.m_net_pw = c->s.m_net_pw;
+  }
   if (getenv("ZKWG_DEBUG_SKIP_INV") && atoi(getenv("ZKWG_DEBUG_SKIP_INV")) && c->s.rsa.present) c->s.rsa.present = 2;  // profiling only
   if (sym_text) {
     ZkSymLayout L;
@@ -427,9 +433,14 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
         if (!ok) return;
         ok = hipMalloc((void**)dst, std::max<size_t>(v.size(), 4) * 4) == hipSuccess && (v.empty() || hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
       };
-      upw(c->net.mask_tab, &c->d_net_mask_tab); upw(c->net.fn_tab, &c->d_net_fn); upw(c->net.slot_desc, &c->d_net_desc);
-      upw(c->net.chain.mask, &c->d_net_cmask); upw(c->net.chain.tab, &c->d_net_ctab);
-      upw(c->net.bchain.mask, &c->d_net_bmask); upw(c->net.bchain.tab, &c->d_net_btab);
+      upw(c->net.mask_tab, &c->d_net_mask_tab); upw(c->net.pd, &c->d_net_pd); upw(c->net.tabs, &c->d_net_tabs);
+      upw(c->net.chain.mask, &c->d_net_cmask);
+      upw(c->net.bchain.mask, &c->d_net_bmask);
+      {
+        ZkNetDec D = c->h_netd;
+        D.pd = c->d_net_pd; D.tab = c->d_net_tabs;
+        ok = ok && hipMalloc((void**)&c->d_netd, sizeof(ZkNetDec)) == hipSuccess && hipMemcpy(c->d_netd, &D, sizeof(D), hipMemcpyHostToDevice) == hipSuccess;
+      }
       auto upb = [&](const std::vector<u8>& v, u8** dst) {
         if (!ok) return;
         ok = hipMalloc((void**)dst, std::max<size_t>(v.size(), 16)) == hipSuccess && (v.empty() || hipMemcpy(*dst, v.data(), v.size(), hipMemcpyHostToDevice) == hipSuccess);
@@ -437,6 +448,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       upb(c->net.chain.cls, &c->d_net_cclass); upb(c->net.chain.delta, &c->d_net_cdelta);
       upb(c->net.bchain.cls, &c->d_net_bclass); upb(c->net.bchain.delta, &c->d_net_bdelta);
       if (ok) for (zkc::ChainTab* t : {&c->net.chain, &c->net.bchain}) { std::vector<u32>().swap(t->tab); std::vector<u32>().swap(t->mask); }
+      if (ok) std::vector<u32>().swap(c->net.fn_tab);
       if (ok) std::vector<u32>().swap(c->net.records);
     }
     if (ok && c->full_W) {
@@ -638,9 +650,9 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     hipSetDevice(c->device);
     hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
     free_o0(c->o0d); free_o0(c->abcd);
-    hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_fn); hipFree(c->d_net_desc);
-    hipFree(c->d_net_cclass); hipFree(c->d_net_cdelta); hipFree(c->d_net_cmask); hipFree(c->d_net_ctab);
-    hipFree(c->d_net_bclass); hipFree(c->d_net_bdelta); hipFree(c->d_net_bmask); hipFree(c->d_net_btab);
+    hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_pd); hipFree(c->d_net_tabs); hipFree(c->d_netd);
+    hipFree(c->d_net_cclass); hipFree(c->d_net_cdelta); hipFree(c->d_net_cmask);
+    hipFree(c->d_net_bclass); hipFree(c->d_net_bdelta); hipFree(c->d_net_bmask);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
     hipFree(c->rp_in); hipFree(c->rp_scr[0]); hipFree(c->rp_scr[1]); hipFree(c->rp_out[0]); hipFree(c->rp_out[1]); hipFree(c->rp_status);
     if (c->rp_exp) hipStreamDestroy(c->rp_exp);
@@ -805,9 +817,6 @@ int zkwg_timing_summary(zkwg_circuit_t* c, int which, float* total_ms, uint32_t*
   return ZKWG_RC_OK;
 }
 
-// (opt-in, ZKWG_NET_FILL_LATE) the table-served slots of a loaded regex template are written in front of every expansion instead of
-// in prepare -- not for handles whose prepare already reads the region (the row kernels of numbered circuits / attached systems)
-static inline bool net_fill_late(const zkwg_circuit* c) { return c->net_fill_late && !c->full_W && !c->abc_m; }
 static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n, void* d_scratch) {
   const ZkSched& s = c->s;
   u8* scr = (u8*)d_scratch;
@@ -825,9 +834,9 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.invtab_m = c->d_invtab_m;
   B.net_records = c->d_net_records;
   B.net_counts = c->d_net_counts;
-  B.net_mask_tab = c->d_net_mask_tab; B.net_fn = c->d_net_fn; B.net_desc = c->d_net_desc;
-  B.net_cclass = c->d_net_cclass; B.net_cdelta = c->d_net_cdelta; B.net_cmask = c->d_net_cmask; B.net_ctab = c->d_net_ctab;
-  B.net_bclass = c->d_net_bclass; B.net_bdelta = c->d_net_bdelta; B.net_bmask = c->d_net_bmask; B.net_btab = c->d_net_btab;
+  B.net_mask_tab = c->d_net_mask_tab;
+  B.net_cclass = c->d_net_cclass; B.net_cdelta = c->d_net_cdelta; B.net_cmask = c->d_net_cmask;
+  B.net_bclass = c->d_net_bclass; B.net_bdelta = c->d_net_bdelta; B.net_bmask = c->d_net_bmask;
   B.pos16 = c->d_pos_rs;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
@@ -848,6 +857,7 @@ static void fill_x3(const zkwg_circuit* c, const ZkBufs& B, ZkX3& A) {
   A.wit_stride16 = B.wit_stride16; A.W = s.W;
   A.in_stride = s.in_stride; A.img_bits = s.img_bits; A.img_small = s.img_small; A.img_fr = s.img_fr; A.inv_half = s.inv_half;
   A.m_dfa_cm = s.m_dfa_cm; A.m_dfa_pm = s.m_dfa_pm; A.m_dfa_st = s.m_dfa_st;
+  A.netd = c->d_netd;
   A.nportions = c->n_ent; A.nsegs = s.nsegs; A.e_first = B.e_first; A.n_count = B.n_emails - B.e_first;
   A.xcd_remap = c->xcd_remap; A.limb_off = s.in_off[ZKWG_IN_PUBKEY];
 }
@@ -930,7 +940,6 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     if (pm & 4u) {
       if (s.net_chain_end) hipLaunchKernelGGL(zk_net_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B);   // chain states first: the list's mask words need them
       hipLaunchKernelGGL(zk_net_eval, dim3((ne + ew - 1) / ew), dim3(64), 4u * s.net_lds_words * ew + 16, st, s, B);
-      if (!net_fill_late(c)) hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (ne + 7) / 8), dim3(256), 0, st, s, B);   // table-served slots (timed with the evaluator)
     }
     if (tm) hipEventRecord(evs[++ki], st);
   }
@@ -1049,10 +1058,6 @@ static int expand_impl(zkwg_circuit_t* c, const void* d_in, uint64_t n, const vo
     B.n_emails = (u32)(first + off + cnt);
     ZkX3 A;
     fill_x3(c, B, A);
-    // (opt-in) the table-served slots of a loaded regex template for exactly these emails, in front of their expansion and on its
-    // stream: a memory-bound kernel that then no longer runs beside the store stream
-    if (s.net_mode && net_fill_late(c))
-      hipLaunchKernelGGL(zk_net_fill, dim3((s.net_kept + 1023) / 1024, (u32)((cnt + 7) / 8)), dim3(256), 0, st, s, B);
     const u64 conv = cnt * (u64)(s.img_fr + ZK_MONT_LIMBS);
     if (OD) {
       // numbered circuit (`--O0` / `--O1`), one pass: the rows that are real sums go into the image extensions of these
@@ -1249,6 +1254,7 @@ static int tables_host(const zkwg_circuit* c, const ZkO0Tables& T, u64 W3, const
     ZkCtx cx;
     cx.rec = records + e * s.in_stride; cx.bits = (const u64*)(scratch_host + L.off_bits) + e * s.img_bits; cx.small = small_w;
     cx.half = (int)s.inv_half; cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm; cx.m_dfa_st = s.m_dfa_st;
+    cx.nd = c->has_net ? &c->h_netd : nullptr;
     ZkRefSrc R;
     R.frv = (const uint4*)frv_w; R.invtab = (const uint4*)c->invtab_host.data(); R.rec = cx.rec; R.small = cx.small;
     if (rows_on_host) {
@@ -1397,6 +1403,7 @@ int zkwg_expand_host(const zkwg_circuit_t* c, const uint8_t* records, uint64_t n
       ZkCtx cx;
       cx.rec = records + e * s.in_stride; cx.bits = bits + e * s.img_bits; cx.small = small + e * s.img_small;
       cx.half = (int)s.inv_half; cx.m_dfa_cm = s.m_dfa_cm; cx.m_dfa_pm = s.m_dfa_pm; cx.m_dfa_st = s.m_dfa_st;
+      cx.nd = c->has_net ? &c->h_netd : nullptr;
         ZkRefSrc R;
       R.frv = (const uint4*)(frv + e * s.img_fr); R.invtab = (const uint4*)c->invtab_host.data(); R.rec = cx.rec; R.small = cx.small;
       u8* w = out + el * out_stride;
@@ -1437,7 +1444,6 @@ int zkwg_set_host_expand(zkwg_circuit_t* c, int threads) {
 static int calculate_batch_hostexpand(zkwg_circuit_t* c, const uint8_t* packed, uint64_t n, uint8_t* out_wtns,
                                       uint64_t out_stride, int32_t* status, uint64_t max_tile) {
   const ZkSched& s = c->s;
-  if (s.net_mode && net_fill_late(c)) { g_last_error = "host expansion reads the image straight after prepare: unset ZKWG_NET_FILL_LATE"; return ZKWG_RC_BAD_CONFIG; }
   if (hipSetDevice(c->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   const u64 tile = std::min<u64>(max_tile ? max_tile : 256, n);
   const u64 scr_bytes = zkwg_scratch_bytes(c, tile);

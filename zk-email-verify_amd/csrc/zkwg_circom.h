@@ -533,6 +533,20 @@ struct Net {
   // of the list still reads are bits of mask[class][state][byte].  `bchain`: what then still runs backwards over the message
   // (is_consecutive / live chains), the same with symbols (forward state, byte).
   ChainTab chain, bchain;
+  // The region as zk_expand reads it (finish_region): a sequence of periodic RUNS.  Slot start + i * period + q of a run is described by
+  // pd entry pd0 + q, taken at position (its own) + i: the circuit instantiates the same components for every message byte, so one
+  // period of descriptors serves the whole run (the stand-in at N = 1,024: 96 % of the region is one run of period 220); what is not
+  // periodic is a run of one period.  A descriptor names a column of one of three TRANSPOSED tables -- all functions of one row side by
+  // side, so that the lanes of a wavefront (neighbouring slots of one position) read neighbouring words:
+  //     byte-local  tabs[(byte) * nL + col]          forward  tabs[offF + (fstate * 256 + byte) * nF + col]
+  //     backward    tabs[offB + ((bstate * fdim + fstate) * 256 + byte) * nB + col]
+  // or says that the evaluator left the word in the image.  zk_expand decodes a table-served slot from the position word
+  // (byte | fstate << 8 | bstate << 16, written by zk_net_eval's prologue): the image holds evaluated words only.
+  struct Run { u32 start, nslots, period, pd0; };
+  std::vector<Run> runs;
+  std::vector<u32> pd;               // 2 words per descriptor: [type << 30 | column] [position of period 0]; type 0 evaluated, 1 byte-local, 2 forward, 3 backward
+  std::vector<u32> tabs;             // transposed tables, L | F | B
+  u32 nL = 0, nF = 0, nB = 0, offF = 0, offB = 0;
   u32 lanes = 64;                    // lanes per email of zk_net_eval = gates per step (64 / lanes emails share a wavefront)
   std::vector<std::string> names;    // kept slot -> name relative to the component (".eq[0][5].isz.inv")
   std::vector<u8> boolean;           // kept slot -> 1 if its interval is [0, 1]
@@ -1350,6 +1364,85 @@ struct Elab {
     if (next >= 0x1fffffffu) fail("the circuit is too large");
     localize(net);
     emit(net);
+    finish_region(net);
+  }
+
+  // the region's slot descriptors -> periodic runs + transposed tables (Net::runs / pd / tabs)
+  static void finish_region(Net& net) {
+    const std::vector<u32>& d = net.slot_desc;
+    const u32 n = net.n_kept;
+    net.runs.clear(); net.pd.clear(); net.tabs.clear();
+    // tables, transposed; a table-served word is decoded without a load (zkwg_expand_dec.h ZkDecNetP: value, table inverse or r - m
+    // with m < 2^28), so a negative stored word must be small
+    auto check = [&](const std::vector<u32>& t) {
+      for (u32 w : t) {
+        if (w & VAL_INVERSE) continue;
+        const int v = (int)(w << 1) >> 1;
+        if (v <= -(1 << 28)) fail("a table-served signal of the regex template holds a value below -2^28");
+      }
+    };
+    check(net.fn_tab); check(net.chain.tab); check(net.bchain.tab);
+    net.nL = (u32)(net.fn_tab.size() / 256);
+    const size_t fcells = (size_t)net.chain.smax * 256, bcells = (size_t)net.bchain.smax * net.bchain.fdim * 256;
+    net.nF = fcells ? (u32)(net.chain.tab.size() / fcells) : 0;
+    net.nB = bcells ? (u32)(net.bchain.tab.size() / bcells) : 0;
+    net.offF = 256u * net.nL; net.offB = net.offF + (u32)(fcells * net.nF);
+    net.tabs.assign((size_t)net.offB + bcells * net.nB + 1, 0);
+    for (u32 t = 0; t < net.nL; ++t) for (u32 v = 0; v < 256; ++v) net.tabs[(size_t)v * net.nL + t] = net.fn_tab[(size_t)t * 256 + v];
+    for (u32 t = 0; t < net.nF; ++t) for (size_t c = 0; c < fcells; ++c) net.tabs[net.offF + c * net.nF + t] = net.chain.tab[t * fcells + c];
+    for (u32 t = 0; t < net.nB; ++t) for (size_t c = 0; c < bcells; ++c) net.tabs[net.offB + c * net.nB + t] = net.bchain.tab[t * bcells + c];
+    if (net.tabs.size() >= (1u << 30)) fail("the regex template's tables are too large");
+    // descriptor of slot r as (type | column, position)
+    auto entry = [&](u32 r, u32& e0, u32& e1) {
+      const u32 x = r < d.size() ? d[r] : 0u, t = x >> 29;
+      if (t < 4u) { e0 = 0; e1 = 0; return; }
+      const u32 ty = t == 7u ? 3u : (t == 6u ? 2u : 1u);
+      e0 = (ty << 30) | ((x >> 16) & 0x1fffu); e1 = x & 0xffffu;
+    };
+    // slot b continues slot a one period later: the same function, one position on (an evaluated slot continues as an evaluated one)
+    auto follows = [&](u32 a, u32 b) {
+      u32 a0, a1, b0, b1;
+      entry(a, a0, a1); entry(b, b0, b1);
+      return a0 == b0 && ((a0 >> 30) == 0u || b1 == a1 + 1u);
+    };
+    const u32 PMAX = 8192;
+    u32 r = 0;
+    while (r < n) {
+      // the period that carries furthest from r
+      u32 bestP = 0, best_len = 0;
+      for (u32 P = 1; P <= PMAX && r + P < n; ++P) {
+        if (!follows(r, r + P)) continue;
+        u32 len = 0;
+        while (r + len + P < n && follows(r + len, r + len + P)) ++len;
+        if (len >= 2 * P && len + P > best_len) { best_len = len + P; bestP = P; }
+        if (bestP && best_len >= 8 * bestP) break;
+      }
+      Net::Run R;
+      R.start = r; R.pd0 = (u32)(net.pd.size() / 2);
+      if (bestP) { R.period = bestP; R.nslots = best_len; }
+      else {
+        // irregular stretch: up to the next slot where a period starts (one run of one period)
+        u32 e = r + 1;
+        for (; e < n; ++e) {
+          bool per = false;
+          for (u32 P = 1; P <= 512 && e + 3 * P < n && !per; ++P) {
+            u32 len = 0;
+            while (len < 2 * P && follows(e + len, e + len + P)) ++len;
+            per = len >= 2 * P;
+          }
+          if (per || e - r >= PMAX) break;
+        }
+        R.period = e - r; R.nslots = e - r;
+      }
+      for (u32 q = 0; q < R.period; ++q) { u32 e0, e1; entry(r + q, e0, e1); net.pd.push_back(e0); net.pd.push_back(e1); }
+      net.runs.push_back(R);
+      r += R.nslots;
+    }
+    if (getenv("ZKWG_DEBUG_NET")) {
+      fprintf(stderr, "[zkwg] region: %u slots in %zu runs, %zu descriptors, tables %u + %u + %u columns (%.1f MB)\n", n, net.runs.size(), net.pd.size() / 2,
+              net.nL, net.nF, net.nB, net.tabs.size() * 4 / 1e6);
+      for (const Net::Run& R : net.runs) if (R.nslots > 4 * R.period) fprintf(stderr, "[zkwg]   run at %u: period %u x %u\n", R.start, R.period, R.nslots / R.period);
+    }
   }
 
   // Operand limits of a record (zkwg_net_core.h): a product has <= 2 + 2 + 4 terms (A, B, C), every other gate
@@ -1791,6 +1884,10 @@ struct Elab {
       }
       for (u32 g : Sn) name_operand(g);
       if (!ok) return give_up("internal: a chain operand without a role");
+      // (backward pass) which symbols (forward state, byte) can occur at a position depends on the position: whether the forward chain
+      // covers it, the forward class there (its transition function prunes the enumeration) -- part of the class identity; and the
+      // forward states that can enter it, which vary from position to position: cells are tabulated as positions need them (below)
+      if (bwd) { D.push_back(at >= F.end ? -1 : (i64)F.cls[at]); }
       max_bits = std::max(max_bits, nbits);
       int use = -1;
       if (i > 0 && classes[cls_of[i - 1]].desc == D) use = (int)cls_of[i - 1];
@@ -1806,11 +1903,35 @@ struct Elab {
       cls_of[i] = (u32)use;
       class_at[at] = (u8)use;
       for (u32 st : reach) reach_bits[(size_t)at * 8 + st / 32] |= 1u << (st % 32);
-      const bool same = i > 0 && cls_of[i - 1] == (u32)use && reach == prev_reach;   // same function, same states: same successors
+      // can symbol y follow state st at this position?  (forward pass: every byte)
+      auto needed = [&](u32 st, u32 y) -> bool {
+        if (!bwd) return true;
+        const u32 f = y / 256, b = y % 256;
+        if (at >= F.end) return f == 0;
+        if (!((F.reach_bits[(size_t)at * 8 + f / 32] >> (f % 32)) & 1u)) return false;
+        const i64 nxt = val_of[st].back();
+        return nxt < 0 || (i64)F.delta[((size_t)F.cls[at] * F.smax + f) * 256 + b] == nxt;
+      };
+      bool same_fwd = true;     // (backward pass) the same forward states enter this byte as the previous one
+      if (bwd && i > 0) {
+        const u32 pat = (u32)tp((int)i - 1);
+        same_fwd = (at >= F.end) == (pat >= F.end);
+        for (u32 k = 0; k < 8 && same_fwd && at < F.end; ++k) same_fwd = F.reach_bits[(size_t)at * 8 + k] == F.reach_bits[(size_t)pat * 8 + k];
+      }
+      const bool same = i > 0 && cls_of[i - 1] == (u32)use && reach == prev_reach && same_fwd;   // same function, same states, same symbols: same successors
       if (!same) {
         Class& C = classes[use];
+        // cells (state, symbol) this position can meet and no earlier position of the class tabulated: a row is NOT complete once some
+        // position reached its state -- the symbols that can follow a state differ between positions (the forward states entering
+        // them do: anchored or periodic automata, the first and last bytes)
         std::vector<u32> todo;
-        for (u32 st : reach) if (st >= C.have.size() || !C.have[st]) todo.push_back(st);
+        for (u32 st : reach) {
+          if (C.have.size() <= st) { C.have.resize(st + 1, 0); C.delta.resize(st + 1); C.words.resize(st + 1); C.valid.resize(st + 1); }
+          if (!C.have[st]) { C.have[st] = 1; C.delta[st].assign(NSYM, 0); C.words[st].assign(B.size() * NSYM, 0); C.valid[st].assign(NSYM, 0); }
+          bool miss = false;
+          for (u32 y = 0; y < NSYM && !miss; ++y) miss = !C.valid[st][y] && needed(st, y);
+          if (miss) todo.push_back(st);
+        }
         if (!todo.empty()) {
           // leaves per symbol: byte-local gates by the byte, forward-chain bits by (forward state, byte)
           std::vector<std::vector<long long>> LV(L.size());
@@ -1830,20 +1951,11 @@ struct Elab {
           std::vector<long long> bv(B.size());
           std::vector<i64> nv;
           for (u32 st : todo) {
-            if (C.have.size() <= st) { C.have.resize(st + 1, 0); C.delta.resize(st + 1); C.words.resize(st + 1); C.valid.resize(st + 1); }
-            C.have[st] = 1; C.delta[st].assign(NSYM, 0); C.words[st].assign(B.size() * NSYM, 0); C.valid[st].assign(NSYM, 0);
             const std::vector<i64> sv = val_of[st];
             if (sv.size() != S.size() + (bwd ? 1 : 0)) return give_up("internal: a state of another shape reaches the position");
             for (u32 y = 0; y < NSYM; ++y) {
               const u32 b = y % 256;
-              if (bwd) {
-                const u32 f = y / 256;
-                if (at >= F.end) { if (f) continue; }
-                else {
-                  if (!((F.reach_bits[(size_t)at * 8 + f / 32] >> (f % 32)) & 1u)) continue;
-                  if (sv.back() >= 0 && (i64)F.delta[((size_t)F.cls[at] * F.smax + f) * 256 + b] != sv.back()) continue;
-                }
-              }
+              if (C.valid[st][y] || !needed(st, y)) continue;
               C.valid[st][y] = 1;
               auto value_of = [&](u32 o) -> long long {
                 switch (role[o]) { case R_STATE: return sv[ridx[o]]; case R_BLOCK: return bv[ridx[o]]; case R_FWD: return LV[ridx[o]][y]; default: return LV[ridx[o]][b]; }
@@ -1884,9 +1996,9 @@ struct Elab {
             }
           }
         }
-        // successors over the symbols that can occur (backward pass: every forward state -- a superset)
+        // successors over the symbols that can occur here
         std::vector<u8> seen(256, 0);
-        for (u32 st : reach) for (u32 y = 0; y < NSYM; ++y) if (C.valid[st][y]) seen[C.delta[st][y]] = 1;
+        for (u32 st : reach) for (u32 y = 0; y < NSYM; ++y) if (C.valid[st][y] && needed(st, y)) seen[C.delta[st][y]] = 1;
         prev_reach.swap(reach);
         reach.clear();
         for (u32 q = 0; q < 256; ++q) if (seen[q]) reach.push_back(q);
@@ -2040,7 +2152,16 @@ struct Elab {
       // the tables are looked up once per slot and email: they have to stay cache-sized
       size_t words = 0;
       for (const Cells& G : groups) words += (size_t)G.nkept + 1 + mw;
-      if (words * CELLS * 4 > (64u << 20)) return give_up("the tables would not stay in the cache");
+      if (words * CELLS * 4 > (64u << 20)) {
+        // not a silent fallback: the gate list would evaluate this recurrence correctly but an order of magnitude slower, and a
+        // deployment should know (ZKWG_NET_ALLOW_LIST_FALLBACK=1 accepts it)
+        char msg[200];
+        snprintf(msg, sizeof msg, "the %s tables of the regex template would take %.0f MB (limit 64 MB: %u states x %u symbols x %zu words per cell); "
+                 "set ZKWG_NET_ALLOW_LIST_FALLBACK=1 to evaluate the recurrence gate by gate instead", tag, words * CELLS * 4 / 1e6, smax, NSYM, words);
+        if (!getenv("ZKWG_NET_ALLOW_LIST_FALLBACK") || !atoi(getenv("ZKWG_NET_ALLOW_LIST_FALLBACK"))) fail(msg);
+        fprintf(stderr, "[zkwg] warning: %s\n", msg);
+        return give_up("the tables would not stay in the cache");
+      }
     }
     T.end = end; T.smax = smax; T.classes = (u32)groups.size(); T.mask_words = mw; T.fdim = fdim;
     T.reach_bits = reach_bits;

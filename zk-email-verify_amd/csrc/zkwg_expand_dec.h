@@ -11,6 +11,7 @@
 #pragma once
 #include "zkwg_dev.h"
 #include "zkwg_bh_dfa.h"
+#include "zkwg_net_core.h"
 
 // the decoders also run on the host (zkwg_expand_host: witnesses expanded in host memory from a downloaded image)
 #define ZK_DEC __host__ __device__
@@ -32,6 +33,7 @@ struct ZkCtx {
   const u32* __restrict__ small;
   int half;           // inverse table covers [-half, half]
   u32 m_dfa_cm, m_dfa_pm, m_dfa_st;   // small[] offsets of the DFA class masks, primitive masks and per-position words
+  const ZkNetDec* nd;                 // loaded regex template (ZSEG_NETP); NULL otherwise
 };
 
 ZK_DEC __forceinline__ u32 zk_udiv(u32 r, u32 d, u32 magic) { return magic ? (u32)(((u64)r * magic) >> 32) : r / d; }
@@ -256,17 +258,26 @@ struct ZkDecRslb {
     return z ? 0u : (u32)enc[r];
   }
 };
-// gate values of a loaded regex template (zkwg_net_core.h): 31-bit signed integer, or the inverse
-// of one (bit 31) from the table; a negative integer -m is the field element r - m.  Every slot of the region is a word of
-// the image: the evaluator's (zk_net_eval) or, for a byte-local signal, zk_net_fill's.
-struct ZkDecNet {
-  const u32* __restrict__ p; u32 base; int half;
-  ZK_DEC ZkDecNet(const ZkSeg& sg, const ZkCtx& cx) : p(cx.small), base(sg.src), half(cx.half) {}
+// One periodic run of a loaded regex template's region (zkwg_circom.h finish_region, zkwg_net_core.h ZkNetDec).  Slot r is
+// element q = r % period of period i = r / period: the run's descriptor q says where the slot's stored word is -- a column of a
+// transposed table, addressed through the position word of position (descriptor's) + i, or, for the few signals the evaluator
+// computes, the image.  A stored word is a 31-bit signed integer or the inverse of one (bit 31) from the table; a negative
+// integer -m is the field element r - m.  Branch-free: every lane forms one address; neighbouring lanes are neighbouring slots
+// of one position, i.e. neighbouring columns of one table row.
+struct ZkDecNetP {
+  const u32* __restrict__ small; ZkNetDec D; u32 pd0, P, magic, c; int half;
+  ZK_DEC ZkDecNetP(const ZkSeg& sg, const ZkCtx& cx) : small(cx.small), D(*cx.nd), pd0(sg.src), P(sg.a), magic(sg.pad), c(sg.c), half(cx.half) {}
   ZK_DEC u32 operator()(u32 r) const {
-    const u32 w = p[base + r];
+    const u32 i = zk_udiv(r, P, magic), q = r - i * P;
+    const uint2 d = ((const uint2*)D.pd)[pd0 + q];
+    const bool tab = (d.x >> 30) != ZKNP_EVAL;
+    const u32 pw = small[D.m_net_pw + (tab ? d.y + i : 0u)];
+    const u32 at = D.m_net + c + r;
+    const u32* __restrict__ src = tab ? D.tab + zk_netp_addr(D, d.x, pw) : small + at;
+    const u32 w = *src;
     const int v = (int)(w << 1) >> 1;
     if (w & 0x80000000u) return zk_inv_code(v, half);
-    return v >= 0 ? (u32)v : (ZK_REF_NEG | (base + r));
+    return v >= 0 ? (u32)v : (tab ? (ZK_REF_MINUS | (u32)(-v)) : (ZK_REF_NEG | at));
   }
 };
 
@@ -277,7 +288,7 @@ struct ZkDecNet {
   X(ZSEG_SHA_T2, ZkDecSha<ZK_T2_SLOTS ZK_COMMA 5>) X(ZSEG_ISZ, ZkDecIsz) X(ZSEG_SEL, ZkDecSel) X(ZSEG_IN8, ZkDecIn8)   \
   X(ZSEG_IN8MASK, ZkDecIn8Mask) X(ZSEG_IN8BITS, ZkDecIn8Bits) X(ZSEG_LIMB, ZkDecLimb) X(ZSEG_LTBITS, ZkDecLtBits)      \
   X(ZSEG_REGSEL, ZkDecRegSel) X(ZSEG_VSHIFT, ZkDecVShift) X(ZSEG_B64BITS, ZkDecB64<false>) X(ZSEG_B64, ZkDecB64<true>) \
-  X(ZSEG_DFA, ZkDecDfa) X(ZSEG_RSLB, ZkDecRslb) X(ZSEG_NET, ZkDecNet)
+  X(ZSEG_DFA, ZkDecDfa) X(ZSEG_RSLB, ZkDecRslb) X(ZSEG_NETP, ZkDecNetP)
 #define ZK_COMMA ,
 
 // one slot of any segment (pieces that straddle segments, the numbered-circuit expansion and the linear-row kernels

@@ -13,7 +13,6 @@ __global__ void zk_poseidon9_wave(ZkSched s, ZkBufs B);
 __global__ void zk_poseidon9_g16(ZkSched s, ZkBufs B);
 __global__ void zk_misc_ev(ZkSched s, ZkBufs B);     // zkwg_kernels_misc.hip
 __global__ void zk_net_eval(ZkSched s, ZkBufs B);    // zkwg_kernels_net.hip
-__global__ void zk_net_fill(ZkSched s, ZkBufs B);
 __global__ void zk_net_scan(ZkSched s, ZkBufs B);
 __global__ void zk_rslb_chunks(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip
 #include "zkwg_rslb_wave.h"   // ZK_RS_MERGE_LANES

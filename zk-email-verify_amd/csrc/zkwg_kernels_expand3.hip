@@ -112,6 +112,7 @@ __device__ __forceinline__ ZkCtx zk_x3_ctx(const ZkX3& A, u32 e) {
   cx.small = A.small + (u64)e * A.img_small;
   cx.half = (int)A.inv_half;
   cx.m_dfa_cm = A.m_dfa_cm; cx.m_dfa_pm = A.m_dfa_pm; cx.m_dfa_st = A.m_dfa_st;
+  cx.nd = A.netd;
   return cx;
 }
 // store side: wavefront w owns the 64 K consecutive slots [64 K w, 64 K (w + 1)) of the piece (K = slots per lane);

@@ -1,7 +1,7 @@
 // zk_net_eval -- BodyHashRegex from a loaded circom template (zkwg_circom.h): net_lanes (32 by default) lanes per
 // email -- two emails per wavefront -- walk the gate list, up to net_lanes gates (one per lane) per step; the gates of a step are mutually
 // independent and only read values of earlier steps.  Results go to the email's image (zk_expand's
-// ZSEG_NET streams them out) and, when a later gate reads them, to an LDS word the loader assigned by
+// ZSEG_NETP streams them out) and, when a later gate reads them, to an LDS word the loader assigned by
 // liveness; an operand is an LDS offset, the image is write-only.  Steps whose records the loader proved
 // exact in 32 bits take a branch-free 32-bit path (zk_net_record32), the others the 64-bit one.  One
 // wavefront per SIMD is the normal occupancy (1,024 emails per prepare launch), so memory latency is
@@ -19,8 +19,8 @@ __device__ __forceinline__ ZkNetChains zk_net_chains(const ZkSched& s, const ZkB
   K.n_in = s.fr[0].max_bytes;
   K.f_end = s.net_chain_end; K.f_smax = s.net_chain_smax; K.f_mw = s.net_chain_mw;
   K.b_end = s.net_bchain_end; K.b_smax = s.net_bchain_smax; K.b_mw = s.net_bchain_mw; K.b_fdim = s.net_bchain_fdim;
-  K.f_cls = B.net_cclass; K.f_delta = B.net_cdelta; K.f_mask = B.net_cmask; K.f_tab = B.net_ctab;
-  K.b_cls = B.net_bclass; K.b_delta = B.net_bdelta; K.b_mask = B.net_bmask; K.b_tab = B.net_btab;
+  K.f_cls = B.net_cclass; K.f_delta = B.net_cdelta; K.f_mask = B.net_cmask;
+  K.b_cls = B.net_bclass; K.b_delta = B.net_bdelta; K.b_mask = B.net_bmask;
   return K;
 }
 
@@ -46,14 +46,15 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   const u32 MW = s.net_mask_words, MS = MW + K.f_mw + K.b_mw;
   const u8* fstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st);
   const u8* bstate = (const u8*)(B.small + (u64)e * s.img_small + s.m_net_bst);
+  u32* small = B.small + (u64)e * s.img_small;
   for (u32 i = gl; i < N; i += L) {
     lds[msg_base + i] = (int)rec[i];
     zk_net_mask_words(K, MW, B.net_mask_tab, i, rec, fstate, bstate, &lds[s.net_lds_masks + i * MS]);
+    small[s.m_net_pw + i] = zk_net_pos_word(K, i, rec, fstate, bstate);   // what zk_expand decodes the table-served slots of position i from
   }
   if (gl == 0) lds[msg_base + N] = 0;
   const u32 scratch = msg_base + N + 1u;
   __syncthreads();
-  u32* small = B.small + (u64)e * s.img_small;
   u32* img = small + s.m_net;
   const uint4* __restrict__ R = (const uint4*)B.net_records;
   const u32* __restrict__ CNT = B.net_counts;
@@ -111,33 +112,6 @@ __global__ __launch_bounds__(64) void zk_net_eval(ZkSched s, ZkBufs B) {
   const u64 bad = __ballot(!ok);
   const u64 mine = (L == 64u ? ~0ull : ((1ull << L) - 1ull)) << (sub * L);
   if ((bad & mine) != 0ull && gl == 0 && live) B.status[e] = 4;
-}
-
-// zk_net_fill -- the words of the byte-local kept signals, written beside the evaluator's.  A workgroup covers 1,024 slots of
-// ZKN_FILL_EMAILS emails: a thread reads 4 slot descriptors once and writes the 4 words of each email, consecutive lanes
-// consecutive words.  zk_expand's ZSEG_NET then reads every slot of the region from the image with one load, like any other
-// segment of small values; resolving descriptor -> message byte -> table inside zk_expand instead (three dependent loads per
-// slot, a divergent branch) cost the store stream 10 % of its rate on its own (profiles/r04: 4.96 -> 4.52 ms per 512 witnesses).
-// (One thread per slot and email -- 578 k tiny workgroups per 1,024 emails -- took 10 ms beside the high-priority store stream.)
-#define ZKN_FILL_EMAILS 8
-__global__ __launch_bounds__(256) void zk_net_fill(ZkSched s, ZkBufs B) {
-  const u32 r0 = blockIdx.x * 1024u + threadIdx.x, e0 = B.e_first + blockIdx.y * ZKN_FILL_EMAILS;   // emails [B.e_first, B.n_emails)
-  const ZkNetChains K = zk_net_chains(s, B);
-  ZkNetFillLane F;
-  if (!F.init(B.net_desc, s.net_kept, r0, B.net_fn, K)) return;
-  auto one = [&](u32 e, u32 (&w)[4]) {
-    F.load(B.in + (u64)e * s.in_stride + s.fr[0].in_data, (const u8*)(B.small + (u64)e * s.img_small + s.m_net_st),
-           (const u8*)(B.small + (u64)e * s.img_small + s.m_net_bst), w);
-  };
-  auto put = [&](u32 e, const u32 (&w)[4]) { F.store(B.small + (u64)e * s.img_small + s.m_net, r0, w); };
-  const u32 e1 = e0 + ZKN_FILL_EMAILS < B.n_emails ? e0 + ZKN_FILL_EMAILS : B.n_emails;
-  u32 e = e0;
-  for (; e + 2 <= e1; e += 2) {
-    u32 wa[4], wb[4];
-    one(e, wa); one(e + 1, wb);
-    put(e, wa); put(e + 1, wb);
-  }
-  if (e < e1) { u32 wa[4]; one(e, wa); put(e, wa); }
 }
 
 // zk_net_scan -- the collapsed recurrences (zkwg_circom.h chain_pass): one lane per email walks

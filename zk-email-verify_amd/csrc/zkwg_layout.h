@@ -308,6 +308,7 @@ static inline void zk_alloc_bh_regex(ZkWalker& w, ZkSched& s, u32 N) {
     s.net_bchain_fdim = w.net->bchain.fdim;
     s.m_net_st = w.net->chain.end ? w.alloc_small(N / 4 + 2) : 0;
     s.m_net_bst = w.net->bchain.end ? w.alloc_small(N / 4 + 2) : 0;
+    s.m_net_pw = w.alloc_small(N + 1);
     s.m_dfa_own = s.m_dfa_st = s.m_dfa_cm = s.m_dfa_pm = s.m_dfa_acc = 0;
     return;
   }
@@ -320,9 +321,11 @@ static inline void zk_alloc_bh_regex(ZkWalker& w, ZkSched& s, u32 N) {
 static inline void zk_walk_bh_regex(ZkWalker& w, const std::string& p, const ZkSched& s, u32 N) {
   const u32 nb = N + 1;
   if (w.net) {   // the kept signals of the loaded template, in the compiler's numbering order (zkwg_circom.h layout_walk)
-    w.seg(ZSEG_NET, w.net->n_kept, s.m_net);
-    if (!w.names) w.skip(w.net->n_kept);
-    else for (u32 i = 0; i < w.net->n_kept; ++i) w.one(p + w.net->names[i]);
+    for (const zkc::Net::Run& R : w.net->runs) {
+      w.seg(ZSEG_NETP, R.nslots, R.pd0, R.period, 0, R.start);
+      if (!w.names) w.skip(R.nslots);
+      else for (u32 i = 0; i < R.nslots; ++i) w.one(p + w.net->names[R.start + i]);
+    }
     return;
   }
   auto arr2 = [&](const std::string& base, u32 k, u32 n, const char* a, const char* b) {

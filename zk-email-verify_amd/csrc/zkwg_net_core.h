@@ -2,7 +2,7 @@
 //
 // Shared by the device kernel zk_net_eval and the host mirror used by the CPU tests.  Values are small
 // signed integers; a kept signal is stored in the image as a 31-bit two's-complement word, the inverse
-// hint of IsZero as the integer it inverts with bit 31 set (zk_expand's ZSEG_NET looks the inverse up).
+// hint of IsZero as the integer it inverts with bit 31 set (zk_expand's ZSEG_NETP looks the inverse up).
 // Every operand is a word of the evaluator's LDS image [gate values | message bytes | 0 | scratch]; the
 // loader assigned the value words by liveness, the image in global memory is write-only.
 //
@@ -22,19 +22,16 @@ enum ZkNetOp : u32 { ZKN_NOP = 0, ZKN_QUAD = 1, ZKN_INV0 = 2, ZKN_BIT = 3, ZKN_N
 
 ZK_HD int zk_net_decode(u32 w) { return (int)(w << 1) >> 1; }   // 31-bit two's complement
 
-// A byte-local kept signal (a function of one message byte: the comparators of the regex circuit; zkwg_circom.h localize) is
-// not a gate of the list: its stored word comes from a 256-entry function table.  d = Net::slot_desc of the slot
-// (0x80000000 | function << 16 | byte index; 0 = a gate of the list writes the word).
-ZK_HD u32 zk_net_local_word(u32 d, const u32* fn_tab, const u8* msg) { return fn_tab[((d >> 16) & 0x7fffu) * 256u + msg[d & 0xffffu]]; }
-// A kept signal of a collapsed recurrence (zkwg_circom.h chain_pass; d = 0xC0000000 | table << 16 | byte index for the forward
-// chain, 0xE0000000 | ... for the backward one): a function of the chain state entering its position (zk_net_scan) and the
-// position's symbol -- its byte, and for the backward chain also the forward state there.
+// A byte-local kept signal (a function of one message byte: the comparators of the regex circuit; zkwg_circom.h localize) is not a
+// gate of the list, and neither is a kept signal of a collapsed recurrence (zkwg_circom.h chain_pass): a function of the chain state
+// entering its position (zk_net_scan) and the position's symbol -- its byte, and for the backward chain also the forward state there.
+// Both are served from tables; how zk_expand reaches them: ZkNetDec below.
 struct ZkNetChains {
   u32 n_in;
   u32 f_end, f_smax, f_mw;            // forward chain: bytes [0, f_end)
   u32 b_end, b_smax, b_mw, b_fdim;    // backward chain: bytes [n_in - b_end, n_in); b_fdim = f_smax (or 1)
   const u8 *f_cls, *f_delta, *b_cls, *b_delta;
-  const u32 *f_mask, *f_tab, *b_mask, *b_tab;
+  const u32 *f_mask, *b_mask;
 };
 ZK_HD u32 zk_net_fwd_row(const ZkNetChains& K, u32 pos, const u8* fstate, const u8* msg) {
   return ((u32)K.f_cls[pos] * K.f_smax + fstate[pos]) * 256u + msg[pos];
@@ -43,15 +40,7 @@ ZK_HD u32 zk_net_bwd_row(const ZkNetChains& K, u32 pos, const u8* fstate, const 
   const u32 f = pos < K.f_end ? (u32)fstate[pos] : 0u;
   return (((u32)K.b_cls[pos] * K.b_smax + bstate[pos]) * K.b_fdim + f) * 256u + msg[pos];
 }
-ZK_HD u32 zk_net_chain_word(u32 d, const ZkNetChains& K, const u8* fstate, const u8* bstate, const u8* msg) {
-  const u32 pos = d & 0xffffu, tab = (d >> 16) & 0x1fffu;
-  if ((d >> 29) == 7u) {
-    const u32 f = pos < K.f_end ? (u32)fstate[pos] : 0u;
-    return K.b_tab[((tab * K.b_smax + bstate[pos]) * K.b_fdim + f) * 256u + msg[pos]];
-  }
-  return K.f_tab[(tab * K.f_smax + fstate[pos]) * 256u + msg[pos]];
-}
-// The bodies of zk_net_scan, zk_net_fill and zk_net_eval's mask prologue (zkwg_kernels_net.hip), shared with the host mirror of
+// The bodies of zk_net_scan and zk_net_eval's prologue (zkwg_kernels_net.hip), shared with the host mirror of
 // the CPU tests (tests/native/hosttest.cpp runs exactly this code).
 //
 // zk_net_scan: the state entering every position, one byte each, packed four to a word
@@ -95,34 +84,37 @@ ZK_HD void zk_net_mask_words(const ZkNetChains& K, u32 MW, const u32* mask_tab, 
     for (u32 m = 0; m < K.b_mw; ++m) mw[MW + K.f_mw + m] = in ? (int)K.b_mask[row + m] : 0;
   }
 }
-// zk_net_fill: one thread's four slots r0, r0 + 256, ... -- branch-free: every slot forms one table address (function table,
-// forward or backward chain table; an evaluated slot reads word 0 of the function tables and stores nothing), so the lookups of
-// several emails can be in flight together
-struct ZkNetFillLane {
-  u32 d[4], pos[4], mul_f[4], mul_b[4], base[4];
-  const u32* tabp[4];
-  ZK_HD bool init(const u32* desc, u32 n_kept, u32 r0, const u32* fn_tab, const ZkNetChains& K) {
-    for (int k = 0; k < 4; ++k) {
-      const u32 r = r0 + 256u * (u32)k;
-      d[k] = r < n_kept ? desc[r] : 0u;
-      const u32 t = d[k] >> 29;                       // 4: byte-local   6: forward chain   7: backward chain   0: evaluated
-      pos[k] = t >= 4u ? (d[k] & 0xffffu) : 0u;
-      const u32 tab13 = (d[k] >> 16) & 0x1fffu;
-      tabp[k] = t == 7u ? K.b_tab : (t == 6u ? K.f_tab : fn_tab);
-      base[k] = t == 7u ? tab13 * K.b_smax * K.b_fdim * 256u : (t == 6u ? tab13 * K.f_smax * 256u : (t >= 4u ? tab13 * 256u : 0u));
-      mul_f[k] = t == 7u ? (pos[k] < K.f_end ? 256u : 0u) : (t == 6u ? 256u : 0u);    // weight of the forward state in the address
-      mul_b[k] = t == 7u ? K.b_fdim * 256u : 0u;                                       // weight of the backward state
-    }
-    return ((d[0] | d[1] | d[2] | d[3]) >> 31) != 0u;
-  }
-  ZK_HD void load(const u8* msg, const u8* fstate, const u8* bstate, u32 (&w)[4]) const {
-    for (int k = 0; k < 4; ++k)
-      w[k] = tabp[k][base[k] + mul_b[k] * bstate[pos[k]] + mul_f[k] * fstate[pos[k]] + ((d[k] >> 31) ? (u32)msg[pos[k]] : 0u)];
-  }
-  ZK_HD void store(u32* img, u32 r0, const u32 (&w)[4]) const {
-    for (int k = 0; k < 4; ++k) if (d[k] >> 31) img[r0 + 256u * (u32)k] = w[k];
-  }
+// ---- the region as zk_expand reads it (zkwg_circom.h finish_region; ZSEG_NETP, zkwg_expand_dec.h ZkDecNetP) -------------------
+// zk_net_eval's prologue leaves one POSITION WORD per message byte in the image: byte | fstate << 8 | bstate << 16 (fstate = 0 beyond
+// the forward chain).  A table-served slot -- byte-local, forward or backward chain -- is then one load of its run's period descriptor,
+// one of the position word and one of a transposed table row; nothing writes such a slot into the image any more (zk_net_fill, rounds
+// 3-4, wrote 4 bytes per slot and email that zk_expand read back).
+struct ZkNetDec {
+  const u32* pd;        // 2 words per descriptor: [type << 30 | column] [position of period 0]
+  const u32* tab;       // transposed tables L | F | B
+  u32 offF, offB, nL, nF, nB, b_fdim;
+  u32 m_net, m_net_pw;  // image (small) offsets: evaluated words, position words
 };
+enum ZkNetPType : u32 { ZKNP_EVAL = 0, ZKNP_LOCAL = 1, ZKNP_FWD = 2, ZKNP_BWD = 3 };
+ZK_HD u32 zk_net_pos_word(const ZkNetChains& K, u32 pos, const u8* msg, const u8* fstate, const u8* bstate) {
+  const u32 f = (K.f_end && pos < K.f_end) ? (u32)fstate[pos] : 0u;
+  const u32 b = (K.b_end && pos + K.b_end >= K.n_in) ? (u32)bstate[pos] : 0u;
+  return (u32)msg[pos] | (f << 8) | (b << 16);
+}
+// table address of a table-served slot (type != ZKNP_EVAL) from its descriptor word and the position word
+ZK_HD u32 zk_netp_addr(const ZkNetDec& D, u32 d0, u32 pw) {
+  const u32 t = d0 >> 30, col = d0 & 0x3fffffffu;
+  const u32 byte = pw & 255u, fs = (pw >> 8) & 255u, bs = (pw >> 16) & 255u;
+  const u32 row = t == ZKNP_LOCAL ? byte : (t == ZKNP_FWD ? fs * 256u + byte : (bs * D.b_fdim + fs) * 256u + byte);
+  const u32 n = t == ZKNP_LOCAL ? D.nL : (t == ZKNP_FWD ? D.nF : D.nB);
+  const u32 base = t == ZKNP_LOCAL ? 0u : (t == ZKNP_FWD ? D.offF : D.offB);
+  return base + row * n + col;
+}
+// stored word of region slot `slot` = element (period i, descriptor (d0, d1)) of a run; small = the email's image
+ZK_HD u32 zk_netp_word(const ZkNetDec& D, u32 d0, u32 d1, u32 i, u32 slot, const u32* small) {
+  if ((d0 >> 30) == ZKNP_EVAL) return small[D.m_net + slot];
+  return D.tab[zk_netp_addr(D, d0, small[D.m_net_pw + d1 + i])];
+}
 ZK_HD bool zk_net_desc_is_chain(u32 d) { return (d >> 30) == 3u; }   // (either chain)
 
 // General path, exact in 64 bits: every record type.  `lds_r` / `lds`: the evaluator's LDS image for reads /

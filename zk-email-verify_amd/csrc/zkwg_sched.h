@@ -50,8 +50,10 @@ enum ZkSegType : u32 {
   ZSEG_IN8MASK = 17,// ByteMask: in[src + r] * in[a + r]   (data byte times mask byte)
   ZSEG_RSLB = 18,   // RemoveSoftLineBreaks byte-derived arrays over in[src ..]: a = ZkRslbKind, b/c = parameters
   ZSEG_HOLE = 19,   // signals this schedule does not produce: left to the linear completion pass (zkwg_full.h)
-  ZSEG_NET = 20,    // gate values of a loaded regex template (zkwg_circom.h): slot r = decode(small[src + r]): 31-bit signed integer, or its inverse (bit 31)
-  ZSEG_NTYPES = 21
+  // 20: (rounds 2-4: ZSEG_NET, the region of a loaded regex template read word by word from the image; replaced by ZSEG_NETP)
+  ZSEG_NETP = 21,   // one periodic run of a loaded regex template's region (zkwg_circom.h finish_region): src = first period descriptor, a = period,
+                    // c = region index of the run's first slot; slot r = descriptor src + r % a at position + r / a (zkwg_net_core.h ZkNetDec)
+  ZSEG_NTYPES = 22
 };
 
 // ZSEG_RSLB kinds (helpers/remove-soft-line-breaks.circom:14-126); enc = the emailBody bytes at src
@@ -104,6 +106,7 @@ ZK_HD u32 zk_seg_period(const ZkSeg& g) {
     case ZSEG_LTBITS: return g.a + 1u;
     case ZSEG_REGSEL: return g.a + 7u;
     case ZSEG_VSHIFT: return g.a;
+    case ZSEG_NETP: return g.a;
     default: return 0;
   }
 }
@@ -242,6 +245,7 @@ struct ZkSched {
   u32 net_bchain_end;    // backward chain: bytes [N - net_bchain_end, N)
   u32 net_bchain_smax, net_bchain_mw, net_bchain_fdim;   // its states, mask words (after the forward chain's), symbols / 256
   u32 m_net_bst;         // small: the backward state entering every position
+  u32 m_net_pw;          // small: one position word per message byte, byte | fstate << 8 | bstate << 16 (zk_net_eval's prologue; read by zk_expand)
   // RemoveSoftLineBreaks(max_body) (template flag removeSoftLineBreaks, email-verifier.circom:148-156)
   u32 rslb;              // 1: present
   u32 rs_nch;            // 2 * max_body / 16 Poseidon(16) chunks of PoseidonModular(2 * max_body)
@@ -289,16 +293,12 @@ struct ZkBufs {
   const u32* net_records; // loaded regex template: 16 words per gate in execution order (zkwg_net_core.h)
   const u32* net_counts;  // loaded regex template: gates per step | flags (0x8000: 64-bit path)
   const u32* net_mask_tab; // loaded regex template: 256 x net_mask_words frontier masks by byte value
-  const u32* net_fn;      // loaded regex template: byte-local function tables (256 stored words each)
-  const u32* net_desc;    // loaded regex template: per kept slot 0 (evaluated), 0x80000000 | fn << 16 | byte index, or 0xC0000000 | table << 16 | position
   const u8* net_cclass;   // forward chain: class of every position
   const u8* net_cdelta;   // [class][state][byte] next state
   const u32* net_cmask;   // [class][state][byte][net_chain_mw] mask words
-  const u32* net_ctab;    // [table][state][byte] stored words
   const u8* net_bclass;   // backward chain: the same with symbols (forward state, byte)
   const u8* net_bdelta;
   const u32* net_bmask;
-  const u32* net_btab;
   const Fr* rtab;        // zk_expand_mont: v * R mod r for v < 65536 (Montgomery-form output)
   Fr* frm;               // Montgomery-form output: per email, Montgomery copies of its img_fr field elements, then of the record's ZK_MONT_LIMBS limbs
   const ZkSeg* segs;     // segment table
@@ -319,6 +319,7 @@ struct ZkX3 {
   Fr* frm_w; u32* small_w; Fr* frv_w;                  // writable views (zk_image_to_mont, the O0 row kernels)
   u64 wit_stride16, W;
   u32 in_stride, img_bits, img_small, img_fr, inv_half, m_dfa_cm, m_dfa_pm, m_dfa_st;
+  const struct ZkNetDec* netd;   // loaded regex template: how a slot of the region is decoded (device copy; NULL otherwise)
   u32 nportions, nsegs, e_first, n_count, xcd_remap, limb_off;   // nportions: pieces per witness (of 256 K slots)
 };
 #endif
