@@ -164,13 +164,13 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
   ZkNetDec D;
   D.pd = N.pd.data(); D.tab = N.tabs.data();
   D.offF = N.offF; D.offB = N.offB; D.nL = N.nL; D.nF = N.nF; D.nB = N.nB; D.b_fdim = N.bchain.fdim;
-  D.m_net = 0; D.m_net_pw = N.n_kept;
+  D.m_net = 0; D.m_net_pw = N.n_kept; D.n_in = N.n_in;
   u32 covered = 0;
   for (const zkc::Net::Run& R : N.runs) {
     if (R.start != covered) return -1;      // the runs tile the region
     for (u32 r = 0; r < R.nslots; ++r) {
       const u32 i = r / R.period, q = r % R.period;
-      words[R.start + r] = zk_netp_word(D, N.pd[2 * (R.pd0 + q)], N.pd[2 * (R.pd0 + q) + 1], i, R.start + r, small.data());
+      words[R.start + r] = zk_netp_word(D, N.pd[2 * (R.pd0 + q)], N.pd[2 * (R.pd0 + q) + 1], R.pos0, i, R.start + r, small.data());
     }
     covered += R.nslots;
   }

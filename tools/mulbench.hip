@@ -13,6 +13,7 @@
 #include <vector>
 #include "zkwg_fr.h"
 #include "zkwg_fr52.h"
+#include "zkwg_fr29.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 // ---------------- part A: raw issue rates -----------------------------------------------------------------------------
@@ -129,6 +130,72 @@ __global__ __launch_bounds__(256) void prod_f52(const Fr* in, Fr* out, u32 iters
   for (int k = 1; k < CH; ++k) s = fr_add(s, fr52_to_fr(x[k], cx));
   out[tid] = s;
 }
+// 32-bit limbs, operand scanning with the carries of a row resolved once per row (8 mads, then one add-with-carry chain)
+__device__ __forceinline__ Fr fr_mont_mul_rw(const Fr& a, const Fr& b) {
+  const u32 P32[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  u32 A[8], Bv[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { A[2 * i] = (u32)a.l[i]; A[2 * i + 1] = (u32)(a.l[i] >> 32); Bv[2 * i] = (u32)b.l[i]; Bv[2 * i + 1] = (u32)(b.l[i] >> 32); }
+  u64 t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // t[j] < 2^32 between rows (the high word of the pair stays zero), t[8] the running top
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u64 d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = (u64)A[j] * Bv[i] + t[j];         // < 2^64
+    const u32 m = (u32)d[0] * 0xefffffffu;
+    // t' = (sum_j d_j 2^(32 j) + t8 2^256 + m P) / 2^32, resolved with one carry chain
+    u64 e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (u64)m * P32[j] + (u32)d[j];      // low halves joined with the reduction row: < 2^64
+    u64 c = e[0] >> 32;                                                   // low word of e[0] is zero
+#pragma unroll
+    for (int j = 1; j < 8; ++j) { c += (u64)(u32)e[j] + (d[j - 1] >> 32); t[j - 1] = (u32)c; c = (c >> 32) + (e[j] >> 32); }
+    c += (d[7] >> 32) + t[8];
+    t[7] = (u32)c; t[8] = c >> 32;
+  }
+  Fr r{{t[0] | (t[1] << 32), t[2] | (t[3] << 32), t[4] | (t[5] << 32), t[6] | (t[7] << 32)}};
+  if (t[8] || fr_geq(r, fr_p())) { u64 bw; r = fr_sub_raw(r, fr_p(), bw); }
+  return r;
+}
+template <int CH>
+__global__ __launch_bounds__(256) void prod_rw(const Fr* in, Fr* out, u32 iters) {
+  const u32 tid = blockIdx.x * 256 + threadIdx.x;
+  Fr x[CH];
+  const Fr y = in[(tid + 1) & 1023];
+  for (int k = 0; k < CH; ++k) x[k] = in[(tid + 7 * k) & 1023];
+  for (u32 i = 0; i < iters; ++i)
+    for (int k = 0; k < CH; ++k) x[k] = fr_mont_mul_rw(x[k], y);
+  Fr s = x[0];
+  for (int k = 1; k < CH; ++k) s = fr_add(s, x[k]);
+  out[tid] = s;
+}
+template <int CH>
+__global__ __launch_bounds__(256) void prod_f29(const Fr* in, Fr* out, u32 iters) {
+  const u32 tid = blockIdx.x * 256 + threadIdx.x;
+  Fr29 x[CH];
+  const Fr29 y = fr29_from_fr(in[(tid + 1) & 1023]);
+  for (int k = 0; k < CH; ++k) x[k] = fr29_from_fr(in[(tid + 7 * k) & 1023]);
+  for (u32 i = 0; i < iters; ++i)
+    for (int k = 0; k < CH; ++k) x[k] = fr29_mul(x[k], y);
+  Fr s = fr29_to_fr(x[0]);
+  for (int k = 1; k < CH; ++k) s = fr_add(s, fr29_to_fr(x[k]));
+  out[tid] = s;
+}
+// out[i] += 1 iff rw(a, b) != cios(a, b); += 2 iff 2^5 * f29(a, b) != cios(a, b) (R = 2^261 against 2^256)
+__global__ __launch_bounds__(256) void check_new(const Fr* a, const Fr* b, u32 n, u32* bad) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Fr c = fr_mont_mul(a[i], b[i]);
+  if (!fr_eq(fr_mont_mul_rw(a[i], b[i]), c)) atomicAdd(bad, 1u);
+  Fr f = fr29_to_fr(fr29_mul(fr29_from_fr(a[i]), fr29_from_fr(b[i])));
+  for (int k = 0; k < 5; ++k) f = fr_add(f, f);
+  if (!fr_eq(f, c)) atomicAdd(bad + 1, 1u);
+  // unnormalised first operand: (a + a + a) * b with lazy limb sums
+  const Fr29 a29 = fr29_from_fr(a[i]);
+  Fr g = fr29_to_fr(fr29_mul(fr29_add(fr29_add(a29, a29), a29), fr29_from_fr(b[i])));
+  for (int k = 0; k < 5; ++k) g = fr_add(g, g);
+  if (!fr_eq(g, fr_add(fr_add(c, c), c))) atomicAdd(bad + 2, 1u);
+}
 // ---------------- part C: bit-exactness --------------------------------------------------------------------------------
 // out[i] = 1 iff 2^4 * f52(a, b) != cios(a, b) (R = 2^260 against R = 2^256), after full reduction of both
 __global__ __launch_bounds__(256) void check_f52(const Fr* a, const Fr* b, u32 n, u32* bad, Fr* first_bad) {
@@ -212,9 +279,18 @@ int main(int argc, char** argv) {
     const char* nm[4] = {"a", "b", "cios", "16*f52"};
     for (int k = 0; k < 4; ++k) printf("   %-7s %016llx %016llx %016llx %016llx\n", nm[k], (unsigned long long)fb[k].l[3], (unsigned long long)fb[k].l[2], (unsigned long long)fb[k].l[1], (unsigned long long)fb[k].l[0]);
   }
+  {
+    u32* dbad3; CK(hipMalloc((void**)&dbad3, 16)); CK(hipMemset(dbad3, 0, 16));
+    hipLaunchKernelGGL(check_new, dim3(NCHK / 256), dim3(256), 0, 0, da, db, NCHK, dbad3);
+    CK(hipDeviceSynchronize());
+    u32 b3[3]; CK(hipMemcpy(b3, dbad3, 12, hipMemcpyDeviceToHost));
+    printf("-- against fr_mont_mul on %u pairs: row-wise 32-bit %u mismatches, 9 x 29-bit Comba %u, with a lazy 3a operand %u\n", NCHK, b3[0], b3[1], b3[2]);
+    if (js) fprintf(js, " \"rw_mismatches\": %u, \"f29_mismatches\": %u, \"f29_lazy_mismatches\": %u,\n", b3[0], b3[1], b3[2]);
+    bad += b3[0] + b3[1] + b3[2];
+  }
   // part B
   const u32 piters = 512;
-  double best_cios = 0, best_f52 = 0;
+  double best_cios = 0, best_f52 = 0, best_rw = 0, best_f29 = 0;
   printf("-- Montgomery products per second (chains per lane x wavefronts per SIMD)\n");
   for (int wps : {1, 2, 4, 8}) {
     const u32 blocks = cus * wps;
@@ -224,15 +300,22 @@ int main(int argc, char** argv) {
     float f2 = time_ms([&] { hipLaunchKernelGGL((prod_f52<2>), dim3(blocks), dim3(256), 0, 0, da, dout, piters); });
     const double n1 = (double)blocks * 256 * piters;
     const double c1 = n1 / m1 / 1e6, c2 = 2 * n1 / m2 / 1e6, g1 = n1 / f1 / 1e6, g2 = 2 * n1 / f2 / 1e6;
-    printf("   %d waves/SIMD: cios 1 chain %7.1f G/s, 2 chains %7.1f | f52 1 chain %7.1f, 2 chains %7.1f\n", wps, c1, c2, g1, g2);
+    float r1 = time_ms([&] { hipLaunchKernelGGL((prod_rw<1>), dim3(blocks), dim3(256), 0, 0, da, dout, piters); });
+    float r2 = time_ms([&] { hipLaunchKernelGGL((prod_rw<2>), dim3(blocks), dim3(256), 0, 0, da, dout, piters); });
+    float h1 = time_ms([&] { hipLaunchKernelGGL((prod_f29<1>), dim3(blocks), dim3(256), 0, 0, da, dout, piters); });
+    float h2 = time_ms([&] { hipLaunchKernelGGL((prod_f29<2>), dim3(blocks), dim3(256), 0, 0, da, dout, piters); });
+    const double rw1 = n1 / r1 / 1e6, rw2 = 2 * n1 / r2 / 1e6, f291 = n1 / h1 / 1e6, f292 = 2 * n1 / h2 / 1e6;
+    if (rw1 > best_rw) best_rw = rw1; if (rw2 > best_rw) best_rw = rw2;
+    if (f291 > best_f29) best_f29 = f291; if (f292 > best_f29) best_f29 = f292;
+    printf("   %d waves/SIMD: cios 1 chain %7.1f G/s, 2 chains %7.1f | f52 %7.1f, %7.1f | row-wise %7.1f, %7.1f | 9x29 %7.1f, %7.1f\n", wps, c1, c2, g1, g2, rw1, rw2, f291, f292);
     if (c1 > best_cios) best_cios = c1; if (c2 > best_cios) best_cios = c2;
     if (g1 > best_f52) best_f52 = g1; if (g2 > best_f52) best_f52 = g2;
   }
   const double mad_bound = rate[OP_MAD64] / 128.0;
-  printf("-- bound from the measured v_mad_u64_u32 rate: %.1f G products/s (128 per product); cios reaches %.1f (%.2f), f52 %.1f (%.2f x cios)\n",
-         mad_bound, best_cios, best_cios / mad_bound, best_f52, best_f52 / best_cios);
+  printf("-- bound from the measured v_mad_u64_u32 rate: %.1f G products/s (128 per product); cios reaches %.1f (%.2f), f52 %.1f (%.2f x cios), row-wise %.1f (%.2f x), 9x29 %.1f (%.2f x)\n",
+         mad_bound, best_cios, best_cios / mad_bound, best_f52, best_f52 / best_cios, best_rw, best_rw / best_cios, best_f29, best_f29 / best_cios);
   if (js) {
-    fprintf(js, " \"f52_mismatches\": %u, \"f52_pairs_checked\": %u,\n \"products_G_per_s\": {\"cios_8x32\": %.2f, \"f52_5x52\": %.2f, \"mad_u64_u32_bound\": %.2f}\n}\n", bad, NCHK, best_cios, best_f52, mad_bound);
+    fprintf(js, " \"f52_mismatches\": %u, \"f52_pairs_checked\": %u,\n \"products_G_per_s\": {\"cios_8x32\": %.2f, \"f52_5x52\": %.2f, \"rowwise_8x32\": %.2f, \"comba_9x29\": %.2f, \"mad_u64_u32_bound_128\": %.2f}\n}\n", bad, NCHK, best_cios, best_f52, best_rw, best_f29, mad_bound);
     fclose(js);
   }
   return bad ? 1 : 0;

@@ -295,7 +295,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     ZkNetDec& D = c->h_netd;
     D.pd = c->net.pd.data(); D.tab = c->net.tabs.data();
     D.offF = c->net.offF; D.offB = c->net.offB; D.nL = c->net.nL; D.nF = c->net.nF; D.nB = c->net.nB; D.b_fdim = c->net.bchain.fdim;
-    D.m_net = c->s.m_net; D.m_net_pw = c->s.m_net_pw;
+    D.m_net = c->s.m_net; D.m_net_pw = c->s.m_net_pw; D.n_in = c->net.n_in;
   }
   if (getenv("ZKWG_DEBUG_SKIP_INV") && atoi(getenv("ZKWG_DEBUG_SKIP_INV")) && c->s.rsa.present) c->s.rsa.present = 2;  // profiling only
   if (sym_text) {

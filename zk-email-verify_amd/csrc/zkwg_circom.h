@@ -542,9 +542,9 @@ struct Net {
   //     backward    tabs[offB + ((bstate * fdim + fstate) * 256 + byte) * nB + col]
   // or says that the evaluator left the word in the image.  zk_expand decodes a table-served slot from the position word
   // (byte | fstate << 8 | bstate << 16, written by zk_net_eval's prologue): the image holds evaluated words only.
-  struct Run { u32 start, nslots, period, pd0; };
+  struct Run { u32 start, nslots, period, pd0, pos0; };   // pos0: the position the run's descriptors are relative to
   std::vector<Run> runs;
-  std::vector<u32> pd;               // 2 words per descriptor: [type << 30 | column] [position of period 0]; type 0 evaluated, 1 byte-local, 2 forward, 3 backward
+  std::vector<u32> pd;               // 2 words per descriptor: [type << 30 | column] [position of period 0 minus the run's pos0 (signed; 0 for nearly all)]; type 0 evaluated, 1 byte-local, 2 forward, 3 backward
   std::vector<u32> tabs;             // transposed tables, L | F | B
   u32 nL = 0, nF = 0, nB = 0, offF = 0, offB = 0;
   u32 lanes = 64;                    // lanes per email of zk_net_eval = gates per step (64 / lanes emails share a wavefront)
@@ -1382,16 +1382,6 @@ struct Elab {
       }
     };
     check(net.fn_tab); check(net.chain.tab); check(net.bchain.tab);
-    net.nL = (u32)(net.fn_tab.size() / 256);
-    const size_t fcells = (size_t)net.chain.smax * 256, bcells = (size_t)net.bchain.smax * net.bchain.fdim * 256;
-    net.nF = fcells ? (u32)(net.chain.tab.size() / fcells) : 0;
-    net.nB = bcells ? (u32)(net.bchain.tab.size() / bcells) : 0;
-    net.offF = 256u * net.nL; net.offB = net.offF + (u32)(fcells * net.nF);
-    net.tabs.assign((size_t)net.offB + bcells * net.nB + 1, 0);
-    for (u32 t = 0; t < net.nL; ++t) for (u32 v = 0; v < 256; ++v) net.tabs[(size_t)v * net.nL + t] = net.fn_tab[(size_t)t * 256 + v];
-    for (u32 t = 0; t < net.nF; ++t) for (size_t c = 0; c < fcells; ++c) net.tabs[net.offF + c * net.nF + t] = net.chain.tab[t * fcells + c];
-    for (u32 t = 0; t < net.nB; ++t) for (size_t c = 0; c < bcells; ++c) net.tabs[net.offB + c * net.nB + t] = net.bchain.tab[t * bcells + c];
-    if (net.tabs.size() >= (1u << 30)) fail("the regex template's tables are too large");
     // descriptor of slot r as (type | column, position)
     auto entry = [&](u32 r, u32& e0, u32& e1) {
       const u32 x = r < d.size() ? d[r] : 0u, t = x >> 29;
@@ -1434,9 +1424,53 @@ struct Elab {
         }
         R.period = e - r; R.nslots = e - r;
       }
-      for (u32 q = 0; q < R.period; ++q) { u32 e0, e1; entry(r + q, e0, e1); net.pd.push_back(e0); net.pd.push_back(e1); }
+      // positions relative to the run's most frequent one, so that zk_expand can ask for the position word before it has the descriptor
+      {
+        std::map<u32, u32> freq;
+        for (u32 q = 0; q < R.period; ++q) { u32 e0, e1; entry(r + q, e0, e1); if (e0 >> 30) ++freq[e1]; }
+        R.pos0 = 0;
+        u32 best = 0;
+        for (auto& kv : freq) if (kv.second > best) { best = kv.second; R.pos0 = kv.first; }
+      }
+      for (u32 q = 0; q < R.period; ++q) { u32 e0, e1; entry(r + q, e0, e1); net.pd.push_back(e0); net.pd.push_back((e0 >> 30) ? e1 - R.pos0 : 0u); }
       net.runs.push_back(R);
       r += R.nslots;
+    }
+    // Columns.  A table of the loader may serve many slots (the same comparator in several transitions); the transposed tables
+    // give every descriptor of the LARGEST run a column of its own, in slot order, so that the lanes of a wavefront -- consecutive
+    // slots of one position -- read consecutive words of one row; the other runs reuse those columns where they name the same table.
+    {
+      const size_t fcells = (size_t)net.chain.smax * 256, bcells = (size_t)net.bchain.smax * net.bchain.fdim * 256;
+      std::vector<u32> cols[4];                      // [type] -> loader table of each column
+      std::map<u32, u32> col_of[4];                  // [type] loader table -> a column that holds it
+      std::vector<size_t> order(net.runs.size());
+      for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+      std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return net.runs[x].nslots > net.runs[y].nslots; });
+      for (size_t oi = 0; oi < order.size(); ++oi) {
+        const Net::Run& R = net.runs[order[oi]];
+        for (u32 q = 0; q < R.period; ++q) {
+          u32& e0 = net.pd[2 * (R.pd0 + q)];
+          const u32 ty = e0 >> 30, old = e0 & 0x3fffffffu;
+          if (!ty) continue;
+          auto it = col_of[ty].find(old);
+          u32 col;
+          if (oi == 0 || it == col_of[ty].end()) {
+            col = (u32)cols[ty].size();
+            cols[ty].push_back(old);
+            if (it == col_of[ty].end()) col_of[ty].emplace(old, col);
+          } else col = it->second;
+          e0 = (ty << 30) | col;
+        }
+      }
+      net.nL = (u32)cols[1].size(); net.nF = (u32)cols[2].size(); net.nB = (u32)cols[3].size();
+      net.offF = 256u * net.nL;
+      const size_t offB = (size_t)net.offF + fcells * net.nF, total = offB + bcells * net.nB + 1;
+      if (total >= (1u << 30)) fail("the regex template's tables are too large");
+      net.offB = (u32)offB;
+      net.tabs.assign(total, 0);
+      for (u32 t = 0; t < net.nL; ++t) for (u32 v = 0; v < 256; ++v) net.tabs[(size_t)v * net.nL + t] = net.fn_tab[(size_t)cols[1][t] * 256 + v];
+      for (u32 t = 0; t < net.nF; ++t) for (size_t c = 0; c < fcells; ++c) net.tabs[net.offF + c * net.nF + t] = net.chain.tab[cols[2][t] * fcells + c];
+      for (u32 t = 0; t < net.nB; ++t) for (size_t c = 0; c < bcells; ++c) net.tabs[net.offB + c * net.nB + t] = net.bchain.tab[cols[3][t] * bcells + c];
     }
     if (getenv("ZKWG_DEBUG_NET")) {
       fprintf(stderr, "[zkwg] region: %u slots in %zu runs, %zu descriptors, tables %u + %u + %u columns (%.1f MB)\n", n, net.runs.size(), net.pd.size() / 2,

@@ -265,15 +265,21 @@ struct ZkDecRslb {
 // integer -m is the field element r - m.  Branch-free: every lane forms one address; neighbouring lanes are neighbouring slots
 // of one position, i.e. neighbouring columns of one table row.
 struct ZkDecNetP {
-  const u32* __restrict__ small; ZkNetDec D; u32 pd0, P, magic, c; int half;
-  ZK_DEC ZkDecNetP(const ZkSeg& sg, const ZkCtx& cx) : small(cx.small), D(*cx.nd), pd0(sg.src), P(sg.a), magic(sg.pad), c(sg.c), half(cx.half) {}
+  const u32* __restrict__ small; const ZkNetDec* __restrict__ D; u32 pd0, P, magic, pos0, c; int half;
+  // (the decode parameters stay behind the pointer: copied into the functor they cost the store kernel 30 scalar registers it does not
+  // have -- 88 bytes of scratch per lane in every zk_expand3 kernel, loaded template or not)
+  ZK_DEC ZkDecNetP(const ZkSeg& sg, const ZkCtx& cx) : small(cx.small), D(cx.nd), pd0(sg.src), P(sg.a), magic(sg.pad), pos0(sg.b), c(sg.c), half(cx.half) {}
   ZK_DEC u32 operator()(u32 r) const {
     const u32 i = zk_udiv(r, P, magic), q = r - i * P;
-    const uint2 d = ((const uint2*)D.pd)[pd0 + q];
+    // descriptor and position word are asked for together: nearly every descriptor of a run sits at the run's own position
+    // (offset 0), so the dependent chain in front of the store is {descriptor, position word} -> table word
+    const u32 pwi = D->m_net_pw + zk_minu(pos0 + i, D->n_in);
+    const uint2 d = ((const uint2*)D->pd)[pd0 + q];
+    u32 pw = small[pwi];
+    if (d.y) pw = small[pwi + d.y];
     const bool tab = (d.x >> 30) != ZKNP_EVAL;
-    const u32 pw = small[D.m_net_pw + (tab ? d.y + i : 0u)];
-    const u32 at = D.m_net + c + r;
-    const u32* __restrict__ src = tab ? D.tab + zk_netp_addr(D, d.x, pw) : small + at;
+    const u32 at = D->m_net + c + r;
+    const u32* __restrict__ src = tab ? D->tab + zk_netp_addr(*D, d.x, pw) : small + at;
     const u32 w = *src;
     const int v = (int)(w << 1) >> 1;
     if (w & 0x80000000u) return zk_inv_code(v, half);

@@ -1,0 +1,87 @@
+// BN254 Fr Montgomery products for the arithmetic-bound kernels (zk_ntt_*, zk_rslb_*, the MSM scalars): 9 limbs of 29 bits, R = 2^261.
+//
+// tools/mulbench.hip (profiles/r05/r05_a_mulbench.txt) measured what gfx950 issues: v_mad_u64_u32 runs at (nearly) the plain VALU
+// rate, NOT at a quarter of it as rounds 2-4 assumed -- the 8 x 32-bit CIOS of zkwg_fr.h is slow because of what surrounds its 128
+// multiply-adds: a 32 x 32 product plus two 32-bit addends needs a 64-bit add with zero-extended operands at every step (120
+// v_lshl_add_u64 + 286 v_mov_b32 per product as compiled).  With 29-bit limbs a column of the schoolbook product -- up to 9 products
+// of the operands and 9 of the reduction, each below 2^58..2^60 -- fits a 64-bit accumulator, so the whole product is 162 v_mad_u64_u32
+// chained through their 64-bit addend, one AND + one 64-bit shift per column, and no carry handling at all (Comba / product scanning).
+//
+// Values are kept in limb form between products.  A product accepts one operand `a` with limbs < 3 * 2^30 (sums and differences of
+// products need no carry propagation first) and one operand `b` with limbs < 2^29 (a twiddle / table constant), and returns limbs
+// < 2^29 (the top one < 2^32) with value < a b / 2^261 + r.
+#pragma once
+#include "zkwg_fr.h"
+
+struct Fr29 {
+  u32 l[9];
+};
+#define ZK29_M 0x1fffffffu
+#define ZK29_N0 0x0fffffffu      // -r^-1 mod 2^29
+
+ZK_HD Fr29 fr29_from_fr(const Fr& x) {
+  Fr29 r;
+  const u64 w[5] = {x.l[0], x.l[1], x.l[2], x.l[3], 0};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, k = bit >> 6, s = bit & 63;
+    const u64 v = s ? ((w[k] >> s) | (w[k + 1] << (64 - s))) : w[k];
+    r.l[i] = i < 8 ? ((u32)v & ZK29_M) : (u32)v;
+  }
+  return r;
+}
+// limb form -> canonical Fr (value < 2^256 required; fully reduced)
+ZK_HD Fr fr29_to_fr(const Fr29& x) {
+  // carry-propagate, then pack
+  u64 t[9];
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { c += x.l[i]; t[i] = i < 8 ? (c & ZK29_M) : c; c >>= 29; }
+  u64 w[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, k = bit >> 6, s = bit & 63;
+    w[k] |= t[i] << s;
+    if (s > 64 - 32 && k + 1 < 5) w[k + 1] |= s ? (t[i] >> (64 - s)) : 0;
+  }
+  Fr r{{w[0], w[1], w[2], w[3]}};
+  for (int k = 0; k < 8 && fr_geq(r, fr_p()); ++k) {
+    u64 bw;
+    r = fr_sub_raw(r, fr_p(), bw);
+  }
+  return r;
+}
+ZK_HD Fr29 fr29_mul(const Fr29& a, const Fr29& b) {
+  const u32 P[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+  u32 q[9];
+  Fr29 r;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (u64)q[i] * P[k - i];
+    q[k] = ((u32)acc * ZK29_N0) & ZK29_M;
+    acc += (u64)q[k] * P[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i < 9; ++i) acc += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - 8; i < 9; ++i) acc += (u64)q[i] * P[k - i];
+    r.l[k - 9] = (u32)acc & ZK29_M;
+    acc >>= 29;
+  }
+  r.l[8] = (u32)acc;
+  return r;
+}
+// lazy sums: limbs add without carries; a difference adds a multiple of r whose limbs dominate a normalised subtrahend's
+ZK_HD Fr29 fr29_add(const Fr29& a, const Fr29& b) {
+  Fr29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}

@@ -94,6 +94,7 @@ struct ZkNetDec {
   const u32* tab;       // transposed tables L | F | B
   u32 offF, offB, nL, nF, nB, b_fdim;
   u32 m_net, m_net_pw;  // image (small) offsets: evaluated words, position words
+  u32 n_in;             // message bytes (= position words)
 };
 enum ZkNetPType : u32 { ZKNP_EVAL = 0, ZKNP_LOCAL = 1, ZKNP_FWD = 2, ZKNP_BWD = 3 };
 ZK_HD u32 zk_net_pos_word(const ZkNetChains& K, u32 pos, const u8* msg, const u8* fstate, const u8* bstate) {
@@ -110,10 +111,11 @@ ZK_HD u32 zk_netp_addr(const ZkNetDec& D, u32 d0, u32 pw) {
   const u32 base = t == ZKNP_LOCAL ? 0u : (t == ZKNP_FWD ? D.offF : D.offB);
   return base + row * n + col;
 }
-// stored word of region slot `slot` = element (period i, descriptor (d0, d1)) of a run; small = the email's image
-ZK_HD u32 zk_netp_word(const ZkNetDec& D, u32 d0, u32 d1, u32 i, u32 slot, const u32* small) {
+// stored word of region slot `slot` = element (period i, descriptor (d0, d1)) of a run whose descriptors are relative to position
+// pos0; small = the email's image
+ZK_HD u32 zk_netp_word(const ZkNetDec& D, u32 d0, u32 d1, u32 pos0, u32 i, u32 slot, const u32* small) {
   if ((d0 >> 30) == ZKNP_EVAL) return small[D.m_net + slot];
-  return D.tab[zk_netp_addr(D, d0, small[D.m_net_pw + d1 + i])];
+  return D.tab[zk_netp_addr(D, d0, small[D.m_net_pw + pos0 + i + d1])];
 }
 ZK_HD bool zk_net_desc_is_chain(u32 d) { return (d >> 30) == 3u; }   // (either chain)
 

@@ -52,7 +52,8 @@ enum ZkSegType : u32 {
   ZSEG_HOLE = 19,   // signals this schedule does not produce: left to the linear completion pass (zkwg_full.h)
   // 20: (rounds 2-4: ZSEG_NET, the region of a loaded regex template read word by word from the image; replaced by ZSEG_NETP)
   ZSEG_NETP = 21,   // one periodic run of a loaded regex template's region (zkwg_circom.h finish_region): src = first period descriptor, a = period,
-                    // c = region index of the run's first slot; slot r = descriptor src + r % a at position + r / a (zkwg_net_core.h ZkNetDec)
+                    // b = the position the descriptors are relative to, c = region index of the run's first slot; slot r = descriptor
+                    // src + r % a at position b + r / a (+ the descriptor's own offset) (zkwg_net_core.h ZkNetDec)
   ZSEG_NTYPES = 22
 };
 
