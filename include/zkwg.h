@@ -420,21 +420,40 @@ int zkwg_ntt_transform_device(zkwg_ntt_t* plan, void* d_data, uint64_t n_polys, 
 int zkwg_h_evaluations_device(zkwg_ntt_t* plan, const void* d_abc, uint64_t abc_stride, uint64_t n_constraints, uint64_t n_emails,
                               void* d_work, void* d_out, uint64_t out_stride, void* hip_stream);
 
-/* ---- prover stage 3: the G1 multi-exponentiations of groth16_prove.js -- DRAFT (branch next/msm) ----------
+/* ---- prover stage 3: the multi-exponentiations of groth16_prove.js (reference call site:
+ * packages/helpers/src/chunked-zkey.ts:80-84, the second half of fullProve) -----------------------------------------------
  * pi_a, pib1, pi_c and resH are  sum_i scalar_i * base_i  over BN254 G1 with the zkey's bases (affine, x | y in Montgomery form,
- * 64 bytes each, the point at infinity all zeros -- sections 5, 6, 8, 9 of the file) and the witness resp. the H evaluations of
- * zkwg_h_evaluations_device as scalars (32 bytes each, standard or Montgomery form).  zkwg_msm_create uploads the bases of one
- * such sum (window_bits = 0: chosen from n); zkwg_msm_g1_device computes it for the n scalars at d_scalars, d_work =
- * zkwg_msm_work_bytes bytes of scratch (256-byte aligned), and returns the point as the zkey would store it (affine, Montgomery
- * form, 64 bytes; zeros = infinity).  ones_apart = 1 for witness scalars (mostly 0 / 1: the bases with scalar 1 are summed by a
- * plain reduction tree instead of all landing in one bucket).  Bucket method, signed windows, XYZZ accumulators: DESIGN.md section 23. */
+ * 64 bytes each, the point at infinity all zeros -- sections 5, 6, 8, 9 of the file), pi_b the same over G2 (section 7: x.c0 | x.c1 |
+ * y.c0 | y.c1, 128 bytes), with the witness resp. the H evaluations of zkwg_h_evaluations_device as scalars (32 bytes each,
+ * standard or Montgomery form).  zkwg_msm_create / _create_g2 upload the bases of one such sum (window_bits = 0: chosen from n);
+ * zkwg_msm_create_device takes bases already in device memory (group 1 / 2; not owned).  zkwg_msm_g1_device / _g2_device compute
+ * the sum for the n scalars at d_scalars, d_work = zkwg_msm_work_bytes bytes of scratch (256-byte aligned), and return the point as
+ * the zkey would store it (affine, Montgomery form, 64 / 128 bytes; zeros = infinity).  ones_apart = 1 for witness scalars (mostly
+ * 0 / 1: the bases with scalar 1 are summed by a plain reduction tree instead of all landing in one bucket).  Bucket method, signed
+ * windows, XYZZ accumulators: DESIGN.md section 23.
+ * zkwg_fixed_base_device: d_out[i] = scalar_i * G for the group's generator (G1: (1, 2); G2: the EIP-197 generator) -- how a key
+ * with a KNOWN trapdoor becomes bases (tests, tools/bench_prove.py; a real key comes from its .zkey). */
 typedef struct zkwg_msm zkwg_msm_t;
 int zkwg_msm_create(int device, const uint8_t* bases, uint64_t n, int window_bits, zkwg_msm_t** out);
+int zkwg_msm_create_g2(int device, const uint8_t* bases, uint64_t n, int window_bits, zkwg_msm_t** out);
+int zkwg_msm_create_device(int device, int group, const void* d_bases, uint64_t n, int window_bits, zkwg_msm_t** out);
 void zkwg_msm_destroy(zkwg_msm_t* plan);
 uint64_t zkwg_msm_work_bytes(const zkwg_msm_t* plan);
 int zkwg_msm_window_bits(const zkwg_msm_t* plan);
+int zkwg_msm_group(const zkwg_msm_t* plan);
 int zkwg_msm_g1_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_montgomery, int ones_apart, void* d_work, uint8_t* out_xy,
                        void* hip_stream);
+int zkwg_msm_g2_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_montgomery, int ones_apart, void* d_work, uint8_t* out_xy,
+                       void* hip_stream);
+int zkwg_fixed_base_device(int device, int group, const void* d_scalars, uint64_t n, void* d_out, void* hip_stream);
+/* pi_a, pi_b, pi_c from the five sums of one proof and the key's alpha / beta / delta points (groth16_prove.js: pi_a = alpha1 + sum_a +
+ * r delta1, pi_b = beta2 + sum_b2 + s delta2, pi_c = sum_c + sum_h + s pi_a + r (beta1 + sum_b1 + s delta1) - r s delta1).  Points in
+ * as the zkey stores them (affine, Montgomery form); r, s = the blinding scalars (32 bytes, little-endian, below the group order);
+ * points out in STANDARD form, little-endian x | y (G2: x.c0 | x.c1 | y.c0 | y.c1): the integers of snarkjs' proof.json.  Host
+ * arithmetic (a dozen group operations).  ZKWG_RC_BAD_ARG for a point that is not on its curve. */
+int zkwg_groth16_assemble(const uint8_t* sum_a, const uint8_t* sum_b1, const uint8_t* sum_b2, const uint8_t* sum_c, const uint8_t* sum_h,
+                          const uint8_t* vk_alpha1, const uint8_t* vk_beta1, const uint8_t* vk_beta2, const uint8_t* vk_delta1,
+                          const uint8_t* vk_delta2, const uint8_t* r32, const uint8_t* s32, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 
 /* The same prover stage without a 32-byte witness in between: the constraint system `r1cs` (its wires = the handle's
  * witness layout: built-in, `.sym`, or -- since ABI 3 -- a fully numbered handle of zkwg_circuit_create_full, whose system is

@@ -1,0 +1,146 @@
+"""Prover stages 1-3 end to end: inputs -> witness -> A.w | B.w | C.w -> H evaluations -> the five
+multi-exponentiations -> pi_a, pi_b, pi_c, all on the device, judged by the PINNED verifier (oracle/pyref/bn254_pairing.py, which
+accepts the reference's own proof packages/rust-verifier/tests/data/proof_of_twitter) under a key made from a known trapdoor
+(oracle/pyref/groth16.py).  Each multi-exponentiation is also compared with (sum_i k_i s_i) G computed in Python from the
+trapdoor's discrete logarithms.  Reference call site: packages/helpers/src/chunked-zkey.ts:80-84."""
+import ctypes as C
+import random
+
+import pytest
+
+from oracle.pyref import bn254_g1 as G1
+from oracle.pyref import bn254_g2 as G2
+from oracle.pyref import bn254_pairing as P
+from oracle.pyref import groth16 as G
+
+R = G.R
+Q = G1.Q
+
+
+def _mont1(p):
+    return bytes(64) if p is None else ((p[0] << 256) % Q).to_bytes(32, "little") + ((p[1] << 256) % Q).to_bytes(32, "little")
+
+
+def _mont2(p):
+    return bytes(128) if p is None else b"".join(((v << 256) % Q).to_bytes(32, "little") for v in (p[0][0], p[0][1], p[1][0], p[1][1]))
+
+
+def test_assemble_on_the_host_equals_the_oracle():
+    """zkwg_groth16_assemble (host arithmetic of zkwg_g1.h / zkwg_g2.h) against Python group operations; no GPU"""
+    from zkwg import _lib
+    lib = _lib.load()
+    rng = random.Random(3)
+    k = {n: rng.randrange(1, R) for n in ("a", "b", "c", "h", "alpha", "beta", "delta", "r", "s")}
+    k["c"] = 0                                                     # a sum at infinity
+    g1 = lambda x: G1.mul(x, G1.G)
+    g2 = lambda x: G2.mul(x, G2.G2)
+    pa, pb, pc = (C.c_uint8 * 64)(), (C.c_uint8 * 128)(), (C.c_uint8 * 64)()
+    rc = lib.zkwg_groth16_assemble(_mont1(g1(k["a"])), _mont1(g1(k["b"])), _mont2(g2(k["b"])), _mont1(g1(k["c"])), _mont1(g1(k["h"])),
+                                   _mont1(g1(k["alpha"])), _mont1(g1(k["beta"])), _mont2(g2(k["beta"])), _mont1(g1(k["delta"])), _mont2(g2(k["delta"])),
+                                   k["r"].to_bytes(32, "little"), k["s"].to_bytes(32, "little"), pa, pb, pc)
+    assert rc == 0
+    i = lambda b, j: int.from_bytes(bytes(b)[32 * j:32 * j + 32], "little")
+    sa = (k["alpha"] + k["a"] + k["r"] * k["delta"]) % R
+    sb = (k["beta"] + k["b"] + k["s"] * k["delta"]) % R
+    sc = (k["c"] + k["h"] + k["s"] * sa + k["r"] * sb - k["r"] * k["s"] * k["delta"]) % R
+    assert (i(pa, 0), i(pa, 1)) == g1(sa)
+    assert ((i(pb, 0), i(pb, 1)), (i(pb, 2), i(pb, 3))) == g2(sb)
+    assert (i(pc, 0), i(pc, 1)) == g1(sc)
+    # a point off the curve is refused
+    bad = bytearray(_mont1(g1(5)))
+    bad[0] ^= 1
+    assert lib.zkwg_groth16_assemble(bytes(bad), _mont1(g1(1)), _mont2(g2(1)), _mont1(g1(1)), _mont1(g1(1)), _mont1(g1(1)), _mont1(g1(1)), _mont2(g2(1)),
+                                     _mont1(g1(1)), _mont2(g2(1)), bytes(32), bytes(32), pa, pb, pc) != 0
+
+
+@pytest.mark.gpu
+def test_gpu_fixed_base_and_g2_sums_equal_the_oracle():
+    import torch
+    import zkwg
+    from zkwg import prover
+    rng = random.Random(8)
+    ks = [0, 1, 2, R - 1, 1 << 253] + [rng.randrange(R) for _ in range(27)]
+    d1 = prover.fixed_base(0, 1, ks)
+    d2 = prover.fixed_base(0, 2, ks)
+    raw1, raw2 = bytes(d1.cpu().numpy()), bytes(d2.cpu().numpy())
+    for j, kk in enumerate(ks):
+        assert prover.point_from_montgomery(raw1[64 * j:64 * j + 64]) == G1.mul(kk, G1.G), j
+        assert prover.point_from_montgomery(raw2[128 * j:128 * j + 128]) == G2.mul(kk, G2.G2), j
+    # a G2 sum over those bases: repeated bases, a base at infinity (index 0), scalars 0 / 1 / r - 1 among random ones; both scalar forms
+    n = 700
+    idx = [rng.randrange(len(ks)) for _ in range(n)]
+    bases = b"".join(raw2[128 * j:128 * j + 128] for j in idx)
+    sc = [rng.choice([0, 1, 1, R - 1, rng.randrange(R), rng.randrange(256)]) for _ in range(n)]
+    dev = torch.device("cuda", 0)
+    d_b = torch.frombuffer(bytearray(bases), dtype=torch.uint8).to(dev)
+    m = prover._DeviceMsm(d_b, 2, 0, window_bits=7)
+    d_w = torch.empty(m.work_bytes() + 256, dtype=torch.uint8, device=dev)
+    d_w = d_w[(-d_w.data_ptr()) % 256:]
+    want = G2.mul(sum(s * ks[j] for s, j in zip(sc, idx)) % R, G2.G2)
+    for mont in (False, True):
+        enc = [(s << 256) % R if mont else s for s in sc]
+        d_s = torch.frombuffer(bytearray(b"".join(int(s).to_bytes(32, "little") for s in enc)), dtype=torch.uint8).to(dev)
+        for ones_apart in (False, True):
+            assert prover.point_from_montgomery(m.run(d_s.data_ptr(), mont, ones_apart, d_w)) == want, (mont, ones_apart)
+
+
+def _prove_case(N, M, records_of, n_emails=2):
+    """EmailVerifier(N, M): toy key from the kept-v1 system, device proofs of the batch's emails, checks"""
+    import torch
+    import zkwg
+    from zkwg import prover
+    from zkwg import r1cs as zr
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    sym = c.symbols()
+    cons = zr.email_verifier_constraints(sym, N, M)
+    n_public = 3 + 17
+    full = zr.append_public_rows(cons, n_public)
+    data = zr.write_r1cs(len(sym), full, n_pub_out=3, n_pub_in=17, n_prv_in=N + 1 + 17 + 1 + 32 + M + 1)
+    key = G.setup(c.W, n_public, cons, seed=11)
+    assert key.m + n_public + 1 == len(full)
+    pk = prover.ProvingKey.from_scalars(0, n_public, key.power, key.a_tau, key.b_tau, key.c_key[n_public + 1:], key.h_key, key.alpha, key.beta, key.delta)
+    pv = prover.Prover(c, data, len(full), pk)
+    recs = records_of(c, n_emails)
+    dev = torch.device("cuda", 0)
+    d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(dev)
+    d_status = torch.zeros(n_emails, dtype=torch.int32, device=dev)
+    d_scratch = torch.empty(c.scratch_bytes(n_emails), dtype=torch.uint8, device=dev)
+    c.prepare_device(d_in, n_emails, d_status, d_scratch)
+    torch.cuda.synchronize()
+    assert d_status.tolist() == [0] * n_emails
+    vk = G.vkey_json(key)
+    rng = random.Random(N)
+    for e in range(n_emails):
+        r, s = rng.randrange(R), rng.randrange(R)
+        proof = pv.prove_prepared(d_in, n_emails, d_scratch, e, r, s)
+        w = zkwg.witness_ints(bytes(pv.d_wit.cpu().numpy()))
+        sc = G.prove_scalars(key, cons, w, r, s)
+        # every sum of the device against its discrete logarithm
+        for name, k_ in (("a", "a"), ("b1", "b"), ("c", "c"), ("h", "h")):
+            assert prover.point_from_montgomery(pv.last_sums[name]) == G1.mul(sc[k_], G1.G), name
+        assert prover.point_from_montgomery(pv.last_sums["b2"]) == G2.mul(sc["b"], G2.G2)
+        assert proof["pi_a"] == G1.mul(sc["pi_a"], G1.G) and proof["pi_c"] == G1.mul(sc["pi_c"], G1.G) and proof["pi_b"] == G2.mul(sc["pi_b"], G2.G2)
+        pub = [str(w[i]) for i in range(1, n_public + 1)]
+        pj = prover.Prover.proof_json(proof)
+        assert P.groth16_verify(vk, pub, pj)
+        if e == 0:
+            bad = list(pub)
+            bad[2] = str((int(bad[2]) + 1) % R)
+            assert not P.groth16_verify(vk, bad, pj)
+
+
+@pytest.mark.gpu
+def test_gpu_proofs_of_synthetic_emails_verify_under_the_pinned_verifier():
+    from zkwg import synth
+    _prove_case(576, 192, lambda c, n: synth.packed_batch(c, seed=5, n=n, body_len=100)[0])
+
+
+@pytest.mark.gpu
+def test_gpu_proof_of_the_reference_test_eml_verifies_under_the_pinned_verifier():
+    """the reference's real email (packages/circuits/tests/test-emails/test.eml, icloud signature) at the size of its own test main,
+    EmailVerifier(640, 768, ...) (email-verifier.test.ts:33-44)"""
+    import real_email
+
+    def records(c, n):
+        return c.pack(real_email.ev_inputs("test_eml", 640, 768)) * n
+    _prove_case(640, 768, records, n_emails=1)

@@ -16,14 +16,22 @@ ZK_HD Fq2 fq2_add(const Fq2& a, const Fq2& b) { return Fq2{fq_add(a.c0, b.c0), f
 ZK_HD Fq2 fq2_sub(const Fq2& a, const Fq2& b) { return Fq2{fq_sub(a.c0, b.c0), fq_sub(a.c1, b.c1)}; }
 ZK_HD Fq2 fq2_neg(const Fq2& a) { return Fq2{fq_neg(a.c0), fq_neg(a.c1)}; }
 ZK_HD Fq2 fq2_dbl(const Fq2& a) { return Fq2{fq_dbl(a.c0), fq_dbl(a.c1)}; }
+// On the device the two products are real functions (arguments by value, in registers): G2 point formulas inline 28 - 42 field
+// products each, and with every product expanded in place (3 x ~560 instructions per fq2_mul) the multi-exponentiation kernels
+// took the compiler more than half an hour; a call costs a few dozen instructions against ~1,700 of work.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_FQ2_FN __device__ __noinline__
+#else
+#define ZK_FQ2_FN inline
+#endif
 // (a0 + a1 i)(b0 + b1 i) = (a0 b0 - a1 b1) + ((a0 + a1)(b0 + b1) - a0 b0 - a1 b1) i
-ZK_HD Fq2 fq2_mul(const Fq2& a, const Fq2& b) {
+ZK_FQ2_FN Fq2 fq2_mul(Fq2 a, Fq2 b) {
   const Fq t0 = fq_mont_mul(a.c0, b.c0), t1 = fq_mont_mul(a.c1, b.c1);
   const Fq t2 = fq_mont_mul(fq_add(a.c0, a.c1), fq_add(b.c0, b.c1));
   return Fq2{fq_sub(t0, t1), fq_sub(fq_sub(t2, t0), t1)};
 }
 // (a0 + a1 i)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 i
-ZK_HD Fq2 fq2_sqr(const Fq2& a) {
+ZK_FQ2_FN Fq2 fq2_sqr(Fq2 a) {
   const Fq t = fq_mont_mul(a.c0, a.c1);
   return Fq2{fq_mont_mul(fq_add(a.c0, a.c1), fq_sub(a.c0, a.c1)), fq_dbl(t)};
 }

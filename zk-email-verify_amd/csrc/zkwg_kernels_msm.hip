@@ -1,40 +1,45 @@
-// G1 multi-exponentiation kernels (bodies: zkwg_msm_core.h).  DRAFT, branch next/msm: never run on a GPU yet.
+// Multi-exponentiation kernels over BN254 G1 and G2 (bodies: zkwg_msm_core.h, shared with the host mirror of the CPU tests).
+// First run on a GPU in round 5 (profiles/r05/r05_a_msm_*): bit-exact against the oracle up to n = 70,000, linear at n = 2^18.
 #include "zkwg_dev.h"
 #include "zkwg_msm_core.h"
 
-__global__ __launch_bounds__(256) void zk_msm_count(ZkMsmArgs A) { zk_msm_count_thread(A, blockIdx.x * 256u + threadIdx.x); }
-__global__ __launch_bounds__(1024) void zk_msm_scan(ZkMsmArgs A) {
+template <class C> __global__ __launch_bounds__(256) void zk_msm_count(ZkMsmArgsT<C> A) { zk_msm_count_thread(A, blockIdx.x * 256u + threadIdx.x); }
+template <class C> __global__ __launch_bounds__(1024) void zk_msm_scan(ZkMsmArgsT<C> A) {
   __shared__ u32 partial[1025];
   zk_msm_scan_thread(A, threadIdx.x, 1024u, partial, 0);
   __syncthreads();
   zk_msm_scan_thread(A, threadIdx.x, 1024u, partial, 1);
 }
-__global__ __launch_bounds__(256) void zk_msm_scatter(ZkMsmArgs A) { zk_msm_scatter_thread(A, blockIdx.x * 256u + threadIdx.x); }
-// 4 wavefronts per SIMD (110 VGPRs for the accumulate loop): 64-thread workgroups so that neighbouring buckets -- runs of similar
-// length -- share a wavefront
-__global__ __launch_bounds__(64) void zk_msm_buckets(ZkMsmArgs A) { zk_msm_bucket_thread(A, blockIdx.x * 64u + threadIdx.x); }
-__global__ __launch_bounds__(64) void zk_msm_reduce(ZkMsmArgs A, const G1Xyzz* in_s, const G1Xyzz* in_a, u32 n_in, u32 span, G1Xyzz* out_s, G1Xyzz* out_a) {
+template <class C> __global__ __launch_bounds__(256) void zk_msm_scatter(ZkMsmArgsT<C> A) { zk_msm_scatter_thread(A, blockIdx.x * 256u + threadIdx.x); }
+// 64-thread workgroups so that neighbouring buckets -- runs of similar length -- share a wavefront
+template <class C> __global__ __launch_bounds__(64) void zk_msm_buckets(ZkMsmArgsT<C> A) { zk_msm_bucket_thread(A, blockIdx.x * 64u + threadIdx.x); }
+template <class C> __global__ __launch_bounds__(64) void zk_msm_reduce(ZkMsmArgsT<C> A, const typename C::Xyzz* in_s, const typename C::Xyzz* in_a, u32 n_in, u32 span,
+                                                                        typename C::Xyzz* out_s, typename C::Xyzz* out_a) {
   zk_msm_reduce_thread(A, blockIdx.x * 64u + threadIdx.x, in_s, in_a, n_in, span, out_s, out_a);
 }
-__global__ __launch_bounds__(64) void zk_msm_ones(ZkMsmArgs A) { zk_msm_ones_thread(A, blockIdx.x * 64u + threadIdx.x); }
-__global__ __launch_bounds__(64) void zk_msm_tree(const G1Xyzz* in, u32 n_in, G1Xyzz* out) { zk_msm_tree_thread(in, n_in, out, blockIdx.x * 64u + threadIdx.x); }
-__global__ __launch_bounds__(64) void zk_msm_combine(ZkMsmArgs A) { if (threadIdx.x == 0 && blockIdx.x == 0) zk_msm_combine_thread(A); }
+template <class C> __global__ __launch_bounds__(64) void zk_msm_ones(ZkMsmArgsT<C> A) { zk_msm_ones_thread(A, blockIdx.x * 64u + threadIdx.x); }
+template <class C> __global__ __launch_bounds__(64) void zk_msm_tree(const typename C::Xyzz* in, u32 n_in, typename C::Xyzz* out) {
+  zk_msm_tree_thread_c<C>(in, n_in, out, blockIdx.x * 64u + threadIdx.x);
+}
+template <class C> __global__ __launch_bounds__(64) void zk_msm_combine(ZkMsmArgsT<C> A) { if (threadIdx.x == 0 && blockIdx.x == 0) zk_msm_combine_thread(A); }
 
 // launches of one multi-exponentiation on `st` (A.count zeroed here)
-void zk_msm_launch(const ZkMsmArgs& A, hipStream_t st) {
+template <class C>
+static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
+  typedef typename C::Xyzz X;
   const u32 total = A.K * A.nb;
   hipMemsetAsync(A.count, 0, ((size_t)total + 1) * 4, st);
-  hipLaunchKernelGGL(zk_msm_count, dim3((A.n + 255) / 256), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(zk_msm_scan, dim3(1), dim3(1024), 0, st, A);
-  hipLaunchKernelGGL(zk_msm_scatter, dim3((A.n + 255) / 256), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(zk_msm_buckets, dim3((total + 63) / 64), dim3(64), 0, st, A);
-  const G1Xyzz* in_s = A.bucket; const G1Xyzz* in_a = nullptr;
+  hipLaunchKernelGGL(zk_msm_count<C>, dim3((A.n + 255) / 256), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(zk_msm_scan<C>, dim3(1), dim3(1024), 0, st, A);
+  hipLaunchKernelGGL(zk_msm_scatter<C>, dim3((A.n + 255) / 256), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(zk_msm_buckets<C>, dim3((total + 63) / 64), dim3(64), 0, st, A);
+  const X* in_s = A.bucket; const X* in_a = nullptr;
   u32 n_in = A.nb, span = 1, half = A.K * ((A.nb + 31) / 32), flip = 0;
   for (;;) {
     const u32 n_out = (n_in + 31) / 32;
-    G1Xyzz* out_s = A.node_s + (size_t)flip * half;
-    G1Xyzz* out_a = A.node_a + (size_t)flip * half;
-    hipLaunchKernelGGL(zk_msm_reduce, dim3((A.K * n_out + 63) / 64), dim3(64), 0, st, A, in_s, in_a, n_in, span, out_s, out_a);
+    X* out_s = A.node_s + (size_t)flip * half;
+    X* out_a = A.node_a + (size_t)flip * half;
+    hipLaunchKernelGGL(zk_msm_reduce<C>, dim3((A.K * n_out + 63) / 64), dim3(64), 0, st, A, in_s, in_a, n_in, span, out_s, out_a);
     if (n_out == 1) break;
     in_s = out_s; in_a = out_a; n_in = n_out; span *= 32; flip ^= 1;
   }
@@ -43,17 +48,49 @@ void zk_msm_launch(const ZkMsmArgs& A, hipStream_t st) {
     const u32 half1 = (A.n + 63) / 64;
     u32 m = half1, levels = 0;
     for (u32 q = m; q > 1; q = (q + 63) / 64) ++levels;
-    G1Xyzz* cur = A.ones + ((levels & 1u) ? half1 : 0);
+    X* cur = A.ones + ((levels & 1u) ? half1 : 0);
     {
-      ZkMsmArgs B = A; B.ones = cur;
-      hipLaunchKernelGGL(zk_msm_ones, dim3((half1 + 63) / 64), dim3(64), 0, st, B);
+      ZkMsmArgsT<C> B = A; B.ones = cur;
+      hipLaunchKernelGGL(zk_msm_ones<C>, dim3((half1 + 63) / 64), dim3(64), 0, st, B);
     }
     while (m > 1) {
       const u32 m2 = (m + 63) / 64;
-      G1Xyzz* nxt = cur == A.ones ? A.ones + half1 : A.ones;
-      hipLaunchKernelGGL(zk_msm_tree, dim3((m2 + 63) / 64), dim3(64), 0, st, (const G1Xyzz*)cur, m, nxt);
+      X* nxt = cur == A.ones ? A.ones + half1 : A.ones;
+      hipLaunchKernelGGL(zk_msm_tree<C>, dim3((m2 + 63) / 64), dim3(64), 0, st, (const X*)cur, m, nxt);
       cur = nxt; m = m2;
     }
   }
-  hipLaunchKernelGGL(zk_msm_combine, dim3(1), dim3(64), 0, st, A);
+  hipLaunchKernelGGL(zk_msm_combine<C>, dim3(1), dim3(64), 0, st, A);
+}
+void zk_msm_launch(const ZkMsmArgs& A, hipStream_t st) { zk_msm_launch_t<ZkCurveG1>(A, st); }
+void zk_msm_launch_g2(const ZkMsmArgsT<ZkCurveG2>& A, hipStream_t st) { zk_msm_launch_t<ZkCurveG2>(A, st); }
+
+// ---- fixed-base multiples: out[i] = k_i G for the group's generator -- how a key with a known trapdoor is turned into bases
+// (tests, tools: oracle/pyref/groth16.py makes the scalars).  One thread per scalar: double-and-add from the top over a 4-bit
+// window table of the generator held in LDS.
+template <class C>
+__global__ __launch_bounds__(64) void zk_fixed_base(const typename C::Affine gen, const Fr* __restrict__ k, typename C::Affine* __restrict__ out, u32 n) {
+  __shared__ typename C::Xyzz tab[16];
+  if (threadIdx.x == 0) {
+    tab[0] = C::inf();
+    for (int j = 1; j < 16; ++j) tab[j] = C::add_mixed(tab[j - 1], gen);
+  }
+  __syncthreads();
+  const u32 i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n) return;
+  const Fr s = k[i];
+  typename C::Xyzz acc = C::inf();
+  for (int w = 63; w >= 0; --w) {
+    acc = C::dbl(C::dbl(C::dbl(C::dbl(acc))));
+    const u32 d = (u32)(s.l[w >> 4] >> (4 * (w & 15))) & 15u;
+    if (d) acc = C::add(acc, tab[d]);
+  }
+  if constexpr (sizeof(typename C::Affine) == sizeof(G1Affine)) out[i] = g1_to_affine(*(const G1Xyzz*)&acc);
+  else out[i] = g2_to_affine(*(const G2Xyzz*)&acc);
+}
+void zk_fixed_base_g1_launch(const G1Affine& gen, const Fr* k, G1Affine* out, u32 n, hipStream_t st) {
+  hipLaunchKernelGGL(zk_fixed_base<ZkCurveG1>, dim3((n + 63) / 64), dim3(64), 0, st, gen, k, out, n);
+}
+void zk_fixed_base_g2_launch(const G2Affine& gen, const Fr* k, G2Affine* out, u32 n, hipStream_t st) {
+  hipLaunchKernelGGL(zk_fixed_base<ZkCurveG2>, dim3((n + 63) / 64), dim3(64), 0, st, gen, k, out, n);
 }

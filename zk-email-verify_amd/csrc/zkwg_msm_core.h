@@ -15,8 +15,32 @@
 // DRAFT (branch next/msm, round 4): written and mirrored on the CPU after the round's GPU budget was spent; it has not run on a GPU.
 #pragma once
 #include "zkwg_g1.h"
+#include "zkwg_g2.h"
 
-struct ZkMsmArgs {
+// the group the sums run over: G1 (pi_a, pib1, pi_c, the H sum) or G2 (pi_b) -- same kernels, other point arithmetic
+struct ZkCurveG1 {
+  typedef G1Affine Affine; typedef G1Xyzz Xyzz;
+  static ZK_HD Xyzz inf() { return g1_xyzz_inf(); }
+  static ZK_HD bool is_inf(const Affine& p) { return g1_is_inf(p); }
+  static ZK_HD Affine neg(const Affine& p) { return g1_neg(p); }
+  static ZK_HD Xyzz add_mixed(const Xyzz& a, const Affine& p) { return g1_add_mixed(a, p); }
+  static ZK_HD Xyzz add(const Xyzz& a, const Xyzz& b) { return g1_add(a, b); }
+  static ZK_HD Xyzz dbl(const Xyzz& a) { return g1_dbl(a); }
+};
+struct ZkCurveG2 {
+  typedef G2Affine Affine; typedef G2Xyzz Xyzz;
+  static ZK_HD Xyzz inf() { return g2_xyzz_inf(); }
+  static ZK_HD bool is_inf(const Affine& p) { return g2_is_inf(p); }
+  static ZK_HD Affine neg(const Affine& p) { return g2_neg(p); }
+  static ZK_HD Xyzz add_mixed(const Xyzz& a, const Affine& p) { return g2_add_mixed(a, p); }
+  static ZK_HD Xyzz add(const Xyzz& a, const Xyzz& b) { return g2_add(a, b); }
+  static ZK_HD Xyzz dbl(const Xyzz& a) { return g2_dbl(a); }
+};
+
+template <class C>
+struct ZkMsmArgsT {
+  typedef typename C::Affine G1Affine;
+  typedef typename C::Xyzz G1Xyzz;
   const G1Affine* bases;      // n points, Montgomery form, (0, 0) = infinity
   const Fr* scalars;          // n scalars of this call
   u32 n, c, K, nb;            // points, window bits, windows, buckets per window = 2^(c-1)
@@ -32,6 +56,7 @@ struct ZkMsmArgs {
   G1Xyzz* window;             // [K] weighted bucket sums
   G1Xyzz* out;                // [1]
 };
+typedef ZkMsmArgsT<ZkCurveG1> ZkMsmArgs;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZK_MSM_ATOMIC_INC(p) atomicAdd((p), 1u)
@@ -40,26 +65,30 @@ struct ZkMsmArgs {
 #endif
 
 // scalar i in standard form
-ZK_HD Fr zk_msm_scalar(const ZkMsmArgs& A, u32 i) { return A.scalars_mont ? fr_from_mont(A.scalars[i]) : A.scalars[i]; }
+template <class C>
+ZK_HD Fr zk_msm_scalar(const ZkMsmArgsT<C>& A, u32 i) { return A.scalars_mont ? fr_from_mont(A.scalars[i]) : A.scalars[i]; }
 ZK_HD bool zk_msm_is_one(const Fr& k) { return k.l[0] == 1 && (k.l[1] | k.l[2] | k.l[3]) == 0; }
 // the bases whose scalar is 1, 64 per thread (ones_apart); then zk_msm_tree_thread joins 64 partial sums per thread until one is left
-ZK_HD void zk_msm_ones_thread(const ZkMsmArgs& A, u32 t) {
+template <class C>
+ZK_HD void zk_msm_ones_thread(const ZkMsmArgsT<C>& A, u32 t) {
   const u32 lo = t * 64u, hi = lo + 64u < A.n ? lo + 64u : A.n;
   if (lo >= A.n) return;
-  G1Xyzz acc = g1_xyzz_inf();
+  typename C::Xyzz acc = C::inf();
   for (u32 i = lo; i < hi; ++i)
-    if (zk_msm_is_one(zk_msm_scalar(A, i))) acc = g1_add_mixed(acc, A.bases[i]);
+    if (zk_msm_is_one(zk_msm_scalar(A, i))) acc = C::add_mixed(acc, A.bases[i]);
   A.ones[t] = acc;
 }
-ZK_HD void zk_msm_tree_thread(const G1Xyzz* in, u32 n_in, G1Xyzz* out, u32 t) {
+template <class C>
+ZK_HD void zk_msm_tree_thread_c(const typename C::Xyzz* in, u32 n_in, typename C::Xyzz* out, u32 t) {
   const u32 lo = t * 64u, hi = lo + 64u < n_in ? lo + 64u : n_in;
   if (lo >= n_in) return;
-  G1Xyzz acc = in[lo];
-  for (u32 i = lo + 1; i < hi; ++i) acc = g1_add(acc, in[i]);
+  typename C::Xyzz acc = in[lo];
+  for (u32 i = lo + 1; i < hi; ++i) acc = C::add(acc, in[i]);
   out[t] = acc;
 }
-ZK_HD void zk_msm_count_thread(const ZkMsmArgs& A, u32 i) {
-  if (i >= A.n || g1_is_inf(A.bases[i])) return;
+template <class C>
+ZK_HD void zk_msm_count_thread(const ZkMsmArgsT<C>& A, u32 i) {
+  if (i >= A.n || C::is_inf(A.bases[i])) return;
   const Fr k = zk_msm_scalar(A, i);
   if (A.ones_apart && zk_msm_is_one(k)) return;
   u32 carry = 0;
@@ -70,7 +99,8 @@ ZK_HD void zk_msm_count_thread(const ZkMsmArgs& A, u32 i) {
 }
 // one workgroup of `threads` threads (thread t of them): counts -> exclusive offsets in place, cursor = offsets; count[total] = entries.
 // Two phases separated by a barrier the caller supplies (host mirror: phase 0 for every t, then phase 1 for every t).
-ZK_HD void zk_msm_scan_thread(const ZkMsmArgs& A, u32 t, u32 threads, u32* partial /*[threads + 1]*/, int phase) {
+template <class C>
+ZK_HD void zk_msm_scan_thread(const ZkMsmArgsT<C>& A, u32 t, u32 threads, u32* partial /*[threads + 1]*/, int phase) {
   const u32 total = A.K * A.nb, per = (total + threads - 1) / threads;
   const u32 lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
   if (phase == 0) {
@@ -86,8 +116,9 @@ ZK_HD void zk_msm_scan_thread(const ZkMsmArgs& A, u32 t, u32 threads, u32* parti
   if (hi == total && lo < total) A.count[total] = base;
   if (total == 0 && t == 0) A.count[0] = 0;
 }
-ZK_HD void zk_msm_scatter_thread(const ZkMsmArgs& A, u32 i) {
-  if (i >= A.n || g1_is_inf(A.bases[i])) return;
+template <class C>
+ZK_HD void zk_msm_scatter_thread(const ZkMsmArgsT<C>& A, u32 i) {
+  if (i >= A.n || C::is_inf(A.bases[i])) return;
   const Fr k = zk_msm_scalar(A, i);
   if (A.ones_apart && zk_msm_is_one(k)) return;
   u32 carry = 0;
@@ -99,46 +130,51 @@ ZK_HD void zk_msm_scatter_thread(const ZkMsmArgs& A, u32 i) {
     A.entry[at] = i | (d < 0 ? 0x80000000u : 0u);
   }
 }
-ZK_HD void zk_msm_bucket_thread(const ZkMsmArgs& A, u32 b) {
+template <class C>
+ZK_HD void zk_msm_bucket_thread(const ZkMsmArgsT<C>& A, u32 b) {
   if (b >= A.K * A.nb) return;
-  G1Xyzz acc = g1_xyzz_inf();
+  typename C::Xyzz acc = C::inf();
   for (u32 k = A.count[b], e = A.count[b + 1]; k < e; ++k) {
     const u32 v = A.entry[k];
-    G1Affine p = A.bases[v & 0x7fffffffu];
-    if (v >> 31) p.y = fq_neg(p.y);
-    acc = g1_add_mixed(acc, p);
+    typename C::Affine p = A.bases[v & 0x7fffffffu];
+    if (v >> 31) p = C::neg(p);
+    acc = C::add_mixed(acc, p);
   }
   A.bucket[b] = acc;
 }
 // one level of the reduction tree.  Nodes of the level below: `n_in` per window with span `span` (weights 1 .. span inside a node);
 // in_a == nullptr: the nodes are the buckets themselves (S = A = bucket, span 1).  Thread g builds node g of the level above
 // (`n_out` = ceil(n_in / 32) per window).  The last level (n_out == 1) writes the window's sum to A.window.
-ZK_HD void zk_msm_reduce_thread(const ZkMsmArgs& A, u32 g, const G1Xyzz* in_s, const G1Xyzz* in_a, u32 n_in, u32 span, G1Xyzz* out_s, G1Xyzz* out_a) {
+template <class C>
+ZK_HD void zk_msm_reduce_thread(const ZkMsmArgsT<C>& A, u32 g, const typename C::Xyzz* in_s, const typename C::Xyzz* in_a, u32 n_in, u32 span, typename C::Xyzz* out_s, typename C::Xyzz* out_a) {
   const u32 n_out = (n_in + 31u) / 32u;
   if (g >= A.K * n_out) return;
   const u32 w = g / n_out, q = g - w * n_out;
   const u32 lo = q * 32u, hi = lo + 32u < n_in ? lo + 32u : n_in;
-  const G1Xyzz* S = in_s + (size_t)w * n_in;
-  const G1Xyzz* Aw = (in_a ? in_a : in_s) + (size_t)w * n_in;
+  const typename C::Xyzz* S = in_s + (size_t)w * n_in;
+  const typename C::Xyzz* Aw = (in_a ? in_a : in_s) + (size_t)w * n_in;
   // sum_i i S_i for i = 1 .. m - 1 (running sum from the top), sum S_i, sum A_i
-  G1Xyzz run = g1_xyzz_inf(), acc = g1_xyzz_inf(), sum_a = g1_xyzz_inf();
+  typename C::Xyzz run = C::inf(), acc = C::inf(), sum_a = C::inf();
   for (u32 k = hi; k-- > lo;) {
-    sum_a = g1_add(sum_a, Aw[k]);
-    if (k > lo) { run = g1_add(run, S[k]); acc = g1_add(acc, run); }
+    sum_a = C::add(sum_a, Aw[k]);
+    if (k > lo) { run = C::add(run, S[k]); acc = C::add(acc, run); }
   }
-  const G1Xyzz sum_s = g1_add(run, S[lo]);
-  for (u32 s = span; s > 1; s >>= 1) acc = g1_dbl(acc);            // span is a power of two
-  const G1Xyzz node_a = g1_add(sum_a, acc);
+  const typename C::Xyzz sum_s = C::add(run, S[lo]);
+  for (u32 s = span; s > 1; s >>= 1) acc = C::dbl(acc);            // span is a power of two
+  const typename C::Xyzz node_a = C::add(sum_a, acc);
   if (n_out == 1) { A.window[w] = node_a; return; }
   out_s[(size_t)w * n_out + q] = sum_s;
   out_a[(size_t)w * n_out + q] = node_a;
 }
-ZK_HD void zk_msm_combine_thread(const ZkMsmArgs& A) {
-  G1Xyzz total = g1_xyzz_inf();
+template <class C>
+ZK_HD void zk_msm_combine_thread(const ZkMsmArgsT<C>& A) {
+  typename C::Xyzz total = C::inf();
   for (u32 w = A.K; w-- > 0;) {
-    for (u32 s = 0; s < A.c; ++s) total = g1_dbl(total);
-    total = g1_add(total, A.window[w]);
+    for (u32 s = 0; s < A.c; ++s) total = C::dbl(total);
+    total = C::add(total, A.window[w]);
   }
-  if (A.ones_apart) total = g1_add(total, A.ones[0]);
+  if (A.ones_apart) total = C::add(total, A.ones[0]);
   A.out[0] = total;
 }
+// (G1 by name: the host mirror of the CPU tests)
+ZK_HD void zk_msm_tree_thread(const G1Xyzz* in, u32 n_in, G1Xyzz* out, u32 t) { zk_msm_tree_thread_c<ZkCurveG1>(in, n_in, out, t); }

@@ -1,0 +1,158 @@
+"""The second half of `snarkjs.groth16.fullProve` on the device (reference call site: packages/helpers/src/chunked-zkey.ts:80-84):
+inputs -> witness -> A.w | B.w | C.w -> H evaluations -> the five multi-exponentiations -> pi_a, pi_b, pi_c.
+
+Host side of include/zkwg.h's prover stages 1-3 (zkwg_expand_abc_device, zkwg_h_evaluations_device, zkwg_msm_*,
+zkwg_groth16_assemble).  The proving key's bases stay resident on the device in the zkey's own point layout; per email only scalars
+move.  torch is plumbing (device buffers, streams).
+
+A key comes from a `.zkey` (zkwg.zkey.read_zkey) or -- tests and tools, where no ceremony output exists -- from the discrete
+logarithms of its points (ProvingKey.from_scalars: zkwg_fixed_base_device turns them into bases on the device).
+"""
+import ctypes as C
+
+from . import _lib
+from . import Ntt, ZkwgError, _check, _stream_ptr
+
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def _scalars_bytes(xs):
+    return b"".join(int(x % R).to_bytes(32, "little") for x in xs)
+
+
+def fixed_base(device, group, scalars):
+    """[k_i] -> device tensor of k_i * G (group 1: 64-byte points, group 2: 128-byte points; affine, Montgomery form)"""
+    import torch
+    lib = _lib.load()
+    dev = torch.device("cuda", device)
+    n = len(scalars)
+    d_k = torch.frombuffer(bytearray(_scalars_bytes(scalars)), dtype=torch.uint8).to(dev)
+    d_out = torch.empty(n * (64 if group == 1 else 128), dtype=torch.uint8, device=dev)
+    _check(lib.zkwg_fixed_base_device(device, group, d_k.data_ptr(), n, d_out.data_ptr(), 0))
+    torch.cuda.synchronize(dev)
+    return d_out
+
+
+class _DeviceMsm:
+    """multi-exponentiation over bases that already live on the device (zkwg_msm_create_device)"""
+
+    def __init__(self, d_bases, group, device, window_bits=0):
+        self.lib = _lib.load()
+        self.group, self.device = group, device
+        self.n = d_bases.numel() // (64 if group == 1 else 128)
+        self.d_bases = d_bases                      # keep the tensor alive
+        h = C.c_void_p()
+        _check(self.lib.zkwg_msm_create_device(device, group, d_bases.data_ptr(), self.n, window_bits, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.zkwg_msm_destroy(self.h)
+            self.h = None
+
+    def work_bytes(self):
+        return self.lib.zkwg_msm_work_bytes(self.h)
+
+    def run(self, scalars_ptr, montgomery, ones_apart, d_work, stream=None):
+        """-> the sum as the zkey would store it (bytes: 64 / 128, affine Montgomery form, zeros = infinity)"""
+        out = (C.c_uint8 * (64 if self.group == 1 else 128))()
+        fn = self.lib.zkwg_msm_g1_device if self.group == 1 else self.lib.zkwg_msm_g2_device
+        _check(fn(self.h, scalars_ptr, 1 if montgomery else 0, 1 if ones_apart else 0, d_work.data_ptr(), out, _stream_ptr(stream)))
+        return bytes(out)
+
+
+class ProvingKey:
+    """bases of one circuit's key on the device + the five verification-key points the prover adds"""
+
+    def __init__(self, device, n_wires, n_public, power, d_a, d_b1, d_b2, d_c, d_h, alpha1, beta1, beta2, delta1, delta2):
+        self.device, self.n_wires, self.n_public, self.power = device, n_wires, n_public, power
+        self.d_a, self.d_b1, self.d_b2, self.d_c, self.d_h = d_a, d_b1, d_b2, d_c, d_h
+        self.alpha1, self.beta1, self.beta2, self.delta1, self.delta2 = alpha1, beta1, beta2, delta1, delta2
+        assert d_a.numel() == 64 * n_wires and d_b1.numel() == 64 * n_wires and d_b2.numel() == 128 * n_wires
+        assert d_c.numel() == 64 * (n_wires - n_public - 1) and d_h.numel() == 64 << power
+
+    @staticmethod
+    def from_scalars(device, n_public, power, a, b, c_private, h, alpha, beta, delta):
+        """a, b: the discrete logarithms of the A / B bases of every wire; c_private: those of the C bases of the private wires
+        (wire nPublic + 1 onwards); h: of the 2^power H bases; alpha, beta, delta: of the key's points (a toy key: tests, tools)"""
+        n_wires = len(a)
+        assert len(b) == n_wires and len(c_private) == n_wires - n_public - 1 and len(h) == 1 << power
+        pts = fixed_base(device, 1, [alpha, beta, delta])
+        p2 = fixed_base(device, 2, [beta, delta])
+        raw1, raw2 = bytes(pts.cpu().numpy()), bytes(p2.cpu().numpy())
+        return ProvingKey(device, n_wires, n_public, power, fixed_base(device, 1, a), fixed_base(device, 1, b), fixed_base(device, 2, b),
+                          fixed_base(device, 1, c_private), fixed_base(device, 1, h),
+                          raw1[0:64], raw1[64:128], raw2[0:128], raw1[128:192], raw2[128:256])
+
+
+class Prover:
+    """groth16.prove for the emails of a prepared batch.  `circuit`: a device handle whose constraint system `r1cs` (bytes of an
+    `.r1cs` over its witness layout, WITH the nPublic + 1 rows snarkjs appends to A -- zkwg.r1cs.append_public_rows) is attached here."""
+
+    def __init__(self, circuit, r1cs, n_constraints, key, stream=None):
+        import torch
+        self.c, self.key = circuit, key
+        self.lib = _lib.load()
+        self.m = n_constraints                      # rows of the attached system (public rows included)
+        if (1 << key.power) < self.m:
+            raise ZkwgError("the key's domain is smaller than the constraint system")
+        if key.n_wires != circuit.W:
+            raise ZkwgError(f"the key has {key.n_wires} wires, the circuit's witness {circuit.W}")
+        circuit.attach_r1cs(r1cs)
+        if circuit.abc_bytes != 96 * self.m:
+            raise ZkwgError("n_constraints does not match the attached system")
+        self.dev = torch.device("cuda", circuit.device)
+        self.ntt = Ntt(key.power, device=circuit.device)
+        d = circuit.device
+        self.msm_a = _DeviceMsm(key.d_a, 1, d)
+        self.msm_b1 = _DeviceMsm(key.d_b1, 1, d)
+        self.msm_b2 = _DeviceMsm(key.d_b2, 2, d)
+        self.msm_c = _DeviceMsm(key.d_c, 1, d)
+        self.msm_h = _DeviceMsm(key.d_h, 1, d)
+        wb = max(m.work_bytes() for m in (self.msm_a, self.msm_b1, self.msm_b2, self.msm_c, self.msm_h))
+        self.d_msm_work = torch.empty(wb + 256, dtype=torch.uint8, device=self.dev)
+        self.d_msm_work = self.d_msm_work[(-self.d_msm_work.data_ptr()) % 256:]
+        self.d_wit = torch.empty(circuit.witness_bytes, dtype=torch.uint8, device=self.dev)
+        self.d_abc = torch.empty(circuit.abc_bytes, dtype=torch.uint8, device=self.dev)
+        self.d_h = torch.empty(32 << key.power, dtype=torch.uint8, device=self.dev)
+        self.d_ntt_work = torch.empty(self.ntt.work_bytes(1), dtype=torch.uint8, device=self.dev)
+        self.last_sums = None
+
+    def prove_prepared(self, d_in, n, d_scratch, index, r, s, stream=None):
+        """the proof of email `index` of a batch of n prepared by circuit.prepare_device(d_in, n, ...): {'pi_a': (x, y), 'pi_b':
+        ((x0, x1), (y0, y1)), 'pi_c': (x, y)} as standard-form integers (snarkjs proof.json without the projective ones)"""
+        c, k = self.c, self.key
+        c.expand_device(d_in, n, d_scratch, index, 1, self.d_wit, stream)
+        c.expand_abc_device(d_in, n, d_scratch, index, 1, self.d_abc, stream, montgomery=True)
+        self.ntt.h_evaluations_device(self.d_abc, c.abc_bytes, self.m, 1, self.d_ntt_work, self.d_h, stream=stream)
+        wit = self.d_wit.data_ptr()
+        sums = {
+            "a": self.msm_a.run(wit, False, True, self.d_msm_work, stream),
+            "b1": self.msm_b1.run(wit, False, True, self.d_msm_work, stream),
+            "b2": self.msm_b2.run(wit, False, True, self.d_msm_work, stream),
+            "c": self.msm_c.run(wit + 32 * (k.n_public + 1), False, True, self.d_msm_work, stream),
+            "h": self.msm_h.run(self.d_h.data_ptr(), True, False, self.d_msm_work, stream),
+        }
+        self.last_sums = sums
+        pa, pb, pc = (C.c_uint8 * 64)(), (C.c_uint8 * 128)(), (C.c_uint8 * 64)()
+        _check(self.lib.zkwg_groth16_assemble(sums["a"], sums["b1"], sums["b2"], sums["c"], sums["h"], k.alpha1, k.beta1, k.beta2, k.delta1, k.delta2,
+                                              int(r % R).to_bytes(32, "little"), int(s % R).to_bytes(32, "little"), pa, pb, pc))
+        i = lambda b, j: int.from_bytes(bytes(b)[32 * j:32 * j + 32], "little")
+        return {"pi_a": (i(pa, 0), i(pa, 1)), "pi_b": ((i(pb, 0), i(pb, 1)), (i(pb, 2), i(pb, 3))), "pi_c": (i(pc, 0), i(pc, 1))}
+
+    @staticmethod
+    def proof_json(p):
+        """snarkjs' proof.json layout (what packages/rust-verifier/src/verifier_utils.rs:20-130 parses)"""
+        return {"pi_a": [str(p["pi_a"][0]), str(p["pi_a"][1]), "1"],
+                "pi_b": [[str(p["pi_b"][0][0]), str(p["pi_b"][0][1])], [str(p["pi_b"][1][0]), str(p["pi_b"][1][1])], ["1", "0"]],
+                "pi_c": [str(p["pi_c"][0]), str(p["pi_c"][1]), "1"], "protocol": "groth16", "curve": "bn128"}
+
+
+def point_from_montgomery(raw):
+    """a sum as zkwg_msm_* returns it (affine, Montgomery form) -> standard-form integers: (x, y), ((x0, x1), (y0, y1)) or None"""
+    if raw == bytes(len(raw)):
+        return None
+    rinv = pow(1 << 256, -1, Q)
+    v = [int.from_bytes(raw[32 * j:32 * j + 32], "little") * rinv % Q for j in range(len(raw) // 32)]
+    return (v[0], v[1]) if len(v) == 2 else ((v[0], v[1]), (v[2], v[3]))

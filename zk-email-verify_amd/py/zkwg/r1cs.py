@@ -875,6 +875,14 @@ def write_r1cs(n_wires, constraints, n_pub_out=0, n_pub_in=0, n_prv_in=0, header
 
 
 
+def append_public_rows(constraints, n_public):
+    """the system a snarkjs zkey is built over: zkey_new.js appends nPublic + 1 rows to the A matrix, row nConstraints + s =
+    the wire s alone (s = 0 .. nPublic; B and C empty there), which keeps the public wires' polynomials independent.  Attached
+    like this (zkwg.Circuit.attach_r1cs), zkwg_expand_abc_device writes the A.w | B.w | C.w that groth16.prove's buildABC1 forms
+    and zkwg_h_evaluations_device the H evaluations of a real zkey's domain."""
+    return list(constraints) + [({s: 1}, {}, {}) for s in range(n_public + 1)]
+
+
 def email_verifier_r1cs(symbols, N, M, enable_header_masking=0, enable_body_masking=0, remove_soft_line_breaks_flag=0,
                         ignore_body_hash_check=0):
     """bytes of the `.r1cs` file of EmailVerifier(N, M, 121, 17, 0, flags...) over the kept-v1 wires `symbols`
