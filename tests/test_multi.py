@@ -127,18 +127,21 @@ def test_multi_create_reports_a_missing_rccl_library(monkeypatch):
         zkwg.MultiCircuit([0, 0], main_kind=zkwg.MAIN_EMAIL_VERIFIER, max_header=576, max_body=192)
 
 
-def test_bench_launches_its_own_ranks_without_torchrun():
-    """`python bench.py --gpus 2` with no launcher on the command line and no WORLD_SIZE in the environment: bench.py
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launches_its_own_ranks_without_torchrun(world):
+    """`python bench.py --gpus N` (N = 2, and 8: the driver's scaling run) with no launcher on the command line and no WORLD_SIZE in the environment: bench.py
     starts two ranks under torch.distributed.run itself (free port, 127.0.0.1) -- checked here on CPU with the
     rendezvous-only mode (gloo); the GPU test below runs the real workload the same way."""
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], cwd=ROOT, env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--launch-check"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    assert json.loads(line) == {"launch_check": 2, "rank_sum": 3, "local_rank_env": 0}
+    assert json.loads(line) == {"launch_check": world, "rank_sum": world * (world + 1) // 2, "local_rank_env": 0}
+    if world != 2:
+        return
     # a launcher whose world size disagrees with --gpus is still refused, with a message that says what to do
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], cwd=ROOT,
                        env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=600)
