@@ -66,9 +66,16 @@ class Pipeline:
         self.R = max(2, ring)
         self.d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(self.R)]
         self.placement = None
-        if place:
-            # the output ring goes where HBM takes zk_expand's stores fastest (zkwg.placement): the first
-            # sub-batch is prepared once, the real expansion of one tile is timed into each candidate buffer, the best are kept
+        if place == 2 or place is True:
+            # the output ring is mapped from 1 GiB physical chunks (zkwg_device_alloc_chunked): every tile then
+            # takes zk_expand's stores at the rate only the best hipMalloc buffers reach -- no candidates, no transient memory
+            from zkwg import placement
+            ntl = min(2, self.ntiles)
+            self.d_out = [placement.chunked_tensor(torch, dev, tile * self.stride) for _ in range(ntl)]
+            self.placement = {"mode": "chunked", "chunk_bytes": 1 << 30, "tiles": ntl, "tile_bytes": tile * self.stride}
+        elif place:
+            # round 4's way (--place-ring 1): spare candidate buffers from hipMalloc, the real expansion of one tile timed into each,
+            # the fastest kept
             from zkwg import placement
             cur = torch.cuda.current_stream()
             c.set_prepare_throttle(0)
@@ -265,9 +272,9 @@ def main():
     ap.add_argument("--prep-cus", type=int, default=0,
                     help="> 0: the prepare kernels run on this many compute units only (CU-masked stream), zk_expand on the others")
     ap.add_argument("--prep-cu-stride", type=int, default=1, help="with --prep-cus: take every stride-th CU instead of the first ones")
-    ap.add_argument("--place-ring", type=int, default=1,
-                    help="1 (default): allocate spare candidate tiles at set-up, time zk_expand into each and keep the output ring where "
-                         "HBM takes its stores fastest (zkwg.placement); 0: the first two allocations, wherever they land")
+    ap.add_argument("--place-ring", type=int, default=2,
+                    help="2 (default): the output ring is mapped from 1 GiB physical chunks (zkwg_device_alloc_chunked); 1: round 4's way -- "
+                         "spare candidate tiles from hipMalloc, zk_expand timed into each, the fastest kept; 0: two plain allocations")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous (gloo, no GPU needed): every rank joins, rank 0 prints {\"launch_check\": world} -- the "
@@ -333,7 +340,7 @@ def main():
     prio = int(os.environ.get("ZKWG_BENCH_EXP_PRIO", "-1"))
     pl = Pipeline(torch, c, dev, d_in, args.batch, tile, prep, ring=args.ring, prep_streams=args.prep_streams,
                   rsa_throttle=args.rsa_throttle, exp_prio=prio, montgomery=bool(args.montgomery), out_align=args.out_align,
-                  serial=bool(args.no_overlap), prep_cus=args.prep_cus, prep_cu_stride=args.prep_cu_stride, place=bool(args.place_ring))
+                  serial=bool(args.no_overlap), prep_cus=args.prep_cus, prep_cu_stride=args.prep_cu_stride, place=args.place_ring)
     from zkwg import shard
     state = {"table": None}
 
@@ -500,7 +507,7 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         _, avg, n, gbs = expand_roofline(c, 256)
         c.set_timing(False)
         assert int(pl.d_status.abs().sum().item()) == 0
-        out["configs[1] batch=256"] = {"value": round(256 * 20 / dt, 1), "unit": "witnesses/s", "steps": 20,
+        out["configs[1] batch=256"] = {"value": round(256 * 20 / dt, 1), "unit": "witnesses/s", "steps": 20, "ring_placement": pl.placement,
                                        "zk_expand_GBps": round(gbs, 1), "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4)}
         del pl, d_in
         torch.cuda.empty_cache()
@@ -511,11 +518,11 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         _, d_in, _ = resident_inputs(torch, c, dev, 0x5A4B + 404, 64, 2048, args.body_len)
         pl = Pipeline(torch, c, dev, d_in, 2048, 512, 1024, ring=2, rsa_throttle=args.rsa_throttle, montgomery=True)
         c.set_timing(True)
-        dt = timed(torch, pl.step, steps=3, warmup=1)
+        dt = timed(torch, pl.step, steps=6, warmup=1)
         _, avg, n, gbs = expand_roofline(c, 512)
         c.set_timing(False)
         assert int(pl.d_status.abs().sum().item()) == 0
-        out["Montgomery-form output (fused hand-off)"] = {"value": round(2048 * 3 / dt, 1), "unit": "witnesses/s", "steps": 3,
+        out["Montgomery-form output (fused hand-off)"] = {"value": round(2048 * 6 / dt, 1), "unit": "witnesses/s", "steps": 6, "ring_placement": pl.placement,
                                                            "zk_expand_GBps": round(gbs, 1), "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4)}
         del pl, d_in
         torch.cuda.empty_cache()
@@ -531,12 +538,12 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
             _, d_in, _ = resident_inputs(torch, cr, dev, 0x5A4B + 505, 64, 4096, args.body_len)
             pl = Pipeline(torch, cr, dev, d_in, 4096, 512, 2048, ring=2, rsa_throttle=args.rsa_throttle)
             cr.set_timing(True)
-            dt = timed(torch, pl.step, steps=2, warmup=1)
+            dt = timed(torch, pl.step, steps=5, warmup=1)
             summ = cr.timing_summary()
             cr.set_timing(False)
             assert int(pl.d_status.abs().sum().item()) == 0
             out["BodyHashRegex compiled from the template file"] = {
-                "value": round(4096 * 2 / dt, 1), "unit": "witnesses/s", "steps": 2,
+                "value": round(4096 * 5 / dt, 1), "unit": "witnesses/s", "steps": 5,
                 "zk_net_scan_eval_fill_ms_per_2048_emails": round(summ["zk_net_eval"][0] / max(summ["zk_net_eval"][1], 1), 3),
                 "gate_list": cr.regex_info()}
             del pl, d_in, cr
@@ -552,13 +559,13 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
             _, d_in, _ = resident_inputs(torch, cr, dev, 0x5A4B + 606, 64, 4096, args.body_len)
             pl = Pipeline(torch, cr, dev, d_in, 4096, 512, 2048, ring=2, rsa_throttle=args.rsa_throttle)
             cr.set_timing(True)
-            dt = timed(torch, pl.step, steps=2, warmup=1)
+            dt = timed(torch, pl.step, steps=5, warmup=1)
             summ = cr.timing_summary()
             _, avg, nl, gbs = expand_roofline(cr, 512)
             cr.set_timing(False)
             assert int(pl.d_status.abs().sum().item()) == 0
             out["BodyHashRegex from a template of the real circuit's size (unshared comparators)"] = {
-                "value": round(4096 * 2 / dt, 1), "unit": "witnesses/s", "steps": 2, "witness_len": cr.W,
+                "value": round(4096 * 5 / dt, 1), "unit": "witnesses/s", "steps": 5, "witness_len": cr.W,
                 "zk_net_scan_eval_fill_ms_per_2048_emails": round(summ["zk_net_eval"][0] / max(summ["zk_net_eval"][1], 1), 3),
                 "zk_expand_GBps": round(gbs, 1), "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4), "gate_list": cr.regex_info()}
             del pl, d_in, cr
@@ -629,14 +636,14 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         res = {}
         for mont in (False, True):
             pl = Pipeline(torch, ca, dev, d_in, ba, ta, 1024, ring=2, montgomery=mont, abc=True)
-            dt = timed(torch, pl.step, steps=3, warmup=1)
+            dt = timed(torch, pl.step, steps=5, warmup=1)
             assert int(pl.d_status.abs().sum().item()) == 0
-            res["montgomery" if mont else "standard"] = {"value": round(ba * 3 / dt, 1), "GBps_written": round(ba * 3 * ca.abc_bytes / dt / 1e9, 1)}
+            res["montgomery" if mont else "standard"] = {"value": round(ba * 5 / dt, 1), "GBps_written": round(ba * 5 * ca.abc_bytes / dt / 1e9, 1)}
             del pl
             torch.cuda.empty_cache()
         out["prover stage 1 from the image, EmailVerifier(576,192)"] = {
             "unit": "witnesses/s (inputs -> A.w|B.w|C.w, witness generation included)", "constraints": cs.n_constraints, "abc_bytes": ca.abc_bytes,
-            **res, "image_bytes_per_email": ca.scratch_bytes(1), "r1cs_export_s": round(t_cs, 1), "steps": 3}
+            **res, "image_bytes_per_email": ca.scratch_bytes(1), "r1cs_export_s": round(t_cs, 1), "steps": 5}
         del d_in, ca, cs
         torch.cuda.empty_cache()
     except Exception as e:
@@ -654,15 +661,21 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         d_work = torch.empty(plan.work_bytes(E), dtype=torch.uint8, device=dev)
         d_out = torch.empty(E * 32 * (1 << L), dtype=torch.uint8, device=dev)
         run = lambda: plan.h_evaluations_device(d_abc.view(torch.uint8), 96 * m, m, E, d_work, d_out)
-        sec = timed(torch, run, steps=3, warmup=1) / 3
+        sec = timed(torch, run, steps=5, warmup=1) / 5
         n = 1 << L
         products = 6 * (n * L // 2 + 2 * n) + 4 * n
-        peak = 256 * 4 * 4 * 2.4e9 / 128
+        # measured on this chip (tools/mulbench.hip, profiles/r05/r05_b_mulbench.json): v_mad_u64_u32 issues 34.4 T lane-ops/s (14 lanes per
+        # cycle and SIMD, not the 4 that rounds 2-4 assumed): 128 per product bound 263 G products/s; the 8 x 32-bit CIOS the transforms
+        # run reaches 95 G/s in a pure product loop, a 9 x 29-bit Comba product 162 G/s
+        peak, cios_rate, comba_rate = 263.0e9, 95.1e9, 162.0e9
         out["prover stage 2: H evaluations (3 ifft + coset shift + 3 fft + a b - c), 2^20 domain"] = {
             "value": round(E / sec, 1), "unit": "emails/s", "montgomery_products_per_email": products,
             "products_per_s": round(E * products / sec), "issue_roofline_products_per_s": round(peak),
             "frac_of_issue_roofline": round(E * products / sec / peak, 4), "emails_per_call": E,
-            "note": "roofline = v_mad_u64_u32 issue: 128 per Montgomery product, 4 lanes per cycle and SIMD, 1,024 SIMDs at 2.4 GHz"}
+            "frac_of_measured_product_rate": round(E * products / sec / cios_rate, 4), "measured_product_rate_per_s": round(cios_rate),
+            "measured_comba_9x29_rate_per_s": round(comba_rate),
+            "note": "issue_roofline = 128 v_mad_u64_u32 per product at the MEASURED issue rate (tools/mulbench.hip); measured_product_rate = what "
+                    "the transform kernels' product (csrc/zkwg_fr.h, 8 x 32-bit CIOS) sustains in a pure product loop on this chip"}
         del d_abc, d_work, d_out, plan
         torch.cuda.empty_cache()
     except Exception as e:
@@ -685,16 +698,16 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
             _, d_in, _ = resident_inputs(torch, co, dev, 0x5A4B + 707, 64, bo, args.body_len if tag[1] >= args.body_len + 64 else 60)
             pl = Pipeline(torch, co, dev, d_in, bo, to, min(1024, bo), ring=2, rsa_throttle=args.rsa_throttle)
             co.set_timing(True)
-            dt = timed(torch, pl.step, steps=3, warmup=1)
+            dt = timed(torch, pl.step, steps=5, warmup=1)
             _, avg, nl, gbs = expand_roofline(co, to)
             co.set_timing(False)
             assert int(pl.d_status.abs().sum().item()) == 0
             kept_W = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=tag[0], max_body=tag[1], device=-1).W
             out[f"complete --O0 witnesses, EmailVerifier({tag[0]},{tag[1]})"] = {
-                "value": round(bo * 3 / dt, 1), "unit": "witnesses/s", "steps": 3, "witness_len": co.W, "witness_bytes": co.witness_bytes,
-                "raw_GBps_whole_job": round(bo * 3 * co.witness_bytes / dt / 1e9, 1), "raw_frac": round(bo * 3 * co.witness_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "value": round(bo * 5 / dt, 1), "unit": "witnesses/s", "steps": 5, "witness_len": co.W, "witness_bytes": co.witness_bytes,
+                "raw_GBps_whole_job": round(bo * 5 * co.witness_bytes / dt / 1e9, 1), "raw_frac": round(bo * 5 * co.witness_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "zk_expand_raw_GBps": round(gbs, 1),
-                "frac_on_W_alg": round(bo * 3 * (32 * kept_W) / dt / 1e9 / HBM_PEAK_GBS, 4), "W_alg": kept_W,
+                "frac_on_W_alg": round(bo * 5 * (32 * kept_W) / dt / 1e9 / HBM_PEAK_GBS, 4), "W_alg": kept_W,
                 "handle_create_s": round(t_create, 1),
                 "note": "one pass: row kernels + zk_expand3_o0 (per-wire descriptors); raw = the bytes actually written; frac_on_W_alg grades the same time on the kept-v1 (information-carrying) signals only (SURVEY.md 8d3)"}
             del pl, d_in, co
@@ -708,12 +721,12 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         d_in = resident_inputs_ragged(torch, c5, dev, 0x5A4B + 303, 16, 1024, 32768, 65536 - 72)
         pl = Pipeline(torch, c5, dev, d_in, 1024, tile5, 128, ring=2, prep_streams=1, rsa_throttle=args.rsa_throttle)
         c5.set_timing(True)
-        dt = timed(torch, pl.step, steps=2, warmup=1)
+        dt = timed(torch, pl.step, steps=5, warmup=1)
         _, avg, nl, gbs = expand_roofline(c5, tile5)
         c5.set_timing(False)
         assert int(pl.d_status.abs().sum().item()) == 0
         out["configs[4] maxBody=65536 batch=1024"] = {
-            "value": round(1024 * 2 / dt, 1), "unit": "witnesses/s", "steps": 2, "witness_len": c5.W,
+            "value": round(1024 * 5 / dt, 1), "unit": "witnesses/s", "steps": 5, "ring_placement": pl.placement, "witness_len": c5.W,
             "zk_expand_GBps": round(gbs, 1), "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4),
             "body_len": "16 distinct emails, body lengths spread over 32768 .. 65464 (parity of this configuration at batch 1,024 with every row checked: tests/test_configs_gpu.py)"}
         del pl, d_in, c5

@@ -420,6 +420,13 @@ int zkwg_ntt_transform_device(zkwg_ntt_t* plan, void* d_data, uint64_t n_polys, 
 int zkwg_h_evaluations_device(zkwg_ntt_t* plan, const void* d_abc, uint64_t abc_stride, uint64_t n_constraints, uint64_t n_emails,
                               void* d_work, void* d_out, uint64_t out_stride, void* hip_stream);
 
+/* Device buffers mapped from physical chunks (HIP virtual-memory API; chunk_bytes = 0: 1 GiB): the allocator for the output ring of
+ * zkwg_expand_device and any other large store target.  A buffer from hipMalloc may take zk_expand's stores 12-20 % slower than
+ * another of the same size (round 4); a buffer mapped chunk by chunk does not (tools/chunkbench.hip, profiles/r05/r05_e_chunkbench.txt)
+ * -- no spare candidates, no transient memory.  The pointer is an ordinary device pointer; free it with zkwg_device_free_chunked. */
+int zkwg_device_alloc_chunked(int device, uint64_t bytes, uint64_t chunk_bytes, void** out);
+int zkwg_device_free_chunked(void* ptr);
+
 /* ---- prover stage 3: the multi-exponentiations of groth16_prove.js (reference call site:
  * packages/helpers/src/chunked-zkey.ts:80-84, the second half of fullProve) -----------------------------------------------
  * pi_a, pib1, pi_c and resH are  sum_i scalar_i * base_i  over BN254 G1 with the zkey's bases (affine, x | y in Montgomery form,
@@ -445,6 +452,12 @@ int zkwg_msm_g1_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_mont
                        void* hip_stream);
 int zkwg_msm_g2_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_montgomery, int ones_apart, void* d_work, uint8_t* out_xy,
                        void* hip_stream);
+/* asynchronous form: the sum is left at d_out_xyzz as an accumulator in XYZZ coordinates (Montgomery form; 128 bytes for a G1 plan,
+ * 256 for a G2 plan) and nothing is synchronised -- the sums of several proofs can be in flight on several streams, which is what
+ * hides the serial tail of each.  zkwg_msm_finish_host: n downloaded accumulators -> n points as the zkey stores them. */
+int zkwg_msm_enqueue_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_montgomery, int ones_apart, void* d_work, void* d_out_xyzz,
+                            void* hip_stream);
+int zkwg_msm_finish_host(int group, const uint8_t* xyzz, uint64_t n, uint8_t* out_points);
 int zkwg_fixed_base_device(int device, int group, const void* d_scalars, uint64_t n, void* d_out, void* hip_stream);
 /* pi_a, pi_b, pi_c from the five sums of one proof and the key's alpha / beta / delta points (groth16_prove.js: pi_a = alpha1 + sum_a +
  * r delta1, pi_b = beta2 + sum_b2 + s delta2, pi_c = sum_c + sum_h + s pi_a + r (beta1 + sum_b1 + s delta1) - r s delta1).  Points in

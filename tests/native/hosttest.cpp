@@ -263,7 +263,18 @@ extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scal
   std::vector<u32> partial(1025);
   for (int phase = 0; phase < 2; ++phase) for (u32 t = 0; t < 1024; ++t) zk_msm_scan_thread(A, t, 1024u, partial.data(), phase);
   for (u32 i : order) zk_msm_scatter_thread(A, i);
-  for (u32 b = 0; b < total; ++b) zk_msm_bucket_thread(A, b);
+  // the buckets' runs in slices (three levels), then one join per bucket -- as zk_msm_launch
+  std::vector<std::vector<u32>> soff(3, std::vector<u32>(total + 1, 0xdeadbeefu));
+  std::vector<std::vector<G1Xyzz>> part(3);
+  {
+    u64 items = (u64)n * A.K;
+    for (int l = 0; l < 3; ++l) { const u64 cap = items / zk_msm_slice_size(l) + total + 1; A.cap[l] = (u32)cap; part[l].resize(cap); A.soff[l] = soff[l].data(); A.part[l] = part[l].data(); items = cap; }
+  }
+  for (int level = 0; level < 3; ++level) {
+    for (int phase = 0; phase < 2; ++phase) for (u32 t = 0; t < 1024; ++t) zk_msm_slice_scan_thread(A, level, t, 1024u, partial.data(), phase);
+    for (u32 t = 0; t < A.cap[level]; ++t) zk_msm_slice_sum_thread(A, level, t);
+  }
+  for (u32 b = 0; b < total; ++b) zk_msm_bucket_join_thread(A, b);
   const G1Xyzz* in_s = A.bucket; const G1Xyzz* in_a = nullptr;
   u32 n_in = A.nb, span = 1, flip = 0;
   for (;;) {

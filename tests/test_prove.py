@@ -110,6 +110,7 @@ def _prove_case(N, M, records_of, n_emails=2):
     assert d_status.tolist() == [0] * n_emails
     vk = G.vkey_json(key)
     rng = random.Random(N)
+    singles = []
     for e in range(n_emails):
         r, s = rng.randrange(R), rng.randrange(R)
         proof = pv.prove_prepared(d_in, n_emails, d_scratch, e, r, s)
@@ -127,6 +128,10 @@ def _prove_case(N, M, records_of, n_emails=2):
             bad = list(pub)
             bad[2] = str((int(bad[2]) + 1) % R)
             assert not P.groth16_verify(vk, bad, pj)
+        singles.append((r, s, proof))
+    # the same proofs with several in flight (one stream per proof, nothing synchronised in between)
+    batch = pv.prove_batch(d_in, n_emails, d_scratch, list(range(n_emails)) * 2, [(r, s) for r, s, _ in singles] * 2, slots=3)
+    assert batch == [p for _, _, p in singles] * 2
 
 
 @pytest.mark.gpu

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rate of prover stage 2 (zkwg_h_evaluations_device): 3 inverse + 3 forward transforms on the 2^20
 domain of EmailVerifier(576,192)'s constraint system and a b - c, for a batch of emails, against the multiplier-issue roofline
-(a Montgomery product = 128 v_mad_u64_u32; 256 CUs x 4 SIMDs x 4 lanes per cycle at 2.4 GHz = 76.8 G products/s)."""
+(a Montgomery product = 128 v_mad_u64_u32 at the issue rate tools/mulbench.hip MEASURED on gfx950 -- 34.4 T lane-ops/s, i.e.
+263 G products/s; rounds 2-4 assumed a quarter-rate multiplier, 76.8 G: profiles/r05/r05_b_mulbench.json)."""
 import argparse
 import json
 import os
@@ -43,7 +44,7 @@ def main():
     passes = (L - g_row + 7) // 8
     per_transform = n * L // 2 + passes * n
     products = 6 * per_transform + 3 * n + n
-    peak = 256 * 4 * 4 * 2.4e9 / 128
+    peak = 263.0e9      # measured v_mad_u64_u32 issue rate / 128 (tools/mulbench.hip); the CIOS product itself sustains 95 G/s in a pure loop
     print(json.dumps({"stage": "H evaluations (3 ifft, coset shift, 3 fft, a b - c)", "log2_domain": L, "constraints": m, "emails": E,
                       "emails_per_s": round(E / sec, 1), "ms_per_email": round(sec / E * 1e3, 3),
                       "montgomery_products_per_email": products, "products_per_s": round(E * products / sec),

@@ -11,8 +11,14 @@ template <class C> __global__ __launch_bounds__(1024) void zk_msm_scan(ZkMsmArgs
   zk_msm_scan_thread(A, threadIdx.x, 1024u, partial, 1);
 }
 template <class C> __global__ __launch_bounds__(256) void zk_msm_scatter(ZkMsmArgsT<C> A) { zk_msm_scatter_thread(A, blockIdx.x * 256u + threadIdx.x); }
-// 64-thread workgroups so that neighbouring buckets -- runs of similar length -- share a wavefront
-template <class C> __global__ __launch_bounds__(64) void zk_msm_buckets(ZkMsmArgsT<C> A) { zk_msm_bucket_thread(A, blockIdx.x * 64u + threadIdx.x); }
+template <class C> __global__ __launch_bounds__(1024) void zk_msm_slice_scan(ZkMsmArgsT<C> A, int level) {
+  __shared__ u32 partial[1025];
+  zk_msm_slice_scan_thread(A, level, threadIdx.x, 1024u, partial, 0);
+  __syncthreads();
+  zk_msm_slice_scan_thread(A, level, threadIdx.x, 1024u, partial, 1);
+}
+template <class C> __global__ __launch_bounds__(64) void zk_msm_slice_sum(ZkMsmArgsT<C> A, int level) { zk_msm_slice_sum_thread(A, level, blockIdx.x * 64u + threadIdx.x); }
+template <class C> __global__ __launch_bounds__(64) void zk_msm_bucket_join(ZkMsmArgsT<C> A) { zk_msm_bucket_join_thread(A, blockIdx.x * 64u + threadIdx.x); }
 template <class C> __global__ __launch_bounds__(64) void zk_msm_reduce(ZkMsmArgsT<C> A, const typename C::Xyzz* in_s, const typename C::Xyzz* in_a, u32 n_in, u32 span,
                                                                         typename C::Xyzz* out_s, typename C::Xyzz* out_a) {
   zk_msm_reduce_thread(A, blockIdx.x * 64u + threadIdx.x, in_s, in_a, n_in, span, out_s, out_a);
@@ -32,7 +38,11 @@ static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
   hipLaunchKernelGGL(zk_msm_count<C>, dim3((A.n + 255) / 256), dim3(256), 0, st, A);
   hipLaunchKernelGGL(zk_msm_scan<C>, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(zk_msm_scatter<C>, dim3((A.n + 255) / 256), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(zk_msm_buckets<C>, dim3((total + 63) / 64), dim3(64), 0, st, A);
+  for (int level = 0; level < 3; ++level) {
+    hipLaunchKernelGGL(zk_msm_slice_scan<C>, dim3(1), dim3(1024), 0, st, A, level);
+    hipLaunchKernelGGL(zk_msm_slice_sum<C>, dim3((A.cap[level] + 63) / 64), dim3(64), 0, st, A, level);
+  }
+  hipLaunchKernelGGL(zk_msm_bucket_join<C>, dim3((total + 63) / 64), dim3(64), 0, st, A);
   const X* in_s = A.bucket; const X* in_a = nullptr;
   u32 n_in = A.nb, span = 1, half = A.K * ((A.nb + 31) / 32), flip = 0;
   for (;;) {

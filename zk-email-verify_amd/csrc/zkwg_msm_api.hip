@@ -20,7 +20,7 @@ struct zkwg_msm {
   void* d_bases;
   bool owns;        // false: the bases are the caller's device memory (zkwg_msm_create_device)
 };
-struct ZkMsmWork { u64 count, cursor, entry, bucket, node_s, node_a, window, out, ones, total; };
+struct ZkMsmWork { u64 count, cursor, entry, bucket, node_s, node_a, window, out, ones, soff[3], part[3], total; u32 cap[3]; };
 static ZkMsmWork msm_work(const zkwg_msm* p) {
   ZkMsmWork W;
   auto al = [](u64 x) { return (x + 255) & ~255ull; };
@@ -36,6 +36,14 @@ static ZkMsmWork msm_work(const zkwg_msm* p) {
   W.window = off; off += al((u64)p->K * xs);
   W.out = off; off += al(xs);
   W.ones = off; off += al(2 * ((p->n + 63) / 64) * xs);
+  u64 items = p->n * p->K;                       // entries: at most one per (scalar, window)
+  for (int l = 0; l < 3; ++l) {
+    const u64 cap = items / zk_msm_slice_size(l) + total + 1;     // sum_b ceil(len_b / S) <= items / S + buckets
+    W.cap[l] = (u32)cap;
+    W.soff[l] = off; off += al((total + 1) * 4);
+    W.part[l] = off; off += al(cap * xs);
+    items = cap;
+  }
   W.total = off;
   return W;
 }
@@ -66,6 +74,7 @@ static void msm_args(const zkwg_msm* p, const void* d_scalars, int mont, int one
   A.scalars_mont = mont ? 1u : 0u; A.ones_apart = ones_apart ? 1u : 0u; A.ones = (X*)(w + W.ones);
   A.count = (u32*)(w + W.count); A.cursor = (u32*)(w + W.cursor); A.entry = (u32*)(w + W.entry); A.bucket = (X*)(w + W.bucket);
   A.node_s = (X*)(w + W.node_s); A.node_a = (X*)(w + W.node_a); A.window = (X*)(w + W.window); A.out = (X*)(w + W.out);
+  for (int l = 0; l < 3; ++l) { A.soff[l] = (u32*)(w + W.soff[l]); A.part[l] = (X*)(w + W.part[l]); A.cap[l] = W.cap[l]; }
 }
 
 extern "C" {
@@ -112,6 +121,36 @@ int zkwg_msm_g2_device(zkwg_msm_t* p, const void* d_scalars, int scalars_montgom
   if (hipGetLastError() != hipSuccess) return ZKWG_RC_HIP_ERROR;
   const G2Affine a = g2_to_affine(r);
   memcpy(out_xy, &a, 128);
+  return ZKWG_RC_OK;
+}
+
+// The same sums without a host round trip per sum: the accumulator (XYZZ coordinates, Montgomery form: 128 bytes for G1, 256 for G2)
+// is left at d_out_xyzz and nothing is synchronised, so the sums of several proofs can be in flight on several streams -- a
+// multi-exponentiation ends in a few hundred dependent group operations on a handful of lanes (the bucket tree, the Horner pass over
+// the windows), which only other proofs' work can hide.  zkwg_msm_finish_host turns downloaded accumulators into the zkey's point form.
+int zkwg_msm_enqueue_device(zkwg_msm_t* p, const void* d_scalars, int scalars_montgomery, int ones_apart, void* d_work, void* d_out_xyzz, void* hip_stream) {
+  if (!p || !d_scalars || !d_work || !d_out_xyzz || ((uintptr_t)d_work & 255) || ((uintptr_t)d_scalars & 15) || ((uintptr_t)d_out_xyzz & 15)) return ZKWG_RC_BAD_ARG;
+  if (hipSetDevice(p->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (p->group == 1) {
+    ZkMsmArgs A;
+    msm_args<ZkCurveG1>(p, d_scalars, scalars_montgomery, ones_apart, d_work, A);
+    A.out = (G1Xyzz*)d_out_xyzz;
+    zk_msm_launch(A, st);
+  } else {
+    ZkMsmArgsT<ZkCurveG2> A;
+    msm_args<ZkCurveG2>(p, d_scalars, scalars_montgomery, ones_apart, d_work, A);
+    A.out = (G2Xyzz*)d_out_xyzz;
+    zk_msm_launch_g2(A, st);
+  }
+  return hipGetLastError() == hipSuccess ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
+}
+int zkwg_msm_finish_host(int group, const uint8_t* xyzz, uint64_t n, uint8_t* out_points) {
+  if (!xyzz || !out_points || (group != 1 && group != 2)) return ZKWG_RC_BAD_ARG;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (group == 1) { G1Xyzz r; memcpy(&r, xyzz + i * sizeof(r), sizeof(r)); const G1Affine a = g1_to_affine(r); memcpy(out_points + 64 * i, &a, 64); }
+    else { G2Xyzz r; memcpy(&r, xyzz + i * sizeof(r), sizeof(r)); const G2Affine a = g2_to_affine(r); memcpy(out_points + 128 * i, &a, 128); }
+  }
   return ZKWG_RC_OK;
 }
 

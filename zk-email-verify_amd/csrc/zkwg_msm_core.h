@@ -52,6 +52,14 @@ struct ZkMsmArgsT {
   u32* cursor;                // [K * nb] running write positions of zk_msm_scatter
   u32* entry;                 // [n * K] base index | sign << 31, grouped by bucket
   G1Xyzz* bucket;             // [K * nb]
+  // a bucket's run of entries is summed in SLICES, by several threads: witness scalars are bits, bytes and a few field elements, so a
+  // handful of buckets (the common byte values) receive thousands of entries while most receive none; one thread per bucket took 58 ms
+  // for a 736 k-wire witness against 16 ms for 2^20 random scalars (profiles/r05/r05_d_bench_prove.json).  Level 0: slices of
+  // ZK_MSM_S0 entries (mixed additions of bases); levels 1, 2: slices of ZK_MSM_S1 partial sums of the level below; then one thread per
+  // bucket joins what is left (one item unless the bucket held more than S0 S1 S1 entries).
+  u32* soff[3];               // [K * nb + 1] per level: first slice of every bucket
+  G1Xyzz* part[3];            // per level: the slices' sums
+  u32 cap[3];                 // slices a level can hold (n K / S + K nb bounds it)
   G1Xyzz* node_s; G1Xyzz* node_a;   // reduction tree scratch: [K * nb / 32 * 2] each (ping-pong halves)
   G1Xyzz* window;             // [K] weighted bucket sums
   G1Xyzz* out;                // [1]
@@ -175,6 +183,65 @@ ZK_HD void zk_msm_combine_thread(const ZkMsmArgsT<C>& A) {
   }
   if (A.ones_apart) total = C::add(total, A.ones[0]);
   A.out[0] = total;
+}
+#define ZK_MSM_S0 64u
+#define ZK_MSM_S1 32u
+ZK_HD u32 zk_msm_slice_size(int level) { return level == 0 ? ZK_MSM_S0 : ZK_MSM_S1; }
+// slices of `level`: the items of bucket b are [in[b], in[b + 1]) -- entries for level 0 (in = A.count), the slices of the level below
+// otherwise; out[b] = first slice of bucket b, out[total] = number of slices.  One workgroup, two phases around a barrier (as zk_msm_scan).
+template <class C>
+ZK_HD void zk_msm_slice_scan_thread(const ZkMsmArgsT<C>& A, int level, u32 t, u32 threads, u32* partial, int phase) {
+  const u32* in = level == 0 ? A.count : A.soff[level - 1];
+  u32* out = A.soff[level];
+  const u32 S = zk_msm_slice_size(level);
+  const u32 total = A.K * A.nb, per = (total + threads - 1) / threads;
+  const u32 lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
+  if (phase == 0) {
+    u32 s = 0;
+    for (u32 k = lo; k < hi; ++k) s += (in[k + 1] - in[k] + S - 1u) / S;
+    partial[t + 1] = s;
+    if (t == 0) partial[0] = 0;
+    return;
+  }
+  u32 base = 0;
+  for (u32 k = 0; k <= t; ++k) base += partial[k];
+  for (u32 k = lo; k < hi; ++k) { out[k] = base; base += (in[k + 1] - in[k] + S - 1u) / S; }
+  if (hi == total && lo < total) out[total] = base;
+  if (total == 0 && t == 0) out[0] = 0;
+}
+// slice t of `level` (nothing beyond the level's slice count or capacity: the capacity is a proven bound)
+template <class C>
+ZK_HD void zk_msm_slice_sum_thread(const ZkMsmArgsT<C>& A, int level, u32 t) {
+  const u32 total = A.K * A.nb;
+  const u32* off = A.soff[level];
+  if (t >= off[total] || t >= A.cap[level]) return;
+  // the bucket whose slices contain t: the last b with off[b] <= t
+  u32 lo = 0, hi = total;
+  while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
+  const u32 b = lo, j = t - off[b], S = zk_msm_slice_size(level);
+  const u32* in = level == 0 ? A.count : A.soff[level - 1];
+  const u32 first = in[b] + j * S, last = first + S < in[b + 1] ? first + S : in[b + 1];
+  typename C::Xyzz acc = C::inf();
+  if (level == 0) {
+    for (u32 k = first; k < last; ++k) {
+      const u32 v = A.entry[k];
+      typename C::Affine p = A.bases[v & 0x7fffffffu];
+      if (v >> 31) p = C::neg(p);
+      acc = C::add_mixed(acc, p);
+    }
+  } else {
+    const typename C::Xyzz* items = A.part[level - 1];
+    for (u32 k = first; k < last; ++k) acc = C::add(acc, items[k]);
+  }
+  A.part[level][t] = acc;
+}
+// bucket b = the sum of its slices of the last level
+template <class C>
+ZK_HD void zk_msm_bucket_join_thread(const ZkMsmArgsT<C>& A, u32 b) {
+  if (b >= A.K * A.nb) return;
+  typename C::Xyzz acc = C::inf();
+  for (u32 k = A.soff[2][b], e = A.soff[2][b + 1]; k < e; ++k) acc = C::add(acc, A.part[2][k]);
+  A.bucket[b] = acc;
 }
 // (G1 by name: the host mirror of the CPU tests)
 ZK_HD void zk_msm_tree_thread(const G1Xyzz* in, u32 n_in, G1Xyzz* out, u32 t) { zk_msm_tree_thread_c<ZkCurveG1>(in, n_in, out, t); }

@@ -54,6 +54,11 @@ class _DeviceMsm:
     def work_bytes(self):
         return self.lib.zkwg_msm_work_bytes(self.h)
 
+    def enqueue(self, scalars_ptr, montgomery, ones_apart, d_work, out_ptr, stream=None):
+        """asynchronous: the sum's accumulator (XYZZ, 128 / 256 bytes) is left at out_ptr on the device"""
+        _check(self.lib.zkwg_msm_enqueue_device(self.h, scalars_ptr, 1 if montgomery else 0, 1 if ones_apart else 0, d_work.data_ptr(), out_ptr,
+                                                _stream_ptr(stream)))
+
     def run(self, scalars_ptr, montgomery, ones_apart, d_work, stream=None):
         """-> the sum as the zkey would store it (bytes: 64 / 128, affine Montgomery form, zeros = infinity)"""
         out = (C.c_uint8 * (64 if self.group == 1 else 128))()
@@ -140,6 +145,62 @@ class Prover:
                                               int(r % R).to_bytes(32, "little"), int(s % R).to_bytes(32, "little"), pa, pb, pc))
         i = lambda b, j: int.from_bytes(bytes(b)[32 * j:32 * j + 32], "little")
         return {"pi_a": (i(pa, 0), i(pa, 1)), "pi_b": ((i(pb, 0), i(pb, 1)), (i(pb, 2), i(pb, 3))), "pi_c": (i(pc, 0), i(pc, 1))}
+
+    # ---- several proofs in flight -------------------------------------------------------------------------------------------
+    # A multi-exponentiation ends in a few hundred dependent group operations on a handful of lanes (bucket tree, Horner over the
+    # windows): a proof at a time leaves the chip idle most of the time.  `slots` proofs run on `slots` streams, each with its own
+    # witness / A.w|B.w|C.w / H / work buffers; nothing synchronises until all of a wave are enqueued.
+    def _slot(self, j):
+        import torch
+        if not hasattr(self, "_slots"):
+            self._slots = []
+        while len(self._slots) <= j:
+            c, k = self.c, self.key
+            new = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            work = new(self.d_msm_work.numel() + 256)
+            self._slots.append({"wit": new(c.witness_bytes), "abc": new(c.abc_bytes), "h": new(32 << k.power), "ntt": new(self.ntt.work_bytes(1)),
+                                "work": work[(-work.data_ptr()) % 256:], "sums": torch.zeros(5 * 256, dtype=torch.uint8, device=self.dev),
+                                "stream": torch.cuda.Stream(device=self.dev)})
+        return self._slots[j]
+
+    def prove_batch(self, d_in, n, d_scratch, indices, blinding, slots=8):
+        """proofs of the emails `indices` of a prepared batch; blinding = [(r, s)] per email -> list of proof dicts (prove_prepared's form)"""
+        import torch
+        c, k = self.c, self.key
+        out = []
+        cur = torch.cuda.current_stream(self.dev)
+        for w0 in range(0, len(indices), slots):
+            wave = list(range(w0, min(w0 + slots, len(indices))))
+            for j, q in enumerate(wave):
+                S = self._slot(j)
+                st = S["stream"]
+                st.wait_stream(cur)
+                e = indices[q]
+                c.expand_device(d_in, n, d_scratch, e, 1, S["wit"], st)
+                c.expand_abc_device(d_in, n, d_scratch, e, 1, S["abc"], st, montgomery=True)
+                self.ntt.h_evaluations_device(S["abc"], c.abc_bytes, self.m, 1, S["ntt"], S["h"], stream=st)
+                wit, sums = S["wit"].data_ptr(), S["sums"].data_ptr()
+                self.msm_a.enqueue(wit, False, True, S["work"], sums, st)
+                self.msm_b1.enqueue(wit, False, True, S["work"], sums + 256, st)
+                self.msm_b2.enqueue(wit, False, True, S["work"], sums + 512, st)
+                self.msm_c.enqueue(wit + 32 * (k.n_public + 1), False, True, S["work"], sums + 768, st)
+                self.msm_h.enqueue(S["h"].data_ptr(), True, False, S["work"], sums + 1024, st)
+            for j, q in enumerate(wave):
+                S = self._slot(j)
+                S["stream"].synchronize()
+                raw = bytes(S["sums"].cpu().numpy())
+                pts = {}
+                for name, off, group in (("a", 0, 1), ("b1", 256, 1), ("b2", 512, 2), ("c", 768, 1), ("h", 1024, 1)):
+                    o = (C.c_uint8 * (64 if group == 1 else 128))()
+                    _check(self.lib.zkwg_msm_finish_host(group, raw[off:off + (128 if group == 1 else 256)], 1, o))
+                    pts[name] = bytes(o)
+                r, s_ = blinding[q]
+                pa, pb, pc = (C.c_uint8 * 64)(), (C.c_uint8 * 128)(), (C.c_uint8 * 64)()
+                _check(self.lib.zkwg_groth16_assemble(pts["a"], pts["b1"], pts["b2"], pts["c"], pts["h"], k.alpha1, k.beta1, k.beta2, k.delta1, k.delta2,
+                                                      int(r % R).to_bytes(32, "little"), int(s_ % R).to_bytes(32, "little"), pa, pb, pc))
+                i = lambda b, jj: int.from_bytes(bytes(b)[32 * jj:32 * jj + 32], "little")
+                out.append({"pi_a": (i(pa, 0), i(pa, 1)), "pi_b": ((i(pb, 0), i(pb, 1)), (i(pb, 2), i(pb, 3))), "pi_c": (i(pc, 0), i(pc, 1))})
+        return out
 
     @staticmethod
     def proof_json(p):
