@@ -149,3 +149,24 @@ def test_gpu_proof_of_the_reference_test_eml_verifies_under_the_pinned_verifier(
     def records(c, n):
         return c.pack(real_email.ev_inputs("test_eml", 640, 768)) * n
     _prove_case(640, 768, records, n_emails=1)
+
+
+def test_zkey_round_trip():
+    """zkwg.zkey: a groth16 .zkey written section by section reads back field by field (layout restated from snarkjs [EXT]; the day
+    a real file exists it goes through the same reader)"""
+    from zkwg import zkey
+    rng = random.Random(2)
+    n_vars, n_public, domain = 12, 3, 16
+    blob = lambda n: bytes(rng.randrange(256) for _ in range(n))
+    pts = {"alpha1": blob(64), "beta1": blob(64), "beta2": blob(128), "gamma2": blob(128), "delta1": blob(64), "delta2": blob(128)}
+    sec = {"ic": blob(64 * 4), "a": blob(64 * 12), "b1": blob(64 * 12), "b2": blob(128 * 12), "c": blob(64 * 8), "h": blob(64 * 16)}
+    coeffs = [(0, 0, 1, 5), (1, 0, 2, R - 1), (0, 9, 0, 1), (0, 10, 1, 1)]
+    data = zkey.write_zkey(n_vars, n_public, domain, pts, sec["ic"], sec["a"], sec["b1"], sec["b2"], sec["c"], sec["h"], coeffs)
+    z = zkey.read_zkey(data)
+    assert (z["n_vars"], z["n_public"], z["domain_size"], z["power"]) == (12, 3, 16, 4)
+    assert all(z[k] == v for k, v in pts.items()) and all(z[k] == v for k, v in sec.items())
+    assert z["coeffs"] == coeffs
+    with pytest.raises(ValueError):
+        zkey.read_zkey(b"zkex" + data[4:])
+    with pytest.raises(ValueError):
+        zkey.read_zkey(data[:-70])          # the last sections cut off

@@ -31,6 +31,8 @@
 #define ZK_POS_RING 64
 #define ZK_EV_RING 512   // launches whose HIP events are kept for zkwg_timing_summary
 
+struct zkwg_circuit;
+static void rp_free_ring(zkwg_circuit* c);   // the resident pipeline's output ring: chunk-mapped (zkwg_vmm.hip) or plain
 struct zkwg_circuit {
   zkwg_config cfg;
   ZkSched s;
@@ -116,7 +118,8 @@ struct zkwg_circuit {
   int* rp_status = nullptr; u64 rp_n_cap = 0;
   hipStream_t rp_exp = nullptr;
   hipEvent_t rp_prep_done[2] = {nullptr, nullptr}, rp_exp_done[2] = {nullptr, nullptr};
-  float rp_place_ms[8] = {0}; int rp_place_n = 0, rp_place_kept[2] = {-1, -1};
+  float rp_place_ms[8] = {0}; int rp_place_n = 0, rp_place_kept[2] = {-1, -1};   // (round 4's candidate timings: unused since the ring is chunked)
+  bool rp_chunked = false;     // the ring's tiles come from zkwg_device_alloc_chunked
 };
 
 // inverse table: entry (d + half) holds d^{-1} mod r in standard form, d in [-half, half]
@@ -654,7 +657,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
     hipFree(c->d_net_cclass); hipFree(c->d_net_cdelta); hipFree(c->d_net_cmask);
     hipFree(c->d_net_bclass); hipFree(c->d_net_bdelta); hipFree(c->d_net_bmask);
     hipFree(c->hb_in); hipFree(c->hb_out[0]); hipFree(c->hb_out[1]); hipFree(c->hb_scr); hipFree(c->hb_status[0]); hipFree(c->hb_status[1]);
-    hipFree(c->rp_in); hipFree(c->rp_scr[0]); hipFree(c->rp_scr[1]); hipFree(c->rp_out[0]); hipFree(c->rp_out[1]); hipFree(c->rp_status);
+    hipFree(c->rp_in); hipFree(c->rp_scr[0]); hipFree(c->rp_scr[1]); rp_free_ring(c); hipFree(c->rp_status);
     if (c->rp_exp) hipStreamDestroy(c->rp_exp);
     for (int i = 0; i < 2; ++i) { if (c->rp_prep_done[i]) hipEventDestroy(c->rp_prep_done[i]); if (c->rp_exp_done[i]) hipEventDestroy(c->rp_exp_done[i]); }
     for (int i = 0; i < 2; ++i) { hipEventDestroy(c->hb_done[i]); hipEventDestroy(c->hb_copied[i]); if (c->hx_img[i]) hipHostFree(c->hx_img[i]); }
@@ -817,6 +820,13 @@ int zkwg_timing_summary(zkwg_circuit_t* c, int which, float* total_ms, uint32_t*
   return ZKWG_RC_OK;
 }
 
+static void rp_free_ring(zkwg_circuit* c) {
+  for (int k = 0; k < 2; ++k) {
+    if (!c->rp_out[k]) continue;
+    if (c->rp_chunked) zkwg_device_free_chunked(c->rp_out[k]); else hipFree(c->rp_out[k]);
+    c->rp_out[k] = nullptr;
+  }
+}
 static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n, void* d_scratch) {
   const ZkSched& s = c->s;
   u8* scr = (u8*)d_scratch;
@@ -1562,7 +1572,7 @@ static int calculate_batch_resident_impl(zkwg_circuit_t* c, const uint8_t* packe
   if (hipMemcpyAsync(c->rp_in, packed, n * in_stride, hipMemcpyHostToDevice, P) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   const u64 tile_bytes = tile * wbytes;
   bool place = c->rp_tile_bytes < tile_bytes;      // (a larger tile: the ring is allocated again, and placed again)
-  if (place) { hipFree(c->rp_out[0]); hipFree(c->rp_out[1]); c->rp_out[0] = c->rp_out[1] = nullptr; c->rp_tile_bytes = 0; }
+  if (place) { rp_free_ring(c); c->rp_tile_bytes = 0; }
   int rc = ZKWG_RC_OK;
   u64 ring = 0;
   const u64 nsub = (n + prep - 1) / prep;
@@ -1575,42 +1585,21 @@ static int calculate_batch_resident_impl(zkwg_circuit_t* c, const uint8_t* packe
     hipEventRecord(c->rp_prep_done[b], P);
     hipStreamWaitEvent(E, c->rp_prep_done[b], 0);
     if (place) {
-      // once per handle (and tile size): spare candidate tiles, the first tile's real expansion timed into each, the two
-      // fastest kept (zkwg.placement / DESIGN.md section 5)
+      // once per handle (and tile size): the two tiles of the output ring, mapped from 1 GiB physical chunks (zkwg_vmm.hip) -- every such
+      // buffer takes zk_expand's stores at the rate only the best of round 4's hipMalloc candidates reached (profiles/r05/r05_f_*), with no
+      // spare candidates and no transient memory.  ZKWG_PLACE_RING=0: two plain hipMalloc buffers.
       place = false;
-      const bool want = !(getenv("ZKWG_PLACE_RING") && atoi(getenv("ZKWG_PLACE_RING")) == 0);
-      hipMemGetInfo(&free_b, &total_b);
-      const u64 reserve = 8ull << 30;
-      int ncand = want ? (int)std::min<u64>(7, free_b > reserve ? (free_b - reserve) / tile_bytes : 0) : 2;
-      ncand = std::max(ncand, 2);
-      std::vector<u8*> cand;
-      for (int i = 0; i < ncand; ++i) { u8* p = nullptr; if (hipMalloc((void**)&p, tile_bytes) != hipSuccess) break; cand.push_back(p); }
-      if (cand.size() < 2) { for (u8* p : cand) hipFree(p); rc = ZKWG_RC_OOM; break; }
-      std::vector<float> ms(cand.size(), 0.f);
-      if (cand.size() > 2) {
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        const u64 k0 = std::min<u64>(tile, cnt);
-        for (size_t i = 0; i < cand.size() && rc == ZKWG_RC_OK; ++i) {
-          rc = zkwg_expand_device(c, c->rp_in + lo * in_stride, cnt, c->rp_scr[b], 0, k0, cand[i], wbytes, E);   // first touch
-          hipEventRecord(e0, E);
-          for (int r = 0; r < 2 && rc == ZKWG_RC_OK; ++r) rc = zkwg_expand_device(c, c->rp_in + lo * in_stride, cnt, c->rp_scr[b], 0, k0, cand[i], wbytes, E);
-          hipEventRecord(e1, E);
-          if (hipEventSynchronize(e1) != hipSuccess) rc = ZKWG_RC_HIP_ERROR;
-          hipEventElapsedTime(&ms[i], e0, e1);
-          ms[i] *= 0.5f;
-        }
-        hipEventDestroy(e0); hipEventDestroy(e1);
+      const bool chunked = !(getenv("ZKWG_PLACE_RING") && atoi(getenv("ZKWG_PLACE_RING")) == 0);
+      c->rp_chunked = chunked;
+      for (int k = 0; k < 2 && rc == ZKWG_RC_OK; ++k) {
+        void* p = nullptr;
+        if (chunked) rc = zkwg_device_alloc_chunked(c->device, tile_bytes, 0, &p);
+        else if (hipMalloc(&p, tile_bytes) != hipSuccess) rc = ZKWG_RC_OOM;
+        c->rp_out[k] = (u8*)p;
       }
-      std::vector<int> order(cand.size());
-      for (size_t i = 0; i < cand.size(); ++i) order[i] = (int)i;
-      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ms[x] < ms[y]; });
-      c->rp_place_n = (int)std::min<size_t>(cand.size(), 8);
-      for (int i = 0; i < c->rp_place_n; ++i) c->rp_place_ms[i] = ms[i];
-      for (int k = 0; k < 2; ++k) { c->rp_out[k] = cand[order[k]]; c->rp_place_kept[k] = order[k]; cand[order[k]] = nullptr; }
-      for (u8* p : cand) if (p) hipFree(p);
-      c->rp_tile_bytes = tile_bytes;
+      c->rp_place_n = 0;
       if (rc != ZKWG_RC_OK) break;
+      c->rp_tile_bytes = tile_bytes;
     }
     for (u64 first = 0; first < cnt && rc == ZKWG_RC_OK; first += tile, ++ring) {
       const u64 count = std::min<u64>(tile, cnt - first);

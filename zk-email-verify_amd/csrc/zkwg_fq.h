@@ -138,8 +138,18 @@ inline Fq fq_mont_mul_64(const Fq& a, const Fq& b) {
   return r;
 }
 #endif
+// the device's product since round 5: 9 x 29-bit product scanning (zkwg_comba29.h), 1.7 x the CIOS's rate
+ZK_HD Fq fq_mont_mul_comba(const Fq& a, const Fq& b) {
+  const ZkComba29P P{{0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu}, 0x04866389u};
+  const u64 p64[4] = {ZK_Q0, ZK_Q1, ZK_Q2, ZK_Q3};
+  Fq r;
+  zk_comba29_mul(a.l, b.l, P, p64, r.l);
+  return r;
+}
 ZK_HD Fq fq_mont_mul(const Fq& a, const Fq& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKWG_FR_CIOS32)
+  return fq_mont_mul_comba(a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
   return fq_mont_mul_32(a, b);
 #else
   return fq_mont_mul_64(a, b);

@@ -112,11 +112,21 @@ ZK_HD Fr fr_neg(const Fr& a) {
   return fr_sub_raw(fr_p(), a, bw);
 }
 
+#include "zkwg_comba29.h"
+// the device's product since round 5 (ZKWG_FR_CIOS32 brings the round 2-4 CIOS back for comparison)
+ZK_HD Fr fr_mont_mul_comba(const Fr& a, const Fr& b) {
+  const ZkComba29P P{{0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu}, 0x0fffffffu};
+  const u64 p64[4] = {ZK_P0, ZK_P1, ZK_P2, ZK_P3};
+  Fr r;
+  zk_comba29_mul(a.l, b.l, P, p64, r.l);
+  return r;
+}
 // Montgomery product a*b*R^{-1} mod r (CIOS).  Host: 4 x 64-bit limbs via __int128.  gfx950 has no
 // 64x64 multiplier: the device path runs the same algorithm on 8 x 32-bit limbs so that every
 // inner step is one v_mad_u64_u32 (32x32+64) plus one 64-bit add.
-ZK_HD Fr fr_mont_mul(const Fr& a, const Fr& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+// rounds 2-4: CIOS over 8 x 32-bit limbs (128 v_mad_u64_u32 + the carry handling: 562 instructions as compiled); kept for comparison
+// (tools/mulbench.hip) and behind ZKWG_FR_CIOS32
+ZK_HD Fr fr_mont_mul_cios32(const Fr& a, const Fr& b) {
   const u32 P32[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
   const u32 N0_32 = 0xefffffffu;  // -r^{-1} mod 2^32
   u32 A[8], Bv[8];
@@ -158,6 +168,12 @@ ZK_HD Fr fr_mont_mul(const Fr& a, const Fr& b) {
     r = fr_sub_raw(r, fr_p(), bw);
   }
   return r;
+}
+ZK_HD Fr fr_mont_mul(const Fr& a, const Fr& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKWG_FR_CIOS32)
+  return fr_mont_mul_comba(a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
+  return fr_mont_mul_cios32(a, b);
 #else
   const u64 p[4] = {ZK_P0, ZK_P1, ZK_P2, ZK_P3};
   u64 t[6] = {0, 0, 0, 0, 0, 0};

@@ -341,6 +341,8 @@ class Circuit:
         ms = (C.c_float * 8)()
         kept = (C.c_int * 2)()
         k = self.lib.zkwg_resident_placement(self.h, ms, 8, kept)
+        if k == 0:      # since round 5 the ring is mapped from 1 GiB physical chunks (zkwg_device_alloc_chunked): nothing to choose from
+            return {"mode": "chunked (ZKWG_PLACE_RING=0: plain allocations)", "chunk_bytes": 1 << 30}
         return {"ms_per_tile": [round(ms[i], 3) for i in range(k)], "kept": list(kept)}
 
     def scratch_bytes(self, n):

@@ -31,7 +31,11 @@ def read_zkey(data):
         raise ValueError(f".zkey version {version} is not supported")
     pos, sec = 12, {}
     for _ in range(nsec):
+        if pos + 12 > len(data):
+            raise ValueError(".zkey: truncated section table")
         sid, size = struct.unpack_from("<IQ", data, pos)
+        if pos + 12 + size > len(data):
+            raise ValueError(f".zkey: section {sid} runs past the end of the file")
         sec[sid] = (pos + 12, size)
         pos += 12 + size
     for need in (1, 2, 3, 5, 6, 7, 8, 9):
