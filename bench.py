@@ -71,8 +71,12 @@ class Pipeline:
             # takes zk_expand's stores at the rate only the best hipMalloc buffers reach -- no candidates, no transient memory
             from zkwg import placement
             ntl = min(2, self.ntiles)
-            self.d_out = [placement.chunked_tensor(torch, dev, tile * self.stride) for _ in range(ntl)]
-            self.placement = {"mode": "chunked", "chunk_bytes": 1 << 30, "tiles": ntl, "tile_bytes": tile * self.stride}
+            nch = (tile * self.stride + (1 << 30) - 1) >> 30
+            extra = min(nch // 2, 16)       # spare candidate chunks per tile: each takes a probe fill, the fastest are kept
+            self.d_out = [placement.chunked_tensor(torch, dev, tile * self.stride, extra=extra) for _ in range(ntl)]
+            rates = sorted(r for t in self.d_out for r in getattr(t._zkwg_owner, "rates", []))
+            self.placement = {"mode": "chunked", "chunk_bytes": 1 << 30, "tiles": ntl, "tile_bytes": tile * self.stride, "spare_chunks_per_tile": extra,
+                              "candidate_chunk_GBps": ({"min": rates[0], "median": rates[len(rates) // 2], "max": rates[-1], "n": len(rates)} if rates else None)}
         elif place:
             # round 4's way (--place-ring 1): spare candidate buffers from hipMalloc, the real expansion of one tile timed into each,
             # the fastest kept

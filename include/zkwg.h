@@ -425,6 +425,11 @@ int zkwg_h_evaluations_device(zkwg_ntt_t* plan, const void* d_abc, uint64_t abc_
  * another of the same size (round 4); a buffer mapped chunk by chunk does not (tools/chunkbench.hip, profiles/r05/r05_e_chunkbench.txt)
  * -- no spare candidates, no transient memory.  The pointer is an ordinary device pointer; free it with zkwg_device_free_chunked. */
 int zkwg_device_alloc_chunked(int device, uint64_t bytes, uint64_t chunk_bytes, void** out);
+/* the same with `extra` spare candidate chunks: every candidate takes a probe fill of zk_expand's store shape on a mapping of its own,
+ * the fastest are kept and mapped back to back, the others released (transient: `extra` chunks).  rates[0 .. *n_rates): GB/s of the
+ * candidates in creation order (rates may be NULL). */
+int zkwg_device_alloc_chunked_ex(int device, uint64_t bytes, uint64_t chunk_bytes, uint32_t extra, void** out, float* rates, uint32_t cap,
+                                 uint32_t* n_rates);
 int zkwg_device_free_chunked(void* ptr);
 
 /* ---- prover stage 3: the multi-exponentiations of groth16_prove.js (reference call site:

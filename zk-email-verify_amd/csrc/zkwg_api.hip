@@ -32,6 +32,7 @@
 #define ZK_EV_RING 512   // launches whose HIP events are kept for zkwg_timing_summary
 
 struct zkwg_circuit;
+extern "C" int zk_rows_copy_launch(const u8* src, u64 stride, u8* dst, u32 count, hipStream_t st);   // zkwg_kernels_handoff.hip
 static void rp_free_ring(zkwg_circuit* c);   // the resident pipeline's output ring: chunk-mapped (zkwg_vmm.hip) or plain
 struct zkwg_circuit {
   zkwg_config cfg;
@@ -1593,7 +1594,12 @@ static int calculate_batch_resident_impl(zkwg_circuit_t* c, const uint8_t* packe
       c->rp_chunked = chunked;
       for (int k = 0; k < 2 && rc == ZKWG_RC_OK; ++k) {
         void* p = nullptr;
-        if (chunked) rc = zkwg_device_alloc_chunked(c->device, tile_bytes, 0, &p);
+        if (chunked) {
+          // spare candidate chunks (half as many again, at most 16 GiB per tile): each takes a probe fill, the fastest are kept
+          const u32 nch = (u32)((tile_bytes + (1ull << 30) - 1) >> 30);
+          rc = zkwg_device_alloc_chunked_ex(c->device, tile_bytes, 0, std::min<u32>(nch / 2, 16u), &p, nullptr, 0, nullptr);
+          if (rc != ZKWG_RC_OK) rc = zkwg_device_alloc_chunked(c->device, tile_bytes, 0, &p);
+        }
         else if (hipMalloc(&p, tile_bytes) != hipSuccess) rc = ZKWG_RC_OOM;
         c->rp_out[k] = (u8*)p;
       }
@@ -1606,7 +1612,7 @@ static int calculate_batch_resident_impl(zkwg_circuit_t* c, const uint8_t* packe
       u8* o = c->rp_out[ring & 1];
       rc = zkwg_expand_device(c, c->rp_in + lo * in_stride, cnt, c->rp_scr[b], first, count, o, wbytes, E);
       if (rc != ZKWG_RC_OK) break;
-      if (d_rows && hipMemcpy2DAsync(d_rows + (lo + first) * 96, 96, o + 32, wbytes, 96, count, hipMemcpyDeviceToDevice, E) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; break; }
+      if (d_rows && zk_rows_copy_launch(o, wbytes, d_rows + (lo + first) * 96, (u32)count, E) != 0) { rc = ZKWG_RC_HIP_ERROR; break; }
       if (consumer) consumer(user, c->device, o, wbytes, lo + first, count, (void*)E);
     }
     hipEventRecord(c->rp_exp_done[b], E);

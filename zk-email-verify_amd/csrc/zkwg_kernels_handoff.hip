@@ -18,3 +18,18 @@ __global__ __launch_bounds__(256) void zk_mont_convert(Fr* __restrict__ v, u64 n
   }
   v[i] = x;
 }
+
+// the 96-byte result rows (w[1 .. 3] = pubkeyHash, shaHi, shaLo) of `count` witnesses `stride` bytes apart -> a packed table: the ring of
+// the resident pipeline is mapped chunk by chunk (zkwg_vmm.hip), and a strided hipMemcpy2DAsync out of such a range is not something
+// every runtime version accepts; a kernel reads it like any other device memory
+__global__ __launch_bounds__(256) void zk_rows_copy(const u8* __restrict__ src, u64 stride, u8* __restrict__ dst, u32 count) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= count * 6u) return;
+  const u32 e = i / 6u, q = i - e * 6u;
+  ((uint4*)(dst + (u64)e * 96u))[q] = ((const uint4*)(src + (u64)e * stride + 32u))[q];
+}
+extern "C" int zk_rows_copy_launch(const u8* src, u64 stride, u8* dst, u32 count, hipStream_t st) {
+  if (!count) return 0;
+  hipLaunchKernelGGL(zk_rows_copy, dim3((count * 6u + 255u) / 256u), dim3(256), 0, st, src, stride, dst, count);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

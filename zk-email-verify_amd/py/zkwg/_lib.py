@@ -145,6 +145,7 @@ def load():
         "zkwg_msm_group": (i32, [vp]),
         "zkwg_device_alloc_chunked": (i32, [i32, u64, u64, C.POINTER(vp)]),
         "zkwg_device_free_chunked": (i32, [vp]),
+        "zkwg_device_alloc_chunked_ex": (i32, [i32, u64, u64, u32, C.POINTER(vp), vp, u32, C.POINTER(u32)]),
         "zkwg_msm_enqueue_device": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "zkwg_msm_finish_host": (i32, [i32, vp, u64, vp]),
         "zkwg_fixed_base_device": (i32, [i32, i32, vp, u64, vp, vp]),
@@ -171,5 +172,5 @@ EXPORTS = [
     "zkwg_multi_circuit", "zkwg_calculate_batch_multi", "zkwg_calculate_batch_resident", "zkwg_resident_placement",
     "zkwg_ntt_create", "zkwg_ntt_destroy", "zkwg_ntt_domain", "zkwg_ntt_work_bytes", "zkwg_ntt_transform_device", "zkwg_h_evaluations_device",
     "zkwg_msm_create", "zkwg_msm_destroy", "zkwg_msm_work_bytes", "zkwg_msm_window_bits", "zkwg_msm_g1_device",
-    "zkwg_msm_g2_device", "zkwg_msm_create_g2", "zkwg_msm_create_device", "zkwg_msm_group", "zkwg_fixed_base_device", "zkwg_groth16_assemble", "zkwg_msm_enqueue_device", "zkwg_msm_finish_host", "zkwg_device_alloc_chunked", "zkwg_device_free_chunked",
+    "zkwg_msm_g2_device", "zkwg_msm_create_g2", "zkwg_msm_create_device", "zkwg_msm_group", "zkwg_fixed_base_device", "zkwg_groth16_assemble", "zkwg_msm_enqueue_device", "zkwg_msm_finish_host", "zkwg_device_alloc_chunked", "zkwg_device_free_chunked", "zkwg_device_alloc_chunked_ex",
 ]

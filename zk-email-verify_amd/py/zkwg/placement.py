@@ -49,11 +49,14 @@ def choose_tiles(torch, dev, tile_bytes, want, run, max_candidates=7, reserve_by
 class _Chunked:
     """owner of one zkwg_device_alloc_chunked buffer, exposed to torch through __cuda_array_interface__"""
 
-    def __init__(self, lib, device, nbytes, chunk_bytes=0):
+    def __init__(self, lib, device, nbytes, chunk_bytes=0, extra=0):
         import ctypes as C
         self.lib, self.nbytes = lib, nbytes
         p = C.c_void_p()
-        rc = lib.zkwg_device_alloc_chunked(device, nbytes, chunk_bytes, C.byref(p))
+        rates = (C.c_float * 512)()
+        nr = C.c_uint32(0)
+        rc = lib.zkwg_device_alloc_chunked_ex(device, nbytes, chunk_bytes, extra, C.byref(p), rates, 512, C.byref(nr))
+        self.rates = [round(rates[i], 0) for i in range(nr.value)]
         if rc != 0:
             raise RuntimeError(f"zkwg_device_alloc_chunked({nbytes}) failed: {lib.zkwg_strerror(rc).decode()}")
         self.ptr = p.value
@@ -65,11 +68,11 @@ class _Chunked:
             self.ptr = None
 
 
-def chunked_tensor(torch, dev, nbytes, chunk_bytes=0):
+def chunked_tensor(torch, dev, nbytes, chunk_bytes=0, extra=0):
     """a uint8 tensor of nbytes on `dev` mapped from physical chunks (include/zkwg.h zkwg_device_alloc_chunked): what the output
     ring is made of since round 5 -- every tile takes zk_expand's stores at the rate of round 4's best candidates, with no candidates"""
     from . import _lib
-    owner = _Chunked(_lib.load(), dev.index if dev.index is not None else 0, int(nbytes), chunk_bytes)
+    owner = _Chunked(_lib.load(), dev.index if dev.index is not None else 0, int(nbytes), chunk_bytes, extra)
     t = torch.as_tensor(owner, device=dev)
     t._zkwg_owner = owner          # the tensor keeps the mapping alive
     return t
