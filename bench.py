@@ -684,6 +684,22 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         torch.cuda.empty_cache()
     except Exception as e:
         out["prover stage 2: H evaluations"] = {"error": repr(e)[:200]}
+    # the whole device-side prover (SURVEY.md 8f4 "next"): witness -> A.w | B.w | C.w -> H evaluations -> the five
+    # multi-exponentiations -> pi_a, pi_b, pi_c, several proofs in flight (zkwg.prover; validity: tests/test_prove.py, pinned verifier)
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import bench_prove
+        r = bench_prove.main(["--emails", "8", "--slots", "16", "--proofs", "48"], quiet=True)
+        # Montgomery products behind the figure: per proof ~ (n H + ones of 3 G1 sums) x 10 + G2 x 28 per mixed addition + trees
+        out["prover stages 1-3: Groth16 proofs, EmailVerifier(576,192)"] = {
+            "value": r["proofs_per_s"], "unit": "proofs/s", "proofs_in_flight": r["proofs_in_flight"], "proofs_timed": r["proofs_timed"],
+            "one_at_a_time_ms_per_proof": r["one_at_a_time_ms_per_proof"], "stages_ms_alone": r["stages"], "W": r["W"], "domain_log2": r["domain_log2"],
+            "note": "bases = fixed-base multiples of random scalars (timing needs points, not a valid key); the field products run at the rate "
+                    "tools/mulbench.hip measures for csrc/zkwg_comba29.h (139 G/s in a pure loop); the sums are bound by their serial tails "
+                    "(bucket tree, Horner over the windows), which is why several proofs are kept in flight"}
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["prover stages 1-3: Groth16 proofs"] = {"error": repr(e)[:300]}
     # complete witnesses of the circuit compiled the way the reference documents (`circom --O0`,
     # docs/zk-email-docs/UsageGuide/README.md:59-64): every alias / constant / linear signal numbered, written in ONE pass
     # from the image (zkwg_circuit_create_full; artefacts = interpreter-generated .sym / .r1cs under artifacts/)
