@@ -247,7 +247,7 @@ extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scal
   for (uint64_t i = 0; i < n; ++i) { memcpy(&S[i], scalars + 4 * i, 32); if (mont) S[i] = fr_to_mont(S[i]); }
   ZkMsmArgs A;
   A.bases = P.data(); A.scalars = S.data(); A.n = (u32)n; A.c = c; A.K = zk_msm_windows(c); A.nb = 1u << (c - 1); A.scalars_mont = mont ? 1u : 0u;
-  const u32 total = A.K * A.nb, half = A.K * ((A.nb + 31) / 32);
+  const u32 total = A.K * A.nb, half = A.K * ((A.nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN);
   std::vector<u32> count(total + 1, 0), cursor(total, 0), entry((size_t)n * A.K + 1, 0xdeadbeefu);
   std::vector<G1Xyzz> bucket(total), ns(2 * (size_t)half + 1), na(2 * (size_t)half + 1), window(A.K), res(1);
   A.count = count.data(); A.cursor = cursor.data(); A.entry = entry.data(); A.bucket = bucket.data();
@@ -278,20 +278,20 @@ extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scal
   const G1Xyzz* in_s = A.bucket; const G1Xyzz* in_a = nullptr;
   u32 n_in = A.nb, span = 1, flip = 0;
   for (;;) {
-    const u32 n_out = (n_in + 31) / 32;
+    const u32 n_out = (n_in + ZK_MSM_FAN - 1) / ZK_MSM_FAN;
     G1Xyzz* out_s = A.node_s + (size_t)flip * half;
     G1Xyzz* out_a = A.node_a + (size_t)flip * half;
     for (u32 g = 0; g < A.K * n_out; ++g) zk_msm_reduce_thread(A, g, in_s, in_a, n_in, span, out_s, out_a);
     if (n_out == 1) break;
-    in_s = out_s; in_a = out_a; n_in = n_out; span *= 32; flip ^= 1;
+    in_s = out_s; in_a = out_a; n_in = n_out; span *= ZK_MSM_FAN; flip ^= 1;
   }
   if (A.ones_apart) {     // as zk_msm_launch does
     u32 m = half1, levels = 0;
-    for (u32 q = m; q > 1; q = (q + 63) / 64) ++levels;
+    for (u32 q = m; q > 1; q = (q + ZK_MSM_JOIN - 1) / ZK_MSM_JOIN) ++levels;
     G1Xyzz* cur = A.ones + ((levels & 1u) ? half1 : 0);
     { ZkMsmArgs B = A; B.ones = cur; for (u32 t = 0; t < half1; ++t) zk_msm_ones_thread(B, t); }
     while (m > 1) {
-      const u32 m2 = (m + 63) / 64;
+      const u32 m2 = (m + ZK_MSM_JOIN - 1) / ZK_MSM_JOIN;
       G1Xyzz* nxt = cur == A.ones ? A.ones + half1 : A.ones;
       for (u32 t = 0; t < m2; ++t) zk_msm_tree_thread(cur, m, nxt, t);
       cur = nxt; m = m2;

@@ -44,27 +44,27 @@ static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
   }
   hipLaunchKernelGGL(zk_msm_bucket_join<C>, dim3((total + 63) / 64), dim3(64), 0, st, A);
   const X* in_s = A.bucket; const X* in_a = nullptr;
-  u32 n_in = A.nb, span = 1, half = A.K * ((A.nb + 31) / 32), flip = 0;
+  u32 n_in = A.nb, span = 1, half = A.K * ((A.nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN), flip = 0;
   for (;;) {
-    const u32 n_out = (n_in + 31) / 32;
+    const u32 n_out = (n_in + ZK_MSM_FAN - 1) / ZK_MSM_FAN;
     X* out_s = A.node_s + (size_t)flip * half;
     X* out_a = A.node_a + (size_t)flip * half;
     hipLaunchKernelGGL(zk_msm_reduce<C>, dim3((A.K * n_out + 63) / 64), dim3(64), 0, st, A, in_s, in_a, n_in, span, out_s, out_a);
     if (n_out == 1) break;
-    in_s = out_s; in_a = out_a; n_in = n_out; span *= 32; flip ^= 1;
+    in_s = out_s; in_a = out_a; n_in = n_out; span *= ZK_MSM_FAN; flip ^= 1;
   }
   if (A.ones_apart) {
-    // the sum of the bases with scalar 1: 64 per thread, then 64-way joins; the halves of A.ones alternate and the last join lands in ones[0]
+    // the sum of the bases with scalar 1: 64 per thread, then ZK_MSM_JOIN-way joins; the halves of A.ones alternate and the last join lands in ones[0]
     const u32 half1 = (A.n + 63) / 64;
     u32 m = half1, levels = 0;
-    for (u32 q = m; q > 1; q = (q + 63) / 64) ++levels;
+    for (u32 q = m; q > 1; q = (q + ZK_MSM_JOIN - 1) / ZK_MSM_JOIN) ++levels;
     X* cur = A.ones + ((levels & 1u) ? half1 : 0);
     {
       ZkMsmArgsT<C> B = A; B.ones = cur;
       hipLaunchKernelGGL(zk_msm_ones<C>, dim3((half1 + 63) / 64), dim3(64), 0, st, B);
     }
     while (m > 1) {
-      const u32 m2 = (m + 63) / 64;
+      const u32 m2 = (m + ZK_MSM_JOIN - 1) / ZK_MSM_JOIN;
       X* nxt = cur == A.ones ? A.ones + half1 : A.ones;
       hipLaunchKernelGGL(zk_msm_tree<C>, dim3((m2 + 63) / 64), dim3(64), 0, st, (const X*)cur, m, nxt);
       cur = nxt; m = m2;

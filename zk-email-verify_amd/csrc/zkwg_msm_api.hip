@@ -25,7 +25,7 @@ static ZkMsmWork msm_work(const zkwg_msm* p) {
   ZkMsmWork W;
   auto al = [](u64 x) { return (x + 255) & ~255ull; };
   const u64 xs = p->group == 2 ? sizeof(G2Xyzz) : sizeof(G1Xyzz);
-  const u64 total = (u64)p->K * p->nb, half = (u64)p->K * ((p->nb + 31) / 32);
+  const u64 total = (u64)p->K * p->nb, half = (u64)p->K * ((p->nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN);
   u64 off = 0;
   W.count = off; off += al((total + 1) * 4);
   W.cursor = off; off += al(total * 4);

@@ -17,6 +17,9 @@
 #include "zkwg_g1.h"
 #include "zkwg_g2.h"
 
+#define ZK_MSM_FAN 8u      // fan-in of the weighted bucket tree: a node's serial work is 3 additions per child; the levels are what a lone sum waits for
+#define ZK_MSM_JOIN 16u    // fan-in of the joins of the ones' partial sums
+
 // the group the sums run over: G1 (pi_a, pib1, pi_c, the H sum) or G2 (pi_b) -- same kernels, other point arithmetic
 struct ZkCurveG1 {
   typedef G1Affine Affine; typedef G1Xyzz Xyzz;
@@ -60,7 +63,7 @@ struct ZkMsmArgsT {
   u32* soff[3];               // [K * nb + 1] per level: first slice of every bucket
   G1Xyzz* part[3];            // per level: the slices' sums
   u32 cap[3];                 // slices a level can hold (n K / S + K nb bounds it)
-  G1Xyzz* node_s; G1Xyzz* node_a;   // reduction tree scratch: [K * nb / 32 * 2] each (ping-pong halves)
+  G1Xyzz* node_s; G1Xyzz* node_a;   // reduction tree scratch: [K * nb / ZK_MSM_FAN * 2] each (ping-pong halves)
   G1Xyzz* window;             // [K] weighted bucket sums
   G1Xyzz* out;                // [1]
 };
@@ -88,7 +91,7 @@ ZK_HD void zk_msm_ones_thread(const ZkMsmArgsT<C>& A, u32 t) {
 }
 template <class C>
 ZK_HD void zk_msm_tree_thread_c(const typename C::Xyzz* in, u32 n_in, typename C::Xyzz* out, u32 t) {
-  const u32 lo = t * 64u, hi = lo + 64u < n_in ? lo + 64u : n_in;
+  const u32 lo = t * ZK_MSM_JOIN, hi = lo + ZK_MSM_JOIN < n_in ? lo + ZK_MSM_JOIN : n_in;
   if (lo >= n_in) return;
   typename C::Xyzz acc = in[lo];
   for (u32 i = lo + 1; i < hi; ++i) acc = C::add(acc, in[i]);
@@ -152,13 +155,13 @@ ZK_HD void zk_msm_bucket_thread(const ZkMsmArgsT<C>& A, u32 b) {
 }
 // one level of the reduction tree.  Nodes of the level below: `n_in` per window with span `span` (weights 1 .. span inside a node);
 // in_a == nullptr: the nodes are the buckets themselves (S = A = bucket, span 1).  Thread g builds node g of the level above
-// (`n_out` = ceil(n_in / 32) per window).  The last level (n_out == 1) writes the window's sum to A.window.
+// (`n_out` = ceil(n_in / ZK_MSM_FAN) per window).  The last level (n_out == 1) writes the window's sum to A.window.
 template <class C>
 ZK_HD void zk_msm_reduce_thread(const ZkMsmArgsT<C>& A, u32 g, const typename C::Xyzz* in_s, const typename C::Xyzz* in_a, u32 n_in, u32 span, typename C::Xyzz* out_s, typename C::Xyzz* out_a) {
-  const u32 n_out = (n_in + 31u) / 32u;
+  const u32 n_out = (n_in + ZK_MSM_FAN - 1u) / ZK_MSM_FAN;
   if (g >= A.K * n_out) return;
   const u32 w = g / n_out, q = g - w * n_out;
-  const u32 lo = q * 32u, hi = lo + 32u < n_in ? lo + 32u : n_in;
+  const u32 lo = q * ZK_MSM_FAN, hi = lo + ZK_MSM_FAN < n_in ? lo + ZK_MSM_FAN : n_in;
   const typename C::Xyzz* S = in_s + (size_t)w * n_in;
   const typename C::Xyzz* Aw = (in_a ? in_a : in_s) + (size_t)w * n_in;
   // sum_i i S_i for i = 1 .. m - 1 (running sum from the top), sum S_i, sum A_i
