@@ -241,15 +241,24 @@ void ht_msm(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t
 // hardware may.  Scalars in standard form or (mont = 1) Montgomery form.
 #include "zkwg_msm_core.h"
 extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t c, int mont, uint32_t shuffle, int ones_apart, uint8_t* out) {
+  // ones_apart bit 1: the precomputed-windows layout (K copies of the bases, one bucket set), as zkwg_msm_create builds it by default
+  const bool precomp = (ones_apart & 2) != 0;
+  ones_apart &= 1;
   std::vector<G1Affine> P(n);
   for (uint64_t i = 0; i < n; ++i) P[i] = ht_pt_in(points + 64 * i);
+  std::vector<G1Affine> EXT;
+  if (precomp) {
+    EXT.resize((size_t)n * zk_msm_windows(c));
+    for (u32 i = 0; i < n; ++i) zk_msm_shift_thread<ZkCurveG1>(P.data(), EXT.data(), (u32)n, c, zk_msm_windows(c), i, [](const G1Xyzz& a) { return g1_to_affine(a); });
+  }
   std::vector<Fr> S(n);
   for (uint64_t i = 0; i < n; ++i) { memcpy(&S[i], scalars + 4 * i, 32); if (mont) S[i] = fr_to_mont(S[i]); }
   ZkMsmArgs A;
-  A.bases = P.data(); A.scalars = S.data(); A.n = (u32)n; A.c = c; A.K = zk_msm_windows(c); A.nb = 1u << (c - 1); A.scalars_mont = mont ? 1u : 0u;
-  const u32 total = A.K * A.nb, half = A.K * ((A.nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN);
+  A.bases = precomp ? EXT.data() : P.data(); A.scalars = S.data(); A.n = (u32)n; A.c = c; A.K = zk_msm_windows(c); A.nb = 1u << (c - 1); A.scalars_mont = mont ? 1u : 0u;
+  A.KS = precomp ? 1u : A.K; A.stride = precomp ? (u32)n : 0u;
+  const u32 total = A.KS * A.nb, half = A.KS * ((A.nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN);
   std::vector<u32> count(total + 1, 0), cursor(total, 0), entry((size_t)n * A.K + 1, 0xdeadbeefu);
-  std::vector<G1Xyzz> bucket(total), ns(2 * (size_t)half + 1), na(2 * (size_t)half + 1), window(A.K), res(1);
+  std::vector<G1Xyzz> bucket(total), ns(2 * (size_t)half + 1), na(2 * (size_t)half + 1), window(A.KS), res(1);
   A.count = count.data(); A.cursor = cursor.data(); A.entry = entry.data(); A.bucket = bucket.data();
   A.node_s = ns.data(); A.node_a = na.data(); A.window = window.data(); A.out = res.data();
   const u32 half1 = (u32)((n + 63) / 64);
@@ -281,7 +290,7 @@ extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scal
     const u32 n_out = (n_in + ZK_MSM_FAN - 1) / ZK_MSM_FAN;
     G1Xyzz* out_s = A.node_s + (size_t)flip * half;
     G1Xyzz* out_a = A.node_a + (size_t)flip * half;
-    for (u32 g = 0; g < A.K * n_out; ++g) zk_msm_reduce_thread(A, g, in_s, in_a, n_in, span, out_s, out_a);
+    for (u32 g = 0; g < A.KS * n_out; ++g) zk_msm_reduce_thread(A, g, in_s, in_a, n_in, span, out_s, out_a);
     if (n_out == 1) break;
     in_s = out_s; in_a = out_a; n_in = n_out; span *= ZK_MSM_FAN; flip ^= 1;
   }

@@ -160,8 +160,9 @@ def test_device_msm_bodies_thread_by_thread_equal_the_oracle(n, c, mont):
     want = G.msm_buckets(pts, ks, 7) if n > 64 else G.msm_naive(pts, ks)
     out = C.create_string_buffer(64)
     for shuffle in (0, 5):
-        lib.ht_msm_device_mirror(buf, sc, C.c_uint64(n), c, mont, shuffle, 0, out)
-        assert _unpt(out.raw) == want, (n, c, mont, shuffle)
+        for layout in (0, 2):        # 2: precomputed windows -- K shifted copies of the bases, one bucket set, no Horner pass (the default layout)
+            lib.ht_msm_device_mirror(buf, sc, C.c_uint64(n), c, mont, shuffle, layout, out)
+            assert _unpt(out.raw) == want, (n, c, mont, shuffle, layout)
 
 
 @pytest.mark.parametrize("n,c", [(40, 4), (5000, 8), (9000, 10)])
@@ -183,7 +184,7 @@ def test_device_msm_bodies_on_witness_like_scalars(n, c):
             folded[p] = (folded.get(p, 0) + k) % R
     want = G.msm_naive(list(folded), list(folded.values()))
     out = C.create_string_buffer(64)
-    for apart in (1, 0):
+    for apart in (1, 0, 3, 2):       # bit 1: the precomputed-windows layout
         lib.ht_msm_device_mirror(buf, sc, C.c_uint64(n), c, 1, 3, apart, out)
         assert _unpt(out.raw) == want, (n, c, apart)
 

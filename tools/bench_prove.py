@@ -12,6 +12,10 @@ import random
 import sys
 import time
 
+# Proofs in flight live on separate HIP streams; the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default),
+# and a multi-exponentiation's serial tail holds its queue: 16 queues took the same code from 43 to 85 proofs/s
+# (profiles/r05/r05_i_bench_prove.json).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "zk-email-verify_amd", "py"))
@@ -22,8 +26,8 @@ def main(argv=None, quiet=False):
     ap.add_argument("--max-header", type=int, default=576)
     ap.add_argument("--max-body", type=int, default=192)
     ap.add_argument("--emails", type=int, default=8)
-    ap.add_argument("--slots", type=int, default=8, help="proofs in flight (one stream each)")
-    ap.add_argument("--proofs", type=int, default=32, help="proofs timed in the batched run")
+    ap.add_argument("--slots", type=int, default=32, help="proofs in flight (one stream each)")
+    ap.add_argument("--proofs", type=int, default=96, help="proofs timed in the batched run")
     args = ap.parse_args(argv)
     import torch
     import zkwg
@@ -87,7 +91,8 @@ def main(argv=None, quiet=False):
     torch.cuda.synchronize()
     per = (time.time() - t) / args.proofs
     out = {"circuit": f"EmailVerifier({N},{M},121,17,0,0,0,0)", "W": c.W, "constraints_with_public_rows": len(full), "domain_log2": power,
-           "emails": n, "proofs_per_s": round(1 / per, 2), "ms_per_proof": round(per * 1e3, 2), "proofs_in_flight": args.slots, "proofs_timed": args.proofs,
+           "emails": n, "proofs_per_s": round(1 / per, 2), "ms_per_proof": round(per * 1e3, 2), "proofs_in_flight": args.slots, "proofs_timed": args.proofs, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+           "msm_layout": "precomputed windows" if os.environ.get("ZKWG_MSM_PRECOMP", "1") != "0" else "classic",
            "one_at_a_time_ms_per_proof": round(per_single * 1e3, 2), "stages": {k: round(v, 2) for k, v in st.items()},
            "setup_s": round(t_setup, 1), "key": "random bases (timing only; validity: tests/test_prove.py under the pinned verifier)"}
     if not quiet:

@@ -33,7 +33,7 @@ template <class C> __global__ __launch_bounds__(64) void zk_msm_combine(ZkMsmArg
 template <class C>
 static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
   typedef typename C::Xyzz X;
-  const u32 total = A.K * A.nb;
+  const u32 total = A.KS * A.nb;
   hipMemsetAsync(A.count, 0, ((size_t)total + 1) * 4, st);
   hipLaunchKernelGGL(zk_msm_count<C>, dim3((A.n + 255) / 256), dim3(256), 0, st, A);
   hipLaunchKernelGGL(zk_msm_scan<C>, dim3(1), dim3(1024), 0, st, A);
@@ -44,12 +44,12 @@ static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
   }
   hipLaunchKernelGGL(zk_msm_bucket_join<C>, dim3((total + 63) / 64), dim3(64), 0, st, A);
   const X* in_s = A.bucket; const X* in_a = nullptr;
-  u32 n_in = A.nb, span = 1, half = A.K * ((A.nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN), flip = 0;
+  u32 n_in = A.nb, span = 1, half = A.KS * ((A.nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN), flip = 0;
   for (;;) {
     const u32 n_out = (n_in + ZK_MSM_FAN - 1) / ZK_MSM_FAN;
     X* out_s = A.node_s + (size_t)flip * half;
     X* out_a = A.node_a + (size_t)flip * half;
-    hipLaunchKernelGGL(zk_msm_reduce<C>, dim3((A.K * n_out + 63) / 64), dim3(64), 0, st, A, in_s, in_a, n_in, span, out_s, out_a);
+    hipLaunchKernelGGL(zk_msm_reduce<C>, dim3((A.KS * n_out + 63) / 64), dim3(64), 0, st, A, in_s, in_a, n_in, span, out_s, out_a);
     if (n_out == 1) break;
     in_s = out_s; in_a = out_a; n_in = n_out; span *= ZK_MSM_FAN; flip ^= 1;
   }
@@ -71,6 +71,17 @@ static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
     }
   }
   hipLaunchKernelGGL(zk_msm_combine<C>, dim3(1), dim3(64), 0, st, A);
+}
+template <class C> __global__ __launch_bounds__(64) void zk_msm_shift(const typename C::Affine* bases, typename C::Affine* ext, u32 n, u32 c, u32 K) {
+  const u32 i = blockIdx.x * 64u + threadIdx.x;
+  if constexpr (sizeof(typename C::Affine) == sizeof(G1Affine))
+    zk_msm_shift_thread<C>(bases, ext, n, c, K, i, [](const G1Xyzz& a) { return g1_to_affine(a); });
+  else
+    zk_msm_shift_thread<C>(bases, ext, n, c, K, i, [](const G2Xyzz& a) { return g2_to_affine(a); });
+}
+void zk_msm_shift_launch(int group, const void* bases, void* ext, u32 n, u32 c, u32 K, hipStream_t st) {
+  if (group == 1) hipLaunchKernelGGL(zk_msm_shift<ZkCurveG1>, dim3((n + 63) / 64), dim3(64), 0, st, (const G1Affine*)bases, (G1Affine*)ext, n, c, K);
+  else hipLaunchKernelGGL(zk_msm_shift<ZkCurveG2>, dim3((n + 63) / 64), dim3(64), 0, st, (const G2Affine*)bases, (G2Affine*)ext, n, c, K);
 }
 void zk_msm_launch(const ZkMsmArgs& A, hipStream_t st) { zk_msm_launch_t<ZkCurveG1>(A, st); }
 void zk_msm_launch_g2(const ZkMsmArgsT<ZkCurveG2>& A, hipStream_t st) { zk_msm_launch_t<ZkCurveG2>(A, st); }

@@ -1,6 +1,7 @@
 // C-ABI of the multi-exponentiations of the prover (include/zkwg.h "prover stage 3"): sums over BN254 G1 (pi_a, pib1, pi_c, the H sum)
 // and G2 (pi_b) with resident bases, and the fixed-base multiples that turn a key with a known trapdoor into bases.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "../../include/zkwg.h"
@@ -9,6 +10,7 @@
 
 void zk_msm_launch(const ZkMsmArgs& A, hipStream_t st);                          // zkwg_kernels_msm.hip
 void zk_msm_launch_g2(const ZkMsmArgsT<ZkCurveG2>& A, hipStream_t st);
+void zk_msm_shift_launch(int group, const void* bases, void* ext, u32 n, u32 c, u32 K, hipStream_t st);
 void zk_fixed_base_g1_launch(const G1Affine& gen, const Fr* k, G1Affine* out, u32 n, hipStream_t st);
 void zk_fixed_base_g2_launch(const G2Affine& gen, const Fr* k, G2Affine* out, u32 n, hipStream_t st);
 
@@ -19,13 +21,15 @@ struct zkwg_msm {
   u32 c, K, nb;
   void* d_bases;
   bool owns;        // false: the bases are the caller's device memory (zkwg_msm_create_device)
+  void* d_ext;      // precomputed windows: K copies of the bases, copy w = 2^(c w) * base (NULL: classic layout, ZKWG_MSM_PRECOMP=0)
 };
 struct ZkMsmWork { u64 count, cursor, entry, bucket, node_s, node_a, window, out, ones, soff[3], part[3], total; u32 cap[3]; };
 static ZkMsmWork msm_work(const zkwg_msm* p) {
   ZkMsmWork W;
   auto al = [](u64 x) { return (x + 255) & ~255ull; };
   const u64 xs = p->group == 2 ? sizeof(G2Xyzz) : sizeof(G1Xyzz);
-  const u64 total = (u64)p->K * p->nb, half = (u64)p->K * ((p->nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN);
+  const u64 sets = p->d_ext ? 1 : p->K;
+  const u64 total = sets * p->nb, half = sets * ((p->nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN);
   u64 off = 0;
   W.count = off; off += al((total + 1) * 4);
   W.cursor = off; off += al(total * 4);
@@ -33,7 +37,7 @@ static ZkMsmWork msm_work(const zkwg_msm* p) {
   W.bucket = off; off += al(total * xs);
   W.node_s = off; off += al(2 * half * xs);
   W.node_a = off; off += al(2 * half * xs);
-  W.window = off; off += al((u64)p->K * xs);
+  W.window = off; off += al(sets * xs);
   W.out = off; off += al(xs);
   W.ones = off; off += al(2 * ((p->n + 63) / 64) * xs);
   u64 items = p->n * p->K;                       // entries: at most one per (scalar, window)
@@ -62,6 +66,17 @@ static int msm_new(int device, int group, const void* bases, bool on_device, uin
     if (hipMalloc(&p->d_bases, bytes) != hipSuccess) { delete p; return ZKWG_RC_OOM; }
     if (hipMemcpy(p->d_bases, bases, bytes, hipMemcpyHostToDevice) != hipSuccess) { hipFree(p->d_bases); delete p; return ZKWG_RC_HIP_ERROR; }
   }
+  // precomputed windows (default; ZKWG_MSM_PRECOMP=0 keeps the classic K bucket sets): K x the bases' memory buys the Horner pass
+  p->d_ext = nullptr;
+  const bool pre = !(getenv("ZKWG_MSM_PRECOMP") && atoi(getenv("ZKWG_MSM_PRECOMP")) == 0) && (u64)p->K * n < (1ull << 31);
+  if (pre) {
+    size_t free_b = 0, total_b = 0;
+    hipMemGetInfo(&free_b, &total_b);
+    if (bytes * p->K + (4ull << 30) < free_b && hipMalloc(&p->d_ext, bytes * p->K) == hipSuccess) {
+      zk_msm_shift_launch(group, p->d_bases, p->d_ext, (u32)n, p->c, p->K, 0);
+      if (hipDeviceSynchronize() != hipSuccess) { hipFree(p->d_ext); p->d_ext = nullptr; (void)hipGetLastError(); }
+    } else (void)hipGetLastError();
+  }
   *out = p;
   return ZKWG_RC_OK;
 }
@@ -70,7 +85,7 @@ static void msm_args(const zkwg_msm* p, const void* d_scalars, int mont, int one
   typedef typename C::Xyzz X;
   const ZkMsmWork W = msm_work(p);
   u8* w = (u8*)d_work;
-  A.bases = (const typename C::Affine*)p->d_bases; A.scalars = (const Fr*)d_scalars; A.n = (u32)p->n; A.c = p->c; A.K = p->K; A.nb = p->nb;
+  A.bases = (const typename C::Affine*)(p->d_ext ? p->d_ext : p->d_bases); A.KS = p->d_ext ? 1u : p->K; A.stride = p->d_ext ? (u32)p->n : 0u; A.scalars = (const Fr*)d_scalars; A.n = (u32)p->n; A.c = p->c; A.K = p->K; A.nb = p->nb;
   A.scalars_mont = mont ? 1u : 0u; A.ones_apart = ones_apart ? 1u : 0u; A.ones = (X*)(w + W.ones);
   A.count = (u32*)(w + W.count); A.cursor = (u32*)(w + W.cursor); A.entry = (u32*)(w + W.entry); A.bucket = (X*)(w + W.bucket);
   A.node_s = (X*)(w + W.node_s); A.node_a = (X*)(w + W.node_a); A.window = (X*)(w + W.window); A.out = (X*)(w + W.out);
@@ -87,7 +102,7 @@ int zkwg_msm_create_device(int device, int group, const void* d_bases, uint64_t 
 }
 void zkwg_msm_destroy(zkwg_msm_t* p) {
   if (!p) return;
-  if (p->device >= 0 && p->owns) { hipSetDevice(p->device); hipFree(p->d_bases); }
+  if (p->device >= 0) { hipSetDevice(p->device); if (p->owns) hipFree(p->d_bases); if (p->d_ext) hipFree(p->d_ext); }
   delete p;
 }
 uint64_t zkwg_msm_work_bytes(const zkwg_msm_t* p) { return p ? msm_work(p).total : 0; }

@@ -47,6 +47,11 @@ struct ZkMsmArgsT {
   const G1Affine* bases;      // n points, Montgomery form, (0, 0) = infinity
   const Fr* scalars;          // n scalars of this call
   u32 n, c, K, nb;            // points, window bits, windows, buckets per window = 2^(c-1)
+  // Precomputed windows (KS = 1, stride = n): `bases` holds K copies of the points, copy w = 2^(c w) * base (zk_msm_shift_thread, once per
+  // key), so digit d of window w selects copy w and ALL windows share one set of nb buckets: there is no Horner pass over the windows (254
+  // dependent doublings on one lane: 3.8 ms of a 15 ms sum, profiles/r05/r05_i_prove_kernel_stats.csv) and one bucket tree instead of K.
+  // Classic layout: KS = K bucket sets, stride = 0.  The memory is what 288 GB are for: 20 x 47 MB per witness-sized sum.
+  u32 KS, stride;
   u32 scalars_mont;           // 1: the scalars are in Montgomery form (the H evaluations of zkwg_ntt_api.hip, a Montgomery witness)
   u32 ones_apart;             // 1: scalars equal to 1 do not enter the buckets (a witness is mostly bits: they would all land in ONE
                               // bucket of window 0); their bases are summed by zk_msm_ones + the 64-way tree and added at the end
@@ -105,14 +110,14 @@ ZK_HD void zk_msm_count_thread(const ZkMsmArgsT<C>& A, u32 i) {
   u32 carry = 0;
   for (u32 w = 0; w < A.K; ++w) {
     const int d = zk_msm_digit(k.l, w, A.c, carry);
-    if (d) ZK_MSM_ATOMIC_INC(&A.count[w * A.nb + (u32)(d < 0 ? -d : d) - 1u]);
+    if (d) ZK_MSM_ATOMIC_INC(&A.count[(A.KS == 1u ? 0u : w) * A.nb + (u32)(d < 0 ? -d : d) - 1u]);
   }
 }
 // one workgroup of `threads` threads (thread t of them): counts -> exclusive offsets in place, cursor = offsets; count[total] = entries.
 // Two phases separated by a barrier the caller supplies (host mirror: phase 0 for every t, then phase 1 for every t).
 template <class C>
 ZK_HD void zk_msm_scan_thread(const ZkMsmArgsT<C>& A, u32 t, u32 threads, u32* partial /*[threads + 1]*/, int phase) {
-  const u32 total = A.K * A.nb, per = (total + threads - 1) / threads;
+  const u32 total = A.KS * A.nb, per = (total + threads - 1) / threads;
   const u32 lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
   if (phase == 0) {
     u32 s = 0;
@@ -136,14 +141,14 @@ ZK_HD void zk_msm_scatter_thread(const ZkMsmArgsT<C>& A, u32 i) {
   for (u32 w = 0; w < A.K; ++w) {
     const int d = zk_msm_digit(k.l, w, A.c, carry);
     if (!d) continue;
-    const u32 b = w * A.nb + (u32)(d < 0 ? -d : d) - 1u;
+    const u32 b = (A.KS == 1u ? 0u : w) * A.nb + (u32)(d < 0 ? -d : d) - 1u;
     const u32 at = ZK_MSM_ATOMIC_INC(&A.cursor[b]);
-    A.entry[at] = i | (d < 0 ? 0x80000000u : 0u);
+    A.entry[at] = (w * A.stride + i) | (d < 0 ? 0x80000000u : 0u);
   }
 }
 template <class C>
 ZK_HD void zk_msm_bucket_thread(const ZkMsmArgsT<C>& A, u32 b) {
-  if (b >= A.K * A.nb) return;
+  if (b >= A.KS * A.nb) return;
   typename C::Xyzz acc = C::inf();
   for (u32 k = A.count[b], e = A.count[b + 1]; k < e; ++k) {
     const u32 v = A.entry[k];
@@ -159,7 +164,7 @@ ZK_HD void zk_msm_bucket_thread(const ZkMsmArgsT<C>& A, u32 b) {
 template <class C>
 ZK_HD void zk_msm_reduce_thread(const ZkMsmArgsT<C>& A, u32 g, const typename C::Xyzz* in_s, const typename C::Xyzz* in_a, u32 n_in, u32 span, typename C::Xyzz* out_s, typename C::Xyzz* out_a) {
   const u32 n_out = (n_in + ZK_MSM_FAN - 1u) / ZK_MSM_FAN;
-  if (g >= A.K * n_out) return;
+  if (g >= A.KS * n_out) return;
   const u32 w = g / n_out, q = g - w * n_out;
   const u32 lo = q * ZK_MSM_FAN, hi = lo + ZK_MSM_FAN < n_in ? lo + ZK_MSM_FAN : n_in;
   const typename C::Xyzz* S = in_s + (size_t)w * n_in;
@@ -180,12 +185,26 @@ ZK_HD void zk_msm_reduce_thread(const ZkMsmArgsT<C>& A, u32 g, const typename C:
 template <class C>
 ZK_HD void zk_msm_combine_thread(const ZkMsmArgsT<C>& A) {
   typename C::Xyzz total = C::inf();
-  for (u32 w = A.K; w-- > 0;) {
-    for (u32 s = 0; s < A.c; ++s) total = C::dbl(total);
-    total = C::add(total, A.window[w]);
-  }
+  if (A.KS == 1u) total = A.window[0];        // precomputed windows: nothing to combine
+  else
+    for (u32 w = A.K; w-- > 0;) {
+      for (u32 s = 0; s < A.c; ++s) total = C::dbl(total);
+      total = C::add(total, A.window[w]);
+    }
   if (A.ones_apart) total = C::add(total, A.ones[0]);
   A.out[0] = total;
+}
+// copy w of base i for the precomputed-windows layout: ext[w n + i] = 2^(c w) base_i, affine (one inversion per copy; once per key)
+template <class C, class ToAffine>
+ZK_HD void zk_msm_shift_thread(const typename C::Affine* bases, typename C::Affine* ext, u32 n, u32 c, u32 K, u32 i, ToAffine to_affine) {
+  if (i >= n) return;
+  const typename C::Affine p = bases[i];
+  ext[i] = p;
+  typename C::Xyzz acc = C::add_mixed(C::inf(), p);
+  for (u32 w = 1; w < K; ++w) {
+    for (u32 s = 0; s < c; ++s) acc = C::dbl(acc);
+    ext[(size_t)w * n + i] = to_affine(acc);
+  }
 }
 #define ZK_MSM_S0 64u
 #define ZK_MSM_S1 32u
@@ -197,7 +216,7 @@ ZK_HD void zk_msm_slice_scan_thread(const ZkMsmArgsT<C>& A, int level, u32 t, u3
   const u32* in = level == 0 ? A.count : A.soff[level - 1];
   u32* out = A.soff[level];
   const u32 S = zk_msm_slice_size(level);
-  const u32 total = A.K * A.nb, per = (total + threads - 1) / threads;
+  const u32 total = A.KS * A.nb, per = (total + threads - 1) / threads;
   const u32 lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
   if (phase == 0) {
     u32 s = 0;
@@ -215,7 +234,7 @@ ZK_HD void zk_msm_slice_scan_thread(const ZkMsmArgsT<C>& A, int level, u32 t, u3
 // slice t of `level` (nothing beyond the level's slice count or capacity: the capacity is a proven bound)
 template <class C>
 ZK_HD void zk_msm_slice_sum_thread(const ZkMsmArgsT<C>& A, int level, u32 t) {
-  const u32 total = A.K * A.nb;
+  const u32 total = A.KS * A.nb;
   const u32* off = A.soff[level];
   if (t >= off[total] || t >= A.cap[level]) return;
   // the bucket whose slices contain t: the last b with off[b] <= t
@@ -241,7 +260,7 @@ ZK_HD void zk_msm_slice_sum_thread(const ZkMsmArgsT<C>& A, int level, u32 t) {
 // bucket b = the sum of its slices of the last level
 template <class C>
 ZK_HD void zk_msm_bucket_join_thread(const ZkMsmArgsT<C>& A, u32 b) {
-  if (b >= A.K * A.nb) return;
+  if (b >= A.KS * A.nb) return;
   typename C::Xyzz acc = C::inf();
   for (u32 k = A.soff[2][b], e = A.soff[2][b + 1]; k < e; ++k) acc = C::add(acc, A.part[2][k]);
   A.bucket[b] = acc;
