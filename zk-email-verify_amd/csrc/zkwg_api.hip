@@ -314,9 +314,12 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
     ZkR1csHost R;
     bool r1cs_ok = true;
     std::thread r1cs_thread;
-    if (r1cs) r1cs_thread = std::thread([&] { r1cs_ok = zk_r1cs_parse(r1cs, r1cs_len, R); });
-    const bool sym_ok = zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net);
+    std::exception_ptr r1cs_err, sym_err;      // neither thread may leave an exception unjoined: both are rethrown below, joined
+    if (r1cs) r1cs_thread = std::thread([&] { try { r1cs_ok = zk_r1cs_parse(r1cs, r1cs_len, R); } catch (...) { r1cs_err = std::current_exception(); } });
+    bool sym_ok = false;
+    try { sym_ok = zk_sym_layout(c->s, sym_text, sym_len, alias_text, alias_len, L, net); } catch (...) { sym_err = std::current_exception(); }
     if (r1cs_thread.joinable()) r1cs_thread.join();
+    if (sym_err || r1cs_err) { delete c; std::rethrow_exception(sym_err ? sym_err : r1cs_err); }      // -> create_guarded's catch (ZKWG_RC_OOM / BAD_CONFIG)
     if (!sym_ok || (!r1cs && !zk_remap_segments(c->s, c->segs, L))) {
       g_last_error = L.err.empty() ? std::string(".sym layout does not tile the witness") : L.err;
       delete c;

@@ -1608,17 +1608,22 @@ struct Elab {
     // functions collide is refused rather than given a wrong witness.
     {
       std::map<u64, u32> first_of;
+      std::map<u64, u32> sharers;          // per signature: gates checked so far
       static const u32 probes[6] = {0u, 10u, 59u, 61u, 97u, 255u};
       for (u32 g = 0; g < n; ++g) {
         if (!local[g]) continue;
         auto it = first_of.find(sig[g]);
         if (it == first_of.end()) { first_of.emplace(sig[g], g); continue; }
         const std::vector<u32>& w = table(it->second);
-        for (u32 v : probes) {
+        // the first gate that shares a table is compared on all 256 byte values (six probes could miss two functions that
+        // differ elsewhere); the later ones on six values that move with the gate, which cover every value between them
+        const bool full = sharers[sig[g]]++ == 0;
+        for (u32 q = 0; q < (full ? 256u : 6u); ++q) {
+          const u32 v = full ? q : (probes[q] + 7u * g) & 255u;
           ++now;
           u32 word = 0;
-          eval(g, (long long)((v + 7u * g) & 255u), word);
-          if (word != w[(v + 7u * g) & 255u]) fail("two different byte-local functions of the regex template share a structural signature (hash collision)");
+          eval(g, (long long)v, word);
+          if (word != w[v]) fail("two different byte-local functions of the regex template share a structural signature (hash collision)");
         }
       }
     }

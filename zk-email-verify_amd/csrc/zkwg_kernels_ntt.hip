@@ -97,7 +97,7 @@ __device__ __forceinline__ void zk_ntt_stages(const ZkLdsFr& y, const ZkLdsFr& t
 // DIT: y *= w_N^(c * bitrev_g(r)) first, then the sub-transform.  `src` may differ from `dst` (first inverse pass: reads
 // A.w | B.w | C.w, `valid` elements per polynomial, zero beyond) -- polynomial q = blockIdx.y: src + (q / 3) * src_es + (q % 3) * src_ps.
 template <bool DIT>
-__global__ __launch_bounds__(256) void zk_ntt_col(const Fr* __restrict__ src, u64 src_es, u64 src_ps, u64 valid, Fr* __restrict__ dst,
+__global__ __launch_bounds__(256) void zk_ntt_col(const Fr* src, u64 src_es, u64 src_ps, u64 valid, Fr* dst,   /* launched in place: src may alias dst */
                                                    const Fr* __restrict__ tw, u32 L, u32 lb, u32 g, u32 inv) {
   extern __shared__ uint4 lds4[];
   const u64 n = 1ull << L;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void zk_ntt_col(const Fr* __restrict__ src, u6
 // The row pass: contiguous blocks of G = 2^g elements (g <= 10), 1,024 elements per workgroup.  DIF (inverse direction of the
 // pipeline): optional multiplication by scale[position] on the way out (coset shift and 1 / n).  `src` / `valid` as above.
 template <bool DIT>
-__global__ __launch_bounds__(256) void zk_ntt_row(const Fr* __restrict__ src, u64 src_es, u64 src_ps, u64 valid, Fr* __restrict__ dst,
+__global__ __launch_bounds__(256) void zk_ntt_row(const Fr* src, u64 src_es, u64 src_ps, u64 valid, Fr* dst,   /* launched in place: src may alias dst */
                                                    const Fr* __restrict__ tw, const Fr* __restrict__ scale, Fr uni, u32 use_uni, u32 L, u32 g, u32 inv) {
   extern __shared__ uint4 lds4[];
   const u64 n = 1ull << L;

@@ -3,6 +3,7 @@
 #pragma once
 #include <stdlib.h>
 #include <algorithm>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -15,9 +16,16 @@ static inline unsigned zk_host_threads() {
 template <class F>
 static inline void zk_parallel_chunks(unsigned n_chunks, F fn) {
   if (n_chunks <= 1) { fn(0u, 1u); return; }
+  // an exception in a worker (bad_alloc on a 0.9 GB .sym) must reach the caller's catch, not std::terminate: every worker catches,
+  // every thread is joined, the first exception is rethrown afterwards
   std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err(n_chunks);
   th.reserve(n_chunks - 1);
-  for (unsigned i = 1; i < n_chunks; ++i) th.emplace_back([&fn, i, n_chunks] { fn(i, n_chunks); });
-  fn(0u, n_chunks);
+  auto guarded = [&fn, &err, n_chunks](unsigned i) { try { fn(i, n_chunks); } catch (...) { err[i] = std::current_exception(); } };
+  try {
+    for (unsigned i = 1; i < n_chunks; ++i) th.emplace_back(guarded, i);
+  } catch (...) { err[0] = std::current_exception(); }     // (thread creation failed: run what was started, then report)
+  if (!err[0]) guarded(0u);
   for (auto& t : th) t.join();
+  for (auto& e : err) if (e) std::rethrow_exception(e);
 }
