@@ -66,6 +66,7 @@ class Pipeline:
         self.R = max(2, ring)
         self.d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(self.R)]
         self.placement = None
+        self.d_out = None
         if place == 2 or place is True:
             # the output ring is mapped from 1 GiB physical chunks (zkwg_device_alloc_chunked): every tile then
             # takes zk_expand's stores at the rate only the best hipMalloc buffers reach -- no candidates, no transient memory
@@ -73,11 +74,16 @@ class Pipeline:
             ntl = min(2, self.ntiles)
             nch = (tile * self.stride + (1 << 30) - 1) >> 30
             extra = min(nch // 2, 16)       # spare candidate chunks per tile: each takes a probe fill, the fastest are kept
-            self.d_out = [placement.chunked_tensor(torch, dev, tile * self.stride, extra=extra) for _ in range(ntl)]
-            rates = sorted(r for t in self.d_out for r in getattr(t._zkwg_owner, "rates", []))
-            self.placement = {"mode": "chunked", "chunk_bytes": 1 << 30, "tiles": ntl, "tile_bytes": tile * self.stride, "spare_chunks_per_tile": extra,
-                              "candidate_chunk_GBps": ({"min": rates[0], "median": rates[len(rates) // 2], "max": rates[-1], "n": len(rates)} if rates else None)}
-        elif place:
+            try:
+                self.d_out = [placement.chunked_tensor(torch, dev, tile * self.stride, extra=extra) for _ in range(ntl)]
+                rates = sorted(r for t in self.d_out for r in getattr(t._zkwg_owner, "rates", []))
+                self.placement = {"mode": "chunked", "chunk_bytes": 1 << 30, "tiles": ntl, "tile_bytes": tile * self.stride, "spare_chunks_per_tile": extra,
+                                  "candidate_chunk_GBps": ({"min": rates[0], "median": rates[len(rates) // 2], "max": rates[-1], "n": len(rates)} if rates else None)}
+            except Exception as e:          # a runtime without the virtual-memory API: round 4's candidate search instead
+                self.d_out = None
+                place = 1
+                chunk_error = repr(e)[:160]
+        if place == 1:
             # round 4's way (--place-ring 1): spare candidate buffers from hipMalloc, the real expansion of one tile timed into each,
             # the fastest kept
             from zkwg import placement
@@ -89,7 +95,9 @@ class Pipeline:
                 torch, dev, tile * self.stride, min(2, self.ntiles),
                 lambda buf: self.expand(d_in[:prep], prep, self.d_scr[0], 0, tile, buf, cur, **kw))
             torch.cuda.synchronize()
-        else:
+            if "chunk_error" in locals():
+                self.placement["chunked_allocation_failed"] = chunk_error
+        if self.d_out is None:
             self.d_out = [torch.empty(tile * self.stride, dtype=torch.uint8, device=dev) for _ in range(min(2, self.ntiles))]
         # several prepare streams let the latency-bound prepare kernels of consecutive SMALL sub-batches overlap
         self.s_preps = [torch.cuda.Stream(device=dev, priority=prep_prio) for _ in range(max(1, prep_streams))]
