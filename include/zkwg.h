@@ -473,6 +473,31 @@ int zkwg_groth16_assemble(const uint8_t* sum_a, const uint8_t* sum_b1, const uin
                           const uint8_t* vk_alpha1, const uint8_t* vk_beta1, const uint8_t* vk_beta2, const uint8_t* vk_delta1,
                           const uint8_t* vk_delta2, const uint8_t* r32, const uint8_t* s32, uint8_t* pi_a, uint8_t* pi_b, uint8_t* pi_c);
 
+/* ---- the prover as one call (reference: the second half of snarkjs.groth16.fullProve, packages/helpers/src/chunked-zkey.ts:80-84) ----
+ * zkwg_prover_create plans everything a circuit's proofs need once: it attaches the constraint system `r1cs` (over the handle's
+ * witness layout, WITH the nPublic + 1 rows snarkjs appends to A; n_rows = its constraint count; NULL if already attached) to `c`,
+ * builds the transform plan of the key's domain and the five multi-exponentiation plans over the key's bases (host pointers to
+ * sections 5-9 of the .zkey, or device pointers with bases_on_device = 1), and allocates `slots` sets of per-proof buffers, one
+ * stream each (a proof's sums end in serial tails that only other proofs in flight hide; the host should run with
+ * GPU_MAX_HW_QUEUES >= 16).  zkwg_prover_prove_prepared: proofs of emails indices[0 .. n_idx) of a batch prepared with
+ * zkwg_prepare_device(c, d_in, n, ..., d_scratch); blinding = n_idx x (r | s), 32-byte little-endian scalars below the group order
+ * (random per proof); out_proofs = n_idx x 256 bytes: pi_a (x | y) | pi_b (x.c0 | x.c1 | y.c0 | y.c1) | pi_c (x | y), standard-form
+ * little-endian integers -- the numbers of snarkjs' proof.json.  zkwg_prover_prove_batch: the same from n packed input records on the
+ * host (status[i] = circom_runtime code of email i; the proof bytes of a failed email are zero). */
+typedef struct zkwg_prover zkwg_prover_t;
+typedef struct zkwg_proving_key {
+  uint64_t n_wires, n_public, log2_domain;
+  const void *a, *b1, *b2, *c, *h;            /* bases: n_wires G1, n_wires G1, n_wires G2, n_wires - n_public - 1 G1, 2^log2_domain G1 */
+  int bases_on_device;                        /* 0: host memory (uploaded here), 1: device memory (not owned) */
+  uint8_t alpha1[64], beta1[64], beta2[128], delta1[64], delta2[128];   /* as the zkey's header stores them */
+} zkwg_proving_key;
+int zkwg_prover_create(zkwg_circuit_t* c, int device, const uint8_t* r1cs, uint64_t r1cs_len, uint64_t n_rows, const zkwg_proving_key* key,
+                       uint32_t slots, zkwg_prover_t** out);
+void zkwg_prover_destroy(zkwg_prover_t* p);
+int zkwg_prover_prove_prepared(zkwg_prover_t* p, const void* d_in, uint64_t n, const void* d_scratch, const uint64_t* indices, uint64_t n_idx,
+                               const uint8_t* blinding, uint8_t* out_proofs);
+int zkwg_prover_prove_batch(zkwg_prover_t* p, const uint8_t* packed, uint64_t n, const uint8_t* blinding, int32_t* status, uint8_t* out_proofs);
+
 /* The same prover stage without a 32-byte witness in between: the constraint system `r1cs` (its wires = the handle's
  * witness layout: built-in, `.sym`, or -- since ABI 3 -- a fully numbered handle of zkwg_circuit_create_full, whose system is
  * the compiler's own `.r1cs`, the file a zkey is keyed to: every wire of every combination is substituted by the kept-v1

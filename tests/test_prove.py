@@ -132,6 +132,11 @@ def _prove_case(N, M, records_of, n_emails=2):
     # the same proofs with several in flight (one stream per proof, nothing synchronised in between)
     batch = pv.prove_batch(d_in, n_emails, d_scratch, list(range(n_emails)) * 2, [(r, s) for r, s, _ in singles] * 2, slots=3)
     assert batch == [p for _, _, p in singles] * 2
+    # inputs -> proofs in one call (zkwg_prover_prove_batch), with a tampered email in the batch: no proof for it, the others unchanged
+    bad = bytearray(recs[:c.in_stride])
+    bad[c.lib.zkwg_input_offset(c.h, zkwg._lib.IN_SIGNATURE)] ^= 1
+    status, proofs = pv.prove_records(recs + bytes(bad), [(r, s) for r, s, _ in singles] + [(1, 2)], slots=3)
+    assert status == [0] * n_emails + [4] and proofs[-1] is None and proofs[:n_emails] == [p for _, _, p in singles]
 
 
 @pytest.mark.gpu
@@ -170,3 +175,48 @@ def test_zkey_round_trip():
         zkey.read_zkey(b"zkex" + data[4:])
     with pytest.raises(ValueError):
         zkey.read_zkey(data[:-70])          # the last sections cut off
+
+
+@pytest.mark.gpu
+def test_gpu_node_host_proves_through_the_addon(tmp_path):
+    """the Node host (zk-email-verify_amd/js/prove.js -> zkwg.js Prover -> N-API addon -> zkwg_prover_prove_batch): input.json + a
+    .zkey written from a toy key + the layout's .r1cs -> proof.json / public signals that the pinned verifier accepts -- the whole
+    of `groth16.fullProve` (packages/helpers/src/chunked-zkey.ts:80-84) behind the reference's host language"""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import torch
+    import zkwg
+    from conftest import ROOT
+    from zkwg import prover, zkey
+    from zkwg import r1cs as zr
+    js = os.path.join(ROOT, "zk-email-verify_amd", "js")
+    if shutil.which("node") is None or not os.path.exists(os.path.join(js, "zkwg_addon.node")):
+        pytest.skip("node or the built addon is missing")
+    kase = json.load(open(os.path.join(ROOT, "tests", "golden", "ev_576_192_case.json")))
+    N, M = kase["maxHeader"], kase["maxBody"]
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    sym = c.symbols()
+    cons = zr.email_verifier_constraints(sym, N, M)
+    n_public = 20
+    full = zr.append_public_rows(cons, n_public)
+    (tmp_path / "c.r1cs").write_bytes(zr.write_r1cs(len(sym), full, n_pub_out=3, n_pub_in=17, n_prv_in=N + 1 + 17 + 1 + 32 + M + 1))
+    key = G.setup(c.W, n_public, cons, seed=21)
+    pk = prover.ProvingKey.from_scalars(0, n_public, key.power, key.a_tau, key.b_tau, key.c_key[n_public + 1:], key.h_key, key.alpha, key.beta, key.delta)
+    down = lambda t: bytes(t.cpu().numpy())
+    pts = {"alpha1": pk.alpha1, "beta1": pk.beta1, "beta2": pk.beta2, "gamma2": _mont2(G2.mul(key.gamma, G2.G2)), "delta1": pk.delta1, "delta2": pk.delta2}
+    ic = b"".join(_mont1(G1.mul(x, G1.G)) for x in key.ic)
+    (tmp_path / "c.zkey").write_bytes(zkey.write_zkey(c.W, n_public, key.n, pts, ic, down(pk.d_a), down(pk.d_b1), down(pk.d_b2), down(pk.d_c), down(pk.d_h)))
+    del pk, c
+    torch.cuda.empty_cache()
+    bad = dict(kase["input"], signature=[str(int(kase["input"]["signature"][0]) ^ 1)] + list(kase["input"]["signature"][1:]))
+    (tmp_path / "in.json").write_text(json.dumps([kase["input"], bad]))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run(["node", os.path.join(js, "prove.js"), f"EmailVerifier({N},{M},121,17,0,0,0,0)", str(tmp_path / "in.json"), str(tmp_path / "c.zkey"),
+                        str(tmp_path / "c.r1cs"), str(len(full)), str(tmp_path / "out.json")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 1 and "1 proof(s), 1 failed email(s)" in r.stdout, r.stdout + r.stderr
+    out = json.load(open(tmp_path / "out.json"))
+    assert out[1]["status"] == 4 and out[1]["proof"] is None
+    assert out[0]["publicSignals"][0] == str(int(kase["pubkeyHash"]))
+    assert P.groth16_verify(G.vkey_json(key), out[0]["publicSignals"], out[0]["proof"])

@@ -57,7 +57,7 @@ def main(argv=None, quiet=False):
     c.prepare_device(d_in, n, d_status, d_scratch)
     torch.cuda.synchronize()
     assert d_status.tolist() == [0] * n
-    pv.prove_prepared(d_in, n, d_scratch, 0, 3, 4)       # warm-up
+    pv.prove_prepared(d_in, n, d_scratch, 0, 3, 4)       # warm-up (builds the per-stage plans)
     torch.cuda.synchronize()
     # stage timings on one email
     def timed(f, reps=3):

@@ -33,7 +33,8 @@ class Circuit {
    *  from the template text instead of zkwg's built-in circuit (zkwg_circuit_create_regex) */
   constructor(opts, device) {
     this.opts = Object.assign({ mainKind: MAIN_EMAIL_VERIFIER, maxHeader: 1024, maxBody: 1536, n: 121, k: 17, ignoreBodyHashCheck: 0, enableHeaderMasking: 0, enableBodyMasking: 0, removeSoftLineBreaks: 0 }, opts || {});
-    this.handle = addon.createCircuit(this.opts, device === undefined ? 0 : device);
+    this.device = device === undefined ? 0 : device;
+    this.handle = addon.createCircuit(this.opts, this.device);
     Object.assign(this, addon.info(this.handle));
   }
 
@@ -165,6 +166,65 @@ class WitnessCalculator {
   }
 }
 
+/** The second half of `snarkjs.groth16.fullProve` (packages/helpers/src/chunked-zkey.ts:80-84) on the device: `groth16.prove(zkey,
+ * wtns)` for whole batches -- witness, A.w | B.w | C.w, H evaluations, the five multi-exponentiations over the zkey's bases, proof
+ * assembly (include/zkwg.h zkwg_prover_*).  `zkey`: the bytes of a snarkjs groth16 .zkey (sections 2, 5-9 are read; layout restated
+ * from snarkjs, DESIGN.md section 23); `r1cs`: the constraint system over the circuit's witness layout WITH the nPublic + 1 rows
+ * snarkjs appends to A; `nRows`: its constraint count.  Set GPU_MAX_HW_QUEUES=16 in the environment: `slots` proofs are in flight. */
+class Prover {
+  constructor(circuit, r1cs, nRows, zkey, slots) {
+    const key = Prover.parseZkey(zkey);
+    if (key.nWires !== circuit.witnessLen) throw new Error(`zkwg: the key has ${key.nWires} wires, the circuit's witness ${circuit.witnessLen}`);
+    this.circuit = circuit;
+    this.handle = addon.createProver(circuit.handle, circuit.device, r1cs, nRows, key, slots || 16);
+  }
+  /** sections of a groth16 .zkey -> the object addon.createProver takes */
+  static parseZkey(buf) {
+    if (buf.slice(0, 4).toString("latin1") !== "zkey" || buf.readUInt32LE(4) !== 1) throw new Error("zkwg: not a version-1 .zkey file");
+    const nsec = buf.readUInt32LE(8), sec = {};
+    let pos = 12;
+    for (let i = 0; i < nsec; ++i) {
+      const id = buf.readUInt32LE(pos), size = Number(buf.readBigUInt64LE(pos + 4));
+      if (pos + 12 + size > buf.length) throw new Error(`zkwg: .zkey section ${id} runs past the end of the file`);
+      sec[id] = [pos + 12, size];
+      pos += 12 + size;
+    }
+    for (const need of [1, 2, 5, 6, 7, 8, 9]) if (!sec[need]) throw new Error(`zkwg: .zkey section ${need} is missing`);
+    if (buf.readUInt32LE(sec[1][0]) !== 1) throw new Error("zkwg: not a groth16 key");
+    let p = sec[2][0];
+    const n8q = buf.readUInt32LE(p); p += 4 + n8q;
+    const n8r = buf.readUInt32LE(p); p += 4 + n8r;
+    if (n8q !== 32 || n8r !== 32) throw new Error("zkwg: not a BN254 key");
+    const nWires = buf.readUInt32LE(p), nPublic = buf.readUInt32LE(p + 4), domain = buf.readUInt32LE(p + 8);
+    p += 12;
+    const take = (n) => { const b = buf.slice(p, p + n); p += n; return b; };
+    const alpha1 = take(64), beta1 = take(64), beta2 = take(128); take(128); const delta1 = take(64), delta2 = take(128);
+    const s = (id) => buf.slice(sec[id][0], sec[id][0] + sec[id][1]);
+    return { nWires, nPublic, log2Domain: Math.round(Math.log2(domain)), a: s(5), b1: s(6), b2: s(7), c: s(8), h: s(9), alpha1, beta1, beta2, delta1, delta2 };
+  }
+  /** inputs[] (generateEmailVerifierInputs objects) -> Promise<{status: Int32Array, proofs: (snarkjs proof.json object | null)[]}>;
+   * blinding: optional [[r, s], ...] bigints (default: random) */
+  async proveBatch(inputs, blinding) {
+    const recs = Buffer.concat(inputs.map((i) => this.circuit.pack(i)));
+    const bl = Buffer.alloc(64 * inputs.length);
+    const put = (v, off) => { let x = BigInt(v) % FIELD_MODULUS; for (let k = 0; k < 32; ++k) { bl[off + k] = Number(x & 255n); x >>= 8n; } };
+    for (let i = 0; i < inputs.length; ++i) {
+      const rs = blinding ? blinding[i] : [BigInt("0x" + require("crypto").randomBytes(31).toString("hex")), BigInt("0x" + require("crypto").randomBytes(31).toString("hex"))];
+      put(rs[0], 64 * i); put(rs[1], 64 * i + 32);
+    }
+    const r = await addon.proveBatch(this.handle, this.circuit.handle, recs, bl);
+    const num = (o) => { let x = 0n; for (let k = 31; k >= 0; --k) x = (x << 8n) | BigInt(r.proofs[o + k]); return x.toString(); };
+    const proofs = [];
+    for (let i = 0; i < inputs.length; ++i) {
+      const o = 256 * i;
+      proofs.push(r.status[i] !== 0 ? null : {
+        pi_a: [num(o), num(o + 32), "1"], pi_b: [[num(o + 64), num(o + 96)], [num(o + 128), num(o + 160)], ["1", "0"]],
+        pi_c: [num(o + 192), num(o + 224), "1"], protocol: "groth16", curve: "bn128" });
+    }
+    return { status: r.status, proofs };
+  }
+}
+
 /** Batch calculation sharded over several GPUs of one node (include/zkwg.h zkwg_multi_*): contiguous
  * shards, one handle + host thread per GPU, witnesses leave through each GPU's own PCIe link; the
  * 100-byte/email result table {status, pubkeyHash, shaHi, shaLo} is gathered on devices[0] over RCCL. */
@@ -272,4 +332,4 @@ function symbols(circuit) {
   return names;
 }
 
-module.exports = { symbols, R1cs, Circuit, WitnessCalculator, MultiCalculator, Tester, tester, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER, MAIN_FP_MUL };
+module.exports = { symbols, R1cs, Circuit, WitnessCalculator, MultiCalculator, Prover, Tester, tester, wtns, FIELD_MODULUS, MAIN_EMAIL_VERIFIER, MAIN_SHA256_BYTES, MAIN_RSA_VERIFIER, MAIN_FP_MUL };

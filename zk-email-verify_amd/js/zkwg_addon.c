@@ -408,6 +408,103 @@ static napi_value R1csCheck(napi_env env, napi_callback_info info) {
   return arr;
 }
 
+/* ---- groth16.prove (zkwg_prover_*, the second half of fullProve: packages/helpers/src/chunked-zkey.ts:80-84) ----------------- */
+static void prover_finalize(napi_env env, void* data, void* hint) { (void)env; (void)hint; zkwg_prover_destroy((zkwg_prover_t*)data); }
+/* createProver(circuit, device, r1cs: Buffer, nRows, key: {nWires, nPublic, log2Domain, a, b1, b2, c, h, alpha1, beta1, beta2, delta1, delta2 (Buffers)}, slots) -> external */
+static napi_value CreateProver(napi_env env, napi_callback_info info) {
+  size_t argc = 6; napi_value argv[6];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkwg_circuit_t* c = unwrap(env, argv[0]);
+  if (!c) return NULL;
+  int32_t device = 0; uint32_t slots = 8; int64_t n_rows = 0;
+  napi_get_value_int32(env, argv[1], &device);
+  void* r1cs; size_t r1cs_len;
+  NAPI_OK(napi_get_buffer_info(env, argv[2], &r1cs, &r1cs_len));
+  napi_get_value_int64(env, argv[3], &n_rows);
+  if (argc > 5) napi_get_value_uint32(env, argv[5], &slots);
+  zkwg_proving_key key;
+  memset(&key, 0, sizeof key);
+  uint32_t u;
+  if (get_u32(env, argv[4], "nWires", &u, 0)) return NULL; key.n_wires = u;
+  if (get_u32(env, argv[4], "nPublic", &u, 0)) return NULL; key.n_public = u;
+  if (get_u32(env, argv[4], "log2Domain", &u, 0)) return NULL; key.log2_domain = u;
+  const char* names[10] = {"a", "b1", "b2", "c", "h", "alpha1", "beta1", "beta2", "delta1", "delta2"};
+  const size_t unit[10] = {64, 64, 128, 64, 64, 64, 64, 128, 64, 128};
+  const size_t count[10] = {key.n_wires, key.n_wires, key.n_wires, key.n_wires - key.n_public - 1, (size_t)1 << key.log2_domain, 1, 1, 1, 1, 1};
+  const void* ptr[10];
+  for (int i = 0; i < 10; ++i) {
+    napi_value v; void* d; size_t len;
+    if (napi_get_named_property(env, argv[4], names[i], &v) != napi_ok || napi_get_buffer_info(env, v, &d, &len) != napi_ok || len != unit[i] * count[i]) {
+      napi_throw_type_error(env, NULL, "zkwg: the proving key needs Buffers a, b1, b2, c, h (sections 5-9 of the .zkey) and alpha1, beta1, beta2, delta1, delta2 of the right sizes");
+      return NULL;
+    }
+    ptr[i] = d;
+  }
+  key.a = ptr[0]; key.b1 = ptr[1]; key.b2 = ptr[2]; key.c = ptr[3]; key.h = ptr[4];
+  memcpy(key.alpha1, ptr[5], 64); memcpy(key.beta1, ptr[6], 64); memcpy(key.beta2, ptr[7], 128); memcpy(key.delta1, ptr[8], 64); memcpy(key.delta2, ptr[9], 128);
+  zkwg_prover_t* pv = NULL;
+  int rc = zkwg_prover_create(c, device, (const uint8_t*)r1cs, r1cs_len, (uint64_t)n_rows, &key, slots, &pv);
+  if (rc != ZKWG_RC_OK) { napi_throw_error(env, NULL, zkwg_strerror(rc)); return NULL; }
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, pv, prover_finalize, NULL, &ext));
+  return ext;
+}
+typedef struct {
+  zkwg_prover_t* p; const uint8_t* in; const uint8_t* blinding; uint64_t n;
+  int32_t* status; uint8_t* proofs; int rc;
+  napi_deferred deferred; napi_async_work work; napi_ref in_ref, bl_ref;
+} prove_job;
+static void prove_execute(napi_env env, void* data) {
+  prove_job* j = (prove_job*)data; (void)env;
+  j->rc = zkwg_prover_prove_batch(j->p, j->in, j->n, j->blinding, j->status, j->proofs);
+}
+static void prove_complete(napi_env env, napi_status st, void* data) {
+  prove_job* j = (prove_job*)data; (void)st;
+  if (j->rc != ZKWG_RC_OK) {
+    napi_value msg, err;
+    napi_create_string_utf8(env, zkwg_strerror(j->rc), NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &err);
+    napi_reject_deferred(env, j->deferred, err);
+  } else {
+    napi_value obj, ab, ta, buf; void* p;
+    napi_create_object(env, &obj);
+    napi_create_arraybuffer(env, j->n * 4, &p, &ab); memcpy(p, j->status, j->n * 4);
+    napi_create_typedarray(env, napi_int32_array, j->n, ab, 0, &ta);
+    napi_set_named_property(env, obj, "status", ta);
+    napi_create_buffer_copy(env, j->n * 256, j->proofs, NULL, &buf);
+    napi_set_named_property(env, obj, "proofs", buf);
+    napi_resolve_deferred(env, j->deferred, obj);
+  }
+  napi_delete_reference(env, j->in_ref); napi_delete_reference(env, j->bl_ref);
+  napi_delete_async_work(env, j->work);
+  free(j->status); free(j->proofs); free(j);
+}
+/* proveBatch(prover, circuit, recordsBuffer, blindingBuffer (64 bytes per email: r | s)) -> Promise<{status: Int32Array, proofs: Buffer (256 bytes per email)}> */
+static napi_value ProveBatch(napi_env env, napi_callback_info info) {
+  size_t argc = 4; napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  void* pv = NULL;
+  if (napi_get_value_external(env, argv[0], &pv) != napi_ok || !pv) { napi_throw_type_error(env, NULL, "zkwg: prover handle expected"); return NULL; }
+  zkwg_circuit_t* c = unwrap(env, argv[1]);
+  if (!c) return NULL;
+  void *data, *bl; size_t len, bl_len;
+  NAPI_OK(napi_get_buffer_info(env, argv[2], &data, &len));
+  NAPI_OK(napi_get_buffer_info(env, argv[3], &bl, &bl_len));
+  const uint64_t stride = zkwg_input_stride(c);
+  if (len == 0 || len % stride || bl_len != (len / stride) * 64) { napi_throw_range_error(env, NULL, "zkwg: records / blinding buffers do not match"); return NULL; }
+  prove_job* j = (prove_job*)calloc(1, sizeof(prove_job));
+  j->p = (zkwg_prover_t*)pv; j->in = (const uint8_t*)data; j->blinding = (const uint8_t*)bl; j->n = len / stride;
+  j->status = (int32_t*)calloc(j->n, 4); j->proofs = (uint8_t*)calloc(j->n, 256);
+  napi_value promise, name;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_reference(env, argv[2], 1, &j->in_ref));
+  NAPI_OK(napi_create_reference(env, argv[3], 1, &j->bl_ref));
+  NAPI_OK(napi_create_string_utf8(env, "zkwg.proveBatch", NAPI_AUTO_LENGTH, &name));
+  NAPI_OK(napi_create_async_work(env, NULL, name, prove_execute, prove_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
 /* symText(circuit) -> the layout's symbol table in `.sym` line format (zkwg_write_sym) */
 static napi_value SymText(napi_env env, napi_callback_info info) {
   size_t argc = 1; napi_value argv[1];
@@ -440,6 +537,8 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"symText", NULL, SymText, NULL, NULL, NULL, napi_default, NULL},
       {"r1csLoad", NULL, R1csLoad, NULL, NULL, NULL, napi_default, NULL},
       {"r1csCheck", NULL, R1csCheck, NULL, NULL, NULL, napi_default, NULL},
+      {"createProver", NULL, CreateProver, NULL, NULL, NULL, napi_default, NULL},
+      {"proveBatch", NULL, ProveBatch, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d);
   return exports;

@@ -91,9 +91,17 @@ class ProvingKey:
                           raw1[0:64], raw1[64:128], raw2[0:128], raw1[128:192], raw2[128:256])
 
 
+class _KeyStruct(C.Structure):
+    _fields_ = [("n_wires", C.c_uint64), ("n_public", C.c_uint64), ("log2_domain", C.c_uint64),
+                ("a", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p), ("c", C.c_void_p), ("h", C.c_void_p), ("bases_on_device", C.c_int),
+                ("alpha1", C.c_uint8 * 64), ("beta1", C.c_uint8 * 64), ("beta2", C.c_uint8 * 128), ("delta1", C.c_uint8 * 64), ("delta2", C.c_uint8 * 128)]
+
+
 class Prover:
     """groth16.prove for the emails of a prepared batch.  `circuit`: a device handle whose constraint system `r1cs` (bytes of an
-    `.r1cs` over its witness layout, WITH the nPublic + 1 rows snarkjs appends to A -- zkwg.r1cs.append_public_rows) is attached here."""
+    `.r1cs` over its witness layout, WITH the nPublic + 1 rows snarkjs appends to A -- zkwg.r1cs.append_public_rows) is attached here.
+    prove_batch is include/zkwg.h's zkwg_prover_prove_prepared (several proofs in flight, what a Node host binds too); prove_prepared
+    runs the same stages one call at a time from Python and keeps the five sums (tests compare each with its discrete logarithm)."""
 
     def __init__(self, circuit, r1cs, n_constraints, key, stream=None):
         import torch
@@ -108,6 +116,21 @@ class Prover:
         if circuit.abc_bytes != 96 * self.m:
             raise ZkwgError("n_constraints does not match the attached system")
         self.dev = torch.device("cuda", circuit.device)
+        self.last_sums = None
+        self._single = False
+        self._h, self._slots_n = None, 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.zkwg_prover_destroy(self._h)
+            self._h = None
+
+    def _plans(self):
+        """the Python-side plans of prove_prepared (built on first use)"""
+        if self._single:
+            return
+        import torch
+        circuit, key = self.c, self.key
         self.ntt = Ntt(key.power, device=circuit.device)
         d = circuit.device
         self.msm_a = _DeviceMsm(key.d_a, 1, d)
@@ -122,11 +145,12 @@ class Prover:
         self.d_abc = torch.empty(circuit.abc_bytes, dtype=torch.uint8, device=self.dev)
         self.d_h = torch.empty(32 << key.power, dtype=torch.uint8, device=self.dev)
         self.d_ntt_work = torch.empty(self.ntt.work_bytes(1), dtype=torch.uint8, device=self.dev)
-        self.last_sums = None
+        self._single = True
 
     def prove_prepared(self, d_in, n, d_scratch, index, r, s, stream=None):
         """the proof of email `index` of a batch of n prepared by circuit.prepare_device(d_in, n, ...): {'pi_a': (x, y), 'pi_b':
         ((x0, x1), (y0, y1)), 'pi_c': (x, y)} as standard-form integers (snarkjs proof.json without the projective ones)"""
+        self._plans()
         c, k = self.c, self.key
         c.expand_device(d_in, n, d_scratch, index, 1, self.d_wit, stream)
         c.expand_abc_device(d_in, n, d_scratch, index, 1, self.d_abc, stream, montgomery=True)
@@ -146,61 +170,51 @@ class Prover:
         i = lambda b, j: int.from_bytes(bytes(b)[32 * j:32 * j + 32], "little")
         return {"pi_a": (i(pa, 0), i(pa, 1)), "pi_b": ((i(pb, 0), i(pb, 1)), (i(pb, 2), i(pb, 3))), "pi_c": (i(pc, 0), i(pc, 1))}
 
-    # ---- several proofs in flight -------------------------------------------------------------------------------------------
-    # A multi-exponentiation ends in a few hundred dependent group operations on a handful of lanes (bucket tree, Horner over the
-    # windows): a proof at a time leaves the chip idle most of the time.  `slots` proofs run on `slots` streams, each with its own
-    # witness / A.w|B.w|C.w / H / work buffers; nothing synchronises until all of a wave are enqueued.
-    def _slot(self, j):
-        import torch
-        if not hasattr(self, "_slots"):
-            self._slots = []
-        while len(self._slots) <= j:
-            c, k = self.c, self.key
-            new = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-            work = new(self.d_msm_work.numel() + 256)
-            self._slots.append({"wit": new(c.witness_bytes), "abc": new(c.abc_bytes), "h": new(32 << k.power), "ntt": new(self.ntt.work_bytes(1)),
-                                "work": work[(-work.data_ptr()) % 256:], "sums": torch.zeros(5 * 256, dtype=torch.uint8, device=self.dev),
-                                "stream": torch.cuda.Stream(device=self.dev)})
-        return self._slots[j]
+    # ---- several proofs in flight: include/zkwg.h zkwg_prover_* ---------------------------------------------------------------------
+    def _native(self, slots):
+        if self._h is not None and self._slots_n >= slots:
+            return self._h
+        if self._h is not None:
+            self.lib.zkwg_prover_destroy(self._h)
+            self._h = None
+        k = self.key
+        ks = _KeyStruct(k.n_wires, k.n_public, k.power, k.d_a.data_ptr(), k.d_b1.data_ptr(), k.d_b2.data_ptr(), k.d_c.data_ptr(), k.d_h.data_ptr(), 1)
+        for name, size in (("alpha1", 64), ("beta1", 64), ("beta2", 128), ("delta1", 64), ("delta2", 128)):
+            C.memmove(getattr(ks, name), getattr(k, name), size)
+        h = C.c_void_p()
+        _check(self.lib.zkwg_prover_create(self.c.h, self.c.device, None, 0, self.m, C.byref(ks), slots, C.byref(h)))
+        self._h, self._slots_n = h, slots
+        return h
+
+    @staticmethod
+    def _proofs_from_bytes(raw, count):
+        i = lambda o: int.from_bytes(raw[o:o + 32], "little")
+        out = []
+        for q in range(count):
+            o = 256 * q
+            out.append({"pi_a": (i(o), i(o + 32)), "pi_b": ((i(o + 64), i(o + 96)), (i(o + 128), i(o + 160))), "pi_c": (i(o + 192), i(o + 224))})
+        return out
 
     def prove_batch(self, d_in, n, d_scratch, indices, blinding, slots=8):
-        """proofs of the emails `indices` of a prepared batch; blinding = [(r, s)] per email -> list of proof dicts (prove_prepared's form)"""
-        import torch
-        c, k = self.c, self.key
-        out = []
-        cur = torch.cuda.current_stream(self.dev)
-        for w0 in range(0, len(indices), slots):
-            wave = list(range(w0, min(w0 + slots, len(indices))))
-            for j, q in enumerate(wave):
-                S = self._slot(j)
-                st = S["stream"]
-                st.wait_stream(cur)
-                e = indices[q]
-                c.expand_device(d_in, n, d_scratch, e, 1, S["wit"], st)
-                c.expand_abc_device(d_in, n, d_scratch, e, 1, S["abc"], st, montgomery=True)
-                self.ntt.h_evaluations_device(S["abc"], c.abc_bytes, self.m, 1, S["ntt"], S["h"], stream=st)
-                wit, sums = S["wit"].data_ptr(), S["sums"].data_ptr()
-                self.msm_a.enqueue(wit, False, True, S["work"], sums, st)
-                self.msm_b1.enqueue(wit, False, True, S["work"], sums + 256, st)
-                self.msm_b2.enqueue(wit, False, True, S["work"], sums + 512, st)
-                self.msm_c.enqueue(wit + 32 * (k.n_public + 1), False, True, S["work"], sums + 768, st)
-                self.msm_h.enqueue(S["h"].data_ptr(), True, False, S["work"], sums + 1024, st)
-            for j, q in enumerate(wave):
-                S = self._slot(j)
-                S["stream"].synchronize()
-                raw = bytes(S["sums"].cpu().numpy())
-                pts = {}
-                for name, off, group in (("a", 0, 1), ("b1", 256, 1), ("b2", 512, 2), ("c", 768, 1), ("h", 1024, 1)):
-                    o = (C.c_uint8 * (64 if group == 1 else 128))()
-                    _check(self.lib.zkwg_msm_finish_host(group, raw[off:off + (128 if group == 1 else 256)], 1, o))
-                    pts[name] = bytes(o)
-                r, s_ = blinding[q]
-                pa, pb, pc = (C.c_uint8 * 64)(), (C.c_uint8 * 128)(), (C.c_uint8 * 64)()
-                _check(self.lib.zkwg_groth16_assemble(pts["a"], pts["b1"], pts["b2"], pts["c"], pts["h"], k.alpha1, k.beta1, k.beta2, k.delta1, k.delta2,
-                                                      int(r % R).to_bytes(32, "little"), int(s_ % R).to_bytes(32, "little"), pa, pb, pc))
-                i = lambda b, jj: int.from_bytes(bytes(b)[32 * jj:32 * jj + 32], "little")
-                out.append({"pi_a": (i(pa, 0), i(pa, 1)), "pi_b": ((i(pb, 0), i(pb, 1)), (i(pb, 2), i(pb, 3))), "pi_c": (i(pc, 0), i(pc, 1))})
-        return out
+        """proofs of the emails `indices` of a prepared batch (complete: synchronise the preparing stream first); blinding = [(r, s)] per
+        email -> list of proof dicts (prove_prepared's form).  `slots` proofs are in flight, each on its own stream."""
+        h = self._native(slots)
+        idx = (C.c_uint64 * len(indices))(*indices)
+        bl = b"".join(int(r % R).to_bytes(32, "little") + int(s % R).to_bytes(32, "little") for r, s in blinding)
+        out = (C.c_uint8 * (256 * len(indices)))()
+        _check(self.lib.zkwg_prover_prove_prepared(h, d_in.data_ptr(), n, d_scratch.data_ptr(), idx, len(indices), bl, out))
+        return self._proofs_from_bytes(bytes(out), len(indices))
+
+    def prove_records(self, records, blinding, slots=8):
+        """inputs -> proofs (zkwg_prover_prove_batch): packed input records on the host -> (status list, proofs; None for a failed email)"""
+        n = len(records) // self.c.in_stride
+        h = self._native(slots)
+        bl = b"".join(int(r % R).to_bytes(32, "little") + int(s % R).to_bytes(32, "little") for r, s in blinding)
+        st = (C.c_int32 * n)()
+        out = (C.c_uint8 * (256 * n))()
+        _check(self.lib.zkwg_prover_prove_batch(h, bytes(records), n, bl, st, out))
+        proofs = self._proofs_from_bytes(bytes(out), n)
+        return list(st), [p if st[i] == 0 else None for i, p in enumerate(proofs)]
 
     @staticmethod
     def proof_json(p):
