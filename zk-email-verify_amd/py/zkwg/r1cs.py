@@ -884,7 +884,7 @@ def append_public_rows(constraints, n_public):
 
 
 def email_verifier_r1cs(symbols, N, M, enable_header_masking=0, enable_body_masking=0, remove_soft_line_breaks_flag=0,
-                        ignore_body_hash_check=0):
+                        ignore_body_hash_check=0, public_rows=False):
     """bytes of the `.r1cs` file of EmailVerifier(N, M, 121, 17, 0, flags...) over the kept-v1 wires `symbols`
     ([(slot, name)], zkwg.Circuit.symbols()): public outputs (pubkeyHash, shaHi, shaLo, masked arrays), 17 public
     inputs (pubkey), the rest private."""
@@ -893,8 +893,12 @@ def email_verifier_r1cs(symbols, N, M, enable_header_masking=0, enable_body_mask
     if ignore_body_hash_check:
         n_out = 3 + (N if enable_header_masking else 0)
         n_prv = N + 1 + 17 + (N if enable_header_masking else 0)
+        if public_rows:
+            cons = append_public_rows(cons, n_out + 17)
         return write_r1cs(len(symbols), cons, n_pub_out=n_out, n_pub_in=17, n_prv_in=n_prv)
     n_out = 3 + (N if enable_header_masking else 0) + (M if enable_body_masking else 0)
+    if public_rows:      # the system a snarkjs zkey is built over (the prover attaches this one)
+        cons = append_public_rows(cons, n_out + 17)
     n_prv = N + 1 + 17 + 1 + 32 + M + 1 + (N if enable_header_masking else 0) + (M if enable_body_masking else 0) + \
         (M if remove_soft_line_breaks_flag else 0)
     return write_r1cs(len(symbols), cons, n_pub_out=n_out, n_pub_in=17, n_prv_in=n_prv)
@@ -914,6 +918,8 @@ def _main():
     ap.add_argument("--remove-soft-line-breaks", type=int, default=0)
     ap.add_argument("-o", "--output", required=True, help=".r1cs file to write")
     ap.add_argument("--sym", help="also write the layout's .sym file here")
+    ap.add_argument("--public-rows", type=int, default=0,
+                    help="1: append the nPublic + 1 rows snarkjs' zkey_new adds to A (the system a prover attaches; email-verifier only)")
     a = ap.parse_args()
     if a.main == "sha256-bytes":
         c = zkwg.Circuit(zkwg.MAIN_SHA256_BYTES, max_header=a.max_header, max_body=0, device=-1)
@@ -930,7 +936,7 @@ def _main():
                          remove_soft_line_breaks=a.remove_soft_line_breaks)
         sym = c.symbols()
         data = email_verifier_r1cs(sym, a.max_header, a.max_body, a.enable_header_masking, a.enable_body_masking,
-                                   a.remove_soft_line_breaks, a.ignore_body_hash_check)
+                                   a.remove_soft_line_breaks, a.ignore_body_hash_check, public_rows=bool(a.public_rows))
     with open(a.output, "wb") as f:
         f.write(data)
     if a.sym:
