@@ -170,6 +170,7 @@ int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, u
     if (R.start != covered) return -1;      // the runs tile the region
     for (u32 r = 0; r < R.nslots; ++r) {
       const u32 i = r / R.period, q = r % R.period;
+      if (R.dense != 0xffffffffu) { words[R.start + r] = zk_netq_word(D, R.dense, R.period, R.pos0, i, q, small.data()); continue; }   // (ZkDecNetQ)
       words[R.start + r] = zk_netp_word(D, N.pd[2 * (R.pd0 + q)], N.pd[2 * (R.pd0 + q) + 1], R.pos0, i, R.start + r, small.data());
     }
     covered += R.nslots;

@@ -542,7 +542,10 @@ struct Net {
   //     backward    tabs[offB + ((bstate * fdim + fstate) * 256 + byte) * nB + col]
   // or says that the evaluator left the word in the image.  zk_expand decodes a table-served slot from the position word
   // (byte | fstate << 8 | bstate << 16, written by zk_net_eval's prologue): the image holds evaluated words only.
-  struct Run { u32 start, nslots, period, pd0, pos0; };   // pos0: the position the run's descriptors are relative to
+  struct Run { u32 start, nslots, period, pd0, pos0, dense; };   // pos0: the position the run's descriptors are relative to
+  // dense != 0xffffffff: a long run all of whose slots are byte-local or forward-chain signals of the run's own position has a DENSE table
+  // tabs[dense + ((fstate * 256 + byte) * period + q)] -- one row per (forward state, byte), one column per slot of the period -- so that
+  // zk_expand reads position word -> table word with no descriptor in between, the lanes of a wavefront reading consecutive words
   std::vector<Run> runs;
   std::vector<u32> pd;               // 2 words per descriptor: [type << 30 | column] [position of period 0 minus the run's pos0 (signed; 0 for nearly all)]; type 0 evaluated, 1 byte-local, 2 forward, 3 backward
   std::vector<u32> tabs;             // transposed tables, L | F | B
@@ -1471,6 +1474,37 @@ struct Elab {
       for (u32 t = 0; t < net.nL; ++t) for (u32 v = 0; v < 256; ++v) net.tabs[(size_t)v * net.nL + t] = net.fn_tab[(size_t)cols[1][t] * 256 + v];
       for (u32 t = 0; t < net.nF; ++t) for (size_t c = 0; c < fcells; ++c) net.tabs[net.offF + c * net.nF + t] = net.chain.tab[cols[2][t] * fcells + c];
       for (u32 t = 0; t < net.nB; ++t) for (size_t c = 0; c < bcells; ++c) net.tabs[net.offB + c * net.nB + t] = net.bchain.tab[cols[3][t] * bcells + c];
+    }
+    // Dense tables for the long runs (the per-byte component block of a regex circuit: 96 % of the region).  Rows = (forward state, byte);
+    // a byte-local column repeats its 256 words in every state's rows.  rows x period words: 6.5 MB for the stand-in (29 states, period
+    // 220), 14 MB at the real circuit's size -- read 256 contiguous bytes per wavefront, and only the rows of (state, byte) pairs that occur.
+    {
+      const u32 frows = std::max<u32>(net.chain.smax, 1u) * 256u;
+      const size_t fcells = (size_t)net.chain.smax * 256;
+      for (Net::Run& R : net.runs) {
+        R.dense = 0xffffffffu;
+        if (R.period < 32 || R.nslots < 64 * R.period || getenv("ZKWG_NET_DENSE_OFF")) continue;
+        bool ok = true;
+        for (u32 q = 0; q < R.period && ok; ++q) {
+          const u32 e0 = net.pd[2 * (R.pd0 + q)], e1 = net.pd[2 * (R.pd0 + q) + 1], ty = e0 >> 30;
+          ok = (ty == 1u || ty == 2u) && e1 == 0u;
+        }
+        const size_t words = (size_t)frows * R.period;
+        if (!ok || words * 4 > (64u << 20) || net.tabs.size() + words >= (1u << 30)) continue;
+        R.dense = (u32)net.tabs.size();
+        net.tabs.resize(net.tabs.size() + words, 0);
+        for (u32 q = 0; q < R.period; ++q) {
+          const u32 e0 = net.pd[2 * (R.pd0 + q)], ty = e0 >> 30, col = e0 & 0x3fffffffu;
+          for (u32 row = 0; row < frows; ++row) {
+            const u32 byte = row & 255u, fs = row >> 8;
+            u32 w;
+            if (ty == 1u) w = net.tabs[(size_t)byte * net.nL + col];
+            else w = fs < net.chain.smax ? net.tabs[net.offF + ((size_t)fs * 256 + byte) * net.nF + col] : 0u;
+            net.tabs[R.dense + (size_t)row * R.period + q] = w;
+          }
+        }
+        (void)fcells;
+      }
     }
     if (getenv("ZKWG_DEBUG_NET")) {
       fprintf(stderr, "[zkwg] region: %u slots in %zu runs, %zu descriptors, tables %u + %u + %u columns (%.1f MB)\n", n, net.runs.size(), net.pd.size() / 2,

@@ -287,6 +287,20 @@ struct ZkDecNetP {
   }
 };
 
+// A long run of the region with a dense table (zkwg_circom.h finish_region): position word -> table word, the chain the built-in DFA
+// segments have (entry -> position word -> value); consecutive lanes read consecutive words of one row.
+struct ZkDecNetQ {
+  const u32* __restrict__ small; const ZkNetDec* __restrict__ D; u32 dense, P, magic, pos0; int half;
+  ZK_DEC ZkDecNetQ(const ZkSeg& sg, const ZkCtx& cx) : small(cx.small), D(cx.nd), dense(sg.src), P(sg.a), magic(sg.pad), pos0(sg.b), half(cx.half) {}
+  ZK_DEC u32 operator()(u32 r) const {
+    const u32 i = zk_udiv(r, P, magic), q = r - i * P;
+    const u32 w = zk_netq_word(*D, dense, P, pos0, i, q, small);
+    const int v = (int)(w << 1) >> 1;
+    if (w & 0x80000000u) return zk_inv_code(v, half);
+    return v >= 0 ? (u32)v : (ZK_REF_MINUS | (u32)(-v));
+  }
+};
+
 // every segment type with its decoder: ZK_FOR_SEG_TYPES(X) expands X(type, Decoder) once per type
 #define ZK_FOR_SEG_TYPES(X)                                                                                           \
   X(ZSEG_SMALL, ZkDecSmall) X(ZSEG_FR, ZkDecFr) X(ZSEG_BITS, ZkDecBits)                                                \
@@ -294,7 +308,7 @@ struct ZkDecNetP {
   X(ZSEG_SHA_T2, ZkDecSha<ZK_T2_SLOTS ZK_COMMA 5>) X(ZSEG_ISZ, ZkDecIsz) X(ZSEG_SEL, ZkDecSel) X(ZSEG_IN8, ZkDecIn8)   \
   X(ZSEG_IN8MASK, ZkDecIn8Mask) X(ZSEG_IN8BITS, ZkDecIn8Bits) X(ZSEG_LIMB, ZkDecLimb) X(ZSEG_LTBITS, ZkDecLtBits)      \
   X(ZSEG_REGSEL, ZkDecRegSel) X(ZSEG_VSHIFT, ZkDecVShift) X(ZSEG_B64BITS, ZkDecB64<false>) X(ZSEG_B64, ZkDecB64<true>) \
-  X(ZSEG_DFA, ZkDecDfa) X(ZSEG_RSLB, ZkDecRslb) X(ZSEG_NETP, ZkDecNetP)
+  X(ZSEG_DFA, ZkDecDfa) X(ZSEG_RSLB, ZkDecRslb) X(ZSEG_NETP, ZkDecNetP) X(ZSEG_NETQ, ZkDecNetQ)
 #define ZK_COMMA ,
 
 // one slot of any segment (pieces that straddle segments, the numbered-circuit expansion and the linear-row kernels

@@ -322,7 +322,8 @@ static inline void zk_walk_bh_regex(ZkWalker& w, const std::string& p, const ZkS
   const u32 nb = N + 1;
   if (w.net) {   // the kept signals of the loaded template, in the compiler's numbering order (zkwg_circom.h layout_walk)
     for (const zkc::Net::Run& R : w.net->runs) {
-      w.seg(ZSEG_NETP, R.nslots, R.pd0, R.period, R.pos0, R.start);
+      if (R.dense != 0xffffffffu) w.seg(ZSEG_NETQ, R.nslots, R.dense, R.period, R.pos0, R.start);
+      else w.seg(ZSEG_NETP, R.nslots, R.pd0, R.period, R.pos0, R.start);
       if (!w.names) w.skip(R.nslots);
       else for (u32 i = 0; i < R.nslots; ++i) w.one(p + w.net->names[R.start + i]);
     }

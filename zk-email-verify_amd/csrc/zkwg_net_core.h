@@ -111,6 +111,11 @@ ZK_HD u32 zk_netp_addr(const ZkNetDec& D, u32 d0, u32 pw) {
   const u32 base = t == ZKNP_LOCAL ? 0u : (t == ZKNP_FWD ? D.offF : D.offB);
   return base + row * n + col;
 }
+// element (period i, slot q) of a run with a dense table at tab[dense ...] (zkwg_circom.h finish_region): rows = (forward state, byte)
+ZK_HD u32 zk_netq_word(const ZkNetDec& D, u32 dense, u32 period, u32 pos0, u32 i, u32 q, const u32* small) {
+  const u32 pw = small[D.m_net_pw + pos0 + i];
+  return D.tab[dense + (((pw >> 8) & 255u) * 256u + (pw & 255u)) * period + q];
+}
 // stored word of region slot `slot` = element (period i, descriptor (d0, d1)) of a run whose descriptors are relative to position
 // pos0; small = the email's image
 ZK_HD u32 zk_netp_word(const ZkNetDec& D, u32 d0, u32 d1, u32 pos0, u32 i, u32 slot, const u32* small) {

@@ -54,7 +54,9 @@ enum ZkSegType : u32 {
   ZSEG_NETP = 21,   // one periodic run of a loaded regex template's region (zkwg_circom.h finish_region): src = first period descriptor, a = period,
                     // b = the position the descriptors are relative to, c = region index of the run's first slot; slot r = descriptor
                     // src + r % a at position b + r / a (+ the descriptor's own offset) (zkwg_net_core.h ZkNetDec)
-  ZSEG_NTYPES = 22
+  ZSEG_NETQ = 22,   // a long run of the same region with a DENSE table: src = the table's offset in the region's tables, a = period, b = position of
+                    // period 0; slot r = table[(fstate, byte of position b + r / a)][r % a] -- no descriptor (zkwg_net_core.h zk_netq_word)
+  ZSEG_NTYPES = 23
 };
 
 // ZSEG_RSLB kinds (helpers/remove-soft-line-breaks.circom:14-126); enc = the emailBody bytes at src
@@ -107,7 +109,7 @@ ZK_HD u32 zk_seg_period(const ZkSeg& g) {
     case ZSEG_LTBITS: return g.a + 1u;
     case ZSEG_REGSEL: return g.a + 7u;
     case ZSEG_VSHIFT: return g.a;
-    case ZSEG_NETP: return g.a;
+    case ZSEG_NETP: case ZSEG_NETQ: return g.a;
     default: return 0;
   }
 }
