@@ -8,6 +8,7 @@
 #include "zkwg_fpmul_core.h"
 #include "zkwg_poseidon_core.h"
 #include "zkwg_poseidon_sparse.h"
+#include "zkwg_poseidon29.h"
 #include "zkwg_r1cs.h"
 #include "zkwg_regex_core.h"
 
@@ -81,6 +82,31 @@ int ht_poseidon_sparse(uint32_t t, const void* inputs, void* emit, void* hash) {
   Fr tmp[17];
   if (t == 3) h = zk_poseidon_sparse<3>(st.data(), 1, tab.data(), rp, (Fr*)emit, tmp, 1);
   else if (t == 17) h = zk_poseidon_sparse<17>(st.data(), 1, tab.data(), rp, (Fr*)emit, tmp, 1);
+  else return 2;
+  *(Fr*)hash = h;
+  return 0;
+}
+// the same permutation through the 29-bit-limb evaluator zk_rslb_chunks runs (zkwg_poseidon29.h); state laid out limb-major as in LDS
+int ht_poseidon29(uint32_t t, uint32_t variant, const void* inputs, void* emit, void* hash) {
+  const u32 rp = ZK_POS_RP_TAB[t - 2];
+  std::vector<Fr> C, M, tab;
+  std::vector<u32> tab29;
+  build_poseidon_constants(t, 8, rp, C, M);
+  if (!zk_build_poseidon_sparse(t, rp, C, M, tab)) return 1;
+  zk_build_poseidon29(t, rp, tab, tab29);
+  std::vector<u32> st(9 * t, 0u);
+  for (u32 j = 1; j < t; ++j) {
+    u32 l[9];
+    zk_l29_from_fr(((const Fr*)inputs)[j - 1], l);
+    for (u32 i = 0; i < 9; ++i) st[i * t + j] = l[i];
+  }
+  Fr h;
+  if (t == 3 && variant == 0) h = zk_poseidon29<3, 0>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
+  else if (t == 3 && variant == 3) h = zk_poseidon29<3, 3>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
+  else if (t == 17 && variant == 0) h = zk_poseidon29<17, 0>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
+  else if (t == 17 && variant == 1) h = zk_poseidon29<17, 1>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
+  else if (t == 17 && variant == 2) h = zk_poseidon29<17, 2>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
+  else if (t == 17 && variant == 3) h = zk_poseidon29<17, 3>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
   else return 2;
   *(Fr*)hash = h;
   return 0;

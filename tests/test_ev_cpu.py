@@ -118,8 +118,10 @@ def test_poseidon_sparse_host_core_matches_oracle():
     lib = hosttest.load()
     rng = random.Random(5)
     for t in (3, 17):
-        for trial in range(2):
+        for trial in range(3):
             xs = [rng.randrange(256) for _ in range(t - 1)] if trial == 0 else [rng.randrange(poseidon.P) for _ in range(t - 1)]
+            if trial == 2:
+                xs = [poseidon.P - 1] * (t - 1)
             comp = poseidon.Poseidon(t - 1, xs)
             kept = witness_kept(comp)[1:]
             n = 3 * (8 * t + poseidon.N_ROUNDS_P[t - 2])
@@ -127,7 +129,12 @@ def test_poseidon_sparse_host_core_matches_oracle():
             inp = b"".join(x.to_bytes(32, "little") for x in xs)
             emit = C.create_string_buffer(32 * n)
             h = C.create_string_buffer(32)
-            assert lib.ht_poseidon_sparse(t, inp, emit, h) == 0
-            assert int.from_bytes(h.raw, "little") == comp.o
-            got = [int.from_bytes(emit.raw[32 * i:32 * i + 32], "little") for i in range(n)]
-            assert got == kept
+            # 4 x 64-bit words | 9 x 29-bit limbs (zk_rslb_chunks' evaluator) in each of its variants
+            fns = [lambda *a: lib.ht_poseidon_sparse(*a)] + [(lambda *a, v=v: lib.ht_poseidon29(a[0], v, *a[1:])) for v in ((0, 3) if t == 3 else (0, 1, 2, 3))]
+            for fn in fns:
+                emit = C.create_string_buffer(32 * n)
+                h = C.create_string_buffer(32)
+                assert fn(t, inp, emit, h) == 0
+                assert int.from_bytes(h.raw, "little") == comp.o
+                got = [int.from_bytes(emit.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+                assert got == kept

@@ -14,6 +14,38 @@ from conftest import ROOT
 CSRC = os.path.join(ROOT, "zk-email-verify_amd", "csrc")
 
 
+def _resource_usage(src, obj):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", os.path.join(CSRC, src),
+                        "-o", str(obj), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    info, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            info[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            info[cur][m.group(1).strip()] = int(m.group(2))
+    return info
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
+def test_soft_line_break_chunk_hashes_use_no_scratch_memory(tmp_path):
+    # zk_rslb_chunks (one Poseidon(16) per lane, 786 k per batch): the dense mixes hold the old state in registers (153 VGPRs) and
+    # fetch their 153 table limbs 9 at a time; if the compiler hoists those scalar loads, or does not unroll the 17
+    # multiply-accumulates of an output, the state lands in scratch (624 B .. 6 KB per lane were seen on the way)
+    info = _resource_usage("zkwg_kernels_rslb.hip", tmp_path / "rslb.o")
+    ks = [v for name, v in info.items() if "zk_rslb_chunks" in name]
+    assert len(ks) == 4, sorted(info)               # the evaluator's four variants (ZKWG_RSLB_V)
+    for k in ks:
+        assert k.get("ScratchSize") == 0, k
+        assert k["LDS Size"] <= 40 * 1024, k       # 4 wavefronts per CU
+    assert next(v for name, v in info.items() if "zk_rslb_scan" in name).get("ScratchSize") == 0
+
+
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
 def test_streaming_kernels_use_no_scratch_memory_and_keep_their_occupancy(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

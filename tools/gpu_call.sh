@@ -7,7 +7,7 @@
 #   beside        tools/beside.py (which prepare kernel costs zk_expand how much)
 #   bench         the default bench.py line     benchq  the headline only (no PMC / other configs / CPU baseline)
 #   prof          rocprofv3 --kernel-trace --stats of the headline pipeline
-#   rslb          removeSoftLineBreaks = 1 variant      abc  tools/bench_abc.py      o0  tools/bench_full.py
+#   rslb          removeSoftLineBreaks = 1 variant (rslb:<label> appends to <tag>_rslb_variants.json)      abc  tools/bench_abc.py      o0  tools/bench_full.py
 #   pmc:<tool.py> per-kernel HBM traffic of a tool (two rocprofv3 --pmc passes)
 #   env:K=V       export K=V for the following steps
 TAG=$1; shift
@@ -54,6 +54,9 @@ d=json.loads(sys.stdin.readline()); print('headline ${step#benchq:}', d['value']
     rslb) timeout 600 python bench.py --remove-soft-line-breaks 1 --batch 4096 --tile 256 --prep-batch 4096 --ring 4 --steps 12 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 2>/dev/null | tail -1 | tee $OUT/${TAG}_rslb.json | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('rslb', d['value'], d['kernel_ms_per_launch'])" ;;
+    rslb:*) timeout 600 python bench.py --remove-soft-line-breaks 1 --batch 4096 --tile 256 --prep-batch 4096 --ring 4 --steps 12 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 2>/dev/null | tail -1 | tee -a $OUT/${TAG}_rslb_variants.json | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('rslb ${step#rslb:}', d['value'], d['kernel_ms_per_launch'])" ;;
     abc) timeout 900 python tools/bench_abc.py 2>/dev/null | tail -1 | tee $OUT/${TAG}_abc.json | cut -c1-600 ;;
     o0) timeout 900 python tools/bench_full.py 2>/dev/null | tail -1 | tee $OUT/${TAG}_o0.json | cut -c1-600 ;;
     pmc:*) # per-kernel HBM traffic of a tool: two separate rocprofv3 --pmc passes (WRITE_SIZE, FETCH_SIZE; KiB units, FETCH x 2 on gfx950)

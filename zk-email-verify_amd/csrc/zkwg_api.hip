@@ -17,6 +17,7 @@
 #include "zkwg_layout.h"
 #include "zkwg_build.h"
 #include "zkwg_poseidon_sparse.h"
+#include "zkwg_poseidon29.h"
 #include "zkwg_full.h"
 #include "zkwg_o0.h"
 #include "zkwg_o0_dec.h"
@@ -66,6 +67,7 @@ struct zkwg_circuit {
   u32 pos2_off;
   u32 pos_dense_off;
   Fr* d_pos_rs;   // removeSoftLineBreaks: Poseidon(16) then Poseidon(2) sparse-round tables
+  u32* d_pos_l29; // removeSoftLineBreaks: Poseidon(16) table in 29-bit limb form (zkwg_poseidon29.h)
   ZkSeg* d_segs;
   ZkPortionEntry* d_ent;   // zk_expand: one entry per piece of 256 K slots (zkwg_build.h zk_build_entries)
   u32 n_ent;
@@ -74,6 +76,7 @@ struct zkwg_circuit {
   u8* hx_img[2]; u64 hx_bytes;   // pinned staging of downloaded images (host expansion)
   int o0_emails_per_wg;          // emails per workgroup of zk_expand3_o0 (ZKWG_O0_EMAILS_PER_WG, default 16)
   int o0_pipe;                   // zk_expand3_o0 variant (ZKWG_O0_PIPE): 0 plain, 1 one email ahead, 2 (default) batches of 4 emails + short paths for uniform pieces, 3 double-buffered batches
+  int rslb_v;              // zk_rslb_chunks' evaluator variant (ZKWG_RSLB_V = 0..3, zkwg_poseidon29.h)
   int x3_k, x3_k_o0;       // slots per thread of zk_expand3 (kept-v1 / sym layouts) and zk_expand3_o0: 1, 2 or 4 (ZKWG_X3_K, ZKWG_X3_K_O0)
   std::vector<ZkSeg> segs;
   hipStream_t own_stream, copy_stream;
@@ -261,6 +264,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   c->device = -1;
   // tuning knobs (DESIGN.md "zk_expand geometry"): slots per workgroup and threads per workgroup
   auto pick_k = [](const char* name, int dflt, bool k8 = false) { const char* v = getenv(name); const int k = v ? atoi(v) : dflt; return (k == 1 || k == 2 || k == 4 || (k8 && k == 8)) ? k : dflt; };
+  { const char* v = getenv("ZKWG_RSLB_V"); c->rslb_v = v ? (atoi(v) & 3) : 0; }
   c->x3_k = pick_k("ZKWG_X3_K", 4, true);
   c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 1);   // (round 4: 8 KiB pieces, 53 VGPRs = 8 wavefronts per SIMD, software-pipelined over the group's emails)
   c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 16;
@@ -492,13 +496,17 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       ok = zk_build_poseidon_sparse(17, 68, C, M, t16);
       build_poseidon_constants(3, 8, 57, C, M);
       ok = ok && zk_build_poseidon_sparse(3, 57, C, M, t2);
+      std::vector<u32> l29;
+      if (ok) zk_build_poseidon29(17, 68, t16, l29);
+      ok = ok && hipMalloc((void**)&c->d_pos_l29, l29.size() * sizeof(u32)) == hipSuccess &&
+           hipMemcpy(c->d_pos_l29, l29.data(), l29.size() * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess;
       c->pos2_off = (u32)t16.size();
       t16.insert(t16.end(), t2.begin(), t2.end());
       ok = ok && hipMalloc((void**)&c->d_pos_rs, t16.size() * sizeof(Fr)) == hipSuccess &&
            hipMemcpy(c->d_pos_rs, t16.data(), t16.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) {
-      hipFree(c->d_pos); hipFree(c->d_pos_rs);
+      hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_pos_l29);
       hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent);
       delete c;
       return ZKWG_RC_OOM;
@@ -655,7 +663,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
-    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
+    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_pos_l29); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
     free_o0(c->o0d); free_o0(c->abcd);
     hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_pd); hipFree(c->d_net_tabs); hipFree(c->d_netd);
     hipFree(c->d_net_cclass); hipFree(c->d_net_cdelta); hipFree(c->d_net_cmask);
@@ -852,6 +860,7 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.net_cclass = c->d_net_cclass; B.net_cdelta = c->d_net_cdelta; B.net_cmask = c->d_net_cmask;
   B.net_bclass = c->d_net_bclass; B.net_bdelta = c->d_net_bdelta; B.net_bmask = c->d_net_bmask;
   B.pos16 = c->d_pos_rs;
+  B.pos16_l29 = c->d_pos_l29;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
   B.wit = nullptr;
@@ -982,7 +991,15 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     // removeSoftLineBreaks: chunk hashes (one lane per 16-byte chunk), then the serial merge chain + scans
     if (tm) hipEventRecord(evs[++ki], st);
     const u64 units = (u64)ne * s.rs_nch;
-    if (pm & 64u) hipLaunchKernelGGL(zk_rslb_chunks, dim3((u32)((units + 63) / 64)), dim3(64), 0, st, s, B);
+    if (pm & 64u) {
+      const dim3 g((u32)((units + 63) / 64));
+      switch (c->rslb_v) {
+        case 1: hipLaunchKernelGGL(zk_rslb_chunks_v1, g, dim3(64), 0, st, s, B); break;
+        case 2: hipLaunchKernelGGL(zk_rslb_chunks_v2, g, dim3(64), 0, st, s, B); break;
+        case 3: hipLaunchKernelGGL(zk_rslb_chunks_v3, g, dim3(64), 0, st, s, B); break;
+        default: hipLaunchKernelGGL(zk_rslb_chunks_v0, g, dim3(64), 0, st, s, B); break;
+      }
+    }
     if (tm) hipEventRecord(evs[++ki], st);
     if (c->rs_sync) {
       if (pm & 128u) { hipLaunchKernelGGL(zk_rslb_merge, dim3((ne + 64u / ZK_RS_MERGE_LANES - 1u) / (64u / ZK_RS_MERGE_LANES)), dim3(64), 0, st, s, B); hipLaunchKernelGGL(zk_rslb_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B); }

@@ -14,7 +14,10 @@ __global__ void zk_poseidon9_g16(ZkSched s, ZkBufs B);
 __global__ void zk_misc_ev(ZkSched s, ZkBufs B);     // zkwg_kernels_misc.hip
 __global__ void zk_net_eval(ZkSched s, ZkBufs B);    // zkwg_kernels_net.hip
 __global__ void zk_net_scan(ZkSched s, ZkBufs B);
-__global__ void zk_rslb_chunks(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip
+__global__ void zk_rslb_chunks_v0(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip (v0..v3: evaluator variants, zkwg_poseidon29.h)
+__global__ void zk_rslb_chunks_v1(ZkSched s, ZkBufs B);
+__global__ void zk_rslb_chunks_v2(ZkSched s, ZkBufs B);
+__global__ void zk_rslb_chunks_v3(ZkSched s, ZkBufs B);
 #include "zkwg_rslb_wave.h"   // ZK_RS_MERGE_LANES
 __global__ void zk_rslb_merge(ZkSched s, ZkBufs B);
 __global__ void zk_rslb_scan(ZkSched s, ZkBufs B);

@@ -11,10 +11,15 @@
 #include "zkwg_dev.h"
 #include "zkwg_kernels.h"
 #include "zkwg_poseidon_sparse.h"
+#include "zkwg_poseidon29.h"
 #include "zkwg_rslb_wave.h"
 
-__global__ __launch_bounds__(64) void zk_rslb_chunks(ZkSched s, ZkBufs B) {
-  __shared__ Fr st[17 * 64];
+// State in LDS as 9 x 29-bit limbs, limb-major (element j, limb l of lane t at st[(l * 17 + j) * 64 + t]: every access is one
+// conflict-free 32-bit word per lane); the dense mixes copy it into registers.  The whole permutation runs in limb form
+// (zkwg_poseidon29.h); only the 612 emitted S-box signals and the digest are packed into 4 x 64-bit words.
+template <int V>
+__device__ __forceinline__ void zk_rslb_chunks_body(const ZkSched& s, const ZkBufs& B) {
+  __shared__ u32 st[9 * 17 * 64];
   const u32 lane = threadIdx.x;
   const u64 unit = (u64)blockIdx.x * 64 + lane;
   const u32 e = (u32)(unit / s.rs_nch), c = (u32)(unit % s.rs_nch);
@@ -23,15 +28,24 @@ __global__ __launch_bounds__(64) void zk_rslb_chunks(ZkSched s, ZkBufs B) {
   const u32 half = s.rs_nch / 2;   // chunks [0, half): encoded (= emailBody), [half, 2 half): decoded
   const uint4 raw = *(const uint4*)(rec + (c < half ? s.fr[1].in_data + 16u * c : s.in_off[11] + 16u * (c - half)));
   const u32 w[4] = {raw.x, raw.y, raw.z, raw.w};
-  Fr* stl = st + lane;
-  stl[0] = fr_zero();
+  u32* stl = st + lane;
 #pragma unroll
-  for (u32 i = 0; i < 16; ++i) stl[(1 + i) * 64] = fr_from_u64((w[i >> 2] >> (8 * (i & 3))) & 255u);
+  for (u32 l = 0; l < 9; ++l) {
+#pragma unroll
+    for (u32 j = 0; j < 17; ++j) stl[(l * 17 + j) * 64] = (l == 0 && j > 0) ? ((w[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 255u) : 0u;
+  }
   Fr* frv = B.frv + (u64)e * s.img_fr;
-  Fr tmp[17];
-  const Fr h = zk_poseidon_sparse<17>(stl, 64, B.pos16, 68, frv + s.f_rs_hash + zk_rs_chunk_off(c), tmp, 1);
+  const Fr h = zk_poseidon29<17, V>(stl, 64, 17 * 64, B.pos16_l29, 68, frv + s.f_rs_hash + zk_rs_chunk_off(c));
   frv[s.f_rs_chunk + c] = h;
 }
+
+// V = evaluator variant (zkwg_poseidon29.h): which of the four runs is ZKWG_RSLB_V's / the measured default's business (zkwg_api.hip)
+#define ZK_RSLB_CHUNKS(V) \
+  __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void zk_rslb_chunks_v##V(ZkSched s, ZkBufs B) { zk_rslb_chunks_body<V>(s, B); }
+ZK_RSLB_CHUNKS(0)
+ZK_RSLB_CHUNKS(1)
+ZK_RSLB_CHUNKS(2)
+ZK_RSLB_CHUNKS(3)
 
 // The merge chain  _out = Poseidon(2)([_out, chunk_hash])  (utils/hash.circom:76-80) is inherently serial per email:
 // rs_nch - 1 permutations (191 for maxBody = 1536), each 8 full + 57 partial rounds.  Round 3 ran it one LANE per email in

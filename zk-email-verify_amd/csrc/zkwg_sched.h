@@ -292,6 +292,7 @@ struct ZkBufs {
   const Fr* pos_m;       // Poseidon(9) dense tables for the wave-collective small-batch kernel: C[680], M[100] (Montgomery)
   const Fr* pos16;       // Poseidon(16) sparse-round table (zkwg_poseidon_sparse.h), removeSoftLineBreaks only
   const Fr* pos2;        // Poseidon(2)  sparse-round table
+  const u32* pos16_l29;  // Poseidon(16) table in 29-bit limb form (zkwg_poseidon29.h): what zk_rslb_chunks reads
   const Fr* invtab_m;    // zk_expand_mont: the inverse table in Montgomery form
   const u32* net_records; // loaded regex template: 16 words per gate in execution order (zkwg_net_core.h)
   const u32* net_counts;  // loaded regex template: gates per step | flags (0x8000: 64-bit path)
