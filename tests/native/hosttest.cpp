@@ -101,12 +101,12 @@ int ht_poseidon29(uint32_t t, uint32_t variant, const void* inputs, void* emit, 
     for (u32 i = 0; i < 9; ++i) st[i * t + j] = l[i];
   }
   Fr h;
-  if (t == 3 && variant == 0) h = zk_poseidon29<3, 0>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
-  else if (t == 3 && variant == 3) h = zk_poseidon29<3, 3>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
-  else if (t == 17 && variant == 0) h = zk_poseidon29<17, 0>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
-  else if (t == 17 && variant == 1) h = zk_poseidon29<17, 1>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
-  else if (t == 17 && variant == 2) h = zk_poseidon29<17, 2>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
-  else if (t == 17 && variant == 3) h = zk_poseidon29<17, 3>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit);
+  std::vector<u32> stage(9 * 17, 0xdeadbeefu);
+#define HT_P29(TT, VV) if (t == TT && variant == VV) h = zk_poseidon29<TT, VV>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit, stage.data(), 1)
+  HT_P29(3, 0); else HT_P29(3, 3); else HT_P29(3, 7);
+  else HT_P29(17, 0); else HT_P29(17, 1); else HT_P29(17, 2); else HT_P29(17, 3);
+  else HT_P29(17, 4); else HT_P29(17, 5); else HT_P29(17, 6); else HT_P29(17, 7);
+#undef HT_P29
   else return 2;
   *(Fr*)hash = h;
   return 0;

@@ -264,7 +264,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   c->device = -1;
   // tuning knobs (DESIGN.md "zk_expand geometry"): slots per workgroup and threads per workgroup
   auto pick_k = [](const char* name, int dflt, bool k8 = false) { const char* v = getenv(name); const int k = v ? atoi(v) : dflt; return (k == 1 || k == 2 || k == 4 || (k8 && k == 8)) ? k : dflt; };
-  { const char* v = getenv("ZKWG_RSLB_V"); c->rslb_v = v ? (atoi(v) & 3) : 0; }
+  { const char* v = getenv("ZKWG_RSLB_V"); c->rslb_v = v ? (atoi(v) & 7) : 2; }
   c->x3_k = pick_k("ZKWG_X3_K", 4, true);
   c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 1);   // (round 4: 8 KiB pieces, 53 VGPRs = 8 wavefronts per SIMD, software-pipelined over the group's emails)
   c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 16;
@@ -623,8 +623,9 @@ int zkwg_o0_gather_host(const zkwg_circuit_t* c, const uint8_t* kept_witness, ui
     o[Pn.dst[r]] = zk_linear_row(Pn.row_ptr.data(), c->o0_src.data(), Pn.coef.data(), Pn.kind.data(), r, kw);
   return ZKWG_RC_OK;
 }
-// scratch buffer of an n-email batch: [SHA chaining states | bits | small | fr (+256) | Montgomery copies (fr + limbs)]
-struct ZkScratchLayout { u64 off_hst, off_bits, off_small, off_fr, off_frm, total; };
+// scratch buffer of an n-email batch: [SHA chaining states | bits | small | fr (+256) | Montgomery copies (fr + limbs) |
+// removeSoftLineBreaks: zk_rslb_chunks' dense-mix staging, 153 words per 16-byte chunk, word-major (zkwg_poseidon29.h)]
+struct ZkScratchLayout { u64 off_hst, off_bits, off_small, off_fr, off_frm, off_rs_stage, rs_units, total; };
 static ZkScratchLayout scratch_layout(const ZkSched& s, u64 n) {
   ZkScratchLayout L;
   u64 off = 0;
@@ -633,6 +634,8 @@ static ZkScratchLayout scratch_layout(const ZkSched& s, u64 n) {
   L.off_small = off; off += align256(n * (u64)s.img_small * 4);
   L.off_fr = off; off += align256(n * (u64)s.img_fr * 32) + 256;
   L.off_frm = off; off += align256(n * (u64)(s.img_fr + ZK_MONT_LIMBS) * 32);
+  L.rs_units = s.rslb ? (n * (u64)s.rs_nch + 63) / 64 * 64 : 0;
+  L.off_rs_stage = off; off += align256(L.rs_units * 153 * 4);
   L.total = off;
   return L;
 }
@@ -861,6 +864,8 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.net_bclass = c->d_net_bclass; B.net_bdelta = c->d_net_bdelta; B.net_bmask = c->d_net_bmask;
   B.pos16 = c->d_pos_rs;
   B.pos16_l29 = c->d_pos_l29;
+  B.rs_stage = (u32*)(scr + L.off_rs_stage);
+  B.rs_units = L.rs_units;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
   B.wit = nullptr;
@@ -997,6 +1002,10 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
         case 1: hipLaunchKernelGGL(zk_rslb_chunks_v1, g, dim3(64), 0, st, s, B); break;
         case 2: hipLaunchKernelGGL(zk_rslb_chunks_v2, g, dim3(64), 0, st, s, B); break;
         case 3: hipLaunchKernelGGL(zk_rslb_chunks_v3, g, dim3(64), 0, st, s, B); break;
+        case 4: hipLaunchKernelGGL(zk_rslb_chunks_v4, g, dim3(64), 0, st, s, B); break;
+        case 5: hipLaunchKernelGGL(zk_rslb_chunks_v5, g, dim3(64), 0, st, s, B); break;
+        case 6: hipLaunchKernelGGL(zk_rslb_chunks_v6, g, dim3(64), 0, st, s, B); break;
+        case 7: hipLaunchKernelGGL(zk_rslb_chunks_v7, g, dim3(64), 0, st, s, B); break;
         default: hipLaunchKernelGGL(zk_rslb_chunks_v0, g, dim3(64), 0, st, s, B); break;
       }
     }

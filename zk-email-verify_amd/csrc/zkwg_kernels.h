@@ -18,6 +18,10 @@ __global__ void zk_rslb_chunks_v0(ZkSched s, ZkBufs B); // zkwg_kernels_rslb.hip
 __global__ void zk_rslb_chunks_v1(ZkSched s, ZkBufs B);
 __global__ void zk_rslb_chunks_v2(ZkSched s, ZkBufs B);
 __global__ void zk_rslb_chunks_v3(ZkSched s, ZkBufs B);
+__global__ void zk_rslb_chunks_v4(ZkSched s, ZkBufs B);
+__global__ void zk_rslb_chunks_v5(ZkSched s, ZkBufs B);
+__global__ void zk_rslb_chunks_v6(ZkSched s, ZkBufs B);
+__global__ void zk_rslb_chunks_v7(ZkSched s, ZkBufs B);
 #include "zkwg_rslb_wave.h"   // ZK_RS_MERGE_LANES
 __global__ void zk_rslb_merge(ZkSched s, ZkBufs B);
 __global__ void zk_rslb_scan(ZkSched s, ZkBufs B);

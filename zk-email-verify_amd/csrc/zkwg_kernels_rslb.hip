@@ -35,7 +35,7 @@ __device__ __forceinline__ void zk_rslb_chunks_body(const ZkSched& s, const ZkBu
     for (u32 j = 0; j < 17; ++j) stl[(l * 17 + j) * 64] = (l == 0 && j > 0) ? ((w[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 255u) : 0u;
   }
   Fr* frv = B.frv + (u64)e * s.img_fr;
-  const Fr h = zk_poseidon29<17, V>(stl, 64, 17 * 64, B.pos16_l29, 68, frv + s.f_rs_hash + zk_rs_chunk_off(c));
+  const Fr h = zk_poseidon29<17, V>(stl, 64, 17 * 64, B.pos16_l29, 68, frv + s.f_rs_hash + zk_rs_chunk_off(c), B.rs_stage + unit, (size_t)B.rs_units);
   frv[s.f_rs_chunk + c] = h;
 }
 
@@ -46,6 +46,10 @@ ZK_RSLB_CHUNKS(0)
 ZK_RSLB_CHUNKS(1)
 ZK_RSLB_CHUNKS(2)
 ZK_RSLB_CHUNKS(3)
+ZK_RSLB_CHUNKS(4)
+ZK_RSLB_CHUNKS(5)
+ZK_RSLB_CHUNKS(6)
+ZK_RSLB_CHUNKS(7)
 
 // The merge chain  _out = Poseidon(2)([_out, chunk_hash])  (utils/hash.circom:76-80) is inherently serial per email:
 // rs_nch - 1 permutations (191 for maxBody = 1536), each 8 full + 57 partial rounds.  Round 3 ran it one LANE per email in

@@ -44,8 +44,16 @@ typedef const u32* ZkTab29;
 // cannot move above the instructions that produce x.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZK_P29_AFTER(p, x) asm volatile("" : "+s"(p) : "v"((u32)(x)))
+// ZK_P29_ARRIVED(a, b) emits nothing either, but uses the 9 + 9 limbs: the compiler puts the wait for their loads HERE; with the
+// scheduling barrier behind it the next operands' loads are issued after that wait and before the 81 multiply-adds that hide them
+#define ZK_P29_ARRIVED(a, b)                                                                                                          \
+  asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "s"(b[0]), \
+               "s"(b[1]), "s"(b[2]), "s"(b[3]), "s"(b[4]), "s"(b[5]), "s"(b[6]), "s"(b[7]), "s"(b[8]))
+#define ZK_P29_BAR() __builtin_amdgcn_sched_barrier(0)
 #else
 #define ZK_P29_AFTER(p, x) ((void)0)
+#define ZK_P29_ARRIVED(a, b) ((void)0)
+#define ZK_P29_BAR() ((void)0)
 #endif
 
 struct ZkW29 { u64 c[17]; };
@@ -209,8 +217,9 @@ ZK_HD void zk_p29_sbox(u32 (&x)[9], Fr* emit) {
 
 // st[i] = sum_j y_j mat[i][j] for all i.  State element j, limb l at st[l * ls + j * js].  The old state is read into registers first
 // (static indices: the j loop is unrolled, the i loop is not), so the result overwrites the state in place.
+// the first n_out outputs only (the permutation's last mix feeds nothing but element 0)
 template <int T>
-ZK_HD void zk_p29_dense(u32* st, const u32 js, const u32 ls, ZkTab29 mat) {
+ZK_HD void zk_p29_dense(u32* st, const u32 js, const u32 ls, ZkTab29 mat, const u32 n_out) {
   u32 y[T][9];
 #pragma unroll T
   for (int j = 0; j < T; ++j) {
@@ -218,7 +227,7 @@ ZK_HD void zk_p29_dense(u32* st, const u32 js, const u32 ls, ZkTab29 mat) {
     for (int l = 0; l < 9; ++l) y[j][l] = st[l * ls + j * js];
   }
 #pragma nounroll
-  for (u32 i = 0; i < (u32)T; ++i) {
+  for (u32 i = 0; i < n_out; ++i) {
     ZkTab29 row = mat + (size_t)i * T * 9;
     ZkW29 w;
     zk_w29_zero(w);
@@ -237,12 +246,68 @@ ZK_HD void zk_p29_dense(u32* st, const u32 js, const u32 ls, ZkTab29 mat) {
   }
 }
 
+// The same mix with NOTHING held in registers across outputs: 446 of a SIMD's 512 registers per lane is what the version above costs
+// (153 of them the old state), and zk_expand -- 64 registers -- then shares the SIMD with one wavefront instead of six while this
+// kernel runs beside it.  Here every multiply-accumulate reads its state element from LDS and its row limbs by
+// scalar loads, one step ahead (two operand sets, A and B); the outputs cannot overwrite the state they are computed from, so they
+// wait in `stage` (global memory, word k of this lane at stage[k * ss]: a wavefront's lanes are adjacent) and are copied back at the end.
+template <int T>
+ZK_HD void zk_p29_dense_lean(u32* st, const u32 js, const u32 ls, ZkTab29 mat, const u32 n_out, u32* stage, const size_t ss) {
+#pragma nounroll
+  for (u32 i = 0; i < n_out; ++i) {
+    ZkTab29 row = mat + (size_t)i * T * 9;
+    ZkW29 w;
+    zk_w29_zero(w);
+    u32 aA[9], bA[9], aB[9], bB[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) { aA[l] = st[l * ls]; bA[l] = row[l]; }
+    u32 j = 0;
+#pragma nounroll
+    for (; j + 1 < (u32)T; j += 2) {
+      ZK_P29_ARRIVED(aA, bA);
+      ZK_P29_BAR();
+#pragma unroll
+      for (int l = 0; l < 9; ++l) { aB[l] = st[l * ls + (j + 1) * js]; bB[l] = row[(j + 1) * 9 + l]; }
+      ZK_P29_BAR();
+      zk_w29_mac(w, aA, bA);
+      ZK_P29_ARRIVED(aB, bB);
+      ZK_P29_BAR();
+      const u32 jn = j + 2 < (u32)T ? j + 2 : j;
+#pragma unroll
+      for (int l = 0; l < 9; ++l) { aA[l] = st[l * ls + jn * js]; bA[l] = row[jn * 9 + l]; }
+      ZK_P29_BAR();
+      zk_w29_mac(w, aB, bB);
+      if (j % 6u == 4u) zk_w29_carry(w);      // after 6 multiply-accumulates
+    }
+    if (T & 1) zk_w29_mac(w, aA, bA);          // element T - 1, fetched by the last pair
+    zk_w29_carry(w);
+    u32 o[9];
+    zk_w29_redc(w, o);
+#pragma unroll
+    for (int l = 0; l < 9; ++l) stage[(size_t)(i * 9 + l) * ss] = o[l];
+  }
+#pragma nounroll
+  for (u32 i = 0; i < n_out; ++i) {
+    u32 o[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) o[l] = stage[(size_t)(i * 9 + l) * ss];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) st[l * ls + i * js] = o[l];
+  }
+}
+template <int T, int V>
+ZK_HD void zk_p29_densev(u32* st, const u32 js, const u32 ls, ZkTab29 mat, const u32 n_out, u32* stage, const size_t ss) {
+  if (V & 4) zk_p29_dense_lean<T>(st, js, ls, mat, n_out, stage, ss);
+  else zk_p29_dense<T>(st, js, ls, mat, n_out);
+}
+
 // One permutation.  st: T state elements in limb form (element j, limb l at st[l * ls + j * js]; values < 2^29 on entry, element 0 =
 // capacity); emit: 3 * (8T + rp) Fr, Sigma signals in component order (sigmaF[8][T], sigmaP[rp]).  Returns out[0] (canonical).
 // V: bit 0 = row-wise products (zk_l29_mul_rows), bit 1 = two state elements per loop iteration (two independent chains of products
-// for the scheduler to interleave).  Same values either way; which is faster is a measurement (zk_rslb_chunks).
+// for the scheduler to interleave), bit 2 = dense mixes through `stage` (zk_p29_dense_lean; stage = 153 words with stride ss, unused
+// otherwise).  Same values either way; which is faster is a measurement (zk_rslb_chunks).
 template <int T, int V = 0>
-ZK_HD Fr zk_poseidon29(u32* st, const u32 js, const u32 ls, const u32* tab_, const u32 rp, Fr* emit) {
+ZK_HD Fr zk_poseidon29(u32* st, const u32 js, const u32 ls, const u32* tab_, const u32 rp, Fr* emit, u32* stage = nullptr, const size_t ss = 0) {
   ZkTab29 cF = ZK_TAB29(tab_);
   ZkTab29 M = cF + 9 * 4 * T;
   ZkTab29 P = M + 9 * T * T;
@@ -302,7 +367,7 @@ ZK_HD Fr zk_poseidon29(u32* st, const u32 js, const u32 ls, const u32* tab_, con
       }
 #pragma unroll
       for (int l = 0; l < 9; ++l) st[l * ls] = u0[l];
-      zk_p29_dense<T>(st, js, ls, B);
+      zk_p29_densev<T, V>(st, js, ls, B, T, stage, ss);
     }
     for (u32 r = 0; r < 4; ++r) {
       ZkTab29 c = (half ? cL : cF) + 9 * r * T;
@@ -331,7 +396,7 @@ ZK_HD Fr zk_poseidon29(u32* st, const u32 js, const u32 ls, const u32* tab_, con
 #pragma unroll
         for (int l = 0; l < 9; ++l) st[l * ls + j * js] = x[l];
       }
-      zk_p29_dense<T>(st, js, ls, M);
+      zk_p29_densev<T, V>(st, js, ls, M, (half == 1 && r == 3) ? 1u : (u32)T, stage, ss);
     }
   }
   u32 h[9];
