@@ -43,6 +43,9 @@ def test_soft_line_break_chunk_hashes_use_no_scratch_memory(tmp_path):
     for k in ks:
         assert k.get("ScratchSize") == 0, k
         assert k["LDS Size"] <= 40 * 1024, k       # 4 wavefronts per CU
+    # the default (6: dense mixes through the staging area) leaves zk_expand six wavefronts per SIMD beside it
+    v6 = next(v for name, v in info.items() if "zk_rslb_chunks_v6" in name)
+    assert v6["VGPRs"] + v6.get("AGPRs", 0) <= 128, v6
     assert next(v for name, v in info.items() if "zk_rslb_scan" in name).get("ScratchSize") == 0
 
 

@@ -264,7 +264,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   c->device = -1;
   // tuning knobs (DESIGN.md "zk_expand geometry"): slots per workgroup and threads per workgroup
   auto pick_k = [](const char* name, int dflt, bool k8 = false) { const char* v = getenv(name); const int k = v ? atoi(v) : dflt; return (k == 1 || k == 2 || k == 4 || (k8 && k == 8)) ? k : dflt; };
-  { const char* v = getenv("ZKWG_RSLB_V"); c->rslb_v = v ? (atoi(v) & 7) : 2; }
+  { const char* v = getenv("ZKWG_RSLB_V"); c->rslb_v = v ? (atoi(v) & 7) : 6; }
   c->x3_k = pick_k("ZKWG_X3_K", 4, true);
   c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 1);   // (round 4: 8 KiB pieces, 53 VGPRs = 8 wavefronts per SIMD, software-pipelined over the group's emails)
   c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 16;

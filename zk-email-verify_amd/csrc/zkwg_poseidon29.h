@@ -17,7 +17,8 @@
 //
 // Table (u32, built by zk_build_poseidon29 from the Fr table of zk_build_poseidon_sparse): additive constants as they are,
 // multiplicative ones times 2^261 (the Fr table holds them times 2^256):
-//   cF[4][T][9] | M[T (row i)][T (j)][9] | P[rp][T][27] = per round k and element j: c'_k[j], (n00 | v_j), (0 | w^_j) | B[T (i)][T (j)][9] | cL[4][T][9]
+//   cF[4][T][9] | M[T (row i)][T (j)][9] | P[rp + 1][T][27] = per round k and element j: c'_k[j], (n00 | v_j), (0 | w^_j); row rp is
+//   all zeros (round k adds round k + 1's constants) | B[T (i)][T (j)][9] | cL[4][T][9]
 // The dense matrices are stored by OUTPUT row, so the 153 limbs one output needs are one contiguous scalar load stream; all table
 // indices are wavefront-uniform (scalar loads, the multiply-adds take the limb from an SGPR).
 #pragma once
@@ -25,7 +26,7 @@
 
 #define ZK_P29_M 0x1fffffffu
 #define ZK_P29_N0 0x0fffffffu      // -r^-1 mod 2^29
-ZK_HD u32 zk_p29_tab_size(u32 t, u32 rp) { return 9u * (4 * t + t * t + 3 * rp * t + t * t + 4 * t); }
+ZK_HD u32 zk_p29_tab_size(u32 t, u32 rp) { return 9u * (4 * t + t * t + 3 * (rp + 1) * t + t * t + 4 * t); }
 
 // table words are read at wavefront-uniform addresses and never written while a kernel runs: on the device they are addressed in the
 // CONSTANT address space, which is what lets the compiler fetch them with scalar loads (a limb is then an SGPR operand of
@@ -174,6 +175,17 @@ ZK_HD void zk_l29_add(u32 (&r)[9], const u32 (&a)[9], BP b) {
     c = t >> 29;
   }
 }
+// r = a + b + c, normalised
+template <class BP, class CP>
+ZK_HD void zk_l29_add3(u32 (&r)[9], const u32 (&a)[9], BP b, CP c) {
+  u32 cy = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const u32 t = a[i] + b[i] + c[i] + cy;
+    r[i] = i < 8 ? (t & ZK_P29_M) : t;
+    cy = t >> 29;
+  }
+}
 // value < 2 r -> the canonical 4 x 64-bit words
 ZK_HD Fr zk_l29_to_fr(const u32 (&x)[9]) {
   u64 w[4] = {0, 0, 0, 0};
@@ -253,8 +265,9 @@ ZK_HD void zk_p29_dense(u32* st, const u32 js, const u32 ls, ZkTab29 mat, const 
 // wait in `stage` (global memory, word k of this lane at stage[k * ss]: a wavefront's lanes are adjacent) and are copied back at the end.
 template <int T>
 ZK_HD void zk_p29_dense_lean(u32* st, const u32 js, const u32 ls, ZkTab29 mat, const u32 n_out, u32* stage, const size_t ss) {
+  u32 i = 0;
 #pragma nounroll
-  for (u32 i = 0; i < n_out; ++i) {
+  for (; i < n_out; ++i) {
     ZkTab29 row = mat + (size_t)i * T * 9;
     ZkW29 w;
     zk_w29_zero(w);
@@ -287,7 +300,7 @@ ZK_HD void zk_p29_dense_lean(u32* st, const u32 js, const u32 ls, ZkTab29 mat, c
     for (int l = 0; l < 9; ++l) stage[(size_t)(i * 9 + l) * ss] = o[l];
   }
 #pragma nounroll
-  for (u32 i = 0; i < n_out; ++i) {
+  for (i = 0; i < n_out; ++i) {
     u32 o[9];
 #pragma unroll
     for (int l = 0; l < 9; ++l) o[l] = stage[(size_t)(i * 9 + l) * ss];
@@ -311,13 +324,24 @@ ZK_HD Fr zk_poseidon29(u32* st, const u32 js, const u32 ls, const u32* tab_, con
   ZkTab29 cF = ZK_TAB29(tab_);
   ZkTab29 M = cF + 9 * 4 * T;
   ZkTab29 P = M + 9 * T * T;
-  ZkTab29 B = P + 27 * rp * T;
+  ZkTab29 B = P + 27 * (rp + 1) * T;
   ZkTab29 cL = B + 9 * T * T;
   for (u32 half = 0; half < 2; ++half) {
     if (half == 1) {
       u32 u0[9];
 #pragma unroll
       for (int l = 0; l < 9; ++l) u0[l] = st[l * ls];
+      // the state elements 1 .. T-1 are kept WITH the coming round's constant added (round k adds round k + 1's: one three-way
+      // addition per element and round instead of two additions)
+#pragma nounroll
+      for (u32 j = 1; j < (u32)T; ++j) {
+        u32 uj[9];
+#pragma unroll
+        for (int l = 0; l < 9; ++l) uj[l] = st[l * ls + j * js];
+        zk_l29_add(uj, uj, P + j * 27);
+#pragma unroll
+        for (int l = 0; l < 9; ++l) st[l * ls + j * js] = uj[l];
+      }
 #pragma nounroll
       for (u32 k = 0; k < rp; ++k) {
         ZkTab29 pk = P + (size_t)k * T * 27;
@@ -335,15 +359,13 @@ ZK_HD Fr zk_poseidon29(u32* st, const u32 js, const u32 ls, const u32* tab_, con
             u32 ua[9], ub[9], pa[9], pb[9];
 #pragma unroll
             for (int l = 0; l < 9; ++l) { ua[l] = st[l * ls + j * js]; ub[l] = st[l * ls + (j + 1) * js]; }
-            zk_l29_add(ua, ua, pj);
-            zk_l29_add(ub, ub, pj + 27);
             zk_w29_mac(w, ua, pj + 9);
             zk_w29_mac(w, ub, pj + 36);
             if ((j & 3u) == 3u) zk_w29_carry(w);       // j = 1, 3, 5 ...: every second pair -> at most 5 multiply-accumulates apart
             zk_l29_mulv<V>(pa, y0, pj + 18);
             zk_l29_mulv<V>(pb, y0, pj + 45);
-            zk_l29_add(ua, ua, pa);
-            zk_l29_add(ub, ub, pb);
+            zk_l29_add3(ua, ua, pa, pj + T * 27);
+            zk_l29_add3(ub, ub, pb, pj + T * 27 + 27);
 #pragma unroll
             for (int l = 0; l < 9; ++l) { st[l * ls + j * js] = ua[l]; st[l * ls + (j + 1) * js] = ub[l]; }
           }
@@ -354,11 +376,10 @@ ZK_HD Fr zk_poseidon29(u32* st, const u32 js, const u32 ls, const u32* tab_, con
           u32 uj[9], p[9];
 #pragma unroll
           for (int l = 0; l < 9; ++l) uj[l] = st[l * ls + j * js];
-          zk_l29_add(uj, uj, pj);
           zk_w29_mac(w, uj, pj + 9);
           if ((j & 3u) == 3u) zk_w29_carry(w);
           zk_l29_mulv<V>(p, y0, pj + 18);
-          zk_l29_add(uj, uj, p);
+          zk_l29_add3(uj, uj, p, pj + T * 27);
 #pragma unroll
           for (int l = 0; l < 9; ++l) st[l * ls + j * js] = uj[l];
         }
@@ -432,6 +453,7 @@ static inline void zk_build_poseidon29(u32 t, u32 rp, const std::vector<Fr>& tab
       put(j ? sk[t - 1 + j] : fr_zero(), true);
     }
   }
+  for (u32 j = 0; j < 3 * t; ++j) put(fr_zero(), false);
   for (u32 i = 0; i < t; ++i) for (u32 j = 0; j < t; ++j) put(bt[j * t + i], true);
   for (u32 i = 0; i < 4 * t; ++i) put(c_last[i], false);
 }
