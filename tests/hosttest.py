@@ -69,6 +69,11 @@ def load():
     lib.ht_net_load.restype = C.c_void_p
     lib.ht_net_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32]
     lib.ht_net_destroy.argtypes = [C.c_void_p]
+    lib.ht_net_self_check.restype = C.c_int
+    lib.ht_net_self_check.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32]
+    lib.ht_net_check_error.restype = C.c_char_p
+    lib.ht_net_check_error.argtypes = [C.c_void_p]
+    lib.ht_net_damage_chain.argtypes = [C.c_void_p]
     lib.ht_net_error.restype = C.c_char_p
     lib.ht_net_error.argtypes = [C.c_void_p]
     lib.ht_net_names.restype = C.c_char_p
@@ -243,6 +248,15 @@ class LoadedRegex:
         if getattr(self, "h", None):
             self.lib.ht_net_destroy(self.h)
             self.h = None
+
+    def self_check(self, path, include_dirs=(), template="BodyHashRegex", damage=False):
+        """the loader's own check of its scan tables against the plain gate list (zkwg_net_host.h zkc::self_check, what
+        zkwg_circuit_create_regex runs once per handle) -> None, or the error text; damage=True zeroes the forward chain's table first"""
+        if damage:
+            self.lib.ht_net_damage_chain(C.c_void_p(self.h))
+        if self.lib.ht_net_self_check(C.c_void_p(self.h), str(path).encode(), ":".join(str(d) for d in include_dirs).encode(), template.encode(), self.n):
+            return None
+        return self.lib.ht_net_check_error(C.c_void_p(self.h)).decode()
 
     def chain_info(self):
         """-> (positions served from the forward chain tables, from the backward ones, steps left in the gate list)"""

@@ -131,8 +131,8 @@ void ht_fr_inv(const void* a, void* out) { *(Fr*)out = fr_inv_std(*(const Fr*)a)
 }
 #include "zkwg_fr_inv.h"
 extern "C" void ht_fr_inv_by(const void* a, void* out) { *(Fr*)out = fr_inv_by(*(const Fr*)a); }
-// Loaded regex template (zkwg_circom.h) + the gate evaluator shared with zk_net_eval (zkwg_net_core.h)
-#include "zkwg_net_core.h"
+// Loaded regex template (zkwg_circom.h) + the host evaluation shared with the kernels and the loader's self-check (zkwg_net_host.h)
+#include "zkwg_net_host.h"
 struct HTNet { zkc::Net net; std::string err; std::string names; };
 extern "C" {
 void* ht_net_load(const char* path, const char* include_dirs, const char* tname, uint32_t n) {
@@ -151,58 +151,22 @@ void ht_net_chain_info(void* p, uint32_t out[4]) {
   out[0] = N.chain.end; out[1] = N.bchain.end; out[2] = N.n_steps; out[3] = N.chain.classes | (N.bchain.classes << 16);
 }
 const char* ht_net_names(void* p) { return ((HTNet*)p)->names.c_str(); }
-// evaluates the gate list exactly as the kernel does (same cache simulation); words[n_kept], reveal[n]
+// evaluates the template exactly as the kernels do (zkwg_net_host.h: the code the loader's self-check runs); words[n_kept], reveal[n]
 int ht_net_eval(void* p, const uint8_t* msg, uint32_t* words, uint32_t* match, uint32_t* reveal) {
-  const zkc::Net& N = ((HTNet*)p)->net;
-  std::vector<int> lds(N.lds_words, 0x55555555);
-  for (u32 i = 0; i < N.n_in; ++i) lds[N.n_pins + i] = msg[i];
-  lds[N.n_pins + N.n_in] = 0;
-  // zk_net_scan: the chain states entering every position (zkwg_circom.h chain_pass)
-  ZkNetChains K;
-  K.n_in = N.n_in;
-  K.f_end = N.chain.end; K.f_smax = N.chain.smax; K.f_mw = N.chain.mask_words;
-  K.b_end = N.bchain.end; K.b_smax = N.bchain.smax; K.b_mw = N.bchain.mask_words; K.b_fdim = N.bchain.fdim;
-  K.f_cls = N.chain.cls.data(); K.f_delta = N.chain.delta.data(); K.f_mask = N.chain.mask.data();
-  K.b_cls = N.bchain.cls.data(); K.b_delta = N.bchain.delta.data(); K.b_mask = N.bchain.mask.data();
-  std::vector<u32> fwords(N.n_in / 4 + 2, 0xa5a5a5a5u), bwords(N.n_in / 4 + 2, 0xa5a5a5a5u);   // (as in the image: stale bytes where no chain wrote)
-  zk_net_scan_email(K, msg, fwords.data(), bwords.data());
-  const u8* fstate = (const u8*)fwords.data(); const u8* bstate = (const u8*)bwords.data();
-  const u32 MS = N.mask_words + K.f_mw + K.b_mw;
-  for (u32 i = 0; i < N.n_in; ++i)          // the evaluator's prologue: per byte its mask words (byte-local frontier bits, then the chains')
-    zk_net_mask_words(K, N.mask_words, N.mask_tab.data(), i, msg, fstate, bstate, &lds[N.lds_masks + i * MS]);
-  std::vector<u32> img(N.n_kept + N.n_temp, 0xdeadbeefu);
-  bool ok = true;
-  size_t g = 0;
-  std::vector<int> snap;
-  for (u32 st = 0; st < N.n_steps; ++st) {
-    snap = lds;   // the lanes of a step read before any of them writes
-    const bool general = N.step_count[st] & 0x8000u;
-    for (u32 lane = 0; lane < (N.step_count[st] & 0x7fu); ++lane, ++g) {
-      if (general) ok &= zk_net_record(&N.records[g * 16], snap.data(), lds.data(), img.data(), match, reveal, (long long)std::max<u32>(N.inv_need + 1, 256));
-      else zk_net_record32(&N.records[g * 16], snap.data(), lds.data(), img.data());
-    }
-  }
-  // byte-local and chain kept signals are not gates of the list: zk_expand decodes them from the position words the evaluator's
-  // prologue leaves (zkwg_expand_dec.h ZkDecNetP / zkwg_net_core.h zk_netp_word) -- the same code, run over the region's runs
-  std::vector<u32> small(N.n_kept + N.n_in, 0);
-  memcpy(small.data(), img.data(), (size_t)N.n_kept * 4);
-  for (u32 i = 0; i < N.n_in; ++i) small[N.n_kept + i] = zk_net_pos_word(K, i, msg, fstate, bstate);
-  ZkNetDec D;
-  D.pd = N.pd.data(); D.tab = N.tabs.data();
-  D.offF = N.offF; D.offB = N.offB; D.nL = N.nL; D.nF = N.nF; D.nB = N.nB; D.b_fdim = N.bchain.fdim;
-  D.m_net = 0; D.m_net_pw = N.n_kept; D.n_in = N.n_in;
-  u32 covered = 0;
-  for (const zkc::Net::Run& R : N.runs) {
-    if (R.start != covered) return -1;      // the runs tile the region
-    for (u32 r = 0; r < R.nslots; ++r) {
-      const u32 i = r / R.period, q = r % R.period;
-      if (R.dense != 0xffffffffu) { words[R.start + r] = zk_netq_word(D, R.dense, R.period, R.pos0, i, q, small.data()); continue; }   // (ZkDecNetQ)
-      words[R.start + r] = zk_netp_word(D, N.pd[2 * (R.pd0 + q)], N.pd[2 * (R.pd0 + q) + 1], R.pos0, i, R.start + r, small.data());
-    }
-    covered += R.nslots;
-  }
-  if (covered != N.n_kept) return -1;
-  return ok ? 1 : 0;
+  return zkc::eval_host(((HTNet*)p)->net, msg, words, match, reveal);
+}
+// the loader's self-check on this template: 1 = tables and gate list agree, 0 = not (ht_net_check_error has the message)
+int ht_net_self_check(void* p, const char* path, const char* include_dirs, const char* tname, uint32_t n) {
+  HTNet* h = (HTNet*)p;
+  std::string err;
+  if (zkc::self_check(path, include_dirs ? include_dirs : "", tname, {(zkc::i64)n}, h->net, err, 3)) return 1;
+  h->err = err;
+  return 0;
+}
+const char* ht_net_check_error(void* p) { return ((HTNet*)p)->err.c_str(); }
+// damages the forward chain's transition table (every entry that is not already 0 becomes 0): what the self-check exists to catch
+void ht_net_damage_chain(void* p) {
+  for (auto& d : ((HTNet*)p)->net.chain.delta) d = 0;
 }
 }
 

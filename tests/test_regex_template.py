@@ -130,6 +130,17 @@ def test_chain_tables_give_the_same_values_as_the_plain_gate_list(monkeypatch, p
         assert regs[None].evaluate(msg) == ref, msg
 
 
+def test_loader_self_check_accepts_its_tables_and_catches_a_damaged_one():
+    """zkwg_net_host.h: what zkwg_circuit_create_regex runs once per handle -- the scan tables against the plain gate list on three
+    messages.  The shipped template passes; with the forward chain's transition table zeroed the check names the disagreement
+    (a wrong table would otherwise write a wrong witness silently)."""
+    reg = hosttest.LoadedRegex(STAND_IN, 256)
+    assert reg.chain_info()[0] > 0
+    assert reg.self_check(STAND_IN) is None
+    err = reg.self_check(STAND_IN, damage=True)
+    assert err is not None and "self-check" in err and "disagree" in err, err
+
+
 def _chain_fuzz_template(rng):
     """a random finite-state circuit in the regex style: S state bits stepped forward by comparators of the current byte, a chain
     that runs backwards over the forward states, an accept counter, a reveal array"""

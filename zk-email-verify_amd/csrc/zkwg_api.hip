@@ -18,6 +18,7 @@
 #include "zkwg_build.h"
 #include "zkwg_poseidon_sparse.h"
 #include "zkwg_poseidon29.h"
+#include "zkwg_net_host.h"
 #include "zkwg_full.h"
 #include "zkwg_o0.h"
 #include "zkwg_o0_dec.h"
@@ -286,6 +287,15 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       g_last_error = "regex template: " + err;
       delete c;
       return ZKWG_RC_BAD_CONFIG;
+    }
+    // the scan tables against the plain gate list on a few messages, once per handle (zkwg_net_host.h; ZKWG_NET_SELFCHECK=0 skips it)
+    if (!getenv("ZKWG_NET_SELFCHECK") || atoi(getenv("ZKWG_NET_SELFCHECK"))) {
+      if (!zkc::self_check(regex->circom_path, regex->include_dirs ? regex->include_dirs : "",
+                           regex->template_name ? regex->template_name : "BodyHashRegex", {(zkc::i64)cfg->max_header}, c->net, err)) {
+        g_last_error = "regex template: " + err;
+        delete c;
+        return ZKWG_RC_BAD_CONFIG;
+      }
     }
     c->has_net = true;
   }

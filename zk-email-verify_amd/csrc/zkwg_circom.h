@@ -564,6 +564,7 @@ static const u32 VAL_INVERSE = 0x80000000u; // stored word: inverse of the 31-bi
 // ------------------------------------------------------------------------------------------------ elaboration
 struct ReturnValue { Val v; };
 struct Elab {
+  int chain_limit = -1;     // see load()
   int call_depth = 0;
   std::deque<Node> pool;
   std::deque<std::string> files;
@@ -1759,7 +1760,7 @@ struct Elab {
   // when that makes the state space explode (a counter taken for a state), the pass falls back to what the intervals prove.
   bool chain_pass(Net& net, int pass, const std::vector<long long>& sup, const std::vector<u64>& sig, const std::vector<u8>& local,
                   LocalEval& eval, u32& now, std::vector<int>& cbit, const std::vector<int>& cbit_fwd) {
-    if (getenv("ZKWG_NET_CHAIN") && atoi(getenv("ZKWG_NET_CHAIN")) <= pass) return false;
+    if (chain_limit >= 0 ? chain_limit <= pass : (getenv("ZKWG_NET_CHAIN") && atoi(getenv("ZKWG_NET_CHAIN")) <= pass)) return false;
     std::vector<u8> nonbool(gates.size(), 0);
     for (int round = 0; round < 6; ++round) {
       const int r = chain_try(net, pass, /*trust=*/true, nonbool, sup, sig, local, eval, now, cbit, cbit_fwd);
@@ -2602,10 +2603,13 @@ template MultiAND(n) {
 }
 
 // Load `tname(args...)` from `path`; include directories separated by ':'.
+// chain_limit: -1 = both recurrences from scan tables where possible (ZKWG_NET_CHAIN overrides), 0 = every gate in the list (what
+// the load-time self-check of zkwg_net_host.h compares the tables with), 1 = the forward recurrence only
 static inline bool load(const std::string& path, const std::string& include_dirs, const std::string& tname,
-                        const std::vector<i64>& args, Net& net, std::string& err) {
+                        const std::vector<i64>& args, Net& net, std::string& err, int chain_limit = -1) {
   try {
     Elab E;
+    E.chain_limit = chain_limit;
     std::stringstream ss(include_dirs);
     std::string d;
     while (std::getline(ss, d, ':')) if (!d.empty()) E.include_dirs.push_back(d);
