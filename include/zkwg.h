@@ -55,7 +55,8 @@ extern "C" {
 
 /* 2 (round 3): ZKWG_IN_NFIELDS = 13 (the record's former padding word is ZKWG_IN_RANGE_FLAGS: hand-built records must
  * zero it, a non-zero word fails the email); zkwg_expand_device accepts out_stride >= 32 W (multiple of 16);
- * zkwg_scratch_bytes includes the Montgomery-copy area; zkwg_segment.pad is kernel-private.
+ * zkwg_scratch_bytes includes the Montgomery-copy area (and, round 5, 612 bytes per 16-byte body chunk of staging for the
+ * removeSoftLineBreaks chunk hashes, behind the image arrays); zkwg_segment.pad is kernel-private.
  * Added since without breaking 2: zkwg_expand_host / zkwg_set_host_expand, zkwg_circuit_attach_r1cs / zkwg_expand_abc_device /
  * zkwg_expand_abc_host / zkwg_abc_bytes, ZKWG_MAIN_FP_MUL. */
 #define ZKWG_ABI_VERSION 3
