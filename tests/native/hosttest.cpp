@@ -233,7 +233,7 @@ void ht_msm(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t
 #include "zkwg_msm_core.h"
 extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t c, int mont, uint32_t shuffle, int ones_apart, uint8_t* out) {
   // ones_apart bit 1: the precomputed-windows layout (K copies of the bases, one bucket set), as zkwg_msm_create builds it by default
-  const bool precomp = (ones_apart & 2) != 0;
+  const bool precomp = (ones_apart & 2) != 0, planes = (ones_apart & 4) != 0, lds_sort = (ones_apart & 8) != 0;
   ones_apart &= 1;
   std::vector<G1Affine> P(n);
   for (uint64_t i = 0; i < n; ++i) P[i] = ht_pt_in(points + 64 * i);
@@ -249,20 +249,36 @@ extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scal
   A.KS = precomp ? 1u : A.K; A.stride = precomp ? (u32)n : 0u;
   const u32 total = A.KS * A.nb, half = A.KS * ((A.nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN);
   std::vector<u32> count(total + 1, 0), cursor(total, 0), entry((size_t)n * A.K + 1, 0xdeadbeefu);
-  std::vector<G1Xyzz> bucket(total), ns(2 * (size_t)half + 1), na(2 * (size_t)half + 1), window(A.KS), res(1);
+  const size_t pn0 = zk_msm_plane_n0(A.nb), pn1 = (pn0 + ZK_MSM_PFAN - 1) / ZK_MSM_PFAN;
+  std::vector<G1Xyzz> bucket(total), ns(std::max<size_t>(2 * (size_t)half, (size_t)A.KS * c * pn0) + 1), na(std::max<size_t>(2 * (size_t)half, (size_t)A.KS * c * pn1) + 1), window(A.KS), res(1);
+  A.plane_sums = planes ? 1u : 0u;
   A.count = count.data(); A.cursor = cursor.data(); A.entry = entry.data(); A.bucket = bucket.data();
   A.node_s = ns.data(); A.node_a = na.data(); A.window = window.data(); A.out = res.data();
-  const u32 half1 = (u32)((n + 63) / 64);
+  const u32 half1 = (u32)((n + ZK_MSM_ONES - 1) / ZK_MSM_ONES);
   std::vector<G1Xyzz> ones(2 * (size_t)half1 + 1);
   A.ones_apart = ones_apart ? 1u : 0u; A.ones = ones.data();
   std::vector<u32> order(n);
   for (u32 i = 0; i < n; ++i) order[i] = i;
   u64 x = 0x9e3779b97f4a7c15ull * (shuffle + 1);
   if (shuffle) for (u64 i = n; i > 1; --i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(order[i - 1], order[x % i]); }
-  for (u32 i : order) zk_msm_count_thread(A, i);
+  // the counting sort: one global atomic per digit, or (lds_sort, when the counters fit LDS) workgroup-local histograms -- as zk_msm_launch
+  const bool wg_sort = lds_sort && total <= ZK_MSM_LDS_BUCKETS;
+  const u32 per_wg = zk_msm_sort_per_wg(A.n) > 64 && shuffle ? 37u : zk_msm_sort_per_wg(A.n);      // (small odd workgroups under `shuffle`: more of them, ragged ends)
+  const u32 n_wg = (A.n + per_wg - 1) / per_wg;
+  std::vector<u32> hist(ZK_MSM_LDS_BUCKETS);
+  auto sort_wg = [&](bool scatter) {
+    for (u32 wgi = 0; wgi < n_wg; ++wgi) {
+      const u32 wg = shuffle ? n_wg - 1 - wgi : wgi;
+      for (int phase = 0; phase < (scatter ? 4 : 3); ++phase)
+        for (u32 t = 0; t < 64; ++t) zk_msm_sort_wg_thread(A, wg, per_wg, shuffle ? 63 - t : t, 64u, hist.data(), phase, scatter);
+    }
+  };
+  if (wg_sort) sort_wg(false);
+  else for (u32 i : order) zk_msm_count_thread(A, i);
   std::vector<u32> partial(1025);
   for (int phase = 0; phase < 2; ++phase) for (u32 t = 0; t < 1024; ++t) zk_msm_scan_thread(A, t, 1024u, partial.data(), phase);
-  for (u32 i : order) zk_msm_scatter_thread(A, i);
+  if (wg_sort) sort_wg(true);
+  else for (u32 i : order) zk_msm_scatter_thread(A, i);
   // the buckets' runs in slices (three levels), then one join per bucket -- as zk_msm_launch
   std::vector<std::vector<u32>> soff(3, std::vector<u32>(total + 1, 0xdeadbeefu));
   std::vector<std::vector<G1Xyzz>> part(3);
@@ -276,14 +292,28 @@ extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scal
   }
   for (u32 b = 0; b < total; ++b) zk_msm_bucket_join_thread(A, b);
   const G1Xyzz* in_s = A.bucket; const G1Xyzz* in_a = nullptr;
-  u32 n_in = A.nb, span = 1, flip = 0;
-  for (;;) {
-    const u32 n_out = (n_in + ZK_MSM_FAN - 1) / ZK_MSM_FAN;
-    G1Xyzz* out_s = A.node_s + (size_t)flip * half;
-    G1Xyzz* out_a = A.node_a + (size_t)flip * half;
-    for (u32 g = 0; g < A.KS * n_out; ++g) zk_msm_reduce_thread(A, g, in_s, in_a, n_in, span, out_s, out_a);
-    if (n_out == 1) break;
-    in_s = out_s; in_a = out_a; n_in = n_out; span *= ZK_MSM_FAN; flip ^= 1;
+  if (A.plane_sums) {     // as zk_msm_launch does
+    const u32 rows = A.KS * A.c;
+    u32 n_in = zk_msm_plane_n0(A.nb);
+    for (u32 g = 0; g < rows * n_in; ++g) zk_msm_plane0_thread(A, g, A.node_s);
+    G1Xyzz* cur = A.node_s;
+    while (n_in > 1) {
+      const u32 n_out = (n_in + ZK_MSM_PFAN - 1) / ZK_MSM_PFAN;
+      G1Xyzz* nxt = cur == A.node_s ? A.node_a : A.node_s;
+      for (u32 g = 0; g < rows * n_out; ++g) zk_msm_plane_join_thread<ZkCurveG1>(cur, rows, n_in, nxt, g);
+      cur = nxt; n_in = n_out;
+    }
+    for (u32 w = 0; w < A.KS; ++w) zk_msm_plane_window_thread(A, cur, w);
+  } else {
+    u32 n_in = A.nb, span = 1, flip = 0;
+    for (;;) {
+      const u32 n_out = (n_in + ZK_MSM_FAN - 1) / ZK_MSM_FAN;
+      G1Xyzz* out_s = A.node_s + (size_t)flip * half;
+      G1Xyzz* out_a = A.node_a + (size_t)flip * half;
+      for (u32 g = 0; g < A.KS * n_out; ++g) zk_msm_reduce_thread(A, g, in_s, in_a, n_in, span, out_s, out_a);
+      if (n_out == 1) break;
+      in_s = out_s; in_a = out_a; n_in = n_out; span *= ZK_MSM_FAN; flip ^= 1;
+    }
   }
   if (A.ones_apart) {     // as zk_msm_launch does
     u32 m = half1, levels = 0;

@@ -35,11 +35,13 @@ static ZkMsmWork msm_work(const zkwg_msm* p) {
   W.cursor = off; off += al(total * 4);
   W.entry = off; off += al(p->n * p->K * 4);
   W.bucket = off; off += al(total * xs);
-  W.node_s = off; off += al(2 * half * xs);
-  W.node_a = off; off += al(2 * half * xs);
+  // the larger of the tree's ping-pong halves and the bit planes' two regions (zkwg_msm_core.h: rows = sets * c, n0 = ceil(nb / PFAN))
+  const u64 n0 = zk_msm_plane_n0(p->nb), n1 = (n0 + ZK_MSM_PFAN - 1) / ZK_MSM_PFAN;
+  W.node_s = off; off += al(std::max<u64>(2 * half, sets * p->c * n0) * xs);
+  W.node_a = off; off += al(std::max<u64>(2 * half, sets * p->c * n1) * xs);
   W.window = off; off += al(sets * xs);
   W.out = off; off += al(xs);
-  W.ones = off; off += al(2 * ((p->n + 63) / 64) * xs);
+  W.ones = off; off += al(2 * ((p->n + ZK_MSM_ONES - 1) / ZK_MSM_ONES) * xs);
   u64 items = p->n * p->K;                       // entries: at most one per (scalar, window)
   for (int l = 0; l < 3; ++l) {
     const u64 cap = items / zk_msm_slice_size(l) + total + 1;     // sum_b ceil(len_b / S) <= items / S + buckets
@@ -87,6 +89,8 @@ static void msm_args(const zkwg_msm* p, const void* d_scalars, int mont, int one
   u8* w = (u8*)d_work;
   A.bases = (const typename C::Affine*)(p->d_ext ? p->d_ext : p->d_bases); A.KS = p->d_ext ? 1u : p->K; A.stride = p->d_ext ? (u32)p->n : 0u; A.scalars = (const Fr*)d_scalars; A.n = (u32)p->n; A.c = p->c; A.K = p->K; A.nb = p->nb;
   A.scalars_mont = mont ? 1u : 0u; A.ones_apart = ones_apart ? 1u : 0u; A.ones = (X*)(w + W.ones);
+  { static const u32 ps = getenv("ZKWG_MSM_PLANES") ? (u32)atoi(getenv("ZKWG_MSM_PLANES")) : 1u; A.plane_sums = ps; }
+  { static const u32 ls = getenv("ZKWG_MSM_LDS_SORT") ? (u32)atoi(getenv("ZKWG_MSM_LDS_SORT")) : 1u; A.lds_sort = ls; }
   A.count = (u32*)(w + W.count); A.cursor = (u32*)(w + W.cursor); A.entry = (u32*)(w + W.entry); A.bucket = (X*)(w + W.bucket);
   A.node_s = (X*)(w + W.node_s); A.node_a = (X*)(w + W.node_a); A.window = (X*)(w + W.window); A.out = (X*)(w + W.out);
   for (int l = 0; l < 3; ++l) { A.soff[l] = (u32*)(w + W.soff[l]); A.part[l] = (X*)(w + W.part[l]); A.cap[l] = W.cap[l]; }

@@ -18,7 +18,8 @@
 #include "zkwg_g2.h"
 
 #define ZK_MSM_FAN 8u      // fan-in of the weighted bucket tree: a node's serial work is 3 additions per child; the levels are what a lone sum waits for
-#define ZK_MSM_JOIN 16u    // fan-in of the joins of the ones' partial sums
+#define ZK_MSM_JOIN 8u     // fan-in of the joins of the ones' partial sums
+#define ZK_MSM_ONES 8u     // bases per lane of zk_msm_ones (64 and 16-way joins until r05_s: 124 dependent additions for a 1.8 M-wire witness, 50 now)
 
 // the group the sums run over: G1 (pi_a, pib1, pi_c, the H sum) or G2 (pi_b) -- same kernels, other point arithmetic
 struct ZkCurveG1 {
@@ -53,9 +54,11 @@ struct ZkMsmArgsT {
   // Classic layout: KS = K bucket sets, stride = 0.  The memory is what 288 GB are for: 20 x 47 MB per witness-sized sum.
   u32 KS, stride;
   u32 scalars_mont;           // 1: the scalars are in Montgomery form (the H evaluations of zkwg_ntt_api.hip, a Montgomery witness)
+  u32 lds_sort;               // 1: count / scatter with workgroup-local histograms (zk_msm_sort_wg_thread) when KS nb fits LDS
+  u32 plane_sums;             // 1: the weighted bucket sum by bit planes (zk_msm_plane*: log depth); 0: the (S, A) tree of zk_msm_reduce
   u32 ones_apart;             // 1: scalars equal to 1 do not enter the buckets (a witness is mostly bits: they would all land in ONE
                               // bucket of window 0); their bases are summed by zk_msm_ones + the 64-way tree and added at the end
-  G1Xyzz* ones;               // [2 x ceil(n / 64)] tree scratch of the ones' sum (ping-pong halves); ones[0] = the sum at the end
+  G1Xyzz* ones;               // [2 x ceil(n / ZK_MSM_ONES)] tree scratch of the ones' sum (ping-pong halves); ones[0] = the sum at the end
   u32* count;                 // [K * nb + 1] counters, then exclusive offsets (zk_msm_scan)
   u32* cursor;                // [K * nb] running write positions of zk_msm_scatter
   u32* entry;                 // [n * K] base index | sign << 31, grouped by bucket
@@ -68,7 +71,7 @@ struct ZkMsmArgsT {
   u32* soff[3];               // [K * nb + 1] per level: first slice of every bucket
   G1Xyzz* part[3];            // per level: the slices' sums
   u32 cap[3];                 // slices a level can hold (n K / S + K nb bounds it)
-  G1Xyzz* node_s; G1Xyzz* node_a;   // reduction tree scratch: [K * nb / ZK_MSM_FAN * 2] each (ping-pong halves)
+  G1Xyzz* node_s; G1Xyzz* node_a;   // bit-plane sums, ping-pong: node_s [KS c n0], node_a [KS c ceil(n0 / F)], n0 = ceil(nb / ZK_MSM_PFAN)
   G1Xyzz* window;             // [K] weighted bucket sums
   G1Xyzz* out;                // [1]
 };
@@ -76,18 +79,21 @@ typedef ZkMsmArgsT<ZkCurveG1> ZkMsmArgs;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZK_MSM_ATOMIC_INC(p) atomicAdd((p), 1u)
+#define ZK_MSM_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #else
 #define ZK_MSM_ATOMIC_INC(p) ((*(p))++)
+static inline u32 zk_msm_host_fetch_add(u32* p, u32 v) { const u32 o = *p; *p = o + v; return o; }
+#define ZK_MSM_ATOMIC_ADD(p, v) zk_msm_host_fetch_add((p), (v))
 #endif
 
 // scalar i in standard form
 template <class C>
 ZK_HD Fr zk_msm_scalar(const ZkMsmArgsT<C>& A, u32 i) { return A.scalars_mont ? fr_from_mont(A.scalars[i]) : A.scalars[i]; }
 ZK_HD bool zk_msm_is_one(const Fr& k) { return k.l[0] == 1 && (k.l[1] | k.l[2] | k.l[3]) == 0; }
-// the bases whose scalar is 1, 64 per thread (ones_apart); then zk_msm_tree_thread joins 64 partial sums per thread until one is left
+// the bases whose scalar is 1, ZK_MSM_ONES per thread (ones_apart); then zk_msm_tree_thread joins ZK_MSM_JOIN partial sums per thread until one is left
 template <class C>
 ZK_HD void zk_msm_ones_thread(const ZkMsmArgsT<C>& A, u32 t) {
-  const u32 lo = t * 64u, hi = lo + 64u < A.n ? lo + 64u : A.n;
+  const u32 lo = t * ZK_MSM_ONES, hi = lo + ZK_MSM_ONES < A.n ? lo + ZK_MSM_ONES : A.n;
   if (lo >= A.n) return;
   typename C::Xyzz acc = C::inf();
   for (u32 i = lo; i < hi; ++i)
@@ -146,6 +152,49 @@ ZK_HD void zk_msm_scatter_thread(const ZkMsmArgsT<C>& A, u32 i) {
     A.entry[at] = (w * A.stride + i) | (d < 0 ? 0x80000000u : 0u);
   }
 }
+// ---- the counting sort with WORKGROUP-LOCAL histograms (round 5, profiles/r05/r05_u_msm0_kernel_stats.csv: for 2^21 full-size scalars
+// the 33.5 M global atomics of zk_msm_count and again of zk_msm_scatter, all on 32,768 addresses, were 1.26 + 2.84 ms of a 9.0 ms sum).
+// When the bucket counters fit LDS (KS nb <= ZK_MSM_LDS_BUCKETS: one bucket set of up to 2^15 -- the precomputed-windows layout at
+// c <= 16), workgroup `wg` owns the scalars [wg per_wg, (wg + 1) per_wg): it counts them into `hist` (LDS atomics), then
+//   count:   adds its non-zero counters to A.count                                     (KS nb global atomics per workgroup, not one per digit)
+//   scatter: reserves hist[b] consecutive places of bucket b with ONE atomicAdd on A.cursor[b], leaves the first place in hist[b],
+//            and walks its scalars again, taking places from hist[b] by LDS atomics.
+// Phases are separated by workgroup barriers the caller supplies (host mirror: every thread of a phase, then the next phase).
+#define ZK_MSM_LDS_BUCKETS 32768u
+template <class C>
+ZK_HD void zk_msm_sort_wg_thread(const ZkMsmArgsT<C>& A, u32 wg, u32 per_wg, u32 t, u32 threads, u32* hist, int phase, bool scatter) {
+  const u32 total = A.KS * A.nb;
+  const u32 lo = wg * per_wg, hi = lo + per_wg < A.n ? lo + per_wg : A.n;
+  if (phase == 0) {
+    for (u32 b = t; b < total; b += threads) hist[b] = 0;
+    return;
+  }
+  if (phase == 2) {
+    for (u32 b = t; b < total; b += threads) {
+      const u32 v = hist[b];
+      if (!v) continue;
+      if (scatter) hist[b] = ZK_MSM_ATOMIC_ADD(&A.cursor[b], v);
+      else ZK_MSM_ATOMIC_ADD(&A.count[b], v);
+    }
+    return;
+  }
+  // phase 1: count; phase 3 (scatter): place
+  for (u32 i = lo + t; i < hi; i += threads) {
+    if (C::is_inf(A.bases[i])) continue;
+    const Fr k = zk_msm_scalar(A, i);
+    if (A.ones_apart && zk_msm_is_one(k)) continue;
+    u32 carry = 0;
+    for (u32 w = 0; w < A.K; ++w) {
+      const int d = zk_msm_digit(k.l, w, A.c, carry);
+      if (!d) continue;
+      const u32 b = (A.KS == 1u ? 0u : w) * A.nb + (u32)(d < 0 ? -d : d) - 1u;
+      if (phase == 1) ZK_MSM_ATOMIC_ADD(&hist[b], 1u);
+      else A.entry[ZK_MSM_ATOMIC_ADD(&hist[b], 1u)] = (w * A.stride + i) | (d < 0 ? 0x80000000u : 0u);
+    }
+  }
+}
+ZK_HD u32 zk_msm_sort_per_wg(u32 n) { const u32 per = (n + 255u) / 256u; return per < 1024u ? 1024u : per; }   // about 256 workgroups
+
 template <class C>
 ZK_HD void zk_msm_bucket_thread(const ZkMsmArgsT<C>& A, u32 b) {
   if (b >= A.KS * A.nb) return;
@@ -182,6 +231,46 @@ ZK_HD void zk_msm_reduce_thread(const ZkMsmArgsT<C>& A, u32 g, const typename C:
   out_s[(size_t)w * n_out + q] = sum_s;
   out_a[(size_t)w * n_out + q] = node_a;
 }
+// ---- the weighted bucket sum  sum_b (b + 1) bucket[b]  by BIT PLANES (round 5, after profiles/r05/r05_s_prove_kernel_stats.csv: the
+// (S, A) tree above is five dependent levels of 21 additions + up to 12 doublings on ever fewer lanes -- 3.4 ms of a 4 ms G1 sum and
+// 10.5 ms of a 16 ms G2 sum are that latency).  With T_j = sum of the buckets whose weight has bit j set, the sum is sum_j 2^j T_j:
+// the c plane sums are PLAIN sums (ZK_MSM_PFAN-way joins: log depth, every level c times wider than the tree's), and one lane folds
+// them with c - 1 doublings.  c/2 times the additions of the tree -- irrelevant next to n K mixed additions -- for 66 dependent
+// point operations instead of 135 (c = 16).
+#define ZK_MSM_PFAN 8u
+ZK_HD u32 zk_msm_plane_n0(u32 nb) { return (nb + ZK_MSM_PFAN - 1u) / ZK_MSM_PFAN; }
+// level 0, thread g = (w c + j) n0 + q: the buckets [q F, (q + 1) F) of set w whose weight b + 1 has bit j set
+template <class C>
+ZK_HD void zk_msm_plane0_thread(const ZkMsmArgsT<C>& A, u32 g, typename C::Xyzz* out) {
+  const u32 n0 = zk_msm_plane_n0(A.nb);
+  if (g >= A.KS * A.c * n0) return;
+  const u32 row = g / n0, q = g - row * n0, w = row / A.c, j = row - w * A.c;
+  const u32 lo = q * ZK_MSM_PFAN, hi = lo + ZK_MSM_PFAN < A.nb ? lo + ZK_MSM_PFAN : A.nb;
+  typename C::Xyzz acc = C::inf();
+  for (u32 b = lo; b < hi; ++b)
+    if (((b + 1u) >> j) & 1u) acc = C::add(acc, A.bucket[(size_t)w * A.nb + b]);
+  out[g] = acc;
+}
+// a join level: `rows` rows of n_in sums -> rows of n_out = ceil(n_in / F); thread g = row n_out + q
+template <class C>
+ZK_HD void zk_msm_plane_join_thread(const typename C::Xyzz* in, u32 rows, u32 n_in, typename C::Xyzz* out, u32 g) {
+  const u32 n_out = (n_in + ZK_MSM_PFAN - 1u) / ZK_MSM_PFAN;
+  if (g >= rows * n_out) return;
+  const u32 row = g / n_out, q = g - row * n_out;
+  const u32 lo = q * ZK_MSM_PFAN, hi = lo + ZK_MSM_PFAN < n_in ? lo + ZK_MSM_PFAN : n_in;
+  const typename C::Xyzz* r = in + (size_t)row * n_in;
+  typename C::Xyzz acc = r[lo];
+  for (u32 k = lo + 1; k < hi; ++k) acc = C::add(acc, r[k]);
+  out[g] = acc;
+}
+// window w from its c plane sums T[w c + j]
+template <class C>
+ZK_HD void zk_msm_plane_window_thread(const ZkMsmArgsT<C>& A, const typename C::Xyzz* T, u32 w) {
+  if (w >= A.KS) return;
+  typename C::Xyzz acc = T[(size_t)w * A.c + A.c - 1u];
+  for (u32 j = A.c - 1u; j-- > 0;) acc = C::add(C::dbl(acc), T[(size_t)w * A.c + j]);
+  A.window[w] = acc;
+}
 template <class C>
 ZK_HD void zk_msm_combine_thread(const ZkMsmArgsT<C>& A) {
   typename C::Xyzz total = C::inf();
@@ -206,8 +295,8 @@ ZK_HD void zk_msm_shift_thread(const typename C::Affine* bases, typename C::Affi
     ext[(size_t)w * n + i] = to_affine(acc);
   }
 }
-#define ZK_MSM_S0 64u
-#define ZK_MSM_S1 32u
+#define ZK_MSM_S0 16u      // (64 / 32 / 32 until r05_s: 128 dependent additions in front of a bucket; 32 now, for 4 x the slices of level 0)
+#define ZK_MSM_S1 8u
 ZK_HD u32 zk_msm_slice_size(int level) { return level == 0 ? ZK_MSM_S0 : ZK_MSM_S1; }
 // slices of `level`: the items of bucket b are [in[b], in[b + 1]) -- entries for level 0 (in = A.count), the slices of the level below
 // otherwise; out[b] = first slice of bucket b, out[total] = number of slices.  One workgroup, two phases around a barrier (as zk_msm_scan).
