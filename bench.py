@@ -699,17 +699,20 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         # the HIP runtime initialises), and this process is already initialised
         env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
         torch.cuda.empty_cache()
-        p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_prove.py"), "--emails", "8",
-                            "--slots", "32", "--proofs", "96"], env=env, capture_output=True, text=True, timeout=300)
-        r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-        # Montgomery products behind the figure: per proof ~ (n H + ones of 3 G1 sums) x 10 + G2 x 28 per mixed addition + trees
-        out["prover stages 1-3: Groth16 proofs, EmailVerifier(576,192)"] = {
-            "value": r["proofs_per_s"], "unit": "proofs/s", "proofs_in_flight": r["proofs_in_flight"], "proofs_timed": r["proofs_timed"],
-            "hw_queues": r.get("hw_queues"), "msm_layout": r.get("msm_layout"),
-            "one_at_a_time_ms_per_proof": r["one_at_a_time_ms_per_proof"], "stages_ms_alone": r["stages"], "W": r["W"], "domain_log2": r["domain_log2"],
-            "note": "bases = fixed-base multiples of random scalars (timing needs points, not a valid key); the field products run at the rate "
-                    "tools/mulbench.hip measures for csrc/zkwg_comba29.h (139 G/s in a pure loop); the sums are bound by their serial tails "
-                    "(bucket tree, Horner over the windows), which is why several proofs are kept in flight"}
+        tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bench_prove.py")
+        for label, extra, tmo in (("EmailVerifier(576,192)", ["--emails", "8", "--slots", "32", "--proofs", "96"], 300),
+                                  (f"EmailVerifier({args.max_header},{args.max_body}) -- the headline circuit",
+                                   ["--max-header", str(args.max_header), "--max-body", str(args.max_body), "--emails", "8", "--slots", "24", "--proofs", "72"], 400)):
+            p = subprocess.run([sys.executable, tool] + extra, env=env, capture_output=True, text=True, timeout=tmo)
+            r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+            # Montgomery products behind the figure: per proof ~ (n H + ones of 3 G1 sums) x 10 + G2 x 28 per mixed addition + bucket sums
+            out["prover stages 1-3: Groth16 proofs, " + label] = {
+                "value": r["proofs_per_s"], "unit": "proofs/s", "proofs_in_flight": r["proofs_in_flight"], "proofs_timed": r["proofs_timed"],
+                "hw_queues": r.get("hw_queues"), "msm_layout": r.get("msm_layout"),
+                "one_at_a_time_ms_per_proof": r["one_at_a_time_ms_per_proof"], "stages_ms_alone": r["stages"], "W": r["W"], "domain_log2": r["domain_log2"],
+                "note": "bases = fixed-base multiples of random scalars (timing needs points, not a valid key); the field products run at the rate "
+                        "tools/mulbench.hip measures for csrc/zkwg_comba29.h (139 G/s in a pure loop); a sum's tail is a few dozen dependent "
+                        "point additions on few lanes, which is why several proofs are kept in flight"}
         torch.cuda.empty_cache()
     except Exception as e:
         out["prover stages 1-3: Groth16 proofs"] = {"error": repr(e)[:300]}
