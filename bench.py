@@ -67,7 +67,8 @@ class Pipeline:
         self.d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(self.R)]
         self.placement = None
         self.d_out = None
-        if place == 2 or place is True:
+        place = 2 if place is True else int(place)      # (True == 1 in Python: without this every default-constructed pipeline ran BOTH placements)
+        if place == 2:
             # the output ring is mapped from 1 GiB physical chunks (zkwg_device_alloc_chunked): every tile then
             # takes zk_expand's stores at the rate only the best hipMalloc buffers reach -- no candidates, no transient memory
             from zkwg import placement
