@@ -1683,6 +1683,7 @@ int zkwg_calculate_batch_resident(zkwg_circuit_t* c, const uint8_t* packed, uint
 // candidate tiles the ring was chosen from (average milliseconds of one tile's expansion into each; kept[2] = the chosen)
 int zkwg_resident_placement(const zkwg_circuit_t* c, float* ms, int cap, int kept[2]) {
   if (!c) return 0;
+  std::lock_guard<std::mutex> lock(const_cast<zkwg_circuit_t*>(c)->hb_mutex);   // (written by zkwg_calculate_batch_resident under the same lock)
   for (int i = 0; i < c->rp_place_n && i < cap; ++i) if (ms) ms[i] = c->rp_place_ms[i];
   if (kept) { kept[0] = c->rp_place_kept[0]; kept[1] = c->rp_place_kept[1]; }
   return c->rp_place_n;
