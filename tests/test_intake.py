@@ -13,7 +13,7 @@ import sys
 
 from conftest import ROOT
 
-sys.path.insert(0, os.path.join(ROOT, "tools"))      # the intake tool is a user tool (tools/intake.py), imported here as a module
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # tests/intake.py (tools/intake.py is its launcher), imported here as a module
 
 REF = os.path.isdir("/root/reference/packages/circuits")
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
