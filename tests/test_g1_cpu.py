@@ -163,7 +163,7 @@ def test_device_msm_bodies_thread_by_thread_equal_the_oracle(n, c, mont):
         # bit 1: precomputed windows -- K shifted copies of the bases, one bucket set, no Horner pass; bit 2: the weighted bucket sum by
         # bit planes (zk_msm_plane*) instead of the (S, A) tree (bits 1 and 2)
         # bit 3: count / scatter with workgroup-local histograms (14 = the default configuration)
-        for layout in (0, 2, 4, 6, 14, 8):
+        for layout in ((0, 2, 4, 6, 14, 8) if shuffle else (0, 14)):
             lib.ht_msm_device_mirror(buf, sc, C.c_uint64(n), c, mont, shuffle, layout, out)
             assert _unpt(out.raw) == want, (n, c, mont, shuffle, layout)
 
@@ -187,7 +187,7 @@ def test_device_msm_bodies_on_witness_like_scalars(n, c):
             folded[p] = (folded.get(p, 0) + k) % R
     want = G.msm_naive(list(folded), list(folded.values()))
     out = C.create_string_buffer(64)
-    for apart in (1, 0, 3, 2, 7, 5, 15, 9):       # bit 1: the precomputed-windows layout, bit 2: bucket sums by bit planes, bit 3: workgroup-local sort
+    for apart in (1, 0, 3, 7, 15, 9):       # bit 1: the precomputed-windows layout, bit 2: bucket sums by bit planes, bit 3: workgroup-local sort
         lib.ht_msm_device_mirror(buf, sc, C.c_uint64(n), c, 1, 3, apart, out)
         assert _unpt(out.raw) == want, (n, c, apart)
 
