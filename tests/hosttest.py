@@ -62,6 +62,7 @@ def load():
     lib.ht_poseidon.argtypes = [C.c_void_p] * 3
     lib.ht_poseidon_sparse.restype = C.c_int
     lib.ht_poseidon_sparse.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ht_p29_violations.restype = C.c_ulonglong
     lib.ht_poseidon29.restype = C.c_int
     lib.ht_poseidon29.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ht_r1cs_first_bad.restype = C.c_longlong

@@ -8,6 +8,7 @@
 #include "zkwg_fpmul_core.h"
 #include "zkwg_poseidon_core.h"
 #include "zkwg_poseidon_sparse.h"
+#define ZKWG_P29_CHECK 1     // count violations of the limb-form evaluator's range argument (zkwg_poseidon29.h)
 #include "zkwg_poseidon29.h"
 #include "zkwg_r1cs.h"
 #include "zkwg_regex_core.h"
@@ -86,6 +87,7 @@ int ht_poseidon_sparse(uint32_t t, const void* inputs, void* emit, void* hash) {
   *(Fr*)hash = h;
   return 0;
 }
+unsigned long long ht_p29_violations() { return zk_p29_violations; }
 // the same permutation through the 29-bit-limb evaluator zk_rslb_chunks runs (zkwg_poseidon29.h); state laid out limb-major as in LDS
 int ht_poseidon29(uint32_t t, uint32_t variant, const void* inputs, void* emit, void* hash) {
   const u32 rp = ZK_POS_RP_TAB[t - 2];

@@ -121,7 +121,7 @@ def test_poseidon_sparse_host_core_matches_oracle():
         for trial in range(3):
             xs = [rng.randrange(256) for _ in range(t - 1)] if trial == 0 else [rng.randrange(poseidon.P) for _ in range(t - 1)]
             if trial == 2:
-                xs = [poseidon.P - 1] * (t - 1)
+                xs = [poseidon.P - 1] * (t - 1)       # the largest inputs: the lazy ranges of zkwg_poseidon29.h at their widest
             comp = poseidon.Poseidon(t - 1, xs)
             kept = witness_kept(comp)[1:]
             n = 3 * (8 * t + poseidon.N_ROUNDS_P[t - 2])
@@ -138,3 +138,5 @@ def test_poseidon_sparse_host_core_matches_oracle():
                 assert int.from_bytes(h.raw, "little") == comp.o
                 got = [int.from_bytes(emit.raw[32 * i:32 * i + 32], "little") for i in range(n)]
                 assert got == kept
+    # every column addition, operand limb and packed result of the limb-form runs above stayed inside the ranges its header argues
+    assert lib.ht_p29_violations() == 0

@@ -57,6 +57,15 @@ typedef const u32* ZkTab29;
 #define ZK_P29_BAR() ((void)0)
 #endif
 
+// ZKWG_P29_CHECK (host builds of the tests only): every column addition is checked for wrap-around and every operand limb for its
+// declared width; zk_p29_violations counts what the range argument above says cannot happen (tests/test_ev_cpu.py asserts 0)
+#if defined(ZKWG_P29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+static unsigned long long zk_p29_violations = 0;
+#define ZK_P29_EXPECT(cond) do { if (!(cond)) ++zk_p29_violations; } while (0)
+#else
+#define ZK_P29_EXPECT(cond) ((void)0)
+#endif
+
 struct ZkW29 { u64 c[17]; };
 ZK_HD void zk_w29_zero(ZkW29& w) {
 #pragma unroll
@@ -67,8 +76,12 @@ template <class BP>
 ZK_HD void zk_w29_mac(ZkW29& w, const u32 (&a)[9], BP b) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
+    ZK_P29_EXPECT(a[i] <= ZK_P29_M);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w.c[i + k] += (u64)a[i] * b[k];
+    for (int k = 0; k < 9; ++k) {
+      ZK_P29_EXPECT(b[k] <= ZK_P29_M && w.c[i + k] + (u64)a[i] * b[k] >= w.c[i + k]);
+      w.c[i + k] += (u64)a[i] * b[k];
+    }
   }
 }
 ZK_HD void zk_w29_carry(ZkW29& w) {
@@ -101,6 +114,7 @@ ZK_HD void zk_w29_redc(const ZkW29& w, u32 (&out)[9]) {
     acc >>= 29;
   }
   out[8] = (u32)acc;
+  ZK_P29_EXPECT((acc >> 29) == 0);           // the reduced dot product stays below 2^261
 }
 // r = a b / 2^261 mod r (+ at most r); a: limbs < 2^29 (top < 2^32), b: limbs < 2^29
 template <class BP>
@@ -108,6 +122,8 @@ ZK_HD void zk_l29_mul(u32 (&r)[9], const u32 (&a)[9], BP b) {
   const u32 P[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
   u32 q[9], o[9];
   u64 acc = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { ZK_P29_EXPECT(i == 8 || a[i] <= ZK_P29_M); ZK_P29_EXPECT(b[i] <= ZK_P29_M); }
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
 #pragma unroll
@@ -128,6 +144,7 @@ ZK_HD void zk_l29_mul(u32 (&r)[9], const u32 (&a)[9], BP b) {
     acc >>= 29;
   }
   o[8] = (u32)acc;
+  ZK_P29_EXPECT((acc >> 29) == 0);           // the result stays below 2^261
 #pragma unroll
   for (int i = 0; i < 9; ++i) r[i] = o[i];
 }
@@ -196,10 +213,12 @@ ZK_HD Fr zk_l29_to_fr(const u32 (&x)[9]) {
     if (s > 64 - 29 && k + 1 < 4) w[k + 1] |= (u64)x[i] >> (64 - s);
   }
   Fr v{{w[0], w[1], w[2], w[3]}};
+  ZK_P29_EXPECT(x[8] < (1u << 24));          // below 2^256: the packing loses nothing
   if (fr_geq(v, fr_p())) {
     u64 bw;
     v = fr_sub_raw(v, fr_p(), bw);
   }
+  ZK_P29_EXPECT(!fr_geq(v, fr_p()));         // one subtraction was enough
   return v;
 }
 ZK_HD void zk_l29_from_fr(const Fr& x, u32 (&l)[9]) {
