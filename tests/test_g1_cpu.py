@@ -143,9 +143,10 @@ def test_device_path_compiles_for_gfx950_without_scratch(tmp_path):
 
 @pytest.mark.parametrize("n,c,mont", [(1, 3, 0), (50, 4, 1), (700, 7, 0), (2000, 11, 1), (3000, 13, 0)])
 def test_device_msm_bodies_thread_by_thread_equal_the_oracle(n, c, mont):
-    """zkwg_msm_core.h -- count / scan / scatter / bucket sums / the 32-way reduction tree / window combination, the bodies of the
-    kernels of zkwg_kernels_msm.hip -- executed thread by thread on the host in launch order, with the atomic passes in a shuffled
-    thread order: equals the oracle's bucket method (c = 11, 13: two and three levels of the tree)."""
+    """zkwg_msm_core.h -- count / scan / scatter (one atomic per digit, or workgroup-local histograms) / sliced bucket sums / the
+    weighted bucket sum (the 8-way (S, A) tree, or bit planes) / window combination, the bodies of the kernels of zkwg_kernels_msm.hip
+    -- executed thread by thread on the host in launch order, with the atomic passes in a shuffled thread and workgroup order: equals
+    the oracle's bucket method (c = 11, 13: several levels of every tree)."""
     lib = _lib()
     lib.ht_msm_device_mirror.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_char_p]
     rng = random.Random(900 + n)
@@ -171,7 +172,7 @@ def test_device_msm_bodies_thread_by_thread_equal_the_oracle(n, c, mont):
 @pytest.mark.parametrize("n,c", [(40, 4), (5000, 8), (9000, 10)])
 def test_device_msm_bodies_on_witness_like_scalars(n, c):
     """scalars as a witness has them -- mostly 0 and 1, some bytes, a few field elements -- with ones_apart: the bases with scalar
-    1 go through zk_msm_ones + the 64-way tree (one, two and three levels here) instead of one bucket"""
+    1 go through zk_msm_ones (8 per lane) + the 8-way joins (several levels here) instead of one bucket"""
     lib = _lib()
     lib.ht_msm_device_mirror.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_char_p]
     rng = random.Random(1700 + n)
