@@ -464,6 +464,27 @@ int zkwg_msm_g2_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_mont
 int zkwg_msm_enqueue_device(zkwg_msm_t* plan, const void* d_scalars, int scalars_montgomery, int ones_apart, void* d_work, void* d_out_xyzz,
                             void* hip_stream);
 int zkwg_msm_finish_host(int group, const uint8_t* xyzz, uint64_t n, uint8_t* out_points);
+/* Round 6: emails are the parallel axis of the sums too.  One launch series sums n_emails scalar vectors (scalar_stride bytes apart,
+ * a multiple of 32) against the plan's bases and leaves n_emails accumulators at d_out_xyzz (128 / 256 bytes each, consecutive); d_work:
+ * zkwg_msm_work_bytes_batch(plan, n_emails) bytes.  zkwg_msm_create_ex: window_bits (0: from n), slice0 = bucket entries per lane at the
+ * first slice level (0: 16; 64 for 2^20 full-size scalars), table_budget = bytes the plan may spend on its K shifted copies of the bases
+ * (0: what is free minus 4 GiB; too small: the classic layout, K bucket sets and a Horner pass -- zkwg_msm_precomputed tells).
+ * For witness scalars one classification pass serves several plans: zkwg_msm_classify_device writes, for up to three plans whose bases
+ * cover the scalars [first[t], first[t] + n_t), the per-email index lists of the scalars that are 1 and of the others that are not 0
+ * (bases at infinity left out) into d_lists[t] (zkwg_msm_lists_bytes(plan, n_emails) bytes, 256-byte aligned), and
+ * zkwg_msm_enqueue_lists_device sums with them (d_work: n_emails * zkwg_msm_work_bytes(plan) bytes). */
+int zkwg_msm_create_ex(int device, int group, const void* bases, int bases_on_device, uint64_t n, int window_bits, int slice0, uint64_t table_budget,
+                       zkwg_msm_t** out);
+uint64_t zkwg_msm_work_bytes_batch(const zkwg_msm_t* plan, uint64_t n_emails);
+uint64_t zkwg_msm_lists_bytes(const zkwg_msm_t* plan, uint64_t n_emails);
+uint64_t zkwg_msm_table_bytes(const zkwg_msm_t* plan);
+int zkwg_msm_precomputed(const zkwg_msm_t* plan);
+int zkwg_msm_enqueue_batch_device(zkwg_msm_t* plan, const void* d_scalars, uint64_t scalar_stride, uint64_t n_emails, int scalars_montgomery, int ones_apart,
+                                  void* d_work, void* d_out_xyzz, void* hip_stream);
+int zkwg_msm_classify_device(zkwg_msm_t* const* plans, const uint64_t* first, uint32_t n_plans, const void* d_scalars, uint64_t scalar_stride, uint64_t n_scalars,
+                             uint64_t n_emails, int scalars_montgomery, int ones_apart, void* const* d_lists, void* hip_stream);
+int zkwg_msm_enqueue_lists_device(zkwg_msm_t* plan, const void* d_scalars, uint64_t scalar_stride, uint64_t n_emails, int scalars_montgomery, const void* d_lists,
+                                  int with_ones, void* d_work, void* d_out_xyzz, void* hip_stream);
 int zkwg_fixed_base_device(int device, int group, const void* d_scalars, uint64_t n, void* d_out, void* hip_stream);
 /* pi_a, pi_b, pi_c from the five sums of one proof and the key's alpha / beta / delta points (groth16_prove.js: pi_a = alpha1 + sum_a +
  * r delta1, pi_b = beta2 + sum_b2 + s delta2, pi_c = sum_c + sum_h + s pi_a + r (beta1 + sum_b1 + s delta1) - r s delta1).  Points in
@@ -478,9 +499,9 @@ int zkwg_groth16_assemble(const uint8_t* sum_a, const uint8_t* sum_b1, const uin
  * zkwg_prover_create plans everything a circuit's proofs need once: it attaches the constraint system `r1cs` (over the handle's
  * witness layout, WITH the nPublic + 1 rows snarkjs appends to A; n_rows = its constraint count; NULL if already attached) to `c`,
  * builds the transform plan of the key's domain and the five multi-exponentiation plans over the key's bases (host pointers to
- * sections 5-9 of the .zkey, or device pointers with bases_on_device = 1), and allocates `slots` sets of per-proof buffers, one
- * stream each (a proof's sums end in serial tails that only other proofs in flight hide; the host should run with
- * GPU_MAX_HW_QUEUES >= 16).  zkwg_prover_prove_prepared: proofs of emails indices[0 .. n_idx) of a batch prepared with
+ * sections 5-9 of the .zkey, or device pointers with bases_on_device = 1), and allocates the buffers of `slots` proofs in flight:
+ * 1-3 contexts of E = zkwg_prover_emails_per_series emails each (round 6: every stage is one launch series for the E emails of a
+ * context; the contexts roll, nothing depends on the number of hardware queues).  zkwg_prover_prove_prepared: proofs of emails indices[0 .. n_idx) of a batch prepared with
  * zkwg_prepare_device(c, d_in, n, ..., d_scratch); blinding = n_idx x (r | s), 32-byte little-endian scalars below the group order
  * (random per proof); out_proofs = n_idx x 256 bytes: pi_a (x | y) | pi_b (x.c0 | x.c1 | y.c0 | y.c1) | pi_c (x | y), standard-form
  * little-endian integers -- the numbers of snarkjs' proof.json.  zkwg_prover_prove_batch: the same from n packed input records on the
@@ -495,6 +516,8 @@ typedef struct zkwg_proving_key {
 int zkwg_prover_create(zkwg_circuit_t* c, int device, const uint8_t* r1cs, uint64_t r1cs_len, uint64_t n_rows, const zkwg_proving_key* key,
                        uint32_t slots, zkwg_prover_t** out);
 void zkwg_prover_destroy(zkwg_prover_t* p);
+uint32_t zkwg_prover_emails_per_series(const zkwg_prover_t* p);
+uint32_t zkwg_prover_contexts(const zkwg_prover_t* p);
 int zkwg_prover_prove_prepared(zkwg_prover_t* p, const void* d_in, uint64_t n, const void* d_scratch, const uint64_t* indices, uint64_t n_idx,
                                const uint8_t* blinding, uint8_t* out_proofs);
 int zkwg_prover_prove_batch(zkwg_prover_t* p, const uint8_t* packed, uint64_t n, const uint8_t* blinding, int32_t* status, uint8_t* out_proofs);

@@ -229,110 +229,6 @@ void ht_msm(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t
 }
 }
 
-// The device multi-exponentiation (zkwg_msm_core.h: the per-thread bodies of the kernels of zkwg_kernels_msm.hip), executed here
-// thread by thread in the launch order of zk_msm_launch; `shuffle` permutes the thread order of the two atomic passes, as the
-// hardware may.  Scalars in standard form or (mont = 1) Montgomery form.
-#include "zkwg_msm_core.h"
-extern "C" void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t c, int mont, uint32_t shuffle, int ones_apart, uint8_t* out) {
-  // ones_apart bit 1: the precomputed-windows layout (K copies of the bases, one bucket set), as zkwg_msm_create builds it by default
-  const bool precomp = (ones_apart & 2) != 0, planes = (ones_apart & 4) != 0, lds_sort = (ones_apart & 8) != 0;
-  ones_apart &= 1;
-  std::vector<G1Affine> P(n);
-  for (uint64_t i = 0; i < n; ++i) P[i] = ht_pt_in(points + 64 * i);
-  std::vector<G1Affine> EXT;
-  if (precomp) {
-    EXT.resize((size_t)n * zk_msm_windows(c));
-    for (u32 i = 0; i < n; ++i) zk_msm_shift_thread<ZkCurveG1>(P.data(), EXT.data(), (u32)n, c, zk_msm_windows(c), i, [](const G1Xyzz& a) { return g1_to_affine(a); });
-  }
-  std::vector<Fr> S(n);
-  for (uint64_t i = 0; i < n; ++i) { memcpy(&S[i], scalars + 4 * i, 32); if (mont) S[i] = fr_to_mont(S[i]); }
-  ZkMsmArgs A;
-  A.bases = precomp ? EXT.data() : P.data(); A.scalars = S.data(); A.n = (u32)n; A.c = c; A.K = zk_msm_windows(c); A.nb = 1u << (c - 1); A.scalars_mont = mont ? 1u : 0u;
-  A.KS = precomp ? 1u : A.K; A.stride = precomp ? (u32)n : 0u;
-  const u32 total = A.KS * A.nb, half = A.KS * ((A.nb + ZK_MSM_FAN - 1) / ZK_MSM_FAN);
-  std::vector<u32> count(total + 1, 0), cursor(total, 0), entry((size_t)n * A.K + 1, 0xdeadbeefu);
-  const size_t pn0 = zk_msm_plane_n0(A.nb), pn1 = (pn0 + ZK_MSM_PFAN - 1) / ZK_MSM_PFAN;
-  std::vector<G1Xyzz> bucket(total), ns(std::max<size_t>(2 * (size_t)half, (size_t)A.KS * c * pn0) + 1), na(std::max<size_t>(2 * (size_t)half, (size_t)A.KS * c * pn1) + 1), window(A.KS), res(1);
-  A.plane_sums = planes ? 1u : 0u;
-  A.count = count.data(); A.cursor = cursor.data(); A.entry = entry.data(); A.bucket = bucket.data();
-  A.node_s = ns.data(); A.node_a = na.data(); A.window = window.data(); A.out = res.data();
-  const u32 half1 = (u32)((n + ZK_MSM_ONES - 1) / ZK_MSM_ONES);
-  std::vector<G1Xyzz> ones(2 * (size_t)half1 + 1);
-  A.ones_apart = ones_apart ? 1u : 0u; A.ones = ones.data();
-  std::vector<u32> order(n);
-  for (u32 i = 0; i < n; ++i) order[i] = i;
-  u64 x = 0x9e3779b97f4a7c15ull * (shuffle + 1);
-  if (shuffle) for (u64 i = n; i > 1; --i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(order[i - 1], order[x % i]); }
-  // the counting sort: one global atomic per digit, or (lds_sort, when the counters fit LDS) workgroup-local histograms -- as zk_msm_launch
-  const bool wg_sort = lds_sort && total <= ZK_MSM_LDS_BUCKETS;
-  const u32 per_wg = zk_msm_sort_per_wg(A.n) > 64 && shuffle ? 37u : zk_msm_sort_per_wg(A.n);      // (small odd workgroups under `shuffle`: more of them, ragged ends)
-  const u32 n_wg = (A.n + per_wg - 1) / per_wg;
-  std::vector<u32> hist(ZK_MSM_LDS_BUCKETS);
-  auto sort_wg = [&](bool scatter) {
-    for (u32 wgi = 0; wgi < n_wg; ++wgi) {
-      const u32 wg = shuffle ? n_wg - 1 - wgi : wgi;
-      for (int phase = 0; phase < (scatter ? 4 : 3); ++phase)
-        for (u32 t = 0; t < 64; ++t) zk_msm_sort_wg_thread(A, wg, per_wg, shuffle ? 63 - t : t, 64u, hist.data(), phase, scatter);
-    }
-  };
-  if (wg_sort) sort_wg(false);
-  else for (u32 i : order) zk_msm_count_thread(A, i);
-  std::vector<u32> partial(1025);
-  for (int phase = 0; phase < 2; ++phase) for (u32 t = 0; t < 1024; ++t) zk_msm_scan_thread(A, t, 1024u, partial.data(), phase);
-  if (wg_sort) sort_wg(true);
-  else for (u32 i : order) zk_msm_scatter_thread(A, i);
-  // the buckets' runs in slices (three levels), then one join per bucket -- as zk_msm_launch
-  std::vector<std::vector<u32>> soff(3, std::vector<u32>(total + 1, 0xdeadbeefu));
-  std::vector<std::vector<G1Xyzz>> part(3);
-  {
-    u64 items = (u64)n * A.K;
-    for (int l = 0; l < 3; ++l) { const u64 cap = items / zk_msm_slice_size(l) + total + 1; A.cap[l] = (u32)cap; part[l].resize(cap); A.soff[l] = soff[l].data(); A.part[l] = part[l].data(); items = cap; }
-  }
-  for (int level = 0; level < 3; ++level) {
-    for (int phase = 0; phase < 2; ++phase) for (u32 t = 0; t < 1024; ++t) zk_msm_slice_scan_thread(A, level, t, 1024u, partial.data(), phase);
-    for (u32 t = 0; t < A.cap[level]; ++t) zk_msm_slice_sum_thread(A, level, t);
-  }
-  for (u32 b = 0; b < total; ++b) zk_msm_bucket_join_thread(A, b);
-  const G1Xyzz* in_s = A.bucket; const G1Xyzz* in_a = nullptr;
-  if (A.plane_sums) {     // as zk_msm_launch does
-    const u32 rows = A.KS * A.c;
-    u32 n_in = zk_msm_plane_n0(A.nb);
-    for (u32 g = 0; g < rows * n_in; ++g) zk_msm_plane0_thread(A, g, A.node_s);
-    G1Xyzz* cur = A.node_s;
-    while (n_in > 1) {
-      const u32 n_out = (n_in + ZK_MSM_PFAN - 1) / ZK_MSM_PFAN;
-      G1Xyzz* nxt = cur == A.node_s ? A.node_a : A.node_s;
-      for (u32 g = 0; g < rows * n_out; ++g) zk_msm_plane_join_thread<ZkCurveG1>(cur, rows, n_in, nxt, g);
-      cur = nxt; n_in = n_out;
-    }
-    for (u32 w = 0; w < A.KS; ++w) zk_msm_plane_window_thread(A, cur, w);
-  } else {
-    u32 n_in = A.nb, span = 1, flip = 0;
-    for (;;) {
-      const u32 n_out = (n_in + ZK_MSM_FAN - 1) / ZK_MSM_FAN;
-      G1Xyzz* out_s = A.node_s + (size_t)flip * half;
-      G1Xyzz* out_a = A.node_a + (size_t)flip * half;
-      for (u32 g = 0; g < A.KS * n_out; ++g) zk_msm_reduce_thread(A, g, in_s, in_a, n_in, span, out_s, out_a);
-      if (n_out == 1) break;
-      in_s = out_s; in_a = out_a; n_in = n_out; span *= ZK_MSM_FAN; flip ^= 1;
-    }
-  }
-  if (A.ones_apart) {     // as zk_msm_launch does
-    u32 m = half1, levels = 0;
-    for (u32 q = m; q > 1; q = (q + ZK_MSM_JOIN - 1) / ZK_MSM_JOIN) ++levels;
-    G1Xyzz* cur = A.ones + ((levels & 1u) ? half1 : 0);
-    { ZkMsmArgs B = A; B.ones = cur; for (u32 t = 0; t < half1; ++t) zk_msm_ones_thread(B, t); }
-    while (m > 1) {
-      const u32 m2 = (m + ZK_MSM_JOIN - 1) / ZK_MSM_JOIN;
-      G1Xyzz* nxt = cur == A.ones ? A.ones + half1 : A.ones;
-      for (u32 t = 0; t < m2; ++t) zk_msm_tree_thread(cur, m, nxt, t);
-      cur = nxt; m = m2;
-    }
-  }
-  zk_msm_combine_thread(A);
-  ht_pt_out(res[0], out);
-}
-
 // BN254 G2 building blocks (zkwg_g2.h): standard form across this boundary; a point is x.c0 | x.c1 | y.c0 | y.c1, zeros = infinity
 #include "zkwg_g2.h"
 static Fq2 ht_f2_in(const uint8_t* p) { Fq2 a; memcpy(&a.c0, p, 32); memcpy(&a.c1, p + 32, 32); return Fq2{fq_to_mont(a.c0), fq_to_mont(a.c1)}; }
@@ -363,4 +259,206 @@ void ht_g2_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* scale, 
   ht_f2_out(q.x, out); ht_f2_out(q.y, out + 64);
 }
 int ht_g2_on_curve(const uint8_t* a) { return g2_on_curve(ht_p2_in(a)) ? 1 : 0; }
+}
+
+// The device multi-exponentiation (zkwg_msm_core.h: the per-thread bodies of the kernels of zkwg_kernels_msm.hip), executed here
+// thread by thread in the launch order of zk_msm_launch_t, for E emails at once; `shuffle` permutes the thread order of the atomic
+// passes, as the hardware may.  Scalars in standard form or (mont = 1) Montgomery form.  The point arithmetic is the lazy 29-bit limb
+// form the device runs (zkwg_ec29.h; G2: both halves of a lane pair computed here), with every precondition of zkwg_fq29.h counted.
+#define ZKWG_FQ29_CHECK 1
+#include "zkwg_msm_core.h"
+template <class C, class Aff, class Xyzz, class In, class Out, class Add, class Dbl, class ToAff, class ToTab, class IsInf>
+static void ht_msm_mirror_t(const uint8_t* points, size_t pt_bytes, const uint64_t* scalars, uint64_t n, uint32_t E, uint32_t c, int mont, uint32_t shuffle, int layout,
+                            uint32_t s0, uint8_t* out, In pt_in, Out pt_out, Xyzz inf, Add add_mixed, Dbl dbl, ToAff to_affine, ToTab to_table, IsInf is_inf) {
+  typedef Xyzz29<typename C::F> X;
+  // layout bit 0: ones apart (classification into index lists); bit 1: precomputed windows; bit 3: workgroup-local sort
+  const bool ones_apart = (layout & 1) != 0, precomp = (layout & 2) != 0, lds_sort = (layout & 8) != 0;
+  const u32 K = zk_msm_windows(c);
+  std::vector<Aff> P(n), T((size_t)n * (precomp ? K : 1));
+  for (uint64_t i = 0; i < n; ++i) P[i] = pt_in(points + pt_bytes * i);
+  for (u32 i = 0; i < n; ++i) zk_msm_table_thread(P.data(), T.data(), (u32)n, c, precomp ? K : 1u, i, inf, add_mixed, dbl, to_affine, to_table);
+  std::vector<u32> infb((n + 31) / 32 + 1, 0);
+  for (u32 i = 0; i < n; ++i) if (is_inf(P[i])) infb[i >> 5] |= 1u << (i & 31);
+  std::vector<Fr> S((size_t)n * E);
+  for (uint64_t i = 0; i < n * E; ++i) { memcpy(&S[i], scalars + 4 * i, 32); if (mont) S[i] = fr_to_mont(S[i]); }
+  ZkMsmArgsT<C> A;
+  A.table = T.data(); A.inf = infb.data(); A.scalars = S.data(); A.scalar_stride = n;
+  A.n = (u32)n; A.c = c; A.K = K; A.nb = 1u << (c - 1); A.KS = precomp ? 1u : K; A.stride = precomp ? (u32)n : 0u; A.E = E; A.scalars_mont = mont ? 1u : 0u;
+  A.lds_sort = lds_sort ? 1u : 0u; A.s0 = s0;
+  const u32 total = A.KS * A.nb;
+  // one email's arrays, as zkwg_msm_api.hip lays them out (sizes in accumulators of this build: sizeof(X) per point)
+  auto al = [](u64 x) { return (x + 255) & ~255ull; };
+  const u64 xs = sizeof(X) * C::LANES;
+  ZkMsmOff& W = A.off;
+  {
+    u64 off = 0;
+    W.count = off; off += al((total + 1) * 4);
+    W.cursor = off; off += al((u64)total * 4);
+    W.entry = off; off += al((u64)n * K * 4);
+    W.bucket = off; off += al((u64)total * xs);
+    const u64 n0 = zk_msm_plane_n0(A.nb), n1 = (n0 + ZK_MSM_PFAN - 1) / ZK_MSM_PFAN;
+    W.node_s = off; off += al((u64)A.KS * c * n0 * xs);
+    W.node_a = off; off += al((u64)A.KS * c * n1 * xs);
+    W.window = off; off += al((u64)A.KS * xs);
+    W.ones = off; off += al(2 * ((n + ZK_MSM_ONES - 1) / ZK_MSM_ONES) * xs);
+    u64 items = (u64)n * K;
+    for (int l = 0; l < 3; ++l) {
+      const u64 cap = items / (l == 0 ? s0 : ZK_MSM_S1) + total + 1;
+      W.cap[l] = (u32)cap; W.soff[l] = off; off += al((total + 1) * 4); W.part[l] = off; off += al(cap * xs); items = cap;
+    }
+    W.total = al(off);
+  }
+  std::vector<u64> workbuf((W.total * E + 15) / 8 + 2, 0xdeadbeefdeadbeefull);
+  A.work = (u8*)(((uintptr_t)workbuf.data() + 15) & ~(uintptr_t)15); A.work_stride = W.total;
+  std::vector<typename C::Out> res(E);
+  A.out = res.data();
+  // thread orders of the atomic passes
+  std::vector<u32> order(n);
+  for (u32 i = 0; i < n; ++i) order[i] = i;
+  u64 x = 0x9e3779b97f4a7c15ull * (shuffle + 1);
+  if (shuffle) for (u64 i = n; i > 1; --i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(order[i - 1], order[x % i]); }
+  // classification (zk_msm_classify: one target)
+  std::vector<u32> sel((size_t)n * E + 1, 0xdeadbeefu), ones((size_t)n * E + 1, 0xdeadbeefu), cnt(2 * E, 0);
+  A.sel = A.n_sel = A.ones = A.n_ones = nullptr; A.list_stride = n;
+  if (ones_apart) {
+    ZkClassifyArgs Q;
+    Q.scalars = S.data(); Q.scalar_stride = n; Q.n = (u32)n; Q.E = E; Q.scalars_mont = A.scalars_mont; Q.ones_apart = 1; Q.n_targets = 1;
+    Q.t[0] = ZkClassifyTarget{infb.data(), 0u, (u32)n, sel.data(), cnt.data(), ones.data(), cnt.data() + E, n};
+    for (u32 e = 0; e < E; ++e) for (u32 i : order) zk_msm_classify_thread(Q, e, i);
+    A.sel = sel.data(); A.n_sel = cnt.data(); A.ones = ones.data(); A.n_ones = cnt.data() + E;
+  }
+  std::vector<u32> hist(ZK_MSM_LDS_BUCKETS), partial(1025);
+  for (u32 e = 0; e < E; ++e) {
+    memset(A.count(e), 0, ((size_t)total + 1) * 4);
+    const u32 len = A.sel_count(e);
+    const bool wg_sort = lds_sort && total <= ZK_MSM_LDS_BUCKETS;
+    const u32 n_wg = shuffle ? 7u : 3u;
+    auto sort_wg = [&](bool scatter) {
+      for (u32 wgi = 0; wgi < n_wg; ++wgi) {
+        const u32 wg = shuffle ? n_wg - 1 - wgi : wgi;
+        for (int phase = 0; phase < (scatter ? 4 : 3); ++phase)
+          for (u32 t = 0; t < 64; ++t) zk_msm_sort_wg_thread(A, e, wg, n_wg, shuffle ? 63 - t : t, 64u, hist.data(), phase, scatter);
+      }
+    };
+    if (wg_sort) sort_wg(false);
+    else for (u32 j : order) if (j < len) zk_msm_count_thread(A, e, j);
+    for (int phase = 0; phase < 2; ++phase) for (u32 t = 0; t < 1024; ++t) zk_msm_scan_thread(A, e, t, 1024u, partial.data(), phase);
+    if (wg_sort) sort_wg(true);
+    else for (u32 j : order) if (j < len) zk_msm_scatter_thread(A, e, j);
+    for (int level = 0; level < 3; ++level) {
+      for (int phase = 0; phase < 2; ++phase) for (u32 t = 0; t < 1024; ++t) zk_msm_slice_scan_thread(A, e, level, t, 1024u, partial.data(), phase);
+      for (u32 t = 0, m = zk_msm_slice_count(A, e, level); t < m; ++t) { if (level == 0) zk_msm_slice_sum_thread<C, true>(A, e, level, t, 0); else zk_msm_slice_sum_thread<C, false>(A, e, level, t, 0); }
+    }
+    for (u32 b = 0; b < total; ++b) zk_msm_bucket_join_thread(A, e, b, 0);
+    const u32 rows = A.KS * A.c;
+    u32 n_in = zk_msm_plane_n0(A.nb), flip = 0;
+    for (u32 g = 0; g < rows * n_in; ++g) zk_msm_plane0_thread(A, e, g, 0);
+    while (n_in > 1) {
+      const u32 n_out = (n_in + ZK_MSM_PFAN - 1) / ZK_MSM_PFAN;
+      for (u32 g = 0; g < rows * n_out; ++g) zk_msm_plane_join_thread<C>(flip ? A.node_a(e) : A.node_s(e), rows, n_in, flip ? A.node_s(e) : A.node_a(e), g, 0);
+      flip ^= 1u; n_in = n_out;
+    }
+    for (u32 w = 0; w < A.KS; ++w) zk_msm_plane_window_thread(A, e, flip ? A.node_a(e) : A.node_s(e), w, 0);
+    u32 half = 0, in_second = 0;
+    if (A.ones) {
+      half = (u32)((n + ZK_MSM_ONES - 1) / ZK_MSM_ONES);
+      X* lo = A.ones_acc(e);
+      X* hi = lo + (u64)half * C::LANES;
+      for (u32 t = 0, m = zk_msm_ones_parts(A.n_ones[e]); t < m; ++t) zk_msm_ones_thread(A, e, t, 0, lo);
+      u32 m = half, level = 0;
+      while (m > 1) {
+        const u32 m2 = (m + ZK_MSM_JOIN - 1) / ZK_MSM_JOIN;
+        const u32 cntl = (zk_msm_ones_level_count(A.n_ones[e], level) + ZK_MSM_JOIN - 1u) / ZK_MSM_JOIN;
+        for (u32 t = 0; t < cntl; ++t) zk_msm_tree_thread(A, e, level, t, 0, in_second ? hi : lo, in_second ? lo : hi);
+        in_second ^= 1u; m = m2; ++level;
+      }
+    }
+    zk_msm_combine_thread(A, e, 0, A.ones ? A.ones_acc(e) + (in_second ? (u64)half * C::LANES : 0) : nullptr);
+    pt_out(res[e], out + pt_bytes * e);
+  }
+}
+
+extern "C" {
+// group 1 / 2; E emails (scalars: E x n x 32 bytes); out: E points in standard form
+void ht_msm_device_mirror_batch(int group, const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t E, uint32_t c, int mont, uint32_t shuffle, int layout,
+                                uint32_t s0, uint8_t* out) {
+  if (group == 1)
+    ht_msm_mirror_t<ZkEcG1, G1Affine, G1Xyzz>(points, 64, scalars, n, E, c, mont, shuffle, layout, s0, out, ht_pt_in, [](const G1Xyzz& r, uint8_t* o) { ht_pt_out(r, o); },
+        g1_xyzz_inf(), [](const G1Xyzz& a, const G1Affine& p) { return g1_add_mixed(a, p); }, [](const G1Xyzz& a) { return g1_dbl(a); },
+        [](const G1Xyzz& a) { return g1_to_affine(a); }, [](const G1Affine& p) { return zk_g1_to_table_form(p); }, [](const G1Affine& p) { return g1_is_inf(p); });
+  else
+    ht_msm_mirror_t<ZkEcG2, G2Affine, G2Xyzz>(points, 128, scalars, n, E, c, mont, shuffle, layout, s0, out, ht_p2_in,
+        [](const G2Xyzz& r, uint8_t* o) { const G2Affine q = g2_to_affine(r); if (g2_is_inf(q)) { memset(o, 0, 128); return; } ht_f2_out(q.x, o); ht_f2_out(q.y, o + 64); },
+        g2_xyzz_inf(), [](const G2Xyzz& a, const G2Affine& p) { return g2_add_mixed(a, p); }, [](const G2Xyzz& a) { return g2_dbl(a); },
+        [](const G2Xyzz& a) { return g2_to_affine(a); }, [](const G2Affine& p) { return zk_g2_to_table_form(p); }, [](const G2Affine& p) { return g2_is_inf(p); });
+}
+void ht_msm_device_mirror(const uint8_t* points, const uint64_t* scalars, uint64_t n, uint32_t c, int mont, uint32_t shuffle, int layout, uint8_t* out) {
+  ht_msm_device_mirror_batch(1, points, scalars, n, 1, c, mont, shuffle, layout, 16, out);
+}
+unsigned long long ht_fq29_violations() { return zk_fq29_violations; }
+
+// The lazy-limb point arithmetic by itself (zkwg_ec29.h), standard form across this boundary.  op 0: scaled(a) + b mixed; 1: scaled(a) +
+// scaled(b); 2: 2 a (affine); 3: 2 scaled(a); `reps` > 1 repeats op 0 / 1 / 3 on the running result (accumulated bounds: acc = acc + b ...)
+static Fq29 ht_q29(const Fq& canon_r256) { return fq29_from_fq(zk_fq_r256_to_r261(canon_r256)); }
+void ht_ec29_g1_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* scale, uint32_t reps, uint8_t* out) {
+  typedef ZkF1 F;
+  const G1Affine A = ht_pt_in(a), B = ht_pt_in(b);
+  Fq s; memcpy(&s, scale, 32); s = fq_to_mont(s);
+  auto scaled = [&](const G1Affine& p) {
+    if (g1_is_inf(p)) return ec29_inf<F>();
+    const Fq s2 = fq_mont_sqr(s), s3 = fq_mont_mul(s2, s);
+    return Xyzz29<F>{ht_q29(fq_mont_mul(p.x, s2)), ht_q29(fq_mont_mul(p.y, s3)), ht_q29(s2), ht_q29(s3)};
+  };
+  const G1Affine Bt = zk_g1_to_table_form(B), At = zk_g1_to_table_form(A);
+  const Aff29<F> Bl = ZkEcG1::load(&Bt, 0, false), Al = ZkEcG1::load(&At, 0, false);
+  Xyzz29<F> r = scaled(A);
+  for (uint32_t i = 0; i < (reps ? reps : 1); ++i) {
+    if (op == 0) r = ec29_add_mixed<F>(r, Bl);
+    else if (op == 1) r = ec29_add<F>(r, scaled(B));
+    else if (op == 2) r = ec29_dbl_affine<F>(Al);
+    else r = ec29_dbl<F>(r);
+  }
+  G1Xyzz o;
+  ZkEcG1::store_out(&o, r, 0);
+  ht_pt_out(o, out);
+}
+void ht_ec29_g2_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* scale, uint32_t reps, uint8_t* out) {
+  typedef ZkF2 F;
+  const G2Affine A = ht_p2_in(a), B = ht_p2_in(b);
+  const Fq2 s = ht_f2_in(scale);
+  auto q2 = [](const Fq2& v) { return Fq29x2{{ht_q29(v.c0), ht_q29(v.c1)}}; };
+  auto scaled = [&](const G2Affine& p) {
+    if (g2_is_inf(p)) return ec29_inf<F>();
+    const Fq2 s2 = fq2_sqr(s), s3 = fq2_mul(s2, s);
+    return Xyzz29<F>{q2(fq2_mul(p.x, s2)), q2(fq2_mul(p.y, s3)), q2(s2), q2(s3)};
+  };
+  const G2Affine Bt = zk_g2_to_table_form(B), At = zk_g2_to_table_form(A);
+  const Aff29<F> Bl = ZkEcG2::load(&Bt, 0, false), Al = ZkEcG2::load(&At, 0, false);
+  Xyzz29<F> r = scaled(A);
+  for (uint32_t i = 0; i < (reps ? reps : 1); ++i) {
+    if (op == 0) r = ec29_add_mixed<F>(r, Bl);
+    else if (op == 1) r = ec29_add<F>(r, scaled(B));
+    else if (op == 2) r = ec29_dbl_affine<F>(Al);
+    else r = ec29_dbl<F>(r);
+  }
+  G2Xyzz o;
+  ZkEcG2::store_out(&o, r, 0);
+  const G2Affine q = g2_to_affine(o);
+  if (g2_is_inf(q)) { memset(out, 0, 128); return; }
+  ht_f2_out(q.x, out); ht_f2_out(q.y, out + 64);
+}
+// the field layer: op 0 mul, 1 dot2 (a b + c d), 2 sub<12,1> then norm, 3 to_fq of a lazy sum a + b + c + d; standard form in / out (2^261 form inside)
+void ht_fq29_op(int op, const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, uint8_t* out) {
+  auto in = [](const uint8_t* p) { Fq v; memcpy(&v, p, 32); return ht_q29(fq_to_mont(v)); };
+  const Fq29 x = in(a), y = in(b), z = in(c), w = in(d);
+  Fq29 r;
+  if (op == 0) r = fq29_mul(x, y);
+  else if (op == 1) r = fq29_dot2(x, y, z, w);
+  else if (op == 2) r = fq29_norm(fq29_sub<12, 1>(x, y));
+  else r = fq29_add(fq29_add(x, y), fq29_add(z, w));
+  // back: the value is v 2^261 (op 0, 1: v 2^261 with v the product) -> x 2^256 -> standard
+  const Fq m = fq29_to_fq<16>(fq29_mul(r, fq29_r256()));
+  const Fq st = fq_from_mont(m);
+  memcpy(out, &st, 32);
+}
 }

@@ -1,5 +1,5 @@
-"""G1 multi-exponentiation on the device (include/zkwg.h "prover stage 3", DRAFT on branch next/msm) against the oracle
-(oracle/pyref/bn254_g1.py).  The kernel bodies are the ones tests/test_g1_cpu.py runs thread by thread on the host."""
+"""G1 multi-exponentiation on the device (include/zkwg.h "prover stage 3") against the oracle (oracle/pyref/bn254_g1.py).  The kernel
+bodies are the ones tests/test_g1_cpu.py / test_ec29_cpu.py run thread by thread on the host."""
 import random
 
 import pytest
@@ -64,12 +64,48 @@ def test_gpu_msm_of_h_sized_input_is_linear():
     assert a == G.msm_naive(base, folded)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,E,c,mont,apart", [(3000, 5, 10, False, True), (20000, 3, 13, True, False), (700, 9, 7, False, True)])
+def test_gpu_batched_msm_equals_one_at_a_time_and_the_oracle(n, E, c, mont, apart):
+    """E scalar vectors in ONE launch series (emails = the second grid dimension of every kernel): every sum equals the oracle's and the
+    sum the same plan gives alone; witness-like scalars (zeros, ones, bytes, negatives, field elements) so that the index lists differ
+    per email"""
+    import torch
+    import zkwg
+    rng = random.Random(6000 + n)
+    base = G.random_points(32, n)
+    pts = [base[rng.randrange(32)] if rng.random() < 0.95 else None for _ in range(n)]
+    pts[1] = G.neg(pts[0]) if pts[0] else None
+    ks = []
+    for e in range(E):
+        for i in range(n):
+            u = rng.random()
+            ks.append(0 if u < 0.4 else 1 if u < 0.7 else rng.randrange(256) if u < 0.8 else R - 1 - rng.randrange(2) if u < 0.85 else rng.randrange(R))
+    ks[n:2 * n] = [0] * n                                      # an email whose lists are empty
+    m = zkwg.Msm(zkwg.Msm.pack_bases(pts), device=0, window_bits=c)
+    enc = [(k << 256) % R if mont else k for k in ks]
+    dev = torch.device("cuda", 0)
+    d_s = torch.frombuffer(bytearray(b"".join(int(k).to_bytes(32, "little") for k in enc)), dtype=torch.uint8).to(dev)
+    d_w = torch.empty(m.work_bytes(E) + 256, dtype=torch.uint8, device=dev)
+    d_w = d_w[(-d_w.data_ptr()) % 256:]
+    got = m.g1_batch_device(d_s, E, mont, d_w, ones_apart=apart)
+    for e in range(E):
+        folded = {}
+        for p, k in zip(pts, ks[e * n:(e + 1) * n]):
+            if p is not None:
+                folded[p] = (folded.get(p, 0) + k) % R
+        assert got[e] == G.msm_naive(list(folded), list(folded.values())), e
+        assert got[e] == m.g1_device(d_s[32 * n * e:32 * n * (e + 1)], mont, d_w, ones_apart=apart), e
+    assert got[1] is None
+
+
 def test_library_exports_the_msm_entry_points_and_refuses_without_a_device():
     import ctypes as C
     import zkwg
     from zkwg import _lib
     lib = _lib.load()
-    for name in ("zkwg_msm_create", "zkwg_msm_destroy", "zkwg_msm_work_bytes", "zkwg_msm_window_bits", "zkwg_msm_g1_device"):
+    for name in ("zkwg_msm_create", "zkwg_msm_destroy", "zkwg_msm_work_bytes", "zkwg_msm_window_bits", "zkwg_msm_g1_device", "zkwg_msm_create_ex",
+                 "zkwg_msm_enqueue_batch_device", "zkwg_msm_classify_device", "zkwg_msm_enqueue_lists_device", "zkwg_msm_lists_bytes"):
         assert hasattr(lib, name)
     h = C.c_void_p()
     assert lib.zkwg_msm_create(-1, bytes(64), 1, 0, C.byref(h)) != 0          # no CPU fallback

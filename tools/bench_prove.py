@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Times the device-side prover (zkwg.prover: witness -> A.w | B.w | C.w -> H evaluations -> five multi-exponentiations -> proof
-assembly) per email, stage by stage.  The bases are fixed-base multiples of RANDOM scalars (zkwg_fixed_base_device): timing needs
-points of the right shape, not a valid key -- validity is tests/test_prove.py's business (pinned verifier).  Prints one JSON line.
+assembly), stage by stage and end to end, E emails per launch series (round 6).  The key is made from KNOWN discrete logarithms
+(zkwg_fixed_base_device): a few thousand distinct scalars repeated, so every timed sum can be checked against (sum_i k_i s_i) G with
+one fixed-base multiple -- `sums_verified` -- without a set-up ceremony; proofs under a VALID key are tests/test_prove.py's business
+(pinned verifier, incl. one at the headline circuit).  Prints one JSON line.
 
-    python tools/bench_prove.py [--max-header 576 --max-body 192] [--emails 8]
+    python tools/bench_prove.py [--max-header 576 --max-body 192] [--emails 8] [--slots 24]
 """
 import argparse
 import json
@@ -12,29 +14,29 @@ import random
 import sys
 import time
 
-# Proofs in flight live on separate HIP streams; the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default),
-# and a multi-exponentiation's serial tail holds its queue: 16 queues took the same code from 43 to 85 proofs/s
-# (profiles/r05/r05_i_bench_prove.json).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "zk-email-verify_amd", "py"))
+
+PRODUCT_RATE = 139.0e9      # field products/s of the 9 x 29-bit product behind the 4 x 64-bit interface in a pure loop (tools/mulbench.hip, profiles/r05/r05_g_mulbench.txt)
+LAZY_RATE = 162.9e9         # the same product without split / pack (zkwg_fq29.h's form), same measurement
 
 
 def main(argv=None, quiet=False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-header", type=int, default=576)
     ap.add_argument("--max-body", type=int, default=192)
-    ap.add_argument("--emails", type=int, default=8)
-    ap.add_argument("--slots", type=int, default=32, help="proofs in flight (one stream each)")
+    ap.add_argument("--emails", type=int, default=8, help="emails of the prepared batch = emails per launch series of the stage timings")
+    ap.add_argument("--slots", type=int, default=24, help="proofs in flight (zkwg_prover_create: 1-3 contexts x emails per series)")
     ap.add_argument("--proofs", type=int, default=96, help="proofs timed in the batched run")
+    ap.add_argument("--check-sums", type=int, default=1)
     args = ap.parse_args(argv)
     import torch
     import zkwg
     from zkwg import prover, synth
     from zkwg import r1cs as zr
     N, M, n = args.max_header, args.max_body, args.emails
-    R = prover.R
+    R, Q = prover.R, prover.Q
     t0 = time.time()
     c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
     sym = c.symbols()
@@ -43,13 +45,13 @@ def main(argv=None, quiet=False):
     data = zr.write_r1cs(len(sym), full, n_pub_out=3, n_pub_in=17, n_prv_in=N + 1 + 17 + 1 + 32 + M + 1)
     power = max(1, (len(full) - 1).bit_length())
     rng = random.Random(1)
-    # random bases: a few thousand distinct points repeated (fixed-base work is not what is timed)
     pool = [rng.randrange(1, R) for _ in range(4096)]
-    rep = lambda k: [pool[(7 * i + 3) % 4096] for i in range(k)]
+    idx_of = lambda i: (7 * i + 3) % 4096
+    rep = lambda k: [pool[idx_of(i)] for i in range(k)]
     pk = prover.ProvingKey.from_scalars(0, n_public, power, rep(c.W), rep(c.W), rep(c.W - n_public - 1), rep(1 << power), 5, 7, 11)
     pv = prover.Prover(c, data, len(full), pk)
     t_setup = time.time() - t0
-    recs, _ = synth.packed_batch(c, seed=9, n=n, body_len=min(100, M - 80))
+    recs, _ = synth.packed_batch(c, seed=9, n=n, body_len=min(1024 if M >= 1536 else 100, M - 80))
     dev = torch.device("cuda", 0)
     d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(dev)
     d_status = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -57,44 +59,104 @@ def main(argv=None, quiet=False):
     c.prepare_device(d_in, n, d_status, d_scratch)
     torch.cuda.synchronize()
     assert d_status.tolist() == [0] * n
-    pv.prove_prepared(d_in, n, d_scratch, 0, 3, 4)       # warm-up (builds the per-stage plans)
+    pv.prove_prepared(d_in, n, d_scratch, 0, 3, 4)       # warm-up (builds the Python-side plans)
     torch.cuda.synchronize()
-    # stage timings on one email
+
     def timed(f, reps=3):
-        torch.cuda.synchronize(); t = time.time()
+        f(); torch.cuda.synchronize(); t = time.time()
         for _ in range(reps): f()
         torch.cuda.synchronize(); return (time.time() - t) / reps * 1e3
-    wit = pv.d_wit.data_ptr()
-    st = {
-        "witness_ms": timed(lambda: c.expand_device(d_in, n, d_scratch, 0, 1, pv.d_wit)),
-        "abc_ms": timed(lambda: c.expand_abc_device(d_in, n, d_scratch, 0, 1, pv.d_abc, montgomery=True)),
-        "h_evaluations_ms": timed(lambda: pv.ntt.h_evaluations_device(pv.d_abc, c.abc_bytes, pv.m, 1, pv.d_ntt_work, pv.d_h)),
-        "msm_a_ms": timed(lambda: pv.msm_a.run(wit, False, True, pv.d_msm_work)),
-        "msm_b1_ms": timed(lambda: pv.msm_b1.run(wit, False, True, pv.d_msm_work)),
-        "msm_b2_g2_ms": timed(lambda: pv.msm_b2.run(wit, False, True, pv.d_msm_work)),
-        "msm_c_ms": timed(lambda: pv.msm_c.run(wit + 32 * (n_public + 1), False, True, pv.d_msm_work)),
-        "msm_h_ms": timed(lambda: pv.msm_h.run(pv.d_h.data_ptr(), True, False, pv.d_msm_work)),
-    }
-    torch.cuda.synchronize()
-    t = time.time()
-    for e in range(min(n, 4)):
-        pv.prove_prepared(d_in, n, d_scratch, e, 3 + e, 4 + e)
-    torch.cuda.synchronize()
-    per_single = (time.time() - t) / min(n, 4)
-    # several proofs in flight
-    idx = [e % n for e in range(args.proofs)]
-    bl = [(3 + e, 4 + e) for e in range(args.proofs)]
-    pv.prove_batch(d_in, n, d_scratch, idx[:args.slots], bl[:args.slots], slots=args.slots)     # buffers, first touch
-    torch.cuda.synchronize()
-    t = time.time()
-    pv.prove_batch(d_in, n, d_scratch, idx, bl, slots=args.slots)
-    torch.cuda.synchronize()
-    per = (time.time() - t) / args.proofs
-    out = {"circuit": f"EmailVerifier({N},{M},121,17,0,0,0,0)", "W": c.W, "constraints_with_public_rows": len(full), "domain_log2": power,
-           "emails": n, "proofs_per_s": round(1 / per, 2), "ms_per_proof": round(per * 1e3, 2), "proofs_in_flight": args.slots, "proofs_timed": args.proofs, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-           "msm_layout": "precomputed windows" if os.environ.get("ZKWG_MSM_PRECOMP", "1") != "0" else "classic",
-           "one_at_a_time_ms_per_proof": round(per_single * 1e3, 2), "stages": {k: round(v, 2) for k, v in st.items()},
-           "setup_s": round(t_setup, 1), "key": "random bases (timing only; validity: tests/test_prove.py under the pinned verifier)"}
+    # ---- stages, E = n emails per series (ms per email) and one email alone (ms) ----------------------------------------------------
+    W, m, dom = c.W, pv.m, 1 << power
+    wb, ab, hb = c.witness_bytes, c.abc_bytes, 32 << power
+    d_wit = torch.empty(n * wb, dtype=torch.uint8, device=dev)
+    d_abc = torch.empty(n * ab, dtype=torch.uint8, device=dev)
+    d_h = torch.empty(n * hb, dtype=torch.uint8, device=dev)
+    d_nw = torch.empty(pv.ntt.work_bytes(n), dtype=torch.uint8, device=dev)
+    plans = {"msm_a": (pv.msm_a, 0), "msm_b1": (pv.msm_b1, 0), "msm_b2_g2": (pv.msm_b2, 0), "msm_c": (pv.msm_c, 32 * (n_public + 1)), "msm_h": (pv.msm_h, 0)}
+    wk = max(p.work_bytes(n) for p, _ in plans.values())
+    d_work = torch.empty(wk + 256, dtype=torch.uint8, device=dev)
+    d_work = d_work[(-d_work.data_ptr()) % 256:]
+    st, st1 = {}, {}
+    for E, out in ((n, st), (1, st1)):
+        out["witness_ms"] = timed(lambda: c.expand_device(d_in, n, d_scratch, 0, E, d_wit)) / E
+        out["abc_ms"] = timed(lambda: c.expand_abc_device(d_in, n, d_scratch, 0, E, d_abc, montgomery=True)) / E
+        out["h_evaluations_ms"] = timed(lambda: pv.ntt.h_evaluations_device(d_abc, ab, m, E, d_nw, d_h)) / E
+        for name, (pl, off) in plans.items():
+            if name == "msm_h":
+                out[name + "_ms"] = timed(lambda: pl.run_batch(d_h.data_ptr(), hb, E, True, False, d_work)) / E
+            else:
+                out[name + "_ms"] = timed(lambda: pl.run_batch(d_wit.data_ptr() + off, wb, E, False, True, d_work)) / E
+    # ---- every sum of email 0 against its discrete logarithm (product code only: Python integers + one fixed-base multiple) -----------
+    sums_ok = None
+    if args.check_sums:
+        import numpy as np
+        wit = np.frombuffer(bytes(d_wit[:wb].cpu().numpy()), dtype="<u8").reshape(-1, 4)
+        hv = np.frombuffer(bytes(d_h[:hb].cpu().numpy()), dtype="<u8").reshape(-1, 4)
+        def dlog(rows, first, count, mont):
+            # fold by distinct base first -- sum_j pool[j] * (sum of the scalars on it) -- with exact 32-bit half-limb sums in numpy
+            idx = (7 * np.arange(count, dtype=np.int64) + 3) % 4096
+            acc = [0] * 4096
+            for hl in range(8):
+                col = (rows[first:first + count, hl // 2] >> np.uint64(32 * (hl & 1))) & np.uint64(0xffffffff)
+                part = np.zeros(4096, dtype=np.uint64)
+                np.add.at(part, idx, col)
+                for j in range(4096):
+                    acc[j] += int(part[j]) << (32 * hl)
+            s = sum(a * pool[j] for j, a in enumerate(acc)) % R
+            return s * pow(1 << 256, -1, R) % R if mont else s
+        want = {"msm_a": dlog(wit, 0, W, False), "msm_b1": dlog(wit, 0, W, False), "msm_b2_g2": dlog(wit, 0, W, False),
+                "msm_c": dlog(wit, n_public + 1, W - n_public - 1, False), "msm_h": dlog(hv, 0, dom, True)}
+        sums_ok = True
+        for name, (pl, off) in plans.items():
+            if name == "msm_h":
+                got = pl.run_batch(d_h.data_ptr(), hb, 1, True, False, d_work)[0]
+            else:
+                got = pl.run_batch(d_wit.data_ptr() + off, wb, 1, False, True, d_work)[0]
+            ref = bytes(prover.fixed_base(0, pl.group, [want[name]]).cpu().numpy())
+            if got != ref:
+                sums_ok = False
+                print("SUM MISMATCH", name, file=sys.stderr)
+    # ---- end to end ---------------------------------------------------------------------------------------------------------------------
+    def run(count, slots):
+        idx = [e % n for e in range(count)]
+        bl = [(3 + e, 4 + e) for e in range(count)]
+        torch.cuda.synchronize(); t = time.time()
+        out = pv.prove_batch(d_in, n, d_scratch, idx, bl, slots=slots)
+        torch.cuda.synchronize()
+        return (time.time() - t) / count, out
+    run(2, 1)
+    per_single, singles = run(min(n, 4), 1)               # one proof in flight: its five sums still run side by side on three streams
+    run(args.slots, args.slots)                           # buffers, first touch
+    per, batch = run(args.proofs, args.slots)
+    same = batch[:min(n, 4)] == singles
+    lib = pv.lib
+    E_series, n_ctx = lib.zkwg_prover_emails_per_series(pv._h), lib.zkwg_prover_contexts(pv._h)
+    # ---- algorithmic field products per email and stage (mixed addition 10, full addition 14 products in G1; G2: 10 / 14 two-product
+    # dot products per lane of a pair = 30 / 42 products; a radix-2 butterfly 1 product) and their rate against the product's own
+    K16, K13 = 16, 20
+    import numpy as np
+    w0 = np.frombuffer(bytes(d_wit[:wb].cpu().numpy()), dtype="<u8").reshape(-1, 4)
+    hi = (w0[:, 1] | w0[:, 2] | w0[:, 3]) != 0
+    n_one = int(((~hi) & (w0[:, 0] == 1)).sum()); n_small = int(((~hi) & (w0[:, 0] > 1)).sum()); n_big = int(hi.sum())
+    adds_w = n_one + n_small * 2 + n_big * K13              # (an upper bound: bases at infinity drop out)
+    prods = {"h_evaluations": 6 * (power * dom // 2) + 5 * dom, "msm_h": dom * K16 * 10 + (dom * K16 // 64 + 3 * 32768 + 16 * 16384) * 14,
+             "msm_a": adds_w * 10, "msm_b1": adds_w * 10, "msm_c": adds_w * 10, "msm_b2_g2": adds_w * 30}
+    frac = {k: round(prods[k] / (st[k + "_ms"] * 1e-3) / PRODUCT_RATE, 3) for k in prods}
+    total_products = sum(prods.values())
+    out = {"circuit": f"EmailVerifier({N},{M},121,17,0,0,0,0)", "W": W, "constraints_with_public_rows": len(full), "domain_log2": power,
+           "emails": n, "proofs_per_s": round(1 / per, 2), "ms_per_proof": round(per * 1e3, 2), "proofs_in_flight": args.slots, "contexts": n_ctx,
+           "emails_per_series": E_series, "proofs_timed": args.proofs, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
+           "one_at_a_time_ms_per_proof": round(per_single * 1e3, 2), "batched_equals_one_at_a_time": same,
+           "stages_ms_per_email_in_series_of_%d" % n: {k: round(v, 3) for k, v in st.items()}, "stages_ms_one_email": {k: round(v, 2) for k, v in st1.items()},
+           "witness_scalars": {"ones": n_one, "small": n_small, "full_size": n_big},
+           "field_products_per_email": prods, "products_per_s_over_139G_by_stage": frac,
+           "whole_proof_products_per_s_over_139G": round(total_products / per / PRODUCT_RATE, 3),
+           "sums_verified": sums_ok, "setup_s": round(t_setup, 1),
+           "key": "bases = k_i G from known k_i (4,096 distinct values repeated): every sum of one timed email equals (sum k_i s_i) G (sums_verified); "
+                  "a VALID key + the pinned pairing check at this circuit: tests/test_prove.py",
+           "product_rate_note": "139.0 G/s = tools/mulbench.hip for the 9 x 29-bit product behind the 4 x 64-bit interface (the transforms' product); "
+                                "the sums run the lazy limb form (162.9 G/s in the same loop)"}
     if not quiet:
         print(json.dumps(out))
     return out

@@ -9,6 +9,8 @@
 #   prof          rocprofv3 --kernel-trace --stats of the headline pipeline
 #   rslb          removeSoftLineBreaks = 1 variant (rslb:<label> appends to <tag>_rslb_variants.json)      abc  tools/bench_abc.py      o0  tools/bench_full.py
 #   pmc:<tool.py> per-kernel HBM traffic of a tool (two rocprofv3 --pmc passes)
+#   prove[:<args>]  tools/bench_prove.py (appends one JSON line to <tag>_bench_prove.json)      provep[:<args>]  the same under rocprofv3 --kernel-trace --stats
+#   msm:<args>    tools/bench_msm.py      ntt[:<args>]  tools/bench_ntt.py      run:<command>  anything else (output tail -> <tag>_run.txt)
 #   env:K=V       export K=V for the following steps
 TAG=$1; shift
 OUT=$PWD/gpurun_out; mkdir -p $OUT
@@ -83,6 +85,17 @@ for k, v in sorted(out.items(), key=lambda kv: -kv[1]["write_GB_per_launch"] * k
     print("%-28s launches %4d  write %8.3f GB  fetch %8.3f GB per launch" % (k, v["launches"], v["write_GB_per_launch"], v["fetch_GB_per_launch_corrected_x2"]))
 PY
       rm -rf $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_FETCH_SIZE ;;
+    prove) timeout 900 python tools/bench_prove.py 2>$OUT/${TAG}_prove.err | tail -1 | tee -a $OUT/${TAG}_bench_prove.json | cut -c1-1500; tail -3 $OUT/${TAG}_prove.err ;;
+    prove:*) timeout 900 python tools/bench_prove.py ${step#prove:} 2>$OUT/${TAG}_prove.err | tail -1 | tee -a $OUT/${TAG}_bench_prove.json | cut -c1-1500; tail -3 $OUT/${TAG}_prove.err ;;
+    provep|provep:*) A=""; [ "$step" != provep ] && A="${step#provep:}"
+          ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_pprof -- \
+              python $REPO/tools/bench_prove.py $A > $OUT/${TAG}_prove_prof.json 2> $OUT/${TAG}_pprof.log )
+          S=$(find $OUT/${TAG}_pprof -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_prove_kernel_stats.csv && head -40 $S | cut -c1-170
+          rm -rf $OUT/${TAG}_pprof; tail -1 $OUT/${TAG}_prove_prof.json | cut -c1-800 ;;
+    msm:*) timeout 600 python tools/bench_msm.py ${step#msm:} 2>&1 | tail -1 | tee -a $OUT/${TAG}_msm.json ;;
+    ntt) timeout 600 python tools/bench_ntt.py 2>&1 | tail -1 | tee -a $OUT/${TAG}_ntt.json | cut -c1-800 ;;
+    ntt:*) timeout 600 python tools/bench_ntt.py ${step#ntt:} 2>&1 | tail -1 | tee -a $OUT/${TAG}_ntt.json | cut -c1-800 ;;
+    run:*) timeout 1500 bash -c "${step#run:}" 2>&1 | tail -30 | tee -a $OUT/${TAG}_run.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done

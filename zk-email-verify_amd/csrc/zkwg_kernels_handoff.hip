@@ -33,3 +33,19 @@ extern "C" int zk_rows_copy_launch(const u8* src, u64 stride, u8* dst, u32 count
   hipLaunchKernelGGL(zk_rows_copy, dim3((count * 6u + 255u) / 256u), dim3(256), 0, st, src, stride, dst, count);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// C.w = A.w o B.w row by row (Montgomery form), for a prover whose constraint system came from a zkey: section 4 of the file holds the
+// rows of A and B only, and snarkjs' buildABC1 computes the third block exactly like this (groth16_prove.js; reference call site
+// packages/helpers/src/chunked-zkey.ts:80-84).  d_abc: n_emails records A.w | B.w | C.w of n_rows values each, abc_stride bytes apart.
+__global__ __launch_bounds__(256) void zk_abc_c_from_ab(Fr* __restrict__ abc, u64 stride_fr, u64 n_rows) {
+  Fr* rec = abc + (u64)blockIdx.y * stride_fr;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (u64)gridDim.x * 256) {
+    const Fr a = rec[i], b = rec[n_rows + i];
+    rec[2 * n_rows + i] = (fr_is_zero(a) || fr_is_zero(b)) ? fr_zero() : fr_mont_mul(a, b);
+  }
+}
+void zk_abc_c_from_ab_launch(void* d_abc, uint64_t abc_stride, uint64_t n_rows, uint32_t n_emails, hipStream_t st) {
+  if (!n_emails || !n_rows) return;
+  const u64 g = (n_rows + 255) / 256;
+  hipLaunchKernelGGL(zk_abc_c_from_ab, dim3((u32)(g > 4096 ? 4096 : g), n_emails), dim3(256), 0, st, (Fr*)d_abc, abc_stride / 32, n_rows);
+}

@@ -1,310 +1,263 @@
-// G1 multi-exponentiation on the device: the per-thread bodies of the kernels of zkwg_kernels_msm.hip, shared with the host
-// mirror of the CPU tests (tests/native/hosttest.cpp runs exactly these functions, thread by thread).  Bucket method with signed
-// c-bit windows (zkwg_g1.h), organised around one counting sort per call:
+// Multi-exponentiations over BN254 G1 / G2 for the prover (second half of groth16.fullProve, reference call site
+// packages/helpers/src/chunked-zkey.ts:80-84): the per-thread bodies of the kernels of zkwg_kernels_msm.hip, shared with the host mirror
+// of the CPU tests (tests/native/hosttest.cpp runs exactly these functions, thread by thread, in launch order).
 //
-//   zk_msm_count    one thread per scalar: leave Montgomery form (one product), cut into K signed digits, count[window * nb + |d| - 1]++
-//   zk_msm_scan     exclusive prefix sums of the K * nb counters (one workgroup)
-//   zk_msm_scatter  one thread per scalar: the same digits again; entry[cursor[bucket]++] = base index | sign << 31
-//                   (the order inside a bucket depends on the atomics; the sum does not -- point addition is exact and commutative)
-//   zk_msm_buckets  one thread per bucket: its run of entries, accumulated with g1_add_mixed
-//   zk_msm_reduce   sum_b (b + 1) bucket[b] per window as a tree of 32-way groups: a node is (S, A) = (plain sum, weighted sum with
-//                   weights 1 .. span); 32 nodes of span s join into A = sum A_i + s * sum_i i S_i (running sum from the top, log2 s
-//                   doublings), S = sum S_i.  nb = 2^(c-1) buckets take ceil((c-1)/5) levels.
-//   zk_msm_combine  one thread: Horner over the windows, c doublings each
+// Round 6: EMAILS ARE THE PARALLEL AXIS here as everywhere else in zkwg.  One launch series sums E scalar vectors against ONE set of bases
+// (every kernel below takes the email as its second grid dimension and its own slice of one work buffer), so the thin tails of a sum --
+// a few lanes folding bit planes, one lane combining windows -- are E lanes wide and the number of launches per proof falls by E; round 5
+// ran one launch chain per proof on its own stream and depended on GPU_MAX_HW_QUEUES to overlap them.  Point arithmetic is the lazy
+// 29-bit limb form of zkwg_ec29.h (G2 on lane pairs).  Steps of one series:
 //
-// DRAFT (branch next/msm, round 4): written and mirrored on the CPU after the round's GPU budget was spent; it has not run on a GPU.
+//   zk_msm_classify  (when the scalars are a witness: > 95 % zeros and ones) one pass over the scalars that writes, per email, the index
+//                    list of the scalars that are 1 and the list of the others (not 0, not 1), skipping bases at infinity (bit map made at
+//                    plan creation).  The prover runs it ONCE for its four witness-shaped sums (three base sets: A, B1 = B2, C).
+//   zk_msm_ones      the bases of the `ones` list, ZK_MSM_ONES per lane, then ZK_MSM_JOIN-way joins (log depth)
+//   zk_msm_sort      counting sort of the other scalars' signed c-bit digits by bucket: count -> scan -> scatter, with workgroup-local
+//                    histograms in LDS when the bucket counters fit (one global atomic per bucket and workgroup, not per digit)
+//   zk_msm_slice_*   a bucket's run of entries is summed in SLICES by as many lanes as it needs (level 0: s0 mixed additions of bases per
+//                    lane, levels 1 and 2: 8 partial sums per lane), then one lane per bucket joins what is left
+//   zk_msm_plane*    the weighted bucket sum  sum_b (b + 1) bucket[b]  by bit planes: T_j = plain sum of the buckets whose weight has bit j
+//                    set (8-way joins, c rows at once), one lane folds sum_j 2^j T_j with c - 1 doublings
+//   zk_msm_combine   windows (Horner, classic layout only) + the ones' sum -> the accumulator in zkwg_g1.h / zkwg_g2.h XYZZ words
+//
+// Precomputed windows (default): the table holds K shifted copies of the bases, copy w = 2^(c w) base, so digit d of window w selects
+// copy w and ALL windows share one set of 2^(c-1) buckets (KS = 1); the classic layout (KS = K bucket sets) is what is left when the
+// copies do not fit.  Tables are in 2^261-Montgomery form (zk_msm_table_thread converts the zkey's 2^256 form once).
 #pragma once
-#include "zkwg_g1.h"
-#include "zkwg_g2.h"
+#include "zkwg_ec29.h"
 
-#define ZK_MSM_FAN 8u      // fan-in of the weighted bucket tree: a node's serial work is 3 additions per child; the levels are what a lone sum waits for
 #define ZK_MSM_JOIN 8u     // fan-in of the joins of the ones' partial sums
-#define ZK_MSM_ONES 8u     // bases per lane of zk_msm_ones (64 and 16-way joins until r05_s: 124 dependent additions for a 1.8 M-wire witness, 50 now)
+#define ZK_MSM_ONES 16u    // list entries per lane of zk_msm_ones
+#define ZK_MSM_PFAN 8u     // fan-in of the bit-plane joins
+#define ZK_MSM_S1 8u       // partial sums per lane at slice levels 1 and 2
+#define ZK_MSM_LDS_BUCKETS 32768u
 
-// the group the sums run over: G1 (pi_a, pib1, pi_c, the H sum) or G2 (pi_b) -- same kernels, other point arithmetic
-struct ZkCurveG1 {
-  typedef G1Affine Affine; typedef G1Xyzz Xyzz;
-  static ZK_HD Xyzz inf() { return g1_xyzz_inf(); }
-  static ZK_HD bool is_inf(const Affine& p) { return g1_is_inf(p); }
-  static ZK_HD Affine neg(const Affine& p) { return g1_neg(p); }
-  static ZK_HD Xyzz add_mixed(const Xyzz& a, const Affine& p) { return g1_add_mixed(a, p); }
-  static ZK_HD Xyzz add(const Xyzz& a, const Xyzz& b) { return g1_add(a, b); }
-  static ZK_HD Xyzz dbl(const Xyzz& a) { return g1_dbl(a); }
-};
-struct ZkCurveG2 {
-  typedef G2Affine Affine; typedef G2Xyzz Xyzz;
-  static ZK_HD Xyzz inf() { return g2_xyzz_inf(); }
-  static ZK_HD bool is_inf(const Affine& p) { return g2_is_inf(p); }
-  static ZK_HD Affine neg(const Affine& p) { return g2_neg(p); }
-  static ZK_HD Xyzz add_mixed(const Xyzz& a, const Affine& p) { return g2_add_mixed(a, p); }
-  static ZK_HD Xyzz add(const Xyzz& a, const Xyzz& b) { return g2_add(a, b); }
-  static ZK_HD Xyzz dbl(const Xyzz& a) { return g2_dbl(a); }
+// offsets of one email's arrays inside its slice of the work buffer
+struct ZkMsmOff {
+  u64 count, cursor, entry, bucket, node_s, node_a, window, ones, soff[3], part[3], total;
+  u32 cap[3];
 };
 
 template <class C>
 struct ZkMsmArgsT {
-  typedef typename C::Affine G1Affine;
-  typedef typename C::Xyzz G1Xyzz;
-  const G1Affine* bases;      // n points, Montgomery form, (0, 0) = infinity
-  const Fr* scalars;          // n scalars of this call
-  u32 n, c, K, nb;            // points, window bits, windows, buckets per window = 2^(c-1)
-  // Precomputed windows (KS = 1, stride = n): `bases` holds K copies of the points, copy w = 2^(c w) * base (zk_msm_shift_thread, once per
-  // key), so digit d of window w selects copy w and ALL windows share one set of nb buckets: there is no Horner pass over the windows (254
-  // dependent doublings on one lane: 3.8 ms of a 15 ms sum, profiles/r05/r05_i_prove_kernel_stats.csv) and one bucket tree instead of K.
-  // Classic layout: KS = K bucket sets, stride = 0.  The memory is what 288 GB are for: 20 x 47 MB per witness-sized sum.
-  u32 KS, stride;
-  u32 scalars_mont;           // 1: the scalars are in Montgomery form (the H evaluations of zkwg_ntt_api.hip, a Montgomery witness)
-  u32 lds_sort;               // 1: count / scatter with workgroup-local histograms (zk_msm_sort_wg_thread) when KS nb fits LDS
-  u32 plane_sums;             // 1: the weighted bucket sum by bit planes (zk_msm_plane*: log depth); 0: the (S, A) tree of zk_msm_reduce
-  u32 ones_apart;             // 1: scalars equal to 1 do not enter the buckets (a witness is mostly bits: they would all land in ONE
-                              // bucket of window 0); their bases are summed by zk_msm_ones + the 64-way tree and added at the end
-  G1Xyzz* ones;               // [2 x ceil(n / ZK_MSM_ONES)] tree scratch of the ones' sum (ping-pong halves); ones[0] = the sum at the end
-  u32* count;                 // [K * nb + 1] counters, then exclusive offsets (zk_msm_scan)
-  u32* cursor;                // [K * nb] running write positions of zk_msm_scatter
-  u32* entry;                 // [n * K] base index | sign << 31, grouped by bucket
-  G1Xyzz* bucket;             // [K * nb]
-  // a bucket's run of entries is summed in SLICES, by several threads: witness scalars are bits, bytes and a few field elements, so a
-  // handful of buckets (the common byte values) receive thousands of entries while most receive none; one thread per bucket took 58 ms
-  // for a 736 k-wire witness against 16 ms for 2^20 random scalars (profiles/r05/r05_d_bench_prove.json).  Level 0: slices of
-  // ZK_MSM_S0 entries (mixed additions of bases); levels 1, 2: slices of ZK_MSM_S1 partial sums of the level below; then one thread per
-  // bucket joins what is left (one item unless the bucket held more than S0 S1 S1 entries).
-  u32* soff[3];               // [K * nb + 1] per level: first slice of every bucket
-  G1Xyzz* part[3];            // per level: the slices' sums
-  u32 cap[3];                 // slices a level can hold (n K / S + K nb bounds it)
-  G1Xyzz* node_s; G1Xyzz* node_a;   // bit-plane sums, ping-pong: node_s [KS c n0], node_a [KS c ceil(n0 / F)], n0 = ceil(nb / ZK_MSM_PFAN)
-  G1Xyzz* window;             // [K] weighted bucket sums
-  G1Xyzz* out;                // [1]
+  typedef typename C::Affine Affine;
+  typedef Xyzz29<typename C::F> X;
+  const Affine* table;        // KS == 1: K copies of the n bases (copy w at table + w n); KS == K: the n bases.  2^261 form, zeros = infinity
+  const u32* inf;             // bit i set: base i is the point at infinity
+  const Fr* scalars;          // email e's scalars at scalars + e * scalar_stride
+  u64 scalar_stride;
+  u32 n, c, K, nb, KS, stride;   // points, window bits, windows, buckets per set = 2^(c-1), bucket sets, stride = n (KS == 1) or 0
+  u32 E;                      // emails of this launch series
+  u32 scalars_mont;           // 1: the scalars are in Montgomery form (the H evaluations of zkwg_ntt_api.hip)
+  u32 lds_sort;               // 1: workgroup-local histograms (KS nb <= ZK_MSM_LDS_BUCKETS)
+  u32 s0;                     // entries per lane at slice level 0 (16 for a witness' few full-size scalars, 64 for 2^21 of them)
+  // index lists (zk_msm_classify).  sel == nullptr: every scalar enters the buckets (the H sum); ones == nullptr: no ones' sum
+  const u32* sel; const u32* n_sel;       // email e: sel + e * list_stride, n_sel[e] entries
+  const u32* ones; const u32* n_ones;
+  u64 list_stride;
+  u8* work; u64 work_stride;  // email e's arrays: work + e * work_stride + off.*
+  ZkMsmOff off;
+  typename C::Out* out;       // [E]
+  ZK_HD u8* w(u32 e) const { return work + (u64)e * work_stride; }
+  ZK_HD u32* count(u32 e) const { return (u32*)(w(e) + off.count); }
+  ZK_HD u32* cursor(u32 e) const { return (u32*)(w(e) + off.cursor); }
+  ZK_HD u32* entry(u32 e) const { return (u32*)(w(e) + off.entry); }
+  ZK_HD X* bucket(u32 e) const { return (X*)(w(e) + off.bucket); }
+  ZK_HD X* node_s(u32 e) const { return (X*)(w(e) + off.node_s); }
+  ZK_HD X* node_a(u32 e) const { return (X*)(w(e) + off.node_a); }
+  ZK_HD X* window(u32 e) const { return (X*)(w(e) + off.window); }
+  ZK_HD X* ones_acc(u32 e) const { return (X*)(w(e) + off.ones); }
+  ZK_HD u32* soff(u32 e, int l) const { return (u32*)(w(e) + off.soff[l]); }
+  ZK_HD X* part(u32 e, int l) const { return (X*)(w(e) + off.part[l]); }
+  ZK_HD u32 sel_count(u32 e) const { return sel ? n_sel[e] : n; }
+  ZK_HD u32 sel_at(u32 e, u32 j) const { return sel ? sel[(u64)e * list_stride + j] : j; }
+  ZK_HD bool base_inf(u32 i) const { return (inf[i >> 5] >> (i & 31u)) & 1u; }
 };
-typedef ZkMsmArgsT<ZkCurveG1> ZkMsmArgs;
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define ZK_MSM_ATOMIC_INC(p) atomicAdd((p), 1u)
 #define ZK_MSM_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #else
-#define ZK_MSM_ATOMIC_INC(p) ((*(p))++)
 static inline u32 zk_msm_host_fetch_add(u32* p, u32 v) { const u32 o = *p; *p = o + v; return o; }
 #define ZK_MSM_ATOMIC_ADD(p, v) zk_msm_host_fetch_add((p), (v))
 #endif
 
-// scalar i in standard form
-template <class C>
-ZK_HD Fr zk_msm_scalar(const ZkMsmArgsT<C>& A, u32 i) { return A.scalars_mont ? fr_from_mont(A.scalars[i]) : A.scalars[i]; }
 ZK_HD bool zk_msm_is_one(const Fr& k) { return k.l[0] == 1 && (k.l[1] | k.l[2] | k.l[3]) == 0; }
-// the bases whose scalar is 1, ZK_MSM_ONES per thread (ones_apart); then zk_msm_tree_thread joins ZK_MSM_JOIN partial sums per thread until one is left
+ZK_HD Fr zk_msm_std(const Fr& k, u32 mont) { return mont ? fr_from_mont(k) : k; }
 template <class C>
-ZK_HD void zk_msm_ones_thread(const ZkMsmArgsT<C>& A, u32 t) {
-  const u32 lo = t * ZK_MSM_ONES, hi = lo + ZK_MSM_ONES < A.n ? lo + ZK_MSM_ONES : A.n;
-  if (lo >= A.n) return;
-  typename C::Xyzz acc = C::inf();
-  for (u32 i = lo; i < hi; ++i)
-    if (zk_msm_is_one(zk_msm_scalar(A, i))) acc = C::add_mixed(acc, A.bases[i]);
-  A.ones[t] = acc;
+ZK_HD Fr zk_msm_scalar(const ZkMsmArgsT<C>& A, u32 e, u32 i) { return zk_msm_std(A.scalars[(u64)e * A.scalar_stride + i], A.scalars_mont); }
+
+// ---- classification: one pass over E scalar vectors for up to three base sets ---------------------------------------------------------
+struct ZkClassifyTarget {
+  const u32* inf;             // the base set's infinity bits
+  u32 first, n;               // the set covers the scalars [first, first + n); list entries are relative to `first`
+  u32* sel; u32* n_sel;       // email e: sel + e * list_stride; n_sel[e] (zeroed by the caller)
+  u32* ones; u32* n_ones;
+  u64 list_stride;
+};
+struct ZkClassifyArgs {
+  const Fr* scalars; u64 scalar_stride;
+  u32 n, E, scalars_mont, ones_apart, n_targets;
+  ZkClassifyTarget t[3];
+};
+// append `val` to a list when `pred`; every lane of the wavefront calls it (device: one atomic per wavefront, ranks from the ballot)
+ZK_HD void zk_msm_append(u32* counter, u32* list, bool pred, u32 val) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const u64 m = __ballot(pred);
+  if (m == 0) return;
+  const u32 lane = __lane_id(), leader = (u32)__builtin_ctzll(m);
+  u32 base = 0;
+  if (lane == leader) base = atomicAdd(counter, (u32)__builtin_popcountll(m));
+  base = (u32)__shfl((int)base, (int)leader);
+  if (pred) list[base + (u32)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = val;
+#else
+  if (pred) list[(*counter)++] = val;
+#endif
+}
+// scalar i of email e (every lane of a wavefront runs it, in range or not: the appends are wavefront-collective)
+ZK_HD void zk_msm_classify_thread(const ZkClassifyArgs& A, u32 e, u32 i) {
+  const bool in = i < A.n;
+  Fr k = fr_zero();
+  if (in) k = zk_msm_std(A.scalars[(u64)e * A.scalar_stride + i], A.scalars_mont);
+  const bool nz = in && !fr_is_zero(k);
+  const bool one = nz && A.ones_apart && zk_msm_is_one(k);
+  for (u32 t = 0; t < A.n_targets; ++t) {
+    const ZkClassifyTarget& T = A.t[t];
+    const u32 r = i - T.first;
+    const bool mine = nz && i >= T.first && r < T.n && !((T.inf[r >> 5] >> (r & 31u)) & 1u);
+    zk_msm_append(&T.n_ones[e], T.ones + (u64)e * T.list_stride, mine && one, r);
+    zk_msm_append(&T.n_sel[e], T.sel + (u64)e * T.list_stride, mine && !one, r);
+  }
+}
+
+// ---- the ones' sum ---------------------------------------------------------------------------------------------------------------------
+// partial sum t of email e: list entries [t ONES, (t + 1) ONES); there is always a partial 0 (infinity for an empty list)
+ZK_HD u32 zk_msm_ones_parts(u32 n_ones) { const u32 m = (n_ones + ZK_MSM_ONES - 1u) / ZK_MSM_ONES; return m ? m : 1u; }
+template <class C>
+ZK_HD void zk_msm_ones_thread(const ZkMsmArgsT<C>& A, u32 e, u32 t, u32 h, typename ZkMsmArgsT<C>::X* out) {
+  const u32 n1 = A.n_ones[e];
+  if (t >= zk_msm_ones_parts(n1)) return;
+  const u32 lo = t * ZK_MSM_ONES, hi = lo + ZK_MSM_ONES < n1 ? lo + ZK_MSM_ONES : n1;
+  const u32* list = A.ones + (u64)e * A.list_stride;
+  // (the next base is in flight while the current one is added)
+  typename ZkMsmArgsT<C>::X acc = ec29_inf<typename C::F>();
+  Aff29<typename C::F> nxt{C::F::zero(), C::F::zero(), true};
+  if (lo < hi) nxt = C::load(A.table + list[lo], h, false);
+  for (u32 j = lo; j < hi; ++j) {
+    const Aff29<typename C::F> cur = nxt;
+    if (j + 1 < hi) nxt = C::load(A.table + list[j + 1], h, false);
+    acc = ec29_add_mixed<typename C::F>(acc, cur);
+  }
+  out[(u64)t * C::LANES + h] = acc;
+}
+// one join level: m_in partial sums -> ceil(m_in / JOIN); m_in follows from the email's list length and the level
+ZK_HD u32 zk_msm_ones_level_count(u32 n_ones, u32 level) {
+  u32 m = zk_msm_ones_parts(n_ones);
+  for (u32 l = 0; l < level; ++l) m = (m + ZK_MSM_JOIN - 1u) / ZK_MSM_JOIN;
+  return m;
 }
 template <class C>
-ZK_HD void zk_msm_tree_thread_c(const typename C::Xyzz* in, u32 n_in, typename C::Xyzz* out, u32 t) {
-  const u32 lo = t * ZK_MSM_JOIN, hi = lo + ZK_MSM_JOIN < n_in ? lo + ZK_MSM_JOIN : n_in;
-  if (lo >= n_in) return;
-  typename C::Xyzz acc = in[lo];
-  for (u32 i = lo + 1; i < hi; ++i) acc = C::add(acc, in[i]);
-  out[t] = acc;
+ZK_HD void zk_msm_tree_thread(const ZkMsmArgsT<C>& A, u32 e, u32 level, u32 t, u32 h, const typename ZkMsmArgsT<C>::X* in, typename ZkMsmArgsT<C>::X* out) {
+  const u32 m_in = zk_msm_ones_level_count(A.n_ones[e], level);
+  const u32 lo = t * ZK_MSM_JOIN, hi = lo + ZK_MSM_JOIN < m_in ? lo + ZK_MSM_JOIN : m_in;
+  if (lo >= m_in) return;
+  typename ZkMsmArgsT<C>::X acc = in[(u64)lo * C::LANES + h];
+  for (u32 i = lo + 1; i < hi; ++i) acc = ec29_add<typename C::F>(acc, in[(u64)i * C::LANES + h]);
+  out[(u64)t * C::LANES + h] = acc;
 }
-template <class C>
-ZK_HD void zk_msm_count_thread(const ZkMsmArgsT<C>& A, u32 i) {
-  if (i >= A.n || C::is_inf(A.bases[i])) return;
-  const Fr k = zk_msm_scalar(A, i);
-  if (A.ones_apart && zk_msm_is_one(k)) return;
+
+// ---- the counting sort -------------------------------------------------------------------------------------------------------------------
+// digits of list entry j of email e -> f(bucket, window, base index, negative)
+template <class C, class Fn>
+ZK_HD void zk_msm_digits_of(const ZkMsmArgsT<C>& A, u32 e, u32 j, Fn f) {
+  const u32 i = A.sel_at(e, j);
+  if (!A.sel && A.base_inf(i)) return;
+  const Fr k = zk_msm_scalar(A, e, i);
   u32 carry = 0;
   for (u32 w = 0; w < A.K; ++w) {
     const int d = zk_msm_digit(k.l, w, A.c, carry);
-    if (d) ZK_MSM_ATOMIC_INC(&A.count[(A.KS == 1u ? 0u : w) * A.nb + (u32)(d < 0 ? -d : d) - 1u]);
+    if (d) f((A.KS == 1u ? 0u : w) * A.nb + (u32)(d < 0 ? -d : d) - 1u, w, i, d < 0);
   }
 }
-// one workgroup of `threads` threads (thread t of them): counts -> exclusive offsets in place, cursor = offsets; count[total] = entries.
+template <class C>
+ZK_HD void zk_msm_count_thread(const ZkMsmArgsT<C>& A, u32 e, u32 j) {
+  if (j >= A.sel_count(e)) return;
+  u32* cnt = A.count(e);
+  zk_msm_digits_of(A, e, j, [&](u32 b, u32, u32, bool) { ZK_MSM_ATOMIC_ADD(&cnt[b], 1u); });
+}
+// one workgroup of `threads` threads per email (thread t of them): counts -> exclusive offsets in place, cursor = offsets; count[total] = entries.
 // Two phases separated by a barrier the caller supplies (host mirror: phase 0 for every t, then phase 1 for every t).
 template <class C>
-ZK_HD void zk_msm_scan_thread(const ZkMsmArgsT<C>& A, u32 t, u32 threads, u32* partial /*[threads + 1]*/, int phase) {
+ZK_HD void zk_msm_scan_thread(const ZkMsmArgsT<C>& A, u32 e, u32 t, u32 threads, u32* partial /*[threads + 1]*/, int phase) {
+  u32* cnt = A.count(e);
+  u32* cur = A.cursor(e);
   const u32 total = A.KS * A.nb, per = (total + threads - 1) / threads;
   const u32 lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
   if (phase == 0) {
     u32 s = 0;
-    for (u32 k = lo; k < hi; ++k) s += A.count[k];
+    for (u32 k = lo; k < hi; ++k) s += cnt[k];
     partial[t + 1] = s;
     if (t == 0) partial[0] = 0;
     return;
   }
   u32 base = 0;
   for (u32 k = 0; k <= t; ++k) base += partial[k];      // (threads is small: 256 .. 1024)
-  for (u32 k = lo; k < hi; ++k) { const u32 v = A.count[k]; A.count[k] = base; A.cursor[k] = base; base += v; }
-  if (hi == total && lo < total) A.count[total] = base;
-  if (total == 0 && t == 0) A.count[0] = 0;
+  for (u32 k = lo; k < hi; ++k) { const u32 v = cnt[k]; cnt[k] = base; cur[k] = base; base += v; }
+  if (hi == total && lo < total) cnt[total] = base;
 }
 template <class C>
-ZK_HD void zk_msm_scatter_thread(const ZkMsmArgsT<C>& A, u32 i) {
-  if (i >= A.n || C::is_inf(A.bases[i])) return;
-  const Fr k = zk_msm_scalar(A, i);
-  if (A.ones_apart && zk_msm_is_one(k)) return;
-  u32 carry = 0;
-  for (u32 w = 0; w < A.K; ++w) {
-    const int d = zk_msm_digit(k.l, w, A.c, carry);
-    if (!d) continue;
-    const u32 b = (A.KS == 1u ? 0u : w) * A.nb + (u32)(d < 0 ? -d : d) - 1u;
-    const u32 at = ZK_MSM_ATOMIC_INC(&A.cursor[b]);
-    A.entry[at] = (w * A.stride + i) | (d < 0 ? 0x80000000u : 0u);
-  }
+ZK_HD void zk_msm_scatter_thread(const ZkMsmArgsT<C>& A, u32 e, u32 j) {
+  if (j >= A.sel_count(e)) return;
+  u32* cur = A.cursor(e);
+  u32* ent = A.entry(e);
+  zk_msm_digits_of(A, e, j, [&](u32 b, u32 w, u32 i, bool neg) { ent[ZK_MSM_ATOMIC_ADD(&cur[b], 1u)] = (w * A.stride + i) | (neg ? 0x80000000u : 0u); });
 }
-// ---- the counting sort with WORKGROUP-LOCAL histograms (round 5, profiles/r05/r05_u_msm0_kernel_stats.csv: for 2^21 full-size scalars
-// the 33.5 M global atomics of zk_msm_count and again of zk_msm_scatter, all on 32,768 addresses, were 1.26 + 2.84 ms of a 9.0 ms sum).
-// When the bucket counters fit LDS (KS nb <= ZK_MSM_LDS_BUCKETS: one bucket set of up to 2^15 -- the precomputed-windows layout at
-// c <= 16), workgroup `wg` owns the scalars [wg per_wg, (wg + 1) per_wg): it counts them into `hist` (LDS atomics), then
-//   count:   adds its non-zero counters to A.count                                     (KS nb global atomics per workgroup, not one per digit)
-//   scatter: reserves hist[b] consecutive places of bucket b with ONE atomicAdd on A.cursor[b], leaves the first place in hist[b],
-//            and walks its scalars again, taking places from hist[b] by LDS atomics.
+// The same with WORKGROUP-LOCAL histograms (round 5, profiles/r05/r05_u_msm0_kernel_stats.csv: for 2^21 full-size scalars the 33.5 M
+// global atomics of count and again of scatter, all on 32,768 addresses, were 1.26 + 2.84 ms of a 9.0 ms sum).  Workgroup `wg` of `n_wg`
+// owns the list entries [wg per, (wg + 1) per), per = ceil(list length / n_wg): it counts them into `hist` (LDS atomics), then
+//   count:   adds its non-zero counters to the email's global ones                     (one global atomic per bucket and workgroup)
+//   scatter: reserves hist[b] consecutive places of bucket b with ONE atomicAdd on cursor[b], leaves the first place in hist[b],
+//            and walks its entries again, taking places from hist[b] by LDS atomics.
 // Phases are separated by workgroup barriers the caller supplies (host mirror: every thread of a phase, then the next phase).
-#define ZK_MSM_LDS_BUCKETS 32768u
 template <class C>
-ZK_HD void zk_msm_sort_wg_thread(const ZkMsmArgsT<C>& A, u32 wg, u32 per_wg, u32 t, u32 threads, u32* hist, int phase, bool scatter) {
-  const u32 total = A.KS * A.nb;
-  const u32 lo = wg * per_wg, hi = lo + per_wg < A.n ? lo + per_wg : A.n;
+ZK_HD void zk_msm_sort_wg_thread(const ZkMsmArgsT<C>& A, u32 e, u32 wg, u32 n_wg, u32 t, u32 threads, u32* hist, int phase, bool scatter) {
+  const u32 total = A.KS * A.nb, len = A.sel_count(e);
+  const u32 per = (len + n_wg - 1u) / n_wg;
+  const u32 lo = wg * per < len ? wg * per : len, hi = lo + per < len ? lo + per : len;
   if (phase == 0) {
     for (u32 b = t; b < total; b += threads) hist[b] = 0;
     return;
   }
   if (phase == 2) {
+    if (lo == hi) return;
+    u32* cnt = A.count(e);
+    u32* cur = A.cursor(e);
     for (u32 b = t; b < total; b += threads) {
       const u32 v = hist[b];
       if (!v) continue;
-      if (scatter) hist[b] = ZK_MSM_ATOMIC_ADD(&A.cursor[b], v);
-      else ZK_MSM_ATOMIC_ADD(&A.count[b], v);
+      if (scatter) hist[b] = ZK_MSM_ATOMIC_ADD(&cur[b], v);
+      else ZK_MSM_ATOMIC_ADD(&cnt[b], v);
     }
     return;
   }
   // phase 1: count; phase 3 (scatter): place
-  for (u32 i = lo + t; i < hi; i += threads) {
-    if (C::is_inf(A.bases[i])) continue;
-    const Fr k = zk_msm_scalar(A, i);
-    if (A.ones_apart && zk_msm_is_one(k)) continue;
-    u32 carry = 0;
-    for (u32 w = 0; w < A.K; ++w) {
-      const int d = zk_msm_digit(k.l, w, A.c, carry);
-      if (!d) continue;
-      const u32 b = (A.KS == 1u ? 0u : w) * A.nb + (u32)(d < 0 ? -d : d) - 1u;
+  u32* ent = A.entry(e);
+  for (u32 j = lo + t; j < hi; j += threads)
+    zk_msm_digits_of(A, e, j, [&](u32 b, u32 w, u32 i, bool neg) {
       if (phase == 1) ZK_MSM_ATOMIC_ADD(&hist[b], 1u);
-      else A.entry[ZK_MSM_ATOMIC_ADD(&hist[b], 1u)] = (w * A.stride + i) | (d < 0 ? 0x80000000u : 0u);
-    }
-  }
+      else ent[ZK_MSM_ATOMIC_ADD(&hist[b], 1u)] = (w * A.stride + i) | (neg ? 0x80000000u : 0u);
+    });
 }
-ZK_HD u32 zk_msm_sort_per_wg(u32 n) { const u32 per = (n + 255u) / 256u; return per < 1024u ? 1024u : per; }   // about 256 workgroups
 
+// ---- sliced bucket sums ----------------------------------------------------------------------------------------------------------------
 template <class C>
-ZK_HD void zk_msm_bucket_thread(const ZkMsmArgsT<C>& A, u32 b) {
-  if (b >= A.KS * A.nb) return;
-  typename C::Xyzz acc = C::inf();
-  for (u32 k = A.count[b], e = A.count[b + 1]; k < e; ++k) {
-    const u32 v = A.entry[k];
-    typename C::Affine p = A.bases[v & 0x7fffffffu];
-    if (v >> 31) p = C::neg(p);
-    acc = C::add_mixed(acc, p);
-  }
-  A.bucket[b] = acc;
-}
-// one level of the reduction tree.  Nodes of the level below: `n_in` per window with span `span` (weights 1 .. span inside a node);
-// in_a == nullptr: the nodes are the buckets themselves (S = A = bucket, span 1).  Thread g builds node g of the level above
-// (`n_out` = ceil(n_in / ZK_MSM_FAN) per window).  The last level (n_out == 1) writes the window's sum to A.window.
+ZK_HD u32 zk_msm_slice_size(const ZkMsmArgsT<C>& A, int level) { return level == 0 ? A.s0 : ZK_MSM_S1; }
+// slices of `level`: the items of bucket b are [in[b], in[b + 1]) -- entries for level 0 (in = count), the slices of the level below
+// otherwise; out[b] = first slice of bucket b, out[total] = number of slices.  One workgroup per email, two phases around a barrier.
 template <class C>
-ZK_HD void zk_msm_reduce_thread(const ZkMsmArgsT<C>& A, u32 g, const typename C::Xyzz* in_s, const typename C::Xyzz* in_a, u32 n_in, u32 span, typename C::Xyzz* out_s, typename C::Xyzz* out_a) {
-  const u32 n_out = (n_in + ZK_MSM_FAN - 1u) / ZK_MSM_FAN;
-  if (g >= A.KS * n_out) return;
-  const u32 w = g / n_out, q = g - w * n_out;
-  const u32 lo = q * ZK_MSM_FAN, hi = lo + ZK_MSM_FAN < n_in ? lo + ZK_MSM_FAN : n_in;
-  const typename C::Xyzz* S = in_s + (size_t)w * n_in;
-  const typename C::Xyzz* Aw = (in_a ? in_a : in_s) + (size_t)w * n_in;
-  // sum_i i S_i for i = 1 .. m - 1 (running sum from the top), sum S_i, sum A_i
-  typename C::Xyzz run = C::inf(), acc = C::inf(), sum_a = C::inf();
-  for (u32 k = hi; k-- > lo;) {
-    sum_a = C::add(sum_a, Aw[k]);
-    if (k > lo) { run = C::add(run, S[k]); acc = C::add(acc, run); }
-  }
-  const typename C::Xyzz sum_s = C::add(run, S[lo]);
-  for (u32 s = span; s > 1; s >>= 1) acc = C::dbl(acc);            // span is a power of two
-  const typename C::Xyzz node_a = C::add(sum_a, acc);
-  if (n_out == 1) { A.window[w] = node_a; return; }
-  out_s[(size_t)w * n_out + q] = sum_s;
-  out_a[(size_t)w * n_out + q] = node_a;
-}
-// ---- the weighted bucket sum  sum_b (b + 1) bucket[b]  by BIT PLANES (round 5, after profiles/r05/r05_s_prove_kernel_stats.csv: the
-// (S, A) tree above is five dependent levels of 21 additions + up to 12 doublings on ever fewer lanes -- 3.4 ms of a 4 ms G1 sum and
-// 10.5 ms of a 16 ms G2 sum are that latency).  With T_j = sum of the buckets whose weight has bit j set, the sum is sum_j 2^j T_j:
-// the c plane sums are PLAIN sums (ZK_MSM_PFAN-way joins: log depth, every level c times wider than the tree's), and one lane folds
-// them with c - 1 doublings.  c/2 times the additions of the tree -- irrelevant next to n K mixed additions -- for 66 dependent
-// point operations instead of 135 (c = 16).
-#define ZK_MSM_PFAN 8u
-ZK_HD u32 zk_msm_plane_n0(u32 nb) { return (nb + ZK_MSM_PFAN - 1u) / ZK_MSM_PFAN; }
-// level 0, thread g = (w c + j) n0 + q: the buckets [q F, (q + 1) F) of set w whose weight b + 1 has bit j set
-template <class C>
-ZK_HD void zk_msm_plane0_thread(const ZkMsmArgsT<C>& A, u32 g, typename C::Xyzz* out) {
-  const u32 n0 = zk_msm_plane_n0(A.nb);
-  if (g >= A.KS * A.c * n0) return;
-  const u32 row = g / n0, q = g - row * n0, w = row / A.c, j = row - w * A.c;
-  const u32 lo = q * ZK_MSM_PFAN, hi = lo + ZK_MSM_PFAN < A.nb ? lo + ZK_MSM_PFAN : A.nb;
-  typename C::Xyzz acc = C::inf();
-  for (u32 b = lo; b < hi; ++b)
-    if (((b + 1u) >> j) & 1u) acc = C::add(acc, A.bucket[(size_t)w * A.nb + b]);
-  out[g] = acc;
-}
-// a join level: `rows` rows of n_in sums -> rows of n_out = ceil(n_in / F); thread g = row n_out + q
-template <class C>
-ZK_HD void zk_msm_plane_join_thread(const typename C::Xyzz* in, u32 rows, u32 n_in, typename C::Xyzz* out, u32 g) {
-  const u32 n_out = (n_in + ZK_MSM_PFAN - 1u) / ZK_MSM_PFAN;
-  if (g >= rows * n_out) return;
-  const u32 row = g / n_out, q = g - row * n_out;
-  const u32 lo = q * ZK_MSM_PFAN, hi = lo + ZK_MSM_PFAN < n_in ? lo + ZK_MSM_PFAN : n_in;
-  const typename C::Xyzz* r = in + (size_t)row * n_in;
-  typename C::Xyzz acc = r[lo];
-  for (u32 k = lo + 1; k < hi; ++k) acc = C::add(acc, r[k]);
-  out[g] = acc;
-}
-// window w from its c plane sums T[w c + j]
-template <class C>
-ZK_HD void zk_msm_plane_window_thread(const ZkMsmArgsT<C>& A, const typename C::Xyzz* T, u32 w) {
-  if (w >= A.KS) return;
-  typename C::Xyzz acc = T[(size_t)w * A.c + A.c - 1u];
-  for (u32 j = A.c - 1u; j-- > 0;) acc = C::add(C::dbl(acc), T[(size_t)w * A.c + j]);
-  A.window[w] = acc;
-}
-template <class C>
-ZK_HD void zk_msm_combine_thread(const ZkMsmArgsT<C>& A) {
-  typename C::Xyzz total = C::inf();
-  if (A.KS == 1u) total = A.window[0];        // precomputed windows: nothing to combine
-  else
-    for (u32 w = A.K; w-- > 0;) {
-      for (u32 s = 0; s < A.c; ++s) total = C::dbl(total);
-      total = C::add(total, A.window[w]);
-    }
-  if (A.ones_apart) total = C::add(total, A.ones[0]);
-  A.out[0] = total;
-}
-// copy w of base i for the precomputed-windows layout: ext[w n + i] = 2^(c w) base_i, affine (one inversion per copy; once per key)
-template <class C, class ToAffine>
-ZK_HD void zk_msm_shift_thread(const typename C::Affine* bases, typename C::Affine* ext, u32 n, u32 c, u32 K, u32 i, ToAffine to_affine) {
-  if (i >= n) return;
-  const typename C::Affine p = bases[i];
-  ext[i] = p;
-  typename C::Xyzz acc = C::add_mixed(C::inf(), p);
-  for (u32 w = 1; w < K; ++w) {
-    for (u32 s = 0; s < c; ++s) acc = C::dbl(acc);
-    ext[(size_t)w * n + i] = to_affine(acc);
-  }
-}
-#define ZK_MSM_S0 16u      // (64 / 32 / 32 until r05_s: 128 dependent additions in front of a bucket; 32 now, for 4 x the slices of level 0)
-#define ZK_MSM_S1 8u
-ZK_HD u32 zk_msm_slice_size(int level) { return level == 0 ? ZK_MSM_S0 : ZK_MSM_S1; }
-// slices of `level`: the items of bucket b are [in[b], in[b + 1]) -- entries for level 0 (in = A.count), the slices of the level below
-// otherwise; out[b] = first slice of bucket b, out[total] = number of slices.  One workgroup, two phases around a barrier (as zk_msm_scan).
-template <class C>
-ZK_HD void zk_msm_slice_scan_thread(const ZkMsmArgsT<C>& A, int level, u32 t, u32 threads, u32* partial, int phase) {
-  const u32* in = level == 0 ? A.count : A.soff[level - 1];
-  u32* out = A.soff[level];
-  const u32 S = zk_msm_slice_size(level);
+ZK_HD void zk_msm_slice_scan_thread(const ZkMsmArgsT<C>& A, u32 e, int level, u32 t, u32 threads, u32* partial, int phase) {
+  const u32* in = level == 0 ? A.count(e) : A.soff(e, level - 1);
+  u32* out = A.soff(e, level);
+  const u32 S = zk_msm_slice_size(A, level);
   const u32 total = A.KS * A.nb, per = (total + threads - 1) / threads;
   const u32 lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
   if (phase == 0) {
@@ -318,41 +271,127 @@ ZK_HD void zk_msm_slice_scan_thread(const ZkMsmArgsT<C>& A, int level, u32 t, u3
   for (u32 k = 0; k <= t; ++k) base += partial[k];
   for (u32 k = lo; k < hi; ++k) { out[k] = base; base += (in[k + 1] - in[k] + S - 1u) / S; }
   if (hi == total && lo < total) out[total] = base;
-  if (total == 0 && t == 0) out[0] = 0;
 }
-// slice t of `level` (nothing beyond the level's slice count or capacity: the capacity is a proven bound)
 template <class C>
-ZK_HD void zk_msm_slice_sum_thread(const ZkMsmArgsT<C>& A, int level, u32 t) {
+ZK_HD u32 zk_msm_slice_count(const ZkMsmArgsT<C>& A, u32 e, int level) {
+  const u32 n = A.soff(e, level)[A.KS * A.nb];
+  return n < A.off.cap[level] ? n : A.off.cap[level];       // (the capacity is a proven bound)
+}
+// slice t of `level` of email e
+// (LEVEL0 is a template argument so that the kernel of the mixed additions does not carry the register budget of the full ones)
+template <class C, bool LEVEL0>
+ZK_HD void zk_msm_slice_sum_thread(const ZkMsmArgsT<C>& A, u32 e, int level, u32 t, u32 h) {
+  typedef typename ZkMsmArgsT<C>::X X;
   const u32 total = A.KS * A.nb;
-  const u32* off = A.soff[level];
-  if (t >= off[total] || t >= A.cap[level]) return;
+  const u32* off = A.soff(e, level);
   // the bucket whose slices contain t: the last b with off[b] <= t
   u32 lo = 0, hi = total;
   while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
-  const u32 b = lo, j = t - off[b], S = zk_msm_slice_size(level);
-  const u32* in = level == 0 ? A.count : A.soff[level - 1];
+  const u32 b = lo, j = t - off[b], S = zk_msm_slice_size(A, level);
+  const u32* in = level == 0 ? A.count(e) : A.soff(e, level - 1);
   const u32 first = in[b] + j * S, last = first + S < in[b + 1] ? first + S : in[b + 1];
-  typename C::Xyzz acc = C::inf();
-  if (level == 0) {
-    for (u32 k = first; k < last; ++k) {
-      const u32 v = A.entry[k];
-      typename C::Affine p = A.bases[v & 0x7fffffffu];
-      if (v >> 31) p = C::neg(p);
-      acc = C::add_mixed(acc, p);
+  X acc = ec29_inf<typename C::F>();
+  if (LEVEL0) {
+    // (the next base and the entry after it are in flight while the current base is added)
+    const u32* ent = A.entry(e);
+    if (first < last) {
+      u32 v1 = ent[first], v2 = first + 1 < last ? ent[first + 1] : 0u;
+      Aff29<typename C::F> nxt = C::load(A.table + (v1 & 0x7fffffffu), h, (v1 >> 31) != 0);
+      for (u32 k = first; k < last; ++k) {
+        const Aff29<typename C::F> cur = nxt;
+        if (k + 1 < last) {
+          nxt = C::load(A.table + (v2 & 0x7fffffffu), h, (v2 >> 31) != 0);
+          if (k + 2 < last) v2 = ent[k + 2];
+        }
+        acc = ec29_add_mixed<typename C::F>(acc, cur);
+      }
     }
   } else {
-    const typename C::Xyzz* items = A.part[level - 1];
-    for (u32 k = first; k < last; ++k) acc = C::add(acc, items[k]);
+    const X* items = A.part(e, level - 1);
+    for (u32 k = first; k < last; ++k) acc = ec29_add<typename C::F>(acc, items[(u64)k * C::LANES + h]);
   }
-  A.part[level][t] = acc;
+  A.part(e, level)[(u64)t * C::LANES + h] = acc;
 }
 // bucket b = the sum of its slices of the last level
 template <class C>
-ZK_HD void zk_msm_bucket_join_thread(const ZkMsmArgsT<C>& A, u32 b) {
+ZK_HD void zk_msm_bucket_join_thread(const ZkMsmArgsT<C>& A, u32 e, u32 b, u32 h) {
+  typedef typename ZkMsmArgsT<C>::X X;
   if (b >= A.KS * A.nb) return;
-  typename C::Xyzz acc = C::inf();
-  for (u32 k = A.soff[2][b], e = A.soff[2][b + 1]; k < e; ++k) acc = C::add(acc, A.part[2][k]);
-  A.bucket[b] = acc;
+  const u32* off = A.soff(e, 2);
+  const X* items = A.part(e, 2);
+  X acc = ec29_inf<typename C::F>();
+  for (u32 k = off[b], end = off[b + 1]; k < end; ++k) acc = ec29_add<typename C::F>(acc, items[(u64)k * C::LANES + h]);
+  A.bucket(e)[(u64)b * C::LANES + h] = acc;
 }
-// (G1 by name: the host mirror of the CPU tests)
-ZK_HD void zk_msm_tree_thread(const G1Xyzz* in, u32 n_in, G1Xyzz* out, u32 t) { zk_msm_tree_thread_c<ZkCurveG1>(in, n_in, out, t); }
+
+// ---- the weighted bucket sum  sum_b (b + 1) bucket[b]  by BIT PLANES ------------------------------------------------------------------
+// With T_j = sum of the buckets whose weight has bit j set, the sum is sum_j 2^j T_j: the c plane sums are PLAIN sums (PFAN-way joins: log
+// depth, every level c rows wide), and one lane folds them with c - 1 doublings -- 66 dependent point operations at c = 16 where the tree
+// of (plain, weighted) nodes of round 5's first version needed 135.
+ZK_HD u32 zk_msm_plane_n0(u32 nb) { return (nb + ZK_MSM_PFAN - 1u) / ZK_MSM_PFAN; }
+// level 0, item g = (w c + j) n0 + q: the buckets [q F, (q + 1) F) of set w whose weight b + 1 has bit j set
+template <class C>
+ZK_HD void zk_msm_plane0_thread(const ZkMsmArgsT<C>& A, u32 e, u32 g, u32 h) {
+  typedef typename ZkMsmArgsT<C>::X X;
+  const u32 n0 = zk_msm_plane_n0(A.nb);
+  if (g >= A.KS * A.c * n0) return;
+  const u32 row = g / n0, q = g - row * n0, w = row / A.c, j = row - w * A.c;
+  const u32 lo = q * ZK_MSM_PFAN, hi = lo + ZK_MSM_PFAN < A.nb ? lo + ZK_MSM_PFAN : A.nb;
+  const X* bk = A.bucket(e);
+  X acc = ec29_inf<typename C::F>();
+  for (u32 b = lo; b < hi; ++b)
+    if (((b + 1u) >> j) & 1u) acc = ec29_add<typename C::F>(acc, bk[((u64)w * A.nb + b) * C::LANES + h]);
+  A.node_s(e)[(u64)g * C::LANES + h] = acc;
+}
+// a join level: `rows` rows of n_in sums -> rows of n_out = ceil(n_in / F); item g = row n_out + q
+template <class C>
+ZK_HD void zk_msm_plane_join_thread(const typename ZkMsmArgsT<C>::X* in, u32 rows, u32 n_in, typename ZkMsmArgsT<C>::X* out, u32 g, u32 h) {
+  typedef typename ZkMsmArgsT<C>::X X;
+  const u32 n_out = (n_in + ZK_MSM_PFAN - 1u) / ZK_MSM_PFAN;
+  if (g >= rows * n_out) return;
+  const u32 row = g / n_out, q = g - row * n_out;
+  const u32 lo = q * ZK_MSM_PFAN, hi = lo + ZK_MSM_PFAN < n_in ? lo + ZK_MSM_PFAN : n_in;
+  const X* r = in + (u64)row * n_in * C::LANES;
+  X acc = r[(u64)lo * C::LANES + h];
+  for (u32 k = lo + 1; k < hi; ++k) acc = ec29_add<typename C::F>(acc, r[(u64)k * C::LANES + h]);
+  out[(u64)g * C::LANES + h] = acc;
+}
+// window w from its c plane sums T[w c + j]
+template <class C>
+ZK_HD void zk_msm_plane_window_thread(const ZkMsmArgsT<C>& A, u32 e, const typename ZkMsmArgsT<C>::X* T, u32 w, u32 h) {
+  typedef typename ZkMsmArgsT<C>::X X;
+  if (w >= A.KS) return;
+  X acc = T[((u64)w * A.c + A.c - 1u) * C::LANES + h];
+  for (u32 j = A.c - 1u; j-- > 0;) acc = ec29_add<typename C::F>(ec29_dbl<typename C::F>(acc), T[((u64)w * A.c + j) * C::LANES + h]);
+  A.window(e)[(u64)w * C::LANES + h] = acc;
+}
+// the sum of email e: windows (Horner over the classic layout's K sets; precomputed windows: nothing to combine) + the ones' sum
+template <class C>
+ZK_HD void zk_msm_combine_thread(const ZkMsmArgsT<C>& A, u32 e, u32 h, const typename ZkMsmArgsT<C>::X* ones_sum) {
+  typedef typename ZkMsmArgsT<C>::X X;
+  const X* win = A.window(e);
+  X total = ec29_inf<typename C::F>();
+  if (A.KS == 1u) total = win[h];
+  else
+    for (u32 w = A.K; w-- > 0;) {
+      for (u32 s = 0; s < A.c; ++s) total = ec29_dbl<typename C::F>(total);
+      total = ec29_add<typename C::F>(total, win[(u64)w * C::LANES + h]);
+    }
+  if (ones_sum) total = ec29_add<typename C::F>(total, ones_sum[h]);
+  C::store_out(A.out + e, total, h);
+}
+
+// ---- tables (once per key) -----------------------------------------------------------------------------------------------------------------
+// copy w of base i: ext[w n + i] = 2^(c w) base_i, affine, 2^261 form (canonical-word arithmetic of zkwg_g1.h / zkwg_g2.h: one inversion
+// per copy, once per key); K = 1: just the conversion (classic layout)
+template <class Aff, class Xyzz, class Add, class Dbl, class ToAffine, class ToTable>
+ZK_HD void zk_msm_table_thread(const Aff* bases, Aff* ext, u32 n, u32 c, u32 K, u32 i, Xyzz inf, Add add_mixed, Dbl dbl, ToAffine to_affine, ToTable to_table) {
+  if (i >= n) return;
+  const Aff p = bases[i];
+  ext[i] = to_table(p);
+  Xyzz acc = add_mixed(inf, p);
+  for (u32 w = 1; w < K; ++w) {
+    for (u32 s = 0; s < c; ++s) acc = dbl(acc);
+    ext[(size_t)w * n + i] = to_table(to_affine(acc));
+  }
+}

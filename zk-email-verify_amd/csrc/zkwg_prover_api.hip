@@ -1,40 +1,178 @@
 // `groth16.prove` for the emails of a prepared batch, behind one C entry point (include/zkwg.h "prover"): the second half of
 // snarkjs.groth16.fullProve (reference call site: packages/helpers/src/chunked-zkey.ts:80-84) as a host such as the N-API addon binds it.
 // It only ORCHESTRATES the stages that have their own entry points -- zkwg_expand_device (the witness as the sums' scalars),
-// zkwg_expand_abc_device (buildABC1), zkwg_h_evaluations_device (ifft / coset shift / fft / joinABC), zkwg_msm_enqueue_device (the five
-// multiExpAffine), zkwg_groth16_assemble -- with `slots` proofs in flight, each on its own stream with its own buffers, because a
-// multi-exponentiation ends in a few hundred dependent group operations on a handful of lanes that only other proofs' work can hide.
+// zkwg_expand_abc_device (buildABC1), zkwg_h_evaluations_device (ifft / coset shift / fft / joinABC), zkwg_msm_* (the five
+// multiExpAffine), zkwg_groth16_assemble.
+//
+// Round 6: proofs are made E AT A TIME.  A context owns the buffers of E emails and three streams; every stage is ONE launch series for
+// its E emails (emails are the second grid dimension of every kernel), so a proof costs 1 / E of the launches and the thin tails of the
+// sums are E lanes wide:
+//     stream h   witnesses of the E emails -> A.w | B.w | C.w -> H evaluations -> the H sum
+//     stream w   (after the witnesses) one classification pass for the three witness-shaped base sets -> sums a, b1, c
+//     stream g   (after the classification) the G2 sum b2
+// and the contexts roll: while the host assembles the proofs of a finished context (a dozen group operations each, host arithmetic), the
+// other contexts' series keep the device busy; nothing waits for a whole wave of proofs, and nothing depends on the number of hardware
+// queues (round 5: one stream per proof, GPU_MAX_HW_QUEUES = 16 or half the rate).
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "../../include/zkwg.h"
 
-struct ZkProveSlot {
-  hipStream_t st = nullptr;
-  uint8_t *wit = nullptr, *abc = nullptr, *h = nullptr, *ntt = nullptr, *work = nullptr, *sums = nullptr;
+struct ZkProveCtx {
+  hipStream_t st_h = nullptr, st_w = nullptr, st_g = nullptr;
+  hipEvent_t ev_wit = nullptr, ev_lists = nullptr, ev_w = nullptr, ev_g = nullptr, ev_done = nullptr;
+  uint8_t *wit = nullptr, *abc = nullptr, *h = nullptr, *ntt = nullptr, *work_h = nullptr, *work_w = nullptr, *work_g = nullptr, *sums = nullptr;
+  uint8_t* lists[3] = {nullptr, nullptr, nullptr};
+  uint8_t* host_sums = nullptr;        // pinned: E x 5 x 256
+  uint64_t first = 0, count = 0;       // positions [first, first + count) of the call's index list are in flight here
+  bool busy = false;
 };
 struct zkwg_prover {
   zkwg_circuit_t* c;
   int device;
   uint64_t n_rows, n_public, W;
-  uint32_t power;
+  uint32_t power, E;
+  int c_from_ab = 0;                   // 1: the attached system has no C rows (a zkey's section 4): C.w = A.w o B.w (zkwg_prover_create_zkey)
   zkwg_ntt_t* ntt = nullptr;
   zkwg_msm_t *ma = nullptr, *mb1 = nullptr, *mb2 = nullptr, *mc = nullptr, *mh = nullptr;
   uint8_t alpha1[64], beta1[64], beta2[128], delta1[64], delta2[128];
-  uint64_t work_bytes = 0;
-  std::vector<ZkProveSlot> slots;
+  std::vector<ZkProveCtx> ctx;
 };
+void zk_abc_c_from_ab_launch(void* d_abc, uint64_t abc_stride, uint64_t n_rows, uint32_t n_emails, hipStream_t st);      // zkwg_kernels_handoff.hip
 
 static void prover_free(zkwg_prover* p) {
   if (!p) return;
   hipSetDevice(p->device);
-  for (ZkProveSlot& s : p->slots) {
-    if (s.st) hipStreamDestroy(s.st);
-    hipFree(s.wit); hipFree(s.abc); hipFree(s.h); hipFree(s.ntt); hipFree(s.work); hipFree(s.sums);
+  for (ZkProveCtx& s : p->ctx) {
+    for (hipStream_t st : {s.st_h, s.st_w, s.st_g}) if (st) hipStreamDestroy(st);
+    for (hipEvent_t ev : {s.ev_wit, s.ev_lists, s.ev_w, s.ev_g, s.ev_done}) if (ev) hipEventDestroy(ev);
+    for (uint8_t* q : {s.wit, s.abc, s.h, s.ntt, s.work_h, s.work_w, s.work_g, s.sums, s.lists[0], s.lists[1], s.lists[2]}) if (q) hipFree(q);
+    if (s.host_sums) hipHostFree(s.host_sums);
   }
   zkwg_msm_destroy(p->ma); zkwg_msm_destroy(p->mb1); zkwg_msm_destroy(p->mb2); zkwg_msm_destroy(p->mc); zkwg_msm_destroy(p->mh);
   zkwg_ntt_destroy(p->ntt);
   delete p;
+}
+// `slots` proofs in flight = contexts x emails per series
+static void prover_shape(uint32_t slots, uint32_t& n_ctx, uint32_t& E) {
+  n_ctx = slots >= 6 ? 3u : slots >= 2 ? 2u : 1u;
+  E = (slots + n_ctx - 1) / n_ctx;
+  if (E > 32) E = 32;
+}
+
+static int prover_new(zkwg_circuit_t* c, int device, uint64_t n_rows, const zkwg_proving_key* key, uint32_t slots, int c_from_ab, zkwg_prover_t** out) {
+  const uint64_t W = zkwg_witness_len(c), n = 1ull << key->log2_domain;
+  if (key->n_wires != W || key->n_public + 1 >= W || n_rows > n || key->log2_domain > 28) return ZKWG_RC_BAD_CONFIG;
+  if (zkwg_abc_bytes(c) != 96 * n_rows) return ZKWG_RC_BAD_CONFIG;
+  if (hipSetDevice(device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  zkwg_prover* p = new zkwg_prover();
+  p->c = c; p->device = device; p->n_rows = n_rows; p->n_public = key->n_public; p->W = W; p->power = (uint32_t)key->log2_domain; p->c_from_ab = c_from_ab;
+  memcpy(p->alpha1, key->alpha1, 64); memcpy(p->beta1, key->beta1, 64); memcpy(p->beta2, key->beta2, 128);
+  memcpy(p->delta1, key->delta1, 64); memcpy(p->delta2, key->delta2, 128);
+  uint32_t n_ctx;
+  prover_shape(slots, n_ctx, p->E);
+  const uint64_t E = p->E;
+  // What the contexts will need is set aside BEFORE the tables are sized (the tables took what was free and the slots then
+  // failed): a table's K copies are only made when they fit beside it, otherwise that plan keeps the classic layout.
+  const uint64_t wb = zkwg_witness_bytes(c), ab = zkwg_abc_bytes(c), hb = 32ull << p->power;
+  // (work buffers: bounded by the witness-shaped G2 plan at window 13 and the H plan at window 16 -- estimated with their own formulas below)
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { free_b = 0; (void)hipGetLastError(); }
+  int rc = zkwg_ntt_create(device, p->power, &p->ntt);
+  const uint64_t ntt_b = rc == ZKWG_RC_OK ? zkwg_ntt_work_bytes(p->ntt, E) : 0;
+  // per email: entries 4 n K, level-0 partial sums, ... ~ (4 K + 9 K 2 / s0 * xs / 8) n: take the generous closed form 120 n (G1, s0 16), 200 n (G2), 40 n (H)
+  const uint64_t est_ctx = E * (wb + ab + hb + 120ull * W + 200ull * W + 40ull * n + 3 * 8ull * W) + ntt_b + (64ull << 20);
+  const uint64_t reserve = n_ctx * est_ctx + (2ull << 30);
+  uint64_t budget = free_b > reserve ? free_b - reserve : 1;      // (1: no room for copies -- classic layout everywhere)
+  auto plan = [&](int group, const void* bases, uint64_t count, int window, int slice0, zkwg_msm_t** m) {
+    if (rc != ZKWG_RC_OK) return;
+    rc = zkwg_msm_create_ex(device, group, bases, key->bases_on_device, count, window, slice0, budget, m);
+    if (rc == ZKWG_RC_OK) { const uint64_t used = zkwg_msm_table_bytes(*m); budget = budget > used ? budget - used : 1; }
+  };
+  // witness-shaped sums: a few ten thousand full-size scalars per email -> window 13 (4,096 buckets, ~ 170 entries each), slices of 16;
+  // the H sum: 2^power full-size scalars -> window 16, slices of 64
+  const int ww = W >= (1u << 16) ? 13 : 0;
+  plan(1, key->h, n, 0, n >= (1u << 18) ? 64 : 16, &p->mh);
+  plan(2, key->b2, W, ww, 16, &p->mb2);
+  plan(1, key->a, W, ww, 16, &p->ma); plan(1, key->b1, W, ww, 16, &p->mb1);
+  plan(1, key->c, W - key->n_public - 1, ww, 16, &p->mc);
+  if (rc != ZKWG_RC_OK) { prover_free(p); return rc; }
+  const uint64_t work_w = std::max(zkwg_msm_work_bytes(p->ma), std::max(zkwg_msm_work_bytes(p->mb1), zkwg_msm_work_bytes(p->mc)));
+  p->ctx.resize(n_ctx);
+  for (ZkProveCtx& s : p->ctx) {
+    bool ok = hipStreamCreateWithFlags(&s.st_h, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s.st_w, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s.st_g, hipStreamNonBlocking) == hipSuccess;
+    for (hipEvent_t* ev : {&s.ev_wit, &s.ev_lists, &s.ev_w, &s.ev_g, &s.ev_done}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.wit, E * wb) == hipSuccess && hipMalloc((void**)&s.abc, E * ab) == hipSuccess && hipMalloc((void**)&s.h, E * hb) == hipSuccess &&
+         hipMalloc((void**)&s.ntt, ntt_b) == hipSuccess && hipMalloc((void**)&s.work_h, E * zkwg_msm_work_bytes(p->mh)) == hipSuccess &&
+         hipMalloc((void**)&s.work_w, E * work_w) == hipSuccess && hipMalloc((void**)&s.work_g, E * zkwg_msm_work_bytes(p->mb2)) == hipSuccess &&
+         hipMalloc((void**)&s.sums, E * 5 * 256) == hipSuccess && hipMalloc((void**)&s.lists[0], zkwg_msm_lists_bytes(p->ma, E)) == hipSuccess &&
+         hipMalloc((void**)&s.lists[1], zkwg_msm_lists_bytes(p->mb1, E)) == hipSuccess && hipMalloc((void**)&s.lists[2], zkwg_msm_lists_bytes(p->mc, E)) == hipSuccess &&
+         hipHostMalloc((void**)&s.host_sums, E * 5 * 256, hipHostMallocDefault) == hipSuccess;
+    if (!ok) { prover_free(p); (void)hipGetLastError(); return ZKWG_RC_OOM; }
+  }
+  *out = p;
+  return ZKWG_RC_OK;
+}
+
+// one series for the emails indices[first .. first + count) on context s (nothing synchronised)
+static int prover_enqueue(zkwg_prover* p, ZkProveCtx& s, const void* d_in, uint64_t n, const void* d_scratch, const uint64_t* indices, uint64_t first, uint64_t count) {
+  zkwg_circuit_t* c = p->c;
+  const uint64_t wb = zkwg_witness_bytes(c), ab = zkwg_abc_bytes(c), hb = 32ull << p->power;
+  int rc = ZKWG_RC_OK;
+  // witnesses and A.w | B.w | C.w: one launch per run of consecutive emails
+  for (uint64_t j = 0; j < count && rc == ZKWG_RC_OK;) {
+    uint64_t run = 1;
+    while (j + run < count && indices[first + j + run] == indices[first + j] + run) ++run;
+    if (indices[first + j] + run > n) return ZKWG_RC_BAD_ARG;
+    rc = zkwg_expand_device(c, d_in, n, d_scratch, indices[first + j], run, s.wit + j * wb, wb, s.st_h);
+    if (rc == ZKWG_RC_OK) rc = zkwg_expand_abc_device(c, d_in, n, d_scratch, indices[first + j], run, 1, s.abc + j * ab, ab, s.st_h);
+    j += run;
+  }
+  if (rc != ZKWG_RC_OK) return rc;
+  if (hipEventRecord(s.ev_wit, s.st_h) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  // stream w: classification for the three base sets, then a, b1, c; stream g: b2
+  if (hipStreamWaitEvent(s.st_w, s.ev_wit, 0) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  zkwg_msm_t* plans[3] = {p->ma, p->mb1, p->mc};
+  const uint64_t firsts[3] = {0, 0, p->n_public + 1};
+  void* lists[3] = {s.lists[0], s.lists[1], s.lists[2]};
+  rc = zkwg_msm_classify_device(plans, firsts, 3, s.wit, wb, p->W, count, 0, 1, lists, s.st_w);
+  if (rc != ZKWG_RC_OK) return rc;
+  if (hipEventRecord(s.ev_lists, s.st_w) != hipSuccess || hipStreamWaitEvent(s.st_g, s.ev_lists, 0) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  rc = zkwg_msm_enqueue_lists_device(p->mb2, s.wit, wb, count, 0, s.lists[1], 1, s.work_g, s.sums + 2 * p->E * 256, s.st_g);
+  if (rc == ZKWG_RC_OK) rc = zkwg_msm_enqueue_lists_device(p->ma, s.wit, wb, count, 0, s.lists[0], 1, s.work_w, s.sums, s.st_w);
+  if (rc == ZKWG_RC_OK) rc = zkwg_msm_enqueue_lists_device(p->mb1, s.wit, wb, count, 0, s.lists[1], 1, s.work_w, s.sums + 1 * p->E * 256, s.st_w);
+  if (rc == ZKWG_RC_OK) rc = zkwg_msm_enqueue_lists_device(p->mc, s.wit + 32 * (p->n_public + 1), wb, count, 0, s.lists[2], 1, s.work_w, s.sums + 3 * p->E * 256, s.st_w);
+  // stream h: the transforms and the H sum
+  if (rc == ZKWG_RC_OK && p->c_from_ab) zk_abc_c_from_ab_launch(s.abc, ab, p->n_rows, (uint32_t)count, s.st_h);
+  if (rc == ZKWG_RC_OK) rc = zkwg_h_evaluations_device(p->ntt, s.abc, ab, p->n_rows, count, s.ntt, s.h, hb, s.st_h);
+  if (rc == ZKWG_RC_OK) rc = zkwg_msm_enqueue_batch_device(p->mh, s.h, hb, count, 1, 0, s.work_h, s.sums + 4 * p->E * 256, s.st_h);
+  if (rc != ZKWG_RC_OK) return rc;
+  if (hipEventRecord(s.ev_w, s.st_w) != hipSuccess || hipEventRecord(s.ev_g, s.st_g) != hipSuccess || hipStreamWaitEvent(s.st_h, s.ev_w, 0) != hipSuccess ||
+      hipStreamWaitEvent(s.st_h, s.ev_g, 0) != hipSuccess)
+    return ZKWG_RC_HIP_ERROR;
+  // (sums: five arrays of E accumulators, array k at sums + k E 256)
+  if (hipMemcpyAsync(s.host_sums, s.sums, p->E * 5 * 256, hipMemcpyDeviceToHost, s.st_h) != hipSuccess || hipEventRecord(s.ev_done, s.st_h) != hipSuccess)
+    return ZKWG_RC_HIP_ERROR;
+  s.first = first; s.count = count; s.busy = true;
+  return ZKWG_RC_OK;
+}
+// wait for context s, assemble its proofs
+static int prover_finish(zkwg_prover* p, ZkProveCtx& s, const uint8_t* blinding, uint8_t* out_proofs) {
+  if (!s.busy) return ZKWG_RC_OK;
+  s.busy = false;
+  if (hipEventSynchronize(s.ev_done) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  int rc = ZKWG_RC_OK;
+  for (uint64_t j = 0; j < s.count && rc == ZKWG_RC_OK; ++j) {
+    uint8_t pts[5][128];
+    // sum k of email j: array k holds E accumulators of 256 bytes (G1 uses the first 128)
+    for (int k = 0; k < 5; ++k) zkwg_msm_finish_host(k == 2 ? 2 : 1, s.host_sums + (uint64_t)k * p->E * 256 + j * (k == 2 ? 256 : 128), 1, pts[k]);
+    uint8_t* o = out_proofs + 256 * (s.first + j);
+    const uint8_t* bl = blinding + 64 * (s.first + j);
+    rc = zkwg_groth16_assemble(pts[0], pts[1], pts[2], pts[3], pts[4], p->alpha1, p->beta1, p->beta2, p->delta1, p->delta2, bl, bl + 32, o, o + 64, o + 192);
+  }
+  return rc;
 }
 
 extern "C" {
@@ -43,78 +181,34 @@ int zkwg_prover_create(zkwg_circuit_t* c, int device, const uint8_t* r1cs, uint6
                        uint32_t slots, zkwg_prover_t** out) {
   if (!c || !key || !out || !key->a || !key->b1 || !key->b2 || !key->c || !key->h || slots == 0 || slots > 256) return ZKWG_RC_BAD_ARG;
   if (device < 0) return ZKWG_RC_NO_DEVICE;
-  const uint64_t W = zkwg_witness_len(c), n = 1ull << key->log2_domain;
-  if (key->n_wires != W || key->n_public + 1 >= W || n_rows > n || key->log2_domain > 28) return ZKWG_RC_BAD_CONFIG;
   if (hipSetDevice(device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   int rc = ZKWG_RC_OK;
   if (r1cs) rc = zkwg_circuit_attach_r1cs(c, r1cs, r1cs_len);     // (NULL: the caller attached the system already)
   if (rc != ZKWG_RC_OK) return rc;
-  if (zkwg_abc_bytes(c) != 96 * n_rows) return ZKWG_RC_BAD_CONFIG;
-  zkwg_prover* p = new zkwg_prover();
-  p->c = c; p->device = device; p->n_rows = n_rows; p->n_public = key->n_public; p->W = W; p->power = (uint32_t)key->log2_domain;
-  memcpy(p->alpha1, key->alpha1, 64); memcpy(p->beta1, key->beta1, 64); memcpy(p->beta2, key->beta2, 128);
-  memcpy(p->delta1, key->delta1, 64); memcpy(p->delta2, key->delta2, 128);
-  auto plan = [&](int group, const void* bases, uint64_t count, zkwg_msm_t** m) {
-    if (rc != ZKWG_RC_OK) return;
-    rc = key->bases_on_device ? zkwg_msm_create_device(device, group, bases, count, 0, m)
-                              : (group == 1 ? zkwg_msm_create(device, (const uint8_t*)bases, count, 0, m) : zkwg_msm_create_g2(device, (const uint8_t*)bases, count, 0, m));
-  };
-  rc = zkwg_ntt_create(device, p->power, &p->ntt);
-  plan(1, key->a, W, &p->ma); plan(1, key->b1, W, &p->mb1); plan(2, key->b2, W, &p->mb2);
-  plan(1, key->c, W - key->n_public - 1, &p->mc); plan(1, key->h, n, &p->mh);
-  if (rc != ZKWG_RC_OK) { prover_free(p); return rc; }
-  for (zkwg_msm_t* m : {p->ma, p->mb1, p->mb2, p->mc, p->mh}) p->work_bytes = std::max<uint64_t>(p->work_bytes, zkwg_msm_work_bytes(m));
-  p->slots.resize(slots);
-  for (ZkProveSlot& s : p->slots) {
-    bool ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void**)&s.wit, zkwg_witness_bytes(c)) == hipSuccess && hipMalloc((void**)&s.abc, zkwg_abc_bytes(c)) == hipSuccess &&
-              hipMalloc((void**)&s.h, 32ull << p->power) == hipSuccess && hipMalloc((void**)&s.ntt, zkwg_ntt_work_bytes(p->ntt, 1)) == hipSuccess &&
-              hipMalloc((void**)&s.work, p->work_bytes + 256) == hipSuccess && hipMalloc((void**)&s.sums, 5 * 256) == hipSuccess;
-    if (!ok) { prover_free(p); (void)hipGetLastError(); return ZKWG_RC_OOM; }
-  }
-  *out = p;
-  return ZKWG_RC_OK;
+  return prover_new(c, device, n_rows, key, slots, 0, out);
 }
 void zkwg_prover_destroy(zkwg_prover_t* p) { prover_free(p); }
+uint32_t zkwg_prover_emails_per_series(const zkwg_prover_t* p) { return p ? p->E : 0; }
+uint32_t zkwg_prover_contexts(const zkwg_prover_t* p) { return p ? (uint32_t)p->ctx.size() : 0; }
 
 int zkwg_prover_prove_prepared(zkwg_prover_t* p, const void* d_in, uint64_t n, const void* d_scratch, const uint64_t* indices, uint64_t n_idx,
                                const uint8_t* blinding, uint8_t* out_proofs) {
   if (!p || !d_in || !d_scratch || !indices || !blinding || !out_proofs) return ZKWG_RC_BAD_ARG;
   if (hipSetDevice(p->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
-  zkwg_circuit_t* c = p->c;
-  const uint64_t wb = zkwg_witness_bytes(c), ab = zkwg_abc_bytes(c);
-  const size_t S = p->slots.size();
-  for (uint64_t w0 = 0; w0 < n_idx; w0 += S) {
-    const uint64_t cnt = std::min<uint64_t>(S, n_idx - w0);
-    int rc = ZKWG_RC_OK;
-    for (uint64_t j = 0; j < cnt && rc == ZKWG_RC_OK; ++j) {
-      ZkProveSlot& s = p->slots[j];
-      const uint64_t e = indices[w0 + j];
-      if (e >= n) { rc = ZKWG_RC_BAD_ARG; break; }
-      uint8_t* work = (uint8_t*)(((uintptr_t)s.work + 255) & ~(uintptr_t)255);
-      rc = zkwg_expand_device(c, d_in, n, d_scratch, e, 1, s.wit, wb, s.st);
-      if (rc == ZKWG_RC_OK) rc = zkwg_expand_abc_device(c, d_in, n, d_scratch, e, 1, 1, s.abc, ab, s.st);
-      if (rc == ZKWG_RC_OK) rc = zkwg_h_evaluations_device(p->ntt, s.abc, ab, p->n_rows, 1, s.ntt, s.h, 32ull << p->power, s.st);
-      if (rc == ZKWG_RC_OK) rc = zkwg_msm_enqueue_device(p->ma, s.wit, 0, 1, work, s.sums, s.st);
-      if (rc == ZKWG_RC_OK) rc = zkwg_msm_enqueue_device(p->mb1, s.wit, 0, 1, work, s.sums + 256, s.st);
-      if (rc == ZKWG_RC_OK) rc = zkwg_msm_enqueue_device(p->mb2, s.wit, 0, 1, work, s.sums + 512, s.st);
-      if (rc == ZKWG_RC_OK) rc = zkwg_msm_enqueue_device(p->mc, s.wit + 32 * (p->n_public + 1), 0, 1, work, s.sums + 768, s.st);
-      if (rc == ZKWG_RC_OK) rc = zkwg_msm_enqueue_device(p->mh, s.h, 1, 0, work, s.sums + 1024, s.st);
-    }
-    for (uint64_t j = 0; j < cnt; ++j) {
-      ZkProveSlot& s = p->slots[j];
-      uint8_t raw[5 * 256], pts[5][128];
-      if (hipStreamSynchronize(s.st) != hipSuccess && rc == ZKWG_RC_OK) rc = ZKWG_RC_HIP_ERROR;
-      if (rc != ZKWG_RC_OK) continue;
-      if (hipMemcpy(raw, s.sums, sizeof raw, hipMemcpyDeviceToHost) != hipSuccess) { rc = ZKWG_RC_HIP_ERROR; continue; }
-      for (int k = 0; k < 5; ++k) zkwg_msm_finish_host(k == 2 ? 2 : 1, raw + 256 * k, 1, pts[k]);
-      uint8_t* o = out_proofs + 256 * (w0 + j);
-      const uint8_t* bl = blinding + 64 * (w0 + j);
-      rc = zkwg_groth16_assemble(pts[0], pts[1], pts[2], pts[3], pts[4], p->alpha1, p->beta1, p->beta2, p->delta1, p->delta2, bl, bl + 32, o, o + 64, o + 192);
-    }
-    if (rc != ZKWG_RC_OK) return rc;
+  for (uint64_t i = 0; i < n_idx; ++i) if (indices[i] >= n) return ZKWG_RC_BAD_ARG;
+  int rc = ZKWG_RC_OK;
+  size_t k = 0;
+  for (uint64_t first = 0; first < n_idx && rc == ZKWG_RC_OK; first += p->E, ++k) {
+    ZkProveCtx& s = p->ctx[k % p->ctx.size()];
+    rc = prover_finish(p, s, blinding, out_proofs);               // the series this context ran before (others are still in flight)
+    if (rc == ZKWG_RC_OK) rc = prover_enqueue(p, s, d_in, n, d_scratch, indices, first, std::min<uint64_t>(p->E, n_idx - first));
   }
-  return ZKWG_RC_OK;
+  for (size_t j = 0; j < p->ctx.size(); ++j) {                    // drain, oldest first
+    const int r2 = prover_finish(p, p->ctx[(k + j) % p->ctx.size()], blinding, out_proofs);
+    if (rc == ZKWG_RC_OK) rc = r2;
+  }
+  if (rc != ZKWG_RC_OK) { hipDeviceSynchronize(); for (ZkProveCtx& s : p->ctx) s.busy = false; (void)hipGetLastError(); }
+  return rc;
 }
 
 // inputs -> proofs: n packed input records (zkwg_pack_input) on the host -> status[n] (circom_runtime codes) and, for every email whose

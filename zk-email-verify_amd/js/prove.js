@@ -9,7 +9,6 @@
 // <circuit.r1cs>: the constraint system over the circuit's witness layout with the nPublic + 1 rows snarkjs appends to A
 // (python -m zkwg.r1cs --public-rows 1 -o circuit.r1cs, or the compiler's file plus those rows), <nRows> its constraint count;
 // <input.json>: one CircuitInput object or an array; <proofs.json> receives [{status, proof, publicSignals}] per email.
-// Run with GPU_MAX_HW_QUEUES=16 in the environment (several proofs are kept in flight).
 const fs = require('fs');
 const z = require('./zkwg.js');
 

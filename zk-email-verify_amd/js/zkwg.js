@@ -170,7 +170,7 @@ class WitnessCalculator {
  * wtns)` for whole batches -- witness, A.w | B.w | C.w, H evaluations, the five multi-exponentiations over the zkey's bases, proof
  * assembly (include/zkwg.h zkwg_prover_*).  `zkey`: the bytes of a snarkjs groth16 .zkey (sections 2, 5-9 are read; layout restated
  * from snarkjs, DESIGN.md section 23); `r1cs`: the constraint system over the circuit's witness layout WITH the nPublic + 1 rows
- * snarkjs appends to A; `nRows`: its constraint count.  Set GPU_MAX_HW_QUEUES=16 in the environment: `slots` proofs are in flight. */
+ * snarkjs appends to A; `nRows`: its constraint count.  `slots` proofs are in flight (1-3 contexts of E emails each, every stage one launch series per context). */
 class Prover {
   constructor(circuit, r1cs, nRows, zkey, slots) {
     const key = Prover.parseZkey(zkey);
@@ -202,6 +202,15 @@ class Prover {
     const s = (id) => buf.slice(sec[id][0], sec[id][0] + sec[id][1]);
     return { nWires, nPublic, log2Domain: Math.round(Math.log2(domain)), a: s(5), b1: s(6), b2: s(7), c: s(8), h: s(9), alpha1, beta1, beta2, delta1, delta2 };
   }
+  /** uniform in Fr, as snarkjs' Fr.random(): 254 random bits, rejected until below the group order (acceptance 0.76) */
+  static randomFr() {
+    for (;;) {
+      const b = require("crypto").randomBytes(32);
+      b[0] &= 0x3f;
+      const x = BigInt("0x" + b.toString("hex"));
+      if (x < FIELD_MODULUS) return x;
+    }
+  }
   /** inputs[] (generateEmailVerifierInputs objects) -> Promise<{status: Int32Array, proofs: (snarkjs proof.json object | null)[]}>;
    * blinding: optional [[r, s], ...] bigints (default: random) */
   async proveBatch(inputs, blinding) {
@@ -209,7 +218,7 @@ class Prover {
     const bl = Buffer.alloc(64 * inputs.length);
     const put = (v, off) => { let x = BigInt(v) % FIELD_MODULUS; for (let k = 0; k < 32; ++k) { bl[off + k] = Number(x & 255n); x >>= 8n; } };
     for (let i = 0; i < inputs.length; ++i) {
-      const rs = blinding ? blinding[i] : [BigInt("0x" + require("crypto").randomBytes(31).toString("hex")), BigInt("0x" + require("crypto").randomBytes(31).toString("hex"))];
+      const rs = blinding ? blinding[i] : [Prover.randomFr(), Prover.randomFr()];
       put(rs[0], 64 * i); put(rs[1], 64 * i + 32);
     }
     const r = await addon.proveBatch(this.handle, this.circuit.handle, recs, bl);

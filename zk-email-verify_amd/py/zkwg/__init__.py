@@ -498,7 +498,7 @@ class Ntt:
 
 
 class Msm:
-    """One G1 multi-exponentiation of groth16.prove (include/zkwg.h "prover stage 3", DRAFT): `bases` = n affine points as the zkey
+    """One G1 multi-exponentiation of groth16.prove (include/zkwg.h "prover stage 3"): `bases` = n affine points as the zkey
     stores them (x | y little-endian Montgomery limbs, 64 bytes each, zeros = infinity), resident on the device."""
     Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 
@@ -527,8 +527,25 @@ class Msm:
                 out += ((p[0] << 256) % Msm.Q).to_bytes(32, "little") + ((p[1] << 256) % Msm.Q).to_bytes(32, "little")
         return bytes(out)
 
-    def work_bytes(self):
-        return self.lib.zkwg_msm_work_bytes(self.h)
+    def work_bytes(self, n_emails=1):
+        return self.lib.zkwg_msm_work_bytes_batch(self.h, n_emails)
+
+    def g1_batch_device(self, d_scalars, n_emails, montgomery, d_work, stream=None, ones_apart=False):
+        """n_emails sums in ONE launch series: the scalar vectors lie back to back at d_scalars -> [(x, y) | None] (standard form)"""
+        import torch
+        d_out = torch.empty(128 * n_emails, dtype=torch.uint8, device=d_scalars.device)
+        _check(self.lib.zkwg_msm_enqueue_batch_device(self.h, d_scalars.data_ptr(), 32 * self.n, n_emails, 1 if montgomery else 0, 1 if ones_apart else 0,
+                                                      d_work.data_ptr(), d_out.data_ptr(), _stream_ptr(stream)))
+        torch.cuda.synchronize(d_scalars.device)
+        raw = bytes(d_out.cpu().numpy())
+        pts = (C.c_uint8 * (64 * n_emails))()
+        _check(self.lib.zkwg_msm_finish_host(1, raw, n_emails, pts))
+        rinv = pow(1 << 256, -1, Msm.Q)
+        out = []
+        for e in range(n_emails):
+            b = bytes(pts)[64 * e:64 * e + 64]
+            out.append(None if b == bytes(64) else (int.from_bytes(b[:32], "little") * rinv % Msm.Q, int.from_bytes(b[32:], "little") * rinv % Msm.Q))
+        return out
 
     def g1_device(self, d_scalars, montgomery, d_work, stream=None, ones_apart=False):
         """sum_i scalar_i * base_i for the n 32-byte scalars at d_scalars (torch tensor) -> (x, y) standard-form integers or None"""

@@ -37,13 +37,13 @@ def fixed_base(device, group, scalars):
 class _DeviceMsm:
     """multi-exponentiation over bases that already live on the device (zkwg_msm_create_device)"""
 
-    def __init__(self, d_bases, group, device, window_bits=0):
+    def __init__(self, d_bases, group, device, window_bits=0, slice0=0):
         self.lib = _lib.load()
         self.group, self.device = group, device
         self.n = d_bases.numel() // (64 if group == 1 else 128)
-        self.d_bases = d_bases                      # keep the tensor alive
         h = C.c_void_p()
-        _check(self.lib.zkwg_msm_create_device(device, group, d_bases.data_ptr(), self.n, window_bits, C.byref(h)))
+        # (the plan keeps its own table of the bases in the kernels' form: the tensor is only read here)
+        _check(self.lib.zkwg_msm_create_ex(device, group, d_bases.data_ptr(), 1, self.n, window_bits, slice0, 0, C.byref(h)))
         self.h = h
 
     def __del__(self):
@@ -51,8 +51,21 @@ class _DeviceMsm:
             self.lib.zkwg_msm_destroy(self.h)
             self.h = None
 
-    def work_bytes(self):
-        return self.lib.zkwg_msm_work_bytes(self.h)
+    def work_bytes(self, n_emails=1):
+        return self.lib.zkwg_msm_work_bytes_batch(self.h, n_emails)
+
+    def run_batch(self, scalars_ptr, scalar_stride, n_emails, montgomery, ones_apart, d_work, stream=None):
+        """n_emails sums in one launch series -> list of the sums as the zkey would store them (bytes: 64 / 128 each)"""
+        import torch
+        size = 128 if self.group == 1 else 256
+        d_out = torch.empty(size * n_emails, dtype=torch.uint8, device=d_work.device)
+        _check(self.lib.zkwg_msm_enqueue_batch_device(self.h, scalars_ptr, scalar_stride, n_emails, 1 if montgomery else 0, 1 if ones_apart else 0,
+                                                      d_work.data_ptr(), d_out.data_ptr(), _stream_ptr(stream)))
+        torch.cuda.synchronize(d_work.device)
+        ps = 64 if self.group == 1 else 128
+        pts = (C.c_uint8 * (ps * n_emails))()
+        _check(self.lib.zkwg_msm_finish_host(self.group, bytes(d_out.cpu().numpy()), n_emails, pts))
+        return [bytes(pts)[ps * e:ps * e + ps] for e in range(n_emails)]
 
     def enqueue(self, scalars_ptr, montgomery, ones_apart, d_work, out_ptr, stream=None):
         """asynchronous: the sum's accumulator (XYZZ, 128 / 256 bytes) is left at out_ptr on the device"""
@@ -100,7 +113,7 @@ class _KeyStruct(C.Structure):
 class Prover:
     """groth16.prove for the emails of a prepared batch.  `circuit`: a device handle whose constraint system `r1cs` (bytes of an
     `.r1cs` over its witness layout, WITH the nPublic + 1 rows snarkjs appends to A -- zkwg.r1cs.append_public_rows) is attached here.
-    prove_batch is include/zkwg.h's zkwg_prover_prove_prepared (several proofs in flight, what a Node host binds too); prove_prepared
+    prove_batch is include/zkwg.h's zkwg_prover_prove_prepared (E emails per launch series, rolling contexts; what a Node host binds too); prove_prepared
     runs the same stages one call at a time from Python and keeps the five sums (tests compare each with its discrete logarithm)."""
 
     def __init__(self, circuit, r1cs, n_constraints, key, stream=None):
@@ -133,11 +146,12 @@ class Prover:
         circuit, key = self.c, self.key
         self.ntt = Ntt(key.power, device=circuit.device)
         d = circuit.device
-        self.msm_a = _DeviceMsm(key.d_a, 1, d)
-        self.msm_b1 = _DeviceMsm(key.d_b1, 1, d)
-        self.msm_b2 = _DeviceMsm(key.d_b2, 2, d)
-        self.msm_c = _DeviceMsm(key.d_c, 1, d)
-        self.msm_h = _DeviceMsm(key.d_h, 1, d)
+        ww = 13 if key.n_wires >= (1 << 16) else 0           # as zkwg_prover_create plans them
+        self.msm_a = _DeviceMsm(key.d_a, 1, d, ww, 16)
+        self.msm_b1 = _DeviceMsm(key.d_b1, 1, d, ww, 16)
+        self.msm_b2 = _DeviceMsm(key.d_b2, 2, d, ww, 16)
+        self.msm_c = _DeviceMsm(key.d_c, 1, d, ww, 16)
+        self.msm_h = _DeviceMsm(key.d_h, 1, d, 0, 64 if key.power >= 18 else 16)
         wb = max(m.work_bytes() for m in (self.msm_a, self.msm_b1, self.msm_b2, self.msm_c, self.msm_h))
         self.d_msm_work = torch.empty(wb + 256, dtype=torch.uint8, device=self.dev)
         self.d_msm_work = self.d_msm_work[(-self.d_msm_work.data_ptr()) % 256:]
@@ -197,7 +211,8 @@ class Prover:
 
     def prove_batch(self, d_in, n, d_scratch, indices, blinding, slots=8):
         """proofs of the emails `indices` of a prepared batch (complete: synchronise the preparing stream first); blinding = [(r, s)] per
-        email -> list of proof dicts (prove_prepared's form).  `slots` proofs are in flight, each on its own stream."""
+        email -> list of proof dicts (prove_prepared's form).  `slots` proofs are in flight: 1-3 contexts of ceil(slots / contexts) emails,
+        every stage one launch series per context."""
         h = self._native(slots)
         idx = (C.c_uint64 * len(indices))(*indices)
         bl = b"".join(int(r % R).to_bytes(32, "little") + int(s % R).to_bytes(32, "little") for r, s in blinding)
