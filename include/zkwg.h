@@ -515,6 +515,10 @@ typedef struct zkwg_proving_key {
 } zkwg_proving_key;
 int zkwg_prover_create(zkwg_circuit_t* c, int device, const uint8_t* r1cs, uint64_t r1cs_len, uint64_t n_rows, const zkwg_proving_key* key,
                        uint32_t slots, zkwg_prover_t** out);
+/* The prover from the zkey ALONE, as `groth16.prove(zkey, wtns)` / `fullProve(input, wasm, zkey)` take it (chunked-zkey.ts:80-84): the
+ * rows of A and B (the nPublic + 1 public rows included) come from section 4 of the file, C.w = A.w o B.w as snarkjs' buildABC1 forms
+ * it, the bases from sections 5-9; `zkey` is only read during the call.  The handle's witness layout must be the key's (nVars wires). */
+int zkwg_prover_create_zkey(zkwg_circuit_t* c, int device, const uint8_t* zkey, uint64_t zkey_len, uint32_t slots, zkwg_prover_t** out);
 void zkwg_prover_destroy(zkwg_prover_t* p);
 uint32_t zkwg_prover_emails_per_series(const zkwg_prover_t* p);
 uint32_t zkwg_prover_contexts(const zkwg_prover_t* p);

@@ -19,8 +19,8 @@ for step in "$@"; do
   echo "=== $step"
   case $step in
     env:*) export "${step#env:}" ;;
-    tests:*) timeout 1500 python -m pytest tests -m gpu -x -q -k "${step#tests:}" 2>&1 | tail -6 | tee $OUT/${TAG}_tests.txt ;;
-    files:*) timeout 1500 python -m pytest $(echo "${step#files:}" | tr ',' ' ') -m gpu -x -q 2>&1 | tail -6 | tee $OUT/${TAG}_tests.txt ;;
+    tests:*) timeout 1500 python -m pytest tests -m gpu -x -q -k "${step#tests:}" 2>&1 | tail -25 | tee $OUT/${TAG}_tests.txt ;;
+    files:*) timeout 1500 python -m pytest $(echo "${step#files:}" | tr ',' ' ') -m gpu -x -q 2>&1 | tail -25 | tee $OUT/${TAG}_tests.txt ;;
     alltests) timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee $OUT/${TAG}_pytest_gpu.txt ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/${TAG}_smoke.txt ;;
     beside) timeout 600 python tools/beside.py --out $OUT/${TAG}_beside.json 2>&1 | tail -20 ;;
@@ -92,6 +92,11 @@ PY
               python $REPO/tools/bench_prove.py $A > $OUT/${TAG}_prove_prof.json 2> $OUT/${TAG}_pprof.log )
           S=$(find $OUT/${TAG}_pprof -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_prove_kernel_stats.csv && head -40 $S | cut -c1-170
           rm -rf $OUT/${TAG}_pprof; tail -1 $OUT/${TAG}_prove_prof.json | cut -c1-800 ;;
+    msmp:*) N=$(echo "${step#msmp:}" | tr -c 'a-zA-Z0-9' '_')
+          ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_mprof -- \
+              python $REPO/tools/bench_msm.py ${step#msmp:} > $OUT/${TAG}_msmp_$N.json 2> $OUT/${TAG}_mprof.log )
+          S=$(find $OUT/${TAG}_mprof -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_msm_kernel_stats_$N.csv && head -24 $S | cut -c1-150
+          rm -rf $OUT/${TAG}_mprof; tail -1 $OUT/${TAG}_msmp_$N.json ;;
     msm:*) timeout 600 python tools/bench_msm.py ${step#msm:} 2>&1 | tail -1 | tee -a $OUT/${TAG}_msm.json ;;
     ntt) timeout 600 python tools/bench_ntt.py 2>&1 | tail -1 | tee -a $OUT/${TAG}_ntt.json | cut -c1-800 ;;
     ntt:*) timeout 600 python tools/bench_ntt.py ${step#ntt:} 2>&1 | tail -1 | tee -a $OUT/${TAG}_ntt.json | cut -c1-800 ;;

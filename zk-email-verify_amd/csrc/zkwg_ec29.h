@@ -71,7 +71,7 @@ struct ZkF2 {
   static __device__ __forceinline__ E store_y(const E& a) { return fq29_norm(a); }
   static __device__ __forceinline__ E zero() { return fq29_zero(); }
   static __device__ __forceinline__ E one() { return odd() ? fq29_zero() : fq29_one(); }
-  static __device__ __forceinline__ bool both(bool mine) { return mine && zk_pair_xchg(mine ? 1u : 0u) != 0; }
+  static __device__ __forceinline__ bool both(bool mine) { const u32 other = zk_pair_xchg(mine ? 1u : 0u); return mine & (other != 0); }
   static __device__ __forceinline__ bool all_zero(const E& a) { return both(fq29_all_zero(a)); }
   template <int V> static __device__ __forceinline__ bool maybe_zero(const E& a) { return both(fq29_maybe_zero<V>(a)); }
   template <int V> static __device__ __forceinline__ bool is_zero_mod(const E& a) { return both(fq29_is_zero_mod<V>(a)); }
@@ -223,6 +223,7 @@ struct ZkEcG1 {
   typedef G1Affine Affine;
   typedef G1Xyzz Out;
   static constexpr int LANES = 1;
+  static constexpr int DEV_LANES = 1;      // lanes per point in the kernels (what the host sizes its launches with)
   static ZK_HD Aff29<F> load(const Affine* p, u32 h, bool neg) {
     const Fq x = zk_ld_fq(&p->x), y = zk_ld_fq(&p->y);
     return Aff29<F>{fq29_from_fq(x), fq29_from_fq(zk_fq_neg_if(y, neg)), fq_is_zero(x) && fq_is_zero(y)};
@@ -237,6 +238,7 @@ struct ZkEcG2 {
   typedef ZkF2 F;
   typedef G2Affine Affine;
   typedef G2Xyzz Out;
+  static constexpr int DEV_LANES = 2;
 #if defined(__HIP_DEVICE_COMPILE__)
   static constexpr int LANES = 2;
   static __device__ __forceinline__ Aff29<F> load(const Affine* p, u32 h, bool neg) {

@@ -94,7 +94,7 @@ static inline u32 zk_grid(u64 items, u32 per_wg, u32 cap) { const u64 g = (items
 // the launch series of E multi-exponentiations over one base set on `st` (the counters are zeroed here)
 template <class C>
 static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
-  constexpr u32 per = 64u / C::LANES;
+  constexpr u32 per = 64u / C::DEV_LANES;     // points per wavefront (host code: C::LANES is the CPU mirror's 1 here)
   const u32 total = A.KS * A.nb, E = A.E;
   for (u32 e = 0; e < E; ++e) hipMemsetAsync(A.count(e), 0, ((size_t)total + 1) * 4, st);
   const bool lds_sort = A.lds_sort && total <= ZK_MSM_LDS_BUCKETS;

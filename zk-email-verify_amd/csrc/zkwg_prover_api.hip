@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <vector>
 #include "../../include/zkwg.h"
+#include "zkwg_fq.h"
 
 struct ZkProveCtx {
   hipStream_t st_h = nullptr, st_w = nullptr, st_g = nullptr;
@@ -186,6 +187,132 @@ int zkwg_prover_create(zkwg_circuit_t* c, int device, const uint8_t* r1cs, uint6
   if (r1cs) rc = zkwg_circuit_attach_r1cs(c, r1cs, r1cs_len);     // (NULL: the caller attached the system already)
   if (rc != ZKWG_RC_OK) return rc;
   return prover_new(c, device, n_rows, key, slots, 0, out);
+}
+// The prover from the zkey ALONE -- what `groth16.prove(zkey, wtns)` takes (reference call site: fullProve(input, wasm, zkey),
+// packages/helpers/src/chunked-zkey.ts:80-84).  A snarkjs groth16 .zkey carries its own constraint system: section 4 lists the
+// coefficients of A and B (matrix, row, wire, value x R^2), the nPublic + 1 rows snarkjs appends to A included, and buildABC1 takes the
+// third block as A.w o B.w; sections 5-9 are the bases.  The rows become an in-memory `.r1cs` with empty C combinations that is attached
+// to the handle like any other system (zkwg_circuit_attach_r1cs: A.w and B.w then come straight from the compact image), and every
+// series computes C.w = A.w o B.w before the transforms (zk_abc_c_from_ab).  Container layout restated from snarkjs [EXT]:
+// zkwg/zkey.py has the field-by-field description.
+static bool zkey_sections(const uint8_t* z, uint64_t len, uint64_t (&off)[11], uint64_t (&size)[11]) {
+  for (int i = 0; i < 11; ++i) off[i] = size[i] = 0;
+  if (len < 12 || memcmp(z, "zkey", 4) != 0) return false;
+  uint32_t version, nsec;
+  memcpy(&version, z + 4, 4); memcpy(&nsec, z + 8, 4);
+  if (version != 1) return false;
+  uint64_t pos = 12;
+  for (uint32_t i = 0; i < nsec; ++i) {
+    if (pos + 12 > len) return false;
+    uint32_t id; uint64_t sz;
+    memcpy(&id, z + pos, 4); memcpy(&sz, z + pos + 4, 8);
+    pos += 12;
+    if (sz > len - pos) return false;
+    if (id >= 1 && id <= 10) { off[id] = pos; size[id] = sz; }
+    pos += sz;
+  }
+  return true;
+}
+int zkwg_prover_create_zkey(zkwg_circuit_t* c, int device, const uint8_t* zkey, uint64_t zkey_len, uint32_t slots, zkwg_prover_t** out) {
+  if (!c || !zkey || !out || slots == 0 || slots > 256) return ZKWG_RC_BAD_ARG;
+  if (device < 0) return ZKWG_RC_NO_DEVICE;
+  uint64_t off[11], size[11];
+  if (!zkey_sections(zkey, zkey_len, off, size)) return ZKWG_RC_BAD_CONFIG;
+  for (int need : {1, 2, 4, 5, 6, 7, 8, 9}) if (!off[need]) return ZKWG_RC_BAD_CONFIG;
+  uint32_t protocol;
+  memcpy(&protocol, zkey + off[1], 4);
+  if (size[1] < 4 || protocol != 1) return ZKWG_RC_BAD_CONFIG;                     // groth16
+  // header: n8q, q, n8r, r, nVars, nPublic, domainSize, alpha1, beta1, beta2, gamma2, delta1, delta2
+  const uint8_t* h = zkey + off[2];
+  if (size[2] < 4 + 32 + 4 + 32 + 12 + 64 + 64 + 128 + 128 + 64 + 128) return ZKWG_RC_BAD_CONFIG;
+  uint32_t n8q, n8r, n_vars, n_public, domain;
+  memcpy(&n8q, h, 4); memcpy(&n8r, h + 36, 4);
+  const Fq q = fq_p(); const Fr r = fr_p();
+  if (n8q != 32 || n8r != 32 || memcmp(h + 4, q.l, 32) != 0 || memcmp(h + 40, r.l, 32) != 0) return ZKWG_RC_BAD_CONFIG;      // BN254
+  memcpy(&n_vars, h + 72, 4); memcpy(&n_public, h + 76, 4); memcpy(&domain, h + 80, 4);
+  if (domain == 0 || (domain & (domain - 1)) || n_public + 1 >= n_vars) return ZKWG_RC_BAD_CONFIG;
+  uint32_t power = 0;
+  while ((1u << power) < domain) ++power;
+  if (size[5] != 64ull * n_vars || size[6] != 64ull * n_vars || size[7] != 128ull * n_vars || size[8] != 64ull * (n_vars - n_public - 1) || size[9] != 64ull * domain)
+    return ZKWG_RC_BAD_CONFIG;
+  zkwg_proving_key key;
+  memset(&key, 0, sizeof key);
+  key.n_wires = n_vars; key.n_public = n_public; key.log2_domain = power;
+  key.a = zkey + off[5]; key.b1 = zkey + off[6]; key.b2 = zkey + off[7]; key.c = zkey + off[8]; key.h = zkey + off[9]; key.bases_on_device = 0;
+  const uint8_t* pts = h + 84;
+  memcpy(key.alpha1, pts, 64); memcpy(key.beta1, pts + 64, 64); memcpy(key.beta2, pts + 128, 128);
+  memcpy(key.delta1, pts + 384, 64); memcpy(key.delta2, pts + 448, 128);                           // (gamma2 sits between beta2 and delta1)
+  // section 4 -> rows of A and B
+  if (size[4] < 4) return ZKWG_RC_BAD_CONFIG;
+  uint32_t n_coef;
+  memcpy(&n_coef, zkey + off[4], 4);
+  if (size[4] != 4 + 44ull * n_coef) return ZKWG_RC_BAD_CONFIG;
+  const uint8_t* cf = zkey + off[4] + 4;
+  uint64_t n_rows = 0;
+  for (uint32_t i = 0; i < n_coef; ++i) {
+    uint32_t m, row, wire;
+    memcpy(&m, cf + 44ull * i, 4); memcpy(&row, cf + 44ull * i + 4, 4); memcpy(&wire, cf + 44ull * i + 8, 4);
+    if (m > 1 || wire >= n_vars || row >= domain) return ZKWG_RC_BAD_CONFIG;
+    n_rows = std::max<uint64_t>(n_rows, (uint64_t)row + 1);
+  }
+  if (n_rows == 0) return ZKWG_RC_BAD_CONFIG;
+  std::vector<uint32_t> cnt(2 * n_rows + 1, 0);                      // terms of A row i at 2 i, of B row i at 2 i + 1
+  for (uint32_t i = 0; i < n_coef; ++i) {
+    uint32_t m, row;
+    memcpy(&m, cf + 44ull * i, 4); memcpy(&row, cf + 44ull * i + 4, 4);
+    ++cnt[2ull * row + m];
+  }
+  // the in-memory .r1cs: per row  A (count, terms) | B (count, terms) | C (0)
+  std::vector<uint64_t> at(2 * n_rows);
+  uint64_t pos = 0;
+  for (uint64_t i = 0; i < n_rows; ++i) {
+    at[2 * i] = pos + 4; pos += 4 + 36ull * cnt[2 * i];
+    at[2 * i + 1] = pos + 4; pos += 4 + 36ull * cnt[2 * i + 1];
+    pos += 4;
+  }
+  const uint64_t cons_len = pos, hdr_len = 4 + 32 + 16 + 8 + 4, w2l_len = 8ull * n_vars;
+  std::vector<uint8_t> file(12 + 3 * 12 + hdr_len + cons_len + w2l_len, 0);
+  uint8_t* f = file.data();
+  memcpy(f, "r1cs", 4);
+  const uint32_t one = 1, three = 3, fs = 32;
+  memcpy(f + 4, &one, 4); memcpy(f + 8, &three, 4);
+  uint64_t o = 12;
+  auto section = [&](uint32_t type, uint64_t sz) { memcpy(f + o, &type, 4); memcpy(f + o + 4, &sz, 8); o += 12; const uint64_t at0 = o; o += sz; return at0; };
+  {
+    uint8_t* hd = f + section(1, hdr_len);
+    memcpy(hd, &fs, 4); memcpy(hd + 4, r.l, 32);
+    const uint32_t n_prv = n_vars - 1 - n_public, zero = 0, m32 = (uint32_t)n_rows;
+    const uint64_t labels = n_vars;
+    memcpy(hd + 36, &n_vars, 4); memcpy(hd + 40, &n_public, 4); memcpy(hd + 44, &zero, 4); memcpy(hd + 48, &n_prv, 4); memcpy(hd + 52, &labels, 8); memcpy(hd + 60, &m32, 4);
+  }
+  {
+    uint8_t* cs = f + section(2, cons_len);
+    for (uint64_t i = 0; i < n_rows; ++i) { memcpy(cs + at[2 * i] - 4, &cnt[2 * i], 4); memcpy(cs + at[2 * i + 1] - 4, &cnt[2 * i + 1], 4); }
+    for (uint32_t i = 0; i < n_coef; ++i) {
+      uint32_t m, row, wire;
+      memcpy(&m, cf + 44ull * i, 4); memcpy(&row, cf + 44ull * i + 4, 4); memcpy(&wire, cf + 44ull * i + 8, 4);
+      Fr v;
+      memcpy(v.l, cf + 44ull * i + 12, 32);
+      if (fr_geq(v, r)) return ZKWG_RC_BAD_CONFIG;
+      v = fr_from_mont(fr_from_mont(v));                             // stored: coefficient x R^2
+      uint8_t* t = cs + at[2ull * row + m];
+      memcpy(t, &wire, 4); memcpy(t + 4, v.l, 32);
+      at[2ull * row + m] += 36;
+    }
+  }
+  {
+    uint8_t* wl = f + section(3, w2l_len);
+    for (uint64_t i = 0; i < n_vars; ++i) memcpy(wl + 8 * i, &i, 8);
+  }
+  if (hipSetDevice(device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  if (zkwg_witness_len(c) != n_vars) return ZKWG_RC_BAD_CONFIG;
+  // (a handle that already carries a system of this size keeps it: a second prover over the same handle, e.g. with more slots)
+  if (zkwg_abc_bytes(c) == 0) {
+    const int rc = zkwg_circuit_attach_r1cs(c, file.data(), file.size());
+    if (rc != ZKWG_RC_OK) return rc;
+  }
+  file.clear(); file.shrink_to_fit();
+  return prover_new(c, device, n_rows, &key, slots, 1, out);
 }
 void zkwg_prover_destroy(zkwg_prover_t* p) { prover_free(p); }
 uint32_t zkwg_prover_emails_per_series(const zkwg_prover_t* p) { return p ? p->E : 0; }

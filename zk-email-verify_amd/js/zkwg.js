@@ -16,6 +16,7 @@ const path = require('path');
 const addon = require(path.join(__dirname, 'zkwg_addon.node'));
 
 const FIELD_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
+const BASE_FIELD_MODULUS = 21888242871839275222246405745257275088696311157297823662689037894645226208583n;   // BN254 Fq (a .zkey states both primes)
 const MAIN_EMAIL_VERIFIER = 0, MAIN_SHA256_BYTES = 1, MAIN_RSA_VERIFIER = 2, MAIN_FP_MUL = 3;
 const IN = { HEADER: 0, BODY: 1, PRECOMPUTED_SHA: 2, PUBKEY: 3, SIGNATURE: 4, MESSAGE: 5, HEADER_LEN: 6, BODY_LEN: 7, BODY_HASH_INDEX: 8, HEADER_MASK: 9, BODY_MASK: 10, DECODED_BODY: 11, RANGE_FLAGS: 12 };
 
@@ -168,15 +169,28 @@ class WitnessCalculator {
 
 /** The second half of `snarkjs.groth16.fullProve` (packages/helpers/src/chunked-zkey.ts:80-84) on the device: `groth16.prove(zkey,
  * wtns)` for whole batches -- witness, A.w | B.w | C.w, H evaluations, the five multi-exponentiations over the zkey's bases, proof
- * assembly (include/zkwg.h zkwg_prover_*).  `zkey`: the bytes of a snarkjs groth16 .zkey (sections 2, 5-9 are read; layout restated
- * from snarkjs, DESIGN.md section 23); `r1cs`: the constraint system over the circuit's witness layout WITH the nPublic + 1 rows
- * snarkjs appends to A; `nRows`: its constraint count.  `slots` proofs are in flight (1-3 contexts of E emails each, every stage one launch series per context). */
+ * assembly (include/zkwg.h zkwg_prover_*).
+ *     new Prover(circuit, zkey, slots)                 what groth16.prove takes: the zkey ALONE (rows of A and B from its section 4, C.w =
+ *                                                      A.w o B.w as buildABC1 forms it, bases from sections 5-9; zkwg_prover_create_zkey)
+ *     new Prover(circuit, r1cs, nRows, zkey, slots)    the constraint system from an .r1cs over the circuit's witness layout WITH the
+ *                                                      nPublic + 1 rows snarkjs appends to A (nRows = its constraint count); the zkey's
+ *                                                      sections 5-9 only
+ * `zkey`: the bytes of a snarkjs groth16 .zkey (layout restated from snarkjs, DESIGN.md section 23).  `slots` proofs are in flight (1-3
+ * contexts of E emails each, every stage one launch series per context). */
 class Prover {
-  constructor(circuit, r1cs, nRows, zkey, slots) {
-    const key = Prover.parseZkey(zkey);
-    if (key.nWires !== circuit.witnessLen) throw new Error(`zkwg: the key has ${key.nWires} wires, the circuit's witness ${circuit.witnessLen}`);
+  constructor(circuit, a, b, c, d) {
     this.circuit = circuit;
-    this.handle = addon.createProver(circuit.handle, circuit.device, r1cs, nRows, key, slots || 16);
+    if (typeof b !== "number" || c === undefined) {           // (circuit, zkey[, slots])
+      const key = Prover.parseZkey(a);
+      if (key.nWires !== circuit.witnessLen) throw new Error(`zkwg: the key has ${key.nWires} wires, the circuit's witness ${circuit.witnessLen}`);
+      this.nPublic = key.nPublic;
+      this.handle = addon.createProverZkey(circuit.handle, circuit.device, a, b || 16);
+      return;
+    }
+    const key = Prover.parseZkey(c);                          // (circuit, r1cs, nRows, zkey[, slots])
+    if (key.nWires !== circuit.witnessLen) throw new Error(`zkwg: the key has ${key.nWires} wires, the circuit's witness ${circuit.witnessLen}`);
+    this.nPublic = key.nPublic;
+    this.handle = addon.createProver(circuit.handle, circuit.device, a, b, key, d || 16);
   }
   /** sections of a groth16 .zkey -> the object addon.createProver takes */
   static parseZkey(buf) {
@@ -192,15 +206,23 @@ class Prover {
     for (const need of [1, 2, 5, 6, 7, 8, 9]) if (!sec[need]) throw new Error(`zkwg: .zkey section ${need} is missing`);
     if (buf.readUInt32LE(sec[1][0]) !== 1) throw new Error("zkwg: not a groth16 key");
     let p = sec[2][0];
-    const n8q = buf.readUInt32LE(p); p += 4 + n8q;
-    const n8r = buf.readUInt32LE(p); p += 4 + n8r;
-    if (n8q !== 32 || n8r !== 32) throw new Error("zkwg: not a BN254 key");
+    const le = (o, n) => { let x = 0n; for (let k = n - 1; k >= 0; --k) x = (x << 8n) | BigInt(buf[o + k]); return x; };
+    const n8q = buf.readUInt32LE(p);
+    if (n8q !== 32 || le(p + 4, 32) !== BASE_FIELD_MODULUS) throw new Error("zkwg: not a BN254 key (base field)");
+    p += 4 + n8q;
+    const n8r = buf.readUInt32LE(p);
+    if (n8r !== 32 || le(p + 4, 32) !== FIELD_MODULUS) throw new Error("zkwg: not a BN254 key (scalar field)");
+    p += 4 + n8r;
     const nWires = buf.readUInt32LE(p), nPublic = buf.readUInt32LE(p + 4), domain = buf.readUInt32LE(p + 8);
     p += 12;
+    if (domain === 0 || (domain & (domain - 1)) !== 0) throw new Error("zkwg: the .zkey's domain size is not a power of two");
+    if (nPublic + 1 >= nWires) throw new Error("zkwg: the .zkey's header is inconsistent (nPublic, nVars)");
+    const want = { 5: 64 * nWires, 6: 64 * nWires, 7: 128 * nWires, 8: 64 * (nWires - nPublic - 1), 9: 64 * domain };
+    for (const id of [5, 6, 7, 8, 9]) if (sec[id][1] !== want[id]) throw new Error(`zkwg: .zkey section ${id} holds ${sec[id][1]} bytes, expected ${want[id]}`);
     const take = (n) => { const b = buf.slice(p, p + n); p += n; return b; };
     const alpha1 = take(64), beta1 = take(64), beta2 = take(128); take(128); const delta1 = take(64), delta2 = take(128);
     const s = (id) => buf.slice(sec[id][0], sec[id][0] + sec[id][1]);
-    return { nWires, nPublic, log2Domain: Math.round(Math.log2(domain)), a: s(5), b1: s(6), b2: s(7), c: s(8), h: s(9), alpha1, beta1, beta2, delta1, delta2 };
+    return { nWires, nPublic, log2Domain: 31 - Math.clz32(domain), a: s(5), b1: s(6), b2: s(7), c: s(8), h: s(9), alpha1, beta1, beta2, delta1, delta2 };
   }
   /** uniform in Fr, as snarkjs' Fr.random(): 254 random bits, rejected until below the group order (acceptance 0.76) */
   static randomFr() {

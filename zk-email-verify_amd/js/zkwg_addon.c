@@ -449,6 +449,25 @@ static napi_value CreateProver(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_create_external(env, pv, prover_finalize, NULL, &ext));
   return ext;
 }
+/* createProverZkey(circuit, device, zkey: Buffer, slots) -> external: the prover from the zkey alone (zkwg_prover_create_zkey) --
+ * what groth16.prove(zkey, wtns) / fullProve(input, wasm, zkey) take (packages/helpers/src/chunked-zkey.ts:80-84) */
+static napi_value CreateProverZkey(napi_env env, napi_callback_info info) {
+  size_t argc = 4; napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  zkwg_circuit_t* c = unwrap(env, argv[0]);
+  if (!c) return NULL;
+  int32_t device = 0; uint32_t slots = 8;
+  napi_get_value_int32(env, argv[1], &device);
+  void* zkey; size_t zkey_len;
+  NAPI_OK(napi_get_buffer_info(env, argv[2], &zkey, &zkey_len));
+  if (argc > 3) napi_get_value_uint32(env, argv[3], &slots);
+  zkwg_prover_t* pv = NULL;
+  int rc = zkwg_prover_create_zkey(c, device, (const uint8_t*)zkey, zkey_len, slots, &pv);
+  if (rc != ZKWG_RC_OK) { napi_throw_error(env, NULL, zkwg_strerror(rc)); return NULL; }
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, pv, prover_finalize, NULL, &ext));
+  return ext;
+}
 typedef struct {
   zkwg_prover_t* p; const uint8_t* in; const uint8_t* blinding; uint64_t n;
   int32_t* status; uint8_t* proofs; int rc;
@@ -538,6 +557,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"r1csLoad", NULL, R1csLoad, NULL, NULL, NULL, napi_default, NULL},
       {"r1csCheck", NULL, R1csCheck, NULL, NULL, NULL, napi_default, NULL},
       {"createProver", NULL, CreateProver, NULL, NULL, NULL, napi_default, NULL},
+      {"createProverZkey", NULL, CreateProverZkey, NULL, NULL, NULL, napi_default, NULL},
       {"proveBatch", NULL, ProveBatch, NULL, NULL, NULL, napi_default, NULL},
   };
   napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d);

@@ -133,6 +133,21 @@ class Prover:
         self._single = False
         self._h, self._slots_n = None, 0
 
+    @classmethod
+    def from_zkey(cls, circuit, zkey, slots=8):
+        """the prover from the zkey alone, as `groth16.prove(zkey, wtns)` takes it (include/zkwg.h zkwg_prover_create_zkey): rows of A and B
+        from section 4, C.w = A.w o B.w, bases from sections 5-9.  prove_batch / prove_records only (the stage-by-stage Python path needs
+        the key's bases as tensors: ProvingKey)."""
+        self = object.__new__(cls)
+        self.c, self.key, self.lib = circuit, None, _lib.load()
+        self._zkey = bytes(zkey)
+        self._single, self.last_sums = False, None
+        h = C.c_void_p()
+        _check(self.lib.zkwg_prover_create_zkey(circuit.h, circuit.device, self._zkey, len(self._zkey), slots, C.byref(h)))
+        self._h, self._slots_n = h, slots
+        self.m = circuit.abc_bytes // 96
+        return self
+
     def __del__(self):
         if getattr(self, "_h", None):
             self.lib.zkwg_prover_destroy(self._h)
@@ -191,6 +206,11 @@ class Prover:
         if self._h is not None:
             self.lib.zkwg_prover_destroy(self._h)
             self._h = None
+        if self.key is None:                        # made from a zkey: the same entry point again, with more proofs in flight
+            h = C.c_void_p()
+            _check(self.lib.zkwg_prover_create_zkey(self.c.h, self.c.device, self._zkey, len(self._zkey), slots, C.byref(h)))
+            self._h, self._slots_n = h, slots
+            return h
         k = self.key
         ks = _KeyStruct(k.n_wires, k.n_public, k.power, k.d_a.data_ptr(), k.d_b1.data_ptr(), k.d_b2.data_ptr(), k.d_c.data_ptr(), k.d_h.data_ptr(), 1)
         for name, size in (("alpha1", 64), ("beta1", 64), ("beta2", 128), ("delta1", 64), ("delta2", 128)):
