@@ -11,8 +11,8 @@
 //          256 VGPRs + 1,168 bytes of scratch, occupancy 1.  On the host (CPU mirror of the kernels) an element is
 //          the pair itself and the same dot products run for both halves, so the CPU tests execute the device's arithmetic and its bounds.
 //
-// Bounds (notation of zkwg_fq29.h: [U, V] = limbs < U 2^29, value < V q).  Stored accumulators: X = [1, 11], Y = [YU, 7] (YU = 3 for
-// G1 -- an unnormalised difference of two products is a legal left operand --, 1 for G2), ZZ, ZZZ = [1, 2]; ZZ = 0 (all limbs) = infinity.
+// Bounds (notation of zkwg_fq29.h: [U, V] = limbs < U 2^29, value < V q).  Stored accumulators: X = [1, 11], Y = [1, 7] (G1: [1, 2] --
+// Y3 = R (Q - X3) - Y1 PPP is ONE two-product dot product there, its result normalised), ZZ, ZZZ = [1, 2]; ZZ = 0 (all limbs) = infinity.
 // Bases: canonical words in 2^261-Montgomery form, [1, 1].  The bound of every intermediate is written beside it; `mul<VB>` names the
 // value bound of its RIGHT operand (G2's even lane needs a multiple of q above it to negate the partner's half); the host build counts
 // violated preconditions (ZKWG_FQ29_CHECK).
@@ -24,15 +24,15 @@
 // ---- Fq: one lane per element ----------------------------------------------------------------------------------------------------------
 struct ZkF1 {
   typedef Fq29 E;
-  static constexpr int YU = 3;
   template <int VB> static ZK_HD E mul(const E& a, const E& b) { return fq29_mul(a, b); }
+  template <int VA> static ZK_HD E sqr(const E& a) { return fq29_sqr(a); }
+  // a b - c d with ONE reduction: d = [1, <= VD], Ua Ub + 2 Uc <= 6; the result is normalised
+  template <int VB, int VD> static ZK_HD E msub(const E& a, const E& b, const E& c, const E& d) { return fq29_dot2(a, b, c, fq29_neg<VD + 1, 1>(d)); }
   static ZK_HD E scale(const E& a, const Fq29& k) { return fq29_mul(a, k); }
   static ZK_HD E add(const E& a, const E& b) { return fq29_add(a, b); }
   static ZK_HD E dbl(const E& a) { return fq29_dbl(a); }
   template <int M, int U> static ZK_HD E sub(const E& a, const E& b) { return fq29_sub<M, U>(a, b); }
   static ZK_HD E norm(const E& a) { return fq29_norm(a); }
-  static ZK_HD E prep_b(const E& a) { return a; }                    // a right operand of [3, *] is fine beside a [1, *] left one
-  static ZK_HD E store_y(const E& a) { return a; }
   static ZK_HD E zero() { return fq29_zero(); }
   static ZK_HD E one() { return fq29_one(); }
   static ZK_HD bool all_zero(const E& a) { return fq29_all_zero(a); }
@@ -51,7 +51,6 @@ __device__ __forceinline__ Fq29 zk_pair_xchg(const Fq29& a) {
 }
 struct ZkF2 {
   typedef Fq29 E;                       // this lane's half: c0 on even lanes, c1 on odd lanes
-  static constexpr int YU = 1;
   static __device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
   template <int VB> static __device__ __forceinline__ E mul(const E& a, const E& b) {
     const Fq29 oa = zk_pair_xchg(a), ob = zk_pair_xchg(b);
@@ -62,13 +61,15 @@ struct ZkF2 {
     for (int i = 0; i < 9; ++i) { S.l[i] = o ? ob.l[i] : b.l[i]; T.l[i] = o ? b.l[i] : nb.l[i]; }
     return fq29_dot2(a, S, oa, T);      // even: a0 b0 + a1 (-b1); odd: a1 b0 + a0 b1
   }
+  template <int VA> static __device__ __forceinline__ E sqr(const E& a) { return mul<VA>(a, a); }
+  template <int VB, int VD> static __device__ __forceinline__ E msub(const E& a, const E& b, const E& c, const E& d) {
+    return fq29_norm(fq29_sub<3, 1>(mul<VB>(a, fq29_norm(b)), mul<VD>(c, d)));       // (c d < 2 q at every call site; two reductions: a four-product dot product per lane would save one)
+  }
   static __device__ __forceinline__ E scale(const E& a, const Fq29& k) { return fq29_mul(a, k); }
   static __device__ __forceinline__ E add(const E& a, const E& b) { return fq29_add(a, b); }
   static __device__ __forceinline__ E dbl(const E& a) { return fq29_dbl(a); }
   template <int M, int U> static __device__ __forceinline__ E sub(const E& a, const E& b) { return fq29_sub<M, U>(a, b); }
   static __device__ __forceinline__ E norm(const E& a) { return fq29_norm(a); }
-  static __device__ __forceinline__ E prep_b(const E& a) { return fq29_norm(a); }
-  static __device__ __forceinline__ E store_y(const E& a) { return fq29_norm(a); }
   static __device__ __forceinline__ E zero() { return fq29_zero(); }
   static __device__ __forceinline__ E one() { return odd() ? fq29_zero() : fq29_one(); }
   static __device__ __forceinline__ bool both(bool mine) { const u32 other = zk_pair_xchg(mine ? 1u : 0u); return mine & (other != 0); }
@@ -80,17 +81,16 @@ struct ZkF2 {
 struct Fq29x2 { Fq29 c[2]; };
 struct ZkF2 {
   typedef Fq29x2 E;
-  static constexpr int YU = 1;
   template <int VB> static inline E mul(const E& a, const E& b) {
     return E{{fq29_dot2(a.c[0], b.c[0], a.c[1], fq29_neg<VB + 1, 1>(b.c[1])), fq29_dot2(a.c[1], b.c[0], a.c[0], b.c[1])}};
   }
+  template <int VA> static inline E sqr(const E& a) { return mul<VA>(a, a); }
+  template <int VB, int VD> static inline E msub(const E& a, const E& b, const E& c, const E& d) { return norm(sub<3, 1>(mul<VB>(a, norm(b)), mul<VD>(c, d))); }
   static inline E scale(const E& a, const Fq29& k) { return E{{fq29_mul(a.c[0], k), fq29_mul(a.c[1], k)}}; }
   static inline E add(const E& a, const E& b) { return E{{fq29_add(a.c[0], b.c[0]), fq29_add(a.c[1], b.c[1])}}; }
   static inline E dbl(const E& a) { return add(a, a); }
   template <int M, int U> static inline E sub(const E& a, const E& b) { return E{{fq29_sub<M, U>(a.c[0], b.c[0]), fq29_sub<M, U>(a.c[1], b.c[1])}}; }
   static inline E norm(const E& a) { return E{{fq29_norm(a.c[0]), fq29_norm(a.c[1])}}; }
-  static inline E prep_b(const E& a) { return norm(a); }
-  static inline E store_y(const E& a) { return norm(a); }
   static inline E zero() { return E{{fq29_zero(), fq29_zero()}}; }
   static inline E one() { return E{{fq29_one(), fq29_zero()}}; }
   static inline bool all_zero(const E& a) { return fq29_all_zero(a.c[0]) && fq29_all_zero(a.c[1]); }
@@ -101,7 +101,7 @@ struct ZkF2 {
 
 // ---- points ------------------------------------------------------------------------------------------------------------------------------
 template <class F> struct Aff29 { typename F::E x, y; bool inf; };          // [1, 1] each
-template <class F> struct alignas(16) Xyzz29 { typename F::E x, y, zz, zzz; };          // X [1, 11], Y [YU, 7], ZZ, ZZZ [1, 2]; ZZ all zero = infinity
+template <class F> struct alignas(16) Xyzz29 { typename F::E x, y, zz, zzz; };          // X [1, 11], Y [1, 7], ZZ, ZZZ [1, 2]; ZZ all zero = infinity
 
 template <class F> ZK_HD Xyzz29<F> ec29_inf() { return Xyzz29<F>{F::zero(), F::zero(), F::zero(), F::zero()}; }
 template <class F> ZK_HD bool ec29_is_inf(const Xyzz29<F>& p) { return F::all_zero(p.zz); }
@@ -114,18 +114,16 @@ ZK_HD Xyzz29<F> ec29_dbl_affine(const Aff29<F>& p) {
   if (p.inf) return ec29_inf<F>();
   if (F::template is_zero_mod<1>(p.y)) return ec29_inf<F>();      // (no point of order 2 on these curves; kept for completeness)
   const E U = F::norm(F::dbl(p.y));                               // [1, 2]
-  const E V = F::template mul<2>(U, U);                           // [1, 2]
+  const E V = F::template sqr<2>(U);                              // [1, 2]
   const E W = F::template mul<2>(U, V);                           // [1, 2]
   const E S = F::template mul<2>(p.x, V);                         // [1, 2]
-  const E X2 = F::template mul<1>(p.x, p.x);                      // [1, 2]
+  const E X2 = F::template sqr<1>(p.x);                           // [1, 2]
   const E M = F::norm(F::add(F::dbl(X2), X2));                    // [1, 6]
-  const E MM = F::template mul<6>(M, M);                          // [1, 2]
+  const E MM = F::template sqr<6>(M);                             // [1, 2]
   Xyzz29<F> r;
   r.x = F::norm(F::template sub<5, 2>(MM, F::dbl(S)));            // [1, 7]
-  const E T = F::prep_b(F::template sub<12, 1>(S, r.x));          // [3, 14]
-  const E M1 = F::template mul<14>(M, T);                         // [1, 3]
-  const E M2 = F::template mul<1>(W, p.y);                        // [1, 2]
-  r.y = F::store_y(F::template sub<3, 1>(M1, M2));                // [3, 6]
+  const E T = F::template sub<12, 1>(S, r.x);                     // [3, 14]
+  r.y = F::template msub<14, 1>(M, T, W, p.y);                    // [1, 7]
   r.zz = V; r.zzz = W;
   return r;
 }
@@ -135,23 +133,21 @@ ZK_HD Xyzz29<F> ec29_dbl(const Xyzz29<F>& p) {
   typedef typename F::E E;
   if (ec29_is_inf(p)) return p;
   const E U = F::norm(F::dbl(p.y));                               // [1, 14]
-  const E V = F::template mul<14>(U, U);                          // [1, 4]
+  const E V = F::template sqr<14>(U);                             // [1, 4]
   const E W = F::template mul<4>(U, V);                           // [1, 2]
   const E S = F::template mul<4>(p.x, V);                         // [1, 2]
-  const E X2 = F::template mul<11>(p.x, p.x);                     // [1, 3]
+  const E X2 = F::template sqr<11>(p.x);                          // [1, 3]
   const E M = F::norm(F::add(F::dbl(X2), X2));                    // [1, 9]
-  const E MM = F::template mul<9>(M, M);                          // [1, 3]
+  const E MM = F::template sqr<9>(M);                             // [1, 3]
   Xyzz29<F> r;
   r.x = F::norm(F::template sub<5, 2>(MM, F::dbl(S)));            // [1, 8]
-  const E T = F::prep_b(F::template sub<12, 1>(S, r.x));          // [3, 14]
-  const E M1 = F::template mul<14>(M, T);                         // [1, 3]
-  const E M2 = F::template mul<7>(W, p.y);                        // [1, 2]   (right operand [YU, 7])
-  r.y = F::store_y(F::template sub<3, 1>(M1, M2));                // [3, 6]
+  const E T = F::template sub<12, 1>(S, r.x);                     // [3, 14]
+  r.y = F::template msub<14, 7>(M, T, W, p.y);                    // [1, 7]
   r.zz = F::template mul<2>(V, p.zz);
   r.zzz = F::template mul<2>(W, p.zzz);
   return r;
 }
-// acc + P for an affine P: 8 M + 2 S and three carry normalisations
+// acc + P for an affine P: 7 M + 2 S + one two-product dot product, three carry normalisations
 template <class F>
 ZK_HD Xyzz29<F> ec29_add_mixed(const Xyzz29<F>& a, const Aff29<F>& p) {
   typedef typename F::E E;
@@ -159,25 +155,23 @@ ZK_HD Xyzz29<F> ec29_add_mixed(const Xyzz29<F>& a, const Aff29<F>& p) {
   if (ec29_is_inf(a)) return Xyzz29<F>{p.x, p.y, F::one(), F::one()};
   // (ordered so that an input dies as early as possible: x2, y2, then ZZ1, X1, ZZZ1, Y1 -- the kernels' register budget)
   const E P = F::norm(F::template sub<12, 1>(F::template mul<2>(p.x, a.zz), a.x));         // U2 [1, 2] - X1 -> [1, 14]
-  const E Rr = F::norm(F::template sub<8, F::YU>(F::template mul<2>(p.y, a.zzz), a.y));    // S2 [1, 2] - Y1 -> [1, 10]
+  const E Rr = F::norm(F::template sub<8, 1>(F::template mul<2>(p.y, a.zzz), a.y));        // S2 [1, 2] - Y1 -> [1, 10]
   if (F::template maybe_zero<14>(P)) {
     if (F::template is_zero_mod<14>(P)) return F::template is_zero_mod<10>(Rr) ? ec29_dbl_affine<F>(p) : ec29_inf<F>();
   }
   Xyzz29<F> r;
-  const E PP = F::template mul<14>(P, P);                         // [1, 4]
+  const E PP = F::template sqr<14>(P);                            // [1, 4]
   r.zz = F::template mul<4>(a.zz, PP);
   const E Q = F::template mul<4>(a.x, PP);                        // [1, 2]
   const E PPP = F::template mul<4>(P, PP);                        // [1, 2]
   r.zzz = F::template mul<2>(a.zzz, PPP);
-  const E M2 = F::template mul<2>(a.y, PPP);                      // [1, 2]   (left operand [YU, 7])
-  const E RR = F::template mul<10>(Rr, Rr);                       // [1, 3]
+  const E RR = F::template sqr<10>(Rr);                           // [1, 3]
   r.x = F::norm(F::template sub<5, 2>(F::template sub<3, 1>(RR, PPP), F::dbl(Q)));     // [6, 11] -> [1, 11]
-  const E T = F::prep_b(F::template sub<12, 1>(Q, r.x));          // [3, 14]
-  const E M1 = F::template mul<14>(Rr, T);                        // [1, 3]
-  r.y = F::store_y(F::template sub<3, 1>(M1, M2));                // [3, 6]
+  const E T = F::template sub<12, 1>(Q, r.x);                     // [3, 14]
+  r.y = F::template msub<14, 2>(Rr, T, a.y, PPP);                 // R (Q - X3) - Y1 PPP: [1, 7] (G1: [1, 2])
   return r;
 }
-// a + b: 12 M + 2 S
+// a + b: 11 M + 2 S + one two-product dot product
 template <class F>
 ZK_HD Xyzz29<F> ec29_add(const Xyzz29<F>& a, const Xyzz29<F>& b) {
   typedef typename F::E E;
@@ -191,17 +185,15 @@ ZK_HD Xyzz29<F> ec29_add(const Xyzz29<F>& a, const Xyzz29<F>& b) {
     if (F::template is_zero_mod<5>(P)) return F::template is_zero_mod<5>(Rr) ? ec29_dbl<F>(a) : ec29_inf<F>();
   }
   Xyzz29<F> r;
-  const E PP = F::template mul<5>(P, P);                          // [1, 2]
+  const E PP = F::template sqr<5>(P);                             // [1, 2]
   r.zz = F::template mul<2>(F::template mul<2>(a.zz, b.zz), PP);
   const E Q = F::template mul<2>(U1, PP);                         // [1, 2]
   const E PPP = F::template mul<2>(P, PP);                        // [1, 2]
   r.zzz = F::template mul<2>(F::template mul<2>(a.zzz, b.zzz), PPP);
-  const E M2 = F::template mul<2>(S1, PPP);                       // [1, 2]
-  const E RR = F::template mul<5>(Rr, Rr);                        // [1, 2]
+  const E RR = F::template sqr<5>(Rr);                            // [1, 2]
   r.x = F::norm(F::template sub<5, 2>(F::template sub<3, 1>(RR, PPP), F::dbl(Q)));     // [1, 10]
-  const E T = F::prep_b(F::template sub<12, 1>(Q, r.x));          // [3, 14]
-  const E M1 = F::template mul<14>(Rr, T);                        // [1, 2]
-  r.y = F::store_y(F::template sub<3, 1>(M1, M2));                // [3, 5]
+  const E T = F::template sub<12, 1>(Q, r.x);                     // [3, 14]
+  r.y = F::template msub<14, 2>(Rr, T, S1, PPP);                  // [1, 7]
   return r;
 }
 

@@ -4,12 +4,44 @@
 #include "zkwg_dev.h"
 #include "zkwg_msm_core.h"
 
-#define ZK_MSM_GRID 2048u      // workgroups per email of the grid-stride kernels (64 lanes each)
+#define ZK_MSM_GRID 16384u     // wavefronts per SERIES of the grid-stride kernels (shared by its emails; 1,024 SIMDs x 3 .. 8 wavefronts each)
 
+// One workgroup classifies ZK_CLS_ROWS x 256 scalars of one email: row j = the scalars base + 256 j + thread (coalesced).  A row's
+// members of list l get their ranks from a ballot; the 4 wavefronts x ROWS row counts are summed once per list, ONE global atomic per
+// list reserves the workgroup's places (one atomic per wavefront and list, all on the same two counters per email, made this kernel
+// 6 ms per 8 x 2^21 scalars -- profiles/r06/r06_d_msm_kernel_stats_wit21_e8_c13.csv -- where reading them takes 0.15 ms).
+#define ZK_CLS_ROWS 16u
 __global__ __launch_bounds__(256) void zk_msm_classify(ZkClassifyArgs A) {
-  const u32 e = blockIdx.y;
-  // whole wavefronts run every iteration: the appends are wavefront-collective
-  for (u32 i0 = blockIdx.x * 256u; i0 < A.n; i0 += gridDim.x * 256u) zk_msm_classify_thread(A, e, i0 + threadIdx.x);
+  __shared__ u32 cnt[6][4 * ZK_CLS_ROWS + 1];          // per list: counts of (row, wavefront), then their exclusive offsets; [..][64] = the workgroup's base
+  const u32 e = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nl = 2 * A.n_targets;
+  for (u32 base = blockIdx.x * (256u * ZK_CLS_ROWS); base < A.n; base += gridDim.x * (256u * ZK_CLS_ROWS)) {
+    u32 codes[ZK_CLS_ROWS];
+#pragma unroll
+    for (u32 j = 0; j < ZK_CLS_ROWS; ++j) codes[j] = zk_msm_classify_code(A, e, base + 256u * j + threadIdx.x);
+#pragma unroll
+    for (u32 j = 0; j < ZK_CLS_ROWS; ++j)
+      for (u32 l = 0; l < nl; ++l) {
+        const u64 m = __ballot((codes[j] >> l) & 1u);
+        if (lane == 0) cnt[l][4 * j + wave] = (u32)__builtin_popcountll(m);
+      }
+    __syncthreads();
+    if (threadIdx.x < nl) {
+      const u32 l = threadIdx.x;
+      u32 s = 0;
+      for (u32 q = 0; q < 4 * ZK_CLS_ROWS; ++q) { const u32 v = cnt[l][q]; cnt[l][q] = s; s += v; }
+      cnt[l][4 * ZK_CLS_ROWS] = s ? atomicAdd(zk_msm_classify_counter(A, e, l), s) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 j = 0; j < ZK_CLS_ROWS; ++j)
+      for (u32 l = 0; l < nl; ++l) {
+        const bool mine = (codes[j] >> l) & 1u;
+        const u64 m = __ballot(mine);
+        if (mine) zk_msm_classify_list(A, e, l)[cnt[l][4 * ZK_CLS_ROWS] + cnt[l][4 * j + wave] + (u32)__builtin_popcountll(m & ((1ull << lane) - 1ull))] =
+            base + 256u * j + threadIdx.x - A.t[l >> 1].first;
+      }
+    __syncthreads();
+  }
 }
 template <class C> __global__ __launch_bounds__(256) void zk_msm_count(ZkMsmArgsT<C> A) {
   const u32 e = blockIdx.y, len = A.sel_count(e);
@@ -106,8 +138,8 @@ static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
   else hipLaunchKernelGGL(zk_msm_scatter<C>, dim3(zk_grid(A.n, 256u, 4096u), E), dim3(256), 0, st, A);
   for (int level = 0; level < 3; ++level) {
     hipLaunchKernelGGL(zk_msm_slice_scan<C>, dim3(1, E), dim3(1024), 0, st, A, level);
-    if (level == 0) hipLaunchKernelGGL((zk_msm_slice_sum<C, true>), dim3(zk_grid(A.off.cap[level], per, ZK_MSM_GRID), E), dim3(64), 0, st, A, level);
-    else hipLaunchKernelGGL((zk_msm_slice_sum<C, false>), dim3(zk_grid(A.off.cap[level], per, ZK_MSM_GRID), E), dim3(64), 0, st, A, level);
+    if (level == 0) hipLaunchKernelGGL((zk_msm_slice_sum<C, true>), dim3(zk_grid(A.off.cap[level], per, (ZK_MSM_GRID + E - 1) / E), E), dim3(64), 0, st, A, level);
+    else hipLaunchKernelGGL((zk_msm_slice_sum<C, false>), dim3(zk_grid(A.off.cap[level], per, (ZK_MSM_GRID + E - 1) / E), E), dim3(64), 0, st, A, level);
   }
   hipLaunchKernelGGL(zk_msm_bucket_join<C>, dim3((total + per - 1) / per, E), dim3(64), 0, st, A);
   // sum_b (b + 1) bucket[b] by bit planes: level 0 into node_s, joins alternate node_a / node_s, one lane per window folds
@@ -123,11 +155,11 @@ static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
   u32 half = 0, in_second = 0;
   if (A.ones) {
     half = (A.n + ZK_MSM_ONES - 1) / ZK_MSM_ONES;
-    hipLaunchKernelGGL(zk_msm_ones<C>, dim3(zk_grid(half, per, ZK_MSM_GRID), E), dim3(64), 0, st, A, half, 0u);
+    hipLaunchKernelGGL(zk_msm_ones<C>, dim3(zk_grid(half, per, (ZK_MSM_GRID + E - 1) / E), E), dim3(64), 0, st, A, half, 0u);
     u32 m = half, level = 0;
     while (m > 1) {
       const u32 m2 = (m + ZK_MSM_JOIN - 1) / ZK_MSM_JOIN;
-      hipLaunchKernelGGL(zk_msm_tree<C>, dim3(zk_grid(m2, per, ZK_MSM_GRID), E), dim3(64), 0, st, A, half, level, in_second);
+      hipLaunchKernelGGL(zk_msm_tree<C>, dim3(zk_grid(m2, per, (ZK_MSM_GRID + E - 1) / E), E), dim3(64), 0, st, A, half, level, in_second);
       in_second ^= 1u; m = m2; ++level;
     }
   }
@@ -136,7 +168,7 @@ static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
 void zk_msm_launch_g1(const ZkMsmArgsT<ZkEcG1>& A, hipStream_t st) { zk_msm_launch_t<ZkEcG1>(A, st); }
 void zk_msm_launch_g2(const ZkMsmArgsT<ZkEcG2>& A, hipStream_t st) { zk_msm_launch_t<ZkEcG2>(A, st); }
 void zk_msm_classify_launch(const ZkClassifyArgs& A, hipStream_t st) {
-  hipLaunchKernelGGL(zk_msm_classify, dim3(zk_grid(A.n, 256u, 4096u), A.E), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(zk_msm_classify, dim3(zk_grid(A.n, 256u * ZK_CLS_ROWS, 4096u), A.E), dim3(256), 0, st, A);
 }
 
 // ---- tables: K shifted copies of the bases in 2^261 form (once per key), and the bases' infinity bits -----------------------------------

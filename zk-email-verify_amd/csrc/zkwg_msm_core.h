@@ -99,34 +99,28 @@ struct ZkClassifyArgs {
   u32 n, E, scalars_mont, ones_apart, n_targets;
   ZkClassifyTarget t[3];
 };
-// append `val` to a list when `pred`; every lane of the wavefront calls it (device: one atomic per wavefront, ranks from the ballot)
-ZK_HD void zk_msm_append(u32* counter, u32* list, bool pred, u32 val) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const u64 m = __ballot(pred);
-  if (m == 0) return;
-  const u32 lane = __lane_id(), leader = (u32)__builtin_ctzll(m);
-  u32 base = 0;
-  if (lane == leader) base = atomicAdd(counter, (u32)__builtin_popcountll(m));
-  base = (u32)__shfl((int)base, (int)leader);
-  if (pred) list[base + (u32)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = val;
-#else
-  if (pred) list[(*counter)++] = val;
-#endif
-}
-// scalar i of email e (every lane of a wavefront runs it, in range or not: the appends are wavefront-collective)
-ZK_HD void zk_msm_classify_thread(const ZkClassifyArgs& A, u32 e, u32 i) {
-  const bool in = i < A.n;
-  Fr k = fr_zero();
-  if (in) k = zk_msm_std(A.scalars[(u64)e * A.scalar_stride + i], A.scalars_mont);
-  const bool nz = in && !fr_is_zero(k);
-  const bool one = nz && A.ones_apart && zk_msm_is_one(k);
+// where scalar i of email e goes: bit 2 t = the ones' list of target t, bit 2 t + 1 = its list of other non-zero scalars
+ZK_HD u32 zk_msm_classify_code(const ZkClassifyArgs& A, u32 e, u32 i) {
+  if (i >= A.n) return 0;
+  const Fr k = zk_msm_std(A.scalars[(u64)e * A.scalar_stride + i], A.scalars_mont);
+  if (fr_is_zero(k)) return 0;
+  const bool one = A.ones_apart && zk_msm_is_one(k);
+  u32 code = 0;
   for (u32 t = 0; t < A.n_targets; ++t) {
     const ZkClassifyTarget& T = A.t[t];
     const u32 r = i - T.first;
-    const bool mine = nz && i >= T.first && r < T.n && !((T.inf[r >> 5] >> (r & 31u)) & 1u);
-    zk_msm_append(&T.n_ones[e], T.ones + (u64)e * T.list_stride, mine && one, r);
-    zk_msm_append(&T.n_sel[e], T.sel + (u64)e * T.list_stride, mine && !one, r);
+    if (i >= T.first && r < T.n && !((T.inf[r >> 5] >> (r & 31u)) & 1u)) code |= (one ? 1u : 2u) << (2 * t);
   }
+  return code;
+}
+// list l (= 2 t + which) of email e: counter and entries
+ZK_HD u32* zk_msm_classify_counter(const ZkClassifyArgs& A, u32 e, u32 l) { return (l & 1u ? A.t[l >> 1].n_sel : A.t[l >> 1].n_ones) + e; }
+ZK_HD u32* zk_msm_classify_list(const ZkClassifyArgs& A, u32 e, u32 l) { return (l & 1u ? A.t[l >> 1].sel : A.t[l >> 1].ones) + (u64)e * A.t[l >> 1].list_stride; }
+// the host mirror's form: one scalar at a time (the kernel reserves places per workgroup -- zkwg_kernels_msm.hip -- the lists are the same sets)
+ZK_HD void zk_msm_classify_thread(const ZkClassifyArgs& A, u32 e, u32 i) {
+  const u32 code = zk_msm_classify_code(A, e, i);
+  for (u32 l = 0; l < 2 * A.n_targets; ++l)
+    if ((code >> l) & 1u) { u32* cnt = zk_msm_classify_counter(A, e, l); zk_msm_classify_list(A, e, l)[ZK_MSM_ATOMIC_ADD(cnt, 1u)] = i - A.t[l >> 1].first; }
 }
 
 // ---- the ones' sum ---------------------------------------------------------------------------------------------------------------------
