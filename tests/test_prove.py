@@ -169,6 +169,58 @@ def test_gpu_proof_at_the_headline_circuit_verifies_under_the_pinned_verifier():
     _prove_case(1024, 1536, lambda c, n: synth.packed_batch(c, seed=5, n=n, body_len=1024)[0], n_emails=2, check_sums=False, slots=2)
 
 
+@pytest.mark.gpu
+def test_gpu_prover_from_the_zkey_alone_equals_the_r1cs_path():
+    """`groth16.prove(zkey, wtns)` takes the zkey and nothing else (fullProve(input, wasm, zkey), chunked-zkey.ts:80-84): the rows of A and B
+    come from its section 4, C.w = A.w o B.w.  A key written by zkey.write_zkey WITH that section -> zkwg_prover_create_zkey -> proofs
+    byte-identical (same r, s) to the ones of the .r1cs path, accepted by the pinned verifier; a tampered email gets no proof."""
+    import torch
+    import zkwg
+    from zkwg import prover, synth, zkey
+    from zkwg import r1cs as zr
+    N, M, n_public, n = 576, 192, 20, 3
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    sym = c.symbols()
+    cons = zr.email_verifier_constraints(sym, N, M)
+    full = zr.append_public_rows(cons, n_public)
+    key = G.setup(c.W, n_public, cons, seed=31)
+    pk = prover.ProvingKey.from_scalars(0, n_public, key.power, key.a_tau, key.b_tau, key.c_key[n_public + 1:], key.h_key, key.alpha, key.beta, key.delta)
+    down = lambda t: bytes(t.cpu().numpy())
+    pts = {"alpha1": pk.alpha1, "beta1": pk.beta1, "beta2": pk.beta2, "gamma2": _mont2(G2.mul(key.gamma, G2.G2)), "delta1": pk.delta1, "delta2": pk.delta2}
+    ic = b"".join(_mont1(G1.mul(x, G1.G)) for x in key.ic)
+    coeffs = [(m, j, w, v % R) for j, row in enumerate(full) for m in (0, 1) for w, v in row[m].items() if v % R]
+    zbytes = zkey.write_zkey(c.W, n_public, key.n, pts, ic, down(pk.d_a), down(pk.d_b1), down(pk.d_b2), down(pk.d_c), down(pk.d_h), coeffs)
+    del coeffs
+    recs, _ = synth.packed_batch(c, seed=8, n=n, body_len=100)
+    bad = bytearray(recs[:c.in_stride])
+    bad[c.lib.zkwg_input_offset(c.h, zkwg._lib.IN_SIGNATURE)] ^= 1
+    rng = random.Random(4)
+    bl = [(rng.randrange(R), rng.randrange(R)) for _ in range(n + 1)]
+    # the .r1cs path
+    data = zr.write_r1cs(len(sym), full, n_pub_out=3, n_pub_in=17, n_prv_in=N + 1 + 17 + 1 + 32 + M + 1)
+    st1, want = prover.Prover(c, data, len(full), pk).prove_records(recs + bytes(bad), bl, slots=4)
+    del pk
+    torch.cuda.empty_cache()
+    # the zkey alone, on a fresh handle
+    c2 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    pz = prover.Prover.from_zkey(c2, zbytes, slots=4)
+    assert c2.abc_bytes == 96 * len(full)
+    st2, got = pz.prove_records(recs + bytes(bad), bl, slots=4)
+    assert st1 == st2 == [0] * n + [4] and got == want and got[-1] is None
+    wit, _ = c2.calculate_batch_host(recs)
+    vk = G.vkey_json(key)
+    for e in range(n):
+        w = zkwg.witness_ints(wit[e * c2.witness_bytes:(e + 1) * c2.witness_bytes])
+        assert P.groth16_verify(vk, [str(w[i]) for i in range(1, n_public + 1)], prover.Prover.proof_json(got[e]))
+    # a file whose section 4 is missing or whose sizes are off is refused
+    z = zkey.read_zkey(zbytes)
+    h = C.c_void_p()
+    short = zkey.write_zkey(c.W, n_public, key.n, pts, ic, z["a"], z["b1"], z["b2"], z["c"], z["h"], [])
+    c3 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
+    assert c3.lib.zkwg_prover_create_zkey(c3.h, 0, short, len(short), 2, C.byref(h)) != 0
+    assert c3.lib.zkwg_prover_create_zkey(c3.h, 0, zbytes[:-100], len(zbytes) - 100, 2, C.byref(h)) != 0
+
+
 def test_zkey_round_trip():
     """zkwg.zkey: a groth16 .zkey written section by section reads back field by field (layout restated from snarkjs [EXT]; the day
     a real file exists it goes through the same reader)"""
@@ -192,9 +244,10 @@ def test_zkey_round_trip():
 
 @pytest.mark.gpu
 def test_gpu_node_host_proves_through_the_addon(tmp_path):
-    """the Node host (zk-email-verify_amd/js/prove.js -> zkwg.js Prover -> N-API addon -> zkwg_prover_prove_batch): input.json + a
-    .zkey written from a toy key + the layout's .r1cs -> proof.json / public signals that the pinned verifier accepts -- the whole
-    of `groth16.fullProve` (packages/helpers/src/chunked-zkey.ts:80-84) behind the reference's host language"""
+    """the Node host (zk-email-verify_amd/js/prove.js -> zkwg.js Prover(circuit, zkey) -> N-API addon -> zkwg_prover_create_zkey /
+    zkwg_prover_prove_batch): input.json + a .zkey written from a toy key, NOTHING else -> proof.json / public signals that the pinned
+    verifier accepts -- the whole of `groth16.fullProve(input, wasm, zkey)` (packages/helpers/src/chunked-zkey.ts:80-84) behind the
+    reference's host language"""
     import json
     import os
     import shutil
@@ -214,20 +267,21 @@ def test_gpu_node_host_proves_through_the_addon(tmp_path):
     cons = zr.email_verifier_constraints(sym, N, M)
     n_public = 20
     full = zr.append_public_rows(cons, n_public)
-    (tmp_path / "c.r1cs").write_bytes(zr.write_r1cs(len(sym), full, n_pub_out=3, n_pub_in=17, n_prv_in=N + 1 + 17 + 1 + 32 + M + 1))
     key = G.setup(c.W, n_public, cons, seed=21)
     pk = prover.ProvingKey.from_scalars(0, n_public, key.power, key.a_tau, key.b_tau, key.c_key[n_public + 1:], key.h_key, key.alpha, key.beta, key.delta)
     down = lambda t: bytes(t.cpu().numpy())
     pts = {"alpha1": pk.alpha1, "beta1": pk.beta1, "beta2": pk.beta2, "gamma2": _mont2(G2.mul(key.gamma, G2.G2)), "delta1": pk.delta1, "delta2": pk.delta2}
     ic = b"".join(_mont1(G1.mul(x, G1.G)) for x in key.ic)
-    (tmp_path / "c.zkey").write_bytes(zkey.write_zkey(c.W, n_public, key.n, pts, ic, down(pk.d_a), down(pk.d_b1), down(pk.d_b2), down(pk.d_c), down(pk.d_h)))
+    coeffs = [(m, j, w, v % R) for j, row in enumerate(full) for m in (0, 1) for w, v in row[m].items() if v % R]
+    (tmp_path / "c.zkey").write_bytes(zkey.write_zkey(c.W, n_public, key.n, pts, ic, down(pk.d_a), down(pk.d_b1), down(pk.d_b2), down(pk.d_c), down(pk.d_h), coeffs))
+    del coeffs
     del pk, c
     torch.cuda.empty_cache()
     bad = dict(kase["input"], signature=[str(int(kase["input"]["signature"][0]) ^ 1)] + list(kase["input"]["signature"][1:]))
     (tmp_path / "in.json").write_text(json.dumps([kase["input"], bad]))
     env = dict(os.environ)
     r = subprocess.run(["node", os.path.join(js, "prove.js"), f"EmailVerifier({N},{M},121,17,0,0,0,0)", str(tmp_path / "in.json"), str(tmp_path / "c.zkey"),
-                        str(tmp_path / "c.r1cs"), str(len(full)), str(tmp_path / "out.json")], capture_output=True, text=True, timeout=900, env=env)
+                        str(tmp_path / "out.json")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 1 and "1 proof(s), 1 failed email(s)" in r.stdout, r.stdout + r.stderr
     out = json.load(open(tmp_path / "out.json"))
     assert out[1]["status"] == 4 and out[1]["proof"] is None
