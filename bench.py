@@ -247,6 +247,86 @@ def pmc_traffic(args, tile, W):
     return write_b + fetch_b, src
 
 
+def prove_main(args, torch, dist, backend, dev, rank, world, local_rank):
+    """`bench.py --gpus N --prove 1`: proofs shard like witnesses (independent emails, contiguous ranges, no data-path
+    collective).  Rank r proves the emails [r pb, (r + 1) pb) of a job of N pb emails -- inputs and blinding are functions of the GLOBAL
+    email index, so the gathered proofs do not depend on N (`proofs_sha256`; tests/test_multi.py compares 1 rank with 2) -- and the only
+    exchange is the gather of status + proof (260 bytes per email) on rank 0, inside the timed region.  Every rank uploads the key once
+    (tables: ~11 GB at the headline circuit).  Reference call site: packages/helpers/src/chunked-zkey.ts:80-84."""
+    import hashlib
+    import random
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import bench_prove
+    from zkwg import shard, synth
+    N, M, pb = args.max_header, args.max_body, args.prove_batch
+    t0 = time.time()
+    c, pv, _, _, n_public, power, n_rows = bench_prove.make_prover(N, M, device=local_rank)
+    t_setup = time.time() - t0
+    lo = rank * pb
+    recs, _ = synth.packed_batch(c, seed=0x5A4B, n=pb, body_len=min(args.body_len, M - 80), first_index=lo)
+    rng = random.Random(0x5A4B)
+    blinding = [(rng.randrange(1, bench_prove_R()), rng.randrange(1, bench_prove_R())) for _ in range(pb * world)][lo:lo + pb]
+    d_in = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(dev)
+    d_status = torch.zeros(pb, dtype=torch.int32, device=dev)
+    d_scratch = torch.empty(c.scratch_bytes(pb), dtype=torch.uint8, device=dev)
+    state = {"table": None}
+
+    def step():
+        c.prepare_device(d_in, pb, d_status, d_scratch)
+        torch.cuda.synchronize()
+        st = d_status.tolist()
+        idx = [i for i in range(pb) if st[i] == 0]
+        proofs = pv.prove_batch_bytes(d_in, pb, d_scratch, idx, [blinding[i] for i in idx], slots=args.prove_slots)
+        rows = bytearray(260 * pb)
+        for i in range(pb):
+            rows[260 * i:260 * i + 4] = int(st[i]).to_bytes(4, "little", signed=True)
+        for k, i in enumerate(idx):
+            rows[260 * i + 4:260 * i + 260] = proofs[256 * k:256 * k + 256]
+        table = torch.frombuffer(rows, dtype=torch.uint8).view(pb, 260)
+        if dist is not None and backend == "nccl":
+            table = table.to(dev)
+        state["table"] = shard.gather_rows(dist, table, pb * world, rank, world) if dist is not None else table
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t1
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        tab = bytes(state["table"].cpu().numpy().tobytes())
+        bad = sum(1 for i in range(pb * world) if tab[260 * i:260 * i + 4] != bytes(4))
+        print(json.dumps({
+            "metric": "Groth16 proofs/s (inputs -> witness -> proof, EmailVerifier)", "value": round(pb * world * args.steps / dt, 2), "unit": "proofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Fr / Fq limbs)", "data": "synthetic",
+            "config": {"workload": f"EmailVerifier({N},{M},121,17,0,0,0,0) proofs, {pb} emails per GPU per step, {args.prove_slots} in flight per GPU",
+                       "W": c.W, "domain_log2": power, "rows": n_rows, "parallelism": f"shard{world}"},
+            "gathered_rows": pb * world, "nonzero_status": bad, "proofs_sha256": hashlib.sha256(tab).hexdigest(),
+            "emails_per_series": pv.lib.zkwg_prover_emails_per_series(pv._h), "contexts": pv.lib.zkwg_prover_contexts(pv._h),
+            "key_setup_s_per_rank": round(t_setup, 1), "backend": backend if dist is not None else None,
+            "note": "key from known discrete logarithms (tools/bench_prove.py: sums_verified there); the same key on every rank"}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+def bench_prove_R():
+    return 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,6 +369,12 @@ def main():
                     help="2 (default): the output ring is mapped from 1 GiB physical chunks (zkwg_device_alloc_chunked); 1: round 4's way -- "
                          "spare candidate tiles from hipMalloc, zk_expand timed into each, the fastest kept; 0: two plain allocations")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--prove", type=int, default=0,
+                    help="1: the workload is groth16.prove -- every rank proves --prove-batch emails per step (its shard of the job: inputs -> "
+                         "witness -> A.w|B.w|C.w -> H evaluations -> five multi-exponentiations -> proof) and rank 0 gathers status + proof "
+                         "(260 bytes per email) inside the timed region; the key is uploaded once per device")
+    ap.add_argument("--prove-batch", type=int, default=48, help="with --prove: emails per GPU per step")
+    ap.add_argument("--prove-slots", type=int, default=24, help="with --prove: proofs in flight per GPU")
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous (gloo, no GPU needed): every rank joins, rank 0 prints {\"launch_check\": world} -- the "
                          "CPU test of the self-launch below")
@@ -336,6 +422,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    if args.prove:
+        return prove_main(args, torch, dist, backend, dev, rank, world, local_rank)
 
     c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank,
                      remove_soft_line_breaks=args.remove_soft_line_breaks, regex=args.regex)

@@ -140,6 +140,11 @@ def test_bench_launches_its_own_ranks_without_torchrun(world):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     assert json.loads(line) == {"launch_check": world, "rank_sum": world * (world + 1) // 2, "local_rank_env": 0}
+    # the proving workload launches the same way (the flags travel through the self-launch)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--prove", "1", "--prove-batch", "6", "--launch-check"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["launch_check"] == world
     if world != 2:
         return
     # a launcher whose world size disagrees with --gpus is still refused, with a message that says what to do
@@ -171,6 +176,29 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert res["value"] > 0
     assert res["gathered_table"] == {"rows": 1024, "status_nonzero": 0, "rows_with_outputs": 1024}
     assert "2 wtns/rank/step gathered" in res["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_proofs_shard_across_ranks_and_equal_the_single_rank_ones():
+    """`bench.py --gpus 2 --prove 1`: proofs shard like witnesses -- rank r proves its contiguous range of the job, every
+    rank uploads the key once, rank 0 gathers status + proof rows.  Two ranks forced onto cuda:0 (gloo) with 2 emails each give the SAME
+    gathered rows (sha256) as one rank with 4: inputs and blinding are functions of the global email index."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--prove", "1", "--max-header", "576", "--max-body", "192", "--body-len", "100", "--steps", "1",
+            "--warmup", "0", "--prove-slots", "2"]
+    out = {}
+    for world, pb in ((1, 4), (2, 2)):
+        e = dict(env)
+        if world > 1:
+            e.update(ZKWG_BENCH_FORCE_DEVICE="0", ZKWG_BENCH_BACKEND="gloo")
+        r = subprocess.run(base + ["--gpus", str(world), "--prove-batch", str(pb)], cwd=ROOT, env=e, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[world] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for world in (1, 2):
+        assert out[world]["n_gpus"] == world and out[world]["gathered_rows"] == 4 and out[world]["nonzero_status"] == 0 and out[world]["value"] > 0
+    assert out[1]["proofs_sha256"] == out[2]["proofs_sha256"]
 
 
 @pytest.mark.gpu

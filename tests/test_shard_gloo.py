@@ -35,6 +35,13 @@ def _worker(rank, world, port, n_total, q):
     allw = shard.gather_witnesses(dist, wt, rank, world, chunk_bytes=256)
     got = []
     shard.gather_witnesses(dist, wt, rank, world, chunk_bytes=512, sink=lambda r, off, t: got.append((r, off, t.clone())))
+    # the prover's rows (status + 256-byte proof per email) through gather_rows: ragged shards, order by global index
+    prow = torch.tensor([[(i * 13 + j) % 249 for j in range(260)] for i in range(lo, hi)], dtype=torch.uint8).view(n, 260)
+    allp = shard.gather_rows(dist, prow, n_total, rank, world)
+    if rank == 0:
+        assert allp.shape == (n_total, 260) and all(allp[i].tolist() == [(i * 13 + j) % 249 for j in range(260)] for i in range(n_total))
+    else:
+        assert allp is None
     if rank == 0:
         assert allw.shape == (world, 3000)
         for r in range(world):

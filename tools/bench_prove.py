@@ -22,6 +22,28 @@ PRODUCT_RATE = 139.0e9      # field products/s of the 9 x 29-bit product behind 
 LAZY_RATE = 162.9e9         # the same product without split / pack (zkwg_fq29.h's form), same measurement
 
 
+def make_prover(N, M, device=0, seed=1):
+    """circuit handle + prover over a key made from KNOWN discrete logarithms (4,096 distinct values repeated; the same key on every
+    rank that uses the same seed) -> (circuit, prover, pool, idx_of, n_public, power, n_rows)"""
+    import zkwg
+    from zkwg import prover
+    from zkwg import r1cs as zr
+    R = prover.R
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=device)
+    sym = c.symbols()
+    n_public = 20
+    full = zr.append_public_rows(zr.email_verifier_constraints(sym, N, M), n_public)
+    data = zr.write_r1cs(len(sym), full, n_pub_out=3, n_pub_in=17, n_prv_in=N + 1 + 17 + 1 + 32 + M + 1)
+    power = max(1, (len(full) - 1).bit_length())
+    rng = random.Random(seed)
+    pool = [rng.randrange(1, R) for _ in range(4096)]
+    idx_of = lambda i: (7 * i + 3) % 4096
+    rep = lambda k: [pool[idx_of(i)] for i in range(k)]
+    pk = prover.ProvingKey.from_scalars(device, n_public, power, rep(c.W), rep(c.W), rep(c.W - n_public - 1), rep(1 << power), 5, 7, 11)
+    pv = prover.Prover(c, data, len(full), pk)
+    return c, pv, pool, idx_of, n_public, power, len(full)
+
+
 def main(argv=None, quiet=False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-header", type=int, default=576)
@@ -38,18 +60,7 @@ def main(argv=None, quiet=False):
     N, M, n = args.max_header, args.max_body, args.emails
     R, Q = prover.R, prover.Q
     t0 = time.time()
-    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0)
-    sym = c.symbols()
-    n_public = 20
-    full = zr.append_public_rows(zr.email_verifier_constraints(sym, N, M), n_public)
-    data = zr.write_r1cs(len(sym), full, n_pub_out=3, n_pub_in=17, n_prv_in=N + 1 + 17 + 1 + 32 + M + 1)
-    power = max(1, (len(full) - 1).bit_length())
-    rng = random.Random(1)
-    pool = [rng.randrange(1, R) for _ in range(4096)]
-    idx_of = lambda i: (7 * i + 3) % 4096
-    rep = lambda k: [pool[idx_of(i)] for i in range(k)]
-    pk = prover.ProvingKey.from_scalars(0, n_public, power, rep(c.W), rep(c.W), rep(c.W - n_public - 1), rep(1 << power), 5, 7, 11)
-    pv = prover.Prover(c, data, len(full), pk)
+    c, pv, pool, idx_of, n_public, power, n_rows = make_prover(N, M)
     t_setup = time.time() - t0
     recs, _ = synth.packed_batch(c, seed=9, n=n, body_len=min(1024 if M >= 1536 else 100, M - 80))
     dev = torch.device("cuda", 0)
@@ -144,7 +155,7 @@ def main(argv=None, quiet=False):
              "msm_a": adds_w * 10, "msm_b1": adds_w * 10, "msm_c": adds_w * 10, "msm_b2_g2": adds_w * 30}
     frac = {k: round(prods[k] / (st[k + "_ms"] * 1e-3) / PRODUCT_RATE, 3) for k in prods}
     total_products = sum(prods.values())
-    out = {"circuit": f"EmailVerifier({N},{M},121,17,0,0,0,0)", "W": W, "constraints_with_public_rows": len(full), "domain_log2": power,
+    out = {"circuit": f"EmailVerifier({N},{M},121,17,0,0,0,0)", "W": W, "constraints_with_public_rows": n_rows, "domain_log2": power,
            "emails": n, "proofs_per_s": round(1 / per, 2), "ms_per_proof": round(per * 1e3, 2), "proofs_in_flight": args.slots, "contexts": n_ctx,
            "emails_per_series": E_series, "proofs_timed": args.proofs, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
            "one_at_a_time_ms_per_proof": round(per_single * 1e3, 2), "batched_equals_one_at_a_time": same,

@@ -229,6 +229,16 @@ class Prover:
             out.append({"pi_a": (i(o), i(o + 32)), "pi_b": ((i(o + 64), i(o + 96)), (i(o + 128), i(o + 160))), "pi_c": (i(o + 192), i(o + 224))})
         return out
 
+    def prove_batch_bytes(self, d_in, n, d_scratch, indices, blinding, slots=8):
+        """prove_batch without the conversion to integers: 256 bytes per proof (pi_a | pi_b | pi_c, standard form, little-endian)"""
+        h = self._native(slots)
+        idx = (C.c_uint64 * len(indices))(*indices)
+        bl = b"".join(int(r % R).to_bytes(32, "little") + int(s % R).to_bytes(32, "little") for r, s in blinding)
+        out = (C.c_uint8 * (256 * len(indices)))()
+        if indices:
+            _check(self.lib.zkwg_prover_prove_prepared(h, d_in.data_ptr(), n, d_scratch.data_ptr(), idx, len(indices), bl, out))
+        return bytes(out)
+
     def prove_batch(self, d_in, n, d_scratch, indices, blinding, slots=8):
         """proofs of the emails `indices` of a prepared batch (complete: synchronise the preparing stream first); blinding = [(r, s)] per
         email -> list of proof dicts (prove_prepared's form).  `slots` proofs are in flight: 1-3 contexts of ceil(slots / contexts) emails,

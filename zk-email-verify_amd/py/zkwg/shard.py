@@ -42,6 +42,20 @@ def gather_table(dist, local_table, n_total, rank, world):
     return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
 
 
+def gather_rows(dist, local_rows, n_total, rank, world):
+    """gather_table for rows of any width (uint8[n_local, width]): the prover's status + proof rows (4 + 256 bytes per email)"""
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    if world == 1:
+        return local_rows
+    pad = torch.zeros((max(sizes), local_rows.shape[1]), dtype=torch.uint8, device=local_rows.device)
+    pad[:local_rows.shape[0]] = local_rows
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([bufs[r][:sizes[r]] for r in range(world)], dim=0)
+
+
 def gather_witnesses(dist, local_wtns, rank, world, chunk_bytes=1 << 30, sink=None):
     """Optional bulk exchange (BASELINE.json config C4): gather `local_wtns`
     (uint8[k, witness_bytes], the same k on every rank) on rank 0 over RCCL/xGMI (gloo in the CPU tests), in
