@@ -30,7 +30,7 @@ def test_library_exports_the_transform_entry_points_and_refuses_without_a_device
     lib = _lib.load()
     h = C.c_void_p()
     assert lib.zkwg_ntt_create(-1, 12, C.byref(h)) == 0          # tables only (layout-only plan)
-    assert lib.zkwg_ntt_domain(h) == 4096 and lib.zkwg_ntt_work_bytes(h, 2) == 2 * 3 * 4096 * 32
+    assert lib.zkwg_ntt_domain(h) == 4096 and lib.zkwg_ntt_work_bytes(h, 2) == 2 * 3 * 4096 * 36     # limb form between the passes: 16 + 16 + 4 bytes per element
     assert lib.zkwg_ntt_transform_device(h, 256, 1, 0, None) == -3   # ZKWG_RC_NO_DEVICE: no CPU fallback
     lib.zkwg_ntt_destroy(h)
     assert lib.zkwg_ntt_create(-1, 1, C.byref(h)) != 0 and lib.zkwg_ntt_create(-1, 40, C.byref(h)) != 0
@@ -114,6 +114,79 @@ def test_h_evaluations_match_the_oracle(power, m):
             for k in [0, n - 1, rng.randrange(n)]:
                 want = (ntt.coset_eval_direct(a, power, k) * ntt.coset_eval_direct(b, power, k) - ntt.coset_eval_direct(c, power, k)) % ntt.P
                 assert got[e * n + k] == want, (e, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("power", [7, 14, 21])
+def test_transforms_hold_their_value_bounds_on_extreme_inputs(power):
+    """the butterflies keep values in limb form across the stages of a pass (round 6): every element r - 1 makes every sum path as large
+    as it can be (a DIF stage pair grows a value 4 x): fft of the constant r - 1 is (-n, 0, 0, ...), and the round trip returns the input;
+    alternating 0 / r - 1 does the same for the difference paths"""
+    import torch
+    import zkwg
+    from oracle.pyref import ntt
+    n = 1 << power
+    plan = zkwg.Ntt(power)
+    top = (ntt.P - 1) * R % ntt.P
+    raw = top.to_bytes(32, "little") * n + (bytes(32) + top.to_bytes(32, "little")) * (n // 2)
+    d = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to("cuda:0")
+    plan.transform_device(d, 2)
+    torch.cuda.synchronize()
+    got = d.cpu().numpy().tobytes()
+    val = lambda q, k: int.from_bytes(got[32 * (q * n + k):32 * (q * n + k) + 32], "little") * pow(R, ntt.P - 2, ntt.P) % ntt.P
+    assert val(0, 0) == (-n) % ntt.P and all(val(0, k) == 0 for k in (1, 2, n // 2, n - 1))
+    assert val(1, 0) == (-(n // 2)) % ntt.P and val(1, n // 2) == (n // 2) % ntt.P and val(1, 1) == 0 and val(1, n - 1) == 0
+    plan.transform_device(d, 2, inverse=True)
+    torch.cuda.synchronize()
+    assert d.cpu().numpy().tobytes() == raw
+
+
+@pytest.mark.gpu
+def test_h_evaluations_on_the_headline_domain():
+    """2^21 points, 1,814,506 rows (EmailVerifier(1024,1536)'s system with its public rows): three passes of seven stages per transform;
+    two emails, spot checks against the oracle's direct evaluation on the coset"""
+    import numpy as np
+    import torch
+    import zkwg
+    from oracle.pyref import ntt
+    power, m, emails = 21, 1814506, 2
+    n = 1 << power
+    rng = np.random.default_rng(21)
+    # small values (a witness is mostly bits) with a sprinkling of full-size ones: the direct evaluation stays affordable in Python
+    vals = rng.integers(0, 3, size=(emails, 3, m), dtype=np.int64)
+    big = {}
+    prng = random.Random(5)
+    for e in range(emails):
+        for j in range(3):
+            for i in prng.sample(range(m), 400):
+                big[(e, j, i)] = prng.randrange(ntt.P)
+    words = np.zeros((emails, 3 * m, 4), dtype="<u8")
+    r1, r2 = R % ntt.P, 2 * R % ntt.P
+    lut = np.array([[0, 0, 0, 0]] + [[(x >> (64 * k)) & (2 ** 64 - 1) for k in range(4)] for x in (r1, r2)], dtype="<u8")
+    words[:] = lut[vals.reshape(emails, 3 * m)]
+    for (e, j, i), v in big.items():
+        x = v * R % ntt.P
+        words[e, j * m + i] = [(x >> (64 * k)) & (2 ** 64 - 1) for k in range(4)]
+    d_abc = torch.from_numpy(words.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    plan = zkwg.Ntt(power)
+    d_work = torch.empty(plan.work_bytes(emails), dtype=torch.uint8, device="cuda:0")
+    d_out = torch.zeros(emails * 32 * n, dtype=torch.uint8, device="cuda:0")
+    plan.h_evaluations_device(d_abc, 96 * m, m, emails, d_work, d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().tobytes()
+    rinv = pow(R, ntt.P - 2, ntt.P)
+    for e in range(emails):
+        polys = []
+        for j in range(3):
+            p = [int(x) for x in vals[e, j]]
+            for (ee, jj, i), v in big.items():
+                if ee == e and jj == j:
+                    p[i] = v
+            polys.append(p)
+        for k in (0, n - 1 - 7 * e):
+            want = (ntt.coset_eval_direct(polys[0], power, k) * ntt.coset_eval_direct(polys[1], power, k) - ntt.coset_eval_direct(polys[2], power, k)) % ntt.P
+            o = 32 * (e * n + k)
+            assert int.from_bytes(got[o:o + 32], "little") * rinv % ntt.P == want, (e, k)
 
 
 @pytest.mark.gpu

@@ -85,3 +85,92 @@ ZK_HD Fr29 fr29_add(const Fr29& a, const Fr29& b) {
   for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
   return r;
 }
+
+// ---- what the transforms of zkwg_kernels_ntt.hip need on top (round 6): values stay in limb form across the butterfly stages of a pass.
+// Notation of zkwg_fq29.h: [U, V] = limbs 0 .. 7 < U 2^29, value < V r; the top limb l[8] is only bounded by the value (V <= 1,300:
+// l[8] < 2^32), a product with a canonical twiddle brings any such value back to < (V / 169 + 1) r.
+#define ZKR29_P(i) ((i) == 0 ? 0x10000001u : (i) == 1 ? 0x1f0fac9fu : (i) == 2 ? 0x0e5c2450u : (i) == 3 ? 0x07d090f3u : (i) == 4 ? 0x1585d283u : (i) == 5 ? 0x02db40c0u : (i) == 6 ? 0x00a6e141u : (i) == 7 ? 0x0e5c2634u : 0x0030644eu)
+ZK_HD Fr29 fr29_zero() { return Fr29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}; }
+// exact carry propagation: limbs 0 .. 7 < 2^29, the value unchanged
+ZK_HD Fr29 fr29_norm(const Fr29& a) {
+  Fr29 r;
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const u32 t = a.l[i] + c; r.l[i] = t & ZK29_M; c = t >> 29; }
+  r.l[8] = a.l[8] + c;
+  return r;
+}
+// M r written so that it dominates a [U, M - 1] value limb by limb (zkwg_fq29.h fq29_negc_make, with r's limbs)
+struct Fr29C { u32 l[9]; };
+template <int M, int U>
+constexpr Fr29C fr29_negc_make() {
+  u64 m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c = 0;
+  for (int i = 0; i < 9; ++i) { c += (u64)M * ZKR29_P(i); m[i] = i < 8 ? (c & ZK29_M) : c; c >>= 29; }
+  u64 bw = 0;
+  for (int i = 1; i < 9; ++i) {
+    const u64 sub = (u64)U + bw;
+    if (i < 8) { if (m[i] >= sub) { m[i] -= sub; bw = 0; } else { m[i] = m[i] + (1u << 29) - sub; bw = 1; } }
+    else m[i] -= sub;
+  }
+  Fr29C r{};
+  for (int i = 0; i < 9; ++i) r.l[i] = i < 8 ? (u32)(m[i] + ((u64)U << 29)) : (u32)m[8];
+  return r;
+}
+// a - b + M r for b = [U, <= M - 1]: [Ua + U + 1, Va + M]
+template <int M, int U>
+ZK_HD Fr29 fr29_sub(const Fr29& a, const Fr29& b) {
+  constexpr Fr29C c = fr29_negc_make<M, U>();
+  Fr29 r;
+  r.l[0] = a.l[0] + (c.l[0] - b.l[0]); r.l[1] = a.l[1] + (c.l[1] - b.l[1]); r.l[2] = a.l[2] + (c.l[2] - b.l[2]);
+  r.l[3] = a.l[3] + (c.l[3] - b.l[3]); r.l[4] = a.l[4] + (c.l[4] - b.l[4]); r.l[5] = a.l[5] + (c.l[5] - b.l[5]);
+  r.l[6] = a.l[6] + (c.l[6] - b.l[6]); r.l[7] = a.l[7] + (c.l[7] - b.l[7]); r.l[8] = a.l[8] + (c.l[8] - b.l[8]);
+  return r;
+}
+// any limb form with value < 2^256 packed into 4 x 64-bit words (NOT reduced: the work buffers of the transforms hold such words)
+ZK_HD Fr fr29_pack(const Fr29& x) {
+  const Fr29 t = fr29_norm(x);
+  u64 w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, k = bit >> 6, s = bit & 63;
+    w[k] |= (u64)t.l[i] << s;
+    if (s > 64 - 29 && k + 1 < 4) w[k + 1] |= (u64)t.l[i] >> (64 - s);
+  }
+  return Fr{{w[0], w[1], w[2], w[3]}};
+}
+// canonical words of a value < V r (V <= 63)
+template <int V>
+ZK_HD Fr fr29_to_fr_v(const Fr29& a) {
+  Fr29 n = fr29_norm(a);
+#pragma unroll
+  for (int s = 5; s >= 0; --s) {
+    if ((1 << s) >= V) continue;
+    // k r, k = 2^s, in plain limbs
+    Fr29 kp;
+    { u64 c = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { c += (u64)(1u << s) * ZKR29_P(i); kp.l[i] = i < 8 ? ((u32)c & ZK29_M) : (u32)c; c >>= 29; } }
+    bool ge = true;
+#pragma unroll
+    for (int i = 8; i >= 0; --i) {
+      if (n.l[i] != kp.l[i]) { ge = n.l[i] > kp.l[i]; break; }
+    }
+    if (ge) {
+      u32 bw = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const u32 t = n.l[i] - kp.l[i] - bw;
+        bw = i < 8 ? (t >> 31) : 0;
+        n.l[i] = i < 8 ? (t & ZK29_M) : t;
+      }
+    }
+  }
+  u64 w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, k = bit >> 6, s = bit & 63;
+    w[k] |= (u64)n.l[i] << s;
+    if (s > 64 - 29 && k + 1 < 4) w[k + 1] |= (u64)n.l[i] >> (64 - s);
+  }
+  return Fr{{w[0], w[1], w[2], w[3]}};
+}

@@ -6,18 +6,20 @@
 #include "../../include/zkwg.h"
 #include "zkwg_fr.h"
 
-extern "C" int zk_ntt_launch(int dit, const Fr* src, u64 src_es, u64 src_ps, u64 valid, Fr* work, const Fr* tw, const Fr* scale, const Fr* uni_host,
-                             u32 L, u32 n_polys, u32 inv, hipStream_t st);
-extern "C" int zk_ntt_join_launch(const Fr* work, Fr* out, u64 n, u64 out_es, u32 n_emails, hipStream_t st);
+extern "C" int zk_ntt_launch(int dit, const Fr* src, u64 src_es, u64 src_ps, u64 valid, int src_lazy, void* work, Fr* out, const Fr* tw, const Fr* scale,
+                             const Fr* uni_host, u32 L, u32 n_polys, u32 inv, hipStream_t st);
+extern "C" int zk_ntt_join_launch(const void* work, Fr* out, u64 n, u64 out_es, u32 n_emails, hipStream_t st);
 extern "C" int zk_ntt_bitrev_launch(Fr* data, u32 L, u32 n_polys, hipStream_t st);
 
 struct zkwg_ntt {
   int device;
   u32 L;
   u64 n;
-  Fr* d_tw;       // w^k, k < n, Montgomery form; w = Fr.w[L] of ffjavascript (nqr = 5)
-  Fr* d_scale;    // position p (bit-reversed coefficient index): inc^bitrev(p) / n, Montgomery form
-  Fr ninv_m;      // 1 / n, Montgomery form
+  // The tables are in 2^261-Montgomery form (canonical words): the kernels keep values in 9 x 29-bit limb form (zkwg_fr29.h), whose
+  // product divides by 2^261; the DATA stay in the callers' 2^256 form (one operand in 2^261 form is what a product needs).
+  Fr* d_tw;       // w^k, k < n; w = Fr.w[L] of ffjavascript (nqr = 5)
+  Fr* d_scale;    // position p (bit-reversed coefficient index): inc^bitrev(p) / n
+  Fr ninv_m;      // 1 / n
 };
 
 static Fr pow_m(Fr base_m, const u64 e[4]) {   // Montgomery in / out
@@ -54,6 +56,10 @@ int zkwg_ntt_create(int device, uint32_t log2_n, zkwg_ntt_t** out) {
     p->ninv_m = pow_m(fr_to_mont(fr_from_u64(p->n)), e2);
     acc = p->ninv_m;
     for (u64 i = 0; i < p->n; ++i) { sc[bitrev_host((u32)i, log2_n)] = acc; acc = fr_mont_mul(acc, inc); }
+    // 2^256 form -> 2^261 form: times 32
+    const Fr m32 = fr_to_mont(fr_from_u64(32));
+    for (u64 k = 0; k < p->n; ++k) { tw[k] = fr_mont_mul(tw[k], m32); sc[k] = fr_mont_mul(sc[k], m32); }
+    p->ninv_m = fr_mont_mul(p->ninv_m, m32);
     if (device >= 0) {
       if (hipSetDevice(device) != hipSuccess) { delete p; return ZKWG_RC_NO_DEVICE; }
       if (hipMalloc((void**)&p->d_tw, p->n * sizeof(Fr)) != hipSuccess || hipMalloc((void**)&p->d_scale, p->n * sizeof(Fr)) != hipSuccess ||
@@ -75,7 +81,8 @@ void zkwg_ntt_destroy(zkwg_ntt_t* p) {
   delete p;
 }
 uint64_t zkwg_ntt_domain(const zkwg_ntt_t* p) { return p ? p->n : 0; }
-uint64_t zkwg_ntt_work_bytes(const zkwg_ntt_t* p, uint64_t n_emails) { return p ? 3ull * p->n * 32ull * n_emails : 0; }
+// three polynomials per email in planar limb form: 16 + 16 + 4 bytes per element
+uint64_t zkwg_ntt_work_bytes(const zkwg_ntt_t* p, uint64_t n_emails) { return p ? 3ull * p->n * 36ull * n_emails : 0; }
 
 int zkwg_ntt_transform_device(zkwg_ntt_t* p, void* d_data, uint64_t n_polys, int inverse, void* hip_stream) {
   if (!p || !d_data) return ZKWG_RC_BAD_ARG;
@@ -85,15 +92,20 @@ int zkwg_ntt_transform_device(zkwg_ntt_t* p, void* d_data, uint64_t n_polys, int
   if (hipSetDevice(p->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   hipStream_t st = (hipStream_t)hip_stream;
   Fr* d = (Fr*)d_data;
+  // the passes run through a temporary limb-form buffer (this entry point is not the pipeline's: it allocates and synchronises)
+  void* work = nullptr;
+  if (hipMalloc(&work, 36ull * p->n * n_polys) != hipSuccess) { (void)hipGetLastError(); return ZKWG_RC_OOM; }
   int rc;
   if (inverse) {
     // natural -> (DIF, inverse roots, x 1 / n) -> bit-reversed -> permuted back to natural order
-    rc = zk_ntt_launch(0, d, 3 * p->n, p->n, p->n, d, p->d_tw, nullptr, &p->ninv_m, p->L, (u32)n_polys, 1u, st);
+    rc = zk_ntt_launch(0, d, 3 * p->n, p->n, p->n, 0, work, d, p->d_tw, nullptr, &p->ninv_m, p->L, (u32)n_polys, 1u, st);
     if (rc == 0) rc = zk_ntt_bitrev_launch(d, p->L, (u32)n_polys, st);
   } else {
     rc = zk_ntt_bitrev_launch(d, p->L, (u32)n_polys, st);
-    if (rc == 0) rc = zk_ntt_launch(1, d, 3 * p->n, p->n, p->n, d, p->d_tw, nullptr, nullptr, p->L, (u32)n_polys, 0u, st);
+    if (rc == 0) rc = zk_ntt_launch(1, d, 3 * p->n, p->n, p->n, 0, work, d, p->d_tw, nullptr, nullptr, p->L, (u32)n_polys, 0u, st);
   }
+  if (hipStreamSynchronize(st) != hipSuccess) rc = -1;
+  hipFree(work);
   return rc == 0 ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
 }
 
@@ -106,12 +118,12 @@ int zkwg_h_evaluations_device(zkwg_ntt_t* p, const void* d_abc, uint64_t abc_str
     return ZKWG_RC_BAD_ARG;
   if (hipSetDevice(p->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
   hipStream_t st = (hipStream_t)hip_stream;
-  Fr* work = (Fr*)d_work;
+  void* work = d_work;
   const u32 np = (u32)(3 * n_emails);
   // 3 inverse transforms per email straight from A.w | B.w | C.w (zero-padded to the domain), leaving the coset-shifted
   // coefficients inc^i a_i in bit-reversed order; 3 forward transforms from that order; a b - c
-  int rc = zk_ntt_launch(0, (const Fr*)d_abc, abc_stride / 32, n_constraints, n_constraints, work, p->d_tw, p->d_scale, nullptr, p->L, np, 1u, st);
-  if (rc == 0) rc = zk_ntt_launch(1, work, 3 * p->n, p->n, p->n, work, p->d_tw, nullptr, nullptr, p->L, np, 0u, st);
+  int rc = zk_ntt_launch(0, (const Fr*)d_abc, abc_stride / 32, n_constraints, n_constraints, 0, work, nullptr, p->d_tw, p->d_scale, nullptr, p->L, np, 1u, st);
+  if (rc == 0) rc = zk_ntt_launch(1, nullptr, 0, 0, p->n, 1, work, nullptr, p->d_tw, nullptr, nullptr, p->L, np, 0u, st);
   if (rc == 0) rc = zk_ntt_join_launch(work, (Fr*)d_out, p->n, out_stride / 32, (u32)n_emails, st);
   return rc == 0 ? ZKWG_RC_OK : ZKWG_RC_HIP_ERROR;
 }
