@@ -50,7 +50,7 @@ def _from_dev(t, mont=True):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("power", [2, 3, 6, 10, 11, 13, 19])
+@pytest.mark.parametrize("power", [2, 3, 6, 8, 9, 10, 11, 13, 19])
 def test_transforms_match_the_oracle(power):
     """Fr.fft / Fr.ifft (natural order in and out) for several polynomials at once: one row pass (<= 2^10), one and two column
     passes above; small domains against the O(n^2) transform, large ones at random output indices."""

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void zk_ntt_col(ZkNttBuf src, ZkNttBuf dst,   
                                                    const Fr* __restrict__ tw, u32 L, u32 lb, u32 g, u32 inv) {
   extern __shared__ uint4 lds4[];
   const u64 n = 1ull << L;
-  const u32 G = 1u << g, C = ZK_NTT_TILE >> g;
+  const u32 TILE = n < ZK_NTT_TILE ? (u32)n : ZK_NTT_TILE;      // (domains below 1,024 points: one workgroup, fewer columns)
+  const u32 G = 1u << g, C = TILE >> g;
   const ZkLds29 y = zk_lds29(lds4, G * C);                                           // [G][C] elements
   const ZkLds29 twl = zk_lds29(lds4 + zk_lds29_bytes(G * C) / 16u, G / 2u);          // w_G^k, k < G / 2 (direction applied)
   const u32 cols_per_block = 1u << (lb - g);
@@ -271,8 +272,8 @@ extern "C" int zk_ntt_launch(int dit, const Fr* src, u64 src_es, u64 src_ps, u64
     u32 lb = L;
     for (u32 i = 0; i < ng; ++i) {
       const u32 g = gs[i];
-      const size_t lds = zk_lds29_bytes(ZK_NTT_TILE) + zk_lds29_bytes((1u << g) / 2u);
-      hipLaunchKernelGGL((zk_ntt_col<false>), dim3((u32)(n / ZK_NTT_TILE), n_polys), dim3(256), lds, st, S, W, tw, L, lb, g, inv);
+      const size_t lds = zk_lds29_bytes(tile) + zk_lds29_bytes((1u << g) / 2u);
+      hipLaunchKernelGGL((zk_ntt_col<false>), dim3((u32)(n / tile), n_polys), dim3(256), lds, st, S, W, tw, L, lb, g, inv);
       S = W;
       lb -= g;
     }
@@ -283,8 +284,8 @@ extern "C" int zk_ntt_launch(int dit, const Fr* src, u64 src_es, u64 src_ps, u64
     for (u32 i = ng; i-- > 0;) {
       const u32 g = gs[i];
       lb += g;
-      const size_t lds = zk_lds29_bytes(ZK_NTT_TILE) + zk_lds29_bytes((1u << g) / 2u);
-      hipLaunchKernelGGL((zk_ntt_col<true>), dim3((u32)(n / ZK_NTT_TILE), n_polys), dim3(256), lds, st, W, (i == 0 && out) ? OUT : W, tw, L, lb, g, inv);
+      const size_t lds = zk_lds29_bytes(tile) + zk_lds29_bytes((1u << g) / 2u);
+      hipLaunchKernelGGL((zk_ntt_col<true>), dim3((u32)(n / tile), n_polys), dim3(256), lds, st, W, (i == 0 && out) ? OUT : W, tw, L, lb, g, inv);
     }
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
