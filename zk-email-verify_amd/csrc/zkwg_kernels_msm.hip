@@ -130,11 +130,7 @@ static void zk_msm_launch_t(const ZkMsmArgsT<C>& A, hipStream_t st) {
   const u32 total = A.KS * A.nb, E = A.E;
   for (u32 e = 0; e < E; ++e) hipMemsetAsync(A.count(e), 0, ((size_t)total + 1) * 4, st);
   const bool lds_sort = A.lds_sort && total <= ZK_MSM_LDS_BUCKETS;
-  // sorting workgroups per email: fewer, larger ones when several emails fill the chip anyway -- a workgroup's entries of one bucket are
-  // contiguous in `entry` (whole cache lines with 16 of them per bucket) and it spends one global atomic per bucket; at least 8 list
-  // entries per lane at full length
-  const u32 wg_cap = E >= 8 ? 64u : E >= 4 ? 128u : 256u;
-  const u32 n_wg = zk_grid(A.n, 8192u, wg_cap);
+  const u32 n_wg = zk_grid(A.n, 8192u, 256u);                 // at least 8 list entries per lane of a sorting workgroup at full length
   if (lds_sort) hipLaunchKernelGGL((zk_msm_sort_wg<C, false>), dim3(n_wg, E), dim3(1024), 0, st, A);
   else hipLaunchKernelGGL(zk_msm_count<C>, dim3(zk_grid(A.n, 256u, 4096u), E), dim3(256), 0, st, A);
   hipLaunchKernelGGL(zk_msm_scan<C>, dim3(1, E), dim3(1024), 0, st, A);
