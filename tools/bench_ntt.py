@@ -40,17 +40,18 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / args.reps
-    g_row = min(L, 10)
-    passes = (L - g_row + 7) // 8
+    passes = (L + 6) // 7 - 1                       # column passes (each closes / opens with one twiddle product per element)
     per_transform = n * L // 2 + passes * n
-    products = 6 * per_transform + 3 * n + n
-    peak = 263.0e9      # measured v_mad_u64_u32 issue rate / 128 (tools/mulbench.hip); the CIOS product itself sustains 95 G/s in a pure loop
+    products = 6 * per_transform + 3 * n + 2 * n    # + the coset scaling of the three inverse transforms + a b (x 2^266) of the join
+    peak = 263.0e9      # measured v_mad_u64_u32 issue rate / 128 (tools/mulbench.hip)
+    rate = 162.9e9      # the product the butterflies run since round 6: 9 x 29-bit limbs, values kept in limb form (zkwg_fr29.h), in a pure product loop (profiles/r05/r05_g_mulbench.txt); 139.0 G/s behind the 4 x 64-bit interface
     print(json.dumps({"stage": "H evaluations (3 ifft, coset shift, 3 fft, a b - c)", "log2_domain": L, "constraints": m, "emails": E,
                       "emails_per_s": round(E / sec, 1), "ms_per_email": round(sec / E * 1e3, 3),
                       "montgomery_products_per_email": products, "products_per_s": round(E * products / sec),
                       "issue_roofline_products_per_s": round(peak), "frac_of_issue_roofline": round(E * products / sec / peak, 4),
-                      "hbm_bytes_per_email": (2 * passes + 2) * 2 * 3 * 32 * n + 4 * 32 * n,
-                      "hbm_GBps": round(E * ((2 * passes + 2) * 2 * 3 * 32 * n + 4 * 32 * n) / sec / 1e9, 1)}))
+                      "frac_of_limb_form_product_rate": round(E * products / sec / rate, 4), "frac_of_139G": round(E * products / sec / 139.0e9, 4),
+                      "hbm_bytes_per_email": (2 * passes + 2) * 2 * 3 * 36 * n + 4 * 32 * n,
+                      "hbm_GBps": round(E * ((2 * passes + 2) * 2 * 3 * 36 * n + 4 * 32 * n) / sec / 1e9, 1)}))
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@
 #   rslb          removeSoftLineBreaks = 1 variant (rslb:<label> appends to <tag>_rslb_variants.json)      abc  tools/bench_abc.py      o0  tools/bench_full.py
 #   pmc:<tool.py> per-kernel HBM traffic of a tool (two rocprofv3 --pmc passes)
 #   prove[:<args>]  tools/bench_prove.py (appends one JSON line to <tag>_bench_prove.json)      provep[:<args>]  the same under rocprofv3 --kernel-trace --stats
-#   msm:<args>    tools/bench_msm.py      ntt[:<args>]  tools/bench_ntt.py      run:<command>  anything else (output tail -> <tag>_run.txt)
+#   msm:<args>    tools/bench_msm.py (msmp:<args> under rocprofv3)      ntt[:<args>]  tools/bench_ntt.py (nttp[:<args>] under rocprofv3)      run:<command>  anything else (output tail -> <tag>_run.txt)
 #   env:K=V       export K=V for the following steps
 TAG=$1; shift
 OUT=$PWD/gpurun_out; mkdir -p $OUT
@@ -98,6 +98,11 @@ PY
           S=$(find $OUT/${TAG}_mprof -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_msm_kernel_stats_$N.csv && head -24 $S | cut -c1-150
           rm -rf $OUT/${TAG}_mprof; tail -1 $OUT/${TAG}_msmp_$N.json ;;
     msm:*) timeout 600 python tools/bench_msm.py ${step#msm:} 2>&1 | tail -1 | tee -a $OUT/${TAG}_msm.json ;;
+    nttp|nttp:*) A=""; [ "$step" != nttp ] && A="${step#nttp:}"
+          ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_nprof -- \
+              python $REPO/tools/bench_ntt.py $A > $OUT/${TAG}_ntt_prof.json 2> $OUT/${TAG}_nprof.log )
+          S=$(find $OUT/${TAG}_nprof -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_ntt_kernel_stats.csv && head -10 $S | cut -c1-170
+          rm -rf $OUT/${TAG}_nprof; tail -1 $OUT/${TAG}_ntt_prof.json | cut -c1-600 ;;
     ntt) timeout 600 python tools/bench_ntt.py 2>&1 | tail -1 | tee -a $OUT/${TAG}_ntt.json | cut -c1-800 ;;
     ntt:*) timeout 600 python tools/bench_ntt.py ${step#ntt:} 2>&1 | tail -1 | tee -a $OUT/${TAG}_ntt.json | cut -c1-800 ;;
     run:*) timeout 1500 bash -c "${step#run:}" 2>&1 | tail -30 | tee -a $OUT/${TAG}_run.txt ;;
