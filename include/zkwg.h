@@ -443,7 +443,8 @@ int zkwg_device_free_chunked(void* ptr);
  * the sum for the n scalars at d_scalars, d_work = zkwg_msm_work_bytes bytes of scratch (256-byte aligned), and return the point as
  * the zkey would store it (affine, Montgomery form, 64 / 128 bytes; zeros = infinity).  ones_apart = 1 for witness scalars (mostly
  * 0 / 1: the bases with scalar 1 are summed by a plain reduction tree instead of all landing in one bucket).  Bucket method, signed
- * windows, XYZZ accumulators: DESIGN.md section 23.
+ * windows, XYZZ accumulators: DESIGN.md section 23.  Scalars must be CANONICAL (below the group order r; a Montgomery-form scalar is
+ * reduced by its conversion): the signed windows cover 255 bits, a value of 2^255 or more would lose its top carry.
  * zkwg_fixed_base_device: d_out[i] = scalar_i * G for the group's generator (G1: (1, 2); G2: the EIP-197 generator) -- how a key
  * with a KNOWN trapdoor becomes bases (tests, tools/bench_prove.py; a real key comes from its .zkey). */
 typedef struct zkwg_msm zkwg_msm_t;

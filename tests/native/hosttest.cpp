@@ -191,6 +191,12 @@ extern "C" {
 void ht_fq_mont_mul(const void* a, const void* b, void* out, int path32) {
   *(Fq*)out = path32 ? fq_mont_mul_32(*(const Fq*)a, *(const Fq*)b) : fq_mont_mul_64(*(const Fq*)a, *(const Fq*)b);
 }
+// the DEVICE's product since round 5 (zkwg_comba29.h: 9 x 29-bit product scanning behind the 4 x 64-bit interface) on raw limbs, for Fq
+// (field 0) and Fr (field 1): ADVICE r5 -- the host mirror ran the 64-bit CIOS only, so no CPU test executed the kernels' product
+void ht_comba_mont_mul(int field, const void* a, const void* b, void* out) {
+  if (field == 0) *(Fq*)out = fq_mont_mul_comba(*(const Fq*)a, *(const Fq*)b);
+  else *(Fr*)out = fr_mont_mul_comba(*(const Fr*)a, *(const Fr*)b);
+}
 void ht_fq_op(int op, const void* a, const void* b, void* out) {   // standard form in and out: 0 add, 1 sub, 2 mul, 3 inv, 4 neg
   const Fq x = fq_to_mont(*(const Fq*)a), y = fq_to_mont(*(const Fq*)b);
   Fq r = op == 0 ? fq_add(x, y) : op == 1 ? fq_sub(x, y) : op == 2 ? fq_mont_mul(x, y) : op == 3 ? fq_mont_inv(x) : fq_neg(x);

@@ -65,6 +65,25 @@ def test_fq_arithmetic_both_montgomery_paths():
             assert int.from_bytes(out.raw, "little") == pow(a, -1, Q)
 
 
+def test_the_devices_9x29_product_equals_the_64_bit_path_on_edge_and_random_operands():
+    """zkwg_comba29.h is every device fr_mont_mul / fq_mont_mul since round 5; here it runs on the host: canonical operands
+    incl. 0, 1, p - 1, the limb boundaries of both splittings (29-bit and the << 5 one), R, R^2, and random ones, both fields"""
+    lib = _lib()
+    lib.ht_comba_mont_mul.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+    out = C.create_string_buffer(32)
+    for field, p in ((0, Q), (1, R)):
+        rng = random.Random(29 + field)
+        rinv = pow(1 << 256, -1, p)
+        edge = [0, 1, 2, p - 1, p - 2, (1 << 256) % p, pow(1 << 256, 2, p), (1 << 253) % p, (1 << 232) - 1, 1 << 232, (1 << 224) - 1, 1 << 224]
+        edge += [(1 << (29 * i)) - 1 for i in range(1, 9)] + [1 << (29 * i) for i in range(1, 9)] + [((1 << (29 * i)) - 1) >> 5 for i in range(2, 9)]
+        edge += [p - (1 << (29 * i)) for i in range(1, 8)]
+        vals = [v % p for v in edge] + [rng.randrange(p) for _ in range(400)]
+        for i, a in enumerate(vals):
+            for b in (vals[(7 * i + 3) % len(vals)], vals[i], p - 1):
+                lib.ht_comba_mont_mul(field, _b(a), _b(b), out)
+                assert int.from_bytes(out.raw, "little") == a * b * rinv % p, (field, a, b)
+
+
 def test_g1_additions_with_every_special_case():
     lib = _lib()
     rng = random.Random(12)
