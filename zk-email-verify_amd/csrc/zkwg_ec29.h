@@ -216,6 +216,7 @@ struct ZkEcG1 {
   typedef G1Xyzz Out;
   static constexpr int LANES = 1;
   static constexpr int DEV_LANES = 1;      // lanes per point in the kernels (what the host sizes its launches with)
+  static constexpr bool PREFETCH = true;   // the slice / ones loops keep the next base in flight
   static ZK_HD Aff29<F> load(const Affine* p, u32 h, bool neg) {
     const Fq x = zk_ld_fq(&p->x), y = zk_ld_fq(&p->y);
     return Aff29<F>{fq29_from_fq(x), fq29_from_fq(zk_fq_neg_if(y, neg)), fq_is_zero(x) && fq_is_zero(y)};
@@ -231,6 +232,7 @@ struct ZkEcG2 {
   typedef G2Affine Affine;
   typedef G2Xyzz Out;
   static constexpr int DEV_LANES = 2;
+  static constexpr bool PREFETCH = false;
 #if defined(__HIP_DEVICE_COMPILE__)
   static constexpr int LANES = 2;
   static __device__ __forceinline__ Aff29<F> load(const Affine* p, u32 h, bool neg) {
