@@ -4,7 +4,8 @@
 // multiplier there: every inner step is one v_mad_u64_u32).  The two paths are plain functions of (a, b, modulus), compiled for
 // both sides, so the CPU tests run the device's 32-bit path as well (tests/test_g1_cpu.py).
 //
-// Status (round 4): host-verified building block of the next row; no kernel uses it yet.
+// Used by: the key tables and fixed-base multiples (zkwg_kernels_msm.hip zk_msm_table / zk_fixed_base), the proof assembly on the host
+// (zkwg_groth16_assemble) and the CPU tests' reference; the sums themselves run the limb form of zkwg_fq29.h since round 6.
 #pragma once
 #include "zkwg_fr.h"
 

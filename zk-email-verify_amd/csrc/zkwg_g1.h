@@ -12,7 +12,8 @@
 // runs exactly these steps with the functions a kernel will call (digit extraction, accumulate, running sum), so the CPU tests pin
 // the arithmetic and the edge cases (equal points, opposite points, infinity, zero and maximal digits) before any kernel exists.
 //
-// Status (round 4): host-verified building blocks of the next row; no kernel uses them yet.
+// Used by: zk_msm_table (K shifted copies of the bases, once per key), zk_fixed_base, zkwg_groth16_assemble / zkwg_msm_finish_host (host), the CPU
+// tests' reference.  The kernels of the sums run the same formulas over the lazy limb form (zkwg_ec29.h).
 #pragma once
 #include "zkwg_fq.h"
 #include <vector>

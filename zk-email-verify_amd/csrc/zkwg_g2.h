@@ -3,7 +3,8 @@
 // quadratic extension: an Fq2 product is 3 Fq products (Karatsuba), a square 2, so a mixed addition costs 8 x 3 + 2 x 2 = 28 Fq
 // products against G1's 10.  Layout as in the zkey: x.c0 | x.c1 | y.c0 | y.c1, Montgomery form, 128 bytes, zeros = infinity.
 //
-// Status (round 4): host-verified building block of the next row; no kernel uses it yet.
+// Used by: zk_msm_table / zk_fixed_base (once per key / tools: one lane per point, Fq2 products as function calls -- 400 bytes of scratch there) and
+// the host (proof assembly, tests).  The G2 sum itself runs on lane pairs in limb form (zkwg_ec29.h).
 #pragma once
 #include "zkwg_fq.h"
 
