@@ -99,6 +99,48 @@ def test_gpu_batched_msm_equals_one_at_a_time_and_the_oracle(n, E, c, mont, apar
     assert got[1] is None
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", [1, 2])
+def test_gpu_classic_layout_when_the_tables_do_not_fit(group):
+    """zkwg_msm_create_ex with a table budget too small for the K shifted copies: the plan keeps the classic layout (K bucket sets, the
+    windows combined by a Horner pass in limb form) -- what a prover falls back to beside full HBM -- and gives the same sums as the
+    precomputed-windows plan and the oracle, E emails per series, both groups"""
+    import ctypes as C
+    import torch
+    from oracle.pyref import bn254_g2 as H
+    from zkwg import _lib, prover
+    lib = _lib.load()
+    rng = random.Random(90 + group)
+    n, E, c = 900, 3, 7
+    ks = [rng.randrange(1, R) for _ in range(40)]
+    d_pts = prover.fixed_base(0, group, ks)
+    size = 64 if group == 1 else 128
+    raw = bytes(d_pts.cpu().numpy())
+    idx = [rng.randrange(40) for _ in range(n)]
+    d_b = torch.frombuffer(bytearray(b"".join(raw[size * j:size * j + size] for j in idx)), dtype=torch.uint8).to("cuda:0")
+    sc = [rng.choice([0, 1, 1, R - 1, rng.randrange(R), rng.randrange(256)]) for _ in range(n * E)]
+    d_s = torch.frombuffer(bytearray(b"".join(int(s).to_bytes(32, "little") for s in sc)), dtype=torch.uint8).to("cuda:0")
+    got = {}
+    for budget in (1, 0):
+        h = C.c_void_p()
+        assert lib.zkwg_msm_create_ex(0, group, d_b.data_ptr(), 1, n, c, 16, budget, C.byref(h)) == 0
+        assert lib.zkwg_msm_precomputed(h) == (0 if budget else 1)
+        d_w = torch.empty(lib.zkwg_msm_work_bytes_batch(h, E) + 256, dtype=torch.uint8, device="cuda:0")
+        d_w = d_w[(-d_w.data_ptr()) % 256:]
+        d_o = torch.empty((128 if group == 1 else 256) * E, dtype=torch.uint8, device="cuda:0")
+        for apart in (1, 0):
+            assert lib.zkwg_msm_enqueue_batch_device(h, d_s.data_ptr(), 32 * n, E, 0, apart, d_w.data_ptr(), d_o.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            pts = (C.c_uint8 * (size * E))()
+            assert lib.zkwg_msm_finish_host(group, bytes(d_o.cpu().numpy()), E, pts) == 0
+            got[(budget, apart)] = [prover.point_from_montgomery(bytes(pts)[size * e:size * e + size]) for e in range(E)]
+        lib.zkwg_msm_destroy(h)
+    gen = G.G if group == 1 else H.G2
+    mul = G.mul if group == 1 else H.mul
+    want = [mul(sum(s * ks[j] for s, j in zip(sc[e * n:(e + 1) * n], idx)) % R, gen) for e in range(E)]
+    assert all(v == want for v in got.values()), {k: v == want for k, v in got.items()}
+
+
 def test_library_exports_the_msm_entry_points_and_refuses_without_a_device():
     import ctypes as C
     import zkwg
