@@ -802,6 +802,7 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
                 "value": r["proofs_per_s"], "unit": "proofs/s", "proofs_in_flight": r["proofs_in_flight"], "contexts": r["contexts"],
                 "emails_per_series": r["emails_per_series"], "proofs_timed": r["proofs_timed"], "hw_queues": r.get("hw_queues"),
                 "one_at_a_time_ms_per_proof": r["one_at_a_time_ms_per_proof"], "sums_verified": r["sums_verified"],
+                "proof_equals_its_discrete_logarithms": r.get("proof_equals_its_discrete_logarithms"),
                 "batched_equals_one_at_a_time": r["batched_equals_one_at_a_time"],
                 "stages_ms_per_email_in_series": next(v for k, v in r.items() if k.startswith("stages_ms_per_email")), "stages_ms_one_email": r["stages_ms_one_email"],
                 "products_per_s_over_139G_by_stage": r["products_per_s_over_139G_by_stage"], "whole_proof_products_per_s_over_139G": r["whole_proof_products_per_s_over_139G"],
