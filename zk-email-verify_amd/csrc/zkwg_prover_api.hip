@@ -15,6 +15,7 @@
 // queues (round 5: one stream per proof, GPU_MAX_HW_QUEUES = 16 or half the rate).
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 #include "../../include/zkwg.h"
@@ -102,8 +103,14 @@ static int prover_new(zkwg_circuit_t* c, int device, uint64_t n_rows, const zkwg
   const uint64_t work_w = std::max(zkwg_msm_work_bytes(p->ma), std::max(zkwg_msm_work_bytes(p->mb1), zkwg_msm_work_bytes(p->mc)));
   p->ctx.resize(n_ctx);
   for (ZkProveCtx& s : p->ctx) {
-    bool ok = hipStreamCreateWithFlags(&s.st_h, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s.st_w, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&s.st_g, hipStreamNonBlocking) == hipSuccess;
+    // the witness-shaped sums are chains of short kernels (sort, slices, joins, plane folds) beside stream h's few long ones (transforms, the H sum's
+    // slices: 16 k wavefronts each): on higher-priority streams their wavefronts are placed first, so the chains do not queue behind the long kernels
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);           // (numerically lower = higher priority)
+    static const int use_prio = getenv("ZKWG_PROVER_PRIO") ? atoi(getenv("ZKWG_PROVER_PRIO")) : 1;
+    const int pw = use_prio ? prio_hi : prio_lo;
+    bool ok = hipStreamCreateWithPriority(&s.st_h, hipStreamNonBlocking, prio_lo) == hipSuccess && hipStreamCreateWithPriority(&s.st_w, hipStreamNonBlocking, pw) == hipSuccess &&
+              hipStreamCreateWithPriority(&s.st_g, hipStreamNonBlocking, pw) == hipSuccess;
     for (hipEvent_t* ev : {&s.ev_wit, &s.ev_lists, &s.ev_w, &s.ev_g, &s.ev_done}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&s.wit, E * wb) == hipSuccess && hipMalloc((void**)&s.abc, E * ab) == hipSuccess && hipMalloc((void**)&s.h, E * hb) == hipSuccess &&
          hipMalloc((void**)&s.ntt, ntt_b) == hipSuccess && hipMalloc((void**)&s.work_h, E * zkwg_msm_work_bytes(p->mh)) == hipSuccess &&
