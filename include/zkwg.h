@@ -478,6 +478,7 @@ int zkwg_msm_create_ex(int device, int group, const void* bases, int bases_on_de
                        zkwg_msm_t** out);
 uint64_t zkwg_msm_work_bytes_batch(const zkwg_msm_t* plan, uint64_t n_emails);
 uint64_t zkwg_msm_lists_bytes(const zkwg_msm_t* plan, uint64_t n_emails);
+uint64_t zkwg_msm_estimate_work_bytes(int group, uint64_t n, int window_bits, int slice0);   /* per email, before a plan exists */
 uint64_t zkwg_msm_table_bytes(const zkwg_msm_t* plan);
 int zkwg_msm_precomputed(const zkwg_msm_t* plan);
 int zkwg_msm_enqueue_batch_device(zkwg_msm_t* plan, const void* d_scalars, uint64_t scalar_stride, uint64_t n_emails, int scalars_montgomery, int ones_apart,

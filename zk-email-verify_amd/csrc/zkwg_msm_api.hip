@@ -159,6 +159,15 @@ void zkwg_msm_destroy(zkwg_msm_t* p) {
 // scratch of one email's sum / of E emails' sums (the generic entry points keep their own index lists behind the sums' arrays)
 uint64_t zkwg_msm_work_bytes_batch(const zkwg_msm_t* p, uint64_t n_emails) { return p && n_emails ? n_emails * msm_off(p).total + msm_lists(p, n_emails).total : 0; }
 uint64_t zkwg_msm_work_bytes(const zkwg_msm_t* p) { return zkwg_msm_work_bytes_batch(p, 1); }
+// the same figures before a plan exists (what a prover sets aside before it sizes its tables): per email, precomputed-windows layout
+uint64_t zkwg_msm_estimate_work_bytes(int group, uint64_t n, int window_bits, int slice0) {
+  if ((group != 1 && group != 2) || n == 0 || n >= (1ull << 31)) return 0;
+  zkwg_msm t;
+  t.group = group; t.n = n; t.precomp = true;
+  t.c = window_bits ? (u32)window_bits : (n >= (1u << 20) ? 16u : n >= (1u << 16) ? 13u : n >= (1u << 12) ? 10u : n >= 256 ? 7u : 4u);
+  t.K = zk_msm_windows(t.c); t.nb = 1u << (t.c - 1); t.s0 = slice0 ? (u32)slice0 : 16u;
+  return msm_off(&t).total + msm_lists(&t, 1).total;
+}
 uint64_t zkwg_msm_lists_bytes(const zkwg_msm_t* p, uint64_t n_emails) { return p && n_emails ? msm_lists(p, n_emails).total : 0; }
 uint64_t zkwg_msm_table_bytes(const zkwg_msm_t* p) { return p ? p->n * (p->group == 2 ? 128ull : 64ull) * (p->precomp ? p->K : 1u) : 0; }
 int zkwg_msm_window_bits(const zkwg_msm_t* p) { return p ? (int)p->c : 0; }

@@ -83,8 +83,9 @@ static int prover_new(zkwg_circuit_t* c, int device, uint64_t n_rows, const zkwg
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { free_b = 0; (void)hipGetLastError(); }
   int rc = zkwg_ntt_create(device, p->power, &p->ntt);
   const uint64_t ntt_b = rc == ZKWG_RC_OK ? zkwg_ntt_work_bytes(p->ntt, E) : 0;
-  // per email: entries 4 n K, level-0 partial sums, ... ~ (4 K + 9 K 2 / s0 * xs / 8) n: take the generous closed form 120 n (G1, s0 16), 200 n (G2), 40 n (H)
-  const uint64_t est_ctx = E * (wb + ab + hb + 120ull * W + 200ull * W + 40ull * n + 3 * 8ull * W) + ntt_b + (64ull << 20);
+  const int ww = W >= (1u << 16) ? 13 : 0, hs0 = n >= (1u << 18) ? 64 : 16;
+  const uint64_t est_ctx = E * (wb + ab + hb + zkwg_msm_estimate_work_bytes(1, W, ww, 16) + zkwg_msm_estimate_work_bytes(2, W, ww, 16) +
+                                zkwg_msm_estimate_work_bytes(1, n, 0, hs0) + 3 * 8ull * W) + ntt_b + (64ull << 20);
   const uint64_t reserve = n_ctx * est_ctx + (2ull << 30);
   uint64_t budget = free_b > reserve ? free_b - reserve : 1;      // (1: no room for copies -- classic layout everywhere)
   auto plan = [&](int group, const void* bases, uint64_t count, int window, int slice0, zkwg_msm_t** m) {
@@ -94,8 +95,7 @@ static int prover_new(zkwg_circuit_t* c, int device, uint64_t n_rows, const zkwg
   };
   // witness-shaped sums: a few ten thousand full-size scalars per email -> window 13 (4,096 buckets, ~ 170 entries each), slices of 16;
   // the H sum: 2^power full-size scalars -> window 16, slices of 64
-  const int ww = W >= (1u << 16) ? 13 : 0;
-  plan(1, key->h, n, 0, n >= (1u << 18) ? 64 : 16, &p->mh);
+  plan(1, key->h, n, 0, hs0, &p->mh);
   plan(2, key->b2, W, ww, 16, &p->mb2);
   plan(1, key->a, W, ww, 16, &p->ma); plan(1, key->b1, W, ww, 16, &p->mb1);
   plan(1, key->c, W - key->n_public - 1, ww, 16, &p->mc);
