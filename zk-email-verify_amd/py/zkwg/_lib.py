@@ -155,6 +155,7 @@ def load():
         "zkwg_msm_create_ex": (i32, [i32, i32, vp, i32, u64, i32, i32, u64, C.POINTER(vp)]),
         "zkwg_msm_work_bytes_batch": (u64, [vp, u64]),
         "zkwg_msm_lists_bytes": (u64, [vp, u64]),
+        "zkwg_msm_estimate_work_bytes": (u64, [i32, u64, i32, i32]),
         "zkwg_msm_table_bytes": (u64, [vp]),
         "zkwg_msm_precomputed": (i32, [vp]),
         "zkwg_msm_enqueue_batch_device": (i32, [vp, vp, u64, u64, i32, i32, vp, vp, vp]),
@@ -187,5 +188,5 @@ EXPORTS = [
     "zkwg_multi_circuit", "zkwg_calculate_batch_multi", "zkwg_calculate_batch_resident", "zkwg_resident_placement",
     "zkwg_ntt_create", "zkwg_ntt_destroy", "zkwg_ntt_domain", "zkwg_ntt_work_bytes", "zkwg_ntt_transform_device", "zkwg_h_evaluations_device",
     "zkwg_msm_create", "zkwg_msm_destroy", "zkwg_msm_work_bytes", "zkwg_msm_window_bits", "zkwg_msm_g1_device",
-    "zkwg_msm_g2_device", "zkwg_msm_create_g2", "zkwg_msm_create_device", "zkwg_msm_group", "zkwg_fixed_base_device", "zkwg_groth16_assemble", "zkwg_msm_enqueue_device", "zkwg_msm_finish_host", "zkwg_msm_create_ex", "zkwg_msm_work_bytes_batch", "zkwg_msm_lists_bytes", "zkwg_msm_table_bytes", "zkwg_msm_precomputed", "zkwg_msm_enqueue_batch_device", "zkwg_msm_classify_device", "zkwg_msm_enqueue_lists_device", "zkwg_prover_emails_per_series", "zkwg_prover_contexts", "zkwg_prover_create_zkey", "zkwg_prover_create", "zkwg_prover_destroy", "zkwg_prover_prove_prepared", "zkwg_prover_prove_batch", "zkwg_device_alloc_chunked", "zkwg_device_free_chunked", "zkwg_device_alloc_chunked_ex",
+    "zkwg_msm_g2_device", "zkwg_msm_create_g2", "zkwg_msm_create_device", "zkwg_msm_group", "zkwg_fixed_base_device", "zkwg_groth16_assemble", "zkwg_msm_enqueue_device", "zkwg_msm_finish_host", "zkwg_msm_create_ex", "zkwg_msm_work_bytes_batch", "zkwg_msm_lists_bytes", "zkwg_msm_estimate_work_bytes", "zkwg_msm_table_bytes", "zkwg_msm_precomputed", "zkwg_msm_enqueue_batch_device", "zkwg_msm_classify_device", "zkwg_msm_enqueue_lists_device", "zkwg_prover_emails_per_series", "zkwg_prover_contexts", "zkwg_prover_create_zkey", "zkwg_prover_create", "zkwg_prover_destroy", "zkwg_prover_prove_prepared", "zkwg_prover_prove_batch", "zkwg_device_alloc_chunked", "zkwg_device_free_chunked", "zkwg_device_alloc_chunked_ex",
 ]
