@@ -850,6 +850,25 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
             torch.cuda.empty_cache()
     except Exception as e:
         out["complete --O0 witnesses"] = {"error": repr(e)[:300]}
+    # the flag variant removeSoftLineBreaks = 1 (packages/circuits/helpers/remove-soft-line-breaks.circom:14-126): the one
+    # Fr-heavy block of the witness path (PoseidonModular over 2 maxBody bytes), whole batches prepared four deep
+    try:
+        cr = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank, remove_soft_line_breaks=1)
+        _, d_in, _ = resident_inputs(torch, cr, dev, 0x5A4B + 404, 64, 4096, args.body_len)
+        pl = Pipeline(torch, cr, dev, d_in, 4096, 256, 4096, ring=4, rsa_throttle=args.rsa_throttle)
+        cr.set_timing(True)
+        dt = timed(torch, pl.step, steps=6, warmup=2)
+        summ, avg, nl, gbs = expand_roofline(cr, 256)
+        cr.set_timing(False)
+        assert int(pl.d_status.abs().sum().item()) == 0
+        out["removeSoftLineBreaks = 1"] = {
+            "value": round(4096 * 6 / dt, 1), "unit": "witnesses/s", "steps": 6, "witness_len": cr.W, "zk_expand_GBps": round(gbs, 1),
+            "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4), "kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 3) for k, v in summ.items() if k.startswith("zk_rslb") or k == "zk_expand"},
+            "note": "target of three rounds: 50 k/s -- not reached (DESIGN.md section 12): the chunk hashes (multiplier-bound) and zk_expand (HBM-bound, but it decodes as it stores) share the SIMDs' issue slots"}
+        del pl, d_in, cr
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["removeSoftLineBreaks = 1"] = {"error": repr(e)[:300]}
     # configs[4]: maxBody = 65536 (SHA-dominated), batch 1024, bodies 32K..65K-72; fewer steps
     try:
         c5 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=1024, max_body=65536, device=local_rank)
