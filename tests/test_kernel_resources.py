@@ -82,8 +82,8 @@ def test_streaming_kernels_use_no_scratch_memory_and_keep_their_occupancy(tmp_pa
 def test_multi_exponentiation_kernels_use_no_scratch_memory(tmp_path):
     """every zk_msm_* kernel of the prover, G1 and G2 (the round-5 G2 kernels -- one lane per point, Fq2 products as
     function calls -- sat at 256 VGPRs + 1,168 bytes of scratch, occupancy 1).  Since round 6 G2 runs on lane pairs in lazy limb form:
-    no scratch anywhere, the kernels of the mixed additions (level-0 slices, the ones' sums) at 3 wavefronts per SIMD for both groups
-    (G2 gives up the prefetch of the next base for it: same measured rate, profiles/r06/r06_l).  zk_msm_table (once per key: K shifted copies of the bases, canonical-word arithmetic with
+    no scratch anywhere, the kernels of the mixed additions (level-0 slices, the ones' sums) at 4 wavefronts per SIMD for G1 and 3 for G2
+    (no software prefetch of the next base: same or better measured rate, profiles/r06/r06_l, r06_s).  zk_msm_table (once per key: K shifted copies of the bases, canonical-word arithmetic with
     one inversion per copy) is exempt."""
     info = _resource_usage("zkwg_kernels_msm.hip", tmp_path / "msm.o")
     ks = {n: v for n, v in info.items() if "zk_msm_" in n and "zk_msm_table" not in n}
@@ -93,6 +93,6 @@ def test_multi_exponentiation_kernels_use_no_scratch_memory(tmp_path):
     hot1 = [v for n, v in ks.items() if "ZkEcG1" in n and ("slice_sumI6ZkEcG1Lb1" in n or "zk_msm_onesI" in n)]
     hot2 = [v for n, v in ks.items() if "ZkEcG2" in n and ("slice_sumI6ZkEcG2Lb1" in n or "zk_msm_onesI" in n)]
     assert len(hot1) == 2 and len(hot2) == 2
-    assert all(v["Occupancy"] >= 3 for v in hot1), hot1
+    assert all(v["Occupancy"] >= 4 for v in hot1), hot1
     assert all(v["Occupancy"] >= 3 for v in hot2), hot2
     assert all(v["Occupancy"] >= 2 for n, v in ks.items()), ks

@@ -100,21 +100,22 @@ struct ZkF2 {
 #endif
 
 // ---- points ------------------------------------------------------------------------------------------------------------------------------
-template <class F> struct Aff29 { typename F::E x, y; bool inf; };          // [1, 1] each
+template <class F> struct Aff29 { typename F::E x, y; bool inf; };          // x [1, 1], y [2, 2] (the negated y of a negative digit is 2 q - y, unnormalised)
 template <class F> struct alignas(16) Xyzz29 { typename F::E x, y, zz, zzz; };          // X [1, 11], Y [1, 7], ZZ, ZZZ [1, 2]; ZZ all zero = infinity
 
 template <class F> ZK_HD Xyzz29<F> ec29_inf() { return Xyzz29<F>{F::zero(), F::zero(), F::zero(), F::zero()}; }
 template <class F> ZK_HD bool ec29_is_inf(const Xyzz29<F>& p) { return F::all_zero(p.zz); }
-template <class F> ZK_HD Xyzz29<F> ec29_from_affine(const Aff29<F>& p) { return p.inf ? ec29_inf<F>() : Xyzz29<F>{p.x, p.y, F::one(), F::one()}; }
+template <class F> ZK_HD Xyzz29<F> ec29_from_affine(const Aff29<F>& p) { return p.inf ? ec29_inf<F>() : Xyzz29<F>{p.x, F::norm(p.y), F::one(), F::one()}; }
 
 // 2 P for an affine P (the equal-points case of a mixed addition: rare, not tuned)
 template <class F>
 ZK_HD Xyzz29<F> ec29_dbl_affine(const Aff29<F>& p) {
   typedef typename F::E E;
   if (p.inf) return ec29_inf<F>();
-  if (F::template is_zero_mod<1>(p.y)) return ec29_inf<F>();      // (no point of order 2 on these curves; kept for completeness)
-  const E U = F::norm(F::dbl(p.y));                               // [1, 2]
-  const E V = F::template sqr<2>(U);                              // [1, 2]
+  const E py = F::norm(p.y);                                      // [1, 2]
+  if (F::template is_zero_mod<2>(py)) return ec29_inf<F>();       // (no point of order 2 on these curves; kept for completeness)
+  const E U = F::norm(F::dbl(py));                                // [1, 4]
+  const E V = F::template sqr<4>(U);                              // [1, 2]
   const E W = F::template mul<2>(U, V);                           // [1, 2]
   const E S = F::template mul<2>(p.x, V);                         // [1, 2]
   const E X2 = F::template sqr<1>(p.x);                           // [1, 2]
@@ -123,7 +124,7 @@ ZK_HD Xyzz29<F> ec29_dbl_affine(const Aff29<F>& p) {
   Xyzz29<F> r;
   r.x = F::norm(F::template sub<5, 2>(MM, F::dbl(S)));            // [1, 7]
   const E T = F::template sub<12, 1>(S, r.x);                     // [3, 14]
-  r.y = F::template msub<14, 1>(M, T, W, p.y);                    // [1, 7]
+  r.y = F::template msub<14, 2>(M, T, W, py);                     // [1, 7]
   r.zz = V; r.zzz = W;
   return r;
 }
@@ -152,7 +153,7 @@ template <class F>
 ZK_HD Xyzz29<F> ec29_add_mixed(const Xyzz29<F>& a, const Aff29<F>& p) {
   typedef typename F::E E;
   if (p.inf) return a;
-  if (ec29_is_inf(a)) return Xyzz29<F>{p.x, p.y, F::one(), F::one()};
+  if (ec29_is_inf(a)) return Xyzz29<F>{p.x, F::norm(p.y), F::one(), F::one()};
   // (ordered so that an input dies as early as possible: x2, y2, then ZZ1, X1, ZZZ1, Y1 -- the kernels' register budget)
   const E P = F::norm(F::template sub<12, 1>(F::template mul<2>(p.x, a.zz), a.x));         // U2 [1, 2] - X1 -> [1, 14]
   const E Rr = F::norm(F::template sub<8, 1>(F::template mul<2>(p.y, a.zzz), a.y));        // S2 [1, 2] - Y1 -> [1, 10]
@@ -200,7 +201,15 @@ ZK_HD Xyzz29<F> ec29_add(const Xyzz29<F>& a, const Xyzz29<F>& b) {
 // ---- the two groups as the kernels see them ------------------------------------------------------------------------------------------------
 // Affine: the memory form of a base (the zkey's layout; tables hold the 2^261 form), Out: the accumulator handed back to the host
 // (zkwg_g1.h / zkwg_g2.h XYZZ, 2^256 form), LANES: lanes per point, load / store per lane half h.
-ZK_HD Fq zk_fq_neg_if(const Fq& a, bool neg) { return neg ? fq_neg(a) : a; }
+// -y of a base for a negative digit, in limb form: 2 q - y without borrows (9 subtractions + 9 selects; the canonical-word negation was a
+// 256-bit compare-and-subtract in front of the split: 45 instructions and 12 wait states per addition).  y canonical -> [2, 2].
+ZK_HD Fq29 zk_q29_neg_if(const Fq29& y, bool neg) {
+  const Fq29 n = fq29_neg<2, 1>(y);
+  Fq29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = neg ? n.l[i] : y.l[i];
+  return r;
+}
 // one coordinate (32 bytes, 16-byte aligned: tables come from hipMalloc) as two 16-byte loads
 ZK_HD Fq zk_ld_fq(const Fq* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -216,10 +225,9 @@ struct ZkEcG1 {
   typedef G1Xyzz Out;
   static constexpr int LANES = 1;
   static constexpr int DEV_LANES = 1;      // lanes per point in the kernels (what the host sizes its launches with)
-  static constexpr bool PREFETCH = true;   // the slice / ones loops keep the next base in flight
   static ZK_HD Aff29<F> load(const Affine* p, u32 h, bool neg) {
     const Fq x = zk_ld_fq(&p->x), y = zk_ld_fq(&p->y);
-    return Aff29<F>{fq29_from_fq(x), fq29_from_fq(zk_fq_neg_if(y, neg)), fq_is_zero(x) && fq_is_zero(y)};
+    return Aff29<F>{fq29_from_fq(x), zk_q29_neg_if(fq29_from_fq(y), neg), fq_is_zero(x) && fq_is_zero(y)};
   }
   static ZK_HD void store_out(Out* o, const Xyzz29<F>& p, u32 h) {
     const Fq29 k = fq29_r256();
@@ -232,14 +240,13 @@ struct ZkEcG2 {
   typedef G2Affine Affine;
   typedef G2Xyzz Out;
   static constexpr int DEV_LANES = 2;
-  static constexpr bool PREFETCH = false;
 #if defined(__HIP_DEVICE_COMPILE__)
   static constexpr int LANES = 2;
   static __device__ __forceinline__ Aff29<F> load(const Affine* p, u32 h, bool neg) {
     const Fq* w = (const Fq*)p;                      // x.c0 | x.c1 | y.c0 | y.c1
     const Fq x = zk_ld_fq(w + h), y = zk_ld_fq(w + 2 + h);
     const bool z = F::both(fq_is_zero(x) && fq_is_zero(y));
-    return Aff29<F>{fq29_from_fq(x), fq29_from_fq(zk_fq_neg_if(y, neg)), z};
+    return Aff29<F>{fq29_from_fq(x), zk_q29_neg_if(fq29_from_fq(y), neg), z};
   }
   static __device__ __forceinline__ void store_out(Out* o, const Xyzz29<F>& p, u32 h) {
     const Fq29 k = fq29_r256();
@@ -251,7 +258,7 @@ struct ZkEcG2 {
   static constexpr int LANES = 1;
   static inline Aff29<F> load(const Affine* p, u32 h, bool neg) {
     const Affine a = *p;
-    return Aff29<F>{Fq29x2{{fq29_from_fq(a.x.c0), fq29_from_fq(a.x.c1)}}, Fq29x2{{fq29_from_fq(zk_fq_neg_if(a.y.c0, neg)), fq29_from_fq(zk_fq_neg_if(a.y.c1, neg))}}, g2_is_inf(a)};
+    return Aff29<F>{Fq29x2{{fq29_from_fq(a.x.c0), fq29_from_fq(a.x.c1)}}, Fq29x2{{zk_q29_neg_if(fq29_from_fq(a.y.c0), neg), zk_q29_neg_if(fq29_from_fq(a.y.c1), neg)}}, g2_is_inf(a)};
   }
   static inline void store_out(Out* o, const Xyzz29<F>& p, u32 h) {
     const Fq29 k = fq29_r256();

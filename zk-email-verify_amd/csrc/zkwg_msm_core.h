@@ -132,19 +132,10 @@ ZK_HD void zk_msm_ones_thread(const ZkMsmArgsT<C>& A, u32 e, u32 t, u32 h, typen
   if (t >= zk_msm_ones_parts(n1)) return;
   const u32 lo = t * ZK_MSM_ONES, hi = lo + ZK_MSM_ONES < n1 ? lo + ZK_MSM_ONES : n1;
   const u32* list = A.ones + (u64)e * A.list_stride;
-  // (G1: the next base is in flight while the current one is added; G2 keeps the 18 registers -- three wavefronts per SIMD hide the gather)
+  // (no software prefetch of the next base: it costs 18 registers and a copy per addition; four (G1) / three (G2) wavefronts per SIMD hide
+  // the gather -- measured both ways, profiles/r06/r06_l, r06_s)
   typename ZkMsmArgsT<C>::X acc = ec29_inf<typename C::F>();
-  if (C::PREFETCH) {
-    Aff29<typename C::F> nxt{C::F::zero(), C::F::zero(), true};
-    if (lo < hi) nxt = C::load(A.table + list[lo], h, false);
-    for (u32 j = lo; j < hi; ++j) {
-      const Aff29<typename C::F> cur = nxt;
-      if (j + 1 < hi) nxt = C::load(A.table + list[j + 1], h, false);
-      acc = ec29_add_mixed<typename C::F>(acc, cur);
-    }
-  } else {
-    for (u32 j = lo; j < hi; ++j) acc = ec29_add_mixed<typename C::F>(acc, C::load(A.table + list[j], h, false));
-  }
+  for (u32 j = lo; j < hi; ++j) acc = ec29_add_mixed<typename C::F>(acc, C::load(A.table + list[j], h, false));
   out[(u64)t * C::LANES + h] = acc;
 }
 // one join level: m_in partial sums -> ceil(m_in / JOIN); m_in follows from the email's list length and the level
@@ -290,26 +281,10 @@ ZK_HD void zk_msm_slice_sum_thread(const ZkMsmArgsT<C>& A, u32 e, int level, u32
   const u32 first = in[b] + j * S, last = first + S < in[b + 1] ? first + S : in[b + 1];
   X acc = ec29_inf<typename C::F>();
   if (LEVEL0) {
-    // (G1: the next base and the entry after it are in flight while the current base is added)
     const u32* ent = A.entry(e);
-    if (C::PREFETCH) {
-      if (first < last) {
-        u32 v1 = ent[first], v2 = first + 1 < last ? ent[first + 1] : 0u;
-        Aff29<typename C::F> nxt = C::load(A.table + (v1 & 0x7fffffffu), h, (v1 >> 31) != 0);
-        for (u32 k = first; k < last; ++k) {
-          const Aff29<typename C::F> cur = nxt;
-          if (k + 1 < last) {
-            nxt = C::load(A.table + (v2 & 0x7fffffffu), h, (v2 >> 31) != 0);
-            if (k + 2 < last) v2 = ent[k + 2];
-          }
-          acc = ec29_add_mixed<typename C::F>(acc, cur);
-        }
-      }
-    } else {
-      for (u32 k = first; k < last; ++k) {
-        const u32 v = ent[k];
-        acc = ec29_add_mixed<typename C::F>(acc, C::load(A.table + (v & 0x7fffffffu), h, (v >> 31) != 0));
-      }
+    for (u32 k = first; k < last; ++k) {
+      const u32 v = ent[k];
+      acc = ec29_add_mixed<typename C::F>(acc, C::load(A.table + (v & 0x7fffffffu), h, (v >> 31) != 0));
     }
   } else {
     const X* items = A.part(e, level - 1);
