@@ -688,22 +688,29 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
     # the device-resident pipeline BELOW the C-ABI (zkwg_calculate_batch_resident: what a Node host without torch drives, and what
     # zkwg_calculate_batch_multi runs on every GPU when no witness is asked back): records from host memory, statuses + result
     # table back, witnesses into the handle's own placed two-tile ring
+    ch = None
     try:
         n = args.batch
-        h_in, _, _ = resident_inputs(torch, c, dev, 0x5A4B + 909, 64, n, args.body_len)
+        # (its own handle: the ring and the scratch buffers of this entry point -- 2 x 29 GB + images -- live in the handle until it is
+        # destroyed, and the legs below need that memory: the removeSoftLineBreaks pipeline holds 4 x 45 GB of prepared batches)
+        ch = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank)
+        h_in, _, _ = resident_inputs(torch, ch, dev, 0x5A4B + 909, 64, n, args.body_len)
         recs = bytes(h_in.repeat((n + 63) // 64, 1)[:n].contiguous().numpy().tobytes())
-        st, _ = c.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)     # (allocates and places the ring)
+        st, _ = ch.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)     # (allocates and places the ring)
         assert not any(st)
         t0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            st, tb = c.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)
+            st, tb = ch.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)
         sec = (time.perf_counter() - t0) / reps
         out["C-ABI resident pipeline (zkwg_calculate_batch_resident)"] = {
-            "value": round(n / sec, 1), "unit": "witnesses/s", "ring_placement": c.resident_placement(),
+            "value": round(n / sec, 1), "unit": "witnesses/s", "ring_placement": ch.resident_placement(),
             "sample": f"{n} emails per call from host records (H2D of the records, statuses and the 100-byte table back included), {reps} calls"}
     except Exception as e:
         out["C-ABI resident pipeline (zkwg_calculate_batch_resident)"] = {"error": repr(e)[:200]}
+    if ch is not None:
+        ch.close()
+    del ch
     # the same delivery with the expansion on the HOST (zkwg_set_host_expand): only the 0.45 MB image crosses PCIe, the
     # witness bytes are written by the host cores (non-temporal stores) -- bounded by host DRAM bandwidth instead
     try:
@@ -801,7 +808,12 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
             out["prover stages 1-3: Groth16 proofs, " + label] = {
                 "value": r["proofs_per_s"], "unit": "proofs/s", "proofs_in_flight": r["proofs_in_flight"], "contexts": r["contexts"],
                 "emails_per_series": r["emails_per_series"], "proofs_timed": r["proofs_timed"], "hw_queues": r.get("hw_queues"),
-                "one_at_a_time_ms_per_proof": r["one_at_a_time_ms_per_proof"], "sums_verified": r["sums_verified"],
+                "one_at_a_time_ms_per_proof": r["one_at_a_time_ms_per_proof"],
+                # one timed proof checked OUTSIDE the timed region: its five sums and pi_a, pi_b, pi_c against their discrete logarithms
+                "verified": bool(r["sums_verified"] and r.get("proof_equals_its_discrete_logarithms") and r["batched_equals_one_at_a_time"]),
+                "verified_how": "trapdoor key: A, B, C and every sum recomputed from the known exponents in Python integers; the pairing check itself "
+                                "is the oracle's and runs in tests/test_prove.py at this circuit (bench.py may not call the oracle here)",
+                "sums_verified": r["sums_verified"],
                 "proof_equals_its_discrete_logarithms": r.get("proof_equals_its_discrete_logarithms"),
                 "batched_equals_one_at_a_time": r["batched_equals_one_at_a_time"],
                 "stages_ms_per_email_in_series": next(v for k, v in r.items() if k.startswith("stages_ms_per_email")), "stages_ms_one_email": r["stages_ms_one_email"],
@@ -852,23 +864,30 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
         out["complete --O0 witnesses"] = {"error": repr(e)[:300]}
     # the flag variant removeSoftLineBreaks = 1 (packages/circuits/helpers/remove-soft-line-breaks.circom:14-126): the one
     # Fr-heavy block of the witness path (PoseidonModular over 2 maxBody bytes), whole batches prepared four deep
+    cr = pl = d_in = None
     try:
+        torch.cuda.empty_cache()
+        free_before = torch.cuda.mem_get_info(dev)[0]
         cr = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank, remove_soft_line_breaks=1)
         _, d_in, _ = resident_inputs(torch, cr, dev, 0x5A4B + 404, 64, 4096, args.body_len)
         pl = Pipeline(torch, cr, dev, d_in, 4096, 256, 4096, ring=4, rsa_throttle=args.rsa_throttle)
         cr.set_timing(True)
-        dt = timed(torch, pl.step, steps=6, warmup=2)
+        dt = timed(torch, pl.step, steps=12, warmup=2)      # (12 steps as in the stand-alone measurement: the ring of four batches needs a few to fill)
         summ, avg, nl, gbs = expand_roofline(cr, 256)
         cr.set_timing(False)
         assert int(pl.d_status.abs().sum().item()) == 0
         out["removeSoftLineBreaks = 1"] = {
-            "value": round(4096 * 6 / dt, 1), "unit": "witnesses/s", "steps": 6, "witness_len": cr.W, "zk_expand_GBps": round(gbs, 1),
+            "value": round(4096 * 12 / dt, 1), "unit": "witnesses/s", "steps": 12, "witness_len": cr.W, "zk_expand_GBps": round(gbs, 1),
             "zk_expand_frac": round(gbs / HBM_PEAK_GBS, 4), "kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 3) for k, v in summ.items() if k.startswith("zk_rslb") or k == "zk_expand"},
             "note": "target of three rounds: 50 k/s -- not reached (DESIGN.md section 12): the chunk hashes (multiplier-bound) and zk_expand (HBM-bound, but it decodes as it stores) share the SIMDs' issue slots"}
-        del pl, d_in, cr
-        torch.cuda.empty_cache()
     except Exception as e:
-        out["removeSoftLineBreaks = 1"] = {"error": repr(e)[:300]}
+        out["removeSoftLineBreaks = 1"] = {"error": repr(e)[:300], "free_GiB_before": round(locals().get("free_before", 0) / 2**30, 1)}
+    # (a failed leg must not keep its 180 GB of prepared batches: the exception's traceback is gone here, the cache is emptied below)
+    pl = d_in = None
+    if cr is not None:
+        cr.close()
+    cr = None
+    torch.cuda.empty_cache()
     # configs[4]: maxBody = 65536 (SHA-dominated), batch 1024, bodies 32K..65K-72; fewer steps
     try:
         c5 = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=1024, max_body=65536, device=local_rank)

@@ -100,18 +100,19 @@ def test_gpu_batched_msm_equals_one_at_a_time_and_the_oracle(n, E, c, mont, apar
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("group", [1, 2])
-def test_gpu_classic_layout_when_the_tables_do_not_fit(group):
+@pytest.mark.parametrize("group,n,c", [(1, 900, 7), (2, 900, 7), (1, 6000, 13)])
+def test_gpu_classic_layout_when_the_tables_do_not_fit(group, n, c):
     """zkwg_msm_create_ex with a table budget too small for the K shifted copies: the plan keeps the classic layout (K bucket sets, the
     windows combined by a Horner pass in limb form) -- what a prover falls back to beside full HBM -- and gives the same sums as the
-    precomputed-windows plan and the oracle, E emails per series, both groups"""
+    precomputed-windows plan and the oracle, E emails per series, both groups.  At window 13 the classic layout has 20 x 4,096 buckets: more
+    than a workgroup's histogram holds, so the counting sort runs its global-counter kernels (zk_msm_count / zk_msm_scan / zk_msm_scatter)"""
     import ctypes as C
     import torch
     from oracle.pyref import bn254_g2 as H
     from zkwg import _lib, prover
     lib = _lib.load()
     rng = random.Random(90 + group)
-    n, E, c = 900, 3, 7
+    E = 3
     ks = [rng.randrange(1, R) for _ in range(40)]
     d_pts = prover.fixed_base(0, group, ks)
     size = 64 if group == 1 else 128

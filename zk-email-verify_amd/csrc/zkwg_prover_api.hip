@@ -59,6 +59,8 @@ static void prover_free(zkwg_prover* p) {
 // `slots` proofs in flight = contexts x emails per series
 static void prover_shape(uint32_t slots, uint32_t& n_ctx, uint32_t& E) {
   n_ctx = slots >= 6 ? 3u : slots >= 2 ? 2u : 1u;
+  // (tuning knob, DESIGN.md section 8: ZKWG_PROVER_CONTEXTS = 1 .. 4 rolling contexts instead of the default)
+  if (const char* v = getenv("ZKWG_PROVER_CONTEXTS")) { const int k = atoi(v); if (k >= 1 && k <= 4 && (uint32_t)k <= slots) n_ctx = (uint32_t)k; }
   E = (slots + n_ctx - 1) / n_ctx;
   if (E > 32) E = 32;
 }
