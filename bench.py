@@ -131,7 +131,45 @@ class Pipeline:
         # per-email result rows (w[0..3] = 1, pubkeyHash, shaHi, shaLo) saved before the ring slot is reused
         self.d_rows = torch.empty((batch, 128), dtype=torch.uint8, device=dev)
 
+    def _expand_tiles(self, lo, b, sb):
+        torch = self.torch
+        with torch.cuda.stream(self.s_exp):
+            for t in range(self.tiles_per_sub):
+                o = self.d_out[(sb * self.tiles_per_sub + t) % len(self.d_out)]
+                if self.stride != self.unit_bytes:
+                    self.expand(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp, out_stride=self.stride)
+                else:
+                    self.expand(self.d_in[lo:lo + self.prep], self.prep, self.d_scr[b], t * self.tile, self.tile, o, self.s_exp)
+                self.d_rows[lo + t * self.tile:lo + (t + 1) * self.tile].copy_(o.view(self.tile, self.stride)[:, :128])
+        self.ev_exp[b].record(self.s_exp)
+
+    def step_lagged(self):
+        """serial == 2: the prepare kernels of sub-batch j and the expansion of sub-batch j - 1 take turns on the chip (P1 P2 E1 P3 E2 ...):
+        neither shares the SIMDs' issue slots with the other, and what a prepare leaves on the handle's side streams (the Poseidon(2) merge
+        chain of removeSoftLineBreaks: 191 dependent permutations per email, a few wavefronts) runs beside the expansion of j - 1 and the
+        prepare of j + 1 before the expansion of j needs it.  A step = one prepare + one expansion per sub-batch, one sub-batch apart; needs
+        a ring of >= 3 image buffers."""
+        c = self.c
+        assert self.R >= 3
+        for sb in range(self.nsub):
+            j = self.j
+            b = j % self.R
+            s_prep = self.s_preps[0]
+            lo = sb * self.prep
+            if j >= 2:
+                s_prep.wait_event(self.ev_exp[(j - 2) % self.R])      # the expansion of j - 2 is over (and image buffer b has long been read)
+            c.set_prepare_throttle(0)
+            c.prepare_device(self.d_in[lo:lo + self.prep], self.prep, self.d_status[lo:lo + self.prep], self.d_scr[b], s_prep)
+            self.ev_prep[b].record(s_prep)
+            if j >= 1:
+                self.s_exp.wait_event(self.ev_prep[b])                 # ... and the expansion of j - 1 starts when the prepare of j is over
+                self._expand_tiles(self._lag[0], self._lag[1], self._lag[2])
+            self._lag = (lo, b, sb)
+            self.j = j + 1
+
     def step(self):
+        if self.serial == 2:
+            return self.step_lagged()
         torch, c = self.torch, self.c
         for sb in range(self.nsub):
             j = self.j
@@ -361,7 +399,8 @@ def main():
     ap.add_argument("--regex", default=None,
                     help="path of a zk-regex style body_hash_regex.circom: BodyHashRegex is compiled from it (zkwg_circuit_create_regex)")
     ap.add_argument("--no-overlap", type=int, default=0,
-                    help="1: measurement aid -- every prepare waits for the previous sub-batch's expands, so zk_expand runs alone on the chip")
+                    help="1: measurement aid -- every prepare waits for the previous sub-batch's expands, so zk_expand runs alone on the chip; "
+                         "2: prepare(j) and expand(j - 1) take turns, side-stream work of the prepares (the removeSoftLineBreaks merge chain) beside both")
     ap.add_argument("--prep-cus", type=int, default=0,
                     help="> 0: the prepare kernels run on this many compute units only (CU-masked stream), zk_expand on the others")
     ap.add_argument("--prep-cu-stride", type=int, default=1, help="with --prep-cus: take every stride-th CU instead of the first ones")
@@ -442,7 +481,7 @@ def main():
     prio = int(os.environ.get("ZKWG_BENCH_EXP_PRIO", "-1"))
     pl = Pipeline(torch, c, dev, d_in, args.batch, tile, prep, ring=args.ring, prep_streams=args.prep_streams,
                   rsa_throttle=args.rsa_throttle, exp_prio=prio, montgomery=bool(args.montgomery), out_align=args.out_align,
-                  serial=bool(args.no_overlap), prep_cus=args.prep_cus, prep_cu_stride=args.prep_cu_stride, place=args.place_ring)
+                  serial=int(args.no_overlap), prep_cus=args.prep_cus, prep_cu_stride=args.prep_cu_stride, place=args.place_ring)
     from zkwg import shard
     state = {"table": None}
 
