@@ -105,7 +105,7 @@ int ht_poseidon29(uint32_t t, uint32_t variant, const void* inputs, void* emit, 
   Fr h;
   std::vector<u32> stage(9 * 17, 0xdeadbeefu);
 #define HT_P29(TT, VV) if (t == TT && variant == VV) h = zk_poseidon29<TT, VV>(st.data(), 1, t, tab29.data(), rp, (Fr*)emit, stage.data(), 1)
-  HT_P29(3, 0); else HT_P29(3, 3); else HT_P29(3, 7);
+  HT_P29(3, 0); else HT_P29(3, 2); else HT_P29(3, 3); else HT_P29(3, 7);      // (3, 2): what zk_rslb_merge1 runs
   else HT_P29(17, 0); else HT_P29(17, 1); else HT_P29(17, 2); else HT_P29(17, 3);
   else HT_P29(17, 4); else HT_P29(17, 5); else HT_P29(17, 6); else HT_P29(17, 7);
 #undef HT_P29

@@ -130,7 +130,7 @@ def test_poseidon_sparse_host_core_matches_oracle():
             emit = C.create_string_buffer(32 * n)
             h = C.create_string_buffer(32)
             # 4 x 64-bit words | 9 x 29-bit limbs (zk_rslb_chunks' evaluator) in each of its variants
-            fns = [lambda *a: lib.ht_poseidon_sparse(*a)] + [(lambda *a, v=v: lib.ht_poseidon29(a[0], v, *a[1:])) for v in ((0, 3, 7) if t == 3 else range(8))]
+            fns = [lambda *a: lib.ht_poseidon_sparse(*a)] + [(lambda *a, v=v: lib.ht_poseidon29(a[0], v, *a[1:])) for v in ((0, 2, 3, 7) if t == 3 else range(8))]
             for fn in fns:
                 emit = C.create_string_buffer(32 * n)
                 h = C.create_string_buffer(32)

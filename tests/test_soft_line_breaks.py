@@ -81,6 +81,28 @@ def test_soft_line_breaks_on_gpu_bit_exact():
 
 
 @pytest.mark.gpu
+def test_constant_chunks_give_the_image_of_hashed_chunks(monkeypatch):
+    """zkwg_kernels_rslb.hip "constant chunks": the all-zero 16-byte chunks of the padded halves take the precomputed signals of
+    Poseidon(16)(0, ..., 0) instead of a lane of zk_rslb_chunks.  Bodies from a few bytes (nearly every chunk constant) to the longest the
+    circuit takes (the encoded half has none); same witnesses as with ZKWG_RSLB_CONST_CHUNKS=0 (every unit hashed) and as the C oracle"""
+    import zkwg
+    from oracle import coracle
+    inps = [_inputs(i, n) for i, n in enumerate((5, 17, 160, 250, 318))]
+    recs = None
+    wits = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ZKWG_RSLB_CONST_CHUNKS", flag)
+        c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, remove_soft_line_breaks=1)
+        recs = recs or b"".join(c.pack(i) for i in inps)
+        wits[flag], status = c.calculate_batch_host(recs)
+        assert status == [0] * len(inps)
+        c.close()
+    assert wits["1"] == wits["0"]
+    owit, ostatus, W = coracle.calculate(0, N, M, 0, inps, threads=4)
+    assert ostatus == [0] * len(inps) and b"".join(owit) == wits["1"]
+
+
+@pytest.mark.gpu
 def test_soft_line_break_edge_patterns_on_gpu():
     """Signed emails whose bodies put "=\\r\\n" where the circuit's index arithmetic has its corners
     (helpers/remove-soft-line-breaks.circom:47-91 and the reference's own cases in remove-soft-line-breaks.test.ts:

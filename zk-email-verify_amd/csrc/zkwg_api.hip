@@ -78,6 +78,9 @@ struct zkwg_circuit {
   int o0_emails_per_wg;          // emails per workgroup of zk_expand3_o0 (ZKWG_O0_EMAILS_PER_WG, default 16)
   int o0_pipe;                   // zk_expand3_o0 variant (ZKWG_O0_PIPE): 0 plain, 1 one email ahead, 2 (default) batches of 4 emails + short paths for uniform pieces, 3 double-buffered batches
   int rslb_v;              // zk_rslb_chunks' evaluator variant (ZKWG_RSLB_V = 0..3, zkwg_poseidon29.h)
+  u32 pos2_l29_off = 0;    // words: the Poseidon(2) limb table behind the Poseidon(16) one in d_pos_l29
+  int rs_merge_lanes = 1;  // zk_rslb_merge1 (one lane per email, limb form) | 4: zk_rslb_merge (ZKWG_RSLB_MERGE_LANES)
+  Fr* d_rs_zero = nullptr; // removeSoftLineBreaks: signals + digest of the all-zero chunk (constant chunks, zkwg_kernels_rslb.hip); null: off
   int x3_k, x3_k_o0;       // slots per thread of zk_expand3 (kept-v1 / sym layouts) and zk_expand3_o0: 1, 2 or 4 (ZKWG_X3_K, ZKWG_X3_K_O0)
   std::vector<ZkSeg> segs;
   hipStream_t own_stream, copy_stream;
@@ -266,6 +269,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
   // tuning knobs (DESIGN.md "zk_expand geometry"): slots per workgroup and threads per workgroup
   auto pick_k = [](const char* name, int dflt, bool k8 = false) { const char* v = getenv(name); const int k = v ? atoi(v) : dflt; return (k == 1 || k == 2 || k == 4 || (k8 && k == 8)) ? k : dflt; };
   { const char* v = getenv("ZKWG_RSLB_V"); c->rslb_v = v ? (atoi(v) & 7) : 6; }
+  { const char* v = getenv("ZKWG_RSLB_MERGE_LANES"); c->rs_merge_lanes = v && atoi(v) == 4 ? 4 : 1; }
   c->x3_k = pick_k("ZKWG_X3_K", 4, true);
   c->x3_k_o0 = pick_k("ZKWG_X3_K_O0", 1);   // (round 4: 8 KiB pieces, 53 VGPRs = 8 wavefronts per SIMD, software-pipelined over the group's emails)
   c->o0_emails_per_wg = getenv("ZKWG_O0_EMAILS_PER_WG") ? std::max(1, atoi(getenv("ZKWG_O0_EMAILS_PER_WG"))) : 16;
@@ -506,17 +510,29 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       ok = zk_build_poseidon_sparse(17, 68, C, M, t16);
       build_poseidon_constants(3, 8, 57, C, M);
       ok = ok && zk_build_poseidon_sparse(3, 57, C, M, t2);
-      std::vector<u32> l29;
-      if (ok) zk_build_poseidon29(17, 68, t16, l29);
+      std::vector<u32> l29, l29_2;
+      if (ok) { zk_build_poseidon29(17, 68, t16, l29); zk_build_poseidon29(3, 57, t2, l29_2); }
+      const size_t n16 = l29.size();
+      c->pos2_l29_off = (u32)n16;
+      l29.insert(l29.end(), l29_2.begin(), l29_2.end());
       ok = ok && hipMalloc((void**)&c->d_pos_l29, l29.size() * sizeof(u32)) == hipSuccess &&
            hipMemcpy(c->d_pos_l29, l29.data(), l29.size() * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess;
+      { const char* v = getenv("ZKWG_RSLB_CONST_CHUNKS");
+        if (ok && !(v && atoi(v) == 0)) {
+          // Poseidon(16)(0, ..., 0): the same evaluator on the host (element j, limb l at st[l * 17 + j])
+          std::vector<u32> st0(9 * 17, 0u);
+          std::vector<Fr> z(ZK_P16_KEPT + 1);
+          z[ZK_P16_KEPT] = zk_poseidon29<17, 0>(st0.data(), 1, 17, l29.data(), 68, z.data());
+          ok = hipMalloc((void**)&c->d_rs_zero, z.size() * sizeof(Fr)) == hipSuccess &&
+               hipMemcpy(c->d_rs_zero, z.data(), z.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
+        } }
       c->pos2_off = (u32)t16.size();
       t16.insert(t16.end(), t2.begin(), t2.end());
       ok = ok && hipMalloc((void**)&c->d_pos_rs, t16.size() * sizeof(Fr)) == hipSuccess &&
            hipMemcpy(c->d_pos_rs, t16.data(), t16.size() * sizeof(Fr), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) {
-      hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_pos_l29);
+      hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_pos_l29); hipFree(c->d_rs_zero);
       hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent);
       delete c;
       return ZKWG_RC_OOM;
@@ -635,7 +651,7 @@ int zkwg_o0_gather_host(const zkwg_circuit_t* c, const uint8_t* kept_witness, ui
 }
 // scratch buffer of an n-email batch: [SHA chaining states | bits | small | fr (+256) | Montgomery copies (fr + limbs) |
 // removeSoftLineBreaks: zk_rslb_chunks' dense-mix staging, 153 words per 16-byte chunk, word-major (zkwg_poseidon29.h)]
-struct ZkScratchLayout { u64 off_hst, off_bits, off_small, off_fr, off_frm, off_rs_stage, rs_units, total; };
+struct ZkScratchLayout { u64 off_hst, off_bits, off_small, off_fr, off_frm, off_rs_stage, off_rs_list, rs_units, total; };
 static ZkScratchLayout scratch_layout(const ZkSched& s, u64 n) {
   ZkScratchLayout L;
   u64 off = 0;
@@ -646,6 +662,7 @@ static ZkScratchLayout scratch_layout(const ZkSched& s, u64 n) {
   L.off_frm = off; off += align256(n * (u64)(s.img_fr + ZK_MONT_LIMBS) * 32);
   L.rs_units = s.rslb ? (n * (u64)s.rs_nch + 63) / 64 * 64 : 0;
   L.off_rs_stage = off; off += align256(L.rs_units * 153 * 4);
+  L.off_rs_list = off; off += s.rslb ? align256(L.rs_units * 2 * 4) + 256 : 0;      // constant chunks: two unit lists | their two counters
   L.total = off;
   return L;
 }
@@ -676,7 +693,7 @@ void zkwg_circuit_destroy(zkwg_circuit_t* c) {
   if (!c) return;
   if (c->device >= 0) {
     hipSetDevice(c->device);
-    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_pos_l29); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
+    hipFree(c->d_invtab); hipFree(c->d_segs); hipFree(c->d_ent); hipFree(c->d_pos); hipFree(c->d_pos_rs); hipFree(c->d_pos_l29); hipFree(c->d_rs_zero); hipFree(c->d_rtab); hipFree(c->d_invtab_m);
     free_o0(c->o0d); free_o0(c->abcd);
     hipFree(c->d_net_records); hipFree(c->d_net_counts); hipFree(c->d_net_mask_tab); hipFree(c->d_net_pd); hipFree(c->d_net_tabs); hipFree(c->d_netd);
     hipFree(c->d_net_cclass); hipFree(c->d_net_cdelta); hipFree(c->d_net_cmask);
@@ -874,8 +891,13 @@ static void fill_bufs(const zkwg_circuit* c, ZkBufs& B, const void* d_in, u64 n,
   B.net_bclass = c->d_net_bclass; B.net_bdelta = c->d_net_bdelta; B.net_bmask = c->d_net_bmask;
   B.pos16 = c->d_pos_rs;
   B.pos16_l29 = c->d_pos_l29;
+  B.pos2_l29 = c->d_pos_l29 ? c->d_pos_l29 + c->pos2_l29_off : nullptr;
+  { static const u32 prio = getenv("ZKWG_RSLB_MERGE_PRIO") ? (u32)atoi(getenv("ZKWG_RSLB_MERGE_PRIO")) : 1u; B.rs_prio = prio; }
   B.rs_stage = (u32*)(scr + L.off_rs_stage);
   B.rs_units = L.rs_units;
+  B.rs_zero = c->d_rs_zero;
+  B.rs_list = c->d_rs_zero ? (u32*)(scr + L.off_rs_list) : nullptr;
+  B.rs_cnt = c->d_rs_zero ? (u32*)(scr + L.off_rs_list + align256(L.rs_units * 2 * 4)) : nullptr;
   B.pos2 = c->d_pos_rs ? c->d_pos_rs + c->pos2_off : nullptr;
   B.segs = c->d_segs;
   B.wit = nullptr;
@@ -1008,6 +1030,11 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     const u64 units = (u64)ne * s.rs_nch;
     if (pm & 64u) {
       const dim3 g((u32)((units + 63) / 64));
+      if (B.rs_list) {     // constant chunks: split the units, copy the constant ones' signals, hash the others (the grid covers the worst case)
+        hipMemsetAsync(B.rs_cnt, 0, 8, st);
+        hipLaunchKernelGGL(zk_rslb_classify, dim3((u32)((units + 255) / 256)), dim3(256), 0, st, s, B);
+        hipLaunchKernelGGL(zk_rslb_fill_const, dim3(8192), dim3(64), 0, st, s, B);
+      }
       switch (c->rslb_v) {
         case 1: hipLaunchKernelGGL(zk_rslb_chunks_v1, g, dim3(64), 0, st, s, B); break;
         case 2: hipLaunchKernelGGL(zk_rslb_chunks_v2, g, dim3(64), 0, st, s, B); break;
@@ -1021,7 +1048,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
     }
     if (tm) hipEventRecord(evs[++ki], st);
     if (c->rs_sync) {
-      if (pm & 128u) { hipLaunchKernelGGL(zk_rslb_merge, dim3((ne + 64u / ZK_RS_MERGE_LANES - 1u) / (64u / ZK_RS_MERGE_LANES)), dim3(64), 0, st, s, B); hipLaunchKernelGGL(zk_rslb_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B); }
+      if (pm & 128u) { if (c->rs_merge_lanes == 1) hipLaunchKernelGGL(zk_rslb_merge1, dim3((ne + 63u) / 64u), dim3(64), 0, st, s, B); else hipLaunchKernelGGL(zk_rslb_merge, dim3((ne + 64u / ZK_RS_MERGE_LANES - 1u) / (64u / ZK_RS_MERGE_LANES)), dim3(64), 0, st, s, B); hipLaunchKernelGGL(zk_rslb_scan, dim3((ne + 63) / 64), dim3(64), 0, st, s, B); }
     } else {
       int slot = -1;
       for (int i = 0; i < ZK_RS_SLOTS; ++i) if (c->rs_scr[i] == d_scratch) slot = i;
@@ -1032,7 +1059,7 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       // ZKWG_RSLB_SIDE_STREAMS raises it (together with GPU_MAX_HW_QUEUES).
       hipStream_t ss = c->side_stream[slot % c->rs_nside];
       hipStreamWaitEvent(ss, c->rs_dep[slot], 0);
-      if (pm & 128u) { hipLaunchKernelGGL(zk_rslb_merge, dim3((ne + 64u / ZK_RS_MERGE_LANES - 1u) / (64u / ZK_RS_MERGE_LANES)), dim3(64), 0, ss, s, B); hipLaunchKernelGGL(zk_rslb_scan, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B); }
+      if (pm & 128u) { if (c->rs_merge_lanes == 1) hipLaunchKernelGGL(zk_rslb_merge1, dim3((ne + 63u) / 64u), dim3(64), 0, ss, s, B); else hipLaunchKernelGGL(zk_rslb_merge, dim3((ne + 64u / ZK_RS_MERGE_LANES - 1u) / (64u / ZK_RS_MERGE_LANES)), dim3(64), 0, ss, s, B); hipLaunchKernelGGL(zk_rslb_scan, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B); }
       if (pm & 256u) {   // the rows read the chain's field elements: they follow it on the side stream
         if (c->full_W) launch_o0_rows(c, c->o0d, B, ss);
         if (c->abc_m) launch_o0_rows(c, c->abcd, B, ss);

@@ -24,6 +24,9 @@ __global__ void zk_rslb_chunks_v6(ZkSched s, ZkBufs B);
 __global__ void zk_rslb_chunks_v7(ZkSched s, ZkBufs B);
 #include "zkwg_rslb_wave.h"   // ZK_RS_MERGE_LANES
 __global__ void zk_rslb_merge(ZkSched s, ZkBufs B);
+__global__ void zk_rslb_merge1(ZkSched s, ZkBufs B);     // the same chain, one lane per email in limb form
+__global__ void zk_rslb_classify(ZkSched s, ZkBufs B);   // constant chunks: the units to hash | the all-zero ones
+__global__ void zk_rslb_fill_const(ZkSched s, ZkBufs B);
 __global__ void zk_rslb_scan(ZkSched s, ZkBufs B);
 __global__ void zk_r1cs_check(const u64* row_ptr, const u32* wire, const Fr* coef, const u8* kind, u32 m,
                               const u8* wit, u64 stride, unsigned long long* first_bad);  // zkwg_kernels_r1cs.hip

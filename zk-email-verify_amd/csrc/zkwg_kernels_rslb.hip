@@ -21,7 +21,11 @@ template <int V>
 __device__ __forceinline__ void zk_rslb_chunks_body(const ZkSched& s, const ZkBufs& B) {
   __shared__ u32 st[9 * 17 * 64];
   const u32 lane = threadIdx.x;
-  const u64 unit = (u64)blockIdx.x * 64 + lane;
+  u64 unit = (u64)blockIdx.x * 64 + lane;
+  if (B.rs_list) {                      // constant chunks apart (zk_rslb_classify): the lanes take the units that need hashing
+    if (unit >= B.rs_cnt[0]) return;
+    unit = B.rs_list[unit];
+  }
   const u32 e = (u32)(unit / s.rs_nch), c = (u32)(unit % s.rs_nch);
   if (e >= B.n_emails) return;
   const u8* rec = B.in + (u64)e * s.in_stride;
@@ -51,6 +55,49 @@ ZK_RSLB_CHUNKS(5)
 ZK_RSLB_CHUNKS(6)
 ZK_RSLB_CHUNKS(7)
 
+// Constant chunks.  Both halves of the hashed string are zero-padded to maxBody (the encoded body behind its SHA padding, the decoded body
+// behind its last byte), so a third of the chunks of a 1 KB body at maxBody = 1536 -- more for shorter bodies -- are sixteen zero bytes, and
+// Poseidon(16)(0, ..., 0) is a constant of the circuit: its 612 S-box signals and its digest are computed once per handle (zkwg_api.hip, the
+// same zk_poseidon29 on the host).  zk_rslb_classify splits a batch's units into the ones to hash and the constant ones (one global atomic
+// per wavefront and list), zk_rslb_chunks runs on the first list with full wavefronts, zk_rslb_fill_const copies the table for the second
+// (one wavefront per unit: 19.6 KB of coalesced stores).  Same image either way (tests/test_soft_line_breaks.py); ZKWG_RSLB_CONST_CHUNKS=0
+// hashes every unit as before.
+__global__ __launch_bounds__(256) void zk_rslb_classify(ZkSched s, ZkBufs B) {
+  const u64 unit = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u32 e = (u32)(unit / s.rs_nch), c = (u32)(unit % s.rs_nch);
+  const bool live = e < B.n_emails;
+  bool zero = false;
+  if (live) {
+    const u8* rec = B.in + (u64)e * s.in_stride;
+    const u32 half = s.rs_nch / 2;
+    const uint4 raw = *(const uint4*)(rec + (c < half ? s.fr[1].in_data + 16u * c : s.in_off[11] + 16u * (c - half)));
+    zero = (raw.x | raw.y | raw.z | raw.w) == 0u;
+  }
+  const u64 mz = __ballot(live && zero), mn = __ballot(live && !zero);
+  const u32 lane = threadIdx.x & 63u;
+  const u64 below = lane ? (~0ull >> (64u - lane)) : 0ull;
+  u32 bn = 0, bz = 0;
+  if (lane == 0) {
+    if (mn) bn = atomicAdd(&B.rs_cnt[0], (u32)__popcll(mn));
+    if (mz) bz = atomicAdd(&B.rs_cnt[1], (u32)__popcll(mz));
+  }
+  bn = __shfl(bn, 0); bz = __shfl(bz, 0);
+  if (live && !zero) B.rs_list[bn + (u32)__popcll(mn & below)] = (u32)unit;
+  if (live && zero) B.rs_list[B.rs_units + bz + (u32)__popcll(mz & below)] = (u32)unit;
+}
+__global__ __launch_bounds__(64) void zk_rslb_fill_const(ZkSched s, ZkBufs B) {
+  const u32 n = B.rs_cnt[1];
+  const uint4* src = (const uint4*)B.rs_zero;
+  for (u32 k = blockIdx.x; k < n; k += gridDim.x) {
+    const u32 unit = B.rs_list[B.rs_units + k];
+    const u32 e = unit / s.rs_nch, c = unit % s.rs_nch;
+    Fr* frv = B.frv + (u64)e * s.img_fr;
+    uint4* dst = (uint4*)(frv + s.f_rs_hash + zk_rs_chunk_off(c));
+    for (u32 i = threadIdx.x; i < 2u * ZK_P16_KEPT; i += 64u) dst[i] = src[i];
+    if (threadIdx.x < 2u) ((uint4*)(frv + s.f_rs_chunk + c))[threadIdx.x] = src[2u * ZK_P16_KEPT + threadIdx.x];
+  }
+}
+
 // The merge chain  _out = Poseidon(2)([_out, chunk_hash])  (utils/hash.circom:76-80) is inherently serial per email:
 // rs_nch - 1 permutations (191 for maxBody = 1536), each 8 full + 57 partial rounds.  Round 3 ran it one LANE per email in
 // standard form: ~8 dependent Montgomery products per round, 289 ms per 4,096 emails on 64 wavefronts.  A quarter-rate
@@ -64,6 +111,33 @@ ZK_RSLB_CHUNKS(7)
 __global__ __launch_bounds__(64) void zk_rslb_merge(ZkSched s, ZkBufs B) {
   __shared__ ZkRsMergeLds S;
   zk_rslb_merge_wave(S, B.pos2, B.frv, blockIdx.x, B.n_emails, s.img_fr, s.rs_nch, s.f_rs_chunk, s.f_rs_hash);
+}
+
+// Round 6: the same chain one LANE per email through the limb-form evaluator of the chunk hashes (zk_poseidon29<3>: S-boxes and mixes in
+// 9 x 29-bit limbs, one reduction per dot product, nothing exchanged between lanes).  A permutation is ~0.6 k dependent product-sized
+// steps instead of the four-lane version's ~0.3 k, but a wavefront carries 64 emails instead of 16 and a product is ~250 instructions
+// instead of ~315: 2.5 x fewer instructions issued per email.  That is what counts beside zk_rslb_chunks and zk_expand, which leave the
+// chain no idle issue slots; the chain's own latency is hidden by the ring of prepared batches either way.
+// ZKWG_RSLB_MERGE_LANES=4 selects zk_rslb_merge.
+__global__ __launch_bounds__(64) void zk_rslb_merge1(ZkSched s, ZkBufs B) {
+  __shared__ u32 st[9 * 3 * 64];
+  const u32 lane = threadIdx.x, e = blockIdx.x * 64 + lane;
+  if (e >= B.n_emails) return;
+  // 64 wavefronts per 4,096 emails, each a chain of 191 x 0.6 k dependent steps: the SIMD's arbiter serves it first (s_setprio), so that
+  // its latency is its own and not three times that beside the throughput kernels' wavefronts -- which lose a 64th of the chip's issue slots
+  if (B.rs_prio) __builtin_amdgcn_s_setprio(3);
+  Fr* frv = B.frv + (u64)e * s.img_fr;
+  u32* stl = st + lane;
+  Fr out = frv[s.f_rs_chunk];
+  for (u32 c = 1; c < s.rs_nch; ++c) {
+    u32 a[9], b[9];
+    zk_l29_from_fr(out, a);
+    zk_l29_from_fr(frv[s.f_rs_chunk + c], b);
+#pragma unroll
+    for (u32 l = 0; l < 9; ++l) { stl[(l * 3 + 0) * 64] = 0u; stl[(l * 3 + 1) * 64] = a[l]; stl[(l * 3 + 2) * 64] = b[l]; }      // [0, _out, chunk_hash_c]
+    out = zk_poseidon29<3, 2>(stl, 64, 3 * 64, B.pos2_l29, 57, frv + s.f_rs_hash + zk_rs_chunk_off(c) + ZK_P16_KEPT);
+  }
+  frv[s.f_rs_chunk] = out;
 }
 
 // the r-power scans (remove-soft-line-breaks.circom:72-126) and the final comparison: one lane per email, r from zk_rslb_merge

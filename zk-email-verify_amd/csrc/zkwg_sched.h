@@ -293,8 +293,13 @@ struct ZkBufs {
   const Fr* pos16;       // Poseidon(16) sparse-round table (zkwg_poseidon_sparse.h), removeSoftLineBreaks only
   const Fr* pos2;        // Poseidon(2)  sparse-round table
   const u32* pos16_l29;  // Poseidon(16) table in 29-bit limb form (zkwg_poseidon29.h): what zk_rslb_chunks reads
+  const u32* pos2_l29;   // Poseidon(2) table in the same form: zk_rslb_merge1
+  u32 rs_prio;           // zk_rslb_merge1 raises its wavefronts' issue priority (ZKWG_RSLB_MERGE_PRIO=0: off)
   u32* rs_stage;         // zk_rslb_chunks' dense-mix staging: word k of unit u at rs_stage[k * rs_units + u] (153 words per unit)
   u64 rs_units;          // emails x chunks, rounded up to whole wavefronts
+  u32* rs_list;          // constant chunks (zkwg_kernels_rslb.hip): units whose 16 bytes are not all zero | units that are, rs_units entries each;
+  u32* rs_cnt;           //   their two lengths (device counters, zeroed per batch).  rs_list = nullptr: every unit is hashed
+  const Fr* rs_zero;     //   the 612 S-box signals + the digest of Poseidon(16)(0, ..., 0)
   const Fr* invtab_m;    // zk_expand_mont: the inverse table in Montgomery form
   const u32* net_records; // loaded regex template: 16 words per gate in execution order (zkwg_net_core.h)
   const u32* net_counts;  // loaded regex template: gates per step | flags (0x8000: 64-bit path)
