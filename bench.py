@@ -64,7 +64,7 @@ class Pipeline:
             self.stride = self.unit_bytes = c.abc_bytes
         self.d_status = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.R = max(2, ring)
-        self.d_scr = [torch.empty(c.scratch_bytes(prep), dtype=torch.uint8, device=dev) for _ in range(self.R)]
+        self.d_scr = [torch.empty(c.scratch_bytes(prep, montgomery=bool(montgomery)), dtype=torch.uint8, device=dev) for _ in range(self.R)]
         self.placement = None
         self.d_out = None
         place = 2 if place is True else int(place)      # (True == 1 in Python: without this every default-constructed pipeline ran BOTH placements)
@@ -913,7 +913,7 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
             os.environ["ZKWG_RSLB_CONST_CHUNKS"] = flag
             cr = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank, remove_soft_line_breaks=1)
             _, d_in, _ = resident_inputs(torch, cr, dev, 0x5A4B + 404, 64, 4096, args.body_len)
-            pl = Pipeline(torch, cr, dev, d_in, 4096, 256, 4096, ring=4, rsa_throttle=args.rsa_throttle)
+            pl = Pipeline(torch, cr, dev, d_in, 4096, 256, 4096, ring=6, rsa_throttle=args.rsa_throttle)     # (6 x 22 GB of prepared batches)
             cr.set_timing(True)
             dt = timed(torch, pl.step, steps=12, warmup=2)      # (12 steps as in the stand-alone measurement: the ring of four batches needs a few to fill)
             summ, avg, nl, gbs = expand_roofline(cr, 256)

@@ -195,6 +195,10 @@ uint32_t zkwg_num_public(const zkwg_circuit_t* c);    /* outputs + public inputs
 uint64_t zkwg_input_stride(const zkwg_circuit_t* c);  /* bytes per packed input record */
 uint64_t zkwg_input_offset(const zkwg_circuit_t* c, int field); /* byte offset inside a record */
 uint64_t zkwg_scratch_bytes(const zkwg_circuit_t* c, uint64_t n_emails); /* device scratch for a batch */
+/* The same without the Montgomery-copy area, which lies at the end of the buffer: enough for every entry point except the ones that
+ * produce Montgomery-form values from this buffer (zkwg_expand_montgomery_device, zkwg_expand_abc_device with montgomery = 1) -- those
+ * need zkwg_scratch_bytes.  For removeSoftLineBreaks = 1 the image is mostly field elements and this is half the size. */
+uint64_t zkwg_scratch_bytes_standard(const zkwg_circuit_t* c, uint64_t n_emails);
 
 /* Pack one email's inputs into a record (host helper; every pointer may be NULL
  * when the main kind does not use that field).  Limbs are 17 x 16-byte LE. */

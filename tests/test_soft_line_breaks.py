@@ -103,6 +103,37 @@ def test_constant_chunks_give_the_image_of_hashed_chunks(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_standard_form_pipeline_fits_the_scratch_without_montgomery_copies():
+    """zkwg_scratch_bytes_standard (include/zkwg.h): prepare + expand into a buffer that ends where the Montgomery-copy area would begin --
+    half the bytes for this circuit -- leave the guard behind it untouched and give the witnesses of the full-size buffer and the C oracle"""
+    import torch
+    import zkwg
+    from oracle import coracle
+    c = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=N, max_body=M, device=0, remove_soft_line_breaks=1)
+    inps = [_inputs(i, 90 + 50 * i) for i in range(4)]
+    n = len(inps)
+    std, full = c.scratch_bytes(n, montgomery=False), c.scratch_bytes(n)
+    assert 256 < std < 0.6 * full and c.scratch_bytes(n, montgomery=True) == full
+    dev = torch.device("cuda:0")
+    d_in = torch.frombuffer(bytearray(b"".join(c.pack(i) for i in inps)), dtype=torch.uint8).view(n, c.in_stride).to(dev)
+    st = torch.cuda.current_stream()
+    outs = []
+    for size in (std, full):
+        d_scr = torch.full((size + 4096,), 0xA5, dtype=torch.uint8, device=dev)
+        d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_out = torch.empty(n * c.witness_bytes, dtype=torch.uint8, device=dev)
+        c.prepare_device(d_in, n, d_st, d_scr, st)
+        c.expand_device(d_in, n, d_scr, 0, n, d_out, st)
+        torch.cuda.synchronize()
+        assert d_st.tolist() == [0] * n
+        assert bool((d_scr[size:] == 0xA5).all())
+        outs.append(bytes(d_out.cpu().numpy()))
+    assert outs[0] == outs[1]
+    owit, ostatus, W = coracle.calculate(0, N, M, 0, inps, threads=4)
+    assert ostatus == [0] * n and b"".join(owit) == outs[0]
+
+
+@pytest.mark.gpu
 def test_soft_line_break_edge_patterns_on_gpu():
     """Signed emails whose bodies put "=\\r\\n" where the circuit's index arithmetic has its corners
     (helpers/remove-soft-line-breaks.circom:47-91 and the reference's own cases in remove-soft-line-breaks.test.ts:

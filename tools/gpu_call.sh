@@ -53,10 +53,10 @@ d=json.loads(sys.stdin.readline()); print('headline ${step#benchq:}', d['value']
               python $REPO/bench.py --steps 5 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 ${step#prof:} > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.log )
           S=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_kernel_stats.csv && head -16 $S
           rm -rf $OUT/${TAG}_prof ;;
-    rslb) timeout 600 python bench.py --remove-soft-line-breaks 1 --batch 4096 --tile 256 --prep-batch 4096 --ring 4 --steps 12 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 2>/dev/null | tail -1 | tee $OUT/${TAG}_rslb.json | python -c "
+    rslb) timeout 600 python bench.py --remove-soft-line-breaks 1 --batch 4096 --tile 256 --prep-batch 4096 --ring 6 --steps 12 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 2>/dev/null | tail -1 | tee $OUT/${TAG}_rslb.json | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('rslb', d['value'], d['kernel_ms_per_launch'])" ;;
-    rslb:*) timeout 600 python bench.py --remove-soft-line-breaks 1 --batch 4096 --tile ${RSLB_TILE:-256} --prep-batch ${RSLB_PREP:-4096} --ring ${RSLB_RING:-4} --steps 12 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 $RSLB_ARGS 2>/dev/null | tail -1 | tee -a $OUT/${TAG}_rslb_variants.json | python -c "
+    rslb:*) timeout 600 python bench.py --remove-soft-line-breaks 1 --batch 4096 --tile ${RSLB_TILE:-256} --prep-batch ${RSLB_PREP:-4096} --ring ${RSLB_RING:-6} --steps 12 --warmup 2 --cpu-sample 0 --pmc-traffic 0 --other-configs 0 $RSLB_ARGS 2>/dev/null | tail -1 | tee -a $OUT/${TAG}_rslb_variants.json | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('rslb ${step#rslb:}', d['value'], d['kernel_ms_per_launch'])" ;;
     abc) timeout 900 python tools/bench_abc.py 2>/dev/null | tail -1 | tee $OUT/${TAG}_abc.json | cut -c1-600 ;;

@@ -554,7 +554,7 @@ static int create_impl(const zkwg_config* cfg_in, int device, const char* sym_te
       }
       c->rs_next = 0;
       c->rs_sync = getenv("ZKWG_RSLB_SYNC") ? atoi(getenv("ZKWG_RSLB_SYNC")) : 0;
-      c->rs_nside = getenv("ZKWG_RSLB_SIDE_STREAMS") ? std::min(ZK_RS_SLOTS, std::max(1, atoi(getenv("ZKWG_RSLB_SIDE_STREAMS")))) : 2;
+      c->rs_nside = getenv("ZKWG_RSLB_SIDE_STREAMS") ? std::min(ZK_RS_SLOTS, std::max(1, atoi(getenv("ZKWG_RSLB_SIDE_STREAMS")))) : 4;
     }
     {
       int prio_lo = 0, prio_hi = 0;
@@ -649,9 +649,12 @@ int zkwg_o0_gather_host(const zkwg_circuit_t* c, const uint8_t* kept_witness, ui
     o[Pn.dst[r]] = zk_linear_row(Pn.row_ptr.data(), c->o0_src.data(), Pn.coef.data(), Pn.kind.data(), r, kw);
   return ZKWG_RC_OK;
 }
-// scratch buffer of an n-email batch: [SHA chaining states | bits | small | fr (+256) | Montgomery copies (fr + limbs) |
-// removeSoftLineBreaks: zk_rslb_chunks' dense-mix staging, 153 words per 16-byte chunk, word-major (zkwg_poseidon29.h)]
-struct ZkScratchLayout { u64 off_hst, off_bits, off_small, off_fr, off_frm, off_rs_stage, off_rs_list, rs_units, total; };
+// scratch buffer of an n-email batch: [SHA chaining states | bits | small | fr (+256) | removeSoftLineBreaks: zk_rslb_chunks' dense-mix
+// staging, 153 words per 16-byte chunk, word-major (zkwg_poseidon29.h) | its two unit lists + counters | Montgomery copies (fr + limbs)].
+// The Montgomery copies come LAST (round 6): a caller that never asks this buffer for a Montgomery-form output allocates
+// zkwg_scratch_bytes_standard -- half the bytes where the image is mostly field elements (removeSoftLineBreaks: 22 instead of 45 GB per
+// 4,096 emails, i.e. twice as many prepared batches in flight in the same HBM).
+struct ZkScratchLayout { u64 off_hst, off_bits, off_small, off_fr, off_img_end, off_frm, off_rs_stage, off_rs_list, rs_units, total_std, total; };
 static ZkScratchLayout scratch_layout(const ZkSched& s, u64 n) {
   ZkScratchLayout L;
   u64 off = 0;
@@ -659,10 +662,12 @@ static ZkScratchLayout scratch_layout(const ZkSched& s, u64 n) {
   L.off_bits = off; off += align256(n * (u64)s.img_bits * 8);
   L.off_small = off; off += align256(n * (u64)s.img_small * 4);
   L.off_fr = off; off += align256(n * (u64)s.img_fr * 32) + 256;
-  L.off_frm = off; off += align256(n * (u64)(s.img_fr + ZK_MONT_LIMBS) * 32);
+  L.off_img_end = off;
   L.rs_units = s.rslb ? (n * (u64)s.rs_nch + 63) / 64 * 64 : 0;
   L.off_rs_stage = off; off += align256(L.rs_units * 153 * 4);
   L.off_rs_list = off; off += s.rslb ? align256(L.rs_units * 2 * 4) + 256 : 0;      // constant chunks: two unit lists | their two counters
+  L.total_std = off;
+  L.off_frm = off; off += align256(n * (u64)(s.img_fr + ZK_MONT_LIMBS) * 32);
   L.total = off;
   return L;
 }
@@ -732,6 +737,7 @@ uint64_t zkwg_input_offset(const zkwg_circuit_t* c, int field) {
   return c->s.in_off[field];
 }
 uint64_t zkwg_scratch_bytes(const zkwg_circuit_t* c, uint64_t n) { return scratch_layout(c->s, n).total; }
+uint64_t zkwg_scratch_bytes_standard(const zkwg_circuit_t* c, uint64_t n) { return scratch_layout(c->s, n).total_std; }
 
 int zkwg_pack_input(const zkwg_circuit_t* c, uint8_t* rec, const uint8_t* header, uint32_t header_len,
                     const uint8_t* body, uint32_t body_len, const uint8_t* pre, const uint8_t* pubkey,
@@ -1054,9 +1060,9 @@ int zkwg_prepare_device(zkwg_circuit_t* c, const void* d_in, uint64_t n, void* d
       for (int i = 0; i < ZK_RS_SLOTS; ++i) if (c->rs_scr[i] == d_scratch) slot = i;
       if (slot < 0) { slot = c->rs_next; c->rs_next = (c->rs_next + 1) % ZK_RS_SLOTS; c->rs_scr[slot] = d_scratch; }
       hipEventRecord(c->rs_dep[slot], st);
-      // two side streams by default: with the caller's prepare and expand streams that is the default number
-      // of hardware queues (GPU_MAX_HW_QUEUES = 4); streams beyond that share queues and serialise.
-      // ZKWG_RSLB_SIDE_STREAMS raises it (together with GPU_MAX_HW_QUEUES).
+      // four side streams by default (ZKWG_RSLB_SIDE_STREAMS): a batch's chain then starts when its chunk hashes are done instead of
+      // behind the chain of the batch before last (round 6, same box: 53.3 k witnesses/s against 51.9 k with two,
+      // profiles/r06/r06_n_rslb_variants.json).  They are lowest-priority streams: their hardware queues come from a pool of their own.
       hipStream_t ss = c->side_stream[slot % c->rs_nside];
       hipStreamWaitEvent(ss, c->rs_dep[slot], 0);
       if (pm & 128u) { if (c->rs_merge_lanes == 1) hipLaunchKernelGGL(zk_rslb_merge1, dim3((ne + 63u) / 64u), dim3(64), 0, ss, s, B); else hipLaunchKernelGGL(zk_rslb_merge, dim3((ne + 64u / ZK_RS_MERGE_LANES - 1u) / (64u / ZK_RS_MERGE_LANES)), dim3(64), 0, ss, s, B); hipLaunchKernelGGL(zk_rslb_scan, dim3((ne + 63) / 64), dim3(64), 0, ss, s, B); }
@@ -1539,7 +1545,7 @@ static int calculate_batch_hostexpand(zkwg_circuit_t* c, const uint8_t* packed, 
         hipMalloc((void**)&d_st[i], tile * sizeof(int)) != hipSuccess) rc = ZKWG_RC_OOM;
   hipStream_t st = c->own_stream;
   const ZkScratchLayout L = scratch_layout(s, tile);
-  const u64 img_lo = L.off_bits, img_hi = L.off_frm;          // the image arrays (not the SHA chaining states / Montgomery copies)
+  const u64 img_lo = L.off_bits, img_hi = L.off_img_end;      // the image arrays (not the SHA chaining states / staging / Montgomery copies)
   auto submit = [&](u64 t) -> int {
     const u64 base = t * tile, cnt = std::min<u64>(tile, n - base);
     const int b = (int)(t & 1);

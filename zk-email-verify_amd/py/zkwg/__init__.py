@@ -345,8 +345,10 @@ class Circuit:
             return {"mode": "chunked (ZKWG_PLACE_RING=0: plain allocations)", "chunk_bytes": 1 << 30}
         return {"ms_per_tile": [round(ms[i], 3) for i in range(k)], "kept": list(kept)}
 
-    def scratch_bytes(self, n):
-        return self.lib.zkwg_scratch_bytes(self.h, n)
+    def scratch_bytes(self, n, montgomery=True):
+        """device scratch of an n-email batch; montgomery=False: without the Montgomery-copy area at its end (include/zkwg.h
+        zkwg_scratch_bytes_standard: every entry point except the Montgomery-form outputs)"""
+        return self.lib.zkwg_scratch_bytes(self.h, n) if montgomery else self.lib.zkwg_scratch_bytes_standard(self.h, n)
 
     def set_prepare_throttle(self, rsa_wavefronts_per_cu):
         _check(self.lib.zkwg_set_prepare_throttle(self.h, rsa_wavefronts_per_cu))

@@ -83,6 +83,7 @@ def load():
         "zkwg_input_stride": (u64, [vp]),
         "zkwg_input_offset": (u64, [vp, i32]),
         "zkwg_scratch_bytes": (u64, [vp, u64]),
+        "zkwg_scratch_bytes_standard": (u64, [vp, u64]),
         "zkwg_pack_input": (i32, [vp, vp, vp, u32, vp, u32, vp, vp, vp, vp, u32]),
         "zkwg_pack_field": (i32, [vp, vp, i32, u64, vp, u64]),
         "zkwg_pack_masks": (i32, [vp, vp, vp, vp]),
@@ -180,7 +181,7 @@ def load():
 EXPORTS = [
     "zkwg_abi_version", "zkwg_strerror", "zkwg_circuit_create", "zkwg_circuit_create_sym", "zkwg_circuit_create_full", "zkwg_circuit_create_regex", "zkwg_regex_info", "zkwg_linear_rows", "zkwg_layout_map", "zkwg_image_layout", "zkwg_segment_table", "zkwg_inverse_table_half", "zkwg_linear_complete_host", "zkwg_o0_gather_host", "zkwg_last_error", "zkwg_circuit_destroy",
     "zkwg_witness_len", "zkwg_witness_bytes", "zkwg_num_public", "zkwg_input_stride",
-    "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_pack_input", "zkwg_pack_field", "zkwg_pack_masks", "zkwg_pack_decoded_body", "zkwg_calculate_batch",
+    "zkwg_input_offset", "zkwg_scratch_bytes", "zkwg_scratch_bytes_standard", "zkwg_pack_input", "zkwg_pack_field", "zkwg_pack_masks", "zkwg_pack_decoded_body", "zkwg_calculate_batch",
     "zkwg_generate_inputs_device", "zkwg_stream_create_masked", "zkwg_stream_destroy", "zkwg_expand_host", "zkwg_set_host_expand", "zkwg_alloc_pinned", "zkwg_free_pinned", "zkwg_calculate_batch_device", "zkwg_prepare_device", "zkwg_expand_device", "zkwg_expand_montgomery_device", "zkwg_circuit_attach_r1cs", "zkwg_abc_bytes", "zkwg_expand_abc_device", "zkwg_expand_abc_host", "zkwg_expand_full_host", "zkwg_set_prepare_throttle", "zkwg_set_prepare_mask", "zkwg_set_timing", "zkwg_last_kernel_ms", "zkwg_timing_summary", "zkwg_num_kernels",
     "zkwg_kernel_name", "zkwg_kernel_slots", "zkwg_wtns_size", "zkwg_write_wtns", "zkwg_write_sym",
     "zkwg_r1cs_load", "zkwg_r1cs_destroy", "zkwg_r1cs_info", "zkwg_check_constraints_device", "zkwg_r1cs_evaluate_device", "zkwg_check_constraints",
