@@ -727,29 +727,28 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
     # the device-resident pipeline BELOW the C-ABI (zkwg_calculate_batch_resident: what a Node host without torch drives, and what
     # zkwg_calculate_batch_multi runs on every GPU when no witness is asked back): records from host memory, statuses + result
     # table back, witnesses into the handle's own placed two-tile ring
-    ch = None
     try:
         n = args.batch
-        # (its own handle: the ring and the scratch buffers of this entry point -- 2 x 29 GB + images -- live in the handle until it is
-        # destroyed, and the legs below need that memory: the removeSoftLineBreaks pipeline holds 4 x 45 GB of prepared batches)
-        ch = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank)
-        h_in, _, _ = resident_inputs(torch, ch, dev, 0x5A4B + 909, 64, n, args.body_len)
+        h_in, _, _ = resident_inputs(torch, c, dev, 0x5A4B + 909, 64, n, args.body_len)
         recs = bytes(h_in.repeat((n + 63) // 64, 1)[:n].contiguous().numpy().tobytes())
-        st, _ = ch.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)     # (allocates and places the ring)
+        st, _ = c.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)     # (allocates and places the ring)
         assert not any(st)
         t0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            st, tb = ch.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)
+            st, tb = c.calculate_batch_resident(recs, tile=min(args.tile, n), prep=args.prep_batch)
         sec = (time.perf_counter() - t0) / reps
         out["C-ABI resident pipeline (zkwg_calculate_batch_resident)"] = {
-            "value": round(n / sec, 1), "unit": "witnesses/s", "ring_placement": ch.resident_placement(),
+            "value": round(n / sec, 1), "unit": "witnesses/s", "ring_placement": c.resident_placement(),
             "sample": f"{n} emails per call from host records (H2D of the records, statuses and the 100-byte table back included), {reps} calls"}
     except Exception as e:
         out["C-ABI resident pipeline (zkwg_calculate_batch_resident)"] = {"error": repr(e)[:200]}
-    if ch is not None:
-        ch.close()
-    del ch
+    # (the ring and the scratch buffers of this entry point -- 2 x 29 GB + images -- live in the handle between calls: given back here, the
+    # legs below need the memory.  A second handle for this leg instead cost the LATER legs 8-18 % on two boxes, profiles/r06/r06_x, r06_zz)
+    try:
+        c.release_resident()
+    except Exception:
+        pass
     # the same delivery with the expansion on the HOST (zkwg_set_host_expand): only the 0.45 MB image crosses PCIe, the
     # witness bytes are written by the host cores (non-temporal stores) -- bounded by host DRAM bandwidth instead
     try:
@@ -904,32 +903,23 @@ def other_configs(torch, zkwg, dev, local_rank, c, args):
     # the flag variant removeSoftLineBreaks = 1 (packages/circuits/helpers/remove-soft-line-breaks.circom:14-126): the one
     # Fr-heavy block of the witness path (PoseidonModular over 2 maxBody bytes), whole batches prepared four deep
     # Twice: as shipped, and with every 16-byte chunk hashed (ZKWG_RSLB_CONST_CHUNKS=0: no constant for the all-zero chunks of the padding).
+    # Each in a process of its own -- this very script with --remove-soft-line-breaks 1: six prepared batches of 22 GB, and streams that
+    # do not share hardware queues with the dozen streams this process has created by now (in-process the same pipeline measured 50.4 k
+    # against 54.3 k stand-alone on one box, profiles/r06/r06_zz_*)
     rs = {}
+    torch.cuda.empty_cache()
     for flag in ("1", "0"):
-        cr = pl = d_in = None
         try:
-            torch.cuda.empty_cache()
-            free_before = torch.cuda.mem_get_info(dev)[0]
-            os.environ["ZKWG_RSLB_CONST_CHUNKS"] = flag
-            cr = zkwg.Circuit(zkwg.MAIN_EMAIL_VERIFIER, max_header=args.max_header, max_body=args.max_body, device=local_rank, remove_soft_line_breaks=1)
-            _, d_in, _ = resident_inputs(torch, cr, dev, 0x5A4B + 404, 64, 4096, args.body_len)
-            pl = Pipeline(torch, cr, dev, d_in, 4096, 256, 4096, ring=6, rsa_throttle=args.rsa_throttle)     # (6 x 22 GB of prepared batches)
-            cr.set_timing(True)
-            dt = timed(torch, pl.step, steps=12, warmup=2)      # (12 steps as in the stand-alone measurement: the ring of four batches needs a few to fill)
-            summ, avg, nl, gbs = expand_roofline(cr, 256)
-            cr.set_timing(False)
-            assert int(pl.d_status.abs().sum().item()) == 0
-            rs[flag] = {"value": round(4096 * 12 / dt, 1), "zk_expand_GBps": round(gbs, 1), "witness_len": cr.W,
-                        "kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 3) for k, v in summ.items() if k.startswith("zk_rslb") or k == "zk_expand"}}
+            env = dict(os.environ, ZKWG_RSLB_CONST_CHUNKS=flag)
+            cmd = [sys.executable, os.path.abspath(__file__), "--remove-soft-line-breaks", "1", "--batch", "4096", "--tile", "256", "--prep-batch", "4096",
+                   "--ring", "6", "--steps", "12", "--warmup", "2", "--cpu-sample", "0", "--pmc-traffic", "0", "--other-configs", "0",
+                   "--max-header", str(args.max_header), "--max-body", str(args.max_body), "--body-len", str(args.body_len)]
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+            r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+            rs[flag] = {"value": r["value"], "zk_expand_GBps": r["roofline"]["achieved"], "witness_len": r["config"].get("witness_len"),
+                        "kernel_ms_per_launch": {k: v for k, v in r["kernel_ms_per_launch"].items() if k.startswith("zk_rslb") or k == "zk_expand"}}
         except Exception as e:
-            rs[flag] = {"error": repr(e)[:300], "free_GiB_before": round(locals().get("free_before", 0) / 2**30, 1)}
-        # (a failed run must not keep its 180 GB of prepared batches: the exception's traceback is gone here, the cache is emptied below)
-        pl = d_in = None
-        if cr is not None:
-            cr.close()
-        cr = None
-        torch.cuda.empty_cache()
-    os.environ.pop("ZKWG_RSLB_CONST_CHUNKS", None)
+            rs[flag] = {"error": repr(e)[:300]}
     if "value" in rs.get("1", {}):
         out["removeSoftLineBreaks = 1"] = {
             "value": rs["1"]["value"], "unit": "witnesses/s", "steps": 12, "witness_len": rs["1"]["witness_len"], "zk_expand_GBps": rs["1"]["zk_expand_GBps"],

@@ -276,6 +276,9 @@ typedef void (*zkwg_tile_fn)(void* user, int device, const void* d_tile, uint64_
 int zkwg_calculate_batch_resident(zkwg_circuit_t* c, const uint8_t* packed_inputs, uint64_t n_emails, int32_t* status,
                                   uint8_t* table, uint64_t tile, uint64_t prep, zkwg_tile_fn consumer, void* user);
 int zkwg_resident_placement(const zkwg_circuit_t* c, float* ms, int cap, int kept[2]);
+/* Give the buffers zkwg_calculate_batch_resident keeps in the handle (records, scratch, the two-tile witness ring, statuses) back to the
+ * device; the next call allocates and places them again.  For a service that shares the GPU between circuits. */
+int zkwg_resident_release(zkwg_circuit_t* c);
 
 
 /* Host expansion (the delivered-to-host rate; the consumer is snarkjs on the host,

@@ -245,3 +245,11 @@ def test_resident_pipeline_below_the_boundary_matches_the_host_path():
     # a second call reuses the ring; a larger tile re-places it
     status2, _ = c.calculate_batch_resident(recs, tile=16, prep=16, want_table=False)
     assert status2 == status
+    # zkwg_resident_release: the handle's buffers go back to the device, the next call allocates them again
+    import torch
+    free0 = torch.cuda.mem_get_info(0)[0]
+    c.release_resident()
+    assert torch.cuda.mem_get_info(0)[0] > free0
+    c.release_resident()                                    # (idempotent)
+    status3, table3 = c.calculate_batch_resident(recs, tile=8, prep=16)
+    assert status3 == status and table3 == table

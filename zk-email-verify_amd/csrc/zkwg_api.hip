@@ -1713,6 +1713,21 @@ int zkwg_calculate_batch_resident(zkwg_circuit_t* c, const uint8_t* packed, uint
   hipFree(d_rows);
   return rc;
 }
+// The buffers zkwg_calculate_batch_resident keeps in the handle between calls -- records, two scratch buffers, the two-tile witness ring
+// (2 x 29 GB at the headline circuit's tile of 512), statuses -- go back to the device; the next call allocates and places them again.
+int zkwg_resident_release(zkwg_circuit_t* c) {
+  if (!c) return ZKWG_RC_BAD_ARG;
+  if (c->device < 0) return ZKWG_RC_OK;
+  std::lock_guard<std::mutex> lock(c->hb_mutex);
+  if (hipSetDevice(c->device) != hipSuccess) return ZKWG_RC_HIP_ERROR;
+  if (c->rp_exp) hipStreamSynchronize(c->rp_exp);
+  if (c->own_stream) hipStreamSynchronize(c->own_stream);
+  hipFree(c->rp_in); c->rp_in = nullptr; c->rp_in_cap = 0;
+  hipFree(c->rp_scr[0]); hipFree(c->rp_scr[1]); c->rp_scr[0] = c->rp_scr[1] = nullptr; c->rp_scr_bytes = 0;
+  rp_free_ring(c); c->rp_tile_bytes = 0;
+  hipFree(c->rp_status); c->rp_status = nullptr; c->rp_n_cap = 0;
+  return ZKWG_RC_OK;
+}
 // candidate tiles the ring was chosen from (average milliseconds of one tile's expansion into each; kept[2] = the chosen)
 int zkwg_resident_placement(const zkwg_circuit_t* c, float* ms, int cap, int kept[2]) {
   if (!c) return 0;

@@ -345,6 +345,10 @@ class Circuit:
             return {"mode": "chunked (ZKWG_PLACE_RING=0: plain allocations)", "chunk_bytes": 1 << 30}
         return {"ms_per_tile": [round(ms[i], 3) for i in range(k)], "kept": list(kept)}
 
+    def release_resident(self):
+        """give the buffers calculate_batch_resident keeps in the handle back to the device (include/zkwg.h zkwg_resident_release)"""
+        _check(self.lib.zkwg_resident_release(self.h))
+
     def scratch_bytes(self, n, montgomery=True):
         """device scratch of an n-email batch; montgomery=False: without the Montgomery-copy area at its end (include/zkwg.h
         zkwg_scratch_bytes_standard: every entry point except the Montgomery-form outputs)"""

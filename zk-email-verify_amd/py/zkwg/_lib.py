@@ -169,6 +169,7 @@ def load():
         "zkwg_groth16_assemble": (i32, [vp] * 15),
         "zkwg_calculate_batch_resident": (i32, [vp, vp, u64, vp, vp, u64, u64, vp, vp]),
         "zkwg_resident_placement": (i32, [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]),
+        "zkwg_resident_release": (i32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
@@ -186,7 +187,7 @@ EXPORTS = [
     "zkwg_kernel_name", "zkwg_kernel_slots", "zkwg_wtns_size", "zkwg_write_wtns", "zkwg_write_sym",
     "zkwg_r1cs_load", "zkwg_r1cs_destroy", "zkwg_r1cs_info", "zkwg_check_constraints_device", "zkwg_r1cs_evaluate_device", "zkwg_check_constraints",
     "zkwg_convert_montgomery_device", "zkwg_shard_range", "zkwg_multi_create", "zkwg_multi_destroy", "zkwg_multi_devices",
-    "zkwg_multi_circuit", "zkwg_calculate_batch_multi", "zkwg_calculate_batch_resident", "zkwg_resident_placement",
+    "zkwg_multi_circuit", "zkwg_calculate_batch_multi", "zkwg_calculate_batch_resident", "zkwg_resident_placement", "zkwg_resident_release",
     "zkwg_ntt_create", "zkwg_ntt_destroy", "zkwg_ntt_domain", "zkwg_ntt_work_bytes", "zkwg_ntt_transform_device", "zkwg_h_evaluations_device",
     "zkwg_msm_create", "zkwg_msm_destroy", "zkwg_msm_work_bytes", "zkwg_msm_window_bits", "zkwg_msm_g1_device",
     "zkwg_msm_g2_device", "zkwg_msm_create_g2", "zkwg_msm_create_device", "zkwg_msm_group", "zkwg_fixed_base_device", "zkwg_groth16_assemble", "zkwg_msm_enqueue_device", "zkwg_msm_finish_host", "zkwg_msm_create_ex", "zkwg_msm_work_bytes_batch", "zkwg_msm_lists_bytes", "zkwg_msm_estimate_work_bytes", "zkwg_msm_table_bytes", "zkwg_msm_precomputed", "zkwg_msm_enqueue_batch_device", "zkwg_msm_classify_device", "zkwg_msm_enqueue_lists_device", "zkwg_prover_emails_per_series", "zkwg_prover_contexts", "zkwg_prover_create_zkey", "zkwg_prover_create", "zkwg_prover_destroy", "zkwg_prover_prove_prepared", "zkwg_prover_prove_batch", "zkwg_device_alloc_chunked", "zkwg_device_free_chunked", "zkwg_device_alloc_chunked_ex",
