@@ -8,7 +8,7 @@
 #   bench         the default bench.py line     benchq  the headline only (no PMC / other configs / CPU baseline)
 #   prof          rocprofv3 --kernel-trace --stats of the headline pipeline
 #   rslb          removeSoftLineBreaks = 1 variant (rslb:<label> appends to <tag>_rslb_variants.json)      abc  tools/bench_abc.py      o0  tools/bench_full.py
-#   pmc:<tool.py> per-kernel HBM traffic of a tool (two rocprofv3 --pmc passes)
+#   pmc:<tool.py> per-kernel HBM traffic of a tool (two rocprofv3 --pmc passes)      pmcv:<tool.py>  VALU wavefront-instructions per launch of its kernels
 #   prove[:<args>]  tools/bench_prove.py (appends one JSON line to <tag>_bench_prove.json)      provep[:<args>]  the same under rocprofv3 --kernel-trace --stats
 #   msm:<args>    tools/bench_msm.py (msmp:<args> under rocprofv3)      ntt[:<args>]  tools/bench_ntt.py (nttp[:<args>] under rocprofv3)      run:<command>  anything else (output tail -> <tag>_run.txt)
 #   env:K=V       export K=V for the following steps
@@ -75,7 +75,7 @@ for ctr, scale in (("WRITE_SIZE", 1024.0), ("FETCH_SIZE", 2048.0)):
         print("no counter file for", ctr); continue
     for r in csv.DictReader(open(f[0])):
         if r.get("Counter_Name", ctr) != ctr: continue
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")      # (templated kernels print as "void zk_...<...>(...)")
         a = agg.setdefault(k, {"launches": 0, "WRITE_SIZE": 0.0, "FETCH_SIZE": 0.0, "n": {"WRITE_SIZE": 0, "FETCH_SIZE": 0}})
         a[ctr] += float(r["Counter_Value"]) * scale; a["n"][ctr] += 1
 out = {k: {"launches": v["n"]["WRITE_SIZE"], "write_GB_per_launch": v["WRITE_SIZE"] / max(v["n"]["WRITE_SIZE"], 1) / 1e9,
@@ -85,6 +85,25 @@ for k, v in sorted(out.items(), key=lambda kv: -kv[1]["write_GB_per_launch"] * k
     print("%-28s launches %4d  write %8.3f GB  fetch %8.3f GB per launch" % (k, v["launches"], v["write_GB_per_launch"], v["fetch_GB_per_launch_corrected_x2"]))
 PY
       rm -rf $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_FETCH_SIZE ;;
+    pmcv:*) # VALU wavefront-instructions per launch of every kernel of a tool (one rocprofv3 --pmc pass: SQ_INSTS_VALU SQ_WAVES)
+      TOOL=${step#pmcv:}
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/${TAG}_pmcv -- python $REPO/$TOOL > /dev/null 2> $OUT/${TAG}_pmcv.log )
+      python - <<PY
+import csv, glob, json
+agg = {}
+f = glob.glob("$OUT/${TAG}_pmcv/**/*counter_collection.csv", recursive=True)
+for r in (csv.DictReader(open(f[0])) if f else []):
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    a = agg.setdefault(k, {"SQ_INSTS_VALU": 0.0, "SQ_WAVES": 0.0, "n": 0})
+    if r["Counter_Name"] in a:
+        a[r["Counter_Name"]] += float(r["Counter_Value"])
+        a["n"] += r["Counter_Name"] == "SQ_WAVES"
+out = {k: {"launches": v["n"], "valu_wave_insts_per_launch": v["SQ_INSTS_VALU"] / max(v["n"], 1), "waves_per_launch": v["SQ_WAVES"] / max(v["n"], 1)} for k, v in agg.items() if "zk_" in k}
+json.dump(out, open("$OUT/${TAG}_pmc_valu.json", "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["valu_wave_insts_per_launch"] * kv[1]["launches"])[:14]:
+    print("%-36s launches %4d  VALU wave-insts %14.0f  waves %9.0f per launch" % (k[:36], v["launches"], v["valu_wave_insts_per_launch"], v["waves_per_launch"]))
+PY
+      rm -rf $OUT/${TAG}_pmcv ;;
     prove) timeout 900 python tools/bench_prove.py 2>$OUT/${TAG}_prove.err | tail -1 | tee -a $OUT/${TAG}_bench_prove.json | cut -c1-1500; tail -3 $OUT/${TAG}_prove.err ;;
     prove:*) timeout 900 python tools/bench_prove.py ${step#prove:} 2>$OUT/${TAG}_prove.err | tail -1 | tee -a $OUT/${TAG}_bench_prove.json | cut -c1-1500; tail -3 $OUT/${TAG}_prove.err ;;
     provep|provep:*) A=""; [ "$step" != provep ] && A="${step#provep:}"
