@@ -47,6 +47,9 @@ def test_soft_line_break_chunk_hashes_use_no_scratch_memory(tmp_path):
     v6 = next(v for name, v in info.items() if "zk_rslb_chunks_v6" in name)
     assert v6["VGPRs"] + v6.get("AGPRs", 0) <= 128, v6
     assert next(v for name, v in info.items() if "zk_rslb_scan" in name).get("ScratchSize") == 0
+    # round 6: the merge chain one lane per email through the same evaluator (t = 3), the constant-chunk passes
+    for frag in ("zk_rslb_merge1", "zk_rslb_classify", "zk_rslb_fill_const"):
+        assert next(v for name, v in info.items() if frag in name).get("ScratchSize") == 0, frag
 
 
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
