@@ -98,9 +98,12 @@ static int prover_new(zkwg_circuit_t* c, int device, uint64_t n_rows, const zkwg
   // witness-shaped sums: a few ten thousand full-size scalars per email -> window 13 (4,096 buckets, ~ 170 entries each), slices of 16;
   // the H sum: 2^power full-size scalars -> window 16, slices of 64
   plan(1, key->h, n, 0, hs0, &p->mh);
-  plan(2, key->b2, W, ww, 16, &p->mb2);
-  plan(1, key->a, W, ww, 16, &p->ma); plan(1, key->b1, W, ww, 16, &p->mb1);
-  plan(1, key->c, W - key->n_public - 1, ww, 16, &p->mc);
+  // (tuning knobs, DESIGN.md section 8: ZKWG_PROVER_WITNESS_SLICE = level-0 slice of the witness-shaped sums, ZKWG_PROVER_WITNESS_WINDOW)
+  const int ws0 = getenv("ZKWG_PROVER_WITNESS_SLICE") ? std::max(1, std::min(1024, atoi(getenv("ZKWG_PROVER_WITNESS_SLICE")))) : 16;
+  const int wwin = getenv("ZKWG_PROVER_WITNESS_WINDOW") ? std::max(2, std::min(16, atoi(getenv("ZKWG_PROVER_WITNESS_WINDOW")))) : ww;
+  plan(2, key->b2, W, wwin, ws0, &p->mb2);
+  plan(1, key->a, W, wwin, ws0, &p->ma); plan(1, key->b1, W, wwin, ws0, &p->mb1);
+  plan(1, key->c, W - key->n_public - 1, wwin, ws0, &p->mc);
   if (rc != ZKWG_RC_OK) { prover_free(p); return rc; }
   const uint64_t work_w = std::max(zkwg_msm_work_bytes(p->ma), std::max(zkwg_msm_work_bytes(p->mb1), zkwg_msm_work_bytes(p->mc)));
   p->ctx.resize(n_ctx);
